@@ -1,0 +1,219 @@
+"""ctypes harness for the CPU oracle (librsim_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package `robosuite_amd` never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "librsim_oracle.so")
+    src = os.path.join(_HERE, "rsim_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+        L.rso_model_create.restype = vp
+        L.rso_model_create.argtypes = [C.c_char_p, C.c_size_t]
+        L.rso_model_free.argtypes = [vp]
+        L.rso_model_field.restype = vp
+        L.rso_model_field.argtypes = [vp, C.c_char_p, ip, ip]
+        L.rso_data_create.restype = vp
+        L.rso_data_create.argtypes = [vp]
+        L.rso_data_free.argtypes = [vp]
+        for f in ("rso_reset", "rso_step1", "rso_step2", "rso_forward", "rso_step"):
+            getattr(L, f).argtypes = [vp]
+        for f in ("rso_jac_site", "rso_jac_body", "rso_jac_geom"):
+            getattr(L, f).argtypes = [vp, C.c_int, dp, dp]
+        L.rso_full_M.argtypes = [vp, dp]
+        L.rso_data_field.restype = dp
+        L.rso_data_field.argtypes = [vp, C.c_char_p, ip]
+        for f in ("rso_ncon", "rso_nefc", "rso_solver_iter"):
+            getattr(L, f).restype = C.c_int
+            getattr(L, f).argtypes = [vp]
+        L.rso_contact_get.argtypes = [vp, C.c_int, dp]
+        L.rso_efc_type.restype = C.c_int
+        L.rso_efc_type.argtypes = [vp, C.c_int]
+        L.rso_ctrl_create.restype = vp
+        L.rso_ctrl_free.argtypes = [vp]
+        L.rso_ctrl_config.argtypes = [vp, C.c_int, ip, ip, ip, C.c_int, C.c_int, dp, C.c_double, dp, dp, dp, dp, C.c_int, C.c_int, ip, dp, C.c_double]
+        L.rso_ctrl_reset.argtypes = [vp, vp]
+        L.rso_ctrl_set_goal.argtypes = [vp, vp, dp]
+        L.rso_ctrl_run.argtypes = [vp, vp]
+        L.rso_ctrl_torques.restype = dp
+        L.rso_ctrl_torques.argtypes = [vp]
+        L.rso_ctrl_goal.restype = dp
+        L.rso_ctrl_goal.argtypes = [vp]
+        L.rso_env_step.argtypes = [vp, vp, dp, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class OracleModel:
+    def __init__(self, blob: bytes):
+        self._L = lib()
+        self.ptr = self._L.rso_model_create(blob, len(blob))
+        if not self.ptr:
+            raise ValueError("bad model blob")
+
+    def field(self, name):
+        """numpy view onto a model array (writes go through: used for domain randomisation tests)."""
+        cnt, dt = C.c_int(), C.c_int()
+        p = self._L.rso_model_field(self.ptr, name.encode(), C.byref(cnt), C.byref(dt))
+        if not p:
+            raise KeyError(name)
+        ctype = C.c_int if dt.value == 0 else C.c_double
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(cnt.value,))
+
+    def __del__(self):
+        try:
+            self._L.rso_model_free(self.ptr)
+        except Exception:
+            pass
+
+
+class OracleData:
+    def __init__(self, model: OracleModel):
+        self._L = lib()
+        self.model = model
+        self.ptr = self._L.rso_data_create(model.ptr)
+        self.nv = int(model.field("nv")[0])
+
+    def field(self, name):
+        cnt = C.c_int()
+        p = self._L.rso_data_field(self.ptr, name.encode(), C.byref(cnt))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(cnt.value,))
+
+    def __getattr__(self, name):
+        if name.startswith("_") or name in ("model", "ptr", "nv"):
+            raise AttributeError(name)
+        return self.field(name)
+
+    def reset(self):
+        self._L.rso_reset(self.ptr)
+
+    def step1(self):
+        self._L.rso_step1(self.ptr)
+
+    def step2(self):
+        self._L.rso_step2(self.ptr)
+
+    def forward(self):
+        self._L.rso_forward(self.ptr)
+
+    def step(self):
+        self._L.rso_step(self.ptr)
+
+    def jac(self, kind, idx):
+        jp = np.zeros((3, self.nv))
+        jr = np.zeros((3, self.nv))
+        getattr(self._L, f"rso_jac_{kind}")(self.ptr, int(idx), _dp(jp), _dp(jr))
+        return jp, jr
+
+    def full_M(self):
+        M = np.zeros((self.nv, self.nv))
+        self._L.rso_full_M(self.ptr, _dp(M))
+        return M
+
+    @property
+    def ncon(self):
+        return self._L.rso_ncon(self.ptr)
+
+    @property
+    def nefc(self):
+        return self._L.rso_nefc(self.ptr)
+
+    @property
+    def solver_iter(self):
+        return self._L.rso_solver_iter(self.ptr)
+
+    def contacts(self):
+        out = []
+        buf = np.zeros(23)
+        for i in range(self.ncon):
+            self._L.rso_contact_get(self.ptr, i, _dp(buf))
+            out.append(
+                dict(dist=buf[0], pos=buf[1:4].copy(), frame=buf[4:13].copy().reshape(3, 3), geom1=int(buf[13]), geom2=int(buf[14]),
+                     dim=int(buf[15]), efc_address=int(buf[16]), normal_force=buf[17], friction=buf[18:23].copy())
+            )
+        return out
+
+    def efc_types(self):
+        return [self._L.rso_efc_type(self.ptr, i) for i in range(self.nefc)]
+
+    def __del__(self):
+        try:
+            self._L.rso_data_free(self.ptr)
+        except Exception:
+            pass
+
+
+class OracleController:
+    """OSC_POSE arm + GRIP gripper; see rsim_oracle.c `rso_ctrl_*`."""
+
+    def __init__(self, cfg: dict):
+        self._L = lib()
+        self.ptr = self._L.rso_ctrl_create()
+        n = len(cfg["qpos_idx"])
+        i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+        f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64)
+        self._keep = [i32(cfg["qpos_idx"]), i32(cfg["dof_idx"]), i32(cfg["act_idx"]), f64(cfg["kp"]), f64(cfg["input_min"]), f64(cfg["input_max"]),
+                      f64(cfg["output_min"]), f64(cfg["output_max"]), i32(cfg["grip_act"]), f64(cfg["grip_sign"])]
+        k = self._keep
+        self._L.rso_ctrl_config(self.ptr, n, _ip(k[0]), _ip(k[1]), _ip(k[2]), int(cfg["eef_site"]), int(cfg["base_site"]), _dp(k[3]), float(cfg["damping_ratio"]),
+                                _dp(k[4]), _dp(k[5]), _dp(k[6]), _dp(k[7]), int(cfg["uncouple"]), len(cfg["grip_act"]), _ip(k[8]), _dp(k[9]), float(cfg["grip_speed"]))
+        self.n = n
+
+    def reset(self, data: OracleData):
+        self._L.rso_ctrl_reset(self.ptr, data.ptr)
+
+    def set_goal(self, data: OracleData, action):
+        a = np.ascontiguousarray(action, dtype=np.float64)
+        self._L.rso_ctrl_set_goal(self.ptr, data.ptr, _dp(a))
+
+    def run(self, data: OracleData):
+        self._L.rso_ctrl_run(self.ptr, data.ptr)
+
+    @property
+    def torques(self):
+        return np.ctypeslib.as_array(self._L.rso_ctrl_torques(self.ptr), shape=(self.n,))
+
+    @property
+    def goal(self):
+        g = np.ctypeslib.as_array(self._L.rso_ctrl_goal(self.ptr), shape=(12,))
+        return g[:3], g[3:].reshape(3, 3)
+
+    def env_step(self, data: OracleData, action, n_sub=25):
+        a = np.ascontiguousarray(action, dtype=np.float64)
+        self._L.rso_env_step(self.ptr, data.ptr, _dp(a), int(n_sub))
+
+    def __del__(self):
+        try:
+            self._L.rso_ctrl_free(self.ptr)
+        except Exception:
+            pass
