@@ -1,0 +1,129 @@
+/*
+ * rsim.h -- C-ABI of librsim_hip.so, the MI355X backend that replaces robosuite's MjSim hot path.
+ *
+ * Every entry point names the reference interface it stands in for (paths relative to the robosuite
+ * checkout).  All functions return 0 on success, non-zero on error (message via rsim_last_error()).
+ * Handles are opaque; the library owns all device memory; host buffers are owned by the caller.
+ * No callbacks into the host language.  Thread-compatible per batch handle (one HIP stream per batch).
+ */
+#ifndef RSIM_H
+#define RSIM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rsim_model rsim_model;
+typedef struct rsim_batch rsim_batch;
+
+/* Built-in controller description: OSC_POSE arm + GRIP gripper.
+ * Replaces controllers/parts/arm/osc.py:120-224 (constructor arguments) and
+ * controllers/parts/gripper/simple_grip.py:62-107; index tables are what
+ * robots/robot.py:300-333 (`setup_references`) resolves by name. */
+typedef struct rsim_ctrl_desc {
+  int32_t ndof;            /* arm joints (<= 8) */
+  int32_t qpos_idx[8];     /* Controller.qpos_index */
+  int32_t dof_idx[8];      /* Controller.qvel_index */
+  int32_t act_idx[8];      /* robot._ref_actuators_indexes_dict[arm] */
+  int32_t eef_site;        /* site id of Controller.ref_name */
+  int32_t base_site;       /* site id of f"{naming_prefix}{part_name}_center" (osc.py:453) */
+  float kp[6];             /* osc.py:176 */
+  float damping_ratio;     /* kd = 2 sqrt(kp) damping_ratio, osc.py:177 */
+  float input_min[6], input_max[6], output_min[6], output_max[6]; /* controller.py:149-168 */
+  int32_t uncouple_pos_ori; /* osc.py:476-482 */
+  float nullspace_kp;       /* control_utils.py:7 (default 10) */
+  int32_t ngrip;            /* gripper actuators (<= 4), 0 = no gripper */
+  int32_t grip_act[4];
+  float grip_sign[4];       /* PandaGripper.format_action direction, models/grippers/panda_gripper.py:55-57 */
+  float grip_speed;         /* panda_gripper.py:61 */
+} rsim_ctrl_desc;
+
+/* state / derived arrays addressable through rsim_get_array / rsim_set_array / rsim_device_ptr */
+enum rsim_field {
+  RSIM_QPOS = 0,       /* [B,nq]  sim.data.qpos   (binding_utils.py MjData.qpos)            */
+  RSIM_QVEL,           /* [B,nv]  sim.data.qvel                                              */
+  RSIM_QACC_WARMSTART, /* [B,nv]                                                            */
+  RSIM_CTRL,           /* [B,nu]  sim.data.ctrl   (fixed_base_robot.py:153)                 */
+  RSIM_TIME,           /* [B]     sim.data.time                                              */
+  RSIM_CSTATE,         /* [B,32]  controller state: goal_pos3 goal_ori9 q0[8] grip[4] tau[8] */
+  RSIM_XPOS,           /* [B,nbody,3]  sim.data.xpos      (derived, valid after forward/step1) */
+  RSIM_XQUAT,          /* [B,nbody,4]  sim.data.xquat                                        */
+  RSIM_QM,             /* [B,nv,nv]    dense mass matrix (mj_fullM, controller.py:226-227)  */
+  RSIM_QFRC_BIAS,      /* [B,nv]       sim.data.qfrc_bias (controller.py:303-311)           */
+  RSIM_QFRC_PASSIVE,   /* [B,nv] */
+  RSIM_QFRC_ACTUATOR,  /* [B,nv] */
+  RSIM_QFRC_CONSTRAINT,/* [B,nv] */
+  RSIM_QACC,           /* [B,nv]       sim.data.qacc                                         */
+  RSIM_CDOF,           /* [B,nv,6]     motion axes about the tree COM (for Jacobians)       */
+  RSIM_ROOTCOM,        /* [B,nbody,3]  subtree COM per tree root                            */
+  RSIM_CONTACT,        /* [B,maxcon,24] dist pos3 frame9 geom1 geom2 dim efc_adr fn friction5 */
+  RSIM_EFC_FORCE,      /* [B,maxefc] */
+  RSIM_NCON,           /* [B] int32    sim.data.ncon                                         */
+  RSIM_NEFC,           /* [B] int32 */
+  RSIM_NITER,          /* [B] int32    solver iterations of the last substep                 */
+  RSIM_FIELD_COUNT
+};
+
+const char* rsim_last_error(void);
+
+/* mujoco.MjModel.from_xml_string (binding_utils.py:1079): the MJCF->flat-model compile happens in the host language
+ * (robosuite_amd/mjcf.py); this call ingests the resulting blob ("RSIMMDL1", see mjcf.to_blob). Host only, no GPU. */
+int rsim_model_create(const void* blob, size_t len, rsim_model** out);
+void rsim_model_free(rsim_model* m);
+/* scalar / size query by blob field name ("nq", "nv", ...); returns -1 if unknown */
+int rsim_model_int(const rsim_model* m, const char* name);
+/* controller_factory (controllers/parts/controller_factory.py:73-159) for the built-in OSC_POSE + GRIP pair */
+int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* desc);
+
+/* mujoco.MjData(model) x B (binding_utils.py:586-590): allocates B environments on `device`.
+ * per_env_params != 0 gives every env its own copy of the float model constants (domain randomisation,
+ * per-episode object sizes); 0 shares one copy. */
+int rsim_batch_create(rsim_model* m, int B, int device, int per_env_params, rsim_batch** out);
+void rsim_batch_free(rsim_batch* b);
+int rsim_batch_size(const rsim_batch* b);
+int rsim_batch_limits(const rsim_batch* b, int* maxcon, int* maxefc);
+
+/* mj_resetData (binding_utils.py:1091): qpos = qpos0, qvel = 0, ctrl = 0, time = 0 for envs with mask[i] != 0 (NULL = all) */
+int rsim_reset(rsim_batch* b, const uint8_t* host_mask);
+/* mj_forward / mj_step1 / mj_step2 / mj_step (binding_utils.py:1095-1107) on every env */
+int rsim_forward(rsim_batch* b);
+int rsim_step1(rsim_batch* b);
+int rsim_step2(rsim_batch* b);
+int rsim_step(rsim_batch* b);
+/* Fused fast path = MujocoEnv.step's substep loop (environments/base.py:494-504) with the built-in controllers:
+ * n_sub x { step1; control(action, policy_step = first); step2 } in ONE launch.  `actions_dev` is a DEVICE pointer
+ * to [B, action_dim] float32 (action_dim = 6 + (ngrip>0)). */
+int rsim_control_step(rsim_batch* b, const float* actions_dev, int n_sub);
+/* Robot.reset's controller re-creation (robots/robot.py:271 -> controller.py:125-131, osc.py:520-532):
+ * forward kinematics, initial_joint := q, goal := current eef pose, gripper action := 0 */
+int rsim_ctrl_reset(rsim_batch* b, const uint8_t* host_mask);
+int rsim_sync(rsim_batch* b);
+
+/* zero-copy numpy-view replacement: copy a field to / from HOST float32 (int32 for RSIM_NCON..) buffers of `count` elements */
+int rsim_get_array(rsim_batch* b, int field, void* host_dst, size_t count);
+int rsim_set_array(rsim_batch* b, int field, const void* host_src, size_t count);
+/* device pointer + element count of a field (for DLPack / __cuda_array_interface__ aliasing by the host language) */
+void* rsim_device_ptr(rsim_batch* b, int field, size_t* count);
+void* rsim_stream(rsim_batch* b);
+
+/* mj_jacSite / mj_jacBody (binding_utils.py:681-695, 826-851) for one env: jacp, jacr are HOST float64 [3,nv], may be NULL.
+ * Valid after forward/step1. */
+int rsim_jac_site(rsim_batch* b, int env, int site, double* jacp, double* jacr);
+int rsim_jac_body(rsim_batch* b, int env, int body, double* jacp, double* jacr);
+
+/* DynamicsModder / per-episode model edits (utils/mjmod.py:1705-1964, lift.py:311-318): overwrite a float model array
+ * (blob field name, e.g. "geom_size", "body_mass", "dof_damping") for envs [env0, env0+nenv). `values` is HOST float64
+ * [nenv, count_per_env] in the blob's layout.  Requires per_env_params unless nenv == B with identical rows. */
+int rsim_model_param_set(rsim_batch* b, const char* field, int env0, int nenv, const double* values, size_t count_per_env);
+
+/* Standalone OSC torque law on explicit inputs (unit-test entry for OperationalSpaceController.run_controller,
+ * osc.py:403-495).  in: HOST float32 [B,192] packed as ep3 eR9 ev6 op3 oR9 bv6 goal_pos3 goal_ori9 J[6x8] M[8x8] bias8 q8 qd8 q0_8;
+ * out: HOST float32 [B,8] pre-clip torques. */
+int rsim_osc_eval(const rsim_ctrl_desc* desc, const float* in, float* out, int B, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -60,6 +60,8 @@ def lib():
         L.rso_ctrl_goal.restype = dp
         L.rso_ctrl_goal.argtypes = [vp]
         L.rso_env_step.argtypes = [vp, vp, dp, C.c_int]
+        L.rso_osc_torques.argtypes = [dp] * 16 + [C.c_double, C.c_int, C.c_int, dp]
+        L.rso_osc_goal.argtypes = [dp] * 7
         _LIB = L
     return _LIB
 
@@ -217,3 +219,21 @@ class OracleController:
             self._L.rso_ctrl_free(self.ptr)
         except Exception:
             pass
+
+
+def osc_torques(kp, kd, ep, eR, ev, op, oR, bv, goal_pos, goal_ori, J, M, bias, q, qd, q0, nullspace_kp=10.0, uncouple=True):
+    """Explicit-input OSC torque law (restates osc.py:403-495); returns pre-clip torques."""
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    args = [f(x) for x in (kp, kd, ep, eR, ev, op, oR, bv, goal_pos, goal_ori, J, M, bias, q, qd, q0)]
+    n = len(args[13])
+    out = np.zeros(n)
+    lib().rso_osc_torques(*[_dp(a) for a in args], float(nullspace_kp), int(uncouple), n, _dp(out))
+    return out
+
+
+def osc_goal(scaled, ep, eR, op, oR):
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    args = [f(x) for x in (scaled, ep, eR, op, oR)]
+    gp, go = np.zeros(3), np.zeros(9)
+    lib().rso_osc_goal(*[_dp(a) for a in args], _dp(gp), _dp(go))
+    return gp, go.reshape(3, 3)

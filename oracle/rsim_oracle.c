@@ -1709,6 +1709,8 @@ void rso_ctrl_config(rso_ctrl *c, int ndof, const int *qpos_idx, const int *dof_
   c->grip_speed = grip_speed;
 }
 
+void rso_osc_goal(const double *scaled, const double *ep, const double *eR, const double *op, const double *oR, double *goal_pos, double *goal_ori);
+
 /* Controller.reset at env reset: initial_joint (controller.py:128-130), goals = current world pose (osc.py:520-532),
  * gripper current_action = 0 (robots/robot.py:289) */
 void rso_ctrl_reset(rso_ctrl *c, rso_data *d) {
@@ -1754,21 +1756,8 @@ void rso_ctrl_set_goal(rso_ctrl *c, rso_data *d, const double *action) {
     double a = fmax(c->in_min[i], fmin(c->in_max[i], action[i]));
     scaled[i] = (a - 0.5 * (c->in_max[i] + c->in_min[i])) * scale + 0.5 * (c->out_max[i] + c->out_min[i]);
   }
-  const double *op = d->site_xpos + 3 * c->base_site, *oR = d->site_xmat + 9 * c->base_site;
-  const double *ep = d->site_xpos + 3 * c->eef_site, *eR = d->site_xmat + 9 * c->eef_site;
-  double rel[3], loc[3];
-  for (int k = 0; k < 3; k++) rel[k] = ep[k] - op[k];
-  matT_vec3(loc, oR, rel); /* world_to_origin_frame */
-  for (int k = 0; k < 3; k++) c->goal_pos[k] = loc[k] + scaled[k];
-  /* orientation: R(axis-angle delta) * (origin^T * eef) */
-  double ang = norm3(scaled + 3), qe[4] = {0, 0, 0, 1}, Rerr[9], cur[9];
-  if (!(fabs(ang) <= 1e-9 * fmax(fabs(ang), 0.0))) { /* math.isclose(angle, 0.0): rel_tol 1e-9, abs_tol 0 -> only exact zero */
-    double s = sin(0.5 * ang);
-    qe[0] = scaled[3] / ang * s; qe[1] = scaled[4] / ang * s; qe[2] = scaled[5] / ang * s; qe[3] = cos(0.5 * ang);
-  }
-  quat2mat_f32(qe, Rerr);
-  mat3T_mul(cur, oR, eR);
-  mat3_mul(c->goal_ori, Rerr, cur);
+  rso_osc_goal(scaled, d->site_xpos + 3 * c->eef_site, d->site_xmat + 9 * c->eef_site, d->site_xpos + 3 * c->base_site, d->site_xmat + 9 * c->base_site,
+               c->goal_pos, c->goal_ori);
   /* gripper */
   if (c->ngrip > 0) {
     double a = action[6], sg = a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0);
@@ -1808,28 +1797,18 @@ static void sym_pinv(const double *A, double *P, int n) {
     }
 }
 
-/* run_controller for one substep: returns nothing, writes clipped ctrl (osc.py:403-495, fixed_base_robot.py:143-153) */
-void rso_ctrl_run(rso_ctrl *c, rso_data *d) {
-  rso_model *m = d->m;
-  int nv = m->nv, n = c->ndof;
-  double *jp = dalloc(3 * nv), *jr = dalloc(3 * nv), *bjp = dalloc(3 * nv), *bjr = dalloc(3 * nv);
-  rso_jac_site(d, c->eef_site, jp, jr);
-  rso_jac_site(d, c->base_site, bjp, bjr);
-  double J[6 * ARM_MAX], M[ARM_MAX * ARM_MAX], Minv[ARM_MAX * ARM_MAX], q[ARM_MAX], qd[ARM_MAX];
-  double ev[6] = {0}, bv[6] = {0};
-  for (int r = 0; r < 3; r++)
-    for (int k = 0; k < nv; k++) { ev[r] += jp[r * nv + k] * d->qvel[k]; ev[3 + r] += jr[r * nv + k] * d->qvel[k]; bv[r] += bjp[r * nv + k] * d->qvel[k]; bv[3 + r] += bjr[r * nv + k] * d->qvel[k]; }
-  for (int i = 0; i < n; i++) {
-    q[i] = d->qpos[c->qpos_idx[i]]; qd[i] = d->qvel[c->dof_idx[i]];
-    for (int r = 0; r < 3; r++) { J[r * n + i] = jp[r * nv + c->dof_idx[i]]; J[(3 + r) * n + i] = jr[r * nv + c->dof_idx[i]]; }
-    for (int j = 0; j < n; j++) M[i * n + j] = d->qM[c->dof_idx[i] * nv + c->dof_idx[j]];
-  }
-  const double *op = d->site_xpos + 3 * c->base_site, *oR = d->site_xmat + 9 * c->base_site;
-  const double *ep = d->site_xpos + 3 * c->eef_site, *eR = d->site_xmat + 9 * c->eef_site;
+/* OSC torque law on explicit inputs (osc.py:403-495 + control_utils.py:7-111); pre-clip torques out[n].
+ *   ep/eR eef site pose, ev[6] eef lin+ang velocity, op/oR base (origin) site pose, bv[6] base site velocity,
+ *   goal_pos/goal_ori in the origin frame, J 6 x n (rows: jacp then jacr, arm columns), M n x n arm sub-block of the
+ *   full mass matrix, bias = qfrc_bias[arm], q/qd arm joint pos/vel, q0 nullspace reference (initial_joint). */
+void rso_osc_torques(const double *kp, const double *kd, const double *ep, const double *eR, const double *ev, const double *op, const double *oR,
+                     const double *bv, const double *goal_pos, const double *goal_ori, const double *J, const double *M, const double *bias,
+                     const double *q, const double *qd, const double *q0, double nullspace_kp, int uncouple, int n, double *out) {
+  double Minv[ARM_MAX * ARM_MAX];
   double dpos[3], dori[9], perr[3], oerr[3] = {0, 0, 0};
-  mat_vec3(dpos, oR, c->goal_pos);
+  mat_vec3(dpos, oR, goal_pos);
   for (int k = 0; k < 3; k++) { dpos[k] += op[k]; perr[k] = dpos[k] - ep[k]; }
-  mat3_mul(dori, oR, c->goal_ori);
+  mat3_mul(dori, oR, goal_ori);
   for (int col = 0; col < 3; col++) { /* control_utils.py:85-111 */
     double rc[3] = {eR[col], eR[3 + col], eR[6 + col]}, rd[3] = {dori[col], dori[3 + col], dori[6 + col]}, t[3];
     cross3(t, rc, rd);
@@ -1837,13 +1816,13 @@ void rso_ctrl_run(rso_ctrl *c, rso_data *d) {
   }
   double F[3], T[3];
   for (int k = 0; k < 3; k++) {
-    F[k] = perr[k] * c->kp[k] + (-(ev[k] - bv[k])) * c->kd[k];
-    T[k] = oerr[k] * c->kp[3 + k] + (-(ev[3 + k] - bv[3 + k])) * c->kd[3 + k];
+    F[k] = perr[k] * kp[k] + (-(ev[k] - bv[k])) * kd[k];
+    T[k] = oerr[k] * kp[3 + k] + (-(ev[3 + k] - bv[3 + k])) * kd[3 + k];
   }
   /* opspace_matrices (control_utils.py:43-82) */
   {
     double A[ARM_MAX * ARM_MAX], b[ARM_MAX];
-    for (int col = 0; col < n; col++) { /* inverse by solving for unit vectors (np.linalg.inv = LU) */
+    for (int col = 0; col < n; col++) { /* np.linalg.inv: solve for unit vectors */
       memcpy(A, M, sizeof(double) * n * n);
       for (int k = 0; k < n; k++) b[k] = k == col;
       solve_small(A, b, n);
@@ -1856,22 +1835,61 @@ void rso_ctrl_run(rso_ctrl *c, rso_data *d) {
   for (int r = 0; r < 3; r++) for (int s2 = 0; s2 < 3; s2++) { lpi[r * 3 + s2] = lfi[r * 6 + s2]; loi[r * 3 + s2] = lfi[(3 + r) * 6 + 3 + s2]; }
   sym_pinv(lfi, lf, 6); sym_pinv(lpi, lp, 3); sym_pinv(loi, lo, 3);
   double wrench[6];
-  if (c->uncouple) { mat_vec3(wrench, lp, F); mat_vec3(wrench + 3, lo, T); }
+  if (uncouple) { mat_vec3(wrench, lp, F); mat_vec3(wrench + 3, lo, T); }
   else { double w[6] = {F[0], F[1], F[2], T[0], T[1], T[2]}; for (int r = 0; r < 6; r++) { double s = 0; for (int k = 0; k < 6; k++) s += lf[r * 6 + k] * w[k]; wrench[r] = s; } }
   /* nullspace: N = I - Jbar J, Jbar = Minv J^T lambda_full; torques += N^T M (kp (q0-q) - kv qd) */
   double Jbar[ARM_MAX * 6], N[ARM_MAX * ARM_MAX], pt[ARM_MAX], tmp[ARM_MAX];
   for (int i = 0; i < n; i++) for (int r = 0; r < 6; r++) { double s = 0; for (int k = 0; k < 6; k++) s += MiJT[i * 6 + k] * lf[k * 6 + r]; Jbar[i * 6 + r] = s; }
   for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { double s = 0; for (int r = 0; r < 6; r++) s += Jbar[i * 6 + r] * J[r * n + j]; N[i * n + j] = (i == j) - s; }
-  double kv = sqrt(c->nullspace_kp) * 2;
-  for (int i = 0; i < n; i++) tmp[i] = c->nullspace_kp * (c->initial_joint[i] - q[i]) - kv * qd[i];
+  double kv = sqrt(nullspace_kp) * 2;
+  for (int i = 0; i < n; i++) tmp[i] = nullspace_kp * (q0[i] - q[i]) - kv * qd[i];
   for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < n; k++) s += M[i * n + k] * tmp[k]; pt[i] = s; }
   for (int i = 0; i < n; i++) {
-    double tq = d->qfrc_bias[c->dof_idx[i]];
+    double tq = bias[i];
     for (int r = 0; r < 6; r++) tq += J[r * n + i] * wrench[r];
     for (int k = 0; k < n; k++) tq += N[k * n + i] * pt[k];
-    c->torques[i] = tq;
+    out[i] = tq;
+  }
+}
+
+/* OSC goal update on explicit inputs (osc.py:306-401; "achieved" mode, "base" frame): scaled[6] = scale_action(action) */
+void rso_osc_goal(const double *scaled, const double *ep, const double *eR, const double *op, const double *oR, double *goal_pos, double *goal_ori) {
+  double rel[3], loc[3];
+  for (int k = 0; k < 3; k++) rel[k] = ep[k] - op[k];
+  matT_vec3(loc, oR, rel); /* world_to_origin_frame */
+  for (int k = 0; k < 3; k++) goal_pos[k] = loc[k] + scaled[k];
+  double ang = norm3(scaled + 3), qe[4] = {0, 0, 0, 1}, Rerr[9], cur[9];
+  if (!(fabs(ang) <= 1e-9 * fmax(fabs(ang), 0.0))) { /* math.isclose(angle, 0.0): only exact zero */
+    double s = sin(0.5 * ang);
+    qe[0] = scaled[3] / ang * s; qe[1] = scaled[4] / ang * s; qe[2] = scaled[5] / ang * s; qe[3] = cos(0.5 * ang);
+  }
+  quat2mat_f32(qe, Rerr);
+  mat3T_mul(cur, oR, eR);
+  mat3_mul(goal_ori, Rerr, cur);
+}
+
+/* run_controller for one substep: gathers from sim data, writes clipped ctrl (controller.py:170-232, fixed_base_robot.py:143-153) */
+void rso_ctrl_run(rso_ctrl *c, rso_data *d) {
+  rso_model *m = d->m;
+  int nv = m->nv, n = c->ndof;
+  double *jp = dalloc(3 * nv), *jr = dalloc(3 * nv), *bjp = dalloc(3 * nv), *bjr = dalloc(3 * nv);
+  rso_jac_site(d, c->eef_site, jp, jr);
+  rso_jac_site(d, c->base_site, bjp, bjr);
+  double J[6 * ARM_MAX], M[ARM_MAX * ARM_MAX], q[ARM_MAX], qd[ARM_MAX], bias[ARM_MAX];
+  double ev[6] = {0}, bv[6] = {0};
+  for (int r = 0; r < 3; r++)
+    for (int k = 0; k < nv; k++) { ev[r] += jp[r * nv + k] * d->qvel[k]; ev[3 + r] += jr[r * nv + k] * d->qvel[k]; bv[r] += bjp[r * nv + k] * d->qvel[k]; bv[3 + r] += bjr[r * nv + k] * d->qvel[k]; }
+  for (int i = 0; i < n; i++) {
+    q[i] = d->qpos[c->qpos_idx[i]]; qd[i] = d->qvel[c->dof_idx[i]]; bias[i] = d->qfrc_bias[c->dof_idx[i]];
+    for (int r = 0; r < 3; r++) { J[r * n + i] = jp[r * nv + c->dof_idx[i]]; J[(3 + r) * n + i] = jr[r * nv + c->dof_idx[i]]; }
+    for (int j = 0; j < n; j++) M[i * n + j] = d->qM[c->dof_idx[i] * nv + c->dof_idx[j]];
+  }
+  rso_osc_torques(c->kp, c->kd, d->site_xpos + 3 * c->eef_site, d->site_xmat + 9 * c->eef_site, ev, d->site_xpos + 3 * c->base_site,
+                  d->site_xmat + 9 * c->base_site, bv, c->goal_pos, c->goal_ori, J, M, bias, q, qd, c->initial_joint, c->nullspace_kp, c->uncouple, n,
+                  c->torques);
+  for (int i = 0; i < n; i++) {
     int a = c->act_idx[i];
-    d->ctrl[a] = fmax(m->actuator_ctrlrange[2 * a], fmin(m->actuator_ctrlrange[2 * a + 1], tq));
+    d->ctrl[a] = fmax(m->actuator_ctrlrange[2 * a], fmin(m->actuator_ctrlrange[2 * a + 1], c->torques[i]));
   }
   /* gripper: ctrl = bias + weight * goal, clipped (simple_grip.py:150-186) */
   for (int i = 0; i < c->ngrip; i++) {

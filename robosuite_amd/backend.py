@@ -1,0 +1,269 @@
+"""ctypes binding of the C-ABI HIP backend (include/rsim.h -> librsim_hip.so).
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is visible when a batch is
+created, this module raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import mjcf
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsim_hip.so")
+_LIB = None
+
+# enum rsim_field (include/rsim.h)
+FIELDS = ["qpos", "qvel", "qacc_warmstart", "ctrl", "time", "cstate", "xpos", "xquat", "qM", "qfrc_bias", "qfrc_passive", "qfrc_actuator",
+          "qfrc_constraint", "qacc", "cdof", "rootcom", "contact", "efc_force", "ncon", "nefc", "niter"]
+FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
+INT_FIELDS = {"ncon", "nefc", "niter"}
+CON_REC = 24
+CSTATE = 32
+
+
+class RsimError(RuntimeError):
+    pass
+
+
+class CtrlDesc(C.Structure):
+    _fields_ = [("ndof", C.c_int32), ("qpos_idx", C.c_int32 * 8), ("dof_idx", C.c_int32 * 8), ("act_idx", C.c_int32 * 8), ("eef_site", C.c_int32),
+                ("base_site", C.c_int32), ("kp", C.c_float * 6), ("damping_ratio", C.c_float), ("input_min", C.c_float * 6), ("input_max", C.c_float * 6),
+                ("output_min", C.c_float * 6), ("output_max", C.c_float * 6), ("uncouple_pos_ori", C.c_int32), ("nullspace_kp", C.c_float),
+                ("ngrip", C.c_int32), ("grip_act", C.c_int32 * 4), ("grip_sign", C.c_float * 4), ("grip_speed", C.c_float)]
+
+
+def ctrl_desc(cfg: dict) -> CtrlDesc:
+    """Build the C struct from the dict form used by tests/golden/*.cfg.json and robosuite_amd.env."""
+    d = CtrlDesc()
+    n = len(cfg["qpos_idx"])
+    d.ndof = n
+    for i in range(n):
+        d.qpos_idx[i], d.dof_idx[i], d.act_idx[i] = cfg["qpos_idx"][i], cfg["dof_idx"][i], cfg["act_idx"][i]
+    d.eef_site, d.base_site = cfg["eef_site"], cfg["base_site"]
+    for i in range(6):
+        d.kp[i] = cfg["kp"][i]
+        d.input_min[i], d.input_max[i] = cfg["input_min"][i], cfg["input_max"][i]
+        d.output_min[i], d.output_max[i] = cfg["output_min"][i], cfg["output_max"][i]
+    d.damping_ratio = cfg.get("damping_ratio", 1.0)
+    d.uncouple_pos_ori = int(cfg.get("uncouple", 1))
+    d.nullspace_kp = cfg.get("nullspace_kp", 10.0)
+    g = cfg.get("grip_act", [])
+    d.ngrip = len(g)
+    for i in range(len(g)):
+        d.grip_act[i] = g[i]
+        d.grip_sign[i] = cfg["grip_sign"][i]
+    d.grip_speed = cfg.get("grip_speed", 0.0)
+    return d
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RsimError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(make -C robosuite_amd/csrc). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.rsim_last_error.restype = C.c_char_p
+        L.rsim_model_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
+        L.rsim_model_free.argtypes = [vp]
+        L.rsim_model_int.argtypes = [vp, C.c_char_p]
+        L.rsim_model_set_controller.argtypes = [vp, C.POINTER(CtrlDesc)]
+        L.rsim_batch_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.rsim_batch_free.argtypes = [vp]
+        L.rsim_batch_size.argtypes = [vp]
+        L.rsim_batch_limits.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.rsim_reset.argtypes = [vp, C.c_char_p]
+        for f in ("rsim_forward", "rsim_step1", "rsim_step2", "rsim_step", "rsim_sync"):
+            getattr(L, f).argtypes = [vp]
+        L.rsim_control_step.argtypes = [vp, vp, C.c_int]
+        L.rsim_ctrl_reset.argtypes = [vp, C.c_char_p]
+        L.rsim_get_array.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        L.rsim_set_array.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        L.rsim_device_ptr.restype = vp
+        L.rsim_device_ptr.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
+        L.rsim_stream.restype = vp
+        L.rsim_stream.argtypes = [vp]
+        L.rsim_jac_site.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+        L.rsim_jac_body.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+        L.rsim_model_param_set.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_size_t]
+        L.rsim_osc_eval.argtypes = [C.POINTER(CtrlDesc), vp, vp, C.c_int, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RsimError(lib().rsim_last_error().decode())
+
+
+class HipModel:
+    """rsim_model handle (host side only; no GPU needed)."""
+
+    def __init__(self, flat_or_blob):
+        self.flat = flat_or_blob if isinstance(flat_or_blob, mjcf.FlatModel) else mjcf.from_blob(flat_or_blob)
+        blob = mjcf.to_blob(self.flat) if isinstance(flat_or_blob, mjcf.FlatModel) else bytes(flat_or_blob)
+        self._L = lib()
+        self.ptr = C.c_void_p()
+        _chk(self._L.rsim_model_create(blob, len(blob), C.byref(self.ptr)))
+        self.ctrl_cfg = None
+
+    def int(self, name):
+        return self._L.rsim_model_int(self.ptr, name.encode())
+
+    def set_controller(self, cfg: dict):
+        d = ctrl_desc(cfg)
+        _chk(self._L.rsim_model_set_controller(self.ptr, C.byref(d)))
+        self.ctrl_cfg = cfg
+        self.action_dim = 6 + (1 if cfg.get("grip_act") else 0)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._L.rsim_model_free(self.ptr)
+        except Exception:
+            pass
+
+
+class _DevArray:
+    """Exposes a library-owned device buffer through __cuda_array_interface__ (torch.as_tensor aliases it, zero-copy)."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
+        self._owner = owner
+
+
+class HipBatch:
+    """B environments resident on one MI355X."""
+
+    def __init__(self, model: HipModel, B: int, device: int = 0, per_env_params: bool = False):
+        self._L = lib()
+        self.model = model
+        self.B = B
+        self.device = device
+        self.ptr = C.c_void_p()
+        _chk(self._L.rsim_batch_create(model.ptr, B, device, int(per_env_params), C.byref(self.ptr)))
+        mc, me = C.c_int(), C.c_int()
+        self._L.rsim_batch_limits(self.ptr, C.byref(mc), C.byref(me))
+        self.maxcon, self.maxefc = mc.value, me.value
+        m = model.flat
+        nq, nv, nu, nb = m.nq, m.nv, m.nu, m.nbody
+        self.shapes = {"qpos": (B, nq), "qvel": (B, nv), "qacc_warmstart": (B, nv), "ctrl": (B, nu), "time": (B,), "cstate": (B, CSTATE),
+                       "xpos": (B, nb, 3), "xquat": (B, nb, 4), "qM": (B, nv, nv), "qfrc_bias": (B, nv), "qfrc_passive": (B, nv),
+                       "qfrc_actuator": (B, nv), "qfrc_constraint": (B, nv), "qacc": (B, nv), "cdof": (B, nv, 6), "rootcom": (B, nb, 3),
+                       "contact": (B, self.maxcon, CON_REC), "efc_force": (B, self.maxefc), "ncon": (B,), "nefc": (B,), "niter": (B,)}
+
+    # ---- state access (host copies) --------------------------------------------------------
+    def get(self, name):
+        dt = np.int32 if name in INT_FIELDS else np.float32
+        out = np.empty(self.shapes[name], dtype=dt)
+        _chk(self._L.rsim_get_array(self.ptr, FIELD_ID[name], out.ctypes.data, out.size))
+        return out
+
+    def set(self, name, value):
+        dt = np.int32 if name in INT_FIELDS else np.float32
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=dt), self.shapes[name]))
+        _chk(self._L.rsim_set_array(self.ptr, FIELD_ID[name], a.ctypes.data, a.size))
+
+    def tensor(self, name):
+        """torch tensor aliasing the device buffer (no copy)."""
+        import torch
+
+        cnt = C.c_size_t()
+        p = self._L.rsim_device_ptr(self.ptr, FIELD_ID[name], C.byref(cnt))
+        typestr = "<i4" if name in INT_FIELDS else "<f4"
+        return torch.as_tensor(_DevArray(p, self.shapes[name], typestr, self), device=f"cuda:{self.device}")
+
+    # ---- simulation ------------------------------------------------------------------------
+    def reset(self, mask=None):
+        _chk(self._L.rsim_reset(self.ptr, None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).tobytes()))
+
+    def forward(self):
+        _chk(self._L.rsim_forward(self.ptr))
+
+    def step1(self):
+        _chk(self._L.rsim_step1(self.ptr))
+
+    def step2(self):
+        _chk(self._L.rsim_step2(self.ptr))
+
+    def step(self):
+        _chk(self._L.rsim_step(self.ptr))
+
+    def sync(self):
+        _chk(self._L.rsim_sync(self.ptr))
+
+    def ctrl_reset(self, mask=None):
+        _chk(self._L.rsim_ctrl_reset(self.ptr, None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).tobytes()))
+
+    def control_step(self, actions, n_sub=25):
+        """actions: torch CUDA float32 tensor [B, action_dim] (or an int device pointer)."""
+        if isinstance(actions, int):
+            ptr = actions
+        else:
+            if not actions.is_cuda or actions.dtype.is_floating_point is False:
+                raise RsimError("actions must be a CUDA float32 tensor")
+            actions = actions.contiguous().float()
+            self._keep = actions
+            ptr = actions.data_ptr()
+        _chk(self._L.rsim_control_step(self.ptr, C.c_void_p(ptr), int(n_sub)))
+
+    def stream(self):
+        return self._L.rsim_stream(self.ptr)
+
+    def jac_site(self, env, site):
+        nv = self.model.flat.nv
+        jp, jr = np.zeros((3, nv)), np.zeros((3, nv))
+        _chk(self._L.rsim_jac_site(self.ptr, env, site, jp.ctypes.data, jr.ctypes.data))
+        return jp, jr
+
+    def jac_body(self, env, body):
+        nv = self.model.flat.nv
+        jp, jr = np.zeros((3, nv)), np.zeros((3, nv))
+        _chk(self._L.rsim_jac_body(self.ptr, env, body, jp.ctypes.data, jr.ctypes.data))
+        return jp, jr
+
+    def param_set(self, field, values, env0=0):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if v.ndim == 1:
+            v = v[None]
+        v = v.reshape(v.shape[0], -1)
+        _chk(self._L.rsim_model_param_set(self.ptr, field.encode(), int(env0), v.shape[0], v.ctypes.data, v.shape[1]))
+
+    def contacts(self, env=0):
+        n = int(self.get("ncon")[env])
+        rec = self.get("contact")[env]
+        return [dict(dist=float(r[0]), pos=r[1:4].astype(np.float64), frame=r[4:13].astype(np.float64).reshape(3, 3), geom1=int(r[13]), geom2=int(r[14]),
+                     dim=int(r[15]), efc_address=int(r[16]), normal_force=float(r[17]), friction=r[18:23].astype(np.float64)) for r in rec[:n]]
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._L.rsim_batch_free(self.ptr)
+        except Exception:
+            pass
+
+
+def osc_eval(cfg: dict, packed: np.ndarray, device=0) -> np.ndarray:
+    """Batched OSC torque law on explicit inputs ([B,192] float32, layout in include/rsim.h) -> [B,8] torques."""
+    d = ctrl_desc(cfg)
+    a = np.ascontiguousarray(packed, dtype=np.float32)
+    out = np.zeros((a.shape[0], 8), dtype=np.float32)
+    _chk(lib().rsim_osc_eval(C.byref(d), a.ctypes.data, out.ctypes.data, a.shape[0], device))
+    return out
+
+
+def pack_osc_inputs(ep, eR, ev, op, oR, bv, goal_pos, goal_ori, J, M, bias, q, qd, q0):
+    """Pack one sample into the 192-float record of rsim_osc_eval."""
+    n = len(q)
+    r = np.zeros(192, dtype=np.float32)
+    r[0:3], r[3:12], r[12:18], r[18:21], r[21:30], r[30:36], r[36:39], r[39:48] = ep, np.ravel(eR), ev, op, np.ravel(oR), bv, goal_pos, np.ravel(goal_ori)
+    Jp = np.zeros((6, 8)); Jp[:, :n] = J
+    Mp = np.zeros((8, 8)); Mp[:n, :n] = M
+    r[48:96], r[96:160] = Jp.ravel(), Mp.ravel()
+    r[160:160 + n], r[168:168 + n], r[176:176 + n], r[184:184 + n] = bias, q, qd, q0
+    return r

@@ -1,0 +1,563 @@
+// rsim_api.cpp -- host side of the C-ABI (include/rsim.h): model blob ingest, table packing, batch memory, launches.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rsim.h"
+#include "rsim_internal.h"
+
+extern "C" int rsim_launch_step_cfg0(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
+extern "C" int rsim_launch_ctrl_reset_cfg0(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
+extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream);
+extern "C" int rsim_cfg0_limits(int* lim);
+
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+extern "C" const char* rsim_last_error(void) { return g_err; }
+#define HIPCHK(x)                                                                  \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) return fail("%s: %s", #x, hipGetErrorString(e_));        \
+  } while (0)
+
+typedef unsigned long long u64;
+
+struct Entry { int dtype; size_t count; const void* ptr; };
+
+struct rsim_model {
+  std::vector<unsigned char> blob;
+  std::map<std::string, Entry> f;
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, npair;
+  // derived host tables
+  std::vector<int> cg;        // colliding geom list (original geom ids)
+  std::vector<int> geom2cg;   // original id -> cg index or -1
+  std::vector<int> itab;
+  std::vector<float> ftab;
+  std::vector<float> mesh_vert;
+  int io[IO_COUNT], fo[FO_COUNT], fcount[FO_COUNT];
+  int maxdepth, nroot;
+  std::vector<u64> body_dofmask;
+  DCtrl ctrl;
+  float meaninertia;
+  const int* I(const char* n) const { auto it = f.find(n); return it == f.end() ? nullptr : (const int*)it->second.ptr; }
+  const double* D(const char* n) const { auto it = f.find(n); return it == f.end() ? nullptr : (const double*)it->second.ptr; }
+  size_t count(const char* n) const { auto it = f.find(n); return it == f.end() ? 0 : it->second.count; }
+};
+
+struct rsim_batch {
+  rsim_model* m;
+  int B, device, per_env;
+  hipStream_t stream;
+  int* d_it;
+  float* d_ft;
+  float* d_mesh;
+  unsigned char* d_mask;
+  DModel dm;
+  DBatch db;
+  void* fptr[RSIM_FIELD_COUNT];
+  size_t fcount[RSIM_FIELD_COUNT];
+  int fis_int[RSIM_FIELD_COUNT];
+  int lim[8];
+  // host cache for jacobians
+  long gen, cache_gen;
+  int cache_env;
+  std::vector<float> h_cdof, h_rootcom, h_xpos, h_xquat;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out) {
+  if (!blob || len < 16 || memcmp(blob, "RSIMMDL1", 8) != 0) return fail("rsim_model_create: bad blob magic");
+  rsim_model* m = new rsim_model();
+  m->blob.assign((const unsigned char*)blob, (const unsigned char*)blob + len);
+  const unsigned char* p = m->blob.data();
+  uint32_t n = *(const uint32_t*)(p + 8);
+  if (16 + 48 * (size_t)n > len) { delete m; return fail("rsim_model_create: truncated header"); }
+  for (uint32_t i = 0; i < n; i++) {
+    const unsigned char* e = p + 16 + 48 * i;
+    char name[33];
+    memcpy(name, e, 32);
+    name[32] = 0;
+    uint32_t dtype = *(const uint32_t*)(e + 32), cnt = *(const uint32_t*)(e + 36);
+    uint64_t off = *(const uint64_t*)(e + 40);
+    size_t bytes = (size_t)cnt * (dtype == 0 ? 4 : 8);
+    if (off + bytes > len) { delete m; return fail("rsim_model_create: field %s out of range", name); }
+    m->f[name] = Entry{(int)dtype, cnt, p + off};
+  }
+  auto geti = [&](const char* k) { const int* v = m->I(k); return v ? v[0] : 0; };
+  m->nq = geti("nq"); m->nv = geti("nv"); m->nu = geti("nu"); m->nbody = geti("nbody"); m->njnt = geti("njnt");
+  m->ngeom = geti("ngeom"); m->nsite = geti("nsite"); m->npair = geti("npair");
+  const char* required[] = {"body_parentid", "body_rootid", "body_weldid", "body_jntadr", "body_jntnum", "body_dofadr", "body_dofnum", "body_pos",
+                            "body_quat", "body_ipos", "body_iquat", "body_mass", "body_inertia", "body_invweight0", "body_subtreemass", "jnt_type",
+                            "jnt_qposadr", "jnt_dofadr", "jnt_bodyid", "jnt_limited", "jnt_pos", "jnt_axis", "jnt_range", "jnt_margin", "jnt_solref",
+                            "jnt_solimp", "qpos0", "dof_bodyid", "dof_jntid", "dof_parentid", "dof_armature", "dof_damping", "dof_frictionloss",
+                            "dof_solref", "dof_solimp", "dof_invweight0", "dof_M0", "geom_type", "geom_bodyid", "geom_condim", "geom_priority",
+                            "geom_dataid", "geom_size", "geom_pos", "geom_quat", "geom_friction", "geom_solref", "geom_solimp", "geom_solmix",
+                            "geom_margin", "geom_gap", "geom_rbound", "geom_rcenter", "site_bodyid", "site_pos", "site_quat", "actuator_trnid",
+                            "actuator_gear", "actuator_gainprm", "actuator_biasprm", "actuator_biastype", "actuator_ctrllimited", "actuator_ctrlrange",
+                            "actuator_forcelimited", "actuator_forcerange", "pair_geom1", "pair_geom2", "gravity", "wind", "timestep"};
+  for (const char* r : required)
+    if (m->f.find(r) == m->f.end()) { delete m; return fail("rsim_model_create: blob lacks field '%s'", r); }
+  if (m->nbody > 64 || m->nv > 64) { delete m; return fail("rsim_model_create: nbody/nv > 64 unsupported (ancestor bit-masks)"); }
+  memset(&m->ctrl, 0, sizeof(m->ctrl));
+
+  const int nb = m->nbody, nv = m->nv, nj = m->njnt;
+  const int *parent = m->I("body_parentid"), *weld = m->I("body_weldid"), *jadr = m->I("body_jntadr"), *jnum = m->I("body_jntnum");
+  const int *bdofadr = m->I("body_dofadr"), *bdofnum = m->I("body_dofnum"), *jtype = m->I("jnt_type"), *jdof = m->I("jnt_dofadr");
+  const int *dofbody = m->I("dof_bodyid"), *dofjnt = m->I("dof_jntid"), *dofpar = m->I("dof_parentid");
+  // colliding geoms = those referenced by a pair
+  m->geom2cg.assign(m->ngeom, -1);
+  {
+    std::vector<char> used(m->ngeom, 0);
+    for (int p2 = 0; p2 < m->npair; p2++) { used[m->I("pair_geom1")[p2]] = 1; used[m->I("pair_geom2")[p2]] = 1; }
+    for (int g = 0; g < m->ngeom; g++) if (used[g]) { m->geom2cg[g] = (int)m->cg.size(); m->cg.push_back(g); }
+  }
+  const int ncg = (int)m->cg.size();
+  // masks, depth
+  std::vector<int> depth(nb, 0), isroot(nb, 0), moving(nb, 0);
+  std::vector<u64> anc(nb, 0), bdm(nb, 0), danc(nv, 0), dcv(nv, 0);
+  std::vector<int> zerodot(nv, 0);
+  m->maxdepth = 0; m->nroot = 0;
+  for (int b = 1; b < nb; b++) {
+    depth[b] = depth[parent[b]] + 1;
+    if (depth[b] > m->maxdepth) m->maxdepth = depth[b];
+    isroot[b] = parent[b] == 0;
+    m->nroot += isroot[b];
+    moving[b] = weld[b] != 0;
+    anc[b] = anc[parent[b]] | (1ull << b);
+    bdm[b] = bdm[parent[b]];
+    for (int k = 0; k < bdofnum[b]; k++) bdm[b] |= 1ull << (bdofadr[b] + k);
+  }
+  for (int i = 0; i < nv; i++) {
+    danc[i] = (dofpar[i] >= 0 ? danc[dofpar[i]] : 0) | (1ull << i);
+    int b = dofbody[i], j = dofjnt[i];
+    u64 mk = bdm[parent[b]];
+    for (int jj = jadr[b]; jj < j; jj++) {
+      int nd = jtype[jj] == 0 ? 6 : (jtype[jj] == 1 ? 3 : 1);
+      for (int k = 0; k < nd; k++) mk |= 1ull << (jdof[jj] + k);
+    }
+    if (jtype[j] == 0) {
+      if (i >= jdof[j] + 3) for (int k = 0; k < 3; k++) mk |= 1ull << (jdof[j] + k);
+      else zerodot[i] = 1;
+    }
+    dcv[i] = mk;
+  }
+  m->body_dofmask = bdm;
+  // ---- int table
+  auto& it = m->itab;
+  auto push = [&](int id, const std::vector<int>& v) { m->io[id] = (int)it.size(); it.insert(it.end(), v.begin(), v.end()); };
+  auto vec = [&](const char* k, size_t n_) { const int* p2 = m->I(k); return std::vector<int>(p2, p2 + n_); };
+  auto split = [&](const std::vector<u64>& v) { std::vector<int> o; for (u64 x : v) { o.push_back((int)(uint32_t)(x & 0xffffffffull)); o.push_back((int)(uint32_t)(x >> 32)); } return o; };
+  push(IO_body_parentid, vec("body_parentid", nb)); push(IO_body_rootid, vec("body_rootid", nb)); push(IO_body_jntadr, vec("body_jntadr", nb));
+  push(IO_body_jntnum, vec("body_jntnum", nb)); push(IO_body_dofadr, vec("body_dofadr", nb)); push(IO_body_dofnum, vec("body_dofnum", nb));
+  push(IO_body_depth, depth); push(IO_body_mocap, std::vector<int>(nb, 0)); push(IO_body_moving, moving); push(IO_body_ancmask, split(anc));
+  push(IO_body_dofmask, split(bdm)); push(IO_body_isroot, isroot);
+  push(IO_jnt_type, vec("jnt_type", nj)); push(IO_jnt_qposadr, vec("jnt_qposadr", nj)); push(IO_jnt_dofadr, vec("jnt_dofadr", nj));
+  push(IO_jnt_bodyid, vec("jnt_bodyid", nj)); push(IO_jnt_limited, vec("jnt_limited", nj));
+  push(IO_dof_bodyid, vec("dof_bodyid", nv)); push(IO_dof_jntid, vec("dof_jntid", nv)); push(IO_dof_ancmask, split(danc)); push(IO_dof_cvelmask, split(dcv));
+  push(IO_dof_zerodot, zerodot);
+  {
+    std::vector<int> gid(ncg), gt(ncg), gb(ncg), gc(ncg), gp(ncg), ma(ncg, 0), mn(ncg, 0);
+    for (int c = 0; c < ncg; c++) {
+      int g = m->cg[c];
+      gid[c] = g; gt[c] = m->I("geom_type")[g]; gb[c] = m->I("geom_bodyid")[g]; gc[c] = m->I("geom_condim")[g]; gp[c] = m->I("geom_priority")[g];
+      int did = m->I("geom_dataid")[g];
+      if (gt[c] == 7) {
+        if (did < 0) { delete m; return fail("mesh geom %d without mesh data", g); }
+        ma[c] = m->I("mesh_vertadr")[did]; mn[c] = m->I("mesh_vertnum")[did];
+      }
+      if (gt[c] == 1) { delete m; return fail("hfield geoms unsupported"); }
+    }
+    push(IO_cg_geomid, gid); push(IO_cg_type, gt); push(IO_cg_bodyid, gb); push(IO_cg_condim, gc); push(IO_cg_priority, gp); push(IO_cg_meshadr, ma);
+    push(IO_cg_meshnum, mn);
+    std::vector<int> p1(m->npair), p2(m->npair);
+    for (int p3 = 0; p3 < m->npair; p3++) { p1[p3] = m->geom2cg[m->I("pair_geom1")[p3]]; p2[p3] = m->geom2cg[m->I("pair_geom2")[p3]]; }
+    push(IO_pair_g1, p1); push(IO_pair_g2, p2);
+  }
+  push(IO_site_bodyid, vec("site_bodyid", m->nsite));
+  push(IO_act_trnid, vec("actuator_trnid", m->nu)); push(IO_act_biastype, vec("actuator_biastype", m->nu));
+  push(IO_act_ctrllimited, vec("actuator_ctrllimited", m->nu)); push(IO_act_forcelimited, vec("actuator_forcelimited", m->nu));
+  // ---- float table
+  auto& ft = m->ftab;
+  auto pushf = [&](int id, const char* k, size_t n_) {
+    m->fo[id] = (int)ft.size(); m->fcount[id] = (int)n_;
+    const double* p2 = m->D(k);
+    for (size_t i = 0; i < n_; i++) ft.push_back((float)p2[i]);
+  };
+  auto pushg = [&](int id, const char* k, int w) {  // geom field restricted to the colliding list
+    m->fo[id] = (int)ft.size(); m->fcount[id] = ncg * w;
+    const double* p2 = m->D(k);
+    for (int c = 0; c < ncg; c++) for (int q = 0; q < w; q++) ft.push_back((float)p2[(size_t)m->cg[c] * w + q]);
+  };
+  pushf(FO_body_pos, "body_pos", 3 * nb); pushf(FO_body_quat, "body_quat", 4 * nb); pushf(FO_body_ipos, "body_ipos", 3 * nb); pushf(FO_body_iquat, "body_iquat", 4 * nb);
+  pushf(FO_body_mass, "body_mass", nb); pushf(FO_body_inertia, "body_inertia", 3 * nb); pushf(FO_body_invweight0, "body_invweight0", 2 * nb);
+  pushf(FO_body_subtreemass, "body_subtreemass", nb);
+  pushf(FO_jnt_pos, "jnt_pos", 3 * nj); pushf(FO_jnt_axis, "jnt_axis", 3 * nj); pushf(FO_jnt_range, "jnt_range", 2 * nj); pushf(FO_jnt_margin, "jnt_margin", nj);
+  pushf(FO_jnt_solref, "jnt_solref", 2 * nj); pushf(FO_jnt_solimp, "jnt_solimp", 5 * nj); pushf(FO_qpos0, "qpos0", m->nq);
+  pushf(FO_dof_armature, "dof_armature", nv); pushf(FO_dof_damping, "dof_damping", nv); pushf(FO_dof_frictionloss, "dof_frictionloss", nv);
+  pushf(FO_dof_solref, "dof_solref", 2 * nv); pushf(FO_dof_solimp, "dof_solimp", 5 * nv); pushf(FO_dof_invweight0, "dof_invweight0", nv);
+  pushg(FO_cg_size, "geom_size", 3); pushg(FO_cg_pos, "geom_pos", 3); pushg(FO_cg_quat, "geom_quat", 4); pushg(FO_cg_friction, "geom_friction", 3);
+  pushg(FO_cg_solref, "geom_solref", 2); pushg(FO_cg_solimp, "geom_solimp", 5); pushg(FO_cg_solmix, "geom_solmix", 1); pushg(FO_cg_margin, "geom_margin", 1);
+  pushg(FO_cg_gap, "geom_gap", 1); pushg(FO_cg_rbound, "geom_rbound", 1); pushg(FO_cg_rcenter, "geom_rcenter", 3);
+  pushf(FO_site_pos, "site_pos", 3 * m->nsite); pushf(FO_site_quat, "site_quat", 4 * m->nsite);
+  pushf(FO_act_gear, "actuator_gear", m->nu); pushf(FO_act_gainprm, "actuator_gainprm", 3 * m->nu); pushf(FO_act_biasprm, "actuator_biasprm", 3 * m->nu);
+  pushf(FO_act_ctrlrange, "actuator_ctrlrange", 2 * m->nu); pushf(FO_act_forcerange, "actuator_forcerange", 2 * m->nu);
+  m->fo[FO_opt] = (int)ft.size(); m->fcount[FO_opt] = 10;
+  {
+    auto d1 = [&](const char* k) { const double* v = m->D(k); return v ? (float)v[0] : 0.f; };
+    ft.push_back(d1("timestep"));
+    for (int k = 0; k < 3; k++) ft.push_back((float)m->D("gravity")[k]);
+    ft.push_back(d1("density")); ft.push_back(d1("viscosity")); ft.push_back(d1("impratio"));
+    for (int k = 0; k < 3; k++) ft.push_back((float)m->D("wind")[k]);
+  }
+  while (ft.size() % 16) ft.push_back(0.f);
+  // mesh vertices
+  {
+    size_t nmv = m->count("mesh_vert");
+    const double* mv = m->D("mesh_vert");
+    m->mesh_vert.resize(nmv ? nmv : 3);
+    for (size_t i = 0; i < nmv; i++) m->mesh_vert[i] = (float)mv[i];
+  }
+  double s = 0;
+  for (int i = 0; i < nv; i++) s += m->D("dof_M0")[i];
+  m->meaninertia = nv > 0 ? (float)(s / nv) : 1.f;
+  if (m->meaninertia < 1e-15f) m->meaninertia = 1.f;
+  *out = m;
+  return 0;
+}
+
+extern "C" void rsim_model_free(rsim_model* m) { delete m; }
+
+extern "C" int rsim_model_int(const rsim_model* m, const char* name) {
+  if (!strcmp(name, "ncgeom")) return (int)m->cg.size();
+  const int* v = m->I(name);
+  return v ? v[0] : -1;
+}
+
+extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d) {
+  if (d->ndof < 1 || d->ndof > RSIM_ARM_MAX || d->ngrip < 0 || d->ngrip > RSIM_GRIP_MAX) return fail("controller: bad ndof/ngrip");
+  DCtrl& c = m->ctrl;
+  memset(&c, 0, sizeof(c));
+  c.enabled = 1; c.ndof = d->ndof;
+  for (int i = 0; i < d->ndof; i++) {
+    if (d->qpos_idx[i] < 0 || d->qpos_idx[i] >= m->nq || d->dof_idx[i] < 0 || d->dof_idx[i] >= m->nv || d->act_idx[i] < 0 || d->act_idx[i] >= m->nu)
+      return fail("controller: index out of range");
+    c.qpos_idx[i] = d->qpos_idx[i]; c.dof_idx[i] = d->dof_idx[i]; c.act_idx[i] = d->act_idx[i];
+  }
+  if (d->eef_site < 0 || d->eef_site >= m->nsite || d->base_site < 0 || d->base_site >= m->nsite) return fail("controller: bad site id");
+  c.eef_site = d->eef_site; c.base_site = d->base_site;
+  for (int i = 0; i < 6; i++) {
+    c.kp[i] = d->kp[i]; c.kd[i] = 2.f * sqrtf(d->kp[i]) * d->damping_ratio;
+    c.in_min[i] = d->input_min[i]; c.in_max[i] = d->input_max[i]; c.out_min[i] = d->output_min[i]; c.out_max[i] = d->output_max[i];
+  }
+  c.uncouple = d->uncouple_pos_ori; c.nullspace_kp = d->nullspace_kp > 0 ? d->nullspace_kp : 10.f;
+  c.ngrip = d->ngrip;
+  for (int i = 0; i < d->ngrip; i++) {
+    if (d->grip_act[i] < 0 || d->grip_act[i] >= m->nu) return fail("controller: bad gripper actuator");
+    c.grip_act[i] = d->grip_act[i]; c.grip_sign[i] = d->grip_sign[i];
+  }
+  c.grip_speed = d->grip_speed;
+  c.action_dim = 6 + (d->ngrip > 0 ? 1 : 0);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <class T>
+static int dalloc(T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+  HIPCHK(hipMemset(*p, 0, (n ? n : 1) * sizeof(T)));
+  return 0;
+}
+
+extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, rsim_batch** out) {
+  if (B < 1) return fail("rsim_batch_create: B < 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("rsim_batch_create: no HIP device visible (the HIP backend has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail("rsim_batch_create: device %d out of range (%d visible)", device, ndev);
+  rsim_batch* b = new rsim_batch();
+  memset(&b->dm, 0, sizeof(b->dm));
+  memset(&b->db, 0, sizeof(b->db));
+  b->m = m; b->B = B; b->device = device; b->per_env = per_env ? 1 : 0;
+  b->gen = 1; b->cache_gen = 0; b->cache_env = -1;
+  rsim_cfg0_limits(b->lim);
+  const int ncg = (int)m->cg.size();
+  if (m->nbody > b->lim[0] || m->njnt > b->lim[1] || m->nv > b->lim[2] || m->nq > b->lim[2] + 8 || m->nu > b->lim[2] || ncg > b->lim[3] || m->nsite > b->lim[4] ||
+      m->npair > b->lim[7]) {
+    int r = fail("rsim_batch_create: model (nbody %d njnt %d nv %d ncgeom %d nsite %d npair %d) exceeds the compiled kernel configuration (%d %d %d %d %d .. %d)",
+                 m->nbody, m->njnt, m->nv, ncg, m->nsite, m->npair, b->lim[0], b->lim[1], b->lim[2], b->lim[3], b->lim[4], b->lim[7]);
+    delete b;
+    return r;
+  }
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamCreate(&b->stream));
+  if (dalloc(&b->d_it, m->itab.size())) return 1;
+  HIPCHK(hipMemcpy(b->d_it, m->itab.data(), m->itab.size() * sizeof(int), hipMemcpyHostToDevice));
+  size_t fs = m->ftab.size();
+  size_t copies = b->per_env ? (size_t)B : 1;
+  if (dalloc(&b->d_ft, fs * copies)) return 1;
+  for (size_t c = 0; c < copies; c++) HIPCHK(hipMemcpy(b->d_ft + c * fs, m->ftab.data(), fs * sizeof(float), hipMemcpyHostToDevice));
+  if (dalloc(&b->d_mesh, m->mesh_vert.size())) return 1;
+  HIPCHK(hipMemcpy(b->d_mesh, m->mesh_vert.data(), m->mesh_vert.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (dalloc(&b->d_mask, (size_t)B)) return 1;
+  DModel& dm = b->dm;
+  dm.nq = m->nq; dm.nv = m->nv; dm.nu = m->nu; dm.nbody = m->nbody; dm.njnt = m->njnt; dm.ncg = ncg; dm.nsite = m->nsite; dm.npair = m->npair;
+  dm.maxdepth = m->maxdepth; dm.nroot = m->nroot;
+  dm.iterations = m->I("iterations") ? m->I("iterations")[0] : 100;
+  dm.ls_iterations = 50; dm.cone = m->I("cone") ? m->I("cone")[0] : 1; dm.solver = 1;
+  dm.tolerance = m->D("tolerance") ? (float)m->D("tolerance")[0] : 1e-8f;
+  dm.meaninertia = m->meaninertia;
+  dm.it = b->d_it; dm.ft = b->d_ft; dm.mesh_vert = b->d_mesh; dm.fstride = b->per_env ? (int)fs : 0;
+  memcpy(dm.io, m->io, sizeof(dm.io));
+  memcpy(dm.fo, m->fo, sizeof(dm.fo));
+  dm.ctrl = m->ctrl;
+  DBatch& db = b->db;
+  db.B = B;
+  const int nq = m->nq, nv = m->nv, nu = m->nu, nb = m->nbody, NCON = b->lim[5], NEFC = b->lim[6];
+  struct { int id; void** p; size_t n; int is_int; } fields[] = {
+      {RSIM_QPOS, (void**)&db.qpos, (size_t)B * nq, 0}, {RSIM_QVEL, (void**)&db.qvel, (size_t)B * nv, 0}, {RSIM_QACC_WARMSTART, (void**)&db.qacc_ws, (size_t)B * nv, 0},
+      {RSIM_CTRL, (void**)&db.ctrl, (size_t)B * nu, 0}, {RSIM_TIME, (void**)&db.time, (size_t)B, 0}, {RSIM_CSTATE, (void**)&db.cstate, (size_t)B * RSIM_CS_SIZE, 0},
+      {RSIM_XPOS, (void**)&db.xpos, (size_t)B * nb * 3, 0}, {RSIM_XQUAT, (void**)&db.xquat, (size_t)B * nb * 4, 0}, {RSIM_QM, (void**)&db.qM, (size_t)B * nv * nv, 0},
+      {RSIM_QFRC_BIAS, (void**)&db.qfrc_bias, (size_t)B * nv, 0}, {RSIM_QFRC_PASSIVE, (void**)&db.qfrc_passive, (size_t)B * nv, 0},
+      {RSIM_QFRC_ACTUATOR, (void**)&db.qfrc_actuator, (size_t)B * nv, 0}, {RSIM_QFRC_CONSTRAINT, (void**)&db.qfrc_constraint, (size_t)B * nv, 0},
+      {RSIM_QACC, (void**)&db.qacc, (size_t)B * nv, 0}, {RSIM_CDOF, (void**)&db.cdof, (size_t)B * nv * 6, 0}, {RSIM_ROOTCOM, (void**)&db.rootcom, (size_t)B * nb * 3, 0},
+      {RSIM_CONTACT, (void**)&db.contact, (size_t)B * NCON * RSIM_CON_REC, 0}, {RSIM_EFC_FORCE, (void**)&db.efc_force, (size_t)B * NEFC, 0},
+      {RSIM_NCON, (void**)&db.ncon, (size_t)B, 1}, {RSIM_NEFC, (void**)&db.nefc, (size_t)B, 1}, {RSIM_NITER, (void**)&db.niter, (size_t)B, 1}};
+  for (auto& fd : fields) {
+    if (dalloc((float**)fd.p, fd.n)) return 1;
+    b->fptr[fd.id] = *fd.p; b->fcount[fd.id] = fd.n; b->fis_int[fd.id] = fd.is_int;
+  }
+  *out = b;
+  return rsim_reset(b, nullptr);
+}
+
+extern "C" void rsim_batch_free(rsim_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  hipStreamSynchronize(b->stream);
+  for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
+  hipFree(b->d_it); hipFree(b->d_ft); hipFree(b->d_mesh); hipFree(b->d_mask);
+  hipStreamDestroy(b->stream);
+  delete b;
+}
+extern "C" int rsim_batch_size(const rsim_batch* b) { return b->B; }
+extern "C" int rsim_batch_limits(const rsim_batch* b, int* maxcon, int* maxefc) { *maxcon = b->lim[5]; *maxefc = b->lim[6]; return 0; }
+extern "C" void* rsim_stream(rsim_batch* b) { return (void*)b->stream; }
+extern "C" int rsim_sync(rsim_batch* b) { HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return 0; }
+
+extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) {
+  rsim_model* m = b->m;
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const int nq = m->nq, nv = m->nv, nu = m->nu, B = b->B;
+  std::vector<float> q0(nq);
+  for (int i = 0; i < nq; i++) q0[i] = (float)m->D("qpos0")[i];
+  std::vector<float> zv(nv > nu ? nv : nu, 0.f);
+  if (!mask) {
+    std::vector<float> all((size_t)B * nq);
+    for (int e = 0; e < B; e++) memcpy(&all[(size_t)e * nq], q0.data(), nq * sizeof(float));
+    HIPCHK(hipMemcpy(b->db.qpos, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(b->db.qvel, 0, (size_t)B * nv * sizeof(float)));
+    HIPCHK(hipMemset(b->db.qacc_ws, 0, (size_t)B * nv * sizeof(float)));
+    HIPCHK(hipMemset(b->db.ctrl, 0, (size_t)B * nu * sizeof(float)));
+    HIPCHK(hipMemset(b->db.time, 0, (size_t)B * sizeof(float)));
+    HIPCHK(hipMemset(b->db.cstate, 0, (size_t)B * RSIM_CS_SIZE * sizeof(float)));
+  } else {
+    for (int e = 0; e < B; e++) {
+      if (!mask[e]) continue;
+      HIPCHK(hipMemcpy(b->db.qpos + (size_t)e * nq, q0.data(), nq * sizeof(float), hipMemcpyHostToDevice));
+      HIPCHK(hipMemset(b->db.qvel + (size_t)e * nv, 0, nv * sizeof(float)));
+      HIPCHK(hipMemset(b->db.qacc_ws + (size_t)e * nv, 0, nv * sizeof(float)));
+      HIPCHK(hipMemset(b->db.ctrl + (size_t)e * nu, 0, nu * sizeof(float)));
+      HIPCHK(hipMemset(b->db.time + e, 0, sizeof(float)));
+      HIPCHK(hipMemset(b->db.cstate + (size_t)e * RSIM_CS_SIZE, 0, RSIM_CS_SIZE * sizeof(float)));
+    }
+  }
+  b->gen++;
+  return 0;
+}
+
+static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
+  HIPCHK(hipSetDevice(b->device));
+  b->dm.ctrl = b->m->ctrl;
+  if ((flags & RF_CTRL) && !b->dm.ctrl.enabled) return fail("no controller configured (rsim_model_set_controller)");
+  int e = rsim_launch_step_cfg0(&b->dm, &b->db, actions, n_sub, flags, b->stream);
+  if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  b->gen++;
+  return 0;
+}
+extern "C" int rsim_forward(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_DEBUG); }
+extern "C" int rsim_step1(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL | RF_DEBUG); }
+extern "C" int rsim_step2(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_INTEGRATE | RF_DEBUG); }
+extern "C" int rsim_step(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_INTEGRATE | RF_DEBUG); }
+extern "C" int rsim_control_step(rsim_batch* b, const float* actions_dev, int n_sub) {
+  if (n_sub < 1) return fail("rsim_control_step: n_sub < 1");
+  if (!actions_dev) return fail("rsim_control_step: actions_dev is NULL");
+  return launch(b, actions_dev, n_sub, RF_POSVEL | RF_CTRL | RF_SETGOAL | RF_ACTSOLVE | RF_INTEGRATE);
+}
+extern "C" int rsim_ctrl_reset(rsim_batch* b, const uint8_t* mask) {
+  HIPCHK(hipSetDevice(b->device));
+  if (!b->m->ctrl.enabled) return fail("no controller configured");
+  b->dm.ctrl = b->m->ctrl;
+  const unsigned char* dmask = nullptr;
+  if (mask) {
+    HIPCHK(hipMemcpyAsync(b->d_mask, mask, (size_t)b->B, hipMemcpyHostToDevice, b->stream));
+    dmask = b->d_mask;
+  }
+  int e = rsim_launch_ctrl_reset_cfg0(&b->dm, &b->db, dmask, b->stream);
+  if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (mask) HIPCHK(hipStreamSynchronize(b->stream));
+  b->gen++;
+  return 0;
+}
+
+extern "C" void* rsim_device_ptr(rsim_batch* b, int field, size_t* count) {
+  if (field < 0 || field >= RSIM_FIELD_COUNT) { fail("bad field id %d", field); return nullptr; }
+  if (count) *count = b->fcount[field];
+  return b->fptr[field];
+}
+extern "C" int rsim_get_array(rsim_batch* b, int field, void* dst, size_t count) {
+  if (field < 0 || field >= RSIM_FIELD_COUNT) return fail("bad field id %d", field);
+  if (count > b->fcount[field]) return fail("rsim_get_array: count %zu > field size %zu", count, b->fcount[field]);
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(dst, b->fptr[field], count * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int rsim_set_array(rsim_batch* b, int field, const void* src, size_t count) {
+  if (field < 0 || field >= RSIM_FIELD_COUNT) return fail("bad field id %d", field);
+  if (count > b->fcount[field]) return fail("rsim_set_array: count %zu > field size %zu", count, b->fcount[field]);
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(b->fptr[field], src, count * 4, hipMemcpyHostToDevice));
+  b->gen++;
+  return 0;
+}
+
+static int refresh_cache(rsim_batch* b, int env) {
+  if (b->cache_gen == b->gen && b->cache_env == env) return 0;
+  rsim_model* m = b->m;
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  b->h_cdof.resize(m->nv * 6); b->h_rootcom.resize(m->nbody * 3); b->h_xpos.resize(m->nbody * 3); b->h_xquat.resize(m->nbody * 4);
+  HIPCHK(hipMemcpy(b->h_cdof.data(), b->db.cdof + (size_t)env * m->nv * 6, m->nv * 6 * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(b->h_rootcom.data(), b->db.rootcom + (size_t)env * m->nbody * 3, m->nbody * 3 * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(b->h_xpos.data(), b->db.xpos + (size_t)env * m->nbody * 3, m->nbody * 3 * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(b->h_xquat.data(), b->db.xquat + (size_t)env * m->nbody * 4, m->nbody * 4 * 4, hipMemcpyDeviceToHost));
+  b->cache_gen = b->gen; b->cache_env = env;
+  return 0;
+}
+static void body_point(rsim_batch* b, int body, const double* local, double* out) {
+  const float* q = &b->h_xquat[4 * body];
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  double R[9] = {w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
+                 2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z};
+  for (int i = 0; i < 3; i++) out[i] = b->h_xpos[3 * body + i] + R[3 * i] * local[0] + R[3 * i + 1] * local[1] + R[3 * i + 2] * local[2];
+}
+static int jac_common(rsim_batch* b, int env, int body, const double* local, double* jacp, double* jacr) {
+  rsim_model* m = b->m;
+  if (env < 0 || env >= b->B) return fail("env out of range");
+  if (refresh_cache(b, env)) return 1;
+  const int nv = m->nv;
+  double p[3];
+  body_point(b, body, local, p);
+  if (jacp) memset(jacp, 0, sizeof(double) * 3 * nv);
+  if (jacr) memset(jacr, 0, sizeof(double) * 3 * nv);
+  int root = m->I("body_rootid")[body];
+  double off[3];
+  for (int k = 0; k < 3; k++) off[k] = p[k] - b->h_rootcom[3 * root + k];
+  u64 mk = m->body_dofmask[body];
+  for (int i = 0; i < nv; i++) {
+    if (!((mk >> i) & 1ull)) continue;
+    const float* cd = &b->h_cdof[6 * i];
+    if (jacr) for (int k = 0; k < 3; k++) jacr[k * nv + i] = cd[k];
+    if (jacp) {
+      double t[3] = {cd[1] * off[2] - cd[2] * off[1], cd[2] * off[0] - cd[0] * off[2], cd[0] * off[1] - cd[1] * off[0]};
+      for (int k = 0; k < 3; k++) jacp[k * nv + i] = cd[3 + k] + t[k];
+    }
+  }
+  return 0;
+}
+extern "C" int rsim_jac_site(rsim_batch* b, int env, int site, double* jacp, double* jacr) {
+  rsim_model* m = b->m;
+  if (site < 0 || site >= m->nsite) return fail("site out of range");
+  return jac_common(b, env, m->I("site_bodyid")[site], m->D("site_pos") + 3 * site, jacp, jacr);
+}
+extern "C" int rsim_jac_body(rsim_batch* b, int env, int body, double* jacp, double* jacr) {
+  if (body < 0 || body >= b->m->nbody) return fail("body out of range");
+  double z[3] = {0, 0, 0};
+  return jac_common(b, env, body, z, jacp, jacr);
+}
+
+extern "C" int rsim_model_param_set(rsim_batch* b, const char* field, int env0, int nenv, const double* values, size_t cpe) {
+  rsim_model* m = b->m;
+  struct Map { const char* name; int fo; int w; int geom; };
+  static const Map maps[] = {
+      {"body_pos", FO_body_pos, 3, 0}, {"body_quat", FO_body_quat, 4, 0}, {"body_ipos", FO_body_ipos, 3, 0}, {"body_iquat", FO_body_iquat, 4, 0},
+      {"body_mass", FO_body_mass, 1, 0}, {"body_inertia", FO_body_inertia, 3, 0}, {"body_invweight0", FO_body_invweight0, 2, 0},
+      {"body_subtreemass", FO_body_subtreemass, 1, 0}, {"jnt_pos", FO_jnt_pos, 3, 0}, {"jnt_axis", FO_jnt_axis, 3, 0}, {"jnt_range", FO_jnt_range, 2, 0},
+      {"jnt_margin", FO_jnt_margin, 1, 0}, {"jnt_solref", FO_jnt_solref, 2, 0}, {"jnt_solimp", FO_jnt_solimp, 5, 0}, {"qpos0", FO_qpos0, 1, 0},
+      {"dof_armature", FO_dof_armature, 1, 0}, {"dof_damping", FO_dof_damping, 1, 0}, {"dof_frictionloss", FO_dof_frictionloss, 1, 0},
+      {"dof_solref", FO_dof_solref, 2, 0}, {"dof_solimp", FO_dof_solimp, 5, 0}, {"dof_invweight0", FO_dof_invweight0, 1, 0},
+      {"geom_size", FO_cg_size, 3, 1}, {"geom_pos", FO_cg_pos, 3, 1}, {"geom_quat", FO_cg_quat, 4, 1}, {"geom_friction", FO_cg_friction, 3, 1},
+      {"geom_solref", FO_cg_solref, 2, 1}, {"geom_solimp", FO_cg_solimp, 5, 1}, {"geom_solmix", FO_cg_solmix, 1, 1}, {"geom_margin", FO_cg_margin, 1, 1},
+      {"geom_gap", FO_cg_gap, 1, 1}, {"geom_rbound", FO_cg_rbound, 1, 1}, {"site_pos", FO_site_pos, 3, 0}, {"site_quat", FO_site_quat, 4, 0},
+      {"actuator_gear", FO_act_gear, 1, 0}, {"actuator_gainprm", FO_act_gainprm, 3, 0}, {"actuator_biasprm", FO_act_biasprm, 3, 0},
+      {"actuator_ctrlrange", FO_act_ctrlrange, 2, 0}, {"actuator_forcerange", FO_act_forcerange, 2, 0}, {"opt", FO_opt, 1, 0}};
+  const Map* mp = nullptr;
+  for (auto& x : maps) if (!strcmp(x.name, field)) mp = &x;
+  if (!mp) return fail("rsim_model_param_set: unknown or read-only field '%s'", field);
+  if (env0 < 0 || nenv < 1 || env0 + nenv > b->B) return fail("rsim_model_param_set: env range out of bounds");
+  if (!b->per_env && !(env0 == 0 && nenv == b->B)) return fail("rsim_model_param_set: batch was created without per-env params");
+  size_t expect = mp->geom ? (size_t)m->ngeom * mp->w : (size_t)m->fcount[mp->fo];
+  if (cpe != expect) return fail("rsim_model_param_set: field '%s' expects %zu values per env, got %zu", field, expect, cpe);
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const int ncg = (int)m->cg.size();
+  size_t n = m->fcount[mp->fo], fs = m->ftab.size();
+  std::vector<float> tmp(n);
+  int envs = b->per_env ? nenv : 1;
+  for (int e = 0; e < envs; e++) {
+    const double* v = values + (size_t)e * cpe;
+    if (mp->geom) {
+      for (int c = 0; c < ncg; c++) for (int q = 0; q < mp->w; q++) tmp[(size_t)c * mp->w + q] = (float)v[(size_t)m->cg[c] * mp->w + q];
+    } else for (size_t i = 0; i < n; i++) tmp[i] = (float)v[i];
+    size_t base = b->per_env ? (size_t)(env0 + e) * fs : 0;
+    HIPCHK(hipMemcpy(b->d_ft + base + m->fo[mp->fo], tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  b->gen++;
+  return 0;
+}
+
+extern "C" int rsim_osc_eval(const rsim_ctrl_desc* d, const float* in, float* out, int B, int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("rsim_osc_eval: no HIP device visible");
+  HIPCHK(hipSetDevice(device));
+  DCtrl c;
+  memset(&c, 0, sizeof(c));
+  c.ndof = d->ndof;
+  for (int i = 0; i < 6; i++) { c.kp[i] = d->kp[i]; c.kd[i] = 2.f * sqrtf(d->kp[i]) * d->damping_ratio; }
+  c.uncouple = d->uncouple_pos_ori; c.nullspace_kp = d->nullspace_kp > 0 ? d->nullspace_kp : 10.f;
+  float *din = nullptr, *dout = nullptr;
+  HIPCHK(hipMalloc((void**)&din, (size_t)B * 192 * 4));
+  HIPCHK(hipMalloc((void**)&dout, (size_t)B * 8 * 4));
+  HIPCHK(hipMemcpy(din, in, (size_t)B * 192 * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dout, 0, (size_t)B * 8 * 4));
+  int e = rsim_launch_osc_eval(&c, din, dout, B, 0);
+  if (e) return fail("osc launch failed: %s", hipGetErrorString((hipError_t)e));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, dout, (size_t)B * 8 * 4, hipMemcpyDeviceToHost));
+  hipFree(din); hipFree(dout);
+  return 0;
+}

@@ -1,0 +1,89 @@
+// rsim_internal.h -- device-side model/batch descriptors shared by the HIP kernels and the C-ABI host code.
+// Not part of the public boundary (that is include/rsim.h).
+#pragma once
+#include <stdint.h>
+
+// ---- packed int tables (shared by all envs) ---------------------------------------------------------------
+enum {
+  IO_body_parentid, IO_body_rootid, IO_body_jntadr, IO_body_jntnum, IO_body_dofadr, IO_body_dofnum, IO_body_depth,
+  IO_body_mocap, IO_body_moving, IO_body_ancmask /*2 ints*/, IO_body_dofmask /*2 ints*/, IO_body_isroot,
+  IO_jnt_type, IO_jnt_qposadr, IO_jnt_dofadr, IO_jnt_bodyid, IO_jnt_limited,
+  IO_dof_bodyid, IO_dof_jntid, IO_dof_ancmask /*2*/, IO_dof_cvelmask /*2*/, IO_dof_zerodot,
+  IO_cg_geomid, IO_cg_type, IO_cg_bodyid, IO_cg_condim, IO_cg_priority, IO_cg_meshadr, IO_cg_meshnum,
+  IO_pair_g1, IO_pair_g2,
+  IO_site_bodyid,
+  IO_act_trnid, IO_act_biastype, IO_act_ctrllimited, IO_act_forcelimited,
+  IO_COUNT
+};
+// ---- packed float tables (per-env stride `fstride`, 0 = shared) -------------------------------------------
+enum {
+  FO_body_pos, FO_body_quat, FO_body_ipos, FO_body_iquat, FO_body_mass, FO_body_inertia, FO_body_invweight0, FO_body_subtreemass,
+  FO_jnt_pos, FO_jnt_axis, FO_jnt_range, FO_jnt_margin, FO_jnt_solref, FO_jnt_solimp, FO_qpos0,
+  FO_dof_armature, FO_dof_damping, FO_dof_frictionloss, FO_dof_solref, FO_dof_solimp, FO_dof_invweight0,
+  FO_cg_size, FO_cg_pos, FO_cg_quat, FO_cg_friction, FO_cg_solref, FO_cg_solimp, FO_cg_solmix, FO_cg_margin, FO_cg_gap,
+  FO_cg_rbound, FO_cg_rcenter,
+  FO_site_pos, FO_site_quat,
+  FO_act_gear, FO_act_gainprm, FO_act_biasprm, FO_act_ctrlrange, FO_act_forcerange,
+  FO_opt /* timestep, gx,gy,gz, density, viscosity, impratio, windx,windy,windz */,
+  FO_COUNT
+};
+
+#define RSIM_ARM_MAX 8
+#define RSIM_GRIP_MAX 4
+
+// built-in controller configuration (OSC_POSE arm + GRIP gripper), SURVEY section 8 rows a9-a19
+struct DCtrl {
+  int enabled;
+  int ndof;
+  int qpos_idx[RSIM_ARM_MAX], dof_idx[RSIM_ARM_MAX], act_idx[RSIM_ARM_MAX];
+  int eef_site, base_site;
+  float kp[6], kd[6], in_min[6], in_max[6], out_min[6], out_max[6];
+  int uncouple;
+  float nullspace_kp;
+  int ngrip;
+  int grip_act[RSIM_GRIP_MAX];
+  float grip_sign[RSIM_GRIP_MAX];
+  float grip_speed;
+  int action_dim;
+};
+// controller state block per env (floats): goal_pos[3] goal_ori[9] q0[8] grip_action[4] torques[8]
+#define RSIM_CS_GOALPOS 0
+#define RSIM_CS_GOALORI 3
+#define RSIM_CS_Q0 12
+#define RSIM_CS_GRIP 20
+#define RSIM_CS_TAU 24
+#define RSIM_CS_SIZE 32
+
+struct DModel {
+  int nq, nv, nu, nbody, njnt, ncg, nsite, npair, maxdepth, nroot;
+  int iterations, ls_iterations, cone, solver;
+  float tolerance, meaninertia;
+  const int* it;
+  const float* ft;
+  const float* mesh_vert;
+  int fstride;
+  int io[IO_COUNT];
+  int fo[FO_COUNT];
+  DCtrl ctrl;
+};
+
+// per-contact record written for the host (floats): dist, pos3, frame9, g1, g2, dim, efc_adr, fn, friction5
+#define RSIM_CON_REC 24
+
+struct DBatch {
+  int B;
+  float *qpos, *qvel, *qacc_ws, *ctrl, *time, *cstate;
+  // compat / debug outputs (may be null)
+  float *xpos, *xquat, *qM, *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_constraint, *qacc, *cdof, *rootcom, *contact, *efc_force;
+  int *ncon, *nefc, *niter, *diverged;
+};
+
+// flags for the step kernel
+enum {
+  RF_POSVEL = 1,     // position + velocity stages (always needed)
+  RF_CTRL = 2,       // run the built-in controller every substep (writes ctrl)
+  RF_SETGOAL = 4,    // first substep: controller.set_goal(action)
+  RF_ACTSOLVE = 8,   // actuation + acceleration + constraint solve
+  RF_INTEGRATE = 16, // Euler integration, advance time, warm start
+  RF_DEBUG = 32,     // write compat/debug arrays
+};

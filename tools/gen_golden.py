@@ -1,0 +1,107 @@
+"""Generate golden fixtures by running the UNMODIFIED reference robosuite (/root/reference) in this
+container.  The reference's physics dependency (`mujoco`) is absent, so its host layers are driven
+through robosuite_amd.shim with the CPU oracle as the arithmetic backend; everything recorded under
+"ctrl_*" is produced by the reference's own controller Python (controllers/parts/arm/osc.py etc.)
+and pins the controller restatements (oracle C and HIP).  Reset-path values (`reset_*`) are produced
+by the reference's own RNG/reset code and are physics independent.
+
+Run:  python tools/gen_golden.py        (writes tests/golden/*.npz, *.rsim, *.json)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from robosuite_amd import mjcf, shim  # noqa: E402
+from oracle.shim_backend import OracleBackend  # noqa: E402
+
+shim.install(OracleBackend)
+import robosuite as suite  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+
+
+def controller_cfg(env):
+    """Extract the index tables / gains the native controller needs from the reference objects."""
+    robot = env.robots[0]
+    osc = robot.part_controllers["right"]
+    grip = robot.part_controllers["right_gripper"]
+    sim = env.sim
+    return dict(
+        qpos_idx=[int(i) for i in osc.qpos_index], dof_idx=[int(i) for i in osc.qvel_index],
+        act_idx=[int(i) for i in robot._ref_actuators_indexes_dict["right"]],
+        eef_site=int(sim.model.site_name2id(osc.ref_name)),
+        base_site=int(sim.model.site_name2id(f"{osc.naming_prefix}{osc.part_name}_center")),
+        kp=[float(x) for x in osc.kp], damping_ratio=1.0,
+        input_min=[float(x) for x in osc.input_min], input_max=[float(x) for x in osc.input_max],
+        output_min=[float(x) for x in osc.output_min], output_max=[float(x) for x in osc.output_max],
+        uncouple=int(osc.uncoupling),
+        grip_act=[int(i) for i in robot._ref_actuators_indexes_dict["right_gripper"]],
+        grip_sign=[-1.0, 1.0], grip_speed=float(robot.gripper["right"].speed),
+        grip_qpos_idx=[int(i) for i in robot._ref_gripper_joint_pos_indexes["right"]],
+        grip_dof_idx=[int(i) for i in robot._ref_gripper_joint_vel_indexes["right"]],
+    )
+
+
+def record_lift(seed, n_steps, action_scale, tag):
+    env = suite.make("Lift", robots="Panda", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False,
+                     use_object_obs=True, reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed)
+    make_qpos = np.array(env.sim.data.qpos)
+    obs = env.reset()
+    flat = env.sim.model._model._flat
+    robot = env.robots[0]
+    osc = robot.part_controllers["right"]
+    rec = {k: [] for k in ("ep", "eR", "ev", "op", "oR", "bv", "goal_pos", "goal_ori", "J", "M", "bias", "q", "qd", "q0", "tau", "ctrl",
+                           "sub_qpos", "sub_qvel")}
+    orig_run = osc.run_controller
+    sim = env.sim
+    base_name = f"{osc.naming_prefix}{osc.part_name}_center"
+
+    def run_and_record():
+        rec["sub_qpos"].append(np.array(sim.data.qpos))
+        rec["sub_qvel"].append(np.array(sim.data.qvel))
+        tau = orig_run()
+        rec["ep"].append(np.array(osc.ref_pos)); rec["eR"].append(np.array(osc.ref_ori_mat))
+        rec["ev"].append(np.concatenate([osc.ref_pos_vel, osc.ref_ori_vel]))
+        rec["op"].append(np.array(osc.origin_pos)); rec["oR"].append(np.array(osc.origin_ori))
+        rec["bv"].append(np.concatenate([sim.data.get_site_xvelp(base_name), sim.data.get_site_xvelr(base_name)]))
+        rec["goal_pos"].append(np.array(osc.goal_pos)); rec["goal_ori"].append(np.array(osc.goal_ori))
+        rec["J"].append(np.array(osc.J_full)); rec["M"].append(np.array(osc.mass_matrix))
+        rec["bias"].append(np.array(osc.torque_compensation)); rec["q"].append(np.array(osc.joint_pos)); rec["qd"].append(np.array(osc.joint_vel))
+        rec["q0"].append(np.array(osc.initial_joint)); rec["tau"].append(np.array(tau))
+        return tau
+
+    osc.run_controller = run_and_record
+    rng = np.random.default_rng(10**6 + seed)
+    actions, states, rewards, obs_flat = [], [env.sim.get_state().flatten()], [], []
+    keys = [k for k in obs.keys()]
+    for t in range(n_steps):
+        a = action_scale * rng.uniform(-1, 1, 7)
+        obs, r, done, info = env.step(a)
+        rec["ctrl"].append(np.array(sim.data.ctrl))
+        actions.append(a); states.append(env.sim.get_state().flatten()); rewards.append(r)
+        obs_flat.append(np.concatenate([np.atleast_1d(obs[k]).astype(np.float64) for k in keys if not k.endswith("-state")]))
+    out = {k: np.array(v) for k, v in rec.items()}
+    out.update(actions=np.array(actions), states=np.array(states), rewards=np.array(rewards), obs=np.array(obs_flat),
+               make_qpos=make_qpos, reset_qpos=states[0][1:1 + flat.nq],
+               cube_size=flat.geom_size[flat.name2id("geom", "cube_g0")])
+    np.savez_compressed(os.path.join(GOLD, f"lift_panda_{tag}.npz"), **out)
+    mjcf.save_model(flat, os.path.join(GOLD, f"lift_panda_{tag}.rsim"))
+    cfg = controller_cfg(env)
+    cfg["obs_keys"] = [k for k in keys if not k.endswith("-state")]
+    cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in cfg["obs_keys"]]
+    with open(os.path.join(GOLD, f"lift_panda_{tag}.cfg.json"), "w") as f:
+        json.dump(cfg, f, indent=1)
+    print(tag, "steps", n_steps, "substeps recorded", len(out["tau"]), "final cube z", states[-1][1 + 11])
+
+
+if __name__ == "__main__":
+    # gentle actions (reference test convention test_action_playback.py:48) and full-range actions
+    record_lift(seed=0, n_steps=40, action_scale=0.1, tag="seed0_gentle")
+    record_lift(seed=1, n_steps=40, action_scale=1.0, tag="seed1_full")
