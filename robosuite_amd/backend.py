@@ -66,6 +66,8 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RsimError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(make -C robosuite_amd/csrc). There is no CPU fallback.")
+        import torch  # noqa: F401  (must come first: librsim_hip.so binds to the HIP runtime torch ships, see csrc/Makefile)
+
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.rsim_last_error.restype = C.c_char_p
