@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the fused control-step hot path on MI355X (BASELINE.json metric).
+
+One "step" = one robosuite `env.step(action)` for every env of the batch = ONE launch of the fused kernel
+(25 physics substeps at dt=0.002 + 25 OSC_POSE/GRIP controller evaluations + set_goal; reference
+environments/base.py:467-521).  Workload at N=1 = BASELINE configs[1]: Lift / Panda / OSC_POSE, 4096 envs on one GPU,
+per-env seeded episodes (cube size, arm noise, cube pose) and per-env action streams.
+N>1: every rank owns 4096 envs of the global index range (weak scaling, no data-path collective; one stats all-reduce
+after the timed region).  Inputs (state, model tables, the whole action tape) are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0.  See DESIGN.md section 6 for the roofline / cpu_baseline definitions.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from robosuite_amd import lift, mjcf, shard  # noqa: E402
+
+ENVS_PER_GPU = 4096
+N_SUB = 25
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def algorithmic_bytes_per_env_step(flat, action_dim):
+    """Compulsory HBM bytes one env-step moves through the fused kernel (fp32 words x 4), DESIGN.md section 6:
+    read  action + qpos + qvel + qacc_warmstart + ctrl + time + controller state + per-env model deltas (cube: size3 rbound1 mass1 inertia3 subtree1 invw2 dofinvw6)
+    write qpos + qvel + qacc_warmstart + ctrl + time + controller state + observation record + reward/done."""
+    from robosuite_amd.backend import CSTATE, OBS_DIM
+    nq, nv, nu = flat.nq, flat.nv, flat.nu
+    rd = action_dim + nq + nv + nv + nu + 1 + CSTATE + 17
+    wr = nq + nv + nv + nu + 1 + CSTATE + OBS_DIM + 2
+    return 4 * (rd + wr)
+
+
+def cpu_baseline(flat, cfg, budget_s=12.0):
+    """The CPU oracle (oracle/rsim_oracle.c: same pipeline, fp64, serial C) timed on this host's cores on a bounded sample of the
+    same workload: `cores` threads (ctypes releases the GIL), each stepping its own seeded Lift env with its own action stream."""
+    import threading
+
+    from oracle.oracle import OracleController, OracleData, OracleModel
+
+    cores = os.cpu_count() or 1
+    counts = [0] * cores
+    stop = time.perf_counter() + budget_s
+
+    def work(k):
+        sizes, qpos = lift.episode_setup(0, [k])
+        f = flat.copy()
+        for field, rows in lift.cube_model_rows(flat, sizes).items():
+            f.arrays[field] = rows[0].reshape(f.arrays[field].shape)
+        om = OracleModel(mjcf.to_blob(f)); od = OracleData(om); oc = OracleController(cfg)
+        od.qpos[:] = qpos[0]; od.qvel[:] = 0; od.qacc_warmstart[:] = 0; od.forward(); oc.reset(od)
+        acts = lift.env_actions([k], 4000)[:, 0].astype(np.float64)
+        n = 0
+        while time.perf_counter() < stop and n < len(acts):
+            oc.env_step(od, acts[n], N_SUB)
+            n += 1
+        counts[k] = n
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dt = time.perf_counter() - t0
+    return {"value": sum(counts) / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{sum(counts)} env.steps of Lift/Panda/OSC_POSE ({cores} envs x ~{sum(counts)//cores} steps, {cores} threads, fp64 C oracle incl. C controllers) in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, world = shard.init_process_group()
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    adir = os.path.join(ROOT, "robosuite_amd", "assets")
+    flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim"))
+    cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
+    B = args.envs_per_gpu
+    ids = shard.env_block(B * world, rank, world)
+    env = lift.LiftBatch(flat, cfg, ids, device=local_rank, seed0=0)
+    K, W = args.steps, args.warmup
+    tape = torch.tensor(lift.env_actions(ids, K + W), device=dev)  # whole action tape resident in HBM
+    stream = torch.cuda.ExternalStream(env.batch.stream(), device=dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for t in range(W):
+        env.step(tape[t])
+    env.batch.sync(); torch.cuda.synchronize(); barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    t0 = time.perf_counter()
+    for t in range(K):
+        ev[t][0].record(stream)
+        env.step(tape[W + t])
+        ev[t][1].record(stream)
+    env.batch.sync(); torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    dt = shard.max_over_ranks(dt, dev)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    st = shard.RolloutStats(dev)
+    q = env.batch.tensor("qpos")
+    st.add(env_steps=B * K, diverged=int((~torch.isfinite(q).all(dim=1)).sum().item()))
+    if hasattr(env, "rollout_totals"):
+        st.add(**env.rollout_totals())
+    tot = st.allreduce()
+
+    if rank == 0:
+        abytes = algorithmic_bytes_per_env_step(flat, env.model.action_dim) * B
+        ach = abytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived bytes per launch, written by tools/pmc_traffic.py
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec (whole node), Lift/Panda/OSC_POSE @4096 envs/GPU", "value": tot["env_steps"] / dt, "unit": "env-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Lift/Panda/OSC_POSE, 25 substeps x dt 0.002 + OSC_POSE/GRIP per substep, fused in one launch (BASELINE configs[1])",
+                       "envs_per_gpu": B, "global_envs": B * world, "n_sub": N_SUB, "per_env_seeded_reset": True, "sharding": f"env-block x{world}",
+                       "diverged_envs": int(tot["diverged"]), "reward_sum": tot["reward_sum"], "successes": int(tot["successes"])},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes,
+                         "note": "latency/VALU/LDS-bound by design (state LDS-resident for 25 substeps); see DESIGN.md section 6"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(flat, cfg)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,6 +101,11 @@ int rsim_control_step(rsim_batch* b, const float* actions_dev, int n_sub);
 int rsim_ctrl_reset(rsim_batch* b, const uint8_t* host_mask);
 int rsim_sync(rsim_batch* b);
 
+/* Per-phase cycle accounting of the fused kernel (no reference counterpart: the reference has no profiling).
+ * enable != 0 (re)arms and zeroes the accumulators, 0 disarms; if `out` is non-NULL the current accumulators are copied out first:
+ * cycles {load kin com crb broad narrow makec vel ctrl act solve euler store} then counts {substeps candidates contacts efc newton ls}. */
+int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, int n_out);
+
 /* zero-copy numpy-view replacement: copy a field to / from HOST float32 (int32 for RSIM_NCON..) buffers of `count` elements */
 int rsim_get_array(rsim_batch* b, int field, void* host_dst, size_t count);
 int rsim_set_array(rsim_batch* b, int field, const void* host_src, size_t count);

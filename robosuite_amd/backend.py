@@ -23,6 +23,7 @@ FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
 INT_FIELDS = {"ncon", "nefc", "niter"}
 CON_REC = 24
 CSTATE = 32
+OBS_DIM = 0  # floats of the per-env observation record the fused kernel writes (0 until the obs epilogue lands)
 
 
 class RsimError(RuntimeError):
@@ -93,6 +94,7 @@ def lib():
         L.rsim_jac_site.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.rsim_jac_body.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.rsim_model_param_set.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_size_t]
+        L.rsim_profile.argtypes = [vp, C.c_int, vp, C.c_int]
         L.rsim_osc_eval.argtypes = [C.POINTER(CtrlDesc), vp, vp, C.c_int, C.c_int]
         _LIB = L
     return _LIB
@@ -216,6 +218,15 @@ class HipBatch:
 
     def stream(self):
         return self._L.rsim_stream(self.ptr)
+
+    PROFILE_SLOTS = ("load", "kin", "com", "crb", "broad", "narrow", "makec", "vel", "ctrl", "act", "solve", "euler", "store",
+                     "n_sub", "n_cand", "n_con", "n_efc", "n_newton", "n_ls")
+
+    def profile(self, enable=True):
+        """Read (then re-arm or disarm) the kernel's per-phase cycle accumulators -> dict."""
+        out = np.zeros(len(self.PROFILE_SLOTS), dtype=np.uint64)
+        _chk(self._L.rsim_profile(self.ptr, int(enable), out.ctypes.data, len(out)))
+        return dict(zip(self.PROFILE_SLOTS, out.tolist()))
 
     def jac_site(self, env, site):
         nv = self.model.flat.nv

@@ -348,6 +348,7 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   hipStreamSynchronize(b->stream);
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
   hipFree(b->d_it); hipFree(b->d_ft); hipFree(b->d_mesh); hipFree(b->d_mask);
+  if (b->db.prof) hipFree(b->db.prof);
   hipStreamDestroy(b->stream);
   delete b;
 }
@@ -419,6 +420,22 @@ extern "C" int rsim_ctrl_reset(rsim_batch* b, const uint8_t* mask) {
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   if (mask) HIPCHK(hipStreamSynchronize(b->stream));
   b->gen++;
+  return 0;
+}
+
+extern "C" int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, int n_out) {
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (out && b->db.prof) {
+    unsigned long long tmp[RP_COUNT];
+    HIPCHK(hipMemcpy(tmp, b->db.prof, sizeof(tmp), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n_out && i < RP_COUNT; i++) out[i] = tmp[i];
+  }
+  if (enable && !b->db.prof) {
+    HIPCHK(hipMalloc((void**)&b->db.prof, RP_COUNT * sizeof(unsigned long long)));
+  }
+  if (enable) HIPCHK(hipMemset(b->db.prof, 0, RP_COUNT * sizeof(unsigned long long)));
+  if (!enable && b->db.prof) { hipFree(b->db.prof); b->db.prof = nullptr; }
   return 0;
 }
 

@@ -76,7 +76,12 @@ struct DBatch {
   // compat / debug outputs (may be null)
   float *xpos, *xquat, *qM, *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_constraint, *qacc, *cdof, *rootcom, *contact, *efc_force;
   int *ncon, *nefc, *niter, *diverged;
+  unsigned long long* prof;  // optional [RP_COUNT] phase-cycle / event accumulators (null = off)
 };
+
+// profile slots (cycles of s_memtime summed over envs and substeps, then event counters)
+enum { RP_LOAD, RP_KIN, RP_COM, RP_CRB, RP_BROAD, RP_NARROW, RP_MAKEC, RP_VEL, RP_CTRL, RP_ACT, RP_SOLVE, RP_EULER, RP_STORE,
+       RP_N_SUB, RP_N_CAND, RP_N_CON, RP_N_EFC, RP_N_NEWTON, RP_N_LS, RP_COUNT };
 
 // flags for the step kernel
 enum {

@@ -51,6 +51,18 @@ __device__ __forceinline__ float bcast(float x, int srclane) {
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ u64 lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
+// optional per-phase cycle accounting (DBatch.prof != null): lane 0 accumulates s_memtime deltas and event counters
+struct Prof {
+  unsigned long long* p;
+  long long t0;
+  int lane;
+  __device__ __forceinline__ void start() { if (p) t0 = clock64(); }
+  __device__ __forceinline__ void mark(int id) {
+    if (p) { long long t1 = clock64(); if (lane == 0) atomicAdd(p + id, (unsigned long long)(t1 - t0)); t0 = clock64(); }
+  }
+  __device__ __forceinline__ void count(int id, int v) { if (p && lane == 0) atomicAdd(p + id, (unsigned long long)v); }
+};
+
 // ------------------------------------------------------------------------------------------------------------
 // small math (float)
 // ------------------------------------------------------------------------------------------------------------
@@ -237,9 +249,10 @@ struct Sim {
   const DModel& m;
   const float* fp;
   int lane;
+  Prof pf;
   static constexpr int NVP = SM::NVP;
 
-  __device__ Sim(SM& s_, const DModel& m_, const float* fp_, int lane_) : s(s_), m(m_), fp(fp_), lane(lane_) {}
+  __device__ Sim(SM& s_, const DModel& m_, const float* fp_, int lane_, unsigned long long* prof) : s(s_), m(m_), fp(fp_), lane(lane_) { pf.p = prof; pf.lane = lane_; pf.t0 = 0; }
 
   __device__ __forceinline__ u64 mask2(int tab, int i) const { return (u64)(uint32_t)IT(tab, 2 * i) | ((u64)(uint32_t)IT(tab, 2 * i + 1) << 32); }
 
@@ -793,6 +806,8 @@ struct Sim {
       ncand += __popcll(mk);
     }
     SYNC();
+    pf.mark(RP_BROAD);
+    pf.count(RP_N_CAND, ncand);
     for (int ci = 0; ci < ncand; ci++) {
       int p = uni(s.cand[ci]);
       int g1 = uni(IT(IO_pair_g1, p)), g2 = uni(IT(IO_pair_g2, p));
@@ -1164,6 +1179,7 @@ struct Sim {
       if (d0 >= 0 || h0 <= 0) break;
       alpha = -d0 / h0;
       for (int ls = 0; ls < m.ls_iterations; ls++) {
+        pf.count(RP_N_LS, 1);
         float c, c1, c2;
         if (lane < nblk) block_ls(lane, alpha, c, c1, c2); else c = c1 = c2 = 0.f;
         p = gauss + alpha * q1 + alpha * alpha * q2 + wave_sum(c);
@@ -1202,6 +1218,7 @@ struct Sim {
       s.qacc[lane] = s.va[lane];
     }
     if (lane == 0) s.niter = iter;
+    pf.count(RP_N_NEWTON, iter);
     SYNC();
   }
 
@@ -1396,7 +1413,8 @@ __global__ __launch_bounds__(64) void k_step(DModel m, DBatch b, const float* __
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= b.B) return;
   const float* fp = m.ft + (size_t)env * m.fstride;
-  Sim<SM> sim(s, m, fp, lane);
+  Sim<SM> sim(s, m, fp, lane, b.prof);
+  sim.pf.start();
   // ---- load state
   for (int i = lane; i < m.nq; i += 64) s.qpos[i] = b.qpos[(size_t)env * m.nq + i];
   for (int i = lane; i < m.nv; i += 64) { s.qvel[i] = b.qvel[(size_t)env * m.nv + i]; s.qacc_ws[i] = b.qacc_ws[(size_t)env * m.nv + i]; }
@@ -1406,25 +1424,39 @@ __global__ __launch_bounds__(64) void k_step(DModel m, DBatch b, const float* __
   SYNC();
   const float* act = actions ? actions + (size_t)env * m.ctrl.action_dim : nullptr;
   float time = b.time[env];
+  sim.pf.mark(RP_LOAD);
   for (int sub = 0; sub < n_sub; sub++) {
     sim.kinematics();
+    sim.pf.mark(RP_KIN);
     sim.com_pos();
+    sim.pf.mark(RP_COM);
     sim.crb();
+    sim.pf.mark(RP_CRB);
     sim.collision();
+    sim.pf.mark(RP_NARROW);
     sim.make_constraint();
+    sim.pf.mark(RP_MAKEC);
     sim.velocity();
+    sim.pf.mark(RP_VEL);
     if (flags & RF_CTRL) {
       if ((flags & RF_SETGOAL) && sub == 0 && act) sim.ctrl_set_goal(act);
       sim.ctrl_run();
+      sim.pf.mark(RP_CTRL);
     }
     if (flags & RF_ACTSOLVE) {
       sim.actuation_acceleration();
+      sim.pf.mark(RP_ACT);
       sim.fwd_constraint();
+      sim.pf.mark(RP_SOLVE);
+      sim.pf.count(RP_N_CON, s.ncon);
+      sim.pf.count(RP_N_EFC, s.nefc);
     }
     if (flags & RF_INTEGRATE) {
       sim.euler();
+      sim.pf.mark(RP_EULER);
       time += fp[m.fo[FO_opt]];
     }
+    sim.pf.count(RP_N_SUB, 1);
   }
   // ---- store state
   for (int i = lane; i < m.nq; i += 64) b.qpos[(size_t)env * m.nq + i] = s.qpos[i];
@@ -1468,7 +1500,7 @@ __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const uns
   if (env >= b.B) return;
   if (mask && !mask[env]) return;
   const float* fp = m.ft + (size_t)env * m.fstride;
-  Sim<SM> sim(s, m, fp, lane);
+  Sim<SM> sim(s, m, fp, lane, nullptr);
   for (int i = lane; i < m.nq; i += 64) s.qpos[i] = b.qpos[(size_t)env * m.nq + i];
   if (lane < RSIM_CS_SIZE) s.cstate[lane] = 0.f;
   SYNC();

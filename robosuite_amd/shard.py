@@ -1,0 +1,81 @@
+"""Environment sharding across the GPUs of one node + the end-of-rollout statistics all-reduce.
+
+Every robosuite environment is an independent world (one MjSim per env object, reference environments/base.py:269), so the path
+shards embarrassingly: rank r owns the contiguous GLOBAL env-index block [r*B/G, (r+1)*B/G); per-env RNG
+streams are keyed by the global index, so results do not depend on G.  The only collective on the path is one all-reduce (sum) of a
+handful of rollout scalars -- RCCL over xGMI on GPUs (backend "nccl"), gloo in the CPU tests.  There is no exchange step inside the
+physics, and none is invented here.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+STAT_FIELDS = ("env_steps", "episodes", "reward_sum", "successes", "diverged")
+
+
+def env_block(n_total: int, rank: int, world: int):
+    """Contiguous block of global env ids owned by `rank` (sizes differ by at most one)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return np.arange(lo, lo + base + (1 if rank < rem else 0), dtype=np.int64)
+
+
+def dist_env():
+    """(rank, local_rank, world) from the torchrun environment; (0, 0, 1) when launched plainly."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_process_group(backend: str | None = None):
+    """Join the job's process group (no-op for world size 1).  backend defaults to nccl (= RCCL) with a GPU, gloo without."""
+    import torch
+    import torch.distributed as dist
+
+    rank, local_rank, world = dist_env()
+    if world == 1 or dist.is_initialized():
+        return rank, local_rank, world
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kwargs = {}
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        kwargs["device_id"] = torch.device("cuda", local_rank)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, local_rank, world
+
+
+class RolloutStats:
+    """Per-rank rollout accumulators; `allreduce()` returns the whole-job totals (float64 on the wire)."""
+
+    def __init__(self, device="cpu"):
+        import torch
+
+        self.t = torch.zeros(len(STAT_FIELDS), dtype=torch.float64, device=device)
+
+    def add(self, **kw):
+        for k, v in kw.items():
+            self.t[STAT_FIELDS.index(k)] += float(v)
+
+    def allreduce(self):
+        import torch.distributed as dist
+
+        t = self.t.clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return dict(zip(STAT_FIELDS, t.tolist()))
+
+
+def max_over_ranks(x: float, device="cpu") -> float:
+    """MAX over ranks of a host scalar (bench timing contract)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(x)
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
