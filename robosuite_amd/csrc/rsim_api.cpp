@@ -211,6 +211,21 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
   pushg(FO_cg_size, "geom_size", 3); pushg(FO_cg_pos, "geom_pos", 3); pushg(FO_cg_quat, "geom_quat", 4); pushg(FO_cg_friction, "geom_friction", 3);
   pushg(FO_cg_solref, "geom_solref", 2); pushg(FO_cg_solimp, "geom_solimp", 5); pushg(FO_cg_solmix, "geom_solmix", 1); pushg(FO_cg_margin, "geom_margin", 1);
   pushg(FO_cg_gap, "geom_gap", 1); pushg(FO_cg_rbound, "geom_rbound", 1); pushg(FO_cg_rcenter, "geom_rcenter", 3);
+  {  // geom-frame bounding boxes of mesh hulls (broadphase OBB test); primitives derive theirs from geom_size in the kernel
+    m->fo[FO_cg_aabb] = (int)ft.size(); m->fcount[FO_cg_aabb] = ncg * 6;
+    const double* mv = m->D("mesh_vert");
+    for (int c = 0; c < ncg; c++) {
+      int g = m->cg[c];
+      double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+      if (m->I("geom_type")[g] == 7) {
+        int did = m->I("geom_dataid")[g], adr = m->I("mesh_vertadr")[did], num = m->I("mesh_vertnum")[did];
+        for (int k = 0; k < 3; k++) { lo[k] = 1e30; hi[k] = -1e30; }
+        for (int v = 0; v < num; v++) for (int k = 0; k < 3; k++) { double x = mv[3 * (size_t)(adr + v) + k]; if (x < lo[k]) lo[k] = x; if (x > hi[k]) hi[k] = x; }
+      }
+      for (int k = 0; k < 3; k++) ft.push_back((float)(0.5 * (lo[k] + hi[k])));
+      for (int k = 0; k < 3; k++) ft.push_back((float)(0.5 * (hi[k] - lo[k]) * 1.000001 + 1e-7));
+    }
+  }
   pushf(FO_site_pos, "site_pos", 3 * m->nsite); pushf(FO_site_quat, "site_quat", 4 * m->nsite);
   pushf(FO_act_gear, "actuator_gear", m->nu); pushf(FO_act_gainprm, "actuator_gainprm", 3 * m->nu); pushf(FO_act_biasprm, "actuator_biasprm", 3 * m->nu);
   pushf(FO_act_ctrlrange, "actuator_ctrlrange", 2 * m->nu); pushf(FO_act_forcerange, "actuator_forcerange", 2 * m->nu);
@@ -318,6 +333,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.ls_iterations = 50; dm.cone = m->I("cone") ? m->I("cone")[0] : 1; dm.solver = 1;
   dm.tolerance = m->D("tolerance") ? (float)m->D("tolerance")[0] : 1e-8f;
   dm.meaninertia = m->meaninertia;
+  dm.nit = (int)m->itab.size(); dm.nft = (int)m->ftab.size();
+  if (dm.nit > RSIM_NIT || dm.nft > RSIM_NFT) { int r = fail("rsim_batch_create: model tables (%d ints, %d floats) exceed the kernel's LDS staging area (%d, %d)", dm.nit, dm.nft, RSIM_NIT, RSIM_NFT); delete b; return r; }
   dm.it = b->d_it; dm.ft = b->d_ft; dm.mesh_vert = b->d_mesh; dm.fstride = b->per_env ? (int)fs : 0;
   memcpy(dm.io, m->io, sizeof(dm.io));
   memcpy(dm.fo, m->fo, sizeof(dm.fo));

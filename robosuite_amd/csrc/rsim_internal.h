@@ -21,13 +21,15 @@ enum {
   FO_jnt_pos, FO_jnt_axis, FO_jnt_range, FO_jnt_margin, FO_jnt_solref, FO_jnt_solimp, FO_qpos0,
   FO_dof_armature, FO_dof_damping, FO_dof_frictionloss, FO_dof_solref, FO_dof_solimp, FO_dof_invweight0,
   FO_cg_size, FO_cg_pos, FO_cg_quat, FO_cg_friction, FO_cg_solref, FO_cg_solimp, FO_cg_solmix, FO_cg_margin, FO_cg_gap,
-  FO_cg_rbound, FO_cg_rcenter,
+  FO_cg_rbound, FO_cg_rcenter, FO_cg_aabb /* mesh geoms: centre3 + half3 of the hull's box in the geom frame */,
   FO_site_pos, FO_site_quat,
   FO_act_gear, FO_act_gainprm, FO_act_biasprm, FO_act_ctrlrange, FO_act_forcerange,
   FO_opt /* timestep, gx,gy,gz, density, viscosity, impratio, windx,windy,windz */,
   FO_COUNT
 };
 
+#define RSIM_NIT 1024   /* LDS capacity for the int table */
+#define RSIM_NFT 1792   /* LDS capacity for the float table */
 #define RSIM_ARM_MAX 8
 #define RSIM_GRIP_MAX 4
 
@@ -62,6 +64,7 @@ struct DModel {
   const float* ft;
   const float* mesh_vert;
   int fstride;
+  int nit, nft;
   int io[IO_COUNT];
   int fo[FO_COUNT];
   DCtrl ctrl;

@@ -153,6 +153,8 @@ __device__ __forceinline__ S6 mul_inert(const float* I, S6 v) {
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 struct Smem {
   static constexpr int NVP = NV + 1;  // padded row stride (bank-conflict-free column access)
+  static constexpr int NV_ = NV;      // register-array extent of per-dof loops (nv <= NV)
+  static constexpr int CD_ = 4;       // largest contact dimension this configuration handles (condim 1, 3, 4)
   float qpos[NV + 8], qvel[NV], qacc[NV], qacc_ws[NV], ctrl[NV];
   float xpos[NB * 3], xquat[NB * 4], xmat[NB * 9], xipos[NB * 3];
   float xanchor[NJ * 3], xaxis[NJ * 3];
@@ -169,9 +171,9 @@ struct Smem {
   // contacts
   float cpos[NCON * 3], cframe[NCON * 9], cdist[NCON], cfri[NCON * 5], csolref[NCON * 2], csolimp[NCON * 5], cmu[NCON], cmargin[NCON];
   int cg1[NCON], cg2[NCON], cdim[NCON], cefc[NCON];
-  float hcone[NCON * 36];
   // constraint rows
-  float J[NEFC * NVP];
+  float J[NEFC * NV];  // row-major, stride NV (= 16): rows are also the MFMA B operand (4 rows per instruction)
+  float W[NEFC * NV];  // Hessian-weighted rows (MFMA A operand)
   float e_pos[NEFC], e_margin[NEFC], e_R[NEFC], e_D[NEFC], e_aref[NEFC], e_fl[NEFC], e_force[NEFC], e_jar[NEFC], e_jv[NEFC], e_K[NEFC], e_B[NEFC], e_imp[NEFC];
   int e_type[NEFC], e_id[NEFC], e_state[NEFC];
   int blk_start[NEFC], blk_dim[NEFC];
@@ -179,10 +181,13 @@ struct Smem {
   float cstate[RSIM_CS_SIZE];
   float scratch[128];
   int ncon, nefc, nblk, niter;
+  // model tables staged once per launch (int: shared topology; float: this env's constants)
+  int tab_i[RSIM_NIT];
+  float tab_f[RSIM_NFT];
 };
 
-#define IT(tab, i) (m.it[m.io[tab] + (i)])
-#define FP(tab, i) (fp[m.fo[tab] + (i)])
+#define IT(tab, i) (s.tab_i[m.io[tab] + (i)])
+#define FP(tab, i) (s.tab_f[m.fo[tab] + (i)])
 
 // ------------------------------------------------------------------------------------------------------------
 // dense Cholesky / solve on an n x n LDS matrix with padded stride NVP, cooperative over the wave
@@ -221,6 +226,45 @@ __device__ __forceinline__ float chol_solve(const float* L, const float* invdiag
   return x;
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Register-resident Cholesky: lane i (< N) owns row i of the SPD matrix in a[0..N); all loops unroll so every index is a
+// compile-time register and every broadcast is a v_readlane.  After the call a[k] = L[i][k] (k <= i), inv[k] = 1 / L[k][k] (uniform).
+template <int N>
+__device__ __forceinline__ void rchol_factor(float (&a)[N], float (&inv)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const float iv = rsqrtf(fmaxf(bcast(a[j], j), FMIN));
+    inv[j] = iv;
+    const float lij = a[j] * iv;
+    a[j] = lij;
+#pragma unroll
+    for (int k = j + 1; k < N; k++) a[k] = fmaf(-lij, bcast(lij, k), a[k]);
+  }
+}
+// x_i in lane i; a = rows of L, at[k] = L[k][i] (column i of L), inv = 1/diag.  Returns (L L^T)^-1 x, component i in lane i.
+template <int N>
+__device__ __forceinline__ float rchol_solve(const float (&a)[N], const float (&at)[N], const float (&inv)[N], float x, int lane) {
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const float xk = bcast(x, k) * inv[k];
+    x = lane == k ? xk : (lane > k ? fmaf(-a[k], xk, x) : x);
+  }
+#pragma unroll
+  for (int k = N - 1; k >= 0; k--) {
+    const float xk = bcast(x, k) * inv[k];
+    x = lane == k ? xk : (lane < k ? fmaf(-at[k], xk, x) : x);
+  }
+  return x;
+}
+template <int N>
+__device__ __forceinline__ float sel(const float (&v)[N], int i) {
+  float r = v[0];
+#pragma unroll
+  for (int k = 1; k < N; k++) r = i == k ? v[k] : r;
+  return r;
+}
+
 // solve SPD N x N system A x = b in registers (N <= 6), evaluated uniformly by every lane
 template <int N>
 __device__ __forceinline__ void spd_solve_small(const float* A, const float* b, float* x) {
@@ -251,6 +295,8 @@ struct Sim {
   int lane;
   Prof pf;
   static constexpr int NVP = SM::NVP;
+  static constexpr int NV16 = SM::NV_;
+  static constexpr int CD = SM::CD_;
 
   __device__ Sim(SM& s_, const DModel& m_, const float* fp_, int lane_, unsigned long long* prof) : s(s_), m(m_), fp(fp_), lane(lane_) { pf.p = prof; pf.lane = lane_; pf.t0 = 0; }
 
@@ -408,7 +454,19 @@ struct Sim {
       s.M[j * NVP + i] = v;
     }
     SYNC();
-    chol_factor<NVP>(s.L, s.invdiag, s.M, nv, lane);
+    {
+      float mr[NV16], minv[NV16];
+      const int rr = lane & (NV16 - 1);
+#pragma unroll
+      for (int k = 0; k < NV16; k++) mr[k] = (rr < nv && k < nv) ? s.M[rr * NVP + k] : (rr == k ? 1.f : 0.f);
+      rchol_factor<NV16>(mr, minv);
+      if (lane < NV16) {
+#pragma unroll
+        for (int k = 0; k < NV16; k++) s.L[lane * NVP + k] = mr[k];
+        s.invdiag[lane] = sel(minv, lane);
+      }
+    }
+    SYNC();
   }
 
   // ---------------------------------------------------------------- velocity stage: cvel, cdof_dot, bias, passive
@@ -781,6 +839,19 @@ struct Sim {
     if (lane == 0) add_contact(-depth, (w1 + w2) * 0.5f, n, g1, g2, margin, gap);
   }
 
+  // oriented bounding box of colliding geom g: world centre o, half extents h along the columns of gmat
+  __device__ __forceinline__ void geom_obb(int g, V3& o, V3& h) const {
+    const int t = IT(IO_cg_type, g);
+    const V3 sz = ld3(&FP(FO_cg_size, 3 * g));
+    V3 lc = v3(0, 0, 0);
+    if (t == G_MESH) { lc = ld3(&FP(FO_cg_aabb, 6 * g)); h = ld3(&FP(FO_cg_aabb, 6 * g + 3)); }
+    else if (t == G_SPHERE) h = v3(sz.x, sz.x, sz.x);
+    else if (t == G_CAPSULE) h = v3(sz.x, sz.x, sz.x + sz.y);
+    else if (t == G_CYLINDER) h = v3(sz.x, sz.x, sz.y);
+    else h = sz;
+    o = ld3(s.gpos + 3 * g) + mv(ldm(s.gmat + 9 * g), lc);
+  }
+
   __device__ void collision() {
     if (lane == 0) s.ncon = 0;
     // broadphase: bounding spheres, order-preserving compaction of candidate pairs
@@ -792,13 +863,33 @@ struct Sim {
         int g1 = IT(IO_pair_g1, p), g2 = IT(IO_pair_g2, p);
         float margin = fmaxf(FP(FO_cg_margin, g1), FP(FO_cg_margin, g2));
         V3 c2 = ld3(s.gcen + 3 * g2);
+        V3 o2, h2;
+        geom_obb(g2, o2, h2);
+        M3 R2 = ldm(s.gmat + 9 * g2);
         if (IT(IO_cg_type, g1) == G_PLANE) {
-          M3 R = ldm(s.gmat + 9 * g1);
-          pass = dot(c2 - ld3(s.gpos + 3 * g1), col(R, 2)) - FP(FO_cg_rbound, g2) <= margin;
+          V3 nrm = col(ldm(s.gmat + 9 * g1), 2);
+          pass = dot(c2 - ld3(s.gpos + 3 * g1), nrm) - FP(FO_cg_rbound, g2) <= margin;
+          // plane vs oriented box of geom 2
+          if (pass) pass = dot(o2 - ld3(s.gpos + 3 * g1), nrm) - (h2.x * fabsf(dot(nrm, col(R2, 0))) + h2.y * fabsf(dot(nrm, col(R2, 1))) + h2.z * fabsf(dot(nrm, col(R2, 2)))) <= margin;
         } else {
           V3 rel = c2 - ld3(s.gcen + 3 * g1);
           float bound = FP(FO_cg_rbound, g1) + FP(FO_cg_rbound, g2) + margin;
           pass = dot(rel, rel) <= bound * bound;
+          if (pass) {
+            // conservative separating-axis test on the 6 face normals of the two oriented bounding boxes
+            V3 o1, h1;
+            geom_obb(g1, o1, h1);
+            M3 R1 = ldm(s.gmat + 9 * g1);
+            M3 C = mtm(R1, R2);  // C[i][j] = A_i . B_j
+            V3 t = o2 - o1, ta = mtv(R1, t), tb = mtv(R2, t);
+            float sepa = fmaxf(fmaxf(fabsf(ta.x) - (h1.x + h2.x * fabsf(C.m[0]) + h2.y * fabsf(C.m[1]) + h2.z * fabsf(C.m[2])),
+                                     fabsf(ta.y) - (h1.y + h2.x * fabsf(C.m[3]) + h2.y * fabsf(C.m[4]) + h2.z * fabsf(C.m[5]))),
+                               fabsf(ta.z) - (h1.z + h2.x * fabsf(C.m[6]) + h2.y * fabsf(C.m[7]) + h2.z * fabsf(C.m[8])));
+            float sepb = fmaxf(fmaxf(fabsf(tb.x) - (h2.x + h1.x * fabsf(C.m[0]) + h1.y * fabsf(C.m[3]) + h1.z * fabsf(C.m[6])),
+                                     fabsf(tb.y) - (h2.y + h1.x * fabsf(C.m[1]) + h1.y * fabsf(C.m[4]) + h1.z * fabsf(C.m[7]))),
+                               fabsf(tb.z) - (h2.z + h1.x * fabsf(C.m[2]) + h1.y * fabsf(C.m[5]) + h1.z * fabsf(C.m[8])));
+            pass = fmaxf(sepa, sepb) <= margin + 1e-6f;
+          }
         }
       }
       u64 mk = __ballot(pass);
@@ -884,13 +975,16 @@ struct Sim {
     const int nv = m.nv;
     constexpr int NEFC = sizeof(s.e_pos) / sizeof(float);
     int nefc = 0, nblk = 0;
+    // zero J (rows >= nefc and columns >= nv feed the matrix cores as padding)
+    for (int e = lane; e < NEFC * NV16; e += 64) s.J[e] = 0.f;
+    SYNC();
     // (1) dof friction loss rows
     {
       bool act = lane < nv && FP(FO_dof_frictionloss, lane) > 0.f;
       u64 mk = __ballot(act);
       if (act) {
         int r = nefc + __popcll(mk & lanemask_lt(lane)), i = lane;
-        for (int k = 0; k < nv; k++) s.J[r * NVP + k] = (k == i) ? 1.f : 0.f;
+        s.J[r * NV16 + i] = 1.f;
         float solref[2] = {FP(FO_dof_solref, 2 * i), FP(FO_dof_solref, 2 * i + 1)}, solimp[5];
         for (int k = 0; k < 5; k++) solimp[k] = FP(FO_dof_solimp, 5 * i + k);
         row_params(r, C_FRICTION_DOF, i, 0, 0, FP(FO_dof_frictionloss, i), solref, solimp, FP(FO_dof_invweight0, i));
@@ -914,7 +1008,7 @@ struct Sim {
       u64 mk = __ballot(act);
       if (act) {
         int r = nefc + __popcll(mk & lanemask_lt(lane)), da = IT(IO_jnt_dofadr, j);
-        for (int k = 0; k < nv; k++) s.J[r * NVP + k] = (k == da) ? (float)(-side) : 0.f;
+        s.J[r * NV16 + da] = (float)(-side);
         float solref[2] = {FP(FO_jnt_solref, 2 * j), FP(FO_jnt_solref, 2 * j + 1)}, solimp[5];
         for (int k = 0; k < 5; k++) solimp[k] = FP(FO_jnt_solimp, 5 * j + k);
         row_params(r, C_LIMIT_JOINT, j, dist, FP(FO_jnt_margin, j), 0, solref, solimp, FP(FO_dof_invweight0, da));
@@ -936,7 +1030,7 @@ struct Sim {
         int k = e / nv, i = e - k * nv;
         V3 ax = ld3(s.cframe + 9 * c + 3 * (k < 3 ? k : k - 3));
         S6 c1 = jac_col(b1, pos, i), c2 = jac_col(b2, pos, i);
-        s.J[(nefc + k) * NVP + i] = (k < 3) ? dot(ax, c2.l - c1.l) : dot(ax, c2.a - c1.a);
+        s.J[(nefc + k) * NV16 + i] = (k < 3) ? dot(ax, c2.l - c1.l) : dot(ax, c2.a - c1.a);
       }
       if (lane < dim) {
         int k = lane;
@@ -963,7 +1057,7 @@ struct Sim {
     for (int r = lane; r < nefc; r += 64) {
       s.e_D[r] = 1.0f / s.e_R[r];
       float v = 0;
-      for (int k = 0; k < nv; k++) v += s.J[r * NVP + k] * s.qvel[k];
+      for (int k = 0; k < nv; k++) v += s.J[r * NV16 + k] * s.qvel[k];
       s.e_aref[r] = -s.e_B[r] * v - s.e_K[r] * s.e_imp[r] * (s.e_pos[r] - s.e_margin[r]);
     }
     if (lane == 0) { s.nefc = nefc; s.nblk = nblk; }
@@ -992,231 +1086,273 @@ struct Sim {
       qs = s.qfrc_passive[d] - s.qfrc_bias[d] + fa;
       s.qfrc_smooth[d] = qs;
     }
-    float as = chol_solve<NVP>(s.L, s.invdiag, qs, nv, lane);
+    float as;
+    {
+      float lr[NV16], lt[NV16], linv[NV16];
+      const int rr = lane & (NV16 - 1);
+#pragma unroll
+      for (int k = 0; k < NV16; k++) { lr[k] = s.L[rr * NVP + k]; lt[k] = s.L[k * NVP + rr]; linv[k] = s.invdiag[k]; }
+      as = rchol_solve<NV16>(lr, lt, linv, lane < nv ? qs : 0.f, lane);
+    }
     if (lane < nv) s.qacc_smooth[lane] = as;
     SYNC();
   }
 
-  // ---------------------------------------------------------------- Newton solver (primal), one lane per constraint block
-  // returns this lane's block cost; writes force/state (and cone Hessian) for its rows
-  __device__ __forceinline__ float block_update(int blk, const float* jar, bool want_h) {
-    int i = s.blk_start[blk], dim = s.blk_dim[blk], type = s.e_type[i];
-    float D = s.e_D[i], R = s.e_R[i], x = jar[i], cost = 0.f;
-    if (type == C_FRICTION_DOF) {
-      float fl = s.e_fl[i];
-      if (x <= -R * fl) { s.e_state[i] = ST_LINEARNEG; s.e_force[i] = fl; cost = fl * (-0.5f * R * fl - x); }
-      else if (x >= R * fl) { s.e_state[i] = ST_LINEARPOS; s.e_force[i] = -fl; cost = fl * (-0.5f * R * fl + x); }
-      else { s.e_state[i] = ST_QUADRATIC; s.e_force[i] = -D * x; cost = 0.5f * D * x * x; }
-    } else if (type != C_CONTACT_ELLIPTIC) {
-      if (x < 0) { s.e_state[i] = ST_QUADRATIC; s.e_force[i] = -D * x; cost = 0.5f * D * x * x; }
-      else { s.e_state[i] = ST_SATISFIED; s.e_force[i] = 0.f; }
+  // ---------------------------------------------------------------- Newton solver (primal): lane r owns constraint row r
+  // Row data (Jacobian row, D, R, aref) live in the owner lane's registers for the whole solve; the dense products
+  // H = M + J^T W and J^T f run on the matrix cores (v_mfma_f32_16x16x4_f32, 4 rows per instruction); the Hessian
+  // factorisation is the register-resident Cholesky above.  Algorithm = oracle solve_newton (MuJoCo's primal Newton).
+  struct Row {
+    float J[NV16];
+    float D, R, aref, fl, mu, fr_own, Dm;
+    float fj[CD - 1];
+    int type, head, kk, dim;
+    bool valid, ell;
+  };
+  __device__ __forceinline__ float row_dot(const Row& rw, float x) const {  // sum_k J[k] * x_k  (x_k lives in lane k)
+    float sv = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV16; k++) sv = fmaf(rw.J[k], bcast(x, k), sv);
+    return sv;
+  }
+  // gather the block's friction-scaled values: out[j] = (x * fr_own) of lane head + j
+  __device__ __forceinline__ void gather(const Row& rw, float x, float (&out)[CD]) const {
+    float u = x * rw.fr_own;
+#pragma unroll
+    for (int j = 0; j < CD; j++) { float t = __shfl(u, rw.head + j); out[j] = (rw.ell && j < rw.dim) ? t : 0.f; }
+  }
+  // force / state / cost of this lane's row at residual jar (siblings of an elliptic block agree on the zone)
+  __device__ __forceinline__ float row_update(const Row& rw, float x, float& force, int& state, float (&uj)[CD], float& T, float& g) const {
+    float cost = 0.f;
+    force = 0.f; state = ST_SATISFIED; T = 0.f; g = 0.f;
+    gather(rw, x, uj);
+    if (!rw.valid) return 0.f;
+    if (rw.type == C_FRICTION_DOF) {
+      if (x <= -rw.R * rw.fl) { state = ST_LINEARNEG; force = rw.fl; cost = rw.fl * (-0.5f * rw.R * rw.fl - x); }
+      else if (x >= rw.R * rw.fl) { state = ST_LINEARPOS; force = -rw.fl; cost = rw.fl * (-0.5f * rw.R * rw.fl + x); }
+      else { state = ST_QUADRATIC; force = -rw.D * x; cost = 0.5f * rw.D * x * x; }
+    } else if (!rw.ell) {
+      if (x < 0) { state = ST_QUADRATIC; force = -rw.D * x; cost = 0.5f * rw.D * x * x; }
     } else {
-      int c = s.e_id[i];
-      const float* fr = s.cfri + 5 * c;
-      float mu = s.cmu[c], U[6], T = 0.f;
-      U[0] = x * mu;
-      for (int j = 1; j < dim; j++) { U[j] = jar[i + j] * fr[j - 1]; T += U[j] * U[j]; }
-      T = sqrtf(T);
-      float N = U[0];
+      float N = uj[0], T2 = 0.f;
+#pragma unroll
+      for (int j = 1; j < CD; j++) T2 = fmaf(uj[j], uj[j], T2);
+      T = sqrtf(T2);
+      const float mu = rw.mu;
       if (N >= mu * T || (T <= 0 && N >= 0)) {
-        for (int j = 0; j < dim; j++) { s.e_force[i + j] = 0.f; s.e_state[i + j] = ST_SATISFIED; }
       } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-        for (int j = 0; j < dim; j++) { float xj = jar[i + j], Dj = s.e_D[i + j]; s.e_force[i + j] = -Dj * xj; s.e_state[i + j] = ST_QUADRATIC; cost += 0.5f * Dj * xj * xj; }
+        state = ST_QUADRATIC; force = -rw.D * x; cost = 0.5f * rw.D * x * x;
       } else {
-        float Dm = D / fmaxf(mu * mu * (1 + mu * mu), 1e-15f), g = N - mu * T;
-        cost = 0.5f * Dm * g * g;
-        float f0 = -Dm * g * mu;
-        s.e_force[i] = f0;
-        for (int j = 1; j < dim; j++) s.e_force[i + j] = -f0 / T * U[j] * fr[j - 1];
-        for (int j = 0; j < dim; j++) s.e_state[i + j] = ST_CONE;
-        if (want_h) {
-          float* Hc = s.hcone + 36 * c;
-          float gr[6];
-          gr[0] = mu;
-          for (int j = 1; j < dim; j++) gr[j] = -mu * U[j] * fr[j - 1] / T;
-          for (int j = 0; j < dim; j++)
-            for (int k = 0; k < dim; k++) {
-              float h = gr[j] * gr[k];
-              if (j > 0 && k > 0) h += -g * mu * fr[j - 1] * fr[k - 1] * ((j == k ? 1.0f / T : 0.0f) - U[j] * U[k] / (T * T * T));
-              Hc[j * 6 + k] = Dm * h;
-            }
-        }
+        g = N - mu * T;
+        float f0 = -rw.Dm * g * mu;
+        state = ST_CONE;
+        if (rw.kk == 0) { force = f0; cost = 0.5f * rw.Dm * g * g; }
+        else force = -f0 / T * (x * rw.fr_own) * rw.fr_own;
       }
     }
     return cost;
   }
-  // value and derivatives of this lane's block along jar + alpha*jv
-  __device__ __forceinline__ void block_ls(int blk, float alpha, float& c, float& c1, float& c2) {
-    int i = s.blk_start[blk], dim = s.blk_dim[blk], type = s.e_type[i];
-    float D = s.e_D[i], R = s.e_R[i], v = s.e_jv[i], x = s.e_jar[i] + alpha * v;
+  // this lane's contribution to the cost and its first two derivatives along jar + alpha * jv
+  __device__ __forceinline__ void row_ls(const Row& rw, float jar, float jv, const float (&g0)[CD], const float (&gv)[CD], float alpha, float& c, float& c1, float& c2) const {
     c = c1 = c2 = 0.f;
-    if (type == C_FRICTION_DOF) {
-      float fl = s.e_fl[i];
-      if (x <= -R * fl) { c = fl * (-0.5f * R * fl - x); c1 = -fl * v; }
-      else if (x >= R * fl) { c = fl * (-0.5f * R * fl + x); c1 = fl * v; }
-      else { c = 0.5f * D * x * x; c1 = D * x * v; c2 = D * v * v; }
-    } else if (type != C_CONTACT_ELLIPTIC) {
-      if (x < 0) { c = 0.5f * D * x * x; c1 = D * x * v; c2 = D * v * v; }
+    if (!rw.valid) return;
+    float x = fmaf(alpha, jv, jar), v = jv;
+    if (rw.type == C_FRICTION_DOF) {
+      if (x <= -rw.R * rw.fl) { c = rw.fl * (-0.5f * rw.R * rw.fl - x); c1 = -rw.fl * v; }
+      else if (x >= rw.R * rw.fl) { c = rw.fl * (-0.5f * rw.R * rw.fl + x); c1 = rw.fl * v; }
+      else { c = 0.5f * rw.D * x * x; c1 = rw.D * x * v; c2 = rw.D * v * v; }
+    } else if (!rw.ell) {
+      if (x < 0) { c = 0.5f * rw.D * x * x; c1 = rw.D * x * v; c2 = rw.D * v * v; }
     } else {
-      int cc = s.e_id[i];
-      const float* fr = s.cfri + 5 * cc;
-      float mu = s.cmu[cc], T = 0.f, UV = 0.f, VV = 0.f;
-      float N = x * mu, V0 = v * mu;
-      for (int j = 1; j < dim; j++) {
-        float Uj = (s.e_jar[i + j] + alpha * s.e_jv[i + j]) * fr[j - 1], Vj = s.e_jv[i + j] * fr[j - 1];
-        T += Uj * Uj; UV += Uj * Vj; VV += Vj * Vj;
-      }
-      T = sqrtf(T);
+      const float mu = rw.mu;
+      float N = fmaf(alpha, gv[0], g0[0]), T2 = 0.f, UV = 0.f, VV = 0.f;
+#pragma unroll
+      for (int j = 1; j < CD; j++) { float U = fmaf(alpha, gv[j], g0[j]); T2 = fmaf(U, U, T2); UV = fmaf(U, gv[j], UV); VV = fmaf(gv[j], gv[j], VV); }
+      float T = sqrtf(T2);
       if (N >= mu * T || (T <= 0 && N >= 0)) {
       } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-        for (int j = 0; j < dim; j++) {
-          float xj = s.e_jar[i + j] + alpha * s.e_jv[i + j], vj = s.e_jv[i + j], Dj = s.e_D[i + j];
-          c += 0.5f * Dj * xj * xj; c1 += Dj * xj * vj; c2 += Dj * vj * vj;
-        }
-      } else {
-        float Dm = D / fmaxf(mu * mu * (1 + mu * mu), 1e-15f), g = N - mu * T;
-        float g1 = V0 - mu * UV / T, g2 = -mu * (VV / T - UV * UV / (T * T * T));
-        c = 0.5f * Dm * g * g; c1 = Dm * g * g1; c2 = Dm * (g1 * g1 + g * g2);
+        c = 0.5f * rw.D * x * x; c1 = rw.D * x * v; c2 = rw.D * v * v;
+      } else if (rw.kk == 0) {
+        float g = N - mu * T, iT = 1.0f / T;
+        float g1 = gv[0] - mu * UV * iT, g2 = -mu * (VV * iT - UV * UV * iT * iT * iT);
+        c = 0.5f * rw.Dm * g * g; c1 = rw.Dm * g * g1; c2 = rw.Dm * (g1 * g1 + g * g2);
       }
     }
   }
+  // out_k (lane k < 16) = sum_r J[r][k] * f_r  on the matrix cores; f_r must already be in s.e_force[0..4*nch)
+  __device__ __forceinline__ float jt_times_force(int nch) {
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s.J[64 * c + lane], s.e_force[4 * c + (lane >> 4)], acc, 0, 0, 0);
+    if ((lane & 15) == 0) { float* o = s.scratch + 4 * (lane >> 4); o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; }
+    SYNC();
+    float r = s.scratch[lane & 15];
+    SYNC();
+    return r;
+  }
 
   __device__ void solve_newton() {
-    const int nv = m.nv, n = s.nefc, nblk = s.nblk;
+    const int nv = m.nv, n = s.nefc;
+    const int nch = (n + 3) >> 2;
     const float scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
     const float tolerance = m.tolerance;
-    // ---- warm start: previous acceleration unless the unconstrained one is cheaper
-    float cost_ws, cost_sm;
-    for (int r = lane; r < n; r += 64) { float sv = 0; for (int k = 0; k < nv; k++) sv += s.J[r * NVP + k] * s.qacc_smooth[k]; s.e_jar[r] = sv - s.e_aref[r]; }
-    SYNC();
-    cost_sm = wave_sum(lane < nblk ? block_update(lane, s.e_jar, false) : 0.f);
-    SYNC();
-    for (int r = lane; r < n; r += 64) { float sv = 0; for (int k = 0; k < nv; k++) sv += s.J[r * NVP + k] * s.qacc_ws[k]; s.e_jar[r] = sv - s.e_aref[r]; }
-    SYNC();
-    cost_ws = wave_sum(lane < nblk ? block_update(lane, s.e_jar, false) : 0.f);
+    // ---- per-lane row registers
+    Row rw;
+    rw.valid = lane < n;
     {
-      float g = 0.f;
-      if (lane < nv) {
-        float sv = 0;
-        for (int k = 0; k < nv; k++) sv += s.M[lane * NVP + k] * (s.qacc_ws[k] - s.qacc_smooth[k]);
-        g = 0.5f * sv * (s.qacc_ws[lane] - s.qacc_smooth[lane]);
-      }
-      cost_ws += wave_sum(g);
+      const int r = rw.valid ? lane : 0;
+#pragma unroll
+      for (int k = 0; k < NV16; k++) rw.J[k] = rw.valid ? s.J[r * NV16 + k] : 0.f;
+      rw.D = s.e_D[r]; rw.R = s.e_R[r]; rw.aref = rw.valid ? s.e_aref[r] : 0.f; rw.fl = s.e_fl[r]; rw.type = rw.valid ? s.e_type[r] : -1;
+      rw.ell = rw.type == C_CONTACT_ELLIPTIC;
+      const int c = rw.ell ? s.e_id[r] : 0;
+      rw.head = rw.ell ? s.cefc[c] : lane; rw.kk = lane - rw.head; rw.dim = rw.ell ? s.cdim[c] : 1;
+      rw.mu = s.cmu[c];
+#pragma unroll
+      for (int j = 0; j < CD - 1; j++) rw.fj[j] = s.cfri[5 * c + j];
+      rw.fr_own = rw.kk == 0 ? rw.mu : s.cfri[5 * c + (rw.ell ? rw.kk - 1 : 0)];
+      rw.Dm = s.e_D[rw.ell ? rw.head : r] / fmaxf(rw.mu * rw.mu * (1 + rw.mu * rw.mu), 1e-15f);
     }
-    SYNC();
-    if (lane < nv) s.va[lane] = cost_ws < cost_sm ? s.qacc_ws[lane] : s.qacc_smooth[lane];
-    SYNC();
+    // M: row i in lane i (matrix-vector products) and in the MFMA accumulator layout (Hessian seed)
+    float Mr[NV16];
+#pragma unroll
+    for (int k = 0; k < NV16; k++) Mr[k] = (lane < nv && k < nv) ? s.M[lane * NVP + k] : 0.f;
+    v4f Macc;
+#pragma unroll
+    for (int v = 0; v < 4; v++) { int i = 4 * (lane >> 4) + v, j = lane & 15; Macc[v] = (i < nv && j < nv) ? s.M[i * NVP + j] : (i == j ? 1.f : 0.f); }
+    const float a_sm = lane < nv ? s.qacc_smooth[lane] : 0.f, a_ws = lane < nv ? s.qacc_ws[lane] : 0.f, f_sm = lane < nv ? s.qfrc_smooth[lane] : 0.f;
+    float force; int state; float uj[CD], T, g;
+    // ---- warm start: previous acceleration unless the unconstrained one is cheaper
+    float cost_sm = wave_sum(row_update(rw, row_dot(rw, a_sm) - rw.aref, force, state, uj, T, g));
+    float cost_ws = wave_sum(row_update(rw, row_dot(rw, a_ws) - rw.aref, force, state, uj, T, g));
+    {
+      float dws = a_ws - a_sm, sv = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV16; k++) sv = fmaf(Mr[k], bcast(dws, k), sv);
+      cost_ws += wave_sum(0.5f * sv * dws);
+    }
+    float a = cost_ws < cost_sm ? a_ws : a_sm;
     int iter = 0;
+    float jar = 0.f;
     for (;;) {
-      // state at the current point
-      for (int r = lane; r < n; r += 64) { float sv = 0; for (int k = 0; k < nv; k++) sv += s.J[r * NVP + k] * s.va[k]; s.e_jar[r] = sv - s.e_aref[r]; }
-      SYNC();
-      float cost = wave_sum(lane < nblk ? block_update(lane, s.e_jar, true) : 0.f);
-      float ma = 0.f, gs = 0.f;
-      if (lane < nv) {
-        for (int k = 0; k < nv; k++) ma += s.M[lane * NVP + k] * s.va[k];
-        s.vMa[lane] = ma;
-        gs = 0.5f * (ma - s.qfrc_smooth[lane]) * (s.va[lane] - s.qacc_smooth[lane]);
-      }
-      float gauss = wave_sum(gs);
+      jar = row_dot(rw, a) - rw.aref;
+      float cost = wave_sum(row_update(rw, jar, force, state, uj, T, g));
+      float ma = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV16; k++) ma = fmaf(Mr[k], bcast(a, k), ma);
+      const float gauss = wave_sum(0.5f * (ma - f_sm) * (a - a_sm));
       cost += gauss;
+      s.e_force[lane] = force;
       SYNC();
-      float gk = 0.f;
-      if (lane < nv) {
-        gk = ma - s.qfrc_smooth[lane];
-        for (int i = 0; i < n; i++) gk -= s.J[i * NVP + lane] * s.e_force[i];
-        s.vgrad[lane] = gk;
-      }
-      float gn = wave_sum(gk * gk);
+      const float jf = jt_times_force(nch);
+      float gk = lane < nv ? ma - f_sm - jf : 0.f;
+      const float gn = wave_sum(gk * gk);
       if (iter >= m.iterations || scale * sqrtf(gn) < tolerance) break;
-      // Hessian H = M + J' D J (quadratic rows) + cone blocks
-      for (int e = lane; e < nv * nv; e += 64) {
-        int r = e / nv, c = e - r * nv;
-        if (c > r) continue;
-        float h = s.M[r * NVP + c];
-        for (int i = 0; i < n; i++) {
-          int st = s.e_state[i];
-          if (st == ST_QUADRATIC) h += s.e_D[i] * s.J[i * NVP + r] * s.J[i * NVP + c];
-          else if (st == ST_CONE) {
-            int cc = s.e_id[i], dim = s.cdim[cc];
-            const float* hc = s.hcone + 36 * cc;
-            for (int j = 0; j < dim; j++) {
-              float jr = s.J[(i + j) * NVP + r];
-              if (jr == 0.f) continue;
-              for (int k = 0; k < dim; k++) h += hc[j * 6 + k] * jr * s.J[(i + k) * NVP + c];
+      // ---- Hessian weights W (row r): D J_r (quadratic), 0 (linear / satisfied), cone block Hc J_block
+      {
+        float w[NV16];
+        const float dq = state == ST_QUADRATIC ? rw.D : 0.f;
+#pragma unroll
+        for (int k = 0; k < NV16; k++) w[k] = dq * rw.J[k];
+        if (state == ST_CONE) {
+          const float mu = rw.mu, iT = 1.0f / T;
+          const float uo = jar * rw.fr_own;  // own friction-scaled residual U_kk
+          const float grj = rw.kk == 0 ? mu : -mu * uo * rw.fr_own * iT;
+#pragma unroll
+          for (int k2 = 0; k2 < CD; k2++) {
+            if (k2 < rw.dim) {
+              const float frk = k2 == 0 ? mu : rw.fj[k2 > 0 ? k2 - 1 : 0];
+              const float grk = k2 == 0 ? mu : -mu * uj[k2] * frk * iT;
+              float h = grj * grk;
+              if (rw.kk > 0 && k2 > 0) h += -g * mu * rw.fr_own * frk * ((rw.kk == k2 ? iT : 0.f) - uo * uj[k2] * iT * iT * iT);
+              h *= rw.Dm;
+              const float* Js = s.J + (rw.head + k2) * NV16;
+#pragma unroll
+              for (int k = 0; k < NV16; k++) w[k] = fmaf(h, Js[k], w[k]);
             }
-            i += dim - 1;
           }
         }
-        s.H[r * NVP + c] = h;
-        s.H[c * NVP + r] = h;
+#pragma unroll
+        for (int k = 0; k < NV16; k++) s.W[lane * NV16 + k] = w[k];
       }
       SYNC();
-      chol_factor<NVP>(s.Lh, s.invdiag_h, s.H, nv, lane);
-      float sk = chol_solve<NVP>(s.Lh, s.invdiag_h, lane < nv ? -gk : 0.f, nv, lane);
-      if (lane < nv) s.vsearch[lane] = sk;
+      v4f acc = Macc;
+      for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s.W[64 * c + lane], s.J[64 * c + lane], acc, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < 4; v++) s.H[(4 * (lane >> 4) + v) * NVP + (lane & 15)] = acc[v];
       SYNC();
-      // line search set-up
-      for (int r = lane; r < n; r += 64) { float sv = 0; for (int k = 0; k < nv; k++) sv += s.J[r * NVP + k] * s.vsearch[k]; s.e_jv[r] = sv; }
-      float q1 = 0.f, q2 = 0.f, sn = 0.f;
-      if (lane < nv) {
-        float mvv = 0;
-        for (int k = 0; k < nv; k++) mvv += s.M[lane * NVP + k] * s.vsearch[k];
-        q1 = sk * (ma - s.qfrc_smooth[lane]);
-        q2 = 0.5f * sk * mvv;
-        sn = sk * sk;
+      float sk;
+      {
+        float hr[NV16], hinv[NV16], ht[NV16];
+        const int rr = lane & 15;
+#pragma unroll
+        for (int k = 0; k < NV16; k++) hr[k] = s.H[rr * NVP + k];
+        rchol_factor<NV16>(hr, hinv);
+        SYNC();
+        if (lane < NV16) {
+#pragma unroll
+          for (int k = 0; k < NV16; k++) s.H[lane * NVP + k] = hr[k];
+        }
+        SYNC();
+#pragma unroll
+        for (int k = 0; k < NV16; k++) ht[k] = s.H[k * NVP + rr];
+        sk = rchol_solve<NV16>(hr, ht, hinv, lane < nv ? -gk : 0.f, lane);
+        if (lane >= nv) sk = 0.f;
       }
-      q1 = wave_sum(q1); q2 = wave_sum(q2); sn = sqrtf(wave_sum(sn));
-      SYNC();
+      // ---- line search along sk
+      const float jv = row_dot(rw, sk);
+      float mvv = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV16; k++) mvv = fmaf(Mr[k], bcast(sk, k), mvv);
+      const float q1 = wave_sum(sk * (ma - f_sm)), q2 = wave_sum(0.5f * sk * mvv), sn = sqrtf(wave_sum(sk * sk));
       if (sn < 1e-15f) break;
+      float g0[CD], gvv[CD];
+      gather(rw, jar, g0);
+      gather(rw, jv, gvv);
       const float gtol = tolerance * 0.01f * sn / scale;
       float p0, d0, h0, p, dp, hp, lo = 0.f, hi = -1.f, alpha;
       {
         float c, c1, c2;
-        if (lane < nblk) block_ls(lane, 0.f, c, c1, c2); else c = c1 = c2 = 0.f;
+        row_ls(rw, jar, jv, g0, gvv, 0.f, c, c1, c2);
         p0 = gauss + wave_sum(c); d0 = q1 + wave_sum(c1); h0 = 2 * q2 + wave_sum(c2);
       }
       if (d0 >= 0 || h0 <= 0) break;
       alpha = -d0 / h0;
+      // fp32 line search: stop when the directional derivative has dropped below MuJoCo's gtol, by 1e6 relative to its
+      // start value (single-precision noise floor), or when the safeguarded Newton update no longer moves alpha
+      const float dtol = fmaxf(gtol, 1e-6f * fabsf(d0));
       for (int ls = 0; ls < m.ls_iterations; ls++) {
         pf.count(RP_N_LS, 1);
         float c, c1, c2;
-        if (lane < nblk) block_ls(lane, alpha, c, c1, c2); else c = c1 = c2 = 0.f;
+        row_ls(rw, jar, jv, g0, gvv, alpha, c, c1, c2);
         p = gauss + alpha * q1 + alpha * alpha * q2 + wave_sum(c);
         dp = q1 + 2 * alpha * q2 + wave_sum(c1);
         hp = 2 * q2 + wave_sum(c2);
-        if (fabsf(dp) < gtol) break;
+        if (fabsf(dp) < dtol) break;
         if (dp < 0) lo = alpha; else hi = alpha;
         float next = hp > 0 ? alpha - dp / hp : -1.f;
         if (hi < 0) { if (next <= lo) next = 2 * alpha + 1e-12f; }
         else if (next <= lo || next >= hi) next = 0.5f * (lo + hi);
-        if (next == alpha) break;
+        if (fabsf(next - alpha) <= 1e-6f * fabsf(alpha)) { alpha = next; break; }
         alpha = next;
       }
       {
         float c, c1, c2;
-        if (lane < nblk) block_ls(lane, alpha, c, c1, c2); else c = c1 = c2 = 0.f;
+        row_ls(rw, jar, jv, g0, gvv, alpha, c, c1, c2);
         p = gauss + alpha * q1 + alpha * alpha * q2 + wave_sum(c);
       }
       if (!(p < p0)) break;
-      if (lane < nv) s.va[lane] += alpha * sk;
+      a = fmaf(alpha, sk, a);
       iter++;
-      SYNC();
       if (scale * (p0 - p) < tolerance) {
-        for (int r = lane; r < n; r += 64) { float sv = 0; for (int k = 0; k < nv; k++) sv += s.J[r * NVP + k] * s.va[k]; s.e_jar[r] = sv - s.e_aref[r]; }
-        SYNC();
-        if (lane < nblk) block_update(lane, s.e_jar, false);
-        SYNC();
+        jar = row_dot(rw, a) - rw.aref;
+        row_update(rw, jar, force, state, uj, T, g);
         break;
       }
     }
+    s.e_force[lane] = force;
     SYNC();
-    if (lane < nv) {
-      float sv = 0;
-      for (int i = 0; i < n; i++) sv += s.J[i * NVP + lane] * s.e_force[i];
-      s.qfrc_constraint[lane] = sv;
-      s.qacc[lane] = s.va[lane];
-    }
+    const float fc = jt_times_force(nch);
+    if (lane < nv) { s.qfrc_constraint[lane] = fc; s.qacc[lane] = a; }
     if (lane == 0) s.niter = iter;
     pf.count(RP_N_NEWTON, iter);
     SYNC();
@@ -1236,13 +1372,23 @@ struct Sim {
   __device__ void euler() {
     const int nv = m.nv;
     const float h = FP(FO_opt, 0);
-    for (int e = lane; e < nv * nv; e += 64) {
-      int i = e / nv, j = e - i * nv;
-      s.H[i * NVP + j] = s.M[i * NVP + j] + (i == j ? h * FP(FO_dof_damping, i) : 0.f);
+    float qa;
+    {
+      float hr[NV16], hinv[NV16], ht[NV16];
+      const int rr = lane & (NV16 - 1);
+      const float hd = rr < nv ? h * FP(FO_dof_damping, rr) : 0.f;
+#pragma unroll
+      for (int k = 0; k < NV16; k++) hr[k] = (rr < nv && k < nv) ? s.M[rr * NVP + k] + (rr == k ? hd : 0.f) : (rr == k ? 1.f : 0.f);
+      rchol_factor<NV16>(hr, hinv);
+      if (lane < NV16) {
+#pragma unroll
+        for (int k = 0; k < NV16; k++) s.H[lane * NVP + k] = hr[k];
+      }
+      SYNC();
+#pragma unroll
+      for (int k = 0; k < NV16; k++) ht[k] = s.H[k * NVP + rr];
+      qa = rchol_solve<NV16>(hr, ht, hinv, lane < nv ? s.qfrc_smooth[lane] + s.qfrc_constraint[lane] : 0.f, lane);
     }
-    SYNC();
-    chol_factor<NVP>(s.Lh, s.invdiag_h, s.H, nv, lane);
-    float qa = chol_solve<NVP>(s.Lh, s.invdiag_h, lane < nv ? s.qfrc_smooth[lane] + s.qfrc_constraint[lane] : 0.f, nv, lane);
     if (lane < nv) { s.qvel[lane] += h * qa; s.qacc_ws[lane] = s.qacc[lane]; }
     SYNC();
     if (lane < m.njnt) {
@@ -1415,6 +1561,8 @@ __global__ __launch_bounds__(64) void k_step(DModel m, DBatch b, const float* __
   const float* fp = m.ft + (size_t)env * m.fstride;
   Sim<SM> sim(s, m, fp, lane, b.prof);
   sim.pf.start();
+  for (int i = lane; i < m.nit; i += 64) s.tab_i[i] = m.it[i];
+  for (int i = lane; i < m.nft; i += 64) s.tab_f[i] = fp[i];
   // ---- load state
   for (int i = lane; i < m.nq; i += 64) s.qpos[i] = b.qpos[(size_t)env * m.nq + i];
   for (int i = lane; i < m.nv; i += 64) { s.qvel[i] = b.qvel[(size_t)env * m.nv + i]; s.qacc_ws[i] = b.qacc_ws[(size_t)env * m.nv + i]; }
@@ -1454,7 +1602,7 @@ __global__ __launch_bounds__(64) void k_step(DModel m, DBatch b, const float* __
     if (flags & RF_INTEGRATE) {
       sim.euler();
       sim.pf.mark(RP_EULER);
-      time += fp[m.fo[FO_opt]];
+      time += s.tab_f[m.fo[FO_opt]];
     }
     sim.pf.count(RP_N_SUB, 1);
   }
@@ -1501,6 +1649,8 @@ __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const uns
   if (mask && !mask[env]) return;
   const float* fp = m.ft + (size_t)env * m.fstride;
   Sim<SM> sim(s, m, fp, lane, nullptr);
+  for (int i = lane; i < m.nit; i += 64) s.tab_i[i] = m.it[i];
+  for (int i = lane; i < m.nft; i += 64) s.tab_f[i] = fp[i];
   for (int i = lane; i < m.nq; i += 64) s.qpos[i] = b.qpos[(size_t)env * m.nq + i];
   if (lane < RSIM_CS_SIZE) s.cstate[lane] = 0.f;
   SYNC();
