@@ -50,6 +50,8 @@ struct rsim_model {
   int io[IO_COUNT], fo[FO_COUNT], fcount[FO_COUNT];
   int maxdepth, nroot;
   std::vector<u64> body_dofmask;
+  std::vector<int> lanetab;   // [LT_COUNT][64]
+  int kin_rounds, ndynroot, dynroot[RSIM_MAXDYNROOT], maxcondim, multijoint;
   DCtrl ctrl;
   float meaninertia;
   const int* I(const char* n) const { auto it = f.find(n); return it == f.end() ? nullptr : (const int*)it->second.ptr; }
@@ -62,6 +64,7 @@ struct rsim_batch {
   int B, device, per_env;
   hipStream_t stream;
   int* d_it;
+  int* d_lt;
   float* d_ft;
   float* d_mesh;
   unsigned char* d_mask;
@@ -155,6 +158,77 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
     dcv[i] = mk;
   }
   m->body_dofmask = bdm;
+  // ---- lane table: per-lane packed constants of the fused kernel (rsim_internal.h LT_*)
+  {
+    m->lanetab.assign((size_t)LT_COUNT * 64, 0);
+    auto LT = [&](int row, int lane) -> int& { return m->lanetab[(size_t)row * 64 + lane]; };
+    m->multijoint = 0;
+    for (int b = 0; b < nb && b < 64; b++) {
+      int p0 = parent[b];
+      auto jump = [&](int x, int times) { for (int t = 0; t < times; t++) x = parent[x]; return x; };
+      int pr[5];
+      for (int r = 0; r < 5; r++) pr[r] = jump(b, 1 << r);
+      (void)p0;
+      LT(LT_part, b) = pr[0] | (pr[1] << 8) | (pr[2] << 16) | (pr[3] << 24);
+      LT(LT_part4, b) = pr[4];
+      int jt = 15, qa = 0, da = 0;
+      if (jnum[b] >= 1) { jt = jtype[jadr[b]]; qa = m->I("jnt_qposadr")[jadr[b]]; da = jdof[jadr[b]]; }
+      if (jnum[b] > 1) m->multijoint = 1;
+      LT(LT_binfo, b) = jt | (qa << 4) | (da << 12) | (m->I("body_rootid")[b] << 20) | (moving[b] << 28);
+      LT(LT_bdofs, b) = (int)(uint32_t)bdm[b];
+    }
+    for (int i = 0; i < nv && i < 64; i++) {
+      int j = dofjnt[i], t = jtype[j];
+      int lim = (t == 2 || t == 3) ? m->I("jnt_limited")[j] : 0;
+      LT(LT_dinfo, i) = dofbody[i] | (zerodot[i] << 8) | (lim << 9) | (m->I("jnt_qposadr")[j] << 10) | (j << 18) | (t << 26);
+    }
+    for (int c = 0; c < ncg && c < 64; c++) LT(LT_ginfo, c) = m->I("geom_bodyid")[m->cg[c]] | (m->I("geom_type")[m->cg[c]] << 8);
+    for (int k = 0; k < m->nsite && k < 64; k++) LT(LT_sinfo, k) = m->I("site_bodyid")[k];
+    for (int a = 0; a < m->nu && a < 64; a++) {
+      int j = m->I("actuator_trnid")[a];
+      LT(LT_ainfo, a) = jdof[j] | (m->I("jnt_qposadr")[j] << 8) | (m->I("actuator_biastype")[a] << 16) | (m->I("actuator_ctrllimited")[a] << 18) |
+                        (m->I("actuator_forcelimited")[a] << 19);
+    }
+    for (int p2 = 0; p2 < m->npair && p2 < 192; p2++)
+      LT(LT_pair0 + p2 / 64, p2 % 64) = m->geom2cg[m->I("pair_geom1")[p2]] | (m->geom2cg[m->I("pair_geom2")[p2]] << 8) | (1 << 16);
+    for (int l = 0; l < 64; l++) {
+      unsigned bits = 0;
+      const int q = l / 16, r = l % 16;
+      for (int c = 0; c < 8; c++) {  // sub[c]: body d = 4c+q in subtree(body(dof r))
+        int d = 4 * c + q;
+        if (r < nv && d < nb && ((anc[d] >> dofbody[r]) & 1ull)) bits |= 1u << c;
+      }
+      for (int rb = 0; rb < 2; rb++)
+        for (int c = 0; c < 4; c++) {  // bodydof[rb][c]: dof k = 4c+q moves body 16rb+r
+          int k = 4 * c + q, b = 16 * rb + r;
+          if (k < nv && b < nb && ((bdm[b] >> k) & 1ull)) bits |= 1u << (8 + 4 * rb + c);
+        }
+      for (int c = 0; c < 4; c++) {  // dcv[c]: dof k = 4c+q precedes dof r in the velocity recursion
+        int k = 4 * c + q;
+        if (k < nv && r < nv && ((dcv[r] >> k) & 1ull)) bits |= 1u << (16 + c);
+      }
+      for (int v = 0; v < 4; v++) {  // M(i = 4q+v, j = r): m1 = j ancestor-or-self of i, m2 = i strict ancestor of j
+        int i = 4 * q + v, j = r;
+        if (i < nv && j < nv) {
+          if ((danc[i] >> j) & 1ull) bits |= 1u << (20 + v);
+          if (i != j && ((danc[j] >> i) & 1ull)) bits |= 1u << (24 + v);
+        }
+      }
+      LT(LT_mfbits, l) = (int)bits;
+    }
+    int md = m->maxdepth > 1 ? m->maxdepth : 1;
+    m->kin_rounds = 0;
+    while ((1 << m->kin_rounds) < md) m->kin_rounds++;
+    m->ndynroot = 0;
+    for (int b = 1; b < nb; b++) {
+      if (parent[b] != 0) continue;
+      bool dyn = false;
+      for (int i = 0; i < nv; i++) if (m->I("body_rootid")[dofbody[i]] == b) dyn = true;
+      if (dyn) { if (m->ndynroot < RSIM_MAXDYNROOT) m->dynroot[m->ndynroot] = b; m->ndynroot++; }
+    }
+    m->maxcondim = 1;
+    for (int c = 0; c < ncg; c++) if (m->I("geom_condim")[m->cg[c]] > m->maxcondim) m->maxcondim = m->I("geom_condim")[m->cg[c]];
+  }
   // ---- int table
   auto& it = m->itab;
   auto push = [&](int id, const std::vector<int>& v) { m->io[id] = (int)it.size(); it.insert(it.end(), v.begin(), v.end()); };
@@ -333,8 +407,14 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.ls_iterations = 50; dm.cone = m->I("cone") ? m->I("cone")[0] : 1; dm.solver = 1;
   dm.tolerance = m->D("tolerance") ? (float)m->D("tolerance")[0] : 1e-8f;
   dm.meaninertia = m->meaninertia;
-  dm.nit = (int)m->itab.size(); dm.nft = (int)m->ftab.size();
-  if (dm.nit > RSIM_NIT || dm.nft > RSIM_NFT) { int r = fail("rsim_batch_create: model tables (%d ints, %d floats) exceed the kernel's LDS staging area (%d, %d)", dm.nit, dm.nft, RSIM_NIT, RSIM_NFT); delete b; return r; }
+  if (m->multijoint) { int r = fail("rsim_batch_create: bodies with more than one joint are not supported by the fused kernel"); delete b; return r; }
+  if (m->ndynroot > RSIM_MAXDYNROOT) { int r = fail("rsim_batch_create: %d articulated trees (max %d)", m->ndynroot, RSIM_MAXDYNROOT); delete b; return r; }
+  if (m->maxcondim > 4) { int r = fail("rsim_batch_create: condim %d contacts are not supported by the compiled kernel configuration (max 4)", m->maxcondim); delete b; return r; }
+  for (int j = 0; j < m->njnt; j++) if (m->I("jnt_type")[j] == 1) { int r = fail("rsim_batch_create: ball joints are not supported by the fused kernel"); delete b; return r; }
+  if (dalloc(&b->d_lt, m->lanetab.size())) return 1;
+  HIPCHK(hipMemcpy(b->d_lt, m->lanetab.data(), m->lanetab.size() * sizeof(int), hipMemcpyHostToDevice));
+  dm.lt = b->d_lt; dm.kin_rounds = m->kin_rounds; dm.ndynroot = m->ndynroot; dm.maxcondim = m->maxcondim;
+  for (int r = 0; r < RSIM_MAXDYNROOT; r++) dm.dynroot[r] = r < m->ndynroot ? m->dynroot[r] : 0;
   dm.it = b->d_it; dm.ft = b->d_ft; dm.mesh_vert = b->d_mesh; dm.fstride = b->per_env ? (int)fs : 0;
   memcpy(dm.io, m->io, sizeof(dm.io));
   memcpy(dm.fo, m->fo, sizeof(dm.fo));
@@ -364,7 +444,7 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   hipSetDevice(b->device);
   hipStreamSynchronize(b->stream);
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
-  hipFree(b->d_it); hipFree(b->d_ft); hipFree(b->d_mesh); hipFree(b->d_mask);
+  hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_mesh); hipFree(b->d_mask);
   if (b->db.prof) hipFree(b->db.prof);
   hipStreamDestroy(b->stream);
   delete b;

@@ -28,8 +28,21 @@ enum {
   FO_COUNT
 };
 
-#define RSIM_NIT 1024   /* LDS capacity for the int table */
-#define RSIM_NFT 1792   /* LDS capacity for the float table */
+// ---- per-lane packed int constants ("lane table", 64 ints per row): what lane l needs in each of its roles --------------
+enum {
+  LT_part,   /* body b = lane: pointer-jump partners of kinematics rounds 0..3 (8 bits each) */
+  LT_part4,  /* round-4 partner (trees deeper than 16) */
+  LT_binfo,  /* body: jtype(4b, 15 = no joint) | qposadr<<4 | dofadr<<12 | rootid<<20 | moving<<28 */
+  LT_bdofs,  /* body: bit k set if dof k moves the body */
+  LT_dinfo,  /* dof i = lane: body | zerodot<<8 | limited<<9 | qposadr<<10 | jntid<<18 | jtype<<26 */
+  LT_ginfo,  /* colliding geom g = lane: body | type<<8 */
+  LT_sinfo,  /* site k = lane: body */
+  LT_ainfo,  /* actuator a = lane: dof | qposadr<<8 | biastype<<16 | ctrllimited<<18 | forcelimited<<19 */
+  LT_pair0, LT_pair1, LT_pair2, /* candidate pair p = lane + 64 t: g1 | g2<<8 | valid<<16 */
+  LT_mfbits, /* 0/1 operands of the tree-incidence MFMAs: sub[8] | bodydof[2][4] | dcv[4] | m1[4] | m2[4] */
+  LT_COUNT
+};
+#define RSIM_MAXDYNROOT 4
 #define RSIM_ARM_MAX 8
 #define RSIM_GRIP_MAX 4
 
@@ -64,7 +77,10 @@ struct DModel {
   const float* ft;
   const float* mesh_vert;
   int fstride;
-  int nit, nft;
+  const int* lt;            // lane table [LT_COUNT][64]
+  int kin_rounds;           // pointer-jumping rounds = ceil(log2(maxdepth))
+  int ndynroot, dynroot[RSIM_MAXDYNROOT];  // tree roots that carry dofs (subtree COM needed)
+  int maxcondim;
   int io[IO_COUNT];
   int fo[FO_COUNT];
   DCtrl ctrl;

@@ -148,46 +148,133 @@ __device__ __forceinline__ S6 mul_inert(const float* I, S6 v) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// per-env LDS state
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------------------
+// per-env LDS state (one wavefront = one environment; everything below lives in LDS for all substeps of a launch)
 // ------------------------------------------------------------------------------------------------------------
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 struct Smem {
-  static constexpr int NVP = NV + 1;  // padded row stride (bank-conflict-free column access)
-  static constexpr int NV_ = NV;      // register-array extent of per-dof loops (nv <= NV)
+  static_assert(NB == 32 && NV == 16 && NEFC == 64, "tree-incidence MFMAs assume 32 bodies x 16 dofs, one lane per constraint row");
+  static constexpr int NVP = NV + 1;  // padded row stride of the dense nv x nv matrices (conflict-free column reads)
+  static constexpr int NV_ = NV;
   static constexpr int CD_ = 4;       // largest contact dimension this configuration handles (condim 1, 3, 4)
+  static constexpr int NCON_ = NCON;
+  static constexpr int NB_ = NB;
   float qpos[NV + 8], qvel[NV], qacc[NV], qacc_ws[NV], ctrl[NV];
-  float xpos[NB * 3], xquat[NB * 4], xmat[NB * 9], xipos[NB * 3];
-  float xanchor[NJ * 3], xaxis[NJ * 3];
+  float xpos[NB * 3], xquat[NB * 4], xmat[NB * 9];
   float rootcom[NB * 3];
-  float cinert[NB * 10], crb[NB * 10];
-  float cdof[NV * 6], cdof_dot[NV * 6], fbuf[NV * 6];
-  float cvel[NB * 6], cacc[NB * 6], cfrc[NB * 6], cflu[NB * 6];
-  float M[NV * NVP], L[NV * NVP], H[NV * NVP], Lh[NV * NVP];
-  float invdiag[NV], invdiag_h[NV];
+  float cinert[NB * 10 + 16];  // +16: the MFMA B-operand read pattern runs 6 floats past the last row
+  float cdof[NV * 8];          // stride 8, components 6..7 stay zero (MFMA K padding)
+  // phase-local storage: crb -> broadphase -> velocity -> controller read cvel -> solver W
+  union {
+    struct { float crbD[NV * 16], fpad[NV * 8]; } c;                                                          // crb()
+    struct { int cand[NPAIR]; } b;                                                                            // collision()
+    struct { float cvel[NB * 8], cvb[NV * 8], cdd[NV * 8], cacc[NB * 8], cf[NB * 16], F[NV * 16]; } v;        // velocity(), ctrl reads cvel
+    float W[NEFC * NV];                                                                                       // solve_newton(): Hessian-weighted rows
+  } u;
+  float M[NV * NVP], L[NV * NVP], H[NV * NVP];
+  float invdiag[NV];
   float qfrc_bias[NV], qfrc_passive[NV], qfrc_actuator[NV], qfrc_smooth[NV], qacc_smooth[NV], qfrc_constraint[NV];
-  float va[NV], vMa[NV], vgrad[NV], vsearch[NV], vMv[NV];
+  // per-launch staged constants that are read by lanes other than their owner
+  float arm[NV];                 // dof armature (1 on padding rows: keeps the padded matrices SPD)
+  float fricR[NV], fricB[NV], fricFl[NV];  // dof friction-loss rows: regulariser, velocity gain, force limit
+  float biw[NB * 2];             // body_invweight0
+  int bdofs[NB], broot[NB];
+  float gst[NG * 8];             // colliding geom statics: half-extents 3, box centre (geom frame) 3, rbound, margin
+  int gtype[NG], gbody[NG];
   float gpos[NG * 3], gmat[NG * 9], gcen[NG * 3];
   float spos[NS * 3], smat[NS * 9];
   // contacts
   float cpos[NCON * 3], cframe[NCON * 9], cdist[NCON], cfri[NCON * 5], csolref[NCON * 2], csolimp[NCON * 5], cmu[NCON], cmargin[NCON];
   int cg1[NCON], cg2[NCON], cdim[NCON], cefc[NCON];
   // constraint rows
-  float J[NEFC * NV];  // row-major, stride NV (= 16): rows are also the MFMA B operand (4 rows per instruction)
-  float W[NEFC * NV];  // Hessian-weighted rows (MFMA A operand)
-  float e_pos[NEFC], e_margin[NEFC], e_R[NEFC], e_D[NEFC], e_aref[NEFC], e_fl[NEFC], e_force[NEFC], e_jar[NEFC], e_jv[NEFC], e_K[NEFC], e_B[NEFC], e_imp[NEFC];
-  int e_type[NEFC], e_id[NEFC], e_state[NEFC];
-  int blk_start[NEFC], blk_dim[NEFC];
-  int cand[NPAIR];
+  float J[NEFC * NV];  // row-major, stride 16: four rows = one MFMA B operand
+  float e_R[NEFC], e_D[NEFC], e_aref[NEFC], e_fl[NEFC], e_force[NEFC], e_B[NEFC];
+  int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
   float cstate[RSIM_CS_SIZE];
-  float scratch[128];
-  int ncon, nefc, nblk, niter;
-  // model tables staged once per launch (int: shared topology; float: this env's constants)
-  int tab_i[RSIM_NIT];
-  float tab_f[RSIM_NFT];
+  float scratch[192];
+  int ncon, nefc, niter;
 };
 
-#define IT(tab, i) (s.tab_i[m.io[tab] + (i)])
-#define FP(tab, i) (s.tab_f[m.fo[tab] + (i)])
+#define IT(tab, i) (m.it[m.io[tab] + (i)])
+#define FP(tab, i) (fp[m.fo[tab] + (i)])
+
+// Register-resident Cholesky: lane i (< N) owns row i of the SPD matrix in a[0..N); all loops unroll so every index is a
+// compile-time register and every broadcast is a v_readlane.  After the call a[k] = L[i][k] (k <= i), inv[k] = 1 / L[k][k] (uniform).
+template <int N>
+__device__ __forceinline__ void rchol_factor(float (&a)[N], float (&inv)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const float iv = rsqrtf(fmaxf(bcast(a[j], j), FMIN));
+    inv[j] = iv;
+    const float lij = a[j] * iv;
+    a[j] = lij;
+#pragma unroll
+    for (int k = j + 1; k < N; k++) a[k] = fmaf(-lij, bcast(lij, k), a[k]);
+  }
+}
+// forward substitution only: returns y = L^-1 x (component i in lane i)
+template <int N>
+__device__ __forceinline__ float rchol_fwd(const float (&a)[N], const float (&inv)[N], float x, int lane) {
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const float xk = bcast(x, k) * inv[k];
+    x = lane == k ? xk : (lane > k ? fmaf(-a[k], xk, x) : x);
+  }
+  return x;
+}
+// x_i in lane i; a = rows of L, at[k] = L[k][i] (column i of L), inv = 1/diag.  Returns (L L^T)^-1 x, component i in lane i.
+template <int N>
+__device__ __forceinline__ float rchol_solve(const float (&a)[N], const float (&at)[N], const float (&inv)[N], float x, int lane) {
+  x = rchol_fwd<N>(a, inv, x, lane);
+#pragma unroll
+  for (int k = N - 1; k >= 0; k--) {
+    const float xk = bcast(x, k) * inv[k];
+    x = lane == k ? xk : (lane < k ? fmaf(-at[k], xk, x) : x);
+  }
+  return x;
+}
+template <int N>
+__device__ __forceinline__ float sel(const float (&v)[N], int i) {
+  float r = v[0];
+#pragma unroll
+  for (int k = 1; k < N; k++) r = i == k ? v[k] : r;
+  return r;
+}
+// 3x3 SPD solve by cofactors (uniform small algebra)
+__device__ __forceinline__ void solve3(const float* A, const float* b, float* x) {
+  const float c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+  const float det = A[0] * c00 + A[1] * c01 + A[2] * c02, id = 1.0f / det;
+  const float c10 = A[2] * A[7] - A[1] * A[8], c11 = A[0] * A[8] - A[2] * A[6], c12 = A[1] * A[6] - A[0] * A[7];
+  const float c20 = A[1] * A[5] - A[2] * A[4], c21 = A[2] * A[3] - A[0] * A[5], c22 = A[0] * A[4] - A[1] * A[3];
+  x[0] = (c00 * b[0] + c10 * b[1] + c20 * b[2]) * id;
+  x[1] = (c01 * b[0] + c11 * b[1] + c21 * b[2]) * id;
+  x[2] = (c02 * b[0] + c12 * b[1] + c22 * b[2]) * id;
+}
+// sin and cos of a bounded angle (|x| < ~1e3): Cody-Waite reduction to [-pi/4, pi/4] + Taylor kernels (abs error < 2e-7)
+__device__ __forceinline__ void sincos_f(float x, float& sn, float& cs) {
+  const float k = rintf(x * 0.636619772367581343f);
+  float r = fmaf(-k, 1.57079625129699707031f, x);
+  r = fmaf(-k, 7.54978941586159635335e-08f, r);
+  const float r2 = r * r;
+  const float sp = r * fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f), 1.0f);
+  const float cp = fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, -2.7557319e-7f, 2.4801587e-5f), -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.0f);
+  const int q = (int)k & 3;
+  const float s1 = (q & 1) ? cp : sp, c1 = (q & 1) ? sp : cp;
+  sn = (q & 2) ? -s1 : s1;
+  cs = ((q + 1) & 2) ? -c1 : c1;
+}
+// rotate v by unit quaternion q
+__device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
+  const V3 u = v3(q.x, q.y, q.z);
+  const V3 t = cross(u, v) * 2.0f;
+  return v + t * q.w + cross(u, t);
+}
+__device__ __forceinline__ float bitf(unsigned bits, int i) { return (float)((bits >> i) & 1u); }
+__device__ __forceinline__ float comp6(S6 a, int r) { return r < 3 ? (r == 0 ? a.a.x : (r == 1 ? a.a.y : a.a.z)) : (r == 3 ? a.l.x : (r == 4 ? a.l.y : a.l.z)); }
+
 
 // ------------------------------------------------------------------------------------------------------------
 // dense Cholesky / solve on an n x n LDS matrix with padded stride NVP, cooperative over the wave
@@ -226,45 +313,6 @@ __device__ __forceinline__ float chol_solve(const float* L, const float* invdiag
   return x;
 }
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// Register-resident Cholesky: lane i (< N) owns row i of the SPD matrix in a[0..N); all loops unroll so every index is a
-// compile-time register and every broadcast is a v_readlane.  After the call a[k] = L[i][k] (k <= i), inv[k] = 1 / L[k][k] (uniform).
-template <int N>
-__device__ __forceinline__ void rchol_factor(float (&a)[N], float (&inv)[N]) {
-#pragma unroll
-  for (int j = 0; j < N; j++) {
-    const float iv = rsqrtf(fmaxf(bcast(a[j], j), FMIN));
-    inv[j] = iv;
-    const float lij = a[j] * iv;
-    a[j] = lij;
-#pragma unroll
-    for (int k = j + 1; k < N; k++) a[k] = fmaf(-lij, bcast(lij, k), a[k]);
-  }
-}
-// x_i in lane i; a = rows of L, at[k] = L[k][i] (column i of L), inv = 1/diag.  Returns (L L^T)^-1 x, component i in lane i.
-template <int N>
-__device__ __forceinline__ float rchol_solve(const float (&a)[N], const float (&at)[N], const float (&inv)[N], float x, int lane) {
-#pragma unroll
-  for (int k = 0; k < N; k++) {
-    const float xk = bcast(x, k) * inv[k];
-    x = lane == k ? xk : (lane > k ? fmaf(-a[k], xk, x) : x);
-  }
-#pragma unroll
-  for (int k = N - 1; k >= 0; k--) {
-    const float xk = bcast(x, k) * inv[k];
-    x = lane == k ? xk : (lane < k ? fmaf(-at[k], xk, x) : x);
-  }
-  return x;
-}
-template <int N>
-__device__ __forceinline__ float sel(const float (&v)[N], int i) {
-  float r = v[0];
-#pragma unroll
-  for (int k = 1; k < N; k++) r = i == k ? v[k] : r;
-  return r;
-}
-
 // solve SPD N x N system A x = b in registers (N <= 6), evaluated uniformly by every lane
 template <int N>
 __device__ __forceinline__ void spd_solve_small(const float* A, const float* b, float* x) {
@@ -285,6 +333,33 @@ __device__ __forceinline__ void spd_solve_small(const float* A, const float* b, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// per-lane model constants, loaded once per launch and kept in registers for all substeps
+// ------------------------------------------------------------------------------------------------------------
+struct LaneConst {
+  // body role (lane b < nbody)
+  int part, part4, binfo;
+  unsigned bdofs;
+  V3 bpos; Q4 bquat; V3 jpos, jaxis; float q0;
+  V3 ipos; Q4 iquat; float mass; V3 inertia;
+  // dof role (lane i < nv)
+  int dinfo;
+  float damping;
+  // joint-limit constants of the dof's joint (hinge / slide)
+  float jr0, jr1, jmargin, jsr0, jsr1, jsi0, jsi1, jsi2, jsi3, jsi4, dinvw;
+  // geom role (lane g < ncg)
+  int ginfo;
+  V3 gp; Q4 gq; V3 grc;
+  // site role
+  int sbody; V3 sp; Q4 sq;
+  // actuator role (lane a < nu)
+  int ainfo;
+  float agear, again, ab0, ab1, ab2, acr0, acr1, afr0, afr1;
+  // candidate pairs p = lane + 64 t
+  int pair[3];
+  unsigned mfbits;
+};
+
+// ------------------------------------------------------------------------------------------------------------
 // the simulator (all methods are wave-cooperative: every lane of the env's wavefront calls them)
 // ------------------------------------------------------------------------------------------------------------
 template <class SM>
@@ -294,171 +369,244 @@ struct Sim {
   const float* fp;
   int lane;
   Prof pf;
+  LaneConst K;
+  float opt_h, opt_density, opt_viscosity, opt_impratio;
+  V3 opt_grav, opt_wind;
   static constexpr int NVP = SM::NVP;
   static constexpr int NV16 = SM::NV_;
   static constexpr int CD = SM::CD_;
+  static constexpr int SM_NB = SM::NB_;
 
   __device__ Sim(SM& s_, const DModel& m_, const float* fp_, int lane_, unsigned long long* prof) : s(s_), m(m_), fp(fp_), lane(lane_) { pf.p = prof; pf.lane = lane_; pf.t0 = 0; }
 
   __device__ __forceinline__ u64 mask2(int tab, int i) const { return (u64)(uint32_t)IT(tab, 2 * i) | ((u64)(uint32_t)IT(tab, 2 * i + 1) << 32); }
 
-  // ---------------------------------------------------------------- kinematics
-  __device__ void kinematics() {
-    const int b = lane;
-    const int nb = m.nbody;
-    int depth = (b < nb) ? IT(IO_body_depth, b) : -1;
-    if (b == 0) {
-      st3(s.xpos, v3(0, 0, 0));
-      Q4 q = {1, 0, 0, 0};
-      stq(s.xquat, q);
-      stm(s.xmat, q2m(q));
+  // ---------------------------------------------------------------- once per launch: constants -> registers / LDS
+  __device__ void load_constants() {
+    const int* lt = m.lt;
+    K.part = lt[LT_part * 64 + lane]; K.part4 = lt[LT_part4 * 64 + lane]; K.binfo = lt[LT_binfo * 64 + lane]; K.bdofs = (unsigned)lt[LT_bdofs * 64 + lane];
+    K.dinfo = lt[LT_dinfo * 64 + lane]; K.ginfo = lt[LT_ginfo * 64 + lane]; K.sbody = lt[LT_sinfo * 64 + lane]; K.ainfo = lt[LT_ainfo * 64 + lane];
+    K.pair[0] = lt[LT_pair0 * 64 + lane]; K.pair[1] = lt[LT_pair1 * 64 + lane]; K.pair[2] = lt[LT_pair2 * 64 + lane];
+    K.mfbits = (unsigned)lt[LT_mfbits * 64 + lane];
+    opt_h = FP(FO_opt, 0); opt_grav = v3(FP(FO_opt, 1), FP(FO_opt, 2), FP(FO_opt, 3)); opt_density = FP(FO_opt, 4); opt_viscosity = FP(FO_opt, 5);
+    opt_impratio = FP(FO_opt, 6); opt_wind = v3(FP(FO_opt, 7), FP(FO_opt, 8), FP(FO_opt, 9));
+    const int nb = m.nbody, nv = m.nv;
+    {  // body role
+      const int b = lane < nb ? lane : 0;
+      K.bpos = ld3(&FP(FO_body_pos, 3 * b)); K.bquat = ldq(&FP(FO_body_quat, 4 * b));
+      K.ipos = ld3(&FP(FO_body_ipos, 3 * b)); K.iquat = ldq(&FP(FO_body_iquat, 4 * b));
+      K.mass = FP(FO_body_mass, b); K.inertia = ld3(&FP(FO_body_inertia, 3 * b));
+      const int jt = K.binfo & 15;
+      const int j = jt != 15 ? IT(IO_body_jntadr, b) : 0;
+      K.jpos = ld3(&FP(FO_jnt_pos, 3 * j)); K.jaxis = ld3(&FP(FO_jnt_axis, 3 * j));
+      K.q0 = FP(FO_qpos0, (K.binfo >> 4) & 255);
+      if (lane >= nb) { K.part = 0; K.part4 = 0; K.binfo = 15; K.bdofs = 0; K.mass = 0.f; }
+      if (lane < SM_NB) { s.biw[2 * lane] = lane < nb ? FP(FO_body_invweight0, 2 * b) : 0.f; s.biw[2 * lane + 1] = lane < nb ? FP(FO_body_invweight0, 2 * b + 1) : 0.f;
+                          s.bdofs[lane] = (int)K.bdofs; s.broot[lane] = (K.binfo >> 20) & 255; }
     }
-    SYNC();
-    for (int lvl = 1; lvl <= m.maxdepth; lvl++) {
-      if (depth == lvl) {
-        int p = IT(IO_body_parentid, b), jadr = IT(IO_body_jntadr, b), jnum = IT(IO_body_jntnum, b);
-        V3 pos;
-        Q4 quat;
-        if (jnum == 1 && IT(IO_jnt_type, jadr) == JNT_FREE) {
-          int a = IT(IO_jnt_qposadr, jadr);
-          pos = ld3(s.qpos + a);
-          quat = qnorm(ldq(s.qpos + a + 3));
-          st3(s.xanchor + 3 * jadr, pos);
-          st3(s.xaxis + 3 * jadr, v3(0, 0, 1));
-        } else {
-          M3 Rp = ldm(s.xmat + 9 * p);
-          pos = ld3(s.xpos + 3 * p) + mv(Rp, ld3(&FP(FO_body_pos, 3 * b)));
-          quat = qmul(ldq(s.xquat + 4 * p), ldq(&FP(FO_body_quat, 4 * b)));
-          for (int j = jadr; j < jadr + jnum; j++) {
-            M3 R = q2m(quat);
-            V3 jpos = ld3(&FP(FO_jnt_pos, 3 * j)), jax = ld3(&FP(FO_jnt_axis, 3 * j));
-            V3 anchor = pos + mv(R, jpos), axis = mv(R, jax);
-            st3(s.xanchor + 3 * j, anchor);
-            st3(s.xaxis + 3 * j, axis);
-            int a = IT(IO_jnt_qposadr, j), t = IT(IO_jnt_type, j);
-            if (t == JNT_SLIDE) pos = pos + axis * (s.qpos[a] - FP(FO_qpos0, a));
-            else {
-              Q4 ql = (t == JNT_HINGE) ? axisangle(jax, s.qpos[a] - FP(FO_qpos0, a)) : qnorm(ldq(s.qpos + a));
-              quat = qmul(quat, ql);
-              pos = anchor - mv(q2m(quat), jpos);
-            }
-          }
-          quat = qnorm(quat);
-        }
-        st3(s.xpos + 3 * b, pos);
-        stq(s.xquat + 4 * b, quat);
-        stm(s.xmat + 9 * b, q2m(quat));
+    {  // dof role
+      const int i = lane < nv ? lane : 0, j = (K.dinfo >> 18) & 255;
+      K.damping = lane < nv ? FP(FO_dof_damping, i) : 0.f;
+      K.jr0 = FP(FO_jnt_range, 2 * j); K.jr1 = FP(FO_jnt_range, 2 * j + 1); K.jmargin = FP(FO_jnt_margin, j);
+      K.jsr0 = FP(FO_jnt_solref, 2 * j); K.jsr1 = FP(FO_jnt_solref, 2 * j + 1);
+      K.jsi0 = FP(FO_jnt_solimp, 5 * j); K.jsi1 = FP(FO_jnt_solimp, 5 * j + 1); K.jsi2 = FP(FO_jnt_solimp, 5 * j + 2); K.jsi3 = FP(FO_jnt_solimp, 5 * j + 3); K.jsi4 = FP(FO_jnt_solimp, 5 * j + 4);
+      K.dinvw = FP(FO_dof_invweight0, i);
+      if (lane < NV16) {
+        s.arm[lane] = lane < nv ? FP(FO_dof_armature, i) : 1.0f;
+        // friction-loss row of this dof: position term is identically 0, so R, the velocity gain and the limit are constants
+        const float fl = lane < nv ? FP(FO_dof_frictionloss, i) : 0.f;
+        float solref[2] = {FP(FO_dof_solref, 2 * i), FP(FO_dof_solref, 2 * i + 1)}, solimp[5];
+        for (int k = 0; k < 5; k++) solimp[k] = FP(FO_dof_solimp, 5 * i + k);
+        float R, Bd, Kimp;
+        row_scalars(0.f, 0.f, solref, solimp, K.dinvw, R, Bd, Kimp);
+        s.fricR[lane] = R; s.fricB[lane] = Bd; s.fricFl[lane] = fl;
       }
-      SYNC();
+      if (lane >= nv) K.dinfo = 0;
     }
-    if (b < nb) st3(s.xipos + 3 * b, ld3(s.xpos + 3 * b) + mv(ldm(s.xmat + 9 * b), ld3(&FP(FO_body_ipos, 3 * b))));
-    // colliding geoms
-    for (int g = lane; g < m.ncg; g += 64) {
-      int gb = IT(IO_cg_bodyid, g);
-      M3 Rb = ldm(s.xmat + 9 * gb);
-      V3 gp = ld3(s.xpos + 3 * gb) + mv(Rb, ld3(&FP(FO_cg_pos, 3 * g)));
-      M3 Rg = q2m(qnorm(qmul(ldq(s.xquat + 4 * gb), ldq(&FP(FO_cg_quat, 4 * g)))));
+    {  // geom role
+      const int g = lane < m.ncg ? lane : 0;
+      K.gp = ld3(&FP(FO_cg_pos, 3 * g)); K.gq = ldq(&FP(FO_cg_quat, 4 * g)); K.grc = ld3(&FP(FO_cg_rcenter, 3 * g));
+      if (lane < m.ncg) {
+        const int t = (K.ginfo >> 8) & 15;
+        const V3 sz = ld3(&FP(FO_cg_size, 3 * g));
+        V3 h = sz, c = v3(0, 0, 0);
+        if (t == G_MESH) { c = ld3(&FP(FO_cg_aabb, 6 * g)); h = ld3(&FP(FO_cg_aabb, 6 * g + 3)); }
+        else if (t == G_SPHERE) h = v3(sz.x, sz.x, sz.x);
+        else if (t == G_CAPSULE) h = v3(sz.x, sz.x, sz.x + sz.y);
+        else if (t == G_CYLINDER) h = v3(sz.x, sz.x, sz.y);
+        float* o = s.gst + 8 * g;
+        st3(o, h); st3(o + 3, c); o[6] = FP(FO_cg_rbound, g); o[7] = FP(FO_cg_margin, g);
+        s.gtype[g] = t; s.gbody[g] = K.ginfo & 255;
+      }
+    }
+    {  // site role
+      const int k = lane < m.nsite ? lane : 0;
+      K.sp = ld3(&FP(FO_site_pos, 3 * k)); K.sq = ldq(&FP(FO_site_quat, 4 * k));
+    }
+    {  // actuator role
+      const int a = lane < m.nu ? lane : 0;
+      K.agear = FP(FO_act_gear, a); K.again = FP(FO_act_gainprm, 3 * a);
+      K.ab0 = FP(FO_act_biasprm, 3 * a); K.ab1 = FP(FO_act_biasprm, 3 * a + 1); K.ab2 = FP(FO_act_biasprm, 3 * a + 2);
+      K.acr0 = FP(FO_act_ctrlrange, 2 * a); K.acr1 = FP(FO_act_ctrlrange, 2 * a + 1); K.afr0 = FP(FO_act_forcerange, 2 * a); K.afr1 = FP(FO_act_forcerange, 2 * a + 1);
+    }
+    // zero the LDS regions whose padding lanes / columns are read but never written
+    for (int e = lane; e < SM_NB * 10 + 16; e += 64) s.cinert[e] = 0.f;
+    for (int e = lane; e < NV16 * 8; e += 64) s.cdof[e] = 0.f;
+    for (int e = lane; e < SM_NB * 3; e += 64) s.rootcom[e] = 0.f;
+    SYNC();
+  }
+
+  // ---------------------------------------------------------------- kinematics: pointer jumping over the body tree
+  // every body composes its local transform with the transform of its 2^r-th ancestor in round r (log2(depth) rounds
+  // instead of a serial root-to-leaf sweep); lane b = body b.  Returns this lane's world frame in registers.
+  __device__ void kinematics(V3& xp, Q4& xq) {
+    const int b = lane;
+    const int jt = K.binfo & 15, qa = (K.binfo >> 4) & 255;
+    V3 lp = K.bpos;
+    Q4 lq = K.bquat;
+    if (jt == JNT_FREE) {
+      lp = ld3(s.qpos + qa);
+      lq = qnorm(ldq(s.qpos + qa + 3));
+    } else if (jt == JNT_HINGE) {
+      float sn, cs;
+      sincos_f(0.5f * (s.qpos[qa] - K.q0), sn, cs);
+      const Q4 ql = {cs, K.jaxis.x * sn, K.jaxis.y * sn, K.jaxis.z * sn};
+      lq = qmul(K.bquat, ql);
+      lp = K.bpos + qrot(K.bquat, K.jpos) - qrot(lq, K.jpos);
+    } else if (jt == JNT_SLIDE) {
+      lp = K.bpos + qrot(K.bquat, K.jaxis) * (s.qpos[qa] - K.q0);
+    }
+    if (b == 0) { lp = v3(0, 0, 0); lq.w = 1.f; lq.x = lq.y = lq.z = 0.f; }
+    for (int r = 0; r < m.kin_rounds; r++) {
+      if (b < SM_NB) { st3(s.xpos + 3 * b, lp); stq(s.xquat + 4 * b, lq); }
+      SYNC();
+      const int p = r < 4 ? (K.part >> (8 * r)) & 255 : K.part4;
+      const V3 pp = ld3(s.xpos + 3 * p);
+      const Q4 pq = ldq(s.xquat + 4 * p);
+      SYNC();
+      lp = pp + qrot(pq, lp);
+      lq = qmul(pq, lq);
+    }
+    lq = qnorm(lq);
+    xp = lp; xq = lq;
+    if (b < SM_NB) { st3(s.xpos + 3 * b, lp); stq(s.xquat + 4 * b, lq); stm(s.xmat + 9 * b, q2m(lq)); }
+    SYNC();
+  }
+
+  // colliding geom and site frames (lane g = geom g, lane k = site k)
+  __device__ void geom_site_frames() {
+    if (lane < m.ncg) {
+      const int g = lane, gb = K.ginfo & 255;
+      const Q4 bq = ldq(s.xquat + 4 * gb);
+      const V3 gp = ld3(s.xpos + 3 * gb) + qrot(bq, K.gp);
+      const M3 Rg = q2m(qnorm(qmul(bq, K.gq)));
       st3(s.gpos + 3 * g, gp);
       stm(s.gmat + 9 * g, Rg);
-      st3(s.gcen + 3 * g, gp + mv(Rg, ld3(&FP(FO_cg_rcenter, 3 * g))));
+      st3(s.gcen + 3 * g, gp + mv(Rg, K.grc));
     }
-    for (int k = lane; k < m.nsite; k += 64) {
-      int sb = IT(IO_site_bodyid, k);
-      st3(s.spos + 3 * k, ld3(s.xpos + 3 * sb) + mv(ldm(s.xmat + 9 * sb), ld3(&FP(FO_site_pos, 3 * k))));
-      stm(s.smat + 9 * k, q2m(qnorm(qmul(ldq(s.xquat + 4 * sb), ldq(&FP(FO_site_quat, 4 * k))))));
+    if (lane < m.nsite) {
+      const int k = lane, sb = K.sbody;
+      const Q4 bq = ldq(s.xquat + 4 * sb);
+      st3(s.spos + 3 * k, ld3(s.xpos + 3 * sb) + qrot(bq, K.sp));
+      stm(s.smat + 9 * k, q2m(qnorm(qmul(bq, K.sq))));
     }
     SYNC();
   }
 
-  // ---------------------------------------------------------------- subtree COM of every tree root, cinert, cdof
-  __device__ void com_pos() {
-    const int nb = m.nbody;
-    if (lane < nb && IT(IO_body_isroot, lane)) {
-      int r = lane;
-      V3 acc = v3(0, 0, 0);
-      for (int b = r; b < nb; b++)
-        if (IT(IO_body_rootid, b) == r) acc = acc + ld3(s.xipos + 3 * b) * FP(FO_body_mass, b);
-      float mt = FP(FO_body_subtreemass, r);
-      st3(s.rootcom + 3 * r, mt < 1e-15f ? ld3(s.xipos + 3 * r) : acc * (1.0f / mt));
+  // ---------------------------------------------------------------- subtree COM of the articulated trees, cinert, cdof
+  __device__ void com_pos(V3 xp, Q4 xq) {
+    const int b = lane, nb = m.nbody;
+    const int root = (K.binfo >> 20) & 255, jt = K.binfo & 15, da = (K.binfo >> 12) & 255;
+    const bool moving = (K.binfo >> 28) & 1;
+    const M3 R = q2m(xq);
+    const V3 xip = xp + mv(R, K.ipos);
+    V3 com = xip;
+    for (int r = 0; r < m.ndynroot; r++) {
+      const int rb = m.dynroot[r];
+      const float w = (b < nb && root == rb) ? K.mass : 0.f;
+      const float sw = wave_sum(w), sx = wave_sum(w * xip.x), sy = wave_sum(w * xip.y), sz = wave_sum(w * xip.z);
+      const float iw = sw > 1e-15f ? 1.0f / sw : 0.f;
+      const V3 cr = v3(sx * iw, sy * iw, sz * iw);
+      if (root == rb) com = cr;
+      if (lane == 0) st3(s.rootcom + 3 * rb, cr);
     }
-    if (lane == 0) st3(s.rootcom, ld3(s.xipos));
-    SYNC();
-    if (lane < nb) {
-      int b = lane;
-      M3 R = q2m(qmul(ldq(s.xquat + 4 * b), ldq(&FP(FO_body_iquat, 4 * b))));
-      V3 I = ld3(&FP(FO_body_inertia, 3 * b));
-      float mass = FP(FO_body_mass, b);
-      V3 off = ld3(s.xipos + 3 * b) - ld3(s.rootcom + 3 * IT(IO_body_rootid, b));
-      float Iw[9];
-      for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) Iw[3 * i + j] = R.m[3 * i] * I.x * R.m[3 * j] + R.m[3 * i + 1] * I.y * R.m[3 * j + 1] + R.m[3 * i + 2] * I.z * R.m[3 * j + 2];
-      float d2 = dot(off, off);
+    if (b < nb && moving) {
+      const M3 Ri = q2m(qmul(xq, K.iquat));
+      const V3 I = K.inertia;
+      const float mass = K.mass;
+      const V3 off = xip - com;
+      float Iw[6];  // xx yy zz xy xz yz of R diag(I) R^T
+      Iw[0] = Ri.m[0] * I.x * Ri.m[0] + Ri.m[1] * I.y * Ri.m[1] + Ri.m[2] * I.z * Ri.m[2];
+      Iw[1] = Ri.m[3] * I.x * Ri.m[3] + Ri.m[4] * I.y * Ri.m[4] + Ri.m[5] * I.z * Ri.m[5];
+      Iw[2] = Ri.m[6] * I.x * Ri.m[6] + Ri.m[7] * I.y * Ri.m[7] + Ri.m[8] * I.z * Ri.m[8];
+      Iw[3] = Ri.m[0] * I.x * Ri.m[3] + Ri.m[1] * I.y * Ri.m[4] + Ri.m[2] * I.z * Ri.m[5];
+      Iw[4] = Ri.m[0] * I.x * Ri.m[6] + Ri.m[1] * I.y * Ri.m[7] + Ri.m[2] * I.z * Ri.m[8];
+      Iw[5] = Ri.m[3] * I.x * Ri.m[6] + Ri.m[4] * I.y * Ri.m[7] + Ri.m[5] * I.z * Ri.m[8];
+      const float d2 = dot(off, off);
       float* ci = s.cinert + 10 * b;
       ci[0] = Iw[0] + mass * (d2 - off.x * off.x);
-      ci[1] = Iw[4] + mass * (d2 - off.y * off.y);
-      ci[2] = Iw[8] + mass * (d2 - off.z * off.z);
-      ci[3] = Iw[1] - mass * off.x * off.y;
-      ci[4] = Iw[2] - mass * off.x * off.z;
+      ci[1] = Iw[1] + mass * (d2 - off.y * off.y);
+      ci[2] = Iw[2] + mass * (d2 - off.z * off.z);
+      ci[3] = Iw[3] - mass * off.x * off.y;
+      ci[4] = Iw[4] - mass * off.x * off.z;
       ci[5] = Iw[5] - mass * off.y * off.z;
       ci[6] = mass * off.x; ci[7] = mass * off.y; ci[8] = mass * off.z; ci[9] = mass;
     }
-    if (lane < m.njnt) {
-      int j = lane, b = IT(IO_jnt_bodyid, j), da = IT(IO_jnt_dofadr, j), t = IT(IO_jnt_type, j);
-      V3 off = ld3(s.rootcom + 3 * IT(IO_body_rootid, b)) - ld3(s.xanchor + 3 * j);
-      if (t == JNT_FREE) {
-        M3 R = ldm(s.xmat + 9 * b);
+    if (b < nb && jt != 15) {
+      float* cd = s.cdof + 8 * da;
+      if (jt == JNT_FREE) {
+        const V3 off = com - xp;
         for (int k = 0; k < 3; k++) {
-          S6 c = {v3(0, 0, 0), v3(k == 0, k == 1, k == 2)};
-          st6(s.cdof + 6 * (da + k), c);
-          V3 ax = col(R, k);
-          S6 cr = {ax, cross(ax, off)};
-          st6(s.cdof + 6 * (da + 3 + k), cr);
+          st3(cd + 8 * k, v3(0, 0, 0)); st3(cd + 8 * k + 3, v3(k == 0, k == 1, k == 2));
+          const V3 ax = col(R, k);
+          st3(cd + 8 * (3 + k), ax); st3(cd + 8 * (3 + k) + 3, cross(ax, off));
         }
-      } else if (t == JNT_BALL) {
-        M3 R = ldm(s.xmat + 9 * b);
-        for (int k = 0; k < 3; k++) { V3 ax = col(R, k); S6 cr = {ax, cross(ax, off)}; st6(s.cdof + 6 * (da + k), cr); }
-      } else if (t == JNT_SLIDE) {
-        S6 c = {v3(0, 0, 0), ld3(s.xaxis + 3 * j)};
-        st6(s.cdof + 6 * da, c);
       } else {
-        V3 ax = ld3(s.xaxis + 3 * j);
-        S6 c = {ax, cross(ax, off)};
-        st6(s.cdof + 6 * da, c);
+        const V3 ax = mv(R, K.jaxis);
+        if (jt == JNT_SLIDE) { st3(cd, v3(0, 0, 0)); st3(cd + 3, ax); }
+        else { const V3 off = com - (xp + mv(R, K.jpos)); st3(cd, ax); st3(cd + 3, cross(ax, off)); }
       }
     }
     SYNC();
   }
 
-  // ---------------------------------------------------------------- CRBA -> dense M, Cholesky
+  // ---------------------------------------------------------------- CRBA on the matrix cores
+  // composite inertia per dof  crbD = Sub x cinert           (Sub = subtree incidence, 16 x 32, 0/1 constants)
+  // f_i = crbD_i * cdof_i ;  M = (m1 o F C^T) + (m2 o C F^T) + diag(armature)        (F, C = 16 x 6 stacks of f_i, cdof_i)
   __device__ void crb() {
-    const int nb = m.nbody, nv = m.nv;
-    for (int item = lane; item < nb * 10; item += 64) {
-      int b = item / 10, k = item - b * 10;
-      float acc = 0.f;
-      if (IT(IO_body_dofnum, b) > 0) {
-        for (int d = b; d < nb; d++)
-          if ((mask2(IO_body_ancmask, d) >> b) & 1ull) acc += s.cinert[10 * d + k];
-      }
-      s.crb[item] = acc;
+    const int nv = m.nv, q = lane >> 4, r = lane & 15;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, c), s.cinert[(4 * c + q) * 10 + r], acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; v++) s.u.c.crbD[(4 * q + v) * 16 + r] = acc[v];
+    SYNC();
+    if (lane < NV16) {
+      S6 f = {v3(0, 0, 0), v3(0, 0, 0)};
+      if (lane < nv) f = mul_inert(s.u.c.crbD + 16 * lane, ld6(s.cdof + 8 * lane));
+      float* o = s.u.c.fpad + 8 * lane;
+      st3(o, f.a); st3(o + 3, f.l); o[6] = 0.f; o[7] = 0.f;
     }
     SYNC();
-    if (lane < nv) st6(s.fbuf + 6 * lane, mul_inert(s.crb + 10 * IT(IO_dof_bodyid, lane), ld6(s.cdof + 6 * lane)));
-    SYNC();
-    for (int e = lane; e < nv * nv; e += 64) {
-      int i = e / nv, j = e - i * nv;
-      if (j > i) continue;
-      float v = 0.f;
-      if ((mask2(IO_dof_ancmask, i) >> j) & 1ull) v = dot6(ld6(s.cdof + 6 * j), ld6(s.fbuf + 6 * i));
-      if (i == j) v += FP(FO_dof_armature, i);
-      s.M[i * NVP + j] = v;
-      s.M[j * NVP + i] = v;
+    v4f R1 = {0.f, 0.f, 0.f, 0.f}, R2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < 2; kc++) {
+      const float fa = s.u.c.fpad[r * 8 + 4 * kc + q], ca = s.cdof[r * 8 + 4 * kc + q];
+      R1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, ca, R1, 0, 0, 0);
+      R2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca, fa, R2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int i = 4 * q + v;
+      float mij = bitf(K.mfbits, 20 + v) * R1[v] + bitf(K.mfbits, 24 + v) * R2[v];
+      if (i == r) mij += s.arm[i];
+      s.M[i * NVP + r] = mij;
     }
     SYNC();
     {
       float mr[NV16], minv[NV16];
-      const int rr = lane & (NV16 - 1);
 #pragma unroll
-      for (int k = 0; k < NV16; k++) mr[k] = (rr < nv && k < nv) ? s.M[rr * NVP + k] : (rr == k ? 1.f : 0.f);
+      for (int k = 0; k < NV16; k++) mr[k] = s.M[r * NVP + k];
       rchol_factor<NV16>(mr, minv);
       if (lane < NV16) {
 #pragma unroll
@@ -469,81 +617,101 @@ struct Sim {
     SYNC();
   }
 
-  // ---------------------------------------------------------------- velocity stage: cvel, cdof_dot, bias, passive
-  __device__ void velocity() {
-    const int nb = m.nbody, nv = m.nv;
-    const float density = FP(FO_opt, 4), viscosity = FP(FO_opt, 5);
-    const V3 grav = v3(FP(FO_opt, 1), FP(FO_opt, 2), FP(FO_opt, 3)), wind = v3(FP(FO_opt, 7), FP(FO_opt, 8), FP(FO_opt, 9));
-    if (lane < nv) {
-      int i = lane;
-      S6 cv = {v3(0, 0, 0), v3(0, 0, 0)};
-      u64 mk = mask2(IO_dof_cvelmask, i);
-      while (mk) { int k = __ffsll((long long)mk) - 1; mk &= mk - 1; cv = cv + ld6(s.cdof + 6 * k) * s.qvel[k]; }
-      S6 cd = {v3(0, 0, 0), v3(0, 0, 0)};
-      if (!IT(IO_dof_zerodot, i)) cd = cross_motion(cv, ld6(s.cdof + 6 * i));
-      st6(s.cdof_dot + 6 * i, cd);
+  // ---------------------------------------------------------------- velocity stage (RNE) on the matrix cores
+  // cvel = BodyDof x (cdof qd) ; cdof_dot_i = cvel_before(i) x cdof_i ; cacc = BodyDof x (cdof_dot qd) - g ;
+  // body wrench cf = I cacc + cvel x* I cvel (+ fluid) ; F = Sub x cf ; bias_i = cdof_i . F_i
+  __device__ void velocity(V3 xp, Q4 xq) {
+    const int nb = m.nbody, nv = m.nv, q = lane >> 4, r = lane & 15;
+    float Bc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) Bc[c] = r < 6 ? s.cdof[(4 * c + q) * 8 + r] * s.qvel[4 * c + q] : 0.f;
+    v4f a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, 8 + c), Bc[c], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, 12 + c), Bc[c], a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, 16 + c), Bc[c], a2, 0, 0, 0);
     }
-    if (lane < nb) {
-      int b = lane;
-      S6 cv = {v3(0, 0, 0), v3(0, 0, 0)};
-      u64 mk = mask2(IO_body_dofmask, b);
-      while (mk) { int k = __ffsll((long long)mk) - 1; mk &= mk - 1; cv = cv + ld6(s.cdof + 6 * k) * s.qvel[k]; }
-      st6(s.cvel + 6 * b, cv);
+    if (r < 8) {
+#pragma unroll
+      for (int v = 0; v < 4; v++) { s.u.v.cvel[(4 * q + v) * 8 + r] = a0[v]; s.u.v.cvel[(16 + 4 * q + v) * 8 + r] = a1[v]; s.u.v.cvb[(4 * q + v) * 8 + r] = a2[v]; }
     }
     SYNC();
-    if (lane < nb) {
-      int b = lane;
+    if (lane < NV16) {
+      S6 cd = {v3(0, 0, 0), v3(0, 0, 0)};
+      if (lane < nv && !((K.dinfo >> 8) & 1)) cd = cross_motion(ld6(s.u.v.cvb + 8 * lane), ld6(s.cdof + 8 * lane));
+      float* o = s.u.v.cdd + 8 * lane;
+      st3(o, cd.a); st3(o + 3, cd.l); o[6] = 0.f; o[7] = 0.f;
+    }
+    SYNC();
+#pragma unroll
+    for (int c = 0; c < 4; c++) Bc[c] = r < 6 ? s.u.v.cdd[(4 * c + q) * 8 + r] * s.qvel[4 * c + q] : 0.f;
+    a0 = a1 = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, 8 + c), Bc[c], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, 12 + c), Bc[c], a1, 0, 0, 0);
+    }
+    if (r < 8) {
+#pragma unroll
+      for (int v = 0; v < 4; v++) { s.u.v.cacc[(4 * q + v) * 8 + r] = a0[v]; s.u.v.cacc[(16 + 4 * q + v) * 8 + r] = a1[v]; }
+    }
+    SYNC();
+    if (lane < SM_NB) {
+      const int b = lane;
       S6 zero = {v3(0, 0, 0), v3(0, 0, 0)};
       S6 frc = zero, flu = zero;
-      if (IT(IO_body_moving, b)) {
-        S6 ca = {v3(0, 0, 0), -grav};
-        u64 mk = mask2(IO_body_dofmask, b);
-        while (mk) { int k = __ffsll((long long)mk) - 1; mk &= mk - 1; ca = ca + ld6(s.cdof_dot + 6 * k) * s.qvel[k]; }
-        S6 cv = ld6(s.cvel + 6 * b);
+      if (b < nb && ((K.binfo >> 28) & 1)) {
+        S6 ca = ld6(s.u.v.cacc + 8 * b);
+        ca.l = ca.l - opt_grav;
+        const S6 cv = ld6(s.u.v.cvel + 8 * b);
         frc = mul_inert(s.cinert + 10 * b, ca) + cross_force(cv, mul_inert(s.cinert + 10 * b, cv));
-        float mass = FP(FO_body_mass, b);
-        if (mass >= 1e-15f && (density > 0.f || viscosity > 0.f)) {
+        const float mass = K.mass;
+        if (mass >= 1e-15f && (opt_density > 0.f || opt_viscosity > 0.f)) {
           // inertia-box fluid model: force/torque at the body COM, folded into a spatial force about the tree COM
-          V3 I = ld3(&FP(FO_body_inertia, 3 * b));
-          M3 R = q2m(qmul(ldq(s.xquat + 4 * b), ldq(&FP(FO_body_iquat, 4 * b))));
-          float bx = sqrtf(fmaxf(1e-15f, I.y + I.z - I.x) / mass * 6.0f), by = sqrtf(fmaxf(1e-15f, I.x + I.z - I.y) / mass * 6.0f),
-                bz = sqrtf(fmaxf(1e-15f, I.x + I.y - I.z) / mass * 6.0f);
-          V3 off = ld3(s.xipos + 3 * b) - ld3(s.rootcom + 3 * IT(IO_body_rootid, b));
-          V3 gl = cv.l + cross(cv.a, off) - wind;
-          V3 la = mtv(R, cv.a), ll = mtv(R, gl);
+          const V3 I = K.inertia;
+          const M3 R = q2m(qmul(xq, K.iquat));
+          const float bx = sqrtf(fmaxf(1e-15f, I.y + I.z - I.x) / mass * 6.0f), by = sqrtf(fmaxf(1e-15f, I.x + I.z - I.y) / mass * 6.0f),
+                      bz = sqrtf(fmaxf(1e-15f, I.x + I.y - I.z) / mass * 6.0f);
+          const V3 off = xp + qrot(xq, K.ipos) - ld3(s.rootcom + 3 * ((K.binfo >> 20) & 255));
+          const V3 gl = cv.l + cross(cv.a, off) - opt_wind;
+          const V3 la = mtv(R, cv.a), ll = mtv(R, gl);
           V3 ft = v3(0, 0, 0), ff = v3(0, 0, 0);
-          if (viscosity > 0.f) {
-            float diam = (bx + by + bz) / 3.0f;
-            ft = la * (-PI_F * diam * diam * diam * viscosity);
-            ff = ll * (-3.0f * PI_F * diam * viscosity);
+          if (opt_viscosity > 0.f) {
+            const float diam = (bx + by + bz) / 3.0f;
+            ft = la * (-PI_F * diam * diam * diam * opt_viscosity);
+            ff = ll * (-3.0f * PI_F * diam * opt_viscosity);
           }
-          if (density > 0.f) {
-            ff.x -= 0.5f * density * by * bz * fabsf(ll.x) * ll.x;
-            ff.y -= 0.5f * density * bx * bz * fabsf(ll.y) * ll.y;
-            ff.z -= 0.5f * density * bx * by * fabsf(ll.z) * ll.z;
-            float bx4 = bx * bx * bx * bx, by4 = by * by * by * by, bz4 = bz * bz * bz * bz;
-            ft.x -= density * bx * (by4 + bz4) * fabsf(la.x) * la.x / 64.0f;
-            ft.y -= density * by * (bx4 + bz4) * fabsf(la.y) * la.y / 64.0f;
-            ft.z -= density * bz * (bx4 + by4) * fabsf(la.z) * la.z / 64.0f;
+          if (opt_density > 0.f) {
+            ff.x -= 0.5f * opt_density * by * bz * fabsf(ll.x) * ll.x;
+            ff.y -= 0.5f * opt_density * bx * bz * fabsf(ll.y) * ll.y;
+            ff.z -= 0.5f * opt_density * bx * by * fabsf(ll.z) * ll.z;
+            const float bx4 = bx * bx * bx * bx, by4 = by * by * by * by, bz4 = bz * bz * bz * bz;
+            ft.x -= opt_density * bx * (by4 + bz4) * fabsf(la.x) * la.x / 64.0f;
+            ft.y -= opt_density * by * (bx4 + bz4) * fabsf(la.y) * la.y / 64.0f;
+            ft.z -= opt_density * bz * (bx4 + by4) * fabsf(la.z) * la.z / 64.0f;
           }
-          V3 gt = mv(R, ft), gf = mv(R, ff);
+          const V3 gt = mv(R, ft), gf = mv(R, ff);
           flu.a = gt + cross(off, gf);
           flu.l = gf;
         }
       }
-      st6(s.cfrc + 6 * b, frc);
-      st6(s.cflu + 6 * b, flu);
+      float* o = s.u.v.cf + 16 * b;
+      st3(o, frc.a); st3(o + 3, frc.l); st3(o + 6, flu.a); st3(o + 9, flu.l);
+      o[12] = o[13] = o[14] = o[15] = 0.f;
     }
     SYNC();
+    v4f af = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 8; c++) af = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, c), s.u.v.cf[(4 * c + q) * 16 + r], af, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; v++) s.u.v.F[(4 * q + v) * 16 + r] = af[v];
+    SYNC();
     if (lane < nv) {
-      int i = lane, bi = IT(IO_dof_bodyid, i);
-      S6 zero = {v3(0, 0, 0), v3(0, 0, 0)};
-      S6 sf = zero, sl = zero;
-      for (int d = bi; d < nb; d++)
-        if ((mask2(IO_body_ancmask, d) >> bi) & 1ull) { sf = sf + ld6(s.cfrc + 6 * d); sl = sl + ld6(s.cflu + 6 * d); }
-      S6 cd = ld6(s.cdof + 6 * i);
-      s.qfrc_bias[i] = dot6(cd, sf);
-      s.qfrc_passive[i] = -FP(FO_dof_damping, i) * s.qvel[i] + dot6(cd, sl);
+      const S6 cd = ld6(s.cdof + 8 * lane);
+      const float* F = s.u.v.F + 16 * lane;
+      s.qfrc_bias[lane] = dot6(cd, ld6(F));
+      s.qfrc_passive[lane] = -K.damping * s.qvel[lane] + dot6(cd, ld6(F + 6));
     }
     SYNC();
   }
@@ -551,13 +719,14 @@ struct Sim {
   // Jacobian column of world point p attached to body `b` for dof i: returns [jacr; jacp] or zero if i does not move b
   __device__ __forceinline__ S6 jac_col(int b, V3 p, int i) const {
     S6 z = {v3(0, 0, 0), v3(0, 0, 0)};
-    if (!((mask2(IO_body_dofmask, b) >> i) & 1ull)) return z;
-    S6 cd = ld6(s.cdof + 6 * i);
-    V3 off = p - ld3(s.rootcom + 3 * IT(IO_body_rootid, b));
-    S6 r = {cd.a, cd.l + cross(cd.a, off)};
-    return r;
+    if (!((s.bdofs[b] >> i) & 1)) return z;
+    S6 cd = ld6(s.cdof + 8 * i);
+    V3 off = p - ld3(s.rootcom + 3 * s.broot[b]);
+    S6 rr = {cd.a, cd.l + cross(cd.a, off)};
+    return rr;
   }
 
+  // ---------------------------------------------------------------- collision narrowphase
   // ---------------------------------------------------------------- collision
   __device__ __forceinline__ void make_frame(V3 n, float* frame) {
     n = normalized(n);
@@ -840,70 +1009,68 @@ struct Sim {
   }
 
   // oriented bounding box of colliding geom g: world centre o, half extents h along the columns of gmat
-  __device__ __forceinline__ void geom_obb(int g, V3& o, V3& h) const {
-    const int t = IT(IO_cg_type, g);
-    const V3 sz = ld3(&FP(FO_cg_size, 3 * g));
-    V3 lc = v3(0, 0, 0);
-    if (t == G_MESH) { lc = ld3(&FP(FO_cg_aabb, 6 * g)); h = ld3(&FP(FO_cg_aabb, 6 * g + 3)); }
-    else if (t == G_SPHERE) h = v3(sz.x, sz.x, sz.x);
-    else if (t == G_CAPSULE) h = v3(sz.x, sz.x, sz.x + sz.y);
-    else if (t == G_CYLINDER) h = v3(sz.x, sz.x, sz.y);
-    else h = sz;
-    o = ld3(s.gpos + 3 * g) + mv(ldm(s.gmat + 9 * g), lc);
+  __device__ __forceinline__ void geom_obb(int g, const M3& R, V3& o, V3& h) const {
+    const float* st = s.gst + 8 * g;
+    h = ld3(st);
+    o = ld3(s.gpos + 3 * g) + mv(R, ld3(st + 3));
   }
 
   __device__ void collision() {
     if (lane == 0) s.ncon = 0;
-    // broadphase: bounding spheres, order-preserving compaction of candidate pairs
+    // broadphase: lane p tests candidate pair p (bounding spheres, then the 6 face axes of the two oriented boxes);
+    // order-preserving compaction of the survivors
     int ncand = 0;
-    for (int base = 0; base < m.npair; base += 64) {
-      int p = base + lane;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      if (64 * t >= m.npair) break;
+      const int pr = K.pair[t];
       bool pass = false;
-      if (p < m.npair) {
-        int g1 = IT(IO_pair_g1, p), g2 = IT(IO_pair_g2, p);
-        float margin = fmaxf(FP(FO_cg_margin, g1), FP(FO_cg_margin, g2));
-        V3 c2 = ld3(s.gcen + 3 * g2);
+      if ((pr >> 16) & 1) {
+        const int g1 = pr & 255, g2 = (pr >> 8) & 255;
+        const float* st1 = s.gst + 8 * g1;
+        const float* st2 = s.gst + 8 * g2;
+        const float margin = fmaxf(st1[7], st2[7]);
+        const V3 c2 = ld3(s.gcen + 3 * g2);
+        const M3 R2 = ldm(s.gmat + 9 * g2);
         V3 o2, h2;
-        geom_obb(g2, o2, h2);
-        M3 R2 = ldm(s.gmat + 9 * g2);
-        if (IT(IO_cg_type, g1) == G_PLANE) {
-          V3 nrm = col(ldm(s.gmat + 9 * g1), 2);
-          pass = dot(c2 - ld3(s.gpos + 3 * g1), nrm) - FP(FO_cg_rbound, g2) <= margin;
-          // plane vs oriented box of geom 2
-          if (pass) pass = dot(o2 - ld3(s.gpos + 3 * g1), nrm) - (h2.x * fabsf(dot(nrm, col(R2, 0))) + h2.y * fabsf(dot(nrm, col(R2, 1))) + h2.z * fabsf(dot(nrm, col(R2, 2)))) <= margin;
+        geom_obb(g2, R2, o2, h2);
+        if (s.gtype[g1] == G_PLANE) {
+          const V3 nrm = v3(s.gmat[9 * g1 + 2], s.gmat[9 * g1 + 5], s.gmat[9 * g1 + 8]);
+          const V3 pp = ld3(s.gpos + 3 * g1);
+          pass = dot(c2 - pp, nrm) - st2[6] <= margin;
+          if (pass) pass = dot(o2 - pp, nrm) - (h2.x * fabsf(dot(nrm, col(R2, 0))) + h2.y * fabsf(dot(nrm, col(R2, 1))) + h2.z * fabsf(dot(nrm, col(R2, 2)))) <= margin;
         } else {
-          V3 rel = c2 - ld3(s.gcen + 3 * g1);
-          float bound = FP(FO_cg_rbound, g1) + FP(FO_cg_rbound, g2) + margin;
+          const V3 rel = c2 - ld3(s.gcen + 3 * g1);
+          const float bound = st1[6] + st2[6] + margin;
           pass = dot(rel, rel) <= bound * bound;
           if (pass) {
-            // conservative separating-axis test on the 6 face normals of the two oriented bounding boxes
+            const M3 R1 = ldm(s.gmat + 9 * g1);
             V3 o1, h1;
-            geom_obb(g1, o1, h1);
-            M3 R1 = ldm(s.gmat + 9 * g1);
-            M3 C = mtm(R1, R2);  // C[i][j] = A_i . B_j
-            V3 t = o2 - o1, ta = mtv(R1, t), tb = mtv(R2, t);
-            float sepa = fmaxf(fmaxf(fabsf(ta.x) - (h1.x + h2.x * fabsf(C.m[0]) + h2.y * fabsf(C.m[1]) + h2.z * fabsf(C.m[2])),
-                                     fabsf(ta.y) - (h1.y + h2.x * fabsf(C.m[3]) + h2.y * fabsf(C.m[4]) + h2.z * fabsf(C.m[5]))),
-                               fabsf(ta.z) - (h1.z + h2.x * fabsf(C.m[6]) + h2.y * fabsf(C.m[7]) + h2.z * fabsf(C.m[8])));
-            float sepb = fmaxf(fmaxf(fabsf(tb.x) - (h2.x + h1.x * fabsf(C.m[0]) + h1.y * fabsf(C.m[3]) + h1.z * fabsf(C.m[6])),
-                                     fabsf(tb.y) - (h2.y + h1.x * fabsf(C.m[1]) + h1.y * fabsf(C.m[4]) + h1.z * fabsf(C.m[7]))),
-                               fabsf(tb.z) - (h2.z + h1.x * fabsf(C.m[2]) + h1.y * fabsf(C.m[5]) + h1.z * fabsf(C.m[8])));
+            geom_obb(g1, R1, o1, h1);
+            const M3 C = mtm(R1, R2);  // C[i][j] = A_i . B_j
+            const V3 tt = o2 - o1, ta = mtv(R1, tt), tb = mtv(R2, tt);
+            const float sepa = fmaxf(fmaxf(fabsf(ta.x) - (h1.x + h2.x * fabsf(C.m[0]) + h2.y * fabsf(C.m[1]) + h2.z * fabsf(C.m[2])),
+                                           fabsf(ta.y) - (h1.y + h2.x * fabsf(C.m[3]) + h2.y * fabsf(C.m[4]) + h2.z * fabsf(C.m[5]))),
+                                     fabsf(ta.z) - (h1.z + h2.x * fabsf(C.m[6]) + h2.y * fabsf(C.m[7]) + h2.z * fabsf(C.m[8])));
+            const float sepb = fmaxf(fmaxf(fabsf(tb.x) - (h2.x + h1.x * fabsf(C.m[0]) + h1.y * fabsf(C.m[3]) + h1.z * fabsf(C.m[6])),
+                                           fabsf(tb.y) - (h2.y + h1.x * fabsf(C.m[1]) + h1.y * fabsf(C.m[4]) + h1.z * fabsf(C.m[7]))),
+                                     fabsf(tb.z) - (h2.z + h1.x * fabsf(C.m[2]) + h1.y * fabsf(C.m[5]) + h1.z * fabsf(C.m[8])));
             pass = fmaxf(sepa, sepb) <= margin + 1e-6f;
           }
         }
       }
-      u64 mk = __ballot(pass);
-      if (pass) s.cand[ncand + __popcll(mk & lanemask_lt(lane))] = p;
+      const u64 mk = __ballot(pass);
+      if (pass) s.u.b.cand[ncand + __popcll(mk & lanemask_lt(lane))] = 64 * t + lane;
       ncand += __popcll(mk);
     }
     SYNC();
     pf.mark(RP_BROAD);
     pf.count(RP_N_CAND, ncand);
     for (int ci = 0; ci < ncand; ci++) {
-      int p = uni(s.cand[ci]);
+      int p = uni(s.u.b.cand[ci]);
       int g1 = uni(IT(IO_pair_g1, p)), g2 = uni(IT(IO_pair_g2, p));
-      int t1 = uni(IT(IO_cg_type, g1)), t2 = uni(IT(IO_cg_type, g2));
-      float margin = fmaxf(FP(FO_cg_margin, g1), FP(FO_cg_margin, g2)), gap = fmaxf(FP(FO_cg_gap, g1), FP(FO_cg_gap, g2));
+      int t1 = uni(s.gtype[g1]), t2 = uni(s.gtype[g2]);
+      float margin = fmaxf(s.gst[8 * g1 + 7], s.gst[8 * g2 + 7]), gap = fmaxf(FP(FO_cg_gap, g1), FP(FO_cg_gap, g2));
       if (t1 == G_PLANE && t2 == G_BOX) {
         M3 Rp = ldm(s.gmat + 9 * g1);
         V3 nrm = col(Rp, 2);
@@ -943,148 +1110,187 @@ struct Sim {
   }
 
   // ---------------------------------------------------------------- constraint rows
-  __device__ __forceinline__ float impedance(const float* solimp, float x_abs) {
+  __device__ __forceinline__ float impedance(const float* solimp, float x_abs) const {
     float dmin = fminf(0.9999f, fmaxf(0.0001f, solimp[0])), dmax = fminf(0.9999f, fmaxf(0.0001f, solimp[1]));
     float width = fmaxf(1e-15f, solimp[2]), mid = fminf(0.9999f, fmaxf(0.0001f, solimp[3])), power = fmaxf(1.0f, solimp[4]);
     float x = x_abs / width, y;
     if (x >= 1) return dmax;
     if (x <= 0) return dmin;
     if (power == 1.0f) y = x;
+    else if (power == 2.0f) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
     else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
     else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
     return dmin + y * (dmax - dmin);
   }
-  __device__ __forceinline__ void row_params(int r, int type, int id, float pos, float margin, float fl, const float* solref, const float* solimp, float diag) {
-    s.e_type[r] = type; s.e_id[r] = id; s.e_pos[r] = pos; s.e_margin[r] = margin; s.e_fl[r] = fl;
-    float imp = impedance(solimp, fabsf(pos - margin));
-    float dmax = fminf(0.9999f, fmaxf(0.0001f, solimp[1]));
-    float K, Bd;
+  // regulariser R, velocity gain B and the position term K*imp*(pos-margin) of a constraint row
+  __device__ __forceinline__ void row_scalars(float pos, float margin, const float* solref, const float* solimp, float diag, float& R, float& Bd, float& Kterm) const {
+    const float imp = impedance(solimp, fabsf(pos - margin));
+    const float dmax = fminf(0.9999f, fmaxf(0.0001f, solimp[1]));
+    float Kk;
     if (solref[0] > 0) {
-      float tc = fmaxf(solref[0], 2 * FP(FO_opt, 0)), dr = solref[1];
+      const float tc = fmaxf(solref[0], 2 * opt_h), dr = solref[1];
       Bd = 2 / fmaxf(1e-15f, dmax * tc);
-      K = 1 / fmaxf(1e-15f, dmax * dmax * tc * tc * dr * dr);
+      Kk = 1 / fmaxf(1e-15f, dmax * dmax * tc * tc * dr * dr);
     } else {
-      K = -solref[0] / fmaxf(1e-15f, dmax * dmax);
+      Kk = -solref[0] / fmaxf(1e-15f, dmax * dmax);
       Bd = -solref[1] / fmaxf(1e-15f, dmax);
     }
-    s.e_K[r] = K; s.e_B[r] = Bd; s.e_imp[r] = imp;
-    s.e_R[r] = fmaxf(1e-15f, (1 - imp) / imp * diag);
+    Kterm = Kk * imp * (pos - margin);
+    R = fmaxf(1e-15f, (1 - imp) / imp * diag);
   }
 
+  // Row list: (1) friction-loss dofs, (2) joint limits (lower side first), (3) contacts in detection order.
+  // The lanes that own the source objects (dof / joint / contact) publish a row descriptor and the row scalars; then lane r
+  // builds Jacobian row r in registers, writes it once to LDS (MFMA operand) and finishes aref with its own J.qvel.
   __device__ void make_constraint() {
     const int nv = m.nv;
-    constexpr int NEFC = sizeof(s.e_pos) / sizeof(float);
-    int nefc = 0, nblk = 0;
-    // zero J (rows >= nefc and columns >= nv feed the matrix cores as padding)
-    for (int e = lane; e < NEFC * NV16; e += 64) s.J[e] = 0.f;
-    SYNC();
-    // (1) dof friction loss rows
+    int nefc = 0;
+    const bool isdof = lane < nv;
+    const int jt = (K.dinfo >> 26) & 15, qa = (K.dinfo >> 10) & 255;
+    // (1) friction loss
     {
-      bool act = lane < nv && FP(FO_dof_frictionloss, lane) > 0.f;
-      u64 mk = __ballot(act);
+      const bool act = isdof && s.fricFl[lane] > 0.f;
+      const u64 mk = __ballot(act);
       if (act) {
-        int r = nefc + __popcll(mk & lanemask_lt(lane)), i = lane;
-        s.J[r * NV16 + i] = 1.f;
-        float solref[2] = {FP(FO_dof_solref, 2 * i), FP(FO_dof_solref, 2 * i + 1)}, solimp[5];
-        for (int k = 0; k < 5; k++) solimp[k] = FP(FO_dof_solimp, 5 * i + k);
-        row_params(r, C_FRICTION_DOF, i, 0, 0, FP(FO_dof_frictionloss, i), solref, solimp, FP(FO_dof_invweight0, i));
-        s.blk_start[r] = r; s.blk_dim[r] = 1;
+        const int r = nefc + __popcll(mk & lanemask_lt(lane));
+        s.e_desc[r] = C_FRICTION_DOF | (lane << 4);
+        s.e_R[r] = s.fricR[lane]; s.e_B[r] = s.fricB[lane]; s.e_aref[r] = 0.f; s.e_fl[r] = s.fricFl[lane];
       }
       nefc += __popcll(mk);
     }
-    // (2) joint limit rows (item = 2*joint + side, lower side first)
-    for (int base = 0; base < 2 * m.njnt; base += 64) {
-      int item = base + lane, j = item >> 1, side = (item & 1) ? 1 : -1;
-      bool act = false;
-      float dist = 0;
-      if (item < 2 * m.njnt && IT(IO_jnt_limited, j)) {
-        int t = IT(IO_jnt_type, j);
-        if (t == JNT_HINGE || t == JNT_SLIDE) {
-          float q = s.qpos[IT(IO_jnt_qposadr, j)];
-          dist = side < 0 ? q - FP(FO_jnt_range, 2 * j) : FP(FO_jnt_range, 2 * j + 1) - q;
-          act = dist < FP(FO_jnt_margin, j);
+    // (2) joint limits: dof lane i owns its hinge / slide joint; lower side before upper side
+    {
+      const bool lim = isdof && ((K.dinfo >> 9) & 1) && (jt == JNT_HINGE || jt == JNT_SLIDE);
+      const float qv = lim ? s.qpos[qa] : 0.f;
+      const float dlo = qv - K.jr0, dhi = K.jr1 - qv;
+      const bool alo = lim && dlo < K.jmargin, ahi = lim && dhi < K.jmargin;
+      const u64 mlo = __ballot(alo), mhi = __ballot(ahi);
+      const int before = __popcll(mlo & lanemask_lt(lane)) + __popcll(mhi & lanemask_lt(lane));
+      const float solref[2] = {K.jsr0, K.jsr1}, solimp[5] = {K.jsi0, K.jsi1, K.jsi2, K.jsi3, K.jsi4};
+      if (alo) {
+        const int r = nefc + before;
+        float R, Bd, Kt;
+        row_scalars(dlo, K.jmargin, solref, solimp, K.dinvw, R, Bd, Kt);
+        s.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (0 << 12);
+        s.e_R[r] = R; s.e_B[r] = Bd; s.e_aref[r] = Kt; s.e_fl[r] = 0.f;
+      }
+      if (ahi) {
+        const int r = nefc + before + (alo ? 1 : 0);
+        float R, Bd, Kt;
+        row_scalars(dhi, K.jmargin, solref, solimp, K.dinvw, R, Bd, Kt);
+        s.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (1 << 12);
+        s.e_R[r] = R; s.e_B[r] = Bd; s.e_aref[r] = Kt; s.e_fl[r] = 0.f;
+      }
+      nefc += __popcll(mlo) + __popcll(mhi);
+    }
+    // (3) contacts: lane c owns contact c; exclusive scan of the active dimensions gives the first row of each block
+    {
+      const int ncon = uni(s.ncon);
+      const bool has = lane < ncon;
+      const int dim = has ? s.cdim[lane] : 0;
+      const bool active = has && s.cdist[lane] < s.cmargin[lane];
+      int need = active ? dim : 0, incl = need;
+#pragma unroll
+      for (int o = 1; o < SM::NCON_; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      int first = nefc + incl - need;
+      const bool fits = active && first + dim <= 64;
+      // a block that does not fit is dropped together with everything after it (rows must stay contiguous)
+      const u64 bad = __ballot(active && !fits);
+      const bool keep = fits && (bad == 0 || lane < (__ffsll((long long)bad) - 1));
+      if (has) s.cefc[lane] = keep ? first : -1;
+      if (keep) {
+        const int g1 = s.cg1[lane], g2 = s.cg2[lane];
+        const int b1 = s.gbody[g1], b2 = s.gbody[g2];
+        const float tran = s.biw[2 * b1] + s.biw[2 * b2], rot = s.biw[2 * b1 + 1] + s.biw[2 * b2 + 1];
+        float R0, Bd, Kt;
+        row_scalars(s.cdist[lane], s.cmargin[lane], s.csolref + 2 * lane, s.csolimp + 5 * lane, tran, R0, Bd, Kt);
+        const int type = dim == 1 ? C_CONTACT_FRICTIONLESS : C_CONTACT_ELLIPTIC;
+        const float* f = s.cfri + 5 * lane;
+        const float R1 = R0 / fmaxf(1e-15f, opt_impratio);
+        (void)rot;  // friction rows: same gains, zero position term; their regularisers follow the cone scaling of R0
+#pragma unroll
+        for (int k = 0; k < CD; k++) {
+          if (k < dim) {
+            const int r = first + k;
+            s.e_desc[r] = type | (lane << 4) | (k << 12);
+            s.e_R[r] = k == 0 ? R0 : (k == 1 ? R1 : R1 * f[0] * f[0] / fmaxf(1e-15f, f[k - 1] * f[k - 1]));
+            s.e_B[r] = Bd; s.e_aref[r] = k == 0 ? Kt : 0.f; s.e_fl[r] = 0.f;
+          }
+        }
+        s.cmu[lane] = dim > 1 ? f[0] * sqrtf(R1 / R0) : 0.f;
+      }
+      const u64 kept = __ballot(keep);
+      const int lastc = kept ? 63 - __clzll((long long)kept) : -1;
+      const int add = lastc >= 0 ? __shfl(first + dim, lastc) - nefc : 0;
+      nefc += add;
+    }
+    if (lane == 0) s.nefc = nefc;
+    SYNC();
+    // ---- lane r builds row r
+    {
+      const bool valid = lane < nefc;
+      const int desc = valid ? s.e_desc[lane] : 0;
+      const int type = desc & 15, id = (desc >> 4) & 255, kk = (desc >> 12) & 15;
+      float Jr[NV16];
+#pragma unroll
+      for (int k = 0; k < NV16; k++) Jr[k] = 0.f;
+      if (valid && type == C_FRICTION_DOF) {
+#pragma unroll
+        for (int k = 0; k < NV16; k++) Jr[k] = k == id ? 1.f : 0.f;
+      } else if (valid && type == C_LIMIT_JOINT) {
+        const float sg = kk ? -1.f : 1.f;  // lower limit: +dq increases the distance; upper: decreases it
+#pragma unroll
+        for (int k = 0; k < NV16; k++) Jr[k] = k == id ? sg : 0.f;
+      } else if (valid) {
+        const int c = id;
+        const int g1 = s.cg1[c], g2 = s.cg2[c];
+        const int b1 = s.gbody[g1], b2 = s.gbody[g2];
+        const unsigned d1 = (unsigned)s.bdofs[b1], d2 = (unsigned)s.bdofs[b2];
+        const V3 pos = ld3(s.cpos + 3 * c);
+        const V3 ax = ld3(s.cframe + 9 * c + 3 * (kk < 3 ? kk : kk - 3));
+        const V3 o1 = pos - ld3(s.rootcom + 3 * s.broot[b1]), o2 = pos - ld3(s.rootcom + 3 * s.broot[b2]);
+        const V3 t1 = cross(o1, ax), t2 = cross(o2, ax);  // ax . (ca x o) = ca . (o x ax)
+        const bool lin = kk < 3;
+#pragma unroll
+        for (int k = 0; k < NV16; k++) {
+          const S6 cd = ld6(s.cdof + 8 * k);
+          const float s1 = (float)((d1 >> k) & 1u), s2 = (float)((d2 >> k) & 1u);
+          const float dl = dot(ax, cd.l), da = dot(ax, cd.a);
+          const float v1 = lin ? dl + dot(t1, cd.a) : da, v2 = lin ? dl + dot(t2, cd.a) : da;
+          Jr[k] = s2 * v2 - s1 * v1;
         }
       }
-      u64 mk = __ballot(act);
-      if (act) {
-        int r = nefc + __popcll(mk & lanemask_lt(lane)), da = IT(IO_jnt_dofadr, j);
-        s.J[r * NV16 + da] = (float)(-side);
-        float solref[2] = {FP(FO_jnt_solref, 2 * j), FP(FO_jnt_solref, 2 * j + 1)}, solimp[5];
-        for (int k = 0; k < 5; k++) solimp[k] = FP(FO_jnt_solimp, 5 * j + k);
-        row_params(r, C_LIMIT_JOINT, j, dist, FP(FO_jnt_margin, j), 0, solref, solimp, FP(FO_dof_invweight0, da));
-        s.blk_start[r] = r; s.blk_dim[r] = 1;
+      float jv = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV16; k++) { s.J[lane * NV16 + k] = Jr[k]; jv = fmaf(Jr[k], s.qvel[k], jv); }
+      if (valid) {
+        const float R = s.e_R[lane];
+        s.e_D[lane] = 1.0f / R;
+        s.e_aref[lane] = -s.e_B[lane] * jv - s.e_aref[lane];
       }
-      nefc += __popcll(mk);
     }
-    nblk = nefc;
-    SYNC();
-    // (3) contacts
-    int ncon = uni(s.ncon);
-    for (int c = 0; c < ncon; c++) {
-      int dim = uni(s.cdim[c]);
-      bool active = s.cdist[c] < s.cmargin[c];
-      if (!active || nefc + dim > NEFC) { if (lane == 0) s.cefc[c] = -1; continue; }
-      int g1 = s.cg1[c], g2 = s.cg2[c], b1 = IT(IO_cg_bodyid, g1), b2 = IT(IO_cg_bodyid, g2);
-      V3 pos = ld3(s.cpos + 3 * c);
-      for (int e = lane; e < dim * nv; e += 64) {
-        int k = e / nv, i = e - k * nv;
-        V3 ax = ld3(s.cframe + 9 * c + 3 * (k < 3 ? k : k - 3));
-        S6 c1 = jac_col(b1, pos, i), c2 = jac_col(b2, pos, i);
-        s.J[(nefc + k) * NV16 + i] = (k < 3) ? dot(ax, c2.l - c1.l) : dot(ax, c2.a - c1.a);
-      }
-      if (lane < dim) {
-        int k = lane;
-        float tran = FP(FO_body_invweight0, 2 * b1) + FP(FO_body_invweight0, 2 * b2), rot = FP(FO_body_invweight0, 2 * b1 + 1) + FP(FO_body_invweight0, 2 * b2 + 1);
-        row_params(nefc + k, dim == 1 ? C_CONTACT_FRICTIONLESS : C_CONTACT_ELLIPTIC, c, k == 0 ? s.cdist[c] : 0.f, k == 0 ? s.cmargin[c] : 0.f, 0.f,
-                   s.csolref + 2 * c, s.csolimp + 5 * c, k < 3 ? tran : rot);
-      }
-      if (lane == 0) { s.cefc[c] = nefc; s.blk_start[nblk] = nefc; s.blk_dim[nblk] = dim; }
-      SYNC();
-      if (lane == 0) {
-        if (dim > 1) {
-          const float* f = s.cfri + 5 * c;
-          float R0 = s.e_R[nefc];
-          float R1 = R0 / fmaxf(1e-15f, FP(FO_opt, 6));
-          s.e_R[nefc + 1] = R1;
-          for (int k = 2; k < dim; k++) s.e_R[nefc + k] = R1 * f[0] * f[0] / fmaxf(1e-15f, f[k - 1] * f[k - 1]);
-          s.cmu[c] = f[0] * sqrtf(R1 / R0);
-        } else s.cmu[c] = 0.f;
-      }
-      nefc += dim;
-      nblk++;
-    }
-    SYNC();
-    for (int r = lane; r < nefc; r += 64) {
-      s.e_D[r] = 1.0f / s.e_R[r];
-      float v = 0;
-      for (int k = 0; k < nv; k++) v += s.J[r * NV16 + k] * s.qvel[k];
-      s.e_aref[r] = -s.e_B[r] * v - s.e_K[r] * s.e_imp[r] * (s.e_pos[r] - s.e_margin[r]);
-    }
-    if (lane == 0) { s.nefc = nefc; s.nblk = nblk; }
     SYNC();
   }
 
   // ---------------------------------------------------------------- actuation / smooth acceleration
   __device__ void actuation_acceleration() {
     const int nv = m.nv;
+    if (lane < NV16) s.qfrc_actuator[lane] = 0.f;
+    SYNC();
+    if (lane < m.nu) {
+      const int d = K.ainfo & 255, qa = (K.ainfo >> 8) & 255;
+      float ctrl = s.ctrl[lane];
+      if ((K.ainfo >> 18) & 1) ctrl = fmaxf(K.acr0, fminf(K.acr1, ctrl));
+      float force = K.again * ctrl;
+      if (((K.ainfo >> 16) & 3) == 1) force += K.ab0 + K.ab1 * K.agear * s.qpos[qa] + K.ab2 * K.agear * s.qvel[d];
+      if ((K.ainfo >> 19) & 1) force = fmaxf(K.afr0, fminf(K.afr1, force));
+      atomicAdd(&s.qfrc_actuator[d], K.agear * force);  // one actuator per dof in every supported model: order-independent
+    }
+    SYNC();
     float qs = 0.f;
     if (lane < nv) {
-      int d = lane;
-      float fa = 0.f;
-      for (int a = 0; a < m.nu; a++) {
-        int j = IT(IO_act_trnid, a);
-        if (IT(IO_jnt_dofadr, j) != d) continue;
-        float ctrl = s.ctrl[a], gear = FP(FO_act_gear, a);
-        if (IT(IO_act_ctrllimited, a)) ctrl = fmaxf(FP(FO_act_ctrlrange, 2 * a), fminf(FP(FO_act_ctrlrange, 2 * a + 1), ctrl));
-        float force = FP(FO_act_gainprm, 3 * a) * ctrl;
-        if (IT(IO_act_biastype, a) == 1)
-          force += FP(FO_act_biasprm, 3 * a) + FP(FO_act_biasprm, 3 * a + 1) * gear * s.qpos[IT(IO_jnt_qposadr, j)] + FP(FO_act_biasprm, 3 * a + 2) * gear * s.qvel[d];
-        if (IT(IO_act_forcelimited, a)) force = fmaxf(FP(FO_act_forcerange, 2 * a), fminf(FP(FO_act_forcerange, 2 * a + 1), force));
-        fa += gear * force;
-      }
-      s.qfrc_actuator[d] = fa;
-      qs = s.qfrc_passive[d] - s.qfrc_bias[d] + fa;
-      s.qfrc_smooth[d] = qs;
+      qs = s.qfrc_passive[lane] - s.qfrc_bias[lane] + s.qfrc_actuator[lane];
+      s.qfrc_smooth[lane] = qs;
     }
     float as;
     {
@@ -1095,6 +1301,216 @@ struct Sim {
       as = rchol_solve<NV16>(lr, lt, linv, lane < nv ? qs : 0.f, lane);
     }
     if (lane < nv) s.qacc_smooth[lane] = as;
+    SYNC();
+  }
+
+  // ---------------------------------------------------------------- semi-implicit Euler with implicit joint damping
+  __device__ void euler() {
+    const int nv = m.nv;
+    const float h = opt_h;
+    float qa;
+    {
+      float hr[NV16], hinv[NV16], ht[NV16];
+      const int rr = lane & (NV16 - 1);
+      const float hd = h * __shfl(K.damping, rr);
+#pragma unroll
+      for (int k = 0; k < NV16; k++) hr[k] = s.M[rr * NVP + k] + (rr == k && rr < nv ? hd : 0.f);
+      rchol_factor<NV16>(hr, hinv);
+      if (lane < NV16) {
+#pragma unroll
+        for (int k = 0; k < NV16; k++) s.H[lane * NVP + k] = hr[k];
+      }
+      SYNC();
+#pragma unroll
+      for (int k = 0; k < NV16; k++) ht[k] = s.H[k * NVP + rr];
+      qa = rchol_solve<NV16>(hr, ht, hinv, lane < nv ? s.qfrc_smooth[lane] + s.qfrc_constraint[lane] : 0.f, lane);
+    }
+    if (lane < nv) { s.qvel[lane] += h * qa; s.qacc_ws[lane] = s.qacc[lane]; }
+    SYNC();
+    // positions: lane b integrates the joint of body b
+    const int jt = K.binfo & 15, pa = (K.binfo >> 4) & 255, da = (K.binfo >> 12) & 255;
+    if (lane < m.nbody && jt != 15) {
+      if (jt == JNT_FREE) {
+        for (int k = 0; k < 3; k++) s.qpos[pa + k] += h * s.qvel[da + k];
+        const V3 w = ld3(s.qvel + da + 3);
+        const float wn = norm(w), ang = wn * h;
+        if (ang > 1e-15f) {
+          float sn, cs;
+          sincos_f(0.5f * ang, sn, cs);
+          const float k = sn / wn;
+          const Q4 dq = {cs, w.x * k, w.y * k, w.z * k};
+          stq(s.qpos + pa + 3, qnorm(qmul(ldq(s.qpos + pa + 3), dq)));
+        }
+      } else s.qpos[pa] += h * s.qvel[da];
+    }
+    SYNC();
+  }
+
+  // ---------------------------------------------------------------- built-in controller: OSC_POSE + GRIP
+  __device__ void ctrl_set_goal(const float* action) {
+    const DCtrl& c = m.ctrl;
+    float sc[6];
+    for (int i = 0; i < 6; i++) {
+      float scale = fabsf(c.out_max[i] - c.out_min[i]) / fabsf(c.in_max[i] - c.in_min[i]);
+      float a = fmaxf(c.in_min[i], fminf(c.in_max[i], action[i]));
+      sc[i] = (a - 0.5f * (c.in_max[i] + c.in_min[i])) * scale + 0.5f * (c.out_max[i] + c.out_min[i]);
+    }
+    V3 op = ld3(s.spos + 3 * c.base_site), ep = ld3(s.spos + 3 * c.eef_site);
+    M3 oR = ldm(s.smat + 9 * c.base_site), eR = ldm(s.smat + 9 * c.eef_site);
+    V3 gp = mtv(oR, ep - op) + v3(sc[0], sc[1], sc[2]);
+    V3 d = v3(sc[3], sc[4], sc[5]);
+    float ang = norm(d);
+    Q4 qe = {1, 0, 0, 0};
+    if (ang != 0.f) { float sn, cs; sincos_f(0.5f * ang, sn, cs); sn /= ang; qe.w = cs; qe.x = d.x * sn; qe.y = d.y * sn; qe.z = d.z * sn; }
+    // reference quat2mat: q *= sqrt(2/n); R = I - ... (transform_utils.py:461-487)
+    float n = qe.w * qe.w + qe.x * qe.x + qe.y * qe.y + qe.z * qe.z, sq = sqrtf(2.0f / n);
+    float q[4] = {qe.w * sq, qe.x * sq, qe.y * sq, qe.z * sq};
+    M3 Re;
+    Re.m[0] = 1.0f - q[2] * q[2] - q[3] * q[3]; Re.m[1] = q[1] * q[2] - q[3] * q[0]; Re.m[2] = q[1] * q[3] + q[2] * q[0];
+    Re.m[3] = q[1] * q[2] + q[3] * q[0]; Re.m[4] = 1.0f - q[1] * q[1] - q[3] * q[3]; Re.m[5] = q[2] * q[3] - q[1] * q[0];
+    Re.m[6] = q[1] * q[3] - q[2] * q[0]; Re.m[7] = q[2] * q[3] + q[1] * q[0]; Re.m[8] = 1.0f - q[1] * q[1] - q[2] * q[2];
+    M3 go = mm(Re, mtm(oR, eR));
+    SYNC();
+    if (lane == 0) {
+      st3(s.cstate + RSIM_CS_GOALPOS, gp);
+      stm(s.cstate + RSIM_CS_GOALORI, go);
+      if (c.ngrip > 0) {
+        float a = action[6], sg = a > 0 ? 1.f : (a < 0 ? -1.f : 0.f);
+        for (int i = 0; i < c.ngrip; i++) s.cstate[RSIM_CS_GRIP + i] = fmaxf(-1.f, fminf(1.f, s.cstate[RSIM_CS_GRIP + i] + c.grip_sign[i] * c.grip_speed * sg));
+      }
+    }
+    SYNC();
+  }
+
+  // reset_goal + initial_joint capture (Controller.__init__ / OSC.reset_goal)
+  __device__ void ctrl_reset() {
+    const DCtrl& c = m.ctrl;
+    if (lane < c.ndof) s.cstate[RSIM_CS_Q0 + lane] = s.qpos[c.qpos_idx[lane]];
+    if (lane == 0) {
+      st3(s.cstate + RSIM_CS_GOALPOS, ld3(s.spos + 3 * c.eef_site));
+      for (int k = 0; k < 9; k++) s.cstate[RSIM_CS_GOALORI + k] = s.smat[9 * c.eef_site + k];
+      for (int i = 0; i < RSIM_GRIP_MAX; i++) s.cstate[RSIM_CS_GRIP + i] = 0.f;
+    }
+    SYNC();
+  }
+
+  // OperationalSpaceController.run_controller (osc.py:403-495) + SimpleGripController, tau clipped into ctrl.
+  // Lambda^-1 = J Ma^-1 J^T = Y^T Y with Y = La^-1 J^T (register Cholesky of the arm block, 6 forward solves);
+  // N^T Ma tmp = Ma tmp - J^T Lambda (J tmp), so no explicit inverse of Ma is ever formed.
+  __device__ void ctrl_run() {
+    const DCtrl& c = m.ctrl;
+    const int n = c.ndof;
+    constexpr int NA = RSIM_ARM_MAX;
+    float* Jm = s.scratch;            // [6][NA]  arm Jacobian (lin rows 0..2, ang rows 3..5)
+    float* Li = s.scratch + 48;       // [6][6]   Lambda^-1
+    float* vv = s.scratch + 84;       // 6: J tmp
+    const int eb = __shfl(K.sbody, c.eef_site), bb = __shfl(K.sbody, c.base_site);
+    const V3 ep = ld3(s.spos + 3 * c.eef_site), op = ld3(s.spos + 3 * c.base_site);
+    // this lane's arm dof (lanes 0..n-1) and its joint-space quantities
+    const int di = lane < n ? c.dof_idx[lane] : 0, qi = lane < n ? c.qpos_idx[lane] : 0;
+    const float qd_i = lane < n ? s.qvel[di] : 0.f;
+    const float tmp_i = lane < n ? c.nullspace_kp * (s.cstate[RSIM_CS_Q0 + lane] - s.qpos[qi]) - 2.f * sqrtf(c.nullspace_kp) * qd_i : 0.f;
+    // Jacobian column of the eef site for this lane's dof
+    S6 jc = {v3(0, 0, 0), v3(0, 0, 0)};
+    if (lane < n) jc = jac_col(eb, ep, di);
+    if (lane < NA) {
+      Jm[0 * NA + lane] = jc.l.x; Jm[1 * NA + lane] = jc.l.y; Jm[2 * NA + lane] = jc.l.z;
+      Jm[3 * NA + lane] = jc.a.x; Jm[4 * NA + lane] = jc.a.y; Jm[5 * NA + lane] = jc.a.z;
+    }
+    // arm block of M: row i in lane i, Cholesky in registers
+    float mr[NA], minv[NA];
+    {
+      int dk[NA];
+#pragma unroll
+      for (int k = 0; k < NA; k++) dk[k] = k < n ? c.dof_idx[k] : 0;
+#pragma unroll
+      for (int k = 0; k < NA; k++) mr[k] = (lane < n && k < n) ? s.M[di * NVP + dk[k]] : ((lane & (NA - 1)) == k ? 1.f : 0.f);
+    }
+    float matmp = 0.f;   // (Ma tmp)_i
+#pragma unroll
+    for (int k = 0; k < NA; k++) matmp = fmaf(mr[k], bcast(tmp_i, k), matmp);
+    rchol_factor<NA>(mr, minv);
+    // Y[:, r] = La^-1 J[r, :]^T  (component i in lane i)
+    float Y[6];
+    Y[0] = rchol_fwd<NA>(mr, minv, jc.l.x, lane); Y[1] = rchol_fwd<NA>(mr, minv, jc.l.y, lane); Y[2] = rchol_fwd<NA>(mr, minv, jc.l.z, lane);
+    Y[3] = rchol_fwd<NA>(mr, minv, jc.a.x, lane); Y[4] = rchol_fwd<NA>(mr, minv, jc.a.y, lane); Y[5] = rchol_fwd<NA>(mr, minv, jc.a.z, lane);
+    // Lambda^-1[r][q] = sum_i Y[i][r] Y[i][q]  (21 unique entries, reduced over the 8 row lanes with DPP row adds)
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int q = r; q < 6; q++) {
+        float p = lane < NA ? Y[r] * Y[q] : 0.f;
+        p += dpp_f<0x111>(p); p += dpp_f<0x112>(p); p += dpp_f<0x114>(p);   // row_shr 1,2,4: lane 7 holds the sum of lanes 0..7
+        if (lane == 7) { Li[r * 6 + q] = p; Li[q * 6 + r] = p; }
+      }
+    // J tmp
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      float p = lane < NA ? comp6(jc, r < 3 ? r + 3 : r - 3) * tmp_i : 0.f;
+      p += dpp_f<0x111>(p); p += dpp_f<0x112>(p); p += dpp_f<0x114>(p);
+      if (lane == 7) vv[r] = p;
+    }
+    SYNC();
+    // operational-space errors and wrench (uniform small algebra)
+    const M3 oR = ldm(s.smat + 9 * c.base_site), eR = ldm(s.smat + 9 * c.eef_site);
+    const V3 gpos = ld3(s.cstate + RSIM_CS_GOALPOS);
+    const M3 gori = ldm(s.cstate + RSIM_CS_GOALORI);
+    const V3 perr = op + mv(oR, gpos) - ep;
+    const M3 dori = mm(oR, gori);
+    const V3 oerr = (cross(col(eR, 0), col(dori, 0)) + cross(col(eR, 1), col(dori, 1)) + cross(col(eR, 2), col(dori, 2))) * 0.5f;
+    // site velocities from the body spatial velocities of the velocity stage: v = cvel.l + w x (p - com)
+    const S6 ce = ld6(s.u.v.cvel + 8 * eb), cb = ld6(s.u.v.cvel + 8 * bb);
+    const V3 evl = ce.l + cross(ce.a, ep - ld3(s.rootcom + 3 * s.broot[eb])), bvl = cb.l + cross(cb.a, op - ld3(s.rootcom + 3 * s.broot[bb]));
+    const V3 dvl = evl - bvl, dva = ce.a - cb.a;
+    float F[3] = {perr.x * c.kp[0] - dvl.x * c.kd[0], perr.y * c.kp[1] - dvl.y * c.kd[1], perr.z * c.kp[2] - dvl.z * c.kd[2]};
+    float T[3] = {oerr.x * c.kp[3] - dva.x * c.kd[3], oerr.y * c.kp[4] - dva.y * c.kd[4], oerr.z * c.kp[5] - dva.z * c.kd[5]};
+    float wrench[6], z[6];
+    // 6x6 SPD solves with Lambda^-1: register Cholesky, row r in lane r
+    float lr6[NA], linv6[NA], lt6[NA];
+#pragma unroll
+    for (int k = 0; k < NA; k++) lr6[k] = ((lane & (NA - 1)) < 6 && k < 6) ? Li[(lane & (NA - 1)) * 6 + k] : ((lane & (NA - 1)) == k ? 1.f : 0.f);
+    if (c.uncouple) {
+      float lp[9], lo[9];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) { lp[r * 3 + q] = Li[r * 6 + q]; lo[r * 3 + q] = Li[(3 + r) * 6 + 3 + q]; }
+      solve3(lp, F, wrench);
+      solve3(lo, T, wrench + 3);
+    }
+    rchol_factor<NA>(lr6, linv6);
+    SYNC();
+    float* Lt = s.scratch + 96;  // [8][8] transpose staging
+    if (lane < NA) {
+#pragma unroll
+      for (int k = 0; k < NA; k++) Lt[lane * NA + k] = lr6[k];
+    }
+    SYNC();
+#pragma unroll
+    for (int k = 0; k < NA; k++) lt6[k] = Lt[k * NA + (lane & (NA - 1))];
+    {
+      const float zl = rchol_solve<NA>(lr6, lt6, linv6, lane < 6 ? vv[lane] : 0.f, lane);
+#pragma unroll
+      for (int r = 0; r < 6; r++) z[r] = bcast(zl, r);
+      if (!c.uncouple) {
+        const float wl = rchol_solve<NA>(lr6, lt6, linv6, lane < 3 ? F[lane] : (lane < 6 ? T[lane - 3] : 0.f), lane);
+#pragma unroll
+        for (int r = 0; r < 6; r++) wrench[r] = bcast(wl, r);
+      }
+    }
+    if (lane < n) {
+      float tq = s.qfrc_bias[di] + matmp;
+#pragma unroll
+      for (int r = 0; r < 6; r++) tq = fmaf(comp6(jc, r < 3 ? r + 3 : r - 3), wrench[r] - z[r], tq);
+      s.cstate[RSIM_CS_TAU + lane] = tq;
+      const int a = c.act_idx[lane];
+      s.ctrl[a] = fmaxf(FP(FO_act_ctrlrange, 2 * a), fminf(FP(FO_act_ctrlrange, 2 * a + 1), tq));
+    }
+    if (lane < c.ngrip) {
+      const int a = c.grip_act[lane];
+      const float lo_ = FP(FO_act_ctrlrange, 2 * a), hi_ = FP(FO_act_ctrlrange, 2 * a + 1);
+      s.ctrl[a] = fmaxf(lo_, fminf(hi_, 0.5f * (hi_ + lo_) + 0.5f * (hi_ - lo_) * s.cstate[RSIM_CS_GRIP + lane]));
+    }
     SYNC();
   }
 
@@ -1201,15 +1617,17 @@ struct Sim {
     {
       const int r = rw.valid ? lane : 0;
 #pragma unroll
-      for (int k = 0; k < NV16; k++) rw.J[k] = rw.valid ? s.J[r * NV16 + k] : 0.f;
-      rw.D = s.e_D[r]; rw.R = s.e_R[r]; rw.aref = rw.valid ? s.e_aref[r] : 0.f; rw.fl = s.e_fl[r]; rw.type = rw.valid ? s.e_type[r] : -1;
+      for (int k = 0; k < NV16; k++) rw.J[k] = s.J[lane * NV16 + k];  // rows >= n were written as zeros
+      const int desc = rw.valid ? s.e_desc[r] : 0;
+      rw.type = rw.valid ? (desc & 15) : -1;
+      rw.D = s.e_D[r]; rw.R = s.e_R[r]; rw.aref = rw.valid ? s.e_aref[r] : 0.f; rw.fl = s.e_fl[r];
       rw.ell = rw.type == C_CONTACT_ELLIPTIC;
-      const int c = rw.ell ? s.e_id[r] : 0;
-      rw.head = rw.ell ? s.cefc[c] : lane; rw.kk = lane - rw.head; rw.dim = rw.ell ? s.cdim[c] : 1;
+      const int c = rw.ell ? (desc >> 4) & 255 : 0;
+      rw.kk = rw.ell ? (desc >> 12) & 15 : 0; rw.head = lane - rw.kk; rw.dim = rw.ell ? s.cdim[c] : 1;
       rw.mu = s.cmu[c];
 #pragma unroll
       for (int j = 0; j < CD - 1; j++) rw.fj[j] = s.cfri[5 * c + j];
-      rw.fr_own = rw.kk == 0 ? rw.mu : s.cfri[5 * c + (rw.ell ? rw.kk - 1 : 0)];
+      rw.fr_own = rw.kk == 0 ? rw.mu : s.cfri[5 * c + rw.kk - 1];
       rw.Dm = s.e_D[rw.ell ? rw.head : r] / fmaxf(rw.mu * rw.mu * (1 + rw.mu * rw.mu), 1e-15f);
     }
     // M: row i in lane i (matrix-vector products) and in the MFMA accumulator layout (Hessian seed)
@@ -1272,11 +1690,11 @@ struct Sim {
           }
         }
 #pragma unroll
-        for (int k = 0; k < NV16; k++) s.W[lane * NV16 + k] = w[k];
+        for (int k = 0; k < NV16; k++) s.u.W[lane * NV16 + k] = w[k];
       }
       SYNC();
       v4f acc = Macc;
-      for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s.W[64 * c + lane], s.J[64 * c + lane], acc, 0, 0, 0);
+      for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s.u.W[64 * c + lane], s.J[64 * c + lane], acc, 0, 0, 0);
 #pragma unroll
       for (int v = 0; v < 4; v++) s.H[(4 * (lane >> 4) + v) * NVP + (lane & 15)] = acc[v];
       SYNC();
@@ -1358,6 +1776,7 @@ struct Sim {
     SYNC();
   }
 
+
   __device__ void fwd_constraint() {
     if (s.nefc == 0) {
       if (lane < m.nv) { s.qacc[lane] = s.qacc_smooth[lane]; s.qfrc_constraint[lane] = 0.f; }
@@ -1366,186 +1785,6 @@ struct Sim {
       return;
     }
     solve_newton();
-  }
-
-  // ---------------------------------------------------------------- semi-implicit Euler with implicit joint damping
-  __device__ void euler() {
-    const int nv = m.nv;
-    const float h = FP(FO_opt, 0);
-    float qa;
-    {
-      float hr[NV16], hinv[NV16], ht[NV16];
-      const int rr = lane & (NV16 - 1);
-      const float hd = rr < nv ? h * FP(FO_dof_damping, rr) : 0.f;
-#pragma unroll
-      for (int k = 0; k < NV16; k++) hr[k] = (rr < nv && k < nv) ? s.M[rr * NVP + k] + (rr == k ? hd : 0.f) : (rr == k ? 1.f : 0.f);
-      rchol_factor<NV16>(hr, hinv);
-      if (lane < NV16) {
-#pragma unroll
-        for (int k = 0; k < NV16; k++) s.H[lane * NVP + k] = hr[k];
-      }
-      SYNC();
-#pragma unroll
-      for (int k = 0; k < NV16; k++) ht[k] = s.H[k * NVP + rr];
-      qa = rchol_solve<NV16>(hr, ht, hinv, lane < nv ? s.qfrc_smooth[lane] + s.qfrc_constraint[lane] : 0.f, lane);
-    }
-    if (lane < nv) { s.qvel[lane] += h * qa; s.qacc_ws[lane] = s.qacc[lane]; }
-    SYNC();
-    if (lane < m.njnt) {
-      int j = lane, pa = IT(IO_jnt_qposadr, j), da = IT(IO_jnt_dofadr, j), t = IT(IO_jnt_type, j);
-      if (t == JNT_FREE || t == JNT_BALL) {
-        if (t == JNT_FREE) { for (int k = 0; k < 3; k++) s.qpos[pa + k] += h * s.qvel[da + k]; pa += 3; da += 3; }
-        V3 w = ld3(s.qvel + da);
-        float ang = norm(w) * h;
-        if (ang > 1e-15f) stq(s.qpos + pa, qnorm(qmul(ldq(s.qpos + pa), axisangle(normalized(w), ang))));
-      } else s.qpos[pa] += h * s.qvel[da];
-    }
-    SYNC();
-  }
-
-  // ---------------------------------------------------------------- built-in controller: OSC_POSE + GRIP
-  __device__ void ctrl_set_goal(const float* action) {
-    const DCtrl& c = m.ctrl;
-    float sc[6];
-    for (int i = 0; i < 6; i++) {
-      float scale = fabsf(c.out_max[i] - c.out_min[i]) / fabsf(c.in_max[i] - c.in_min[i]);
-      float a = fmaxf(c.in_min[i], fminf(c.in_max[i], action[i]));
-      sc[i] = (a - 0.5f * (c.in_max[i] + c.in_min[i])) * scale + 0.5f * (c.out_max[i] + c.out_min[i]);
-    }
-    V3 op = ld3(s.spos + 3 * c.base_site), ep = ld3(s.spos + 3 * c.eef_site);
-    M3 oR = ldm(s.smat + 9 * c.base_site), eR = ldm(s.smat + 9 * c.eef_site);
-    V3 gp = mtv(oR, ep - op) + v3(sc[0], sc[1], sc[2]);
-    V3 d = v3(sc[3], sc[4], sc[5]);
-    float ang = norm(d);
-    Q4 qe = {1, 0, 0, 0};
-    if (ang != 0.f) { float sn = sinf(0.5f * ang) / ang; qe.w = cosf(0.5f * ang); qe.x = d.x * sn; qe.y = d.y * sn; qe.z = d.z * sn; }
-    // reference quat2mat: q *= sqrt(2/n); R = I - ... (transform_utils.py:461-487)
-    float n = qe.w * qe.w + qe.x * qe.x + qe.y * qe.y + qe.z * qe.z, sq = sqrtf(2.0f / n);
-    float q[4] = {qe.w * sq, qe.x * sq, qe.y * sq, qe.z * sq};
-    M3 Re;
-    Re.m[0] = 1.0f - q[2] * q[2] - q[3] * q[3]; Re.m[1] = q[1] * q[2] - q[3] * q[0]; Re.m[2] = q[1] * q[3] + q[2] * q[0];
-    Re.m[3] = q[1] * q[2] + q[3] * q[0]; Re.m[4] = 1.0f - q[1] * q[1] - q[3] * q[3]; Re.m[5] = q[2] * q[3] - q[1] * q[0];
-    Re.m[6] = q[1] * q[3] - q[2] * q[0]; Re.m[7] = q[2] * q[3] + q[1] * q[0]; Re.m[8] = 1.0f - q[1] * q[1] - q[2] * q[2];
-    M3 go = mm(Re, mtm(oR, eR));
-    SYNC();
-    if (lane == 0) {
-      st3(s.cstate + RSIM_CS_GOALPOS, gp);
-      stm(s.cstate + RSIM_CS_GOALORI, go);
-      if (c.ngrip > 0) {
-        float a = action[6], sg = a > 0 ? 1.f : (a < 0 ? -1.f : 0.f);
-        for (int i = 0; i < c.ngrip; i++) s.cstate[RSIM_CS_GRIP + i] = fmaxf(-1.f, fminf(1.f, s.cstate[RSIM_CS_GRIP + i] + c.grip_sign[i] * c.grip_speed * sg));
-      }
-    }
-    SYNC();
-  }
-
-  // reset_goal + initial_joint capture (Controller.__init__ / OSC.reset_goal)
-  __device__ void ctrl_reset() {
-    const DCtrl& c = m.ctrl;
-    if (lane < c.ndof) s.cstate[RSIM_CS_Q0 + lane] = s.qpos[c.qpos_idx[lane]];
-    if (lane == 0) {
-      st3(s.cstate + RSIM_CS_GOALPOS, ld3(s.spos + 3 * c.eef_site));
-      for (int k = 0; k < 9; k++) s.cstate[RSIM_CS_GOALORI + k] = s.smat[9 * c.eef_site + k];
-      for (int i = 0; i < RSIM_GRIP_MAX; i++) s.cstate[RSIM_CS_GRIP + i] = 0.f;
-    }
-    SYNC();
-  }
-
-  __device__ void ctrl_run() {
-    const DCtrl& c = m.ctrl;
-    const int nv = m.nv, n = c.ndof;
-    constexpr int NA = RSIM_ARM_MAX;
-    float* Jm = s.scratch;            // 6 x NA   arm Jacobian
-    float* X = s.scratch + 6 * NA;    // NA x 6   Minv J^T  (stored [i*6 + r])
-    float* vel = s.scratch + 12 * NA; // 12: eef vel(6), base vel(6)
-    float* Ma = s.H;                  // arm mass sub-block (NVP stride), factor into s.Lh
-    int eb = IT(IO_site_bodyid, c.eef_site), bb = IT(IO_site_bodyid, c.base_site);
-    V3 ep = ld3(s.spos + 3 * c.eef_site), op = ld3(s.spos + 3 * c.base_site);
-    if (lane < 6 * n) {
-      int r = lane / n, i = lane - r * n;
-      S6 jc = jac_col(eb, ep, c.dof_idx[i]);
-      float v = r < 3 ? (r == 0 ? jc.l.x : (r == 1 ? jc.l.y : jc.l.z)) : (r == 3 ? jc.a.x : (r == 4 ? jc.a.y : jc.a.z));
-      Jm[r * NA + i] = v;
-    }
-    if (lane < 12) {
-      int which = lane / 6, r = lane - 6 * which, b = which ? bb : eb;
-      V3 p = which ? op : ep;
-      float v = 0.f;
-      u64 mk = mask2(IO_body_dofmask, b);
-      while (mk) {
-        int k = __ffsll((long long)mk) - 1;
-        mk &= mk - 1;
-        S6 jc = jac_col(b, p, k);
-        float jv = r < 3 ? (r == 0 ? jc.l.x : (r == 1 ? jc.l.y : jc.l.z)) : (r == 3 ? jc.a.x : (r == 4 ? jc.a.y : jc.a.z));
-        v += jv * s.qvel[k];
-      }
-      vel[lane] = v;
-    }
-    for (int e = lane; e < n * n; e += 64) { int i = e / n, j = e - i * n; Ma[i * NVP + j] = s.M[c.dof_idx[i] * NVP + c.dof_idx[j]]; }
-    SYNC();
-    chol_factor<NVP>(s.Lh, s.invdiag_h, Ma, n, lane);
-    // X = Minv J^T : lane group r (6 groups of 8 lanes) solves column r
-    {
-      int r = lane >> 3, i = lane & 7;
-      float x = (r < 6 && i < n) ? Jm[r * NA + i] : 0.f;
-      // forward / backward substitution inside 8-lane groups
-      for (int k = 0; k < n; k++) {
-        float xk = __shfl(x, (lane & ~7) + k) * s.invdiag_h[k];
-        if (i == k) x = xk; else if (i > k && i < n) x -= s.Lh[i * NVP + k] * xk;
-      }
-      for (int k = n - 1; k >= 0; k--) {
-        float xk = __shfl(x, (lane & ~7) + k) * s.invdiag_h[k];
-        if (i == k) x = xk; else if (i < k) x -= s.Lh[k * NVP + i] * xk;
-      }
-      if (r < 6 && i < n) X[i * 6 + r] = x;
-    }
-    SYNC();
-    // everything below is tiny dense algebra evaluated uniformly by all lanes
-    float lfi[36];
-    for (int r = 0; r < 6; r++)
-      for (int q = 0; q < 6; q++) { float sv = 0; for (int k = 0; k < n; k++) sv += Jm[r * NA + k] * X[k * 6 + q]; lfi[r * 6 + q] = sv; }
-    M3 oR = ldm(s.smat + 9 * c.base_site), eR = ldm(s.smat + 9 * c.eef_site);
-    V3 gpos = ld3(s.cstate + RSIM_CS_GOALPOS);
-    M3 gori = ldm(s.cstate + RSIM_CS_GOALORI);
-    V3 perr = op + mv(oR, gpos) - ep;
-    M3 dori = mm(oR, gori);
-    V3 oerr = (cross(col(eR, 0), col(dori, 0)) + cross(col(eR, 1), col(dori, 1)) + cross(col(eR, 2), col(dori, 2))) * 0.5f;
-    float F[3], T[3];
-    float pe[3] = {perr.x, perr.y, perr.z}, oe[3] = {oerr.x, oerr.y, oerr.z};
-    for (int k = 0; k < 3; k++) {
-      F[k] = pe[k] * c.kp[k] - (vel[k] - vel[6 + k]) * c.kd[k];
-      T[k] = oe[k] * c.kp[3 + k] - (vel[3 + k] - vel[9 + k]) * c.kd[3 + k];
-    }
-    float wrench[6];
-    if (c.uncouple) {
-      float lp[9], lo[9];
-      for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) { lp[r * 3 + q] = lfi[r * 6 + q]; lo[r * 3 + q] = lfi[(3 + r) * 6 + 3 + q]; }
-      spd_solve_small<3>(lp, F, wrench);
-      spd_solve_small<3>(lo, T, wrench + 3);
-    } else {
-      float w[6] = {F[0], F[1], F[2], T[0], T[1], T[2]};
-      spd_solve_small<6>(lfi, w, wrench);
-    }
-    // nullspace: N^T M tmp = M tmp - J^T Lambda_full (J tmp)
-    float kv = sqrtf(c.nullspace_kp) * 2, tmp[NA], jt[6], z[6];
-    for (int i = 0; i < n; i++) tmp[i] = c.nullspace_kp * (s.cstate[RSIM_CS_Q0 + i] - s.qpos[c.qpos_idx[i]]) - kv * s.qvel[c.dof_idx[i]];
-    for (int r = 0; r < 6; r++) { float sv = 0; for (int k = 0; k < n; k++) sv += Jm[r * NA + k] * tmp[k]; jt[r] = sv; }
-    spd_solve_small<6>(lfi, jt, z);
-    if (lane < n) {
-      int i = lane;
-      float tq = s.qfrc_bias[c.dof_idx[i]];
-      for (int r = 0; r < 6; r++) tq += Jm[r * NA + i] * (wrench[r] - z[r]);
-      for (int k = 0; k < n; k++) tq += Ma[i * NVP + k] * tmp[k];
-      s.cstate[RSIM_CS_TAU + i] = tq;
-      int a = c.act_idx[i];
-      s.ctrl[a] = fmaxf(FP(FO_act_ctrlrange, 2 * a), fminf(FP(FO_act_ctrlrange, 2 * a + 1), tq));
-    }
-    if (lane < c.ngrip) {
-      int a = c.grip_act[lane];
-      float lo_ = FP(FO_act_ctrlrange, 2 * a), hi_ = FP(FO_act_ctrlrange, 2 * a + 1);
-      s.ctrl[a] = fmaxf(lo_, fminf(hi_, 0.5f * (hi_ + lo_) + 0.5f * (hi_ - lo_) * s.cstate[RSIM_CS_GRIP + lane]));
-    }
-    SYNC();
   }
 };
 
@@ -1561,22 +1800,23 @@ __global__ __launch_bounds__(64) void k_step(DModel m, DBatch b, const float* __
   const float* fp = m.ft + (size_t)env * m.fstride;
   Sim<SM> sim(s, m, fp, lane, b.prof);
   sim.pf.start();
-  for (int i = lane; i < m.nit; i += 64) s.tab_i[i] = m.it[i];
-  for (int i = lane; i < m.nft; i += 64) s.tab_f[i] = fp[i];
   // ---- load state
   for (int i = lane; i < m.nq; i += 64) s.qpos[i] = b.qpos[(size_t)env * m.nq + i];
   for (int i = lane; i < m.nv; i += 64) { s.qvel[i] = b.qvel[(size_t)env * m.nv + i]; s.qacc_ws[i] = b.qacc_ws[(size_t)env * m.nv + i]; }
+  if (lane >= m.nv && lane < NV) { s.qvel[lane] = 0.f; s.qacc_ws[lane] = 0.f; s.qacc[lane] = 0.f; }
   for (int i = lane; i < m.nu; i += 64) s.ctrl[i] = b.ctrl[(size_t)env * m.nu + i];
   if (lane < RSIM_CS_SIZE) s.cstate[lane] = b.cstate[(size_t)env * RSIM_CS_SIZE + lane];
-  if (lane == 0) { s.ncon = 0; s.nefc = 0; s.nblk = 0; s.niter = 0; }
-  SYNC();
+  if (lane == 0) { s.ncon = 0; s.nefc = 0; s.niter = 0; }
+  sim.load_constants();
   const float* act = actions ? actions + (size_t)env * m.ctrl.action_dim : nullptr;
   float time = b.time[env];
   sim.pf.mark(RP_LOAD);
   for (int sub = 0; sub < n_sub; sub++) {
-    sim.kinematics();
+    V3 xp; Q4 xq;
+    sim.kinematics(xp, xq);
+    sim.geom_site_frames();
     sim.pf.mark(RP_KIN);
-    sim.com_pos();
+    sim.com_pos(xp, xq);
     sim.pf.mark(RP_COM);
     sim.crb();
     sim.pf.mark(RP_CRB);
@@ -1584,7 +1824,7 @@ __global__ __launch_bounds__(64) void k_step(DModel m, DBatch b, const float* __
     sim.pf.mark(RP_NARROW);
     sim.make_constraint();
     sim.pf.mark(RP_MAKEC);
-    sim.velocity();
+    sim.velocity(xp, xq);
     sim.pf.mark(RP_VEL);
     if (flags & RF_CTRL) {
       if ((flags & RF_SETGOAL) && sub == 0 && act) sim.ctrl_set_goal(act);
@@ -1602,7 +1842,7 @@ __global__ __launch_bounds__(64) void k_step(DModel m, DBatch b, const float* __
     if (flags & RF_INTEGRATE) {
       sim.euler();
       sim.pf.mark(RP_EULER);
-      time += s.tab_f[m.fo[FO_opt]];
+      time += sim.opt_h;
     }
     sim.pf.count(RP_N_SUB, 1);
   }
@@ -1614,10 +1854,10 @@ __global__ __launch_bounds__(64) void k_step(DModel m, DBatch b, const float* __
   if (lane == 0) b.time[env] = time;
   if (flags & RF_DEBUG) {
     const int nb = m.nbody, nv = m.nv;
-    for (int i = lane; i < nb * 3; i += 64) { b.xpos[(size_t)env * nb * 3 + i] = s.xpos[i]; b.rootcom[(size_t)env * nb * 3 + i] = s.rootcom[i]; }
+    for (int i = lane; i < nb * 3; i += 64) { b.xpos[(size_t)env * nb * 3 + i] = s.xpos[i]; b.rootcom[(size_t)env * nb * 3 + i] = s.rootcom[3 * s.broot[i / 3] + i % 3]; }
     for (int i = lane; i < nb * 4; i += 64) b.xquat[(size_t)env * nb * 4 + i] = s.xquat[i];
     for (int e = lane; e < nv * nv; e += 64) { int i = e / nv, j = e - i * nv; b.qM[(size_t)env * nv * nv + e] = s.M[i * SM::NVP + j]; }
-    for (int i = lane; i < nv * 6; i += 64) b.cdof[(size_t)env * nv * 6 + i] = s.cdof[i];
+    for (int e = lane; e < nv * 6; e += 64) b.cdof[(size_t)env * nv * 6 + e] = s.cdof[(e / 6) * 8 + e % 6];
     for (int i = lane; i < nv; i += 64) {
       size_t o = (size_t)env * nv + i;
       b.qfrc_bias[o] = s.qfrc_bias[i]; b.qfrc_passive[o] = s.qfrc_passive[i];
@@ -1649,15 +1889,16 @@ __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const uns
   if (mask && !mask[env]) return;
   const float* fp = m.ft + (size_t)env * m.fstride;
   Sim<SM> sim(s, m, fp, lane, nullptr);
-  for (int i = lane; i < m.nit; i += 64) s.tab_i[i] = m.it[i];
-  for (int i = lane; i < m.nft; i += 64) s.tab_f[i] = fp[i];
   for (int i = lane; i < m.nq; i += 64) s.qpos[i] = b.qpos[(size_t)env * m.nq + i];
   if (lane < RSIM_CS_SIZE) s.cstate[lane] = 0.f;
-  SYNC();
-  sim.kinematics();
+  sim.load_constants();
+  V3 xp; Q4 xq;
+  sim.kinematics(xp, xq);
+  sim.geom_site_frames();
   sim.ctrl_reset();
   if (lane < RSIM_CS_SIZE) b.cstate[(size_t)env * RSIM_CS_SIZE + lane] = s.cstate[lane];
 }
+
 
 // ------------------------------------------------------------------------------------------------------------
 // standalone batched OSC torque law on explicit inputs (unit-test entry: parity against the reference's own
