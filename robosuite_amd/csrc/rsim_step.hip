@@ -163,18 +163,21 @@ struct Smem {
   static constexpr int NCON_ = NCON;
   static constexpr int NB_ = NB;
   float qpos[NV + 8], qvel[NV], qacc[NV], qacc_ws[NV], ctrl[NV];
-  float xpos[NB * 3], xquat[NB * 4], xmat[NB * 9];
-  float rootcom[NB * 3];
+  float xpos[NB * 3], xquat[NB * 4];
+  float rootcom[(RSIM_MAXDYNROOT + 1) * 3];  // subtree COM per articulated tree; last slot = 0 for static trees
   float cinert[NB * 10 + 16];  // +16: the MFMA B-operand read pattern runs 6 floats past the last row
   float cdof[NV * 8];          // stride 8, components 6..7 stay zero (MFMA K padding)
   // phase-local storage: crb -> broadphase -> velocity -> controller read cvel -> solver W
   union {
-    struct { float crbD[NV * 16], fpad[NV * 8]; } c;                                                          // crb()
-    struct { int cand[NPAIR]; } b;                                                                            // collision()
-    struct { float cvel[NB * 8], cvb[NV * 8], cdd[NV * 8], cacc[NB * 8], cf[NB * 16], F[NV * 16]; } v;        // velocity(), ctrl reads cvel
-    float W[NEFC * NV];                                                                                       // solve_newton(): Hessian-weighted rows
+    struct { float crbD[NV * 16], fpad[NV * 8]; } c;                                       // crb()
+    struct { int cand[NPAIR]; float poly[96]; } b;                                         // collision(): candidates, box-box clip polygons
+    struct { float cvel[NB * 8]; union { struct { float cvb[NV * 8], cdd[NV * 8]; }; float cacc[NB * 8]; };
+             union { float cf[NB * 16]; float F[NV * 16]; }; } v;                          // velocity(): later stages overwrite dead earlier ones
+    struct { float cvel[NB * 8]; float Jm[48], Li[36], vv[8], Lt[64]; } k;                  // ctrl_run(): cvel stays live from velocity()
+    float W[NEFC * NV];                                                                    // solve_newton(): Hessian-weighted rows
   } u;
-  float M[NV * NVP], L[NV * NVP], H[NV * NVP];
+  float M[NV * NVP];
+  union { float L[NV * NVP]; float H[NV * NVP]; };  // L (factor of M) is dead once qacc_smooth exists; H is the solver / Euler work matrix
   float invdiag[NV];
   float qfrc_bias[NV], qfrc_passive[NV], qfrc_actuator[NV], qfrc_smooth[NV], qacc_smooth[NV], qfrc_constraint[NV];
   // per-launch staged constants that are read by lanes other than their owner
@@ -183,7 +186,8 @@ struct Smem {
   float biw[NB * 2];             // body_invweight0
   int bdofs[NB], broot[NB];
   float gst[NG * 8];             // colliding geom statics: half-extents 3, box centre (geom frame) 3, rbound, margin
-  int gtype[NG], gbody[NG];
+  int gtype[NG], gbody[NG], gcp[NG];   // type, body, condim | priority<<8
+  float gpar[NG * 12];             // contact material per geom: friction3 solref2 solimp5 solmix gap
   float gpos[NG * 3], gmat[NG * 9], gcen[NG * 3];
   float spos[NS * 3], smat[NS * 9];
   // contacts
@@ -191,10 +195,10 @@ struct Smem {
   int cg1[NCON], cg2[NCON], cdim[NCON], cefc[NCON];
   // constraint rows
   float J[NEFC * NV];  // row-major, stride 16: four rows = one MFMA B operand
-  float e_R[NEFC], e_D[NEFC], e_aref[NEFC], e_fl[NEFC], e_force[NEFC], e_B[NEFC];
+  float e_R[NEFC], e_aref[NEFC], e_force[NEFC], e_B[NEFC];
   int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
   float cstate[RSIM_CS_SIZE];
-  float scratch[192];
+  float red[16];
   int ncon, nefc, niter;
 };
 
@@ -379,6 +383,12 @@ struct Sim {
 
   __device__ Sim(SM& s_, const DModel& m_, const float* fp_, int lane_, unsigned long long* prof) : s(s_), m(m_), fp(fp_), lane(lane_) { pf.p = prof; pf.lane = lane_; pf.t0 = 0; }
 
+  // articulated-tree slot of a root body (RSIM_MAXDYNROOT = static tree, COM unused / zero)
+  __device__ __forceinline__ int root_slot(int rootbody) const {
+    int sl = RSIM_MAXDYNROOT;
+    for (int r = 0; r < m.ndynroot; r++) if (m.dynroot[r] == rootbody) sl = r;
+    return sl;
+  }
   __device__ __forceinline__ u64 mask2(int tab, int i) const { return (u64)(uint32_t)IT(tab, 2 * i) | ((u64)(uint32_t)IT(tab, 2 * i + 1) << 32); }
 
   // ---------------------------------------------------------------- once per launch: constants -> registers / LDS
@@ -402,7 +412,7 @@ struct Sim {
       K.q0 = FP(FO_qpos0, (K.binfo >> 4) & 255);
       if (lane >= nb) { K.part = 0; K.part4 = 0; K.binfo = 15; K.bdofs = 0; K.mass = 0.f; }
       if (lane < SM_NB) { s.biw[2 * lane] = lane < nb ? FP(FO_body_invweight0, 2 * b) : 0.f; s.biw[2 * lane + 1] = lane < nb ? FP(FO_body_invweight0, 2 * b + 1) : 0.f;
-                          s.bdofs[lane] = (int)K.bdofs; s.broot[lane] = (K.binfo >> 20) & 255; }
+                          s.bdofs[lane] = (int)K.bdofs; s.broot[lane] = root_slot((K.binfo >> 20) & 255); }
     }
     {  // dof role
       const int i = lane < nv ? lane : 0, j = (K.dinfo >> 18) & 255;
@@ -437,6 +447,12 @@ struct Sim {
         float* o = s.gst + 8 * g;
         st3(o, h); st3(o + 3, c); o[6] = FP(FO_cg_rbound, g); o[7] = FP(FO_cg_margin, g);
         s.gtype[g] = t; s.gbody[g] = K.ginfo & 255;
+        s.gcp[g] = IT(IO_cg_condim, g) | (IT(IO_cg_priority, g) << 8);
+        float* gp = s.gpar + 12 * g;
+        for (int k = 0; k < 3; k++) gp[k] = FP(FO_cg_friction, 3 * g + k);
+        gp[3] = FP(FO_cg_solref, 2 * g); gp[4] = FP(FO_cg_solref, 2 * g + 1);
+        for (int k = 0; k < 5; k++) gp[5 + k] = FP(FO_cg_solimp, 5 * g + k);
+        gp[10] = FP(FO_cg_solmix, g); gp[11] = FP(FO_cg_gap, g);
       }
     }
     {  // site role
@@ -452,7 +468,7 @@ struct Sim {
     // zero the LDS regions whose padding lanes / columns are read but never written
     for (int e = lane; e < SM_NB * 10 + 16; e += 64) s.cinert[e] = 0.f;
     for (int e = lane; e < NV16 * 8; e += 64) s.cdof[e] = 0.f;
-    for (int e = lane; e < SM_NB * 3; e += 64) s.rootcom[e] = 0.f;
+    if (lane < (RSIM_MAXDYNROOT + 1) * 3) s.rootcom[lane] = 0.f;
     SYNC();
   }
 
@@ -489,7 +505,7 @@ struct Sim {
     }
     lq = qnorm(lq);
     xp = lp; xq = lq;
-    if (b < SM_NB) { st3(s.xpos + 3 * b, lp); stq(s.xquat + 4 * b, lq); stm(s.xmat + 9 * b, q2m(lq)); }
+    if (b < SM_NB) { st3(s.xpos + 3 * b, lp); stq(s.xquat + 4 * b, lq); }
     SYNC();
   }
 
@@ -528,7 +544,7 @@ struct Sim {
       const float iw = sw > 1e-15f ? 1.0f / sw : 0.f;
       const V3 cr = v3(sx * iw, sy * iw, sz * iw);
       if (root == rb) com = cr;
-      if (lane == 0) st3(s.rootcom + 3 * rb, cr);
+      if (lane == 0) st3(s.rootcom + 3 * r, cr);
     }
     if (b < nb && moving) {
       const M3 Ri = q2m(qmul(xq, K.iquat));
@@ -673,7 +689,7 @@ struct Sim {
           const M3 R = q2m(qmul(xq, K.iquat));
           const float bx = sqrtf(fmaxf(1e-15f, I.y + I.z - I.x) / mass * 6.0f), by = sqrtf(fmaxf(1e-15f, I.x + I.z - I.y) / mass * 6.0f),
                       bz = sqrtf(fmaxf(1e-15f, I.x + I.y - I.z) / mass * 6.0f);
-          const V3 off = xp + qrot(xq, K.ipos) - ld3(s.rootcom + 3 * ((K.binfo >> 20) & 255));
+          const V3 off = xp + qrot(xq, K.ipos) - ld3(s.rootcom + 3 * s.broot[b]);
           const V3 gl = cv.l + cross(cv.a, off) - opt_wind;
           const V3 la = mtv(R, cv.a), ll = mtv(R, gl);
           V3 ft = v3(0, 0, 0), ff = v3(0, 0, 0);
@@ -778,143 +794,174 @@ struct Sim {
     return p + mv(R, lp);
   }
 
-  __device__ __forceinline__ void add_contact(float dist, V3 pos, V3 nrm, int g1, int g2, float margin, float gap) {
-    // executed by ONE lane; caller maintains s.ncon
-    int c = s.ncon;
-    if (c >= (int)(sizeof(s.cdist) / sizeof(float))) return;
-    s.ncon = c + 1;
-    s.cdist[c] = dist;
-    st3(s.cpos + 3 * c, pos);
-    make_frame(nrm, s.cframe + 9 * c);
-    s.cg1[c] = g1; s.cg2[c] = g2;
-    s.cmargin[c] = margin - gap;
-    int p1 = IT(IO_cg_priority, g1), p2 = IT(IO_cg_priority, g2);
-    float fr[3];
+  // contact parameters of a geom pair (MuJoCo's mixing rules: priority, solmix-weighted solref/solimp, max friction);
+  // evaluated once per candidate pair, uniformly by every lane, from the per-geom table staged in LDS
+  struct CPar { int dim; float solref[2], solimp[5], fr[3]; float margin_gap; };
+  __device__ __forceinline__ CPar contact_params(int g1, int g2, float margin, float gap) const {
+    CPar cp;
+    cp.margin_gap = margin - gap;
+    const float* a = s.gpar + 12 * g1;
+    const float* b = s.gpar + 12 * g2;
+    const int c1 = s.gcp[g1], c2 = s.gcp[g2];
+    const int p1 = c1 >> 8, p2 = c2 >> 8, d1 = c1 & 255, d2 = c2 & 255;
     if (p1 != p2) {
-      int gp = p1 > p2 ? g1 : g2;
-      s.cdim[c] = IT(IO_cg_condim, gp);
-      for (int k = 0; k < 2; k++) s.csolref[2 * c + k] = FP(FO_cg_solref, 2 * gp + k);
-      for (int k = 0; k < 5; k++) s.csolimp[5 * c + k] = FP(FO_cg_solimp, 5 * gp + k);
-      for (int k = 0; k < 3; k++) fr[k] = FP(FO_cg_friction, 3 * gp + k);
+      const float* w = p1 > p2 ? a : b;
+      cp.dim = p1 > p2 ? d1 : d2;
+      for (int k = 0; k < 3; k++) cp.fr[k] = w[k];
+      for (int k = 0; k < 2; k++) cp.solref[k] = w[3 + k];
+      for (int k = 0; k < 5; k++) cp.solimp[k] = w[5 + k];
     } else {
-      int d1 = IT(IO_cg_condim, g1), d2 = IT(IO_cg_condim, g2);
-      s.cdim[c] = d1 > d2 ? d1 : d2;
-      float s1 = FP(FO_cg_solmix, g1), s2 = FP(FO_cg_solmix, g2), mix;
+      cp.dim = d1 > d2 ? d1 : d2;
+      const float s1 = a[10], s2 = b[10];
+      float mix;
       if (s1 >= 1e-15f && s2 >= 1e-15f) mix = s1 / (s1 + s2);
       else if (s1 < 1e-15f && s2 < 1e-15f) mix = 0.5f;
       else mix = s1 < 1e-15f ? 0.0f : 1.0f;
-      float r10 = FP(FO_cg_solref, 2 * g1), r11 = FP(FO_cg_solref, 2 * g1 + 1), r20 = FP(FO_cg_solref, 2 * g2), r21 = FP(FO_cg_solref, 2 * g2 + 1);
-      if (r10 > 0 && r20 > 0) { s.csolref[2 * c] = mix * r10 + (1 - mix) * r20; s.csolref[2 * c + 1] = mix * r11 + (1 - mix) * r21; }
-      else { s.csolref[2 * c] = fminf(r10, r20); s.csolref[2 * c + 1] = fminf(r11, r21); }
-      for (int k = 0; k < 5; k++) s.csolimp[5 * c + k] = mix * FP(FO_cg_solimp, 5 * g1 + k) + (1 - mix) * FP(FO_cg_solimp, 5 * g2 + k);
-      for (int k = 0; k < 3; k++) fr[k] = fmaxf(FP(FO_cg_friction, 3 * g1 + k), FP(FO_cg_friction, 3 * g2 + k));
+      if (a[3] > 0 && b[3] > 0) { cp.solref[0] = mix * a[3] + (1 - mix) * b[3]; cp.solref[1] = mix * a[4] + (1 - mix) * b[4]; }
+      else { cp.solref[0] = fminf(a[3], b[3]); cp.solref[1] = fminf(a[4], b[4]); }
+      for (int k = 0; k < 5; k++) cp.solimp[k] = mix * a[5 + k] + (1 - mix) * b[5 + k];
+      for (int k = 0; k < 3; k++) cp.fr[k] = fmaxf(a[k], b[k]);
     }
-    float* f = s.cfri + 5 * c;
-    f[0] = f[1] = fr[0]; f[2] = fr[1]; f[3] = f[4] = fr[2];
+    return cp;
+  }
+  // Lanes with has == true append one contact each, in lane order, at most `cap` of them (the rest are dropped);
+  // every lane of the wave must call this (ballot + shared counter).
+  __device__ __forceinline__ void emit_contacts(bool has, int cap, float dist, V3 pos, V3 nrm, int g1, int g2, const CPar& cp) {
+    const u64 mk = __ballot(has);
+    const int rank = __popcll(mk & lanemask_lt(lane));
+    const int base = s.ncon;
+    int total = __popcll(mk);
+    if (total > cap) total = cap;
+    if (base + total > SM::NCON_) total = SM::NCON_ - base;
+    if (has && rank < total) {
+      const int c = base + rank;
+      s.cdist[c] = dist;
+      st3(s.cpos + 3 * c, pos);
+      make_frame(nrm, s.cframe + 9 * c);
+      s.cg1[c] = g1; s.cg2[c] = g2; s.cdim[c] = cp.dim;
+      s.cmargin[c] = cp.margin_gap;
+      s.csolref[2 * c] = cp.solref[0]; s.csolref[2 * c + 1] = cp.solref[1];
+      for (int k = 0; k < 5; k++) s.csolimp[5 * c + k] = cp.solimp[k];
+      float* f = s.cfri + 5 * c;
+      f[0] = f[1] = cp.fr[0]; f[2] = cp.fr[1]; f[3] = f[4] = cp.fr[2];
+    }
+    SYNC();
+    if (lane == 0) s.ncon = base + total;
+    SYNC();
   }
 
-  // box(g1)-box(g2): SAT + face clipping / edge-edge; executed by lane 0 (serial geometry, LDS scratch polygons)
-  __device__ void box_box_lane0(int g1, int g2, float margin, float gap) {
-    V3 pa = ld3(s.gpos + 3 * g1), pb = ld3(s.gpos + 3 * g2);
-    M3 Ra = ldm(s.gmat + 9 * g1), Rb = ldm(s.gmat + 9 * g2);
-    float ha[3] = {FP(FO_cg_size, 3 * g1), FP(FO_cg_size, 3 * g1 + 1), FP(FO_cg_size, 3 * g1 + 2)};
-    float hb[3] = {FP(FO_cg_size, 3 * g2), FP(FO_cg_size, 3 * g2 + 1), FP(FO_cg_size, 3 * g2 + 2)};
-    V3 A[3] = {col(Ra, 0), col(Ra, 1), col(Ra, 2)}, B[3] = {col(Rb, 0), col(Rb, 1), col(Rb, 2)};
-    V3 dab = pb - pa;
-    float sA = -3e38f, sB = -3e38f, best_face, best_edge = -3e38f;
-    int idA = 0, idB = 3, face_id, edge_id = -1;
-    V3 edge_axis = v3(0, 0, 0);
-    for (int i = 0; i < 6; i++) {
-      V3 Lx = i < 3 ? A[i] : B[i - 3];
-      float ra = 0, rb = 0;
-      for (int k = 0; k < 3; k++) { ra += ha[k] * fabsf(dot(Lx, A[k])); rb += hb[k] * fabsf(dot(Lx, B[k])); }
-      float sv = fabsf(dot(Lx, dab)) - ra - rb;
-      if (sv > margin) return;
-      if (i < 3) { if (sv > sA) { sA = sv; idA = i; } }
-      else if (sv > sB) { sB = sv; idB = i; }
+  __device__ __forceinline__ V3 pick3(V3 a, V3 b, V3 c, int i) const { return i == 0 ? a : (i == 1 ? b : c); }
+  __device__ __forceinline__ float pickf(V3 a, int i) const { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+  __device__ __forceinline__ V3 bcast3(V3 a, int src) const { return v3(__shfl(a.x, src), __shfl(a.y, src), __shfl(a.z, src)); }
+
+  // box(g1)-box(g2): separating-axis test with one lane per axis (6 face + 9 edge), then either one edge-edge contact or a
+  // lane-parallel Sutherland-Hodgman clip of the incident face against the reference face (lane i = polygon vertex i).
+  // Same decisions, tie-breaks and contact order as the serial restatement in oracle/rsim_oracle.c box_box().
+  __device__ void box_box(int g1, int g2, float margin, const CPar& cp) {
+    const V3 pa = ld3(s.gpos + 3 * g1), pb = ld3(s.gpos + 3 * g2);
+    const M3 Ra = ldm(s.gmat + 9 * g1), Rb = ldm(s.gmat + 9 * g2);
+    const V3 ha = ld3(s.gst + 8 * g1), hb = ld3(s.gst + 8 * g2);
+    const V3 A0 = col(Ra, 0), A1 = col(Ra, 1), A2 = col(Ra, 2), B0 = col(Rb, 0), B1 = col(Rb, 1), B2 = col(Rb, 2);
+    const V3 dab = pb - pa;
+    // ---- one axis per lane
+    const int al = lane < 15 ? lane : 0;
+    bool valid = lane < 15;
+    V3 L;
+    if (al < 3) L = pick3(A0, A1, A2, al);
+    else if (al < 6) L = pick3(B0, B1, B2, al - 3);
+    else {
+      const int i = (al - 6) / 3, j = (al - 6) - 3 * i;
+      L = cross(pick3(A0, A1, A2, i), pick3(B0, B1, B2, j));
+      const float nn = norm(L);
+      if (nn < 1e-6f) { valid = false; L = v3(1, 0, 0); } else L = L * (1.0f / nn);
     }
+    const float ra = ha.x * fabsf(dot(L, A0)) + ha.y * fabsf(dot(L, A1)) + ha.z * fabsf(dot(L, A2));
+    const float rb = hb.x * fabsf(dot(L, B0)) + hb.y * fabsf(dot(L, B1)) + hb.z * fabsf(dot(L, B2));
+    const float sv = fabsf(dot(L, dab)) - ra - rb;
+    if (__ballot(valid && sv > margin)) return;
+    const u64 vmask = __ballot(valid);
+    // ---- axis selection on uniform scalars (first maximum wins, as in the serial scan)
+    float sA = bcast(sv, 0), sB = bcast(sv, 3);
+    int idA = 0, idB = 3;
+    { float t = bcast(sv, 1); if (t > sA) { sA = t; idA = 1; } t = bcast(sv, 2); if (t > sA) { sA = t; idA = 2; }
+      t = bcast(sv, 4); if (t > sB) { sB = t; idB = 4; } t = bcast(sv, 5); if (t > sB) { sB = t; idB = 5; } }
+    float best_face; int face_id;
     if (sB > sA + 1e-6f) { best_face = sB; face_id = idB; } else { best_face = sA; face_id = idA; }
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) {
-        V3 Lx = cross(A[i], B[j]);
-        float n = norm(Lx);
-        if (n < 1e-6f) continue;
-        Lx = Lx * (1.0f / n);
-        float ra = 0, rb = 0;
-        for (int k = 0; k < 3; k++) { ra += ha[k] * fabsf(dot(Lx, A[k])); rb += hb[k] * fabsf(dot(Lx, B[k])); }
-        float sv = fabsf(dot(Lx, dab)) - ra - rb;
-        if (sv > margin) return;
-        if (sv > best_edge) { best_edge = sv; edge_id = 3 * i + j; edge_axis = Lx; }
-      }
+    float best_edge = -3e38f; int edge_id = -1;
+#pragma unroll
+    for (int e = 0; e < 9; e++) { const float t = bcast(sv, 6 + e); if (((vmask >> (6 + e)) & 1ull) && t > best_edge) { best_edge = t; edge_id = e; } }
     if (edge_id >= 0 && best_edge > 0.95f * best_face + 1e-5f && best_edge > best_face + 1e-5f) {
-      int i = edge_id / 3, j = edge_id - 3 * i;
-      V3 n = edge_axis;
+      const int i = edge_id / 3, j = edge_id - 3 * i;
+      V3 n = bcast3(L, 6 + edge_id);
       if (dot(n, dab) < 0) n = -n;
+      const V3 Ai = pick3(A0, A1, A2, i), Bj = pick3(B0, B1, B2, j);
       V3 qa = pa, qb = pb;
-      for (int a = 0; a < 3; a++) {
-        if (a != i) qa = qa + A[a] * ((dot(n, A[a]) > 0 ? 1.f : -1.f) * ha[a]);
-        if (a != j) qb = qb + B[a] * ((dot(n, B[a]) > 0 ? -1.f : 1.f) * hb[a]);
-      }
-      V3 r = qb - qa;
-      float ab = dot(A[i], B[j]), den = 1 - ab * ab, ra_ = dot(r, A[i]), rb_ = dot(r, B[j]), sp = 0, tp = 0;
+      if (i != 0) qa = qa + A0 * ((dot(n, A0) > 0 ? 1.f : -1.f) * ha.x);
+      if (i != 1) qa = qa + A1 * ((dot(n, A1) > 0 ? 1.f : -1.f) * ha.y);
+      if (i != 2) qa = qa + A2 * ((dot(n, A2) > 0 ? 1.f : -1.f) * ha.z);
+      if (j != 0) qb = qb + B0 * ((dot(n, B0) > 0 ? -1.f : 1.f) * hb.x);
+      if (j != 1) qb = qb + B1 * ((dot(n, B1) > 0 ? -1.f : 1.f) * hb.y);
+      if (j != 2) qb = qb + B2 * ((dot(n, B2) > 0 ? -1.f : 1.f) * hb.z);
+      const V3 r = qb - qa;
+      const float ab = dot(Ai, Bj), den = 1 - ab * ab, ra_ = dot(r, Ai), rb_ = dot(r, Bj);
+      float sp = 0, tp = 0;
       if (den > 1e-12f) { sp = (ra_ - ab * rb_) / den; tp = (ab * ra_ - rb_) / den; }
-      sp = fmaxf(-ha[i], fminf(ha[i], sp));
-      tp = fmaxf(-hb[j], fminf(hb[j], tp));
-      add_contact(best_edge, ((qa + A[i] * sp) + (qb + B[j] * tp)) * 0.5f, n, g1, g2, margin, gap);
+      const float hai = pickf(ha, i), hbj = pickf(hb, j);
+      sp = fmaxf(-hai, fminf(hai, sp));
+      tp = fmaxf(-hbj, fminf(hbj, tp));
+      emit_contacts(lane == 0, 1, best_edge, ((qa + Ai * sp) + (qb + Bj * tp)) * 0.5f, n, g1, g2, cp);
       return;
     }
-    bool ref_is_a = face_id < 3;
-    int ax = face_id % 3;
-    V3 pr = ref_is_a ? pa : pb, pi_ = ref_is_a ? pb : pa;
-    const float* hr = ref_is_a ? ha : hb;
-    const float* hi = ref_is_a ? hb : ha;
-    const V3* Rr = ref_is_a ? A : B;
-    const V3* Ri = ref_is_a ? B : A;
-    V3 dri = pi_ - pr;
-    float sg = dot(Rr[ax], dri) >= 0 ? 1.f : -1.f;
-    V3 n = Rr[ax] * sg;
+    // ---- face contact: the reference box owns the axis
+    const bool ref_is_a = face_id < 3;
+    const int ax = ref_is_a ? face_id : face_id - 3;
+    const V3 pr = ref_is_a ? pa : pb, pi_ = ref_is_a ? pb : pa, hr = ref_is_a ? ha : hb, hi = ref_is_a ? hb : ha;
+    const V3 Rr0 = ref_is_a ? A0 : B0, Rr1 = ref_is_a ? A1 : B1, Rr2 = ref_is_a ? A2 : B2;
+    const V3 Ri0 = ref_is_a ? B0 : A0, Ri1 = ref_is_a ? B1 : A1, Ri2 = ref_is_a ? B2 : A2;
+    const V3 Rax = pick3(Rr0, Rr1, Rr2, ax);
+    const V3 n = Rax * (dot(Rax, pi_ - pr) >= 0 ? 1.f : -1.f);  // from reference toward incident
     int iax = 0;
-    float bestd = -1;
-    for (int k = 0; k < 3; k++) { float v = fabsf(dot(Ri[k], n)); if (v > bestd) { bestd = v; iax = k; } }
-    float isg = dot(Ri[iax], n) > 0 ? -1.f : 1.f;
-    int u = (iax + 1) % 3, v = (iax + 2) % 3, ru = (ax + 1) % 3, rv = (ax + 2) % 3;
-    float* poly = s.scratch;        // [16][3]
-    float* tmp = s.scratch + 48;    // [16][3]
-    int np = 0;
-    const float cs[4][2] = {{1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
-    for (int c = 0; c < 4; c++) {
-      V3 w = pi_ + Ri[iax] * (isg * hi[iax]) + Ri[u] * (cs[c][0] * hi[u]) + Ri[v] * (cs[c][1] * hi[v]);
-      V3 rel = w - pr;
-      poly[3 * np] = dot(rel, Rr[ru]); poly[3 * np + 1] = dot(rel, Rr[rv]); poly[3 * np + 2] = dot(rel, n) - hr[ax];
-      np++;
+    { float bestd = fabsf(dot(Ri0, n)), t = fabsf(dot(Ri1, n)); if (t > bestd) { bestd = t; iax = 1; } t = fabsf(dot(Ri2, n)); if (t > bestd) { bestd = t; iax = 2; } }
+    const V3 Riax = pick3(Ri0, Ri1, Ri2, iax);
+    const float isg = dot(Riax, n) > 0 ? -1.f : 1.f;
+    const int u = iax == 2 ? 0 : iax + 1, v = u == 2 ? 0 : u + 1, ru = ax == 2 ? 0 : ax + 1, rv = ru == 2 ? 0 : ru + 1;
+    const V3 Riu = pick3(Ri0, Ri1, Ri2, u), Riv = pick3(Ri0, Ri1, Ri2, v), Rru = pick3(Rr0, Rr1, Rr2, ru), Rrv = pick3(Rr0, Rr1, Rr2, rv);
+    const float hrax = pickf(hr, ax), hru = pickf(hr, ru), hrv = pickf(hr, rv);
+    // incident-face corners in the reference-face frame (along ru, along rv, height above the face): lane c = corner c
+    float px, py, pz;
+    {
+      const float cx = (lane == 0 || lane == 3) ? 1.f : -1.f, cy = lane < 2 ? 1.f : -1.f;
+      const V3 w = pi_ + Riax * (isg * pickf(hi, iax)) + Riu * (cx * pickf(hi, u)) + Riv * (cy * pickf(hi, v));
+      const V3 rel = w - pr;
+      px = dot(rel, Rru); py = dot(rel, Rrv); pz = dot(rel, n) - hrax;
     }
+    int np = 4;
+    float* poly = s.u.b.poly;  // [16][3] staging for the order-preserving scatter
     for (int pass = 0; pass < 4 && np > 0; pass++) {
-      int axis = pass >> 1;
-      float h = axis == 0 ? hr[ru] : hr[rv], sign = (pass & 1) ? -1.f : 1.f;
-      int cnt = 0;
-      for (int i = 0; i < np; i++) {
-        const float* a = poly + 3 * i;
-        const float* b = poly + 3 * ((i + 1) % np);
-        float da = sign * a[axis] - h, db = sign * b[axis] - h;
-        if (da <= 0) { tmp[3 * cnt] = a[0]; tmp[3 * cnt + 1] = a[1]; tmp[3 * cnt + 2] = a[2]; cnt++; }
-        if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
-          float t = da / (da - db);
-          for (int k = 0; k < 3; k++) tmp[3 * cnt + k] = a[k] + t * (b[k] - a[k]);
-          cnt++;
-        }
-        if (cnt >= 15) break;
+      const bool ax0 = pass < 2;
+      const float h = ax0 ? hru : hrv, sign = (pass & 1) ? -1.f : 1.f;
+      const int nxt = lane + 1 >= np ? 0 : lane + 1;
+      const float bx = __shfl(px, nxt), by = __shfl(py, nxt), bz = __shfl(pz, nxt);
+      const bool act = lane < np;
+      const float da = sign * (ax0 ? px : py) - h, db = sign * (ax0 ? bx : by) - h;
+      const bool e1 = act && da <= 0, e2 = act && ((da < 0 && db > 0) || (da > 0 && db < 0));
+      const u64 m1 = __ballot(e1), m2 = __ballot(e2);
+      const int off = __popcll(m1 & lanemask_lt(lane)) + __popcll(m2 & lanemask_lt(lane));
+      if (e1 && off < 16) { poly[3 * off] = px; poly[3 * off + 1] = py; poly[3 * off + 2] = pz; }
+      if (e2 && off + (e1 ? 1 : 0) < 16) {
+        const int o = off + (e1 ? 1 : 0);
+        const float t = da / (da - db);
+        poly[3 * o] = px + t * (bx - px); poly[3 * o + 1] = py + t * (by - py); poly[3 * o + 2] = pz + t * (bz - pz);
       }
-      for (int i = 0; i < 3 * cnt; i++) poly[i] = tmp[i];
-      np = cnt;
+      np = __popcll(m1) + __popcll(m2);
+      if (np > 15) np = 15;
+      SYNC();
+      if (lane < np) { px = poly[3 * lane]; py = poly[3 * lane + 1]; pz = poly[3 * lane + 2]; }
+      SYNC();
     }
-    int cnt = 0;
-    for (int i = 0; i < np && cnt < 8; i++) {
-      float dist = poly[3 * i + 2];
-      if (dist > margin) continue;
-      V3 w = pr + Rr[ru] * poly[3 * i] + Rr[rv] * poly[3 * i + 1] + n * (hr[ax] + dist);
-      add_contact(dist, w - n * (0.5f * dist), ref_is_a ? n : -n, g1, g2, margin, gap);
-      cnt++;
-    }
+    const bool hit = lane < np && pz <= margin;
+    const V3 w = pr + Rru * px + Rrv * py + n * (hrax + pz);
+    emit_contacts(hit, 8, pz, w - n * (0.5f * pz), ref_is_a ? n : -n, g1, g2, cp);
   }
 
   // closest point on triangle to the origin (barycentric)
@@ -947,7 +994,7 @@ struct Sim {
   }
 
   // Minkowski Portal Refinement (uniform control flow; support() is wave-cooperative)
-  __device__ void convex_convex(int g1, int g2, float margin, float gap) {
+  __device__ void convex_convex(int g1, int g2, float margin, const CPar& cp) {
     const float tol = 1e-6f;
     V3 v0 = ld3(s.gcen + 3 * g1) - ld3(s.gcen + 3 * g2);
     if (norm(v0) < 1e-9f) v0.x = 1e-5f;
@@ -957,7 +1004,7 @@ struct Sim {
     dir = cross(v0, v1);
     if (norm(dir) < 1e-12f) {
       V3 n = normalized(v1 - v0);
-      if (lane == 0) add_contact(-dot(v1, n), (p11 + p12) * 0.5f, n, g1, g2, margin, gap);
+      emit_contacts(lane == 0, 1, -dot(v1, n), (p11 + p12) * 0.5f, n, g1, g2, cp);
       return;
     }
     dir = normalized(dir);
@@ -1001,11 +1048,11 @@ struct Sim {
     }
     if (!hit) return;
     float bary[3];
-    V3 cp = tri_closest_origin(v1, v2, v3_, bary);
-    float depth = norm(cp);
-    V3 n = depth > 1e-12f ? cp * (1.0f / depth) : dir;
+    V3 cpt = tri_closest_origin(v1, v2, v3_, bary);
+    float depth = norm(cpt);
+    V3 n = depth > 1e-12f ? cpt * (1.0f / depth) : dir;
     V3 w1 = p11 * bary[0] + p21 * bary[1] + p31 * bary[2], w2 = p12 * bary[0] + p22 * bary[1] + p32 * bary[2];
-    if (lane == 0) add_contact(-depth, (w1 + w2) * 0.5f, n, g1, g2, margin, gap);
+    emit_contacts(lane == 0, 1, -depth, (w1 + w2) * 0.5f, n, g1, g2, cp);
   }
 
   // oriented bounding box of colliding geom g: world centre o, half extents h along the columns of gmat
@@ -1070,40 +1117,30 @@ struct Sim {
       int p = uni(s.u.b.cand[ci]);
       int g1 = uni(IT(IO_pair_g1, p)), g2 = uni(IT(IO_pair_g2, p));
       int t1 = uni(s.gtype[g1]), t2 = uni(s.gtype[g2]);
-      float margin = fmaxf(s.gst[8 * g1 + 7], s.gst[8 * g2 + 7]), gap = fmaxf(FP(FO_cg_gap, g1), FP(FO_cg_gap, g2));
+      const float margin = fmaxf(s.gst[8 * g1 + 7], s.gst[8 * g2 + 7]), gap = fmaxf(s.gpar[12 * g1 + 11], s.gpar[12 * g2 + 11]);
+      const CPar cp = contact_params(g1, g2, margin, gap);
       if (t1 == G_PLANE && t2 == G_BOX) {
-        M3 Rp = ldm(s.gmat + 9 * g1);
-        V3 nrm = col(Rp, 2);
+        const V3 nrm = v3(s.gmat[9 * g1 + 2], s.gmat[9 * g1 + 5], s.gmat[9 * g1 + 8]);
         float dist = 0;
         V3 wp = v3(0, 0, 0);
         bool hit = false;
         if (lane < 8) {
-          V3 sz = ld3(&FP(FO_cg_size, 3 * g2));
-          V3 lp = v3((lane & 1) ? sz.x : -sz.x, (lane & 2) ? sz.y : -sz.y, (lane & 4) ? sz.z : -sz.z);
+          const V3 sz = ld3(s.gst + 8 * g2);
+          const V3 lp = v3((lane & 1) ? sz.x : -sz.x, (lane & 2) ? sz.y : -sz.y, (lane & 4) ? sz.z : -sz.z);
           wp = ld3(s.gpos + 3 * g2) + mv(ldm(s.gmat + 9 * g2), lp);
           dist = dot(wp - ld3(s.gpos + 3 * g1), nrm);
           hit = dist <= margin;
         }
-        u64 mk = __ballot(hit);
-        // serialise in corner order (first four), one lane at a time
-        int taken = 0;
-        while (mk && taken < 4) {
-          int l = __ffsll((long long)mk) - 1;
-          mk &= mk - 1;
-          if (lane == l) add_contact(dist, wp - nrm * (0.5f * dist), nrm, g1, g2, margin, gap);
-          taken++;
-          SYNC();
-        }
+        emit_contacts(hit, 4, dist, wp - nrm * (0.5f * dist), nrm, g1, g2, cp);  // first four corners in corner order
       } else if (t1 == G_PLANE) {
-        M3 Rp = ldm(s.gmat + 9 * g1);
-        V3 nrm = col(Rp, 2);
-        V3 sp = support(g2, -nrm);
-        float dist = dot(sp - ld3(s.gpos + 3 * g1), nrm);
-        if (dist <= margin && lane == 0) add_contact(dist, sp - nrm * (0.5f * dist), nrm, g1, g2, margin, gap);
+        const V3 nrm = v3(s.gmat[9 * g1 + 2], s.gmat[9 * g1 + 5], s.gmat[9 * g1 + 8]);
+        const V3 sp = support(g2, -nrm);
+        const float dist = dot(sp - ld3(s.gpos + 3 * g1), nrm);
+        emit_contacts(lane == 0 && dist <= margin, 1, dist, sp - nrm * (0.5f * dist), nrm, g1, g2, cp);
       } else if (t1 == G_BOX && t2 == G_BOX) {
-        if (lane == 0) box_box_lane0(g1, g2, margin, gap);
+        box_box(g1, g2, margin, cp);
       } else {
-        convex_convex(g1, g2, margin, gap);
+        convex_convex(g1, g2, margin, cp);
       }
       SYNC();
     }
@@ -1154,7 +1191,7 @@ struct Sim {
       if (act) {
         const int r = nefc + __popcll(mk & lanemask_lt(lane));
         s.e_desc[r] = C_FRICTION_DOF | (lane << 4);
-        s.e_R[r] = s.fricR[lane]; s.e_B[r] = s.fricB[lane]; s.e_aref[r] = 0.f; s.e_fl[r] = s.fricFl[lane];
+        s.e_R[r] = s.fricR[lane]; s.e_B[r] = s.fricB[lane]; s.e_aref[r] = 0.f;
       }
       nefc += __popcll(mk);
     }
@@ -1172,14 +1209,14 @@ struct Sim {
         float R, Bd, Kt;
         row_scalars(dlo, K.jmargin, solref, solimp, K.dinvw, R, Bd, Kt);
         s.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (0 << 12);
-        s.e_R[r] = R; s.e_B[r] = Bd; s.e_aref[r] = Kt; s.e_fl[r] = 0.f;
+        s.e_R[r] = R; s.e_B[r] = Bd; s.e_aref[r] = Kt;
       }
       if (ahi) {
         const int r = nefc + before + (alo ? 1 : 0);
         float R, Bd, Kt;
         row_scalars(dhi, K.jmargin, solref, solimp, K.dinvw, R, Bd, Kt);
         s.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (1 << 12);
-        s.e_R[r] = R; s.e_B[r] = Bd; s.e_aref[r] = Kt; s.e_fl[r] = 0.f;
+        s.e_R[r] = R; s.e_B[r] = Bd; s.e_aref[r] = Kt;
       }
       nefc += __popcll(mlo) + __popcll(mhi);
     }
@@ -1214,7 +1251,7 @@ struct Sim {
             const int r = first + k;
             s.e_desc[r] = type | (lane << 4) | (k << 12);
             s.e_R[r] = k == 0 ? R0 : (k == 1 ? R1 : R1 * f[0] * f[0] / fmaxf(1e-15f, f[k - 1] * f[k - 1]));
-            s.e_B[r] = Bd; s.e_aref[r] = k == 0 ? Kt : 0.f; s.e_fl[r] = 0.f;
+            s.e_B[r] = Bd; s.e_aref[r] = k == 0 ? Kt : 0.f;
           }
         }
         s.cmu[lane] = dim > 1 ? f[0] * sqrtf(R1 / R0) : 0.f;
@@ -1263,11 +1300,7 @@ struct Sim {
       float jv = 0.f;
 #pragma unroll
       for (int k = 0; k < NV16; k++) { s.J[lane * NV16 + k] = Jr[k]; jv = fmaf(Jr[k], s.qvel[k], jv); }
-      if (valid) {
-        const float R = s.e_R[lane];
-        s.e_D[lane] = 1.0f / R;
-        s.e_aref[lane] = -s.e_B[lane] * jv - s.e_aref[lane];
-      }
+      if (valid) s.e_aref[lane] = -s.e_B[lane] * jv - s.e_aref[lane];
     }
     SYNC();
   }
@@ -1401,9 +1434,9 @@ struct Sim {
     const DCtrl& c = m.ctrl;
     const int n = c.ndof;
     constexpr int NA = RSIM_ARM_MAX;
-    float* Jm = s.scratch;            // [6][NA]  arm Jacobian (lin rows 0..2, ang rows 3..5)
-    float* Li = s.scratch + 48;       // [6][6]   Lambda^-1
-    float* vv = s.scratch + 84;       // 6: J tmp
+    float* Jm = s.u.k.Jm;             // [6][NA]  arm Jacobian (lin rows 0..2, ang rows 3..5)
+    float* Li = s.u.k.Li;             // [6][6]   Lambda^-1
+    float* vv = s.u.k.vv;             // 6: J tmp
     const int eb = __shfl(K.sbody, c.eef_site), bb = __shfl(K.sbody, c.base_site);
     const V3 ep = ld3(s.spos + 3 * c.eef_site), op = ld3(s.spos + 3 * c.base_site);
     // this lane's arm dof (lanes 0..n-1) and its joint-space quantities
@@ -1480,7 +1513,7 @@ struct Sim {
     }
     rchol_factor<NA>(lr6, linv6);
     SYNC();
-    float* Lt = s.scratch + 96;  // [8][8] transpose staging
+    float* Lt = s.u.k.Lt;        // [8][8] transpose staging
     if (lane < NA) {
 #pragma unroll
       for (int k = 0; k < NA; k++) Lt[lane * NA + k] = lr6[k];
@@ -1599,9 +1632,9 @@ struct Sim {
   __device__ __forceinline__ float jt_times_force(int nch) {
     v4f acc = {0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s.J[64 * c + lane], s.e_force[4 * c + (lane >> 4)], acc, 0, 0, 0);
-    if ((lane & 15) == 0) { float* o = s.scratch + 4 * (lane >> 4); o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; }
+    if ((lane & 15) == 0) { float* o = s.red + 4 * (lane >> 4); o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; }
     SYNC();
-    float r = s.scratch[lane & 15];
+    float r = s.red[lane & 15];
     SYNC();
     return r;
   }
@@ -1620,7 +1653,7 @@ struct Sim {
       for (int k = 0; k < NV16; k++) rw.J[k] = s.J[lane * NV16 + k];  // rows >= n were written as zeros
       const int desc = rw.valid ? s.e_desc[r] : 0;
       rw.type = rw.valid ? (desc & 15) : -1;
-      rw.D = s.e_D[r]; rw.R = s.e_R[r]; rw.aref = rw.valid ? s.e_aref[r] : 0.f; rw.fl = s.e_fl[r];
+      rw.R = s.e_R[r]; rw.D = 1.0f / rw.R; rw.aref = rw.valid ? s.e_aref[r] : 0.f; rw.fl = rw.type == C_FRICTION_DOF ? s.fricFl[(desc >> 4) & 255] : 0.f;
       rw.ell = rw.type == C_CONTACT_ELLIPTIC;
       const int c = rw.ell ? (desc >> 4) & 255 : 0;
       rw.kk = rw.ell ? (desc >> 12) & 15 : 0; rw.head = lane - rw.kk; rw.dim = rw.ell ? s.cdim[c] : 1;
@@ -1628,7 +1661,7 @@ struct Sim {
 #pragma unroll
       for (int j = 0; j < CD - 1; j++) rw.fj[j] = s.cfri[5 * c + j];
       rw.fr_own = rw.kk == 0 ? rw.mu : s.cfri[5 * c + rw.kk - 1];
-      rw.Dm = s.e_D[rw.ell ? rw.head : r] / fmaxf(rw.mu * rw.mu * (1 + rw.mu * rw.mu), 1e-15f);
+      rw.Dm = (1.0f / s.e_R[rw.ell ? rw.head : r]) / fmaxf(rw.mu * rw.mu * (1 + rw.mu * rw.mu), 1e-15f);
     }
     // M: row i in lane i (matrix-vector products) and in the MFMA accumulator layout (Hessian seed)
     float Mr[NV16];

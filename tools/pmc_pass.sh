@@ -1,12 +1,19 @@
 #!/bin/bash
-# PMC passes over the fused kernel (counters only: no trace domains besides kernel-trace).  Usage: tools/pmc_pass.sh <tag>
-tag=${1:-pmc}
+# PMC passes over the fused kernel (counters only: no trace domains besides kernel-trace).  Usage: tools/pmc_pass.sh <tag> [sets...]
+tag=${1:-pmc}; shift
+sets=${@:-sq1 sq2 ic}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 run() { # name, counters
   rm -rf gpurun_out/$tag.$1
   timeout 600 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/$tag.$1 -o r -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/$tag.$1.log 2>&1
-  python tools/pmc_sum.py gpurun_out/$tag.$1 k_step | tee gpurun_out/$tag.$1.txt
+  python tools/pmc_sum.py gpurun_out/$tag.$1 k_step | tee gpurun_out/$tag.$1.txt; rm -rf gpurun_out/$tag.$1
 }
-run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU"
-run sq2 "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA"
+for s in $sets; do
+case $s in
+ sq1) run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU";;
+ sq2) run sq2 "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA";;
+ ic) run ic "SQ_IFETCH SQ_IFETCH_LEVEL SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_INSTS_BRANCH SQ_BUSY_CYCLES";;
+ lv) run lv "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_LEVEL_WAVES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_TRANS_F32 SQ_LDS_IDX_ACTIVE";;
+esac
+done
