@@ -118,6 +118,8 @@ def main():
     dt = time.perf_counter() - t0
     dt = shard.max_over_ranks(dt, dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if os.environ.get("RSIM_BENCH_TRACE"):
+        print("per-step ms:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in ev), file=sys.stderr)
 
     st = shard.RolloutStats(dev)
     q = env.batch.tensor("qpos")

@@ -105,6 +105,8 @@ int rsim_sync(rsim_batch* b);
  * enable != 0 (re)arms and zeroes the accumulators, 0 disarms; if `out` is non-NULL the current accumulators are copied out first:
  * cycles {load kin com crb broad narrow makec vel ctrl act solve euler store} then counts {substeps candidates contacts efc newton ls}. */
 int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, int n_out);
+/* While profiling is armed every launch also logs, per env, {HW_ID, XCC_ID, start, end (s_memrealtime ticks, 100 MHz)}: out = HOST u64 [B,4]. */
+int rsim_wavelog(rsim_batch* b, unsigned long long* out);
 
 /* zero-copy numpy-view replacement: copy a field to / from HOST float32 (int32 for RSIM_NCON..) buffers of `count` elements */
 int rsim_get_array(rsim_batch* b, int field, void* host_dst, size_t count);

@@ -95,6 +95,7 @@ def lib():
         L.rsim_jac_body.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.rsim_model_param_set.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_size_t]
         L.rsim_profile.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.rsim_wavelog.argtypes = [vp, vp]
         L.rsim_osc_eval.argtypes = [C.POINTER(CtrlDesc), vp, vp, C.c_int, C.c_int]
         _LIB = L
     return _LIB
@@ -221,6 +222,12 @@ class HipBatch:
 
     PROFILE_SLOTS = ("load", "kin", "com", "crb", "broad", "narrow", "makec", "vel", "ctrl", "act", "solve", "euler", "store",
                      "n_sub", "n_cand", "n_con", "n_efc", "n_newton", "n_ls")
+
+    def wavelog(self):
+        """Per-env {hw_id, xcc_id, t_start, t_end} of the last launch (profiling must be armed)."""
+        out = np.zeros((self.B, 4), dtype=np.uint64)
+        _chk(self._L.rsim_wavelog(self.ptr, out.ctypes.data))
+        return out
 
     def profile(self, enable=True):
         """Read (then re-arm or disarm) the kernel's per-phase cycle accumulators -> dict."""

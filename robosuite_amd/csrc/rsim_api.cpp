@@ -528,11 +528,20 @@ extern "C" int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, 
     HIPCHK(hipMemcpy(tmp, b->db.prof, sizeof(tmp), hipMemcpyDeviceToHost));
     for (int i = 0; i < n_out && i < RP_COUNT; i++) out[i] = tmp[i];
   }
+  const size_t nprof = RP_COUNT + 4 * (size_t)b->B;  // phase accumulators, then per-env {hw_id, xcc_id, t_start, t_end} of the last launch
   if (enable && !b->db.prof) {
-    HIPCHK(hipMalloc((void**)&b->db.prof, RP_COUNT * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void**)&b->db.prof, nprof * sizeof(unsigned long long)));
   }
-  if (enable) HIPCHK(hipMemset(b->db.prof, 0, RP_COUNT * sizeof(unsigned long long)));
+  if (enable) HIPCHK(hipMemset(b->db.prof, 0, nprof * sizeof(unsigned long long)));
   if (!enable && b->db.prof) { hipFree(b->db.prof); b->db.prof = nullptr; }
+  return 0;
+}
+
+extern "C" int rsim_wavelog(rsim_batch* b, unsigned long long* out) {
+  if (!b->db.prof) return fail("rsim_wavelog: profiling is not enabled");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(out, b->db.prof + RP_COUNT, 4 * (size_t)b->B * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return 0;
 }
 

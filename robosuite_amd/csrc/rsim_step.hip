@@ -13,6 +13,10 @@
 
 #include "rsim_internal.h"
 
+#ifndef RSIM_MINWAVES
+#define RSIM_MINWAVES 1  /* waves per SIMD the register allocator must leave room for (1: 512 registers, 2: 256) */
+#endif
+
 typedef unsigned long long u64;
 #define SYNC() __syncthreads()
 #define FMIN 1e-20f
@@ -44,6 +48,21 @@ __device__ __forceinline__ float wave_sum(float x) {
   x += dpp_f<0x143>(x);  // row_bcast:31
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 #endif
+}
+// DPP steps that leave lanes without a source unchanged (reductions whose identity is not 0)
+template <int CTRL>
+__device__ __forceinline__ int dpp_keep_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ float wave_max(float x) {
+#define RSIM_MX(C) x = fmaxf(x, __builtin_bit_cast(float, dpp_keep_i<C>(__builtin_bit_cast(int, x))))
+  RSIM_MX(0x111); RSIM_MX(0x112); RSIM_MX(0x114); RSIM_MX(0x118); RSIM_MX(0x142); RSIM_MX(0x143);
+#undef RSIM_MX
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+__device__ __forceinline__ int wave_min_i(int x) {
+#define RSIM_MN(C) { int t_ = dpp_keep_i<C>(x); x = t_ < x ? t_ : x; }
+  RSIM_MN(0x111) RSIM_MN(0x112) RSIM_MN(0x114) RSIM_MN(0x118) RSIM_MN(0x142) RSIM_MN(0x143)
+#undef RSIM_MN
+  return __builtin_amdgcn_readlane(x, 63);
 }
 __device__ __forceinline__ float bcast(float x, int srclane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), srclane));
@@ -149,7 +168,16 @@ __device__ __forceinline__ S6 mul_inert(const float* I, S6 v) {
 
 // ------------------------------------------------------------------------------------------------------------
 
+// LDS words of the per-lane constant block: 29 body fields x 32, 13 dof x 16, 11 geom x 32, 8 site x 16, 10 actuator x 16, 5 ctrl x 8, 3 pair rows + mfbits x 64
+#define RSIM_KC_WORDS (29 * 32 + 13 * 16 + 11 * 32 + 8 * 16 + 10 * 16 + 5 * 8 + 4 * 64)
+
 typedef float v4f __attribute__((ext_vector_type(4)));
+// explicitly global (address space 1) views of the model tables: pointers that arrive inside the by-value DModel would otherwise be
+// treated as generic and compile to flat_load
+typedef const float __attribute__((address_space(1)))* gcf;
+typedef const int __attribute__((address_space(1)))* gci;
+__device__ __forceinline__ V3 ld3(gcf p) { return v3(p[0], p[1], p[2]); }
+__device__ __forceinline__ Q4 ldq(gcf p) { Q4 q = {p[0], p[1], p[2], p[3]}; return q; }
 
 // ------------------------------------------------------------------------------------------------------------
 // per-env LDS state (one wavefront = one environment; everything below lives in LDS for all substeps of a launch)
@@ -159,6 +187,7 @@ struct Smem {
   static_assert(NB == 32 && NV == 16 && NEFC == 64, "tree-incidence MFMAs assume 32 bodies x 16 dofs, one lane per constraint row");
   static constexpr int NVP = NV + 1;  // padded row stride of the dense nv x nv matrices (conflict-free column reads)
   static constexpr int NV_ = NV;
+  static constexpr int JS_ = 17, CS6_ = 9, FS_ = 17;  // LDS row strides (odd => bank-conflict-free lane-per-row access)
   static constexpr int CD_ = 4;       // largest contact dimension this configuration handles (condim 1, 3, 4)
   static constexpr int NCON_ = NCON;
   static constexpr int NB_ = NB;
@@ -166,15 +195,15 @@ struct Smem {
   float xpos[NB * 3], xquat[NB * 4];
   float rootcom[(RSIM_MAXDYNROOT + 1) * 3];  // subtree COM per articulated tree; last slot = 0 for static trees
   float cinert[NB * 10 + 16];  // +16: the MFMA B-operand read pattern runs 6 floats past the last row
-  float cdof[NV * 8];          // stride 8, components 6..7 stay zero (MFMA K padding)
+  float cdof[NV * 9];          // stride CS6 = 9 (odd: conflict-free row reads), components 6..8 stay zero (MFMA K padding)
   // phase-local storage: crb -> broadphase -> velocity -> controller read cvel -> solver W
   union {
-    struct { float crbD[NV * 16], fpad[NV * 8]; } c;                                       // crb()
+    struct { float crbD[NV * 17], fpad[NV * 9]; } c;                                       // crb()
     struct { int cand[NPAIR]; float poly[96]; } b;                                         // collision(): candidates, box-box clip polygons
-    struct { float cvel[NB * 8]; union { struct { float cvb[NV * 8], cdd[NV * 8]; }; float cacc[NB * 8]; };
-             union { float cf[NB * 16]; float F[NV * 16]; }; } v;                          // velocity(): later stages overwrite dead earlier ones
-    struct { float cvel[NB * 8]; float Jm[48], Li[36], vv[8], Lt[64]; } k;                  // ctrl_run(): cvel stays live from velocity()
-    float W[NEFC * NV];                                                                    // solve_newton(): Hessian-weighted rows
+    struct { float cvel[NB * 9]; union { struct { float cvb[NV * 9], cdd[NV * 9]; }; float cacc[NB * 9]; };
+             union { float cf[NB * 17]; float F[NV * 17]; }; } v;                          // velocity(): later stages overwrite dead earlier ones
+    struct { float cvel[NB * 9]; float Jm[48], Li[36], vv[8], Lt[64]; } k;                  // ctrl_run(): cvel stays live from velocity()
+    float W[NEFC * 17];                                                                    // solve_newton(): Hessian-weighted rows
   } u;
   float M[NV * NVP];
   union { float L[NV * NVP]; float H[NV * NVP]; };  // L (factor of M) is dead once qacc_smooth exists; H is the solver / Euler work matrix
@@ -186,7 +215,7 @@ struct Smem {
   float biw[NB * 2];             // body_invweight0
   int bdofs[NB], broot[NB];
   float gst[NG * 8];             // colliding geom statics: half-extents 3, box centre (geom frame) 3, rbound, margin
-  int gtype[NG], gbody[NG], gcp[NG];   // type, body, condim | priority<<8
+  int gtype[NG], gbody[NG], gcp[NG], gmesh[NG];   // type, body, condim | priority<<8, hull vertex adr | count<<16
   float gpar[NG * 12];             // contact material per geom: friction3 solref2 solimp5 solmix gap
   float gpos[NG * 3], gmat[NG * 9], gcen[NG * 3];
   float spos[NS * 3], smat[NS * 9];
@@ -194,16 +223,23 @@ struct Smem {
   float cpos[NCON * 3], cframe[NCON * 9], cdist[NCON], cfri[NCON * 5], csolref[NCON * 2], csolimp[NCON * 5], cmu[NCON], cmargin[NCON];
   int cg1[NCON], cg2[NCON], cdim[NCON], cefc[NCON];
   // constraint rows
-  float J[NEFC * NV];  // row-major, stride 16: four rows = one MFMA B operand
+  float J[NEFC * 17];  // row-major, stride JS = 17 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
   float e_R[NEFC], e_aref[NEFC], e_force[NEFC], e_B[NEFC];
   int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
   float cstate[RSIM_CS_SIZE];
   float red[16];
+  // per-lane model constants, one row per field (LaneConst below); phases fetch the handful they need instead of pinning ~80 VGPRs
+  float kc[RSIM_KC_WORDS];
   int ncon, nefc, niter;
 };
 
-#define IT(tab, i) (m.it[m.io[tab] + (i)])
-#define FP(tab, i) (fp[m.fo[tab] + (i)])
+// The one per-workgroup LDS object, declared at file scope so that every access is a direct LDS (ds_*) instruction with an
+// immediate offset: routing it through a reference member made the compiler fall back to flat_* loads/stores.
+typedef Smem<32, 16, 16, 24, 16, 16, 64, 192> Smem0;
+__shared__ Smem0 sm;
+
+#define IT(tab, i) (((gci)m.it)[m.io[tab] + (i)])
+#define FP(tab, i) (((gcf)fp)[m.fo[tab] + (i)])
 
 // Register-resident Cholesky: lane i (< N) owns row i of the SPD matrix in a[0..N); all loops unroll so every index is a
 // compile-time register and every broadcast is a v_readlane.  After the call a[k] = L[i][k] (k <= i), inv[k] = 1 / L[k][k] (uniform).
@@ -239,6 +275,13 @@ __device__ __forceinline__ float rchol_solve(const float (&a)[N], const float (&
     x = lane == k ? xk : (lane < k ? fmaf(-at[k], xk, x) : x);
   }
   return x;
+}
+template <int N>
+__device__ __forceinline__ int seli(const int (&v)[N], int i) {
+  int r = v[0];
+#pragma unroll
+  for (int k = 1; k < N; k++) r = i == k ? v[k] : r;
+  return r;
 }
 template <int N>
 __device__ __forceinline__ float sel(const float (&v)[N], int i) {
@@ -336,6 +379,55 @@ __device__ __forceinline__ void spd_solve_small(const float* A, const float* b, 
   for (int i = N - 1; i >= 0; i--) { float t = x[i]; for (int k = i + 1; k < N; k++) t -= Lm[k * N + i] * x[k]; x[i] = t / Lm[i * N + i]; }
 }
 
+// support point of colliding geom g along world direction dir (wave-cooperative for meshes; result uniform).
+// A real function (not inlined into its ~10 call sites); it only touches the LDS object and the hull vertex table.
+__device__ __forceinline__ V3 geom_support(int g, V3 dir, gcf mesh_vert, int lane) {
+  const int t = sm.gtype[g];
+  const M3 R = ldm(sm.gmat + 9 * g);
+  const V3 p = ld3(sm.gpos + 3 * g), h = ld3(sm.gst + 8 * g);
+  const V3 ld = mtv(R, dir);
+  V3 lp = v3(0, 0, 0);
+  if (t == G_BOX) lp = v3(ld.x >= 0 ? h.x : -h.x, ld.y >= 0 ? h.y : -h.y, ld.z >= 0 ? h.z : -h.z);
+  else if (t == G_SPHERE) { float n = norm(ld); if (n > FMIN) lp = ld * (h.x / n); }
+  else if (t == G_CYLINDER) {
+    float n = sqrtf(ld.x * ld.x + ld.y * ld.y);
+    if (n > FMIN) { lp.x = ld.x / n * h.x; lp.y = ld.y / n * h.x; }
+    lp.z = ld.z >= 0 ? h.z : -h.z;
+  } else if (t == G_CAPSULE) {
+    float n = norm(ld);
+    if (n > FMIN) lp = ld * (h.x / n);
+    lp.z += ld.z >= 0 ? (h.z - h.x) : -(h.z - h.x);
+  } else if (t == G_ELLIPSOID) {
+    V3 tt = v3(ld.x * h.x, ld.y * h.y, ld.z * h.z);
+    float n = norm(tt);
+    if (n > FMIN) lp = v3(tt.x / n * h.x, tt.y / n * h.y, tt.z / n * h.z);
+  } else if (t == G_MESH) {
+    const int adr = sm.gmesh[g] & 0xffff, num = sm.gmesh[g] >> 16;
+    float bv = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f;
+    int bi = 0x7fffffff;
+    for (int base = 0; base < num; base += 256) {
+      float vx[4], vy[4], vz[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {   // all loads of the chunk first, then the compares
+        const int i = base + 64 * u + lane;
+        gcf v = mesh_vert + 3 * (adr + (i < num ? i : 0));
+        vx[u] = v[0]; vy[u] = v[1]; vz[u] = v[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = base + 64 * u + lane;
+        const float val = vx[u] * ld.x + vy[u] * ld.y + vz[u] * ld.z;
+        if (i < num && val > bv) { bv = val; bi = i; bx = vx[u]; by = vy[u]; bz = vz[u]; }
+      }
+    }
+    // wave arg-max, lowest index wins ties (matches the serial first-maximum scan)
+    const float mx = wave_max(bv);
+    const int win = wave_min_i(bv == mx ? bi : 0x7fffffff) & 63;  // vertex i is scanned by lane i % 64
+    lp = v3(__shfl(bx, win), __shfl(by, win), __shfl(bz, win));
+  }
+  return p + mv(R, lp);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // per-lane model constants, loaded once per launch and kept in registers for all substeps
 // ------------------------------------------------------------------------------------------------------------
@@ -361,6 +453,9 @@ struct LaneConst {
   // candidate pairs p = lane + 64 t
   int pair[3];
   unsigned mfbits;
+  // built-in controller, lane i = arm joint i / gripper actuator i
+  int cq, cd, ca, cga;
+  float cgs;
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -368,32 +463,90 @@ struct LaneConst {
 // ------------------------------------------------------------------------------------------------------------
 template <class SM>
 struct Sim {
-  SM& s;
   const DModel& m;
   const float* fp;
   int lane;
   Prof pf;
-  LaneConst K;
   float opt_h, opt_density, opt_viscosity, opt_impratio;
   V3 opt_grav, opt_wind;
   static constexpr int NVP = SM::NVP;
   static constexpr int NV16 = SM::NV_;
   static constexpr int CD = SM::CD_;
+  static constexpr int JS = SM::JS_, CS6 = SM::CS6_, FS = SM::FS_;
   static constexpr int SM_NB = SM::NB_;
 
-  __device__ Sim(SM& s_, const DModel& m_, const float* fp_, int lane_, unsigned long long* prof) : s(s_), m(m_), fp(fp_), lane(lane_) { pf.p = prof; pf.lane = lane_; pf.t0 = 0; }
+  __device__ Sim(const DModel& m_, const float* fp_, int lane_, unsigned long long* prof) : m(m_), fp(fp_), lane(lane_) { pf.p = prof; pf.lane = lane_; pf.t0 = 0; }
 
   // articulated-tree slot of a root body (RSIM_MAXDYNROOT = static tree, COM unused / zero)
   __device__ __forceinline__ int root_slot(int rootbody) const {
     int sl = RSIM_MAXDYNROOT;
-    for (int r = 0; r < m.ndynroot; r++) if (m.dynroot[r] == rootbody) sl = r;
+#pragma unroll
+    for (int r = 0; r < RSIM_MAXDYNROOT; r++) if (r < m.ndynroot && m.dynroot[r] == rootbody) sl = r;
     return sl;
   }
   __device__ __forceinline__ u64 mask2(int tab, int i) const { return (u64)(uint32_t)IT(tab, 2 * i) | ((u64)(uint32_t)IT(tab, 2 * i + 1) << 32); }
 
-  // ---------------------------------------------------------------- once per launch: constants -> registers / LDS
-  __device__ void load_constants() {
-    const int* lt = m.lt;
+  // ---------------------------------------------------------------- per-lane constants <-> LDS (row = field, column = lane of the role)
+  template <bool STORE> __device__ __forceinline__ void kio(float& x, int idx) const { if (STORE) sm.kc[idx] = x; else x = sm.kc[idx]; }
+  template <bool STORE> __device__ __forceinline__ void kio(int& x, int idx) const { if (STORE) sm.kc[idx] = __builtin_bit_cast(float, x); else x = __builtin_bit_cast(int, sm.kc[idx]); }
+  template <bool STORE> __device__ __forceinline__ void kio(unsigned& x, int idx) const { if (STORE) sm.kc[idx] = __builtin_bit_cast(float, x); else x = __builtin_bit_cast(unsigned, sm.kc[idx]); }
+  template <bool STORE> __device__ __forceinline__ void kio(V3& x, int idx, int stride) const { kio<STORE>(x.x, idx); kio<STORE>(x.y, idx + stride); kio<STORE>(x.z, idx + 2 * stride); }
+  template <bool STORE> __device__ __forceinline__ void kio(Q4& x, int idx, int stride) const { kio<STORE>(x.w, idx); kio<STORE>(x.x, idx + stride); kio<STORE>(x.y, idx + 2 * stride); kio<STORE>(x.z, idx + 3 * stride); }
+  // STORE: called once by load_constants (lanes outside a role's width skip it); fetch: every lane reads its (wrapped) column and the
+  // compiler drops the rows a phase does not use
+  template <bool STORE> __device__ __forceinline__ void kxfer(LaneConst& K) const {
+    int o = 0;
+    {  // body role, 32 columns
+      const int l = lane & 31, W = 32;
+      if (!STORE || lane < W) {
+        kio<STORE>(K.part, o + 0 * W + l); kio<STORE>(K.part4, o + 1 * W + l); kio<STORE>(K.binfo, o + 2 * W + l); kio<STORE>(K.bdofs, o + 3 * W + l);
+        kio<STORE>(K.bpos, o + 4 * W + l, W); kio<STORE>(K.bquat, o + 7 * W + l, W); kio<STORE>(K.jpos, o + 11 * W + l, W); kio<STORE>(K.jaxis, o + 14 * W + l, W);
+        kio<STORE>(K.q0, o + 17 * W + l); kio<STORE>(K.ipos, o + 18 * W + l, W); kio<STORE>(K.iquat, o + 21 * W + l, W); kio<STORE>(K.mass, o + 25 * W + l);
+        kio<STORE>(K.inertia, o + 26 * W + l, W);
+      }
+      o += 29 * W;
+    }
+    {  // dof role, 16 columns
+      const int l = lane & 15, W = 16;
+      if (!STORE || lane < W) {
+        kio<STORE>(K.dinfo, o + 0 * W + l); kio<STORE>(K.damping, o + 1 * W + l); kio<STORE>(K.jr0, o + 2 * W + l); kio<STORE>(K.jr1, o + 3 * W + l);
+        kio<STORE>(K.jmargin, o + 4 * W + l); kio<STORE>(K.jsr0, o + 5 * W + l); kio<STORE>(K.jsr1, o + 6 * W + l); kio<STORE>(K.jsi0, o + 7 * W + l);
+        kio<STORE>(K.jsi1, o + 8 * W + l); kio<STORE>(K.jsi2, o + 9 * W + l); kio<STORE>(K.jsi3, o + 10 * W + l); kio<STORE>(K.jsi4, o + 11 * W + l);
+        kio<STORE>(K.dinvw, o + 12 * W + l);
+      }
+      o += 13 * W;
+    }
+    {  // geom role, 32 columns
+      const int l = lane & 31, W = 32;
+      if (!STORE || lane < W) { kio<STORE>(K.ginfo, o + l); kio<STORE>(K.gp, o + 1 * W + l, W); kio<STORE>(K.gq, o + 4 * W + l, W); kio<STORE>(K.grc, o + 8 * W + l, W); }
+      o += 11 * W;
+    }
+    {  // site role, 16 columns
+      const int l = lane & 15, W = 16;
+      if (!STORE || lane < W) { kio<STORE>(K.sbody, o + l); kio<STORE>(K.sp, o + 1 * W + l, W); kio<STORE>(K.sq, o + 4 * W + l, W); }
+      o += 8 * W;
+    }
+    {  // actuator role, 16 columns
+      const int l = lane & 15, W = 16;
+      if (!STORE || lane < W) {
+        kio<STORE>(K.ainfo, o + l); kio<STORE>(K.agear, o + 1 * W + l); kio<STORE>(K.again, o + 2 * W + l); kio<STORE>(K.ab0, o + 3 * W + l); kio<STORE>(K.ab1, o + 4 * W + l);
+        kio<STORE>(K.ab2, o + 5 * W + l); kio<STORE>(K.acr0, o + 6 * W + l); kio<STORE>(K.acr1, o + 7 * W + l); kio<STORE>(K.afr0, o + 8 * W + l); kio<STORE>(K.afr1, o + 9 * W + l);
+      }
+      o += 10 * W;
+    }
+    {  // controller role, 8 columns
+      const int l = lane & 7, W = 8;
+      if (!STORE || lane < W) { kio<STORE>(K.cq, o + l); kio<STORE>(K.cd, o + W + l); kio<STORE>(K.ca, o + 2 * W + l); kio<STORE>(K.cga, o + 3 * W + l); kio<STORE>(K.cgs, o + 4 * W + l); }
+      o += 5 * W;
+    }
+    kio<STORE>(K.pair[0], o + lane); kio<STORE>(K.pair[1], o + 64 + lane); kio<STORE>(K.pair[2], o + 128 + lane); kio<STORE>(K.mfbits, o + 192 + lane);
+  }
+  __device__ __forceinline__ LaneConst fetchK() const { LaneConst K; kxfer<false>(K); return K; }
+
+  // ---------------------------------------------------------------- once per launch: constants -> LDS
+  __device__ __forceinline__ void load_constants() {
+    LaneConst K;
+    gci lt = (gci)m.lt;
     K.part = lt[LT_part * 64 + lane]; K.part4 = lt[LT_part4 * 64 + lane]; K.binfo = lt[LT_binfo * 64 + lane]; K.bdofs = (unsigned)lt[LT_bdofs * 64 + lane];
     K.dinfo = lt[LT_dinfo * 64 + lane]; K.ginfo = lt[LT_ginfo * 64 + lane]; K.sbody = lt[LT_sinfo * 64 + lane]; K.ainfo = lt[LT_ainfo * 64 + lane];
     K.pair[0] = lt[LT_pair0 * 64 + lane]; K.pair[1] = lt[LT_pair1 * 64 + lane]; K.pair[2] = lt[LT_pair2 * 64 + lane];
@@ -411,8 +564,8 @@ struct Sim {
       K.jpos = ld3(&FP(FO_jnt_pos, 3 * j)); K.jaxis = ld3(&FP(FO_jnt_axis, 3 * j));
       K.q0 = FP(FO_qpos0, (K.binfo >> 4) & 255);
       if (lane >= nb) { K.part = 0; K.part4 = 0; K.binfo = 15; K.bdofs = 0; K.mass = 0.f; }
-      if (lane < SM_NB) { s.biw[2 * lane] = lane < nb ? FP(FO_body_invweight0, 2 * b) : 0.f; s.biw[2 * lane + 1] = lane < nb ? FP(FO_body_invweight0, 2 * b + 1) : 0.f;
-                          s.bdofs[lane] = (int)K.bdofs; s.broot[lane] = root_slot((K.binfo >> 20) & 255); }
+      if (lane < SM_NB) { sm.biw[2 * lane] = lane < nb ? FP(FO_body_invweight0, 2 * b) : 0.f; sm.biw[2 * lane + 1] = lane < nb ? FP(FO_body_invweight0, 2 * b + 1) : 0.f;
+                          sm.bdofs[lane] = (int)K.bdofs; sm.broot[lane] = root_slot((K.binfo >> 20) & 255); }
     }
     {  // dof role
       const int i = lane < nv ? lane : 0, j = (K.dinfo >> 18) & 255;
@@ -422,14 +575,14 @@ struct Sim {
       K.jsi0 = FP(FO_jnt_solimp, 5 * j); K.jsi1 = FP(FO_jnt_solimp, 5 * j + 1); K.jsi2 = FP(FO_jnt_solimp, 5 * j + 2); K.jsi3 = FP(FO_jnt_solimp, 5 * j + 3); K.jsi4 = FP(FO_jnt_solimp, 5 * j + 4);
       K.dinvw = FP(FO_dof_invweight0, i);
       if (lane < NV16) {
-        s.arm[lane] = lane < nv ? FP(FO_dof_armature, i) : 1.0f;
+        sm.arm[lane] = lane < nv ? FP(FO_dof_armature, i) : 1.0f;
         // friction-loss row of this dof: position term is identically 0, so R, the velocity gain and the limit are constants
         const float fl = lane < nv ? FP(FO_dof_frictionloss, i) : 0.f;
         float solref[2] = {FP(FO_dof_solref, 2 * i), FP(FO_dof_solref, 2 * i + 1)}, solimp[5];
         for (int k = 0; k < 5; k++) solimp[k] = FP(FO_dof_solimp, 5 * i + k);
         float R, Bd, Kimp;
         row_scalars(0.f, 0.f, solref, solimp, K.dinvw, R, Bd, Kimp);
-        s.fricR[lane] = R; s.fricB[lane] = Bd; s.fricFl[lane] = fl;
+        sm.fricR[lane] = R; sm.fricB[lane] = Bd; sm.fricFl[lane] = fl;
       }
       if (lane >= nv) K.dinfo = 0;
     }
@@ -444,11 +597,12 @@ struct Sim {
         else if (t == G_SPHERE) h = v3(sz.x, sz.x, sz.x);
         else if (t == G_CAPSULE) h = v3(sz.x, sz.x, sz.x + sz.y);
         else if (t == G_CYLINDER) h = v3(sz.x, sz.x, sz.y);
-        float* o = s.gst + 8 * g;
+        float* o = sm.gst + 8 * g;
         st3(o, h); st3(o + 3, c); o[6] = FP(FO_cg_rbound, g); o[7] = FP(FO_cg_margin, g);
-        s.gtype[g] = t; s.gbody[g] = K.ginfo & 255;
-        s.gcp[g] = IT(IO_cg_condim, g) | (IT(IO_cg_priority, g) << 8);
-        float* gp = s.gpar + 12 * g;
+        sm.gtype[g] = t; sm.gbody[g] = K.ginfo & 255;
+        sm.gcp[g] = IT(IO_cg_condim, g) | (IT(IO_cg_priority, g) << 8);
+        sm.gmesh[g] = IT(IO_cg_meshadr, g) | (IT(IO_cg_meshnum, g) << 16);
+        float* gp = sm.gpar + 12 * g;
         for (int k = 0; k < 3; k++) gp[k] = FP(FO_cg_friction, 3 * g + k);
         gp[3] = FP(FO_cg_solref, 2 * g); gp[4] = FP(FO_cg_solref, 2 * g + 1);
         for (int k = 0; k < 5; k++) gp[5 + k] = FP(FO_cg_solimp, 5 * g + k);
@@ -465,86 +619,97 @@ struct Sim {
       K.ab0 = FP(FO_act_biasprm, 3 * a); K.ab1 = FP(FO_act_biasprm, 3 * a + 1); K.ab2 = FP(FO_act_biasprm, 3 * a + 2);
       K.acr0 = FP(FO_act_ctrlrange, 2 * a); K.acr1 = FP(FO_act_ctrlrange, 2 * a + 1); K.afr0 = FP(FO_act_forcerange, 2 * a); K.afr1 = FP(FO_act_forcerange, 2 * a + 1);
     }
+    {  // controller role (kernel-argument arrays are only ever indexed with compile-time constants: no private copy)
+      const DCtrl& c = m.ctrl;
+      K.cq = seli(c.qpos_idx, lane); K.cd = seli(c.dof_idx, lane); K.ca = seli(c.act_idx, lane);
+      K.cga = seli(c.grip_act, lane); K.cgs = sel(c.grip_sign, lane);
+    }
     // zero the LDS regions whose padding lanes / columns are read but never written
-    for (int e = lane; e < SM_NB * 10 + 16; e += 64) s.cinert[e] = 0.f;
-    for (int e = lane; e < NV16 * 8; e += 64) s.cdof[e] = 0.f;
-    if (lane < (RSIM_MAXDYNROOT + 1) * 3) s.rootcom[lane] = 0.f;
+    for (int e = lane; e < SM_NB * 10 + 16; e += 64) sm.cinert[e] = 0.f;
+    for (int e = lane; e < NV16 * CS6; e += 64) sm.cdof[e] = 0.f;
+    if (lane < (RSIM_MAXDYNROOT + 1) * 3) sm.rootcom[lane] = 0.f;
+    kxfer<true>(K);
     SYNC();
   }
 
   // ---------------------------------------------------------------- kinematics: pointer jumping over the body tree
   // every body composes its local transform with the transform of its 2^r-th ancestor in round r (log2(depth) rounds
   // instead of a serial root-to-leaf sweep); lane b = body b.  Returns this lane's world frame in registers.
-  __device__ void kinematics(V3& xp, Q4& xq) {
+  __device__ __forceinline__ void kinematics(V3& xp, Q4& xq) {
+    const LaneConst K = fetchK();
     const int b = lane;
     const int jt = K.binfo & 15, qa = (K.binfo >> 4) & 255;
     V3 lp = K.bpos;
     Q4 lq = K.bquat;
     if (jt == JNT_FREE) {
-      lp = ld3(s.qpos + qa);
-      lq = qnorm(ldq(s.qpos + qa + 3));
+      lp = ld3(sm.qpos + qa);
+      lq = qnorm(ldq(sm.qpos + qa + 3));
     } else if (jt == JNT_HINGE) {
       float sn, cs;
-      sincos_f(0.5f * (s.qpos[qa] - K.q0), sn, cs);
+      sincos_f(0.5f * (sm.qpos[qa] - K.q0), sn, cs);
       const Q4 ql = {cs, K.jaxis.x * sn, K.jaxis.y * sn, K.jaxis.z * sn};
       lq = qmul(K.bquat, ql);
       lp = K.bpos + qrot(K.bquat, K.jpos) - qrot(lq, K.jpos);
     } else if (jt == JNT_SLIDE) {
-      lp = K.bpos + qrot(K.bquat, K.jaxis) * (s.qpos[qa] - K.q0);
+      lp = K.bpos + qrot(K.bquat, K.jaxis) * (sm.qpos[qa] - K.q0);
     }
     if (b == 0) { lp = v3(0, 0, 0); lq.w = 1.f; lq.x = lq.y = lq.z = 0.f; }
     for (int r = 0; r < m.kin_rounds; r++) {
-      if (b < SM_NB) { st3(s.xpos + 3 * b, lp); stq(s.xquat + 4 * b, lq); }
+      if (b < SM_NB) { st3(sm.xpos + 3 * b, lp); stq(sm.xquat + 4 * b, lq); }
       SYNC();
       const int p = r < 4 ? (K.part >> (8 * r)) & 255 : K.part4;
-      const V3 pp = ld3(s.xpos + 3 * p);
-      const Q4 pq = ldq(s.xquat + 4 * p);
+      const V3 pp = ld3(sm.xpos + 3 * p);
+      const Q4 pq = ldq(sm.xquat + 4 * p);
       SYNC();
       lp = pp + qrot(pq, lp);
       lq = qmul(pq, lq);
     }
     lq = qnorm(lq);
     xp = lp; xq = lq;
-    if (b < SM_NB) { st3(s.xpos + 3 * b, lp); stq(s.xquat + 4 * b, lq); }
+    if (b < SM_NB) { st3(sm.xpos + 3 * b, lp); stq(sm.xquat + 4 * b, lq); }
     SYNC();
   }
 
   // colliding geom and site frames (lane g = geom g, lane k = site k)
-  __device__ void geom_site_frames() {
+  __device__ __forceinline__ void geom_site_frames() {
+    const LaneConst K = fetchK();
     if (lane < m.ncg) {
       const int g = lane, gb = K.ginfo & 255;
-      const Q4 bq = ldq(s.xquat + 4 * gb);
-      const V3 gp = ld3(s.xpos + 3 * gb) + qrot(bq, K.gp);
+      const Q4 bq = ldq(sm.xquat + 4 * gb);
+      const V3 gp = ld3(sm.xpos + 3 * gb) + qrot(bq, K.gp);
       const M3 Rg = q2m(qnorm(qmul(bq, K.gq)));
-      st3(s.gpos + 3 * g, gp);
-      stm(s.gmat + 9 * g, Rg);
-      st3(s.gcen + 3 * g, gp + mv(Rg, K.grc));
+      st3(sm.gpos + 3 * g, gp);
+      stm(sm.gmat + 9 * g, Rg);
+      st3(sm.gcen + 3 * g, gp + mv(Rg, K.grc));
     }
     if (lane < m.nsite) {
       const int k = lane, sb = K.sbody;
-      const Q4 bq = ldq(s.xquat + 4 * sb);
-      st3(s.spos + 3 * k, ld3(s.xpos + 3 * sb) + qrot(bq, K.sp));
-      stm(s.smat + 9 * k, q2m(qnorm(qmul(bq, K.sq))));
+      const Q4 bq = ldq(sm.xquat + 4 * sb);
+      st3(sm.spos + 3 * k, ld3(sm.xpos + 3 * sb) + qrot(bq, K.sp));
+      stm(sm.smat + 9 * k, q2m(qnorm(qmul(bq, K.sq))));
     }
     SYNC();
   }
 
   // ---------------------------------------------------------------- subtree COM of the articulated trees, cinert, cdof
-  __device__ void com_pos(V3 xp, Q4 xq) {
+  __device__ __forceinline__ void com_pos(V3 xp, Q4 xq) {
+    const LaneConst K = fetchK();
     const int b = lane, nb = m.nbody;
     const int root = (K.binfo >> 20) & 255, jt = K.binfo & 15, da = (K.binfo >> 12) & 255;
     const bool moving = (K.binfo >> 28) & 1;
     const M3 R = q2m(xq);
     const V3 xip = xp + mv(R, K.ipos);
     V3 com = xip;
-    for (int r = 0; r < m.ndynroot; r++) {
+#pragma unroll
+    for (int r = 0; r < RSIM_MAXDYNROOT; r++) {
+      if (r >= m.ndynroot) break;
       const int rb = m.dynroot[r];
       const float w = (b < nb && root == rb) ? K.mass : 0.f;
       const float sw = wave_sum(w), sx = wave_sum(w * xip.x), sy = wave_sum(w * xip.y), sz = wave_sum(w * xip.z);
       const float iw = sw > 1e-15f ? 1.0f / sw : 0.f;
       const V3 cr = v3(sx * iw, sy * iw, sz * iw);
       if (root == rb) com = cr;
-      if (lane == 0) st3(s.rootcom + 3 * r, cr);
+      if (lane == 0) st3(sm.rootcom + 3 * r, cr);
     }
     if (b < nb && moving) {
       const M3 Ri = q2m(qmul(xq, K.iquat));
@@ -559,7 +724,7 @@ struct Sim {
       Iw[4] = Ri.m[0] * I.x * Ri.m[6] + Ri.m[1] * I.y * Ri.m[7] + Ri.m[2] * I.z * Ri.m[8];
       Iw[5] = Ri.m[3] * I.x * Ri.m[6] + Ri.m[4] * I.y * Ri.m[7] + Ri.m[5] * I.z * Ri.m[8];
       const float d2 = dot(off, off);
-      float* ci = s.cinert + 10 * b;
+      float* ci = sm.cinert + 10 * b;
       ci[0] = Iw[0] + mass * (d2 - off.x * off.x);
       ci[1] = Iw[1] + mass * (d2 - off.y * off.y);
       ci[2] = Iw[2] + mass * (d2 - off.z * off.z);
@@ -569,13 +734,13 @@ struct Sim {
       ci[6] = mass * off.x; ci[7] = mass * off.y; ci[8] = mass * off.z; ci[9] = mass;
     }
     if (b < nb && jt != 15) {
-      float* cd = s.cdof + 8 * da;
+      float* cd = sm.cdof + CS6 * da;
       if (jt == JNT_FREE) {
         const V3 off = com - xp;
         for (int k = 0; k < 3; k++) {
-          st3(cd + 8 * k, v3(0, 0, 0)); st3(cd + 8 * k + 3, v3(k == 0, k == 1, k == 2));
+          st3(cd + CS6 * k, v3(0, 0, 0)); st3(cd + CS6 * k + 3, v3(k == 0, k == 1, k == 2));
           const V3 ax = col(R, k);
-          st3(cd + 8 * (3 + k), ax); st3(cd + 8 * (3 + k) + 3, cross(ax, off));
+          st3(cd + CS6 * (3 + k), ax); st3(cd + CS6 * (3 + k) + 3, cross(ax, off));
         }
       } else {
         const V3 ax = mv(R, K.jaxis);
@@ -589,25 +754,26 @@ struct Sim {
   // ---------------------------------------------------------------- CRBA on the matrix cores
   // composite inertia per dof  crbD = Sub x cinert           (Sub = subtree incidence, 16 x 32, 0/1 constants)
   // f_i = crbD_i * cdof_i ;  M = (m1 o F C^T) + (m2 o C F^T) + diag(armature)        (F, C = 16 x 6 stacks of f_i, cdof_i)
-  __device__ void crb() {
+  __device__ __forceinline__ void crb() {
+    const LaneConst K = fetchK();
     const int nv = m.nv, q = lane >> 4, r = lane & 15;
     v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 8; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, c), s.cinert[(4 * c + q) * 10 + r], acc, 0, 0, 0);
+    for (int c = 0; c < 8; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, c), sm.cinert[(4 * c + q) * 10 + r], acc, 0, 0, 0);
 #pragma unroll
-    for (int v = 0; v < 4; v++) s.u.c.crbD[(4 * q + v) * 16 + r] = acc[v];
+    for (int v = 0; v < 4; v++) sm.u.c.crbD[(4 * q + v) * FS + r] = acc[v];
     SYNC();
     if (lane < NV16) {
       S6 f = {v3(0, 0, 0), v3(0, 0, 0)};
-      if (lane < nv) f = mul_inert(s.u.c.crbD + 16 * lane, ld6(s.cdof + 8 * lane));
-      float* o = s.u.c.fpad + 8 * lane;
+      if (lane < nv) f = mul_inert(sm.u.c.crbD + FS * lane, ld6(sm.cdof + CS6 * lane));
+      float* o = sm.u.c.fpad + CS6 * lane;
       st3(o, f.a); st3(o + 3, f.l); o[6] = 0.f; o[7] = 0.f;
     }
     SYNC();
     v4f R1 = {0.f, 0.f, 0.f, 0.f}, R2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kc = 0; kc < 2; kc++) {
-      const float fa = s.u.c.fpad[r * 8 + 4 * kc + q], ca = s.cdof[r * 8 + 4 * kc + q];
+      const float fa = sm.u.c.fpad[r * CS6 + 4 * kc + q], ca = sm.cdof[r * CS6 + 4 * kc + q];
       R1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, ca, R1, 0, 0, 0);
       R2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca, fa, R2, 0, 0, 0);
     }
@@ -615,19 +781,19 @@ struct Sim {
     for (int v = 0; v < 4; v++) {
       const int i = 4 * q + v;
       float mij = bitf(K.mfbits, 20 + v) * R1[v] + bitf(K.mfbits, 24 + v) * R2[v];
-      if (i == r) mij += s.arm[i];
-      s.M[i * NVP + r] = mij;
+      if (i == r) mij += sm.arm[i];
+      sm.M[i * NVP + r] = mij;
     }
     SYNC();
     {
       float mr[NV16], minv[NV16];
 #pragma unroll
-      for (int k = 0; k < NV16; k++) mr[k] = s.M[r * NVP + k];
+      for (int k = 0; k < NV16; k++) mr[k] = sm.M[r * NVP + k];
       rchol_factor<NV16>(mr, minv);
       if (lane < NV16) {
 #pragma unroll
-        for (int k = 0; k < NV16; k++) s.L[lane * NVP + k] = mr[k];
-        s.invdiag[lane] = sel(minv, lane);
+        for (int k = 0; k < NV16; k++) sm.L[lane * NVP + k] = mr[k];
+        sm.invdiag[lane] = sel(minv, lane);
       }
     }
     SYNC();
@@ -636,11 +802,12 @@ struct Sim {
   // ---------------------------------------------------------------- velocity stage (RNE) on the matrix cores
   // cvel = BodyDof x (cdof qd) ; cdof_dot_i = cvel_before(i) x cdof_i ; cacc = BodyDof x (cdof_dot qd) - g ;
   // body wrench cf = I cacc + cvel x* I cvel (+ fluid) ; F = Sub x cf ; bias_i = cdof_i . F_i
-  __device__ void velocity(V3 xp, Q4 xq) {
+  __device__ __forceinline__ void velocity(V3 xp, Q4 xq) {
+    const LaneConst K = fetchK();
     const int nb = m.nbody, nv = m.nv, q = lane >> 4, r = lane & 15;
     float Bc[4];
 #pragma unroll
-    for (int c = 0; c < 4; c++) Bc[c] = r < 6 ? s.cdof[(4 * c + q) * 8 + r] * s.qvel[4 * c + q] : 0.f;
+    for (int c = 0; c < 4; c++) Bc[c] = r < 6 ? sm.cdof[(4 * c + q) * CS6 + r] * sm.qvel[4 * c + q] : 0.f;
     v4f a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -650,18 +817,18 @@ struct Sim {
     }
     if (r < 8) {
 #pragma unroll
-      for (int v = 0; v < 4; v++) { s.u.v.cvel[(4 * q + v) * 8 + r] = a0[v]; s.u.v.cvel[(16 + 4 * q + v) * 8 + r] = a1[v]; s.u.v.cvb[(4 * q + v) * 8 + r] = a2[v]; }
+      for (int v = 0; v < 4; v++) { sm.u.v.cvel[(4 * q + v) * CS6 + r] = a0[v]; sm.u.v.cvel[(16 + 4 * q + v) * CS6 + r] = a1[v]; sm.u.v.cvb[(4 * q + v) * CS6 + r] = a2[v]; }
     }
     SYNC();
     if (lane < NV16) {
       S6 cd = {v3(0, 0, 0), v3(0, 0, 0)};
-      if (lane < nv && !((K.dinfo >> 8) & 1)) cd = cross_motion(ld6(s.u.v.cvb + 8 * lane), ld6(s.cdof + 8 * lane));
-      float* o = s.u.v.cdd + 8 * lane;
+      if (lane < nv && !((K.dinfo >> 8) & 1)) cd = cross_motion(ld6(sm.u.v.cvb + CS6 * lane), ld6(sm.cdof + CS6 * lane));
+      float* o = sm.u.v.cdd + CS6 * lane;
       st3(o, cd.a); st3(o + 3, cd.l); o[6] = 0.f; o[7] = 0.f;
     }
     SYNC();
 #pragma unroll
-    for (int c = 0; c < 4; c++) Bc[c] = r < 6 ? s.u.v.cdd[(4 * c + q) * 8 + r] * s.qvel[4 * c + q] : 0.f;
+    for (int c = 0; c < 4; c++) Bc[c] = r < 6 ? sm.u.v.cdd[(4 * c + q) * CS6 + r] * sm.qvel[4 * c + q] : 0.f;
     a0 = a1 = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -670,7 +837,7 @@ struct Sim {
     }
     if (r < 8) {
 #pragma unroll
-      for (int v = 0; v < 4; v++) { s.u.v.cacc[(4 * q + v) * 8 + r] = a0[v]; s.u.v.cacc[(16 + 4 * q + v) * 8 + r] = a1[v]; }
+      for (int v = 0; v < 4; v++) { sm.u.v.cacc[(4 * q + v) * CS6 + r] = a0[v]; sm.u.v.cacc[(16 + 4 * q + v) * CS6 + r] = a1[v]; }
     }
     SYNC();
     if (lane < SM_NB) {
@@ -678,10 +845,10 @@ struct Sim {
       S6 zero = {v3(0, 0, 0), v3(0, 0, 0)};
       S6 frc = zero, flu = zero;
       if (b < nb && ((K.binfo >> 28) & 1)) {
-        S6 ca = ld6(s.u.v.cacc + 8 * b);
+        S6 ca = ld6(sm.u.v.cacc + CS6 * b);
         ca.l = ca.l - opt_grav;
-        const S6 cv = ld6(s.u.v.cvel + 8 * b);
-        frc = mul_inert(s.cinert + 10 * b, ca) + cross_force(cv, mul_inert(s.cinert + 10 * b, cv));
+        const S6 cv = ld6(sm.u.v.cvel + CS6 * b);
+        frc = mul_inert(sm.cinert + 10 * b, ca) + cross_force(cv, mul_inert(sm.cinert + 10 * b, cv));
         const float mass = K.mass;
         if (mass >= 1e-15f && (opt_density > 0.f || opt_viscosity > 0.f)) {
           // inertia-box fluid model: force/torque at the body COM, folded into a spatial force about the tree COM
@@ -689,7 +856,7 @@ struct Sim {
           const M3 R = q2m(qmul(xq, K.iquat));
           const float bx = sqrtf(fmaxf(1e-15f, I.y + I.z - I.x) / mass * 6.0f), by = sqrtf(fmaxf(1e-15f, I.x + I.z - I.y) / mass * 6.0f),
                       bz = sqrtf(fmaxf(1e-15f, I.x + I.y - I.z) / mass * 6.0f);
-          const V3 off = xp + qrot(xq, K.ipos) - ld3(s.rootcom + 3 * s.broot[b]);
+          const V3 off = xp + qrot(xq, K.ipos) - ld3(sm.rootcom + 3 * sm.broot[b]);
           const V3 gl = cv.l + cross(cv.a, off) - opt_wind;
           const V3 la = mtv(R, cv.a), ll = mtv(R, gl);
           V3 ft = v3(0, 0, 0), ff = v3(0, 0, 0);
@@ -712,22 +879,22 @@ struct Sim {
           flu.l = gf;
         }
       }
-      float* o = s.u.v.cf + 16 * b;
+      float* o = sm.u.v.cf + FS * b;
       st3(o, frc.a); st3(o + 3, frc.l); st3(o + 6, flu.a); st3(o + 9, flu.l);
       o[12] = o[13] = o[14] = o[15] = 0.f;
     }
     SYNC();
     v4f af = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 8; c++) af = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, c), s.u.v.cf[(4 * c + q) * 16 + r], af, 0, 0, 0);
+    for (int c = 0; c < 8; c++) af = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, c), sm.u.v.cf[(4 * c + q) * FS + r], af, 0, 0, 0);
 #pragma unroll
-    for (int v = 0; v < 4; v++) s.u.v.F[(4 * q + v) * 16 + r] = af[v];
+    for (int v = 0; v < 4; v++) sm.u.v.F[(4 * q + v) * FS + r] = af[v];
     SYNC();
     if (lane < nv) {
-      const S6 cd = ld6(s.cdof + 8 * lane);
-      const float* F = s.u.v.F + 16 * lane;
-      s.qfrc_bias[lane] = dot6(cd, ld6(F));
-      s.qfrc_passive[lane] = -K.damping * s.qvel[lane] + dot6(cd, ld6(F + 6));
+      const S6 cd = ld6(sm.cdof + CS6 * lane);
+      const float* F = sm.u.v.F + FS * lane;
+      sm.qfrc_bias[lane] = dot6(cd, ld6(F));
+      sm.qfrc_passive[lane] = -K.damping * sm.qvel[lane] + dot6(cd, ld6(F + 6));
     }
     SYNC();
   }
@@ -735,9 +902,9 @@ struct Sim {
   // Jacobian column of world point p attached to body `b` for dof i: returns [jacr; jacp] or zero if i does not move b
   __device__ __forceinline__ S6 jac_col(int b, V3 p, int i) const {
     S6 z = {v3(0, 0, 0), v3(0, 0, 0)};
-    if (!((s.bdofs[b] >> i) & 1)) return z;
-    S6 cd = ld6(s.cdof + 8 * i);
-    V3 off = p - ld3(s.rootcom + 3 * s.broot[b]);
+    if (!((sm.bdofs[b] >> i) & 1)) return z;
+    S6 cd = ld6(sm.cdof + CS6 * i);
+    V3 off = p - ld3(sm.rootcom + 3 * sm.broot[b]);
     S6 rr = {cd.a, cd.l + cross(cd.a, off)};
     return rr;
   }
@@ -753,46 +920,7 @@ struct Sim {
     st3(frame, n); st3(frame + 3, y); st3(frame + 6, z);
   }
 
-  // support point of colliding geom g along world direction dir (wave-cooperative for meshes; result uniform)
-  __device__ V3 support(int g, V3 dir) {
-    int t = IT(IO_cg_type, g);
-    M3 R = ldm(s.gmat + 9 * g);
-    V3 p = ld3(s.gpos + 3 * g), sz = ld3(&FP(FO_cg_size, 3 * g));
-    V3 ld = mtv(R, dir), lp = v3(0, 0, 0);
-    if (t == G_BOX) lp = v3(ld.x >= 0 ? sz.x : -sz.x, ld.y >= 0 ? sz.y : -sz.y, ld.z >= 0 ? sz.z : -sz.z);
-    else if (t == G_SPHERE) { float n = norm(ld); if (n > FMIN) lp = ld * (sz.x / n); }
-    else if (t == G_CYLINDER) {
-      float n = sqrtf(ld.x * ld.x + ld.y * ld.y);
-      if (n > FMIN) { lp.x = ld.x / n * sz.x; lp.y = ld.y / n * sz.x; }
-      lp.z = ld.z >= 0 ? sz.y : -sz.y;
-    } else if (t == G_CAPSULE) {
-      float n = norm(ld);
-      if (n > FMIN) lp = ld * (sz.x / n);
-      lp.z += ld.z >= 0 ? sz.y : -sz.y;
-    } else if (t == G_ELLIPSOID) {
-      V3 tt = v3(ld.x * sz.x, ld.y * sz.y, ld.z * sz.z);
-      float n = norm(tt);
-      if (n > FMIN) lp = v3(tt.x / n * sz.x, tt.y / n * sz.y, tt.z / n * sz.z);
-    } else if (t == G_MESH) {
-      int adr = IT(IO_cg_meshadr, g), num = IT(IO_cg_meshnum, g);
-      float bv = -3.0e38f;
-      int bi = 0x7fffffff;
-      for (int i = lane; i < num; i += 64) {
-        const float* v = m.mesh_vert + 3 * (adr + i);
-        float val = v[0] * ld.x + v[1] * ld.y + v[2] * ld.z;
-        if (val > bv) { bv = val; bi = i; }
-      }
-      // wave arg-max, lowest index wins ties (matches the serial first-maximum scan)
-      for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_xor(bv, o);
-        int oi = __shfl_xor(bi, o);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-      }
-      bi = uni(bi);
-      lp = ld3(m.mesh_vert + 3 * (adr + bi));
-    }
-    return p + mv(R, lp);
-  }
+  __device__ __forceinline__ V3 support(int g, V3 dir) const { return geom_support(g, dir, (gcf)m.mesh_vert, lane); }
 
   // contact parameters of a geom pair (MuJoCo's mixing rules: priority, solmix-weighted solref/solimp, max friction);
   // evaluated once per candidate pair, uniformly by every lane, from the per-geom table staged in LDS
@@ -800,9 +928,9 @@ struct Sim {
   __device__ __forceinline__ CPar contact_params(int g1, int g2, float margin, float gap) const {
     CPar cp;
     cp.margin_gap = margin - gap;
-    const float* a = s.gpar + 12 * g1;
-    const float* b = s.gpar + 12 * g2;
-    const int c1 = s.gcp[g1], c2 = s.gcp[g2];
+    const float* a = sm.gpar + 12 * g1;
+    const float* b = sm.gpar + 12 * g2;
+    const int c1 = sm.gcp[g1], c2 = sm.gcp[g2];
     const int p1 = c1 >> 8, p2 = c2 >> 8, d1 = c1 & 255, d2 = c2 & 255;
     if (p1 != p2) {
       const float* w = p1 > p2 ? a : b;
@@ -829,24 +957,24 @@ struct Sim {
   __device__ __forceinline__ void emit_contacts(bool has, int cap, float dist, V3 pos, V3 nrm, int g1, int g2, const CPar& cp) {
     const u64 mk = __ballot(has);
     const int rank = __popcll(mk & lanemask_lt(lane));
-    const int base = s.ncon;
+    const int base = sm.ncon;
     int total = __popcll(mk);
     if (total > cap) total = cap;
     if (base + total > SM::NCON_) total = SM::NCON_ - base;
     if (has && rank < total) {
       const int c = base + rank;
-      s.cdist[c] = dist;
-      st3(s.cpos + 3 * c, pos);
-      make_frame(nrm, s.cframe + 9 * c);
-      s.cg1[c] = g1; s.cg2[c] = g2; s.cdim[c] = cp.dim;
-      s.cmargin[c] = cp.margin_gap;
-      s.csolref[2 * c] = cp.solref[0]; s.csolref[2 * c + 1] = cp.solref[1];
-      for (int k = 0; k < 5; k++) s.csolimp[5 * c + k] = cp.solimp[k];
-      float* f = s.cfri + 5 * c;
+      sm.cdist[c] = dist;
+      st3(sm.cpos + 3 * c, pos);
+      make_frame(nrm, sm.cframe + 9 * c);
+      sm.cg1[c] = g1; sm.cg2[c] = g2; sm.cdim[c] = cp.dim;
+      sm.cmargin[c] = cp.margin_gap;
+      sm.csolref[2 * c] = cp.solref[0]; sm.csolref[2 * c + 1] = cp.solref[1];
+      for (int k = 0; k < 5; k++) sm.csolimp[5 * c + k] = cp.solimp[k];
+      float* f = sm.cfri + 5 * c;
       f[0] = f[1] = cp.fr[0]; f[2] = cp.fr[1]; f[3] = f[4] = cp.fr[2];
     }
     SYNC();
-    if (lane == 0) s.ncon = base + total;
+    if (lane == 0) sm.ncon = base + total;
     SYNC();
   }
 
@@ -857,10 +985,10 @@ struct Sim {
   // box(g1)-box(g2): separating-axis test with one lane per axis (6 face + 9 edge), then either one edge-edge contact or a
   // lane-parallel Sutherland-Hodgman clip of the incident face against the reference face (lane i = polygon vertex i).
   // Same decisions, tie-breaks and contact order as the serial restatement in oracle/rsim_oracle.c box_box().
-  __device__ void box_box(int g1, int g2, float margin, const CPar& cp) {
-    const V3 pa = ld3(s.gpos + 3 * g1), pb = ld3(s.gpos + 3 * g2);
-    const M3 Ra = ldm(s.gmat + 9 * g1), Rb = ldm(s.gmat + 9 * g2);
-    const V3 ha = ld3(s.gst + 8 * g1), hb = ld3(s.gst + 8 * g2);
+  __device__ __forceinline__ void box_box(int g1, int g2, float margin, const CPar& cp) {
+    const V3 pa = ld3(sm.gpos + 3 * g1), pb = ld3(sm.gpos + 3 * g2);
+    const M3 Ra = ldm(sm.gmat + 9 * g1), Rb = ldm(sm.gmat + 9 * g2);
+    const V3 ha = ld3(sm.gst + 8 * g1), hb = ld3(sm.gst + 8 * g2);
     const V3 A0 = col(Ra, 0), A1 = col(Ra, 1), A2 = col(Ra, 2), B0 = col(Rb, 0), B1 = col(Rb, 1), B2 = col(Rb, 2);
     const V3 dab = pb - pa;
     // ---- one axis per lane
@@ -936,7 +1064,7 @@ struct Sim {
       px = dot(rel, Rru); py = dot(rel, Rrv); pz = dot(rel, n) - hrax;
     }
     int np = 4;
-    float* poly = s.u.b.poly;  // [16][3] staging for the order-preserving scatter
+    float* poly = sm.u.b.poly;  // [16][3] staging for the order-preserving scatter
     for (int pass = 0; pass < 4 && np > 0; pass++) {
       const bool ax0 = pass < 2;
       const float h = ax0 ? hru : hrv, sign = (pass & 1) ? -1.f : 1.f;
@@ -994,9 +1122,9 @@ struct Sim {
   }
 
   // Minkowski Portal Refinement (uniform control flow; support() is wave-cooperative)
-  __device__ void convex_convex(int g1, int g2, float margin, const CPar& cp) {
+  __device__ __forceinline__ void convex_convex(int g1, int g2, float margin, const CPar& cp) {
     const float tol = 1e-6f;
-    V3 v0 = ld3(s.gcen + 3 * g1) - ld3(s.gcen + 3 * g2);
+    V3 v0 = ld3(sm.gcen + 3 * g1) - ld3(sm.gcen + 3 * g2);
     if (norm(v0) < 1e-9f) v0.x = 1e-5f;
     V3 dir = normalized(-v0);
     V3 p11 = support(g1, dir), p12 = support(g2, -dir), v1 = p11 - p12;
@@ -1057,13 +1185,14 @@ struct Sim {
 
   // oriented bounding box of colliding geom g: world centre o, half extents h along the columns of gmat
   __device__ __forceinline__ void geom_obb(int g, const M3& R, V3& o, V3& h) const {
-    const float* st = s.gst + 8 * g;
+    const float* st = sm.gst + 8 * g;
     h = ld3(st);
-    o = ld3(s.gpos + 3 * g) + mv(R, ld3(st + 3));
+    o = ld3(sm.gpos + 3 * g) + mv(R, ld3(st + 3));
   }
 
-  __device__ void collision() {
-    if (lane == 0) s.ncon = 0;
+  __device__ __forceinline__ void collision() {
+    const LaneConst K = fetchK();
+    if (lane == 0) sm.ncon = 0;
     // broadphase: lane p tests candidate pair p (bounding spheres, then the 6 face axes of the two oriented boxes);
     // order-preserving compaction of the survivors
     int ncand = 0;
@@ -1074,24 +1203,24 @@ struct Sim {
       bool pass = false;
       if ((pr >> 16) & 1) {
         const int g1 = pr & 255, g2 = (pr >> 8) & 255;
-        const float* st1 = s.gst + 8 * g1;
-        const float* st2 = s.gst + 8 * g2;
+        const float* st1 = sm.gst + 8 * g1;
+        const float* st2 = sm.gst + 8 * g2;
         const float margin = fmaxf(st1[7], st2[7]);
-        const V3 c2 = ld3(s.gcen + 3 * g2);
-        const M3 R2 = ldm(s.gmat + 9 * g2);
+        const V3 c2 = ld3(sm.gcen + 3 * g2);
+        const M3 R2 = ldm(sm.gmat + 9 * g2);
         V3 o2, h2;
         geom_obb(g2, R2, o2, h2);
-        if (s.gtype[g1] == G_PLANE) {
-          const V3 nrm = v3(s.gmat[9 * g1 + 2], s.gmat[9 * g1 + 5], s.gmat[9 * g1 + 8]);
-          const V3 pp = ld3(s.gpos + 3 * g1);
+        if (sm.gtype[g1] == G_PLANE) {
+          const V3 nrm = v3(sm.gmat[9 * g1 + 2], sm.gmat[9 * g1 + 5], sm.gmat[9 * g1 + 8]);
+          const V3 pp = ld3(sm.gpos + 3 * g1);
           pass = dot(c2 - pp, nrm) - st2[6] <= margin;
           if (pass) pass = dot(o2 - pp, nrm) - (h2.x * fabsf(dot(nrm, col(R2, 0))) + h2.y * fabsf(dot(nrm, col(R2, 1))) + h2.z * fabsf(dot(nrm, col(R2, 2)))) <= margin;
         } else {
-          const V3 rel = c2 - ld3(s.gcen + 3 * g1);
+          const V3 rel = c2 - ld3(sm.gcen + 3 * g1);
           const float bound = st1[6] + st2[6] + margin;
           pass = dot(rel, rel) <= bound * bound;
           if (pass) {
-            const M3 R1 = ldm(s.gmat + 9 * g1);
+            const M3 R1 = ldm(sm.gmat + 9 * g1);
             V3 o1, h1;
             geom_obb(g1, R1, o1, h1);
             const M3 C = mtm(R1, R2);  // C[i][j] = A_i . B_j
@@ -1107,35 +1236,35 @@ struct Sim {
         }
       }
       const u64 mk = __ballot(pass);
-      if (pass) s.u.b.cand[ncand + __popcll(mk & lanemask_lt(lane))] = 64 * t + lane;
+      if (pass) sm.u.b.cand[ncand + __popcll(mk & lanemask_lt(lane))] = 64 * t + lane;
       ncand += __popcll(mk);
     }
     SYNC();
     pf.mark(RP_BROAD);
     pf.count(RP_N_CAND, ncand);
     for (int ci = 0; ci < ncand; ci++) {
-      int p = uni(s.u.b.cand[ci]);
+      int p = uni(sm.u.b.cand[ci]);
       int g1 = uni(IT(IO_pair_g1, p)), g2 = uni(IT(IO_pair_g2, p));
-      int t1 = uni(s.gtype[g1]), t2 = uni(s.gtype[g2]);
-      const float margin = fmaxf(s.gst[8 * g1 + 7], s.gst[8 * g2 + 7]), gap = fmaxf(s.gpar[12 * g1 + 11], s.gpar[12 * g2 + 11]);
+      int t1 = uni(sm.gtype[g1]), t2 = uni(sm.gtype[g2]);
+      const float margin = fmaxf(sm.gst[8 * g1 + 7], sm.gst[8 * g2 + 7]), gap = fmaxf(sm.gpar[12 * g1 + 11], sm.gpar[12 * g2 + 11]);
       const CPar cp = contact_params(g1, g2, margin, gap);
       if (t1 == G_PLANE && t2 == G_BOX) {
-        const V3 nrm = v3(s.gmat[9 * g1 + 2], s.gmat[9 * g1 + 5], s.gmat[9 * g1 + 8]);
+        const V3 nrm = v3(sm.gmat[9 * g1 + 2], sm.gmat[9 * g1 + 5], sm.gmat[9 * g1 + 8]);
         float dist = 0;
         V3 wp = v3(0, 0, 0);
         bool hit = false;
         if (lane < 8) {
-          const V3 sz = ld3(s.gst + 8 * g2);
+          const V3 sz = ld3(sm.gst + 8 * g2);
           const V3 lp = v3((lane & 1) ? sz.x : -sz.x, (lane & 2) ? sz.y : -sz.y, (lane & 4) ? sz.z : -sz.z);
-          wp = ld3(s.gpos + 3 * g2) + mv(ldm(s.gmat + 9 * g2), lp);
-          dist = dot(wp - ld3(s.gpos + 3 * g1), nrm);
+          wp = ld3(sm.gpos + 3 * g2) + mv(ldm(sm.gmat + 9 * g2), lp);
+          dist = dot(wp - ld3(sm.gpos + 3 * g1), nrm);
           hit = dist <= margin;
         }
         emit_contacts(hit, 4, dist, wp - nrm * (0.5f * dist), nrm, g1, g2, cp);  // first four corners in corner order
       } else if (t1 == G_PLANE) {
-        const V3 nrm = v3(s.gmat[9 * g1 + 2], s.gmat[9 * g1 + 5], s.gmat[9 * g1 + 8]);
+        const V3 nrm = v3(sm.gmat[9 * g1 + 2], sm.gmat[9 * g1 + 5], sm.gmat[9 * g1 + 8]);
         const V3 sp = support(g2, -nrm);
-        const float dist = dot(sp - ld3(s.gpos + 3 * g1), nrm);
+        const float dist = dot(sp - ld3(sm.gpos + 3 * g1), nrm);
         emit_contacts(lane == 0 && dist <= margin, 1, dist, sp - nrm * (0.5f * dist), nrm, g1, g2, cp);
       } else if (t1 == G_BOX && t2 == G_BOX) {
         box_box(g1, g2, margin, cp);
@@ -1179,26 +1308,27 @@ struct Sim {
   // Row list: (1) friction-loss dofs, (2) joint limits (lower side first), (3) contacts in detection order.
   // The lanes that own the source objects (dof / joint / contact) publish a row descriptor and the row scalars; then lane r
   // builds Jacobian row r in registers, writes it once to LDS (MFMA operand) and finishes aref with its own J.qvel.
-  __device__ void make_constraint() {
+  __device__ __forceinline__ void make_constraint() {
+    const LaneConst K = fetchK();
     const int nv = m.nv;
     int nefc = 0;
     const bool isdof = lane < nv;
     const int jt = (K.dinfo >> 26) & 15, qa = (K.dinfo >> 10) & 255;
     // (1) friction loss
     {
-      const bool act = isdof && s.fricFl[lane] > 0.f;
+      const bool act = isdof && sm.fricFl[lane] > 0.f;
       const u64 mk = __ballot(act);
       if (act) {
         const int r = nefc + __popcll(mk & lanemask_lt(lane));
-        s.e_desc[r] = C_FRICTION_DOF | (lane << 4);
-        s.e_R[r] = s.fricR[lane]; s.e_B[r] = s.fricB[lane]; s.e_aref[r] = 0.f;
+        sm.e_desc[r] = C_FRICTION_DOF | (lane << 4);
+        sm.e_R[r] = sm.fricR[lane]; sm.e_B[r] = sm.fricB[lane]; sm.e_aref[r] = 0.f;
       }
       nefc += __popcll(mk);
     }
     // (2) joint limits: dof lane i owns its hinge / slide joint; lower side before upper side
     {
       const bool lim = isdof && ((K.dinfo >> 9) & 1) && (jt == JNT_HINGE || jt == JNT_SLIDE);
-      const float qv = lim ? s.qpos[qa] : 0.f;
+      const float qv = lim ? sm.qpos[qa] : 0.f;
       const float dlo = qv - K.jr0, dhi = K.jr1 - qv;
       const bool alo = lim && dlo < K.jmargin, ahi = lim && dhi < K.jmargin;
       const u64 mlo = __ballot(alo), mhi = __ballot(ahi);
@@ -1208,24 +1338,24 @@ struct Sim {
         const int r = nefc + before;
         float R, Bd, Kt;
         row_scalars(dlo, K.jmargin, solref, solimp, K.dinvw, R, Bd, Kt);
-        s.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (0 << 12);
-        s.e_R[r] = R; s.e_B[r] = Bd; s.e_aref[r] = Kt;
+        sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (0 << 12);
+        sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt;
       }
       if (ahi) {
         const int r = nefc + before + (alo ? 1 : 0);
         float R, Bd, Kt;
         row_scalars(dhi, K.jmargin, solref, solimp, K.dinvw, R, Bd, Kt);
-        s.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (1 << 12);
-        s.e_R[r] = R; s.e_B[r] = Bd; s.e_aref[r] = Kt;
+        sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (1 << 12);
+        sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt;
       }
       nefc += __popcll(mlo) + __popcll(mhi);
     }
     // (3) contacts: lane c owns contact c; exclusive scan of the active dimensions gives the first row of each block
     {
-      const int ncon = uni(s.ncon);
+      const int ncon = uni(sm.ncon);
       const bool has = lane < ncon;
-      const int dim = has ? s.cdim[lane] : 0;
-      const bool active = has && s.cdist[lane] < s.cmargin[lane];
+      const int dim = has ? sm.cdim[lane] : 0;
+      const bool active = has && sm.cdist[lane] < sm.cmargin[lane];
       int need = active ? dim : 0, incl = need;
 #pragma unroll
       for (int o = 1; o < SM::NCON_; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
@@ -1234,39 +1364,39 @@ struct Sim {
       // a block that does not fit is dropped together with everything after it (rows must stay contiguous)
       const u64 bad = __ballot(active && !fits);
       const bool keep = fits && (bad == 0 || lane < (__ffsll((long long)bad) - 1));
-      if (has) s.cefc[lane] = keep ? first : -1;
+      if (has) sm.cefc[lane] = keep ? first : -1;
       if (keep) {
-        const int g1 = s.cg1[lane], g2 = s.cg2[lane];
-        const int b1 = s.gbody[g1], b2 = s.gbody[g2];
-        const float tran = s.biw[2 * b1] + s.biw[2 * b2], rot = s.biw[2 * b1 + 1] + s.biw[2 * b2 + 1];
+        const int g1 = sm.cg1[lane], g2 = sm.cg2[lane];
+        const int b1 = sm.gbody[g1], b2 = sm.gbody[g2];
+        const float tran = sm.biw[2 * b1] + sm.biw[2 * b2], rot = sm.biw[2 * b1 + 1] + sm.biw[2 * b2 + 1];
         float R0, Bd, Kt;
-        row_scalars(s.cdist[lane], s.cmargin[lane], s.csolref + 2 * lane, s.csolimp + 5 * lane, tran, R0, Bd, Kt);
+        row_scalars(sm.cdist[lane], sm.cmargin[lane], sm.csolref + 2 * lane, sm.csolimp + 5 * lane, tran, R0, Bd, Kt);
         const int type = dim == 1 ? C_CONTACT_FRICTIONLESS : C_CONTACT_ELLIPTIC;
-        const float* f = s.cfri + 5 * lane;
+        const float* f = sm.cfri + 5 * lane;
         const float R1 = R0 / fmaxf(1e-15f, opt_impratio);
         (void)rot;  // friction rows: same gains, zero position term; their regularisers follow the cone scaling of R0
 #pragma unroll
         for (int k = 0; k < CD; k++) {
           if (k < dim) {
             const int r = first + k;
-            s.e_desc[r] = type | (lane << 4) | (k << 12);
-            s.e_R[r] = k == 0 ? R0 : (k == 1 ? R1 : R1 * f[0] * f[0] / fmaxf(1e-15f, f[k - 1] * f[k - 1]));
-            s.e_B[r] = Bd; s.e_aref[r] = k == 0 ? Kt : 0.f;
+            sm.e_desc[r] = type | (lane << 4) | (k << 12);
+            sm.e_R[r] = k == 0 ? R0 : (k == 1 ? R1 : R1 * f[0] * f[0] / fmaxf(1e-15f, f[k - 1] * f[k - 1]));
+            sm.e_B[r] = Bd; sm.e_aref[r] = k == 0 ? Kt : 0.f;
           }
         }
-        s.cmu[lane] = dim > 1 ? f[0] * sqrtf(R1 / R0) : 0.f;
+        sm.cmu[lane] = dim > 1 ? f[0] * sqrtf(R1 / R0) : 0.f;
       }
       const u64 kept = __ballot(keep);
       const int lastc = kept ? 63 - __clzll((long long)kept) : -1;
       const int add = lastc >= 0 ? __shfl(first + dim, lastc) - nefc : 0;
       nefc += add;
     }
-    if (lane == 0) s.nefc = nefc;
+    if (lane == 0) sm.nefc = nefc;
     SYNC();
     // ---- lane r builds row r
     {
       const bool valid = lane < nefc;
-      const int desc = valid ? s.e_desc[lane] : 0;
+      const int desc = valid ? sm.e_desc[lane] : 0;
       const int type = desc & 15, id = (desc >> 4) & 255, kk = (desc >> 12) & 15;
       float Jr[NV16];
 #pragma unroll
@@ -1280,17 +1410,17 @@ struct Sim {
         for (int k = 0; k < NV16; k++) Jr[k] = k == id ? sg : 0.f;
       } else if (valid) {
         const int c = id;
-        const int g1 = s.cg1[c], g2 = s.cg2[c];
-        const int b1 = s.gbody[g1], b2 = s.gbody[g2];
-        const unsigned d1 = (unsigned)s.bdofs[b1], d2 = (unsigned)s.bdofs[b2];
-        const V3 pos = ld3(s.cpos + 3 * c);
-        const V3 ax = ld3(s.cframe + 9 * c + 3 * (kk < 3 ? kk : kk - 3));
-        const V3 o1 = pos - ld3(s.rootcom + 3 * s.broot[b1]), o2 = pos - ld3(s.rootcom + 3 * s.broot[b2]);
+        const int g1 = sm.cg1[c], g2 = sm.cg2[c];
+        const int b1 = sm.gbody[g1], b2 = sm.gbody[g2];
+        const unsigned d1 = (unsigned)sm.bdofs[b1], d2 = (unsigned)sm.bdofs[b2];
+        const V3 pos = ld3(sm.cpos + 3 * c);
+        const V3 ax = ld3(sm.cframe + 9 * c + 3 * (kk < 3 ? kk : kk - 3));
+        const V3 o1 = pos - ld3(sm.rootcom + 3 * sm.broot[b1]), o2 = pos - ld3(sm.rootcom + 3 * sm.broot[b2]);
         const V3 t1 = cross(o1, ax), t2 = cross(o2, ax);  // ax . (ca x o) = ca . (o x ax)
         const bool lin = kk < 3;
 #pragma unroll
         for (int k = 0; k < NV16; k++) {
-          const S6 cd = ld6(s.cdof + 8 * k);
+          const S6 cd = ld6(sm.cdof + CS6 * k);
           const float s1 = (float)((d1 >> k) & 1u), s2 = (float)((d2 >> k) & 1u);
           const float dl = dot(ax, cd.l), da = dot(ax, cd.a);
           const float v1 = lin ? dl + dot(t1, cd.a) : da, v2 = lin ? dl + dot(t2, cd.a) : da;
@@ -1299,46 +1429,48 @@ struct Sim {
       }
       float jv = 0.f;
 #pragma unroll
-      for (int k = 0; k < NV16; k++) { s.J[lane * NV16 + k] = Jr[k]; jv = fmaf(Jr[k], s.qvel[k], jv); }
-      if (valid) s.e_aref[lane] = -s.e_B[lane] * jv - s.e_aref[lane];
+      for (int k = 0; k < NV16; k++) { sm.J[lane * JS + k] = Jr[k]; jv = fmaf(Jr[k], sm.qvel[k], jv); }
+      if (valid) sm.e_aref[lane] = -sm.e_B[lane] * jv - sm.e_aref[lane];
     }
     SYNC();
   }
 
   // ---------------------------------------------------------------- actuation / smooth acceleration
-  __device__ void actuation_acceleration() {
+  __device__ __forceinline__ void actuation_acceleration() {
+    const LaneConst K = fetchK();
     const int nv = m.nv;
-    if (lane < NV16) s.qfrc_actuator[lane] = 0.f;
+    if (lane < NV16) sm.qfrc_actuator[lane] = 0.f;
     SYNC();
     if (lane < m.nu) {
       const int d = K.ainfo & 255, qa = (K.ainfo >> 8) & 255;
-      float ctrl = s.ctrl[lane];
+      float ctrl = sm.ctrl[lane];
       if ((K.ainfo >> 18) & 1) ctrl = fmaxf(K.acr0, fminf(K.acr1, ctrl));
       float force = K.again * ctrl;
-      if (((K.ainfo >> 16) & 3) == 1) force += K.ab0 + K.ab1 * K.agear * s.qpos[qa] + K.ab2 * K.agear * s.qvel[d];
+      if (((K.ainfo >> 16) & 3) == 1) force += K.ab0 + K.ab1 * K.agear * sm.qpos[qa] + K.ab2 * K.agear * sm.qvel[d];
       if ((K.ainfo >> 19) & 1) force = fmaxf(K.afr0, fminf(K.afr1, force));
-      atomicAdd(&s.qfrc_actuator[d], K.agear * force);  // one actuator per dof in every supported model: order-independent
+      atomicAdd(&sm.qfrc_actuator[d], K.agear * force);  // one actuator per dof in every supported model: order-independent
     }
     SYNC();
     float qs = 0.f;
     if (lane < nv) {
-      qs = s.qfrc_passive[lane] - s.qfrc_bias[lane] + s.qfrc_actuator[lane];
-      s.qfrc_smooth[lane] = qs;
+      qs = sm.qfrc_passive[lane] - sm.qfrc_bias[lane] + sm.qfrc_actuator[lane];
+      sm.qfrc_smooth[lane] = qs;
     }
     float as;
     {
       float lr[NV16], lt[NV16], linv[NV16];
       const int rr = lane & (NV16 - 1);
 #pragma unroll
-      for (int k = 0; k < NV16; k++) { lr[k] = s.L[rr * NVP + k]; lt[k] = s.L[k * NVP + rr]; linv[k] = s.invdiag[k]; }
+      for (int k = 0; k < NV16; k++) { lr[k] = sm.L[rr * NVP + k]; lt[k] = sm.L[k * NVP + rr]; linv[k] = sm.invdiag[k]; }
       as = rchol_solve<NV16>(lr, lt, linv, lane < nv ? qs : 0.f, lane);
     }
-    if (lane < nv) s.qacc_smooth[lane] = as;
+    if (lane < nv) sm.qacc_smooth[lane] = as;
     SYNC();
   }
 
   // ---------------------------------------------------------------- semi-implicit Euler with implicit joint damping
-  __device__ void euler() {
+  __device__ __forceinline__ void euler() {
+    const LaneConst K = fetchK();
     const int nv = m.nv;
     const float h = opt_h;
     float qa;
@@ -1347,49 +1479,51 @@ struct Sim {
       const int rr = lane & (NV16 - 1);
       const float hd = h * __shfl(K.damping, rr);
 #pragma unroll
-      for (int k = 0; k < NV16; k++) hr[k] = s.M[rr * NVP + k] + (rr == k && rr < nv ? hd : 0.f);
+      for (int k = 0; k < NV16; k++) hr[k] = sm.M[rr * NVP + k] + (rr == k && rr < nv ? hd : 0.f);
       rchol_factor<NV16>(hr, hinv);
       if (lane < NV16) {
 #pragma unroll
-        for (int k = 0; k < NV16; k++) s.H[lane * NVP + k] = hr[k];
+        for (int k = 0; k < NV16; k++) sm.H[lane * NVP + k] = hr[k];
       }
       SYNC();
 #pragma unroll
-      for (int k = 0; k < NV16; k++) ht[k] = s.H[k * NVP + rr];
-      qa = rchol_solve<NV16>(hr, ht, hinv, lane < nv ? s.qfrc_smooth[lane] + s.qfrc_constraint[lane] : 0.f, lane);
+      for (int k = 0; k < NV16; k++) ht[k] = sm.H[k * NVP + rr];
+      qa = rchol_solve<NV16>(hr, ht, hinv, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, lane);
     }
-    if (lane < nv) { s.qvel[lane] += h * qa; s.qacc_ws[lane] = s.qacc[lane]; }
+    if (lane < nv) { sm.qvel[lane] += h * qa; sm.qacc_ws[lane] = sm.qacc[lane]; }
     SYNC();
     // positions: lane b integrates the joint of body b
     const int jt = K.binfo & 15, pa = (K.binfo >> 4) & 255, da = (K.binfo >> 12) & 255;
     if (lane < m.nbody && jt != 15) {
       if (jt == JNT_FREE) {
-        for (int k = 0; k < 3; k++) s.qpos[pa + k] += h * s.qvel[da + k];
-        const V3 w = ld3(s.qvel + da + 3);
+        for (int k = 0; k < 3; k++) sm.qpos[pa + k] += h * sm.qvel[da + k];
+        const V3 w = ld3(sm.qvel + da + 3);
         const float wn = norm(w), ang = wn * h;
         if (ang > 1e-15f) {
           float sn, cs;
           sincos_f(0.5f * ang, sn, cs);
           const float k = sn / wn;
           const Q4 dq = {cs, w.x * k, w.y * k, w.z * k};
-          stq(s.qpos + pa + 3, qnorm(qmul(ldq(s.qpos + pa + 3), dq)));
+          stq(sm.qpos + pa + 3, qnorm(qmul(ldq(sm.qpos + pa + 3), dq)));
         }
-      } else s.qpos[pa] += h * s.qvel[da];
+      } else sm.qpos[pa] += h * sm.qvel[da];
     }
     SYNC();
   }
 
   // ---------------------------------------------------------------- built-in controller: OSC_POSE + GRIP
-  __device__ void ctrl_set_goal(const float* action) {
+  __device__ __forceinline__ void ctrl_set_goal(const float* action) {
+    const LaneConst K = fetchK();
     const DCtrl& c = m.ctrl;
     float sc[6];
+#pragma unroll
     for (int i = 0; i < 6; i++) {
       float scale = fabsf(c.out_max[i] - c.out_min[i]) / fabsf(c.in_max[i] - c.in_min[i]);
       float a = fmaxf(c.in_min[i], fminf(c.in_max[i], action[i]));
       sc[i] = (a - 0.5f * (c.in_max[i] + c.in_min[i])) * scale + 0.5f * (c.out_max[i] + c.out_min[i]);
     }
-    V3 op = ld3(s.spos + 3 * c.base_site), ep = ld3(s.spos + 3 * c.eef_site);
-    M3 oR = ldm(s.smat + 9 * c.base_site), eR = ldm(s.smat + 9 * c.eef_site);
+    V3 op = ld3(sm.spos + 3 * c.base_site), ep = ld3(sm.spos + 3 * c.eef_site);
+    M3 oR = ldm(sm.smat + 9 * c.base_site), eR = ldm(sm.smat + 9 * c.eef_site);
     V3 gp = mtv(oR, ep - op) + v3(sc[0], sc[1], sc[2]);
     V3 d = v3(sc[3], sc[4], sc[5]);
     float ang = norm(d);
@@ -1405,24 +1539,25 @@ struct Sim {
     M3 go = mm(Re, mtm(oR, eR));
     SYNC();
     if (lane == 0) {
-      st3(s.cstate + RSIM_CS_GOALPOS, gp);
-      stm(s.cstate + RSIM_CS_GOALORI, go);
-      if (c.ngrip > 0) {
-        float a = action[6], sg = a > 0 ? 1.f : (a < 0 ? -1.f : 0.f);
-        for (int i = 0; i < c.ngrip; i++) s.cstate[RSIM_CS_GRIP + i] = fmaxf(-1.f, fminf(1.f, s.cstate[RSIM_CS_GRIP + i] + c.grip_sign[i] * c.grip_speed * sg));
-      }
+      st3(sm.cstate + RSIM_CS_GOALPOS, gp);
+      stm(sm.cstate + RSIM_CS_GOALORI, go);
+    }
+    if (lane < c.ngrip) {
+      const float a = action[6], sg = a > 0 ? 1.f : (a < 0 ? -1.f : 0.f);
+      sm.cstate[RSIM_CS_GRIP + lane] = fmaxf(-1.f, fminf(1.f, sm.cstate[RSIM_CS_GRIP + lane] + K.cgs * c.grip_speed * sg));
     }
     SYNC();
   }
 
   // reset_goal + initial_joint capture (Controller.__init__ / OSC.reset_goal)
-  __device__ void ctrl_reset() {
+  __device__ __forceinline__ void ctrl_reset() {
+    const LaneConst K = fetchK();
     const DCtrl& c = m.ctrl;
-    if (lane < c.ndof) s.cstate[RSIM_CS_Q0 + lane] = s.qpos[c.qpos_idx[lane]];
+    if (lane < c.ndof) sm.cstate[RSIM_CS_Q0 + lane] = sm.qpos[K.cq];
     if (lane == 0) {
-      st3(s.cstate + RSIM_CS_GOALPOS, ld3(s.spos + 3 * c.eef_site));
-      for (int k = 0; k < 9; k++) s.cstate[RSIM_CS_GOALORI + k] = s.smat[9 * c.eef_site + k];
-      for (int i = 0; i < RSIM_GRIP_MAX; i++) s.cstate[RSIM_CS_GRIP + i] = 0.f;
+      st3(sm.cstate + RSIM_CS_GOALPOS, ld3(sm.spos + 3 * c.eef_site));
+      for (int k = 0; k < 9; k++) sm.cstate[RSIM_CS_GOALORI + k] = sm.smat[9 * c.eef_site + k];
+      for (int i = 0; i < RSIM_GRIP_MAX; i++) sm.cstate[RSIM_CS_GRIP + i] = 0.f;
     }
     SYNC();
   }
@@ -1430,19 +1565,20 @@ struct Sim {
   // OperationalSpaceController.run_controller (osc.py:403-495) + SimpleGripController, tau clipped into ctrl.
   // Lambda^-1 = J Ma^-1 J^T = Y^T Y with Y = La^-1 J^T (register Cholesky of the arm block, 6 forward solves);
   // N^T Ma tmp = Ma tmp - J^T Lambda (J tmp), so no explicit inverse of Ma is ever formed.
-  __device__ void ctrl_run() {
+  __device__ __forceinline__ void ctrl_run() {
+    const LaneConst K = fetchK();
     const DCtrl& c = m.ctrl;
     const int n = c.ndof;
     constexpr int NA = RSIM_ARM_MAX;
-    float* Jm = s.u.k.Jm;             // [6][NA]  arm Jacobian (lin rows 0..2, ang rows 3..5)
-    float* Li = s.u.k.Li;             // [6][6]   Lambda^-1
-    float* vv = s.u.k.vv;             // 6: J tmp
+    float* Jm = sm.u.k.Jm;             // [6][NA]  arm Jacobian (lin rows 0..2, ang rows 3..5)
+    float* Li = sm.u.k.Li;             // [6][6]   Lambda^-1
+    float* vv = sm.u.k.vv;             // 6: J tmp
     const int eb = __shfl(K.sbody, c.eef_site), bb = __shfl(K.sbody, c.base_site);
-    const V3 ep = ld3(s.spos + 3 * c.eef_site), op = ld3(s.spos + 3 * c.base_site);
+    const V3 ep = ld3(sm.spos + 3 * c.eef_site), op = ld3(sm.spos + 3 * c.base_site);
     // this lane's arm dof (lanes 0..n-1) and its joint-space quantities
-    const int di = lane < n ? c.dof_idx[lane] : 0, qi = lane < n ? c.qpos_idx[lane] : 0;
-    const float qd_i = lane < n ? s.qvel[di] : 0.f;
-    const float tmp_i = lane < n ? c.nullspace_kp * (s.cstate[RSIM_CS_Q0 + lane] - s.qpos[qi]) - 2.f * sqrtf(c.nullspace_kp) * qd_i : 0.f;
+    const int di = lane < n ? K.cd : 0, qi = lane < n ? K.cq : 0;
+    const float qd_i = lane < n ? sm.qvel[di] : 0.f;
+    const float tmp_i = lane < n ? c.nullspace_kp * (sm.cstate[RSIM_CS_Q0 + lane] - sm.qpos[qi]) - 2.f * sqrtf(c.nullspace_kp) * qd_i : 0.f;
     // Jacobian column of the eef site for this lane's dof
     S6 jc = {v3(0, 0, 0), v3(0, 0, 0)};
     if (lane < n) jc = jac_col(eb, ep, di);
@@ -1457,7 +1593,7 @@ struct Sim {
 #pragma unroll
       for (int k = 0; k < NA; k++) dk[k] = k < n ? c.dof_idx[k] : 0;
 #pragma unroll
-      for (int k = 0; k < NA; k++) mr[k] = (lane < n && k < n) ? s.M[di * NVP + dk[k]] : ((lane & (NA - 1)) == k ? 1.f : 0.f);
+      for (int k = 0; k < NA; k++) mr[k] = (lane < n && k < n) ? sm.M[di * NVP + dk[k]] : ((lane & (NA - 1)) == k ? 1.f : 0.f);
     }
     float matmp = 0.f;   // (Ma tmp)_i
 #pragma unroll
@@ -1485,15 +1621,15 @@ struct Sim {
     }
     SYNC();
     // operational-space errors and wrench (uniform small algebra)
-    const M3 oR = ldm(s.smat + 9 * c.base_site), eR = ldm(s.smat + 9 * c.eef_site);
-    const V3 gpos = ld3(s.cstate + RSIM_CS_GOALPOS);
-    const M3 gori = ldm(s.cstate + RSIM_CS_GOALORI);
+    const M3 oR = ldm(sm.smat + 9 * c.base_site), eR = ldm(sm.smat + 9 * c.eef_site);
+    const V3 gpos = ld3(sm.cstate + RSIM_CS_GOALPOS);
+    const M3 gori = ldm(sm.cstate + RSIM_CS_GOALORI);
     const V3 perr = op + mv(oR, gpos) - ep;
     const M3 dori = mm(oR, gori);
     const V3 oerr = (cross(col(eR, 0), col(dori, 0)) + cross(col(eR, 1), col(dori, 1)) + cross(col(eR, 2), col(dori, 2))) * 0.5f;
     // site velocities from the body spatial velocities of the velocity stage: v = cvel.l + w x (p - com)
-    const S6 ce = ld6(s.u.v.cvel + 8 * eb), cb = ld6(s.u.v.cvel + 8 * bb);
-    const V3 evl = ce.l + cross(ce.a, ep - ld3(s.rootcom + 3 * s.broot[eb])), bvl = cb.l + cross(cb.a, op - ld3(s.rootcom + 3 * s.broot[bb]));
+    const S6 ce = ld6(sm.u.v.cvel + CS6 * eb), cb = ld6(sm.u.v.cvel + CS6 * bb);
+    const V3 evl = ce.l + cross(ce.a, ep - ld3(sm.rootcom + 3 * sm.broot[eb])), bvl = cb.l + cross(cb.a, op - ld3(sm.rootcom + 3 * sm.broot[bb]));
     const V3 dvl = evl - bvl, dva = ce.a - cb.a;
     float F[3] = {perr.x * c.kp[0] - dvl.x * c.kd[0], perr.y * c.kp[1] - dvl.y * c.kd[1], perr.z * c.kp[2] - dvl.z * c.kd[2]};
     float T[3] = {oerr.x * c.kp[3] - dva.x * c.kd[3], oerr.y * c.kp[4] - dva.y * c.kd[4], oerr.z * c.kp[5] - dva.z * c.kd[5]};
@@ -1513,7 +1649,7 @@ struct Sim {
     }
     rchol_factor<NA>(lr6, linv6);
     SYNC();
-    float* Lt = s.u.k.Lt;        // [8][8] transpose staging
+    float* Lt = sm.u.k.Lt;        // [8][8] transpose staging
     if (lane < NA) {
 #pragma unroll
       for (int k = 0; k < NA; k++) Lt[lane * NA + k] = lr6[k];
@@ -1531,18 +1667,20 @@ struct Sim {
         for (int r = 0; r < 6; r++) wrench[r] = bcast(wl, r);
       }
     }
+    const float alo = __shfl(K.acr0, K.ca), ahi = __shfl(K.acr1, K.ca);
     if (lane < n) {
-      float tq = s.qfrc_bias[di] + matmp;
+      float tq = sm.qfrc_bias[di] + matmp;
 #pragma unroll
       for (int r = 0; r < 6; r++) tq = fmaf(comp6(jc, r < 3 ? r + 3 : r - 3), wrench[r] - z[r], tq);
-      s.cstate[RSIM_CS_TAU + lane] = tq;
-      const int a = c.act_idx[lane];
-      s.ctrl[a] = fmaxf(FP(FO_act_ctrlrange, 2 * a), fminf(FP(FO_act_ctrlrange, 2 * a + 1), tq));
+      sm.cstate[RSIM_CS_TAU + lane] = tq;
+      const int a = K.ca;
+      sm.ctrl[a] = fmaxf(alo, fminf(ahi, tq));
     }
+    const float glo = __shfl(K.acr0, K.cga), ghi = __shfl(K.acr1, K.cga);
     if (lane < c.ngrip) {
-      const int a = c.grip_act[lane];
-      const float lo_ = FP(FO_act_ctrlrange, 2 * a), hi_ = FP(FO_act_ctrlrange, 2 * a + 1);
-      s.ctrl[a] = fmaxf(lo_, fminf(hi_, 0.5f * (hi_ + lo_) + 0.5f * (hi_ - lo_) * s.cstate[RSIM_CS_GRIP + lane]));
+      const int a = K.cga;
+      const float lo_ = glo, hi_ = ghi;
+      sm.ctrl[a] = fmaxf(lo_, fminf(hi_, 0.5f * (hi_ + lo_) + 0.5f * (hi_ - lo_) * sm.cstate[RSIM_CS_GRIP + lane]));
     }
     SYNC();
   }
@@ -1628,19 +1766,19 @@ struct Sim {
       }
     }
   }
-  // out_k (lane k < 16) = sum_r J[r][k] * f_r  on the matrix cores; f_r must already be in s.e_force[0..4*nch)
+  // out_k (lane k < 16) = sum_r J[r][k] * f_r  on the matrix cores; f_r must already be in sm.e_force[0..4*nch)
   __device__ __forceinline__ float jt_times_force(int nch) {
     v4f acc = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s.J[64 * c + lane], s.e_force[4 * c + (lane >> 4)], acc, 0, 0, 0);
-    if ((lane & 15) == 0) { float* o = s.red + 4 * (lane >> 4); o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; }
+    for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.J[(4 * c + (lane >> 4)) * JS + (lane & 15)], sm.e_force[4 * c + (lane >> 4)], acc, 0, 0, 0);
+    if ((lane & 15) == 0) { float* o = sm.red + 4 * (lane >> 4); o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; }
     SYNC();
-    float r = s.red[lane & 15];
+    float r = sm.red[lane & 15];
     SYNC();
     return r;
   }
 
-  __device__ void solve_newton() {
-    const int nv = m.nv, n = s.nefc;
+  __device__ __forceinline__ void solve_newton() {
+    const int nv = m.nv, n = sm.nefc;
     const int nch = (n + 3) >> 2;
     const float scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
     const float tolerance = m.tolerance;
@@ -1650,27 +1788,27 @@ struct Sim {
     {
       const int r = rw.valid ? lane : 0;
 #pragma unroll
-      for (int k = 0; k < NV16; k++) rw.J[k] = s.J[lane * NV16 + k];  // rows >= n were written as zeros
-      const int desc = rw.valid ? s.e_desc[r] : 0;
+      for (int k = 0; k < NV16; k++) rw.J[k] = sm.J[lane * JS + k];  // rows >= n were written as zeros
+      const int desc = rw.valid ? sm.e_desc[r] : 0;
       rw.type = rw.valid ? (desc & 15) : -1;
-      rw.R = s.e_R[r]; rw.D = 1.0f / rw.R; rw.aref = rw.valid ? s.e_aref[r] : 0.f; rw.fl = rw.type == C_FRICTION_DOF ? s.fricFl[(desc >> 4) & 255] : 0.f;
+      rw.R = sm.e_R[r]; rw.D = 1.0f / rw.R; rw.aref = rw.valid ? sm.e_aref[r] : 0.f; rw.fl = rw.type == C_FRICTION_DOF ? sm.fricFl[(desc >> 4) & 255] : 0.f;
       rw.ell = rw.type == C_CONTACT_ELLIPTIC;
       const int c = rw.ell ? (desc >> 4) & 255 : 0;
-      rw.kk = rw.ell ? (desc >> 12) & 15 : 0; rw.head = lane - rw.kk; rw.dim = rw.ell ? s.cdim[c] : 1;
-      rw.mu = s.cmu[c];
+      rw.kk = rw.ell ? (desc >> 12) & 15 : 0; rw.head = lane - rw.kk; rw.dim = rw.ell ? sm.cdim[c] : 1;
+      rw.mu = sm.cmu[c];
 #pragma unroll
-      for (int j = 0; j < CD - 1; j++) rw.fj[j] = s.cfri[5 * c + j];
-      rw.fr_own = rw.kk == 0 ? rw.mu : s.cfri[5 * c + rw.kk - 1];
-      rw.Dm = (1.0f / s.e_R[rw.ell ? rw.head : r]) / fmaxf(rw.mu * rw.mu * (1 + rw.mu * rw.mu), 1e-15f);
+      for (int j = 0; j < CD - 1; j++) rw.fj[j] = sm.cfri[5 * c + j];
+      rw.fr_own = rw.kk == 0 ? rw.mu : sm.cfri[5 * c + rw.kk - 1];
+      rw.Dm = (1.0f / sm.e_R[rw.ell ? rw.head : r]) / fmaxf(rw.mu * rw.mu * (1 + rw.mu * rw.mu), 1e-15f);
     }
     // M: row i in lane i (matrix-vector products) and in the MFMA accumulator layout (Hessian seed)
     float Mr[NV16];
 #pragma unroll
-    for (int k = 0; k < NV16; k++) Mr[k] = (lane < nv && k < nv) ? s.M[lane * NVP + k] : 0.f;
+    for (int k = 0; k < NV16; k++) Mr[k] = (lane < nv && k < nv) ? sm.M[lane * NVP + k] : 0.f;
     v4f Macc;
 #pragma unroll
-    for (int v = 0; v < 4; v++) { int i = 4 * (lane >> 4) + v, j = lane & 15; Macc[v] = (i < nv && j < nv) ? s.M[i * NVP + j] : (i == j ? 1.f : 0.f); }
-    const float a_sm = lane < nv ? s.qacc_smooth[lane] : 0.f, a_ws = lane < nv ? s.qacc_ws[lane] : 0.f, f_sm = lane < nv ? s.qfrc_smooth[lane] : 0.f;
+    for (int v = 0; v < 4; v++) { int i = 4 * (lane >> 4) + v, j = lane & 15; Macc[v] = (i < nv && j < nv) ? sm.M[i * NVP + j] : (i == j ? 1.f : 0.f); }
+    const float a_sm = lane < nv ? sm.qacc_smooth[lane] : 0.f, a_ws = lane < nv ? sm.qacc_ws[lane] : 0.f, f_sm = lane < nv ? sm.qfrc_smooth[lane] : 0.f;
     float force; int state; float uj[CD], T, g;
     // ---- warm start: previous acceleration unless the unconstrained one is cheaper
     float cost_sm = wave_sum(row_update(rw, row_dot(rw, a_sm) - rw.aref, force, state, uj, T, g));
@@ -1692,7 +1830,7 @@ struct Sim {
       for (int k = 0; k < NV16; k++) ma = fmaf(Mr[k], bcast(a, k), ma);
       const float gauss = wave_sum(0.5f * (ma - f_sm) * (a - a_sm));
       cost += gauss;
-      s.e_force[lane] = force;
+      sm.e_force[lane] = force;
       SYNC();
       const float jf = jt_times_force(nch);
       float gk = lane < nv ? ma - f_sm - jf : 0.f;
@@ -1716,36 +1854,36 @@ struct Sim {
               float h = grj * grk;
               if (rw.kk > 0 && k2 > 0) h += -g * mu * rw.fr_own * frk * ((rw.kk == k2 ? iT : 0.f) - uo * uj[k2] * iT * iT * iT);
               h *= rw.Dm;
-              const float* Js = s.J + (rw.head + k2) * NV16;
+              const float* Js = sm.J + (rw.head + k2) * JS;
 #pragma unroll
               for (int k = 0; k < NV16; k++) w[k] = fmaf(h, Js[k], w[k]);
             }
           }
         }
 #pragma unroll
-        for (int k = 0; k < NV16; k++) s.u.W[lane * NV16 + k] = w[k];
+        for (int k = 0; k < NV16; k++) sm.u.W[lane * JS + k] = w[k];
       }
       SYNC();
       v4f acc = Macc;
-      for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s.u.W[64 * c + lane], s.J[64 * c + lane], acc, 0, 0, 0);
+      for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.u.W[(4 * c + (lane >> 4)) * JS + (lane & 15)], sm.J[(4 * c + (lane >> 4)) * JS + (lane & 15)], acc, 0, 0, 0);
 #pragma unroll
-      for (int v = 0; v < 4; v++) s.H[(4 * (lane >> 4) + v) * NVP + (lane & 15)] = acc[v];
+      for (int v = 0; v < 4; v++) sm.H[(4 * (lane >> 4) + v) * NVP + (lane & 15)] = acc[v];
       SYNC();
       float sk;
       {
         float hr[NV16], hinv[NV16], ht[NV16];
         const int rr = lane & 15;
 #pragma unroll
-        for (int k = 0; k < NV16; k++) hr[k] = s.H[rr * NVP + k];
+        for (int k = 0; k < NV16; k++) hr[k] = sm.H[rr * NVP + k];
         rchol_factor<NV16>(hr, hinv);
         SYNC();
         if (lane < NV16) {
 #pragma unroll
-          for (int k = 0; k < NV16; k++) s.H[lane * NVP + k] = hr[k];
+          for (int k = 0; k < NV16; k++) sm.H[lane * NVP + k] = hr[k];
         }
         SYNC();
 #pragma unroll
-        for (int k = 0; k < NV16; k++) ht[k] = s.H[k * NVP + rr];
+        for (int k = 0; k < NV16; k++) ht[k] = sm.H[k * NVP + rr];
         sk = rchol_solve<NV16>(hr, ht, hinv, lane < nv ? -gk : 0.f, lane);
         if (lane >= nv) sk = 0.f;
       }
@@ -1800,20 +1938,20 @@ struct Sim {
         break;
       }
     }
-    s.e_force[lane] = force;
+    sm.e_force[lane] = force;
     SYNC();
     const float fc = jt_times_force(nch);
-    if (lane < nv) { s.qfrc_constraint[lane] = fc; s.qacc[lane] = a; }
-    if (lane == 0) s.niter = iter;
+    if (lane < nv) { sm.qfrc_constraint[lane] = fc; sm.qacc[lane] = a; }
+    if (lane == 0) sm.niter = iter;
     pf.count(RP_N_NEWTON, iter);
     SYNC();
   }
 
 
-  __device__ void fwd_constraint() {
-    if (s.nefc == 0) {
-      if (lane < m.nv) { s.qacc[lane] = s.qacc_smooth[lane]; s.qfrc_constraint[lane] = 0.f; }
-      if (lane == 0) s.niter = 0;
+  __device__ __forceinline__ void fwd_constraint() {
+    if (sm.nefc == 0) {
+      if (lane < m.nv) { sm.qacc[lane] = sm.qacc_smooth[lane]; sm.qfrc_constraint[lane] = 0.f; }
+      if (lane == 0) sm.niter = 0;
       SYNC();
       return;
     }
@@ -1825,21 +1963,26 @@ struct Sim {
 // the step kernel
 // ------------------------------------------------------------------------------------------------------------
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
-__global__ __launch_bounds__(64) void k_step(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
+__global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
   typedef Smem<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> SM;
-  __shared__ SM s;
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= b.B) return;
   const float* fp = m.ft + (size_t)env * m.fstride;
-  Sim<SM> sim(s, m, fp, lane, b.prof);
+  Sim<SM> sim(m, fp, lane, b.prof);
   sim.pf.start();
+  if (b.prof && lane == 0) {
+    unsigned long long* wl = b.prof + RP_COUNT + 4 * (size_t)env;
+    wl[0] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+    wl[1] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    wl[2] = wall_clock64();
+  }
   // ---- load state
-  for (int i = lane; i < m.nq; i += 64) s.qpos[i] = b.qpos[(size_t)env * m.nq + i];
-  for (int i = lane; i < m.nv; i += 64) { s.qvel[i] = b.qvel[(size_t)env * m.nv + i]; s.qacc_ws[i] = b.qacc_ws[(size_t)env * m.nv + i]; }
-  if (lane >= m.nv && lane < NV) { s.qvel[lane] = 0.f; s.qacc_ws[lane] = 0.f; s.qacc[lane] = 0.f; }
-  for (int i = lane; i < m.nu; i += 64) s.ctrl[i] = b.ctrl[(size_t)env * m.nu + i];
-  if (lane < RSIM_CS_SIZE) s.cstate[lane] = b.cstate[(size_t)env * RSIM_CS_SIZE + lane];
-  if (lane == 0) { s.ncon = 0; s.nefc = 0; s.niter = 0; }
+  for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = b.qpos[(size_t)env * m.nq + i];
+  for (int i = lane; i < m.nv; i += 64) { sm.qvel[i] = b.qvel[(size_t)env * m.nv + i]; sm.qacc_ws[i] = b.qacc_ws[(size_t)env * m.nv + i]; }
+  if (lane >= m.nv && lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.qacc[lane] = 0.f; }
+  for (int i = lane; i < m.nu; i += 64) sm.ctrl[i] = b.ctrl[(size_t)env * m.nu + i];
+  if (lane < RSIM_CS_SIZE) sm.cstate[lane] = b.cstate[(size_t)env * RSIM_CS_SIZE + lane];
+  if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; }
   sim.load_constants();
   const float* act = actions ? actions + (size_t)env * m.ctrl.action_dim : nullptr;
   float time = b.time[env];
@@ -1869,8 +2012,8 @@ __global__ __launch_bounds__(64) void k_step(DModel m, DBatch b, const float* __
       sim.pf.mark(RP_ACT);
       sim.fwd_constraint();
       sim.pf.mark(RP_SOLVE);
-      sim.pf.count(RP_N_CON, s.ncon);
-      sim.pf.count(RP_N_EFC, s.nefc);
+      sim.pf.count(RP_N_CON, sm.ncon);
+      sim.pf.count(RP_N_EFC, sm.nefc);
     }
     if (flags & RF_INTEGRATE) {
       sim.euler();
@@ -1880,35 +2023,36 @@ __global__ __launch_bounds__(64) void k_step(DModel m, DBatch b, const float* __
     sim.pf.count(RP_N_SUB, 1);
   }
   // ---- store state
-  for (int i = lane; i < m.nq; i += 64) b.qpos[(size_t)env * m.nq + i] = s.qpos[i];
-  for (int i = lane; i < m.nv; i += 64) { b.qvel[(size_t)env * m.nv + i] = s.qvel[i]; b.qacc_ws[(size_t)env * m.nv + i] = s.qacc_ws[i]; }
-  for (int i = lane; i < m.nu; i += 64) b.ctrl[(size_t)env * m.nu + i] = s.ctrl[i];
-  if (lane < RSIM_CS_SIZE) b.cstate[(size_t)env * RSIM_CS_SIZE + lane] = s.cstate[lane];
+  for (int i = lane; i < m.nq; i += 64) b.qpos[(size_t)env * m.nq + i] = sm.qpos[i];
+  for (int i = lane; i < m.nv; i += 64) { b.qvel[(size_t)env * m.nv + i] = sm.qvel[i]; b.qacc_ws[(size_t)env * m.nv + i] = sm.qacc_ws[i]; }
+  for (int i = lane; i < m.nu; i += 64) b.ctrl[(size_t)env * m.nu + i] = sm.ctrl[i];
+  if (lane < RSIM_CS_SIZE) b.cstate[(size_t)env * RSIM_CS_SIZE + lane] = sm.cstate[lane];
   if (lane == 0) b.time[env] = time;
+  if (b.prof && lane == 0) b.prof[RP_COUNT + 4 * (size_t)env + 3] = wall_clock64();
   if (flags & RF_DEBUG) {
     const int nb = m.nbody, nv = m.nv;
-    for (int i = lane; i < nb * 3; i += 64) { b.xpos[(size_t)env * nb * 3 + i] = s.xpos[i]; b.rootcom[(size_t)env * nb * 3 + i] = s.rootcom[3 * s.broot[i / 3] + i % 3]; }
-    for (int i = lane; i < nb * 4; i += 64) b.xquat[(size_t)env * nb * 4 + i] = s.xquat[i];
-    for (int e = lane; e < nv * nv; e += 64) { int i = e / nv, j = e - i * nv; b.qM[(size_t)env * nv * nv + e] = s.M[i * SM::NVP + j]; }
-    for (int e = lane; e < nv * 6; e += 64) b.cdof[(size_t)env * nv * 6 + e] = s.cdof[(e / 6) * 8 + e % 6];
+    for (int i = lane; i < nb * 3; i += 64) { b.xpos[(size_t)env * nb * 3 + i] = sm.xpos[i]; b.rootcom[(size_t)env * nb * 3 + i] = sm.rootcom[3 * sm.broot[i / 3] + i % 3]; }
+    for (int i = lane; i < nb * 4; i += 64) b.xquat[(size_t)env * nb * 4 + i] = sm.xquat[i];
+    for (int e = lane; e < nv * nv; e += 64) { int i = e / nv, j = e - i * nv; b.qM[(size_t)env * nv * nv + e] = sm.M[i * SM::NVP + j]; }
+    for (int e = lane; e < nv * 6; e += 64) b.cdof[(size_t)env * nv * 6 + e] = sm.cdof[(e / 6) * 9 + e % 6];
     for (int i = lane; i < nv; i += 64) {
       size_t o = (size_t)env * nv + i;
-      b.qfrc_bias[o] = s.qfrc_bias[i]; b.qfrc_passive[o] = s.qfrc_passive[i];
-      if (flags & RF_ACTSOLVE) { b.qfrc_actuator[o] = s.qfrc_actuator[i]; b.qfrc_constraint[o] = s.qfrc_constraint[i]; b.qacc[o] = s.qacc[i]; }
+      b.qfrc_bias[o] = sm.qfrc_bias[i]; b.qfrc_passive[o] = sm.qfrc_passive[i];
+      if (flags & RF_ACTSOLVE) { b.qfrc_actuator[o] = sm.qfrc_actuator[i]; b.qfrc_constraint[o] = sm.qfrc_constraint[i]; b.qacc[o] = sm.qacc[i]; }
     }
-    int ncon = s.ncon;
+    int ncon = sm.ncon;
     for (int c = lane; c < ncon; c += 64) {
       float* r = b.contact + ((size_t)env * NCON + c) * RSIM_CON_REC;
-      r[0] = s.cdist[c];
-      for (int k = 0; k < 3; k++) r[1 + k] = s.cpos[3 * c + k];
-      for (int k = 0; k < 9; k++) r[4 + k] = s.cframe[9 * c + k];
-      r[13] = (float)IT(IO_cg_geomid, s.cg1[c]); r[14] = (float)IT(IO_cg_geomid, s.cg2[c]); r[15] = (float)s.cdim[c]; r[16] = (float)s.cefc[c];
-      r[17] = ((flags & RF_ACTSOLVE) && s.cefc[c] >= 0) ? s.e_force[s.cefc[c]] : 0.f;
-      for (int k = 0; k < 5; k++) r[18 + k] = s.cfri[5 * c + k];
+      r[0] = sm.cdist[c];
+      for (int k = 0; k < 3; k++) r[1 + k] = sm.cpos[3 * c + k];
+      for (int k = 0; k < 9; k++) r[4 + k] = sm.cframe[9 * c + k];
+      r[13] = (float)IT(IO_cg_geomid, sm.cg1[c]); r[14] = (float)IT(IO_cg_geomid, sm.cg2[c]); r[15] = (float)sm.cdim[c]; r[16] = (float)sm.cefc[c];
+      r[17] = ((flags & RF_ACTSOLVE) && sm.cefc[c] >= 0) ? sm.e_force[sm.cefc[c]] : 0.f;
+      for (int k = 0; k < 5; k++) r[18 + k] = sm.cfri[5 * c + k];
     }
     if (flags & RF_ACTSOLVE)
-      for (int i = lane; i < s.nefc; i += 64) b.efc_force[(size_t)env * NEFC + i] = s.e_force[i];
-    if (lane == 0) { b.ncon[env] = ncon; b.nefc[env] = s.nefc; b.niter[env] = s.niter; }
+      for (int i = lane; i < sm.nefc; i += 64) b.efc_force[(size_t)env * NEFC + i] = sm.e_force[i];
+    if (lane == 0) { b.ncon[env] = ncon; b.nefc[env] = sm.nefc; b.niter[env] = sm.niter; }
   }
 }
 
@@ -1916,20 +2060,19 @@ __global__ __launch_bounds__(64) void k_step(DModel m, DBatch b, const float* __
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const unsigned char* __restrict__ mask) {
   typedef Smem<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> SM;
-  __shared__ SM s;
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= b.B) return;
   if (mask && !mask[env]) return;
   const float* fp = m.ft + (size_t)env * m.fstride;
-  Sim<SM> sim(s, m, fp, lane, nullptr);
-  for (int i = lane; i < m.nq; i += 64) s.qpos[i] = b.qpos[(size_t)env * m.nq + i];
-  if (lane < RSIM_CS_SIZE) s.cstate[lane] = 0.f;
+  Sim<SM> sim(m, fp, lane, nullptr);
+  for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = b.qpos[(size_t)env * m.nq + i];
+  if (lane < RSIM_CS_SIZE) sm.cstate[lane] = 0.f;
   sim.load_constants();
   V3 xp; Q4 xq;
   sim.kinematics(xp, xq);
   sim.geom_site_frames();
   sim.ctrl_reset();
-  if (lane < RSIM_CS_SIZE) b.cstate[(size_t)env * RSIM_CS_SIZE + lane] = s.cstate[lane];
+  if (lane < RSIM_CS_SIZE) b.cstate[(size_t)env * RSIM_CS_SIZE + lane] = sm.cstate[lane];
 }
 
 

@@ -7,18 +7,19 @@ from robosuite_amd import lift, mjcf
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 adir = os.path.join(ROOT, "robosuite_amd", "assets")
 flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim"))
 cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
 env = lift.LiftBatch(flat, cfg, np.arange(B), seed0=0)
-tape = torch.tensor(lift.env_actions(np.arange(B), steps + 3), device="cuda")
-for t in range(3):
+tape = torch.tensor(lift.env_actions(np.arange(B), steps + skip), device="cuda")
+for t in range(skip):
     env.step(tape[t])
 env.batch.sync()
 env.batch.profile(True)
 t0 = time.perf_counter()
 for t in range(steps):
-    env.step(tape[3 + t])
+    env.step(tape[skip + t])
 env.batch.sync()
 dt = time.perf_counter() - t0
 p = env.batch.profile(False)
