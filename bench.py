@@ -33,7 +33,8 @@ def algorithmic_bytes_per_env_step(flat, action_dim):
     """Compulsory HBM bytes one env-step moves through the fused kernel (fp32 words x 4), DESIGN.md section 6:
     read  action + qpos + qvel + qacc_warmstart + ctrl + time + controller state + per-env model deltas (cube: size3 rbound1 mass1 inertia3 subtree1 invw2 dofinvw6)
     write qpos + qvel + qacc_warmstart + ctrl + time + controller state + observation record + reward/done."""
-    from robosuite_amd.backend import CSTATE, OBS_DIM
+    from robosuite_amd.backend import CSTATE
+    OBS_DIM = len(lift.lift_task(flat, json.load(open(os.path.join(ROOT, "robosuite_amd", "assets", "lift_panda.cfg.json"))))["obs"])
     nq, nv, nu = flat.nq, flat.nv, flat.nu
     rd = action_dim + nq + nv + nv + nu + 1 + CSTATE + 17
     wr = nq + nv + nv + nu + 1 + CSTATE + OBS_DIM + 2
@@ -123,7 +124,8 @@ def main():
 
     st = shard.RolloutStats(dev)
     q = env.batch.tensor("qpos")
-    st.add(env_steps=B * K, diverged=int((~torch.isfinite(q).all(dim=1)).sum().item()))
+    st.add(env_steps=B * K, diverged=int((~torch.isfinite(q).all(dim=1)).sum().item()),
+           reward_sum=float(env.reward().sum().item()), successes=int(env.success().sum().item()))
     if hasattr(env, "rollout_totals"):
         st.add(**env.rollout_totals())
     tot = st.allreduce()

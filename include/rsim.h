@@ -40,6 +40,34 @@ typedef struct rsim_ctrl_desc {
   float grip_speed;         /* panda_gripper.py:61 */
 } rsim_ctrl_desc;
 
+/* On-device observation / reward epilogue of the fused control step.
+ * Observation record = robosuite's per-key observables concatenated in `_get_observations` order (environments/base.py:429-465),
+ * one float per entry of `obs_prog`; every entry is (kind, a, b):
+ *   RSIM_OBS_QPOS/COS/SIN/QVEL/QACC: joint quantity at address a          (robots/robot.py:334-394)
+ *   RSIM_OBS_SITE_POS: site a, component b                                 (robot.py:412-414 eef_pos)
+ *   RSIM_OBS_BODY_QUAT / RSIM_OBS_SITE_QUAT: body / site a, xyzw comp b    (robot.py:416-462; T.convert_quat / T.mat2quat)
+ *   RSIM_OBS_BODY_POS: body a, component b                                 (lift.py:371-373 cube_pos)
+ *   RSIM_OBS_BODY_MINUS_SITE: body a minus site (b >> 2), component b & 3  (manipulation_env.py:218-242 gripper_to_cube_pos)
+ * Sampling instants follow the reference exactly: after `reset()` every Observable samples on the LAST substep of a control step,
+ * i.e. positions/orientations come from that substep's step1 kinematics, qpos/qvel from after its step2 (utils/observables.py:214-259).
+ * Reward = Lift.reward (environments/manipulation/lift.py:224-273), success = Lift._check_success (lift.py:433-444),
+ * grasp = ManipulationEnv._check_grasp on the contact list (manipulation_env.py:331-376). */
+enum { RSIM_OBS_QPOS = 0, RSIM_OBS_COS, RSIM_OBS_SIN, RSIM_OBS_QVEL, RSIM_OBS_QACC, RSIM_OBS_SITE_POS, RSIM_OBS_BODY_QUAT, RSIM_OBS_SITE_QUAT,
+       RSIM_OBS_BODY_POS, RSIM_OBS_BODY_MINUS_SITE };
+#define RSIM_OBS_MAX 128
+typedef struct rsim_task_desc {
+  int32_t nobs;                       /* floats in the observation record (<= RSIM_OBS_MAX) */
+  int32_t obs_prog[RSIM_OBS_MAX * 3]; /* (kind, a, b) per output float */
+  int32_t task;                       /* 1 = Lift */
+  int32_t object_body;                /* cube root body */
+  int32_t grip_site;                  /* gripper.important_sites["grip_site"] */
+  float table_height;                 /* model.mujoco_arena.table_offset[2] */
+  float lift_margin;                  /* 0.04 */
+  float reward_scale;                 /* reward_scale (1.0), applied as reward_scale / 2.25 */
+  int32_t reward_shaping;
+  uint64_t left_pad_geoms, right_pad_geoms, object_geoms; /* bit g set: colliding-geom index g belongs to the group (_check_grasp) */
+} rsim_task_desc;
+
 /* state / derived arrays addressable through rsim_get_array / rsim_set_array / rsim_device_ptr */
 enum rsim_field {
   RSIM_QPOS = 0,       /* [B,nq]  sim.data.qpos   (binding_utils.py MjData.qpos)            */
@@ -63,6 +91,9 @@ enum rsim_field {
   RSIM_NCON,           /* [B] int32    sim.data.ncon                                         */
   RSIM_NEFC,           /* [B] int32 */
   RSIM_NITER,          /* [B] int32    solver iterations of the last substep                 */
+  RSIM_OBS,            /* [B,nobs]     observation record of the last control step (float32) */
+  RSIM_REWARD,         /* [B]          reward of the last control step                       */
+  RSIM_SUCCESS,        /* [B] int32    _check_success() after the last control step          */
   RSIM_FIELD_COUNT
 };
 
@@ -76,6 +107,10 @@ void rsim_model_free(rsim_model* m);
 int rsim_model_int(const rsim_model* m, const char* name);
 /* controller_factory (controllers/parts/controller_factory.py:73-159) for the built-in OSC_POSE + GRIP pair */
 int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* desc);
+/* observation / reward epilogue of rsim_control_step (must be set before rsim_batch_create) */
+int rsim_model_set_task(rsim_model* m, const rsim_task_desc* desc);
+/* colliding-geom index (bit position in rsim_task_desc geom masks) of a model geom id, -1 if the geom never collides */
+int rsim_model_cgeom(const rsim_model* m, int geom_id);
 
 /* mujoco.MjData(model) x B (binding_utils.py:586-590): allocates B environments on `device`.
  * per_env_params != 0 gives every env its own copy of the float model constants (domain randomisation,
@@ -105,8 +140,11 @@ int rsim_sync(rsim_batch* b);
  * enable != 0 (re)arms and zeroes the accumulators, 0 disarms; if `out` is non-NULL the current accumulators are copied out first:
  * cycles {load kin com crb broad narrow makec vel ctrl act solve euler store} then counts {substeps candidates contacts efc newton ls}. */
 int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, int n_out);
-/* While profiling is armed every launch also logs, per env, {HW_ID, XCC_ID, start, end (s_memrealtime ticks, 100 MHz)}: out = HOST u64 [B,4]. */
+/* While profiling is armed every launch also logs, per env, {HW_ID, XCC_ID, start, end (s_memrealtime ticks, 100 MHz), #MPR runs, #support
+ * evaluations, #Newton iterations, #broadphase candidates}: out = HOST u64 [B,8]. */
 int rsim_wavelog(rsim_batch* b, unsigned long long* out);
+/* restrict the phase accumulators to one env (-1 = all envs) */
+int rsim_profile_env(rsim_batch* b, int env);
 
 /* zero-copy numpy-view replacement: copy a field to / from HOST float32 (int32 for RSIM_NCON..) buffers of `count` elements */
 int rsim_get_array(rsim_batch* b, int field, void* host_dst, size_t count);

@@ -18,12 +18,13 @@ _LIB = None
 
 # enum rsim_field (include/rsim.h)
 FIELDS = ["qpos", "qvel", "qacc_warmstart", "ctrl", "time", "cstate", "xpos", "xquat", "qM", "qfrc_bias", "qfrc_passive", "qfrc_actuator",
-          "qfrc_constraint", "qacc", "cdof", "rootcom", "contact", "efc_force", "ncon", "nefc", "niter"]
+          "qfrc_constraint", "qacc", "cdof", "rootcom", "contact", "efc_force", "ncon", "nefc", "niter", "obs", "reward", "success"]
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
-INT_FIELDS = {"ncon", "nefc", "niter"}
+INT_FIELDS = {"ncon", "nefc", "niter", "success"}
 CON_REC = 24
 CSTATE = 32
-OBS_DIM = 0  # floats of the per-env observation record the fused kernel writes (0 until the obs epilogue lands)
+OBS_MAX = 128
+OBS_KINDS = {"qpos": 0, "cos": 1, "sin": 2, "qvel": 3, "qacc": 4, "site_pos": 5, "body_quat": 6, "site_quat": 7, "body_pos": 8, "body_minus_site": 9}
 
 
 class RsimError(RuntimeError):
@@ -35,6 +36,12 @@ class CtrlDesc(C.Structure):
                 ("base_site", C.c_int32), ("kp", C.c_float * 6), ("damping_ratio", C.c_float), ("input_min", C.c_float * 6), ("input_max", C.c_float * 6),
                 ("output_min", C.c_float * 6), ("output_max", C.c_float * 6), ("uncouple_pos_ori", C.c_int32), ("nullspace_kp", C.c_float),
                 ("ngrip", C.c_int32), ("grip_act", C.c_int32 * 4), ("grip_sign", C.c_float * 4), ("grip_speed", C.c_float)]
+
+
+class TaskDesc(C.Structure):
+    _fields_ = [("nobs", C.c_int32), ("obs_prog", C.c_int32 * (OBS_MAX * 3)), ("task", C.c_int32), ("object_body", C.c_int32), ("grip_site", C.c_int32),
+                ("table_height", C.c_float), ("lift_margin", C.c_float), ("reward_scale", C.c_float), ("reward_shaping", C.c_int32),
+                ("left_pad_geoms", C.c_uint64), ("right_pad_geoms", C.c_uint64), ("object_geoms", C.c_uint64)]
 
 
 def ctrl_desc(cfg: dict) -> CtrlDesc:
@@ -76,6 +83,8 @@ def lib():
         L.rsim_model_free.argtypes = [vp]
         L.rsim_model_int.argtypes = [vp, C.c_char_p]
         L.rsim_model_set_controller.argtypes = [vp, C.POINTER(CtrlDesc)]
+        L.rsim_model_set_task.argtypes = [vp, C.POINTER(TaskDesc)]
+        L.rsim_model_cgeom.argtypes = [vp, C.c_int]
         L.rsim_batch_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.rsim_batch_free.argtypes = [vp]
         L.rsim_batch_size.argtypes = [vp]
@@ -96,6 +105,7 @@ def lib():
         L.rsim_model_param_set.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_size_t]
         L.rsim_profile.argtypes = [vp, C.c_int, vp, C.c_int]
         L.rsim_wavelog.argtypes = [vp, vp]
+        L.rsim_profile_env.argtypes = [vp, C.c_int]
         L.rsim_osc_eval.argtypes = [C.POINTER(CtrlDesc), vp, vp, C.c_int, C.c_int]
         _LIB = L
     return _LIB
@@ -116,6 +126,8 @@ class HipModel:
         self.ptr = C.c_void_p()
         _chk(self._L.rsim_model_create(blob, len(blob), C.byref(self.ptr)))
         self.ctrl_cfg = None
+        self.task_cfg = None
+        self.nobs = 0
 
     def int(self, name):
         return self._L.rsim_model_int(self.ptr, name.encode())
@@ -125,6 +137,34 @@ class HipModel:
         _chk(self._L.rsim_model_set_controller(self.ptr, C.byref(d)))
         self.ctrl_cfg = cfg
         self.action_dim = 6 + (1 if cfg.get("grip_act") else 0)
+
+    def set_task(self, task: dict):
+        """task: dict(obs=[(kind, a, b), ...], task="lift", object_body, grip_site, table_height, lift_margin, reward_scale, reward_shaping,
+        left_pad_geoms=[geom ids], right_pad_geoms=[...], object_geoms=[...]) -- see include/rsim.h rsim_task_desc."""
+        d = TaskDesc()
+        obs = task["obs"]
+        if len(obs) > OBS_MAX:
+            raise RsimError(f"observation record of {len(obs)} floats exceeds RSIM_OBS_MAX")
+        d.nobs = len(obs)
+        for i, (kind, a, b) in enumerate(obs):
+            d.obs_prog[3 * i], d.obs_prog[3 * i + 1], d.obs_prog[3 * i + 2] = OBS_KINDS[kind] if isinstance(kind, str) else int(kind), int(a), int(b)
+        d.task = {"none": 0, "lift": 1}[task.get("task", "none")]
+        d.object_body, d.grip_site = int(task.get("object_body", 0)), int(task.get("grip_site", 0))
+        d.table_height, d.lift_margin = float(task.get("table_height", 0.0)), float(task.get("lift_margin", 0.04))
+        d.reward_scale, d.reward_shaping = float(task.get("reward_scale", 1.0)), int(bool(task.get("reward_shaping", True)))
+
+        def mask(geoms):
+            mk = 0
+            for g in geoms:
+                c = self._L.rsim_model_cgeom(self.ptr, int(g))
+                if c >= 0:
+                    mk |= 1 << c
+            return mk
+
+        d.left_pad_geoms, d.right_pad_geoms, d.object_geoms = mask(task.get("left_pad_geoms", [])), mask(task.get("right_pad_geoms", [])), mask(task.get("object_geoms", []))
+        _chk(self._L.rsim_model_set_task(self.ptr, C.byref(d)))
+        self.task_cfg = task
+        self.nobs = len(obs)
 
     def __del__(self):
         try:
@@ -160,7 +200,8 @@ class HipBatch:
         self.shapes = {"qpos": (B, nq), "qvel": (B, nv), "qacc_warmstart": (B, nv), "ctrl": (B, nu), "time": (B,), "cstate": (B, CSTATE),
                        "xpos": (B, nb, 3), "xquat": (B, nb, 4), "qM": (B, nv, nv), "qfrc_bias": (B, nv), "qfrc_passive": (B, nv),
                        "qfrc_actuator": (B, nv), "qfrc_constraint": (B, nv), "qacc": (B, nv), "cdof": (B, nv, 6), "rootcom": (B, nb, 3),
-                       "contact": (B, self.maxcon, CON_REC), "efc_force": (B, self.maxefc), "ncon": (B,), "nefc": (B,), "niter": (B,)}
+                       "contact": (B, self.maxcon, CON_REC), "efc_force": (B, self.maxefc), "ncon": (B,), "nefc": (B,), "niter": (B,),
+                       "obs": (B, model.nobs), "reward": (B,), "success": (B,)}
 
     # ---- state access (host copies) --------------------------------------------------------
     def get(self, name):
@@ -221,11 +262,14 @@ class HipBatch:
         return self._L.rsim_stream(self.ptr)
 
     PROFILE_SLOTS = ("load", "kin", "com", "crb", "broad", "narrow", "makec", "vel", "ctrl", "act", "solve", "euler", "store",
-                     "n_sub", "n_cand", "n_con", "n_efc", "n_newton", "n_ls")
+                     "n_sub", "n_cand", "n_con", "n_efc", "n_newton", "n_ls", "boxbox", "mpr", "plane", "n_boxbox", "n_mpr", "n_support")
+
+    def profile_env(self, env=-1):
+        _chk(self._L.rsim_profile_env(self.ptr, int(env)))
 
     def wavelog(self):
         """Per-env {hw_id, xcc_id, t_start, t_end} of the last launch (profiling must be armed)."""
-        out = np.zeros((self.B, 4), dtype=np.uint64)
+        out = np.zeros((self.B, 8), dtype=np.uint64)
         _chk(self._L.rsim_wavelog(self.ptr, out.ctypes.data))
         return out
 

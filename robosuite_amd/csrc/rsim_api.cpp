@@ -53,6 +53,8 @@ struct rsim_model {
   std::vector<int> lanetab;   // [LT_COUNT][64]
   int kin_rounds, ndynroot, dynroot[RSIM_MAXDYNROOT], maxcondim, multijoint;
   DCtrl ctrl;
+  rsim_task_desc task;
+  int has_task;
   float meaninertia;
   const int* I(const char* n) const { auto it = f.find(n); return it == f.end() ? nullptr : (const int*)it->second.ptr; }
   const double* D(const char* n) const { auto it = f.find(n); return it == f.end() ? nullptr : (const double*)it->second.ptr; }
@@ -65,6 +67,7 @@ struct rsim_batch {
   hipStream_t stream;
   int* d_it;
   int* d_lt;
+  int* d_obsprog;
   float* d_ft;
   float* d_mesh;
   unsigned char* d_mask;
@@ -115,6 +118,8 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
     if (m->f.find(r) == m->f.end()) { delete m; return fail("rsim_model_create: blob lacks field '%s'", r); }
   if (m->nbody > 64 || m->nv > 64) { delete m; return fail("rsim_model_create: nbody/nv > 64 unsupported (ancestor bit-masks)"); }
   memset(&m->ctrl, 0, sizeof(m->ctrl));
+  memset(&m->task, 0, sizeof(m->task));
+  m->has_task = 0;
 
   const int nb = m->nbody, nv = m->nv, nj = m->njnt;
   const int *parent = m->I("body_parentid"), *weld = m->I("body_weldid"), *jadr = m->I("body_jntadr"), *jnum = m->I("body_jntnum");
@@ -300,6 +305,60 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
       for (int k = 0; k < 3; k++) ft.push_back((float)(0.5 * (hi[k] - lo[k]) * 1.000001 + 1e-7));
     }
   }
+  {  // bounding capsules of mesh hulls (broadphase: adjacent arm links overlap as boxes but not as capsules)
+    m->fo[FO_cg_capsule] = (int)ft.size(); m->fcount[FO_cg_capsule] = ncg * 8;
+    const double* mv = m->D("mesh_vert");
+    for (int c = 0; c < ncg; c++) {
+      int g = m->cg[c];
+      double cap[8] = {0, 0, 0, 0, 0, 0, -1, 0};
+      if (m->I("geom_type")[g] == 7) {
+        int did = m->I("geom_dataid")[g], adr = m->I("mesh_vertadr")[did], num = m->I("mesh_vertnum")[did];
+        const double* V = mv + 3 * (size_t)adr;
+        double cen[3] = {0, 0, 0};
+        for (int v = 0; v < num; v++) for (int k = 0; k < 3; k++) cen[k] += V[3 * v + k] / num;
+        // candidate axes: principal axes of the vertex cloud (Jacobi eigenvectors of the covariance) + the frame axes
+        double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, E[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int v = 0; v < num; v++) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[i][j] += (V[3 * v + i] - cen[i]) * (V[3 * v + j] - cen[j]);
+        for (int sweep = 0; sweep < 30; sweep++)
+          for (int p2 = 0; p2 < 2; p2++) for (int q2 = p2 + 1; q2 < 3; q2++) {
+            if (fabs(C[p2][q2]) < 1e-18) continue;
+            double th = 0.5 * atan2(2 * C[p2][q2], C[q2][q2] - C[p2][p2]), cs = cos(th), sn = sin(th);
+            for (int k = 0; k < 3; k++) { double a = C[k][p2], b2 = C[k][q2]; C[k][p2] = cs * a - sn * b2; C[k][q2] = sn * a + cs * b2; }
+            for (int k = 0; k < 3; k++) { double a = C[p2][k], b2 = C[q2][k]; C[p2][k] = cs * a - sn * b2; C[q2][k] = sn * a + cs * b2; }
+            for (int k = 0; k < 3; k++) { double a = E[k][p2], b2 = E[k][q2]; E[k][p2] = cs * a - sn * b2; E[k][q2] = sn * a + cs * b2; }
+          }
+        double bestvol = 1e300;
+        for (int cand = 0; cand < 6; cand++) {
+          double ax[3];
+          for (int k = 0; k < 3; k++) ax[k] = cand < 3 ? E[k][cand] : (k == cand - 3 ? 1.0 : 0.0);
+          double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+          if (n < 1e-12) continue;
+          for (int k = 0; k < 3; k++) ax[k] /= n;
+          double rmax = 0;
+          for (int v = 0; v < num; v++) {
+            double d[3] = {V[3 * v] - cen[0], V[3 * v + 1] - cen[1], V[3 * v + 2] - cen[2]}, t = d[0] * ax[0] + d[1] * ax[1] + d[2] * ax[2];
+            double pp = sqrt(fmax(0.0, d[0] * d[0] + d[1] * d[1] + d[2] * d[2] - t * t));
+            if (pp > rmax) rmax = pp;
+          }
+          double R = rmax * 1.02 + 1e-4, lo = 1e300, hi = -1e300;  // every vertex within R of the segment [lo, hi] on the axis
+          for (int v = 0; v < num; v++) {
+            double d[3] = {V[3 * v] - cen[0], V[3 * v + 1] - cen[1], V[3 * v + 2] - cen[2]}, t = d[0] * ax[0] + d[1] * ax[1] + d[2] * ax[2];
+            double pp2 = fmax(0.0, d[0] * d[0] + d[1] * d[1] + d[2] * d[2] - t * t), reach = sqrt(fmax(0.0, R * R - pp2));
+            if (t + reach < lo) lo = t + reach;
+            if (t - reach > hi) hi = t - reach;
+          }
+          if (lo > hi) lo = hi = 0.5 * (lo + hi);
+          double vol = 3.14159265358979 * R * R * (hi - lo) + 4.18879020478639 * R * R * R;
+          if (vol < bestvol) {
+            bestvol = vol;
+            for (int k = 0; k < 3; k++) { cap[k] = cen[k] + lo * ax[k]; cap[3 + k] = cen[k] + hi * ax[k]; }
+            cap[6] = R;
+          }
+        }
+      }
+      for (int k = 0; k < 8; k++) ft.push_back((float)cap[k]);
+    }
+  }
   pushf(FO_site_pos, "site_pos", 3 * m->nsite); pushf(FO_site_quat, "site_quat", 4 * m->nsite);
   pushf(FO_act_gear, "actuator_gear", m->nu); pushf(FO_act_gainprm, "actuator_gainprm", 3 * m->nu); pushf(FO_act_biasprm, "actuator_biasprm", 3 * m->nu);
   pushf(FO_act_ctrlrange, "actuator_ctrlrange", 2 * m->nu); pushf(FO_act_forcerange, "actuator_forcerange", 2 * m->nu);
@@ -362,6 +421,35 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
   return 0;
 }
 
+extern "C" int rsim_model_cgeom(const rsim_model* m, int geom_id) {
+  if (geom_id < 0 || geom_id >= m->ngeom) return -1;
+  return m->geom2cg[geom_id];
+}
+
+extern "C" int rsim_model_set_task(rsim_model* m, const rsim_task_desc* d) {
+  if (d->nobs < 0 || d->nobs > RSIM_OBS_MAX) return fail("task: nobs out of range");
+  for (int i = 0; i < d->nobs; i++) {
+    int kind = d->obs_prog[3 * i], a = d->obs_prog[3 * i + 1], b2 = d->obs_prog[3 * i + 2];
+    bool ok = true;
+    switch (kind) {
+      case RSIM_OBS_QPOS: case RSIM_OBS_COS: case RSIM_OBS_SIN: ok = a >= 0 && a < m->nq; break;
+      case RSIM_OBS_QVEL: case RSIM_OBS_QACC: ok = a >= 0 && a < m->nv; break;
+      case RSIM_OBS_SITE_POS: ok = a >= 0 && a < m->nsite && b2 >= 0 && b2 < 3; break;
+      case RSIM_OBS_SITE_QUAT: ok = a >= 0 && a < m->nsite && b2 >= 0 && b2 < 4; break;
+      case RSIM_OBS_BODY_QUAT: ok = a >= 0 && a < m->nbody && b2 >= 0 && b2 < 4; break;
+      case RSIM_OBS_BODY_POS: ok = a >= 0 && a < m->nbody && b2 >= 0 && b2 < 3; break;
+      case RSIM_OBS_BODY_MINUS_SITE: ok = a >= 0 && a < m->nbody && (b2 & 3) < 3 && (b2 >> 2) >= 0 && (b2 >> 2) < m->nsite; break;
+      default: ok = false;
+    }
+    if (!ok) return fail("task: observation entry %d (kind %d, a %d, b %d) is invalid for this model", i, kind, a, b2);
+  }
+  if (d->task != 0 && d->task != 1) return fail("task: unknown task id %d", d->task);
+  if (d->task == 1 && (d->object_body < 0 || d->object_body >= m->nbody || d->grip_site < 0 || d->grip_site >= m->nsite)) return fail("task: bad body / site id");
+  m->task = *d;
+  m->has_task = 1;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 template <class T>
 static int dalloc(T** p, size_t n) {
@@ -380,6 +468,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   memset(&b->db, 0, sizeof(b->db));
   b->m = m; b->B = B; b->device = device; b->per_env = per_env ? 1 : 0;
   b->gen = 1; b->cache_gen = 0; b->cache_env = -1;
+  b->db.prof_env = -1;
   rsim_cfg0_limits(b->lim);
   const int ncg = (int)m->cg.size();
   if (m->nbody > b->lim[0] || m->njnt > b->lim[1] || m->nv > b->lim[2] || m->nq > b->lim[2] + 8 || m->nu > b->lim[2] || ncg > b->lim[3] || m->nsite > b->lim[4] ||
@@ -419,6 +508,16 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   memcpy(dm.io, m->io, sizeof(dm.io));
   memcpy(dm.fo, m->fo, sizeof(dm.fo));
   dm.ctrl = m->ctrl;
+  b->d_obsprog = nullptr;
+  memset(&dm.task, 0, sizeof(dm.task));
+  if (m->has_task) {
+    const rsim_task_desc& t = m->task;
+    if (dalloc(&b->d_obsprog, (size_t)RSIM_OBS_MAX * 3)) return 1;
+    HIPCHK(hipMemcpy(b->d_obsprog, t.obs_prog, sizeof(t.obs_prog), hipMemcpyHostToDevice));
+    dm.task.enabled = 1; dm.task.nobs = t.nobs; dm.task.task = t.task; dm.task.object_body = t.object_body; dm.task.grip_site = t.grip_site;
+    dm.task.reward_shaping = t.reward_shaping; dm.task.table_height = t.table_height; dm.task.lift_margin = t.lift_margin; dm.task.reward_scale = t.reward_scale;
+    dm.task.left_pad = t.left_pad_geoms; dm.task.right_pad = t.right_pad_geoms; dm.task.object_geoms = t.object_geoms; dm.task.obs_prog = b->d_obsprog;
+  }
   DBatch& db = b->db;
   db.B = B;
   const int nq = m->nq, nv = m->nv, nu = m->nu, nb = m->nbody, NCON = b->lim[5], NEFC = b->lim[6];
@@ -430,7 +529,9 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
       {RSIM_QFRC_ACTUATOR, (void**)&db.qfrc_actuator, (size_t)B * nv, 0}, {RSIM_QFRC_CONSTRAINT, (void**)&db.qfrc_constraint, (size_t)B * nv, 0},
       {RSIM_QACC, (void**)&db.qacc, (size_t)B * nv, 0}, {RSIM_CDOF, (void**)&db.cdof, (size_t)B * nv * 6, 0}, {RSIM_ROOTCOM, (void**)&db.rootcom, (size_t)B * nb * 3, 0},
       {RSIM_CONTACT, (void**)&db.contact, (size_t)B * NCON * RSIM_CON_REC, 0}, {RSIM_EFC_FORCE, (void**)&db.efc_force, (size_t)B * NEFC, 0},
-      {RSIM_NCON, (void**)&db.ncon, (size_t)B, 1}, {RSIM_NEFC, (void**)&db.nefc, (size_t)B, 1}, {RSIM_NITER, (void**)&db.niter, (size_t)B, 1}};
+      {RSIM_NCON, (void**)&db.ncon, (size_t)B, 1}, {RSIM_NEFC, (void**)&db.nefc, (size_t)B, 1}, {RSIM_NITER, (void**)&db.niter, (size_t)B, 1},
+      {RSIM_OBS, (void**)&db.obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0}, {RSIM_REWARD, (void**)&db.reward, (size_t)B, 0},
+      {RSIM_SUCCESS, (void**)&db.success, (size_t)B, 1}};
   for (auto& fd : fields) {
     if (dalloc((float**)fd.p, fd.n)) return 1;
     b->fptr[fd.id] = *fd.p; b->fcount[fd.id] = fd.n; b->fis_int[fd.id] = fd.is_int;
@@ -444,7 +545,7 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   hipSetDevice(b->device);
   hipStreamSynchronize(b->stream);
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
-  hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_mesh); hipFree(b->d_mask);
+  hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); if (b->d_obsprog) hipFree(b->d_obsprog); hipFree(b->d_mesh); hipFree(b->d_mask);
   if (b->db.prof) hipFree(b->db.prof);
   hipStreamDestroy(b->stream);
   delete b;
@@ -489,6 +590,7 @@ extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) {
 static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   HIPCHK(hipSetDevice(b->device));
   b->dm.ctrl = b->m->ctrl;
+  if ((flags & RF_OBS) && !b->dm.task.enabled) return fail("the task (observation / reward epilogue) was configured after the batch was created");
   if ((flags & RF_CTRL) && !b->dm.ctrl.enabled) return fail("no controller configured (rsim_model_set_controller)");
   int e = rsim_launch_step_cfg0(&b->dm, &b->db, actions, n_sub, flags, b->stream);
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -502,7 +604,7 @@ extern "C" int rsim_step(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL
 extern "C" int rsim_control_step(rsim_batch* b, const float* actions_dev, int n_sub) {
   if (n_sub < 1) return fail("rsim_control_step: n_sub < 1");
   if (!actions_dev) return fail("rsim_control_step: actions_dev is NULL");
-  return launch(b, actions_dev, n_sub, RF_POSVEL | RF_CTRL | RF_SETGOAL | RF_ACTSOLVE | RF_INTEGRATE);
+  return launch(b, actions_dev, n_sub, RF_POSVEL | RF_CTRL | RF_SETGOAL | RF_ACTSOLVE | RF_INTEGRATE | (b->m->has_task ? RF_OBS : 0));
 }
 extern "C" int rsim_ctrl_reset(rsim_batch* b, const uint8_t* mask) {
   HIPCHK(hipSetDevice(b->device));
@@ -528,7 +630,7 @@ extern "C" int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, 
     HIPCHK(hipMemcpy(tmp, b->db.prof, sizeof(tmp), hipMemcpyDeviceToHost));
     for (int i = 0; i < n_out && i < RP_COUNT; i++) out[i] = tmp[i];
   }
-  const size_t nprof = RP_COUNT + 4 * (size_t)b->B;  // phase accumulators, then per-env {hw_id, xcc_id, t_start, t_end} of the last launch
+  const size_t nprof = RP_COUNT + 8 * (size_t)b->B;  // phase accumulators, then per-env {hw_id, xcc_id, t_start, t_end, n_mpr, n_support, n_newton, n_cand} of the last launch
   if (enable && !b->db.prof) {
     HIPCHK(hipMalloc((void**)&b->db.prof, nprof * sizeof(unsigned long long)));
   }
@@ -537,11 +639,13 @@ extern "C" int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, 
   return 0;
 }
 
+extern "C" int rsim_profile_env(rsim_batch* b, int env) { b->db.prof_env = env; return 0; }
+
 extern "C" int rsim_wavelog(rsim_batch* b, unsigned long long* out) {
   if (!b->db.prof) return fail("rsim_wavelog: profiling is not enabled");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
-  HIPCHK(hipMemcpy(out, b->db.prof + RP_COUNT, 4 * (size_t)b->B * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, b->db.prof + RP_COUNT, 8 * (size_t)b->B * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return 0;
 }
 

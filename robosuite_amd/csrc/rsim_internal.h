@@ -22,6 +22,7 @@ enum {
   FO_dof_armature, FO_dof_damping, FO_dof_frictionloss, FO_dof_solref, FO_dof_solimp, FO_dof_invweight0,
   FO_cg_size, FO_cg_pos, FO_cg_quat, FO_cg_friction, FO_cg_solref, FO_cg_solimp, FO_cg_solmix, FO_cg_margin, FO_cg_gap,
   FO_cg_rbound, FO_cg_rcenter, FO_cg_aabb /* mesh geoms: centre3 + half3 of the hull's box in the geom frame */,
+  FO_cg_capsule /* mesh geoms: bounding capsule p3 q3 R in the geom frame (R < 0: none) + pad */,
   FO_site_pos, FO_site_quat,
   FO_act_gear, FO_act_gainprm, FO_act_biasprm, FO_act_ctrlrange, FO_act_forcerange,
   FO_opt /* timestep, gx,gy,gz, density, viscosity, impratio, windx,windy,windz */,
@@ -69,6 +70,14 @@ struct DCtrl {
 #define RSIM_CS_TAU 24
 #define RSIM_CS_SIZE 32
 
+// observation / reward epilogue (include/rsim.h rsim_task_desc), device form
+struct DTask {
+  int enabled, nobs, task, object_body, grip_site, reward_shaping;
+  float table_height, lift_margin, reward_scale;
+  unsigned long long left_pad, right_pad, object_geoms;
+  const int* obs_prog;   // device [nobs][3]
+};
+
 struct DModel {
   int nq, nv, nu, nbody, njnt, ncg, nsite, npair, maxdepth, nroot;
   int iterations, ls_iterations, cone, solver;
@@ -84,6 +93,7 @@ struct DModel {
   int io[IO_COUNT];
   int fo[FO_COUNT];
   DCtrl ctrl;
+  DTask task;
 };
 
 // per-contact record written for the host (floats): dist, pos3, frame9, g1, g2, dim, efc_adr, fn, friction5
@@ -95,12 +105,15 @@ struct DBatch {
   // compat / debug outputs (may be null)
   float *xpos, *xquat, *qM, *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_constraint, *qacc, *cdof, *rootcom, *contact, *efc_force;
   int *ncon, *nefc, *niter, *diverged;
+  float *obs, *reward;   // [B, nobs], [B]
+  int* success;          // [B]
   unsigned long long* prof;  // optional [RP_COUNT] phase-cycle / event accumulators (null = off)
+  int prof_env;              // >= 0: only this env adds to the phase accumulators
 };
 
 // profile slots (cycles of s_memtime summed over envs and substeps, then event counters)
 enum { RP_LOAD, RP_KIN, RP_COM, RP_CRB, RP_BROAD, RP_NARROW, RP_MAKEC, RP_VEL, RP_CTRL, RP_ACT, RP_SOLVE, RP_EULER, RP_STORE,
-       RP_N_SUB, RP_N_CAND, RP_N_CON, RP_N_EFC, RP_N_NEWTON, RP_N_LS, RP_COUNT };
+       RP_N_SUB, RP_N_CAND, RP_N_CON, RP_N_EFC, RP_N_NEWTON, RP_N_LS, RP_BOXBOX, RP_MPR, RP_PLANE, RP_N_BOXBOX, RP_N_MPR, RP_N_SUPPORT, RP_COUNT };
 
 // flags for the step kernel
 enum {
@@ -110,4 +123,5 @@ enum {
   RF_ACTSOLVE = 8,   // actuation + acceleration + constraint solve
   RF_INTEGRATE = 16, // Euler integration, advance time, warm start
   RF_DEBUG = 32,     // write compat/debug arrays
+  RF_OBS = 64,       // observation / reward epilogue after the last substep
 };

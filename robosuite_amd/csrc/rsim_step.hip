@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/rsim.h"
 #include "rsim_internal.h"
 
 #ifndef RSIM_MINWAVES
@@ -75,11 +76,18 @@ struct Prof {
   unsigned long long* p;
   long long t0;
   int lane;
+  int c_mpr = 0, c_support = 0, c_newton = 0, c_cand = 0;   // per-env event counts of this launch (wave log)
+  bool acc = true;                                          // this env contributes to the shared accumulators
   __device__ __forceinline__ void start() { if (p) t0 = clock64(); }
   __device__ __forceinline__ void mark(int id) {
-    if (p) { long long t1 = clock64(); if (lane == 0) atomicAdd(p + id, (unsigned long long)(t1 - t0)); t0 = clock64(); }
+    if (p) { long long t1 = clock64(); if (lane == 0 && acc) atomicAdd(p + id, (unsigned long long)(t1 - t0)); t0 = clock64(); }
   }
-  __device__ __forceinline__ void count(int id, int v) { if (p && lane == 0) atomicAdd(p + id, (unsigned long long)v); }
+  __device__ __forceinline__ void count(int id, int v) {
+    if (p) {
+      if (id == RP_N_MPR) c_mpr += v; else if (id == RP_N_SUPPORT) c_support += v; else if (id == RP_N_NEWTON) c_newton += v; else if (id == RP_N_CAND) c_cand += v;
+      if (lane == 0 && acc) atomicAdd(p + id, (unsigned long long)v);
+    }
+  }
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -215,6 +223,7 @@ struct Smem {
   float biw[NB * 2];             // body_invweight0
   int bdofs[NB], broot[NB];
   float gst[NG * 8];             // colliding geom statics: half-extents 3, box centre (geom frame) 3, rbound, margin
+  float gcap[NG * 8];            // bounding capsule of mesh hulls in the geom frame: p3 q3 R (R < 0: none)
   int gtype[NG], gbody[NG], gcp[NG], gmesh[NG];   // type, body, condim | priority<<8, hull vertex adr | count<<16
   float gpar[NG * 12];             // contact material per geom: friction3 solref2 solimp5 solmix gap
   float gpos[NG * 3], gmat[NG * 9], gcen[NG * 3];
@@ -228,6 +237,8 @@ struct Smem {
   int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
   float cstate[RSIM_CS_SIZE];
   float red[16];
+  float hull[2][3 * 256];   // hull vertices (SoA x|y|z, 256 slots) of the two geoms of the convex pair being tested
+  int hull_n[2];
   // per-lane model constants, one row per field (LaneConst below); phases fetch the handful they need instead of pinning ~80 VGPRs
   float kc[RSIM_KC_WORDS];
   int ncon, nefc, niter;
@@ -381,7 +392,23 @@ __device__ __forceinline__ void spd_solve_small(const float* A, const float* b, 
 
 // support point of colliding geom g along world direction dir (wave-cooperative for meshes; result uniform).
 // A real function (not inlined into its ~10 call sites); it only touches the LDS object and the hull vertex table.
-__device__ __forceinline__ V3 geom_support(int g, V3 dir, gcf mesh_vert, int lane) {
+// copy the hull of mesh geom g (<= 256 vertices) into LDS slot `slot` so that the ~10 support scans of one MPR run read LDS
+__device__ __forceinline__ void stage_hull(int g, int slot, gcf mesh_vert, int lane) {
+  int n = 0;
+  if (sm.gtype[g] == G_MESH) {
+    const int adr = sm.gmesh[g] & 0xffff, num = sm.gmesh[g] >> 16;
+    if (num <= 256) {
+      n = num;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = 64 * u + lane;
+        if (i < num) { gcf v = mesh_vert + 3 * (adr + i); sm.hull[slot][i] = v[0]; sm.hull[slot][256 + i] = v[1]; sm.hull[slot][512 + i] = v[2]; }
+      }
+    }
+  }
+  if (lane == 0) sm.hull_n[slot] = n;
+}
+__device__ __forceinline__ V3 geom_support(int g, V3 dir, gcf mesh_vert, int lane, int slot) {
   const int t = sm.gtype[g];
   const M3 R = ldm(sm.gmat + 9 * g);
   const V3 p = ld3(sm.gpos + 3 * g), h = ld3(sm.gst + 8 * g);
@@ -405,19 +432,33 @@ __device__ __forceinline__ V3 geom_support(int g, V3 dir, gcf mesh_vert, int lan
     const int adr = sm.gmesh[g] & 0xffff, num = sm.gmesh[g] >> 16;
     float bv = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f;
     int bi = 0x7fffffff;
-    for (int base = 0; base < num; base += 256) {
-      float vx[4], vy[4], vz[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {   // all loads of the chunk first, then the compares
-        const int i = base + 64 * u + lane;
-        gcf v = mesh_vert + 3 * (adr + (i < num ? i : 0));
-        vx[u] = v[0]; vy[u] = v[1]; vz[u] = v[2];
-      }
+    if (slot >= 0 && sm.hull_n[slot] > 0) {
+      // vertices staged in LDS by stage_hull(): lane l scans slots l, l+64, l+128, l+192
+      const float* hv = sm.hull[slot];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int i = base + 64 * u + lane;
-        const float val = vx[u] * ld.x + vy[u] * ld.y + vz[u] * ld.z;
-        if (i < num && val > bv) { bv = val; bi = i; bx = vx[u]; by = vy[u]; bz = vz[u]; }
+        const int i = 64 * u + lane;
+        if (64 * u < num) {
+          const float x = hv[i], y = hv[256 + i], z = hv[512 + i];
+          const float val = x * ld.x + y * ld.y + z * ld.z;
+          if (i < num && val > bv) { bv = val; bi = i; bx = x; by = y; bz = z; }
+        }
+      }
+    } else {
+      for (int base = 0; base < num; base += 256) {
+        float vx[4], vy[4], vz[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {   // all loads of the chunk first, then the compares
+          const int i = base + 64 * u + lane;
+          gcf v = mesh_vert + 3 * (adr + (i < num ? i : 0));
+          vx[u] = v[0]; vy[u] = v[1]; vz[u] = v[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = base + 64 * u + lane;
+          const float val = vx[u] * ld.x + vy[u] * ld.y + vz[u] * ld.z;
+          if (i < num && val > bv) { bv = val; bi = i; bx = vx[u]; by = vy[u]; bz = vz[u]; }
+        }
       }
     }
     // wave arg-max, lowest index wins ties (matches the serial first-maximum scan)
@@ -600,6 +641,7 @@ struct Sim {
         float* o = sm.gst + 8 * g;
         st3(o, h); st3(o + 3, c); o[6] = FP(FO_cg_rbound, g); o[7] = FP(FO_cg_margin, g);
         sm.gtype[g] = t; sm.gbody[g] = K.ginfo & 255;
+        for (int k = 0; k < 8; k++) sm.gcap[8 * g + k] = FP(FO_cg_capsule, 8 * g + k);
         sm.gcp[g] = IT(IO_cg_condim, g) | (IT(IO_cg_priority, g) << 8);
         sm.gmesh[g] = IT(IO_cg_meshadr, g) | (IT(IO_cg_meshnum, g) << 16);
         float* gp = sm.gpar + 12 * g;
@@ -920,7 +962,7 @@ struct Sim {
     st3(frame, n); st3(frame + 3, y); st3(frame + 6, z);
   }
 
-  __device__ __forceinline__ V3 support(int g, V3 dir) const { return geom_support(g, dir, (gcf)m.mesh_vert, lane); }
+  __device__ __forceinline__ V3 support(int g, V3 dir, int slot = -1) { pf.count(RP_N_SUPPORT, 1); return geom_support(g, dir, (gcf)m.mesh_vert, lane, slot); }
 
   // contact parameters of a geom pair (MuJoCo's mixing rules: priority, solmix-weighted solref/solimp, max friction);
   // evaluated once per candidate pair, uniformly by every lane, from the per-geom table staged in LDS
@@ -1124,10 +1166,18 @@ struct Sim {
   // Minkowski Portal Refinement (uniform control flow; support() is wave-cooperative)
   __device__ __forceinline__ void convex_convex(int g1, int g2, float margin, const CPar& cp) {
     const float tol = 1e-6f;
+#ifndef RSIM_NO_HULL_STAGE
+    stage_hull(g1, 0, (gcf)m.mesh_vert, lane);
+    stage_hull(g2, 1, (gcf)m.mesh_vert, lane);
+    SYNC();
+#else
+    if (lane == 0) { sm.hull_n[0] = 0; sm.hull_n[1] = 0; }
+    SYNC();
+#endif
     V3 v0 = ld3(sm.gcen + 3 * g1) - ld3(sm.gcen + 3 * g2);
     if (norm(v0) < 1e-9f) v0.x = 1e-5f;
     V3 dir = normalized(-v0);
-    V3 p11 = support(g1, dir), p12 = support(g2, -dir), v1 = p11 - p12;
+    V3 p11 = support(g1, dir, 0), p12 = support(g2, -dir, 1), v1 = p11 - p12;
     if (dot(v1, dir) <= 0) return;
     dir = cross(v0, v1);
     if (norm(dir) < 1e-12f) {
@@ -1136,7 +1186,7 @@ struct Sim {
       return;
     }
     dir = normalized(dir);
-    V3 p21 = support(g1, dir), p22 = support(g2, -dir), v2 = p21 - p22;
+    V3 p21 = support(g1, dir, 0), p22 = support(g2, -dir, 1), v2 = p21 - p22;
     if (dot(v2, dir) <= 0) return;
     dir = cross(v1 - v0, v2 - v0);
     if (dot(dir, v0) > 0) {
@@ -1150,7 +1200,7 @@ struct Sim {
       float len;
       dir = normalized(dir, &len);
       if (len < FMIN) return;
-      p31 = support(g1, dir); p32 = support(g2, -dir); v3_ = p31 - p32;
+      p31 = support(g1, dir, 0); p32 = support(g2, -dir, 1); v3_ = p31 - p32;
       if (dot(v3_, dir) <= 0) return;
       if (dot(cross(v1, v3_), v0) < -1e-14f) { v2 = v3_; p21 = p31; p22 = p32; dir = cross(v1 - v0, v3_ - v0); continue; }
       if (dot(cross(v3_, v2), v0) < -1e-14f) { v1 = v3_; p11 = p31; p12 = p32; dir = cross(v3_ - v0, v2 - v0); continue; }
@@ -1162,7 +1212,7 @@ struct Sim {
       dir = normalized(cross(v2 - v1, v3_ - v1), &len);
       if (len < FMIN) break;
       if (dot(dir, v1) >= 0) hit = true;
-      V3 p41 = support(g1, dir), p42 = support(g2, -dir), v4 = p41 - p42;
+      V3 p41 = support(g1, dir, 0), p42 = support(g2, -dir, 1), v4 = p41 - p42;
       float dv4 = dot(v4, dir);
       if (dv4 < 0 && !hit) return;
       float delta = dv4 - dot(v3_, dir);
@@ -1188,6 +1238,23 @@ struct Sim {
     const float* st = sm.gst + 8 * g;
     h = ld3(st);
     o = ld3(sm.gpos + 3 * g) + mv(R, ld3(st + 3));
+  }
+
+  // squared distance between segments [p1,q1] and [p2,q2] (clamped closest-point parameters)
+  __device__ __forceinline__ float segment_dist2(V3 p1, V3 q1, V3 p2, V3 q2) const {
+    const V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+    const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
+    float sp = 0.f, tp = 0.f;
+    if (a > 1e-12f && e > 1e-12f) {
+      const float den = a * e - b * b;
+      sp = den > 1e-12f ? fminf(1.f, fmaxf(0.f, (b * f - c * e) / den)) : 0.f;
+      tp = (b * sp + f) / e;
+      if (tp < 0.f) { tp = 0.f; sp = fminf(1.f, fmaxf(0.f, -c / a)); }
+      else if (tp > 1.f) { tp = 1.f; sp = fminf(1.f, fmaxf(0.f, (b - c) / a)); }
+    } else if (a > 1e-12f) sp = fminf(1.f, fmaxf(0.f, -c / a));
+    else if (e > 1e-12f) tp = fminf(1.f, fmaxf(0.f, f / e));
+    const V3 dd = (p1 + d1 * sp) - (p2 + d2 * tp);
+    return dot(dd, dd);
   }
 
   __device__ __forceinline__ void collision() {
@@ -1232,6 +1299,15 @@ struct Sim {
                                            fabsf(tb.y) - (h2.y + h1.x * fabsf(C.m[1]) + h1.y * fabsf(C.m[4]) + h1.z * fabsf(C.m[7]))),
                                      fabsf(tb.z) - (h2.z + h1.x * fabsf(C.m[2]) + h1.y * fabsf(C.m[5]) + h1.z * fabsf(C.m[8])));
             pass = fmaxf(sepa, sepb) <= margin + 1e-6f;
+            // bounding capsules (mesh hulls): distance between the two axis segments against the radii
+            const float* k1 = sm.gcap + 8 * g1;
+            const float* k2 = sm.gcap + 8 * g2;
+            if (pass && k1[6] >= 0.f && k2[6] >= 0.f) {
+              const V3 gp1 = ld3(sm.gpos + 3 * g1), gp2 = ld3(sm.gpos + 3 * g2);
+              const V3 p1 = gp1 + mv(R1, ld3(k1)), q1 = gp1 + mv(R1, ld3(k1 + 3)), p2 = gp2 + mv(R2, ld3(k2)), q2 = gp2 + mv(R2, ld3(k2 + 3));
+              const float reach = k1[6] + k2[6] + margin + 1e-6f;
+              pass = segment_dist2(p1, q1, p2, q2) <= reach * reach;
+            }
           }
         }
       }
@@ -1267,9 +1343,13 @@ struct Sim {
         const float dist = dot(sp - ld3(sm.gpos + 3 * g1), nrm);
         emit_contacts(lane == 0 && dist <= margin, 1, dist, sp - nrm * (0.5f * dist), nrm, g1, g2, cp);
       } else if (t1 == G_BOX && t2 == G_BOX) {
+        pf.mark(RP_PLANE);
         box_box(g1, g2, margin, cp);
+        pf.mark(RP_BOXBOX); pf.count(RP_N_BOXBOX, 1);
       } else {
+        pf.mark(RP_PLANE);
         convex_convex(g1, g2, margin, cp);
+        pf.mark(RP_MPR); pf.count(RP_N_MPR, 1);
       }
       SYNC();
     }
@@ -1948,6 +2028,61 @@ struct Sim {
   }
 
 
+  // ---------------------------------------------------------------- observation / reward epilogue (after the last substep)
+  // lane i fills observation floats i, i + 64; poses are those of the last substep's kinematics (the reference samples its
+  // Observables after the last sim.step2() of a control step, when site/body frames still belong to that substep's step1)
+  __device__ __forceinline__ Q4 mat2quat_xyzw(const float* R) const {   // returned as {w=x, x=y, y=z, z=w} slots: see caller
+    const float m00 = R[0], m01 = R[1], m02 = R[2], m10 = R[3], m11 = R[4], m12 = R[5], m20 = R[6], m21 = R[7], m22 = R[8];
+    float qw, qx, qy, qz;
+    const float tr = m00 + m11 + m22;
+    if (tr > 0.f) { const float sq = sqrtf(tr + 1.f) * 2.f; qw = 0.25f * sq; qx = (m21 - m12) / sq; qy = (m02 - m20) / sq; qz = (m10 - m01) / sq; }
+    else if (m00 > m11 && m00 > m22) { const float sq = sqrtf(1.f + m00 - m11 - m22) * 2.f; qw = (m21 - m12) / sq; qx = 0.25f * sq; qy = (m01 + m10) / sq; qz = (m02 + m20) / sq; }
+    else if (m11 > m22) { const float sq = sqrtf(1.f + m11 - m00 - m22) * 2.f; qw = (m02 - m20) / sq; qx = (m01 + m10) / sq; qy = 0.25f * sq; qz = (m12 + m21) / sq; }
+    else { const float sq = sqrtf(1.f + m22 - m00 - m11) * 2.f; qw = (m10 - m01) / sq; qx = (m02 + m20) / sq; qy = (m12 + m21) / sq; qz = 0.25f * sq; }
+    if (qw < 0.f) { qw = -qw; qx = -qx; qy = -qy; qz = -qz; }   // transform_utils.mat2quat canonicalises w >= 0
+    Q4 q = {qw, qx, qy, qz};
+    return q;
+  }
+  __device__ __forceinline__ void obs_reward(float* __restrict__ obs, float* __restrict__ reward, int* __restrict__ success) {
+    const DTask& t = m.task;
+    gci prog = (gci)t.obs_prog;
+    for (int i = lane; i < t.nobs; i += 64) {
+      const int kind = prog[3 * i], a = prog[3 * i + 1], b2 = prog[3 * i + 2];
+      float v = 0.f;
+      if (kind == RSIM_OBS_QPOS) v = sm.qpos[a];
+      else if (kind == RSIM_OBS_COS) { float sn, cs; sincos_f(sm.qpos[a], sn, cs); v = cs; }
+      else if (kind == RSIM_OBS_SIN) { float sn, cs; sincos_f(sm.qpos[a], sn, cs); v = sn; }
+      else if (kind == RSIM_OBS_QVEL) v = sm.qvel[a];
+      else if (kind == RSIM_OBS_QACC) v = sm.qacc[a];
+      else if (kind == RSIM_OBS_SITE_POS) v = sm.spos[3 * a + b2];
+      else if (kind == RSIM_OBS_BODY_POS) v = sm.xpos[3 * a + b2];
+      else if (kind == RSIM_OBS_BODY_MINUS_SITE) v = sm.xpos[3 * a + (b2 & 3)] - sm.spos[3 * (b2 >> 2) + (b2 & 3)];
+      else if (kind == RSIM_OBS_BODY_QUAT) v = sm.xquat[4 * a + (b2 == 3 ? 0 : b2 + 1)];   // wxyz -> xyzw
+      else if (kind == RSIM_OBS_SITE_QUAT) { const Q4 q = mat2quat_xyzw(sm.smat + 9 * a); v = b2 == 0 ? q.x : (b2 == 1 ? q.y : (b2 == 2 ? q.z : q.w)); }
+      obs[i] = v;
+    }
+    if (t.task == 1) {
+      // grasp: both finger-pad geom groups touch the object (contact list of the last substep)
+      bool lc = false, rc = false;
+      if (lane < sm.ncon) {
+        const unsigned long long b1 = 1ull << sm.cg1[lane], b2 = 1ull << sm.cg2[lane];
+        const bool obj1 = (t.object_geoms & b1) != 0, obj2 = (t.object_geoms & b2) != 0;
+        lc = (obj1 && (t.left_pad & b2)) || (obj2 && (t.left_pad & b1));
+        rc = (obj1 && (t.right_pad & b2)) || (obj2 && (t.right_pad & b1));
+      }
+      const bool grasp = __ballot(lc) != 0 && __ballot(rc) != 0;
+      if (lane == 0) {
+        const V3 cube = ld3(sm.xpos + 3 * t.object_body), grip = ld3(sm.spos + 3 * t.grip_site);
+        const bool succ = cube.z > t.table_height + t.lift_margin;
+        float r = 0.f;
+        if (succ) r = 2.25f;
+        else if (t.reward_shaping) { r = 1.f - tanhf(10.f * norm(cube - grip)); if (grasp) r += 0.25f; }
+        *reward = r * t.reward_scale / 2.25f;
+        *success = succ ? 1 : 0;
+      }
+    }
+  }
+
   __device__ __forceinline__ void fwd_constraint() {
     if (sm.nefc == 0) {
       if (lane < m.nv) { sm.qacc[lane] = sm.qacc_smooth[lane]; sm.qfrc_constraint[lane] = 0.f; }
@@ -1969,9 +2104,10 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   if (env >= b.B) return;
   const float* fp = m.ft + (size_t)env * m.fstride;
   Sim<SM> sim(m, fp, lane, b.prof);
+  sim.pf.acc = b.prof_env < 0 || b.prof_env == env;
   sim.pf.start();
   if (b.prof && lane == 0) {
-    unsigned long long* wl = b.prof + RP_COUNT + 4 * (size_t)env;
+    unsigned long long* wl = b.prof + RP_COUNT + 8 * (size_t)env;
     wl[0] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
     wl[1] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
     wl[2] = wall_clock64();
@@ -2022,13 +2158,17 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
     }
     sim.pf.count(RP_N_SUB, 1);
   }
+  if ((flags & RF_OBS) && m.task.enabled) sim.obs_reward(b.obs + (size_t)env * m.task.nobs, b.reward + env, b.success + env);
   // ---- store state
   for (int i = lane; i < m.nq; i += 64) b.qpos[(size_t)env * m.nq + i] = sm.qpos[i];
   for (int i = lane; i < m.nv; i += 64) { b.qvel[(size_t)env * m.nv + i] = sm.qvel[i]; b.qacc_ws[(size_t)env * m.nv + i] = sm.qacc_ws[i]; }
   for (int i = lane; i < m.nu; i += 64) b.ctrl[(size_t)env * m.nu + i] = sm.ctrl[i];
   if (lane < RSIM_CS_SIZE) b.cstate[(size_t)env * RSIM_CS_SIZE + lane] = sm.cstate[lane];
   if (lane == 0) b.time[env] = time;
-  if (b.prof && lane == 0) b.prof[RP_COUNT + 4 * (size_t)env + 3] = wall_clock64();
+  if (b.prof && lane == 0) {
+    unsigned long long* wl = b.prof + RP_COUNT + 8 * (size_t)env;
+    wl[3] = wall_clock64(); wl[4] = sim.pf.c_mpr; wl[5] = sim.pf.c_support; wl[6] = sim.pf.c_newton; wl[7] = sim.pf.c_cand;
+  }
   if (flags & RF_DEBUG) {
     const int nb = m.nbody, nv = m.nv;
     for (int i = lane; i < nb * 3; i += 64) { b.xpos[(size_t)env * nb * 3 + i] = sm.xpos[i]; b.rootcom[(size_t)env * nb * 3 + i] = sm.rootcom[3 * sm.broot[i / 3] + i % 3]; }

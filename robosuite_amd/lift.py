@@ -113,6 +113,32 @@ def env_actions(env_ids, n_steps: int, scale: float = 1.0, action_dim: int = 7):
     return out
 
 
+def lift_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool = True):
+    """Observation program + reward description of Lift/Panda for the on-device epilogue (include/rsim.h rsim_task_desc).
+
+    Key order = the reference's `_get_observations` order for use_object_obs=True, use_camera_obs=False:
+    robot0_joint_pos, _cos, _sin, joint_vel, joint_acc, eef_pos, eef_quat (BODY robot0_right_hand, xyzw), eef_quat_site, gripper_qpos,
+    gripper_qvel (robots/robot.py:334-484), cube_pos, cube_quat, gripper_to_cube_pos (lift.py:356-399)."""
+    names = flat.names
+    site = int(cfg["eef_site"])                      # gripper0_right_grip_site
+    eef_body = names["body"].index("robot0_right_hand")
+    cube_body = names["body"].index("cube_main")
+    qi, di = cfg["qpos_idx"], cfg["dof_idx"]
+    gq, gd = cfg["grip_qpos_idx"], cfg["grip_dof_idx"]
+    obs = []
+    obs += [("qpos", q, 0) for q in qi] + [("cos", q, 0) for q in qi] + [("sin", q, 0) for q in qi]
+    obs += [("qvel", d, 0) for d in di] + [("qacc", d, 0) for d in di]
+    obs += [("site_pos", site, k) for k in range(3)] + [("body_quat", eef_body, k) for k in range(4)] + [("site_quat", site, k) for k in range(4)]
+    obs += [("qpos", q, 0) for q in gq] + [("qvel", d, 0) for d in gd]
+    obs += [("body_pos", cube_body, k) for k in range(3)] + [("body_quat", cube_body, k) for k in range(4)]
+    obs += [("body_minus_site", cube_body, k | (site << 2)) for k in range(3)]
+    g = names["geom"]
+    return dict(obs=obs, task="lift", object_body=cube_body, grip_site=site, table_height=float(TABLE_OFFSET[2]), lift_margin=0.04,
+                reward_scale=reward_scale, reward_shaping=reward_shaping,
+                left_pad_geoms=[g.index("gripper0_right_finger1_pad_collision")], right_pad_geoms=[g.index("gripper0_right_finger2_pad_collision")],
+                object_geoms=[g.index("cube_g0")])
+
+
 class LiftBatch:
     """B Lift/Panda/OSC_POSE environments resident on one GPU, stepped by the fused HIP control-step kernel.
 
@@ -126,6 +152,7 @@ class LiftBatch:
         self.B = len(self.env_ids)
         self.model = HipModel(flat)
         self.model.set_controller(cfg)
+        self.model.set_task(lift_task(flat, cfg))
         self.batch = HipBatch(self.model, self.B, device, per_env_params=per_env_cube)
         self.per_env_cube = per_env_cube
         self.seed0 = seed0
@@ -147,4 +174,14 @@ class LiftBatch:
         self.sizes, self.qpos0 = sizes, qpos
 
     def step(self, actions, n_sub: int = 25):
+        """One env.step for every env: fused physics + controllers + observation / reward epilogue (results stay on the device)."""
         self.batch.control_step(actions, n_sub)
+
+    def obs(self):
+        return self.batch.tensor("obs")
+
+    def reward(self):
+        return self.batch.tensor("reward")
+
+    def success(self):
+        return self.batch.tensor("success")

@@ -134,3 +134,31 @@ def test_missing_controller_is_an_error():
     hm, hb = make_hip(flat, None, B=1)
     with pytest.raises(backend.RsimError):
         hb.control_step(torch.zeros(1, 7, device="cuda"), 25)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_observation_and_reward_epilogue_matches_reference_env(tag):
+    """obs / reward written by the fused kernel vs what the reference's env.step() returned (golden `obs`, `rewards`): key order,
+    last-substep sampling of the Observables, body-vs-site eef quaternion, xyzw convention, Lift.reward shaping."""
+    g, cfg, flat = load_golden(tag)
+    nq = flat.nq
+    hm, _ = make_hip(flat, cfg, B=1)
+    from robosuite_amd.backend import HipBatch
+    hm.set_task(lift.lift_task(flat, cfg))
+    hb = HipBatch(hm, 2, 0, False)
+    s0 = g["states"][0]
+    hb.set("qpos", s0[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    assert hb.get("obs").shape == (2, 60)
+    dims = np.cumsum([0] + cfg["obs_dims"])
+    for t in range(len(g["actions"])):
+        hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+        obs, rew = hb.get("obs")[0], hb.get("reward")[0]
+        for k, key in enumerate(cfg["obs_keys"]):
+            ref, got = g["obs"][t][dims[k]:dims[k + 1]], obs[dims[k]:dims[k + 1]]
+            tol = 2e-2 * max(1.0, np.abs(ref).max()) if key.endswith("joint_acc") else (5e-3 if key.endswith("vel") else 5e-4)
+            if key.endswith("quat") or key.endswith("quat_site"):
+                got = got * np.sign(np.dot(got, ref))  # q and -q are the same rotation
+            assert np.abs(got - ref).max() < tol, (t, key)
+        assert abs(rew - g["rewards"][t]) < 1e-4, t
+        assert hb.get("success")[0] == 0

@@ -24,11 +24,12 @@ env.batch.sync()
 dt = time.perf_counter() - t0
 p = env.batch.profile(False)
 nsub = max(1, p["n_sub"])
-cyc = {k: v for k, v in p.items() if not k.startswith("n_")}
+cyc = {k: v for k, v in p.items() if not k.startswith("n_") and k not in ("boxbox", "mpr", "plane")}
 tot = sum(cyc.values())
 print(f"B={B} steps={steps}: {1e3*dt/steps:.2f} ms/step -> {B*steps/dt:.0f} env-steps/s")
 print(f"per env-substep: total {tot/nsub:.0f} cycles (s_memtime ticks, 100 MHz => {tot/nsub/100:.1f} us)")
 for k, v in cyc.items():
     print(f"  {k:8s} {v/nsub:10.1f}  {100*v/tot:5.1f}%")
-for k in ("n_cand", "n_con", "n_efc", "n_newton", "n_ls"):
+print(f"  inside narrow: boxbox {p['boxbox']/nsub:.0f} mpr {p['mpr']/nsub:.0f} other {p['plane']/nsub:.0f} cycles/substep")
+for k in ("n_cand", "n_con", "n_efc", "n_newton", "n_ls", "n_boxbox", "n_mpr", "n_support"):
     print(f"  {k:8s} {p[k]/nsub:8.3f} per substep")

@@ -9,8 +9,11 @@ adir = os.path.join(ROOT, "robosuite_amd", "assets")
 flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim")); cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
 env = lift.LiftBatch(flat, cfg, np.arange(B), seed0=0, per_env_cube=False)
 a = torch.zeros(B, 7, device="cuda").uniform_(-1, 1)
-for _ in range(2): env.step(a)
-env.batch.sync(); env.batch.profile(True); env.step(a); env.batch.sync()
+nskip = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+tape = torch.tensor(lift.env_actions(np.arange(B), nskip + 1), device="cuda")
+for t in range(nskip): env.step(tape[t])
+a = tape[nskip]
+env.batch.sync(); env.batch.profile(True); env.batch.profile_env(0); env.step(a); env.batch.sync()
 w = env.batch.wavelog()
 hw, xcc, t0, t1 = w[:, 0].astype(np.int64), w[:, 1].astype(np.int64) & 0xF, w[:, 2].astype(np.int64), w[:, 3].astype(np.int64)
 simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
@@ -35,3 +38,12 @@ print("start time percentiles (us):", np.percentile(st, [0, 10, 25, 50, 75, 90, 
 print("duration percentiles (us):", np.percentile(dur, [0, 10, 25, 50, 75, 90, 100]).round(1))
 k0 = np.unique(key_cu)[0]; mm = key_cu == k0
 print("one CU:", sorted([(int(simd[i]), round(float(st[i]), 1), round(float(dur[i]), 1)) for i in np.nonzero(mm)[0]], key=lambda x: x[1])[:12])
+
+cnt = w[:, 4:8].astype(np.int64)
+order = np.argsort(-dur)
+print("slowest envs: dur_us n_mpr n_support n_newton n_cand (per launch of 25 substeps)")
+for i in order[:8]: print(f"  env {i}: {dur[i]:.0f} us  {cnt[i].tolist()}")
+print("fastest:"); 
+for i in order[-3:]: print(f"  env {i}: {dur[i]:.0f} us  {cnt[i].tolist()}")
+print("corr(dur, n_support) =", np.corrcoef(dur, cnt[:, 1])[0, 1].round(3), " corr(dur, n_newton) =", np.corrcoef(dur, cnt[:, 2])[0, 1].round(3))
+print("mean counts per launch:", cnt.mean(0).round(1).tolist(), " p99 of n_support:", np.percentile(cnt[:, 1], 99))
