@@ -753,16 +753,18 @@ extern "C" int rsim_model_param_set(rsim_batch* b, const char* field, int env0, 
   HIPCHK(hipStreamSynchronize(b->stream));
   const int ncg = (int)m->cg.size();
   size_t n = m->fcount[mp->fo], fs = m->ftab.size();
-  std::vector<float> tmp(n);
   int envs = b->per_env ? nenv : 1;
+  std::vector<float> tmp((size_t)envs * n);
   for (int e = 0; e < envs; e++) {
     const double* v = values + (size_t)e * cpe;
+    float* t = tmp.data() + (size_t)e * n;
     if (mp->geom) {
-      for (int c = 0; c < ncg; c++) for (int q = 0; q < mp->w; q++) tmp[(size_t)c * mp->w + q] = (float)v[(size_t)m->cg[c] * mp->w + q];
-    } else for (size_t i = 0; i < n; i++) tmp[i] = (float)v[i];
-    size_t base = b->per_env ? (size_t)(env0 + e) * fs : 0;
-    HIPCHK(hipMemcpy(b->d_ft + base + m->fo[mp->fo], tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+      for (int c = 0; c < ncg; c++) for (int q = 0; q < mp->w; q++) t[(size_t)c * mp->w + q] = (float)v[(size_t)m->cg[c] * mp->w + q];
+    } else for (size_t i = 0; i < n; i++) t[i] = (float)v[i];
   }
+  // one strided copy: row e of `tmp` -> the field's slot inside env (env0 + e)'s float table
+  const size_t base = b->per_env ? (size_t)env0 * fs : 0;
+  HIPCHK(hipMemcpy2D(b->d_ft + base + m->fo[mp->fo], fs * sizeof(float), tmp.data(), n * sizeof(float), n * sizeof(float), (size_t)envs, hipMemcpyHostToDevice));
   b->gen++;
   return 0;
 }
