@@ -162,3 +162,46 @@ def test_observation_and_reward_epilogue_matches_reference_env(tag):
             assert np.abs(got - ref).max() < tol, (t, key)
         assert abs(rew - g["rewards"][t]) < 1e-4, t
         assert hb.get("success")[0] == 0
+
+
+def test_mujoco_shaped_shim_on_the_hip_backend_matches_the_oracle_backend():
+    """B=1 compatibility boundary: the calls robosuite's MjSim / Controller.update make (mj_step1, mj_jacSite, mj_fullM, views into
+    data, writes to data.ctrl, mj_step2) through robosuite_amd.shim, once on the HIP backend and once on the oracle backend."""
+    from oracle.shim_backend import OracleBackend
+    from robosuite_amd import shim
+    from robosuite_amd.hip_shim_backend import HipShimBackend
+
+    g, cfg, flat = load_golden("seed0_gentle")
+    xml_free = flat  # models are built from the compiled fixture (the reference's MJCF is not on the GPU box)
+    sims = []
+    for factory in (HipShimBackend, OracleBackend):
+        shim.install(factory, stub_missing=False)
+        model = shim.MjModel(xml_free.copy())
+        data = shim.MjData(model)
+        sims.append((model, data))
+    nq, nv = flat.nq, flat.nv
+    s0 = g["states"][0]
+    rng = np.random.default_rng(0)
+    site = cfg["eef_site"]
+    for model, data in sims:
+        data.qpos[:] = s0[1:1 + nq]; data.qvel[:] = s0[1 + nq:]
+        shim.mj_forward(model, data)
+    for k in range(30):
+        tau = rng.uniform(-5, 5, 7)
+        out = []
+        for model, data in sims:
+            shim.mj_step1(model, data)
+            jp, jr = np.zeros((3, nv)), np.zeros((3, nv))
+            shim.mj_jacSite(model, data, jp, jr, site)
+            M = np.zeros((nv, nv)); shim.mj_fullM(model, M, data.qM)
+            data.ctrl[:7] = tau + data.qfrc_bias[:7]       # what FixedBaseRobot.control writes (fixed_base_robot.py:149-153)
+            data.ctrl[7:9] = [0.02, -0.02]
+            shim.mj_step2(model, data)
+            out.append(dict(jp=jp, jr=jr, M=M, qpos=np.array(data.qpos), qvel=np.array(data.qvel), site=np.array(data.site_xpos[site]),
+                            smat=np.array(data.site_xmat[site]), bias=np.array(data.qfrc_bias), t=data.time, ncon=data.ncon))
+        h, o = out
+        assert np.abs(h["jp"] - o["jp"]).max() < 5e-6 and np.abs(h["jr"] - o["jr"]).max() < 5e-6
+        assert np.abs(h["M"] - o["M"]).max() < 1e-4 * np.abs(o["M"]).max()
+        assert np.abs(h["site"] - o["site"]).max() < 5e-6 and np.abs(h["smat"] - o["smat"]).max() < 5e-6
+        assert np.abs(h["qpos"] - o["qpos"]).max() < 2e-5 and np.abs(h["qvel"] - o["qvel"]).max() < 2e-3
+        assert abs(h["t"] - o["t"]) < 1e-5 and h["ncon"] == o["ncon"]
