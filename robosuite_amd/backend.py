@@ -13,7 +13,7 @@ import numpy as np
 from . import mjcf
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsim_hip.so")
+LIB_PATH = os.environ.get("RSIM_LIB", os.path.join(_HERE, "librsim_hip.so"))  # RSIM_LIB: A/B a second build of the same ABI
 _LIB = None
 
 # enum rsim_field (include/rsim.h)
@@ -262,7 +262,8 @@ class HipBatch:
         return self._L.rsim_stream(self.ptr)
 
     PROFILE_SLOTS = ("load", "kin", "com", "crb", "broad", "narrow", "makec", "vel", "ctrl", "act", "solve", "euler", "store",
-                     "n_sub", "n_cand", "n_con", "n_efc", "n_newton", "n_ls", "boxbox", "mpr", "plane", "n_boxbox", "n_mpr", "n_support")
+                     "n_sub", "n_cand", "n_con", "n_efc", "n_newton", "n_ls", "boxbox", "mpr", "plane", "n_boxbox", "n_mpr", "n_support",
+                     "x0", "x1", "x2", "x3", "x4", "x5", "x6", "x7", "x8", "x9")
 
     def profile_env(self, env=-1):
         _chk(self._L.rsim_profile_env(self.ptr, int(env)))

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -189,6 +190,16 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
     }
     for (int c = 0; c < ncg && c < 64; c++) LT(LT_ginfo, c) = m->I("geom_bodyid")[m->cg[c]] | (m->I("geom_type")[m->cg[c]] << 8);
     for (int k = 0; k < m->nsite && k < 64; k++) LT(LT_sinfo, k) = m->I("site_bodyid")[k];
+    {  // LDS-resident hull pool: deepest bodies first (gripper, distal links collide most), whole hulls only
+      std::vector<int> order;
+      for (int c = 0; c < ncg && c < 64; c++) { LT(LT_ghull, c) = -1; if (m->I("geom_type")[m->cg[c]] == 7) order.push_back(c); }
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return depth[m->I("geom_bodyid")[m->cg[a]]] > depth[m->I("geom_bodyid")[m->cg[b2]]]; });
+      int used = 0;
+      for (int c : order) {
+        int num = m->I("mesh_vertnum")[m->I("geom_dataid")[m->cg[c]]];
+        if (used + num <= RSIM_HULL_POOL) { LT(LT_ghull, c) = used; used += num; }
+      }
+    }
     for (int a = 0; a < m->nu && a < 64; a++) {
       int j = m->I("actuator_trnid")[a];
       LT(LT_ainfo, a) = jdof[j] | (m->I("jnt_qposadr")[j] << 8) | (m->I("actuator_biastype")[a] << 16) | (m->I("actuator_ctrllimited")[a] << 18) |

@@ -40,10 +40,12 @@ enum {
   LT_sinfo,  /* site k = lane: body */
   LT_ainfo,  /* actuator a = lane: dof | qposadr<<8 | biastype<<16 | ctrllimited<<18 | forcelimited<<19 */
   LT_pair0, LT_pair1, LT_pair2, /* candidate pair p = lane + 64 t: g1 | g2<<8 | valid<<16 */
+  LT_ghull,  /* colliding geom g = lane: first slot of its hull in the LDS-resident vertex pool, -1 = scan from global memory */
   LT_mfbits, /* 0/1 operands of the tree-incidence MFMAs: sub[8] | bodydof[2][4] | dcv[4] | m1[4] | m2[4] */
   LT_COUNT
 };
 #define RSIM_MAXDYNROOT 4
+#define RSIM_HULL_POOL 512   /* hull vertices kept resident in LDS (distal links / gripper first) */
 #define RSIM_ARM_MAX 8
 #define RSIM_GRIP_MAX 4
 
@@ -113,7 +115,8 @@ struct DBatch {
 
 // profile slots (cycles of s_memtime summed over envs and substeps, then event counters)
 enum { RP_LOAD, RP_KIN, RP_COM, RP_CRB, RP_BROAD, RP_NARROW, RP_MAKEC, RP_VEL, RP_CTRL, RP_ACT, RP_SOLVE, RP_EULER, RP_STORE,
-       RP_N_SUB, RP_N_CAND, RP_N_CON, RP_N_EFC, RP_N_NEWTON, RP_N_LS, RP_BOXBOX, RP_MPR, RP_PLANE, RP_N_BOXBOX, RP_N_MPR, RP_N_SUPPORT, RP_COUNT };
+       RP_N_SUB, RP_N_CAND, RP_N_CON, RP_N_EFC, RP_N_NEWTON, RP_N_LS, RP_BOXBOX, RP_MPR, RP_PLANE, RP_N_BOXBOX, RP_N_MPR, RP_N_SUPPORT,
+       RP_X0, RP_X1, RP_X2, RP_X3, RP_X4, RP_X5, RP_X6, RP_X7, RP_X8, RP_X9, /* ad-hoc sub-phase cycle slots */ RP_COUNT };
 
 // flags for the step kernel
 enum {

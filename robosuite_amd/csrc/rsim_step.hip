@@ -68,6 +68,12 @@ __device__ __forceinline__ int wave_min_i(int x) {
 __device__ __forceinline__ float bcast(float x, int srclane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), srclane));
 }
+// value of lane K of the caller's own 16-lane row (DPP row_newbcast, gfx90a+): a full-rate VALU operand modifier, no SGPR round trip.
+// The dense 16x16 algebra keeps row r of a matrix in lanes r, 16+r, 32+r, 48+r so every lane finds its operand in its own row.
+template <int K>
+__device__ __forceinline__ float rbcast(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + K, 0xf, 0xf, true));
+}
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ u64 lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
@@ -237,8 +243,8 @@ struct Smem {
   int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
   float cstate[RSIM_CS_SIZE];
   float red[16];
-  float hull[2][3 * 256];   // hull vertices (SoA x|y|z, 256 slots) of the two geoms of the convex pair being tested
-  int hull_n[2];
+  float hull[3 * RSIM_HULL_POOL];   // LDS-resident hull vertex pool (SoA x | y | z); filled once per launch
+  int ghull[NG];                    // first pool slot of geom g, -1: not resident
   // per-lane model constants, one row per field (LaneConst below); phases fetch the handful they need instead of pinning ~80 VGPRs
   float kc[RSIM_KC_WORDS];
   int ncon, nefc, niter;
@@ -252,41 +258,70 @@ __shared__ Smem0 sm;
 #define IT(tab, i) (((gci)m.it)[m.io[tab] + (i)])
 #define FP(tab, i) (((gcf)fp)[m.fo[tab] + (i)])
 
-// Register-resident Cholesky: lane i (< N) owns row i of the SPD matrix in a[0..N); all loops unroll so every index is a
-// compile-time register and every broadcast is a v_readlane.  After the call a[k] = L[i][k] (k <= i), inv[k] = 1 / L[k][k] (uniform).
-template <int N>
-__device__ __forceinline__ void rchol_factor(float (&a)[N], float (&inv)[N]) {
-#pragma unroll
-  for (int j = 0; j < N; j++) {
-    const float iv = rsqrtf(fmaxf(bcast(a[j], j), FMIN));
-    inv[j] = iv;
-    const float lij = a[j] * iv;
-    a[j] = lij;
-#pragma unroll
-    for (int k = j + 1; k < N; k++) a[k] = fmaf(-lij, bcast(lij, k), a[k]);
+// Register-resident Cholesky: lane i owns row (i & 15) of the SPD matrix in a[0..N) (the four 16-lane rows of the wave hold identical
+// copies); all loops unroll so every index is a compile-time register and every broadcast is a DPP row_newbcast operand.
+// After the call a[k] = L[i][k] (k <= i), inv[k] = 1 / L[k][k] (uniform).
+template <int N, int J, int K>
+struct RcholUpd {
+  static __device__ __forceinline__ void run(float (&a)[N], float lij) {
+    if constexpr (K < N) { a[K] = fmaf(-lij, rbcast<K>(lij), a[K]); RcholUpd<N, J, K + 1>::run(a, lij); }
   }
-}
-// forward substitution only: returns y = L^-1 x (component i in lane i)
-template <int N>
-__device__ __forceinline__ float rchol_fwd(const float (&a)[N], const float (&inv)[N], float x, int lane) {
-#pragma unroll
-  for (int k = 0; k < N; k++) {
-    const float xk = bcast(x, k) * inv[k];
-    x = lane == k ? xk : (lane > k ? fmaf(-a[k], xk, x) : x);
+};
+template <int N, int J>
+struct RcholStep {
+  static __device__ __forceinline__ void run(float (&a)[N], float (&inv)[N]) {
+    if constexpr (J < N) {
+      const float iv = rsqrtf(fmaxf(rbcast<J>(a[J]), FMIN));
+      inv[J] = iv;
+      const float lij = a[J] * iv;
+      a[J] = lij;
+      RcholUpd<N, J, J + 1>::run(a, lij);
+      RcholStep<N, J + 1>::run(a, inv);
+    }
   }
-  return x;
-}
-// x_i in lane i; a = rows of L, at[k] = L[k][i] (column i of L), inv = 1/diag.  Returns (L L^T)^-1 x, component i in lane i.
+};
+template <int N>
+__device__ __forceinline__ void rchol_factor(float (&a)[N], float (&inv)[N]) { RcholStep<N, 0>::run(a, inv); }
+// forward substitution only: returns y = L^-1 x (component i in the lanes of row i); `row` = lane & 15
+template <int N, int K>
+struct RcholFwd {
+  static __device__ __forceinline__ float run(const float (&a)[N], const float (&inv)[N], float x, int row) {
+    if constexpr (K < N) {
+      const float xk = rbcast<K>(x) * inv[K];
+      x = row == K ? xk : (row > K ? fmaf(-a[K], xk, x) : x);
+      return RcholFwd<N, K + 1>::run(a, inv, x, row);
+    } else return x;
+  }
+};
+template <int N, int K>
+struct RcholBwd {
+  static __device__ __forceinline__ float run(const float (&at)[N], const float (&inv)[N], float x, int row) {
+    if constexpr (K >= 0) {
+      const float xk = rbcast<K>(x) * inv[K];
+      x = row == K ? xk : (row < K ? fmaf(-at[K], xk, x) : x);
+      return RcholBwd<N, K - 1>::run(at, inv, x, row);
+    } else return x;
+  }
+};
+template <int N>
+__device__ __forceinline__ float rchol_fwd(const float (&a)[N], const float (&inv)[N], float x, int lane) { return RcholFwd<N, 0>::run(a, inv, x, lane & 15); }
+// x_i in the lanes of row i; a = rows of L, at[k] = L[k][i] (column i of L), inv = 1/diag.  Returns (L L^T)^-1 x.
 template <int N>
 __device__ __forceinline__ float rchol_solve(const float (&a)[N], const float (&at)[N], const float (&inv)[N], float x, int lane) {
-  x = rchol_fwd<N>(a, inv, x, lane);
-#pragma unroll
-  for (int k = N - 1; k >= 0; k--) {
-    const float xk = bcast(x, k) * inv[k];
-    x = lane == k ? xk : (lane < k ? fmaf(-at[k], xk, x) : x);
-  }
-  return x;
+  x = RcholFwd<N, 0>::run(a, inv, x, lane & 15);
+  return RcholBwd<N, N - 1>::run(at, inv, x, lane & 15);
 }
+// sum_k r[k] * x_k, where x_k lives in lane k of every 16-lane row (replicated per-dof vector)
+template <int N, int K>
+struct RowDot {
+  static __device__ __forceinline__ float run(const float (&r)[N], float x, float acc) {
+    if constexpr (K < N) return RowDot<N, K + 1>::run(r, x, fmaf(r[K], rbcast<K>(x), acc));
+    else return acc;
+  }
+};
+template <int N>
+__device__ __forceinline__ float dot_rows(const float (&r)[N], float x) { return RowDot<N, 0>::run(r, x, 0.f); }
+
 template <int N>
 __device__ __forceinline__ int seli(const int (&v)[N], int i) {
   int r = v[0];
@@ -392,23 +427,7 @@ __device__ __forceinline__ void spd_solve_small(const float* A, const float* b, 
 
 // support point of colliding geom g along world direction dir (wave-cooperative for meshes; result uniform).
 // A real function (not inlined into its ~10 call sites); it only touches the LDS object and the hull vertex table.
-// copy the hull of mesh geom g (<= 256 vertices) into LDS slot `slot` so that the ~10 support scans of one MPR run read LDS
-__device__ __forceinline__ void stage_hull(int g, int slot, gcf mesh_vert, int lane) {
-  int n = 0;
-  if (sm.gtype[g] == G_MESH) {
-    const int adr = sm.gmesh[g] & 0xffff, num = sm.gmesh[g] >> 16;
-    if (num <= 256) {
-      n = num;
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = 64 * u + lane;
-        if (i < num) { gcf v = mesh_vert + 3 * (adr + i); sm.hull[slot][i] = v[0]; sm.hull[slot][256 + i] = v[1]; sm.hull[slot][512 + i] = v[2]; }
-      }
-    }
-  }
-  if (lane == 0) sm.hull_n[slot] = n;
-}
-__device__ __forceinline__ V3 geom_support(int g, V3 dir, gcf mesh_vert, int lane, int slot) {
+__device__ __forceinline__ V3 geom_support(int g, V3 dir, gcf mesh_vert, int lane) {
   const int t = sm.gtype[g];
   const M3 R = ldm(sm.gmat + 9 * g);
   const V3 p = ld3(sm.gpos + 3 * g), h = ld3(sm.gst + 8 * g);
@@ -432,14 +451,16 @@ __device__ __forceinline__ V3 geom_support(int g, V3 dir, gcf mesh_vert, int lan
     const int adr = sm.gmesh[g] & 0xffff, num = sm.gmesh[g] >> 16;
     float bv = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f;
     int bi = 0x7fffffff;
-    if (slot >= 0 && sm.hull_n[slot] > 0) {
-      // vertices staged in LDS by stage_hull(): lane l scans slots l, l+64, l+128, l+192
-      const float* hv = sm.hull[slot];
+    const int pool = sm.ghull[g];
+    if (pool >= 0) {
+      // hull resident in LDS: lane l scans vertices l, l+64, ... (at most 256 per hull in the pool)
+      const float* hv = sm.hull + pool;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int i = 64 * u + lane;
         if (64 * u < num) {
-          const float x = hv[i], y = hv[256 + i], z = hv[512 + i];
+          const int ii = i < num ? i : 0;
+          const float x = hv[ii], y = hv[RSIM_HULL_POOL + ii], z = hv[2 * RSIM_HULL_POOL + ii];
           const float val = x * ld.x + y * ld.y + z * ld.z;
           if (i < num && val > bv) { bv = val; bi = i; bx = x; by = y; bz = z; }
         }
@@ -644,6 +665,7 @@ struct Sim {
         for (int k = 0; k < 8; k++) sm.gcap[8 * g + k] = FP(FO_cg_capsule, 8 * g + k);
         sm.gcp[g] = IT(IO_cg_condim, g) | (IT(IO_cg_priority, g) << 8);
         sm.gmesh[g] = IT(IO_cg_meshadr, g) | (IT(IO_cg_meshnum, g) << 16);
+        sm.ghull[g] = lt[LT_ghull * 64 + lane];
         float* gp = sm.gpar + 12 * g;
         for (int k = 0; k < 3; k++) gp[k] = FP(FO_cg_friction, 3 * g + k);
         gp[3] = FP(FO_cg_solref, 2 * g); gp[4] = FP(FO_cg_solref, 2 * g + 1);
@@ -671,6 +693,15 @@ struct Sim {
     for (int e = lane; e < NV16 * CS6; e += 64) sm.cdof[e] = 0.f;
     if (lane < (RSIM_MAXDYNROOT + 1) * 3) sm.rootcom[lane] = 0.f;
     kxfer<true>(K);
+    SYNC();
+    // resident hull pool: one pass per pooled mesh, lane-parallel over its vertices
+    for (int g = 0; g < m.ncg; g++) {
+      const int pool = sm.ghull[g];
+      if (pool < 0) continue;
+      const int adr = sm.gmesh[g] & 0xffff, num = sm.gmesh[g] >> 16;
+      gcf mvp = (gcf)m.mesh_vert + 3 * adr;
+      for (int i = lane; i < num; i += 64) { sm.hull[pool + i] = mvp[3 * i]; sm.hull[RSIM_HULL_POOL + pool + i] = mvp[3 * i + 1]; sm.hull[2 * RSIM_HULL_POOL + pool + i] = mvp[3 * i + 2]; }
+    }
     SYNC();
   }
 
@@ -962,7 +993,7 @@ struct Sim {
     st3(frame, n); st3(frame + 3, y); st3(frame + 6, z);
   }
 
-  __device__ __forceinline__ V3 support(int g, V3 dir, int slot = -1) { pf.count(RP_N_SUPPORT, 1); return geom_support(g, dir, (gcf)m.mesh_vert, lane, slot); }
+  __device__ __forceinline__ V3 support(int g, V3 dir, int slot = -1) { pf.count(RP_N_SUPPORT, 1); return geom_support(g, dir, (gcf)m.mesh_vert, lane); }
 
   // contact parameters of a geom pair (MuJoCo's mixing rules: priority, solmix-weighted solref/solimp, max friction);
   // evaluated once per candidate pair, uniformly by every lane, from the per-geom table staged in LDS
@@ -1166,14 +1197,6 @@ struct Sim {
   // Minkowski Portal Refinement (uniform control flow; support() is wave-cooperative)
   __device__ __forceinline__ void convex_convex(int g1, int g2, float margin, const CPar& cp) {
     const float tol = 1e-6f;
-#ifndef RSIM_NO_HULL_STAGE
-    stage_hull(g1, 0, (gcf)m.mesh_vert, lane);
-    stage_hull(g2, 1, (gcf)m.mesh_vert, lane);
-    SYNC();
-#else
-    if (lane == 0) { sm.hull_n[0] = 0; sm.hull_n[1] = 0; }
-    SYNC();
-#endif
     V3 v0 = ld3(sm.gcen + 3 * g1) - ld3(sm.gcen + 3 * g2);
     if (norm(v0) < 1e-9f) v0.x = 1e-5f;
     V3 dir = normalized(-v0);
@@ -1777,10 +1800,7 @@ struct Sim {
     bool valid, ell;
   };
   __device__ __forceinline__ float row_dot(const Row& rw, float x) const {  // sum_k J[k] * x_k  (x_k lives in lane k)
-    float sv = 0.f;
-#pragma unroll
-    for (int k = 0; k < NV16; k++) sv = fmaf(rw.J[k], bcast(x, k), sv);
-    return sv;
+    return dot_rows<NV16>(rw.J, x);
   }
   // gather the block's friction-scaled values: out[j] = (x * fr_own) of lane head + j
   __device__ __forceinline__ void gather(const Row& rw, float x, float (&out)[CD]) const {
@@ -1882,39 +1902,40 @@ struct Sim {
       rw.Dm = (1.0f / sm.e_R[rw.ell ? rw.head : r]) / fmaxf(rw.mu * rw.mu * (1 + rw.mu * rw.mu), 1e-15f);
     }
     // M: row i in lane i (matrix-vector products) and in the MFMA accumulator layout (Hessian seed)
+    const int rr = lane & 15;   // per-dof vectors (a, gradient, search direction) are replicated in all four 16-lane rows
+    const bool dofl = lane < NV16;  // ... and reduced over the first row only
     float Mr[NV16];
 #pragma unroll
-    for (int k = 0; k < NV16; k++) Mr[k] = (lane < nv && k < nv) ? sm.M[lane * NVP + k] : 0.f;
+    for (int k = 0; k < NV16; k++) Mr[k] = (rr < nv && k < nv) ? sm.M[rr * NVP + k] : 0.f;
     v4f Macc;
 #pragma unroll
     for (int v = 0; v < 4; v++) { int i = 4 * (lane >> 4) + v, j = lane & 15; Macc[v] = (i < nv && j < nv) ? sm.M[i * NVP + j] : (i == j ? 1.f : 0.f); }
-    const float a_sm = lane < nv ? sm.qacc_smooth[lane] : 0.f, a_ws = lane < nv ? sm.qacc_ws[lane] : 0.f, f_sm = lane < nv ? sm.qfrc_smooth[lane] : 0.f;
+    const float a_sm = rr < nv ? sm.qacc_smooth[rr] : 0.f, a_ws = rr < nv ? sm.qacc_ws[rr] : 0.f, f_sm = rr < nv ? sm.qfrc_smooth[rr] : 0.f;
     float force; int state; float uj[CD], T, g;
+    pf.mark(RP_X0);   // row / M loads
     // ---- warm start: previous acceleration unless the unconstrained one is cheaper
     float cost_sm = wave_sum(row_update(rw, row_dot(rw, a_sm) - rw.aref, force, state, uj, T, g));
     float cost_ws = wave_sum(row_update(rw, row_dot(rw, a_ws) - rw.aref, force, state, uj, T, g));
     {
-      float dws = a_ws - a_sm, sv = 0.f;
-#pragma unroll
-      for (int k = 0; k < NV16; k++) sv = fmaf(Mr[k], bcast(dws, k), sv);
-      cost_ws += wave_sum(0.5f * sv * dws);
+      const float dws = a_ws - a_sm, sv = dot_rows<NV16>(Mr, dws);
+      cost_ws += wave_sum(dofl ? 0.5f * sv * dws : 0.f);
     }
     float a = cost_ws < cost_sm ? a_ws : a_sm;
+    pf.mark(RP_X1);   // warm start
     int iter = 0;
     float jar = 0.f;
     for (;;) {
       jar = row_dot(rw, a) - rw.aref;
       float cost = wave_sum(row_update(rw, jar, force, state, uj, T, g));
-      float ma = 0.f;
-#pragma unroll
-      for (int k = 0; k < NV16; k++) ma = fmaf(Mr[k], bcast(a, k), ma);
-      const float gauss = wave_sum(0.5f * (ma - f_sm) * (a - a_sm));
+      const float ma = dot_rows<NV16>(Mr, a);
+      const float gauss = wave_sum(dofl ? 0.5f * (ma - f_sm) * (a - a_sm) : 0.f);
       cost += gauss;
       sm.e_force[lane] = force;
       SYNC();
       const float jf = jt_times_force(nch);
-      float gk = lane < nv ? ma - f_sm - jf : 0.f;
-      const float gn = wave_sum(gk * gk);
+      float gk = rr < nv ? ma - f_sm - jf : 0.f;
+      const float gn = wave_sum(dofl ? gk * gk : 0.f);
+      pf.mark(RP_X2);   // state, cost, gradient
       if (iter >= m.iterations || scale * sqrtf(gn) < tolerance) break;
       // ---- Hessian weights W (row r): D J_r (quadratic), 0 (linear / satisfied), cone block Hc J_block
       {
@@ -1949,6 +1970,7 @@ struct Sim {
 #pragma unroll
       for (int v = 0; v < 4; v++) sm.H[(4 * (lane >> 4) + v) * NVP + (lane & 15)] = acc[v];
       SYNC();
+      pf.mark(RP_X3);   // W rows + Hessian MFMAs
       float sk;
       {
         float hr[NV16], hinv[NV16], ht[NV16];
@@ -1964,15 +1986,14 @@ struct Sim {
         SYNC();
 #pragma unroll
         for (int k = 0; k < NV16; k++) ht[k] = sm.H[k * NVP + rr];
-        sk = rchol_solve<NV16>(hr, ht, hinv, lane < nv ? -gk : 0.f, lane);
-        if (lane >= nv) sk = 0.f;
+        sk = rchol_solve<NV16>(hr, ht, hinv, rr < nv ? -gk : 0.f, lane);
+        if (rr >= nv) sk = 0.f;
       }
+      pf.mark(RP_X4);   // Cholesky + solve
       // ---- line search along sk
       const float jv = row_dot(rw, sk);
-      float mvv = 0.f;
-#pragma unroll
-      for (int k = 0; k < NV16; k++) mvv = fmaf(Mr[k], bcast(sk, k), mvv);
-      const float q1 = wave_sum(sk * (ma - f_sm)), q2 = wave_sum(0.5f * sk * mvv), sn = sqrtf(wave_sum(sk * sk));
+      const float mvv = dot_rows<NV16>(Mr, sk);
+      const float q1 = wave_sum(dofl ? sk * (ma - f_sm) : 0.f), q2 = wave_sum(dofl ? 0.5f * sk * mvv : 0.f), sn = sqrtf(wave_sum(dofl ? sk * sk : 0.f));
       if (sn < 1e-15f) break;
       float g0[CD], gvv[CD];
       gather(rw, jar, g0);
@@ -1984,6 +2005,7 @@ struct Sim {
         row_ls(rw, jar, jv, g0, gvv, 0.f, c, c1, c2);
         p0 = gauss + wave_sum(c); d0 = q1 + wave_sum(c1); h0 = 2 * q2 + wave_sum(c2);
       }
+      pf.mark(RP_X5);   // line-search set-up + first evaluation
       if (d0 >= 0 || h0 <= 0) break;
       alpha = -d0 / h0;
       // fp32 line search: stop when the directional derivative has dropped below MuJoCo's gtol, by 1e6 relative to its
@@ -2009,6 +2031,7 @@ struct Sim {
         row_ls(rw, jar, jv, g0, gvv, alpha, c, c1, c2);
         p = gauss + alpha * q1 + alpha * alpha * q2 + wave_sum(c);
       }
+      pf.mark(RP_X6);   // line-search iterations
       if (!(p < p0)) break;
       a = fmaf(alpha, sk, a);
       iter++;
@@ -2018,6 +2041,7 @@ struct Sim {
         break;
       }
     }
+    pf.mark(RP_X7);   // loop exit
     sm.e_force[lane] = force;
     SYNC();
     const float fc = jt_times_force(nch);

@@ -20,5 +20,6 @@ for which, e in (("slowest", int(np.argmax(dur))), ("median", int(np.argsort(dur
     w2, p = run(e)
     print(f"{which} env {e}: {dur[e]:.0f} us in run 1; counts {w2[e, 4:8].tolist()}")
     nsub = max(1, p["n_sub"])
-    print("   cycles/substep:", {k: int(v / nsub) for k, v in p.items() if not k.startswith("n_")})
+    print("   cycles/substep:", {k: int(v / nsub) for k, v in p.items() if not k.startswith("n_") and not k.startswith("x")})
+    print("   sub-phase slots:", {k: int(v / nsub) for k, v in p.items() if k.startswith("x") and v})
     print("   counts/substep:", {k: round(v / nsub, 2) for k, v in p.items() if k.startswith("n_")})
