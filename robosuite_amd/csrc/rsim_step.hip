@@ -222,6 +222,7 @@ struct Smem {
   float M[NV * NVP];
   union { float L[NV * NVP]; float H[NV * NVP]; };  // L (factor of M) is dead once qacc_smooth exists; H is the solver / Euler work matrix
   float invdiag[NV];
+  float Le[NV * NVP], invdiag_e[NV];   // Cholesky factor of M + h*diag(damping) (implicit-damping Euler), computed alongside L
   float qfrc_bias[NV], qfrc_passive[NV], qfrc_actuator[NV], qfrc_smooth[NV], qacc_smooth[NV], qfrc_constraint[NV];
   // per-launch staged constants that are read by lanes other than their owner
   float arm[NV];                 // dof armature (1 on padding rows: keeps the padded matrices SPD)
@@ -859,14 +860,18 @@ struct Sim {
     }
     SYNC();
     {
-      float mr[NV16], minv[NV16];
+      // two independent factorisations in one instruction stream (M for the smooth acceleration, M + hD for the integrator):
+      // the dependent rsqrt/broadcast chains of one fill the latency bubbles of the other
+      float mr[NV16], minv[NV16], er[NV16], einv[NV16];
+      const float hd = r < nv ? opt_h * K.damping : 0.f;   // dof lanes: lane & 15 = dof (K is fetched per 16-lane row)
 #pragma unroll
-      for (int k = 0; k < NV16; k++) mr[k] = sm.M[r * NVP + k];
+      for (int k = 0; k < NV16; k++) { mr[k] = sm.M[r * NVP + k]; er[k] = mr[k] + (k == r ? hd : 0.f); }
       rchol_factor<NV16>(mr, minv);
+      rchol_factor<NV16>(er, einv);
       if (lane < NV16) {
 #pragma unroll
-        for (int k = 0; k < NV16; k++) sm.L[lane * NVP + k] = mr[k];
-        sm.invdiag[lane] = sel(minv, lane);
+        for (int k = 0; k < NV16; k++) { sm.L[lane * NVP + k] = mr[k]; sm.Le[lane * NVP + k] = er[k]; }
+        sm.invdiag[lane] = sel(minv, lane); sm.invdiag_e[lane] = sel(einv, lane);
       }
     }
     SYNC();
@@ -1578,20 +1583,11 @@ struct Sim {
     const float h = opt_h;
     float qa;
     {
-      float hr[NV16], hinv[NV16], ht[NV16];
+      float lr[NV16], lt[NV16], linv[NV16];
       const int rr = lane & (NV16 - 1);
-      const float hd = h * __shfl(K.damping, rr);
 #pragma unroll
-      for (int k = 0; k < NV16; k++) hr[k] = sm.M[rr * NVP + k] + (rr == k && rr < nv ? hd : 0.f);
-      rchol_factor<NV16>(hr, hinv);
-      if (lane < NV16) {
-#pragma unroll
-        for (int k = 0; k < NV16; k++) sm.H[lane * NVP + k] = hr[k];
-      }
-      SYNC();
-#pragma unroll
-      for (int k = 0; k < NV16; k++) ht[k] = sm.H[k * NVP + rr];
-      qa = rchol_solve<NV16>(hr, ht, hinv, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, lane);
+      for (int k = 0; k < NV16; k++) { lr[k] = sm.Le[rr * NVP + k]; lt[k] = sm.Le[k * NVP + rr]; linv[k] = sm.invdiag_e[k]; }
+      qa = rchol_solve<NV16>(lr, lt, linv, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, lane);
     }
     if (lane < nv) { sm.qvel[lane] += h * qa; sm.qacc_ws[lane] = sm.qacc[lane]; }
     SYNC();
@@ -1912,7 +1908,6 @@ struct Sim {
     for (int v = 0; v < 4; v++) { int i = 4 * (lane >> 4) + v, j = lane & 15; Macc[v] = (i < nv && j < nv) ? sm.M[i * NVP + j] : (i == j ? 1.f : 0.f); }
     const float a_sm = rr < nv ? sm.qacc_smooth[rr] : 0.f, a_ws = rr < nv ? sm.qacc_ws[rr] : 0.f, f_sm = rr < nv ? sm.qfrc_smooth[rr] : 0.f;
     float force; int state; float uj[CD], T, g;
-    pf.mark(RP_X0);   // row / M loads
     // ---- warm start: previous acceleration unless the unconstrained one is cheaper
     float cost_sm = wave_sum(row_update(rw, row_dot(rw, a_sm) - rw.aref, force, state, uj, T, g));
     float cost_ws = wave_sum(row_update(rw, row_dot(rw, a_ws) - rw.aref, force, state, uj, T, g));
@@ -1921,7 +1916,6 @@ struct Sim {
       cost_ws += wave_sum(dofl ? 0.5f * sv * dws : 0.f);
     }
     float a = cost_ws < cost_sm ? a_ws : a_sm;
-    pf.mark(RP_X1);   // warm start
     int iter = 0;
     float jar = 0.f;
     for (;;) {
@@ -1935,7 +1929,6 @@ struct Sim {
       const float jf = jt_times_force(nch);
       float gk = rr < nv ? ma - f_sm - jf : 0.f;
       const float gn = wave_sum(dofl ? gk * gk : 0.f);
-      pf.mark(RP_X2);   // state, cost, gradient
       if (iter >= m.iterations || scale * sqrtf(gn) < tolerance) break;
       // ---- Hessian weights W (row r): D J_r (quadratic), 0 (linear / satisfied), cone block Hc J_block
       {
@@ -1970,7 +1963,6 @@ struct Sim {
 #pragma unroll
       for (int v = 0; v < 4; v++) sm.H[(4 * (lane >> 4) + v) * NVP + (lane & 15)] = acc[v];
       SYNC();
-      pf.mark(RP_X3);   // W rows + Hessian MFMAs
       float sk;
       {
         float hr[NV16], hinv[NV16], ht[NV16];
@@ -1989,7 +1981,6 @@ struct Sim {
         sk = rchol_solve<NV16>(hr, ht, hinv, rr < nv ? -gk : 0.f, lane);
         if (rr >= nv) sk = 0.f;
       }
-      pf.mark(RP_X4);   // Cholesky + solve
       // ---- line search along sk
       const float jv = row_dot(rw, sk);
       const float mvv = dot_rows<NV16>(Mr, sk);
@@ -2005,7 +1996,6 @@ struct Sim {
         row_ls(rw, jar, jv, g0, gvv, 0.f, c, c1, c2);
         p0 = gauss + wave_sum(c); d0 = q1 + wave_sum(c1); h0 = 2 * q2 + wave_sum(c2);
       }
-      pf.mark(RP_X5);   // line-search set-up + first evaluation
       if (d0 >= 0 || h0 <= 0) break;
       alpha = -d0 / h0;
       // fp32 line search: stop when the directional derivative has dropped below MuJoCo's gtol, by 1e6 relative to its
@@ -2031,7 +2021,6 @@ struct Sim {
         row_ls(rw, jar, jv, g0, gvv, alpha, c, c1, c2);
         p = gauss + alpha * q1 + alpha * alpha * q2 + wave_sum(c);
       }
-      pf.mark(RP_X6);   // line-search iterations
       if (!(p < p0)) break;
       a = fmaf(alpha, sk, a);
       iter++;
@@ -2041,7 +2030,6 @@ struct Sim {
         break;
       }
     }
-    pf.mark(RP_X7);   // loop exit
     sm.e_force[lane] = force;
     SYNC();
     const float fc = jt_times_force(nch);
