@@ -97,7 +97,7 @@ def main():
     cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
     B = args.envs_per_gpu
     ids = shard.env_block(B * world, rank, world)
-    env = lift.LiftBatch(flat, cfg, ids, device=local_rank, seed0=0)
+    env = lift.LiftBatch(flat, cfg, ids, device=local_rank, seed0=0, horizon=500, bank_episodes=2)  # config 2: episodes auto-reset at horizon 500
     K, W = args.steps, args.warmup
     tape = torch.tensor(lift.env_actions(ids, K + W), device=dev)  # whole action tape resident in HBM
     stream = torch.cuda.ExternalStream(env.batch.stream(), device=dev)
@@ -131,6 +131,7 @@ def main():
     tot = st.allreduce()
 
     if rank == 0:
+        OBS_DIM_REPORT = env.model.nobs
         abytes = algorithmic_bytes_per_env_step(flat, env.model.action_dim) * B
         ach = abytes / (kern_ms * 1e-3) / 1e9
         traffic = None
@@ -145,7 +146,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Lift/Panda/OSC_POSE, 25 substeps x dt 0.002 + OSC_POSE/GRIP per substep, fused in one launch (BASELINE configs[1])",
-                       "envs_per_gpu": B, "global_envs": B * world, "n_sub": N_SUB, "per_env_seeded_reset": True, "sharding": f"env-block x{world}",
+                       "envs_per_gpu": B, "global_envs": B * world, "n_sub": N_SUB, "per_env_seeded_reset": True, "horizon": 500, "on_device_auto_reset": True, "obs_dim": OBS_DIM_REPORT, "sharding": f"env-block x{world}",
                        "diverged_envs": int(tot["diverged"]), "reward_sum": tot["reward_sum"], "successes": int(tot["successes"])},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes,

@@ -94,6 +94,9 @@ enum rsim_field {
   RSIM_OBS,            /* [B,nobs]     observation record of the last control step (float32) */
   RSIM_REWARD,         /* [B]          reward of the last control step                       */
   RSIM_SUCCESS,        /* [B] int32    _check_success() after the last control step          */
+  RSIM_DONE,           /* [B] int32    timestep >= horizon after the last control step (base.py:532-548) */
+  RSIM_EP_STEP,        /* [B] int32    MujocoEnv.timestep of the running episode            */
+  RSIM_EP_INDEX,       /* [B] int32    which entry of the reset bank the running episode came from */
   RSIM_FIELD_COUNT
 };
 
@@ -135,6 +138,20 @@ int rsim_control_step(rsim_batch* b, const float* actions_dev, int n_sub);
  * forward kinematics, initial_joint := q, goal := current eef pose, gripper action := 0 */
 int rsim_ctrl_reset(rsim_batch* b, const uint8_t* host_mask);
 int rsim_sync(rsim_batch* b);
+/* forward() + observation/reward epilogue without advancing time: the observation MujocoEnv.reset returns (base.py:298-347) */
+int rsim_observe(rsim_batch* b);
+
+/* Episode bookkeeping of MujocoEnv.step (base.py:508, 532-548): every rsim_control_step increments the per-env timestep and sets
+ * RSIM_DONE when it reaches `horizon` (0 = never).  With a reset bank installed, a finished env is re-initialised ON THE DEVICE at the
+ * end of that same launch: qpos := bank entry, qvel/ctrl/warm start/time := 0, the listed float-table entries (per-episode model edits
+ * such as the Lift cube size, lift.py:311-318) are patched, and the controller is re-created at the start of the next launch
+ * (robots/robot.py:271).  The bank holds `n_episodes` pre-drawn resets per env (drawn by the host in the reference's RNG order);
+ * entries are used cyclically.  bank: HOST float32 [B, n_episodes, nq + n_patch]; patch_idx: HOST int32 [n_patch] offsets into the
+ * env's float table (rsim_param_offset).  Requires per_env_params when n_patch > 0. */
+int rsim_set_episode(rsim_batch* b, int horizon);
+int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, const int32_t* patch_idx, const float* bank);
+/* offset of element `elem` of model float array `field` ("geom_size", "body_mass", ...) inside an env's float table, -1 if unknown */
+int rsim_param_offset(const rsim_batch* b, const char* field, int elem);
 
 /* Per-phase cycle accounting of the fused kernel (no reference counterpart: the reference has no profiling).
  * enable != 0 (re)arms and zeroes the accumulators, 0 disarms; if `out` is non-NULL the current accumulators are copied out first:

@@ -18,9 +18,10 @@ _LIB = None
 
 # enum rsim_field (include/rsim.h)
 FIELDS = ["qpos", "qvel", "qacc_warmstart", "ctrl", "time", "cstate", "xpos", "xquat", "qM", "qfrc_bias", "qfrc_passive", "qfrc_actuator",
-          "qfrc_constraint", "qacc", "cdof", "rootcom", "contact", "efc_force", "ncon", "nefc", "niter", "obs", "reward", "success"]
+          "qfrc_constraint", "qacc", "cdof", "rootcom", "contact", "efc_force", "ncon", "nefc", "niter", "obs", "reward", "success", "done", "ep_step",
+          "ep_index"]
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
-INT_FIELDS = {"ncon", "nefc", "niter", "success"}
+INT_FIELDS = {"ncon", "nefc", "niter", "success", "done", "ep_step", "ep_index"}
 CON_REC = 24
 CSTATE = 32
 OBS_MAX = 128
@@ -90,7 +91,10 @@ def lib():
         L.rsim_batch_size.argtypes = [vp]
         L.rsim_batch_limits.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.rsim_reset.argtypes = [vp, C.c_char_p]
-        for f in ("rsim_forward", "rsim_step1", "rsim_step2", "rsim_step", "rsim_sync"):
+        L.rsim_set_episode.argtypes = [vp, C.c_int]
+        L.rsim_set_reset_bank.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+        L.rsim_param_offset.argtypes = [vp, C.c_char_p, C.c_int]
+        for f in ("rsim_forward", "rsim_step1", "rsim_step2", "rsim_step", "rsim_sync", "rsim_observe"):
             getattr(L, f).argtypes = [vp]
         L.rsim_control_step.argtypes = [vp, vp, C.c_int]
         L.rsim_ctrl_reset.argtypes = [vp, C.c_char_p]
@@ -201,7 +205,7 @@ class HipBatch:
                        "xpos": (B, nb, 3), "xquat": (B, nb, 4), "qM": (B, nv, nv), "qfrc_bias": (B, nv), "qfrc_passive": (B, nv),
                        "qfrc_actuator": (B, nv), "qfrc_constraint": (B, nv), "qacc": (B, nv), "cdof": (B, nv, 6), "rootcom": (B, nb, 3),
                        "contact": (B, self.maxcon, CON_REC), "efc_force": (B, self.maxefc), "ncon": (B,), "nefc": (B,), "niter": (B,),
-                       "obs": (B, model.nobs), "reward": (B,), "success": (B,)}
+                       "obs": (B, model.nobs), "reward": (B,), "success": (B,), "done": (B,), "ep_step": (B,), "ep_index": (B,)}
 
     # ---- state access (host copies) --------------------------------------------------------
     def get(self, name):
@@ -242,6 +246,25 @@ class HipBatch:
 
     def sync(self):
         _chk(self._L.rsim_sync(self.ptr))
+
+    def observe(self):
+        """forward() + observation / reward epilogue without advancing time (the observation `env.reset()` returns)."""
+        _chk(self._L.rsim_observe(self.ptr))
+
+    def set_episode(self, horizon: int):
+        _chk(self._L.rsim_set_episode(self.ptr, int(horizon)))
+
+    def param_offset(self, field: str, elem: int) -> int:
+        return self._L.rsim_param_offset(self.ptr, field.encode(), int(elem))
+
+    def set_reset_bank(self, qpos, patch_idx=(), patch_val=None):
+        """qpos: [B, E, nq]; patch_idx: float-table offsets (param_offset); patch_val: [B, E, len(patch_idx)]."""
+        q = np.asarray(qpos, dtype=np.float32)
+        B, E, nq = q.shape
+        idx = np.ascontiguousarray(patch_idx, dtype=np.int32)
+        bank = q if len(idx) == 0 else np.concatenate([q, np.asarray(patch_val, dtype=np.float32).reshape(B, E, len(idx))], axis=2)
+        bank = np.ascontiguousarray(bank, dtype=np.float32)
+        _chk(self._L.rsim_set_reset_bank(self.ptr, E, len(idx), idx.ctypes.data if len(idx) else None, bank.ctypes.data))
 
     def ctrl_reset(self, mask=None):
         _chk(self._L.rsim_ctrl_reset(self.ptr, None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).tobytes()))

@@ -19,6 +19,8 @@ extern "C" int rsim_launch_ctrl_reset_cfg0(const DModel* m, const DBatch* b, con
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream);
 extern "C" int rsim_cfg0_limits(int* lim);
 
+struct rsim_model;
+static int param_offset_impl(const rsim_model* m, const char* field, int elem);
 static thread_local char g_err[512] = "";
 static int fail(const char* fmt, ...) {
   va_list ap;
@@ -69,6 +71,8 @@ struct rsim_batch {
   int* d_it;
   int* d_lt;
   int* d_obsprog;
+  float* d_bank;
+  int* d_patch;
   float* d_ft;
   float* d_mesh;
   unsigned char* d_mask;
@@ -480,6 +484,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   b->m = m; b->B = B; b->device = device; b->per_env = per_env ? 1 : 0;
   b->gen = 1; b->cache_gen = 0; b->cache_env = -1;
   b->db.prof_env = -1;
+  b->d_bank = nullptr; b->d_patch = nullptr;
   rsim_cfg0_limits(b->lim);
   const int ncg = (int)m->cg.size();
   if (m->nbody > b->lim[0] || m->njnt > b->lim[1] || m->nv > b->lim[2] || m->nq > b->lim[2] + 8 || m->nu > b->lim[2] || ncg > b->lim[3] || m->nsite > b->lim[4] ||
@@ -500,6 +505,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   if (dalloc(&b->d_mesh, m->mesh_vert.size())) return 1;
   HIPCHK(hipMemcpy(b->d_mesh, m->mesh_vert.data(), m->mesh_vert.size() * sizeof(float), hipMemcpyHostToDevice));
   if (dalloc(&b->d_mask, (size_t)B)) return 1;
+  if (dalloc(&b->db.needs_reset, (size_t)B)) return 1;
+  b->db.ft_rw = b->d_ft;
   DModel& dm = b->dm;
   dm.nq = m->nq; dm.nv = m->nv; dm.nu = m->nu; dm.nbody = m->nbody; dm.njnt = m->njnt; dm.ncg = ncg; dm.nsite = m->nsite; dm.npair = m->npair;
   dm.maxdepth = m->maxdepth; dm.nroot = m->nroot;
@@ -542,7 +549,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
       {RSIM_CONTACT, (void**)&db.contact, (size_t)B * NCON * RSIM_CON_REC, 0}, {RSIM_EFC_FORCE, (void**)&db.efc_force, (size_t)B * NEFC, 0},
       {RSIM_NCON, (void**)&db.ncon, (size_t)B, 1}, {RSIM_NEFC, (void**)&db.nefc, (size_t)B, 1}, {RSIM_NITER, (void**)&db.niter, (size_t)B, 1},
       {RSIM_OBS, (void**)&db.obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0}, {RSIM_REWARD, (void**)&db.reward, (size_t)B, 0},
-      {RSIM_SUCCESS, (void**)&db.success, (size_t)B, 1}};
+      {RSIM_SUCCESS, (void**)&db.success, (size_t)B, 1}, {RSIM_DONE, (void**)&db.done, (size_t)B, 1}, {RSIM_EP_STEP, (void**)&db.ep_step, (size_t)B, 1},
+      {RSIM_EP_INDEX, (void**)&db.ep_index, (size_t)B, 1}};
   for (auto& fd : fields) {
     if (dalloc((float**)fd.p, fd.n)) return 1;
     b->fptr[fd.id] = *fd.p; b->fcount[fd.id] = fd.n; b->fis_int[fd.id] = fd.is_int;
@@ -556,7 +564,8 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   hipSetDevice(b->device);
   hipStreamSynchronize(b->stream);
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
-  hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); if (b->d_obsprog) hipFree(b->d_obsprog); hipFree(b->d_mesh); hipFree(b->d_mask);
+  hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); if (b->d_obsprog) hipFree(b->d_obsprog);
+  if (b->d_bank) hipFree(b->d_bank); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); hipFree(b->d_mesh); hipFree(b->d_mask);
   if (b->db.prof) hipFree(b->db.prof);
   hipStreamDestroy(b->stream);
   delete b;
@@ -583,6 +592,8 @@ extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) {
     HIPCHK(hipMemset(b->db.ctrl, 0, (size_t)B * nu * sizeof(float)));
     HIPCHK(hipMemset(b->db.time, 0, (size_t)B * sizeof(float)));
     HIPCHK(hipMemset(b->db.cstate, 0, (size_t)B * RSIM_CS_SIZE * sizeof(float)));
+    HIPCHK(hipMemset(b->db.ep_step, 0, (size_t)B * sizeof(int))); HIPCHK(hipMemset(b->db.ep_index, 0, (size_t)B * sizeof(int)));
+    HIPCHK(hipMemset(b->db.done, 0, (size_t)B * sizeof(int))); HIPCHK(hipMemset(b->db.needs_reset, 0, (size_t)B * sizeof(int)));
   } else {
     for (int e = 0; e < B; e++) {
       if (!mask[e]) continue;
@@ -592,6 +603,7 @@ extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) {
       HIPCHK(hipMemset(b->db.ctrl + (size_t)e * nu, 0, nu * sizeof(float)));
       HIPCHK(hipMemset(b->db.time + e, 0, sizeof(float)));
       HIPCHK(hipMemset(b->db.cstate + (size_t)e * RSIM_CS_SIZE, 0, RSIM_CS_SIZE * sizeof(float)));
+      HIPCHK(hipMemset(b->db.ep_step + e, 0, sizeof(int))); HIPCHK(hipMemset(b->db.done + e, 0, sizeof(int))); HIPCHK(hipMemset(b->db.needs_reset + e, 0, sizeof(int)));
     }
   }
   b->gen++;
@@ -615,8 +627,38 @@ extern "C" int rsim_step(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL
 extern "C" int rsim_control_step(rsim_batch* b, const float* actions_dev, int n_sub) {
   if (n_sub < 1) return fail("rsim_control_step: n_sub < 1");
   if (!actions_dev) return fail("rsim_control_step: actions_dev is NULL");
-  return launch(b, actions_dev, n_sub, RF_POSVEL | RF_CTRL | RF_SETGOAL | RF_ACTSOLVE | RF_INTEGRATE | (b->m->has_task ? RF_OBS : 0));
+  return launch(b, actions_dev, n_sub, RF_POSVEL | RF_CTRL | RF_SETGOAL | RF_ACTSOLVE | RF_INTEGRATE | (b->m->has_task ? RF_OBS : 0) | RF_EPISODE);
 }
+extern "C" int rsim_observe(rsim_batch* b) {
+  if (!b->m->has_task) return fail("rsim_observe: no task configured");
+  return launch(b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_OBS | RF_DEBUG);
+}
+extern "C" int rsim_set_episode(rsim_batch* b, int horizon) {
+  if (horizon < 0) return fail("rsim_set_episode: horizon < 0");
+  b->db.horizon = horizon;
+  return 0;
+}
+extern "C" int rsim_param_offset(const rsim_batch* b, const char* field, int elem) {
+  return param_offset_impl(b->m, field, elem);
+}
+extern "C" int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, const int32_t* patch_idx, const float* bank) {
+  rsim_model* m = b->m;
+  if (n_episodes < 1 || n_patch < 0) return fail("rsim_set_reset_bank: bad sizes");
+  if (n_patch > 0 && !b->per_env) return fail("rsim_set_reset_bank: per-episode model patches need per_env_params");
+  for (int p2 = 0; p2 < n_patch; p2++) if (patch_idx[p2] < 0 || patch_idx[p2] >= (int)m->ftab.size()) return fail("rsim_set_reset_bank: patch offset out of range");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (b->d_bank) { hipFree(b->d_bank); b->d_bank = nullptr; }
+  if (b->d_patch) { hipFree(b->d_patch); b->d_patch = nullptr; }
+  const size_t stride = (size_t)m->nq + n_patch, total = (size_t)b->B * n_episodes * stride;
+  if (dalloc(&b->d_bank, total)) return 1;
+  HIPCHK(hipMemcpy(b->d_bank, bank, total * sizeof(float), hipMemcpyHostToDevice));
+  if (dalloc(&b->d_patch, (size_t)(n_patch ? n_patch : 1))) return 1;
+  if (n_patch) HIPCHK(hipMemcpy(b->d_patch, patch_idx, n_patch * sizeof(int), hipMemcpyHostToDevice));
+  b->db.bank = b->d_bank; b->db.patch_idx = b->d_patch; b->db.bank_E = n_episodes; b->db.bank_P = n_patch;
+  return 0;
+}
+
 extern "C" int rsim_ctrl_reset(rsim_batch* b, const uint8_t* mask) {
   HIPCHK(hipSetDevice(b->device));
   if (!b->m->ctrl.enabled) return fail("no controller configured");
@@ -738,10 +780,25 @@ extern "C" int rsim_jac_body(rsim_batch* b, int env, int body, double* jacp, dou
   return jac_common(b, env, body, z, jacp, jacr);
 }
 
-extern "C" int rsim_model_param_set(rsim_batch* b, const char* field, int env0, int nenv, const double* values, size_t cpe) {
-  rsim_model* m = b->m;
-  struct Map { const char* name; int fo; int w; int geom; };
-  static const Map maps[] = {
+struct ParamMap { const char* name; int fo; int w; int geom; };
+static const ParamMap* param_maps(int* n);
+static int param_offset_impl(const rsim_model* m, const char* field, int elem) {
+  int n = 0;
+  const ParamMap* maps = param_maps(&n);
+  for (int i = 0; i < n; i++)
+    if (!strcmp(maps[i].name, field)) {
+      if (maps[i].geom) {  // elem indexes the full geom array: (geom id, component)
+        int g = elem / maps[i].w, q = elem % maps[i].w;
+        if (g < 0 || g >= m->ngeom || m->geom2cg[g] < 0) return -1;
+        return m->fo[maps[i].fo] + m->geom2cg[g] * maps[i].w + q;
+      }
+      if (elem < 0 || elem >= m->fcount[maps[i].fo]) return -1;
+      return m->fo[maps[i].fo] + elem;
+    }
+  return -1;
+}
+static const ParamMap* param_maps(int* n) {
+  static const ParamMap maps[] = {
       {"body_pos", FO_body_pos, 3, 0}, {"body_quat", FO_body_quat, 4, 0}, {"body_ipos", FO_body_ipos, 3, 0}, {"body_iquat", FO_body_iquat, 4, 0},
       {"body_mass", FO_body_mass, 1, 0}, {"body_inertia", FO_body_inertia, 3, 0}, {"body_invweight0", FO_body_invweight0, 2, 0},
       {"body_subtreemass", FO_body_subtreemass, 1, 0}, {"jnt_pos", FO_jnt_pos, 3, 0}, {"jnt_axis", FO_jnt_axis, 3, 0}, {"jnt_range", FO_jnt_range, 2, 0},
@@ -753,8 +810,16 @@ extern "C" int rsim_model_param_set(rsim_batch* b, const char* field, int env0, 
       {"geom_gap", FO_cg_gap, 1, 1}, {"geom_rbound", FO_cg_rbound, 1, 1}, {"site_pos", FO_site_pos, 3, 0}, {"site_quat", FO_site_quat, 4, 0},
       {"actuator_gear", FO_act_gear, 1, 0}, {"actuator_gainprm", FO_act_gainprm, 3, 0}, {"actuator_biasprm", FO_act_biasprm, 3, 0},
       {"actuator_ctrlrange", FO_act_ctrlrange, 2, 0}, {"actuator_forcerange", FO_act_forcerange, 2, 0}, {"opt", FO_opt, 1, 0}};
-  const Map* mp = nullptr;
-  for (auto& x : maps) if (!strcmp(x.name, field)) mp = &x;
+  *n = (int)(sizeof(maps) / sizeof(maps[0]));
+  return maps;
+}
+
+extern "C" int rsim_model_param_set(rsim_batch* b, const char* field, int env0, int nenv, const double* values, size_t cpe) {
+  rsim_model* m = b->m;
+  int nmaps = 0;
+  const ParamMap* maps = param_maps(&nmaps);
+  const ParamMap* mp = nullptr;
+  for (int i = 0; i < nmaps; i++) if (!strcmp(maps[i].name, field)) mp = &maps[i];
   if (!mp) return fail("rsim_model_param_set: unknown or read-only field '%s'", field);
   if (env0 < 0 || nenv < 1 || env0 + nenv > b->B) return fail("rsim_model_param_set: env range out of bounds");
   if (!b->per_env && !(env0 == 0 && nenv == b->B)) return fail("rsim_model_param_set: batch was created without per-env params");

@@ -109,6 +109,12 @@ struct DBatch {
   int *ncon, *nefc, *niter, *diverged;
   float *obs, *reward;   // [B, nobs], [B]
   int* success;          // [B]
+  // episode bookkeeping / on-device reset
+  int *done, *ep_step, *ep_index, *needs_reset;   // [B]
+  int horizon, bank_E, bank_P;
+  const float* bank;     // [B][bank_E][nq + bank_P]
+  const int* patch_idx;  // [bank_P] offsets into the env's float table
+  float* ft_rw;          // writable alias of the float tables (per-env patches)
   unsigned long long* prof;  // optional [RP_COUNT] phase-cycle / event accumulators (null = off)
   int prof_env;              // >= 0: only this env adds to the phase accumulators
 };
@@ -127,4 +133,5 @@ enum {
   RF_INTEGRATE = 16, // Euler integration, advance time, warm start
   RF_DEBUG = 32,     // write compat/debug arrays
   RF_OBS = 64,       // observation / reward epilogue after the last substep
+  RF_EPISODE = 128,  // episode step counter, done flag, on-device reset from the bank
 };

@@ -2134,6 +2134,16 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   sim.load_constants();
   const float* act = actions ? actions + (size_t)env * m.ctrl.action_dim : nullptr;
   float time = b.time[env];
+  if ((flags & RF_CTRL) && b.needs_reset[env]) {
+    // this env was re-initialised on the device when its previous episode ended: fresh controller objects (robots/robot.py:271)
+    V3 xp0; Q4 xq0;
+    if (lane < RSIM_CS_SIZE) sm.cstate[lane] = 0.f;
+    SYNC();
+    sim.kinematics(xp0, xq0);
+    sim.geom_site_frames();
+    sim.ctrl_reset();
+    if (lane == 0) b.needs_reset[env] = 0;
+  }
   sim.pf.mark(RP_LOAD);
   for (int sub = 0; sub < n_sub; sub++) {
     V3 xp; Q4 xq;
@@ -2171,6 +2181,24 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
     sim.pf.count(RP_N_SUB, 1);
   }
   if ((flags & RF_OBS) && m.task.enabled) sim.obs_reward(b.obs + (size_t)env * m.task.nobs, b.reward + env, b.success + env);
+  if (flags & RF_EPISODE) {
+    // MujocoEnv.step: timestep += 1; done = timestep >= horizon (base.py:508, 532-548); optional on-device reset from the bank
+    int st = b.ep_step[env] + 1;
+    const bool done = b.horizon > 0 && st >= b.horizon;
+    if (done && b.bank) {
+      const int ep = (b.ep_index[env] + 1) % b.bank_E;
+      const float* src = b.bank + ((size_t)env * b.bank_E + ep) * (m.nq + b.bank_P);
+      SYNC();
+      for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = src[i];
+      if (lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.ctrl[lane] = 0.f; }
+      for (int p2 = lane; p2 < b.bank_P; p2 += 64) b.ft_rw[(size_t)env * m.fstride + b.patch_idx[p2]] = src[m.nq + p2];
+      time = 0.f;
+      st = 0;
+      if (lane == 0) { b.ep_index[env] = ep; b.needs_reset[env] = 1; }
+      SYNC();
+    }
+    if (lane == 0) { b.done[env] = done ? 1 : 0; b.ep_step[env] = st; }
+  }
   // ---- store state
   for (int i = lane; i < m.nq; i += 64) b.qpos[(size_t)env * m.nq + i] = sm.qpos[i];
   for (int i = lane; i < m.nv; i += 64) { b.qvel[(size_t)env * m.nv + i] = sm.qvel[i]; b.qacc_ws[(size_t)env * m.nv + i] = sm.qacc_ws[i]; }

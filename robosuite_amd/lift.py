@@ -144,7 +144,7 @@ class LiftBatch:
 
     `env_ids` are GLOBAL env indices (results do not depend on how envs are sharded over GPUs)."""
 
-    def __init__(self, flat, cfg, env_ids, device: int = 0, seed0: int = 0, per_env_cube: bool = True):
+    def __init__(self, flat, cfg, env_ids, device: int = 0, seed0: int = 0, per_env_cube: bool = True, horizon: int = 0, bank_episodes: int = 0):
         from .backend import HipBatch, HipModel
 
         self.flat, self.cfg = flat, cfg
@@ -157,6 +157,35 @@ class LiftBatch:
         self.per_env_cube = per_env_cube
         self.seed0 = seed0
         self.reset()
+        if horizon:
+            self.batch.set_episode(horizon)
+        if bank_episodes:
+            self.install_reset_bank(bank_episodes)
+
+    def install_reset_bank(self, n_episodes: int):
+        """Pre-draw `n_episodes` hard resets per env (blocks 0..n-1 of each env's generator, the reference's draw order) and hand them to
+        the device: when an env reaches the horizon the kernel re-initialises it in place (MujocoEnv.reset with hard_reset, base.py:277-347)
+        without a host round trip.  Entry 0 is the episode the batch was constructed with."""
+        b = self.batch
+        fields = cube_model_rows(self.flat, self.sizes[:1])  # which float-table slots depend on the cube size
+        base = {k: np.asarray(self.flat.arrays[k], dtype=np.float64).ravel() for k in fields}
+        slots = []  # (field, element) pairs whose value changes with the cube
+        probe = cube_model_rows(self.flat, np.array([[0.0201, 0.0213, 0.0207]]))
+        for k, rows in probe.items():
+            for e in np.nonzero(np.abs(rows[0] - base[k]) > 0)[0]:
+                off = b.param_offset(k, int(e))
+                if off >= 0:
+                    slots.append((k, int(e), off))
+        qbank = np.zeros((self.B, n_episodes, self.flat.nq), dtype=np.float32)
+        pbank = np.zeros((self.B, n_episodes, len(slots)), dtype=np.float32)
+        for ep in range(n_episodes):
+            sizes, qpos = episode_setup(self.seed0, self.env_ids, ep)
+            rows = cube_model_rows(self.flat, sizes)
+            qbank[:, ep] = qpos
+            for j, (k, e, _) in enumerate(slots):
+                pbank[:, ep, j] = rows[k][:, e]
+        b.set_reset_bank(qbank, [o for _, _, o in slots], pbank)
+        self.bank_episodes = n_episodes
 
     def reset(self, block: int = 0):
         sizes, qpos = episode_setup(self.seed0, self.env_ids, block)
@@ -185,3 +214,55 @@ class LiftBatch:
 
     def success(self):
         return self.batch.tensor("success")
+
+
+class LiftVecEnv:
+    """Vectorised `suite.make("Lift", robots="Panda", ...)`: the batched counterpart of the reference's Gym-style loop
+    (`obs = env.reset(); obs, reward, done, info = env.step(action)`, environments/base.py:277-347, 467-521; key selection / flattening
+    as wrappers/gym_wrapper.py:45-163 with the default keys object-state + robot0_proprio-state).  All returned tensors alias device
+    memory owned by the backend; envs that reach `horizon` restart on the device (ignore_done=False semantics: `done` is reported once).
+    """
+
+    def __init__(self, n_envs: int, device: int = 0, seed: int = 0, horizon: int = 500, env_ids=None, bank_episodes: int = 4, flat=None, cfg=None):
+        import json
+        import os
+
+        from . import mjcf
+
+        if flat is None:
+            adir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+            flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim"))
+            cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
+        ids = np.arange(n_envs) if env_ids is None else np.asarray(env_ids)
+        self.env = LiftBatch(flat, cfg, ids, device=device, seed0=seed, horizon=horizon, bank_episodes=bank_episodes)
+        self.n_envs, self.horizon = len(ids), horizon
+        self.action_dim = self.env.model.action_dim
+        self.obs_dim = self.env.model.nobs
+        keys, dims = cfg["obs_keys"], cfg["obs_dims"]
+        off = np.cumsum([0] + list(dims))
+        self.obs_slices = {k: slice(int(off[i]), int(off[i + 1])) for i, k in enumerate(keys)}
+        # GymWrapper default flattening: ["object-state", "robot0_proprio-state"] (gym_wrapper.py:56-64)
+        self._object_keys = [k for k in keys if not k.startswith("robot0_")]
+        self._proprio_keys = [k for k in keys if k.startswith("robot0_")]
+
+    @property
+    def action_spec(self):
+        return -np.ones(self.action_dim), np.ones(self.action_dim)
+
+    def reset(self):
+        """Hard reset of every env to its first pre-drawn episode; returns the observation record [n_envs, obs_dim]."""
+        self.env.reset(block=0)
+        self.env.batch.set("ep_step", 0); self.env.batch.set("ep_index", 0); self.env.batch.set("done", 0)
+        self.env.batch.observe()
+        return self.env.obs()
+
+    def step(self, actions):
+        """actions: CUDA float32 [n_envs, action_dim] in [-1, 1].  Returns (obs, reward, done, info) as device tensors."""
+        self.env.step(actions)
+        return self.env.obs(), self.env.reward(), self.env.batch.tensor("done"), {"success": self.env.success()}
+
+    def flat_obs(self, obs):
+        """GymWrapper layout: object-state keys first, then the robot proprio keys."""
+        import torch
+
+        return torch.cat([obs[:, self.obs_slices[k]] for k in self._object_keys + self._proprio_keys], dim=1)

@@ -205,3 +205,47 @@ def test_mujoco_shaped_shim_on_the_hip_backend_matches_the_oracle_backend():
         assert np.abs(h["site"] - o["site"]).max() < 5e-6 and np.abs(h["smat"] - o["smat"]).max() < 5e-6
         assert np.abs(h["qpos"] - o["qpos"]).max() < 2e-5 and np.abs(h["qvel"] - o["qvel"]).max() < 2e-3
         assert abs(h["t"] - o["t"]) < 1e-5 and h["ncon"] == o["ncon"]
+
+
+def test_on_device_episode_reset_equals_a_fresh_host_reset():
+    """horizon reached -> done flag, and the env restarts ON THE DEVICE from the next pre-drawn reset (cube size included);
+    afterwards it must evolve bit-for-bit like a batch constructed by the host with that reset block."""
+    g, cfg, flat = load_golden("seed1_full")
+    ids = np.array([3, 11, 200])
+    H = 4
+    auto = lift.LiftBatch(flat, cfg, ids, seed0=0, horizon=H, bank_episodes=3)
+    acts = lift.env_actions(ids, 12)
+    done_log = []
+    for t in range(H):
+        auto.step(torch.tensor(acts[t], device="cuda"))
+        done_log.append(auto.batch.get("done").copy())
+    assert all(d.sum() == 0 for d in done_log[:-1]) and done_log[-1].tolist() == [1, 1, 1]
+    assert auto.batch.get("ep_step").tolist() == [0, 0, 0] and auto.batch.get("ep_index").tolist() == [1, 1, 1]
+    fresh = lift.LiftBatch(flat, cfg, ids, seed0=0)
+    fresh.reset(block=1)
+    assert np.array_equal(auto.batch.get("qpos"), fresh.batch.get("qpos"))
+    for t in range(H, H + 3):
+        a = torch.tensor(acts[t], device="cuda")
+        auto.step(a); fresh.step(a)
+        assert np.array_equal(auto.batch.get("qpos"), fresh.batch.get("qpos")) and np.array_equal(auto.batch.get("qvel"), fresh.batch.get("qvel")), t
+        assert np.array_equal(auto.batch.get("obs"), fresh.batch.get("obs"))
+    # the initial observation of an episode without stepping (what env.reset() returns)
+    fresh2 = lift.LiftBatch(flat, cfg, ids, seed0=0)
+    fresh2.batch.observe()
+    o = fresh2.batch.get("obs")
+    assert np.isfinite(o).all() and np.abs(o[:, :7] - fresh2.qpos0[:, :7]).max() < 1e-6
+
+
+def test_vectorised_env_facade():
+    env = lift.LiftVecEnv(6, seed=0, horizon=3, bank_episodes=2)
+    obs = env.reset()
+    assert tuple(obs.shape) == (6, 60) and env.action_dim == 7
+    lo, hi = env.action_spec
+    a = torch.zeros(6, 7, device="cuda")
+    dones = []
+    for t in range(3):
+        obs, rew, done, info = env.step(a)
+        dones.append(done.clone())
+    assert dones[0].sum().item() == 0 and dones[2].sum().item() == 6
+    assert tuple(env.flat_obs(obs).shape) == (6, 60) and torch.isfinite(rew).all()
+    assert tuple(info["success"].shape) == (6,)
