@@ -180,6 +180,26 @@ int rsim_jac_body(rsim_batch* b, int env, int body, double* jacp, double* jacr);
  * [nenv, count_per_env] in the blob's layout.  Requires per_env_params unless nenv == B with identical rows. */
 int rsim_model_param_set(rsim_batch* b, const char* field, int env0, int nenv, const double* values, size_t count_per_env);
 
+/* read back the live value of a float model array (same field names / layout as rsim_model_param_set): HOST float64 [nenv, count_per_env] */
+int rsim_model_param_get(rsim_batch* b, const char* field, int env0, int nenv, double* values, size_t count_per_env);
+
+/* Dynamics domain randomisation on the device = DomainRandomizationWrapper(randomize_dynamics) + DynamicsModder.randomize
+ * (wrappers/domain_randomization_wrapper.py:47-81,227-259; utils/mjmod.py:1540-1729).  Every call re-draws all enabled parameters of every
+ * env RELATIVE TO THE SAVED DEFAULTS (never cumulatively): val = default * (1 + p u) for "ratio" entries, default + p u for "size" entries,
+ * u ~ U(-1, 1), then the reference's clips (>= 0; solref in [0, 1]); body quaternions are re-normalised (mjmod.py:1811-1826).
+ * Defaults are the float tables at the time of rsim_dr_save_defaults (the wrapper calls save_defaults() after every reset); the on-device
+ * episode reset patches defaults and live tables alike.  Draws come from a counter-based generator keyed by (seed, step, env, parameter):
+ * the reference uses the unseeded global numpy generator here (mjmod.py:1721), so only the distribution can be matched, not a stream.
+ * Requires per_env_params.  A magnitude of 0 disables that parameter. */
+typedef struct rsim_dr_desc {
+  float density_ratio, viscosity_ratio;                                   /* 0.1, 0.1 */
+  float position_size, quaternion_size, inertia_ratio, mass_ratio;        /* 0.0015, 0.003, 0.02, 0.02 */
+  float friction_ratio, solref_ratio, solimp_ratio;                       /* 0.1, 0.1, 0.1 */
+  float frictionloss_size, damping_size, armature_size;                   /* 0.05, 0.01, 0.01 */
+} rsim_dr_desc;
+int rsim_dr_save_defaults(rsim_batch* b);
+int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uint64_t seed, uint64_t step);
+
 /* Standalone OSC torque law on explicit inputs (unit-test entry for OperationalSpaceController.run_controller,
  * osc.py:403-495).  in: HOST float32 [B,192] packed as ep3 eR9 ev6 op3 oR9 bv6 goal_pos3 goal_ori9 J[6x8] M[8x8] bias8 q8 qd8 q0_8;
  * out: HOST float32 [B,8] pre-clip torques. */

@@ -45,6 +45,16 @@ class TaskDesc(C.Structure):
                 ("left_pad_geoms", C.c_uint64), ("right_pad_geoms", C.c_uint64), ("object_geoms", C.c_uint64)]
 
 
+class DrDesc(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("density_ratio", "viscosity_ratio", "position_size", "quaternion_size", "inertia_ratio", "mass_ratio",
+                                         "friction_ratio", "solref_ratio", "solimp_ratio", "frictionloss_size", "damping_size", "armature_size")]
+
+
+# DEFAULT_DYNAMICS_ARGS of the reference (wrappers/domain_randomization_wrapper.py:47-81)
+DEFAULT_DYNAMICS_ARGS = dict(density_ratio=0.1, viscosity_ratio=0.1, position_size=0.0015, quaternion_size=0.003, inertia_ratio=0.02, mass_ratio=0.02,
+                             friction_ratio=0.1, solref_ratio=0.1, solimp_ratio=0.1, frictionloss_size=0.05, damping_size=0.01, armature_size=0.01)
+
+
 def ctrl_desc(cfg: dict) -> CtrlDesc:
     """Build the C struct from the dict form used by tests/golden/*.cfg.json and robosuite_amd.env."""
     d = CtrlDesc()
@@ -91,6 +101,8 @@ def lib():
         L.rsim_batch_size.argtypes = [vp]
         L.rsim_batch_limits.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.rsim_reset.argtypes = [vp, C.c_char_p]
+        L.rsim_dr_save_defaults.argtypes = [vp]
+        L.rsim_randomize_dynamics.argtypes = [vp, C.POINTER(DrDesc), C.c_uint64, C.c_uint64]
         L.rsim_set_episode.argtypes = [vp, C.c_int]
         L.rsim_set_reset_bank.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.rsim_param_offset.argtypes = [vp, C.c_char_p, C.c_int]
@@ -107,6 +119,7 @@ def lib():
         L.rsim_jac_site.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.rsim_jac_body.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.rsim_model_param_set.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_size_t]
+        L.rsim_model_param_get.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_size_t]
         L.rsim_profile.argtypes = [vp, C.c_int, vp, C.c_int]
         L.rsim_wavelog.argtypes = [vp, vp]
         L.rsim_profile_env.argtypes = [vp, C.c_int]
@@ -250,6 +263,22 @@ class HipBatch:
     def observe(self):
         """forward() + observation / reward epilogue without advancing time (the observation `env.reset()` returns)."""
         _chk(self._L.rsim_observe(self.ptr))
+
+    def dr_save_defaults(self):
+        _chk(self._L.rsim_dr_save_defaults(self.ptr))
+
+    def randomize_dynamics(self, seed: int, step: int, **args):
+        """Re-draw the dynamics parameters of every env around the saved defaults (reference DynamicsModder.randomize)."""
+        d = DrDesc(**{**DEFAULT_DYNAMICS_ARGS, **args})
+        _chk(self._L.rsim_randomize_dynamics(self.ptr, C.byref(d), int(seed), int(step)))
+
+    def param_get(self, field, env0=0, nenv=None):
+        """Live values of a float model array for envs [env0, env0+nenv): float64 [nenv, ...] in the compiled model's layout."""
+        nenv = self.B - env0 if nenv is None else nenv
+        shape = np.asarray(self.model.flat.arrays[field]).shape if field != "opt" else (10,)
+        out = np.zeros((nenv, int(np.prod(shape))), dtype=np.float64)
+        _chk(self._L.rsim_model_param_get(self.ptr, field.encode(), int(env0), int(nenv), out.ctypes.data, out.shape[1]))
+        return out.reshape((nenv,) + tuple(shape))
 
     def set_episode(self, horizon: int):
         _chk(self._L.rsim_set_episode(self.ptr, int(horizon)))

@@ -18,6 +18,7 @@ extern "C" int rsim_launch_step_cfg0(const DModel* m, const DBatch* b, const flo
 extern "C" int rsim_launch_ctrl_reset_cfg0(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream);
 extern "C" int rsim_cfg0_limits(int* lim);
+extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr* d, unsigned long long seed, unsigned long long step, hipStream_t stream);
 
 struct rsim_model;
 static int param_offset_impl(const rsim_model* m, const char* field, int elem);
@@ -73,6 +74,7 @@ struct rsim_batch {
   int* d_obsprog;
   float* d_bank;
   int* d_patch;
+  float* d_ft_base;
   float* d_ft;
   float* d_mesh;
   unsigned char* d_mask;
@@ -484,7 +486,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   b->m = m; b->B = B; b->device = device; b->per_env = per_env ? 1 : 0;
   b->gen = 1; b->cache_gen = 0; b->cache_env = -1;
   b->db.prof_env = -1;
-  b->d_bank = nullptr; b->d_patch = nullptr;
+  b->d_bank = nullptr; b->d_patch = nullptr; b->d_ft_base = nullptr;
   rsim_cfg0_limits(b->lim);
   const int ncg = (int)m->cg.size();
   if (m->nbody > b->lim[0] || m->njnt > b->lim[1] || m->nv > b->lim[2] || m->nq > b->lim[2] + 8 || m->nu > b->lim[2] || ncg > b->lim[3] || m->nsite > b->lim[4] ||
@@ -565,7 +567,7 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   hipStreamSynchronize(b->stream);
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
   hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); if (b->d_obsprog) hipFree(b->d_obsprog);
-  if (b->d_bank) hipFree(b->d_bank); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); hipFree(b->d_mesh); hipFree(b->d_mask);
+  if (b->d_bank) hipFree(b->d_bank); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); if (b->d_ft_base) hipFree(b->d_ft_base); hipFree(b->d_mesh); hipFree(b->d_mask);
   if (b->db.prof) hipFree(b->db.prof);
   hipStreamDestroy(b->stream);
   delete b;
@@ -656,6 +658,27 @@ extern "C" int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, c
   if (dalloc(&b->d_patch, (size_t)(n_patch ? n_patch : 1))) return 1;
   if (n_patch) HIPCHK(hipMemcpy(b->d_patch, patch_idx, n_patch * sizeof(int), hipMemcpyHostToDevice));
   b->db.bank = b->d_bank; b->db.patch_idx = b->d_patch; b->db.bank_E = n_episodes; b->db.bank_P = n_patch;
+  return 0;
+}
+
+extern "C" int rsim_dr_save_defaults(rsim_batch* b) {
+  if (!b->per_env) return fail("rsim_dr_save_defaults: the batch was created without per_env_params");
+  HIPCHK(hipSetDevice(b->device));
+  const size_t n = b->m->ftab.size() * (size_t)b->B;
+  if (!b->d_ft_base) HIPCHK(hipMalloc((void**)&b->d_ft_base, n * sizeof(float)));
+  HIPCHK(hipMemcpyAsync(b->d_ft_base, b->d_ft, n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+  b->db.ft_base = b->d_ft_base;
+  return 0;
+}
+extern "C" int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uint64_t seed, uint64_t step) {
+  if (!b->per_env) return fail("rsim_randomize_dynamics: the batch was created without per_env_params");
+  if (!b->d_ft_base) return fail("rsim_randomize_dynamics: call rsim_dr_save_defaults first");
+  HIPCHK(hipSetDevice(b->device));
+  DDr dd = {d->density_ratio, d->viscosity_ratio, d->position_size, d->quaternion_size, d->inertia_ratio, d->mass_ratio, d->friction_ratio, d->solref_ratio,
+            d->solimp_ratio, d->frictionloss_size, d->damping_size, d->armature_size};
+  int e = rsim_launch_randomize(&b->dm, &b->db, &dd, seed, step, b->stream);
+  if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  b->gen++;
   return 0;
 }
 
@@ -842,6 +865,35 @@ extern "C" int rsim_model_param_set(rsim_batch* b, const char* field, int env0, 
   const size_t base = b->per_env ? (size_t)env0 * fs : 0;
   HIPCHK(hipMemcpy2D(b->d_ft + base + m->fo[mp->fo], fs * sizeof(float), tmp.data(), n * sizeof(float), n * sizeof(float), (size_t)envs, hipMemcpyHostToDevice));
   b->gen++;
+  return 0;
+}
+
+extern "C" int rsim_model_param_get(rsim_batch* b, const char* field, int env0, int nenv, double* values, size_t cpe) {
+  rsim_model* m = b->m;
+  int nmaps = 0;
+  const ParamMap* maps = param_maps(&nmaps);
+  const ParamMap* mp = nullptr;
+  for (int i = 0; i < nmaps; i++) if (!strcmp(maps[i].name, field)) mp = &maps[i];
+  if (!mp) return fail("rsim_model_param_get: unknown field '%s'", field);
+  if (env0 < 0 || nenv < 1 || env0 + nenv > b->B) return fail("rsim_model_param_get: env range out of bounds");
+  size_t expect = mp->geom ? (size_t)m->ngeom * mp->w : (size_t)m->fcount[mp->fo];
+  if (cpe != expect) return fail("rsim_model_param_get: field '%s' has %zu values per env, got %zu", field, expect, cpe);
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const size_t n = m->fcount[mp->fo], fs = m->ftab.size();
+  std::vector<float> tmp((size_t)nenv * n);
+  if (b->per_env) HIPCHK(hipMemcpy2D(tmp.data(), n * sizeof(float), b->d_ft + (size_t)env0 * fs + m->fo[mp->fo], fs * sizeof(float), n * sizeof(float), (size_t)nenv, hipMemcpyDeviceToHost));
+  else for (int e = 0; e < nenv; e++) HIPCHK(hipMemcpy(tmp.data() + (size_t)e * n, b->d_ft + m->fo[mp->fo], n * sizeof(float), hipMemcpyDeviceToHost));
+  const int ncg = (int)m->cg.size();
+  for (int e = 0; e < nenv; e++) {
+    double* v = values + (size_t)e * cpe;
+    const float* t = tmp.data() + (size_t)e * n;
+    if (mp->geom) {
+      const double* base = m->D(mp->name);   // non-colliding geoms are not on the device: report the compiled value
+      for (size_t i = 0; i < cpe; i++) v[i] = base ? base[i] : 0.0;
+      for (int c = 0; c < ncg; c++) for (int q = 0; q < mp->w; q++) v[(size_t)m->cg[c] * mp->w + q] = t[(size_t)c * mp->w + q];
+    } else for (size_t i = 0; i < n; i++) v[i] = t[i];
+  }
   return 0;
 }
 

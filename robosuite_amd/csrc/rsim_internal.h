@@ -115,6 +115,7 @@ struct DBatch {
   const float* bank;     // [B][bank_E][nq + bank_P]
   const int* patch_idx;  // [bank_P] offsets into the env's float table
   float* ft_rw;          // writable alias of the float tables (per-env patches)
+  float* ft_base;        // saved defaults of the float tables (domain randomisation), may be null
   unsigned long long* prof;  // optional [RP_COUNT] phase-cycle / event accumulators (null = off)
   int prof_env;              // >= 0: only this env adds to the phase accumulators
 };
@@ -123,6 +124,9 @@ struct DBatch {
 enum { RP_LOAD, RP_KIN, RP_COM, RP_CRB, RP_BROAD, RP_NARROW, RP_MAKEC, RP_VEL, RP_CTRL, RP_ACT, RP_SOLVE, RP_EULER, RP_STORE,
        RP_N_SUB, RP_N_CAND, RP_N_CON, RP_N_EFC, RP_N_NEWTON, RP_N_LS, RP_BOXBOX, RP_MPR, RP_PLANE, RP_N_BOXBOX, RP_N_MPR, RP_N_SUPPORT,
        RP_X0, RP_X1, RP_X2, RP_X3, RP_X4, RP_X5, RP_X6, RP_X7, RP_X8, RP_X9, /* ad-hoc sub-phase cycle slots */ RP_COUNT };
+
+// device form of rsim_dr_desc
+struct DDr { float density, viscosity, pos, quat, inertia, mass, friction, solref, solimp, frictionloss, damping, armature; };
 
 // flags for the step kernel
 enum {

@@ -1410,7 +1410,11 @@ struct Sim {
       Bd = -solref[1] / fmaxf(1e-15f, dmax);
     }
     Kterm = Kk * imp * (pos - margin);
-    R = fmaxf(1e-15f, (1 - imp) / imp * diag);
+    // fp32 safeguard: a contact between a static body and a link whose COM sits on its joint axis has diagApprox = 0 (e.g. Panda link0-link1
+    // once domain randomisation closes their 1 mm gap); MuJoCo's floor of 1e-15 gives D = 1e15, which multiplies the ~1e-7 rounding noise of
+    // a single-precision Jacobian row into a real torque.  1e-7 keeps D J_noise^2 negligible against M and changes no regular contact
+    // (their R is >= 1e-5).
+    R = fmaxf(1e-7f, (1 - imp) / imp * diag);
   }
 
   // Row list: (1) friction-loss dofs, (2) joint limits (lower side first), (3) contacts in detection order.
@@ -2191,7 +2195,10 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
       SYNC();
       for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = src[i];
       if (lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.ctrl[lane] = 0.f; }
-      for (int p2 = lane; p2 < b.bank_P; p2 += 64) b.ft_rw[(size_t)env * m.fstride + b.patch_idx[p2]] = src[m.nq + p2];
+      for (int p2 = lane; p2 < b.bank_P; p2 += 64) {
+        b.ft_rw[(size_t)env * m.fstride + b.patch_idx[p2]] = src[m.nq + p2];
+        if (b.ft_base) b.ft_base[(size_t)env * m.fstride + b.patch_idx[p2]] = src[m.nq + p2];
+      }
       time = 0.f;
       st = 0;
       if (lane == 0) { b.ep_index[env] = ep; b.needs_reset[env] = 1; }
@@ -2314,6 +2321,66 @@ __global__ __launch_bounds__(64) void k_osc_eval(DCtrl c, const float* __restric
     for (int k = 0; k < n; k++) tq += M[lane * 8 + k] * tmp[k];
     out[(size_t)env * 8 + lane] = tq;
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// dynamics domain randomisation (include/rsim.h rsim_randomize_dynamics): one workgroup per env rewrites that env's float table
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dr_uniform(unsigned long long seed, unsigned long long step, unsigned env, unsigned item) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (step + 1) + ((unsigned long long)env << 32 | item);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;   // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
+  return (float)(z >> 40) * (2.0f / 16777216.0f) - 1.0f;   // U(-1, 1), 24-bit
+}
+__global__ __launch_bounds__(64) void k_randomize(DModel m, DBatch b, DDr d, unsigned long long seed, unsigned long long step) {
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= b.B) return;
+  const float* base = b.ft_base + (size_t)env * m.fstride;
+  float* out = b.ft_rw + (size_t)env * m.fstride;
+  gci it = (gci)m.it;
+  unsigned item = 0;
+  auto ratio = [&](int off, float mag, float lo, float hi, unsigned id) {
+    if (mag > 0.f) out[off] = fminf(hi, fmaxf(lo, base[off] * (1.0f + mag * dr_uniform(seed, step, env, id))));
+  };
+  auto size_ = [&](int off, float mag, float lo, unsigned id) {
+    if (mag > 0.f) out[off] = fmaxf(lo, base[off] + mag * dr_uniform(seed, step, env, id));
+  };
+  const float INF = 3.0e38f;
+  if (lane == 0) { ratio(m.fo[FO_opt] + 4, d.density, 0.f, INF, 1); ratio(m.fo[FO_opt] + 5, d.viscosity, 0.f, INF, 2); }
+  item = 16;
+  for (int bd = 1 + lane; bd < m.nbody; bd += 64) {
+    const unsigned id = item + 16u * bd;
+    for (int k = 0; k < 3; k++) size_(m.fo[FO_body_pos] + 3 * bd + k, d.pos, -INF, id + k);
+    if (d.quat > 0.f) {
+      float q[4], n = 0.f;
+      for (int k = 0; k < 4; k++) { q[k] = base[m.fo[FO_body_quat] + 4 * bd + k] + d.quat * dr_uniform(seed, step, env, id + 3 + k); n += q[k] * q[k]; }
+      n = rsqrtf(fmaxf(n, 1e-20f));
+      for (int k = 0; k < 4; k++) out[m.fo[FO_body_quat] + 4 * bd + k] = q[k] * n;
+    }
+    for (int k = 0; k < 3; k++) ratio(m.fo[FO_body_inertia] + 3 * bd + k, d.inertia, 0.f, INF, id + 7 + k);
+    ratio(m.fo[FO_body_mass] + bd, d.mass, 0.f, INF, id + 10);
+  }
+  item += 16u * 64;
+  for (int g = lane; g < m.ncg; g += 64) {
+    const unsigned id = item + 16u * g;
+    for (int k = 0; k < 3; k++) ratio(m.fo[FO_cg_friction] + 3 * g + k, d.friction, 0.f, INF, id + k);
+    for (int k = 0; k < 2; k++) ratio(m.fo[FO_cg_solref] + 2 * g + k, d.solref, 0.f, 1.0f, id + 3 + k);
+    for (int k = 0; k < 5; k++) ratio(m.fo[FO_cg_solimp] + 5 * g + k, d.solimp, 0.f, INF, id + 5 + k);
+  }
+  item += 16u * 64;
+  for (int i = lane; i < m.nv; i += 64) {
+    const int j = it[m.io[IO_dof_jntid] + i];
+    if (it[m.io[IO_jnt_type] + j] == JNT_FREE) continue;   // mjmod.py:1927: free joints keep their values
+    const unsigned id = item + 4u * i;
+    size_(m.fo[FO_dof_frictionloss] + i, d.frictionloss, 0.f, id);
+    size_(m.fo[FO_dof_damping] + i, d.damping, 0.f, id + 1);
+    size_(m.fo[FO_dof_armature] + i, d.armature, 0.f, id + 2);
+  }
+}
+extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr* d, unsigned long long seed, unsigned long long step, hipStream_t stream) {
+  hipLaunchKernelGGL(k_randomize, dim3(b->B), dim3(64), 0, stream, *m, *b, *d, seed, step);
+  return (int)hipGetLastError();
 }
 
 // explicit instantiations + launchers ------------------------------------------------------------------------

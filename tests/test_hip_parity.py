@@ -249,3 +249,48 @@ def test_vectorised_env_facade():
     assert dones[0].sum().item() == 0 and dones[2].sum().item() == 6
     assert tuple(env.flat_obs(obs).shape) == (6, 60) and torch.isfinite(rew).all()
     assert tuple(info["success"].shape) == (6,)
+
+
+def test_dynamics_domain_randomisation_on_device():
+    """DynamicsModder semantics (utils/mjmod.py:1705-1729): every draw is default*(1+p u) / default+p u inside the clip range, relative to the
+    saved defaults (not cumulative), quaternions stay unit, free-joint dofs untouched; per-env, per-step, reproducible from (seed, step)."""
+    from robosuite_amd.backend import DEFAULT_DYNAMICS_ARGS as A
+    g, cfg, flat = load_golden("seed1_full")
+    B = 64
+    env = lift.LiftBatch(flat, cfg, np.arange(B), seed0=0)
+    b = env.batch
+    base = {k: b.param_get(k) for k in ("body_mass", "body_inertia", "body_pos", "body_quat", "geom_friction", "geom_solref", "geom_solimp",
+                                         "dof_damping", "dof_armature", "dof_frictionloss", "opt")}
+    b.dr_save_defaults()
+    b.randomize_dynamics(seed=7, step=0)
+    r0 = {k: b.param_get(k) for k in base}
+    b.randomize_dynamics(seed=7, step=1)
+    r1 = {k: b.param_get(k) for k in base}
+    b.randomize_dynamics(seed=7, step=0)
+    r0b = {k: b.param_get(k) for k in base}
+    for k in base:
+        assert np.array_equal(r0[k], r0b[k]), k                       # reproducible, relative to defaults (not cumulative)
+    cg = [i for i in range(flat.ngeom) if i in set(flat.pair_geom1) | set(flat.pair_geom2)]
+    m, m0 = r0["body_mass"][:, 1:], base["body_mass"][:, 1:]
+    assert np.all(np.abs(m - m0) <= A["mass_ratio"] * m0 * 1.0001 + 1e-9) and np.abs(m - m0).max() > 0
+    assert np.abs(r0["body_mass"] - r1["body_mass"]).max() > 0 and np.abs(r0["body_mass"][0] - r0["body_mass"][1]).max() > 0   # per step, per env
+    i0 = base["body_inertia"][:, 1:]
+    assert np.all(np.abs(r0["body_inertia"][:, 1:] - i0) <= A["inertia_ratio"] * i0 * 1.0001 + 1e-12)
+    assert np.all(np.abs(r0["body_pos"][:, 1:] - base["body_pos"][:, 1:]) <= A["position_size"] * 1.0001)
+    assert np.abs(np.linalg.norm(r0["body_quat"][:, 1:], axis=2) - 1).max() < 1e-6
+    f0 = base["geom_friction"][:, cg]
+    assert np.all(np.abs(r0["geom_friction"][:, cg] - f0) <= A["friction_ratio"] * f0 * 1.0001 + 1e-9)
+    sr = r0["geom_solref"][:, cg]
+    assert sr.min() >= 0 and sr.max() <= 1.0 and np.all(np.abs(sr - base["geom_solref"][:, cg]) <= A["solref_ratio"] * base["geom_solref"][:, cg] + 1e-7)
+    d = r0["dof_damping"]
+    assert d.min() >= 0 and np.all(np.abs(d[:, :9] - base["dof_damping"][:, :9]) <= A["damping_size"] * 1.0001)
+    assert np.array_equal(d[:, 9:], base["dof_damping"][:, 9:])     # cube free joint untouched
+    assert np.all(np.abs(r0["dof_frictionloss"][:, :9] - base["dof_frictionloss"][:, :9]) <= A["frictionloss_size"] * 1.0001)
+    assert abs(r0["opt"][0, 4] / base["opt"][0, 4] - 1) <= A["density_ratio"] * 1.0001 and r0["opt"][0, 0] == base["opt"][0, 0]
+    # the simulation keeps running on randomised parameters (randomize_every_n_steps = 1)
+    acts = lift.env_actions(np.arange(B), 10, scale=0.5)
+    for t in range(10):
+        b.randomize_dynamics(seed=7, step=t)
+        env.step(torch.tensor(acts[t], device="cuda"))
+    assert np.isfinite(b.get("qpos")).all() and np.isfinite(b.get("qvel")).all()
+    b.randomize_dynamics(seed=7, step=0, **{k: 0.0 for k in A})     # all magnitudes 0 => nothing is rewritten (values of the last draw stay)
