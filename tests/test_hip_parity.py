@@ -294,3 +294,29 @@ def test_dynamics_domain_randomisation_on_device():
         env.step(torch.tensor(acts[t], device="cuda"))
     assert np.isfinite(b.get("qpos")).all() and np.isfinite(b.get("qvel")).all()
     b.randomize_dynamics(seed=7, step=0, **{k: 0.0 for k in A})     # all magnitudes 0 => nothing is rewritten (values of the last draw stay)
+
+
+def test_grasp_and_lift_replay_matches_oracle_and_sets_success():
+    """The scripted grasp (condim-4 pad contacts, elliptic cones in the sliding / sticking regimes, joint limits of the fingers) replayed on
+    the HIP path: same qualitative outcome as the oracle, reward = grasp bonus then success, trajectories close before chaos matters."""
+    from tests.util import scripted_grasp_and_lift
+    g, cfg, flat = load_golden("seed1_full")
+    nq = flat.nq
+    q0 = g["states"][0][1:1 + nq]
+    acts, qs, cube_z, _ = scripted_grasp_and_lift(flat, cfg, q0)
+    hm, _ = make_hip(flat, cfg, B=1)
+    from robosuite_amd.backend import HipBatch
+    hm.set_task(lift.lift_task(flat, cfg))
+    hb = HipBatch(hm, 2, 0, False)
+    hb.set("qpos", q0[None].repeat(2, 0)); hb.set("qvel", 0); hb.forward(); hb.ctrl_reset()
+    rewards, succ = [], []
+    for t in range(len(acts)):
+        hb.control_step(torch.tensor(np.repeat(acts[t][None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+        rewards.append(hb.get("reward")[0]); succ.append(hb.get("success")[0])
+        if t == 25:   # approach finished, before the grasp: still tight agreement
+            assert np.abs(hb.get("qpos")[0] - qs[t][:nq]).max() < 2e-3
+    q = hb.get("qpos")[0]
+    assert q[11] > 0.8 + 0.04 + 0.1 and abs(q[11] - cube_z) < 0.02
+    assert succ[-1] == 1 and abs(rewards[-1] - 1.0) < 1e-6       # success => 2.25 * reward_scale / 2.25
+    assert any(abs(r - (1 - np.tanh(0)) / 2.25) < 0.2 and r > 1.0 / 2.25 for r in rewards)   # reaching (~1) + grasp bonus 0.25 seen before lift-off
+    assert np.isfinite(hb.get("qvel")).all()

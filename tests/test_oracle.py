@@ -160,3 +160,16 @@ def test_resting_contact_normal_forces_balance_weight():
     fn = sum(c["normal_force"] for c in od.contacts() if c["geom1"] in cube_geoms or c["geom2"] in cube_geoms)
     assert fn == pytest.approx(mass * 9.81, rel=2e-3)
     assert np.abs(od.qvel[9:15]).max() < 1e-4
+
+
+def test_scripted_grasp_lifts_the_cube():
+    """Behavioural anchor of the contact / friction model (reference shape: GripperTester raises unless the cube is lifted,
+    models/grippers/gripper_tester.py:204-226 via tests/test_grippers/test_panda_gripper.py): hover, descend, close, lift."""
+    from tests.util import scripted_grasp_and_lift
+    g, cfg, flat = load_golden("seed1_full")
+    acts, qs, cube_z, od = scripted_grasp_and_lift(flat, cfg, g["states"][0][1:1 + flat.nq])
+    assert cube_z > 0.8 + 0.04 + 0.1                      # Lift._check_success threshold cleared with margin
+    pads = {flat.names["geom"].index(n) for n in ("gripper0_right_finger1_pad_collision", "gripper0_right_finger2_pad_collision")}
+    cube = flat.names["geom"].index("cube_g0")
+    touching = {c["geom1"] if c["geom2"] == cube else c["geom2"] for c in od.contacts() if cube in (c["geom1"], c["geom2"])}
+    assert pads <= touching                               # held by both finger pads (ManipulationEnv._check_grasp)
