@@ -76,6 +76,7 @@ struct rsim_batch {
   int* d_patch;
   float* d_ft_base;
   float* d_ft;
+  float* d_ft0;
   float* d_mesh;
   unsigned char* d_mask;
   DModel dm;
@@ -504,6 +505,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   size_t copies = b->per_env ? (size_t)B : 1;
   if (dalloc(&b->d_ft, fs * copies)) return 1;
   for (size_t c = 0; c < copies; c++) HIPCHK(hipMemcpy(b->d_ft + c * fs, m->ftab.data(), fs * sizeof(float), hipMemcpyHostToDevice));
+  if (dalloc(&b->d_ft0, fs)) return 1;
+  HIPCHK(hipMemcpy(b->d_ft0, m->ftab.data(), fs * sizeof(float), hipMemcpyHostToDevice));
   if (dalloc(&b->d_mesh, m->mesh_vert.size())) return 1;
   HIPCHK(hipMemcpy(b->d_mesh, m->mesh_vert.data(), m->mesh_vert.size() * sizeof(float), hipMemcpyHostToDevice));
   if (dalloc(&b->d_mask, (size_t)B)) return 1;
@@ -524,6 +527,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   HIPCHK(hipMemcpy(b->d_lt, m->lanetab.data(), m->lanetab.size() * sizeof(int), hipMemcpyHostToDevice));
   dm.lt = b->d_lt; dm.kin_rounds = m->kin_rounds; dm.ndynroot = m->ndynroot; dm.maxcondim = m->maxcondim;
   for (int r = 0; r < RSIM_MAXDYNROOT; r++) dm.dynroot[r] = r < m->ndynroot ? m->dynroot[r] : 0;
+  dm.ft0 = b->d_ft0; dm.fenv = 0;
   dm.it = b->d_it; dm.ft = b->d_ft; dm.mesh_vert = b->d_mesh; dm.fstride = b->per_env ? (int)fs : 0;
   memcpy(dm.io, m->io, sizeof(dm.io));
   memcpy(dm.fo, m->fo, sizeof(dm.fo));
@@ -566,7 +570,7 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   hipSetDevice(b->device);
   hipStreamSynchronize(b->stream);
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
-  hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); if (b->d_obsprog) hipFree(b->d_obsprog);
+  hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_ft0); if (b->d_obsprog) hipFree(b->d_obsprog);
   if (b->d_bank) hipFree(b->d_bank); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); if (b->d_ft_base) hipFree(b->d_ft_base); hipFree(b->d_mesh); hipFree(b->d_mask);
   if (b->db.prof) hipFree(b->db.prof);
   hipStreamDestroy(b->stream);
@@ -658,6 +662,9 @@ extern "C" int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, c
   if (dalloc(&b->d_patch, (size_t)(n_patch ? n_patch : 1))) return 1;
   if (n_patch) HIPCHK(hipMemcpy(b->d_patch, patch_idx, n_patch * sizeof(int), hipMemcpyHostToDevice));
   b->db.bank = b->d_bank; b->db.patch_idx = b->d_patch; b->db.bank_E = n_episodes; b->db.bank_P = n_patch;
+  for (int p2 = 0; p2 < n_patch; p2++)
+    for (int f = 0; f < FO_COUNT; f++)
+      if (patch_idx[p2] >= m->fo[f] && patch_idx[p2] < m->fo[f] + m->fcount[f]) b->dm.fenv |= 1ull << f;
   return 0;
 }
 
@@ -676,6 +683,8 @@ extern "C" int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uin
   HIPCHK(hipSetDevice(b->device));
   DDr dd = {d->density_ratio, d->viscosity_ratio, d->position_size, d->quaternion_size, d->inertia_ratio, d->mass_ratio, d->friction_ratio, d->solref_ratio,
             d->solimp_ratio, d->frictionloss_size, d->damping_size, d->armature_size};
+  b->dm.fenv |= (1ull << FO_opt) | (1ull << FO_body_pos) | (1ull << FO_body_quat) | (1ull << FO_body_inertia) | (1ull << FO_body_mass) | (1ull << FO_cg_friction) |
+                (1ull << FO_cg_solref) | (1ull << FO_cg_solimp) | (1ull << FO_dof_frictionloss) | (1ull << FO_dof_damping) | (1ull << FO_dof_armature);
   int e = rsim_launch_randomize(&b->dm, &b->db, &dd, seed, step, b->stream);
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   b->gen++;
@@ -864,6 +873,8 @@ extern "C" int rsim_model_param_set(rsim_batch* b, const char* field, int env0, 
   // one strided copy: row e of `tmp` -> the field's slot inside env (env0 + e)'s float table
   const size_t base = b->per_env ? (size_t)env0 * fs : 0;
   HIPCHK(hipMemcpy2D(b->d_ft + base + m->fo[mp->fo], fs * sizeof(float), tmp.data(), n * sizeof(float), n * sizeof(float), (size_t)envs, hipMemcpyHostToDevice));
+  if (b->per_env) b->dm.fenv |= 1ull << mp->fo;   // from now on the kernel reads this field from the env's own table
+  else HIPCHK(hipMemcpy(b->d_ft0 + m->fo[mp->fo], tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
   b->gen++;
   return 0;
 }
@@ -882,8 +893,8 @@ extern "C" int rsim_model_param_get(rsim_batch* b, const char* field, int env0, 
   HIPCHK(hipStreamSynchronize(b->stream));
   const size_t n = m->fcount[mp->fo], fs = m->ftab.size();
   std::vector<float> tmp((size_t)nenv * n);
-  if (b->per_env) HIPCHK(hipMemcpy2D(tmp.data(), n * sizeof(float), b->d_ft + (size_t)env0 * fs + m->fo[mp->fo], fs * sizeof(float), n * sizeof(float), (size_t)nenv, hipMemcpyDeviceToHost));
-  else for (int e = 0; e < nenv; e++) HIPCHK(hipMemcpy(tmp.data() + (size_t)e * n, b->d_ft + m->fo[mp->fo], n * sizeof(float), hipMemcpyDeviceToHost));
+  if (b->per_env && ((b->dm.fenv >> mp->fo) & 1ull)) HIPCHK(hipMemcpy2D(tmp.data(), n * sizeof(float), b->d_ft + (size_t)env0 * fs + m->fo[mp->fo], fs * sizeof(float), n * sizeof(float), (size_t)nenv, hipMemcpyDeviceToHost));
+  else for (int e = 0; e < nenv; e++) HIPCHK(hipMemcpy(tmp.data() + (size_t)e * n, b->d_ft0 + m->fo[mp->fo], n * sizeof(float), hipMemcpyDeviceToHost));
   const int ncg = (int)m->cg.size();
   for (int e = 0; e < nenv; e++) {
     double* v = values + (size_t)e * cpe;

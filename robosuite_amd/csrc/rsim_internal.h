@@ -86,6 +86,8 @@ struct DModel {
   float tolerance, meaninertia;
   const int* it;
   const float* ft;
+  const float* ft0;            // shared copy of the float table (read for every field no env has overridden)
+  unsigned long long fenv;     // bit f set: float-table field f has per-env values (read from ft + env * fstride)
   const float* mesh_vert;
   int fstride;
   const int* lt;            // lane table [LT_COUNT][64]

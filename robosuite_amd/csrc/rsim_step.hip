@@ -257,7 +257,9 @@ typedef Smem<32, 16, 16, 24, 16, 16, 64, 192> Smem0;
 __shared__ Smem0 sm;
 
 #define IT(tab, i) (((gci)m.it)[m.io[tab] + (i)])
-#define FP(tab, i) (((gcf)fp)[m.fo[tab] + (i)])
+// per-env value only for fields some env has overridden (per-episode object sizes, domain randomisation); everything else comes from the
+// shared copy, which stays L2-resident instead of being streamed from HBM once per env and launch
+#define FP(tab, i) (((gcf)(((m.fenv >> (tab)) & 1ull) ? fp : m.ft0))[m.fo[tab] + (i)])
 
 // Register-resident Cholesky: lane i owns row (i & 15) of the SPD matrix in a[0..N) (the four 16-lane rows of the wave hold identical
 // copies); all loops unroll so every index is a compile-time register and every broadcast is a DPP row_newbcast operand.
@@ -270,19 +272,23 @@ struct RcholUpd {
 };
 template <int N, int J>
 struct RcholStep {
-  static __device__ __forceinline__ void run(float (&a)[N], float (&inv)[N]) {
+  static __device__ __forceinline__ void run(float (&a)[N], float (&inv)[N], int row, float& own) {
     if constexpr (J < N) {
       const float iv = rsqrtf(fmaxf(rbcast<J>(a[J]), FMIN));
       inv[J] = iv;
+      own = row == J ? iv : own;
       const float lij = a[J] * iv;
       a[J] = lij;
       RcholUpd<N, J, J + 1>::run(a, lij);
-      RcholStep<N, J + 1>::run(a, inv);
+      RcholStep<N, J + 1>::run(a, inv, row, own);
     }
   }
 };
 template <int N>
-__device__ __forceinline__ void rchol_factor(float (&a)[N], float (&inv)[N]) { RcholStep<N, 0>::run(a, inv); }
+__device__ __forceinline__ void rchol_factor(float (&a)[N], float (&inv)[N]) { float own = 0.f; RcholStep<N, 0>::run(a, inv, -1, own); }
+// same, also returning 1 / L[row][row] of the caller's own row (for the lane that stores invdiag[row])
+template <int N>
+__device__ __forceinline__ float rchol_factor_own(float (&a)[N], float (&inv)[N], int row) { float own = 0.f; RcholStep<N, 0>::run(a, inv, row, own); return own; }
 // forward substitution only: returns y = L^-1 x (component i in the lanes of row i); `row` = lane & 15
 template <int N, int K>
 struct RcholFwd {
@@ -866,12 +872,11 @@ struct Sim {
       const float hd = r < nv ? opt_h * K.damping : 0.f;   // dof lanes: lane & 15 = dof (K is fetched per 16-lane row)
 #pragma unroll
       for (int k = 0; k < NV16; k++) { mr[k] = sm.M[r * NVP + k]; er[k] = mr[k] + (k == r ? hd : 0.f); }
-      rchol_factor<NV16>(mr, minv);
-      rchol_factor<NV16>(er, einv);
+      const float mown = rchol_factor_own<NV16>(mr, minv, r), eown = rchol_factor_own<NV16>(er, einv, r);
       if (lane < NV16) {
 #pragma unroll
         for (int k = 0; k < NV16; k++) { sm.L[lane * NVP + k] = mr[k]; sm.Le[lane * NVP + k] = er[k]; }
-        sm.invdiag[lane] = sel(minv, lane); sm.invdiag_e[lane] = sel(einv, lane);
+        sm.invdiag[lane] = mown; sm.invdiag_e[lane] = eown;
       }
     }
     SYNC();
@@ -1171,7 +1176,8 @@ struct Sim {
   }
 
   // closest point on triangle to the origin (barycentric)
-  __device__ __forceinline__ V3 tri_closest_origin(V3 a, V3 b, V3 c, float* bary) {
+  __device__ __forceinline__ V3 tri_closest_origin(V3 a, V3 b, V3 c, V3& bw) {
+    float bary[3];
     V3 ab = b - a, ac = c - a, ap = -a, bp = -b, cp = -c;
     float d1 = dot(ab, ap), d2 = dot(ac, ap);
     if (d1 <= 0 && d2 <= 0) { bary[0] = 1; bary[1] = 0; bary[2] = 0; }
@@ -1196,6 +1202,7 @@ struct Sim {
         }
       }
     }
+    bw = v3(bary[0], bary[1], bary[2]);
     return a * bary[0] + b * bary[1] + c * bary[2];
   }
 
@@ -1253,11 +1260,11 @@ struct Sim {
       }
     }
     if (!hit) return;
-    float bary[3];
-    V3 cpt = tri_closest_origin(v1, v2, v3_, bary);
+    V3 bw;
+    V3 cpt = tri_closest_origin(v1, v2, v3_, bw);
     float depth = norm(cpt);
     V3 n = depth > 1e-12f ? cpt * (1.0f / depth) : dir;
-    V3 w1 = p11 * bary[0] + p21 * bary[1] + p31 * bary[2], w2 = p12 * bary[0] + p22 * bary[1] + p32 * bary[2];
+    V3 w1 = p11 * bw.x + p21 * bw.y + p31 * bw.z, w2 = p12 * bw.x + p22 * bw.y + p32 * bw.z;
     emit_contacts(lane == 0, 1, -depth, (w1 + w2) * 0.5f, n, g1, g2, cp);
   }
 
