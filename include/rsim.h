@@ -22,6 +22,12 @@ typedef struct rsim_batch rsim_batch;
  * Replaces controllers/parts/arm/osc.py:120-224 (constructor arguments) and
  * controllers/parts/gripper/simple_grip.py:62-107; index tables are what
  * robots/robot.py:300-333 (`setup_references`) resolves by name. */
+/* arm part-controller types with an in-kernel implementation (names = the reference's `type` strings, controller_factory.py:93-147):
+ *   OSC_POSE       arm/osc.py, control_dim 6            OSC_POSITION  arm/osc.py with use_ori=False, control_dim 3 (zero orientation delta, osc.py:255-263)
+ *   JOINT_POSITION generic/joint_pos.py:200-266, control_dim ndof: goal = q + scaled delta, tau = M_arm (kp (goal - q) - kd qd) + qfrc_bias
+ *   JOINT_TORQUE   generic/joint_tor.py:111-167, control_dim ndof: tau = clip(scaled action, torque_limits) + qfrc_bias
+ * The action row of rsim_control_step is [control_dim arm entries, 1 gripper entry if ngrip > 0]. */
+enum rsim_ctrl_type { RSIM_CTRL_OSC_POSE = 0, RSIM_CTRL_OSC_POSITION = 1, RSIM_CTRL_JOINT_POSITION = 2, RSIM_CTRL_JOINT_TORQUE = 3 };
 typedef struct rsim_ctrl_desc {
   int32_t ndof;            /* arm joints (<= 8) */
   int32_t qpos_idx[8];     /* Controller.qpos_index */
@@ -29,15 +35,17 @@ typedef struct rsim_ctrl_desc {
   int32_t act_idx[8];      /* robot._ref_actuators_indexes_dict[arm] */
   int32_t eef_site;        /* site id of Controller.ref_name */
   int32_t base_site;       /* site id of f"{naming_prefix}{part_name}_center" (osc.py:453) */
-  float kp[6];             /* osc.py:176 */
-  float damping_ratio;     /* kd = 2 sqrt(kp) damping_ratio, osc.py:177 */
-  float input_min[6], input_max[6], output_min[6], output_max[6]; /* controller.py:149-168 */
+  float kp[8];             /* osc.py:176 (6 task-space gains) / joint_pos.py:150 (ndof joint gains) */
+  float damping_ratio;     /* kd = 2 sqrt(kp) damping_ratio, osc.py:177, joint_pos.py:151 */
+  float input_min[8], input_max[8], output_min[8], output_max[8]; /* controller.py:149-168, first control_dim entries used */
   int32_t uncouple_pos_ori; /* osc.py:476-482 */
   float nullspace_kp;       /* control_utils.py:7 (default 10) */
   int32_t ngrip;            /* gripper actuators (<= 4), 0 = no gripper */
   int32_t grip_act[4];
   float grip_sign[4];       /* PandaGripper.format_action direction, models/grippers/panda_gripper.py:55-57 */
   float grip_speed;         /* panda_gripper.py:61 */
+  int32_t type;             /* enum rsim_ctrl_type: which arm part controller of controller_factory.py:73-159 */
+  float torque_min[8], torque_max[8]; /* RSIM_CTRL_JOINT_TORQUE: torque_limits (joint_tor.py:95-96; default = actuator ctrlrange) */
 } rsim_ctrl_desc;
 
 /* On-device observation / reward epilogue of the fused control step.
@@ -75,7 +83,7 @@ enum rsim_field {
   RSIM_QACC_WARMSTART, /* [B,nv]                                                            */
   RSIM_CTRL,           /* [B,nu]  sim.data.ctrl   (fixed_base_robot.py:153)                 */
   RSIM_TIME,           /* [B]     sim.data.time                                              */
-  RSIM_CSTATE,         /* [B,32]  controller state: goal_pos3 goal_ori9 q0[8] grip[4] tau[8] */
+  RSIM_CSTATE,         /* [B,32]  controller state: goal_pos3 goal_ori9 (joint types: goal_q/goal_torque[8] in the same slots) q0[8] grip[4] tau[8] */
   RSIM_XPOS,           /* [B,nbody,3]  sim.data.xpos      (derived, valid after forward/step1) */
   RSIM_XQUAT,          /* [B,nbody,4]  sim.data.xquat                                        */
   RSIM_QM,             /* [B,nv,nv]    dense mass matrix (mj_fullM, controller.py:226-227)  */
@@ -108,7 +116,7 @@ int rsim_model_create(const void* blob, size_t len, rsim_model** out);
 void rsim_model_free(rsim_model* m);
 /* scalar / size query by blob field name ("nq", "nv", ...); returns -1 if unknown */
 int rsim_model_int(const rsim_model* m, const char* name);
-/* controller_factory (controllers/parts/controller_factory.py:73-159) for the built-in OSC_POSE + GRIP pair */
+/* controller_factory (controllers/parts/controller_factory.py:73-159) for the built-in arm part (rsim_ctrl_type) + GRIP pair */
 int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* desc);
 /* observation / reward epilogue of rsim_control_step (must be set before rsim_batch_create) */
 int rsim_model_set_task(rsim_model* m, const rsim_task_desc* desc);
@@ -132,7 +140,7 @@ int rsim_step2(rsim_batch* b);
 int rsim_step(rsim_batch* b);
 /* Fused fast path = MujocoEnv.step's substep loop (environments/base.py:494-504) with the built-in controllers:
  * n_sub x { step1; control(action, policy_step = first); step2 } in ONE launch.  `actions_dev` is a DEVICE pointer
- * to [B, action_dim] float32 (action_dim = 6 + (ngrip>0)). */
+ * to [B, action_dim] float32 (action_dim = control_dim(type) + (ngrip>0); rsim_model_int(m, "action_dim")). */
 int rsim_control_step(rsim_batch* b, const float* actions_dev, int n_sub);
 /* Robot.reset's controller re-creation (robots/robot.py:271 -> controller.py:125-131, osc.py:520-532):
  * forward kinematics, initial_joint := q, goal := current eef pose, gripper action := 0 */

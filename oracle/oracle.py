@@ -51,6 +51,7 @@ def lib():
         L.rso_efc_type.argtypes = [vp, C.c_int]
         L.rso_ctrl_create.restype = vp
         L.rso_ctrl_free.argtypes = [vp]
+        L.rso_ctrl_set_type.argtypes = [vp, C.c_int, C.c_int, dp, C.c_double, dp, dp, dp, dp, dp, dp]
         L.rso_ctrl_config.argtypes = [vp, C.c_int, ip, ip, ip, C.c_int, C.c_int, dp, C.c_double, dp, dp, dp, dp, C.c_int, C.c_int, ip, dp, C.c_double]
         L.rso_ctrl_reset.argtypes = [vp, vp]
         L.rso_ctrl_set_goal.argtypes = [vp, vp, dp]
@@ -175,6 +176,9 @@ class OracleData:
             pass
 
 
+CTRL_TYPES = {"OSC_POSE": 0, "OSC_POSITION": 1, "JOINT_POSITION": 2, "JOINT_TORQUE": 3}
+
+
 class OracleController:
     """OSC_POSE arm + GRIP gripper; see rsim_oracle.c `rso_ctrl_*`."""
 
@@ -184,12 +188,22 @@ class OracleController:
         n = len(cfg["qpos_idx"])
         i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)
         f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64)
-        self._keep = [i32(cfg["qpos_idx"]), i32(cfg["dof_idx"]), i32(cfg["act_idx"]), f64(cfg["kp"]), f64(cfg["input_min"]), f64(cfg["input_max"]),
-                      f64(cfg["output_min"]), f64(cfg["output_max"]), i32(cfg["grip_act"]), f64(cfg["grip_sign"])]
+        pad = lambda v, fill: f64((list(v) + [fill] * 8)[:8])   # the OSC_POSE entry point reads 6 of each; other types overwrite below
+        self._keep = [i32(cfg["qpos_idx"]), i32(cfg["dof_idx"]), i32(cfg["act_idx"]), pad(cfg.get("kp", []), 1.0), pad(cfg["input_min"], -1.0), pad(cfg["input_max"], 1.0),
+                      pad(cfg["output_min"], 0.0), pad(cfg["output_max"], 0.0), i32(cfg["grip_act"]), f64(cfg["grip_sign"])]
         k = self._keep
-        self._L.rso_ctrl_config(self.ptr, n, _ip(k[0]), _ip(k[1]), _ip(k[2]), int(cfg["eef_site"]), int(cfg["base_site"]), _dp(k[3]), float(cfg["damping_ratio"]),
-                                _dp(k[4]), _dp(k[5]), _dp(k[6]), _dp(k[7]), int(cfg["uncouple"]), len(cfg["grip_act"]), _ip(k[8]), _dp(k[9]), float(cfg["grip_speed"]))
+        self._L.rso_ctrl_config(self.ptr, n, _ip(k[0]), _ip(k[1]), _ip(k[2]), int(cfg["eef_site"]), int(cfg["base_site"]), _dp(k[3]), float(cfg.get("damping_ratio", 1.0)),
+                                _dp(k[4]), _dp(k[5]), _dp(k[6]), _dp(k[7]), int(cfg.get("uncouple", 1)), len(cfg["grip_act"]), _ip(k[8]), _dp(k[9]), float(cfg["grip_speed"]))
         self.n = n
+        ctype = CTRL_TYPES[cfg.get("type", "OSC_POSE")]
+        if ctype:
+            cdim = len(cfg["input_min"])
+            jkp = f64(cfg["kp"]) if ctype == 2 else np.zeros(8)
+            tl = cfg.get("torque_limits") or [[0.0] * 8, [0.0] * 8]
+            self._keep2 = [jkp, f64(cfg["input_min"]), f64(cfg["input_max"]), f64(cfg["output_min"]), f64(cfg["output_max"]), f64(tl[0]), f64(tl[1])]
+            k2 = self._keep2
+            self._L.rso_ctrl_set_type(self.ptr, ctype, cdim, _dp(k2[0]), float(cfg.get("damping_ratio", 1.0)), _dp(k2[1]), _dp(k2[2]), _dp(k2[3]),
+                                      _dp(k2[4]), _dp(k2[5]), _dp(k2[6]))
 
     def reset(self, data: OracleData):
         self._L.rso_ctrl_reset(self.ptr, data.ptr)

@@ -1677,8 +1677,12 @@ typedef struct {
   int qpos_idx[ARM_MAX], dof_idx[ARM_MAX], act_idx[ARM_MAX];
   int eef_site, base_site;
   double kp[6], kd[6];
-  double in_min[6], in_max[6], out_min[6], out_max[6];
+  double in_min[ARM_MAX], in_max[ARM_MAX], out_min[ARM_MAX], out_max[ARM_MAX];
   int uncouple;
+  /* part-controller type: 0 OSC_POSE (osc.py), 1 OSC_POSITION (osc.py use_ori=False), 2 JOINT_POSITION (generic/joint_pos.py),
+   * 3 JOINT_TORQUE (generic/joint_tor.py); cdim = control_dim of the arm part */
+  int type, cdim;
+  double jkp[ARM_MAX], jkd[ARM_MAX], tl_lo[ARM_MAX], tl_hi[ARM_MAX], goal_j[ARM_MAX];
   double nullspace_kp;
   /* gripper */
   int ngrip;               /* number of gripper actuators (2) */
@@ -1707,6 +1711,17 @@ void rso_ctrl_config(rso_ctrl *c, int ndof, const int *qpos_idx, const int *dof_
   c->ngrip = ngrip;
   for (int i = 0; i < ngrip; i++) { c->grip_act[i] = grip_act[i]; c->grip_sign[i] = grip_sign[i]; }
   c->grip_speed = grip_speed;
+  c->type = 0; c->cdim = 6;
+}
+
+/* the other arm part-controller types of controller_factory.py:73-159: per-joint gains / scaling for the joint-space ones
+ * (joint_pos.py:135-175: kd = 2 sqrt(kp) damping_ratio; joint_tor.py:95-96: torque_limits default to the actuator ctrlrange) */
+void rso_ctrl_set_type(rso_ctrl *c, int type, int cdim, const double *jkp, double damping_ratio, const double *in_min, const double *in_max,
+                       const double *out_min, const double *out_max, const double *tl_lo, const double *tl_hi) {
+  c->type = type; c->cdim = cdim;
+  for (int i = 0; i < cdim; i++) { c->in_min[i] = in_min[i]; c->in_max[i] = in_max[i]; c->out_min[i] = out_min[i]; c->out_max[i] = out_max[i]; }
+  if (type == 2) for (int i = 0; i < c->ndof; i++) { c->jkp[i] = jkp[i]; c->jkd[i] = 2 * sqrt(jkp[i]) * damping_ratio; }
+  if (type == 3) for (int i = 0; i < c->ndof; i++) { c->tl_lo[i] = tl_lo[i]; c->tl_hi[i] = tl_hi[i]; }
 }
 
 void rso_osc_goal(const double *scaled, const double *ep, const double *eR, const double *op, const double *oR, double *goal_pos, double *goal_ori);
@@ -1718,6 +1733,8 @@ void rso_ctrl_reset(rso_ctrl *c, rso_data *d) {
   memcpy(c->goal_pos, d->site_xpos + 3 * c->eef_site, sizeof(c->goal_pos));
   memcpy(c->goal_ori, d->site_xmat + 9 * c->eef_site, sizeof(c->goal_ori));
   for (int i = 0; i < 4; i++) { c->grip_action[i] = 0; c->grip_goal[i] = 0; }
+  /* joint_pos.py:268-276 reset_goal: goal_qpos = joint_pos; joint_tor.py:170-178: goal_torque = 0 */
+  for (int i = 0; i < c->ndof; i++) c->goal_j[i] = c->type == 2 ? d->qpos[c->qpos_idx[i]] : 0.0;
 }
 
 /* float32 quat2mat of the reference (transform_utils.py:461-487 casts to float32; under NumPy>=2 the
@@ -1750,17 +1767,23 @@ static void mat3T_mul(double *r, const double *a, const double *b) { /* a^T b */
 /* set_goal at a policy step: OSC (osc.py:225-283, 306-401, mode "achieved", frame "base", delta input) + gripper
  * (composite_controller.py:97-103 -> panda_gripper.py:43-58 -> simple_grip.py:110-148) */
 void rso_ctrl_set_goal(rso_ctrl *c, rso_data *d, const double *action) {
-  double scaled[6];
-  for (int i = 0; i < 6; i++) { /* controller.py:149-168 */
+  double scaled[ARM_MAX] = {0};
+  for (int i = 0; i < c->cdim; i++) { /* controller.py:149-168 */
     double scale = fabs(c->out_max[i] - c->out_min[i]) / fabs(c->in_max[i] - c->in_min[i]);
     double a = fmax(c->in_min[i], fmin(c->in_max[i], action[i]));
     scaled[i] = (a - 0.5 * (c->in_max[i] + c->in_min[i])) * scale + 0.5 * (c->out_max[i] + c->out_min[i]);
   }
-  rso_osc_goal(scaled, d->site_xpos + 3 * c->eef_site, d->site_xmat + 9 * c->eef_site, d->site_xpos + 3 * c->base_site, d->site_xmat + 9 * c->base_site,
-               c->goal_pos, c->goal_ori);
+  if (c->type == 2) {        /* joint_pos.py:200-236: goal_qpos = joint_pos + scaled delta (no position limits) */
+    for (int i = 0; i < c->ndof; i++) c->goal_j[i] = d->qpos[c->qpos_idx[i]] + scaled[i];
+  } else if (c->type == 3) { /* joint_tor.py:111-128: goal_torque = clip(scale_action(a), torque_limits) */
+    for (int i = 0; i < c->ndof; i++) c->goal_j[i] = fmax(c->tl_lo[i], fmin(c->tl_hi[i], scaled[i]));
+  } else {                   /* osc.py:255-263: OSC_POSITION passes a zero orientation delta (scaled[3..5] stay 0) */
+    rso_osc_goal(scaled, d->site_xpos + 3 * c->eef_site, d->site_xmat + 9 * c->eef_site, d->site_xpos + 3 * c->base_site, d->site_xmat + 9 * c->base_site,
+                 c->goal_pos, c->goal_ori);
+  }
   /* gripper */
   if (c->ngrip > 0) {
-    double a = action[6], sg = a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0);
+    double a = action[c->cdim], sg = a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0);
     for (int i = 0; i < c->ngrip; i++) {
       c->grip_action[i] = fmax(-1.0, fmin(1.0, c->grip_action[i] + c->grip_sign[i] * c->grip_speed * sg));
       c->grip_goal[i] = c->grip_action[i];
@@ -1884,6 +1907,15 @@ void rso_ctrl_run(rso_ctrl *c, rso_data *d) {
     for (int r = 0; r < 3; r++) { J[r * n + i] = jp[r * nv + c->dof_idx[i]]; J[(3 + r) * n + i] = jr[r * nv + c->dof_idx[i]]; }
     for (int j = 0; j < n; j++) M[i * n + j] = d->qM[c->dof_idx[i] * nv + c->dof_idx[j]];
   }
+  if (c->type == 2) {        /* joint_pos.py:238-266: M_arm (kp (goal - q) - kd qd) + qfrc_bias[arm] */
+    for (int i = 0; i < n; i++) {
+      double t = bias[i];
+      for (int j = 0; j < n; j++) t += M[i * n + j] * (c->jkp[j] * (c->goal_j[j] - q[j]) - c->jkd[j] * qd[j]);
+      c->torques[i] = t;
+    }
+  } else if (c->type == 3) { /* joint_tor.py:130-167: goal_torque + qfrc_bias[arm] */
+    for (int i = 0; i < n; i++) c->torques[i] = c->goal_j[i] + bias[i];
+  } else
   rso_osc_torques(c->kp, c->kd, d->site_xpos + 3 * c->eef_site, d->site_xmat + 9 * c->eef_site, ev, d->site_xpos + 3 * c->base_site,
                   d->site_xmat + 9 * c->base_site, bv, c->goal_pos, c->goal_ori, J, M, bias, q, qd, c->initial_joint, c->nullspace_kp, c->uncouple, n,
                   c->torques);

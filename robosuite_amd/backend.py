@@ -34,9 +34,19 @@ class RsimError(RuntimeError):
 
 class CtrlDesc(C.Structure):
     _fields_ = [("ndof", C.c_int32), ("qpos_idx", C.c_int32 * 8), ("dof_idx", C.c_int32 * 8), ("act_idx", C.c_int32 * 8), ("eef_site", C.c_int32),
-                ("base_site", C.c_int32), ("kp", C.c_float * 6), ("damping_ratio", C.c_float), ("input_min", C.c_float * 6), ("input_max", C.c_float * 6),
-                ("output_min", C.c_float * 6), ("output_max", C.c_float * 6), ("uncouple_pos_ori", C.c_int32), ("nullspace_kp", C.c_float),
-                ("ngrip", C.c_int32), ("grip_act", C.c_int32 * 4), ("grip_sign", C.c_float * 4), ("grip_speed", C.c_float)]
+                ("base_site", C.c_int32), ("kp", C.c_float * 8), ("damping_ratio", C.c_float), ("input_min", C.c_float * 8), ("input_max", C.c_float * 8),
+                ("output_min", C.c_float * 8), ("output_max", C.c_float * 8), ("uncouple_pos_ori", C.c_int32), ("nullspace_kp", C.c_float),
+                ("ngrip", C.c_int32), ("grip_act", C.c_int32 * 4), ("grip_sign", C.c_float * 4), ("grip_speed", C.c_float),
+                ("type", C.c_int32), ("torque_min", C.c_float * 8), ("torque_max", C.c_float * 8)]
+
+
+# arm part-controller types with an in-kernel implementation (include/rsim.h enum rsim_ctrl_type; names = the reference's config "type" strings)
+CTRL_TYPES = {"OSC_POSE": 0, "OSC_POSITION": 1, "JOINT_POSITION": 2, "JOINT_TORQUE": 3}
+
+
+def control_dim(cfg: dict) -> int:
+    t = cfg.get("type", "OSC_POSE")
+    return {"OSC_POSE": 6, "OSC_POSITION": 3}.get(t, len(cfg["qpos_idx"]))
 
 
 class TaskDesc(C.Structure):
@@ -63,10 +73,23 @@ def ctrl_desc(cfg: dict) -> CtrlDesc:
     for i in range(n):
         d.qpos_idx[i], d.dof_idx[i], d.act_idx[i] = cfg["qpos_idx"][i], cfg["dof_idx"][i], cfg["act_idx"][i]
     d.eef_site, d.base_site = cfg["eef_site"], cfg["base_site"]
-    for i in range(6):
-        d.kp[i] = cfg["kp"][i]
+    ctype = cfg.get("type", "OSC_POSE")
+    if ctype not in CTRL_TYPES:
+        raise RsimError(f"part controller type {ctype!r} has no in-kernel implementation (have {sorted(CTRL_TYPES)})")
+    d.type = CTRL_TYPES[ctype]
+    cdim = control_dim(cfg)
+    for i, v in enumerate(cfg.get("kp", [])[:8]):
+        d.kp[i] = v
+    for k in ("input_min", "input_max", "output_min", "output_max"):
+        if len(cfg[k]) != cdim:
+            raise RsimError(f"controller {ctype}: {k} has {len(cfg[k])} entries, control_dim is {cdim}")
+    for i in range(cdim):
         d.input_min[i], d.input_max[i] = cfg["input_min"][i], cfg["input_max"][i]
         d.output_min[i], d.output_max[i] = cfg["output_min"][i], cfg["output_max"][i]
+    tl = cfg.get("torque_limits")
+    if tl:
+        for i in range(n):
+            d.torque_min[i], d.torque_max[i] = tl[0][i], tl[1][i]
     d.damping_ratio = cfg.get("damping_ratio", 1.0)
     d.uncouple_pos_ori = int(cfg.get("uncouple", 1))
     d.nullspace_kp = cfg.get("nullspace_kp", 10.0)
@@ -153,7 +176,7 @@ class HipModel:
         d = ctrl_desc(cfg)
         _chk(self._L.rsim_model_set_controller(self.ptr, C.byref(d)))
         self.ctrl_cfg = cfg
-        self.action_dim = 6 + (1 if cfg.get("grip_act") else 0)
+        self.action_dim = control_dim(cfg) + (1 if cfg.get("grip_act") else 0)
 
     def set_task(self, task: dict):
         """task: dict(obs=[(kind, a, b), ...], task="lift", object_body, grip_site, table_height, lift_margin, reward_scale, reward_shaping,

@@ -424,9 +424,26 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
   }
   if (d->eef_site < 0 || d->eef_site >= m->nsite || d->base_site < 0 || d->base_site >= m->nsite) return fail("controller: bad site id");
   c.eef_site = d->eef_site; c.base_site = d->base_site;
-  for (int i = 0; i < 6; i++) {
+  if (d->type < RSIM_CTRL_OSC_POSE || d->type > RSIM_CTRL_JOINT_TORQUE) return fail("controller: unknown part-controller type %d", d->type);
+  c.type = d->type;
+  c.cdim = d->type == RSIM_CTRL_OSC_POSE ? 6 : d->type == RSIM_CTRL_OSC_POSITION ? 3 : d->ndof;
+  const int ngain = d->type == RSIM_CTRL_JOINT_POSITION ? d->ndof : (d->type == RSIM_CTRL_JOINT_TORQUE ? 0 : 6);
+  for (int i = 0; i < ngain; i++) {
+    if (!(d->kp[i] >= 0.f)) return fail("controller: negative / NaN kp");
     c.kp[i] = d->kp[i]; c.kd[i] = 2.f * sqrtf(d->kp[i]) * d->damping_ratio;
+  }
+  for (int i = 0; i < c.cdim; i++) {
+    if (!(d->input_max[i] > d->input_min[i])) return fail("controller: input_max <= input_min");
     c.in_min[i] = d->input_min[i]; c.in_max[i] = d->input_max[i]; c.out_min[i] = d->output_min[i]; c.out_max[i] = d->output_max[i];
+  }
+  {
+    bool given = false;   // torque_limits=None -> actuator ctrlrange (joint_tor.py:95-96, controller.py:313-322)
+    for (int i = 0; i < d->ndof; i++) given |= d->torque_min[i] != 0.f || d->torque_max[i] != 0.f;
+    const double* cr = m->D("actuator_ctrlrange");
+    for (int i = 0; i < d->ndof; i++) {
+      c.tl_lo[i] = given ? d->torque_min[i] : (float)cr[2 * d->act_idx[i]];
+      c.tl_hi[i] = given ? d->torque_max[i] : (float)cr[2 * d->act_idx[i] + 1];
+    }
   }
   c.uncouple = d->uncouple_pos_ori; c.nullspace_kp = d->nullspace_kp > 0 ? d->nullspace_kp : 10.f;
   c.ngrip = d->ngrip;
@@ -435,7 +452,7 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
     c.grip_act[i] = d->grip_act[i]; c.grip_sign[i] = d->grip_sign[i];
   }
   c.grip_speed = d->grip_speed;
-  c.action_dim = 6 + (d->ngrip > 0 ? 1 : 0);
+  c.action_dim = c.cdim + (d->ngrip > 0 ? 1 : 0);
   return 0;
 }
 

@@ -55,7 +55,9 @@ struct DCtrl {
   int ndof;
   int qpos_idx[RSIM_ARM_MAX], dof_idx[RSIM_ARM_MAX], act_idx[RSIM_ARM_MAX];
   int eef_site, base_site;
-  float kp[6], kd[6], in_min[6], in_max[6], out_min[6], out_max[6];
+  float kp[RSIM_ARM_MAX], kd[RSIM_ARM_MAX], in_min[RSIM_ARM_MAX], in_max[RSIM_ARM_MAX], out_min[RSIM_ARM_MAX], out_max[RSIM_ARM_MAX];
+  float tl_lo[RSIM_ARM_MAX], tl_hi[RSIM_ARM_MAX];
+  int type, cdim;   // rsim_ctrl_type, control_dim of the arm part
   int uncouple;
   float nullspace_kp;
   int ngrip;
@@ -65,6 +67,7 @@ struct DCtrl {
   int action_dim;
 };
 // controller state block per env (floats): goal_pos[3] goal_ori[9] q0[8] grip_action[4] torques[8]
+#define RSIM_CS_GOALQ 0    /* joint-space parts: goal_qpos / goal_torque[8] share the task-space goal slots */
 #define RSIM_CS_GOALPOS 0
 #define RSIM_CS_GOALORI 3
 #define RSIM_CS_Q0 12

@@ -1625,12 +1625,33 @@ struct Sim {
   __device__ __forceinline__ void ctrl_set_goal(const float* action) {
     const LaneConst K = fetchK();
     const DCtrl& c = m.ctrl;
+    if (c.type >= RSIM_CTRL_JOINT_POSITION) {
+      // joint-space parts: lane i scales its own component (controller.py:149-168).  JOINT_POSITION: goal_qpos = joint_pos + delta
+      // (joint_pos.py:200-236); JOINT_TORQUE: goal_torque = clip(scaled, torque_limits) (joint_tor.py:111-128)
+      const int li = lane & (RSIM_ARM_MAX - 1);
+      const float imin = sel(c.in_min, li), imax = sel(c.in_max, li), omin = sel(c.out_min, li), omax = sel(c.out_max, li);
+      const float tlo = sel(c.tl_lo, li), thi = sel(c.tl_hi, li);
+      if (lane < c.ndof) {
+        const float scale = fabsf(omax - omin) / fabsf(imax - imin);
+        const float a = fmaxf(imin, fminf(imax, action[lane]));
+        const float sv = (a - 0.5f * (imax + imin)) * scale + 0.5f * (omax + omin);
+        sm.cstate[RSIM_CS_GOALQ + lane] = c.type == RSIM_CTRL_JOINT_POSITION ? sm.qpos[K.cq] + sv : fmaxf(tlo, fminf(thi, sv));
+      }
+      if (lane < c.ngrip) {
+        const float a = action[c.cdim], sg = a > 0 ? 1.f : (a < 0 ? -1.f : 0.f);
+        sm.cstate[RSIM_CS_GRIP + lane] = fmaxf(-1.f, fminf(1.f, sm.cstate[RSIM_CS_GRIP + lane] + K.cgs * c.grip_speed * sg));
+      }
+      SYNC();
+      return;
+    }
     float sc[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      float scale = fabsf(c.out_max[i] - c.out_min[i]) / fabsf(c.in_max[i] - c.in_min[i]);
-      float a = fmaxf(c.in_min[i], fminf(c.in_max[i], action[i]));
-      sc[i] = (a - 0.5f * (c.in_max[i] + c.in_min[i])) * scale + 0.5f * (c.out_max[i] + c.out_min[i]);
+    for (int i = 0; i < 6; i++) {   // OSC_POSITION (cdim 3): zero orientation delta, osc.py:255-263
+      if (i < c.cdim) {
+        float scale = fabsf(c.out_max[i] - c.out_min[i]) / fabsf(c.in_max[i] - c.in_min[i]);
+        float a = fmaxf(c.in_min[i], fminf(c.in_max[i], action[i]));
+        sc[i] = (a - 0.5f * (c.in_max[i] + c.in_min[i])) * scale + 0.5f * (c.out_max[i] + c.out_min[i]);
+      } else sc[i] = 0.f;
     }
     V3 op = ld3(sm.spos + 3 * c.base_site), ep = ld3(sm.spos + 3 * c.eef_site);
     M3 oR = ldm(sm.smat + 9 * c.base_site), eR = ldm(sm.smat + 9 * c.eef_site);
@@ -1653,7 +1674,7 @@ struct Sim {
       stm(sm.cstate + RSIM_CS_GOALORI, go);
     }
     if (lane < c.ngrip) {
-      const float a = action[6], sg = a > 0 ? 1.f : (a < 0 ? -1.f : 0.f);
+      const float a = action[c.cdim], sg = a > 0 ? 1.f : (a < 0 ? -1.f : 0.f);
       sm.cstate[RSIM_CS_GRIP + lane] = fmaxf(-1.f, fminf(1.f, sm.cstate[RSIM_CS_GRIP + lane] + K.cgs * c.grip_speed * sg));
     }
     SYNC();
@@ -1664,7 +1685,10 @@ struct Sim {
     const LaneConst K = fetchK();
     const DCtrl& c = m.ctrl;
     if (lane < c.ndof) sm.cstate[RSIM_CS_Q0 + lane] = sm.qpos[K.cq];
-    if (lane == 0) {
+    if (c.type >= RSIM_CTRL_JOINT_POSITION) {   // joint_pos.py:268-276 (goal_qpos = joint_pos), joint_tor.py:170-178 (goal_torque = 0)
+      if (lane < c.ndof) sm.cstate[RSIM_CS_GOALQ + lane] = c.type == RSIM_CTRL_JOINT_POSITION ? sm.qpos[K.cq] : 0.f;
+      if (lane < RSIM_GRIP_MAX) sm.cstate[RSIM_CS_GRIP + lane] = 0.f;
+    } else if (lane == 0) {
       st3(sm.cstate + RSIM_CS_GOALPOS, ld3(sm.spos + 3 * c.eef_site));
       for (int k = 0; k < 9; k++) sm.cstate[RSIM_CS_GOALORI + k] = sm.smat[9 * c.eef_site + k];
       for (int i = 0; i < RSIM_GRIP_MAX; i++) sm.cstate[RSIM_CS_GRIP + i] = 0.f;
@@ -1675,9 +1699,44 @@ struct Sim {
   // OperationalSpaceController.run_controller (osc.py:403-495) + SimpleGripController, tau clipped into ctrl.
   // Lambda^-1 = J Ma^-1 J^T = Y^T Y with Y = La^-1 J^T (register Cholesky of the arm block, 6 forward solves);
   // N^T Ma tmp = Ma tmp - J^T Lambda (J tmp), so no explicit inverse of Ma is ever formed.
+  // arm torques -> clipped ctrl (fixed_base_robot.py:143-153) + SimpleGripController output (simple_grip.py:150-186)
+  __device__ __forceinline__ void ctrl_write(const LaneConst& K, float tq) {
+    const DCtrl& c = m.ctrl;
+    const float alo = __shfl(K.acr0, K.ca), ahi = __shfl(K.acr1, K.ca);
+    if (lane < c.ndof) {
+      sm.cstate[RSIM_CS_TAU + lane] = tq;
+      sm.ctrl[K.ca] = fmaxf(alo, fminf(ahi, tq));
+    }
+    const float glo = __shfl(K.acr0, K.cga), ghi = __shfl(K.acr1, K.cga);
+    if (lane < c.ngrip) sm.ctrl[K.cga] = fmaxf(glo, fminf(ghi, 0.5f * (ghi + glo) + 0.5f * (ghi - glo) * sm.cstate[RSIM_CS_GRIP + lane]));
+    SYNC();
+  }
+
+  // JointPositionController.run_controller (joint_pos.py:238-266): tau = M_arm (kp (goal - q) - kd qd) + qfrc_bias[arm];
+  // JointTorqueController.run_controller (joint_tor.py:130-167): tau = goal_torque + qfrc_bias[arm].  Lane i owns arm joint i.
+  __device__ __forceinline__ void ctrl_run_joint(const LaneConst& K) {
+    const DCtrl& c = m.ctrl;
+    const int n = c.ndof;
+    constexpr int NA = RSIM_ARM_MAX;
+    const int li = lane & (NA - 1);
+    const int di = lane < n ? K.cd : 0, qi = lane < n ? K.cq : 0;
+    const float goal = lane < n ? sm.cstate[RSIM_CS_GOALQ + lane] : 0.f;
+    float tq = lane < n ? sm.qfrc_bias[di] : 0.f;
+    if (c.type == RSIM_CTRL_JOINT_POSITION) {
+      const float des = lane < n ? sel(c.kp, li) * (goal - sm.qpos[qi]) - sel(c.kd, li) * sm.qvel[di] : 0.f;
+#pragma unroll
+      for (int k = 0; k < NA; k++) {
+        const float mk = (lane < n && k < n) ? sm.M[di * NVP + c.dof_idx[k]] : 0.f;
+        tq = fmaf(mk, bcast(des, k), tq);
+      }
+    } else tq += goal;
+    ctrl_write(K, tq);
+  }
+
   __device__ __forceinline__ void ctrl_run() {
     const LaneConst K = fetchK();
     const DCtrl& c = m.ctrl;
+    if (c.type >= RSIM_CTRL_JOINT_POSITION) { ctrl_run_joint(K); return; }
     const int n = c.ndof;
     constexpr int NA = RSIM_ARM_MAX;
     float* Jm = sm.u.k.Jm;             // [6][NA]  arm Jacobian (lin rows 0..2, ang rows 3..5)
@@ -1777,22 +1836,13 @@ struct Sim {
         for (int r = 0; r < 6; r++) wrench[r] = bcast(wl, r);
       }
     }
-    const float alo = __shfl(K.acr0, K.ca), ahi = __shfl(K.acr1, K.ca);
+    float tq = 0.f;
     if (lane < n) {
-      float tq = sm.qfrc_bias[di] + matmp;
+      tq = sm.qfrc_bias[di] + matmp;
 #pragma unroll
       for (int r = 0; r < 6; r++) tq = fmaf(comp6(jc, r < 3 ? r + 3 : r - 3), wrench[r] - z[r], tq);
-      sm.cstate[RSIM_CS_TAU + lane] = tq;
-      const int a = K.ca;
-      sm.ctrl[a] = fmaxf(alo, fminf(ahi, tq));
     }
-    const float glo = __shfl(K.acr0, K.cga), ghi = __shfl(K.acr1, K.cga);
-    if (lane < c.ngrip) {
-      const int a = K.cga;
-      const float lo_ = glo, hi_ = ghi;
-      sm.ctrl[a] = fmaxf(lo_, fminf(hi_, 0.5f * (hi_ + lo_) + 0.5f * (hi_ - lo_) * sm.cstate[RSIM_CS_GRIP + lane]));
-    }
-    SYNC();
+    ctrl_write(K, tq);
   }
 
   // ---------------------------------------------------------------- Newton solver (primal): lane r owns constraint row r

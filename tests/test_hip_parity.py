@@ -81,6 +81,30 @@ def test_fused_control_step_tracks_oracle_and_golden(tag):
     assert np.abs(hb.get("ctrl")[0] - g["ctrl"][-1]).max() < 2e-2 * max(1.0, np.abs(g["ctrl"][-1]).max())
 
 
+@pytest.mark.parametrize("tag", ("ctl_joint_position", "ctl_joint_torque", "ctl_osc_position"))
+def test_other_part_controllers_track_the_reference_env_loop(tag):
+    """In-kernel JOINT_POSITION / JOINT_TORQUE / OSC_POSITION arm parts (+ GRIP) vs fixtures recorded with the reference's own controller
+    classes (generic/joint_pos.py, generic/joint_tor.py, arm/osc.py use_ori=False) and vs the oracle restatement; same tolerances as OSC_POSE."""
+    g, cfg, flat = load_golden(tag)
+    nq = flat.nq
+    om, od, oc = make_oracle(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=2)
+    assert hm.action_dim == g["actions"].shape[1]
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0; od.forward(); oc.reset(od)
+    hb.set("qpos", s0[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    for t in range(len(g["actions"])):
+        a = torch.tensor(np.repeat(g["actions"][t][None], 2, 0), dtype=torch.float32, device="cuda")
+        hb.control_step(a, 25)
+        oc.env_step(od, g["actions"][t], 25)
+        hq, hv = hb.get("qpos")[0], hb.get("qvel")[0]
+        assert np.abs(hq - od.qpos).max() < 5e-4 and np.abs(hv - od.qvel).max() < 5e-3, t
+        assert np.abs(hq - g["states"][t + 1][1:1 + nq]).max() < 5e-4 and np.abs(hv - g["states"][t + 1][1 + nq:]).max() < 5e-3, t
+        assert np.abs(hb.get("ctrl")[0] - g["ctrl"][t]).max() < 2e-2 * max(1.0, np.abs(g["ctrl"][t]).max()), t
+    assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[1])
+
+
 def test_replay_is_bitwise_deterministic():
     """The reference's only numeric assert on sim state is bitwise replay equality (test_action_playback.py:46-68)."""
     g, cfg, flat = load_golden("seed1_full")

@@ -45,6 +45,27 @@ def test_env_step_replay_matches_reference_loop(tag):
         assert np.abs(od.qvel - g["states"][t + 1][1 + nq:]).max() < 5e-4
 
 
+CTL_TAGS = ("ctl_joint_position", "ctl_joint_torque", "ctl_osc_position")
+
+
+@pytest.mark.parametrize("tag", CTL_TAGS)
+def test_other_part_controllers_match_reference_loop(tag):
+    """JOINT_POSITION (generic/joint_pos.py:200-266), JOINT_TORQUE (generic/joint_tor.py:111-167) and OSC_POSITION (osc.py:255-263, use_ori=False):
+    the C restatement replays env.step fixtures recorded with the reference's own controller classes (tools/gen_golden.py --controllers-only)."""
+    g, cfg, flat = load_golden(tag)
+    om, od, oc = make_oracle(flat, cfg)
+    nq = flat.nq
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0
+    od.forward(); oc.reset(od)
+    assert g["actions"].shape[1] == len(cfg["input_min"]) + 1
+    for t in range(len(g["actions"])):
+        oc.env_step(od, g["actions"][t], 25)
+        assert np.abs(od.ctrl - g["ctrl"][t]).max() < 1e-4 * max(1.0, np.abs(g["ctrl"][t]).max())
+        assert np.abs(od.qpos - g["states"][t + 1][1:1 + nq]).max() < 1e-6
+        assert np.abs(od.qvel - g["states"][t + 1][1 + nq:]).max() < 1e-5
+
+
 def test_reset_path_known_answers():
     """values produced by the reference's own reset code (placement_samplers.py:221-309,
     robots/robot.py:247-259, lift.py:311-318) for seed 0, re-derived from the documented draw order."""

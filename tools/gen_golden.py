@@ -49,6 +49,71 @@ def controller_cfg(env):
     )
 
 
+def record_lift_controller(seed, n_steps, action_scale, ctype):
+    """Env-level fixture for another arm part-controller type (JOINT_POSITION / JOINT_TORQUE / OSC_POSITION): the reference's own
+    controller classes drive the env; only states / ctrl / obs / rewards are recorded (the controller is pinned end to end)."""
+    from robosuite.controllers import load_part_controller_config
+    from robosuite.controllers.composite.composite_controller_factory import refactor_composite_controller_config
+
+    part = load_part_controller_config(default_controller=ctype)
+    ccfg = refactor_composite_controller_config(part, "Panda", ["right"])
+    env = suite.make("Lift", robots="Panda", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
+                     reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed, controller_configs=ccfg)
+    obs = env.reset()
+    sim, robot = env.sim, env.robots[0]
+    ctl = robot.part_controllers["right"]
+    flat = sim.model._model._flat
+    adim = env.action_dim
+    rng = np.random.default_rng(10**6 + seed)
+    keys = [k for k in obs.keys()]
+    actions, states, rewards, obs_flat, ctrls = [], [sim.get_state().flatten()], [], [], []
+    for t in range(n_steps):
+        a = action_scale * rng.uniform(-1, 1, adim)
+        obs, r, done, info = env.step(a)
+        ctrls.append(np.array(sim.data.ctrl)); actions.append(a); states.append(sim.get_state().flatten()); rewards.append(r)
+        obs_flat.append(np.concatenate([np.atleast_1d(obs[k]).astype(np.float64) for k in keys if not k.endswith("-state")]))
+    tag = f"ctl_{ctype.lower()}"
+    np.savez_compressed(os.path.join(GOLD, f"lift_panda_{tag}.npz"), actions=np.array(actions), states=np.array(states), rewards=np.array(rewards),
+                        obs=np.array(obs_flat), ctrl=np.array(ctrls), cube_size=flat.geom_size[flat.name2id("geom", "cube_g0")])
+    mjcf.save_model(flat, os.path.join(GOLD, f"lift_panda_{tag}.rsim"))
+    cfg = controller_cfg_generic(env, ctype)
+    cfg["obs_keys"] = [k for k in keys if not k.endswith("-state")]
+    cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in cfg["obs_keys"]]
+    with open(os.path.join(GOLD, f"lift_panda_{tag}.cfg.json"), "w") as f:
+        json.dump(cfg, f, indent=1)
+    print(tag, "action_dim", adim, "steps", n_steps, "final cube z", states[-1][1 + 11])
+
+
+def controller_cfg_generic(env, ctype):
+    robot = env.robots[0]
+    ctl = robot.part_controllers["right"]
+    sim = env.sim
+    base = dict(
+        type=ctype,
+        qpos_idx=[int(i) for i in ctl.qpos_index], dof_idx=[int(i) for i in ctl.qvel_index],
+        act_idx=[int(i) for i in robot._ref_actuators_indexes_dict["right"]],
+        eef_site=int(sim.model.site_name2id(ctl.ref_name)),
+        base_site=int(sim.model.site_name2id(f"{ctl.naming_prefix}{ctl.part_name}_center")),
+        input_min=[float(x) for x in ctl.input_min], input_max=[float(x) for x in ctl.input_max],
+        output_min=[float(x) for x in ctl.output_min], output_max=[float(x) for x in ctl.output_max],
+        grip_act=[int(i) for i in robot._ref_actuators_indexes_dict["right_gripper"]],
+        grip_sign=[-1.0, 1.0], grip_speed=float(robot.gripper["right"].speed),
+        grip_qpos_idx=[int(i) for i in robot._ref_gripper_joint_pos_indexes["right"]],
+        grip_dof_idx=[int(i) for i in robot._ref_gripper_joint_vel_indexes["right"]],
+    )
+    if ctype in ("JOINT_POSITION", "OSC_POSITION"):
+        base["kp"] = [float(x) for x in np.atleast_1d(ctl.kp)]
+        base["kd"] = [float(x) for x in np.atleast_1d(ctl.kd)]
+        base["damping_ratio"] = 1.0
+    if ctype == "OSC_POSITION":
+        base["uncouple"] = int(ctl.uncoupling)
+    if ctype == "JOINT_TORQUE":
+        base["torque_limits"] = [[float(x) for x in ctl.torque_limits[0]], [float(x) for x in ctl.torque_limits[1]]]
+    if ctype in ("JOINT_POSITION", "JOINT_TORQUE"):
+        base["use_torque_compensation"] = int(getattr(ctl, "use_torque_compensation", True))
+    return base
+
+
 def record_lift(seed, n_steps, action_scale, tag):
     env = suite.make("Lift", robots="Panda", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False,
                      use_object_obs=True, reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed)
@@ -102,6 +167,13 @@ def record_lift(seed, n_steps, action_scale, tag):
 
 
 if __name__ == "__main__":
+    if "--controllers-only" in sys.argv:
+        for ct in ("JOINT_POSITION", "JOINT_TORQUE", "OSC_POSITION"):
+            record_lift_controller(seed=2, n_steps=30, action_scale=1.0, ctype=ct)
+        sys.exit(0)
     # gentle actions (reference test convention test_action_playback.py:48) and full-range actions
     record_lift(seed=0, n_steps=40, action_scale=0.1, tag="seed0_gentle")
     record_lift(seed=1, n_steps=40, action_scale=1.0, tag="seed1_full")
+    if "--controllers" in sys.argv:
+        for ct in ("JOINT_POSITION", "JOINT_TORQUE", "OSC_POSITION"):
+            record_lift_controller(seed=2, n_steps=30, action_scale=1.0, ctype=ct)
