@@ -14,10 +14,21 @@
 #include "../../include/rsim.h"
 #include "rsim_internal.h"
 
+// one set of launchers per compiled kernel configuration (rsim_step.hip is built once per RSIM_CFG)
+#define RSIM_NCFG 2
 extern "C" int rsim_launch_step_cfg0(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
 extern "C" int rsim_launch_ctrl_reset_cfg0(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
+extern "C" int rsim_limits_cfg0(int* lim);
+extern "C" int rsim_launch_step_cfg1(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
+extern "C" int rsim_launch_ctrl_reset_cfg1(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
+extern "C" int rsim_limits_cfg1(int* lim);
+typedef int (*step_fn)(const DModel*, const DBatch*, const float*, int, int, hipStream_t);
+typedef int (*creset_fn)(const DModel*, const DBatch*, const unsigned char*, hipStream_t);
+typedef int (*limits_fn)(int*);
+static const step_fn k_step_launch[RSIM_NCFG] = {rsim_launch_step_cfg0, rsim_launch_step_cfg1};
+static const creset_fn k_creset_launch[RSIM_NCFG] = {rsim_launch_ctrl_reset_cfg0, rsim_launch_ctrl_reset_cfg1};
+static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1};
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream);
-extern "C" int rsim_cfg0_limits(int* lim);
 extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr* d, unsigned long long seed, unsigned long long step, hipStream_t stream);
 
 struct rsim_model;
@@ -85,6 +96,7 @@ struct rsim_batch {
   size_t fcount[RSIM_FIELD_COUNT];
   int fis_int[RSIM_FIELD_COUNT];
   int lim[8];
+  int cfg;   // compiled kernel configuration serving this model (smallest that fits)
   // host cache for jacobians
   long gen, cache_gen;
   int cache_env;
@@ -505,10 +517,15 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   b->gen = 1; b->cache_gen = 0; b->cache_env = -1;
   b->db.prof_env = -1;
   b->d_bank = nullptr; b->d_patch = nullptr; b->d_ft_base = nullptr;
-  rsim_cfg0_limits(b->lim);
   const int ncg = (int)m->cg.size();
-  if (m->nbody > b->lim[0] || m->njnt > b->lim[1] || m->nv > b->lim[2] || m->nq > b->lim[2] + 8 || m->nu > b->lim[2] || ncg > b->lim[3] || m->nsite > b->lim[4] ||
-      m->npair > b->lim[7]) {
+  b->cfg = -1;
+  for (int c = 0; c < RSIM_NCFG && b->cfg < 0; c++) {
+    k_limits[c](b->lim);
+    if (!(m->nbody > b->lim[0] || m->njnt > b->lim[1] || m->nv > b->lim[2] || m->nq > b->lim[2] + 8 || m->nu > 16 || ncg > b->lim[3] || m->nsite > b->lim[4] ||
+          m->npair > b->lim[7]))
+      b->cfg = c;
+  }
+  if (b->cfg < 0) {
     int r = fail("rsim_batch_create: model (nbody %d njnt %d nv %d ncgeom %d nsite %d npair %d) exceeds the compiled kernel configuration (%d %d %d %d %d .. %d)",
                  m->nbody, m->njnt, m->nv, ncg, m->nsite, m->npair, b->lim[0], b->lim[1], b->lim[2], b->lim[3], b->lim[4], b->lim[7]);
     delete b;
@@ -638,7 +655,7 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   b->dm.ctrl = b->m->ctrl;
   if ((flags & RF_OBS) && !b->dm.task.enabled) return fail("the task (observation / reward epilogue) was configured after the batch was created");
   if ((flags & RF_CTRL) && !b->dm.ctrl.enabled) return fail("no controller configured (rsim_model_set_controller)");
-  int e = rsim_launch_step_cfg0(&b->dm, &b->db, actions, n_sub, flags, b->stream);
+  int e = k_step_launch[b->cfg](&b->dm, &b->db, actions, n_sub, flags, b->stream);
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   b->gen++;
   return 0;
@@ -717,7 +734,7 @@ extern "C" int rsim_ctrl_reset(rsim_batch* b, const uint8_t* mask) {
     HIPCHK(hipMemcpyAsync(b->d_mask, mask, (size_t)b->B, hipMemcpyHostToDevice, b->stream));
     dmask = b->d_mask;
   }
-  int e = rsim_launch_ctrl_reset_cfg0(&b->dm, &b->db, dmask, b->stream);
+  int e = k_creset_launch[b->cfg](&b->dm, &b->db, dmask, b->stream);
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   if (mask) HIPCHK(hipStreamSynchronize(b->stream));
   b->gen++;

@@ -14,6 +14,21 @@
 #include "../../include/rsim.h"
 #include "rsim_internal.h"
 
+// Two builds of this file: RSIM_CFG 0 = up to 16 dofs (Lift/Panda; every dense nv x nv product on one 16x16 MFMA tile, register-resident
+// Cholesky), RSIM_CFG 1 = up to 32 dofs (Stack/Panda: two free cubes).  The wide build keeps the lane roles, the collision pipeline, the
+// constraint rows and the Newton algorithm; the tree products run as mask-guided lane loops, the dense ones as 2 x 2 MFMA tiles and the
+// factorisations on the LDS matrix.  `sm` is one file-scope LDS object, so each configuration is its own translation unit.
+#ifndef RSIM_CFG
+#define RSIM_CFG 0
+#endif
+#if RSIM_CFG == 0
+#define RSIM_DIMS 32, 16, 16, 24, 16, 16, 64, 192
+#define RSIM_SYM(x) x##_cfg0
+#else
+#define RSIM_DIMS 32, 16, 32, 24, 16, 32, 64, 192
+#define RSIM_SYM(x) x##_cfg1
+#endif
+
 #ifndef RSIM_MINWAVES
 #define RSIM_MINWAVES 1  /* waves per SIMD the register allocator must leave room for (1: 512 registers, 2: 256) */
 #endif
@@ -182,8 +197,8 @@ __device__ __forceinline__ S6 mul_inert(const float* I, S6 v) {
 
 // ------------------------------------------------------------------------------------------------------------
 
-// LDS words of the per-lane constant block: 29 body fields x 32, 13 dof x 16, 11 geom x 32, 8 site x 16, 10 actuator x 16, 5 ctrl x 8, 3 pair rows + mfbits x 64
-#define RSIM_KC_WORDS (29 * 32 + 13 * 16 + 11 * 32 + 8 * 16 + 10 * 16 + 5 * 8 + 4 * 64)
+// LDS words of the per-lane constant block: 29 body fields x 32, 13 dof x NV, 11 geom x 32, 8 site x 16, 10 actuator x 16, 5 ctrl x 8, 3 pair rows + mfbits x 64
+#define RSIM_KC_WORDS(NV) (29 * 32 + 13 * (NV) + 11 * 32 + 8 * 16 + 10 * 16 + 5 * 8 + 4 * 64)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 // explicitly global (address space 1) views of the model tables: pointers that arrive inside the by-value DModel would otherwise be
@@ -198,10 +213,11 @@ __device__ __forceinline__ Q4 ldq(gcf p) { Q4 q = {p[0], p[1], p[2], p[3]}; retu
 // ------------------------------------------------------------------------------------------------------------
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 struct Smem {
-  static_assert(NB == 32 && NV == 16 && NEFC == 64, "tree-incidence MFMAs assume 32 bodies x 16 dofs, one lane per constraint row");
+  static_assert(NB == 32 && (NV == 16 || NV == 32) && NEFC == 64, "32 body lanes, 16 (one MFMA tile, register Cholesky) or 32 dofs, one lane per constraint row");
   static constexpr int NVP = NV + 1;  // padded row stride of the dense nv x nv matrices (conflict-free column reads)
   static constexpr int NV_ = NV;
-  static constexpr int JS_ = 17, CS6_ = 9, FS_ = 17;  // LDS row strides (odd => bank-conflict-free lane-per-row access)
+  static constexpr int JS_ = NV + 1, CS6_ = 9, FS_ = 17;  // LDS row strides (odd => bank-conflict-free lane-per-row access)
+  static constexpr int NM_ = NV == 16 ? 1 : NV;         // extent of the tree bit-mask tables (wide configuration only)
   static constexpr int CD_ = 4;       // largest contact dimension this configuration handles (condim 1, 3, 4)
   static constexpr int NCON_ = NCON;
   static constexpr int NB_ = NB;
@@ -217,7 +233,7 @@ struct Smem {
     struct { float cvel[NB * 9]; union { struct { float cvb[NV * 9], cdd[NV * 9]; }; float cacc[NB * 9]; };
              union { float cf[NB * 17]; float F[NV * 17]; }; } v;                          // velocity(): later stages overwrite dead earlier ones
     struct { float cvel[NB * 9]; float Jm[48], Li[36], vv[8], Lt[64]; } k;                  // ctrl_run(): cvel stays live from velocity()
-    float W[NEFC * 17];                                                                    // solve_newton(): Hessian-weighted rows
+    float W[NEFC * (NV + 1)];                                                              // solve_newton(): Hessian-weighted rows
   } u;
   float M[NV * NVP];
   union { float L[NV * NVP]; float H[NV * NVP]; };  // L (factor of M) is dead once qacc_smooth exists; H is the solver / Euler work matrix
@@ -239,22 +255,24 @@ struct Smem {
   float cpos[NCON * 3], cframe[NCON * 9], cdist[NCON], cfri[NCON * 5], csolref[NCON * 2], csolimp[NCON * 5], cmu[NCON], cmargin[NCON];
   int cg1[NCON], cg2[NCON], cdim[NCON], cefc[NCON];
   // constraint rows
-  float J[NEFC * 17];  // row-major, stride JS = 17 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
+  float J[NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
   float e_R[NEFC], e_aref[NEFC], e_force[NEFC], e_B[NEFC];
   int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
   float cstate[RSIM_CS_SIZE];
-  float red[16];
+  float red[NV];
+  // wide configuration: tree incidence as bit masks (dof-ancestor set, dofs summed before dof i in the velocity recursion, body ancestors)
+  int dmask_anc[NM_], dmask_cvel[NM_], bmask_anc[NV == 16 ? 1 : NB];
   float hull[3 * RSIM_HULL_POOL];   // LDS-resident hull vertex pool (SoA x | y | z); filled once per launch
   int ghull[NG];                    // first pool slot of geom g, -1: not resident
   // per-lane model constants, one row per field (LaneConst below); phases fetch the handful they need instead of pinning ~80 VGPRs
-  float kc[RSIM_KC_WORDS];
+  float kc[RSIM_KC_WORDS(NV)];
   int ncon, nefc, niter;
 };
 
 // The one per-workgroup LDS object, declared at file scope so that every access is a direct LDS (ds_*) instruction with an
 // immediate offset: routing it through a reference member made the compiler fall back to flat_* loads/stores.
-typedef Smem<32, 16, 16, 24, 16, 16, 64, 192> Smem0;
-__shared__ Smem0 sm;
+typedef Smem<RSIM_DIMS> Smem0;
+static __shared__ Smem0 sm;
 
 #define IT(tab, i) (((gci)m.it)[m.io[tab] + (i)])
 // per-env value only for fields some env has overridden (per-episode object sizes, domain randomisation); everything else comes from the
@@ -393,6 +411,22 @@ __device__ __forceinline__ void chol_factor(float* L, float* invdiag, const floa
     float dj = sqrtf(fmaxf(sj, FMIN));
     float inv = 1.0f / dj;
     if (lane >= j && lane < n) L[lane * NVP + j] = (lane == j) ? dj : s * inv;
+    if (lane == 0) invdiag[j] = inv;
+    SYNC();
+  }
+}
+// same, factoring the matrix already stored in L (lower triangle read, lower triangle written)
+template <int NVP>
+__device__ __forceinline__ void chol_inplace(float* L, float* invdiag, int n, int lane) {
+  for (int j = 0; j < n; j++) {
+    float s = 0.f;
+    if (lane >= j && lane < n) {
+      s = L[lane * NVP + j];
+      for (int k = 0; k < j; k++) s -= L[lane * NVP + k] * L[j * NVP + k];
+    }
+    const float sj = bcast(s, j);
+    const float inv = rsqrtf(fmaxf(sj, FMIN));
+    if (lane >= j && lane < n) L[lane * NVP + j] = (lane == j) ? sj * inv : s * inv;
     if (lane == 0) invdiag[j] = inv;
     SYNC();
   }
@@ -543,6 +577,8 @@ struct Sim {
   static constexpr int CD = SM::CD_;
   static constexpr int JS = SM::JS_, CS6 = SM::CS6_, FS = SM::FS_;
   static constexpr int SM_NB = SM::NB_;
+  static constexpr bool FAST = SM::NV_ == 16;   // one-tile configuration: register Cholesky + incidence-matrix MFMAs
+  static constexpr int NT = SM::NV_ / 16;       // 16-dof tiles per dimension of the dense nv x nv products
 
   __device__ Sim(const DModel& m_, const float* fp_, int lane_, unsigned long long* prof) : m(m_), fp(fp_), lane(lane_) { pf.p = prof; pf.lane = lane_; pf.t0 = 0; }
 
@@ -575,8 +611,8 @@ struct Sim {
       }
       o += 29 * W;
     }
-    {  // dof role, 16 columns
-      const int l = lane & 15, W = 16;
+    {  // dof role, NV columns
+      const int l = lane & (NV16 - 1), W = NV16;
       if (!STORE || lane < W) {
         kio<STORE>(K.dinfo, o + 0 * W + l); kio<STORE>(K.damping, o + 1 * W + l); kio<STORE>(K.jr0, o + 2 * W + l); kio<STORE>(K.jr1, o + 3 * W + l);
         kio<STORE>(K.jmargin, o + 4 * W + l); kio<STORE>(K.jsr0, o + 5 * W + l); kio<STORE>(K.jsr1, o + 6 * W + l); kio<STORE>(K.jsi0, o + 7 * W + l);
@@ -654,6 +690,10 @@ struct Sim {
         sm.fricR[lane] = R; sm.fricB[lane] = Bd; sm.fricFl[lane] = fl;
       }
       if (lane >= nv) K.dinfo = 0;
+      if constexpr (!FAST) {
+        if (lane < NV16) { sm.dmask_anc[lane] = lane < nv ? IT(IO_dof_ancmask, 2 * i) : 0; sm.dmask_cvel[lane] = lane < nv ? IT(IO_dof_cvelmask, 2 * i) : 0; }
+        if (lane < SM_NB) sm.bmask_anc[lane] = lane < nb ? IT(IO_body_ancmask, 2 * lane) : 0;
+      }
     }
     {  // geom role
       const int g = lane < m.ncg ? lane : 0;
@@ -834,7 +874,54 @@ struct Sim {
   // ---------------------------------------------------------------- CRBA on the matrix cores
   // composite inertia per dof  crbD = Sub x cinert           (Sub = subtree incidence, 16 x 32, 0/1 constants)
   // f_i = crbD_i * cdof_i ;  M = (m1 o F C^T) + (m2 o C F^T) + diag(armature)        (F, C = 16 x 6 stacks of f_i, cdof_i)
+  // wide configuration: the same products as mask-guided lane loops (lane i = dof i sums the bodies of its subtree; element-parallel M),
+  // factorisations on the LDS matrix
+  __device__ __forceinline__ void crb_wide() {
+    const LaneConst K = fetchK();
+    const int nv = m.nv, nb = m.nbody;
+    if (lane < NV16) {
+      float acc[10];
+#pragma unroll
+      for (int k = 0; k < 10; k++) acc[k] = 0.f;
+      const int bi = K.dinfo & 255;
+      if (lane < nv)
+        for (int d = 1; d < nb; d++) {
+          const float w = (float)((sm.bmask_anc[d] >> bi) & 1);
+#pragma unroll
+          for (int k = 0; k < 10; k++) acc[k] = fmaf(w, sm.cinert[10 * d + k], acc[k]);
+        }
+#pragma unroll
+      for (int k = 0; k < 10; k++) sm.u.c.crbD[lane * FS + k] = acc[k];
+      S6 f = {v3(0, 0, 0), v3(0, 0, 0)};
+      if (lane < nv) f = mul_inert(acc, ld6(sm.cdof + CS6 * lane));
+      float* o = sm.u.c.fpad + CS6 * lane;
+      st3(o, f.a); st3(o + 3, f.l); o[6] = 0.f; o[7] = 0.f;
+    }
+    SYNC();
+    for (int e = lane; e < NV16 * NV16; e += 64) {
+      const int i = e / NV16, j = e - i * NV16;
+      float mij = 0.f;
+      if (i < nv && j < nv) {
+        if ((sm.dmask_anc[i] >> j) & 1) mij = dot6(ld6(sm.u.c.fpad + CS6 * i), ld6(sm.cdof + CS6 * j));
+        else if ((sm.dmask_anc[j] >> i) & 1) mij = dot6(ld6(sm.cdof + CS6 * i), ld6(sm.u.c.fpad + CS6 * j));
+      }
+      if (i == j) mij += sm.arm[i];
+      sm.M[i * NVP + j] = mij;
+    }
+    SYNC();
+    const float hd = lane < nv ? opt_h * K.damping : 0.f;
+    for (int e = lane; e < nv * nv; e += 64) { const int i = e / nv, j = e - i * nv; const float v = sm.M[i * NVP + j]; sm.L[i * NVP + j] = v; sm.Le[i * NVP + j] = v; }
+    SYNC();
+    if (lane < nv) sm.Le[lane * NVP + lane] += hd;
+    SYNC();
+    chol_inplace<NVP>(sm.L, sm.invdiag, nv, lane);
+    chol_inplace<NVP>(sm.Le, sm.invdiag_e, nv, lane);
+  }
+
   __device__ __forceinline__ void crb() {
+    if constexpr (FAST) crb_tile(); else crb_wide();
+  }
+  __device__ __forceinline__ void crb_tile() {
     const LaneConst K = fetchK();
     const int nv = m.nv, q = lane >> 4, r = lane & 15;
     v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -885,13 +972,22 @@ struct Sim {
   // ---------------------------------------------------------------- velocity stage (RNE) on the matrix cores
   // cvel = BodyDof x (cdof qd) ; cdof_dot_i = cvel_before(i) x cdof_i ; cacc = BodyDof x (cdof_dot qd) - g ;
   // body wrench cf = I cacc + cvel x* I cvel (+ fluid) ; F = Sub x cf ; bias_i = cdof_i . F_i
+  // out[row] = sum over dofs i in mask of cdof_i * qvel_i (wide configuration); rows are written by the lanes with `store`
+  __device__ __forceinline__ void masked_dof_sum(const float* cdofs, unsigned mask, bool store, float* out) {
+    S6 acc = {v3(0, 0, 0), v3(0, 0, 0)};
+    const int nv = m.nv;
+    for (int i = 0; i < nv; i++) if ((mask >> i) & 1u) acc = acc + ld6(cdofs + CS6 * i) * sm.qvel[i];
+    if (store) { float* o = out + CS6 * lane; st3(o, acc.a); st3(o + 3, acc.l); o[6] = 0.f; o[7] = 0.f; }
+  }
+
   __device__ __forceinline__ void velocity(V3 xp, Q4 xq) {
     const LaneConst K = fetchK();
     const int nb = m.nbody, nv = m.nv, q = lane >> 4, r = lane & 15;
     float Bc[4];
+    v4f a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+    if constexpr (FAST) {
 #pragma unroll
     for (int c = 0; c < 4; c++) Bc[c] = r < 6 ? sm.cdof[(4 * c + q) * CS6 + r] * sm.qvel[4 * c + q] : 0.f;
-    v4f a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, 8 + c), Bc[c], a0, 0, 0, 0);
@@ -902,6 +998,11 @@ struct Sim {
 #pragma unroll
       for (int v = 0; v < 4; v++) { sm.u.v.cvel[(4 * q + v) * CS6 + r] = a0[v]; sm.u.v.cvel[(16 + 4 * q + v) * CS6 + r] = a1[v]; sm.u.v.cvb[(4 * q + v) * CS6 + r] = a2[v]; }
     }
+    } else {
+      // wide configuration: lane b sums the dofs that move body b, lane i the dofs summed before dof i (mask-guided loops)
+      masked_dof_sum(sm.cdof, lane < SM_NB && lane < nb ? (unsigned)sm.bdofs[lane] : 0u, lane < SM_NB, sm.u.v.cvel);
+      masked_dof_sum(sm.cdof, lane < nv ? (unsigned)sm.dmask_cvel[lane] : 0u, lane < NV16, sm.u.v.cvb);
+    }
     SYNC();
     if (lane < NV16) {
       S6 cd = {v3(0, 0, 0), v3(0, 0, 0)};
@@ -910,6 +1011,7 @@ struct Sim {
       st3(o, cd.a); st3(o + 3, cd.l); o[6] = 0.f; o[7] = 0.f;
     }
     SYNC();
+    if constexpr (FAST) {
 #pragma unroll
     for (int c = 0; c < 4; c++) Bc[c] = r < 6 ? sm.u.v.cdd[(4 * c + q) * CS6 + r] * sm.qvel[4 * c + q] : 0.f;
     a0 = a1 = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -921,6 +1023,14 @@ struct Sim {
     if (r < 8) {
 #pragma unroll
       for (int v = 0; v < 4; v++) { sm.u.v.cacc[(4 * q + v) * CS6 + r] = a0[v]; sm.u.v.cacc[(16 + 4 * q + v) * CS6 + r] = a1[v]; }
+    }
+    } else {
+      // cacc aliases cvb/cdd: every lane finishes its sum in registers before any lane stores
+      S6 ca = {v3(0, 0, 0), v3(0, 0, 0)};
+      const unsigned mk = lane < SM_NB && lane < nb ? (unsigned)sm.bdofs[lane] : 0u;
+      for (int i = 0; i < nv; i++) if ((mk >> i) & 1u) ca = ca + ld6(sm.u.v.cdd + CS6 * i) * sm.qvel[i];
+      SYNC();
+      if (lane < SM_NB) { float* o = sm.u.v.cacc + CS6 * lane; st3(o, ca.a); st3(o + 3, ca.l); }
     }
     SYNC();
     if (lane < SM_NB) {
@@ -967,11 +1077,30 @@ struct Sim {
       o[12] = o[13] = o[14] = o[15] = 0.f;
     }
     SYNC();
+    if constexpr (FAST) {
     v4f af = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 8; c++) af = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, c), sm.u.v.cf[(4 * c + q) * FS + r], af, 0, 0, 0);
 #pragma unroll
     for (int v = 0; v < 4; v++) sm.u.v.F[(4 * q + v) * FS + r] = af[v];
+    } else {
+      // F aliases cf: sum in registers (lane i = dof i over the bodies of its subtree), then store
+      float acc[12];
+#pragma unroll
+      for (int k = 0; k < 12; k++) acc[k] = 0.f;
+      const int bi = K.dinfo & 255;
+      if (lane < nv)
+        for (int d = 1; d < nb; d++) {
+          const float w = (float)((sm.bmask_anc[d] >> bi) & 1);
+#pragma unroll
+          for (int k = 0; k < 12; k++) acc[k] = fmaf(w, sm.u.v.cf[d * FS + k], acc[k]);
+        }
+      SYNC();
+      if (lane < NV16) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) sm.u.v.F[lane * FS + k] = acc[k];
+      }
+    }
     SYNC();
     if (lane < nv) {
       const S6 cd = ld6(sm.cdof + CS6 * lane);
@@ -1479,7 +1608,7 @@ struct Sim {
 #pragma unroll
       for (int o = 1; o < SM::NCON_; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
       int first = nefc + incl - need;
-      const bool fits = active && first + dim <= 64;
+      const bool fits = active && first + dim <= 64;   // NEFC: one lane per row
       // a block that does not fit is dropped together with everything after it (rows must stay contiguous)
       const u64 bad = __ballot(active && !fits);
       const bool keep = fits && (bad == 0 || lane < (__ffsll((long long)bad) - 1));
@@ -1576,7 +1705,8 @@ struct Sim {
       sm.qfrc_smooth[lane] = qs;
     }
     float as;
-    {
+    if constexpr (!FAST) as = chol_solve<NVP>(sm.L, sm.invdiag, lane < nv ? qs : 0.f, nv, lane);
+    else {
       float lr[NV16], lt[NV16], linv[NV16];
       const int rr = lane & (NV16 - 1);
 #pragma unroll
@@ -1593,7 +1723,8 @@ struct Sim {
     const int nv = m.nv;
     const float h = opt_h;
     float qa;
-    {
+    if constexpr (!FAST) qa = chol_solve<NVP>(sm.Le, sm.invdiag_e, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, nv, lane);
+    else {
       float lr[NV16], lt[NV16], linv[NV16];
       const int rr = lane & (NV16 - 1);
 #pragma unroll
@@ -1856,9 +1987,17 @@ struct Sim {
     int type, head, kk, dim;
     bool valid, ell;
   };
-  __device__ __forceinline__ float row_dot(const Row& rw, float x) const {  // sum_k J[k] * x_k  (x_k lives in lane k)
-    return dot_rows<NV16>(rw.J, x);
+  // sum_k r[k] * x_k.  One-tile configuration: x is replicated in every 16-lane row (DPP row broadcast); wide: x_k lives in lane k (readlane)
+  __device__ __forceinline__ float vec_dot(const float (&r)[NV16], float x) const {
+    if constexpr (FAST) return dot_rows<NV16>(r, x);
+    else {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV16; k++) acc = fmaf(r[k], bcast(x, k), acc);
+      return acc;
+    }
   }
+  __device__ __forceinline__ float row_dot(const Row& rw, float x) const { return vec_dot(rw.J, x); }
   // gather the block's friction-scaled values: out[j] = (x * fr_own) of lane head + j
   __device__ __forceinline__ void gather(const Row& rw, float x, float (&out)[CD]) const {
     float u = x * rw.fr_own;
@@ -1925,11 +2064,15 @@ struct Sim {
   }
   // out_k (lane k < 16) = sum_r J[r][k] * f_r  on the matrix cores; f_r must already be in sm.e_force[0..4*nch)
   __device__ __forceinline__ float jt_times_force(int nch) {
-    v4f acc = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.J[(4 * c + (lane >> 4)) * JS + (lane & 15)], sm.e_force[4 * c + (lane >> 4)], acc, 0, 0, 0);
-    if ((lane & 15) == 0) { float* o = sm.red + 4 * (lane >> 4); o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; }
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < nch; c++)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.J[(4 * c + (lane >> 4)) * JS + 16 * t + (lane & 15)], sm.e_force[4 * c + (lane >> 4)], acc, 0, 0, 0);
+      if ((lane & 15) == 0) { float* o = sm.red + 16 * t + 4 * (lane >> 4); o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; }
+    }
     SYNC();
-    float r = sm.red[lane & 15];
+    float r = FAST ? sm.red[lane & 15] : (lane < NV16 ? sm.red[lane] : 0.f);
     SYNC();
     return r;
   }
@@ -1959,21 +2102,25 @@ struct Sim {
       rw.Dm = (1.0f / sm.e_R[rw.ell ? rw.head : r]) / fmaxf(rw.mu * rw.mu * (1 + rw.mu * rw.mu), 1e-15f);
     }
     // M: row i in lane i (matrix-vector products) and in the MFMA accumulator layout (Hessian seed)
-    const int rr = lane & 15;   // per-dof vectors (a, gradient, search direction) are replicated in all four 16-lane rows
-    const bool dofl = lane < NV16;  // ... and reduced over the first row only
+    // per-dof vectors (a, gradient, search direction): one-tile configuration = replicated in all four 16-lane rows and reduced over the
+    // first row only; wide = component k in lane k
+    const int rr = FAST ? (lane & 15) : lane;
+    const bool dofl = lane < NV16;
     float Mr[NV16];
 #pragma unroll
     for (int k = 0; k < NV16; k++) Mr[k] = (rr < nv && k < nv) ? sm.M[rr * NVP + k] : 0.f;
-    v4f Macc;
+    v4f Macc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FAST) {
 #pragma unroll
-    for (int v = 0; v < 4; v++) { int i = 4 * (lane >> 4) + v, j = lane & 15; Macc[v] = (i < nv && j < nv) ? sm.M[i * NVP + j] : (i == j ? 1.f : 0.f); }
+      for (int v = 0; v < 4; v++) { int i = 4 * (lane >> 4) + v, j = lane & 15; Macc[v] = (i < nv && j < nv) ? sm.M[i * NVP + j] : (i == j ? 1.f : 0.f); }
+    }
     const float a_sm = rr < nv ? sm.qacc_smooth[rr] : 0.f, a_ws = rr < nv ? sm.qacc_ws[rr] : 0.f, f_sm = rr < nv ? sm.qfrc_smooth[rr] : 0.f;
     float force; int state; float uj[CD], T, g;
     // ---- warm start: previous acceleration unless the unconstrained one is cheaper
     float cost_sm = wave_sum(row_update(rw, row_dot(rw, a_sm) - rw.aref, force, state, uj, T, g));
     float cost_ws = wave_sum(row_update(rw, row_dot(rw, a_ws) - rw.aref, force, state, uj, T, g));
     {
-      const float dws = a_ws - a_sm, sv = dot_rows<NV16>(Mr, dws);
+      const float dws = a_ws - a_sm, sv = vec_dot(Mr, dws);
       cost_ws += wave_sum(dofl ? 0.5f * sv * dws : 0.f);
     }
     float a = cost_ws < cost_sm ? a_ws : a_sm;
@@ -1982,7 +2129,7 @@ struct Sim {
     for (;;) {
       jar = row_dot(rw, a) - rw.aref;
       float cost = wave_sum(row_update(rw, jar, force, state, uj, T, g));
-      const float ma = dot_rows<NV16>(Mr, a);
+      const float ma = vec_dot(Mr, a);
       const float gauss = wave_sum(dofl ? 0.5f * (ma - f_sm) * (a - a_sm) : 0.f);
       cost += gauss;
       sm.e_force[lane] = force;
@@ -2019,13 +2166,31 @@ struct Sim {
         for (int k = 0; k < NV16; k++) sm.u.W[lane * JS + k] = w[k];
       }
       SYNC();
+      float sk;
+      if constexpr (!FAST) {
+        // H = M + J^T W as NT x NT MFMA tiles, factorised in place on the LDS matrix (H aliases the dead factor of M)
+#pragma unroll
+        for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+          for (int tj = 0; tj < NT; tj++) {
+            v4f acc;
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[v] = sm.M[(16 * ti + 4 * (lane >> 4) + v) * NVP + 16 * tj + (lane & 15)];
+            for (int c = 0; c < nch; c++)
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.u.W[(4 * c + (lane >> 4)) * JS + 16 * ti + (lane & 15)], sm.J[(4 * c + (lane >> 4)) * JS + 16 * tj + (lane & 15)], acc, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; v++) sm.H[(16 * ti + 4 * (lane >> 4) + v) * NVP + 16 * tj + (lane & 15)] = acc[v];
+          }
+        SYNC();
+        chol_inplace<NVP>(sm.H, sm.invdiag, nv, lane);
+        sk = chol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -gk : 0.f, nv, lane);
+        if (lane >= nv) sk = 0.f;
+      } else {
       v4f acc = Macc;
       for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.u.W[(4 * c + (lane >> 4)) * JS + (lane & 15)], sm.J[(4 * c + (lane >> 4)) * JS + (lane & 15)], acc, 0, 0, 0);
 #pragma unroll
       for (int v = 0; v < 4; v++) sm.H[(4 * (lane >> 4) + v) * NVP + (lane & 15)] = acc[v];
       SYNC();
-      float sk;
-      {
         float hr[NV16], hinv[NV16], ht[NV16];
         const int rr = lane & 15;
 #pragma unroll
@@ -2044,7 +2209,7 @@ struct Sim {
       }
       // ---- line search along sk
       const float jv = row_dot(rw, sk);
-      const float mvv = dot_rows<NV16>(Mr, sk);
+      const float mvv = vec_dot(Mr, sk);
       const float q1 = wave_sum(dofl ? sk * (ma - f_sm) : 0.f), q2 = wave_sum(dofl ? 0.5f * sk * mvv : 0.f), sn = sqrtf(wave_sum(dofl ? sk * sk : 0.f));
       if (sn < 1e-15f) break;
       float g0[CD], gvv[CD];
@@ -2325,6 +2490,7 @@ __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const uns
 // OperationalSpaceController.run_controller).  One wave per sample.
 // in: [B, 128] floats: ep3 eR9 ev6 op3 oR9 bv6 goal_pos3 goal_ori9 J(6x7) M(7x7) bias7 q7 qd7 q0 7 (=168?) -> packed by host
 // ------------------------------------------------------------------------------------------------------------
+#if RSIM_CFG == 0
 #define OSC_IN 192
 __global__ __launch_bounds__(64) void k_osc_eval(DCtrl c, const float* __restrict__ in, float* __restrict__ out, int B) {
   const int env = blockIdx.x, lane = threadIdx.x;
@@ -2440,26 +2606,26 @@ extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr
   return (int)hipGetLastError();
 }
 
-// explicit instantiations + launchers ------------------------------------------------------------------------
-#define RSIM_INST(NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR)                                                                          \
-  template __global__ void k_step<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR>(DModel, DBatch, const float*, int, int);                 \
-  template __global__ void k_ctrl_reset<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR>(DModel, DBatch, const unsigned char*);
-
-RSIM_INST(32, 16, 16, 24, 16, 16, 64, 192)
-
-extern "C" int rsim_launch_step_cfg0(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream) {
-  hipLaunchKernelGGL((k_step<32, 16, 16, 24, 16, 16, 64, 192>), dim3(b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
-  return (int)hipGetLastError();
-}
-extern "C" int rsim_launch_ctrl_reset_cfg0(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream) {
-  hipLaunchKernelGGL((k_ctrl_reset<32, 16, 16, 24, 16, 16, 64, 192>), dim3(b->B), dim3(64), 0, stream, *m, *b, mask);
-  return (int)hipGetLastError();
-}
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream) {
   hipLaunchKernelGGL(k_osc_eval, dim3(B), dim3(64), 0, stream, *c, in, out, B);
   return (int)hipGetLastError();
 }
-extern "C" int rsim_cfg0_limits(int* lim) {
-  lim[0] = 32; lim[1] = 16; lim[2] = 16; lim[3] = 24; lim[4] = 16; lim[5] = 16; lim[6] = 64; lim[7] = 192;
+#endif  // RSIM_CFG == 0
+
+// explicit instantiations + launchers (one set per configuration build) ----------------------------------------------------------
+template __global__ void k_step<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
+template __global__ void k_ctrl_reset<RSIM_DIMS>(DModel, DBatch, const unsigned char*);
+
+extern "C" int RSIM_SYM(rsim_launch_step)(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream) {
+  hipLaunchKernelGGL((k_step<RSIM_DIMS>), dim3(b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
+  return (int)hipGetLastError();
+}
+extern "C" int RSIM_SYM(rsim_launch_ctrl_reset)(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream) {
+  hipLaunchKernelGGL((k_ctrl_reset<RSIM_DIMS>), dim3(b->B), dim3(64), 0, stream, *m, *b, mask);
+  return (int)hipGetLastError();
+}
+extern "C" int RSIM_SYM(rsim_limits)(int* lim) {
+  const int dims[8] = {RSIM_DIMS};
+  for (int i = 0; i < 8; i++) lim[i] = dims[i];
   return 0;
 }

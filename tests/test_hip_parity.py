@@ -105,6 +105,43 @@ def test_other_part_controllers_track_the_reference_env_loop(tag):
     assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[1])
 
 
+def test_wide_configuration_stack_model_matches_oracle_and_reference_loop():
+    """Stack / Panda (BASELINE configs[2] model: nv = 21 > 16) runs on the 32-dof kernel configuration: forward quantities against the oracle
+    along the recorded trajectory, then the fused control step against the oracle loop and the states the reference env loop recorded."""
+    g, cfg, flat = load_golden("seed0_full", "stack_panda")
+    assert flat.nv == 21
+    nq = flat.nq
+    om, od, oc = make_oracle(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=2)
+    for i in (0, 7, 15, 29):
+        s = g["states"][i]
+        od.qpos[:] = s[1:1 + nq]; od.qvel[:] = s[1 + nq:]; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0
+        od.forward()
+        hb.set("qpos", s[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+        hb.forward()
+        assert np.abs(hb.get("xpos")[0].ravel() - od.xpos).max() < 2e-6
+        assert rel(hb.get("qM")[0].ravel(), od.qM) < 1e-5
+        assert rel(hb.get("qfrc_bias")[0], od.qfrc_bias) < 1e-5
+        assert np.abs(hb.get("qfrc_passive")[0] - od.qfrc_passive).max() < 1e-4 * max(1.0, np.abs(od.qfrc_passive).max())
+        assert hb.get("ncon")[0] == od.ncon and hb.get("nefc")[0] == od.nefc
+        assert np.abs(hb.get("qacc")[0] - od.qacc).max() < 2e-4 * max(1.0, np.abs(od.qacc).max())
+        for a, b in zip(hb.contacts(0), od.contacts()):
+            assert (a["geom1"], a["geom2"], a["dim"]) == (b["geom1"], b["geom2"], b["dim"])
+            assert abs(a["normal_force"] - b["normal_force"]) < 1e-3 * max(1.0, abs(b["normal_force"]))
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0; od.forward(); oc.reset(od)
+    hb.set("qpos", s0[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    for t in range(len(g["actions"])):
+        a = torch.tensor(np.repeat(g["actions"][t][None], 2, 0), dtype=torch.float32, device="cuda")
+        hb.control_step(a, 25)
+        oc.env_step(od, g["actions"][t], 25)
+        hq, hv = hb.get("qpos")[0], hb.get("qvel")[0]
+        assert np.abs(hq - od.qpos).max() < 5e-4 and np.abs(hv - od.qvel).max() < 5e-3, t
+        assert np.abs(hq - g["states"][t + 1][1:1 + nq]).max() < 5e-4 and np.abs(hv - g["states"][t + 1][1 + nq:]).max() < 5e-3, t
+    assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[1])
+
+
 def test_replay_is_bitwise_deterministic():
     """The reference's only numeric assert on sim state is bitwise replay equality (test_action_playback.py:46-68)."""
     g, cfg, flat = load_golden("seed1_full")

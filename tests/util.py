@@ -10,10 +10,10 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TAGS = ("seed0_gentle", "seed1_full")
 
 
-def load_golden(tag):
-    g = np.load(os.path.join(GOLD, f"lift_panda_{tag}.npz"))
-    cfg = json.load(open(os.path.join(GOLD, f"lift_panda_{tag}.cfg.json")))
-    flat = mjcf.load_model(os.path.join(GOLD, f"lift_panda_{tag}.rsim"))
+def load_golden(tag, model="lift_panda"):
+    g = np.load(os.path.join(GOLD, f"{model}_{tag}.npz"))
+    cfg = json.load(open(os.path.join(GOLD, f"{model}_{tag}.cfg.json")))
+    flat = mjcf.load_model(os.path.join(GOLD, f"{model}_{tag}.rsim"))
     return g, cfg, flat
 
 

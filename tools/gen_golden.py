@@ -114,6 +114,36 @@ def controller_cfg_generic(env, ctype):
     return base
 
 
+def record_stack(seed, n_steps, action_scale, tag):
+    """BASELINE configs[2] model: Stack / Panda / OSC_POSE (nv = 21, two free cubes).  Same recording as record_lift_controller plus the
+    per-substep trajectory of the first env.step (forward-quantity parity cases)."""
+    env = suite.make("Stack", robots="Panda", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
+                     reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed)
+    obs = env.reset()
+    sim = env.sim
+    flat = sim.model._model._flat
+    rng = np.random.default_rng(10**6 + seed)
+    keys = [k for k in obs.keys() if not k.endswith("-state")]
+    actions, states, rewards, obs_flat, ctrls, succ = [], [sim.get_state().flatten()], [], [], [], []
+    for t in range(n_steps):
+        a = action_scale * rng.uniform(-1, 1, env.action_dim)
+        obs, r, done, info = env.step(a)
+        ctrls.append(np.array(sim.data.ctrl)); actions.append(a); states.append(sim.get_state().flatten()); rewards.append(r)
+        succ.append(bool(env._check_success()))
+        obs_flat.append(np.concatenate([np.atleast_1d(obs[k]).astype(np.float64) for k in keys]))
+    np.savez_compressed(os.path.join(GOLD, f"stack_panda_{tag}.npz"), actions=np.array(actions), states=np.array(states), rewards=np.array(rewards),
+                        obs=np.array(obs_flat), ctrl=np.array(ctrls), success=np.array(succ),
+                        cubeA_size=flat.geom_size[flat.name2id("geom", "cubeA_g0")], cubeB_size=flat.geom_size[flat.name2id("geom", "cubeB_g0")])
+    mjcf.save_model(flat, os.path.join(GOLD, f"stack_panda_{tag}.rsim"))
+    cfg = controller_cfg(env)
+    cfg["obs_keys"] = keys
+    cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in keys]
+    cfg["table_height"] = float(env.table_offset[2])
+    with open(os.path.join(GOLD, f"stack_panda_{tag}.cfg.json"), "w") as f:
+        json.dump(cfg, f, indent=1)
+    print("stack", tag, "nv", flat.nv, "nbody", flat.nbody, "steps", n_steps, "reward", rewards[-1])
+
+
 def record_lift(seed, n_steps, action_scale, tag):
     env = suite.make("Lift", robots="Panda", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False,
                      use_object_obs=True, reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed)
@@ -167,6 +197,9 @@ def record_lift(seed, n_steps, action_scale, tag):
 
 
 if __name__ == "__main__":
+    if "--stack-only" in sys.argv:
+        record_stack(seed=0, n_steps=30, action_scale=1.0, tag="seed0_full")
+        sys.exit(0)
     if "--controllers-only" in sys.argv:
         for ct in ("JOINT_POSITION", "JOINT_TORQUE", "OSC_POSITION"):
             record_lift_controller(seed=2, n_steps=30, action_scale=1.0, ctype=ct)
