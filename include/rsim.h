@@ -56,17 +56,21 @@ typedef struct rsim_ctrl_desc {
  *   RSIM_OBS_BODY_QUAT / RSIM_OBS_SITE_QUAT: body / site a, xyzw comp b    (robot.py:416-462; T.convert_quat / T.mat2quat)
  *   RSIM_OBS_BODY_POS: body a, component b                                 (lift.py:371-373 cube_pos)
  *   RSIM_OBS_BODY_MINUS_SITE: body a minus site (b >> 2), component b & 3  (manipulation_env.py:218-242 gripper_to_cube_pos)
+ *   RSIM_OBS_BODY_MINUS_BODY: body a minus body (b >> 2), component b & 3  (stack.py:432-438 cubeA_to_cubeB = cubeB_pos - cubeA_pos)
  * Sampling instants follow the reference exactly: after `reset()` every Observable samples on the LAST substep of a control step,
  * i.e. positions/orientations come from that substep's step1 kinematics, qpos/qvel from after its step2 (utils/observables.py:214-259).
- * Reward = Lift.reward (environments/manipulation/lift.py:224-273), success = Lift._check_success (lift.py:433-444),
- * grasp = ManipulationEnv._check_grasp on the contact list (manipulation_env.py:331-376). */
+ * task 1: reward = Lift.reward (environments/manipulation/lift.py:224-273), success = Lift._check_success (lift.py:433-444),
+ * grasp = ManipulationEnv._check_grasp on the contact list (manipulation_env.py:331-376).
+ * task 2: reward = Stack.reward / staged_rewards (environments/manipulation/stack.py:224-312) with object = cubeA, object2 = cubeB
+ * (reach + grasp, lift + align, stack = lifted, released and cubeA touching cubeB via check_contact, utils/sim_utils.py:8-40),
+ * success = Stack._check_success (stack.py:476-484: r_stack > 0); scaled by reward_scale / 2.0. */
 enum { RSIM_OBS_QPOS = 0, RSIM_OBS_COS, RSIM_OBS_SIN, RSIM_OBS_QVEL, RSIM_OBS_QACC, RSIM_OBS_SITE_POS, RSIM_OBS_BODY_QUAT, RSIM_OBS_SITE_QUAT,
-       RSIM_OBS_BODY_POS, RSIM_OBS_BODY_MINUS_SITE };
+       RSIM_OBS_BODY_POS, RSIM_OBS_BODY_MINUS_SITE, RSIM_OBS_BODY_MINUS_BODY };
 #define RSIM_OBS_MAX 128
 typedef struct rsim_task_desc {
   int32_t nobs;                       /* floats in the observation record (<= RSIM_OBS_MAX) */
   int32_t obs_prog[RSIM_OBS_MAX * 3]; /* (kind, a, b) per output float */
-  int32_t task;                       /* 1 = Lift */
+  int32_t task;                       /* 0 = none, 1 = Lift, 2 = Stack */
   int32_t object_body;                /* cube root body */
   int32_t grip_site;                  /* gripper.important_sites["grip_site"] */
   float table_height;                 /* model.mujoco_arena.table_offset[2] */
@@ -74,6 +78,8 @@ typedef struct rsim_task_desc {
   float reward_scale;                 /* reward_scale (1.0), applied as reward_scale / 2.25 */
   int32_t reward_shaping;
   uint64_t left_pad_geoms, right_pad_geoms, object_geoms; /* bit g set: colliding-geom index g belongs to the group (_check_grasp) */
+  int32_t object2_body;               /* Stack: cubeB root body */
+  uint64_t object2_geoms;             /* Stack: cubeB contact geoms */
 } rsim_task_desc;
 
 /* state / derived arrays addressable through rsim_get_array / rsim_set_array / rsim_device_ptr */

@@ -25,7 +25,7 @@ INT_FIELDS = {"ncon", "nefc", "niter", "success", "done", "ep_step", "ep_index"}
 CON_REC = 24
 CSTATE = 32
 OBS_MAX = 128
-OBS_KINDS = {"qpos": 0, "cos": 1, "sin": 2, "qvel": 3, "qacc": 4, "site_pos": 5, "body_quat": 6, "site_quat": 7, "body_pos": 8, "body_minus_site": 9}
+OBS_KINDS = {"qpos": 0, "cos": 1, "sin": 2, "qvel": 3, "qacc": 4, "site_pos": 5, "body_quat": 6, "site_quat": 7, "body_pos": 8, "body_minus_site": 9, "body_minus_body": 10}
 
 
 class RsimError(RuntimeError):
@@ -52,7 +52,8 @@ def control_dim(cfg: dict) -> int:
 class TaskDesc(C.Structure):
     _fields_ = [("nobs", C.c_int32), ("obs_prog", C.c_int32 * (OBS_MAX * 3)), ("task", C.c_int32), ("object_body", C.c_int32), ("grip_site", C.c_int32),
                 ("table_height", C.c_float), ("lift_margin", C.c_float), ("reward_scale", C.c_float), ("reward_shaping", C.c_int32),
-                ("left_pad_geoms", C.c_uint64), ("right_pad_geoms", C.c_uint64), ("object_geoms", C.c_uint64)]
+                ("left_pad_geoms", C.c_uint64), ("right_pad_geoms", C.c_uint64), ("object_geoms", C.c_uint64), ("object2_body", C.c_int32),
+                ("object2_geoms", C.c_uint64)]
 
 
 class DrDesc(C.Structure):
@@ -188,7 +189,8 @@ class HipModel:
         d.nobs = len(obs)
         for i, (kind, a, b) in enumerate(obs):
             d.obs_prog[3 * i], d.obs_prog[3 * i + 1], d.obs_prog[3 * i + 2] = OBS_KINDS[kind] if isinstance(kind, str) else int(kind), int(a), int(b)
-        d.task = {"none": 0, "lift": 1}[task.get("task", "none")]
+        d.task = {"none": 0, "lift": 1, "stack": 2}[task.get("task", "none")]
+        d.object2_body = int(task.get("object2_body", 0))
         d.object_body, d.grip_site = int(task.get("object_body", 0)), int(task.get("grip_site", 0))
         d.table_height, d.lift_margin = float(task.get("table_height", 0.0)), float(task.get("lift_margin", 0.04))
         d.reward_scale, d.reward_shaping = float(task.get("reward_scale", 1.0)), int(bool(task.get("reward_shaping", True)))
@@ -202,6 +204,7 @@ class HipModel:
             return mk
 
         d.left_pad_geoms, d.right_pad_geoms, d.object_geoms = mask(task.get("left_pad_geoms", [])), mask(task.get("right_pad_geoms", [])), mask(task.get("object_geoms", []))
+        d.object2_geoms = mask(task.get("object2_geoms", []))
         _chk(self._L.rsim_model_set_task(self.ptr, C.byref(d)))
         self.task_cfg = task
         self.nobs = len(obs)

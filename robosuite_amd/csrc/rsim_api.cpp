@@ -486,12 +486,14 @@ extern "C" int rsim_model_set_task(rsim_model* m, const rsim_task_desc* d) {
       case RSIM_OBS_BODY_QUAT: ok = a >= 0 && a < m->nbody && b2 >= 0 && b2 < 4; break;
       case RSIM_OBS_BODY_POS: ok = a >= 0 && a < m->nbody && b2 >= 0 && b2 < 3; break;
       case RSIM_OBS_BODY_MINUS_SITE: ok = a >= 0 && a < m->nbody && (b2 & 3) < 3 && (b2 >> 2) >= 0 && (b2 >> 2) < m->nsite; break;
+      case RSIM_OBS_BODY_MINUS_BODY: ok = a >= 0 && a < m->nbody && (b2 & 3) < 3 && (b2 >> 2) >= 0 && (b2 >> 2) < m->nbody; break;
       default: ok = false;
     }
     if (!ok) return fail("task: observation entry %d (kind %d, a %d, b %d) is invalid for this model", i, kind, a, b2);
   }
-  if (d->task != 0 && d->task != 1) return fail("task: unknown task id %d", d->task);
-  if (d->task == 1 && (d->object_body < 0 || d->object_body >= m->nbody || d->grip_site < 0 || d->grip_site >= m->nsite)) return fail("task: bad body / site id");
+  if (d->task < 0 || d->task > 2) return fail("task: unknown task id %d", d->task);
+  if (d->task >= 1 && (d->object_body < 0 || d->object_body >= m->nbody || d->grip_site < 0 || d->grip_site >= m->nsite)) return fail("task: bad body / site id");
+  if (d->task == 2 && (d->object2_body < 0 || d->object2_body >= m->nbody)) return fail("task: bad second object body id");
   m->task = *d;
   m->has_task = 1;
   return 0;
@@ -575,6 +577,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
     dm.task.enabled = 1; dm.task.nobs = t.nobs; dm.task.task = t.task; dm.task.object_body = t.object_body; dm.task.grip_site = t.grip_site;
     dm.task.reward_shaping = t.reward_shaping; dm.task.table_height = t.table_height; dm.task.lift_margin = t.lift_margin; dm.task.reward_scale = t.reward_scale;
     dm.task.left_pad = t.left_pad_geoms; dm.task.right_pad = t.right_pad_geoms; dm.task.object_geoms = t.object_geoms; dm.task.obs_prog = b->d_obsprog;
+    dm.task.object2_body = t.object2_body; dm.task.object2_geoms = t.object2_geoms;
   }
   DBatch& db = b->db;
   db.B = B;

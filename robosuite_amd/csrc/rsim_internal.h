@@ -79,7 +79,8 @@ struct DCtrl {
 struct DTask {
   int enabled, nobs, task, object_body, grip_site, reward_shaping;
   float table_height, lift_margin, reward_scale;
-  unsigned long long left_pad, right_pad, object_geoms;
+  unsigned long long left_pad, right_pad, object_geoms, object2_geoms;
+  int object2_body;
   const int* obs_prog;   // device [nobs][3]
 };
 

@@ -2295,21 +2295,37 @@ struct Sim {
       else if (kind == RSIM_OBS_SITE_POS) v = sm.spos[3 * a + b2];
       else if (kind == RSIM_OBS_BODY_POS) v = sm.xpos[3 * a + b2];
       else if (kind == RSIM_OBS_BODY_MINUS_SITE) v = sm.xpos[3 * a + (b2 & 3)] - sm.spos[3 * (b2 >> 2) + (b2 & 3)];
+      else if (kind == RSIM_OBS_BODY_MINUS_BODY) v = sm.xpos[3 * a + (b2 & 3)] - sm.xpos[3 * (b2 >> 2) + (b2 & 3)];
       else if (kind == RSIM_OBS_BODY_QUAT) v = sm.xquat[4 * a + (b2 == 3 ? 0 : b2 + 1)];   // wxyz -> xyzw
       else if (kind == RSIM_OBS_SITE_QUAT) { const Q4 q = mat2quat_xyzw(sm.smat + 9 * a); v = b2 == 0 ? q.x : (b2 == 1 ? q.y : (b2 == 2 ? q.z : q.w)); }
       obs[i] = v;
     }
-    if (t.task == 1) {
+    if (t.task >= 1) {
       // grasp: both finger-pad geom groups touch the object (contact list of the last substep)
-      bool lc = false, rc = false;
+      bool lc = false, rc = false, oo = false;
       if (lane < sm.ncon) {
         const unsigned long long b1 = 1ull << sm.cg1[lane], b2 = 1ull << sm.cg2[lane];
         const bool obj1 = (t.object_geoms & b1) != 0, obj2 = (t.object_geoms & b2) != 0;
         lc = (obj1 && (t.left_pad & b2)) || (obj2 && (t.left_pad & b1));
         rc = (obj1 && (t.right_pad & b2)) || (obj2 && (t.right_pad & b1));
+        oo = (obj1 && (t.object2_geoms & b2)) || (obj2 && (t.object2_geoms & b1));   // check_contact(cubeA, cubeB)
       }
       const bool grasp = __ballot(lc) != 0 && __ballot(rc) != 0;
-      if (lane == 0) {
+      const bool touching = __ballot(oo) != 0;
+      if (lane == 0 && t.task == 2) {
+        // Stack.staged_rewards (stack.py:268-312): max(reach + grasp, lift + align, stack), x reward_scale / 2
+        const V3 cA = ld3(sm.xpos + 3 * t.object_body), cB = ld3(sm.xpos + 3 * t.object2_body), grip = ld3(sm.spos + 3 * t.grip_site);
+        float r_reach = (1.f - tanhf(10.f * norm(cA - grip))) * 0.25f;
+        if (grasp) r_reach += 0.25f;
+        const bool lifted = cA.z > t.table_height + t.lift_margin;
+        float r_lift = lifted ? 1.f : 0.f;
+        if (lifted) { const float dx = cA.x - cB.x, dy = cA.y - cB.y; r_lift += 0.5f * (1.f - tanhf(sqrtf(dx * dx + dy * dy))); }
+        const float r_stack = (!grasp && r_lift > 0.f && touching) ? 2.f : 0.f;
+        const float r = t.reward_shaping ? fmaxf(r_reach, fmaxf(r_lift, r_stack)) : r_stack;
+        *reward = r * t.reward_scale / 2.0f;
+        *success = r_stack > 0.f ? 1 : 0;
+      }
+      if (lane == 0 && t.task == 1) {
         const V3 cube = ld3(sm.xpos + 3 * t.object_body), grip = ld3(sm.spos + 3 * t.grip_site);
         const bool succ = cube.z > t.table_height + t.lift_margin;
         float r = 0.f;

@@ -142,6 +142,63 @@ def test_wide_configuration_stack_model_matches_oracle_and_reference_loop():
     assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[1])
 
 
+def test_stack_observation_and_reward_epilogue_matches_reference_env():
+    """Stack epilogue (task 2) vs what the reference's env.step() returned: the Stack key order incl. cubeA_to_cubeB, Stack.reward staging."""
+    from robosuite_amd import stack
+    from robosuite_amd.backend import HipBatch
+    g, cfg, flat = load_golden("seed0_full", "stack_panda")
+    nq = flat.nq
+    hm, _ = make_hip(flat, cfg, B=1)
+    hm.set_task(stack.stack_task(flat, cfg))
+    hb = HipBatch(hm, 2, 0, False)
+    s0 = g["states"][0]
+    hb.set("qpos", s0[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    dims = np.cumsum([0] + cfg["obs_dims"])
+    assert hb.get("obs").shape == (2, dims[-1])
+    for t in range(len(g["actions"])):
+        hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+        obs, rew = hb.get("obs")[0], hb.get("reward")[0]
+        for k, key in enumerate(cfg["obs_keys"]):
+            ref, got = g["obs"][t][dims[k]:dims[k + 1]], obs[dims[k]:dims[k + 1]]
+            tol = 2e-2 * max(1.0, np.abs(ref).max()) if key.endswith("joint_acc") else (5e-3 if key.endswith("vel") else 5e-4)
+            if key.endswith("quat") or key.endswith("quat_site"):
+                got = got * np.sign(np.dot(got, ref))
+            assert np.abs(got - ref).max() < tol, (t, key)
+        assert abs(rew - g["rewards"][t]) < 1e-4, t
+        assert hb.get("success")[0] == int(g["success"][t])
+
+
+def test_scripted_stacking_replay_reaches_success_on_the_device():
+    """Grasp cubeA, carry, place on cubeB, release (tape from the closed-loop script on the oracle) replayed on the HIP path: staged rewards
+    pass through reach+grasp -> lift+align -> stack, success is set once the gripper lets go, as on the oracle."""
+    from robosuite_amd import stack
+    from robosuite_amd.backend import HipBatch
+    from tests.util import scripted_stack
+    g, cfg, flat = load_golden("seed0_full", "stack_panda")
+    nq = flat.nq
+    q0 = g["states"][0][1:1 + nq]
+    acts, rew, od = scripted_stack(flat, cfg, q0)
+    assert rew[-1][1] and not rew[40][1]
+    hm, _ = make_hip(flat, cfg, B=1)
+    hm.set_task(stack.stack_task(flat, cfg))
+    hb = HipBatch(hm, 2, 0, False)
+    hb.set("qpos", q0[None].repeat(2, 0)); hb.set("qvel", 0); hb.forward(); hb.ctrl_reset()
+    rewards, succ = [], []
+    for t in range(len(acts)):
+        hb.control_step(torch.tensor(np.repeat(acts[t][None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+        rewards.append(float(hb.get("reward")[0])); succ.append(int(hb.get("success")[0]))
+        if t == 20:
+            assert abs(rewards[-1] - rew[t][0]) < 1e-3       # approach: tight agreement with the oracle-side restatement of staged_rewards
+    first = next(i for i, (_, s) in enumerate(rew) if s)
+    assert succ[-1] == 1 and abs(rewards[-1] - 1.0) < 1e-6    # r_stack = 2 -> x reward_scale / 2
+    assert abs(succ.index(1) - first) <= 3                    # released within a few control steps of the oracle
+    assert max(rewards[:first - 5]) < 0.8 and max(rewards[:first - 5]) > 0.7   # lift + align plateau (1 + 0.5 (1 - tanh d)) / 2 before the release
+    q = hb.get("qpos")[0]
+    assert abs(q[11] - (q[18] + 0.045)) < 3e-3                # cubeA rests on cubeB: centre heights differ by the two half sizes
+    assert np.isfinite(hb.get("qvel")).all()
+
+
 def test_replay_is_bitwise_deterministic():
     """The reference's only numeric assert on sim state is bitwise replay equality (test_action_playback.py:46-68)."""
     g, cfg, flat = load_golden("seed1_full")

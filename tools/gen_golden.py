@@ -144,6 +144,19 @@ def record_stack(seed, n_steps, action_scale, tag):
     print("stack", tag, "nv", flat.nv, "nbody", flat.nbody, "steps", n_steps, "reward", rewards[-1])
 
 
+def record_stack_resets(seeds):
+    """Reset-path fixture (physics independent): qpos after make() (draw block 0) and after the first user reset() (block 1) per seed."""
+    out = {}
+    for seed in seeds:
+        env = suite.make("Stack", robots="Panda", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
+                         reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed)
+        out[f"make_{seed}"] = np.array(env.sim.data.qpos)
+        env.reset()
+        out[f"reset_{seed}"] = np.array(env.sim.data.qpos)
+    np.savez_compressed(os.path.join(GOLD, "stack_panda_resets.npz"), seeds=np.array(seeds), **out)
+    print("stack resets", seeds)
+
+
 def record_lift(seed, n_steps, action_scale, tag):
     env = suite.make("Lift", robots="Panda", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False,
                      use_object_obs=True, reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed)
@@ -199,6 +212,7 @@ def record_lift(seed, n_steps, action_scale, tag):
 if __name__ == "__main__":
     if "--stack-only" in sys.argv:
         record_stack(seed=0, n_steps=30, action_scale=1.0, tag="seed0_full")
+        record_stack_resets([0, 1, 2, 3, 4, 5])
         sys.exit(0)
     if "--controllers-only" in sys.argv:
         for ct in ("JOINT_POSITION", "JOINT_TORQUE", "OSC_POSITION"):
