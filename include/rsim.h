@@ -28,16 +28,18 @@ typedef struct rsim_batch rsim_batch;
  *   JOINT_TORQUE   generic/joint_tor.py:111-167, control_dim ndof: tau = clip(scaled action, torque_limits) + qfrc_bias
  * The action row of rsim_control_step is [control_dim arm entries, 1 gripper entry if ngrip > 0]. */
 enum rsim_ctrl_type { RSIM_CTRL_OSC_POSE = 0, RSIM_CTRL_OSC_POSITION = 1, RSIM_CTRL_JOINT_POSITION = 2, RSIM_CTRL_JOINT_TORQUE = 3 };
+#define RSIM_JNT_MAX 16
 typedef struct rsim_ctrl_desc {
-  int32_t ndof;            /* arm joints (<= 8) */
-  int32_t qpos_idx[8];     /* Controller.qpos_index */
-  int32_t dof_idx[8];      /* Controller.qvel_index */
-  int32_t act_idx[8];      /* robot._ref_actuators_indexes_dict[arm] */
+  int32_t ndof;            /* controlled joints: <= 8 for the OSC types (one arm); <= 16 for the joint-space types, where the arms of a multi-arm
+                            * robot are concatenated in `robot.arms` order (= the order CompositeController slices the action, composite_controller.py:97-103) */
+  int32_t qpos_idx[RSIM_JNT_MAX];     /* Controller.qpos_index */
+  int32_t dof_idx[RSIM_JNT_MAX];      /* Controller.qvel_index */
+  int32_t act_idx[RSIM_JNT_MAX];      /* robot._ref_actuators_indexes_dict[arm] */
   int32_t eef_site;        /* site id of Controller.ref_name */
   int32_t base_site;       /* site id of f"{naming_prefix}{part_name}_center" (osc.py:453) */
-  float kp[8];             /* osc.py:176 (6 task-space gains) / joint_pos.py:150 (ndof joint gains) */
+  float kp[RSIM_JNT_MAX];  /* osc.py:176 (6 task-space gains) / joint_pos.py:150 (ndof joint gains) */
   float damping_ratio;     /* kd = 2 sqrt(kp) damping_ratio, osc.py:177, joint_pos.py:151 */
-  float input_min[8], input_max[8], output_min[8], output_max[8]; /* controller.py:149-168, first control_dim entries used */
+  float input_min[RSIM_JNT_MAX], input_max[RSIM_JNT_MAX], output_min[RSIM_JNT_MAX], output_max[RSIM_JNT_MAX]; /* controller.py:149-168, first control_dim entries used */
   int32_t uncouple_pos_ori; /* osc.py:476-482 */
   float nullspace_kp;       /* control_utils.py:7 (default 10) */
   int32_t ngrip;            /* gripper actuators (<= 4), 0 = no gripper */
@@ -45,7 +47,9 @@ typedef struct rsim_ctrl_desc {
   float grip_sign[4];       /* PandaGripper.format_action direction, models/grippers/panda_gripper.py:55-57 */
   float grip_speed;         /* panda_gripper.py:61 */
   int32_t type;             /* enum rsim_ctrl_type: which arm part controller of controller_factory.py:73-159 */
-  float torque_min[8], torque_max[8]; /* RSIM_CTRL_JOINT_TORQUE: torque_limits (joint_tor.py:95-96; default = actuator ctrlrange) */
+  float torque_min[RSIM_JNT_MAX], torque_max[RSIM_JNT_MAX]; /* RSIM_CTRL_JOINT_TORQUE: torque_limits (joint_tor.py:95-96; default = actuator ctrlrange) */
+  int32_t part_of[RSIM_JNT_MAX];      /* joint-space types: which part controller (arm) owns joint i; JOINT_POSITION multiplies by that part's own
+                                       * mass-matrix block only (joint_pos.py:256-259 uses Controller.mass_matrix of the part) */
 } rsim_ctrl_desc;
 
 /* On-device observation / reward epilogue of the fused control step.
@@ -89,7 +93,8 @@ enum rsim_field {
   RSIM_QACC_WARMSTART, /* [B,nv]                                                            */
   RSIM_CTRL,           /* [B,nu]  sim.data.ctrl   (fixed_base_robot.py:153)                 */
   RSIM_TIME,           /* [B]     sim.data.time                                              */
-  RSIM_CSTATE,         /* [B,32]  controller state: goal_pos3 goal_ori9 (joint types: goal_q/goal_torque[8] in the same slots) q0[8] grip[4] tau[8] */
+  RSIM_CSTATE,         /* [B,cs]  controller state, cs = rsim_model_int(m, "cstate_size"): OSC types (32) goal_pos3 goal_ori9 q0[8] grip[4] tau[8];
+                        *          joint-space types (64) goal[16] - grip[4] at 20 - tau[16] at 32 */
   RSIM_XPOS,           /* [B,nbody,3]  sim.data.xpos      (derived, valid after forward/step1) */
   RSIM_XQUAT,          /* [B,nbody,4]  sim.data.xquat                                        */
   RSIM_QM,             /* [B,nv,nv]    dense mass matrix (mj_fullM, controller.py:226-227)  */

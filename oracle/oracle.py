@@ -235,6 +235,21 @@ class OracleController:
             pass
 
 
+def env_step_parts(data: OracleData, parts, action, n_sub=25):
+    """One env.step() for a robot whose arms are separate part controllers (composite_controller.py:97-121): `parts` is a list of
+    (OracleController, action_dim); the flat action is sliced in list order; n_sub x { step1, set_goal on the first substep, run, step2 }."""
+    a = np.asarray(action, dtype=np.float64)
+    for i in range(n_sub):
+        data.step1()
+        off = 0
+        for c, adim in parts:
+            if i == 0:
+                c.set_goal(data, a[off:off + adim])
+            off += adim
+            c.run(data)
+        data.step2()
+
+
 def osc_torques(kp, kd, ep, eR, ev, op, oR, bv, goal_pos, goal_ori, J, M, bias, q, qd, q0, nullspace_kp=10.0, uncouple=True):
     """Explicit-input OSC torque law (restates osc.py:403-495); returns pre-clip torques."""
     f = lambda a: np.ascontiguousarray(a, dtype=np.float64)

@@ -32,12 +32,15 @@ class RsimError(RuntimeError):
     pass
 
 
+JNT_MAX = 16  # include/rsim.h RSIM_JNT_MAX
+
+
 class CtrlDesc(C.Structure):
-    _fields_ = [("ndof", C.c_int32), ("qpos_idx", C.c_int32 * 8), ("dof_idx", C.c_int32 * 8), ("act_idx", C.c_int32 * 8), ("eef_site", C.c_int32),
-                ("base_site", C.c_int32), ("kp", C.c_float * 8), ("damping_ratio", C.c_float), ("input_min", C.c_float * 8), ("input_max", C.c_float * 8),
-                ("output_min", C.c_float * 8), ("output_max", C.c_float * 8), ("uncouple_pos_ori", C.c_int32), ("nullspace_kp", C.c_float),
+    _fields_ = [("ndof", C.c_int32), ("qpos_idx", C.c_int32 * JNT_MAX), ("dof_idx", C.c_int32 * JNT_MAX), ("act_idx", C.c_int32 * JNT_MAX), ("eef_site", C.c_int32),
+                ("base_site", C.c_int32), ("kp", C.c_float * JNT_MAX), ("damping_ratio", C.c_float), ("input_min", C.c_float * JNT_MAX), ("input_max", C.c_float * JNT_MAX),
+                ("output_min", C.c_float * JNT_MAX), ("output_max", C.c_float * JNT_MAX), ("uncouple_pos_ori", C.c_int32), ("nullspace_kp", C.c_float),
                 ("ngrip", C.c_int32), ("grip_act", C.c_int32 * 4), ("grip_sign", C.c_float * 4), ("grip_speed", C.c_float),
-                ("type", C.c_int32), ("torque_min", C.c_float * 8), ("torque_max", C.c_float * 8)]
+                ("type", C.c_int32), ("torque_min", C.c_float * JNT_MAX), ("torque_max", C.c_float * JNT_MAX), ("part_of", C.c_int32 * JNT_MAX)]
 
 
 # arm part-controller types with an in-kernel implementation (include/rsim.h enum rsim_ctrl_type; names = the reference's config "type" strings)
@@ -73,13 +76,15 @@ def ctrl_desc(cfg: dict) -> CtrlDesc:
     d.ndof = n
     for i in range(n):
         d.qpos_idx[i], d.dof_idx[i], d.act_idx[i] = cfg["qpos_idx"][i], cfg["dof_idx"][i], cfg["act_idx"][i]
-    d.eef_site, d.base_site = cfg["eef_site"], cfg["base_site"]
+    d.eef_site, d.base_site = cfg.get("eef_site", 0), cfg.get("base_site", 0)
+    for i, p in enumerate(cfg.get("part_of", [0] * n)):
+        d.part_of[i] = p
     ctype = cfg.get("type", "OSC_POSE")
     if ctype not in CTRL_TYPES:
         raise RsimError(f"part controller type {ctype!r} has no in-kernel implementation (have {sorted(CTRL_TYPES)})")
     d.type = CTRL_TYPES[ctype]
     cdim = control_dim(cfg)
-    for i, v in enumerate(cfg.get("kp", [])[:8]):
+    for i, v in enumerate(cfg.get("kp", [])[:JNT_MAX]):
         d.kp[i] = v
     for k in ("input_min", "input_max", "output_min", "output_max"):
         if len(cfg[k]) != cdim:
@@ -178,6 +183,7 @@ class HipModel:
         _chk(self._L.rsim_model_set_controller(self.ptr, C.byref(d)))
         self.ctrl_cfg = cfg
         self.action_dim = control_dim(cfg) + (1 if cfg.get("grip_act") else 0)
+        self.cstate_size = self._L.rsim_model_int(self.ptr, b"cstate_size")
 
     def set_task(self, task: dict):
         """task: dict(obs=[(kind, a, b), ...], task="lift", object_body, grip_site, table_height, lift_margin, reward_scale, reward_shaping,
@@ -240,7 +246,7 @@ class HipBatch:
         self.maxcon, self.maxefc = mc.value, me.value
         m = model.flat
         nq, nv, nu, nb = m.nq, m.nv, m.nu, m.nbody
-        self.shapes = {"qpos": (B, nq), "qvel": (B, nv), "qacc_warmstart": (B, nv), "ctrl": (B, nu), "time": (B,), "cstate": (B, CSTATE),
+        self.shapes = {"qpos": (B, nq), "qvel": (B, nv), "qacc_warmstart": (B, nv), "ctrl": (B, nu), "time": (B,), "cstate": (B, getattr(model, "cstate_size", CSTATE)),
                        "xpos": (B, nb, 3), "xquat": (B, nb, 4), "qM": (B, nv, nv), "qfrc_bias": (B, nv), "qfrc_passive": (B, nv),
                        "qfrc_actuator": (B, nv), "qfrc_constraint": (B, nv), "qacc": (B, nv), "cdof": (B, nv, 6), "rootcom": (B, nb, 3),
                        "contact": (B, self.maxcon, CON_REC), "efc_force": (B, self.maxefc), "ncon": (B,), "nefc": (B,), "niter": (B,),

@@ -15,19 +15,22 @@
 #include "rsim_internal.h"
 
 // one set of launchers per compiled kernel configuration (rsim_step.hip is built once per RSIM_CFG)
-#define RSIM_NCFG 2
+#define RSIM_NCFG 3
 extern "C" int rsim_launch_step_cfg0(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
 extern "C" int rsim_launch_ctrl_reset_cfg0(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
 extern "C" int rsim_limits_cfg0(int* lim);
 extern "C" int rsim_launch_step_cfg1(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
 extern "C" int rsim_launch_ctrl_reset_cfg1(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
 extern "C" int rsim_limits_cfg1(int* lim);
+extern "C" int rsim_launch_step_cfg2(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
+extern "C" int rsim_launch_ctrl_reset_cfg2(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
+extern "C" int rsim_limits_cfg2(int* lim);
 typedef int (*step_fn)(const DModel*, const DBatch*, const float*, int, int, hipStream_t);
 typedef int (*creset_fn)(const DModel*, const DBatch*, const unsigned char*, hipStream_t);
 typedef int (*limits_fn)(int*);
-static const step_fn k_step_launch[RSIM_NCFG] = {rsim_launch_step_cfg0, rsim_launch_step_cfg1};
-static const creset_fn k_creset_launch[RSIM_NCFG] = {rsim_launch_ctrl_reset_cfg0, rsim_launch_ctrl_reset_cfg1};
-static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1};
+static const step_fn k_step_launch[RSIM_NCFG] = {rsim_launch_step_cfg0, rsim_launch_step_cfg1, rsim_launch_step_cfg2};
+static const creset_fn k_creset_launch[RSIM_NCFG] = {rsim_launch_ctrl_reset_cfg0, rsim_launch_ctrl_reset_cfg1, rsim_launch_ctrl_reset_cfg2};
+static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1, rsim_limits_cfg2};
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream);
 extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr* d, unsigned long long seed, unsigned long long step, hipStream_t stream);
 
@@ -97,6 +100,7 @@ struct rsim_batch {
   int fis_int[RSIM_FIELD_COUNT];
   int lim[8];
   int cfg;   // compiled kernel configuration serving this model (smallest that fits)
+  int cs;    // floats of controller state per env (fixed when the batch is created)
   // host cache for jacobians
   long gen, cache_gen;
   int cache_env;
@@ -224,8 +228,8 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
       LT(LT_ainfo, a) = jdof[j] | (m->I("jnt_qposadr")[j] << 8) | (m->I("actuator_biastype")[a] << 16) | (m->I("actuator_ctrllimited")[a] << 18) |
                         (m->I("actuator_forcelimited")[a] << 19);
     }
-    for (int p2 = 0; p2 < m->npair && p2 < 192; p2++)
-      LT(LT_pair0 + p2 / 64, p2 % 64) = m->geom2cg[m->I("pair_geom1")[p2]] | (m->geom2cg[m->I("pair_geom2")[p2]] << 8) | (1 << 16);
+    for (int p2 = 0; p2 < m->npair && p2 < 320; p2++)
+      LT(p2 < 192 ? LT_pair0 + p2 / 64 : LT_pair3 + (p2 - 192) / 64, p2 % 64) = m->geom2cg[m->I("pair_geom1")[p2]] | (m->geom2cg[m->I("pair_geom2")[p2]] << 8) | (1 << 16);
     for (int l = 0; l < 64; l++) {
       unsigned bits = 0;
       const int q = l / 16, r = l % 16;
@@ -420,12 +424,17 @@ extern "C" void rsim_model_free(rsim_model* m) { delete m; }
 
 extern "C" int rsim_model_int(const rsim_model* m, const char* name) {
   if (!strcmp(name, "ncgeom")) return (int)m->cg.size();
+  if (!strcmp(name, "cstate_size")) return m->ctrl.enabled ? m->ctrl.cs_size : RSIM_CS_SIZE;
+  if (!strcmp(name, "action_dim")) return m->ctrl.enabled ? m->ctrl.action_dim : 0;
   const int* v = m->I(name);
   return v ? v[0] : -1;
 }
 
 extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d) {
-  if (d->ndof < 1 || d->ndof > RSIM_ARM_MAX || d->ngrip < 0 || d->ngrip > RSIM_GRIP_MAX) return fail("controller: bad ndof/ngrip");
+  if (d->type < RSIM_CTRL_OSC_POSE || d->type > RSIM_CTRL_JOINT_TORQUE) return fail("controller: unknown part-controller type %d", d->type);
+  const bool jointspace = d->type >= RSIM_CTRL_JOINT_POSITION;
+  if (d->ndof < 1 || d->ndof > (jointspace ? RSIM_JNT_MAX : RSIM_ARM_MAX) || d->ngrip < 0 || d->ngrip > RSIM_GRIP_MAX)
+    return fail("controller: bad ndof/ngrip (%d joints: at most %d for this controller type)", d->ndof, jointspace ? RSIM_JNT_MAX : RSIM_ARM_MAX);
   DCtrl& c = m->ctrl;
   memset(&c, 0, sizeof(c));
   c.enabled = 1; c.ndof = d->ndof;
@@ -434,10 +443,11 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
       return fail("controller: index out of range");
     c.qpos_idx[i] = d->qpos_idx[i]; c.dof_idx[i] = d->dof_idx[i]; c.act_idx[i] = d->act_idx[i];
   }
-  if (d->eef_site < 0 || d->eef_site >= m->nsite || d->base_site < 0 || d->base_site >= m->nsite) return fail("controller: bad site id");
-  c.eef_site = d->eef_site; c.base_site = d->base_site;
-  if (d->type < RSIM_CTRL_OSC_POSE || d->type > RSIM_CTRL_JOINT_TORQUE) return fail("controller: unknown part-controller type %d", d->type);
+  if (!jointspace && (d->eef_site < 0 || d->eef_site >= m->nsite || d->base_site < 0 || d->base_site >= m->nsite)) return fail("controller: bad site id");
+  c.eef_site = jointspace ? 0 : d->eef_site; c.base_site = jointspace ? 0 : d->base_site;
   c.type = d->type;
+  c.cs_size = jointspace ? RSIM_CS_SIZE_JOINT : RSIM_CS_SIZE;
+  for (int i = 0; i < d->ndof; i++) c.part_of[i] = d->part_of[i];
   c.cdim = d->type == RSIM_CTRL_OSC_POSE ? 6 : d->type == RSIM_CTRL_OSC_POSITION ? 3 : d->ndof;
   const int ngain = d->type == RSIM_CTRL_JOINT_POSITION ? d->ndof : (d->type == RSIM_CTRL_JOINT_TORQUE ? 0 : 6);
   for (int i = 0; i < ngain; i++) {
@@ -568,6 +578,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   memcpy(dm.io, m->io, sizeof(dm.io));
   memcpy(dm.fo, m->fo, sizeof(dm.fo));
   dm.ctrl = m->ctrl;
+  b->cs = m->ctrl.enabled ? m->ctrl.cs_size : RSIM_CS_SIZE;
+  dm.ctrl.cs_size = b->cs;
   b->d_obsprog = nullptr;
   memset(&dm.task, 0, sizeof(dm.task));
   if (m->has_task) {
@@ -584,7 +596,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   const int nq = m->nq, nv = m->nv, nu = m->nu, nb = m->nbody, NCON = b->lim[5], NEFC = b->lim[6];
   struct { int id; void** p; size_t n; int is_int; } fields[] = {
       {RSIM_QPOS, (void**)&db.qpos, (size_t)B * nq, 0}, {RSIM_QVEL, (void**)&db.qvel, (size_t)B * nv, 0}, {RSIM_QACC_WARMSTART, (void**)&db.qacc_ws, (size_t)B * nv, 0},
-      {RSIM_CTRL, (void**)&db.ctrl, (size_t)B * nu, 0}, {RSIM_TIME, (void**)&db.time, (size_t)B, 0}, {RSIM_CSTATE, (void**)&db.cstate, (size_t)B * RSIM_CS_SIZE, 0},
+      {RSIM_CTRL, (void**)&db.ctrl, (size_t)B * nu, 0}, {RSIM_TIME, (void**)&db.time, (size_t)B, 0}, {RSIM_CSTATE, (void**)&db.cstate, (size_t)B * b->cs, 0},
       {RSIM_XPOS, (void**)&db.xpos, (size_t)B * nb * 3, 0}, {RSIM_XQUAT, (void**)&db.xquat, (size_t)B * nb * 4, 0}, {RSIM_QM, (void**)&db.qM, (size_t)B * nv * nv, 0},
       {RSIM_QFRC_BIAS, (void**)&db.qfrc_bias, (size_t)B * nv, 0}, {RSIM_QFRC_PASSIVE, (void**)&db.qfrc_passive, (size_t)B * nv, 0},
       {RSIM_QFRC_ACTUATOR, (void**)&db.qfrc_actuator, (size_t)B * nv, 0}, {RSIM_QFRC_CONSTRAINT, (void**)&db.qfrc_constraint, (size_t)B * nv, 0},
@@ -634,7 +646,7 @@ extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) {
     HIPCHK(hipMemset(b->db.qacc_ws, 0, (size_t)B * nv * sizeof(float)));
     HIPCHK(hipMemset(b->db.ctrl, 0, (size_t)B * nu * sizeof(float)));
     HIPCHK(hipMemset(b->db.time, 0, (size_t)B * sizeof(float)));
-    HIPCHK(hipMemset(b->db.cstate, 0, (size_t)B * RSIM_CS_SIZE * sizeof(float)));
+    HIPCHK(hipMemset(b->db.cstate, 0, (size_t)B * b->cs * sizeof(float)));
     HIPCHK(hipMemset(b->db.ep_step, 0, (size_t)B * sizeof(int))); HIPCHK(hipMemset(b->db.ep_index, 0, (size_t)B * sizeof(int)));
     HIPCHK(hipMemset(b->db.done, 0, (size_t)B * sizeof(int))); HIPCHK(hipMemset(b->db.needs_reset, 0, (size_t)B * sizeof(int)));
   } else {
@@ -645,7 +657,7 @@ extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) {
       HIPCHK(hipMemset(b->db.qacc_ws + (size_t)e * nv, 0, nv * sizeof(float)));
       HIPCHK(hipMemset(b->db.ctrl + (size_t)e * nu, 0, nu * sizeof(float)));
       HIPCHK(hipMemset(b->db.time + e, 0, sizeof(float)));
-      HIPCHK(hipMemset(b->db.cstate + (size_t)e * RSIM_CS_SIZE, 0, RSIM_CS_SIZE * sizeof(float)));
+      HIPCHK(hipMemset(b->db.cstate + (size_t)e * b->cs, 0, b->cs * sizeof(float)));
       HIPCHK(hipMemset(b->db.ep_step + e, 0, sizeof(int))); HIPCHK(hipMemset(b->db.done + e, 0, sizeof(int))); HIPCHK(hipMemset(b->db.needs_reset + e, 0, sizeof(int)));
     }
   }

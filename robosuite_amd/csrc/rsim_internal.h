@@ -42,6 +42,7 @@ enum {
   LT_pair0, LT_pair1, LT_pair2, /* candidate pair p = lane + 64 t: g1 | g2<<8 | valid<<16 */
   LT_ghull,  /* colliding geom g = lane: first slot of its hull in the LDS-resident vertex pool, -1 = scan from global memory */
   LT_mfbits, /* 0/1 operands of the tree-incidence MFMAs: sub[8] | bodydof[2][4] | dcv[4] | m1[4] | m2[4] */
+  LT_pair3, LT_pair4, /* candidate pairs 192..319 (configurations with more than three rows of pairs) */
   LT_COUNT
 };
 #define RSIM_MAXDYNROOT 4
@@ -53,11 +54,13 @@ enum {
 struct DCtrl {
   int enabled;
   int ndof;
-  int qpos_idx[RSIM_ARM_MAX], dof_idx[RSIM_ARM_MAX], act_idx[RSIM_ARM_MAX];
+  int qpos_idx[RSIM_JNT_MAX], dof_idx[RSIM_JNT_MAX], act_idx[RSIM_JNT_MAX];
   int eef_site, base_site;
-  float kp[RSIM_ARM_MAX], kd[RSIM_ARM_MAX], in_min[RSIM_ARM_MAX], in_max[RSIM_ARM_MAX], out_min[RSIM_ARM_MAX], out_max[RSIM_ARM_MAX];
-  float tl_lo[RSIM_ARM_MAX], tl_hi[RSIM_ARM_MAX];
-  int type, cdim;   // rsim_ctrl_type, control_dim of the arm part
+  float kp[RSIM_JNT_MAX], kd[RSIM_JNT_MAX], in_min[RSIM_JNT_MAX], in_max[RSIM_JNT_MAX], out_min[RSIM_JNT_MAX], out_max[RSIM_JNT_MAX];
+  float tl_lo[RSIM_JNT_MAX], tl_hi[RSIM_JNT_MAX];
+  int part_of[RSIM_JNT_MAX];
+  int type, cdim;   // rsim_ctrl_type, control_dim of the arm part(s)
+  int cs_size;      // floats of per-env controller state (RSIM_CS_SIZE for the OSC types, RSIM_CS_SIZE_JOINT for the joint-space ones)
   int uncouple;
   float nullspace_kp;
   int ngrip;
@@ -74,6 +77,10 @@ struct DCtrl {
 #define RSIM_CS_GRIP 20
 #define RSIM_CS_TAU 24
 #define RSIM_CS_SIZE 32
+/* joint-space parts (up to RSIM_JNT_MAX joints): goal[16] at 0, grip[4] at 20 (shared with the OSC layout), tau[16] at 32 */
+#define RSIM_CS_TAU_JOINT 32
+#define RSIM_CS_SIZE_JOINT 64
+#define RSIM_CS_MAX 64
 
 // observation / reward epilogue (include/rsim.h rsim_task_desc), device form
 struct DTask {

@@ -14,19 +14,23 @@
 #include "../../include/rsim.h"
 #include "rsim_internal.h"
 
-// Two builds of this file: RSIM_CFG 0 = up to 16 dofs (Lift/Panda; every dense nv x nv product on one 16x16 MFMA tile, register-resident
-// Cholesky), RSIM_CFG 1 = up to 32 dofs (Stack/Panda: two free cubes).  The wide build keeps the lane roles, the collision pipeline, the
-// constraint rows and the Newton algorithm; the tree products run as mask-guided lane loops, the dense ones as 2 x 2 MFMA tiles and the
-// factorisations on the LDS matrix.  `sm` is one file-scope LDS object, so each configuration is its own translation unit.
+// Three builds of this file: RSIM_CFG 0 = 32 bodies x 16 dofs (Lift/Panda; tree products as incidence-matrix MFMAs, every dense nv x nv
+// product on one 16x16 MFMA tile, register-resident Cholesky), RSIM_CFG 1 = 32 bodies x 32 dofs (Stack/Panda: two free cubes),
+// RSIM_CFG 2 = 64 bodies x 16 dofs (Baxter).  The larger builds keep the lane roles, the collision pipeline, the constraint rows and the
+// Newton algorithm; beyond 32 x 16 the tree products run as mask-guided lane loops, beyond 16 dofs the dense products as 2 x 2 MFMA
+// tiles with the factorisations on the LDS matrix.  `sm` is one file-scope LDS object, so each configuration is its own translation unit.
 #ifndef RSIM_CFG
 #define RSIM_CFG 0
 #endif
 #if RSIM_CFG == 0
 #define RSIM_DIMS 32, 16, 16, 24, 16, 16, 64, 192
 #define RSIM_SYM(x) x##_cfg0
-#else
+#elif RSIM_CFG == 1
 #define RSIM_DIMS 32, 16, 32, 24, 16, 32, 64, 192
 #define RSIM_SYM(x) x##_cfg1
+#else  // 64 bodies x 16 dofs (Baxter: 36 bodies, 29 colliding geoms, 17 sites, 299 candidate pairs): tree products as mask loops, dense ones on one tile
+#define RSIM_DIMS 64, 16, 16, 32, 32, 32, 64, 320
+#define RSIM_SYM(x) x##_cfg2
 #endif
 
 #ifndef RSIM_MINWAVES
@@ -197,8 +201,8 @@ __device__ __forceinline__ S6 mul_inert(const float* I, S6 v) {
 
 // ------------------------------------------------------------------------------------------------------------
 
-// LDS words of the per-lane constant block: 29 body fields x 32, 13 dof x NV, 11 geom x 32, 8 site x 16, 10 actuator x 16, 5 ctrl x 8, 3 pair rows + mfbits x 64
-#define RSIM_KC_WORDS(NV) (29 * 32 + 13 * (NV) + 11 * 32 + 8 * 16 + 10 * 16 + 5 * 8 + 4 * 64)
+// LDS words of the per-lane constant block: 29 body fields x NB, 13 dof x NV, 11 geom x 32, 8 site x NS, 10 actuator x 16, 5 ctrl x 16, pair rows + mfbits x 64
+#define RSIM_KC_WORDS(NB, NV, NS, NPAIR) (29 * (NB) + 13 * (NV) + 11 * 32 + 8 * (NS) + 10 * 16 + 5 * 16 + ((NPAIR) / 64 + 1) * 64)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 // explicitly global (address space 1) views of the model tables: pointers that arrive inside the by-value DModel would otherwise be
@@ -213,11 +217,14 @@ __device__ __forceinline__ Q4 ldq(gcf p) { Q4 q = {p[0], p[1], p[2], p[3]}; retu
 // ------------------------------------------------------------------------------------------------------------
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 struct Smem {
-  static_assert(NB == 32 && (NV == 16 || NV == 32) && NEFC == 64, "32 body lanes, 16 (one MFMA tile, register Cholesky) or 32 dofs, one lane per constraint row");
+  static_assert((NB == 32 || NB == 64) && (NV == 16 || NV == 32) && NEFC == 64 && NG <= 32 && (NS == 16 || NS == 32) && NPAIR % 64 == 0 && NPAIR <= 320,
+                "lane roles: body / site / dof columns are powers of two, one lane per constraint row, candidate pairs in rows of 64");
+  static constexpr bool TREE_TILE_ = NB == 32 && NV == 16;   // tree products as 32-body x 16-dof incidence-matrix MFMAs
   static constexpr int NVP = NV + 1;  // padded row stride of the dense nv x nv matrices (conflict-free column reads)
   static constexpr int NV_ = NV;
   static constexpr int JS_ = NV + 1, CS6_ = 9, FS_ = 17;  // LDS row strides (odd => bank-conflict-free lane-per-row access)
-  static constexpr int NM_ = NV == 16 ? 1 : NV;         // extent of the tree bit-mask tables (wide configuration only)
+  static constexpr int NM_ = TREE_TILE_ ? 1 : NV;       // extent of the tree bit-mask tables (mask-loop configurations only)
+  static constexpr int NS_ = NS, NPT_ = NPAIR / 64;
   static constexpr int CD_ = 4;       // largest contact dimension this configuration handles (condim 1, 3, 4)
   static constexpr int NCON_ = NCON;
   static constexpr int NB_ = NB;
@@ -258,14 +265,15 @@ struct Smem {
   float J[NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
   float e_R[NEFC], e_aref[NEFC], e_force[NEFC], e_B[NEFC];
   int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
-  float cstate[RSIM_CS_SIZE];
+  float cstate[RSIM_CS_MAX];
   float red[NV];
   // wide configuration: tree incidence as bit masks (dof-ancestor set, dofs summed before dof i in the velocity recursion, body ancestors)
-  int dmask_anc[NM_], dmask_cvel[NM_], bmask_anc[NV == 16 ? 1 : NB];
+  int dmask_anc[NM_], dmask_cvel[NM_];
+  unsigned long long bmask_anc[TREE_TILE_ ? 1 : NB];
   float hull[3 * RSIM_HULL_POOL];   // LDS-resident hull vertex pool (SoA x | y | z); filled once per launch
   int ghull[NG];                    // first pool slot of geom g, -1: not resident
   // per-lane model constants, one row per field (LaneConst below); phases fetch the handful they need instead of pinning ~80 VGPRs
-  float kc[RSIM_KC_WORDS(NV)];
+  float kc[RSIM_KC_WORDS(NB, NV, NS, NPAIR)];
   int ncon, nefc, niter;
 };
 
@@ -554,7 +562,7 @@ struct LaneConst {
   int ainfo;
   float agear, again, ab0, ab1, ab2, acr0, acr1, afr0, afr1;
   // candidate pairs p = lane + 64 t
-  int pair[3];
+  int pair[5];
   unsigned mfbits;
   // built-in controller, lane i = arm joint i / gripper actuator i
   int cq, cd, ca, cga;
@@ -577,7 +585,9 @@ struct Sim {
   static constexpr int CD = SM::CD_;
   static constexpr int JS = SM::JS_, CS6 = SM::CS6_, FS = SM::FS_;
   static constexpr int SM_NB = SM::NB_;
-  static constexpr bool FAST = SM::NV_ == 16;   // one-tile configuration: register Cholesky + incidence-matrix MFMAs
+  static constexpr bool FAST = SM::NV_ == 16;   // one-tile dense algebra: 16 x 16 MFMA products + register Cholesky
+  static constexpr bool TREE = SM::TREE_TILE_;  // tree products (CRBA composite inertias, RNE sums) as incidence-matrix MFMAs
+  static constexpr int NPT = SM::NPT_;          // rows of 64 candidate pairs
   static constexpr int NT = SM::NV_ / 16;       // 16-dof tiles per dimension of the dense nv x nv products
 
   __device__ Sim(const DModel& m_, const float* fp_, int lane_, unsigned long long* prof) : m(m_), fp(fp_), lane(lane_) { pf.p = prof; pf.lane = lane_; pf.t0 = 0; }
@@ -601,8 +611,8 @@ struct Sim {
   // compiler drops the rows a phase does not use
   template <bool STORE> __device__ __forceinline__ void kxfer(LaneConst& K) const {
     int o = 0;
-    {  // body role, 32 columns
-      const int l = lane & 31, W = 32;
+    {  // body role, NB columns
+      const int l = lane & (SM_NB - 1), W = SM_NB;
       if (!STORE || lane < W) {
         kio<STORE>(K.part, o + 0 * W + l); kio<STORE>(K.part4, o + 1 * W + l); kio<STORE>(K.binfo, o + 2 * W + l); kio<STORE>(K.bdofs, o + 3 * W + l);
         kio<STORE>(K.bpos, o + 4 * W + l, W); kio<STORE>(K.bquat, o + 7 * W + l, W); kio<STORE>(K.jpos, o + 11 * W + l, W); kio<STORE>(K.jaxis, o + 14 * W + l, W);
@@ -626,8 +636,8 @@ struct Sim {
       if (!STORE || lane < W) { kio<STORE>(K.ginfo, o + l); kio<STORE>(K.gp, o + 1 * W + l, W); kio<STORE>(K.gq, o + 4 * W + l, W); kio<STORE>(K.grc, o + 8 * W + l, W); }
       o += 11 * W;
     }
-    {  // site role, 16 columns
-      const int l = lane & 15, W = 16;
+    {  // site role, NS columns
+      const int l = lane & (SM::NS_ - 1), W = SM::NS_;
       if (!STORE || lane < W) { kio<STORE>(K.sbody, o + l); kio<STORE>(K.sp, o + 1 * W + l, W); kio<STORE>(K.sq, o + 4 * W + l, W); }
       o += 8 * W;
     }
@@ -639,12 +649,14 @@ struct Sim {
       }
       o += 10 * W;
     }
-    {  // controller role, 8 columns
-      const int l = lane & 7, W = 8;
+    {  // controller role, 16 columns (joint-space parts drive up to 16 joints; the OSC types use the first 8)
+      const int l = lane & 15, W = 16;
       if (!STORE || lane < W) { kio<STORE>(K.cq, o + l); kio<STORE>(K.cd, o + W + l); kio<STORE>(K.ca, o + 2 * W + l); kio<STORE>(K.cga, o + 3 * W + l); kio<STORE>(K.cgs, o + 4 * W + l); }
       o += 5 * W;
     }
-    kio<STORE>(K.pair[0], o + lane); kio<STORE>(K.pair[1], o + 64 + lane); kio<STORE>(K.pair[2], o + 128 + lane); kio<STORE>(K.mfbits, o + 192 + lane);
+#pragma unroll
+    for (int t = 0; t < NPT; t++) kio<STORE>(K.pair[t], o + 64 * t + lane);
+    kio<STORE>(K.mfbits, o + 64 * NPT + lane);
   }
   __device__ __forceinline__ LaneConst fetchK() const { LaneConst K; kxfer<false>(K); return K; }
 
@@ -654,7 +666,8 @@ struct Sim {
     gci lt = (gci)m.lt;
     K.part = lt[LT_part * 64 + lane]; K.part4 = lt[LT_part4 * 64 + lane]; K.binfo = lt[LT_binfo * 64 + lane]; K.bdofs = (unsigned)lt[LT_bdofs * 64 + lane];
     K.dinfo = lt[LT_dinfo * 64 + lane]; K.ginfo = lt[LT_ginfo * 64 + lane]; K.sbody = lt[LT_sinfo * 64 + lane]; K.ainfo = lt[LT_ainfo * 64 + lane];
-    K.pair[0] = lt[LT_pair0 * 64 + lane]; K.pair[1] = lt[LT_pair1 * 64 + lane]; K.pair[2] = lt[LT_pair2 * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < NPT; t++) K.pair[t] = lt[(t < 3 ? LT_pair0 + t : LT_pair3 + (t - 3)) * 64 + lane];
     K.mfbits = (unsigned)lt[LT_mfbits * 64 + lane];
     opt_h = FP(FO_opt, 0); opt_grav = v3(FP(FO_opt, 1), FP(FO_opt, 2), FP(FO_opt, 3)); opt_density = FP(FO_opt, 4); opt_viscosity = FP(FO_opt, 5);
     opt_impratio = FP(FO_opt, 6); opt_wind = v3(FP(FO_opt, 7), FP(FO_opt, 8), FP(FO_opt, 9));
@@ -690,9 +703,9 @@ struct Sim {
         sm.fricR[lane] = R; sm.fricB[lane] = Bd; sm.fricFl[lane] = fl;
       }
       if (lane >= nv) K.dinfo = 0;
-      if constexpr (!FAST) {
+      if constexpr (!TREE) {
         if (lane < NV16) { sm.dmask_anc[lane] = lane < nv ? IT(IO_dof_ancmask, 2 * i) : 0; sm.dmask_cvel[lane] = lane < nv ? IT(IO_dof_cvelmask, 2 * i) : 0; }
-        if (lane < SM_NB) sm.bmask_anc[lane] = lane < nb ? IT(IO_body_ancmask, 2 * lane) : 0;
+        if (lane < SM_NB) sm.bmask_anc[lane] = lane < nb ? mask2(IO_body_ancmask, lane) : 0ull;
       }
     }
     {  // geom role
@@ -876,7 +889,7 @@ struct Sim {
   // f_i = crbD_i * cdof_i ;  M = (m1 o F C^T) + (m2 o C F^T) + diag(armature)        (F, C = 16 x 6 stacks of f_i, cdof_i)
   // wide configuration: the same products as mask-guided lane loops (lane i = dof i sums the bodies of its subtree; element-parallel M),
   // factorisations on the LDS matrix
-  __device__ __forceinline__ void crb_wide() {
+  __device__ __forceinline__ void crb_composite_loops() {
     const LaneConst K = fetchK();
     const int nv = m.nv, nb = m.nbody;
     if (lane < NV16) {
@@ -898,6 +911,10 @@ struct Sim {
       st3(o, f.a); st3(o + 3, f.l); o[6] = 0.f; o[7] = 0.f;
     }
     SYNC();
+  }
+  __device__ __forceinline__ void crb_mass_loops() {
+    const LaneConst K = fetchK();
+    const int nv = m.nv;
     for (int e = lane; e < NV16 * NV16; e += 64) {
       const int i = e / NV16, j = e - i * NV16;
       float mij = 0.f;
@@ -919,9 +936,10 @@ struct Sim {
   }
 
   __device__ __forceinline__ void crb() {
-    if constexpr (FAST) crb_tile(); else crb_wide();
+    if constexpr (TREE) crb_composite_tile(); else crb_composite_loops();
+    if constexpr (FAST) crb_mass_tile(); else crb_mass_loops();
   }
-  __device__ __forceinline__ void crb_tile() {
+  __device__ __forceinline__ void crb_composite_tile() {
     const LaneConst K = fetchK();
     const int nv = m.nv, q = lane >> 4, r = lane & 15;
     v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -937,6 +955,10 @@ struct Sim {
       st3(o, f.a); st3(o + 3, f.l); o[6] = 0.f; o[7] = 0.f;
     }
     SYNC();
+  }
+  __device__ __forceinline__ void crb_mass_tile() {
+    const LaneConst K = fetchK();
+    const int nv = m.nv, q = lane >> 4, r = lane & 15;
     v4f R1 = {0.f, 0.f, 0.f, 0.f}, R2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kc = 0; kc < 2; kc++) {
@@ -985,7 +1007,7 @@ struct Sim {
     const int nb = m.nbody, nv = m.nv, q = lane >> 4, r = lane & 15;
     float Bc[4];
     v4f a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
-    if constexpr (FAST) {
+    if constexpr (TREE) {
 #pragma unroll
     for (int c = 0; c < 4; c++) Bc[c] = r < 6 ? sm.cdof[(4 * c + q) * CS6 + r] * sm.qvel[4 * c + q] : 0.f;
 #pragma unroll
@@ -1011,7 +1033,7 @@ struct Sim {
       st3(o, cd.a); st3(o + 3, cd.l); o[6] = 0.f; o[7] = 0.f;
     }
     SYNC();
-    if constexpr (FAST) {
+    if constexpr (TREE) {
 #pragma unroll
     for (int c = 0; c < 4; c++) Bc[c] = r < 6 ? sm.u.v.cdd[(4 * c + q) * CS6 + r] * sm.qvel[4 * c + q] : 0.f;
     a0 = a1 = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -1077,7 +1099,7 @@ struct Sim {
       o[12] = o[13] = o[14] = o[15] = 0.f;
     }
     SYNC();
-    if constexpr (FAST) {
+    if constexpr (TREE) {
     v4f af = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 8; c++) af = __builtin_amdgcn_mfma_f32_16x16x4f32(bitf(K.mfbits, c), sm.u.v.cf[(4 * c + q) * FS + r], af, 0, 0, 0);
@@ -1428,7 +1450,7 @@ struct Sim {
     // order-preserving compaction of the survivors
     int ncand = 0;
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
+    for (int t = 0; t < NPT; t++) {
       if (64 * t >= m.npair) break;
       const int pr = K.pair[t];
       bool pass = false;
@@ -1759,7 +1781,7 @@ struct Sim {
     if (c.type >= RSIM_CTRL_JOINT_POSITION) {
       // joint-space parts: lane i scales its own component (controller.py:149-168).  JOINT_POSITION: goal_qpos = joint_pos + delta
       // (joint_pos.py:200-236); JOINT_TORQUE: goal_torque = clip(scaled, torque_limits) (joint_tor.py:111-128)
-      const int li = lane & (RSIM_ARM_MAX - 1);
+      const int li = lane & (RSIM_JNT_MAX - 1);
       const float imin = sel(c.in_min, li), imax = sel(c.in_max, li), omin = sel(c.out_min, li), omax = sel(c.out_max, li);
       const float tlo = sel(c.tl_lo, li), thi = sel(c.tl_hi, li);
       if (lane < c.ndof) {
@@ -1815,7 +1837,7 @@ struct Sim {
   __device__ __forceinline__ void ctrl_reset() {
     const LaneConst K = fetchK();
     const DCtrl& c = m.ctrl;
-    if (lane < c.ndof) sm.cstate[RSIM_CS_Q0 + lane] = sm.qpos[K.cq];
+    if (c.type < RSIM_CTRL_JOINT_POSITION && lane < c.ndof) sm.cstate[RSIM_CS_Q0 + lane] = sm.qpos[K.cq];
     if (c.type >= RSIM_CTRL_JOINT_POSITION) {   // joint_pos.py:268-276 (goal_qpos = joint_pos), joint_tor.py:170-178 (goal_torque = 0)
       if (lane < c.ndof) sm.cstate[RSIM_CS_GOALQ + lane] = c.type == RSIM_CTRL_JOINT_POSITION ? sm.qpos[K.cq] : 0.f;
       if (lane < RSIM_GRIP_MAX) sm.cstate[RSIM_CS_GRIP + lane] = 0.f;
@@ -1835,7 +1857,7 @@ struct Sim {
     const DCtrl& c = m.ctrl;
     const float alo = __shfl(K.acr0, K.ca), ahi = __shfl(K.acr1, K.ca);
     if (lane < c.ndof) {
-      sm.cstate[RSIM_CS_TAU + lane] = tq;
+      sm.cstate[(c.type >= RSIM_CTRL_JOINT_POSITION ? RSIM_CS_TAU_JOINT : RSIM_CS_TAU) + lane] = tq;
       sm.ctrl[K.ca] = fmaxf(alo, fminf(ahi, tq));
     }
     const float glo = __shfl(K.acr0, K.cga), ghi = __shfl(K.acr1, K.cga);
@@ -1848,16 +1870,17 @@ struct Sim {
   __device__ __forceinline__ void ctrl_run_joint(const LaneConst& K) {
     const DCtrl& c = m.ctrl;
     const int n = c.ndof;
-    constexpr int NA = RSIM_ARM_MAX;
+    constexpr int NA = RSIM_JNT_MAX;
     const int li = lane & (NA - 1);
     const int di = lane < n ? K.cd : 0, qi = lane < n ? K.cq : 0;
     const float goal = lane < n ? sm.cstate[RSIM_CS_GOALQ + lane] : 0.f;
     float tq = lane < n ? sm.qfrc_bias[di] : 0.f;
     if (c.type == RSIM_CTRL_JOINT_POSITION) {
       const float des = lane < n ? sel(c.kp, li) * (goal - sm.qpos[qi]) - sel(c.kd, li) * sm.qvel[di] : 0.f;
+      const int mypart = seli(c.part_of, li);
 #pragma unroll
-      for (int k = 0; k < NA; k++) {
-        const float mk = (lane < n && k < n) ? sm.M[di * NVP + c.dof_idx[k]] : 0.f;
+      for (int k = 0; k < NA; k++) {   // the part's own mass-matrix block (each arm of a multi-arm robot is its own controller object)
+        const float mk = (lane < n && k < n && c.part_of[k] == mypart) ? sm.M[di * NVP + c.dof_idx[k]] : 0.f;
         tq = fmaf(mk, bcast(des, k), tq);
       }
     } else tq += goal;
@@ -2371,7 +2394,8 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   for (int i = lane; i < m.nv; i += 64) { sm.qvel[i] = b.qvel[(size_t)env * m.nv + i]; sm.qacc_ws[i] = b.qacc_ws[(size_t)env * m.nv + i]; }
   if (lane >= m.nv && lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.qacc[lane] = 0.f; }
   for (int i = lane; i < m.nu; i += 64) sm.ctrl[i] = b.ctrl[(size_t)env * m.nu + i];
-  if (lane < RSIM_CS_SIZE) sm.cstate[lane] = b.cstate[(size_t)env * RSIM_CS_SIZE + lane];
+  const int cs = m.ctrl.cs_size;
+  if (lane < cs) sm.cstate[lane] = b.cstate[(size_t)env * cs + lane];
   if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; }
   sim.load_constants();
   const float* act = actions ? actions + (size_t)env * m.ctrl.action_dim : nullptr;
@@ -2379,7 +2403,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   if ((flags & RF_CTRL) && b.needs_reset[env]) {
     // this env was re-initialised on the device when its previous episode ended: fresh controller objects (robots/robot.py:271)
     V3 xp0; Q4 xq0;
-    if (lane < RSIM_CS_SIZE) sm.cstate[lane] = 0.f;
+    if (lane < cs) sm.cstate[lane] = 0.f;
     SYNC();
     sim.kinematics(xp0, xq0);
     sim.geom_site_frames();
@@ -2448,7 +2472,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   for (int i = lane; i < m.nq; i += 64) b.qpos[(size_t)env * m.nq + i] = sm.qpos[i];
   for (int i = lane; i < m.nv; i += 64) { b.qvel[(size_t)env * m.nv + i] = sm.qvel[i]; b.qacc_ws[(size_t)env * m.nv + i] = sm.qacc_ws[i]; }
   for (int i = lane; i < m.nu; i += 64) b.ctrl[(size_t)env * m.nu + i] = sm.ctrl[i];
-  if (lane < RSIM_CS_SIZE) b.cstate[(size_t)env * RSIM_CS_SIZE + lane] = sm.cstate[lane];
+  if (lane < cs) b.cstate[(size_t)env * cs + lane] = sm.cstate[lane];
   if (lane == 0) b.time[env] = time;
   if (b.prof && lane == 0) {
     unsigned long long* wl = b.prof + RP_COUNT + 8 * (size_t)env;
@@ -2491,13 +2515,14 @@ __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const uns
   const float* fp = m.ft + (size_t)env * m.fstride;
   Sim<SM> sim(m, fp, lane, nullptr);
   for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = b.qpos[(size_t)env * m.nq + i];
-  if (lane < RSIM_CS_SIZE) sm.cstate[lane] = 0.f;
+  const int cs = m.ctrl.cs_size;
+  if (lane < cs) sm.cstate[lane] = 0.f;
   sim.load_constants();
   V3 xp; Q4 xq;
   sim.kinematics(xp, xq);
   sim.geom_site_frames();
   sim.ctrl_reset();
-  if (lane < RSIM_CS_SIZE) b.cstate[(size_t)env * RSIM_CS_SIZE + lane] = sm.cstate[lane];
+  if (lane < cs) b.cstate[(size_t)env * cs + lane] = sm.cstate[lane];
 }
 
 

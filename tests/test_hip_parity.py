@@ -199,6 +199,73 @@ def test_scripted_stacking_replay_reaches_success_on_the_device():
     assert np.isfinite(hb.get("qvel")).all()
 
 
+def test_baxter_model_forward_quantities_with_contacts_match_oracle():
+    """TwoArmPegInHole / Baxter (36 bodies, 29 colliding geoms incl. 19 cylinders, 299 candidate pairs) on the 64-body kernel configuration:
+    random arm configurations, including self-colliding ones, against the oracle (kinematics, M, bias, contact list, accelerations)."""
+    g, cfg, flat = load_golden("ctl_joint_torque", "peg_baxter")
+    assert flat.nbody == 36
+    om, od, _ = make_oracle(flat)
+    hm, hb = make_hip(flat, None, B=2)
+    rng = np.random.default_rng(7)
+    seen_contacts = tight = total = 0
+    for it in range(40):
+        q = flat.qpos0.copy()
+        for j in range(flat.njnt):
+            lo, hi = flat.jnt_range[j]
+            q[flat.jnt_qposadr[j]] = rng.uniform(lo + 0.05 * (hi - lo), hi - 0.05 * (hi - lo))
+        v = 0.5 * rng.standard_normal(flat.nv)
+        od.qpos[:] = q; od.qvel[:] = v; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0; od.forward()
+        if it >= 6 and od.ncon == 0:
+            continue                       # a few contact-free states, then only colliding ones
+        if od.ncon >= hb.maxcon or od.nefc >= hb.maxefc:
+            continue
+        hb.set("qpos", q[None].repeat(2, 0)); hb.set("qvel", v[None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0); hb.forward()
+        assert np.abs(hb.get("xpos")[0].ravel() - od.xpos).max() < 3e-6
+        assert rel(hb.get("qM")[0].ravel(), od.qM) < 1e-5
+        assert rel(hb.get("qfrc_bias")[0], od.qfrc_bias) < 1e-5
+        assert hb.get("ncon")[0] == od.ncon and hb.get("nefc")[0] == od.nefc, it
+        for a, b in zip(hb.contacts(0), od.contacts()):
+            assert (a["geom1"], a["geom2"], a["dim"]) == (b["geom1"], b["geom2"], b["dim"])
+            # Cylinder / sphere / hull pairs go through MPR, whose answer is the depth and normal of the LAST portal.  These random poses
+            # interpenetrate by centimetres, where the penetration direction can be ambiguous: a near-degenerate portal choice then falls
+            # differently in fp32 and fp64 and the two runs end on different (equally valid) portals.  So: most contacts agree to rounding,
+            # every contact agrees to 5% of its depth + 0.5 mm.
+            d = abs(a["dist"] - b["dist"])
+            assert d < 5e-4 + 5e-2 * abs(b["dist"]), (it, a["geom1"], a["geom2"])
+            tight += d < 2e-6 + 1e-4 * abs(b["dist"]); total += 1
+        if od.ncon == 0:
+            assert np.abs(hb.get("qacc")[0] - od.qacc).max() < 2e-4 * max(1.0, np.abs(od.qacc).max())
+        seen_contacts += od.ncon > 0
+    assert seen_contacts >= 3 and tight >= 0.75 * total
+
+
+@pytest.mark.parametrize("tag", ("ctl_joint_position", "ctl_joint_torque"))
+def test_baxter_two_arm_joint_space_control_step_tracks_reference_loop(tag):
+    """Two arms = two part controllers in the reference, one 14-joint joint-space part in the kernel (part_of keeps JOINT_POSITION on each arm's
+    own mass-matrix block): fused control step vs the oracle loop and the states the reference env loop recorded."""
+    from oracle.oracle import env_step_parts
+    from tests.util import make_oracle_parts
+    g, cfg, flat = load_golden(tag, "peg_baxter")
+    nq = flat.nq
+    om, od, parts = make_oracle_parts(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=2)
+    assert hm.action_dim == 14 and hb.get("cstate").shape == (2, 64)
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0; od.forward()
+    for c, _ in parts:
+        c.reset(od)
+    hb.set("qpos", s0[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    for t in range(len(g["actions"])):
+        hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+        env_step_parts(od, parts, g["actions"][t], 25)
+        hq, hv = hb.get("qpos")[0], hb.get("qvel")[0]
+        assert np.abs(hq - od.qpos).max() < 5e-4 and np.abs(hv - od.qvel).max() < 5e-3, t
+        assert np.abs(hq - g["states"][t + 1][1:1 + nq]).max() < 5e-4 and np.abs(hv - g["states"][t + 1][1 + nq:]).max() < 5e-3, t
+        assert np.abs(hb.get("ctrl")[0] - g["ctrl"][t]).max() < 2e-2 * max(1.0, np.abs(g["ctrl"][t]).max()), t
+    assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[1])
+
+
 def test_replay_is_bitwise_deterministic():
     """The reference's only numeric assert on sim state is bitwise replay equality (test_action_playback.py:46-68)."""
     g, cfg, flat = load_golden("seed1_full")

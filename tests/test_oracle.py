@@ -66,6 +66,27 @@ def test_other_part_controllers_match_reference_loop(tag):
         assert np.abs(od.qvel - g["states"][t + 1][1 + nq:]).max() < 1e-5
 
 
+@pytest.mark.parametrize("tag", ("ctl_joint_position", "ctl_joint_torque"))
+def test_two_arm_joint_space_controllers_match_reference_loop(tag):
+    """TwoArmPegInHole / Baxter (BASELINE configs[3] model), one part controller per arm (composite_controller.py:70-121): the oracle loop
+    with two controller objects replays the env.step fixture recorded with the reference's own classes."""
+    from oracle.oracle import env_step_parts
+    from tests.util import make_oracle_parts
+    g, cfg, flat = load_golden(tag, "peg_baxter")
+    om, od, parts = make_oracle_parts(flat, cfg)
+    nq = flat.nq
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0
+    od.forward()
+    for c, _ in parts:
+        c.reset(od)
+    for t in range(len(g["actions"])):
+        env_step_parts(od, parts, g["actions"][t], 25)
+        assert np.abs(od.ctrl - g["ctrl"][t]).max() < 1e-4 * max(1.0, np.abs(g["ctrl"][t]).max())
+        assert np.abs(od.qpos - g["states"][t + 1][1:1 + nq]).max() < 1e-6
+        assert np.abs(od.qvel - g["states"][t + 1][1 + nq:]).max() < 1e-5
+
+
 def test_reset_path_known_answers():
     """values produced by the reference's own reset code (placement_samplers.py:221-309,
     robots/robot.py:247-259, lift.py:311-318) for seed 0, re-derived from the documented draw order."""

@@ -119,3 +119,12 @@ def scripted_stack(flat, cfg, qpos0, n_steps=170):
         r = stack_staged_rewards(flat, cfg, od)
         rew.append((max(r) / 2.0, r[2] > 0))
     return np.array(acts), rew, od
+
+
+def make_oracle_parts(flat, cfg):
+    """Multi-arm robots: one oracle controller per part (cfg["parts"]); returns (model, data, [(controller, action_dim), ...])."""
+    from oracle.oracle import OracleController, OracleData, OracleModel
+
+    om = OracleModel(mjcf.to_blob(flat))
+    d = OracleData(om)
+    return om, d, [(OracleController(p), len(p["input_min"])) for p in cfg["parts"]]

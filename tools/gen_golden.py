@@ -144,6 +144,61 @@ def record_stack(seed, n_steps, action_scale, tag):
     print("stack", tag, "nv", flat.nv, "nbody", flat.nbody, "steps", n_steps, "reward", rewards[-1])
 
 
+def record_baxter(seed, n_steps, action_scale, ctype):
+    """BASELINE configs[3] model: TwoArmPegInHole / Baxter (single-robot, no grippers; 36 bodies, 14 dofs, 29 colliding geoms) with the two
+    arms under joint-space part controllers (one controller object per arm, composite_controller.py:70-95).  JOINT_VELOCITY, the type the
+    BASELINE config names, cannot be constructed in this reference snapshot (joint_vel.py:118 assigns to a read-only property), so the
+    fixtures use the two joint-space types that do run: JOINT_POSITION and JOINT_TORQUE."""
+    from robosuite.controllers import load_part_controller_config
+    from robosuite.controllers.composite.composite_controller_factory import refactor_composite_controller_config
+
+    part = load_part_controller_config(default_controller=ctype)
+    ccfg = refactor_composite_controller_config(part, "Baxter", ["right", "left"])
+    env = suite.make("TwoArmPegInHole", robots="Baxter", env_configuration="single-robot", gripper_types=None, controller_configs=ccfg,
+                     has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True, reward_shaping=True,
+                     control_freq=20, horizon=500, ignore_done=True, seed=seed)
+    obs = env.reset()
+    sim, robot = env.sim, env.robots[0]
+    flat = sim.model._model._flat
+    rng = np.random.default_rng(10**6 + seed)
+    keys = [k for k in obs.keys() if not k.endswith("-state")]
+    actions, states, rewards, obs_flat, ctrls, ncon = [], [sim.get_state().flatten()], [], [], [], []
+    for t in range(n_steps):
+        a = action_scale * rng.uniform(-1, 1, env.action_dim)
+        obs, r, done, info = env.step(a)
+        ctrls.append(np.array(sim.data.ctrl)); actions.append(a); states.append(sim.get_state().flatten()); rewards.append(r); ncon.append(int(sim.data.ncon))
+        obs_flat.append(np.concatenate([np.atleast_1d(obs[k]).astype(np.float64) for k in keys]))
+    tag = f"ctl_{ctype.lower()}"
+    np.savez_compressed(os.path.join(GOLD, f"peg_baxter_{tag}.npz"), actions=np.array(actions), states=np.array(states), rewards=np.array(rewards),
+                        obs=np.array(obs_flat), ctrl=np.array(ctrls), ncon=np.array(ncon))
+    mjcf.save_model(flat, os.path.join(GOLD, f"peg_baxter_{tag}.rsim"))
+    parts = []
+    for arm in robot.arms:
+        ctl = robot.part_controllers[arm]
+        pc = dict(type=ctype, qpos_idx=[int(i) for i in ctl.qpos_index], dof_idx=[int(i) for i in ctl.qvel_index],
+                  act_idx=[int(i) for i in robot._ref_actuators_indexes_dict[arm]], eef_site=0, base_site=0,
+                  input_min=[float(x) for x in ctl.input_min], input_max=[float(x) for x in ctl.input_max],
+                  output_min=[float(x) for x in ctl.output_min], output_max=[float(x) for x in ctl.output_max],
+                  grip_act=[], grip_sign=[], grip_speed=0.0, damping_ratio=1.0)
+        if ctype == "JOINT_POSITION":
+            pc["kp"] = [float(x) for x in np.atleast_1d(ctl.kp)]
+        if ctype == "JOINT_TORQUE":
+            pc["torque_limits"] = [[float(x) for x in ctl.torque_limits[0]], [float(x) for x in ctl.torque_limits[1]]]
+        parts.append(pc)
+    cat = lambda k: sum((p[k] for p in parts), [])
+    cfg = dict(type=ctype, parts=parts, qpos_idx=cat("qpos_idx"), dof_idx=cat("dof_idx"), act_idx=cat("act_idx"), input_min=cat("input_min"),
+               input_max=cat("input_max"), output_min=cat("output_min"), output_max=cat("output_max"), grip_act=[], grip_sign=[], grip_speed=0.0,
+               damping_ratio=1.0, part_of=sum(([k] * len(p["qpos_idx"]) for k, p in enumerate(parts)), []), obs_keys=keys,
+               obs_dims=[int(np.atleast_1d(obs[k]).size) for k in keys])
+    if ctype == "JOINT_POSITION":
+        cfg["kp"] = cat("kp")
+    if ctype == "JOINT_TORQUE":
+        cfg["torque_limits"] = [sum((p["torque_limits"][0] for p in parts), []), sum((p["torque_limits"][1] for p in parts), [])]
+    with open(os.path.join(GOLD, f"peg_baxter_{tag}.cfg.json"), "w") as f:
+        json.dump(cfg, f, indent=1)
+    print("baxter", tag, "nbody", flat.nbody, "nv", flat.nv, "steps", n_steps, "max ncon", max(ncon), "reward", rewards[-1])
+
+
 def record_stack_resets(seeds):
     """Reset-path fixture (physics independent): qpos after make() (draw block 0) and after the first user reset() (block 1) per seed."""
     out = {}
@@ -210,6 +265,10 @@ def record_lift(seed, n_steps, action_scale, tag):
 
 
 if __name__ == "__main__":
+    if "--baxter-only" in sys.argv:
+        record_baxter(seed=0, n_steps=30, action_scale=1.0, ctype="JOINT_POSITION")
+        record_baxter(seed=0, n_steps=30, action_scale=1.0, ctype="JOINT_TORQUE")
+        sys.exit(0)
     if "--stack-only" in sys.argv:
         record_stack(seed=0, n_steps=30, action_scale=1.0, tag="seed0_full")
         record_stack_resets([0, 1, 2, 3, 4, 5])
