@@ -26,8 +26,12 @@ typedef struct rsim_batch rsim_batch;
  *   OSC_POSE       arm/osc.py, control_dim 6            OSC_POSITION  arm/osc.py with use_ori=False, control_dim 3 (zero orientation delta, osc.py:255-263)
  *   JOINT_POSITION generic/joint_pos.py:200-266, control_dim ndof: goal = q + scaled delta, tau = M_arm (kp (goal - q) - kd qd) + qfrc_bias
  *   JOINT_TORQUE   generic/joint_tor.py:111-167, control_dim ndof: tau = clip(scaled action, torque_limits) + qfrc_bias
+ *   JOINT_VELOCITY generic/joint_vel.py:129-209, control_dim ndof: PID on the joint-velocity error (kp per joint, ki = 0.005 kp, kd = 0.001 kp over a
+ *                  5-tap mean of the error increments, integrator frozen while the part's torques saturate) + qfrc_bias, clipped to the actuator range.
+ *                  The reference constructor raises in the surveyed snapshot (joint_vel.py:118 assigns to a read-only property); the law implemented
+ *                  is that file's run_controller with the defect resolved as use_torque_compensation = True.
  * The action row of rsim_control_step is [control_dim arm entries, 1 gripper entry if ngrip > 0]. */
-enum rsim_ctrl_type { RSIM_CTRL_OSC_POSE = 0, RSIM_CTRL_OSC_POSITION = 1, RSIM_CTRL_JOINT_POSITION = 2, RSIM_CTRL_JOINT_TORQUE = 3 };
+enum rsim_ctrl_type { RSIM_CTRL_OSC_POSE = 0, RSIM_CTRL_OSC_POSITION = 1, RSIM_CTRL_JOINT_POSITION = 2, RSIM_CTRL_JOINT_TORQUE = 3, RSIM_CTRL_JOINT_VELOCITY = 4 };
 #define RSIM_JNT_MAX 16
 typedef struct rsim_ctrl_desc {
   int32_t ndof;            /* controlled joints: <= 8 for the OSC types (one arm); <= 16 for the joint-space types, where the arms of a multi-arm
@@ -47,7 +51,8 @@ typedef struct rsim_ctrl_desc {
   float grip_sign[4];       /* PandaGripper.format_action direction, models/grippers/panda_gripper.py:55-57 */
   float grip_speed;         /* panda_gripper.py:61 */
   int32_t type;             /* enum rsim_ctrl_type: which arm part controller of controller_factory.py:73-159 */
-  float torque_min[RSIM_JNT_MAX], torque_max[RSIM_JNT_MAX]; /* RSIM_CTRL_JOINT_TORQUE: torque_limits (joint_tor.py:95-96; default = actuator ctrlrange) */
+  float torque_min[RSIM_JNT_MAX], torque_max[RSIM_JNT_MAX]; /* RSIM_CTRL_JOINT_TORQUE: torque_limits (joint_tor.py:95-96; default = actuator ctrlrange);
+                                                             * RSIM_CTRL_JOINT_VELOCITY: velocity_limits (joint_vel.py:113, 147-148; all zero = none) */
   int32_t part_of[RSIM_JNT_MAX];      /* joint-space types: which part controller (arm) owns joint i; JOINT_POSITION multiplies by that part's own
                                        * mass-matrix block only (joint_pos.py:256-259 uses Controller.mass_matrix of the part) */
 } rsim_ctrl_desc;
@@ -61,20 +66,24 @@ typedef struct rsim_ctrl_desc {
  *   RSIM_OBS_BODY_POS: body a, component b                                 (lift.py:371-373 cube_pos)
  *   RSIM_OBS_BODY_MINUS_SITE: body a minus site (b >> 2), component b & 3  (manipulation_env.py:218-242 gripper_to_cube_pos)
  *   RSIM_OBS_BODY_MINUS_BODY: body a minus body (b >> 2), component b & 3  (stack.py:432-438 cubeA_to_cubeB = cubeB_pos - cubeA_pos)
+ *   RSIM_OBS_PEG_COS / _T / _D: `angle`, `t`, `d` of TwoArmPegInHole._compute_orientation (two_arm_peg_in_hole.py:462-486, 523-560) between
+ *                             object_body (peg) and object2_body (hole)
  * Sampling instants follow the reference exactly: after `reset()` every Observable samples on the LAST substep of a control step,
  * i.e. positions/orientations come from that substep's step1 kinematics, qpos/qvel from after its step2 (utils/observables.py:214-259).
  * task 1: reward = Lift.reward (environments/manipulation/lift.py:224-273), success = Lift._check_success (lift.py:433-444),
  * grasp = ManipulationEnv._check_grasp on the contact list (manipulation_env.py:331-376).
  * task 2: reward = Stack.reward / staged_rewards (environments/manipulation/stack.py:224-312) with object = cubeA, object2 = cubeB
  * (reach + grasp, lift + align, stack = lifted, released and cubeA touching cubeB via check_contact, utils/sim_utils.py:8-40),
- * success = Stack._check_success (stack.py:476-484: r_stack > 0); scaled by reward_scale / 2.0. */
+ * success = Stack._check_success (stack.py:476-484: r_stack > 0); scaled by reward_scale / 2.0.
+ * task 3: reward = TwoArmPegInHole.reward (two_arm_peg_in_hole.py:240-290) with object = peg, object2 = hole: success (d < 0.06, -0.12 <= t <= 0.14,
+ * cos > 0.95; :513-521) + reaching + perpendicular / parallel distance + alignment terms, scaled by reward_scale / 5.0. */
 enum { RSIM_OBS_QPOS = 0, RSIM_OBS_COS, RSIM_OBS_SIN, RSIM_OBS_QVEL, RSIM_OBS_QACC, RSIM_OBS_SITE_POS, RSIM_OBS_BODY_QUAT, RSIM_OBS_SITE_QUAT,
-       RSIM_OBS_BODY_POS, RSIM_OBS_BODY_MINUS_SITE, RSIM_OBS_BODY_MINUS_BODY };
+       RSIM_OBS_BODY_POS, RSIM_OBS_BODY_MINUS_SITE, RSIM_OBS_BODY_MINUS_BODY, RSIM_OBS_PEG_COS, RSIM_OBS_PEG_T, RSIM_OBS_PEG_D };
 #define RSIM_OBS_MAX 128
 typedef struct rsim_task_desc {
   int32_t nobs;                       /* floats in the observation record (<= RSIM_OBS_MAX) */
   int32_t obs_prog[RSIM_OBS_MAX * 3]; /* (kind, a, b) per output float */
-  int32_t task;                       /* 0 = none, 1 = Lift, 2 = Stack */
+  int32_t task;                       /* 0 = none, 1 = Lift, 2 = Stack, 3 = TwoArmPegInHole */
   int32_t object_body;                /* cube root body */
   int32_t grip_site;                  /* gripper.important_sites["grip_site"] */
   float table_height;                 /* model.mujoco_arena.table_offset[2] */
@@ -94,7 +103,8 @@ enum rsim_field {
   RSIM_CTRL,           /* [B,nu]  sim.data.ctrl   (fixed_base_robot.py:153)                 */
   RSIM_TIME,           /* [B]     sim.data.time                                              */
   RSIM_CSTATE,         /* [B,cs]  controller state, cs = rsim_model_int(m, "cstate_size"): OSC types (32) goal_pos3 goal_ori9 q0[8] grip[4] tau[8];
-                        *          joint-space types (64) goal[16] - grip[4] at 20 - tau[16] at 32 */
+                        *          joint-space types (64) goal[16] - grip[4] at 20 - tau[16] at 32; JOINT_VELOCITY (192) adds last_err[16] at 48,
+                        *          summed_err[16] at 64, derr ring[5][16] at 80, ring ptr / size at 160 / 161, saturated[part] at 164 */
   RSIM_XPOS,           /* [B,nbody,3]  sim.data.xpos      (derived, valid after forward/step1) */
   RSIM_XQUAT,          /* [B,nbody,4]  sim.data.xquat                                        */
   RSIM_QM,             /* [B,nv,nv]    dense mass matrix (mj_fullM, controller.py:226-227)  */

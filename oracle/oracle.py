@@ -176,7 +176,7 @@ class OracleData:
             pass
 
 
-CTRL_TYPES = {"OSC_POSE": 0, "OSC_POSITION": 1, "JOINT_POSITION": 2, "JOINT_TORQUE": 3}
+CTRL_TYPES = {"OSC_POSE": 0, "OSC_POSITION": 1, "JOINT_POSITION": 2, "JOINT_TORQUE": 3, "JOINT_VELOCITY": 4}
 
 
 class OracleController:
@@ -198,8 +198,8 @@ class OracleController:
         ctype = CTRL_TYPES[cfg.get("type", "OSC_POSE")]
         if ctype:
             cdim = len(cfg["input_min"])
-            jkp = f64(cfg["kp"]) if ctype == 2 else np.zeros(8)
-            tl = cfg.get("torque_limits") or [[0.0] * 8, [0.0] * 8]
+            jkp = f64(cfg["kp"]) if ctype in (2, 4) else np.zeros(8)
+            tl = cfg.get("torque_limits") or cfg.get("velocity_limits") or ([[-1e300] * 8, [1e300] * 8] if ctype == 4 else [[0.0] * 8, [0.0] * 8])
             self._keep2 = [jkp, f64(cfg["input_min"]), f64(cfg["input_max"]), f64(cfg["output_min"]), f64(cfg["output_max"]), f64(tl[0]), f64(tl[1])]
             k2 = self._keep2
             self._L.rso_ctrl_set_type(self.ptr, ctype, cdim, _dp(k2[0]), float(cfg.get("damping_ratio", 1.0)), _dp(k2[1]), _dp(k2[2]), _dp(k2[3]),

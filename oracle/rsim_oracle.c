@@ -1680,9 +1680,13 @@ typedef struct {
   double in_min[ARM_MAX], in_max[ARM_MAX], out_min[ARM_MAX], out_max[ARM_MAX];
   int uncouple;
   /* part-controller type: 0 OSC_POSE (osc.py), 1 OSC_POSITION (osc.py use_ori=False), 2 JOINT_POSITION (generic/joint_pos.py),
-   * 3 JOINT_TORQUE (generic/joint_tor.py); cdim = control_dim of the arm part */
+   * 3 JOINT_TORQUE (generic/joint_tor.py), 4 JOINT_VELOCITY (generic/joint_vel.py, with the constructor defect of the surveyed snapshot
+   * resolved as use_torque_compensation = True); cdim = control_dim of the arm part */
   int type, cdim;
   double jkp[ARM_MAX], jkd[ARM_MAX], tl_lo[ARM_MAX], tl_hi[ARM_MAX], goal_j[ARM_MAX];
+  /* JOINT_VELOCITY PID state (joint_vel.py:105-110): RingBuffer(dim, 5) of error increments (utils/buffers.py:24-91) */
+  double last_err[ARM_MAX], summed_err[ARM_MAX], ring[5][ARM_MAX];
+  int ring_ptr, ring_size, saturated;
   double nullspace_kp;
   /* gripper */
   int ngrip;               /* number of gripper actuators (2) */
@@ -1721,7 +1725,8 @@ void rso_ctrl_set_type(rso_ctrl *c, int type, int cdim, const double *jkp, doubl
   c->type = type; c->cdim = cdim;
   for (int i = 0; i < cdim; i++) { c->in_min[i] = in_min[i]; c->in_max[i] = in_max[i]; c->out_min[i] = out_min[i]; c->out_max[i] = out_max[i]; }
   if (type == 2) for (int i = 0; i < c->ndof; i++) { c->jkp[i] = jkp[i]; c->jkd[i] = 2 * sqrt(jkp[i]) * damping_ratio; }
-  if (type == 3) for (int i = 0; i < c->ndof; i++) { c->tl_lo[i] = tl_lo[i]; c->tl_hi[i] = tl_hi[i]; }
+  if (type == 4) for (int i = 0; i < c->ndof; i++) c->jkp[i] = jkp[i];   /* joint_vel.py:96-103: kp (x (high - low) when scalar), ki = 0.005 kp, kd = 0.001 kp */
+  if (type == 3 || type == 4) for (int i = 0; i < c->ndof; i++) { c->tl_lo[i] = tl_lo[i]; c->tl_hi[i] = tl_hi[i]; }  /* torque / velocity limits */
 }
 
 void rso_osc_goal(const double *scaled, const double *ep, const double *eR, const double *op, const double *oR, double *goal_pos, double *goal_ori);
@@ -1735,6 +1740,8 @@ void rso_ctrl_reset(rso_ctrl *c, rso_data *d) {
   for (int i = 0; i < 4; i++) { c->grip_action[i] = 0; c->grip_goal[i] = 0; }
   /* joint_pos.py:268-276 reset_goal: goal_qpos = joint_pos; joint_tor.py:170-178: goal_torque = 0 */
   for (int i = 0; i < c->ndof; i++) c->goal_j[i] = c->type == 2 ? d->qpos[c->qpos_idx[i]] : 0.0;
+  memset(c->last_err, 0, sizeof(c->last_err)); memset(c->summed_err, 0, sizeof(c->summed_err)); memset(c->ring, 0, sizeof(c->ring));
+  c->ring_ptr = 4; c->ring_size = 0; c->saturated = 0;
 }
 
 /* float32 quat2mat of the reference (transform_utils.py:461-487 casts to float32; under NumPy>=2 the
@@ -1775,7 +1782,7 @@ void rso_ctrl_set_goal(rso_ctrl *c, rso_data *d, const double *action) {
   }
   if (c->type == 2) {        /* joint_pos.py:200-236: goal_qpos = joint_pos + scaled delta (no position limits) */
     for (int i = 0; i < c->ndof; i++) c->goal_j[i] = d->qpos[c->qpos_idx[i]] + scaled[i];
-  } else if (c->type == 3) { /* joint_tor.py:111-128: goal_torque = clip(scale_action(a), torque_limits) */
+  } else if (c->type == 3 || c->type == 4) { /* joint_tor.py:111-128 / joint_vel.py:145-148: goal = clip(scale_action(a), torque / velocity limits) */
     for (int i = 0; i < c->ndof; i++) c->goal_j[i] = fmax(c->tl_lo[i], fmin(c->tl_hi[i], scaled[i]));
   } else {                   /* osc.py:255-263: OSC_POSITION passes a zero orientation delta (scaled[3..5] stay 0) */
     rso_osc_goal(scaled, d->site_xpos + 3 * c->eef_site, d->site_xmat + 9 * c->eef_site, d->site_xpos + 3 * c->base_site, d->site_xmat + 9 * c->base_site,
@@ -1915,6 +1922,25 @@ void rso_ctrl_run(rso_ctrl *c, rso_data *d) {
     }
   } else if (c->type == 3) { /* joint_tor.py:130-167: goal_torque + qfrc_bias[arm] */
     for (int i = 0; i < n; i++) c->torques[i] = c->goal_j[i] + bias[i];
+  } else if (c->type == 4) { /* joint_vel.py:166-198 */
+    c->ring_ptr = (c->ring_ptr + 1) % 5;
+    if (c->ring_size < 5) c->ring_size++;
+    int sat = 0;
+    for (int i = 0; i < n; i++) {
+      double err = c->goal_j[i] - qd[i], derr = err - c->last_err[i];
+      c->last_err[i] = err;
+      c->ring[c->ring_ptr][i] = derr;
+      if (!c->saturated) c->summed_err[i] += err;
+      double avg = 0;
+      for (int k = 0; k < c->ring_size; k++) avg += c->ring[k][i];
+      avg /= c->ring_size;
+      double t = c->jkp[i] * err + 0.005 * c->jkp[i] * c->summed_err[i] + 0.001 * c->jkp[i] * avg + bias[i];
+      int a = c->act_idx[i];
+      double cl = fmax(m->actuator_ctrlrange[2 * a], fmin(m->actuator_ctrlrange[2 * a + 1], t));   /* clip_torques, controller.py:264-274 */
+      if (cl != t) sat = 1;
+      c->torques[i] = cl;
+    }
+    c->saturated = sat;
   } else
   rso_osc_torques(c->kp, c->kd, d->site_xpos + 3 * c->eef_site, d->site_xmat + 9 * c->eef_site, ev, d->site_xpos + 3 * c->base_site,
                   d->site_xmat + 9 * c->base_site, bv, c->goal_pos, c->goal_ori, J, M, bias, q, qd, c->initial_joint, c->nullspace_kp, c->uncouple, n,

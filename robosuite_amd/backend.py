@@ -25,7 +25,8 @@ INT_FIELDS = {"ncon", "nefc", "niter", "success", "done", "ep_step", "ep_index"}
 CON_REC = 24
 CSTATE = 32
 OBS_MAX = 128
-OBS_KINDS = {"qpos": 0, "cos": 1, "sin": 2, "qvel": 3, "qacc": 4, "site_pos": 5, "body_quat": 6, "site_quat": 7, "body_pos": 8, "body_minus_site": 9, "body_minus_body": 10}
+OBS_KINDS = {"qpos": 0, "cos": 1, "sin": 2, "qvel": 3, "qacc": 4, "site_pos": 5, "body_quat": 6, "site_quat": 7, "body_pos": 8, "body_minus_site": 9, "body_minus_body": 10,
+             "peg_cos": 11, "peg_t": 12, "peg_d": 13}
 
 
 class RsimError(RuntimeError):
@@ -44,7 +45,7 @@ class CtrlDesc(C.Structure):
 
 
 # arm part-controller types with an in-kernel implementation (include/rsim.h enum rsim_ctrl_type; names = the reference's config "type" strings)
-CTRL_TYPES = {"OSC_POSE": 0, "OSC_POSITION": 1, "JOINT_POSITION": 2, "JOINT_TORQUE": 3}
+CTRL_TYPES = {"OSC_POSE": 0, "OSC_POSITION": 1, "JOINT_POSITION": 2, "JOINT_TORQUE": 3, "JOINT_VELOCITY": 4}
 
 
 def control_dim(cfg: dict) -> int:
@@ -92,7 +93,7 @@ def ctrl_desc(cfg: dict) -> CtrlDesc:
     for i in range(cdim):
         d.input_min[i], d.input_max[i] = cfg["input_min"][i], cfg["input_max"][i]
         d.output_min[i], d.output_max[i] = cfg["output_min"][i], cfg["output_max"][i]
-    tl = cfg.get("torque_limits")
+    tl = cfg.get("torque_limits") or cfg.get("velocity_limits")
     if tl:
         for i in range(n):
             d.torque_min[i], d.torque_max[i] = tl[0][i], tl[1][i]
@@ -195,7 +196,7 @@ class HipModel:
         d.nobs = len(obs)
         for i, (kind, a, b) in enumerate(obs):
             d.obs_prog[3 * i], d.obs_prog[3 * i + 1], d.obs_prog[3 * i + 2] = OBS_KINDS[kind] if isinstance(kind, str) else int(kind), int(a), int(b)
-        d.task = {"none": 0, "lift": 1, "stack": 2}[task.get("task", "none")]
+        d.task = {"none": 0, "lift": 1, "stack": 2, "peg_in_hole": 3}[task.get("task", "none")]
         d.object2_body = int(task.get("object2_body", 0))
         d.object_body, d.grip_site = int(task.get("object_body", 0)), int(task.get("grip_site", 0))
         d.table_height, d.lift_margin = float(task.get("table_height", 0.0)), float(task.get("lift_margin", 0.04))

@@ -431,7 +431,7 @@ extern "C" int rsim_model_int(const rsim_model* m, const char* name) {
 }
 
 extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d) {
-  if (d->type < RSIM_CTRL_OSC_POSE || d->type > RSIM_CTRL_JOINT_TORQUE) return fail("controller: unknown part-controller type %d", d->type);
+  if (d->type < RSIM_CTRL_OSC_POSE || d->type > RSIM_CTRL_JOINT_VELOCITY) return fail("controller: unknown part-controller type %d", d->type);
   const bool jointspace = d->type >= RSIM_CTRL_JOINT_POSITION;
   if (d->ndof < 1 || d->ndof > (jointspace ? RSIM_JNT_MAX : RSIM_ARM_MAX) || d->ngrip < 0 || d->ngrip > RSIM_GRIP_MAX)
     return fail("controller: bad ndof/ngrip (%d joints: at most %d for this controller type)", d->ndof, jointspace ? RSIM_JNT_MAX : RSIM_ARM_MAX);
@@ -446,10 +446,13 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
   if (!jointspace && (d->eef_site < 0 || d->eef_site >= m->nsite || d->base_site < 0 || d->base_site >= m->nsite)) return fail("controller: bad site id");
   c.eef_site = jointspace ? 0 : d->eef_site; c.base_site = jointspace ? 0 : d->base_site;
   c.type = d->type;
-  c.cs_size = jointspace ? RSIM_CS_SIZE_JOINT : RSIM_CS_SIZE;
-  for (int i = 0; i < d->ndof; i++) c.part_of[i] = d->part_of[i];
+  c.cs_size = d->type == RSIM_CTRL_JOINT_VELOCITY ? RSIM_CS_SIZE_JVEL : (jointspace ? RSIM_CS_SIZE_JOINT : RSIM_CS_SIZE);
+  for (int i = 0; i < d->ndof; i++) {
+    if (d->part_of[i] < 0 || d->part_of[i] > 3) return fail("controller: part_of[%d] = %d (at most 4 parts)", i, d->part_of[i]);
+    c.part_of[i] = d->part_of[i];
+  }
   c.cdim = d->type == RSIM_CTRL_OSC_POSE ? 6 : d->type == RSIM_CTRL_OSC_POSITION ? 3 : d->ndof;
-  const int ngain = d->type == RSIM_CTRL_JOINT_POSITION ? d->ndof : (d->type == RSIM_CTRL_JOINT_TORQUE ? 0 : 6);
+  const int ngain = (d->type == RSIM_CTRL_JOINT_POSITION || d->type == RSIM_CTRL_JOINT_VELOCITY) ? d->ndof : (d->type == RSIM_CTRL_JOINT_TORQUE ? 0 : 6);
   for (int i = 0; i < ngain; i++) {
     if (!(d->kp[i] >= 0.f)) return fail("controller: negative / NaN kp");
     c.kp[i] = d->kp[i]; c.kd[i] = 2.f * sqrtf(d->kp[i]) * d->damping_ratio;
@@ -463,8 +466,12 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
     for (int i = 0; i < d->ndof; i++) given |= d->torque_min[i] != 0.f || d->torque_max[i] != 0.f;
     const double* cr = m->D("actuator_ctrlrange");
     for (int i = 0; i < d->ndof; i++) {
-      c.tl_lo[i] = given ? d->torque_min[i] : (float)cr[2 * d->act_idx[i]];
-      c.tl_hi[i] = given ? d->torque_max[i] : (float)cr[2 * d->act_idx[i] + 1];
+      if (d->type == RSIM_CTRL_JOINT_VELOCITY) {   // velocity_limits=None: no clipping
+        c.tl_lo[i] = given ? d->torque_min[i] : -3.0e38f; c.tl_hi[i] = given ? d->torque_max[i] : 3.0e38f;
+      } else {
+        c.tl_lo[i] = given ? d->torque_min[i] : (float)cr[2 * d->act_idx[i]];
+        c.tl_hi[i] = given ? d->torque_max[i] : (float)cr[2 * d->act_idx[i] + 1];
+      }
     }
   }
   c.uncouple = d->uncouple_pos_ori; c.nullspace_kp = d->nullspace_kp > 0 ? d->nullspace_kp : 10.f;
@@ -497,13 +504,15 @@ extern "C" int rsim_model_set_task(rsim_model* m, const rsim_task_desc* d) {
       case RSIM_OBS_BODY_POS: ok = a >= 0 && a < m->nbody && b2 >= 0 && b2 < 3; break;
       case RSIM_OBS_BODY_MINUS_SITE: ok = a >= 0 && a < m->nbody && (b2 & 3) < 3 && (b2 >> 2) >= 0 && (b2 >> 2) < m->nsite; break;
       case RSIM_OBS_BODY_MINUS_BODY: ok = a >= 0 && a < m->nbody && (b2 & 3) < 3 && (b2 >> 2) >= 0 && (b2 >> 2) < m->nbody; break;
+      case RSIM_OBS_PEG_COS: case RSIM_OBS_PEG_T: case RSIM_OBS_PEG_D: ok = d->task == 3; break;
       default: ok = false;
     }
     if (!ok) return fail("task: observation entry %d (kind %d, a %d, b %d) is invalid for this model", i, kind, a, b2);
   }
-  if (d->task < 0 || d->task > 2) return fail("task: unknown task id %d", d->task);
-  if (d->task >= 1 && (d->object_body < 0 || d->object_body >= m->nbody || d->grip_site < 0 || d->grip_site >= m->nsite)) return fail("task: bad body / site id");
-  if (d->task == 2 && (d->object2_body < 0 || d->object2_body >= m->nbody)) return fail("task: bad second object body id");
+  if (d->task < 0 || d->task > 3) return fail("task: unknown task id %d", d->task);
+  if (d->task >= 1 && (d->object_body < 0 || d->object_body >= m->nbody)) return fail("task: bad object body id");
+  if ((d->task == 1 || d->task == 2) && (d->grip_site < 0 || d->grip_site >= m->nsite)) return fail("task: bad grip site id");
+  if (d->task >= 2 && (d->object2_body < 0 || d->object2_body >= m->nbody)) return fail("task: bad second object body id");
   m->task = *d;
   m->has_task = 1;
   return 0;

@@ -80,7 +80,15 @@ struct DCtrl {
 /* joint-space parts (up to RSIM_JNT_MAX joints): goal[16] at 0, grip[4] at 20 (shared with the OSC layout), tau[16] at 32 */
 #define RSIM_CS_TAU_JOINT 32
 #define RSIM_CS_SIZE_JOINT 64
-#define RSIM_CS_MAX 64
+/* JOINT_VELOCITY PID state (joint_vel.py:105-110): last_err[16], summed_err[16], RingBuffer(5) of error increments, its ptr / size, saturated flag per part */
+#define RSIM_CS_JV_LASTERR 48
+#define RSIM_CS_JV_SUMMED 64
+#define RSIM_CS_JV_RING 80
+#define RSIM_CS_JV_PTR 160
+#define RSIM_CS_JV_SIZE 161
+#define RSIM_CS_JV_SAT 164
+#define RSIM_CS_SIZE_JVEL 192
+#define RSIM_CS_MAX 192
 
 // observation / reward epilogue (include/rsim.h rsim_task_desc), device form
 struct DTask {

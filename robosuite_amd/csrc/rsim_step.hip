@@ -1788,6 +1788,7 @@ struct Sim {
         const float scale = fabsf(omax - omin) / fabsf(imax - imin);
         const float a = fmaxf(imin, fminf(imax, action[lane]));
         const float sv = (a - 0.5f * (imax + imin)) * scale + 0.5f * (omax + omin);
+        // JOINT_VELOCITY: goal_vel = clip(scaled, velocity_limits) (joint_vel.py:145-148) -- same clamp, limits in the same slots
         sm.cstate[RSIM_CS_GOALQ + lane] = c.type == RSIM_CTRL_JOINT_POSITION ? sm.qpos[K.cq] + sv : fmaxf(tlo, fminf(thi, sv));
       }
       if (lane < c.ngrip) {
@@ -1841,6 +1842,8 @@ struct Sim {
     if (c.type >= RSIM_CTRL_JOINT_POSITION) {   // joint_pos.py:268-276 (goal_qpos = joint_pos), joint_tor.py:170-178 (goal_torque = 0)
       if (lane < c.ndof) sm.cstate[RSIM_CS_GOALQ + lane] = c.type == RSIM_CTRL_JOINT_POSITION ? sm.qpos[K.cq] : 0.f;
       if (lane < RSIM_GRIP_MAX) sm.cstate[RSIM_CS_GRIP + lane] = 0.f;
+      // JOINT_VELOCITY: fresh PID state (joint_vel.py:105-110; RingBuffer starts with ptr = length - 1, size 0); the caller zeroed the block
+      if (c.type == RSIM_CTRL_JOINT_VELOCITY && lane == 0) sm.cstate[RSIM_CS_JV_PTR] = 4.f;
     } else if (lane == 0) {
       st3(sm.cstate + RSIM_CS_GOALPOS, ld3(sm.spos + 3 * c.eef_site));
       for (int k = 0; k < 9; k++) sm.cstate[RSIM_CS_GOALORI + k] = sm.smat[9 * c.eef_site + k];
@@ -1883,6 +1886,35 @@ struct Sim {
         const float mk = (lane < n && k < n && c.part_of[k] == mypart) ? sm.M[di * NVP + c.dof_idx[k]] : 0.f;
         tq = fmaf(mk, bcast(des, k), tq);
       }
+    } else if (c.type == RSIM_CTRL_JOINT_VELOCITY) {
+      // joint_vel.py:166-198: err = goal - qd; derr ring (5) mean; integrator frozen while this part saturated on the previous call
+      const float kp = sel(c.kp, li), alo = __shfl(K.acr0, K.ca), ahi = __shfl(K.acr1, K.ca);
+      const int mypart = seli(c.part_of, li);
+      const int ptr = ((int)sm.cstate[RSIM_CS_JV_PTR] + 1) % 5, size = min((int)sm.cstate[RSIM_CS_JV_SIZE] + 1, 5);
+      float pid = 0.f;
+      bool over = false;
+      if (lane < n) {
+        const float err = goal - sm.qvel[di], derr = err - sm.cstate[RSIM_CS_JV_LASTERR + lane];
+        sm.cstate[RSIM_CS_JV_LASTERR + lane] = err;
+        sm.cstate[RSIM_CS_JV_RING + 16 * ptr + lane] = derr;
+        float summed = sm.cstate[RSIM_CS_JV_SUMMED + lane];
+        if (sm.cstate[RSIM_CS_JV_SAT + mypart] == 0.f) summed += err;
+        sm.cstate[RSIM_CS_JV_SUMMED + lane] = summed;
+        float avg = 0.f;
+        for (int k = 0; k < size; k++) avg += sm.cstate[RSIM_CS_JV_RING + 16 * k + lane];   // RingBuffer.average: mean of buf[:size]
+        avg /= (float)size;
+        pid = kp * err + 0.005f * kp * summed + 0.001f * kp * avg;
+        const float raw = pid + tq;
+        over = fmaxf(alo, fminf(ahi, raw)) != raw;
+      }
+      tq += pid;
+      SYNC();
+#pragma unroll
+      for (int p2 = 0; p2 < 4; p2++) {   // saturated = any clipped torque within the part (one controller object per arm)
+        const bool any = __ballot(over && mypart == p2) != 0;
+        if (lane == 0) sm.cstate[RSIM_CS_JV_SAT + p2] = any ? 1.f : 0.f;
+      }
+      if (lane == 0) { sm.cstate[RSIM_CS_JV_PTR] = (float)ptr; sm.cstate[RSIM_CS_JV_SIZE] = (float)size; }
     } else tq += goal;
     ctrl_write(K, tq);
   }
@@ -2304,9 +2336,25 @@ struct Sim {
     Q4 q = {qw, qx, qy, qz};
     return q;
   }
+  // TwoArmPegInHole._compute_orientation (two_arm_peg_in_hole.py:523-560): parallel distance t, perpendicular distance d of the hole centre
+  // from the peg axis, |cos| between the peg axis and the hole normal
+  __device__ __forceinline__ void peg_orientation(int peg, int hole, float& tt, float& dd, float& cs) const {
+    const M3 Rp = q2m(ldq(sm.xquat + 4 * peg)), Rh = q2m(ldq(sm.xquat + 4 * hole));
+    const V3 pp = ld3(sm.xpos + 3 * peg), hp = ld3(sm.xpos + 3 * hole);
+    V3 v = col(Rp, 2);
+    v = v * (1.0f / norm(v));
+    const V3 center = hp + col(Rh, 0) * 0.1f;
+    const float vn = norm(v);
+    tt = dot(center - pp, v) / (vn * vn);
+    dd = norm(cross(v, pp - center)) / vn;
+    const V3 hn = col(Rh, 2);
+    cs = fabsf(dot(hn, v) / norm(hn) / vn);
+  }
   __device__ __forceinline__ void obs_reward(float* __restrict__ obs, float* __restrict__ reward, int* __restrict__ success) {
     const DTask& t = m.task;
     gci prog = (gci)t.obs_prog;
+    float peg_t = 0.f, peg_d = 0.f, peg_c = 0.f;
+    if (t.task == 3) peg_orientation(t.object_body, t.object2_body, peg_t, peg_d, peg_c);
     for (int i = lane; i < t.nobs; i += 64) {
       const int kind = prog[3 * i], a = prog[3 * i + 1], b2 = prog[3 * i + 2];
       float v = 0.f;
@@ -2319,11 +2367,25 @@ struct Sim {
       else if (kind == RSIM_OBS_BODY_POS) v = sm.xpos[3 * a + b2];
       else if (kind == RSIM_OBS_BODY_MINUS_SITE) v = sm.xpos[3 * a + (b2 & 3)] - sm.spos[3 * (b2 >> 2) + (b2 & 3)];
       else if (kind == RSIM_OBS_BODY_MINUS_BODY) v = sm.xpos[3 * a + (b2 & 3)] - sm.xpos[3 * (b2 >> 2) + (b2 & 3)];
+      else if (kind == RSIM_OBS_PEG_COS) v = peg_c;
+      else if (kind == RSIM_OBS_PEG_T) v = peg_t;
+      else if (kind == RSIM_OBS_PEG_D) v = peg_d;
       else if (kind == RSIM_OBS_BODY_QUAT) v = sm.xquat[4 * a + (b2 == 3 ? 0 : b2 + 1)];   // wxyz -> xyzw
       else if (kind == RSIM_OBS_SITE_QUAT) { const Q4 q = mat2quat_xyzw(sm.smat + 9 * a); v = b2 == 0 ? q.x : (b2 == 1 ? q.y : (b2 == 2 ? q.z : q.w)); }
       obs[i] = v;
     }
-    if (t.task >= 1) {
+    if (t.task == 3) {
+      if (lane == 0) {
+        const bool succ = peg_d < 0.06f && peg_t >= -0.12f && peg_t <= 0.14f && peg_c > 0.95f;
+        float r = succ ? 1.f : 0.f;
+        if (t.reward_shaping) {
+          const float dist = norm(ld3(sm.xpos + 3 * t.object_body) - ld3(sm.xpos + 3 * t.object2_body));
+          r += (1.f - tanhf(dist)) + (1.f - tanhf(peg_d)) + (1.f - tanhf(fabsf(peg_t))) + peg_c;
+        } else r *= 5.f;
+        *reward = r * t.reward_scale / 5.0f;
+        *success = succ ? 1 : 0;
+      }
+    } else if (t.task >= 1) {
       // grasp: both finger-pad geom groups touch the object (contact list of the last substep)
       bool lc = false, rc = false, oo = false;
       if (lane < sm.ncon) {
@@ -2395,7 +2457,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   if (lane >= m.nv && lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.qacc[lane] = 0.f; }
   for (int i = lane; i < m.nu; i += 64) sm.ctrl[i] = b.ctrl[(size_t)env * m.nu + i];
   const int cs = m.ctrl.cs_size;
-  if (lane < cs) sm.cstate[lane] = b.cstate[(size_t)env * cs + lane];
+  for (int i = lane; i < cs; i += 64) sm.cstate[i] = b.cstate[(size_t)env * cs + i];
   if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; }
   sim.load_constants();
   const float* act = actions ? actions + (size_t)env * m.ctrl.action_dim : nullptr;
@@ -2403,7 +2465,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   if ((flags & RF_CTRL) && b.needs_reset[env]) {
     // this env was re-initialised on the device when its previous episode ended: fresh controller objects (robots/robot.py:271)
     V3 xp0; Q4 xq0;
-    if (lane < cs) sm.cstate[lane] = 0.f;
+    for (int i = lane; i < cs; i += 64) sm.cstate[i] = 0.f;
     SYNC();
     sim.kinematics(xp0, xq0);
     sim.geom_site_frames();
@@ -2472,7 +2534,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   for (int i = lane; i < m.nq; i += 64) b.qpos[(size_t)env * m.nq + i] = sm.qpos[i];
   for (int i = lane; i < m.nv; i += 64) { b.qvel[(size_t)env * m.nv + i] = sm.qvel[i]; b.qacc_ws[(size_t)env * m.nv + i] = sm.qacc_ws[i]; }
   for (int i = lane; i < m.nu; i += 64) b.ctrl[(size_t)env * m.nu + i] = sm.ctrl[i];
-  if (lane < cs) b.cstate[(size_t)env * cs + lane] = sm.cstate[lane];
+  for (int i = lane; i < cs; i += 64) b.cstate[(size_t)env * cs + i] = sm.cstate[i];
   if (lane == 0) b.time[env] = time;
   if (b.prof && lane == 0) {
     unsigned long long* wl = b.prof + RP_COUNT + 8 * (size_t)env;
@@ -2516,13 +2578,13 @@ __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const uns
   Sim<SM> sim(m, fp, lane, nullptr);
   for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = b.qpos[(size_t)env * m.nq + i];
   const int cs = m.ctrl.cs_size;
-  if (lane < cs) sm.cstate[lane] = 0.f;
+  for (int i = lane; i < cs; i += 64) sm.cstate[i] = 0.f;
   sim.load_constants();
   V3 xp; Q4 xq;
   sim.kinematics(xp, xq);
   sim.geom_site_frames();
   sim.ctrl_reset();
-  if (lane < cs) b.cstate[(size_t)env * cs + lane] = sm.cstate[lane];
+  for (int i = lane; i < cs; i += 64) b.cstate[(size_t)env * cs + i] = sm.cstate[i];
 }
 
 

@@ -239,7 +239,7 @@ def test_baxter_model_forward_quantities_with_contacts_match_oracle():
     assert seen_contacts >= 3 and tight >= 0.75 * total
 
 
-@pytest.mark.parametrize("tag", ("ctl_joint_position", "ctl_joint_torque"))
+@pytest.mark.parametrize("tag", ("ctl_joint_position", "ctl_joint_torque", "ctl_joint_velocity"))
 def test_baxter_two_arm_joint_space_control_step_tracks_reference_loop(tag):
     """Two arms = two part controllers in the reference, one 14-joint joint-space part in the kernel (part_of keeps JOINT_POSITION on each arm's
     own mass-matrix block): fused control step vs the oracle loop and the states the reference env loop recorded."""
@@ -249,7 +249,7 @@ def test_baxter_two_arm_joint_space_control_step_tracks_reference_loop(tag):
     nq = flat.nq
     om, od, parts = make_oracle_parts(flat, cfg)
     hm, hb = make_hip(flat, cfg, B=2)
-    assert hm.action_dim == 14 and hb.get("cstate").shape == (2, 64)
+    assert hm.action_dim == 14 and hb.get("cstate").shape == (2, 192 if tag.endswith("velocity") else 64)
     s0 = g["states"][0]
     od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0; od.forward()
     for c, _ in parts:
@@ -260,10 +260,63 @@ def test_baxter_two_arm_joint_space_control_step_tracks_reference_loop(tag):
         hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 2, 0), dtype=torch.float32, device="cuda"), 25)
         env_step_parts(od, parts, g["actions"][t], 25)
         hq, hv = hb.get("qpos")[0], hb.get("qvel")[0]
+        if tag.endswith("velocity") and t >= 3:
+            # The default JOINT_VELOCITY gains (kp = 3 x torque range, joint_velocity.json) make the light wrist joints chatter between their
+            # +-15 N m limits (~3000 rad/s^2) every few substeps; which substep a sign flip lands on is decided at rounding level, so beyond
+            # the first control steps the fp32 and fp64 runs are different samples of the same limit cycle.  The PID is checked over a long
+            # horizon below with gains that do not chatter.
+            break
         assert np.abs(hq - od.qpos).max() < 5e-4 and np.abs(hv - od.qvel).max() < 5e-3, t
         assert np.abs(hq - g["states"][t + 1][1:1 + nq]).max() < 5e-4 and np.abs(hv - g["states"][t + 1][1 + nq:]).max() < 5e-3, t
         assert np.abs(hb.get("ctrl")[0] - g["ctrl"][t]).max() < 2e-2 * max(1.0, np.abs(g["ctrl"][t]).max()), t
     assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[1])
+    if tag.endswith("velocity"):
+        # same law, kp / 20: integrator and 5-tap derivative mean over 500 substeps, tight tracking of the oracle (the per-arm saturation freeze is
+        # exercised by the default gains in the first control steps above, where most torques sit on their limits)
+        import copy
+        cfg2 = copy.deepcopy(cfg)
+        cfg2["kp"] = [k / 20 for k in cfg["kp"]]
+        for p in cfg2["parts"]:
+            p["kp"] = [k / 20 for k in p["kp"]]
+        om, od, parts = make_oracle_parts(flat, cfg2)
+        hm, hb = make_hip(flat, cfg2, B=2)
+        od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0; od.forward()
+        for c, _ in parts:
+            c.reset(od)
+        hb.set("qpos", s0[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+        hb.forward(); hb.ctrl_reset()
+        for t in range(20):
+            hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+            env_step_parts(od, parts, g["actions"][t], 25)
+            assert np.abs(hb.get("qpos")[0] - od.qpos).max() < 1e-3 and np.abs(hb.get("qvel")[0] - od.qvel).max() < 2e-2, t
+
+
+def test_peg_in_hole_observation_and_reward_epilogue_matches_reference_env():
+    """TwoArmPegInHole epilogue (task 3) vs what the reference's env.step() returned: two-arm robot keys, hole / peg keys, the
+    _compute_orientation scalars (angle, t, d) and the shaped reward."""
+    from robosuite_amd import peg_in_hole
+    from robosuite_amd.backend import HipBatch
+    g, cfg, flat = load_golden("ctl_joint_torque", "peg_baxter")
+    nq = flat.nq
+    hm, _ = make_hip(flat, cfg, B=1)
+    hm.set_task(peg_in_hole.peg_task(flat, cfg))
+    hb = HipBatch(hm, 2, 0, False)
+    s0 = g["states"][0]
+    hb.set("qpos", s0[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    dims = np.cumsum([0] + cfg["obs_dims"])
+    assert hb.get("obs").shape == (2, dims[-1])
+    for t in range(len(g["actions"])):
+        hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+        obs, rew = hb.get("obs")[0], hb.get("reward")[0]
+        for k, key in enumerate(cfg["obs_keys"]):
+            ref, got = g["obs"][t][dims[k]:dims[k + 1]], obs[dims[k]:dims[k + 1]]
+            tol = 2e-2 * max(1.0, np.abs(ref).max()) if key.endswith("joint_acc") else (5e-3 if key.endswith("vel") else 5e-4)
+            if "quat" in key:
+                got = got * np.sign(np.dot(got, ref))
+            assert np.abs(got - ref).max() < tol, (t, key)
+        assert abs(rew - g["rewards"][t]) < 2e-4, t
+        assert hb.get("success")[0] == 0
 
 
 def test_replay_is_bitwise_deterministic():

@@ -66,10 +66,12 @@ def test_other_part_controllers_match_reference_loop(tag):
         assert np.abs(od.qvel - g["states"][t + 1][1 + nq:]).max() < 1e-5
 
 
-@pytest.mark.parametrize("tag", ("ctl_joint_position", "ctl_joint_torque"))
+@pytest.mark.parametrize("tag", ("ctl_joint_position", "ctl_joint_torque", "ctl_joint_velocity"))
 def test_two_arm_joint_space_controllers_match_reference_loop(tag):
     """TwoArmPegInHole / Baxter (BASELINE configs[3] model), one part controller per arm (composite_controller.py:70-121): the oracle loop
-    with two controller objects replays the env.step fixture recorded with the reference's own classes."""
+    with two controller objects replays the env.step fixture recorded with the reference's own classes.  JOINT_VELOCITY (the type BASELINE
+    configs[3] names) was recorded with the reference's own set_goal / run_controller after the constructor defect was patched as SURVEY.md
+    prescribes (tools/gen_golden.py patch_joint_velocity_defect)."""
     from oracle.oracle import env_step_parts
     from tests.util import make_oracle_parts
     g, cfg, flat = load_golden(tag, "peg_baxter")

@@ -144,6 +144,33 @@ def record_stack(seed, n_steps, action_scale, tag):
     print("stack", tag, "nv", flat.nv, "nbody", flat.nbody, "steps", n_steps, "reward", rewards[-1])
 
 
+def patch_joint_velocity_defect():
+    """JointVelocityController cannot be constructed in the surveyed snapshot: joint_vel.py:118 assigns `self.torque_compensation = ...`
+    although `torque_compensation` is a read-only property of Controller (controller.py:303-311), and run_controller then tests the truth
+    value of that 7-vector (joint_vel.py:186).  SURVEY.md section 8 (config 4) resolves the defect as use_torque_compensation = True.
+    This patch does exactly that and nothing else: the property accepts (and ignores) the assignment and returns qfrc_bias[qvel_index] wrapped
+    in an object whose truth value is True and which adds to an ndarray as a plain ndarray; set_goal / run_controller / RingBuffer / the
+    saturation logic stay the reference's own code."""
+    from robosuite.controllers.parts.generic.joint_vel import JointVelocityController
+
+    class _Compensation:
+        """qfrc_bias[qvel_index] with truth value True; adds to an ndarray as a plain ndarray (so later comparisons keep numpy semantics)."""
+
+        def __init__(self, v):
+            self.v = np.array(v, dtype=np.float64)
+
+        def __bool__(self):
+            return True
+
+        def __array__(self, dtype=None, copy=None):
+            return self.v if dtype is None else self.v.astype(dtype)
+
+    def getter(self):
+        return _Compensation(self.sim.data.qfrc_bias[self.qvel_index])
+
+    JointVelocityController.torque_compensation = property(getter, lambda self, value: None)
+
+
 def record_baxter(seed, n_steps, action_scale, ctype):
     """BASELINE configs[3] model: TwoArmPegInHole / Baxter (single-robot, no grippers; 36 bodies, 14 dofs, 29 colliding geoms) with the two
     arms under joint-space part controllers (one controller object per arm, composite_controller.py:70-95).  JOINT_VELOCITY, the type the
@@ -152,6 +179,8 @@ def record_baxter(seed, n_steps, action_scale, ctype):
     from robosuite.controllers import load_part_controller_config
     from robosuite.controllers.composite.composite_controller_factory import refactor_composite_controller_config
 
+    if ctype == "JOINT_VELOCITY":
+        patch_joint_velocity_defect()
     part = load_part_controller_config(default_controller=ctype)
     ccfg = refactor_composite_controller_config(part, "Baxter", ["right", "left"])
     env = suite.make("TwoArmPegInHole", robots="Baxter", env_configuration="single-robot", gripper_types=None, controller_configs=ccfg,
@@ -180,8 +209,11 @@ def record_baxter(seed, n_steps, action_scale, ctype):
                   input_min=[float(x) for x in ctl.input_min], input_max=[float(x) for x in ctl.input_max],
                   output_min=[float(x) for x in ctl.output_min], output_max=[float(x) for x in ctl.output_max],
                   grip_act=[], grip_sign=[], grip_speed=0.0, damping_ratio=1.0)
-        if ctype == "JOINT_POSITION":
+        if ctype in ("JOINT_POSITION", "JOINT_VELOCITY"):
             pc["kp"] = [float(x) for x in np.atleast_1d(ctl.kp)]
+        if ctype == "JOINT_VELOCITY" and ctl.velocity_limits is not None:
+            lo, hi = np.broadcast_to(ctl.velocity_limits[0], (len(pc["qpos_idx"]),)), np.broadcast_to(ctl.velocity_limits[1], (len(pc["qpos_idx"]),))
+            pc["velocity_limits"] = [[float(x) for x in lo], [float(x) for x in hi]]
         if ctype == "JOINT_TORQUE":
             pc["torque_limits"] = [[float(x) for x in ctl.torque_limits[0]], [float(x) for x in ctl.torque_limits[1]]]
         parts.append(pc)
@@ -190,8 +222,10 @@ def record_baxter(seed, n_steps, action_scale, ctype):
                input_max=cat("input_max"), output_min=cat("output_min"), output_max=cat("output_max"), grip_act=[], grip_sign=[], grip_speed=0.0,
                damping_ratio=1.0, part_of=sum(([k] * len(p["qpos_idx"]) for k, p in enumerate(parts)), []), obs_keys=keys,
                obs_dims=[int(np.atleast_1d(obs[k]).size) for k in keys])
-    if ctype == "JOINT_POSITION":
+    if ctype in ("JOINT_POSITION", "JOINT_VELOCITY"):
         cfg["kp"] = cat("kp")
+    if ctype == "JOINT_VELOCITY" and "velocity_limits" in parts[0]:
+        cfg["velocity_limits"] = [sum((p["velocity_limits"][0] for p in parts), []), sum((p["velocity_limits"][1] for p in parts), [])]
     if ctype == "JOINT_TORQUE":
         cfg["torque_limits"] = [sum((p["torque_limits"][0] for p in parts), []), sum((p["torque_limits"][1] for p in parts), [])]
     with open(os.path.join(GOLD, f"peg_baxter_{tag}.cfg.json"), "w") as f:
@@ -268,6 +302,7 @@ if __name__ == "__main__":
     if "--baxter-only" in sys.argv:
         record_baxter(seed=0, n_steps=30, action_scale=1.0, ctype="JOINT_POSITION")
         record_baxter(seed=0, n_steps=30, action_scale=1.0, ctype="JOINT_TORQUE")
+        record_baxter(seed=0, n_steps=30, action_scale=1.0, ctype="JOINT_VELOCITY")
         sys.exit(0)
     if "--stack-only" in sys.argv:
         record_stack(seed=0, n_steps=30, action_scale=1.0, tag="seed0_full")
