@@ -182,6 +182,11 @@ int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, const int32_
 /* offset of element `elem` of model float array `field` ("geom_size", "body_mass", ...) inside an env's float table, -1 if unknown */
 int rsim_param_offset(const rsim_batch* b, const char* field, int elem);
 
+/* Dispatch order of rsim_control_step (no reference counterpart; results do not depend on it).  longest_first != 0 (default): the envs that took
+ * longest in the previous control step (contact-rich envs stay so for many steps) are handed to the first workgroups, which shortens the
+ * tail of a launch; 0: env i = workgroup i.  Batches of more than 8192 envs always use the identity order. */
+int rsim_set_schedule(rsim_batch* b, int longest_first);
+
 /* Per-phase cycle accounting of the fused kernel (no reference counterpart: the reference has no profiling).
  * enable != 0 (re)arms and zeroes the accumulators, 0 disarms; if `out` is non-NULL the current accumulators are copied out first:
  * cycles {load kin com crb broad narrow makec vel ctrl act solve euler store} then counts {substeps candidates contacts efc newton ls}. */
@@ -191,6 +196,8 @@ int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, int n_out);
 int rsim_wavelog(rsim_batch* b, unsigned long long* out);
 /* restrict the phase accumulators to one env (-1 = all envs) */
 int rsim_profile_env(rsim_batch* b, int env);
+/* per candidate pair p (model pair order): out[p] = narrow-phase visits, out[320 + p] = support-function calls, summed over envs and launches since arming */
+int rsim_pairlog(rsim_batch* b, unsigned long long* out);
 
 /* zero-copy numpy-view replacement: copy a field to / from HOST float32 (int32 for RSIM_NCON..) buffers of `count` elements */
 int rsim_get_array(rsim_batch* b, int field, void* host_dst, size_t count);

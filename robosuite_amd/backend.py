@@ -152,6 +152,8 @@ def lib():
         L.rsim_model_param_get.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_size_t]
         L.rsim_profile.argtypes = [vp, C.c_int, vp, C.c_int]
         L.rsim_wavelog.argtypes = [vp, vp]
+        L.rsim_pairlog.argtypes = [vp, vp]
+        L.rsim_set_schedule.argtypes = [vp, C.c_int]
         L.rsim_profile_env.argtypes = [vp, C.c_int]
         L.rsim_osc_eval.argtypes = [C.POINTER(CtrlDesc), vp, vp, C.c_int, C.c_int]
         _LIB = L
@@ -358,6 +360,17 @@ class HipBatch:
         out = np.zeros((self.B, 8), dtype=np.uint64)
         _chk(self._L.rsim_wavelog(self.ptr, out.ctypes.data))
         return out
+
+    def set_schedule(self, longest_first=True):
+        """Dispatch order of control_step: slowest envs of the previous step first (default) or identity."""
+        _chk(self._L.rsim_set_schedule(self.ptr, int(bool(longest_first))))
+
+    def pairlog(self):
+        """Per candidate pair {narrow-phase visits, support calls} since profiling was armed -> (visits[npair], supports[npair])."""
+        out = np.zeros(640, dtype=np.uint64)
+        _chk(self._L.rsim_pairlog(self.ptr, out.ctypes.data))
+        n = len(self.model.flat.arrays["pair_geom1"])
+        return out[:n].astype(np.int64), out[320:320 + n].astype(np.int64)
 
     def profile(self, enable=True):
         """Read (then re-arm or disarm) the kernel's per-phase cycle accumulators -> dict."""

@@ -32,6 +32,7 @@ static const step_fn k_step_launch[RSIM_NCFG] = {rsim_launch_step_cfg0, rsim_lau
 static const creset_fn k_creset_launch[RSIM_NCFG] = {rsim_launch_ctrl_reset_cfg0, rsim_launch_ctrl_reset_cfg1, rsim_launch_ctrl_reset_cfg2};
 static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1, rsim_limits_cfg2};
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream);
+extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStream_t stream);
 extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr* d, unsigned long long seed, unsigned long long step, hipStream_t stream);
 
 struct rsim_model;
@@ -101,6 +102,10 @@ struct rsim_batch {
   int lim[8];
   int cfg;   // compiled kernel configuration serving this model (smallest that fits)
   int cs;    // floats of controller state per env (fixed when the batch is created)
+  int* d_order;       // longest-job-first dispatch order of rsim_control_step (null: B too large for the one-workgroup sort)
+  unsigned* d_cost;
+  int have_cost;      // d_cost holds the costs of a previous control step
+  int schedule;       // 1 = reorder before every control step (default), 0 = identity order
   // host cache for jacobians
   long gen, cache_gen;
   int cache_env;
@@ -565,6 +570,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   if (dalloc(&b->d_mesh, m->mesh_vert.size())) return 1;
   HIPCHK(hipMemcpy(b->d_mesh, m->mesh_vert.data(), m->mesh_vert.size() * sizeof(float), hipMemcpyHostToDevice));
   if (dalloc(&b->d_mask, (size_t)B)) return 1;
+  b->d_order = nullptr; b->d_cost = nullptr; b->schedule = 1; b->have_cost = 0;
+  if (B <= 8192) { if (dalloc(&b->d_order, (size_t)B)) return 1; if (dalloc(&b->d_cost, (size_t)B)) return 1; }
   if (dalloc(&b->db.needs_reset, (size_t)B)) return 1;
   b->db.ft_rw = b->d_ft;
   DModel& dm = b->dm;
@@ -630,6 +637,7 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
   hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_ft0); if (b->d_obsprog) hipFree(b->d_obsprog);
   if (b->d_bank) hipFree(b->d_bank); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); if (b->d_ft_base) hipFree(b->d_ft_base); hipFree(b->d_mesh); hipFree(b->d_mask);
+  if (b->d_order) hipFree(b->d_order); if (b->d_cost) hipFree(b->d_cost);
   if (b->db.prof) hipFree(b->db.prof);
   hipStreamDestroy(b->stream);
   delete b;
@@ -679,6 +687,16 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   b->dm.ctrl = b->m->ctrl;
   if ((flags & RF_OBS) && !b->dm.task.enabled) return fail("the task (observation / reward epilogue) was configured after the batch was created");
   if ((flags & RF_CTRL) && !b->dm.ctrl.enabled) return fail("no controller configured (rsim_model_set_controller)");
+  b->db.order = nullptr; b->db.cost = nullptr;
+  if ((flags & RF_EPISODE) && b->schedule && b->d_order) {   // control steps only: forward()/step1()/step2() launches are one substep long
+    if (b->have_cost) {
+      int eo = rsim_launch_order(b->d_cost, b->d_order, b->B, b->stream);
+      if (eo) return fail("dispatch-order kernel launch failed: %s", hipGetErrorString((hipError_t)eo));
+      b->db.order = b->d_order;
+    }
+    b->db.cost = b->d_cost;
+    b->have_cost = 1;
+  }
   int e = k_step_launch[b->cfg](&b->dm, &b->db, actions, n_sub, flags, b->stream);
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   b->gen++;
@@ -773,7 +791,7 @@ extern "C" int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, 
     HIPCHK(hipMemcpy(tmp, b->db.prof, sizeof(tmp), hipMemcpyDeviceToHost));
     for (int i = 0; i < n_out && i < RP_COUNT; i++) out[i] = tmp[i];
   }
-  const size_t nprof = RP_COUNT + 8 * (size_t)b->B;  // phase accumulators, then per-env {hw_id, xcc_id, t_start, t_end, n_mpr, n_support, n_newton, n_cand} of the last launch
+  const size_t nprof = RP_COUNT + 8 * (size_t)b->B + 2 * RSIM_PAIR_MAX;  // + per candidate pair {narrow-phase visits, support calls}; before that: phase accumulators, then per-env {hw_id, xcc_id, t_start, t_end, n_mpr, n_support, n_newton, n_cand} of the last launch
   if (enable && !b->db.prof) {
     HIPCHK(hipMalloc((void**)&b->db.prof, nprof * sizeof(unsigned long long)));
   }
@@ -782,6 +800,14 @@ extern "C" int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, 
   return 0;
 }
 
+extern "C" int rsim_set_schedule(rsim_batch* b, int longest_first) { b->schedule = longest_first ? 1 : 0; b->have_cost = 0; return 0; }
+extern "C" int rsim_pairlog(rsim_batch* b, unsigned long long* out) {
+  if (!b->db.prof) return fail("rsim_pairlog: profiling is not armed (rsim_profile(b, 1, ...))");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(out, b->db.prof + RP_COUNT + 8 * (size_t)b->B, 2 * RSIM_PAIR_MAX * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return 0;
+}
 extern "C" int rsim_profile_env(rsim_batch* b, int env) { b->db.prof_env = env; return 0; }
 
 extern "C" int rsim_wavelog(rsim_batch* b, unsigned long long* out) {

@@ -46,6 +46,7 @@ enum {
   LT_COUNT
 };
 #define RSIM_MAXDYNROOT 4
+#define RSIM_PAIR_MAX 320    /* candidate pairs of the largest kernel configuration (per-pair profile counters) */
 #define RSIM_HULL_POOL 512   /* hull vertices kept resident in LDS (distal links / gripper first) */
 #define RSIM_ARM_MAX 8
 #define RSIM_GRIP_MAX 4
@@ -88,7 +89,9 @@ struct DCtrl {
 #define RSIM_CS_JV_SIZE 161
 #define RSIM_CS_JV_SAT 164
 #define RSIM_CS_SIZE_JVEL 192
+#ifndef RSIM_CS_MAX
 #define RSIM_CS_MAX 192
+#endif
 
 // observation / reward epilogue (include/rsim.h rsim_task_desc), device form
 struct DTask {
@@ -137,6 +140,9 @@ struct DBatch {
   const int* patch_idx;  // [bank_P] offsets into the env's float table
   float* ft_rw;          // writable alias of the float tables (per-env patches)
   float* ft_base;        // saved defaults of the float tables (domain randomisation), may be null
+  // longest-job-first dispatch: workgroup i steps env order[i]; cost[env] = shader-clock ticks the env's wavefront took in the previous launch
+  const int* order;      // [B] or null (identity)
+  unsigned* cost;        // [B] or null
   unsigned long long* prof;  // optional [RP_COUNT] phase-cycle / event accumulators (null = off)
   int prof_env;              // >= 0: only this env adds to the phase accumulators
 };

@@ -99,6 +99,7 @@ __device__ __forceinline__ u64 lanemask_lt(int lane) { return (1ull << lane) - 1
 // optional per-phase cycle accounting (DBatch.prof != null): lane 0 accumulates s_memtime deltas and event counters
 struct Prof {
   unsigned long long* p;
+  unsigned long long* pairs = nullptr;   // per-pair {visits, supports} counters
   long long t0;
   int lane;
   int c_mpr = 0, c_support = 0, c_newton = 0, c_cand = 0;   // per-env event counts of this launch (wave log)
@@ -1510,6 +1511,7 @@ struct Sim {
       int t1 = uni(sm.gtype[g1]), t2 = uni(sm.gtype[g2]);
       const float margin = fmaxf(sm.gst[8 * g1 + 7], sm.gst[8 * g2 + 7]), gap = fmaxf(sm.gpar[12 * g1 + 11], sm.gpar[12 * g2 + 11]);
       const CPar cp = contact_params(g1, g2, margin, gap);
+      const int sup0 = pf.c_support;
       if (t1 == G_PLANE && t2 == G_BOX) {
         const V3 nrm = v3(sm.gmat[9 * g1 + 2], sm.gmat[9 * g1 + 5], sm.gmat[9 * g1 + 8]);
         float dist = 0;
@@ -1537,6 +1539,7 @@ struct Sim {
         convex_convex(g1, g2, margin, cp);
         pf.mark(RP_MPR); pf.count(RP_N_MPR, 1);
       }
+      if (pf.pairs && lane == 0) { atomicAdd(pf.pairs + p, 1ull); atomicAdd(pf.pairs + RSIM_PAIR_MAX + p, (unsigned long long)(pf.c_support - sup0)); }
       SYNC();
     }
   }
@@ -2439,11 +2442,16 @@ struct Sim {
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
   typedef Smem<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> SM;
-  const int env = blockIdx.x, lane = threadIdx.x;
-  if (env >= b.B) return;
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= b.B) return;
+  // workgroups are dispatched in index order: handing the envs that were slowest in the previous launch to the first workgroups
+  // (contact-rich envs stay contact-rich for many control steps) keeps the last wave of envs short
+  const int env = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
+  const long long t_launch = b.cost ? clock64() : 0;
   const float* fp = m.ft + (size_t)env * m.fstride;
   Sim<SM> sim(m, fp, lane, b.prof);
   sim.pf.acc = b.prof_env < 0 || b.prof_env == env;
+  if (b.prof) sim.pf.pairs = b.prof + RP_COUNT + 8 * (size_t)b.B;
   sim.pf.start();
   if (b.prof && lane == 0) {
     unsigned long long* wl = b.prof + RP_COUNT + 8 * (size_t)env;
@@ -2536,6 +2544,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   for (int i = lane; i < m.nu; i += 64) b.ctrl[(size_t)env * m.nu + i] = sm.ctrl[i];
   for (int i = lane; i < cs; i += 64) b.cstate[(size_t)env * cs + i] = sm.cstate[i];
   if (lane == 0) b.time[env] = time;
+  if (b.cost && lane == 0) b.cost[env] = (unsigned)((clock64() - t_launch) >> 6);
   if (b.prof && lane == 0) {
     unsigned long long* wl = b.prof + RP_COUNT + 8 * (size_t)env;
     wl[3] = wall_clock64(); wl[4] = sim.pf.c_mpr; wl[5] = sim.pf.c_support; wl[6] = sim.pf.c_newton; wl[7] = sim.pf.c_cand;
@@ -2709,6 +2718,34 @@ extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr
   return (int)hipGetLastError();
 }
 
+// order[] := env indices by decreasing cost[] (bitonic sort of 64-bit keys {~cost, env} in LDS; one workgroup, B <= 8192)
+#define RSIM_ORDER_MAX 8192
+__global__ __launch_bounds__(1024) void k_order(const unsigned* __restrict__ cost, int* __restrict__ order, int B, int n) {
+  __shared__ unsigned long long key[RSIM_ORDER_MAX];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += 1024) key[i] = i < B ? (((unsigned long long)(0xFFFFFFFFu - cost[i]) << 32) | (unsigned)i) : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= n; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n; i += 1024) {
+        const int p = i ^ j;
+        if (p > i) {
+          const unsigned long long a = key[i], c = key[p];
+          const bool up = (i & k) == 0;
+          if ((a > c) == up) { key[i] = c; key[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < B; i += 1024) order[i] = (int)(unsigned)(key[i] & 0xFFFFFFFFull);
+}
+extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStream_t stream) {
+  int n = 2;
+  while (n < B) n <<= 1;
+  if (n > RSIM_ORDER_MAX) return -1;
+  hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, cost, order, B, n);
+  return (int)hipGetLastError();
+}
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream) {
   hipLaunchKernelGGL(k_osc_eval, dim3(B), dim3(64), 0, stream, *c, in, out, B);
   return (int)hipGetLastError();

@@ -8,6 +8,7 @@ B = 4096; N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 adir = os.path.join(ROOT, "robosuite_amd", "assets")
 flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim")); cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
 env = lift.LiftBatch(flat, cfg, np.arange(B), seed0=0)
+if os.environ.get("RSIM_NOSCHED"): env.batch.set_schedule(False)
 tape = torch.tensor(lift.env_actions(np.arange(B), 50), device="cuda")
 stream = torch.cuda.ExternalStream(env.batch.stream())
 time.sleep(2.0)
