@@ -137,6 +137,9 @@ int rsim_model_create(const void* blob, size_t len, rsim_model** out);
 void rsim_model_free(rsim_model* m);
 /* scalar / size query by blob field name ("nq", "nv", ...); returns -1 if unknown */
 int rsim_model_int(const rsim_model* m, const char* name);
+/* Which compiled kernel configuration serves this model: 0 = 32 bodies x 16 dofs (Lift/Panda), 1 = 32 x 32 (Stack/Panda), 2 = 64 x 16 (Baxter);
+ * -1 = none (rsim_batch_create would refuse it).  limits, if not NULL, receives {nbody, njnt, nv, ncgeom, nsite, ncon, nefc, npair} maxima. */
+int rsim_model_config(const rsim_model* m, int* limits);
 /* controller_factory (controllers/parts/controller_factory.py:73-159) for the built-in arm part (rsim_ctrl_type) + GRIP pair */
 int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* desc);
 /* observation / reward epilogue of rsim_control_step (must be set before rsim_batch_create) */

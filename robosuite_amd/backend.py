@@ -126,6 +126,7 @@ def lib():
         L.rsim_model_set_controller.argtypes = [vp, C.POINTER(CtrlDesc)]
         L.rsim_model_set_task.argtypes = [vp, C.POINTER(TaskDesc)]
         L.rsim_model_cgeom.argtypes = [vp, C.c_int]
+        L.rsim_model_config.argtypes = [vp, C.POINTER(C.c_int * 8)]
         L.rsim_batch_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.rsim_batch_free.argtypes = [vp]
         L.rsim_batch_size.argtypes = [vp]
@@ -180,6 +181,12 @@ class HipModel:
 
     def int(self, name):
         return self._L.rsim_model_int(self.ptr, name.encode())
+
+    def kernel_config(self):
+        """(config id, limits dict) of the compiled kernel configuration that serves this model; id -1 = unsupported size."""
+        lim = (C.c_int * 8)()
+        c = self._L.rsim_model_config(self.ptr, C.byref(lim))
+        return c, dict(zip(("nbody", "njnt", "nv", "ncgeom", "nsite", "ncon", "nefc", "npair"), list(lim)))
 
     def set_controller(self, cfg: dict):
         d = ctrl_desc(cfg)

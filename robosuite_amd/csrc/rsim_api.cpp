@@ -531,6 +531,21 @@ static int dalloc(T** p, size_t n) {
   return 0;
 }
 
+// smallest compiled kernel configuration whose lane roles hold the model, -1 if none does; lim (8 ints, may be null) receives its limits
+static int pick_config(const rsim_model* m, int* lim_out) {
+  const int ncg = (int)m->cg.size();
+  for (int c = 0; c < RSIM_NCFG; c++) {
+    int lim[8];
+    k_limits[c](lim);
+    if (!(m->nbody > lim[0] || m->njnt > lim[1] || m->nv > lim[2] || m->nq > lim[2] + 8 || m->nu > 16 || ncg > lim[3] || m->nsite > lim[4] || m->npair > lim[7])) {
+      if (lim_out) memcpy(lim_out, lim, sizeof(lim));
+      return c;
+    }
+  }
+  return -1;
+}
+extern "C" int rsim_model_config(const rsim_model* m, int* limits) { return pick_config(m, limits); }
+
 extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, rsim_batch** out) {
   if (B < 1) return fail("rsim_batch_create: B < 1");
   int ndev = 0;
@@ -544,13 +559,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   b->db.prof_env = -1;
   b->d_bank = nullptr; b->d_patch = nullptr; b->d_ft_base = nullptr;
   const int ncg = (int)m->cg.size();
-  b->cfg = -1;
-  for (int c = 0; c < RSIM_NCFG && b->cfg < 0; c++) {
-    k_limits[c](b->lim);
-    if (!(m->nbody > b->lim[0] || m->njnt > b->lim[1] || m->nv > b->lim[2] || m->nq > b->lim[2] + 8 || m->nu > 16 || ncg > b->lim[3] || m->nsite > b->lim[4] ||
-          m->npair > b->lim[7]))
-      b->cfg = c;
-  }
+  b->cfg = pick_config(m, b->lim);
   if (b->cfg < 0) {
     int r = fail("rsim_batch_create: model (nbody %d njnt %d nv %d ncgeom %d nsite %d npair %d) exceeds the compiled kernel configuration (%d %d %d %d %d .. %d)",
                  m->nbody, m->njnt, m->nv, ncg, m->nsite, m->npair, b->lim[0], b->lim[1], b->lim[2], b->lim[3], b->lim[4], b->lim[7]);

@@ -532,10 +532,15 @@ __device__ __forceinline__ V3 geom_support(int g, V3 dir, gcf mesh_vert, int lan
         }
       }
     }
-    // wave arg-max, lowest index wins ties (matches the serial first-maximum scan)
+    // wave arg-max, lowest index wins ties (matches the serial first-maximum scan).  One lane holds the maximum in all but degenerate
+    // directions: its id comes from a ballot; exact ties fall back to the index reduction.  The winner's vertex is read with
+    // v_readlane (uniform lane id), not a cross-lane LDS permute.
     const float mx = wave_max(bv);
-    const int win = wave_min_i(bv == mx ? bi : 0x7fffffff) & 63;  // vertex i is scanned by lane i % 64
-    lp = v3(__shfl(bx, win), __shfl(by, win), __shfl(bz, win));
+    const u64 tie = __ballot(bv == mx);
+    int win = __ffsll((long long)tie) - 1;
+    if (__popcll(tie) > 1) win = wave_min_i(bv == mx ? bi : 0x7fffffff) & 63;  // vertex i is scanned by lane i % 64
+    win = uni(win);
+    lp = v3(bcast(bx, win), bcast(by, win), bcast(bz, win));
   }
   return p + mv(R, lp);
 }

@@ -57,3 +57,22 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
     m = backend.HipModel(flat)
     with pytest.raises(backend.RsimError, match="no HIP device|no CPU fallback|hip"):
         backend.HipBatch(m, 4)
+
+
+def test_kernel_configuration_is_chosen_by_model_size():
+    """BASELINE configs[1-3] models map onto the three compiled configurations; an oversized model is refused, not truncated."""
+    for tag, model, want in (("seed1_full", "lift_panda", 0), ("seed0_full", "stack_panda", 1), ("ctl_joint_torque", "peg_baxter", 2)):
+        _, cfg, flat = load_golden(tag, model)
+        cid, lim = backend.HipModel(flat).kernel_config()
+        assert cid == want, (model, cid)
+        assert flat.nbody <= lim["nbody"] and flat.nv <= lim["nv"] and len(flat.arrays["pair_geom1"]) <= lim["npair"]
+    # two-arm joint-space parts: 14 joints in one descriptor; the OSC types stay at one arm of <= 8 joints
+    _, cfg, flat = load_golden("ctl_joint_velocity", "peg_baxter")
+    m = backend.HipModel(flat)
+    m.set_controller(cfg)
+    assert m.action_dim == 14 and m.cstate_size == 192
+    bad = dict(cfg); bad["type"] = "OSC_POSE"; bad["kp"] = [150.0] * 6
+    for k in ("input_min", "input_max", "output_min", "output_max"):
+        bad[k] = cfg[k][:6]
+    with pytest.raises(backend.RsimError, match="at most 8"):
+        m.set_controller(bad)
