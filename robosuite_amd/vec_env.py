@@ -1,0 +1,60 @@
+"""Vectorised counterpart of `suite.make(env_name, robots=...)` + `GymWrapper` for the tasks the fused kernel carries.
+
+    env = VecEnv("Stack", n_envs=4096, flat=..., cfg=...)       # Lift | Stack | TwoArmPegInHole
+    obs = env.reset()                                           # device tensor [n_envs, obs_dim], the reference's per-key record concatenated
+    obs, reward, done, info = env.step(actions)                 # actions: CUDA float32 [n_envs, action_dim] in [-1, 1]
+    flat = env.flat_obs(obs)                                    # GymWrapper layout (wrappers/gym_wrapper.py:45-163): object-state + robot proprio keys
+    cube = env.key(obs, "cubeA_pos")                            # one observable by the reference's key name
+
+Semantics follow the reference loop (environments/base.py:277-347, 467-521): `done` is reported on the control step that reaches `horizon`,
+the env restarts on the device from its next pre-drawn reset (hard reset draws in the reference's RNG order) and the next `step` continues
+the new episode.  Everything returned aliases device memory owned by the backend.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import lift, peg_in_hole, stack
+
+TASKS = {"Lift": lift.LiftBatch, "Stack": stack.StackBatch, "TwoArmPegInHole": peg_in_hole.PegBatch}
+
+
+class VecEnv:
+    def __init__(self, env_name: str, n_envs: int, flat, cfg, device: int = 0, seed: int = 0, horizon: int = 500, env_ids=None, bank_episodes: int = 4):
+        if env_name not in TASKS:
+            raise ValueError(f"{env_name!r} has no on-device task epilogue (have {sorted(TASKS)})")
+        ids = np.arange(n_envs) if env_ids is None else np.asarray(env_ids)
+        self.env_name = env_name
+        self.env = TASKS[env_name](flat, cfg, ids, device=device, seed0=seed, horizon=horizon, bank_episodes=bank_episodes)
+        self.n_envs, self.horizon = len(ids), horizon
+        self.action_dim, self.obs_dim = self.env.model.action_dim, self.env.model.nobs
+        keys, dims = cfg["obs_keys"], cfg["obs_dims"]
+        off = np.cumsum([0] + list(dims))
+        self.obs_slices = {k: slice(int(off[i]), int(off[i + 1])) for i, k in enumerate(keys)}
+        self._object_keys = [k for k in keys if not k.startswith("robot0_")]
+        self._proprio_keys = [k for k in keys if k.startswith("robot0_")]
+
+    @property
+    def action_spec(self):
+        return -np.ones(self.action_dim), np.ones(self.action_dim)
+
+    def reset(self):
+        self.env.reset(block=0)
+        b = self.env.batch
+        b.set("ep_step", 0); b.set("ep_index", 0); b.set("done", 0)
+        b.observe()
+        return self.env.obs()
+
+    def step(self, actions):
+        self.env.step(actions)
+        return self.env.obs(), self.env.reward(), self.env.batch.tensor("done"), {"success": self.env.success()}
+
+    def key(self, obs, name: str):
+        return obs[:, self.obs_slices[name]]
+
+    def flat_obs(self, obs, keys=None):
+        """GymWrapper default: ["object-state", "robot0_proprio-state"] = object keys then robot keys; or an explicit list of observable keys."""
+        import torch
+
+        keys = self._object_keys + self._proprio_keys if keys is None else keys
+        return torch.cat([obs[:, self.obs_slices[k]] for k in keys], dim=1)

@@ -489,6 +489,33 @@ def test_vectorised_env_facade():
     assert tuple(info["success"].shape) == (6,)
 
 
+@pytest.mark.parametrize("name,tag,model", (("Stack", "seed0_full", "stack_panda"), ("TwoArmPegInHole", "ctl_joint_velocity", "peg_baxter")))
+def test_vectorised_env_for_the_other_tasks(name, tag, model):
+    """VecEnv over the Stack (32-dof configuration) and TwoArmPegInHole (64-body configuration, JOINT_VELOCITY x 2 arms) tasks: reset observation,
+    horizon / done, on-device restart from the pre-drawn bank, key lookup and the GymWrapper flattening order."""
+    from robosuite_amd import peg_in_hole, stack
+    from robosuite_amd.vec_env import VecEnv
+    g, cfg, flat = load_golden(tag, model)
+    env = VecEnv(name, 5, flat, cfg, seed=0, horizon=3, bank_episodes=2)
+    obs = env.reset()
+    assert tuple(obs.shape) == (5, sum(cfg["obs_dims"])) and env.action_dim == g["actions"].shape[1]
+    setup = stack.episode_setup if name == "Stack" else peg_in_hole.episode_setup
+    first_key = "cubeA_pos" if name == "Stack" else "hole_pos"
+    assert tuple(env.key(obs, first_key).shape) == (5, 3)
+    a = torch.zeros(5, env.action_dim, device="cuda")
+    dones = []
+    for t in range(3):
+        obs, rew, done, info = env.step(a)
+        dones.append(done.clone())
+    assert dones[0].sum().item() == 0 and dones[2].sum().item() == 5
+    # every env restarted on the device from block 1 of its own generator
+    q = env.env.batch.get("qpos")
+    assert np.abs(q - setup(0, np.arange(5), 1)).max() < 1e-6
+    fo = env.flat_obs(obs)
+    assert tuple(fo.shape) == tuple(obs.shape) and torch.equal(fo[:, :3], env.key(obs, first_key))   # object keys lead the GymWrapper layout
+    assert torch.isfinite(rew).all() and tuple(info["success"].shape) == (5,)
+
+
 def test_dynamics_domain_randomisation_on_device():
     """DynamicsModder semantics (utils/mjmod.py:1705-1729): every draw is default*(1+p u) / default+p u inside the clip range, relative to the
     saved defaults (not cumulative), quaternions stay unit, free-joint dofs untouched; per-env, per-step, reproducible from (seed, step)."""
