@@ -53,6 +53,10 @@ typedef struct rsim_ctrl_desc {
   int32_t type;             /* enum rsim_ctrl_type: which arm part controller of controller_factory.py:73-159 */
   float torque_min[RSIM_JNT_MAX], torque_max[RSIM_JNT_MAX]; /* RSIM_CTRL_JOINT_TORQUE: torque_limits (joint_tor.py:95-96; default = actuator ctrlrange);
                                                              * RSIM_CTRL_JOINT_VELOCITY: velocity_limits (joint_vel.py:113, 147-148; all zero = none) */
+  int32_t impedance_mode;             /* 0 "fixed", 1 "variable": action = [damping_ratio x n, kp x n, goal update], 2 "variable_kp": [kp x n, goal update]
+                                       * (osc.py:243-253 with n = 6, joint_pos.py:204-214 with n = ndof): kp = clip(kp, kp_limits),
+                                       * kd = 2 sqrt(kp) clip(damping_ratio, damping_ratio_limits) (1 in mode 2), applied from this control step on */
+  float kp_min[RSIM_JNT_MAX], kp_max[RSIM_JNT_MAX], damping_min[RSIM_JNT_MAX], damping_max[RSIM_JNT_MAX];
   int32_t part_of[RSIM_JNT_MAX];      /* joint-space types: which part controller (arm) owns joint i; JOINT_POSITION multiplies by that part's own
                                        * mass-matrix block only (joint_pos.py:256-259 uses Controller.mass_matrix of the part) */
 } rsim_ctrl_desc;
@@ -104,7 +108,8 @@ enum rsim_field {
   RSIM_TIME,           /* [B]     sim.data.time                                              */
   RSIM_CSTATE,         /* [B,cs]  controller state, cs = rsim_model_int(m, "cstate_size"): OSC types (32) goal_pos3 goal_ori9 q0[8] grip[4] tau[8];
                         *          joint-space types (64) goal[16] - grip[4] at 20 - tau[16] at 32; JOINT_VELOCITY (192) adds last_err[16] at 48,
-                        *          summed_err[16] at 64, derr ring[5][16] at 80, ring ptr / size at 160 / 161, saturated[part] at 164 */
+                        *          summed_err[16] at 64, derr ring[5][16] at 80, ring ptr / size at 160 / 161, saturated[part] at 164;
+                        *          variable-impedance modes (128): current kp[16] at 96, kd[16] at 112 */
   RSIM_XPOS,           /* [B,nbody,3]  sim.data.xpos      (derived, valid after forward/step1) */
   RSIM_XQUAT,          /* [B,nbody,4]  sim.data.xquat                                        */
   RSIM_QM,             /* [B,nv,nv]    dense mass matrix (mj_fullM, controller.py:226-227)  */

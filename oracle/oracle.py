@@ -51,6 +51,7 @@ def lib():
         L.rso_efc_type.argtypes = [vp, C.c_int]
         L.rso_ctrl_create.restype = vp
         L.rso_ctrl_free.argtypes = [vp]
+        L.rso_ctrl_set_impedance.argtypes = [vp, C.c_int, dp, dp, dp, dp]
         L.rso_ctrl_set_type.argtypes = [vp, C.c_int, C.c_int, dp, C.c_double, dp, dp, dp, dp, dp, dp]
         L.rso_ctrl_config.argtypes = [vp, C.c_int, ip, ip, ip, C.c_int, C.c_int, dp, C.c_double, dp, dp, dp, dp, C.c_int, C.c_int, ip, dp, C.c_double]
         L.rso_ctrl_reset.argtypes = [vp, vp]
@@ -179,6 +180,9 @@ class OracleData:
 CTRL_TYPES = {"OSC_POSE": 0, "OSC_POSITION": 1, "JOINT_POSITION": 2, "JOINT_TORQUE": 3, "JOINT_VELOCITY": 4}
 
 
+IMPEDANCE_MODES = {"fixed": 0, "variable": 1, "variable_kp": 2}
+
+
 class OracleController:
     """OSC_POSE arm + GRIP gripper; see rsim_oracle.c `rso_ctrl_*`."""
 
@@ -204,6 +208,13 @@ class OracleController:
             k2 = self._keep2
             self._L.rso_ctrl_set_type(self.ptr, ctype, cdim, _dp(k2[0]), float(cfg.get("damping_ratio", 1.0)), _dp(k2[1]), _dp(k2[2]), _dp(k2[3]),
                                       _dp(k2[4]), _dp(k2[5]), _dp(k2[6]))
+
+        mode = IMPEDANCE_MODES[cfg.get("impedance_mode", "fixed")]
+        if mode:
+            ng = n if ctype >= 2 else 6
+            kl, dl = cfg["kp_limits"], cfg["damping_ratio_limits"]
+            self._keep3 = [f64(np.broadcast_to(kl[0], (ng,))), f64(np.broadcast_to(kl[1], (ng,))), f64(np.broadcast_to(dl[0], (ng,))), f64(np.broadcast_to(dl[1], (ng,)))]
+            self._L.rso_ctrl_set_impedance(self.ptr, mode, *[_dp(a) for a in self._keep3])
 
     def reset(self, data: OracleData):
         self._L.rso_ctrl_reset(self.ptr, data.ptr)

@@ -1687,6 +1687,9 @@ typedef struct {
   /* JOINT_VELOCITY PID state (joint_vel.py:105-110): RingBuffer(dim, 5) of error increments (utils/buffers.py:24-91) */
   double last_err[ARM_MAX], summed_err[ARM_MAX], ring[5][ARM_MAX];
   int ring_ptr, ring_size, saturated;
+  /* impedance mode (osc.py:243-253, joint_pos.py:204-214): 0 fixed, 1 variable, 2 variable_kp; limits per gain */
+  int imp_mode;
+  double kp_min[ARM_MAX], kp_max[ARM_MAX], dr_min[ARM_MAX], dr_max[ARM_MAX];
   double nullspace_kp;
   /* gripper */
   int ngrip;               /* number of gripper actuators (2) */
@@ -1727,6 +1730,12 @@ void rso_ctrl_set_type(rso_ctrl *c, int type, int cdim, const double *jkp, doubl
   if (type == 2) for (int i = 0; i < c->ndof; i++) { c->jkp[i] = jkp[i]; c->jkd[i] = 2 * sqrt(jkp[i]) * damping_ratio; }
   if (type == 4) for (int i = 0; i < c->ndof; i++) c->jkp[i] = jkp[i];   /* joint_vel.py:96-103: kp (x (high - low) when scalar), ki = 0.005 kp, kd = 0.001 kp */
   if (type == 3 || type == 4) for (int i = 0; i < c->ndof; i++) { c->tl_lo[i] = tl_lo[i]; c->tl_hi[i] = tl_hi[i]; }  /* torque / velocity limits */
+}
+
+void rso_ctrl_set_impedance(rso_ctrl *c, int mode, const double *kp_min, const double *kp_max, const double *dr_min, const double *dr_max) {
+  c->imp_mode = mode;
+  int n = c->type >= 2 ? c->ndof : 6;
+  for (int i = 0; i < n; i++) { c->kp_min[i] = kp_min[i]; c->kp_max[i] = kp_max[i]; c->dr_min[i] = dr_min[i]; c->dr_max[i] = dr_max[i]; }
 }
 
 void rso_osc_goal(const double *scaled, const double *ep, const double *eR, const double *op, const double *oR, double *goal_pos, double *goal_ori);
@@ -1774,6 +1783,15 @@ static void mat3T_mul(double *r, const double *a, const double *b) { /* a^T b */
 /* set_goal at a policy step: OSC (osc.py:225-283, 306-401, mode "achieved", frame "base", delta input) + gripper
  * (composite_controller.py:97-103 -> panda_gripper.py:43-58 -> simple_grip.py:110-148) */
 void rso_ctrl_set_goal(rso_ctrl *c, rso_data *d, const double *action) {
+  if (c->imp_mode) { /* [damping_ratio x n, kp x n, goal update] (mode 1) or [kp x n, goal update] (mode 2) */
+    int n = c->type >= 2 ? c->ndof : 6;
+    double *kp = c->type >= 2 ? c->jkp : c->kp, *kd = c->type >= 2 ? c->jkd : c->kd;
+    for (int i = 0; i < n; i++) {
+      kp[i] = fmax(c->kp_min[i], fmin(c->kp_max[i], action[(c->imp_mode == 1 ? n : 0) + i]));
+      kd[i] = 2 * sqrt(kp[i]) * (c->imp_mode == 1 ? fmax(c->dr_min[i], fmin(c->dr_max[i], action[i])) : 1.0);
+    }
+    action += n * (c->imp_mode == 1 ? 2 : 1);
+  }
   double scaled[ARM_MAX] = {0};
   for (int i = 0; i < c->cdim; i++) { /* controller.py:149-168 */
     double scale = fabs(c->out_max[i] - c->out_min[i]) / fabs(c->in_max[i] - c->in_min[i]);

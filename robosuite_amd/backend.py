@@ -41,16 +41,29 @@ class CtrlDesc(C.Structure):
                 ("base_site", C.c_int32), ("kp", C.c_float * JNT_MAX), ("damping_ratio", C.c_float), ("input_min", C.c_float * JNT_MAX), ("input_max", C.c_float * JNT_MAX),
                 ("output_min", C.c_float * JNT_MAX), ("output_max", C.c_float * JNT_MAX), ("uncouple_pos_ori", C.c_int32), ("nullspace_kp", C.c_float),
                 ("ngrip", C.c_int32), ("grip_act", C.c_int32 * 4), ("grip_sign", C.c_float * 4), ("grip_speed", C.c_float),
-                ("type", C.c_int32), ("torque_min", C.c_float * JNT_MAX), ("torque_max", C.c_float * JNT_MAX), ("part_of", C.c_int32 * JNT_MAX)]
+                ("type", C.c_int32), ("torque_min", C.c_float * JNT_MAX), ("torque_max", C.c_float * JNT_MAX), ("impedance_mode", C.c_int32),
+                ("kp_min", C.c_float * JNT_MAX), ("kp_max", C.c_float * JNT_MAX), ("damping_min", C.c_float * JNT_MAX), ("damping_max", C.c_float * JNT_MAX),
+                ("part_of", C.c_int32 * JNT_MAX)]
 
 
 # arm part-controller types with an in-kernel implementation (include/rsim.h enum rsim_ctrl_type; names = the reference's config "type" strings)
 CTRL_TYPES = {"OSC_POSE": 0, "OSC_POSITION": 1, "JOINT_POSITION": 2, "JOINT_TORQUE": 3, "JOINT_VELOCITY": 4}
 
 
+IMPEDANCE_MODES = {"fixed": 0, "variable": 1, "variable_kp": 2}
+
+
 def control_dim(cfg: dict) -> int:
+    """control_dim of the goal-update part of the action (without the variable-impedance gain entries)."""
     t = cfg.get("type", "OSC_POSE")
     return {"OSC_POSE": 6, "OSC_POSITION": 3}.get(t, len(cfg["qpos_idx"]))
+
+
+def gain_dim(cfg: dict) -> int:
+    """Gain entries in front of the goal update: 2n ("variable"), n ("variable_kp"), 0 ("fixed"); n = 6 for the OSC types, ndof for JOINT_POSITION."""
+    mode = IMPEDANCE_MODES[cfg.get("impedance_mode", "fixed")]
+    n = 6 if cfg.get("type", "OSC_POSE").startswith("OSC") else len(cfg["qpos_idx"])
+    return {0: 0, 1: 2 * n, 2: n}[mode]
 
 
 class TaskDesc(C.Structure):
@@ -88,7 +101,7 @@ def ctrl_desc(cfg: dict) -> CtrlDesc:
     for i, v in enumerate(cfg.get("kp", [])[:JNT_MAX]):
         d.kp[i] = v
     for k in ("input_min", "input_max", "output_min", "output_max"):
-        if len(cfg[k]) != cdim:
+        if len(cfg[k]) != cdim:  # noqa: E501
             raise RsimError(f"controller {ctype}: {k} has {len(cfg[k])} entries, control_dim is {cdim}")
     for i in range(cdim):
         d.input_min[i], d.input_max[i] = cfg["input_min"][i], cfg["input_max"][i]
@@ -98,6 +111,13 @@ def ctrl_desc(cfg: dict) -> CtrlDesc:
         for i in range(n):
             d.torque_min[i], d.torque_max[i] = tl[0][i], tl[1][i]
     d.damping_ratio = cfg.get("damping_ratio", 1.0)
+    d.impedance_mode = IMPEDANCE_MODES[cfg.get("impedance_mode", "fixed")]
+    if d.impedance_mode:
+        ng = 6 if ctype.startswith("OSC") else n
+        kl, dl = cfg["kp_limits"], cfg["damping_ratio_limits"]
+        for i in range(ng):
+            d.kp_min[i], d.kp_max[i] = np.broadcast_to(kl[0], (ng,))[i], np.broadcast_to(kl[1], (ng,))[i]
+            d.damping_min[i], d.damping_max[i] = np.broadcast_to(dl[0], (ng,))[i], np.broadcast_to(dl[1], (ng,))[i]
     d.uncouple_pos_ori = int(cfg.get("uncouple", 1))
     d.nullspace_kp = cfg.get("nullspace_kp", 10.0)
     g = cfg.get("grip_act", [])
@@ -192,7 +212,7 @@ class HipModel:
         d = ctrl_desc(cfg)
         _chk(self._L.rsim_model_set_controller(self.ptr, C.byref(d)))
         self.ctrl_cfg = cfg
-        self.action_dim = control_dim(cfg) + (1 if cfg.get("grip_act") else 0)
+        self.action_dim = control_dim(cfg) + gain_dim(cfg) + (1 if cfg.get("grip_act") else 0)
         self.cstate_size = self._L.rsim_model_int(self.ptr, b"cstate_size")
 
     def set_task(self, task: dict):

@@ -452,6 +452,15 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
   c.eef_site = jointspace ? 0 : d->eef_site; c.base_site = jointspace ? 0 : d->base_site;
   c.type = d->type;
   c.cs_size = d->type == RSIM_CTRL_JOINT_VELOCITY ? RSIM_CS_SIZE_JVEL : (jointspace ? RSIM_CS_SIZE_JOINT : RSIM_CS_SIZE);
+  if (d->impedance_mode < 0 || d->impedance_mode > 2) return fail("controller: impedance_mode %d", d->impedance_mode);
+  if (d->impedance_mode && (d->type == RSIM_CTRL_JOINT_TORQUE || d->type == RSIM_CTRL_JOINT_VELOCITY)) return fail("controller: this part type has no variable-impedance mode");
+  c.imp_mode = d->impedance_mode;
+  c.nimp = d->impedance_mode ? (jointspace ? d->ndof : 6) : 0;
+  if (c.imp_mode) c.cs_size = RSIM_CS_SIZE_VARIMP;
+  for (int i = 0; i < c.nimp; i++) {
+    if (!(d->kp_max[i] >= d->kp_min[i]) || !(d->kp_min[i] >= 0.f) || !(d->damping_max[i] >= d->damping_min[i])) return fail("controller: bad kp / damping_ratio limits");
+    c.kp_min[i] = d->kp_min[i]; c.kp_max[i] = d->kp_max[i]; c.dr_min[i] = d->damping_min[i]; c.dr_max[i] = d->damping_max[i];
+  }
   for (int i = 0; i < d->ndof; i++) {
     if (d->part_of[i] < 0 || d->part_of[i] > 3) return fail("controller: part_of[%d] = %d (at most 4 parts)", i, d->part_of[i]);
     c.part_of[i] = d->part_of[i];
@@ -486,7 +495,7 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
     c.grip_act[i] = d->grip_act[i]; c.grip_sign[i] = d->grip_sign[i];
   }
   c.grip_speed = d->grip_speed;
-  c.action_dim = c.cdim + (d->ngrip > 0 ? 1 : 0);
+  c.action_dim = c.cdim + c.nimp * (c.imp_mode == 1 ? 2 : 1) + (d->ngrip > 0 ? 1 : 0);
   return 0;
 }
 

@@ -60,6 +60,8 @@ struct DCtrl {
   float kp[RSIM_JNT_MAX], kd[RSIM_JNT_MAX], in_min[RSIM_JNT_MAX], in_max[RSIM_JNT_MAX], out_min[RSIM_JNT_MAX], out_max[RSIM_JNT_MAX];
   float tl_lo[RSIM_JNT_MAX], tl_hi[RSIM_JNT_MAX];
   int part_of[RSIM_JNT_MAX];
+  int imp_mode, nimp;   // impedance mode (0 fixed, 1 variable, 2 variable_kp) and number of gains in the action (6 / ndof)
+  float kp_min[RSIM_JNT_MAX], kp_max[RSIM_JNT_MAX], dr_min[RSIM_JNT_MAX], dr_max[RSIM_JNT_MAX];
   int type, cdim;   // rsim_ctrl_type, control_dim of the arm part(s)
   int cs_size;      // floats of per-env controller state (RSIM_CS_SIZE for the OSC types, RSIM_CS_SIZE_JOINT for the joint-space ones)
   int uncouple;
@@ -88,6 +90,9 @@ struct DCtrl {
 #define RSIM_CS_JV_PTR 160
 #define RSIM_CS_JV_SIZE 161
 #define RSIM_CS_JV_SAT 164
+#define RSIM_CS_KP 96          /* variable-impedance modes: gains in force (set by set_goal, read by run_controller) */
+#define RSIM_CS_KD 112
+#define RSIM_CS_SIZE_VARIMP 128
 #define RSIM_CS_SIZE_JVEL 192
 #ifndef RSIM_CS_MAX
 #define RSIM_CS_MAX 192

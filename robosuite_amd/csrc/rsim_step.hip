@@ -1786,6 +1786,18 @@ struct Sim {
   __device__ __forceinline__ void ctrl_set_goal(const float* action) {
     const LaneConst K = fetchK();
     const DCtrl& c = m.ctrl;
+    // variable-impedance action layouts (osc.py:243-253, joint_pos.py:204-214): [damping_ratio x n, kp x n, goal update] or [kp x n, goal update]
+    if (c.imp_mode) {
+      const int li = lane & (RSIM_JNT_MAX - 1);
+      const float kmin = sel(c.kp_min, li), kmax = sel(c.kp_max, li), dmin = sel(c.dr_min, li), dmax = sel(c.dr_max, li);
+      if (lane < c.nimp) {
+        const float kp = fmaxf(kmin, fminf(kmax, action[(c.imp_mode == 1 ? c.nimp : 0) + lane]));
+        const float dr = c.imp_mode == 1 ? fmaxf(dmin, fminf(dmax, action[lane])) : 1.f;
+        sm.cstate[RSIM_CS_KP + lane] = kp;
+        sm.cstate[RSIM_CS_KD + lane] = 2.f * sqrtf(kp) * dr;
+      }
+      action += c.nimp * (c.imp_mode == 1 ? 2 : 1);
+    }
     if (c.type >= RSIM_CTRL_JOINT_POSITION) {
       // joint-space parts: lane i scales its own component (controller.py:149-168).  JOINT_POSITION: goal_qpos = joint_pos + delta
       // (joint_pos.py:200-236); JOINT_TORQUE: goal_torque = clip(scaled, torque_limits) (joint_tor.py:111-128)
@@ -1847,6 +1859,11 @@ struct Sim {
     const LaneConst K = fetchK();
     const DCtrl& c = m.ctrl;
     if (c.type < RSIM_CTRL_JOINT_POSITION && lane < c.ndof) sm.cstate[RSIM_CS_Q0 + lane] = sm.qpos[K.cq];
+    if (c.imp_mode) {   // the constructor's gains stay in force until the first set_goal
+      const int li = lane & (RSIM_JNT_MAX - 1);
+      const float kp0 = sel(c.kp, li), kd0 = sel(c.kd, li);
+      if (lane < c.nimp) { sm.cstate[RSIM_CS_KP + lane] = kp0; sm.cstate[RSIM_CS_KD + lane] = kd0; }
+    }
     if (c.type >= RSIM_CTRL_JOINT_POSITION) {   // joint_pos.py:268-276 (goal_qpos = joint_pos), joint_tor.py:170-178 (goal_torque = 0)
       if (lane < c.ndof) sm.cstate[RSIM_CS_GOALQ + lane] = c.type == RSIM_CTRL_JOINT_POSITION ? sm.qpos[K.cq] : 0.f;
       if (lane < RSIM_GRIP_MAX) sm.cstate[RSIM_CS_GRIP + lane] = 0.f;
@@ -1887,7 +1904,8 @@ struct Sim {
     const float goal = lane < n ? sm.cstate[RSIM_CS_GOALQ + lane] : 0.f;
     float tq = lane < n ? sm.qfrc_bias[di] : 0.f;
     if (c.type == RSIM_CTRL_JOINT_POSITION) {
-      const float des = lane < n ? sel(c.kp, li) * (goal - sm.qpos[qi]) - sel(c.kd, li) * sm.qvel[di] : 0.f;
+      const float kpj = c.imp_mode ? sm.cstate[RSIM_CS_KP + li] : sel(c.kp, li), kdj = c.imp_mode ? sm.cstate[RSIM_CS_KD + li] : sel(c.kd, li);
+      const float des = lane < n ? kpj * (goal - sm.qpos[qi]) - kdj * sm.qvel[di] : 0.f;
       const int mypart = seli(c.part_of, li);
 #pragma unroll
       for (int k = 0; k < NA; k++) {   // the part's own mass-matrix block (each arm of a multi-arm robot is its own controller object)
@@ -1994,8 +2012,11 @@ struct Sim {
     const S6 ce = ld6(sm.u.v.cvel + CS6 * eb), cb = ld6(sm.u.v.cvel + CS6 * bb);
     const V3 evl = ce.l + cross(ce.a, ep - ld3(sm.rootcom + 3 * sm.broot[eb])), bvl = cb.l + cross(cb.a, op - ld3(sm.rootcom + 3 * sm.broot[bb]));
     const V3 dvl = evl - bvl, dva = ce.a - cb.a;
-    float F[3] = {perr.x * c.kp[0] - dvl.x * c.kd[0], perr.y * c.kp[1] - dvl.y * c.kd[1], perr.z * c.kp[2] - dvl.z * c.kd[2]};
-    float T[3] = {oerr.x * c.kp[3] - dva.x * c.kd[3], oerr.y * c.kp[4] - dva.y * c.kd[4], oerr.z * c.kp[5] - dva.z * c.kd[5]};
+    float kp6[6], kd6[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { kp6[i] = c.imp_mode ? sm.cstate[RSIM_CS_KP + i] : c.kp[i]; kd6[i] = c.imp_mode ? sm.cstate[RSIM_CS_KD + i] : c.kd[i]; }
+    float F[3] = {perr.x * kp6[0] - dvl.x * kd6[0], perr.y * kp6[1] - dvl.y * kd6[1], perr.z * kp6[2] - dvl.z * kd6[2]};
+    float T[3] = {oerr.x * kp6[3] - dva.x * kd6[3], oerr.y * kp6[4] - dva.y * kd6[4], oerr.z * kp6[5] - dva.z * kd6[5]};
     float wrench[6], z[6];
     // 6x6 SPD solves with Lambda^-1: register Cholesky, row r in lane r
     float lr6[NA], linv6[NA], lt6[NA];

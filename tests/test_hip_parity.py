@@ -81,7 +81,8 @@ def test_fused_control_step_tracks_oracle_and_golden(tag):
     assert np.abs(hb.get("ctrl")[0] - g["ctrl"][-1]).max() < 2e-2 * max(1.0, np.abs(g["ctrl"][-1]).max())
 
 
-@pytest.mark.parametrize("tag", ("ctl_joint_position", "ctl_joint_torque", "ctl_osc_position"))
+@pytest.mark.parametrize("tag", ("ctl_joint_position", "ctl_joint_torque", "ctl_osc_position", "ctl_osc_pose_variable", "ctl_osc_pose_variable_kp",
+                                 "ctl_joint_position_variable"))
 def test_other_part_controllers_track_the_reference_env_loop(tag):
     """In-kernel JOINT_POSITION / JOINT_TORQUE / OSC_POSITION arm parts (+ GRIP) vs fixtures recorded with the reference's own controller
     classes (generic/joint_pos.py, generic/joint_tor.py, arm/osc.py use_ori=False) and vs the oracle restatement; same tolerances as OSC_POSE."""

@@ -45,7 +45,9 @@ def test_env_step_replay_matches_reference_loop(tag):
         assert np.abs(od.qvel - g["states"][t + 1][1 + nq:]).max() < 5e-4
 
 
-CTL_TAGS = ("ctl_joint_position", "ctl_joint_torque", "ctl_osc_position")
+CTL_TAGS = ("ctl_joint_position", "ctl_joint_torque", "ctl_osc_position",
+            # variable-impedance action layouts (osc.py:243-253, joint_pos.py:204-214): [damping_ratio, kp, goal update] / [kp, goal update]
+            "ctl_osc_pose_variable", "ctl_osc_pose_variable_kp", "ctl_joint_position_variable")
 
 
 @pytest.mark.parametrize("tag", CTL_TAGS)
@@ -58,7 +60,8 @@ def test_other_part_controllers_match_reference_loop(tag):
     s0 = g["states"][0]
     od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0
     od.forward(); oc.reset(od)
-    assert g["actions"].shape[1] == len(cfg["input_min"]) + 1
+    from robosuite_amd.backend import gain_dim
+    assert g["actions"].shape[1] == len(cfg["input_min"]) + gain_dim(cfg) + 1
     for t in range(len(g["actions"])):
         oc.env_step(od, g["actions"][t], 25)
         assert np.abs(od.ctrl - g["ctrl"][t]).max() < 1e-4 * max(1.0, np.abs(g["ctrl"][t]).max())

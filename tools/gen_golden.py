@@ -49,13 +49,14 @@ def controller_cfg(env):
     )
 
 
-def record_lift_controller(seed, n_steps, action_scale, ctype):
+def record_lift_controller(seed, n_steps, action_scale, ctype, impedance_mode="fixed"):
     """Env-level fixture for another arm part-controller type (JOINT_POSITION / JOINT_TORQUE / OSC_POSITION): the reference's own
     controller classes drive the env; only states / ctrl / obs / rewards are recorded (the controller is pinned end to end)."""
     from robosuite.controllers import load_part_controller_config
     from robosuite.controllers.composite.composite_controller_factory import refactor_composite_controller_config
 
     part = load_part_controller_config(default_controller=ctype)
+    part["impedance_mode"] = impedance_mode
     ccfg = refactor_composite_controller_config(part, "Panda", ["right"])
     env = suite.make("Lift", robots="Panda", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
                      reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed, controller_configs=ccfg)
@@ -67,16 +68,24 @@ def record_lift_controller(seed, n_steps, action_scale, ctype):
     rng = np.random.default_rng(10**6 + seed)
     keys = [k for k in obs.keys()]
     actions, states, rewards, obs_flat, ctrls = [], [sim.get_state().flatten()], [], [], []
+    lo, hi = env.action_spec   # variable-impedance modes: [damping_ratio, kp, goal update] ranges from Controller.control_limits (osc.py:546-570)
     for t in range(n_steps):
-        a = action_scale * rng.uniform(-1, 1, adim)
+        a = action_scale * rng.uniform(-1, 1, adim) if impedance_mode == "fixed" else rng.uniform(lo, hi)
         obs, r, done, info = env.step(a)
         ctrls.append(np.array(sim.data.ctrl)); actions.append(a); states.append(sim.get_state().flatten()); rewards.append(r)
         obs_flat.append(np.concatenate([np.atleast_1d(obs[k]).astype(np.float64) for k in keys if not k.endswith("-state")]))
-    tag = f"ctl_{ctype.lower()}"
+    tag = f"ctl_{ctype.lower()}" + ("" if impedance_mode == "fixed" else f"_{impedance_mode}")
     np.savez_compressed(os.path.join(GOLD, f"lift_panda_{tag}.npz"), actions=np.array(actions), states=np.array(states), rewards=np.array(rewards),
                         obs=np.array(obs_flat), ctrl=np.array(ctrls), cube_size=flat.geom_size[flat.name2id("geom", "cube_g0")])
     mjcf.save_model(flat, os.path.join(GOLD, f"lift_panda_{tag}.rsim"))
     cfg = controller_cfg_generic(env, ctype)
+    if impedance_mode != "fixed":
+        cfg["impedance_mode"] = impedance_mode
+        ng = 6 if ctype.startswith("OSC") else len(cfg["qpos_idx"])
+        cfg["kp"] = [float(x) for x in np.broadcast_to(part["kp"], (ng,))]   # gains in force before the first set_goal
+        cfg["kp_limits"] = [[float(x) for x in ctl.kp_min], [float(x) for x in ctl.kp_max]]
+        cfg["damping_ratio_limits"] = [[float(x) for x in ctl.damping_ratio_min], [float(x) for x in ctl.damping_ratio_max]]
+        cfg["input_min"], cfg["input_max"] = [float(x) for x in ctl.input_min], [float(x) for x in ctl.input_max]
     cfg["obs_keys"] = [k for k in keys if not k.endswith("-state")]
     cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in cfg["obs_keys"]]
     with open(os.path.join(GOLD, f"lift_panda_{tag}.cfg.json"), "w") as f:
@@ -101,11 +110,11 @@ def controller_cfg_generic(env, ctype):
         grip_qpos_idx=[int(i) for i in robot._ref_gripper_joint_pos_indexes["right"]],
         grip_dof_idx=[int(i) for i in robot._ref_gripper_joint_vel_indexes["right"]],
     )
-    if ctype in ("JOINT_POSITION", "OSC_POSITION"):
-        base["kp"] = [float(x) for x in np.atleast_1d(ctl.kp)]
+    if ctype in ("JOINT_POSITION", "OSC_POSITION", "OSC_POSE"):
+        base["kp"] = [float(x) for x in np.atleast_1d(ctl.kp)]   # variable-impedance recordings overwrite this with the constructor value
         base["kd"] = [float(x) for x in np.atleast_1d(ctl.kd)]
         base["damping_ratio"] = 1.0
-    if ctype == "OSC_POSITION":
+    if ctype in ("OSC_POSITION", "OSC_POSE"):
         base["uncouple"] = int(ctl.uncoupling)
     if ctype == "JOINT_TORQUE":
         base["torque_limits"] = [[float(x) for x in ctl.torque_limits[0]], [float(x) for x in ctl.torque_limits[1]]]
@@ -299,6 +308,11 @@ def record_lift(seed, n_steps, action_scale, tag):
 
 
 if __name__ == "__main__":
+    if "--impedance-only" in sys.argv:
+        record_lift_controller(seed=3, n_steps=30, action_scale=1.0, ctype="OSC_POSE", impedance_mode="variable")
+        record_lift_controller(seed=3, n_steps=30, action_scale=1.0, ctype="OSC_POSE", impedance_mode="variable_kp")
+        record_lift_controller(seed=3, n_steps=30, action_scale=1.0, ctype="JOINT_POSITION", impedance_mode="variable")
+        sys.exit(0)
     if "--baxter-only" in sys.argv:
         record_baxter(seed=0, n_steps=30, action_scale=1.0, ctype="JOINT_POSITION")
         record_baxter(seed=0, n_steps=30, action_scale=1.0, ctype="JOINT_TORQUE")
