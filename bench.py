@@ -27,6 +27,8 @@ from robosuite_amd import lift, mjcf, shard  # noqa: E402
 ENVS_PER_GPU = 4096
 N_SUB = 25
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+VALU_PER_ENV_SUBSTEP = 8700.0  # SQ_INSTS_VALU / (4096 envs x 25 substeps), profiles/r01_c_pmc_sq1.txt (bench workload, steps 1-4 of an episode)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4  # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles at 2.4 GHz
 
 
 def algorithmic_bytes_per_env_step(flat, action_dim):
@@ -150,7 +152,11 @@ def main():
                        "diverged_envs": int(tot["diverged"]), "reward_sum": tot["reward_sum"], "successes": int(tot["successes"])},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes,
-                         "note": "latency/VALU/LDS-bound by design (state LDS-resident for 25 substeps); see DESIGN.md section 6"},
+                         "note": "latency/VALU/LDS-bound by design (state LDS-resident for 25 substeps); see DESIGN.md section 6",
+                         # the fraction that describes this kernel: VALU issue slots used (PMC instruction count x measured rate), one wave per SIMD
+                         "issue": {"bound": "valu-issue", "valu_instr_per_env_substep": VALU_PER_ENV_SUBSTEP,
+                                   "achieved": VALU_PER_ENV_SUBSTEP * B * N_SUB / (kern_ms * 1e-3) / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instr/s",
+                                   "frac": VALU_PER_ENV_SUBSTEP * B * N_SUB / (kern_ms * 1e-3) / VALU_ISSUE_PEAK}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(flat, cfg)

@@ -192,7 +192,7 @@ int rsim_param_offset(const rsim_batch* b, const char* field, int elem);
 
 /* Dispatch order of rsim_control_step (no reference counterpart; results do not depend on it).  longest_first != 0 (default): the envs that took
  * longest in the previous control step (contact-rich envs stay so for many steps) are handed to the first workgroups, which shortens the
- * tail of a launch; 0: env i = workgroup i.  Batches of more than 8192 envs always use the identity order. */
+ * tail of a launch; 0: env i = workgroup i. */
 int rsim_set_schedule(rsim_batch* b, int longest_first);
 
 /* Per-phase cycle accounting of the fused kernel (no reference counterpart: the reference has no profiling).

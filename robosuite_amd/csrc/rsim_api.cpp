@@ -102,7 +102,7 @@ struct rsim_batch {
   int lim[8];
   int cfg;   // compiled kernel configuration serving this model (smallest that fits)
   int cs;    // floats of controller state per env (fixed when the batch is created)
-  int* d_order;       // longest-job-first dispatch order of rsim_control_step (null: B too large for the one-workgroup sort)
+  int* d_order;       // longest-job-first dispatch order of rsim_control_step
   unsigned* d_cost;
   int have_cost;      // d_cost holds the costs of a previous control step
   int schedule;       // 1 = reorder before every control step (default), 0 = identity order
@@ -589,7 +589,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   HIPCHK(hipMemcpy(b->d_mesh, m->mesh_vert.data(), m->mesh_vert.size() * sizeof(float), hipMemcpyHostToDevice));
   if (dalloc(&b->d_mask, (size_t)B)) return 1;
   b->d_order = nullptr; b->d_cost = nullptr; b->schedule = 1; b->have_cost = 0;
-  if (B <= 8192) { if (dalloc(&b->d_order, (size_t)B)) return 1; if (dalloc(&b->d_cost, (size_t)B)) return 1; }
+  if (dalloc(&b->d_order, (size_t)B)) return 1;
+  if (dalloc(&b->d_cost, (size_t)B)) return 1;
   if (dalloc(&b->db.needs_reset, (size_t)B)) return 1;
   b->db.ft_rw = b->d_ft;
   DModel& dm = b->dm;

@@ -2744,32 +2744,29 @@ extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr
   return (int)hipGetLastError();
 }
 
-// order[] := env indices by decreasing cost[] (bitonic sort of 64-bit keys {~cost, env} in LDS; one workgroup, B <= 8192)
-#define RSIM_ORDER_MAX 8192
-__global__ __launch_bounds__(1024) void k_order(const unsigned* __restrict__ cost, int* __restrict__ order, int B, int n) {
-  __shared__ unsigned long long key[RSIM_ORDER_MAX];
+// order[] := env indices by decreasing cost[]: one-workgroup counting sort into 256 cost bins (exact order inside a bin is irrelevant for
+// longest-job-first dispatch; results never depend on the dispatch order)
+__global__ __launch_bounds__(1024) void k_order(const unsigned* __restrict__ cost, int* __restrict__ order, int B) {
+  __shared__ unsigned lo_hi[2];
+  __shared__ int hist[256], base[256];
   const int tid = threadIdx.x;
-  for (int i = tid; i < n; i += 1024) key[i] = i < B ? (((unsigned long long)(0xFFFFFFFFu - cost[i]) << 32) | (unsigned)i) : ~0ull;
+  if (tid < 256) hist[tid] = 0;
+  if (tid == 0) { lo_hi[0] = 0xFFFFFFFFu; lo_hi[1] = 0u; }
   __syncthreads();
-  for (int k = 2; k <= n; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n; i += 1024) {
-        const int p = i ^ j;
-        if (p > i) {
-          const unsigned long long a = key[i], c = key[p];
-          const bool up = (i & k) == 0;
-          if ((a > c) == up) { key[i] = c; key[p] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  for (int i = tid; i < B; i += 1024) order[i] = (int)(unsigned)(key[i] & 0xFFFFFFFFull);
+  unsigned lo = 0xFFFFFFFFu, hi = 0u;
+  for (int i = tid; i < B; i += 1024) { const unsigned c = cost[i]; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+  atomicMin(&lo_hi[0], lo); atomicMax(&lo_hi[1], hi);
+  __syncthreads();
+  lo = lo_hi[0]; hi = lo_hi[1];
+  const float scale = 255.0f / (float)(hi - lo + 1u);
+  for (int i = tid; i < B; i += 1024) atomicAdd(&hist[(int)((float)(hi - cost[i]) * scale)], 1);   // bin 0 = most expensive
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int k = 0; k < 256; k++) { base[k] = acc; acc += hist[k]; } }
+  __syncthreads();
+  for (int i = tid; i < B; i += 1024) order[atomicAdd(&base[(int)((float)(hi - cost[i]) * scale)], 1)] = i;
 }
 extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStream_t stream) {
-  int n = 2;
-  while (n < B) n <<= 1;
-  if (n > RSIM_ORDER_MAX) return -1;
-  hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, cost, order, B, n);
+  hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, cost, order, B);
   return (int)hipGetLastError();
 }
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream) {
