@@ -1,0 +1,108 @@
+"""-m gpu: edge cases of the HIP path against the oracle -- odd batch sizes, out-of-range actions, joint limits, the cube leaving the table
+(plane contacts, free fall), masked resets.  Same tolerances as tests/test_hip_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load_golden, make_hip, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _start(g, flat, od, oc, hb, B, q=None, v=None):
+    nq = flat.nq
+    s0 = g["states"][0]
+    q = s0[1:1 + nq] if q is None else q
+    v = np.zeros(flat.nv) if v is None else v
+    od.qpos[:] = q; od.qvel[:] = v; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0; od.forward()
+    if oc is not None:
+        oc.reset(od)
+    hb.set("qpos", q[None].repeat(B, 0)); hb.set("qvel", v[None].repeat(B, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+
+
+@pytest.mark.parametrize("B", (1, 3, 4097))
+def test_batch_sizes_that_are_not_round(B):
+    """Every env of a batch of any size gets the same answer as env 0 (one workgroup per env, no cross-env state)."""
+    g, cfg, flat = load_golden("seed1_full")
+    om, od, oc = make_oracle(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=B)
+    _start(g, flat, od, oc, hb, B)
+    for t in range(3):
+        hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], B, 0), dtype=torch.float32, device="cuda"), 25)
+        oc.env_step(od, g["actions"][t], 25)
+    q = hb.get("qpos")
+    assert np.abs(q[0] - od.qpos).max() < 5e-5
+    assert (q == q[0]).all()
+
+
+def test_out_of_range_actions_are_clipped_like_the_reference():
+    """Controller.scale_action clips to [input_min, input_max] first (controller.py:149-168): +-10 behaves as +-1, and the gripper takes only the sign."""
+    g, cfg, flat = load_golden("seed1_full")
+    hm, hb = make_hip(flat, cfg, B=2)
+    om, od, oc = make_oracle(flat, cfg)
+    _start(g, flat, od, oc, hb, 2)
+    a = np.array([[1, -1, 1, -1, 1, -1, 1], [10, -10, 10, -10, 10, -10, 0.01]], dtype=np.float32)
+    for t in range(4):
+        hb.control_step(torch.tensor(a, device="cuda"), 25)
+    q = hb.get("qpos")
+    assert np.array_equal(q[0], q[1])
+
+
+def test_joint_limits_engage():
+    """Arm started next to two joint limits and commanded into them (JOINT_POSITION): limit rows against the oracle."""
+    g, cfg, flat = load_golden("ctl_joint_position")
+    nq = flat.nq
+    om, od, oc = make_oracle(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=2)
+    q = g["states"][0][1:1 + nq].copy()
+    lo, hi = flat.jnt_range[:7, 0], flat.jnt_range[:7, 1]
+    q[3], q[5] = hi[3] - 0.01, hi[5] - 0.01
+    _start(g, flat, od, oc, hb, 2, q)
+    a = np.array([0, 0, 0, 1, 0, 1, 0, 0.0])
+    hit = 0
+    for t in range(12):
+        hb.control_step(torch.tensor(np.repeat(a[None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+        oc.env_step(od, a, 25)
+        assert np.abs(hb.get("qpos")[0] - od.qpos).max() < 5e-4 and np.abs(hb.get("qvel")[0] - od.qvel).max() < 5e-3, t
+        hit += int(od.qpos[3] > hi[3] - 1e-3 or od.qpos[5] > hi[5] - 1e-3)
+    assert hit > 0     # a joint sat on (or slightly past) its soft limit
+
+
+def test_cube_sliding_off_the_table_and_landing_on_the_floor():
+    """Free flight, then plane-box contacts with the floor (a pair type the table-top episodes never exercise)."""
+    g, cfg, flat = load_golden("seed1_full")
+    nq = flat.nq
+    om, od, oc = make_oracle(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=2)
+    q = g["states"][0][1:1 + nq].copy()
+    q[9:12] = [0.55, 0.0, 0.84]           # beyond the table edge (half extent 0.4), slightly above it
+    v = np.zeros(flat.nv); v[9] = 0.6; v[13] = 2.0
+    _start(g, flat, od, oc, hb, 2, q, v)
+    zero = np.zeros(7)
+    seen_floor = False
+    for t in range(14):                   # 0.7 s: falls 0.8 m, lands, tumbles
+        hb.control_step(torch.tensor(np.repeat(zero[None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+        oc.env_step(od, zero, 25)
+        assert np.isfinite(hb.get("qvel")).all()
+        if t < 7:                         # flight: tight agreement
+            assert np.abs(hb.get("qpos")[0] - od.qpos).max() < 1e-4, t
+        floor = flat.names["geom"].index("floor")
+        seen_floor |= any(c["geom1"] == floor or c["geom2"] == floor for c in od.contacts())
+    assert seen_floor and od.qpos[11] < 0.1
+    assert abs(hb.get("qpos")[0][11] - od.qpos[11]) < 5e-3       # both came to rest on the floor (tumbling decorrelates the rest of the pose)
+
+
+def test_masked_reset_touches_only_the_selected_envs():
+    g, cfg, flat = load_golden("seed1_full")
+    om, od, oc = make_oracle(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=4)
+    _start(g, flat, od, oc, hb, 4)
+    for t in range(2):
+        hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 4, 0), dtype=torch.float32, device="cuda"), 25)
+    before = hb.get("qpos").copy()
+    hb.reset(mask=np.array([0, 1, 0, 1], dtype=np.uint8))
+    after = hb.get("qpos")
+    assert np.array_equal(after[0], before[0]) and np.array_equal(after[2], before[2])
+    assert np.allclose(after[1], flat.qpos0, atol=1e-6) and np.allclose(after[3], flat.qpos0, atol=1e-6)
+    assert hb.get("time")[1] == 0 and hb.get("time")[0] > 0
