@@ -37,7 +37,8 @@
 
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
 enum { G_PLANE = 0, G_HFIELD, G_SPHERE, G_CAPSULE, G_ELLIPSOID, G_CYLINDER, G_BOX, G_MESH };
-enum { C_FRICTION_DOF = 0, C_LIMIT_JOINT = 1, C_CONTACT_FRICTIONLESS = 2, C_CONTACT_ELLIPTIC = 3 };
+enum { C_FRICTION_DOF = 0, C_LIMIT_JOINT = 1, C_CONTACT_FRICTIONLESS = 2, C_CONTACT_ELLIPTIC = 3,
+       C_EQUALITY = 4 /* bilateral: always quadratic */, C_LIMIT_TENDON = 5 /* as a joint limit, on a fixed tendon's length */ };
 
 /* ------------------------------------------------------------------------------------------- */
 /* model blob                                                                                  */
@@ -72,6 +73,10 @@ typedef struct {
   int *actuator_trnid, *actuator_biastype, *actuator_ctrllimited, *actuator_forcelimited;
   double *actuator_gear, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange, *actuator_forcerange;
   int *pair_geom1, *pair_geom2;
+  /* fixed tendons (length = sum coef q) and equality/tendon constraints; absent in models compiled before they existed */
+  int ntendon, neq;
+  int *tendon_adr, *tendon_num, *wrap_objid, *tendon_limited, *eq_obj1id;
+  double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_length0, *tendon_invweight0, *eq_data, *eq_solref, *eq_solimp;
 } rso_model;
 
 static void *blob_find(rso_model *m, const char *name, int *count) {
@@ -114,6 +119,10 @@ rso_model *rso_model_create(const void *blob, size_t len) {
   PI_(actuator_trnid); PI_(actuator_biastype); PI_(actuator_ctrllimited); PI_(actuator_forcelimited);
   PD_(actuator_gear); PD_(actuator_gainprm); PD_(actuator_biasprm); PD_(actuator_ctrlrange); PD_(actuator_forcerange);
   PI_(pair_geom1); PI_(pair_geom2);
+  GI(ntendon); GI(neq);
+  PI_(tendon_adr); PI_(tendon_num); PI_(wrap_objid); PI_(tendon_limited); PI_(eq_obj1id);
+  PD_(wrap_prm); PD_(tendon_range); PD_(tendon_margin); PD_(tendon_solref_lim); PD_(tendon_solimp_lim); PD_(tendon_length0); PD_(tendon_invweight0);
+  PD_(eq_data); PD_(eq_solref); PD_(eq_solimp);
   /* mean diagonal inertia at qpos0 (MuJoCo stat.meaninertia [3P]) */
   double s = 0;
   for (int i = 0; i < m->nv; i++) s += m->dof_M0[i];
@@ -1080,6 +1089,19 @@ static void make_constraint(rso_data *d) {
   rso_model *m = d->m;
   int nv = m->nv;
   d->nefc = 0;
+  /* equality constraints come first (mj_makeConstraint order [3P]: equality, friction loss, limits, contacts); only equality/tendon over one
+   * fixed tendon exists here: residual = (length - length0) - polycoef[0], Jacobian = the tendon's coefficient row */
+  for (int e = 0; e < m->neq; e++) {
+    int t = m->eq_obj1id[e], r = d->nefc;
+    double *J = d->efc_J + (size_t)r * nv, len = 0;
+    memset(J, 0, sizeof(double) * nv);
+    for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) {
+      int j = m->wrap_objid[w];
+      len += m->wrap_prm[w] * d->qpos[m->jnt_qposadr[j]];
+      J[m->jnt_dofadr[j]] += m->wrap_prm[w];
+    }
+    add_row(d, C_EQUALITY, e, len - m->tendon_length0[t] - m->eq_data[5 * e], 0, 0, m->eq_solref + 2 * e, m->eq_solimp + 5 * e, m->tendon_invweight0[t]);
+  }
   /* dof friction loss */
   for (int i = 0; i < nv; i++)
     if (m->dof_frictionloss[i] > 0) {
@@ -1099,6 +1121,22 @@ static void make_constraint(rso_data *d) {
         memset(d->efc_J + (size_t)r * nv, 0, sizeof(double) * nv);
         d->efc_J[(size_t)r * nv + m->jnt_dofadr[j]] = -side;
         add_row(d, C_LIMIT_JOINT, j, dist, margin, 0, m->jnt_solref + 2 * j, m->jnt_solimp + 5 * j, m->dof_invweight0[m->jnt_dofadr[j]]);
+      }
+    }
+  }
+  /* tendon limits */
+  for (int t = 0; t < m->ntendon; t++) {
+    if (!m->tendon_limited[t]) continue;
+    double len = 0, margin = m->tendon_margin[t];
+    for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) len += m->wrap_prm[w] * d->qpos[m->jnt_qposadr[m->wrap_objid[w]]];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side < 0 ? len - m->tendon_range[2 * t] : m->tendon_range[2 * t + 1] - len;
+      if (dist < margin) {
+        int r = d->nefc;
+        double *J = d->efc_J + (size_t)r * nv;
+        memset(J, 0, sizeof(double) * nv);
+        for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) J[m->jnt_dofadr[m->wrap_objid[w]]] += -side * m->wrap_prm[w];
+        add_row(d, C_LIMIT_TENDON, t, dist, margin, 0, m->tendon_solref_lim + 2 * t, m->tendon_solimp_lim + 5 * t, m->tendon_invweight0[t]);
       }
     }
   }
@@ -1218,7 +1256,11 @@ static void primal_force(rso_data *d, const double *jar, double *f) {
         double v = -d->efc_D[i] * jar[i], fl = d->efc_frictionloss[i];
         f[i] = v > fl ? fl : (v < -fl ? -fl : v);
       } break;
+      case C_EQUALITY:
+        f[i] = -d->efc_D[i] * jar[i];
+        break;
       case C_LIMIT_JOINT:
+      case C_LIMIT_TENDON:
       case C_CONTACT_FRICTIONLESS:
         f[i] = jar[i] < 0 ? -d->efc_D[i] * jar[i] : 0;
         break;
@@ -1291,6 +1333,7 @@ static void solve_pgs(rso_data *d) {
       if (dim == 1) {
         double v = f[i] - res[0] / Athis[0];
         if (type == C_FRICTION_DOF) { double fl = d->efc_frictionloss[i]; v = v > fl ? fl : (v < -fl ? -fl : v); }
+        else if (type == C_EQUALITY) { /* bilateral: unbounded */ }
         else if (v < 0) v = 0;
         f[i] = v;
       } else {
@@ -1363,7 +1406,11 @@ static double constraint_update(rso_data *d, const double *jar, double *force, i
         else if (jar[i] >= R * fl) { state[i] = ST_LINEARPOS; force[i] = -fl; cost += fl * (-0.5 * R * fl + jar[i]); }
         else { state[i] = ST_QUADRATIC; force[i] = -D * jar[i]; cost += 0.5 * D * jar[i] * jar[i]; }
       } break;
+      case C_EQUALITY:
+        state[i] = ST_QUADRATIC; force[i] = -D * jar[i]; cost += 0.5 * D * jar[i] * jar[i];
+        break;
       case C_LIMIT_JOINT:
+      case C_LIMIT_TENDON:
       case C_CONTACT_FRICTIONLESS:
         if (jar[i] < 0) { state[i] = ST_QUADRATIC; force[i] = -D * jar[i]; cost += 0.5 * D * jar[i] * jar[i]; }
         else { state[i] = ST_SATISFIED; force[i] = 0; }
@@ -1420,7 +1467,11 @@ static void ls_eval(rso_data *d, const double *jar, const double *jv, const doub
         else if (x >= R * fl) { c += fl * (-0.5 * R * fl + x); c1 += fl * v; }
         else { c += 0.5 * D * x * x; c1 += D * x * v; c2 += D * v * v; }
       } break;
+      case C_EQUALITY:
+        c += 0.5 * D * x * x; c1 += D * x * v; c2 += D * v * v;
+        break;
       case C_LIMIT_JOINT:
+      case C_LIMIT_TENDON:
       case C_CONTACT_FRICTIONLESS:
         if (x < 0) { c += 0.5 * D * x * x; c1 += D * x * v; c2 += D * v * v; }
         break;

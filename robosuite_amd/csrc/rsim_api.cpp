@@ -601,6 +601,9 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.tolerance = m->D("tolerance") ? (float)m->D("tolerance")[0] : 1e-8f;
   dm.meaninertia = m->meaninertia;
   if (m->multijoint) { int r = fail("rsim_batch_create: bodies with more than one joint are not supported by the fused kernel"); delete b; return r; }
+  if ((m->I("ntendon") && m->I("ntendon")[0] > 0) || (m->I("neq") && m->I("neq")[0] > 0)) {
+    int r = fail("rsim_batch_create: tendons / equality constraints are not supported by the fused kernel yet (CPU oracle only)"); delete b; return r;
+  }
   if (m->ndynroot > RSIM_MAXDYNROOT) { int r = fail("rsim_batch_create: %d articulated trees (max %d)", m->ndynroot, RSIM_MAXDYNROOT); delete b; return r; }
   if (m->maxcondim > 4) { int r = fail("rsim_batch_create: condim %d contacts are not supported by the compiled kernel configuration (max 4)", m->maxcondim); delete b; return r; }
   for (int j = 0; j < m->njnt; j++) if (m->I("jnt_type")[j] == 1) { int r = fail("rsim_batch_create: ball joints are not supported by the fused kernel"); delete b; return r; }

@@ -325,7 +325,7 @@ class FlatModel:
 
 _SCALARS = {
     "nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "nmesh", "nmeshvert", "npair", "ncam", "nlight",
-    "nsensor", "ntendon", "nmocap", "timestep", "density", "viscosity", "impratio", "cone", "iterations",
+    "nsensor", "ntendon", "neq", "nmocap", "timestep", "density", "viscosity", "impratio", "cone", "iterations",
     "tolerance", "ncgeom", "solver",
 }
 
@@ -1016,13 +1016,61 @@ def compile_mjcf(xml: str, asset_dir: str | None = None, max_hull_vert: int = 0)
     sname2id = {s["name"]: i for i, s in enumerate(sites)}
     m.set("sensor_objid", np.array([sname2id.get(s["site"], -1) for s in sens], dtype=I32), I32)
     m.set("sensor_type", np.array([{"force": 0, "torque": 1}.get(s["type"], -1) for s in sens], dtype=I32), I32)
+    # ---- fixed tendons, tendon equality constraints (Robotiq grippers: models/assets/grippers/robotiq_gripper_140.xml:15-44) -------------
+    # MuJoCo semantics [3P, docs "XML reference: tendon/fixed, equality/tendon"]: length = sum_i coef_i q_i; optional limit rows on the length;
+    # an equality/tendon with one tendon constrains (length - length0) to polycoef[0] (default 0).
     tend = root.find("tendon")
-    ntendon = 0 if tend is None else len(list(tend))
+    tendons = []
+    jname2id = {j["name"]: i for i, j in enumerate(joints)}
+    if tend is not None:
+        for t in tend:
+            if t.tag != "fixed":
+                raise MJCFError("spatial tendons are not supported (only <tendon><fixed>)")
+            for k in ("stiffness", "damping", "frictionloss", "springlength"):
+                if t.get(k) is not None and any(abs(x) > 0 for x in _floats(t.get(k))):
+                    raise MJCFError(f"tendon attribute {k} is not supported")
+            wraps = [(jname2id[w.get("joint")], float(w.get("coef", "1"))) for w in t.findall("joint")]
+            for jid, _ in wraps:
+                if joints[jid]["type"] not in (JNT_HINGE, JNT_SLIDE):
+                    raise MJCFError("fixed tendons over ball / free joints are not supported")
+            rng = _floats(t.get("range"), 2, [0.0, 0.0])
+            limited = t.get("limited")
+            tendons.append(dict(name=t.get("name"), wraps=wraps, range=rng, limited=1 if (limited == "true" or (limited in (None, "auto") and t.get("range") is not None and compiler["autolimits"])) else 0,
+                                margin=float(t.get("margin", "0")), solref=_floats(t.get("solreflimit"), 2, [0.02, 1.0]),
+                                solimp=_floats(t.get("solimplimit"), 5, [0.9, 0.95, 0.001, 0.5, 2.0])))
+    ntendon = len(tendons)
+    eqs = []
     eq = root.find("equality")
-    neq = 0 if eq is None else len(list(eq))
-    if ntendon or neq:
-        raise MJCFError("tendons / equality constraints not supported yet (needed for Robotiq grippers; SURVEY §8 config 5)")
+    tname2id = {t["name"]: i for i, t in enumerate(tendons)}
+    if eq is not None:
+        for e in eq:
+            if e.tag != "tendon" or e.get("tendon2") is not None:
+                raise MJCFError(f"equality/{e.tag} is not supported (only equality/tendon with one tendon)")
+            if e.get("active", "true") != "true":
+                continue
+            eqs.append(dict(name=e.get("name"), tendon=tname2id[e.get("tendon1")], polycoef=_floats(e.get("polycoef"), 5, [0.0, 1.0, 0.0, 0.0, 0.0]),
+                            solref=_floats(e.get("solref"), 2, [0.02, 1.0]), solimp=_floats(e.get("solimp"), 5, [0.9, 0.95, 0.001, 0.5, 2.0])))
+    neq = len(eqs)
     m.set("ntendon", ntendon, I32)
+    m.set("neq", neq, I32)
+    wrap_adr, wrap_jnt, wrap_coef = [], [], []
+    for t in tendons:
+        wrap_adr.append(len(wrap_jnt))
+        for jid, coef in t["wraps"]:
+            wrap_jnt.append(jid); wrap_coef.append(coef)
+    m.set("tendon_adr", np.array(wrap_adr, dtype=I32), I32)
+    m.set("tendon_num", np.array([len(t["wraps"]) for t in tendons], dtype=I32), I32)
+    m.set("wrap_objid", np.array(wrap_jnt, dtype=I32), I32)
+    m.set("wrap_prm", np.array(wrap_coef, dtype=F64), F64)
+    m.set("tendon_limited", np.array([t["limited"] for t in tendons], dtype=I32), I32)
+    m.set("tendon_range", np.array([t["range"] for t in tendons], dtype=F64).reshape(ntendon, 2), F64)
+    m.set("tendon_margin", np.array([t["margin"] for t in tendons], dtype=F64), F64)
+    m.set("tendon_solref_lim", np.array([t["solref"] for t in tendons], dtype=F64).reshape(ntendon, 2), F64)
+    m.set("tendon_solimp_lim", np.array([t["solimp"] for t in tendons], dtype=F64).reshape(ntendon, 5), F64)
+    m.set("eq_obj1id", np.array([e["tendon"] for e in eqs], dtype=I32), I32)
+    m.set("eq_data", np.array([e["polycoef"] for e in eqs], dtype=F64).reshape(neq, 5), F64)
+    m.set("eq_solref", np.array([e["solref"] for e in eqs], dtype=F64).reshape(neq, 2), F64)
+    m.set("eq_solimp", np.array([e["solimp"] for e in eqs], dtype=F64).reshape(neq, 5), F64)
 
     # ---- collision pair list (MuJoCo filter rules, docs "Collision detection") -----------------
     excl = set()
@@ -1076,7 +1124,8 @@ def compile_mjcf(xml: str, asset_dir: str | None = None, max_hull_vert: int = 0)
         "light": [l["name"] for l in lights],
         "actuator": [a["name"] for a in acts],
         "sensor": [s["name"] for s in sens],
-        "tendon": [],
+        "tendon": [t["name"] for t in tendons],
+        "equality": [e["name"] for e in eqs],
         "mesh": mesh_names,
     }
 
@@ -1209,6 +1258,19 @@ def _set_const(m: FlatModel):
     m.set("body_invweight0", body_invweight0, F64)
     m.set("dof_invweight0", dof_invweight0, F64)
     m.set("dof_M0", dof_M0, F64)
+    # fixed tendons: length at qpos0 and inverse weight J M^-1 J^T (mj_setConst [3P])
+    nt = int(m.ntendon) if "ntendon" in m.arrays else 0
+    len0, tinv = np.zeros(nt), np.zeros(nt)
+    if nt:
+        for t in range(nt):
+            J = np.zeros(nv)
+            for w in range(int(m.tendon_adr[t]), int(m.tendon_adr[t]) + int(m.tendon_num[t])):
+                j = int(m.wrap_objid[w])
+                len0[t] += m.wrap_prm[w] * m.qpos0[m.jnt_qposadr[j]]
+                J[m.jnt_dofadr[j]] += m.wrap_prm[w]
+            tinv[t] = J @ Minv @ J
+    m.set("tendon_length0", len0, F64)
+    m.set("tendon_invweight0", tinv, F64)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -76,3 +76,13 @@ def test_kernel_configuration_is_chosen_by_model_size():
         bad[k] = cfg[k][:6]
     with pytest.raises(backend.RsimError, match="at most 8"):
         m.set_controller(bad)
+
+
+def test_models_with_tendons_are_ingested_but_flagged():
+    """Tendon / equality tables reach the library (rsim_model_int), the fused kernel refuses them at batch creation (checked on the GPU box)."""
+    import os
+    from robosuite_amd import mjcf
+    from tests.util import GOLD
+    flat = mjcf.compile_mjcf(open(os.path.join(GOLD, "coupled_fingers.xml")).read())
+    m = backend.HipModel(flat)
+    assert m.int("ntendon") == 2 and m.int("neq") == 1

@@ -92,6 +92,28 @@ def test_two_arm_joint_space_controllers_match_reference_loop(tag):
         assert np.abs(od.qvel - g["states"][t + 1][1 + nq:]).max() < 1e-5
 
 
+def test_pickplace_iiwa_robotiq_fixture_replays_on_the_oracle():
+    """BASELINE configs[4] model (nv 37; Robotiq140 = 6 finger joints tied by 4 fixed tendons under equality/tendon rows): the C controllers
+    (OSC_POSE on the IIWA arm, GRIP with the Robotiq sign table) + oracle loop replay the fixture recorded from the reference env loop, and
+    the tendon couplings hold along the way.  CPU only: the fused kernel has no configuration for this model yet."""
+    g, cfg, flat = load_golden("seed0_full", "pickplace_iiwa")
+    assert flat.nv == 37 and int(flat.ntendon) == 4 and int(flat.neq) == 4
+    om, od, oc = make_oracle(flat, cfg)
+    nq = flat.nq
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0
+    od.forward(); oc.reset(od)
+    assert od.efc_types()[:4] == [4, 4, 4, 4]
+    for t in range(len(g["actions"])):
+        oc.env_step(od, g["actions"][t], 25)
+        assert np.abs(od.ctrl - g["ctrl"][t]).max() < 1e-4 * max(1.0, np.abs(g["ctrl"][t]).max())
+        assert np.abs(od.qpos - g["states"][t + 1][1:1 + nq]).max() < 5e-4     # C vs Python controllers; the four objects rest on single MPR contacts, which amplifies rounding
+        for tnd in range(4):
+            w = range(int(flat.tendon_adr[tnd]), int(flat.tendon_adr[tnd]) + int(flat.tendon_num[tnd]))
+            length = sum(flat.wrap_prm[k] * od.qpos[flat.jnt_qposadr[flat.wrap_objid[k]]] for k in w)
+            assert abs(length - flat.tendon_length0[tnd]) < 0.02
+
+
 def test_reset_path_known_answers():
     """values produced by the reference's own reset code (placement_samplers.py:221-309,
     robots/robot.py:247-259, lift.py:311-318) for seed 0, re-derived from the documented draw order."""

@@ -242,6 +242,38 @@ def record_baxter(seed, n_steps, action_scale, ctype):
     print("baxter", tag, "nbody", flat.nbody, "nv", flat.nv, "steps", n_steps, "max ncon", max(ncon), "reward", rewards[-1])
 
 
+GRIPPER_SIGNS = {"PandaGripper": [-1.0, 1.0], "Robotiq140Gripper": [1.0, -1.0]}   # format_action direction tables (panda_gripper.py:55-57, robotiq_140_gripper.py:66-68)
+
+
+def record_pickplace(seed, n_steps, action_scale, tag):
+    """BASELINE configs[4] model: PickPlace / IIWA + Robotiq140 (nv 37, 4 fixed tendons under equality/tendon constraints, 41 colliding geoms).
+    Runs on the CPU oracle only so far; the fixture pins the OSC / gripper restatement on this robot and is the target of the next kernel
+    configuration."""
+    env = suite.make("PickPlace", robots="IIWA", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
+                     reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed)
+    obs = env.reset()
+    sim = env.sim
+    flat = sim.model._model._flat
+    rng = np.random.default_rng(10**6 + seed)
+    keys = [k for k in obs.keys() if not k.endswith("-state")]
+    actions, states, rewards, obs_flat, ctrls = [], [sim.get_state().flatten()], [], [], []
+    for t in range(n_steps):
+        a = action_scale * rng.uniform(-1, 1, env.action_dim)
+        obs, r, done, info = env.step(a)
+        ctrls.append(np.array(sim.data.ctrl)); actions.append(a); states.append(sim.get_state().flatten()); rewards.append(r)
+        obs_flat.append(np.concatenate([np.atleast_1d(obs[k]).astype(np.float64) for k in keys]))
+    np.savez_compressed(os.path.join(GOLD, f"pickplace_iiwa_{tag}.npz"), actions=np.array(actions), states=np.array(states), rewards=np.array(rewards),
+                        obs=np.array(obs_flat), ctrl=np.array(ctrls))
+    mjcf.save_model(flat, os.path.join(GOLD, f"pickplace_iiwa_{tag}.rsim"))
+    cfg = controller_cfg(env)
+    cfg["grip_sign"] = GRIPPER_SIGNS[type(env.robots[0].gripper["right"]).__name__]
+    cfg["obs_keys"] = keys
+    cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in keys]
+    with open(os.path.join(GOLD, f"pickplace_iiwa_{tag}.cfg.json"), "w") as f:
+        json.dump(cfg, f, indent=1)
+    print("pickplace", tag, "nv", flat.nv, "nbody", flat.nbody, "ntendon", int(flat.ntendon), "neq", int(flat.neq), "steps", n_steps, "reward", rewards[-1])
+
+
 def record_stack_resets(seeds):
     """Reset-path fixture (physics independent): qpos after make() (draw block 0) and after the first user reset() (block 1) per seed."""
     out = {}
@@ -308,6 +340,9 @@ def record_lift(seed, n_steps, action_scale, tag):
 
 
 if __name__ == "__main__":
+    if "--pickplace-only" in sys.argv:
+        record_pickplace(seed=0, n_steps=20, action_scale=1.0, tag="seed0_full")
+        sys.exit(0)
     if "--impedance-only" in sys.argv:
         record_lift_controller(seed=3, n_steps=30, action_scale=1.0, ctype="OSC_POSE", impedance_mode="variable")
         record_lift_controller(seed=3, n_steps=30, action_scale=1.0, ctype="OSC_POSE", impedance_mode="variable_kp")
