@@ -143,7 +143,8 @@ void rsim_model_free(rsim_model* m);
 /* scalar / size query by blob field name ("nq", "nv", ...); returns -1 if unknown */
 int rsim_model_int(const rsim_model* m, const char* name);
 /* Which compiled kernel configuration serves this model: 0 = 32 bodies x 16 dofs (Lift/Panda), 1 = 32 x 32 (Stack/Panda), 2 = 64 x 16 (Baxter);
- * -1 = none (rsim_batch_create would refuse it).  limits, if not NULL, receives {nbody, njnt, nv, ncgeom, nsite, ncon, nefc, npair} maxima. */
+ * 3 = 64 x 64 with tendon rows (PickPlace/IIWA+Robotiq140); -1 = none (rsim_batch_create would refuse it).  limits, if not NULL, receives 10 ints: {nbody, njnt, nv, ncgeom, nsite, ncon, nefc, npair, articulated trees} maxima
+ * and whether the configuration carries tendon / equality rows (the 32 x 16 one does not: such models go to the next larger one). */
 int rsim_model_config(const rsim_model* m, int* limits);
 /* controller_factory (controllers/parts/controller_factory.py:73-159) for the built-in arm part (rsim_ctrl_type) + GRIP pair */
 int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* desc);
@@ -204,7 +205,7 @@ int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, int n_out);
 int rsim_wavelog(rsim_batch* b, unsigned long long* out);
 /* restrict the phase accumulators to one env (-1 = all envs) */
 int rsim_profile_env(rsim_batch* b, int env);
-/* per candidate pair p (model pair order): out[p] = narrow-phase visits, out[320 + p] = support-function calls, summed over envs and launches since arming */
+/* per candidate pair p (model pair order): out[p] = narrow-phase visits, out[640 + p] = support-function calls (out: 1280 entries), summed over envs and launches since arming */
 int rsim_pairlog(rsim_batch* b, unsigned long long* out);
 
 /* zero-copy numpy-view replacement: copy a field to / from HOST float32 (int32 for RSIM_NCON..) buffers of `count` elements */

@@ -146,7 +146,7 @@ def lib():
         L.rsim_model_set_controller.argtypes = [vp, C.POINTER(CtrlDesc)]
         L.rsim_model_set_task.argtypes = [vp, C.POINTER(TaskDesc)]
         L.rsim_model_cgeom.argtypes = [vp, C.c_int]
-        L.rsim_model_config.argtypes = [vp, C.POINTER(C.c_int * 8)]
+        L.rsim_model_config.argtypes = [vp, C.POINTER(C.c_int * 10)]
         L.rsim_batch_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.rsim_batch_free.argtypes = [vp]
         L.rsim_batch_size.argtypes = [vp]
@@ -204,9 +204,9 @@ class HipModel:
 
     def kernel_config(self):
         """(config id, limits dict) of the compiled kernel configuration that serves this model; id -1 = unsupported size."""
-        lim = (C.c_int * 8)()
+        lim = (C.c_int * 10)()
         c = self._L.rsim_model_config(self.ptr, C.byref(lim))
-        return c, dict(zip(("nbody", "njnt", "nv", "ncgeom", "nsite", "ncon", "nefc", "npair"), list(lim)))
+        return c, dict(zip(("nbody", "njnt", "nv", "ncgeom", "nsite", "ncon", "nefc", "npair", "ntree", "tendons"), list(lim)))
 
     def set_controller(self, cfg: dict):
         d = ctrl_desc(cfg)
@@ -394,10 +394,10 @@ class HipBatch:
 
     def pairlog(self):
         """Per candidate pair {narrow-phase visits, support calls} since profiling was armed -> (visits[npair], supports[npair])."""
-        out = np.zeros(640, dtype=np.uint64)
+        out = np.zeros(1280, dtype=np.uint64)
         _chk(self._L.rsim_pairlog(self.ptr, out.ctypes.data))
         n = len(self.model.flat.arrays["pair_geom1"])
-        return out[:n].astype(np.int64), out[320:320 + n].astype(np.int64)
+        return out[:n].astype(np.int64), out[640:640 + n].astype(np.int64)
 
     def profile(self, enable=True):
         """Read (then re-arm or disarm) the kernel's per-phase cycle accumulators -> dict."""

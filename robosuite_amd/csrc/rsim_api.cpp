@@ -15,7 +15,7 @@
 #include "rsim_internal.h"
 
 // one set of launchers per compiled kernel configuration (rsim_step.hip is built once per RSIM_CFG)
-#define RSIM_NCFG 3
+#define RSIM_NCFG 4
 extern "C" int rsim_launch_step_cfg0(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
 extern "C" int rsim_launch_ctrl_reset_cfg0(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
 extern "C" int rsim_limits_cfg0(int* lim);
@@ -25,12 +25,15 @@ extern "C" int rsim_limits_cfg1(int* lim);
 extern "C" int rsim_launch_step_cfg2(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
 extern "C" int rsim_launch_ctrl_reset_cfg2(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
 extern "C" int rsim_limits_cfg2(int* lim);
+extern "C" int rsim_launch_step_cfg3(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
+extern "C" int rsim_launch_ctrl_reset_cfg3(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
+extern "C" int rsim_limits_cfg3(int* lim);
 typedef int (*step_fn)(const DModel*, const DBatch*, const float*, int, int, hipStream_t);
 typedef int (*creset_fn)(const DModel*, const DBatch*, const unsigned char*, hipStream_t);
 typedef int (*limits_fn)(int*);
-static const step_fn k_step_launch[RSIM_NCFG] = {rsim_launch_step_cfg0, rsim_launch_step_cfg1, rsim_launch_step_cfg2};
-static const creset_fn k_creset_launch[RSIM_NCFG] = {rsim_launch_ctrl_reset_cfg0, rsim_launch_ctrl_reset_cfg1, rsim_launch_ctrl_reset_cfg2};
-static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1, rsim_limits_cfg2};
+static const step_fn k_step_launch[RSIM_NCFG] = {rsim_launch_step_cfg0, rsim_launch_step_cfg1, rsim_launch_step_cfg2, rsim_launch_step_cfg3};
+static const creset_fn k_creset_launch[RSIM_NCFG] = {rsim_launch_ctrl_reset_cfg0, rsim_launch_ctrl_reset_cfg1, rsim_launch_ctrl_reset_cfg2, rsim_launch_ctrl_reset_cfg3};
+static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1, rsim_limits_cfg2, rsim_limits_cfg3};
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream);
 extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStream_t stream);
 extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr* d, unsigned long long seed, unsigned long long step, hipStream_t stream);
@@ -71,6 +74,7 @@ struct rsim_model {
   std::vector<u64> body_dofmask;
   std::vector<int> lanetab;   // [LT_COUNT][64]
   int kin_rounds, ndynroot, dynroot[RSIM_MAXDYNROOT], maxcondim, multijoint;
+  int ntendon, neq;
   DCtrl ctrl;
   rsim_task_desc task;
   int has_task;
@@ -99,7 +103,7 @@ struct rsim_batch {
   void* fptr[RSIM_FIELD_COUNT];
   size_t fcount[RSIM_FIELD_COUNT];
   int fis_int[RSIM_FIELD_COUNT];
-  int lim[8];
+  int lim[10];
   int cfg;   // compiled kernel configuration serving this model (smallest that fits)
   int cs;    // floats of controller state per env (fixed when the batch is created)
   int* d_order;       // longest-job-first dispatch order of rsim_control_step
@@ -233,8 +237,8 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
       LT(LT_ainfo, a) = jdof[j] | (m->I("jnt_qposadr")[j] << 8) | (m->I("actuator_biastype")[a] << 16) | (m->I("actuator_ctrllimited")[a] << 18) |
                         (m->I("actuator_forcelimited")[a] << 19);
     }
-    for (int p2 = 0; p2 < m->npair && p2 < 320; p2++)
-      LT(p2 < 192 ? LT_pair0 + p2 / 64 : LT_pair3 + (p2 - 192) / 64, p2 % 64) = m->geom2cg[m->I("pair_geom1")[p2]] | (m->geom2cg[m->I("pair_geom2")[p2]] << 8) | (1 << 16);
+    for (int p2 = 0; p2 < m->npair && p2 < RSIM_PAIR_MAX; p2++)
+      LT(p2 < 192 ? LT_pair0 + p2 / 64 : (p2 < 320 ? LT_pair3 + (p2 - 192) / 64 : LT_pair5 + (p2 - 320) / 64), p2 % 64) = m->geom2cg[m->I("pair_geom1")[p2]] | (m->geom2cg[m->I("pair_geom2")[p2]] << 8) | (1 << 16);
     for (int l = 0; l < 64; l++) {
       unsigned bits = 0;
       const int q = l / 16, r = l % 16;
@@ -307,6 +311,18 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
   push(IO_site_bodyid, vec("site_bodyid", m->nsite));
   push(IO_act_trnid, vec("actuator_trnid", m->nu)); push(IO_act_biastype, vec("actuator_biastype", m->nu));
   push(IO_act_ctrllimited, vec("actuator_ctrllimited", m->nu)); push(IO_act_forcelimited, vec("actuator_forcelimited", m->nu));
+  // fixed tendons / equality-tendon rows (absent in blobs compiled before they existed)
+  m->ntendon = m->I("ntendon") ? m->I("ntendon")[0] : 0;
+  m->neq = m->I("neq") ? m->I("neq")[0] : 0;
+  if (m->ntendon > 64 || m->neq > 64) { delete m; return fail("rsim_model_create: more than 64 tendons / equality constraints"); }
+  {
+    const int nw = (int)m->count("wrap_objid");
+    std::vector<int> wd(nw), wq(nw);
+    for (int w = 0; w < nw; w++) { int j = m->I("wrap_objid")[w]; wd[w] = jdof[j]; wq[w] = m->I("jnt_qposadr")[j]; }
+    for (int t = 0; t < m->ntendon; t++) if (m->I("tendon_num")[t] > 4) { delete m; return fail("rsim_model_create: fixed tendon over more than 4 joints"); }
+    push(IO_tendon_adr, vec("tendon_adr", m->ntendon)); push(IO_tendon_num, vec("tendon_num", m->ntendon)); push(IO_tendon_limited, vec("tendon_limited", m->ntendon));
+    push(IO_wrap_dof, wd); push(IO_wrap_qadr, wq); push(IO_eq_tendon, vec("eq_obj1id", m->neq));
+  }
   // ---- float table
   auto& ft = m->ftab;
   auto pushf = [&](int id, const char* k, size_t n_) {
@@ -401,6 +417,15 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
   pushf(FO_site_pos, "site_pos", 3 * m->nsite); pushf(FO_site_quat, "site_quat", 4 * m->nsite);
   pushf(FO_act_gear, "actuator_gear", m->nu); pushf(FO_act_gainprm, "actuator_gainprm", 3 * m->nu); pushf(FO_act_biasprm, "actuator_biasprm", 3 * m->nu);
   pushf(FO_act_ctrlrange, "actuator_ctrlrange", 2 * m->nu); pushf(FO_act_forcerange, "actuator_forcerange", 2 * m->nu);
+  {
+    const int nw = (int)m->count("wrap_prm"), nt = m->ntendon, ne = m->neq;
+    pushf(FO_wrap_prm, "wrap_prm", nw); pushf(FO_tendon_range, "tendon_range", 2 * nt); pushf(FO_tendon_margin, "tendon_margin", nt);
+    pushf(FO_tendon_solref, "tendon_solref_lim", 2 * nt); pushf(FO_tendon_solimp, "tendon_solimp_lim", 5 * nt);
+    pushf(FO_tendon_len0, "tendon_length0", nt); pushf(FO_tendon_invw, "tendon_invweight0", nt);
+    m->fo[FO_eq_data0] = (int)ft.size(); m->fcount[FO_eq_data0] = ne;
+    for (int e = 0; e < ne; e++) ft.push_back((float)m->D("eq_data")[5 * e]);
+    pushf(FO_eq_solref, "eq_solref", 2 * ne); pushf(FO_eq_solimp, "eq_solimp", 5 * ne);
+  }
   m->fo[FO_opt] = (int)ft.size(); m->fcount[FO_opt] = 10;
   {
     auto d1 = [&](const char* k) { const double* v = m->D(k); return v ? (float)v[0] : 0.f; };
@@ -540,13 +565,15 @@ static int dalloc(T** p, size_t n) {
   return 0;
 }
 
-// smallest compiled kernel configuration whose lane roles hold the model, -1 if none does; lim (8 ints, may be null) receives its limits
+// smallest compiled kernel configuration whose lane roles hold the model, -1 if none does; lim (10 ints, may be null) receives its limits
 static int pick_config(const rsim_model* m, int* lim_out) {
   const int ncg = (int)m->cg.size();
   for (int c = 0; c < RSIM_NCFG; c++) {
-    int lim[8];
+    int lim[10];
     k_limits[c](lim);
-    if (!(m->nbody > lim[0] || m->njnt > lim[1] || m->nv > lim[2] || m->nq > lim[2] + 8 || m->nu > 16 || ncg > lim[3] || m->nsite > lim[4] || m->npair > lim[7])) {
+    const bool tendons = m->ntendon > 0 || m->neq > 0;
+    if (!(m->nbody > lim[0] || m->njnt > lim[1] || m->nv > lim[2] || m->nq > lim[2] + 8 || m->nu > 16 || ncg > lim[3] || m->nsite > lim[4] || m->npair > lim[7] ||
+          m->ndynroot > lim[8] || (tendons && !lim[9]))) {
       if (lim_out) memcpy(lim_out, lim, sizeof(lim));
       return c;
     }
@@ -570,8 +597,10 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   const int ncg = (int)m->cg.size();
   b->cfg = pick_config(m, b->lim);
   if (b->cfg < 0) {
-    int r = fail("rsim_batch_create: model (nbody %d njnt %d nv %d ncgeom %d nsite %d npair %d) exceeds the compiled kernel configuration (%d %d %d %d %d .. %d)",
-                 m->nbody, m->njnt, m->nv, ncg, m->nsite, m->npair, b->lim[0], b->lim[1], b->lim[2], b->lim[3], b->lim[4], b->lim[7]);
+    int lim[10];
+    k_limits[RSIM_NCFG - 1](lim);
+    int r = fail("rsim_batch_create: model (nbody %d njnt %d nv %d ncgeom %d nsite %d npair %d, %d articulated trees) exceeds the largest compiled kernel configuration "
+                 "(%d %d %d %d %d .. %d, %d trees)", m->nbody, m->njnt, m->nv, ncg, m->nsite, m->npair, m->ndynroot, lim[0], lim[1], lim[2], lim[3], lim[4], lim[7], lim[8]);
     delete b;
     return r;
   }
@@ -596,15 +625,13 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   DModel& dm = b->dm;
   dm.nq = m->nq; dm.nv = m->nv; dm.nu = m->nu; dm.nbody = m->nbody; dm.njnt = m->njnt; dm.ncg = ncg; dm.nsite = m->nsite; dm.npair = m->npair;
   dm.maxdepth = m->maxdepth; dm.nroot = m->nroot;
+  dm.ntendon = m->ntendon; dm.neq = m->neq;
   dm.iterations = m->I("iterations") ? m->I("iterations")[0] : 100;
   dm.ls_iterations = 50; dm.cone = m->I("cone") ? m->I("cone")[0] : 1; dm.solver = 1;
   dm.tolerance = m->D("tolerance") ? (float)m->D("tolerance")[0] : 1e-8f;
   dm.meaninertia = m->meaninertia;
   if (m->multijoint) { int r = fail("rsim_batch_create: bodies with more than one joint are not supported by the fused kernel"); delete b; return r; }
-  if ((m->I("ntendon") && m->I("ntendon")[0] > 0) || (m->I("neq") && m->I("neq")[0] > 0)) {
-    int r = fail("rsim_batch_create: tendons / equality constraints are not supported by the fused kernel yet (CPU oracle only)"); delete b; return r;
-  }
-  if (m->ndynroot > RSIM_MAXDYNROOT) { int r = fail("rsim_batch_create: %d articulated trees (max %d)", m->ndynroot, RSIM_MAXDYNROOT); delete b; return r; }
+
   if (m->maxcondim > 4) { int r = fail("rsim_batch_create: condim %d contacts are not supported by the compiled kernel configuration (max 4)", m->maxcondim); delete b; return r; }
   for (int j = 0; j < m->njnt; j++) if (m->I("jnt_type")[j] == 1) { int r = fail("rsim_batch_create: ball joints are not supported by the fused kernel"); delete b; return r; }
   if (dalloc(&b->d_lt, m->lanetab.size())) return 1;

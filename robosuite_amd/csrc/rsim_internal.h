@@ -13,6 +13,7 @@ enum {
   IO_pair_g1, IO_pair_g2,
   IO_site_bodyid,
   IO_act_trnid, IO_act_biastype, IO_act_ctrllimited, IO_act_forcelimited,
+  IO_tendon_adr, IO_tendon_num, IO_tendon_limited, IO_wrap_dof, IO_wrap_qadr, IO_eq_tendon,   /* fixed tendons + equality/tendon rows */
   IO_COUNT
 };
 // ---- packed float tables (per-env stride `fstride`, 0 = shared) -------------------------------------------
@@ -26,6 +27,8 @@ enum {
   FO_site_pos, FO_site_quat,
   FO_act_gear, FO_act_gainprm, FO_act_biasprm, FO_act_ctrlrange, FO_act_forcerange,
   FO_opt /* timestep, gx,gy,gz, density, viscosity, impratio, windx,windy,windz */,
+  FO_wrap_prm, FO_tendon_range, FO_tendon_margin, FO_tendon_solref, FO_tendon_solimp, FO_tendon_len0, FO_tendon_invw,
+  FO_eq_data0 /* polycoef[0] */, FO_eq_solref, FO_eq_solimp,
   FO_COUNT
 };
 
@@ -43,10 +46,11 @@ enum {
   LT_ghull,  /* colliding geom g = lane: first slot of its hull in the LDS-resident vertex pool, -1 = scan from global memory */
   LT_mfbits, /* 0/1 operands of the tree-incidence MFMAs: sub[8] | bodydof[2][4] | dcv[4] | m1[4] | m2[4] */
   LT_pair3, LT_pair4, /* candidate pairs 192..319 (configurations with more than three rows of pairs) */
+  LT_pair5, LT_pair6, LT_pair7, LT_pair8, LT_pair9, /* candidate pairs 320..639 */
   LT_COUNT
 };
-#define RSIM_MAXDYNROOT 4
-#define RSIM_PAIR_MAX 320    /* candidate pairs of the largest kernel configuration (per-pair profile counters) */
+#define RSIM_MAXDYNROOT 8
+#define RSIM_PAIR_MAX 640    /* candidate pairs of the largest kernel configuration (per-pair profile counters) */
 #define RSIM_HULL_POOL 512   /* hull vertices kept resident in LDS (distal links / gripper first) */
 #define RSIM_ARM_MAX 8
 #define RSIM_GRIP_MAX 4
@@ -109,6 +113,7 @@ struct DTask {
 
 struct DModel {
   int nq, nv, nu, nbody, njnt, ncg, nsite, npair, maxdepth, nroot;
+  int ntendon, neq;   // fixed tendons, equality/tendon constraints
   int iterations, ls_iterations, cone, solver;
   float tolerance, meaninertia;
   const int* it;

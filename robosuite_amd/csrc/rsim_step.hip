@@ -10,6 +10,7 @@
 // per constraint block.  Algorithm (not code) follows oracle/rsim_oracle.c, which cites the reference call sites.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/rsim.h"
 #include "rsim_internal.h"
@@ -28,9 +29,12 @@
 #elif RSIM_CFG == 1
 #define RSIM_DIMS 32, 16, 32, 24, 16, 32, 64, 192
 #define RSIM_SYM(x) x##_cfg1
-#else  // 64 bodies x 16 dofs (Baxter: 36 bodies, 29 colliding geoms, 17 sites, 299 candidate pairs): tree products as mask loops, dense ones on one tile
+#elif RSIM_CFG == 2  // 64 bodies x 16 dofs (Baxter: 36 bodies, 29 colliding geoms, 17 sites, 299 candidate pairs): tree products as mask loops, dense ones on one tile
 #define RSIM_DIMS 64, 16, 16, 32, 32, 32, 64, 320
 #define RSIM_SYM(x) x##_cfg2
+#else  // 64 bodies x 64 dofs (PickPlace / IIWA + Robotiq140: 36 bodies, 37 dofs, 41 colliding geoms, 622 candidate pairs, tendon rows)
+#define RSIM_DIMS 64, 32, 64, 64, 32, 32, 64, 640
+#define RSIM_SYM(x) x##_cfg3
 #endif
 
 #ifndef RSIM_MINWAVES
@@ -44,7 +48,8 @@ typedef unsigned long long u64;
 
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
 enum { G_PLANE = 0, G_HFIELD, G_SPHERE, G_CAPSULE, G_ELLIPSOID, G_CYLINDER, G_BOX, G_MESH };
-enum { C_FRICTION_DOF = 0, C_LIMIT_JOINT = 1, C_CONTACT_FRICTIONLESS = 2, C_CONTACT_ELLIPTIC = 3 };
+enum { C_FRICTION_DOF = 0, C_LIMIT_JOINT = 1, C_CONTACT_FRICTIONLESS = 2, C_CONTACT_ELLIPTIC = 3,
+       C_EQUALITY = 4 /* equality/tendon: bilateral, always quadratic */, C_LIMIT_TENDON = 5 /* limit on a fixed tendon's length */ };
 enum { ST_SATISFIED = 0, ST_QUADRATIC = 1, ST_LINEARNEG = 2, ST_LINEARPOS = 3, ST_CONE = 4 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -203,7 +208,7 @@ __device__ __forceinline__ S6 mul_inert(const float* I, S6 v) {
 // ------------------------------------------------------------------------------------------------------------
 
 // LDS words of the per-lane constant block: 29 body fields x NB, 13 dof x NV, 11 geom x 32, 8 site x NS, 10 actuator x 16, 5 ctrl x 16, pair rows + mfbits x 64
-#define RSIM_KC_WORDS(NB, NV, NS, NPAIR) (29 * (NB) + 13 * (NV) + 11 * 32 + 8 * (NS) + 10 * 16 + 5 * 16 + ((NPAIR) / 64 + 1) * 64)
+#define RSIM_KC_WORDS(NB, NV, NGW, NS, NPAIR) (29 * (NB) + 13 * (NV) + 11 * (NGW) + 8 * (NS) + 10 * 16 + 5 * 16 + ((NPAIR) / 64 + 1) * 64)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 // explicitly global (address space 1) views of the model tables: pointers that arrive inside the by-value DModel would otherwise be
@@ -218,7 +223,7 @@ __device__ __forceinline__ Q4 ldq(gcf p) { Q4 q = {p[0], p[1], p[2], p[3]}; retu
 // ------------------------------------------------------------------------------------------------------------
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 struct Smem {
-  static_assert((NB == 32 || NB == 64) && (NV == 16 || NV == 32) && NEFC == 64 && NG <= 32 && (NS == 16 || NS == 32) && NPAIR % 64 == 0 && NPAIR <= 320,
+  static_assert((NB == 32 || NB == 64) && (NV == 16 || NV == 32 || NV == 64) && NEFC == 64 && NG <= 64 && (NS == 16 || NS == 32) && NPAIR % 64 == 0 && NPAIR <= 640,
                 "lane roles: body / site / dof columns are powers of two, one lane per constraint row, candidate pairs in rows of 64");
   static constexpr bool TREE_TILE_ = NB == 32 && NV == 16;   // tree products as 32-body x 16-dof incidence-matrix MFMAs
   static constexpr int NVP = NV + 1;  // padded row stride of the dense nv x nv matrices (conflict-free column reads)
@@ -226,12 +231,18 @@ struct Smem {
   static constexpr int JS_ = NV + 1, CS6_ = 9, FS_ = 17;  // LDS row strides (odd => bank-conflict-free lane-per-row access)
   static constexpr int NM_ = TREE_TILE_ ? 1 : NV;       // extent of the tree bit-mask tables (mask-loop configurations only)
   static constexpr int NS_ = NS, NPT_ = NPAIR / 64;
+  static constexpr int NGW_ = NG <= 32 ? 32 : 64;       // columns of the geom role in the per-lane constant block
+  typedef typename std::conditional<(NV > 32), unsigned long long, unsigned>::type dmask_t;   // one bit per dof
   static constexpr int CD_ = 4;       // largest contact dimension this configuration handles (condim 1, 3, 4)
   static constexpr int NCON_ = NCON;
   static constexpr int NB_ = NB;
   float qpos[NV + 8], qvel[NV], qacc[NV], qacc_ws[NV], ctrl[NV];
   float xpos[NB * 3], xquat[NB * 4];
-  float rootcom[(RSIM_MAXDYNROOT + 1) * 3];  // subtree COM per articulated tree; last slot = 0 for static trees
+  // articulated trees (robot + free objects) and tendon / equality rows are compiled per configuration: the 32 x 16 one (the bench workload)
+  // keeps four trees and no tendon code
+  static constexpr int NROOT_ = NV > 32 ? RSIM_MAXDYNROOT : 4;
+  static constexpr bool TENDONS_ = !(NB == 32 && NV == 16);
+  float rootcom[(NROOT_ + 1) * 3];  // subtree COM per articulated tree; last slot = 0 for static trees
   float cinert[NB * 10 + 16];  // +16: the MFMA B-operand read pattern runs 6 floats past the last row
   float cdof[NV * 9];          // stride CS6 = 9 (odd: conflict-free row reads), components 6..8 stay zero (MFMA K padding)
   // phase-local storage: crb -> broadphase -> velocity -> controller read cvel -> solver W
@@ -252,7 +263,8 @@ struct Smem {
   float arm[NV];                 // dof armature (1 on padding rows: keeps the padded matrices SPD)
   float fricR[NV], fricB[NV], fricFl[NV];  // dof friction-loss rows: regulariser, velocity gain, force limit
   float biw[NB * 2];             // body_invweight0
-  int bdofs[NB], broot[NB];
+  dmask_t bdofs[NB];
+  int broot[NB];
   float gst[NG * 8];             // colliding geom statics: half-extents 3, box centre (geom frame) 3, rbound, margin
   float gcap[NG * 8];            // bounding capsule of mesh hulls in the geom frame: p3 q3 R (R < 0: none)
   int gtype[NG], gbody[NG], gcp[NG], gmesh[NG];   // type, body, condim | priority<<8, hull vertex adr | count<<16
@@ -269,12 +281,12 @@ struct Smem {
   float cstate[RSIM_CS_MAX];
   float red[NV];
   // wide configuration: tree incidence as bit masks (dof-ancestor set, dofs summed before dof i in the velocity recursion, body ancestors)
-  int dmask_anc[NM_], dmask_cvel[NM_];
+  dmask_t dmask_anc[NM_], dmask_cvel[NM_];
   unsigned long long bmask_anc[TREE_TILE_ ? 1 : NB];
   float hull[3 * RSIM_HULL_POOL];   // LDS-resident hull vertex pool (SoA x | y | z); filled once per launch
   int ghull[NG];                    // first pool slot of geom g, -1: not resident
   // per-lane model constants, one row per field (LaneConst below); phases fetch the handful they need instead of pinning ~80 VGPRs
-  float kc[RSIM_KC_WORDS(NB, NV, NS, NPAIR)];
+  float kc[RSIM_KC_WORDS(NB, NV, NGW_, NS, NPAIR)];
   int ncon, nefc, niter;
 };
 
@@ -568,7 +580,7 @@ struct LaneConst {
   int ainfo;
   float agear, again, ab0, ab1, ab2, acr0, acr1, afr0, afr1;
   // candidate pairs p = lane + 64 t
-  int pair[5];
+  int pair[10];
   unsigned mfbits;
   // built-in controller, lane i = arm joint i / gripper actuator i
   int cq, cd, ca, cga;
@@ -594,15 +606,21 @@ struct Sim {
   static constexpr bool FAST = SM::NV_ == 16;   // one-tile dense algebra: 16 x 16 MFMA products + register Cholesky
   static constexpr bool TREE = SM::TREE_TILE_;  // tree products (CRBA composite inertias, RNE sums) as incidence-matrix MFMAs
   static constexpr int NPT = SM::NPT_;          // rows of 64 candidate pairs
+  static constexpr int NROOT = SM::NROOT_;
+  static constexpr bool TENDONS = SM::TENDONS_;
+  typedef typename SM::dmask_t dmask_t;
+  __device__ __forceinline__ dmask_t dmask_load(int tab, int i) const {   // dof bit mask i of an int-table entry stored as two 32-bit words
+    if constexpr (sizeof(dmask_t) == 8) return mask2(tab, i); else return (dmask_t)(unsigned)IT(tab, 2 * i);
+  }
   static constexpr int NT = SM::NV_ / 16;       // 16-dof tiles per dimension of the dense nv x nv products
 
   __device__ Sim(const DModel& m_, const float* fp_, int lane_, unsigned long long* prof) : m(m_), fp(fp_), lane(lane_) { pf.p = prof; pf.lane = lane_; pf.t0 = 0; }
 
-  // articulated-tree slot of a root body (RSIM_MAXDYNROOT = static tree, COM unused / zero)
+  // articulated-tree slot of a root body (NROOT = static tree, COM unused / zero)
   __device__ __forceinline__ int root_slot(int rootbody) const {
-    int sl = RSIM_MAXDYNROOT;
+    int sl = NROOT;
 #pragma unroll
-    for (int r = 0; r < RSIM_MAXDYNROOT; r++) if (r < m.ndynroot && m.dynroot[r] == rootbody) sl = r;
+    for (int r = 0; r < NROOT; r++) if (r < m.ndynroot && m.dynroot[r] == rootbody) sl = r;
     return sl;
   }
   __device__ __forceinline__ u64 mask2(int tab, int i) const { return (u64)(uint32_t)IT(tab, 2 * i) | ((u64)(uint32_t)IT(tab, 2 * i + 1) << 32); }
@@ -637,8 +655,8 @@ struct Sim {
       }
       o += 13 * W;
     }
-    {  // geom role, 32 columns
-      const int l = lane & 31, W = 32;
+    {  // geom role, 32 or 64 columns
+      const int l = lane & (SM::NGW_ - 1), W = SM::NGW_;
       if (!STORE || lane < W) { kio<STORE>(K.ginfo, o + l); kio<STORE>(K.gp, o + 1 * W + l, W); kio<STORE>(K.gq, o + 4 * W + l, W); kio<STORE>(K.grc, o + 8 * W + l, W); }
       o += 11 * W;
     }
@@ -673,7 +691,7 @@ struct Sim {
     K.part = lt[LT_part * 64 + lane]; K.part4 = lt[LT_part4 * 64 + lane]; K.binfo = lt[LT_binfo * 64 + lane]; K.bdofs = (unsigned)lt[LT_bdofs * 64 + lane];
     K.dinfo = lt[LT_dinfo * 64 + lane]; K.ginfo = lt[LT_ginfo * 64 + lane]; K.sbody = lt[LT_sinfo * 64 + lane]; K.ainfo = lt[LT_ainfo * 64 + lane];
 #pragma unroll
-    for (int t = 0; t < NPT; t++) K.pair[t] = lt[(t < 3 ? LT_pair0 + t : LT_pair3 + (t - 3)) * 64 + lane];
+    for (int t = 0; t < NPT; t++) K.pair[t] = lt[(t < 3 ? LT_pair0 + t : (t < 5 ? LT_pair3 + (t - 3) : LT_pair5 + (t - 5))) * 64 + lane];
     K.mfbits = (unsigned)lt[LT_mfbits * 64 + lane];
     opt_h = FP(FO_opt, 0); opt_grav = v3(FP(FO_opt, 1), FP(FO_opt, 2), FP(FO_opt, 3)); opt_density = FP(FO_opt, 4); opt_viscosity = FP(FO_opt, 5);
     opt_impratio = FP(FO_opt, 6); opt_wind = v3(FP(FO_opt, 7), FP(FO_opt, 8), FP(FO_opt, 9));
@@ -689,7 +707,7 @@ struct Sim {
       K.q0 = FP(FO_qpos0, (K.binfo >> 4) & 255);
       if (lane >= nb) { K.part = 0; K.part4 = 0; K.binfo = 15; K.bdofs = 0; K.mass = 0.f; }
       if (lane < SM_NB) { sm.biw[2 * lane] = lane < nb ? FP(FO_body_invweight0, 2 * b) : 0.f; sm.biw[2 * lane + 1] = lane < nb ? FP(FO_body_invweight0, 2 * b + 1) : 0.f;
-                          sm.bdofs[lane] = (int)K.bdofs; sm.broot[lane] = root_slot((K.binfo >> 20) & 255); }
+                          sm.bdofs[lane] = lane < nb ? dmask_load(IO_body_dofmask, b) : (dmask_t)0; sm.broot[lane] = root_slot((K.binfo >> 20) & 255); }
     }
     {  // dof role
       const int i = lane < nv ? lane : 0, j = (K.dinfo >> 18) & 255;
@@ -710,7 +728,7 @@ struct Sim {
       }
       if (lane >= nv) K.dinfo = 0;
       if constexpr (!TREE) {
-        if (lane < NV16) { sm.dmask_anc[lane] = lane < nv ? IT(IO_dof_ancmask, 2 * i) : 0; sm.dmask_cvel[lane] = lane < nv ? IT(IO_dof_cvelmask, 2 * i) : 0; }
+        if (lane < NV16) { sm.dmask_anc[lane] = lane < nv ? dmask_load(IO_dof_ancmask, i) : (dmask_t)0; sm.dmask_cvel[lane] = lane < nv ? dmask_load(IO_dof_cvelmask, i) : (dmask_t)0; }
         if (lane < SM_NB) sm.bmask_anc[lane] = lane < nb ? mask2(IO_body_ancmask, lane) : 0ull;
       }
     }
@@ -757,7 +775,7 @@ struct Sim {
     // zero the LDS regions whose padding lanes / columns are read but never written
     for (int e = lane; e < SM_NB * 10 + 16; e += 64) sm.cinert[e] = 0.f;
     for (int e = lane; e < NV16 * CS6; e += 64) sm.cdof[e] = 0.f;
-    if (lane < (RSIM_MAXDYNROOT + 1) * 3) sm.rootcom[lane] = 0.f;
+    if (lane < (NROOT + 1) * 3) sm.rootcom[lane] = 0.f;
     kxfer<true>(K);
     SYNC();
     // resident hull pool: one pass per pooled mesh, lane-parallel over its vertices
@@ -840,7 +858,7 @@ struct Sim {
     const V3 xip = xp + mv(R, K.ipos);
     V3 com = xip;
 #pragma unroll
-    for (int r = 0; r < RSIM_MAXDYNROOT; r++) {
+    for (int r = 0; r < NROOT; r++) {
       if (r >= m.ndynroot) break;
       const int rb = m.dynroot[r];
       const float w = (b < nb && root == rb) ? K.mass : 0.f;
@@ -1001,10 +1019,10 @@ struct Sim {
   // cvel = BodyDof x (cdof qd) ; cdof_dot_i = cvel_before(i) x cdof_i ; cacc = BodyDof x (cdof_dot qd) - g ;
   // body wrench cf = I cacc + cvel x* I cvel (+ fluid) ; F = Sub x cf ; bias_i = cdof_i . F_i
   // out[row] = sum over dofs i in mask of cdof_i * qvel_i (wide configuration); rows are written by the lanes with `store`
-  __device__ __forceinline__ void masked_dof_sum(const float* cdofs, unsigned mask, bool store, float* out) {
+  __device__ __forceinline__ void masked_dof_sum(const float* cdofs, dmask_t mask, bool store, float* out) {
     S6 acc = {v3(0, 0, 0), v3(0, 0, 0)};
     const int nv = m.nv;
-    for (int i = 0; i < nv; i++) if ((mask >> i) & 1u) acc = acc + ld6(cdofs + CS6 * i) * sm.qvel[i];
+    for (int i = 0; i < nv; i++) if ((mask >> i) & 1) acc = acc + ld6(cdofs + CS6 * i) * sm.qvel[i];
     if (store) { float* o = out + CS6 * lane; st3(o, acc.a); st3(o + 3, acc.l); o[6] = 0.f; o[7] = 0.f; }
   }
 
@@ -1028,8 +1046,8 @@ struct Sim {
     }
     } else {
       // wide configuration: lane b sums the dofs that move body b, lane i the dofs summed before dof i (mask-guided loops)
-      masked_dof_sum(sm.cdof, lane < SM_NB && lane < nb ? (unsigned)sm.bdofs[lane] : 0u, lane < SM_NB, sm.u.v.cvel);
-      masked_dof_sum(sm.cdof, lane < nv ? (unsigned)sm.dmask_cvel[lane] : 0u, lane < NV16, sm.u.v.cvb);
+      masked_dof_sum(sm.cdof, lane < SM_NB && lane < nb ? sm.bdofs[lane] : (dmask_t)0, lane < SM_NB, sm.u.v.cvel);
+      masked_dof_sum(sm.cdof, lane < nv ? sm.dmask_cvel[lane] : (dmask_t)0, lane < NV16, sm.u.v.cvb);
     }
     SYNC();
     if (lane < NV16) {
@@ -1055,8 +1073,8 @@ struct Sim {
     } else {
       // cacc aliases cvb/cdd: every lane finishes its sum in registers before any lane stores
       S6 ca = {v3(0, 0, 0), v3(0, 0, 0)};
-      const unsigned mk = lane < SM_NB && lane < nb ? (unsigned)sm.bdofs[lane] : 0u;
-      for (int i = 0; i < nv; i++) if ((mk >> i) & 1u) ca = ca + ld6(sm.u.v.cdd + CS6 * i) * sm.qvel[i];
+      const dmask_t mk = lane < SM_NB && lane < nb ? sm.bdofs[lane] : (dmask_t)0;
+      for (int i = 0; i < nv; i++) if ((mk >> i) & 1) ca = ca + ld6(sm.u.v.cdd + CS6 * i) * sm.qvel[i];
       SYNC();
       if (lane < SM_NB) { float* o = sm.u.v.cacc + CS6 * lane; st3(o, ca.a); st3(o + 3, ca.l); }
     }
@@ -1586,22 +1604,46 @@ struct Sim {
   // Row list: (1) friction-loss dofs, (2) joint limits (lower side first), (3) contacts in detection order.
   // The lanes that own the source objects (dof / joint / contact) publish a row descriptor and the row scalars; then lane r
   // builds Jacobian row r in registers, writes it once to LDS (MFMA operand) and finishes aref with its own J.qvel.
+  // length of fixed tendon t = sum coef_w * q_w  (uniform or per-lane t; the tables are global, at most four joints per tendon)
+  __device__ __forceinline__ float tendon_length(int t) const {
+    const int adr = IT(IO_tendon_adr, t), num = IT(IO_tendon_num, t);
+    float len = 0.f;
+    for (int w = 0; w < num; w++) len = fmaf(FP(FO_wrap_prm, adr + w), sm.qpos[IT(IO_wrap_qadr, adr + w)], len);
+    return len;
+  }
+
   __device__ __forceinline__ void make_constraint() {
     const LaneConst K = fetchK();
     const int nv = m.nv;
     int nefc = 0;
     const bool isdof = lane < nv;
     const int jt = (K.dinfo >> 26) & 15, qa = (K.dinfo >> 10) & 255;
+    // (0) equality/tendon rows come first (MuJoCo row order: equality, friction loss, limits, contacts): lane e owns constraint e;
+    //     residual = (length - length0) - polycoef[0] of a fixed tendon, always active
+    if (TENDONS && m.neq) {
+      if (lane < m.neq) {
+        const int t = IT(IO_eq_tendon, lane);
+        const float pos = tendon_length(t) - FP(FO_tendon_len0, t) - FP(FO_eq_data0, lane);
+        const float solref[2] = {FP(FO_eq_solref, 2 * lane), FP(FO_eq_solref, 2 * lane + 1)};
+        float solimp[5];
+        for (int k = 0; k < 5; k++) solimp[k] = FP(FO_eq_solimp, 5 * lane + k);
+        float R, Bd, Kt;
+        row_scalars(pos, 0.f, solref, solimp, FP(FO_tendon_invw, t), R, Bd, Kt);
+        sm.e_desc[lane] = C_EQUALITY | (t << 4);
+        sm.e_R[lane] = R; sm.e_B[lane] = Bd; sm.e_aref[lane] = Kt;
+      }
+      nefc += m.neq;
+    }
     // (1) friction loss
     {
       const bool act = isdof && sm.fricFl[lane] > 0.f;
       const u64 mk = __ballot(act);
       if (act) {
         const int r = nefc + __popcll(mk & lanemask_lt(lane));
-        sm.e_desc[r] = C_FRICTION_DOF | (lane << 4);
-        sm.e_R[r] = sm.fricR[lane]; sm.e_B[r] = sm.fricB[lane]; sm.e_aref[r] = 0.f;
+        if (r < 64) { sm.e_desc[r] = C_FRICTION_DOF | (lane << 4); sm.e_R[r] = sm.fricR[lane]; sm.e_B[r] = sm.fricB[lane]; sm.e_aref[r] = 0.f; }
       }
       nefc += __popcll(mk);
+      if (nefc > 64) nefc = 64;   // one lane per row: rows beyond 64 are dropped (never reached by the BASELINE models)
     }
     // (2) joint limits: dof lane i owns its hinge / slide joint; lower side before upper side
     {
@@ -1616,17 +1658,44 @@ struct Sim {
         const int r = nefc + before;
         float R, Bd, Kt;
         row_scalars(dlo, K.jmargin, solref, solimp, K.dinvw, R, Bd, Kt);
-        sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (0 << 12);
-        sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt;
+        if (r < 64) { sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (0 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
       }
       if (ahi) {
         const int r = nefc + before + (alo ? 1 : 0);
         float R, Bd, Kt;
         row_scalars(dhi, K.jmargin, solref, solimp, K.dinvw, R, Bd, Kt);
-        sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (1 << 12);
-        sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt;
+        if (r < 64) { sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (1 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
       }
       nefc += __popcll(mlo) + __popcll(mhi);
+      if (nefc > 64) nefc = 64;
+    }
+    // (2b) limits on fixed-tendon lengths: lane t owns tendon t, lower side before upper side
+    if (TENDONS && m.ntendon) {
+      const int tl = lane < m.ntendon ? lane : 0;
+      const bool lim = lane < m.ntendon && IT(IO_tendon_limited, tl);
+      const float len = lim ? tendon_length(tl) : 0.f, margin = FP(FO_tendon_margin, tl);
+      const float dlo = len - FP(FO_tendon_range, 2 * tl), dhi = FP(FO_tendon_range, 2 * tl + 1) - len;
+      const bool alo = lim && dlo < margin, ahi = lim && dhi < margin;
+      const u64 mlo = __ballot(alo), mhi = __ballot(ahi);
+      const int before = __popcll(mlo & lanemask_lt(lane)) + __popcll(mhi & lanemask_lt(lane));
+      const float solref[2] = {FP(FO_tendon_solref, 2 * tl), FP(FO_tendon_solref, 2 * tl + 1)};
+      float solimp[5];
+      for (int k = 0; k < 5; k++) solimp[k] = FP(FO_tendon_solimp, 5 * tl + k);
+      const float invw = FP(FO_tendon_invw, tl);
+      if (alo) {
+        const int r = nefc + before;
+        float R, Bd, Kt;
+        row_scalars(dlo, margin, solref, solimp, invw, R, Bd, Kt);
+        if (r < 64) { sm.e_desc[r] = C_LIMIT_TENDON | (lane << 4) | (0 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
+      }
+      if (ahi) {
+        const int r = nefc + before + (alo ? 1 : 0);
+        float R, Bd, Kt;
+        row_scalars(dhi, margin, solref, solimp, invw, R, Bd, Kt);
+        if (r < 64) { sm.e_desc[r] = C_LIMIT_TENDON | (lane << 4) | (1 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
+      }
+      nefc += __popcll(mlo) + __popcll(mhi);
+      if (nefc > 64) nefc = 64;
     }
     // (3) contacts: lane c owns contact c; exclusive scan of the active dimensions gives the first row of each block
     {
@@ -1686,11 +1755,21 @@ struct Sim {
         const float sg = kk ? -1.f : 1.f;  // lower limit: +dq increases the distance; upper: decreases it
 #pragma unroll
         for (int k = 0; k < NV16; k++) Jr[k] = k == id ? sg : 0.f;
+      } else if (TENDONS && valid && (type == C_EQUALITY || type == C_LIMIT_TENDON)) {
+        // row of a fixed tendon: its coefficients on the dofs of its (at most four) joints; an upper limit takes the negative row
+        const float sg = (type == C_LIMIT_TENDON && kk) ? -1.f : 1.f;
+        const int adr = IT(IO_tendon_adr, id), num = IT(IO_tendon_num, id);
+        int wd[4];
+        float wc[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) { wd[w] = w < num ? IT(IO_wrap_dof, adr + w) : -1; wc[w] = w < num ? sg * FP(FO_wrap_prm, adr + w) : 0.f; }
+#pragma unroll
+        for (int k = 0; k < NV16; k++) Jr[k] = (wd[0] == k ? wc[0] : 0.f) + (wd[1] == k ? wc[1] : 0.f) + (wd[2] == k ? wc[2] : 0.f) + (wd[3] == k ? wc[3] : 0.f);
       } else if (valid) {
         const int c = id;
         const int g1 = sm.cg1[c], g2 = sm.cg2[c];
         const int b1 = sm.gbody[g1], b2 = sm.gbody[g2];
-        const unsigned d1 = (unsigned)sm.bdofs[b1], d2 = (unsigned)sm.bdofs[b2];
+        const dmask_t d1 = sm.bdofs[b1], d2 = sm.bdofs[b2];
         const V3 pos = ld3(sm.cpos + 3 * c);
         const V3 ax = ld3(sm.cframe + 9 * c + 3 * (kk < 3 ? kk : kk - 3));
         const V3 o1 = pos - ld3(sm.rootcom + 3 * sm.broot[b1]), o2 = pos - ld3(sm.rootcom + 3 * sm.broot[b2]);
@@ -1699,7 +1778,7 @@ struct Sim {
 #pragma unroll
         for (int k = 0; k < NV16; k++) {
           const S6 cd = ld6(sm.cdof + CS6 * k);
-          const float s1 = (float)((d1 >> k) & 1u), s2 = (float)((d2 >> k) & 1u);
+          const float s1 = (float)((d1 >> k) & 1), s2 = (float)((d2 >> k) & 1);
           const float dl = dot(ax, cd.l), da = dot(ax, cd.a);
           const float v1 = lin ? dl + dot(t1, cd.a) : da, v2 = lin ? dl + dot(t2, cd.a) : da;
           Jr[k] = s2 * v2 - s1 * v1;
@@ -2098,6 +2177,8 @@ struct Sim {
       if (x <= -rw.R * rw.fl) { state = ST_LINEARNEG; force = rw.fl; cost = rw.fl * (-0.5f * rw.R * rw.fl - x); }
       else if (x >= rw.R * rw.fl) { state = ST_LINEARPOS; force = -rw.fl; cost = rw.fl * (-0.5f * rw.R * rw.fl + x); }
       else { state = ST_QUADRATIC; force = -rw.D * x; cost = 0.5f * rw.D * x * x; }
+    } else if (TENDONS && rw.type == C_EQUALITY) {
+      state = ST_QUADRATIC; force = -rw.D * x; cost = 0.5f * rw.D * x * x;
     } else if (!rw.ell) {
       if (x < 0) { state = ST_QUADRATIC; force = -rw.D * x; cost = 0.5f * rw.D * x * x; }
     } else {
@@ -2128,6 +2209,8 @@ struct Sim {
       if (x <= -rw.R * rw.fl) { c = rw.fl * (-0.5f * rw.R * rw.fl - x); c1 = -rw.fl * v; }
       else if (x >= rw.R * rw.fl) { c = rw.fl * (-0.5f * rw.R * rw.fl + x); c1 = rw.fl * v; }
       else { c = 0.5f * rw.D * x * x; c1 = rw.D * x * v; c2 = rw.D * v * v; }
+    } else if (TENDONS && rw.type == C_EQUALITY) {
+      c = 0.5f * rw.D * x * x; c1 = rw.D * x * v; c2 = rw.D * v * v;
     } else if (!rw.ell) {
       if (x < 0) { c = 0.5f * rw.D * x * x; c1 = rw.D * x * v; c2 = rw.D * v * v; }
     } else {
@@ -2787,8 +2870,10 @@ extern "C" int RSIM_SYM(rsim_launch_ctrl_reset)(const DModel* m, const DBatch* b
   hipLaunchKernelGGL((k_ctrl_reset<RSIM_DIMS>), dim3(b->B), dim3(64), 0, stream, *m, *b, mask);
   return (int)hipGetLastError();
 }
+// {nbody, njnt, nv, ncgeom, nsite, ncon, nefc, npair, articulated trees, tendon / equality rows (0 / 1)}
 extern "C" int RSIM_SYM(rsim_limits)(int* lim) {
   const int dims[8] = {RSIM_DIMS};
   for (int i = 0; i < 8; i++) lim[i] = dims[i];
+  lim[8] = Smem0::NROOT_; lim[9] = Smem0::TENDONS_ ? 1 : 0;
   return 0;
 }

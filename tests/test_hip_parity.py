@@ -320,6 +320,65 @@ def test_peg_in_hole_observation_and_reward_epilogue_matches_reference_env():
         assert hb.get("success")[0] == 0
 
 
+def test_tendon_equality_and_limit_rows_on_the_small_configuration():
+    """Fixed-tendon coupling + tendon limits (tests/golden/coupled_fingers.xml) on kernel configuration 0: step-by-step against the oracle."""
+    import os
+    from robosuite_amd import mjcf
+    from tests.util import GOLD
+    flat = mjcf.compile_mjcf(open(os.path.join(GOLD, "coupled_fingers.xml")).read())
+    om, od, _ = make_oracle(flat)
+    hm, hb = make_hip(flat, None, B=2)
+    od.forward()
+    hb.set("qpos", flat.qpos0[None].repeat(2, 0)); hb.set("qvel", 0); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0); hb.forward()
+    assert hb.get("nefc")[0] == od.nefc == 1
+    ctrl = np.array([0.8, 0.5])
+    for t in range(900):
+        od.ctrl[:] = ctrl; od.step()
+        hb.set("ctrl", ctrl[None].repeat(2, 0)); hb.step()
+        if t % 100 == 99:
+            assert np.abs(hb.get("qpos")[0] - od.qpos).max() < 2e-3 and hb.get("nefc")[0] == od.nefc, t
+    assert od.nefc >= 2 and abs(2 * hb.get("qpos")[0][2] - 0.3) < 0.03          # resting on the tendon's upper length limit
+    assert abs(hb.get("qpos")[0][0] + 1.5 * hb.get("qpos")[0][1]) < 5e-3        # coupling held
+
+
+def test_pickplace_iiwa_robotiq_model_on_the_64_dof_configuration():
+    """BASELINE configs[4] model (nv 37, 36 bodies, 41 colliding geoms, 622 candidate pairs, 4 tendon equality rows): forward quantities against the
+    oracle along the recorded trajectory, then the fused control step (OSC_POSE on the IIWA arm + Robotiq GRIP) against the oracle loop and
+    the states the reference env loop recorded."""
+    g, cfg, flat = load_golden("seed0_full", "pickplace_iiwa")
+    nq = flat.nq
+    om, od, oc = make_oracle(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=2)
+    assert hm.kernel_config()[0] == 3
+    for i in (0, 5, 19):
+        s = g["states"][i]
+        od.qpos[:] = s[1:1 + nq]; od.qvel[:] = s[1 + nq:]; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0; od.forward()
+        hb.set("qpos", s[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0); hb.forward()
+        assert np.abs(hb.get("xpos")[0].ravel() - od.xpos).max() < 3e-6
+        assert rel(hb.get("qM")[0].ravel(), od.qM) < 1e-5
+        assert rel(hb.get("qfrc_bias")[0], od.qfrc_bias) < 1e-5
+        assert hb.get("ncon")[0] == od.ncon and hb.get("nefc")[0] == od.nefc, i
+        # the Robotiq finger links have 5e-5 kg m^2 of inertia and no armature: a 1e-3 N m residual of the fp32 Newton solve (1e-5 of the arm
+        # torques) is 20 rad/s^2 on such a dof.  Arm and object accelerations to the usual tolerance, finger dofs to 5 % of the largest.
+        dacc = np.abs(hb.get("qacc")[0] - od.qacc)
+        fd = np.zeros(flat.nv, dtype=bool); fd[7:13] = True
+        assert dacc[~fd].max() < 1e-3 * max(1.0, np.abs(od.qacc).max()) and dacc[fd].max() < 5e-2 * max(1.0, np.abs(od.qacc).max()), i
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0; od.forward(); oc.reset(od)
+    hb.set("qpos", s0[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    fingers = np.zeros(nq, dtype=bool); fingers[7:13] = True
+    arm = np.zeros(nq, dtype=bool); arm[:7] = True
+    for t in range(len(g["actions"])):
+        hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+        oc.env_step(od, g["actions"][t], 25)
+        dq = np.abs(hb.get("qpos")[0] - od.qpos)
+        # arm and objects to the usual tolerance; the undamped 5e-5 kg m^2 finger links under kp = 20 actuators amplify rounding (see the CPU test)
+        # ... and the four objects rest on single MPR contact points (MuJoCo's convex-convex default), where they rock at rounding level
+        assert dq[arm].max() < 5e-4 and dq[fingers].max() < 5e-2 and dq[~(arm | fingers)].max() < 5e-3, t
+    assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[1])
+
+
 def test_replay_is_bitwise_deterministic():
     """The reference's only numeric assert on sim state is bitwise replay equality (test_action_playback.py:46-68)."""
     g, cfg, flat = load_golden("seed1_full")
