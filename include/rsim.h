@@ -72,6 +72,12 @@ typedef struct rsim_ctrl_desc {
  *   RSIM_OBS_BODY_MINUS_BODY: body a minus body (b >> 2), component b & 3  (stack.py:432-438 cubeA_to_cubeB = cubeB_pos - cubeA_pos)
  *   RSIM_OBS_PEG_COS / _T / _D: `angle`, `t`, `d` of TwoArmPegInHole._compute_orientation (two_arm_peg_in_hole.py:462-486, 523-560) between
  *                             object_body (peg) and object2_body (hole)
+ *   RSIM_OBS_REL_POS / REL_QUAT: `{obj}_to_{arm}eef_pos / _quat` of PickPlace (manipulation_env.py:244-329, pick_place.py:639-668): pose of object a
+ *                             (index into objects[]) in the gripper frame {eef_pos = grip_site, eef_quat = eef_body}, component b.  As in the
+ *                             reference, the OBJECT pose is the one sampled at the previous control step (the relative sensors run before the
+ *                             object's own pos / quat sensors and read them from the observation cache) while the gripper pose is current; after
+ *                             rsim_observe (reset) they are zero.  pos_slot[a] = offset of `{obj}_pos` (3 floats, followed by `{obj}_quat` xyzw)
+ *                             in the observation record.
  * Sampling instants follow the reference exactly: after `reset()` every Observable samples on the LAST substep of a control step,
  * i.e. positions/orientations come from that substep's step1 kinematics, qpos/qvel from after its step2 (utils/observables.py:214-259).
  * task 1: reward = Lift.reward (environments/manipulation/lift.py:224-273), success = Lift._check_success (lift.py:433-444),
@@ -80,14 +86,17 @@ typedef struct rsim_ctrl_desc {
  * (reach + grasp, lift + align, stack = lifted, released and cubeA touching cubeB via check_contact, utils/sim_utils.py:8-40),
  * success = Stack._check_success (stack.py:476-484: r_stack > 0); scaled by reward_scale / 2.0.
  * task 3: reward = TwoArmPegInHole.reward (two_arm_peg_in_hole.py:240-290) with object = peg, object2 = hole: success (d < 0.06, -0.12 <= t <= 0.14,
- * cos > 0.95; :513-521) + reaching + perpendicular / parallel distance + alignment terms, scaled by reward_scale / 5.0. */
+ * cos > 0.95; :513-521) + reaching + perpendicular / parallel distance + alignment terms, scaled by reward_scale / 5.0.
+ * task 4: reward = PickPlace.reward / staged_rewards / _check_success (pick_place.py:274-429, 737-762) over nobj objects (all-objects mode): objects
+ * in their bins + max(reach, grasp, lift, hover) over the others, scaled by reward_scale / 4.0; success = every object in its bin. */
 enum { RSIM_OBS_QPOS = 0, RSIM_OBS_COS, RSIM_OBS_SIN, RSIM_OBS_QVEL, RSIM_OBS_QACC, RSIM_OBS_SITE_POS, RSIM_OBS_BODY_QUAT, RSIM_OBS_SITE_QUAT,
-       RSIM_OBS_BODY_POS, RSIM_OBS_BODY_MINUS_SITE, RSIM_OBS_BODY_MINUS_BODY, RSIM_OBS_PEG_COS, RSIM_OBS_PEG_T, RSIM_OBS_PEG_D };
+       RSIM_OBS_BODY_POS, RSIM_OBS_BODY_MINUS_SITE, RSIM_OBS_BODY_MINUS_BODY, RSIM_OBS_PEG_COS, RSIM_OBS_PEG_T, RSIM_OBS_PEG_D,
+       RSIM_OBS_REL_POS, RSIM_OBS_REL_QUAT };
 #define RSIM_OBS_MAX 128
 typedef struct rsim_task_desc {
   int32_t nobs;                       /* floats in the observation record (<= RSIM_OBS_MAX) */
   int32_t obs_prog[RSIM_OBS_MAX * 3]; /* (kind, a, b) per output float */
-  int32_t task;                       /* 0 = none, 1 = Lift, 2 = Stack, 3 = TwoArmPegInHole */
+  int32_t task;                       /* 0 = none, 1 = Lift, 2 = Stack, 3 = TwoArmPegInHole, 4 = PickPlace */
   int32_t object_body;                /* cube root body */
   int32_t grip_site;                  /* gripper.important_sites["grip_site"] */
   float table_height;                 /* model.mujoco_arena.table_offset[2] */
@@ -97,6 +106,14 @@ typedef struct rsim_task_desc {
   uint64_t left_pad_geoms, right_pad_geoms, object_geoms; /* bit g set: colliding-geom index g belongs to the group (_check_grasp) */
   int32_t object2_body;               /* Stack: cubeB root body */
   uint64_t object2_geoms;             /* Stack: cubeB contact geoms */
+  /* PickPlace (task 4) */
+  int32_t nobj;                       /* objects (<= 4), bin i is the target of object i */
+  int32_t obj_body[4];                /* object root bodies */
+  uint64_t obj_geoms[4];              /* contact geoms per object (colliding-geom bit masks) */
+  int32_t pos_slot[4];                /* offset of `{obj}_pos` in the observation record (see RSIM_OBS_REL_POS) */
+  int32_t eef_body;                   /* body whose quaternion is `{arm}eef_quat` */
+  float bin2_pos[3], bin_size[2];     /* pick_place.py:188-199 */
+  float bin_target[8];                /* target_bin_placements[i][0..1] (pick_place.py:570-583) */
 } rsim_task_desc;
 
 /* state / derived arrays addressable through rsim_get_array / rsim_set_array / rsim_device_ptr */

@@ -26,7 +26,7 @@ CON_REC = 24
 CSTATE = 32
 OBS_MAX = 128
 OBS_KINDS = {"qpos": 0, "cos": 1, "sin": 2, "qvel": 3, "qacc": 4, "site_pos": 5, "body_quat": 6, "site_quat": 7, "body_pos": 8, "body_minus_site": 9, "body_minus_body": 10,
-             "peg_cos": 11, "peg_t": 12, "peg_d": 13}
+             "peg_cos": 11, "peg_t": 12, "peg_d": 13, "rel_pos": 14, "rel_quat": 15}
 
 
 class RsimError(RuntimeError):
@@ -70,7 +70,8 @@ class TaskDesc(C.Structure):
     _fields_ = [("nobs", C.c_int32), ("obs_prog", C.c_int32 * (OBS_MAX * 3)), ("task", C.c_int32), ("object_body", C.c_int32), ("grip_site", C.c_int32),
                 ("table_height", C.c_float), ("lift_margin", C.c_float), ("reward_scale", C.c_float), ("reward_shaping", C.c_int32),
                 ("left_pad_geoms", C.c_uint64), ("right_pad_geoms", C.c_uint64), ("object_geoms", C.c_uint64), ("object2_body", C.c_int32),
-                ("object2_geoms", C.c_uint64)]
+                ("object2_geoms", C.c_uint64), ("nobj", C.c_int32), ("obj_body", C.c_int32 * 4), ("obj_geoms", C.c_uint64 * 4), ("pos_slot", C.c_int32 * 4),
+                ("eef_body", C.c_int32), ("bin2_pos", C.c_float * 3), ("bin_size", C.c_float * 2), ("bin_target", C.c_float * 8)]
 
 
 class DrDesc(C.Structure):
@@ -225,7 +226,7 @@ class HipModel:
         d.nobs = len(obs)
         for i, (kind, a, b) in enumerate(obs):
             d.obs_prog[3 * i], d.obs_prog[3 * i + 1], d.obs_prog[3 * i + 2] = OBS_KINDS[kind] if isinstance(kind, str) else int(kind), int(a), int(b)
-        d.task = {"none": 0, "lift": 1, "stack": 2, "peg_in_hole": 3}[task.get("task", "none")]
+        d.task = {"none": 0, "lift": 1, "stack": 2, "peg_in_hole": 3, "pick_place": 4}[task.get("task", "none")]
         d.object2_body = int(task.get("object2_body", 0))
         d.object_body, d.grip_site = int(task.get("object_body", 0)), int(task.get("grip_site", 0))
         d.table_height, d.lift_margin = float(task.get("table_height", 0.0)), float(task.get("lift_margin", 0.04))
@@ -241,6 +242,15 @@ class HipModel:
 
         d.left_pad_geoms, d.right_pad_geoms, d.object_geoms = mask(task.get("left_pad_geoms", [])), mask(task.get("right_pad_geoms", [])), mask(task.get("object_geoms", []))
         d.object2_geoms = mask(task.get("object2_geoms", []))
+        if d.task == 4:
+            d.nobj, d.eef_body = len(task["obj_body"]), int(task["eef_body"])
+            for i in range(d.nobj):
+                d.obj_body[i], d.pos_slot[i], d.obj_geoms[i] = int(task["obj_body"][i]), int(task["pos_slot"][i]), mask(task["obj_geoms"][i])
+            for i in range(3):
+                d.bin2_pos[i] = task["bin2_pos"][i]
+            d.bin_size[0], d.bin_size[1] = task["bin_size"][0], task["bin_size"][1]
+            for i in range(d.nobj):
+                d.bin_target[2 * i], d.bin_target[2 * i + 1] = task["bin_target"][i][0], task["bin_target"][i][1]
         _chk(self._L.rsim_model_set_task(self.ptr, C.byref(d)))
         self.task_cfg = task
         self.nobs = len(obs)

@@ -544,14 +544,21 @@ extern "C" int rsim_model_set_task(rsim_model* m, const rsim_task_desc* d) {
       case RSIM_OBS_BODY_MINUS_SITE: ok = a >= 0 && a < m->nbody && (b2 & 3) < 3 && (b2 >> 2) >= 0 && (b2 >> 2) < m->nsite; break;
       case RSIM_OBS_BODY_MINUS_BODY: ok = a >= 0 && a < m->nbody && (b2 & 3) < 3 && (b2 >> 2) >= 0 && (b2 >> 2) < m->nbody; break;
       case RSIM_OBS_PEG_COS: case RSIM_OBS_PEG_T: case RSIM_OBS_PEG_D: ok = d->task == 3; break;
+      case RSIM_OBS_REL_POS: ok = d->task == 4 && a >= 0 && a < d->nobj && b2 >= 0 && b2 < 3; break;
+      case RSIM_OBS_REL_QUAT: ok = d->task == 4 && a >= 0 && a < d->nobj && b2 >= 0 && b2 < 4; break;
       default: ok = false;
     }
     if (!ok) return fail("task: observation entry %d (kind %d, a %d, b %d) is invalid for this model", i, kind, a, b2);
   }
-  if (d->task < 0 || d->task > 3) return fail("task: unknown task id %d", d->task);
-  if (d->task >= 1 && (d->object_body < 0 || d->object_body >= m->nbody)) return fail("task: bad object body id");
+  if (d->task < 0 || d->task > 4) return fail("task: unknown task id %d", d->task);
+  if (d->task == 4) {
+    if (d->nobj < 1 || d->nobj > 4 || d->eef_body < 0 || d->eef_body >= m->nbody || d->grip_site < 0 || d->grip_site >= m->nsite) return fail("task: bad PickPlace description");
+    for (int i = 0; i < d->nobj; i++)
+      if (d->obj_body[i] < 0 || d->obj_body[i] >= m->nbody || d->pos_slot[i] < 0 || d->pos_slot[i] + 7 > d->nobs) return fail("task: bad PickPlace object %d", i);
+  }
+  if (d->task >= 1 && d->task <= 3 && (d->object_body < 0 || d->object_body >= m->nbody)) return fail("task: bad object body id");
   if ((d->task == 1 || d->task == 2) && (d->grip_site < 0 || d->grip_site >= m->nsite)) return fail("task: bad grip site id");
-  if (d->task >= 2 && (d->object2_body < 0 || d->object2_body >= m->nbody)) return fail("task: bad second object body id");
+  if ((d->task == 2 || d->task == 3) && (d->object2_body < 0 || d->object2_body >= m->nbody)) return fail("task: bad second object body id");
   m->task = *d;
   m->has_task = 1;
   return 0;
@@ -655,6 +662,11 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
     dm.task.reward_shaping = t.reward_shaping; dm.task.table_height = t.table_height; dm.task.lift_margin = t.lift_margin; dm.task.reward_scale = t.reward_scale;
     dm.task.left_pad = t.left_pad_geoms; dm.task.right_pad = t.right_pad_geoms; dm.task.object_geoms = t.object_geoms; dm.task.obs_prog = b->d_obsprog;
     dm.task.object2_body = t.object2_body; dm.task.object2_geoms = t.object2_geoms;
+    dm.task.nobj = t.nobj; dm.task.eef_body = t.eef_body;
+    for (int i = 0; i < 4; i++) { dm.task.obj_body[i] = t.obj_body[i]; dm.task.pos_slot[i] = t.pos_slot[i]; dm.task.obj_geoms[i] = t.obj_geoms[i]; }
+    for (int i = 0; i < 3; i++) dm.task.bin2_pos[i] = t.bin2_pos[i];
+    for (int i = 0; i < 2; i++) dm.task.bin_size[i] = t.bin_size[i];
+    for (int i = 0; i < 8; i++) dm.task.bin_target[i] = t.bin_target[i];
   }
   DBatch& db = b->db;
   db.B = B;

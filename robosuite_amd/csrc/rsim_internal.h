@@ -108,6 +108,9 @@ struct DTask {
   float table_height, lift_margin, reward_scale;
   unsigned long long left_pad, right_pad, object_geoms, object2_geoms;
   int object2_body;
+  int nobj, obj_body[4], pos_slot[4], eef_body;
+  unsigned long long obj_geoms[4];
+  float bin2_pos[3], bin_size[2], bin_target[8];
   const int* obs_prog;   // device [nobs][3]
 };
 

@@ -83,6 +83,7 @@ __device__ __forceinline__ float wave_max(float x) {
 #undef RSIM_MX
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
+__device__ __forceinline__ float wave_min_f(float x) { return -wave_max(-x); }
 __device__ __forceinline__ int wave_min_i(int x) {
 #define RSIM_MN(C) { int t_ = dpp_keep_i<C>(x); x = t_ < x ? t_ : x; }
   RSIM_MN(0x111) RSIM_MN(0x112) RSIM_MN(0x114) RSIM_MN(0x118) RSIM_MN(0x142) RSIM_MN(0x143)
@@ -2462,11 +2463,17 @@ struct Sim {
     const V3 hn = col(Rh, 2);
     cs = fabsf(dot(hn, v) / norm(hn) / vn);
   }
-  __device__ __forceinline__ void obs_reward(float* __restrict__ obs, float* __restrict__ reward, int* __restrict__ success) {
+  // `reset_obs`: the record MujocoEnv.reset returns (rsim_observe), where the relative-pose sensors of PickPlace find an empty observation cache
+  __device__ __forceinline__ void obs_reward(float* obs, float* __restrict__ reward, int* __restrict__ success, bool reset_obs) {
     const DTask& t = m.task;
     gci prog = (gci)t.obs_prog;
     float peg_t = 0.f, peg_d = 0.f, peg_c = 0.f;
     if (t.task == 3) peg_orientation(t.object_body, t.object2_body, peg_t, peg_d, peg_c);
+    float* prev = sm.u.b.poly;   // PickPlace: object poses as sampled at the PREVIOUS control step (still in the record), 7 floats per object
+    if (t.task == 4) {
+      if (lane < 7 * t.nobj) prev[lane] = obs[seli(t.pos_slot, lane / 7) + lane % 7];   // select chain: kernel-argument arrays are never indexed dynamically
+      SYNC();
+    }
     for (int i = lane; i < t.nobs; i += 64) {
       const int kind = prog[3 * i], a = prog[3 * i + 1], b2 = prog[3 * i + 2];
       float v = 0.f;
@@ -2479,6 +2486,22 @@ struct Sim {
       else if (kind == RSIM_OBS_BODY_POS) v = sm.xpos[3 * a + b2];
       else if (kind == RSIM_OBS_BODY_MINUS_SITE) v = sm.xpos[3 * a + (b2 & 3)] - sm.spos[3 * (b2 >> 2) + (b2 & 3)];
       else if (kind == RSIM_OBS_BODY_MINUS_BODY) v = sm.xpos[3 * a + (b2 & 3)] - sm.xpos[3 * (b2 >> 2) + (b2 & 3)];
+      else if (kind == RSIM_OBS_REL_POS || kind == RSIM_OBS_REL_QUAT) {
+        // world_pose_in_gripper @ obj_pose (manipulation_env.py:244-303): gripper = {grip site position, eef body quaternion} now, object = cached
+        if (!reset_obs) {
+          const float* o = prev + 7 * a;
+          const Q4 qo = {o[6], o[3], o[4], o[5]};                       // record holds xyzw
+          const M3 Re = q2m(ldq(sm.xquat + 4 * t.eef_body)), Ro = q2m(qnorm(qo));
+          if (kind == RSIM_OBS_REL_POS) {
+            const V3 r = mtv(Re, v3(o[0], o[1], o[2]) - ld3(sm.spos + 3 * t.grip_site));
+            v = b2 == 0 ? r.x : (b2 == 1 ? r.y : r.z);
+          } else {
+            const M3 Rr = mtm(Re, Ro);
+            const Q4 q = mat2quat_xyzw(Rr.m);
+            v = b2 == 0 ? q.x : (b2 == 1 ? q.y : (b2 == 2 ? q.z : q.w));
+          }
+        }
+      }
       else if (kind == RSIM_OBS_PEG_COS) v = peg_c;
       else if (kind == RSIM_OBS_PEG_T) v = peg_t;
       else if (kind == RSIM_OBS_PEG_D) v = peg_d;
@@ -2486,7 +2509,49 @@ struct Sim {
       else if (kind == RSIM_OBS_SITE_QUAT) { const Q4 q = mat2quat_xyzw(sm.smat + 9 * a); v = b2 == 0 ? q.x : (b2 == 1 ? q.y : (b2 == 2 ? q.z : q.w)); }
       obs[i] = v;
     }
-    if (t.task == 3) {
+    if (t.task == 4) {
+      // PickPlace._check_success + staged_rewards (pick_place.py:274-429, 737-762), all-objects mode.  Lane i = object i for the per-object
+      // terms; the contact scan for the grasp runs over the contact lanes against the union of the active objects' geoms.
+      const int i = lane < t.nobj ? lane : 0;
+      const V3 op = ld3(sm.xpos + 3 * seli(t.obj_body, i)), grip = ld3(sm.spos + 3 * t.grip_site);
+      const float dist = norm(grip - op);
+      float bxl = t.bin2_pos[0], byl = t.bin2_pos[1];
+      if (i == 0 || i == 2) bxl -= t.bin_size[0] * 0.5f;
+      if (i < 2) byl -= t.bin_size[1] * 0.5f;
+      const bool inside = bxl < op.x && op.x < bxl + t.bin_size[0] * 0.5f && byl < op.y && op.y < byl + t.bin_size[1] * 0.5f && t.bin2_pos[2] < op.z && op.z < t.bin2_pos[2] + 0.1f;
+      const bool in_bin = lane < t.nobj && inside && (1.f - tanhf(10.f * dist)) < 0.6f;
+      const bool activeo = lane < t.nobj && !in_bin;
+      const u64 act_mask = __ballot(activeo), in_mask = __ballot(in_bin);
+      u64 ageoms = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) if ((act_mask >> k) & 1ull) ageoms |= t.obj_geoms[k];
+      bool lc = false, rc = false;
+      if (lane < sm.ncon) {
+        const u64 b1 = 1ull << sm.cg1[lane], b2 = 1ull << sm.cg2[lane];
+        const bool o1 = (ageoms & b1) != 0, o2 = (ageoms & b2) != 0;
+        lc = (o1 && (t.left_pad & b2)) || (o2 && (t.left_pad & b1));
+        rc = (o1 && (t.right_pad & b2)) || (o2 && (t.right_pad & b1));
+      }
+      const bool grasp = __ballot(lc) != 0 && __ballot(rc) != 0;
+      const float BIG = 3.0e38f;
+      const float dmin = wave_min_f(activeo ? dist : BIG);
+      const float zd = fmaxf(t.bin2_pos[2] + 0.25f - op.z, 0.f), zmin = wave_min_f(activeo ? zd : BIG);
+      const float r_reach = act_mask ? (1.f - tanhf(10.f * dmin)) * 0.1f : 0.f;
+      const float r_grasp = grasp ? 0.35f : 0.f;
+      const float r_lift = (act_mask && grasp) ? 0.35f + (1.f - tanhf(15.f * zmin)) * 0.15f : 0.f;
+      const float tx = sel(t.bin_target, 2 * i), ty = sel(t.bin_target, 2 * i + 1);
+      const bool above = fabsf(op.x - tx) < t.bin_size[0] * 0.25f && fabsf(op.y - ty) < t.bin_size[1] * 0.25f;
+      const float dxy = sqrtf((tx - op.x) * (tx - op.x) + (ty - op.y) * (ty - op.y));
+      const float hov = (above ? 0.5f : r_lift) + (1.f - tanhf(10.f * dxy)) * 0.2f;
+      const float r_hover = act_mask ? wave_max(activeo ? hov : -BIG) : 0.f;
+      if (lane == 0) {
+        const int nin = __popcll(in_mask);
+        float r = (float)nin;
+        if (t.reward_shaping) r += fmaxf(fmaxf(r_reach, r_grasp), fmaxf(r_lift, r_hover));
+        *reward = r * t.reward_scale / 4.0f;
+        *success = nin == t.nobj ? 1 : 0;
+      }
+    } else if (t.task == 3) {
       if (lane == 0) {
         const bool succ = peg_d < 0.06f && peg_t >= -0.12f && peg_t <= 0.14f && peg_c > 0.95f;
         float r = succ ? 1.f : 0.f;
@@ -2625,7 +2690,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
     }
     sim.pf.count(RP_N_SUB, 1);
   }
-  if ((flags & RF_OBS) && m.task.enabled) sim.obs_reward(b.obs + (size_t)env * m.task.nobs, b.reward + env, b.success + env);
+  if ((flags & RF_OBS) && m.task.enabled) sim.obs_reward(b.obs + (size_t)env * m.task.nobs, b.reward + env, b.success + env, !(flags & RF_CTRL));
   if (flags & RF_EPISODE) {
     // MujocoEnv.step: timestep += 1; done = timestep >= horizon (base.py:508, 532-548); optional on-device reset from the bank
     int st = b.ep_step[env] + 1;
@@ -2642,6 +2707,13 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
       }
       time = 0.f;
       st = 0;
+      if (m.task.enabled && m.task.task == 4 && lane < m.task.nobj) {
+        // PickPlace relative-pose sensors read the object's pose from the observation cache: after reset() that is the reset pose
+        const int qa = IT(IO_jnt_qposadr, IT(IO_body_jntadr, seli(m.task.obj_body, lane)));
+        float* o = b.obs + (size_t)env * m.task.nobs + seli(m.task.pos_slot, lane);
+        const Q4 q = qnorm(ldq(src + qa + 3));
+        o[0] = src[qa]; o[1] = src[qa + 1]; o[2] = src[qa + 2]; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+      }
       if (lane == 0) { b.ep_index[env] = ep; b.needs_reset[env] = 1; }
       SYNC();
     }

@@ -379,6 +379,42 @@ def test_pickplace_iiwa_robotiq_model_on_the_64_dof_configuration():
     assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[1])
 
 
+def test_pickplace_observation_and_reward_epilogue_matches_reference_env():
+    """PickPlace epilogue (task 4) vs what the reference's env.step() returned: per-object relative pose in the gripper frame (with the
+    reference's one-step-stale object pose, manipulation_env.py:286-303), object poses, staged reward."""
+    from robosuite_amd import pick_place
+    from robosuite_amd.backend import HipBatch
+    g, cfg, flat = load_golden("seed0_full", "pickplace_iiwa")
+    nq = flat.nq
+    hm, _ = make_hip(flat, cfg, B=1)
+    hm.set_task(pick_place.pick_place_task(flat, cfg))
+    hb = HipBatch(hm, 2, 0, False)
+    s0 = g["states"][0]
+    hb.set("qpos", s0[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    hb.observe()                                              # the record reset() returns: relative sensors are zero, object poses are cached
+    dims = np.cumsum([0] + cfg["obs_dims"])
+    o0 = hb.get("obs")[0]
+    k = cfg["obs_keys"].index("Milk_to_robot0_eef_pos")
+    assert tuple(hb.get("obs").shape) == (2, dims[-1]) and np.all(o0[dims[k]:dims[k + 2]] == 0) and np.abs(o0[dims[k + 2]:dims[k + 3]]).max() > 0
+    for t in range(len(g["actions"])):
+        hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+        obs, rew = hb.get("obs")[0], hb.get("reward")[0]
+        for k, key in enumerate(cfg["obs_keys"]):
+            ref, got = g["obs"][t][dims[k]:dims[k + 1]], obs[dims[k]:dims[k + 1]]
+            if key.endswith("joint_acc"):
+                tol = 2e-2 * max(1.0, np.abs(ref).max())
+            elif "gripper_q" in key:
+                tol = 5e-2 if key.endswith("qpos") else 3.0   # undamped 5e-5 kg m^2 finger links (see the physics test of this model)
+            else:
+                tol = 5e-3 if (key.endswith("vel") or key[:4] in ("Milk", "Brea", "Cere", "Can_")) else 5e-4
+            if "quat" in key:
+                got = got * np.sign(np.dot(got, ref))
+            assert np.abs(got - ref).max() < tol, (t, key, np.abs(got - ref).max())
+        assert abs(rew - g["rewards"][t]) < 2e-4, t
+        assert hb.get("success")[0] == 0
+
+
 def test_replay_is_bitwise_deterministic():
     """The reference's only numeric assert on sim state is bitwise replay equality (test_action_playback.py:46-68)."""
     g, cfg, flat = load_golden("seed1_full")

@@ -267,6 +267,13 @@ def record_pickplace(seed, n_steps, action_scale, tag):
     mjcf.save_model(flat, os.path.join(GOLD, f"pickplace_iiwa_{tag}.rsim"))
     cfg = controller_cfg(env)
     cfg["grip_sign"] = GRIPPER_SIGNS[type(env.robots[0].gripper["right"]).__name__]
+    # task constants of PickPlace (pick_place.py:188-199, 560-583): object order, bin geometry, the gripper's finger-pad geom groups
+    g = env.robots[0].gripper["right"]
+    cfg["task"] = dict(objects=[o.name for o in env.objects], object_bodies=[o.root_body for o in env.objects],
+                       object_geoms=[list(o.contact_geoms) for o in env.objects], bin2_pos=[float(x) for x in env.bin2_pos],
+                       bin_size=[float(x) for x in env.bin_size], target_bin_placements=[[float(x) for x in r] for r in env.target_bin_placements],
+                       left_pad=list(g.important_geoms["left_fingerpad"]), right_pad=list(g.important_geoms["right_fingerpad"]),
+                       eef_body=env.robots[0].robot_model.eef_name["right"], grip_site=g.important_sites["grip_site"])
     cfg["obs_keys"] = keys
     cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in keys]
     with open(os.path.join(GOLD, f"pickplace_iiwa_{tag}.cfg.json"), "w") as f:
