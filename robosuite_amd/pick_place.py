@@ -33,3 +33,101 @@ def pick_place_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool =
                 obj_geoms=[[geom.index(g) for g in gs] for gs in t["object_geoms"]], bin2_pos=t["bin2_pos"], bin_size=t["bin_size"][:2],
                 bin_target=[r[:2] for r in t["target_bin_placements"]], left_pad_geoms=[geom.index(g) for g in t["left_pad"]],
                 right_pad_geoms=[geom.index(g) for g in t["right_pad"]], reward_scale=reward_scale, reward_shaping=reward_shaping)
+
+
+import numpy as np  # noqa: E402
+
+
+def reset_draws(rng: np.random.Generator, placement: dict):
+    """One hard-reset block of the env generator in the reference's order (pick_place.py:670-700 -> robots/robot.py:247-259,
+    utils/placement_samplers.py:221-309, 383-470): arm noise N(0,1) x 7 x 0.02; CollisionObjectSampler over the objects in list order
+    (x, y uniform inside bin 1 shrunk by the object's horizontal radius, redrawn while it overlaps an already placed object, then a uniform yaw);
+    then one x and one y draw over a zero-width range per visual object (their rotation is fixed)."""
+    arm = np.array(placement["arm_init_qpos"]) + rng.standard_normal(len(placement["arm_init_qpos"])) * 0.02
+    bx, by, bz = placement["bin1_pos"]
+    xh, yh = placement["x_half"], placement["y_half"]
+    placed, out = [], []
+    for o in placement["objects"]:
+        r, bot = o["horizontal_radius"], o["bottom_z"]
+        for _ in range(5000):
+            x = rng.uniform(-xh + r, xh - r) + bx
+            y = rng.uniform(-yh + r, yh - r) + by
+            z = placement["z_offset"] + bz - bot
+            ok = True
+            for (px, py, pz, pr, ptop) in placed:
+                if np.linalg.norm((x - px, y - py)) <= pr + r and z - pz <= ptop - bot:
+                    ok = False
+                    break
+            if ok:
+                yaw = rng.uniform(0.0, 2.0 * np.pi)
+                placed.append((x, y, z, r, o["top_z"]))
+                out.append((np.array([x, y, z]), yaw))
+                break
+        else:
+            raise RuntimeError("Cannot place all objects")
+    for _ in placement["objects"]:        # the four visual twins: x and y over [c, c]
+        rng.uniform(0.0, 0.0); rng.uniform(0.0, 0.0)
+    return dict(arm=arm, objects=out)
+
+
+def initial_qpos(draw, placement: dict, nq: int) -> np.ndarray:
+    q = np.zeros(nq)
+    q[placement["arm_qpos_idx"]] = draw["arm"]
+    q[placement["gripper_qpos_idx"]] = placement["gripper_init_qpos"]
+    for o, (pos, yaw) in zip(placement["objects"], draw["objects"]):
+        a = o["qposadr"]
+        q[a:a + 3] = pos
+        q[a + 3], q[a + 6] = np.cos(yaw / 2.0), np.sin(yaw / 2.0)
+    return q
+
+
+def episode_setup(cfg, nq: int, seed0: int, env_ids, block: int = 0):
+    pl = cfg["task"]["placement"]
+    out = []
+    for i in env_ids:
+        rng = np.random.default_rng(seed0 + int(i))
+        for _ in range(block + 1):
+            d = reset_draws(rng, pl)
+        out.append(initial_qpos(d, pl, nq))
+    return np.array(out)
+
+
+class PickPlaceBatch:
+    """B PickPlace/IIWA+Robotiq140 environments on one GPU (64 x 64 kernel configuration).  `env_ids` are GLOBAL indices."""
+
+    def __init__(self, flat, cfg, env_ids, device: int = 0, seed0: int = 0, horizon: int = 0, bank_episodes: int = 0):
+        from .backend import HipBatch, HipModel
+
+        self.flat, self.cfg = flat, cfg
+        self.env_ids = np.asarray(env_ids, dtype=np.int64)
+        self.B = len(self.env_ids)
+        self.model = HipModel(flat)
+        self.model.set_controller(cfg)
+        self.model.set_task(pick_place_task(flat, cfg))
+        self.batch = HipBatch(self.model, self.B, device, per_env_params=False)
+        self.seed0 = seed0
+        self.reset()
+        if horizon:
+            self.batch.set_episode(horizon)
+        if bank_episodes:
+            qbank = np.stack([episode_setup(cfg, flat.nq, seed0, self.env_ids, ep) for ep in range(bank_episodes)], axis=1).astype(np.float32)
+            self.batch.set_reset_bank(qbank, [], np.zeros((self.B, bank_episodes, 0), dtype=np.float32))
+
+    def reset(self, block: int = 0):
+        qpos = episode_setup(self.cfg, self.flat.nq, self.seed0, self.env_ids, block)
+        b = self.batch
+        b.set("qpos", qpos); b.set("qvel", 0.0); b.set("ctrl", 0.0); b.set("time", 0.0); b.set("qacc_warmstart", 0.0)
+        b.forward(); b.ctrl_reset()
+        self.qpos0 = qpos
+
+    def step(self, actions, n_sub: int = 25):
+        self.batch.control_step(actions, n_sub)
+
+    def obs(self):
+        return self.batch.tensor("obs")
+
+    def reward(self):
+        return self.batch.tensor("reward")
+
+    def success(self):
+        return self.batch.tensor("success")

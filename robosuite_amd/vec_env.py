@@ -1,6 +1,6 @@
 """Vectorised counterpart of `suite.make(env_name, robots=...)` + `GymWrapper` for the tasks the fused kernel carries.
 
-    env = VecEnv("Stack", n_envs=4096, flat=..., cfg=...)       # Lift | Stack | TwoArmPegInHole
+    env = VecEnv("Stack", n_envs=4096, flat=..., cfg=...)       # Lift | Stack | TwoArmPegInHole | PickPlace
     obs = env.reset()                                           # device tensor [n_envs, obs_dim], the reference's per-key record concatenated
     obs, reward, done, info = env.step(actions)                 # actions: CUDA float32 [n_envs, action_dim] in [-1, 1]
     flat = env.flat_obs(obs)                                    # GymWrapper layout (wrappers/gym_wrapper.py:45-163): object-state + robot proprio keys
@@ -14,9 +14,9 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import lift, peg_in_hole, stack
+from . import lift, peg_in_hole, pick_place, stack
 
-TASKS = {"Lift": lift.LiftBatch, "Stack": stack.StackBatch, "TwoArmPegInHole": peg_in_hole.PegBatch}
+TASKS = {"Lift": lift.LiftBatch, "Stack": stack.StackBatch, "TwoArmPegInHole": peg_in_hole.PegBatch, "PickPlace": pick_place.PickPlaceBatch}
 
 
 class VecEnv:

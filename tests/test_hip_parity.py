@@ -585,7 +585,8 @@ def test_vectorised_env_facade():
     assert tuple(info["success"].shape) == (6,)
 
 
-@pytest.mark.parametrize("name,tag,model", (("Stack", "seed0_full", "stack_panda"), ("TwoArmPegInHole", "ctl_joint_velocity", "peg_baxter")))
+@pytest.mark.parametrize("name,tag,model", (("Stack", "seed0_full", "stack_panda"), ("TwoArmPegInHole", "ctl_joint_velocity", "peg_baxter"),
+                                            ("PickPlace", "seed0_full", "pickplace_iiwa")))
 def test_vectorised_env_for_the_other_tasks(name, tag, model):
     """VecEnv over the Stack (32-dof configuration) and TwoArmPegInHole (64-body configuration, JOINT_VELOCITY x 2 arms) tasks: reset observation,
     horizon / done, on-device restart from the pre-drawn bank, key lookup and the GymWrapper flattening order."""
@@ -595,8 +596,10 @@ def test_vectorised_env_for_the_other_tasks(name, tag, model):
     env = VecEnv(name, 5, flat, cfg, seed=0, horizon=3, bank_episodes=2)
     obs = env.reset()
     assert tuple(obs.shape) == (5, sum(cfg["obs_dims"])) and env.action_dim == g["actions"].shape[1]
-    setup = stack.episode_setup if name == "Stack" else peg_in_hole.episode_setup
-    first_key = "cubeA_pos" if name == "Stack" else "hole_pos"
+    from robosuite_amd import pick_place
+    setup = {"Stack": stack.episode_setup, "TwoArmPegInHole": peg_in_hole.episode_setup,
+             "PickPlace": lambda s, ids, blk: pick_place.episode_setup(cfg, flat.nq, s, ids, blk)}[name]
+    first_key = {"Stack": "cubeA_pos", "TwoArmPegInHole": "hole_pos", "PickPlace": "Milk_to_robot0_eef_pos"}[name]
     assert tuple(env.key(obs, first_key).shape) == (5, 3)
     a = torch.zeros(5, env.action_dim, device="cuda")
     dones = []

@@ -274,11 +274,32 @@ def record_pickplace(seed, n_steps, action_scale, tag):
                        bin_size=[float(x) for x in env.bin_size], target_bin_placements=[[float(x) for x in r] for r in env.target_bin_placements],
                        left_pad=list(g.important_geoms["left_fingerpad"]), right_pad=list(g.important_geoms["right_fingerpad"]),
                        eef_body=env.robots[0].robot_model.eef_name["right"], grip_site=g.important_sites["grip_site"])
+    # reset path constants (pick_place.py:431-483, placement_samplers.py:221-309): bin the objects are dropped into, per-object footprint
+    cfg["task"]["placement"] = dict(
+        bin1_pos=[float(x) for x in env.bin1_pos], z_offset=float(env.z_offset), z_rotation=env.z_rotation,
+        x_half=float(env.model.mujoco_arena.table_full_size[0] / 2 - 0.05), y_half=float(env.model.mujoco_arena.table_full_size[1] / 2 - 0.05),
+        objects=[dict(name=o.name, horizontal_radius=float(o.horizontal_radius), bottom_z=float(o.bottom_offset[-1]), top_z=float(o.top_offset[-1]),
+                      qposadr=int(sim.model.get_joint_qpos_addr(o.joints[0])[0])) for o in env.objects],
+        arm_init_qpos=[float(x) for x in env.robots[0].init_qpos], gripper_init_qpos=[float(x) for x in g.init_qpos],
+        arm_qpos_idx=[int(i) for i in env.robots[0]._ref_joint_pos_indexes], gripper_qpos_idx=[int(i) for i in env.robots[0]._ref_gripper_joint_pos_indexes["right"]])
     cfg["obs_keys"] = keys
     cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in keys]
     with open(os.path.join(GOLD, f"pickplace_iiwa_{tag}.cfg.json"), "w") as f:
         json.dump(cfg, f, indent=1)
     print("pickplace", tag, "nv", flat.nv, "nbody", flat.nbody, "ntendon", int(flat.ntendon), "neq", int(flat.neq), "steps", n_steps, "reward", rewards[-1])
+
+
+def record_pickplace_resets(seeds):
+    """Reset-path fixture for PickPlace (physics independent): qpos after make() and after the first user reset() per seed."""
+    out = {}
+    for seed in seeds:
+        env = suite.make("PickPlace", robots="IIWA", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
+                         reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed)
+        out[f"make_{seed}"] = np.array(env.sim.data.qpos)
+        env.reset()
+        out[f"reset_{seed}"] = np.array(env.sim.data.qpos)
+    np.savez_compressed(os.path.join(GOLD, "pickplace_iiwa_resets.npz"), seeds=np.array(seeds), **out)
+    print("pickplace resets", seeds)
 
 
 def record_stack_resets(seeds):
@@ -349,6 +370,7 @@ def record_lift(seed, n_steps, action_scale, tag):
 if __name__ == "__main__":
     if "--pickplace-only" in sys.argv:
         record_pickplace(seed=0, n_steps=20, action_scale=1.0, tag="seed0_full")
+        record_pickplace_resets([0, 1, 2, 3])
         sys.exit(0)
     if "--impedance-only" in sys.argv:
         record_lift_controller(seed=3, n_steps=30, action_scale=1.0, ctype="OSC_POSE", impedance_mode="variable")
