@@ -660,6 +660,31 @@ def test_dynamics_domain_randomisation_on_device():
     b.randomize_dynamics(seed=7, step=0, **{k: 0.0 for k in A})     # all magnitudes 0 => nothing is rewritten (values of the last draw stay)
 
 
+def test_dynamics_domain_randomisation_on_the_pickplace_configuration():
+    """BASELINE configs[4] asks for dynamics-only DR on PickPlace / IIWA: per-env float tables on the 64 x 64 configuration, one draw per
+    control step (randomize_every_n_steps = 1), simulation stays finite; the draws obey the reference's ranges and leave free joints alone."""
+    from robosuite_amd import pick_place
+    from robosuite_amd.backend import DEFAULT_DYNAMICS_ARGS as A, HipBatch, HipModel
+    g, cfg, flat = load_golden("seed0_full", "pickplace_iiwa")
+    B = 16
+    hm = HipModel(flat); hm.set_controller(cfg); hm.set_task(pick_place.pick_place_task(flat, cfg))
+    b = HipBatch(hm, B, 0, True)
+    q = pick_place.episode_setup(cfg, flat.nq, 0, np.arange(B), 0)
+    b.set("qpos", q); b.set("qvel", 0); b.set("qacc_warmstart", 0); b.set("ctrl", 0); b.forward(); b.ctrl_reset(); b.observe()
+    m0, d0 = b.param_get("body_mass"), b.param_get("dof_damping")
+    b.dr_save_defaults()
+    rng = np.random.default_rng(3)
+    for t in range(6):
+        b.randomize_dynamics(seed=11, step=t)
+        b.control_step(torch.tensor(rng.uniform(-0.5, 0.5, (B, 7)), dtype=torch.float32, device="cuda"), 25)
+    m1, d1 = b.param_get("body_mass"), b.param_get("dof_damping")
+    assert np.all(np.abs(m1[:, 1:] - m0[:, 1:]) <= A["mass_ratio"] * m0[:, 1:] * 1.0001 + 1e-9) and np.abs(m1 - m0).max() > 0
+    assert np.abs(m1[0] - m1[1]).max() > 0                                   # per env
+    free = np.array([flat.jnt_type[flat.dof_jntid[i]] == 0 for i in range(flat.nv)])
+    assert np.array_equal(d1[:, free], d0[:, free]) and np.abs(d1[:, ~free] - d0[:, ~free]).max() > 0
+    assert np.isfinite(b.get("qpos")).all() and np.isfinite(b.get("obs")).all() and np.isfinite(b.get("reward")).all()
+
+
 def test_grasp_and_lift_replay_matches_oracle_and_sets_success():
     """The scripted grasp (condim-4 pad contacts, elliptic cones in the sliding / sticking regimes, joint limits of the fingers) replayed on
     the HIP path: same qualitative outcome as the oracle, reward = grasp bonus then success, trajectories close before chaos matters."""
