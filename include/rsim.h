@@ -57,6 +57,12 @@ typedef struct rsim_ctrl_desc {
                                        * (osc.py:243-253 with n = 6, joint_pos.py:204-214 with n = ndof): kp = clip(kp, kp_limits),
                                        * kd = 2 sqrt(kp) clip(damping_ratio, damping_ratio_limits) (1 in mode 2), applied from this control step on */
   float kp_min[RSIM_JNT_MAX], kp_max[RSIM_JNT_MAX], damping_min[RSIM_JNT_MAX], damping_max[RSIM_JNT_MAX];
+  int32_t interp_steps;               /* 0: no interpolator; > 0: LinearInterpolator.total_steps = ceil(ramp_ratio * controller_freq / policy_freq)
+                                       * (utils/traj_utils.py:25-155, controller_factory.py:87-94).  Restated as it is: set_goal moves start := previous
+                                       * GOAL (not the value reached) and step := 0; each run_controller uses start + (goal - start) / (total - step)
+                                       * and advances step up to total - 1.  Joint-space types interpolate their goal vector; OSC_POSITION its goal_pos,
+                                       * which the reference then uses as a WORLD position although it holds base-frame coordinates (osc.py:418-423).
+                                       * OSC_POSE with an interpolator (Euler / slerp orientation path) is not implemented and is refused. */
   int32_t part_of[RSIM_JNT_MAX];      /* joint-space types: which part controller (arm) owns joint i; JOINT_POSITION multiplies by that part's own
                                        * mass-matrix block only (joint_pos.py:256-259 uses Controller.mass_matrix of the part) */
 } rsim_ctrl_desc;
@@ -126,7 +132,8 @@ enum rsim_field {
   RSIM_CSTATE,         /* [B,cs]  controller state, cs = rsim_model_int(m, "cstate_size"): OSC types (32) goal_pos3 goal_ori9 q0[8] grip[4] tau[8];
                         *          joint-space types (64) goal[16] - grip[4] at 20 - tau[16] at 32; JOINT_VELOCITY (192) adds last_err[16] at 48,
                         *          summed_err[16] at 64, derr ring[5][16] at 80, ring ptr / size at 160 / 161, saturated[part] at 164;
-                        *          variable-impedance modes (128): current kp[16] at 96, kd[16] at 112 */
+                        *          variable-impedance modes (128): current kp[16] at 96, kd[16] at 112;
+                        *          interpolator (200): start[16] at 180, step at 196 */
   RSIM_XPOS,           /* [B,nbody,3]  sim.data.xpos      (derived, valid after forward/step1) */
   RSIM_XQUAT,          /* [B,nbody,4]  sim.data.xquat                                        */
   RSIM_QM,             /* [B,nv,nv]    dense mass matrix (mj_fullM, controller.py:226-227)  */

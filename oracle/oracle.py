@@ -51,6 +51,7 @@ def lib():
         L.rso_efc_type.argtypes = [vp, C.c_int]
         L.rso_ctrl_create.restype = vp
         L.rso_ctrl_free.argtypes = [vp]
+        L.rso_ctrl_set_interpolator.argtypes = [vp, C.c_int]
         L.rso_ctrl_set_impedance.argtypes = [vp, C.c_int, dp, dp, dp, dp]
         L.rso_ctrl_set_type.argtypes = [vp, C.c_int, C.c_int, dp, C.c_double, dp, dp, dp, dp, dp, dp]
         L.rso_ctrl_config.argtypes = [vp, C.c_int, ip, ip, ip, C.c_int, C.c_int, dp, C.c_double, dp, dp, dp, dp, C.c_int, C.c_int, ip, dp, C.c_double]
@@ -209,6 +210,8 @@ class OracleController:
             self._L.rso_ctrl_set_type(self.ptr, ctype, cdim, _dp(k2[0]), float(cfg.get("damping_ratio", 1.0)), _dp(k2[1]), _dp(k2[2]), _dp(k2[3]),
                                       _dp(k2[4]), _dp(k2[5]), _dp(k2[6]))
 
+        if cfg.get("interp_steps", 0):
+            self._L.rso_ctrl_set_interpolator(self.ptr, int(cfg["interp_steps"]))
         mode = IMPEDANCE_MODES[cfg.get("impedance_mode", "fixed")]
         if mode:
             ng = n if ctype >= 2 else 6

@@ -1741,6 +1741,9 @@ typedef struct {
   /* impedance mode (osc.py:243-253, joint_pos.py:204-214): 0 fixed, 1 variable, 2 variable_kp; limits per gain */
   int imp_mode;
   double kp_min[ARM_MAX], kp_max[ARM_MAX], dr_min[ARM_MAX], dr_max[ARM_MAX];
+  /* LinearInterpolator (utils/traj_utils.py:25-155): total steps (0 = none), start vector, step counter; the goal is goal_j / goal_pos */
+  int interp_total, interp_step;
+  double interp_start[ARM_MAX];
   double nullspace_kp;
   /* gripper */
   int ngrip;               /* number of gripper actuators (2) */
@@ -1783,6 +1786,14 @@ void rso_ctrl_set_type(rso_ctrl *c, int type, int cdim, const double *jkp, doubl
   if (type == 3 || type == 4) for (int i = 0; i < c->ndof; i++) { c->tl_lo[i] = tl_lo[i]; c->tl_hi[i] = tl_hi[i]; }  /* torque / velocity limits */
 }
 
+void rso_ctrl_set_interpolator(rso_ctrl *c, int total_steps) { c->interp_total = total_steps; c->interp_step = 0; memset(c->interp_start, 0, sizeof(c->interp_start)); }
+
+/* LinearInterpolator.get_interpolated_goal for one component set; advances the step counter once per call */
+static void interp_get(rso_ctrl *c, const double *goal, int n, double *out) {
+  for (int i = 0; i < n; i++) out[i] = c->interp_start[i] + (goal[i] - c->interp_start[i]) / (double)(c->interp_total - c->interp_step);
+  if (c->interp_step < c->interp_total - 1) c->interp_step++;
+}
+
 void rso_ctrl_set_impedance(rso_ctrl *c, int mode, const double *kp_min, const double *kp_max, const double *dr_min, const double *dr_max) {
   c->imp_mode = mode;
   int n = c->type >= 2 ? c->ndof : 6;
@@ -1802,6 +1813,7 @@ void rso_ctrl_reset(rso_ctrl *c, rso_data *d) {
   for (int i = 0; i < c->ndof; i++) c->goal_j[i] = c->type == 2 ? d->qpos[c->qpos_idx[i]] : 0.0;
   memset(c->last_err, 0, sizeof(c->last_err)); memset(c->summed_err, 0, sizeof(c->summed_err)); memset(c->ring, 0, sizeof(c->ring));
   c->ring_ptr = 4; c->ring_size = 0; c->saturated = 0;
+  memset(c->interp_start, 0, sizeof(c->interp_start)); c->interp_step = 0;   /* fresh interpolator, then set_goal(reset goal): start = zeros */
 }
 
 /* float32 quat2mat of the reference (transform_utils.py:461-487 casts to float32; under NumPy>=2 the
@@ -1848,6 +1860,11 @@ void rso_ctrl_set_goal(rso_ctrl *c, rso_data *d, const double *action) {
     double scale = fabs(c->out_max[i] - c->out_min[i]) / fabs(c->in_max[i] - c->in_min[i]);
     double a = fmax(c->in_min[i], fmin(c->in_max[i], action[i]));
     scaled[i] = (a - 0.5 * (c->in_max[i] + c->in_min[i])) * scale + 0.5 * (c->out_max[i] + c->out_min[i]);
+  }
+  if (c->interp_total) {     /* LinearInterpolator.set_goal: start := previous goal, step := 0 (traj_utils.py:101-116) */
+    if (c->type >= 2) memcpy(c->interp_start, c->goal_j, sizeof(double) * c->ndof);
+    else memcpy(c->interp_start, c->goal_pos, sizeof(double) * 3);
+    c->interp_step = 0;
   }
   if (c->type == 2) {        /* joint_pos.py:200-236: goal_qpos = joint_pos + scaled delta (no position limits) */
     for (int i = 0; i < c->ndof; i++) c->goal_j[i] = d->qpos[c->qpos_idx[i]] + scaled[i];
@@ -1983,20 +2000,23 @@ void rso_ctrl_run(rso_ctrl *c, rso_data *d) {
     for (int r = 0; r < 3; r++) { J[r * n + i] = jp[r * nv + c->dof_idx[i]]; J[(3 + r) * n + i] = jr[r * nv + c->dof_idx[i]]; }
     for (int j = 0; j < n; j++) M[i * n + j] = d->qM[c->dof_idx[i] * nv + c->dof_idx[j]];
   }
+  double gj[ARM_MAX];
+  memcpy(gj, c->goal_j, sizeof(gj));
+  if (c->interp_total && c->type >= 2) interp_get(c, c->goal_j, n, gj);
   if (c->type == 2) {        /* joint_pos.py:238-266: M_arm (kp (goal - q) - kd qd) + qfrc_bias[arm] */
     for (int i = 0; i < n; i++) {
       double t = bias[i];
-      for (int j = 0; j < n; j++) t += M[i * n + j] * (c->jkp[j] * (c->goal_j[j] - q[j]) - c->jkd[j] * qd[j]);
+      for (int j = 0; j < n; j++) t += M[i * n + j] * (c->jkp[j] * (gj[j] - q[j]) - c->jkd[j] * qd[j]);
       c->torques[i] = t;
     }
   } else if (c->type == 3) { /* joint_tor.py:130-167: goal_torque + qfrc_bias[arm] */
-    for (int i = 0; i < n; i++) c->torques[i] = c->goal_j[i] + bias[i];
+    for (int i = 0; i < n; i++) c->torques[i] = gj[i] + bias[i];
   } else if (c->type == 4) { /* joint_vel.py:166-198 */
     c->ring_ptr = (c->ring_ptr + 1) % 5;
     if (c->ring_size < 5) c->ring_size++;
     int sat = 0;
     for (int i = 0; i < n; i++) {
-      double err = c->goal_j[i] - qd[i], derr = err - c->last_err[i];
+      double err = gj[i] - qd[i], derr = err - c->last_err[i];
       c->last_err[i] = err;
       c->ring[c->ring_ptr][i] = derr;
       if (!c->saturated) c->summed_err[i] += err;
@@ -2010,10 +2030,21 @@ void rso_ctrl_run(rso_ctrl *c, rso_data *d) {
       c->torques[i] = cl;
     }
     c->saturated = sat;
-  } else
-  rso_osc_torques(c->kp, c->kd, d->site_xpos + 3 * c->eef_site, d->site_xmat + 9 * c->eef_site, ev, d->site_xpos + 3 * c->base_site,
-                  d->site_xmat + 9 * c->base_site, bv, c->goal_pos, c->goal_ori, J, M, bias, q, qd, c->initial_joint, c->nullspace_kp, c->uncouple, n,
-                  c->torques);
+  } else {
+    /* osc.py:418-423: with an interpolator the ramped goal values are taken as the desired WORLD position (although set_goal stores base-frame
+     * coordinates); expressed here as the base-frame goal that maps onto that world point */
+    double gp[3] = {c->goal_pos[0], c->goal_pos[1], c->goal_pos[2]};
+    if (c->interp_total) {
+      double des[3], rel[3];
+      const double *op = d->site_xpos + 3 * c->base_site, *oR = d->site_xmat + 9 * c->base_site;
+      interp_get(c, c->goal_pos, 3, des);
+      for (int k = 0; k < 3; k++) rel[k] = des[k] - op[k];
+      matT_vec3(gp, oR, rel);
+    }
+    rso_osc_torques(c->kp, c->kd, d->site_xpos + 3 * c->eef_site, d->site_xmat + 9 * c->eef_site, ev, d->site_xpos + 3 * c->base_site,
+                    d->site_xmat + 9 * c->base_site, bv, gp, c->goal_ori, J, M, bias, q, qd, c->initial_joint, c->nullspace_kp, c->uncouple, n,
+                    c->torques);
+  }
   for (int i = 0; i < n; i++) {
     int a = c->act_idx[i];
     d->ctrl[a] = fmax(m->actuator_ctrlrange[2 * a], fmin(m->actuator_ctrlrange[2 * a + 1], c->torques[i]));

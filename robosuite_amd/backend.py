@@ -43,7 +43,7 @@ class CtrlDesc(C.Structure):
                 ("ngrip", C.c_int32), ("grip_act", C.c_int32 * 4), ("grip_sign", C.c_float * 4), ("grip_speed", C.c_float),
                 ("type", C.c_int32), ("torque_min", C.c_float * JNT_MAX), ("torque_max", C.c_float * JNT_MAX), ("impedance_mode", C.c_int32),
                 ("kp_min", C.c_float * JNT_MAX), ("kp_max", C.c_float * JNT_MAX), ("damping_min", C.c_float * JNT_MAX), ("damping_max", C.c_float * JNT_MAX),
-                ("part_of", C.c_int32 * JNT_MAX)]
+                ("interp_steps", C.c_int32), ("part_of", C.c_int32 * JNT_MAX)]
 
 
 # arm part-controller types with an in-kernel implementation (include/rsim.h enum rsim_ctrl_type; names = the reference's config "type" strings)
@@ -112,6 +112,7 @@ def ctrl_desc(cfg: dict) -> CtrlDesc:
         for i in range(n):
             d.torque_min[i], d.torque_max[i] = tl[0][i], tl[1][i]
     d.damping_ratio = cfg.get("damping_ratio", 1.0)
+    d.interp_steps = int(cfg.get("interp_steps", 0))
     d.impedance_mode = IMPEDANCE_MODES[cfg.get("impedance_mode", "fixed")]
     if d.impedance_mode:
         ng = 6 if ctype.startswith("OSC") else n

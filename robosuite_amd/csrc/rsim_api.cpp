@@ -482,6 +482,10 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
   c.imp_mode = d->impedance_mode;
   c.nimp = d->impedance_mode ? (jointspace ? d->ndof : 6) : 0;
   if (c.imp_mode) c.cs_size = RSIM_CS_SIZE_VARIMP;
+  if (d->interp_steps < 0 || d->interp_steps > 1000) return fail("controller: interp_steps %d", d->interp_steps);
+  if (d->interp_steps && d->type == RSIM_CTRL_OSC_POSE) return fail("controller: OSC_POSE with an interpolator (orientation slerp path, osc.py:425-430) is not implemented");
+  c.interp_steps = d->interp_steps;
+  if (c.interp_steps) c.cs_size = RSIM_CS_SIZE_INTERP;
   for (int i = 0; i < c.nimp; i++) {
     if (!(d->kp_max[i] >= d->kp_min[i]) || !(d->kp_min[i] >= 0.f) || !(d->damping_max[i] >= d->damping_min[i])) return fail("controller: bad kp / damping_ratio limits");
     c.kp_min[i] = d->kp_min[i]; c.kp_max[i] = d->kp_max[i]; c.dr_min[i] = d->damping_min[i]; c.dr_max[i] = d->damping_max[i];

@@ -64,6 +64,7 @@ struct DCtrl {
   float kp[RSIM_JNT_MAX], kd[RSIM_JNT_MAX], in_min[RSIM_JNT_MAX], in_max[RSIM_JNT_MAX], out_min[RSIM_JNT_MAX], out_max[RSIM_JNT_MAX];
   float tl_lo[RSIM_JNT_MAX], tl_hi[RSIM_JNT_MAX];
   int part_of[RSIM_JNT_MAX];
+  int interp_steps;     // LinearInterpolator.total_steps, 0 = none
   int imp_mode, nimp;   // impedance mode (0 fixed, 1 variable, 2 variable_kp) and number of gains in the action (6 / ndof)
   float kp_min[RSIM_JNT_MAX], kp_max[RSIM_JNT_MAX], dr_min[RSIM_JNT_MAX], dr_max[RSIM_JNT_MAX];
   int type, cdim;   // rsim_ctrl_type, control_dim of the arm part(s)
@@ -98,8 +99,11 @@ struct DCtrl {
 #define RSIM_CS_KD 112
 #define RSIM_CS_SIZE_VARIMP 128
 #define RSIM_CS_SIZE_JVEL 192
+#define RSIM_CS_ISTART 180     /* LinearInterpolator: start[16], step */
+#define RSIM_CS_ISTEP 196
+#define RSIM_CS_SIZE_INTERP 200
 #ifndef RSIM_CS_MAX
-#define RSIM_CS_MAX 192
+#define RSIM_CS_MAX 200
 #endif
 
 // observation / reward epilogue (include/rsim.h rsim_task_desc), device form

@@ -1885,6 +1885,7 @@ struct Sim {
       const float imin = sel(c.in_min, li), imax = sel(c.in_max, li), omin = sel(c.out_min, li), omax = sel(c.out_max, li);
       const float tlo = sel(c.tl_lo, li), thi = sel(c.tl_hi, li);
       if (lane < c.ndof) {
+        if (c.interp_steps) sm.cstate[RSIM_CS_ISTART + lane] = sm.cstate[RSIM_CS_GOALQ + lane];   // LinearInterpolator.set_goal: start := previous goal
         const float scale = fabsf(omax - omin) / fabsf(imax - imin);
         const float a = fmaxf(imin, fminf(imax, action[lane]));
         const float sv = (a - 0.5f * (imax + imin)) * scale + 0.5f * (omax + omin);
@@ -1895,6 +1896,7 @@ struct Sim {
         const float a = action[c.cdim], sg = a > 0 ? 1.f : (a < 0 ? -1.f : 0.f);
         sm.cstate[RSIM_CS_GRIP + lane] = fmaxf(-1.f, fminf(1.f, sm.cstate[RSIM_CS_GRIP + lane] + K.cgs * c.grip_speed * sg));
       }
+      if (c.interp_steps && lane == 0) sm.cstate[RSIM_CS_ISTEP] = 0.f;
       SYNC();
       return;
     }
@@ -1924,6 +1926,7 @@ struct Sim {
     M3 go = mm(Re, mtm(oR, eR));
     SYNC();
     if (lane == 0) {
+      if (c.interp_steps) { st3(sm.cstate + RSIM_CS_ISTART, ld3(sm.cstate + RSIM_CS_GOALPOS)); sm.cstate[RSIM_CS_ISTEP] = 0.f; }
       st3(sm.cstate + RSIM_CS_GOALPOS, gp);
       stm(sm.cstate + RSIM_CS_GOALORI, go);
     }
@@ -1981,7 +1984,13 @@ struct Sim {
     constexpr int NA = RSIM_JNT_MAX;
     const int li = lane & (NA - 1);
     const int di = lane < n ? K.cd : 0, qi = lane < n ? K.cq : 0;
-    const float goal = lane < n ? sm.cstate[RSIM_CS_GOALQ + lane] : 0.f;
+    float goal = lane < n ? sm.cstate[RSIM_CS_GOALQ + lane] : 0.f;
+    if (c.interp_steps) {   // LinearInterpolator.get_interpolated_goal (traj_utils.py:118-155)
+      const float step = sm.cstate[RSIM_CS_ISTEP], start = lane < n ? sm.cstate[RSIM_CS_ISTART + lane] : 0.f;
+      goal = start + (goal - start) / ((float)c.interp_steps - step);
+      SYNC();
+      if (lane == 0 && step < (float)(c.interp_steps - 1)) sm.cstate[RSIM_CS_ISTEP] = step + 1.f;
+    }
     float tq = lane < n ? sm.qfrc_bias[di] : 0.f;
     if (c.type == RSIM_CTRL_JOINT_POSITION) {
       const float kpj = c.imp_mode ? sm.cstate[RSIM_CS_KP + li] : sel(c.kp, li), kdj = c.imp_mode ? sm.cstate[RSIM_CS_KD + li] : sel(c.kd, li);
@@ -2085,7 +2094,15 @@ struct Sim {
     const M3 oR = ldm(sm.smat + 9 * c.base_site), eR = ldm(sm.smat + 9 * c.eef_site);
     const V3 gpos = ld3(sm.cstate + RSIM_CS_GOALPOS);
     const M3 gori = ldm(sm.cstate + RSIM_CS_GOALORI);
-    const V3 perr = op + mv(oR, gpos) - ep;
+    V3 perr = op + mv(oR, gpos) - ep;
+    if (c.interp_steps) {
+      // osc.py:418-423: with an interpolator the (base-frame) goal values, linearly ramped, ARE the desired world position
+      const float step = sm.cstate[RSIM_CS_ISTEP];
+      const V3 start = ld3(sm.cstate + RSIM_CS_ISTART);
+      perr = start + (gpos - start) * (1.0f / ((float)c.interp_steps - step)) - ep;
+      SYNC();
+      if (lane == 0 && step < (float)(c.interp_steps - 1)) sm.cstate[RSIM_CS_ISTEP] = step + 1.f;
+    }
     const M3 dori = mm(oR, gori);
     const V3 oerr = (cross(col(eR, 0), col(dori, 0)) + cross(col(eR, 1), col(dori, 1)) + cross(col(eR, 2), col(dori, 2))) * 0.5f;
     // site velocities from the body spatial velocities of the velocity stage: v = cvel.l + w x (p - com)

@@ -141,7 +141,13 @@ class MjModel:
         self._flat = flat
         self._dirty = False
         self._backend = _BACKEND_FACTORY(flat)
-        self.opt = _Opt(self)
+        self._opt = _Opt(self)
+
+    @property
+    def opt(self):
+        """mjOption view.  A class-level attribute: robosuite's MjModel wrapper builds its delegating properties from `dir(mujoco.MjModel)`
+        (utils/binding_utils.py:252-268), and `controller_factory` reads `sim.model.opt.timestep` for the interpolators."""
+        return self._opt
 
     @classmethod
     def from_xml_string(cls, xml, assets=None):

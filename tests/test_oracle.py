@@ -47,7 +47,9 @@ def test_env_step_replay_matches_reference_loop(tag):
 
 CTL_TAGS = ("ctl_joint_position", "ctl_joint_torque", "ctl_osc_position",
             # variable-impedance action layouts (osc.py:243-253, joint_pos.py:204-214): [damping_ratio, kp, goal update] / [kp, goal update]
-            "ctl_osc_pose_variable", "ctl_osc_pose_variable_kp", "ctl_joint_position_variable")
+            "ctl_osc_pose_variable", "ctl_osc_pose_variable_kp", "ctl_joint_position_variable",
+            # LinearInterpolator (utils/traj_utils.py:25-155) incl. the OSC quirk of using the ramped base-frame goal as a world position
+            "ctl_joint_position_linear", "ctl_joint_torque_linear", "ctl_osc_position_linear")
 
 
 @pytest.mark.parametrize("tag", CTL_TAGS)

@@ -49,7 +49,7 @@ def controller_cfg(env):
     )
 
 
-def record_lift_controller(seed, n_steps, action_scale, ctype, impedance_mode="fixed"):
+def record_lift_controller(seed, n_steps, action_scale, ctype, impedance_mode="fixed", interpolation=None):
     """Env-level fixture for another arm part-controller type (JOINT_POSITION / JOINT_TORQUE / OSC_POSITION): the reference's own
     controller classes drive the env; only states / ctrl / obs / rewards are recorded (the controller is pinned end to end)."""
     from robosuite.controllers import load_part_controller_config
@@ -57,6 +57,7 @@ def record_lift_controller(seed, n_steps, action_scale, ctype, impedance_mode="f
 
     part = load_part_controller_config(default_controller=ctype)
     part["impedance_mode"] = impedance_mode
+    part["interpolation"] = interpolation
     ccfg = refactor_composite_controller_config(part, "Panda", ["right"])
     env = suite.make("Lift", robots="Panda", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
                      reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed, controller_configs=ccfg)
@@ -74,7 +75,7 @@ def record_lift_controller(seed, n_steps, action_scale, ctype, impedance_mode="f
         obs, r, done, info = env.step(a)
         ctrls.append(np.array(sim.data.ctrl)); actions.append(a); states.append(sim.get_state().flatten()); rewards.append(r)
         obs_flat.append(np.concatenate([np.atleast_1d(obs[k]).astype(np.float64) for k in keys if not k.endswith("-state")]))
-    tag = f"ctl_{ctype.lower()}" + ("" if impedance_mode == "fixed" else f"_{impedance_mode}")
+    tag = f"ctl_{ctype.lower()}" + ("" if impedance_mode == "fixed" else f"_{impedance_mode}") + ("" if interpolation is None else f"_{interpolation}")
     np.savez_compressed(os.path.join(GOLD, f"lift_panda_{tag}.npz"), actions=np.array(actions), states=np.array(states), rewards=np.array(rewards),
                         obs=np.array(obs_flat), ctrl=np.array(ctrls), cube_size=flat.geom_size[flat.name2id("geom", "cube_g0")])
     mjcf.save_model(flat, os.path.join(GOLD, f"lift_panda_{tag}.rsim"))
@@ -86,6 +87,9 @@ def record_lift_controller(seed, n_steps, action_scale, ctype, impedance_mode="f
         cfg["kp_limits"] = [[float(x) for x in ctl.kp_min], [float(x) for x in ctl.kp_max]]
         cfg["damping_ratio_limits"] = [[float(x) for x in ctl.damping_ratio_min], [float(x) for x in ctl.damping_ratio_max]]
         cfg["input_min"], cfg["input_max"] = [float(x) for x in ctl.input_min], [float(x) for x in ctl.input_max]
+    if interpolation is not None:
+        ip = getattr(ctl, "interpolator", None) or ctl.interpolator_pos
+        cfg["interp_steps"] = int(ip.total_steps)      # ceil(ramp_ratio * controller_freq / policy_freq), traj_utils.py:55-57
     cfg["obs_keys"] = [k for k in keys if not k.endswith("-state")]
     cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in cfg["obs_keys"]]
     with open(os.path.join(GOLD, f"lift_panda_{tag}.cfg.json"), "w") as f:
@@ -360,6 +364,9 @@ def record_lift(seed, n_steps, action_scale, tag):
     np.savez_compressed(os.path.join(GOLD, f"lift_panda_{tag}.npz"), **out)
     mjcf.save_model(flat, os.path.join(GOLD, f"lift_panda_{tag}.rsim"))
     cfg = controller_cfg(env)
+    if interpolation is not None:
+        ip = getattr(ctl, "interpolator", None) or ctl.interpolator_pos
+        cfg["interp_steps"] = int(ip.total_steps)      # ceil(ramp_ratio * controller_freq / policy_freq), traj_utils.py:55-57
     cfg["obs_keys"] = [k for k in keys if not k.endswith("-state")]
     cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in cfg["obs_keys"]]
     with open(os.path.join(GOLD, f"lift_panda_{tag}.cfg.json"), "w") as f:
@@ -371,6 +378,10 @@ if __name__ == "__main__":
     if "--pickplace-only" in sys.argv:
         record_pickplace(seed=0, n_steps=20, action_scale=1.0, tag="seed0_full")
         record_pickplace_resets([0, 1, 2, 3])
+        sys.exit(0)
+    if "--interp-only" in sys.argv:
+        for ct in ("JOINT_POSITION", "JOINT_TORQUE", "OSC_POSITION"):
+            record_lift_controller(seed=4, n_steps=30, action_scale=1.0, ctype=ct, interpolation="linear")
         sys.exit(0)
     if "--impedance-only" in sys.argv:
         record_lift_controller(seed=3, n_steps=30, action_scale=1.0, ctype="OSC_POSE", impedance_mode="variable")
