@@ -126,7 +126,8 @@ def main():
 
     st = shard.RolloutStats(dev)
     q = env.batch.tensor("qpos")
-    st.add(env_steps=B * K, diverged=int((~torch.isfinite(q).all(dim=1)).sum().item()),
+    # envs that hit the bad-state guard (RSIM_DIVERGED, MuJoCo's mj_checkPos semantics) or hold a non-finite coordinate
+    st.add(env_steps=B * K, diverged=int((~torch.isfinite(q).all(dim=1)).sum().item()) + int((env.batch.tensor("diverged") > 0).sum().item()),
            reward_sum=float(env.reward().sum().item()), successes=int(env.success().sum().item()))
     if hasattr(env, "rollout_totals"):
         st.add(**env.rollout_totals())

@@ -155,6 +155,9 @@ enum rsim_field {
   RSIM_DONE,           /* [B] int32    timestep >= horizon after the last control step (base.py:532-548) */
   RSIM_EP_STEP,        /* [B] int32    MujocoEnv.timestep of the running episode            */
   RSIM_EP_INDEX,       /* [B] int32    which entry of the reset bank the running episode came from */
+  RSIM_DIVERGED,       /* [B] int32    how often the env hit MuJoCo's bad-state guard: after a substep that leaves a non-finite or > 1e10 qpos / qvel
+                        *               entry the env is put back to qpos0 with zero velocity, control and time, as mj_checkPos / mj_checkVel +
+                        *               mj_resetData do [3P]; robosuite never reads the corresponding mjData warning, this counter makes it visible */
   RSIM_FIELD_COUNT
 };
 

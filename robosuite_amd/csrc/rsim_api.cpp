@@ -686,7 +686,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
       {RSIM_NCON, (void**)&db.ncon, (size_t)B, 1}, {RSIM_NEFC, (void**)&db.nefc, (size_t)B, 1}, {RSIM_NITER, (void**)&db.niter, (size_t)B, 1},
       {RSIM_OBS, (void**)&db.obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0}, {RSIM_REWARD, (void**)&db.reward, (size_t)B, 0},
       {RSIM_SUCCESS, (void**)&db.success, (size_t)B, 1}, {RSIM_DONE, (void**)&db.done, (size_t)B, 1}, {RSIM_EP_STEP, (void**)&db.ep_step, (size_t)B, 1},
-      {RSIM_EP_INDEX, (void**)&db.ep_index, (size_t)B, 1}};
+      {RSIM_EP_INDEX, (void**)&db.ep_index, (size_t)B, 1}, {RSIM_DIVERGED, (void**)&db.diverged, (size_t)B, 1}};
   for (auto& fd : fields) {
     if (dalloc((float**)fd.p, fd.n)) return 1;
     b->fptr[fd.id] = *fd.p; b->fcount[fd.id] = fd.n; b->fis_int[fd.id] = fd.is_int;

@@ -2704,6 +2704,19 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
       sim.euler();
       sim.pf.mark(RP_EULER);
       time += sim.opt_h;
+      // MuJoCo's bad-state guard (mj_checkPos / mj_checkVel -> mj_resetData [3P]): a non-finite or absurdly large coordinate puts the env back
+      // to qpos0 with zero velocity / control / time instead of letting NaNs run on.  Controller state is the caller's (robosuite objects).
+      bool bad = false;
+      for (int i = lane; i < m.nq; i += 64) bad |= !(fabsf(sm.qpos[i]) < 1.0e10f);
+      if (lane < m.nv) bad |= !(fabsf(sm.qvel[lane]) < 1.0e10f);
+      if (__ballot(bad)) {
+        SYNC();
+        for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = FP(FO_qpos0, i);
+        if (lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.qacc[lane] = 0.f; sm.ctrl[lane] = 0.f; }
+        time = 0.f;
+        if (lane == 0) b.diverged[env] += 1;
+        SYNC();
+      }
     }
     sim.pf.count(RP_N_SUB, 1);
   }

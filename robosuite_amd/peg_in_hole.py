@@ -5,8 +5,8 @@ Task program (observation order, reward) of the reference env restated for the o
                {prefix}eef_pos (site), {prefix}eef_quat (body, xyzw), {prefix}eef_quat_site
   object keys  two_arm_peg_in_hole.py:414-475: hole_pos, hole_quat, peg_to_hole (= hole_pos - peg_pos), peg_quat, angle (cos), t, d
   reward       two_arm_peg_in_hole.py:240-290, success :513-521
-The reset path of this env draws nothing for the objects (peg and hole are welded to the hands, :488-497); the per-episode peg size
-(two_arm_peg_in_hole.py:175-176) is a model edit that is not restated yet: batches use the model they were compiled from.
+The reset path of this env places no objects (peg and hole are welded to the hands, :488-497); the per-episode peg radius
+(two_arm_peg_in_hole.py:175-176, 343-351) is a model edit, restated in closed form by `peg_model_rows` and applied per env / per episode.
 """
 from __future__ import annotations
 
@@ -45,21 +45,22 @@ def reset_draws(rng: np.random.Generator):
     return dict(peg_radius=radius, qpos=BAXTER_INIT_QPOS + rng.standard_normal(14) * 0.02)
 
 
-def episode_setup(seed0: int, env_ids, block: int = 0):
-    out = []
+def episode_setup(seed0: int, env_ids, block: int = 0, with_radius: bool = False):
+    out, rad = [], []
     for i in env_ids:
         rng = np.random.default_rng(seed0 + int(i))
         for _ in range(block + 1):
             d = reset_draws(rng)
-        out.append(d["qpos"])
-    return np.array(out)
+        out.append(d["qpos"]); rad.append(d["peg_radius"])
+    return (np.array(out), np.array(rad)) if with_radius else np.array(out)
 
 
 class PegBatch:
-    """B TwoArmPegInHole/Baxter environments on one GPU (64-body kernel configuration, joint-space part controllers).  The peg keeps the radius of
-    the model the batch was built from (see the module docstring)."""
+    """B TwoArmPegInHole/Baxter environments on one GPU (64-body kernel configuration, joint-space part controllers).  With `per_env_peg`
+    (default) every env carries its own peg radius, redrawn per episode like the reference's hard reset (closed-form model rows,
+    `peg_model_rows`); without it all envs keep the radius of the model the batch was built from."""
 
-    def __init__(self, flat, cfg, env_ids, device: int = 0, seed0: int = 0, horizon: int = 0, bank_episodes: int = 0):
+    def __init__(self, flat, cfg, env_ids, device: int = 0, seed0: int = 0, horizon: int = 0, bank_episodes: int = 0, per_env_peg: bool = True):
         from .backend import HipBatch, HipModel
 
         self.flat, self.cfg = flat, cfg
@@ -68,21 +69,47 @@ class PegBatch:
         self.model = HipModel(flat)
         self.model.set_controller(cfg)
         self.model.set_task(peg_task(flat, cfg))
-        self.batch = HipBatch(self.model, self.B, device, per_env_params=False)
+        self.per_env_peg = per_env_peg
+        self.batch = HipBatch(self.model, self.B, device, per_env_params=per_env_peg)
         self.seed0 = seed0
         self.reset()
         if horizon:
             self.batch.set_episode(horizon)
         if bank_episodes:
-            qbank = np.stack([episode_setup(seed0, self.env_ids, ep) for ep in range(bank_episodes)], axis=1).astype(np.float32)
-            self.batch.set_reset_bank(qbank, [], np.zeros((self.B, bank_episodes, 0), dtype=np.float32))
+            self.install_reset_bank(bank_episodes)
+
+    def install_reset_bank(self, n_episodes: int):
+        """Pre-drawn hard resets per env for the on-device restart: qpos plus, with per-env pegs, the float-table slots that depend on the radius."""
+        b = self.batch
+        qbank = np.zeros((self.B, n_episodes, self.flat.nq), dtype=np.float32)
+        slots = []
+        if self.per_env_peg:
+            base = peg_model_rows(self.flat, [0.02])
+            probe = peg_model_rows(self.flat, [0.0271])
+            for k in base:
+                for e in np.nonzero(np.abs(probe[k][0] - base[k][0]) > 0)[0]:
+                    off = b.param_offset(k, int(e))
+                    if off >= 0:
+                        slots.append((k, int(e), off))
+        pbank = np.zeros((self.B, n_episodes, len(slots)), dtype=np.float32)
+        for ep in range(n_episodes):
+            qpos, radii = episode_setup(self.seed0, self.env_ids, ep, with_radius=True)
+            qbank[:, ep] = qpos
+            if slots:
+                rows = peg_model_rows(self.flat, radii)
+                for j, (k, e, _) in enumerate(slots):
+                    pbank[:, ep, j] = rows[k][:, e]
+        b.set_reset_bank(qbank, [o for _, _, o in slots], pbank)
 
     def reset(self, block: int = 0):
-        qpos = episode_setup(self.seed0, self.env_ids, block)
+        qpos, radii = episode_setup(self.seed0, self.env_ids, block, with_radius=True)
         b = self.batch
+        if self.per_env_peg:
+            for field, rows in peg_model_rows(self.flat, radii).items():
+                b.param_set(field, rows)
         b.set("qpos", qpos); b.set("qvel", 0.0); b.set("ctrl", 0.0); b.set("time", 0.0); b.set("qacc_warmstart", 0.0)
         b.forward(); b.ctrl_reset()
-        self.qpos0 = qpos
+        self.qpos0, self.radii = qpos, radii
 
     def step(self, actions, n_sub: int = 25):
         self.batch.control_step(actions, n_sub)
@@ -95,3 +122,69 @@ class PegBatch:
 
     def success(self):
         return self.batch.tensor("success")
+
+
+def peg_model_rows(flat, radii, density: float = 1000.0):
+    """Model arrays that depend on the per-episode peg radius (two_arm_peg_in_hole.py:343-351), for n envs at once.
+
+    The reference recompiles the MJCF on every hard reset.  The peg is a cylinder welded to the right hand, so the affected compiled fields are:
+    geom_size / geom_rbound of the peg geom (+ its visual twin), body_mass / body_inertia of the peg body, body_subtreemass along its ancestors,
+    and -- because the arm's mass matrix at qpos0 changes -- dof_invweight0 and body_invweight0 of everything in that kinematic tree
+    (mj_setConst [3P]: diag / Jacobian traces of M^-1).  M(r) = M(r0) + C(r) - C(r0) with C the peg's projected spatial inertia, so all envs are
+    handled with batched numpy (checked against a full recompile in tests/test_peg_host.py)."""
+    from . import mjcf
+
+    radii = np.asarray(radii, dtype=np.float64).ravel()
+    n = len(radii)
+    nv, nbody = flat.nv, flat.nbody
+    pb = flat.name2id("body", "peg_main")
+    g0, gv = flat.name2id("geom", "peg_g0"), flat.name2id("geom", "peg_g0_vis")
+    r0, h = float(flat.geom_size[g0][0]), float(flat.geom_size[g0][1])
+    M0, (xpos, xquat, xmat, xipos, ximat, xanchor, xaxis) = mjcf.mass_matrix_np(flat, flat.qpos0)
+
+    def cyl(r):
+        m = density * np.pi * r * r * 2 * h
+        return m, np.stack([m * (3 * r * r + 4 * h * h) / 12.0, m * (3 * r * r + 4 * h * h) / 12.0, m * r * r / 2.0], axis=-1)
+
+    jp, jr = mjcf.body_jacobian_np(flat, xpos, xmat, xanchor, xaxis, pb, xipos[pb])
+    R = np.asarray(ximat[pb]).reshape(3, 3)
+
+    def project(m, I):       # C = m jp^T jp + jr^T (R diag(I) R^T) jr, batched over envs
+        Iw = np.einsum("ab,nb,cb->nac", R, I, R)
+        return m[:, None, None] * (jp.T @ jp)[None] + np.einsum("ai,nab,bj->nij", jr, Iw, jr)
+
+    m_new, I_new = cyl(radii)
+    m_old, I_old = cyl(np.array([r0]))
+    M = M0[None] + project(m_new, I_new) - project(m_old, I_old)
+    Minv = np.linalg.inv(M)
+
+    def tile(a):
+        return np.repeat(np.asarray(a, dtype=np.float64)[None], n, axis=0).copy()
+
+    geom_size, geom_rbound = tile(flat.geom_size), tile(flat.geom_rbound)
+    for g in (g0, gv):
+        geom_size[:, g, 0] = radii
+        geom_rbound[:, g] = np.sqrt(radii**2 + h * h)
+    body_mass, body_inertia, sub = tile(flat.body_mass), tile(flat.body_inertia), tile(flat.body_subtreemass)
+    body_mass[:, pb] = m_new
+    body_inertia[:, pb] = I_new
+    b = pb
+    while True:
+        sub[:, b] += m_new - m_old[0]
+        if b == 0:
+            break
+        b = int(flat.body_parentid[b])
+    diw = np.einsum("nii->ni", Minv).copy()                       # every Baxter joint is a hinge: dof_invweight0 = diag(M^-1)
+    for j in range(flat.njnt):
+        if flat.jnt_type[j] not in (2, 3):
+            raise NotImplementedError("peg_model_rows: only hinge / slide joints")
+    biw = tile(flat.body_invweight0)
+    for bb in range(1, nbody):
+        if flat.body_weldid[bb] == 0:
+            continue
+        bjp, bjr = mjcf.body_jacobian_np(flat, xpos, xmat, xanchor, xaxis, bb, xipos[bb])
+        biw[:, bb, 0] = np.einsum("ai,nij,aj->n", bjp, Minv, bjp) / 3.0
+        biw[:, bb, 1] = np.einsum("ai,nij,aj->n", bjr, Minv, bjr) / 3.0
+    return {"geom_size": geom_size.reshape(n, -1), "geom_rbound": geom_rbound.reshape(n, -1), "body_mass": body_mass.reshape(n, -1),
+            "body_inertia": body_inertia.reshape(n, -1), "body_subtreemass": sub.reshape(n, -1), "body_invweight0": biw.reshape(n, -1),
+            "dof_invweight0": diw.reshape(n, -1)}

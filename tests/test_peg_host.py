@@ -20,3 +20,23 @@ def test_task_program_matches_the_recorded_observation_layout():
     g, cfg, flat = load_golden("ctl_joint_torque", "peg_baxter")
     t = peg_in_hole.peg_task(flat, cfg)
     assert len(t["obs"]) == sum(cfg["obs_dims"]) == g["obs"].shape[1]
+
+
+def test_per_episode_peg_rows_equal_a_full_recompile():
+    """Closed-form model rows for another peg radius == the arrays of the model the reference built (and this compiler compiled) for that radius."""
+    import os
+    from robosuite_amd import mjcf
+    from tests.util import GOLD
+    g, cfg, flat0 = load_golden("ctl_joint_torque", "peg_baxter")
+    flat1 = mjcf.load_model(os.path.join(GOLD, "peg_baxter_model_seed1.rsim"))
+    r1 = float(flat1.geom_size[flat1.names["geom"].index("peg_g0")][0])
+    assert abs(r1 - flat0.geom_size[flat0.names["geom"].index("peg_g0")][0]) > 1e-4
+    rows = peg_in_hole.peg_model_rows(flat0, [r1, r1])
+    for k, v in rows.items():
+        ref = np.asarray(flat1.arrays[k], dtype=np.float64).ravel()
+        assert np.abs(v[0] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), k
+        assert np.array_equal(v[0], v[1])
+    # and the draw that produced that model is block 1 of seed 1's generator
+    rng = np.random.default_rng(1)
+    peg_in_hole.reset_draws(rng)
+    assert abs(peg_in_hole.reset_draws(rng)["peg_radius"] - r1) < 1e-12

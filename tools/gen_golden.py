@@ -306,6 +306,19 @@ def record_pickplace_resets(seeds):
     print("pickplace resets", seeds)
 
 
+def record_baxter_model(seed):
+    """A second TwoArmPegInHole model (another peg-radius draw): the recompile the closed-form per-episode model rows are checked against."""
+    from robosuite.controllers import load_part_controller_config
+    from robosuite.controllers.composite.composite_controller_factory import refactor_composite_controller_config
+
+    ccfg = refactor_composite_controller_config(load_part_controller_config(default_controller="JOINT_TORQUE"), "Baxter", ["right", "left"])
+    env = suite.make("TwoArmPegInHole", robots="Baxter", env_configuration="single-robot", gripper_types=None, controller_configs=ccfg,
+                     has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, control_freq=20, horizon=500, ignore_done=True, seed=seed)
+    env.reset()
+    mjcf.save_model(env.sim.model._model._flat, os.path.join(GOLD, f"peg_baxter_model_seed{seed}.rsim"))
+    print("baxter model seed", seed, "peg radius", env.sim.model._model._flat.geom_size[env.sim.model.geom_name2id("peg_g0")][0])
+
+
 def record_stack_resets(seeds):
     """Reset-path fixture (physics independent): qpos after make() (draw block 0) and after the first user reset() (block 1) per seed."""
     out = {}
@@ -379,6 +392,9 @@ if __name__ == "__main__":
         record_pickplace(seed=0, n_steps=20, action_scale=1.0, tag="seed0_full")
         record_pickplace_resets([0, 1, 2, 3])
         sys.exit(0)
+    if "--baxter-model-only" in sys.argv:
+        record_baxter_model(1)
+        sys.exit(0)
     if "--interp-only" in sys.argv:
         for ct in ("JOINT_POSITION", "JOINT_TORQUE", "OSC_POSITION"):
             record_lift_controller(seed=4, n_steps=30, action_scale=1.0, ctype=ct, interpolation="linear")
@@ -392,6 +408,7 @@ if __name__ == "__main__":
         record_baxter(seed=0, n_steps=30, action_scale=1.0, ctype="JOINT_POSITION")
         record_baxter(seed=0, n_steps=30, action_scale=1.0, ctype="JOINT_TORQUE")
         record_baxter(seed=0, n_steps=30, action_scale=1.0, ctype="JOINT_VELOCITY")
+        record_baxter_model(1)
         sys.exit(0)
     if "--stack-only" in sys.argv:
         record_stack(seed=0, n_steps=30, action_scale=1.0, tag="seed0_full")
