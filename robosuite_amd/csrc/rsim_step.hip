@@ -32,8 +32,9 @@
 #elif RSIM_CFG == 2  // 64 bodies x 16 dofs (Baxter: 36 bodies, 29 colliding geoms, 17 sites, 299 candidate pairs): tree products as mask loops, dense ones on one tile
 #define RSIM_DIMS 64, 16, 16, 32, 32, 32, 64, 320
 #define RSIM_SYM(x) x##_cfg2
-#else  // 64 bodies x 64 dofs (PickPlace / IIWA + Robotiq140: 36 bodies, 37 dofs, 41 colliding geoms, 622 candidate pairs, tendon rows)
-#define RSIM_DIMS 64, 32, 64, 64, 32, 32, 64, 640
+#else  // 64 bodies x 64 dofs x 128 constraint rows (PickPlace / IIWA + Robotiq140: 36 bodies, 37 dofs, 41 colliding geoms, 622 candidate pairs,
+       // tendon rows; a closed Robotiq gripper alone holds ~30 rows of self-contact)
+#define RSIM_DIMS 64, 32, 64, 64, 32, 32, 128, 640
 #define RSIM_SYM(x) x##_cfg3
 #endif
 
@@ -224,7 +225,7 @@ __device__ __forceinline__ Q4 ldq(gcf p) { Q4 q = {p[0], p[1], p[2], p[3]}; retu
 // ------------------------------------------------------------------------------------------------------------
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 struct Smem {
-  static_assert((NB == 32 || NB == 64) && (NV == 16 || NV == 32 || NV == 64) && NEFC == 64 && NG <= 64 && (NS == 16 || NS == 32) && NPAIR % 64 == 0 && NPAIR <= 640,
+  static_assert((NB == 32 || NB == 64) && (NV == 16 || NV == 32 || NV == 64) && (NEFC == 64 || NEFC == 128) && NG <= 64 && (NS == 16 || NS == 32) && NPAIR % 64 == 0 && NPAIR <= 640,
                 "lane roles: body / site / dof columns are powers of two, one lane per constraint row, candidate pairs in rows of 64");
   static constexpr bool TREE_TILE_ = NB == 32 && NV == 16;   // tree products as 32-body x 16-dof incidence-matrix MFMAs
   static constexpr int NVP = NV + 1;  // padded row stride of the dense nv x nv matrices (conflict-free column reads)
@@ -236,6 +237,9 @@ struct Smem {
   typedef typename std::conditional<(NV > 32), unsigned long long, unsigned>::type dmask_t;   // one bit per dof
   static constexpr int CD_ = 4;       // largest contact dimension this configuration handles (condim 1, 3, 4)
   static constexpr int NCON_ = NCON;
+  static constexpr int NEFC_ = NEFC;                    // constraint-row capacity: 64 (one row per lane) or 128 (two)
+  static constexpr bool HAS_LE_ = NV <= 32;             // keep the factor of M + hD next to the one of M (else Euler factors it again)
+  static constexpr int HULLPOOL_ = NV <= 32 ? RSIM_HULL_POOL : 0;   // LDS-resident hull vertices
   static constexpr int NB_ = NB;
   float qpos[NV + 8], qvel[NV], qacc[NV], qacc_ws[NV], ctrl[NV];
   float xpos[NB * 3], xquat[NB * 4];
@@ -258,7 +262,7 @@ struct Smem {
   float M[NV * NVP];
   union { float L[NV * NVP]; float H[NV * NVP]; };  // L (factor of M) is dead once qacc_smooth exists; H is the solver / Euler work matrix
   float invdiag[NV];
-  float Le[NV * NVP], invdiag_e[NV];   // Cholesky factor of M + h*diag(damping) (implicit-damping Euler), computed alongside L
+  float Le[HAS_LE_ ? NV * NVP : 1], invdiag_e[NV];   // Cholesky factor of M + h*diag(damping) (implicit-damping Euler), computed alongside L
   float qfrc_bias[NV], qfrc_passive[NV], qfrc_actuator[NV], qfrc_smooth[NV], qacc_smooth[NV], qfrc_constraint[NV];
   // per-launch staged constants that are read by lanes other than their owner
   float arm[NV];                 // dof armature (1 on padding rows: keeps the padded matrices SPD)
@@ -284,7 +288,7 @@ struct Smem {
   // wide configuration: tree incidence as bit masks (dof-ancestor set, dofs summed before dof i in the velocity recursion, body ancestors)
   dmask_t dmask_anc[NM_], dmask_cvel[NM_];
   unsigned long long bmask_anc[TREE_TILE_ ? 1 : NB];
-  float hull[3 * RSIM_HULL_POOL];   // LDS-resident hull vertex pool (SoA x | y | z); filled once per launch
+  float hull[3 * HULLPOOL_ + 1];    // LDS-resident hull vertex pool (SoA x | y | z); filled once per launch
   int ghull[NG];                    // first pool slot of geom g, -1: not resident
   // per-lane model constants, one row per field (LaneConst below); phases fetch the handful they need instead of pinning ~80 VGPRs
   float kc[RSIM_KC_WORDS(NB, NV, NGW_, NS, NPAIR)];
@@ -441,12 +445,14 @@ __device__ __forceinline__ void chol_factor(float* L, float* invdiag, const floa
 template <int NVP>
 __device__ __forceinline__ void chol_inplace(float* L, float* invdiag, int n, int lane) {
   for (int j = 0; j < n; j++) {
-    float s = 0.f;
+    float s = 0.f, d0 = 0.f;
     if (lane >= j && lane < n) {
-      s = L[lane * NVP + j];
+      s = d0 = L[lane * NVP + j];
       for (int k = 0; k < j; k++) s -= L[lane * NVP + k] * L[j * NVP + k];
     }
-    const float sj = bcast(s, j);
+    // fp32 safeguard: a pivot that cancelled below 1e-6 of its diagonal entry is rounding noise (nearly dependent constraint rows on links of
+    // 5e-5 kg m^2); flooring it there keeps the factor finite and the Newton direction a descent direction.  Inactive on well-conditioned H.
+    const float sj = fmaxf(bcast(s, j), 1e-6f * bcast(d0, j));
     const float inv = rsqrtf(fmaxf(sj, FMIN));
     if (lane >= j && lane < n) L[lane * NVP + j] = (lane == j) ? sj * inv : s * inv;
     if (lane == 0) invdiag[j] = inv;
@@ -523,7 +529,7 @@ __device__ __forceinline__ V3 geom_support(int g, V3 dir, gcf mesh_vert, int lan
         const int i = 64 * u + lane;
         if (64 * u < num) {
           const int ii = i < num ? i : 0;
-          const float x = hv[ii], y = hv[RSIM_HULL_POOL + ii], z = hv[2 * RSIM_HULL_POOL + ii];
+          const float x = hv[ii], y = hv[Smem0::HULLPOOL_ + ii], z = hv[2 * Smem0::HULLPOOL_ + ii];
           const float val = x * ld.x + y * ld.y + z * ld.z;
           if (i < num && val > bv) { bv = val; bi = i; bx = x; by = y; bz = z; }
         }
@@ -608,6 +614,8 @@ struct Sim {
   static constexpr bool TREE = SM::TREE_TILE_;  // tree products (CRBA composite inertias, RNE sums) as incidence-matrix MFMAs
   static constexpr int NPT = SM::NPT_;          // rows of 64 candidate pairs
   static constexpr int NROOT = SM::NROOT_;
+  static constexpr int NSLOT = SM::NEFC_ / 64;  // constraint rows per lane (row r lives in lane r & 63, slot r >> 6)
+  static constexpr int NEFCAP = SM::NEFC_;
   static constexpr bool TENDONS = SM::TENDONS_;
   typedef typename SM::dmask_t dmask_t;
   __device__ __forceinline__ dmask_t dmask_load(int tab, int i) const {   // dof bit mask i of an int-table entry stored as two 32-bit words
@@ -750,7 +758,7 @@ struct Sim {
         for (int k = 0; k < 8; k++) sm.gcap[8 * g + k] = FP(FO_cg_capsule, 8 * g + k);
         sm.gcp[g] = IT(IO_cg_condim, g) | (IT(IO_cg_priority, g) << 8);
         sm.gmesh[g] = IT(IO_cg_meshadr, g) | (IT(IO_cg_meshnum, g) << 16);
-        sm.ghull[g] = lt[LT_ghull * 64 + lane];
+        sm.ghull[g] = SM::HULLPOOL_ ? lt[LT_ghull * 64 + lane] : -1;   // configurations without a resident pool scan every hull from global memory
         float* gp = sm.gpar + 12 * g;
         for (int k = 0; k < 3; k++) gp[k] = FP(FO_cg_friction, 3 * g + k);
         gp[3] = FP(FO_cg_solref, 2 * g); gp[4] = FP(FO_cg_solref, 2 * g + 1);
@@ -785,7 +793,7 @@ struct Sim {
       if (pool < 0) continue;
       const int adr = sm.gmesh[g] & 0xffff, num = sm.gmesh[g] >> 16;
       gcf mvp = (gcf)m.mesh_vert + 3 * adr;
-      for (int i = lane; i < num; i += 64) { sm.hull[pool + i] = mvp[3 * i]; sm.hull[RSIM_HULL_POOL + pool + i] = mvp[3 * i + 1]; sm.hull[2 * RSIM_HULL_POOL + pool + i] = mvp[3 * i + 2]; }
+      for (int i = lane; i < num; i += 64) { sm.hull[pool + i] = mvp[3 * i]; sm.hull[SM::HULLPOOL_ + pool + i] = mvp[3 * i + 1]; sm.hull[2 * SM::HULLPOOL_ + pool + i] = mvp[3 * i + 2]; }
     }
     SYNC();
   }
@@ -952,12 +960,19 @@ struct Sim {
     }
     SYNC();
     const float hd = lane < nv ? opt_h * K.damping : 0.f;
-    for (int e = lane; e < nv * nv; e += 64) { const int i = e / nv, j = e - i * nv; const float v = sm.M[i * NVP + j]; sm.L[i * NVP + j] = v; sm.Le[i * NVP + j] = v; }
+    for (int e = lane; e < nv * nv; e += 64) {
+      const int i = e / nv, j = e - i * nv;
+      const float v = sm.M[i * NVP + j];
+      sm.L[i * NVP + j] = v;
+      if constexpr (SM::HAS_LE_) sm.Le[i * NVP + j] = v;
+    }
     SYNC();
-    if (lane < nv) sm.Le[lane * NVP + lane] += hd;
-    SYNC();
+    if constexpr (SM::HAS_LE_) {
+      if (lane < nv) sm.Le[lane * NVP + lane] += hd;
+      SYNC();
+    }
     chol_inplace<NVP>(sm.L, sm.invdiag, nv, lane);
-    chol_inplace<NVP>(sm.Le, sm.invdiag_e, nv, lane);
+    if constexpr (SM::HAS_LE_) chol_inplace<NVP>(sm.Le, sm.invdiag_e, nv, lane);
   }
 
   __device__ __forceinline__ void crb() {
@@ -1641,10 +1656,10 @@ struct Sim {
       const u64 mk = __ballot(act);
       if (act) {
         const int r = nefc + __popcll(mk & lanemask_lt(lane));
-        if (r < 64) { sm.e_desc[r] = C_FRICTION_DOF | (lane << 4); sm.e_R[r] = sm.fricR[lane]; sm.e_B[r] = sm.fricB[lane]; sm.e_aref[r] = 0.f; }
+        if (r < NEFCAP) { sm.e_desc[r] = C_FRICTION_DOF | (lane << 4); sm.e_R[r] = sm.fricR[lane]; sm.e_B[r] = sm.fricB[lane]; sm.e_aref[r] = 0.f; }
       }
       nefc += __popcll(mk);
-      if (nefc > 64) nefc = 64;   // one lane per row: rows beyond 64 are dropped (never reached by the BASELINE models)
+      if (nefc > NEFCAP) nefc = NEFCAP;   // rows beyond the capacity (64 or 128) are dropped
     }
     // (2) joint limits: dof lane i owns its hinge / slide joint; lower side before upper side
     {
@@ -1659,16 +1674,16 @@ struct Sim {
         const int r = nefc + before;
         float R, Bd, Kt;
         row_scalars(dlo, K.jmargin, solref, solimp, K.dinvw, R, Bd, Kt);
-        if (r < 64) { sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (0 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
+        if (r < NEFCAP) { sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (0 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
       }
       if (ahi) {
         const int r = nefc + before + (alo ? 1 : 0);
         float R, Bd, Kt;
         row_scalars(dhi, K.jmargin, solref, solimp, K.dinvw, R, Bd, Kt);
-        if (r < 64) { sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (1 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
+        if (r < NEFCAP) { sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (1 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
       }
       nefc += __popcll(mlo) + __popcll(mhi);
-      if (nefc > 64) nefc = 64;
+      if (nefc > NEFCAP) nefc = NEFCAP;
     }
     // (2b) limits on fixed-tendon lengths: lane t owns tendon t, lower side before upper side
     if (TENDONS && m.ntendon) {
@@ -1687,16 +1702,16 @@ struct Sim {
         const int r = nefc + before;
         float R, Bd, Kt;
         row_scalars(dlo, margin, solref, solimp, invw, R, Bd, Kt);
-        if (r < 64) { sm.e_desc[r] = C_LIMIT_TENDON | (lane << 4) | (0 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
+        if (r < NEFCAP) { sm.e_desc[r] = C_LIMIT_TENDON | (lane << 4) | (0 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
       }
       if (ahi) {
         const int r = nefc + before + (alo ? 1 : 0);
         float R, Bd, Kt;
         row_scalars(dhi, margin, solref, solimp, invw, R, Bd, Kt);
-        if (r < 64) { sm.e_desc[r] = C_LIMIT_TENDON | (lane << 4) | (1 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
+        if (r < NEFCAP) { sm.e_desc[r] = C_LIMIT_TENDON | (lane << 4) | (1 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
       }
       nefc += __popcll(mlo) + __popcll(mhi);
-      if (nefc > 64) nefc = 64;
+      if (nefc > NEFCAP) nefc = NEFCAP;
     }
     // (3) contacts: lane c owns contact c; exclusive scan of the active dimensions gives the first row of each block
     {
@@ -1708,7 +1723,7 @@ struct Sim {
 #pragma unroll
       for (int o = 1; o < SM::NCON_; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
       int first = nefc + incl - need;
-      const bool fits = active && first + dim <= 64;   // NEFC: one lane per row
+      const bool fits = active && first + dim <= NEFCAP;
       // a block that does not fit is dropped together with everything after it (rows must stay contiguous)
       const u64 bad = __ballot(active && !fits);
       const bool keep = fits && (bad == 0 || lane < (__ffsll((long long)bad) - 1));
@@ -1741,10 +1756,12 @@ struct Sim {
     }
     if (lane == 0) sm.nefc = nefc;
     SYNC();
-    // ---- lane r builds row r
-    {
-      const bool valid = lane < nefc;
-      const int desc = valid ? sm.e_desc[lane] : 0;
+    // ---- lane r builds row r (and row r + 64 in the 128-row configuration)
+#pragma unroll
+    for (int slot = 0; slot < NSLOT; slot++) {
+      const int row = lane + 64 * slot;
+      const bool valid = row < nefc;
+      const int desc = valid ? sm.e_desc[row] : 0;
       const int type = desc & 15, id = (desc >> 4) & 255, kk = (desc >> 12) & 15;
       float Jr[NV16];
 #pragma unroll
@@ -1787,8 +1804,8 @@ struct Sim {
       }
       float jv = 0.f;
 #pragma unroll
-      for (int k = 0; k < NV16; k++) { sm.J[lane * JS + k] = Jr[k]; jv = fmaf(Jr[k], sm.qvel[k], jv); }
-      if (valid) sm.e_aref[lane] = -sm.e_B[lane] * jv - sm.e_aref[lane];
+      for (int k = 0; k < NV16; k++) { sm.J[row * JS + k] = Jr[k]; jv = fmaf(Jr[k], sm.qvel[k], jv); }
+      if (valid) sm.e_aref[row] = -sm.e_B[row] * jv - sm.e_aref[row];
     }
     SYNC();
   }
@@ -1833,7 +1850,17 @@ struct Sim {
     const int nv = m.nv;
     const float h = opt_h;
     float qa;
-    if constexpr (!FAST) qa = chol_solve<NVP>(sm.Le, sm.invdiag_e, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, nv, lane);
+    if constexpr (!FAST && !SM::HAS_LE_) {
+      // the factor of M + h diag(damping) is not kept in this configuration: build it in the solver's (now free) work matrix
+      const float hd = lane < nv ? h * K.damping : 0.f;
+      SYNC();
+      for (int e = lane; e < nv * nv; e += 64) { const int i = e / nv, j = e - i * nv; sm.H[i * NVP + j] = sm.M[i * NVP + j]; }
+      SYNC();
+      if (lane < nv) sm.H[lane * NVP + lane] += hd;
+      SYNC();
+      chol_inplace<NVP>(sm.H, sm.invdiag_e, nv, lane);
+      qa = chol_solve<NVP>(sm.H, sm.invdiag_e, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, nv, lane);
+    } else if constexpr (!FAST) qa = chol_solve<NVP>(sm.Le, sm.invdiag_e, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, nv, lane);
     else {
       float lr[NV16], lt[NV16], linv[NV16];
       const int rr = lane & (NV16 - 1);
@@ -2162,34 +2189,51 @@ struct Sim {
   // H = M + J^T W and J^T f run on the matrix cores (v_mfma_f32_16x16x4_f32, 4 rows per instruction); the Hessian
   // factorisation is the register-resident Cholesky above.  Algorithm = oracle solve_newton (MuJoCo's primal Newton).
   struct Row {
-    float J[NV16];
+    float J[FAST ? NV16 : 1];   // one-tile configuration: the Jacobian row stays in registers; wide configurations read it from LDS
     float D, R, aref, fl, mu, fr_own, Dm;
     float fj[CD - 1];
-    int type, head, kk, dim;
+    int row, type, head, kk, dim;
     bool valid, ell;
   };
   // sum_k r[k] * x_k.  One-tile configuration: x is replicated in every 16-lane row (DPP row broadcast); wide: x_k lives in lane k (readlane)
-  __device__ __forceinline__ float vec_dot(const float (&r)[NV16], float x) const {
-    if constexpr (FAST) return dot_rows<NV16>(r, x);
+  __device__ __forceinline__ float row_dot(const Row& rw, float x) const {
+    if constexpr (FAST) return dot_rows<NV16>(rw.J, x);
     else {
+      const float* Jr = sm.J + rw.row * JS;
       float acc = 0.f;
-#pragma unroll
-      for (int k = 0; k < NV16; k++) acc = fmaf(r[k], bcast(x, k), acc);
+      for (int k = 0; k < m.nv; k++) acc = fmaf(Jr[k], bcast(x, k), acc);
       return acc;
     }
   }
-  __device__ __forceinline__ float row_dot(const Row& rw, float x) const { return vec_dot(rw.J, x); }
-  // gather the block's friction-scaled values: out[j] = (x * fr_own) of lane head + j
-  __device__ __forceinline__ void gather(const Row& rw, float x, float (&out)[CD]) const {
-    float u = x * rw.fr_own;
+  // (M x)_i for the dof of this lane
+  __device__ __forceinline__ float mass_dot(const float (&Mr)[FAST ? NV16 : 1], float x) const {
+    if constexpr (FAST) return dot_rows<NV16>(Mr, x);
+    else {
+      const float* Mi = sm.M + (lane < m.nv ? lane : 0) * NVP;
+      float acc = 0.f;
+      for (int k = 0; k < m.nv; k++) acc = fmaf(Mi[k], bcast(x, k), acc);
+      return lane < m.nv ? acc : 0.f;
+    }
+  }
+  // gather every block's friction-scaled values: out[s][j] = (x * fr_own) of row head(s) + j, which lives in lane (head + j) & 63, slot (head + j) >> 6
+  __device__ __forceinline__ void gather(const Row (&rw)[NSLOT], const float (&x)[NSLOT], float (&out)[NSLOT][CD]) const {
+    float u[NSLOT];
 #pragma unroll
-    for (int j = 0; j < CD; j++) { float t = __shfl(u, rw.head + j); out[j] = (rw.ell && j < rw.dim) ? t : 0.f; }
+    for (int s = 0; s < NSLOT; s++) u[s] = x[s] * rw[s].fr_own;
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++)
+#pragma unroll
+      for (int j = 0; j < CD; j++) {
+        const int R = rw[s].head + j;
+        float t = __shfl(u[0], R & 63);
+        if constexpr (NSLOT > 1) { const float t1 = __shfl(u[NSLOT - 1], R & 63); t = (R >> 6) ? t1 : t; }
+        out[s][j] = (rw[s].ell && j < rw[s].dim) ? t : 0.f;
+      }
   }
   // force / state / cost of this lane's row at residual jar (siblings of an elliptic block agree on the zone)
-  __device__ __forceinline__ float row_update(const Row& rw, float x, float& force, int& state, float (&uj)[CD], float& T, float& g) const {
+  __device__ __forceinline__ float row_update(const Row& rw, float x, float& force, int& state, const float (&uj)[CD], float& T, float& g) const {
     float cost = 0.f;
     force = 0.f; state = ST_SATISFIED; T = 0.f; g = 0.f;
-    gather(rw, x, uj);
     if (!rw.valid) return 0.f;
     if (rw.type == C_FRICTION_DOF) {
       if (x <= -rw.R * rw.fl) { state = ST_LINEARNEG; force = rw.fl; cost = rw.fl * (-0.5f * rw.R * rw.fl - x); }
@@ -2267,88 +2311,128 @@ struct Sim {
     const int nch = (n + 3) >> 2;
     const float scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
     const float tolerance = m.tolerance;
-    // ---- per-lane row registers
-    Row rw;
-    rw.valid = lane < n;
-    {
-      const int r = rw.valid ? lane : 0;
+    // ---- per-lane row data (NSLOT rows per lane)
+    Row rw[NSLOT];
 #pragma unroll
-      for (int k = 0; k < NV16; k++) rw.J[k] = sm.J[lane * JS + k];  // rows >= n were written as zeros
-      const int desc = rw.valid ? sm.e_desc[r] : 0;
-      rw.type = rw.valid ? (desc & 15) : -1;
-      rw.R = sm.e_R[r]; rw.D = 1.0f / rw.R; rw.aref = rw.valid ? sm.e_aref[r] : 0.f; rw.fl = rw.type == C_FRICTION_DOF ? sm.fricFl[(desc >> 4) & 255] : 0.f;
-      rw.ell = rw.type == C_CONTACT_ELLIPTIC;
-      const int c = rw.ell ? (desc >> 4) & 255 : 0;
-      rw.kk = rw.ell ? (desc >> 12) & 15 : 0; rw.head = lane - rw.kk; rw.dim = rw.ell ? sm.cdim[c] : 1;
-      rw.mu = sm.cmu[c];
+    for (int s = 0; s < NSLOT; s++) {
+      Row& w_ = rw[s];
+      const int row = lane + 64 * s;
+      w_.row = row;
+      w_.valid = row < n;
+      const int r = w_.valid ? row : 0;
+      if constexpr (FAST) {
 #pragma unroll
-      for (int j = 0; j < CD - 1; j++) rw.fj[j] = sm.cfri[5 * c + j];
-      rw.fr_own = rw.kk == 0 ? rw.mu : sm.cfri[5 * c + rw.kk - 1];
-      rw.Dm = (1.0f / sm.e_R[rw.ell ? rw.head : r]) / fmaxf(rw.mu * rw.mu * (1 + rw.mu * rw.mu), 1e-15f);
+        for (int k = 0; k < NV16; k++) w_.J[k] = sm.J[row * JS + k];  // rows >= n were written as zeros
+      }
+      const int desc = w_.valid ? sm.e_desc[r] : 0;
+      w_.type = w_.valid ? (desc & 15) : -1;
+      w_.R = sm.e_R[r]; w_.D = 1.0f / w_.R; w_.aref = w_.valid ? sm.e_aref[r] : 0.f; w_.fl = w_.type == C_FRICTION_DOF ? sm.fricFl[(desc >> 4) & 255] : 0.f;
+      w_.ell = w_.type == C_CONTACT_ELLIPTIC;
+      const int c = w_.ell ? (desc >> 4) & 255 : 0;
+      w_.kk = w_.ell ? (desc >> 12) & 15 : 0; w_.head = row - w_.kk; w_.dim = w_.ell ? sm.cdim[c] : 1;
+      w_.mu = sm.cmu[c];
+#pragma unroll
+      for (int j = 0; j < CD - 1; j++) w_.fj[j] = sm.cfri[5 * c + j];
+      w_.fr_own = w_.kk == 0 ? w_.mu : sm.cfri[5 * c + w_.kk - 1];
+      w_.Dm = (1.0f / sm.e_R[w_.ell ? w_.head : r]) / fmaxf(w_.mu * w_.mu * (1 + w_.mu * w_.mu), 1e-15f);
     }
     // M: row i in lane i (matrix-vector products) and in the MFMA accumulator layout (Hessian seed)
     // per-dof vectors (a, gradient, search direction): one-tile configuration = replicated in all four 16-lane rows and reduced over the
     // first row only; wide = component k in lane k
     const int rr = FAST ? (lane & 15) : lane;
     const bool dofl = lane < NV16;
-    float Mr[NV16];
-#pragma unroll
-    for (int k = 0; k < NV16; k++) Mr[k] = (rr < nv && k < nv) ? sm.M[rr * NVP + k] : 0.f;
+    float Mr[FAST ? NV16 : 1];
     v4f Macc = {0.f, 0.f, 0.f, 0.f};
     if constexpr (FAST) {
+#pragma unroll
+      for (int k = 0; k < NV16; k++) Mr[k] = (rr < nv && k < nv) ? sm.M[rr * NVP + k] : 0.f;
 #pragma unroll
       for (int v = 0; v < 4; v++) { int i = 4 * (lane >> 4) + v, j = lane & 15; Macc[v] = (i < nv && j < nv) ? sm.M[i * NVP + j] : (i == j ? 1.f : 0.f); }
     }
     const float a_sm = rr < nv ? sm.qacc_smooth[rr] : 0.f, a_ws = rr < nv ? sm.qacc_ws[rr] : 0.f, f_sm = rr < nv ? sm.qfrc_smooth[rr] : 0.f;
-    float force; int state; float uj[CD], T, g;
+    float force[NSLOT], jar[NSLOT], uj[NSLOT][CD], T[NSLOT], g[NSLOT];
+    int state[NSLOT];
+    // residuals of all rows of this lane at acceleration x, then cost / force / state of each (the cone blocks gather their siblings first)
+    auto evaluate = [&](float x) -> float {
+#pragma unroll
+      for (int s = 0; s < NSLOT; s++) jar[s] = row_dot(rw[s], x) - rw[s].aref;
+      gather(rw, jar, uj);
+      float c = 0.f;
+#pragma unroll
+      for (int s = 0; s < NSLOT; s++) c += row_update(rw[s], jar[s], force[s], state[s], uj[s], T[s], g[s]);
+      return c;
+    };
     // ---- warm start: previous acceleration unless the unconstrained one is cheaper
-    float cost_sm = wave_sum(row_update(rw, row_dot(rw, a_sm) - rw.aref, force, state, uj, T, g));
-    float cost_ws = wave_sum(row_update(rw, row_dot(rw, a_ws) - rw.aref, force, state, uj, T, g));
+    float cost_sm = wave_sum(evaluate(a_sm));
+    float cost_ws = wave_sum(evaluate(a_ws));
     {
-      const float dws = a_ws - a_sm, sv = vec_dot(Mr, dws);
+      const float dws = a_ws - a_sm, sv = mass_dot(Mr, dws);
       cost_ws += wave_sum(dofl ? 0.5f * sv * dws : 0.f);
     }
     float a = cost_ws < cost_sm ? a_ws : a_sm;
     int iter = 0;
-    float jar = 0.f;
     for (;;) {
-      jar = row_dot(rw, a) - rw.aref;
-      float cost = wave_sum(row_update(rw, jar, force, state, uj, T, g));
-      const float ma = vec_dot(Mr, a);
+      float cost = wave_sum(evaluate(a));
+      const float ma = mass_dot(Mr, a);
       const float gauss = wave_sum(dofl ? 0.5f * (ma - f_sm) * (a - a_sm) : 0.f);
       cost += gauss;
-      sm.e_force[lane] = force;
+#pragma unroll
+      for (int s = 0; s < NSLOT; s++) sm.e_force[lane + 64 * s] = force[s];
       SYNC();
       const float jf = jt_times_force(nch);
       float gk = rr < nv ? ma - f_sm - jf : 0.f;
       const float gn = wave_sum(dofl ? gk * gk : 0.f);
       if (iter >= m.iterations || scale * sqrtf(gn) < tolerance) break;
       // ---- Hessian weights W (row r): D J_r (quadratic), 0 (linear / satisfied), cone block Hc J_block
-      {
-        float w[NV16];
-        const float dq = state == ST_QUADRATIC ? rw.D : 0.f;
 #pragma unroll
-        for (int k = 0; k < NV16; k++) w[k] = dq * rw.J[k];
-        if (state == ST_CONE) {
-          const float mu = rw.mu, iT = 1.0f / T;
-          const float uo = jar * rw.fr_own;  // own friction-scaled residual U_kk
-          const float grj = rw.kk == 0 ? mu : -mu * uo * rw.fr_own * iT;
+      for (int s = 0; s < NSLOT; s++) {
+        const Row& w_ = rw[s];
+        const float dq = state[s] == ST_QUADRATIC ? w_.D : 0.f;
+        float hk[CD];
+#pragma unroll
+        for (int k2 = 0; k2 < CD; k2++) hk[k2] = 0.f;
+        if (state[s] == ST_CONE) {
+          const float mu = w_.mu, iT = 1.0f / T[s];
+          const float uo = jar[s] * w_.fr_own;  // own friction-scaled residual U_kk
+          const float grj = w_.kk == 0 ? mu : -mu * uo * w_.fr_own * iT;
 #pragma unroll
           for (int k2 = 0; k2 < CD; k2++) {
-            if (k2 < rw.dim) {
-              const float frk = k2 == 0 ? mu : rw.fj[k2 > 0 ? k2 - 1 : 0];
-              const float grk = k2 == 0 ? mu : -mu * uj[k2] * frk * iT;
+            if (k2 < w_.dim) {
+              const float frk = k2 == 0 ? mu : w_.fj[k2 > 0 ? k2 - 1 : 0];
+              const float grk = k2 == 0 ? mu : -mu * uj[s][k2] * frk * iT;
               float h = grj * grk;
-              if (rw.kk > 0 && k2 > 0) h += -g * mu * rw.fr_own * frk * ((rw.kk == k2 ? iT : 0.f) - uo * uj[k2] * iT * iT * iT);
-              h *= rw.Dm;
-              const float* Js = sm.J + (rw.head + k2) * JS;
-#pragma unroll
-              for (int k = 0; k < NV16; k++) w[k] = fmaf(h, Js[k], w[k]);
+              if (w_.kk > 0 && k2 > 0) h += -g[s] * mu * w_.fr_own * frk * ((w_.kk == k2 ? iT : 0.f) - uo * uj[s][k2] * iT * iT * iT);
+              hk[k2] = h * w_.Dm;
             }
           }
         }
+        if constexpr (FAST) {
+          float w[NV16];
 #pragma unroll
-        for (int k = 0; k < NV16; k++) sm.u.W[lane * JS + k] = w[k];
+          for (int k = 0; k < NV16; k++) w[k] = dq * w_.J[k];
+          if (state[s] == ST_CONE) {
+#pragma unroll
+            for (int k2 = 0; k2 < CD; k2++) {
+              if (k2 < w_.dim) {
+                const float* Js = sm.J + (w_.head + k2) * JS;
+#pragma unroll
+                for (int k = 0; k < NV16; k++) w[k] = fmaf(hk[k2], Js[k], w[k]);
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < NV16; k++) sm.u.W[w_.row * JS + k] = w[k];
+        } else {
+          const float* Jo = sm.J + w_.row * JS;
+          const float* Jh = sm.J + (state[s] == ST_CONE ? w_.head : w_.row) * JS;
+          float* Wo = sm.u.W + w_.row * JS;
+          for (int k = 0; k < NV16; k++) {
+            float w = dq * Jo[k];
+#pragma unroll
+            for (int k2 = 0; k2 < CD; k2++) if (k2 < w_.dim) w = fmaf(hk[k2], Jh[k2 * JS + k], w);   // hk = 0 outside the cone state
+            Wo[k] = w;
+          }
+        }
       }
       SYNC();
       float sk;
@@ -2371,15 +2455,15 @@ struct Sim {
         sk = chol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -gk : 0.f, nv, lane);
         if (lane >= nv) sk = 0.f;
       } else {
-      v4f acc = Macc;
-      for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.u.W[(4 * c + (lane >> 4)) * JS + (lane & 15)], sm.J[(4 * c + (lane >> 4)) * JS + (lane & 15)], acc, 0, 0, 0);
+        v4f acc = Macc;
+        for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.u.W[(4 * c + (lane >> 4)) * JS + (lane & 15)], sm.J[(4 * c + (lane >> 4)) * JS + (lane & 15)], acc, 0, 0, 0);
 #pragma unroll
-      for (int v = 0; v < 4; v++) sm.H[(4 * (lane >> 4) + v) * NVP + (lane & 15)] = acc[v];
-      SYNC();
+        for (int v = 0; v < 4; v++) sm.H[(4 * (lane >> 4) + v) * NVP + (lane & 15)] = acc[v];
+        SYNC();
         float hr[NV16], hinv[NV16], ht[NV16];
-        const int rr = lane & 15;
+        const int rr2 = lane & 15;
 #pragma unroll
-        for (int k = 0; k < NV16; k++) hr[k] = sm.H[rr * NVP + k];
+        for (int k = 0; k < NV16; k++) hr[k] = sm.H[rr2 * NVP + k];
         rchol_factor<NV16>(hr, hinv);
         SYNC();
         if (lane < NV16) {
@@ -2388,23 +2472,31 @@ struct Sim {
         }
         SYNC();
 #pragma unroll
-        for (int k = 0; k < NV16; k++) ht[k] = sm.H[k * NVP + rr];
-        sk = rchol_solve<NV16>(hr, ht, hinv, rr < nv ? -gk : 0.f, lane);
-        if (rr >= nv) sk = 0.f;
+        for (int k = 0; k < NV16; k++) ht[k] = sm.H[k * NVP + rr2];
+        sk = rchol_solve<NV16>(hr, ht, hinv, rr2 < nv ? -gk : 0.f, lane);
+        if (rr2 >= nv) sk = 0.f;
       }
       // ---- line search along sk
-      const float jv = row_dot(rw, sk);
-      const float mvv = vec_dot(Mr, sk);
+      float jv[NSLOT];
+#pragma unroll
+      for (int s = 0; s < NSLOT; s++) jv[s] = row_dot(rw[s], sk);
+      const float mvv = mass_dot(Mr, sk);
       const float q1 = wave_sum(dofl ? sk * (ma - f_sm) : 0.f), q2 = wave_sum(dofl ? 0.5f * sk * mvv : 0.f), sn = sqrtf(wave_sum(dofl ? sk * sk : 0.f));
       if (sn < 1e-15f) break;
-      float g0[CD], gvv[CD];
+      float g0[NSLOT][CD], gvv[NSLOT][CD];
       gather(rw, jar, g0);
       gather(rw, jv, gvv);
       const float gtol = tolerance * 0.01f * sn / scale;
       float p0, d0, h0, p, dp, hp, lo = 0.f, hi = -1.f, alpha;
+      // cost and its first two derivatives along the search direction, summed over this lane's rows
+      auto line = [&](float al, float& c, float& c1, float& c2) {
+        c = c1 = c2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSLOT; s++) { float t, t1, t2; row_ls(rw[s], jar[s], jv[s], g0[s], gvv[s], al, t, t1, t2); c += t; c1 += t1; c2 += t2; }
+      };
       {
         float c, c1, c2;
-        row_ls(rw, jar, jv, g0, gvv, 0.f, c, c1, c2);
+        line(0.f, c, c1, c2);
         p0 = gauss + wave_sum(c); d0 = q1 + wave_sum(c1); h0 = 2 * q2 + wave_sum(c2);
       }
       if (d0 >= 0 || h0 <= 0) break;
@@ -2415,7 +2507,7 @@ struct Sim {
       for (int ls = 0; ls < m.ls_iterations; ls++) {
         pf.count(RP_N_LS, 1);
         float c, c1, c2;
-        row_ls(rw, jar, jv, g0, gvv, alpha, c, c1, c2);
+        line(alpha, c, c1, c2);
         p = gauss + alpha * q1 + alpha * alpha * q2 + wave_sum(c);
         dp = q1 + 2 * alpha * q2 + wave_sum(c1);
         hp = 2 * q2 + wave_sum(c2);
@@ -2429,19 +2521,19 @@ struct Sim {
       }
       {
         float c, c1, c2;
-        row_ls(rw, jar, jv, g0, gvv, alpha, c, c1, c2);
+        line(alpha, c, c1, c2);
         p = gauss + alpha * q1 + alpha * alpha * q2 + wave_sum(c);
       }
       if (!(p < p0)) break;
       a = fmaf(alpha, sk, a);
       iter++;
       if (scale * (p0 - p) < tolerance) {
-        jar = row_dot(rw, a) - rw.aref;
-        row_update(rw, jar, force, state, uj, T, g);
+        evaluate(a);
         break;
       }
     }
-    sm.e_force[lane] = force;
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) sm.e_force[lane + 64 * s] = force[s];
     SYNC();
     const float fc = jt_times_force(nch);
     if (lane < nv) { sm.qfrc_constraint[lane] = fc; sm.qacc[lane] = a; }

@@ -131,8 +131,8 @@ def test_long_random_rollouts_stay_finite_on_every_configuration(name, tag, mode
             assert float(rew.min()) >= 0.0 and float(rew.max()) <= 1.0 + 1e-6
     assert ndone == B                                  # one horizon crossing per env
     assert np.isfinite(env.env.batch.get("qpos")).all() and np.isfinite(env.env.batch.get("qvel")).all()
-    # MuJoCo's bad-state guard (RSIM_DIVERGED) must stay silent on the table-top tasks.  PickPlace under full-range random actions closes the
-    # Robotiq gripper on itself while the arm rams the bins: beyond 64 constraint rows (the oracle counts up to 75 there) contacts are dropped,
-    # and a few envs blow up and are put back to qpos0 exactly as MuJoCo would do with a diverged state.
+    # MuJoCo's bad-state guard (RSIM_DIVERGED) must stay silent on the table-top tasks.  PickPlace under full-range random actions drives the
+    # closed Robotiq gripper (5e-5 kg m^2 links, no damping) into the bin at > 10 rad/s with 80 constraint rows: the fp64 oracle rides such states
+    # out, the fp32 kernel occasionally does not; the guard then puts the env back to qpos0 as MuJoCo does with a diverged state.
     nbad = int((env.env.batch.get("diverged") > 0).sum())
-    assert nbad == 0 if name != "PickPlace" else nbad <= B // 10
+    assert nbad == 0 if name != "PickPlace" else nbad <= max(2, B // 50)

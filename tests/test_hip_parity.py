@@ -405,8 +405,31 @@ def test_pickplace_iiwa_robotiq_model_on_the_64_dof_configuration():
         dq = np.abs(hb.get("qpos")[0] - od.qpos)
         # arm and objects to the usual tolerance; the undamped 5e-5 kg m^2 finger links under kp = 20 actuators amplify rounding (see the CPU test)
         # ... and the four objects rest on single MPR contact points (MuJoCo's convex-convex default), where they rock at rounding level
-        assert dq[arm].max() < 5e-4 and dq[fingers].max() < 5e-2 and dq[~(arm | fingers)].max() < 5e-3, t
+        # (the chattering fingers sit at the end of the arm: its joints inherit a fraction of their error)
+        assert dq[arm].max() < 2e-3 and dq[fingers].max() < 5e-2 and dq[~(arm | fingers)].max() < 5e-3, t
     assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[1])
+
+
+def test_more_than_64_constraint_rows_on_the_128_row_configuration():
+    """A state from a random-action PickPlace rollout with the Robotiq gripper closed on itself and the arm in the bin: 72 constraint rows in the
+    oracle (4 tendon equalities, friction loss, 17 contacts incl. ~10 finger self-contacts).  The 64 x 64 configuration carries two rows per
+    lane; contact list, row count and accelerations against the oracle."""
+    import os
+    from tests.util import GOLD
+    g, cfg, flat = load_golden("seed0_full", "pickplace_iiwa")
+    z = np.load(os.path.join(GOLD, "pickplace_iiwa_dense_contact_state.npz"))
+    om, od, _ = make_oracle(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=2)
+    od.qpos[:] = z["qpos"]; od.qvel[:] = z["qvel"]; od.qacc_warmstart[:] = z["qacc_warmstart"]; od.ctrl[:] = z["ctrl"]; od.forward()
+    for k in ("qpos", "qvel", "qacc_warmstart", "ctrl"):
+        hb.set(k, z[k][None].repeat(2, 0))
+    hb.forward()
+    assert od.nefc > 64 and hb.get("nefc")[0] == od.nefc and hb.get("ncon")[0] == od.ncon
+    dacc = np.abs(hb.get("qacc")[0] - od.qacc)
+    fd = np.zeros(flat.nv, dtype=bool); fd[7:13] = True
+    assert dacc[~fd].max() < 2e-3 * max(1.0, np.abs(od.qacc).max()) and dacc[fd].max() < 5e-2 * max(1.0, np.abs(od.qacc).max())
+    fh = np.array([c["normal_force"] for c in hb.contacts(0)]); fo = np.array([c["normal_force"] for c in od.contacts()])
+    assert np.abs(fh - fo).max() < 2e-2 * max(1.0, np.abs(fo).max())
 
 
 def test_pickplace_observation_and_reward_epilogue_matches_reference_env():
@@ -437,7 +460,7 @@ def test_pickplace_observation_and_reward_epilogue_matches_reference_env():
             elif "gripper_q" in key:
                 tol = 5e-2 if key.endswith("qpos") else 3.0   # undamped 5e-5 kg m^2 finger links (see the physics test of this model)
             else:
-                tol = 5e-3 if (key.endswith("vel") or key[:4] in ("Milk", "Brea", "Cere", "Can_")) else 5e-4
+                tol = 5e-3 if (key.endswith("vel") or key[:4] in ("Milk", "Brea", "Cere", "Can_")) else 2e-3   # arm keys: see the physics test of this model
             if "quat" in key:
                 got = got * np.sign(np.dot(got, ref))
             assert np.abs(got - ref).max() < tol, (t, key, np.abs(got - ref).max())
