@@ -80,6 +80,7 @@ typedef struct {
   int ntendon, neq;
   int *tendon_adr, *tendon_num, *wrap_objid, *tendon_limited, *eq_obj1id;
   double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_length0, *tendon_invweight0, *eq_data, *eq_solref, *eq_solimp;
+  double *tendon_stiffness, *tendon_damping, *tendon_lengthspring;   /* spring-damper on the tendon length (may be absent) */
 } rso_model;
 
 static void *blob_find(rso_model *m, const char *name, int *count) {
@@ -126,6 +127,7 @@ rso_model *rso_model_create(const void *blob, size_t len) {
   PI_(tendon_adr); PI_(tendon_num); PI_(wrap_objid); PI_(tendon_limited); PI_(eq_obj1id);
   PD_(wrap_prm); PD_(tendon_range); PD_(tendon_margin); PD_(tendon_solref_lim); PD_(tendon_solimp_lim); PD_(tendon_length0); PD_(tendon_invweight0);
   PD_(eq_data); PD_(eq_solref); PD_(eq_solimp);
+  PD_(tendon_stiffness); PD_(tendon_damping); PD_(tendon_lengthspring);
   /* mean diagonal inertia at qpos0 (MuJoCo stat.meaninertia [3P]) */
   double s = 0;
   for (int i = 0; i < m->nv; i++) s += m->dof_M0[i];
@@ -570,6 +572,22 @@ static void passive(rso_data *d) {
   for (int j = 0; j < m->njnt; j++)
     if (m->jnt_stiffness[j] > 0 && (m->jnt_type[j] == JNT_HINGE || m->jnt_type[j] == JNT_SLIDE))
       d->qfrc_passive[m->jnt_dofadr[j]] -= m->jnt_stiffness[j] * (d->qpos[m->jnt_qposadr[j]] - m->qpos_spring[m->jnt_qposadr[j]]);
+  /* spring-damper on fixed-tendon lengths (mj_passive [3P]: deadband [lengthspring0, lengthspring1], damping on the length rate) */
+  if (m->tendon_stiffness)
+    for (int t = 0; t < m->ntendon; t++) {
+      double k = m->tendon_stiffness[t], b = m->tendon_damping ? m->tendon_damping[t] : 0;
+      if (k <= 0 && b <= 0) continue;
+      double len = 0, vel = 0, frc = 0;
+      for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) {
+        int j = m->wrap_objid[w];
+        len += m->wrap_prm[w] * d->qpos[m->jnt_qposadr[j]];
+        vel += m->wrap_prm[w] * d->qvel[m->jnt_dofadr[j]];
+      }
+      double lo = m->tendon_lengthspring[2 * t], hi = m->tendon_lengthspring[2 * t + 1];
+      if (len > hi) frc = k * (hi - len); else if (len < lo) frc = k * (lo - len);
+      frc -= b * vel;
+      for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) d->qfrc_passive[m->jnt_dofadr[m->wrap_objid[w]]] += m->wrap_prm[w] * frc;
+    }
   /* inertia-box fluid model (density/viscosity of the medium, base.xml:4) */
   if (m->density > 0 || m->viscosity > 0) {
     for (int b = 1; b < m->nbody; b++) {

@@ -425,6 +425,13 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
     m->fo[FO_eq_data0] = (int)ft.size(); m->fcount[FO_eq_data0] = ne;
     for (int e = 0; e < ne; e++) ft.push_back((float)m->D("eq_data")[5 * e]);
     pushf(FO_eq_solref, "eq_solref", 2 * ne); pushf(FO_eq_solimp, "eq_solimp", 5 * ne);
+    auto pushopt = [&](int id, const char* k, size_t n_, double dflt) {   // fields absent in blobs compiled before they existed
+      m->fo[id] = (int)ft.size(); m->fcount[id] = (int)n_;
+      const double* p2 = m->D(k);
+      for (size_t i = 0; i < n_; i++) ft.push_back(p2 ? (float)p2[i] : (float)dflt);
+    };
+    pushopt(FO_tendon_stiffness, "tendon_stiffness", nt, 0.0); pushopt(FO_tendon_damping, "tendon_damping", nt, 0.0);
+    pushopt(FO_tendon_lspring, "tendon_lengthspring", 2 * nt, 0.0);
   }
   m->fo[FO_opt] = (int)ft.size(); m->fcount[FO_opt] = 10;
   {

@@ -1164,11 +1164,32 @@ struct Sim {
       }
     }
     SYNC();
+    float tfrc = 0.f;
+    if (TENDONS && m.ntendon) {
+      // spring-damper on fixed-tendon lengths (mj_passive [3P]): force k (lo - len) / k (hi - len) outside the deadband minus damping on the
+      // length rate, mapped onto the tendon's dofs by its coefficients; uniform loop over the tendons, lane = dof picks its own terms
+      for (int t = 0; t < m.ntendon; t++) {
+        const float k = FP(FO_tendon_stiffness, t), bd = FP(FO_tendon_damping, t);
+        if (k <= 0.f && bd <= 0.f) continue;
+        const int adr = IT(IO_tendon_adr, t), num = IT(IO_tendon_num, t);
+        float len = 0.f, vel = 0.f, mine = 0.f;
+        for (int w = 0; w < num; w++) {
+          const float cf = FP(FO_wrap_prm, adr + w);
+          const int dw = IT(IO_wrap_dof, adr + w);
+          len = fmaf(cf, sm.qpos[IT(IO_wrap_qadr, adr + w)], len);
+          vel = fmaf(cf, sm.qvel[dw], vel);
+          mine += dw == lane ? cf : 0.f;
+        }
+        const float lo = FP(FO_tendon_lspring, 2 * t), hi = FP(FO_tendon_lspring, 2 * t + 1);
+        const float frc = (len > hi ? k * (hi - len) : (len < lo ? k * (lo - len) : 0.f)) - bd * vel;
+        tfrc = fmaf(mine, frc, tfrc);
+      }
+    }
     if (lane < nv) {
       const S6 cd = ld6(sm.cdof + CS6 * lane);
       const float* F = sm.u.v.F + FS * lane;
       sm.qfrc_bias[lane] = dot6(cd, ld6(F));
-      sm.qfrc_passive[lane] = -K.damping * sm.qvel[lane] + dot6(cd, ld6(F + 6));
+      sm.qfrc_passive[lane] = -K.damping * sm.qvel[lane] + dot6(cd, ld6(F + 6)) + tfrc;
     }
     SYNC();
   }
@@ -1718,7 +1739,9 @@ struct Sim {
       const int ncon = uni(sm.ncon);
       const bool has = lane < ncon;
       const int dim = has ? sm.cdim[lane] : 0;
-      const bool active = has && sm.cdist[lane] < sm.cmargin[lane];
+      // fp32: hulls that share a face plane (UR5e base / shoulder) come out of MPR at -5e-9 m, which is rounding, not penetration; a contact
+      // becomes active 0.1 um inside the margin (MuJoCo: dist < margin), so that such pairs do not add constraint rows the fp64 path lacks
+      const bool active = has && sm.cdist[lane] < sm.cmargin[lane] - 1.0e-7f;
       int need = active ? dim : 0, incl = need;
 #pragma unroll
       for (int o = 1; o < SM::NCON_; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }

@@ -1026,16 +1026,17 @@ def compile_mjcf(xml: str, asset_dir: str | None = None, max_hull_vert: int = 0)
         for t in tend:
             if t.tag != "fixed":
                 raise MJCFError("spatial tendons are not supported (only <tendon><fixed>)")
-            for k in ("stiffness", "damping", "frictionloss", "springlength"):
-                if t.get(k) is not None and any(abs(x) > 0 for x in _floats(t.get(k))):
-                    raise MJCFError(f"tendon attribute {k} is not supported")
+            if t.get("frictionloss") is not None and any(abs(x) > 0 for x in _floats(t.get("frictionloss"))):
+                raise MJCFError("tendon attribute frictionloss is not supported")
+            sl = _floats(t.get("springlength"), None, [-1.0])     # one value = no deadband; -1 = the length at qpos0 (set in _set_const)
+            sl = [sl[0], sl[0]] if len(sl) == 1 else list(sl[:2])
             wraps = [(jname2id[w.get("joint")], float(w.get("coef", "1"))) for w in t.findall("joint")]
             for jid, _ in wraps:
                 if joints[jid]["type"] not in (JNT_HINGE, JNT_SLIDE):
                     raise MJCFError("fixed tendons over ball / free joints are not supported")
             rng = _floats(t.get("range"), 2, [0.0, 0.0])
             limited = t.get("limited")
-            tendons.append(dict(name=t.get("name"), wraps=wraps, range=rng, limited=1 if (limited == "true" or (limited in (None, "auto") and t.get("range") is not None and compiler["autolimits"])) else 0,
+            tendons.append(dict(name=t.get("name"), wraps=wraps, range=rng, stiffness=float(t.get("stiffness", "0")), damping=float(t.get("damping", "0")), lengthspring=sl, limited=1 if (limited == "true" or (limited in (None, "auto") and t.get("range") is not None and compiler["autolimits"])) else 0,
                                 margin=float(t.get("margin", "0")), solref=_floats(t.get("solreflimit"), 2, [0.02, 1.0]),
                                 solimp=_floats(t.get("solimplimit"), 5, [0.9, 0.95, 0.001, 0.5, 2.0])))
     ntendon = len(tendons)
@@ -1065,6 +1066,9 @@ def compile_mjcf(xml: str, asset_dir: str | None = None, max_hull_vert: int = 0)
     m.set("tendon_limited", np.array([t["limited"] for t in tendons], dtype=I32), I32)
     m.set("tendon_range", np.array([t["range"] for t in tendons], dtype=F64).reshape(ntendon, 2), F64)
     m.set("tendon_margin", np.array([t["margin"] for t in tendons], dtype=F64), F64)
+    m.set("tendon_stiffness", np.array([t["stiffness"] for t in tendons], dtype=F64), F64)
+    m.set("tendon_damping", np.array([t["damping"] for t in tendons], dtype=F64), F64)
+    m.set("tendon_lengthspring", np.array([t["lengthspring"] for t in tendons], dtype=F64).reshape(ntendon, 2), F64)
     m.set("tendon_solref_lim", np.array([t["solref"] for t in tendons], dtype=F64).reshape(ntendon, 2), F64)
     m.set("tendon_solimp_lim", np.array([t["solimp"] for t in tendons], dtype=F64).reshape(ntendon, 5), F64)
     m.set("eq_obj1id", np.array([e["tendon"] for e in eqs], dtype=I32), I32)
@@ -1271,6 +1275,12 @@ def _set_const(m: FlatModel):
             tinv[t] = J @ Minv @ J
     m.set("tendon_length0", len0, F64)
     m.set("tendon_invweight0", tinv, F64)
+    if nt and "tendon_lengthspring" in m.arrays:      # springlength -1: rest length = length at qpos0 (mj_setConst [3P])
+        ls = np.array(m.tendon_lengthspring, dtype=np.float64).reshape(nt, 2)
+        for t in range(nt):
+            if ls[t, 0] == -1.0 and ls[t, 1] == -1.0:
+                ls[t] = len0[t]
+        m.set("tendon_lengthspring", ls, F64)
 
 
 # ------------------------------------------------------------------------------------------------

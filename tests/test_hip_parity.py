@@ -468,6 +468,36 @@ def test_pickplace_observation_and_reward_epilogue_matches_reference_env():
         assert hb.get("success")[0] == 0
 
 
+def test_lift_ur5e_with_spring_tendon_gripper():
+    """Lift / UR5e + Robotiq85: passive spring force and length limits of the two fixed tendons on the device against the oracle, then the fused
+    control step against the oracle loop (arm and cube tight, the undamped finger links loosely, as for the Robotiq140)."""
+    g, cfg, flat = load_golden("seed0", "lift_ur5e")
+    nq = flat.nq
+    om, od, oc = make_oracle(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=2)
+    for i in (0, 6, 19):
+        s = g["states"][i]
+        od.qpos[:] = s[1:1 + nq]; od.qvel[:] = s[1 + nq:]; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0; od.forward()
+        hb.set("qpos", s[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0); hb.forward()
+        assert np.abs(hb.get("qfrc_passive")[0] - od.qfrc_passive).max() < 1e-5 * max(1.0, np.abs(od.qfrc_passive).max())
+        assert np.abs(od.qfrc_passive[cfg["grip_dof_idx"]]).max() > 1e-3          # the springs are loaded
+        # the UR5e base and shoulder hulls share a face plane: fp32 MPR reports that pair as touching at -5e-9 m (a contact with no force),
+        # fp64 as separated; compare the contacts that actually penetrate
+        deep = lambda cs: [(c["geom1"], c["geom2"]) for c in cs if c["dist"] < -1e-6]
+        assert deep(hb.contacts(0)) == deep(od.contacts())
+        assert hb.get("nefc")[0] == od.nefc and 0 <= hb.get("ncon")[0] - od.ncon <= 1   # detected, but not active: no constraint rows (make_constraint)
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0; od.forward(); oc.reset(od)
+    hb.set("qpos", s0[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    fingers = np.zeros(nq, dtype=bool); fingers[cfg["grip_qpos_idx"]] = True
+    for t in range(len(g["actions"])):
+        hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+        oc.env_step(od, g["actions"][t], 25)
+        dq = np.abs(hb.get("qpos")[0] - od.qpos)
+        assert dq[~fingers].max() < 1e-3 and dq[fingers].max() < 0.1, t
+
+
 def test_replay_is_bitwise_deterministic():
     """The reference's only numeric assert on sim state is bitwise replay equality (test_action_playback.py:46-68)."""
     g, cfg, flat = load_golden("seed1_full")

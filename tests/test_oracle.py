@@ -123,6 +123,24 @@ def test_pickplace_iiwa_robotiq_fixture_replays_on_the_oracle():
     assert np.isfinite(od.qpos).all() and np.abs(lengths() - flat.tendon_length0).max() < 0.3
 
 
+def test_lift_ur5e_robotiq85_fixture_replays_on_the_oracle():
+    """Lift / UR5e + Robotiq85 (two spring-loaded fixed tendons with length limits, no equality rows; robotiq_gripper_85.xml:15-29): the oracle
+    loop with the C controllers replays the fixture recorded from the reference env loop; the tendon springs act (non-zero passive force)."""
+    g, cfg, flat = load_golden("seed0", "lift_ur5e")
+    assert int(flat.ntendon) == 2 and int(flat.neq) == 0 and flat.tendon_stiffness.tolist() == [0.4, 0.4]
+    om, od, oc = make_oracle(flat, cfg)
+    nq = flat.nq
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0
+    od.forward(); oc.reset(od)
+    fingers = np.zeros(nq, dtype=bool); fingers[cfg["grip_qpos_idx"]] = True
+    assert np.abs(od.qfrc_passive[cfg["grip_dof_idx"]]).max() > 1e-3
+    for t in range(len(g["actions"])):
+        oc.env_step(od, g["actions"][t], 25)
+        dq = np.abs(od.qpos - g["states"][t + 1][1:1 + nq])
+        assert dq[~fingers].max() < 5e-5 and dq[fingers].max() < 5e-2, t     # undamped finger links under kp = 20 actuators amplify 1e-6 of ctrl
+
+
 def test_reset_path_known_answers():
     """values produced by the reference's own reset code (placement_samplers.py:221-309,
     robots/robot.py:247-259, lift.py:311-318) for seed 0, re-derived from the documented draw order."""

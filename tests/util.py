@@ -11,6 +11,7 @@ TAGS = ("seed0_gentle", "seed1_full")
 
 
 def load_golden(tag, model="lift_panda"):
+    """(arrays, controller / key cfg, compiled model) of fixture `{model}_{tag}` under tests/golden (recorded by tools/gen_golden.py)."""
     g = np.load(os.path.join(GOLD, f"{model}_{tag}.npz"))
     cfg = json.load(open(os.path.join(GOLD, f"{model}_{tag}.cfg.json")))
     flat = mjcf.load_model(os.path.join(GOLD, f"{model}_{tag}.rsim"))

@@ -246,7 +246,8 @@ def record_baxter(seed, n_steps, action_scale, ctype):
     print("baxter", tag, "nbody", flat.nbody, "nv", flat.nv, "steps", n_steps, "max ncon", max(ncon), "reward", rewards[-1])
 
 
-GRIPPER_SIGNS = {"PandaGripper": [-1.0, 1.0], "Robotiq140Gripper": [1.0, -1.0]}   # format_action direction tables (panda_gripper.py:55-57, robotiq_140_gripper.py:66-68)
+# format_action direction tables (panda_gripper.py:55-57, robotiq_140_gripper.py:66-68, robotiq_85_gripper.py:65-67)
+GRIPPER_SIGNS = {"PandaGripper": [-1.0, 1.0], "Robotiq140Gripper": [1.0, -1.0], "Robotiq85Gripper": [1.0, 1.0]}
 
 
 def record_pickplace(seed, n_steps, action_scale, tag):
@@ -317,6 +318,29 @@ def record_baxter_model(seed):
     env.reset()
     mjcf.save_model(env.sim.model._model._flat, os.path.join(GOLD, f"peg_baxter_model_seed{seed}.rsim"))
     print("baxter model seed", seed, "peg radius", env.sim.model._model._flat.geom_size[env.sim.model.geom_name2id("peg_g0")][0])
+
+
+def record_lift_robot(robot, seed, n_steps, action_scale):
+    """Lift with another arm / gripper (UR5e + Robotiq85: spring-loaded fixed tendons with length limits): physics + OSC_POSE fixture."""
+    env = suite.make("Lift", robots=robot, has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
+                     reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed)
+    obs = env.reset()
+    sim = env.sim
+    flat = sim.model._model._flat
+    rng = np.random.default_rng(10**6 + seed)
+    actions, states, ctrls = [], [sim.get_state().flatten()], []
+    for t in range(n_steps):
+        a = action_scale * rng.uniform(-1, 1, env.action_dim)
+        env.step(a)
+        ctrls.append(np.array(sim.data.ctrl)); actions.append(a); states.append(sim.get_state().flatten())
+    tag = f"lift_{robot.lower()}_seed{seed}"
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), actions=np.array(actions), states=np.array(states), ctrl=np.array(ctrls))
+    mjcf.save_model(flat, os.path.join(GOLD, f"{tag}.rsim"))
+    cfg = controller_cfg(env)
+    cfg["grip_sign"] = GRIPPER_SIGNS[type(env.robots[0].gripper["right"]).__name__]
+    with open(os.path.join(GOLD, f"{tag}.cfg.json"), "w") as f:
+        json.dump(cfg, f, indent=1)
+    print(tag, "nv", flat.nv, "nbody", flat.nbody, "ntendon", int(flat.ntendon), "jnt_stiffness max", float(np.abs(flat.jnt_stiffness).max()), "grip_sign", cfg["grip_sign"])
 
 
 def record_stack_resets(seeds):
@@ -391,6 +415,9 @@ if __name__ == "__main__":
     if "--pickplace-only" in sys.argv:
         record_pickplace(seed=0, n_steps=20, action_scale=1.0, tag="seed0_full")
         record_pickplace_resets([0, 1, 2, 3])
+        sys.exit(0)
+    if "--ur5e-only" in sys.argv:
+        record_lift_robot("UR5e", 0, 20, 1.0)
         sys.exit(0)
     if "--baxter-model-only" in sys.argv:
         record_baxter_model(1)
