@@ -62,7 +62,10 @@ typedef struct rsim_ctrl_desc {
                                        * GOAL (not the value reached) and step := 0; each run_controller uses start + (goal - start) / (total - step)
                                        * and advances step up to total - 1.  Joint-space types interpolate their goal vector; OSC_POSITION its goal_pos,
                                        * which the reference then uses as a WORLD position although it holds base-frame coordinates (osc.py:418-423).
-                                       * OSC_POSE with an interpolator (Euler / slerp orientation path) is not implemented and is refused. */
+                                       * OSC_POSE adds the orientation interpolator (controller_factory.py:102-106, osc.py:277-283, 433-437): set_goal
+                                       * stores orientation_error(goal_ori, current eef ori) as the new goal VECTOR, run_controller takes
+                                       * mat2euler(slerp(quat(euler start), quat(euler goal), (step + 1) / total)) as its orientation error
+                                       * (traj_utils.py:129-146: the error vectors are handled as Euler angles). */
   int32_t part_of[RSIM_JNT_MAX];      /* joint-space types: which part controller (arm) owns joint i; JOINT_POSITION multiplies by that part's own
                                        * mass-matrix block only (joint_pos.py:256-259 uses Controller.mass_matrix of the part) */
 } rsim_ctrl_desc;
@@ -133,7 +136,7 @@ enum rsim_field {
                         *          joint-space types (64) goal[16] - grip[4] at 20 - tau[16] at 32; JOINT_VELOCITY (192) adds last_err[16] at 48,
                         *          summed_err[16] at 64, derr ring[5][16] at 80, ring ptr / size at 160 / 161, saturated[part] at 164;
                         *          variable-impedance modes (128): current kp[16] at 96, kd[16] at 112;
-                        *          interpolator (200): start[16] at 180, step at 196 */
+                        *          interpolator (200): start[16] at 180, step at 196; OSC_POSE orientation interpolator start[3] at 184, goal[3] at 188 */
   RSIM_XPOS,           /* [B,nbody,3]  sim.data.xpos      (derived, valid after forward/step1) */
   RSIM_XQUAT,          /* [B,nbody,4]  sim.data.xquat                                        */
   RSIM_QM,             /* [B,nv,nv]    dense mass matrix (mj_fullM, controller.py:226-227)  */

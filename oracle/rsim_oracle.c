@@ -1765,6 +1765,9 @@ typedef struct {
   /* LinearInterpolator (utils/traj_utils.py:25-155): total steps (0 = none), start vector, step counter; the goal is goal_j / goal_pos */
   int interp_total, interp_step;
   double interp_start[ARM_MAX];
+  /* OSC_POSE orientation interpolator (controller_factory.py:102-106: a deepcopy in 'euler' mode): start / goal are orientation-error
+   * vectors that get_interpolated_goal treats as Euler angles (osc.py:277-283, traj_utils.py:129-146) */
+  double interp_ori_start[3], interp_ori_goal[3];
   double nullspace_kp;
   /* gripper */
   int ngrip;               /* number of gripper actuators (2) */
@@ -1807,7 +1810,10 @@ void rso_ctrl_set_type(rso_ctrl *c, int type, int cdim, const double *jkp, doubl
   if (type == 3 || type == 4) for (int i = 0; i < c->ndof; i++) { c->tl_lo[i] = tl_lo[i]; c->tl_hi[i] = tl_hi[i]; }  /* torque / velocity limits */
 }
 
-void rso_ctrl_set_interpolator(rso_ctrl *c, int total_steps) { c->interp_total = total_steps; c->interp_step = 0; memset(c->interp_start, 0, sizeof(c->interp_start)); }
+void rso_ctrl_set_interpolator(rso_ctrl *c, int total_steps) {
+  c->interp_total = total_steps; c->interp_step = 0; memset(c->interp_start, 0, sizeof(c->interp_start));
+  memset(c->interp_ori_start, 0, sizeof(c->interp_ori_start)); memset(c->interp_ori_goal, 0, sizeof(c->interp_ori_goal));
+}
 
 /* LinearInterpolator.get_interpolated_goal for one component set; advances the step counter once per call */
 static void interp_get(rso_ctrl *c, const double *goal, int n, double *out) {
@@ -1835,6 +1841,7 @@ void rso_ctrl_reset(rso_ctrl *c, rso_data *d) {
   memset(c->last_err, 0, sizeof(c->last_err)); memset(c->summed_err, 0, sizeof(c->summed_err)); memset(c->ring, 0, sizeof(c->ring));
   c->ring_ptr = 4; c->ring_size = 0; c->saturated = 0;
   memset(c->interp_start, 0, sizeof(c->interp_start)); c->interp_step = 0;   /* fresh interpolator, then set_goal(reset goal): start = zeros */
+  memset(c->interp_ori_start, 0, sizeof(c->interp_ori_start)); memset(c->interp_ori_goal, 0, sizeof(c->interp_ori_goal));   /* osc.py:538-544: error of ref vs itself */
 }
 
 /* float32 quat2mat of the reference (transform_utils.py:461-487 casts to float32; under NumPy>=2 the
@@ -1862,6 +1869,62 @@ static void mat3T_mul(double *r, const double *a, const double *b) { /* a^T b */
   double t[9];
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t[3 * i + j] = a[i] * b[j] + a[3 + i] * b[3 + j] + a[6 + i] * b[6 + j];
   memcpy(r, t, sizeof(t));
+}
+
+static void orientation_error(const double *desired, const double *current, double *err);
+
+/* ---- orientation interpolator of OSC_POSE: LinearInterpolator in 'euler' mode (traj_utils.py:129-146) ------------------------------------
+ * x = mat2quat(euler2mat(start)); g = mat2quat(euler2mat(goal)); q = quat_slerp(x, g, (step + 1) / total); out = mat2euler(quat2mat(q)) */
+static void euler2mat(const double *e, double *R) { /* transform_utils.py:358-391 */
+  double ai = -e[2], aj = -e[1], ak = -e[0];
+  double si = sin(ai), sj = sin(aj), sk = sin(ak), ci = cos(ai), cj = cos(aj), ck = cos(ak);
+  double cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
+  R[8] = cj * ck; R[7] = sj * sc - cs; R[6] = sj * cc + ss;
+  R[5] = cj * sk; R[4] = sj * ss + cc; R[3] = sj * cs - sc;
+  R[2] = -sj;     R[1] = cj * si;      R[0] = cj * ci;
+}
+/* transform_utils.py:316-355 takes the eigenvector of the largest eigenvalue of the 4 x 4 matrix K built from the float32 matrix, i.e. the
+ * unit quaternion of the rotation, made unique by w >= 0.  Restated with the branch-on-largest-component extraction (same quaternion for a
+ * rotation matrix; the reference's float32 eigh noise of ~1e-7 is inside the test tolerance).  Output (x, y, z, w). */
+static void mat2quat_f32(const double *Rd, double *q) {
+  float m[9];
+  for (int i = 0; i < 9; i++) m[i] = (float)Rd[i];
+  double tr = (double)m[0] + m[4] + m[8], w, x, y, z;
+  if (tr > 0) { double s = 2 * sqrt(1 + tr); w = 0.25 * s; x = (m[7] - m[5]) / s; y = (m[2] - m[6]) / s; z = (m[3] - m[1]) / s; }
+  else if (m[0] > m[4] && m[0] > m[8]) { double s = 2 * sqrt(1 + m[0] - m[4] - m[8]); w = (m[7] - m[5]) / s; x = 0.25 * s; y = (m[1] + m[3]) / s; z = (m[2] + m[6]) / s; }
+  else if (m[4] > m[8]) { double s = 2 * sqrt(1 + m[4] - m[0] - m[8]); w = (m[2] - m[6]) / s; x = (m[1] + m[3]) / s; y = 0.25 * s; z = (m[5] + m[7]) / s; }
+  else { double s = 2 * sqrt(1 + m[8] - m[0] - m[4]); w = (m[3] - m[1]) / s; x = (m[2] + m[6]) / s; y = (m[5] + m[7]) / s; z = 0.25 * s; }
+  double n = sqrt(w * w + x * x + y * y + z * z), sg = w < 0 ? -1.0 : 1.0;
+  q[0] = sg * x / n; q[1] = sg * y / n; q[2] = sg * z / n; q[3] = sg * w / n;
+}
+static void quat_slerp(const double *a, const double *b, double fraction, double *out) { /* transform_utils.py:151-201, shortestpath = True */
+  const double EPS = 8.881784197001252e-16;
+  double q0[4], q1[4], n0 = 0, n1 = 0, d = 0;
+  for (int i = 0; i < 4; i++) { n0 += a[i] * a[i]; n1 += b[i] * b[i]; }
+  for (int i = 0; i < 4; i++) { q0[i] = a[i] / sqrt(n0); q1[i] = b[i] / sqrt(n1); d += q0[i] * q1[i]; }
+  if (fraction == 0.0) { memcpy(out, q0, sizeof(q0)); return; }
+  if (fraction == 1.0) { memcpy(out, q1, sizeof(q1)); return; }
+  if (fabs(fabs(d) - 1.0) < EPS) { memcpy(out, q0, sizeof(q0)); return; }
+  if (d < 0.0) { d = -d; for (int i = 0; i < 4; i++) q1[i] = -q1[i]; }
+  double angle = acos(fmax(-1.0, fmin(1.0, d)));
+  if (fabs(angle) < EPS) { memcpy(out, q0, sizeof(q0)); return; }
+  double isin = 1.0 / sin(angle), w0 = sin((1.0 - fraction) * angle) * isin, w1 = sin(fraction * angle) * isin;
+  for (int i = 0; i < 4; i++) out[i] = q0[i] * w0 + q1[i] * w1;
+}
+static void mat2euler_sxyz(const double *Rd, double *e) { /* transform_utils.py:394-440, axes 'sxyz' = (0, 0, 0, 0): i, j, k = 0, 1, 2; float32 input */
+  float M[9];
+  for (int i = 0; i < 9; i++) M[i] = (float)Rd[i];
+  double cy = sqrt((double)(float)(M[0] * M[0] + M[3] * M[3]));
+  if (cy > 8.881784197001252e-16) { e[0] = atan2(M[7], M[8]); e[1] = atan2(-M[6], cy); e[2] = atan2(M[3], M[0]); }
+  else { e[0] = atan2(-M[5], M[4]); e[1] = atan2(-M[6], cy); e[2] = 0; }
+}
+static void interp_ori_get(const rso_ctrl *c, int step, double *out) {
+  double R[9], x[4], g[4], q[4];
+  euler2mat(c->interp_ori_start, R); mat2quat_f32(R, x);
+  euler2mat(c->interp_ori_goal, R); mat2quat_f32(R, g);
+  quat_slerp(x, g, (double)(step + 1) / (double)c->interp_total, q);
+  quat2mat_f32(q, R);
+  mat2euler_sxyz(R, out);
 }
 
 /* set_goal at a policy step: OSC (osc.py:225-283, 306-401, mode "achieved", frame "base", delta input) + gripper
@@ -1894,6 +1957,10 @@ void rso_ctrl_set_goal(rso_ctrl *c, rso_data *d, const double *action) {
   } else {                   /* osc.py:255-263: OSC_POSITION passes a zero orientation delta (scaled[3..5] stay 0) */
     rso_osc_goal(scaled, d->site_xpos + 3 * c->eef_site, d->site_xmat + 9 * c->eef_site, d->site_xpos + 3 * c->base_site, d->site_xmat + 9 * c->base_site,
                  c->goal_pos, c->goal_ori);
+    if (c->interp_total && c->type == 0) {   /* osc.py:277-283: ori_ref = current eef orientation; goal = error of the (base-frame) goal_ori against it */
+      memcpy(c->interp_ori_start, c->interp_ori_goal, sizeof(c->interp_ori_start));
+      orientation_error(c->goal_ori, d->site_xmat + 9 * c->eef_site, c->interp_ori_goal);
+    }
   }
   /* gripper */
   if (c->ngrip > 0) {
@@ -1938,19 +2005,35 @@ static void sym_pinv(const double *A, double *P, int n) {
  *   ep/eR eef site pose, ev[6] eef lin+ang velocity, op/oR base (origin) site pose, bv[6] base site velocity,
  *   goal_pos/goal_ori in the origin frame, J 6 x n (rows: jacp then jacr, arm columns), M n x n arm sub-block of the
  *   full mass matrix, bias = qfrc_bias[arm], q/qd arm joint pos/vel, q0 nullspace reference (initial_joint). */
+/* orientation_error(desired, current) = 1/2 sum_i current[:, i] x desired[:, i]  (control_utils.py:85-111) */
+static void orientation_error(const double *desired, const double *current, double *err) {
+  err[0] = err[1] = err[2] = 0;
+  for (int col = 0; col < 3; col++) {
+    double rc[3] = {current[col], current[3 + col], current[6 + col]}, rd[3] = {desired[col], desired[3 + col], desired[6 + col]}, t[3];
+    cross3(t, rc, rd);
+    for (int k = 0; k < 3; k++) err[k] += 0.5 * t[k];
+  }
+}
+
+/* oerr_in != NULL: the orientation error comes from the orientation interpolator (osc.py:433-437) instead of goal_ori */
+static void osc_torques_impl(const double *kp, const double *kd, const double *ep, const double *eR, const double *ev, const double *op, const double *oR,
+                             const double *bv, const double *goal_pos, const double *goal_ori, const double *oerr_in, const double *J, const double *M,
+                             const double *bias, const double *q, const double *qd, const double *q0, double nullspace_kp, int uncouple, int n, double *out);
 void rso_osc_torques(const double *kp, const double *kd, const double *ep, const double *eR, const double *ev, const double *op, const double *oR,
                      const double *bv, const double *goal_pos, const double *goal_ori, const double *J, const double *M, const double *bias,
                      const double *q, const double *qd, const double *q0, double nullspace_kp, int uncouple, int n, double *out) {
+  osc_torques_impl(kp, kd, ep, eR, ev, op, oR, bv, goal_pos, goal_ori, NULL, J, M, bias, q, qd, q0, nullspace_kp, uncouple, n, out);
+}
+static void osc_torques_impl(const double *kp, const double *kd, const double *ep, const double *eR, const double *ev, const double *op, const double *oR,
+                             const double *bv, const double *goal_pos, const double *goal_ori, const double *oerr_in, const double *J, const double *M,
+                             const double *bias, const double *q, const double *qd, const double *q0, double nullspace_kp, int uncouple, int n, double *out) {
   double Minv[ARM_MAX * ARM_MAX];
   double dpos[3], dori[9], perr[3], oerr[3] = {0, 0, 0};
   mat_vec3(dpos, oR, goal_pos);
   for (int k = 0; k < 3; k++) { dpos[k] += op[k]; perr[k] = dpos[k] - ep[k]; }
   mat3_mul(dori, oR, goal_ori);
-  for (int col = 0; col < 3; col++) { /* control_utils.py:85-111 */
-    double rc[3] = {eR[col], eR[3 + col], eR[6 + col]}, rd[3] = {dori[col], dori[3 + col], dori[6 + col]}, t[3];
-    cross3(t, rc, rd);
-    for (int k = 0; k < 3; k++) oerr[k] += 0.5 * t[k];
-  }
+  if (oerr_in) memcpy(oerr, oerr_in, sizeof(oerr));
+  else orientation_error(dori, eR, oerr);
   double F[3], T[3];
   for (int k = 0; k < 3; k++) {
     F[k] = perr[k] * kp[k] + (-(ev[k] - bv[k])) * kd[k];
@@ -2055,6 +2138,9 @@ void rso_ctrl_run(rso_ctrl *c, rso_data *d) {
     /* osc.py:418-423: with an interpolator the ramped goal values are taken as the desired WORLD position (although set_goal stores base-frame
      * coordinates); expressed here as the base-frame goal that maps onto that world point */
     double gp[3] = {c->goal_pos[0], c->goal_pos[1], c->goal_pos[2]};
+    double oerr[3];
+    const int use_ori = c->interp_total && c->type == 0;
+    if (use_ori) interp_ori_get(c, c->interp_step, oerr);   /* both interpolators count the same steps (deepcopy, stepped once per run each) */
     if (c->interp_total) {
       double des[3], rel[3];
       const double *op = d->site_xpos + 3 * c->base_site, *oR = d->site_xmat + 9 * c->base_site;
@@ -2062,9 +2148,9 @@ void rso_ctrl_run(rso_ctrl *c, rso_data *d) {
       for (int k = 0; k < 3; k++) rel[k] = des[k] - op[k];
       matT_vec3(gp, oR, rel);
     }
-    rso_osc_torques(c->kp, c->kd, d->site_xpos + 3 * c->eef_site, d->site_xmat + 9 * c->eef_site, ev, d->site_xpos + 3 * c->base_site,
-                    d->site_xmat + 9 * c->base_site, bv, gp, c->goal_ori, J, M, bias, q, qd, c->initial_joint, c->nullspace_kp, c->uncouple, n,
-                    c->torques);
+    osc_torques_impl(c->kp, c->kd, d->site_xpos + 3 * c->eef_site, d->site_xmat + 9 * c->eef_site, ev, d->site_xpos + 3 * c->base_site,
+                     d->site_xmat + 9 * c->base_site, bv, gp, c->goal_ori, use_ori ? oerr : NULL, J, M, bias, q, qd, c->initial_joint, c->nullspace_kp,
+                     c->uncouple, n, c->torques);
   }
   for (int i = 0; i < n; i++) {
     int a = c->act_idx[i];

@@ -490,7 +490,6 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
   c.nimp = d->impedance_mode ? (jointspace ? d->ndof : 6) : 0;
   if (c.imp_mode) c.cs_size = RSIM_CS_SIZE_VARIMP;
   if (d->interp_steps < 0 || d->interp_steps > 1000) return fail("controller: interp_steps %d", d->interp_steps);
-  if (d->interp_steps && d->type == RSIM_CTRL_OSC_POSE) return fail("controller: OSC_POSE with an interpolator (orientation slerp path, osc.py:425-430) is not implemented");
   c.interp_steps = d->interp_steps;
   if (c.interp_steps) c.cs_size = RSIM_CS_SIZE_INTERP;
   for (int i = 0; i < c.nimp; i++) {

@@ -101,6 +101,8 @@ struct DCtrl {
 #define RSIM_CS_SIZE_VARIMP 128
 #define RSIM_CS_SIZE_JVEL 192
 #define RSIM_CS_ISTART 180     /* LinearInterpolator: start[16], step */
+#define RSIM_CS_ISTART_ORI (RSIM_CS_ISTART + 4)    /* OSC_POSE orientation interpolator: start[3], goal[3] (error vectors) */
+#define RSIM_CS_IGOAL_ORI (RSIM_CS_ISTART + 8)
 #define RSIM_CS_ISTEP 196
 #define RSIM_CS_SIZE_INTERP 200
 #ifndef RSIM_CS_MAX

@@ -410,6 +410,45 @@ __device__ __forceinline__ void sincos_f(float x, float& sn, float& cs) {
   sn = (q & 2) ? -s1 : s1;
   cs = ((q + 1) & 2) ? -c1 : c1;
 }
+
+// ---- orientation interpolator of OSC_POSE (LinearInterpolator in 'euler' mode, utils/traj_utils.py:129-146) ------------------------------
+// start / goal are orientation-error vectors that the reference treats as Euler angles:
+//   mat2euler(quat2mat(quat_slerp(mat2quat(euler2mat(start)), mat2quat(euler2mat(goal)), fraction)))   (transform_utils.py:151-201, 316-440)
+__device__ __forceinline__ Q4 euler_to_quat(V3 e) {
+  float si, ci, sj, cj, sk, ck;
+  sincos_f(-e.z, si, ci); sincos_f(-e.y, sj, cj); sincos_f(-e.x, sk, ck);
+  const float cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
+  const float m00 = cj * ci, m01 = cj * si, m02 = -sj, m10 = sj * cs - sc, m11 = sj * ss + cc, m12 = cj * sk, m20 = sj * cc + ss, m21 = sj * sc - cs, m22 = cj * ck;
+  // unit quaternion of the matrix with w >= 0 (the reference takes the dominant eigenvector of K and flips it to w >= 0)
+  const float tr = m00 + m11 + m22;
+  Q4 q;
+  if (tr > 0.f) { const float s = 2.f * sqrtf(1.f + tr); q.w = 0.25f * s; q.x = (m21 - m12) / s; q.y = (m02 - m20) / s; q.z = (m10 - m01) / s; }
+  else if (m00 > m11 && m00 > m22) { const float s = 2.f * sqrtf(1.f + m00 - m11 - m22); q.w = (m21 - m12) / s; q.x = 0.25f * s; q.y = (m01 + m10) / s; q.z = (m02 + m20) / s; }
+  else if (m11 > m22) { const float s = 2.f * sqrtf(1.f + m11 - m00 - m22); q.w = (m02 - m20) / s; q.x = (m01 + m10) / s; q.y = 0.25f * s; q.z = (m12 + m21) / s; }
+  else { const float s = 2.f * sqrtf(1.f + m22 - m00 - m11); q.w = (m10 - m01) / s; q.x = (m02 + m20) / s; q.y = (m12 + m21) / s; q.z = 0.25f * s; }
+  const float inv = (q.w < 0.f ? -1.f : 1.f) * rsqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  q.w *= inv; q.x *= inv; q.y *= inv; q.z *= inv;
+  return q;
+}
+__device__ __forceinline__ V3 euler_slerp(V3 start, V3 goal, float fraction) {
+  const Q4 a = euler_to_quat(start);
+  Q4 b = euler_to_quat(goal);
+  float d = a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z, w0, w1;
+  if (d < 0.f) { d = -d; b.w = -b.w; b.x = -b.x; b.y = -b.y; b.z = -b.z; }
+  if (fraction >= 1.f) { w0 = 0.f; w1 = 1.f; }
+  else if (d > 0.9995f) { w0 = 1.f - fraction; w1 = fraction; }   // fp32: sin(t angle) / sin(angle) -> t below 0.03 rad (rel. error 2e-4 angle^2)
+  else {
+    const float angle = acosf(d), isin = 1.f / sinf(angle);
+    w0 = sinf((1.f - fraction) * angle) * isin; w1 = sinf(fraction * angle) * isin;
+  }
+  const float qw = a.w * w0 + b.w * w1, qx = a.x * w0 + b.x * w1, qy = a.y * w0 + b.y * w1, qz = a.z * w0 + b.z * w1;
+  // quat2mat (scale 2 / |q|^2) -> mat2euler 'sxyz'
+  const float k = 2.f / (qw * qw + qx * qx + qy * qy + qz * qz);
+  const float m00 = 1.f - k * (qy * qy + qz * qz), m10 = k * (qx * qy + qz * qw), m20 = k * (qx * qz - qy * qw);
+  const float m21 = k * (qy * qz + qx * qw), m22 = 1.f - k * (qx * qx + qy * qy);
+  const float cy = sqrtf(m00 * m00 + m10 * m10);
+  return v3(atan2f(m21, m22), atan2f(-m20, cy), atan2f(m10, m00));   // cy = 0 (gimbal lock) needs a pi/2 error component: out of the |e| <= 1 range
+}
 // rotate v by unit quaternion q
 __device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
   const V3 u = v3(q.x, q.y, q.z);
@@ -1976,7 +2015,13 @@ struct Sim {
     M3 go = mm(Re, mtm(oR, eR));
     SYNC();
     if (lane == 0) {
-      if (c.interp_steps) { st3(sm.cstate + RSIM_CS_ISTART, ld3(sm.cstate + RSIM_CS_GOALPOS)); sm.cstate[RSIM_CS_ISTEP] = 0.f; }
+      if (c.interp_steps) {
+        st3(sm.cstate + RSIM_CS_ISTART, ld3(sm.cstate + RSIM_CS_GOALPOS)); sm.cstate[RSIM_CS_ISTEP] = 0.f;
+        if (c.type == RSIM_CTRL_OSC_POSE) {   // osc.py:277-283: ori_ref = current eef orientation, goal = error of the (base-frame) goal_ori against it
+          st3(sm.cstate + RSIM_CS_ISTART_ORI, ld3(sm.cstate + RSIM_CS_IGOAL_ORI));
+          st3(sm.cstate + RSIM_CS_IGOAL_ORI, (cross(col(eR, 0), col(go, 0)) + cross(col(eR, 1), col(go, 1)) + cross(col(eR, 2), col(go, 2))) * 0.5f);
+        }
+      }
       st3(sm.cstate + RSIM_CS_GOALPOS, gp);
       stm(sm.cstate + RSIM_CS_GOALORI, go);
     }
@@ -2145,16 +2190,19 @@ struct Sim {
     const V3 gpos = ld3(sm.cstate + RSIM_CS_GOALPOS);
     const M3 gori = ldm(sm.cstate + RSIM_CS_GOALORI);
     V3 perr = op + mv(oR, gpos) - ep;
+    const float istep = c.interp_steps ? sm.cstate[RSIM_CS_ISTEP] : 0.f;
     if (c.interp_steps) {
       // osc.py:418-423: with an interpolator the (base-frame) goal values, linearly ramped, ARE the desired world position
-      const float step = sm.cstate[RSIM_CS_ISTEP];
+      const float step = istep;
       const V3 start = ld3(sm.cstate + RSIM_CS_ISTART);
       perr = start + (gpos - start) * (1.0f / ((float)c.interp_steps - step)) - ep;
       SYNC();
       if (lane == 0 && step < (float)(c.interp_steps - 1)) sm.cstate[RSIM_CS_ISTEP] = step + 1.f;
     }
     const M3 dori = mm(oR, gori);
-    const V3 oerr = (cross(col(eR, 0), col(dori, 0)) + cross(col(eR, 1), col(dori, 1)) + cross(col(eR, 2), col(dori, 2))) * 0.5f;
+    V3 oerr = (cross(col(eR, 0), col(dori, 0)) + cross(col(eR, 1), col(dori, 1)) + cross(col(eR, 2), col(dori, 2))) * 0.5f;
+    if (c.interp_steps && c.type == RSIM_CTRL_OSC_POSE)   // osc.py:433-437: the ramped error vector replaces the measured one
+      oerr = euler_slerp(ld3(sm.cstate + RSIM_CS_ISTART_ORI), ld3(sm.cstate + RSIM_CS_IGOAL_ORI), (istep + 1.f) / (float)c.interp_steps);
     // site velocities from the body spatial velocities of the velocity stage: v = cvel.l + w x (p - com)
     const S6 ce = ld6(sm.u.v.cvel + CS6 * eb), cb = ld6(sm.u.v.cvel + CS6 * bb);
     const V3 evl = ce.l + cross(ce.a, ep - ld3(sm.rootcom + 3 * sm.broot[eb])), bvl = cb.l + cross(cb.a, op - ld3(sm.rootcom + 3 * sm.broot[bb]));

@@ -422,6 +422,9 @@ if __name__ == "__main__":
     if "--baxter-model-only" in sys.argv:
         record_baxter_model(1)
         sys.exit(0)
+    if "--interp-pose-only" in sys.argv:
+        record_lift_controller(seed=4, n_steps=30, action_scale=1.0, ctype="OSC_POSE", interpolation="linear")
+        sys.exit(0)
     if "--interp-only" in sys.argv:
         for ct in ("JOINT_POSITION", "JOINT_TORQUE", "OSC_POSITION"):
             record_lift_controller(seed=4, n_steps=30, action_scale=1.0, ctype=ct, interpolation="linear")
