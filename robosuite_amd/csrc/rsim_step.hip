@@ -43,7 +43,10 @@
 #endif
 
 typedef unsigned long long u64;
-#define SYNC() __syncthreads()
+// One workgroup = one wavefront: LDS instructions of a wave execute in issue order, so cross-lane communication through LDS needs no
+// s_waitcnt / s_barrier, only a compiler-level ordering point (wavefront-scope fences emit no instructions; __syncthreads() would
+// drain the LDS queue with s_waitcnt lgkmcnt(0) at every one of the ~110 sites).
+#define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define FMIN 1e-20f
 #define PI_F 3.14159265358979f
 
