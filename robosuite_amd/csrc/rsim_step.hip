@@ -43,6 +43,11 @@
 #endif
 
 typedef unsigned long long u64;
+#ifdef RSIM_SUBPROF   /* profiling build (tools/subprof.sh): sub-phase marks inside the solver and the OSC controller -> slots x0..x9 */
+#define SUBMARK(id) pf.mark(id)
+#else
+#define SUBMARK(id)
+#endif
 // One workgroup = one wavefront: LDS instructions of a wave execute in issue order, so cross-lane communication through LDS needs no
 // s_waitcnt / s_barrier, only a compiler-level ordering point (wavefront-scope fences emit no instructions; __syncthreads() would
 // drain the LDS queue with s_waitcnt lgkmcnt(0) at every one of the ~110 sites).
@@ -259,7 +264,7 @@ struct Smem {
     struct { int cand[NPAIR]; float poly[96]; } b;                                         // collision(): candidates, box-box clip polygons
     struct { float cvel[NB * 9]; union { struct { float cvb[NV * 9], cdd[NV * 9]; }; float cacc[NB * 9]; };
              union { float cf[NB * 17]; float F[NV * 17]; }; } v;                          // velocity(): later stages overwrite dead earlier ones
-    struct { float cvel[NB * 9]; float Jm[48], Li[36], vv[8], Lt[64]; } k;                  // ctrl_run(): cvel stays live from velocity()
+    struct { float cvel[NB * 9]; float Jm[48], Li[36], vv[8], Lt[64], Ys[128]; } k;                  // ctrl_run(): cvel stays live from velocity()
     float W[NEFC * (NV + 1)];                                                              // solve_newton(): Hessian-weighted rows
   } u;
   float M[NV * NVP];
@@ -2138,7 +2143,6 @@ struct Sim {
     if (c.type >= RSIM_CTRL_JOINT_POSITION) { ctrl_run_joint(K); return; }
     const int n = c.ndof;
     constexpr int NA = RSIM_ARM_MAX;
-    float* Jm = sm.u.k.Jm;             // [6][NA]  arm Jacobian (lin rows 0..2, ang rows 3..5)
     float* Li = sm.u.k.Li;             // [6][6]   Lambda^-1
     float* vv = sm.u.k.vv;             // 6: J tmp
     const int eb = __shfl(K.sbody, c.eef_site), bb = __shfl(K.sbody, c.base_site);
@@ -2150,10 +2154,6 @@ struct Sim {
     // Jacobian column of the eef site for this lane's dof
     S6 jc = {v3(0, 0, 0), v3(0, 0, 0)};
     if (lane < n) jc = jac_col(eb, ep, di);
-    if (lane < NA) {
-      Jm[0 * NA + lane] = jc.l.x; Jm[1 * NA + lane] = jc.l.y; Jm[2 * NA + lane] = jc.l.z;
-      Jm[3 * NA + lane] = jc.a.x; Jm[4 * NA + lane] = jc.a.y; Jm[5 * NA + lane] = jc.a.z;
-    }
     // arm block of M: row i in lane i, Cholesky in registers
     float mr[NA], minv[NA];
     {
@@ -2171,23 +2171,36 @@ struct Sim {
     float Y[6];
     Y[0] = rchol_fwd<NA>(mr, minv, jc.l.x, lane); Y[1] = rchol_fwd<NA>(mr, minv, jc.l.y, lane); Y[2] = rchol_fwd<NA>(mr, minv, jc.l.z, lane);
     Y[3] = rchol_fwd<NA>(mr, minv, jc.a.x, lane); Y[4] = rchol_fwd<NA>(mr, minv, jc.a.y, lane); Y[5] = rchol_fwd<NA>(mr, minv, jc.a.z, lane);
-    // Lambda^-1[r][q] = sum_i Y[i][r] Y[i][q]  (21 unique entries, reduced over the 8 row lanes with DPP row adds)
+    SUBMARK(RP_X7);
+    // Lambda^-1[r][q] = sum_i Y[i][r] Y[i][q] and (J tmp)[r] = sum_i J[r][i] tmp_i in one 16 x 16 x 8 product on the matrix cores:
+    // staging row i (arm joint) = [Y[i][0..5] | J[0..5][i] | tmp_i | 0 0 0]; A[a][i] = S[i][a], B[i][b] = (b < 6 ? S[i][b] : b == 6 ? tmp_i : 0)
+    // => D[r][q] = Lambda^-1 (r, q < 6, exactly symmetric: same products in the same order) and D[6 + r][6] = (J tmp)[r]
+    {
+      float* S = sm.u.k.Ys;   // [NA][16]
+      static_assert(NA == 8, "two K = 4 chunks");
+      if (lane < NA) {
 #pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-      for (int q = r; q < 6; q++) {
-        float p = lane < NA ? Y[r] * Y[q] : 0.f;
-        p += dpp_f<0x111>(p); p += dpp_f<0x112>(p); p += dpp_f<0x114>(p);   // row_shr 1,2,4: lane 7 holds the sum of lanes 0..7
-        if (lane == 7) { Li[r * 6 + q] = p; Li[q * 6 + r] = p; }
+        for (int r = 0; r < 6; r++) { S[lane * 16 + r] = Y[r]; S[lane * 16 + 6 + r] = comp6(jc, r < 3 ? r + 3 : r - 3); }
+        S[lane * 16 + 12] = tmp_i; S[lane * 16 + 13] = 0.f; S[lane * 16 + 14] = 0.f; S[lane * 16 + 15] = 0.f;
       }
-    // J tmp
+      SYNC();
+      const int col = lane & 15, kq = lane >> 4;
+      const float a0 = S[kq * 16 + col], a1 = S[(4 + kq) * 16 + col];
+      const int bi = col < 6 ? col : 12;
+      float b0 = S[kq * 16 + bi], b1 = S[(4 + kq) * 16 + bi];
+      if (col > 6) { b0 = 0.f; b1 = 0.f; }
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-      float p = lane < NA ? comp6(jc, r < 3 ? r + 3 : r - 3) * tmp_i : 0.f;
-      p += dpp_f<0x111>(p); p += dpp_f<0x112>(p); p += dpp_f<0x114>(p);
-      if (lane == 7) vv[r] = p;
+      for (int v = 0; v < 4; v++) {
+        const int row = 4 * kq + v;
+        if (col < 6 && row < 6) Li[row * 6 + col] = acc[v];
+        if (col == 6 && row >= 6 && row < 12) vv[row - 6] = acc[v];
+      }
     }
     SYNC();
+    SUBMARK(RP_X8);
     // operational-space errors and wrench (uniform small algebra)
     const M3 oR = ldm(sm.smat + 9 * c.base_site), eR = ldm(sm.smat + 9 * c.eef_site);
     const V3 gpos = ld3(sm.cstate + RSIM_CS_GOALPOS);
@@ -2229,6 +2242,7 @@ struct Sim {
       solve3(lp, F, wrench);
       solve3(lo, T, wrench + 3);
     }
+    SUBMARK(RP_X9);
     rchol_factor<NA>(lr6, linv6);
     SYNC();
     float* Lt = sm.u.k.Lt;        // [8][8] transpose staging
@@ -2370,6 +2384,15 @@ struct Sim {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       v4f acc = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (FAST) {   // four row chunks per trip (rows >= nefc of J and e_force are zero up to row 63)
+        for (int c0 = 0; c0 < nch; c0 += 4) {
+          float ja[4], fb[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int r = 4 * (c0 + u) + (lane >> 4); ja[u] = sm.J[r * JS + (lane & 15)]; fb[u] = sm.e_force[r]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ja[u], fb[u], acc, 0, 0, 0);
+        }
+      } else
       for (int c = 0; c < nch; c++)
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.J[(4 * c + (lane >> 4)) * JS + 16 * t + (lane & 15)], sm.e_force[4 * c + (lane >> 4)], acc, 0, 0, 0);
       if ((lane & 15) == 0) { float* o = sm.red + 16 * t + 4 * (lane >> 4); o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; }
@@ -2423,6 +2446,7 @@ struct Sim {
 #pragma unroll
       for (int v = 0; v < 4; v++) { int i = 4 * (lane >> 4) + v, j = lane & 15; Macc[v] = (i < nv && j < nv) ? sm.M[i * NVP + j] : (i == j ? 1.f : 0.f); }
     }
+    SUBMARK(RP_X0);
     const float a_sm = rr < nv ? sm.qacc_smooth[rr] : 0.f, a_ws = rr < nv ? sm.qacc_ws[rr] : 0.f, f_sm = rr < nv ? sm.qfrc_smooth[rr] : 0.f;
     float force[NSLOT], jar[NSLOT], uj[NSLOT][CD], T[NSLOT], g[NSLOT];
     int state[NSLOT];
@@ -2443,6 +2467,7 @@ struct Sim {
       const float dws = a_ws - a_sm, sv = mass_dot(Mr, dws);
       cost_ws += wave_sum(dofl ? 0.5f * sv * dws : 0.f);
     }
+    SUBMARK(RP_X1);
     float a = cost_ws < cost_sm ? a_ws : a_sm;
     int iter = 0;
     for (;;) {
@@ -2456,6 +2481,7 @@ struct Sim {
       const float jf = jt_times_force(nch);
       float gk = rr < nv ? ma - f_sm - jf : 0.f;
       const float gn = wave_sum(dofl ? gk * gk : 0.f);
+      SUBMARK(RP_X2);
       if (iter >= m.iterations || scale * sqrtf(gn) < tolerance) break;
       // ---- Hessian weights W (row r): D J_r (quadratic), 0 (linear / satisfied), cone block Hc J_block
 #pragma unroll
@@ -2510,6 +2536,7 @@ struct Sim {
       }
       SYNC();
       float sk;
+      SUBMARK(RP_X3);
       if constexpr (!FAST) {
         // H = M + J^T W as NT x NT MFMA tiles, factorised in place on the LDS matrix (H aliases the dead factor of M)
 #pragma unroll
@@ -2530,7 +2557,14 @@ struct Sim {
         if (lane >= nv) sk = 0.f;
       } else {
         v4f acc = Macc;
-        for (int c = 0; c < nch; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.u.W[(4 * c + (lane >> 4)) * JS + (lane & 15)], sm.J[(4 * c + (lane >> 4)) * JS + (lane & 15)], acc, 0, 0, 0);
+        // four row chunks per trip: eight LDS reads in flight, then four MFMAs (rows >= nefc of W and J are zero up to row 63)
+        for (int c0 = 0; c0 < nch; c0 += 4) {
+          float wa[4], jb[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int o = (4 * (c0 + u) + (lane >> 4)) * JS + (lane & 15); wa[u] = sm.u.W[o]; jb[u] = sm.J[o]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u], jb[u], acc, 0, 0, 0);
+        }
 #pragma unroll
         for (int v = 0; v < 4; v++) sm.H[(4 * (lane >> 4) + v) * NVP + (lane & 15)] = acc[v];
         SYNC();
@@ -2550,6 +2584,7 @@ struct Sim {
         sk = rchol_solve<NV16>(hr, ht, hinv, rr2 < nv ? -gk : 0.f, lane);
         if (rr2 >= nv) sk = 0.f;
       }
+      SUBMARK(RP_X4);
       // ---- line search along sk
       float jv[NSLOT];
 #pragma unroll
@@ -2573,6 +2608,7 @@ struct Sim {
         line(0.f, c, c1, c2);
         p0 = gauss + wave_sum(c); d0 = q1 + wave_sum(c1); h0 = 2 * q2 + wave_sum(c2);
       }
+      SUBMARK(RP_X5);
       if (d0 >= 0 || h0 <= 0) break;
       alpha = -d0 / h0;
       // fp32 line search: stop when the directional derivative has dropped below MuJoCo's gtol, by 1e6 relative to its
@@ -2598,6 +2634,7 @@ struct Sim {
         line(alpha, c, c1, c2);
         p = gauss + alpha * q1 + alpha * alpha * q2 + wave_sum(c);
       }
+      SUBMARK(RP_X6);
       if (!(p < p0)) break;
       a = fmaf(alpha, sk, a);
       iter++;
