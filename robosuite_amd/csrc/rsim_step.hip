@@ -370,6 +370,40 @@ __device__ __forceinline__ float rchol_solve(const float (&a)[N], const float (&
   x = RcholFwd<N, 0>::run(a, inv, x, lane & 15);
   return RcholBwd<N, N - 1>::run(at, inv, x, lane & 15);
 }
+// ---- mask-free triangular solves.  The selects `row == K ? .. : row > K ? ..` above cost a lane predicate per step; those predicates are
+// loop-invariant, so the compiler hoists all of them out of the substep loop as 64-bit SGPR masks and then spills / reloads them around
+// every use (4 v_readlane + s_nop per step).  Here the factor rows are masked ONCE to their strictly-lower part (am[k] = 0 for k >= row;
+// the transposed copy atm[k] = L[k][row] for k > row, else 0), the diagonal scaling is deferred to the end (lane K's x is not touched
+// after step K), and every step is two instructions: a DPP multiply and an FMA.
+__device__ __forceinline__ int opaque_lane(int x) { asm volatile("" : "+v"(x)); return x; }   // fresh value: keeps the masks from being hoisted
+template <int N>
+__device__ __forceinline__ void rchol_mask_lower(float (&a)[N], int row) {
+#pragma unroll
+  for (int k = 0; k < N; k++) a[k] = k < row ? a[k] : 0.f;
+}
+template <int N, int K>
+struct RcholFwdM {
+  static __device__ __forceinline__ float run(const float (&am)[N], const float (&inv)[N], float x) {
+    if constexpr (K < N) { const float xk = rbcast<K>(x) * inv[K]; return RcholFwdM<N, K + 1>::run(am, inv, fmaf(-am[K], xk, x)); }
+    else return x;
+  }
+};
+template <int N, int K>
+struct RcholBwdM {
+  static __device__ __forceinline__ float run(const float (&atm)[N], const float (&inv)[N], float x) {
+    if constexpr (K >= 0) { const float xk = rbcast<K>(x) * inv[K]; return RcholBwdM<N, K - 1>::run(atm, inv, fmaf(-atm[K], xk, x)); }
+    else return x;
+  }
+};
+// y = L^-1 x;  am = strictly-lower row of L, inv[k] = 1 / L[k][k] (uniform), own = 1 / L[row][row]
+template <int N>
+__device__ __forceinline__ float rchol_fwd_m(const float (&am)[N], const float (&inv)[N], float own, float x) { return RcholFwdM<N, 0>::run(am, inv, x) * own; }
+// (L L^T)^-1 x
+template <int N>
+__device__ __forceinline__ float rchol_solve_m(const float (&am)[N], const float (&atm)[N], const float (&inv)[N], float own, float x) {
+  x = RcholFwdM<N, 0>::run(am, inv, x) * own;
+  return RcholBwdM<N, N - 1>::run(atm, inv, x) * own;
+}
 // sum_k r[k] * x_k, where x_k lives in lane k of every 16-lane row (replicated per-dof vector)
 template <int N, int K>
 struct RowDot {
@@ -1068,7 +1102,9 @@ struct Sim {
       const float hd = r < nv ? opt_h * K.damping : 0.f;   // dof lanes: lane & 15 = dof (K is fetched per 16-lane row)
 #pragma unroll
       for (int k = 0; k < NV16; k++) { mr[k] = sm.M[r * NVP + k]; er[k] = mr[k] + (k == r ? hd : 0.f); }
-      const float mown = rchol_factor_own<NV16>(mr, minv, r), eown = rchol_factor_own<NV16>(er, einv, r);
+      const int ro = opaque_lane(r);
+      const float mown = rchol_factor_own<NV16>(mr, minv, ro), eown = rchol_factor_own<NV16>(er, einv, ro);
+      rchol_mask_lower<NV16>(mr, ro); rchol_mask_lower<NV16>(er, ro);   // stored strictly lower: rows and columns read back ready for rchol_solve_m
       if (lane < NV16) {
 #pragma unroll
         for (int k = 0; k < NV16; k++) { sm.L[lane * NVP + k] = mr[k]; sm.Le[lane * NVP + k] = er[k]; }
@@ -1908,7 +1944,7 @@ struct Sim {
       const int rr = lane & (NV16 - 1);
 #pragma unroll
       for (int k = 0; k < NV16; k++) { lr[k] = sm.L[rr * NVP + k]; lt[k] = sm.L[k * NVP + rr]; linv[k] = sm.invdiag[k]; }
-      as = rchol_solve<NV16>(lr, lt, linv, lane < nv ? qs : 0.f, lane);
+      as = rchol_solve_m<NV16>(lr, lt, linv, sm.invdiag[rr], lane < nv ? qs : 0.f);
     }
     if (lane < nv) sm.qacc_smooth[lane] = as;
     SYNC();
@@ -1936,7 +1972,7 @@ struct Sim {
       const int rr = lane & (NV16 - 1);
 #pragma unroll
       for (int k = 0; k < NV16; k++) { lr[k] = sm.Le[rr * NVP + k]; lt[k] = sm.Le[k * NVP + rr]; linv[k] = sm.invdiag_e[k]; }
-      qa = rchol_solve<NV16>(lr, lt, linv, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, lane);
+      qa = rchol_solve_m<NV16>(lr, lt, linv, sm.invdiag_e[rr], lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f);
     }
     if (lane < nv) { sm.qvel[lane] += h * qa; sm.qacc_ws[lane] = sm.qacc[lane]; }
     SYNC();
@@ -2155,22 +2191,24 @@ struct Sim {
     S6 jc = {v3(0, 0, 0), v3(0, 0, 0)};
     if (lane < n) jc = jac_col(eb, ep, di);
     // arm block of M: row i in lane i, Cholesky in registers
+    const int row8 = opaque_lane(lane & (NA - 1));
     float mr[NA], minv[NA];
     {
       int dk[NA];
 #pragma unroll
       for (int k = 0; k < NA; k++) dk[k] = k < n ? c.dof_idx[k] : 0;
 #pragma unroll
-      for (int k = 0; k < NA; k++) mr[k] = (lane < n && k < n) ? sm.M[di * NVP + dk[k]] : ((lane & (NA - 1)) == k ? 1.f : 0.f);
+      for (int k = 0; k < NA; k++) { const float v = sm.M[di * NVP + dk[k]]; mr[k] = (lane < n && k < n) ? v : (row8 == k ? 1.f : 0.f); }   // di = 0 on padding lanes
     }
     float matmp = 0.f;   // (Ma tmp)_i
 #pragma unroll
     for (int k = 0; k < NA; k++) matmp = fmaf(mr[k], bcast(tmp_i, k), matmp);
-    rchol_factor<NA>(mr, minv);
+    const float mown = rchol_factor_own<NA>(mr, minv, row8);
+    rchol_mask_lower<NA>(mr, row8);
     // Y[:, r] = La^-1 J[r, :]^T  (component i in lane i)
     float Y[6];
-    Y[0] = rchol_fwd<NA>(mr, minv, jc.l.x, lane); Y[1] = rchol_fwd<NA>(mr, minv, jc.l.y, lane); Y[2] = rchol_fwd<NA>(mr, minv, jc.l.z, lane);
-    Y[3] = rchol_fwd<NA>(mr, minv, jc.a.x, lane); Y[4] = rchol_fwd<NA>(mr, minv, jc.a.y, lane); Y[5] = rchol_fwd<NA>(mr, minv, jc.a.z, lane);
+    Y[0] = rchol_fwd_m<NA>(mr, minv, mown, jc.l.x); Y[1] = rchol_fwd_m<NA>(mr, minv, mown, jc.l.y); Y[2] = rchol_fwd_m<NA>(mr, minv, mown, jc.l.z);
+    Y[3] = rchol_fwd_m<NA>(mr, minv, mown, jc.a.x); Y[4] = rchol_fwd_m<NA>(mr, minv, mown, jc.a.y); Y[5] = rchol_fwd_m<NA>(mr, minv, mown, jc.a.z);
     SUBMARK(RP_X7);
     // Lambda^-1[r][q] = sum_i Y[i][r] Y[i][q] and (J tmp)[r] = sum_i J[r][i] tmp_i in one 16 x 16 x 8 product on the matrix cores:
     // staging row i (arm joint) = [Y[i][0..5] | J[0..5][i] | tmp_i | 0 0 0]; A[a][i] = S[i][a], B[i][b] = (b < 6 ? S[i][b] : b == 6 ? tmp_i : 0)
@@ -2243,7 +2281,8 @@ struct Sim {
       solve3(lo, T, wrench + 3);
     }
     SUBMARK(RP_X9);
-    rchol_factor<NA>(lr6, linv6);
+    const float own6 = rchol_factor_own<NA>(lr6, linv6, row8);
+    rchol_mask_lower<NA>(lr6, row8);
     SYNC();
     float* Lt = sm.u.k.Lt;        // [8][8] transpose staging
     if (lane < NA) {
@@ -2254,11 +2293,11 @@ struct Sim {
 #pragma unroll
     for (int k = 0; k < NA; k++) lt6[k] = Lt[k * NA + (lane & (NA - 1))];
     {
-      const float zl = rchol_solve<NA>(lr6, lt6, linv6, lane < 6 ? vv[lane] : 0.f, lane);
+      const float zl = rchol_solve_m<NA>(lr6, lt6, linv6, own6, lane < 6 ? vv[lane] : 0.f);
 #pragma unroll
       for (int r = 0; r < 6; r++) z[r] = bcast(zl, r);
       if (!c.uncouple) {
-        const float wl = rchol_solve<NA>(lr6, lt6, linv6, lane < 3 ? F[lane] : (lane < 6 ? T[lane - 3] : 0.f), lane);
+        const float wl = rchol_solve_m<NA>(lr6, lt6, linv6, own6, lane < 3 ? F[lane] : (lane < 6 ? T[lane - 3] : 0.f));
 #pragma unroll
         for (int r = 0; r < 6; r++) wrench[r] = bcast(wl, r);
       }
@@ -2572,7 +2611,9 @@ struct Sim {
         const int rr2 = lane & 15;
 #pragma unroll
         for (int k = 0; k < NV16; k++) hr[k] = sm.H[rr2 * NVP + k];
-        rchol_factor<NV16>(hr, hinv);
+        const int ro = opaque_lane(rr2);
+        const float hown = rchol_factor_own<NV16>(hr, hinv, ro);
+        rchol_mask_lower<NV16>(hr, ro);
         SYNC();
         if (lane < NV16) {
 #pragma unroll
@@ -2581,7 +2622,7 @@ struct Sim {
         SYNC();
 #pragma unroll
         for (int k = 0; k < NV16; k++) ht[k] = sm.H[k * NVP + rr2];
-        sk = rchol_solve<NV16>(hr, ht, hinv, rr2 < nv ? -gk : 0.f, lane);
+        sk = rchol_solve_m<NV16>(hr, ht, hinv, hown, rr2 < nv ? -gk : 0.f);
         if (rr2 >= nv) sk = 0.f;
       }
       SUBMARK(RP_X4);
