@@ -41,7 +41,8 @@
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
 enum { G_PLANE = 0, G_HFIELD, G_SPHERE, G_CAPSULE, G_ELLIPSOID, G_CYLINDER, G_BOX, G_MESH };
 enum { C_FRICTION_DOF = 0, C_LIMIT_JOINT = 1, C_CONTACT_FRICTIONLESS = 2, C_CONTACT_ELLIPTIC = 3,
-       C_EQUALITY = 4 /* bilateral: always quadratic */, C_LIMIT_TENDON = 5 /* as a joint limit, on a fixed tendon's length */ };
+       C_EQUALITY = 4 /* bilateral: always quadratic */, C_LIMIT_TENDON = 5 /* as a joint limit, on a fixed tendon's length */,
+       C_FRICTION_TENDON = 6 /* friction loss along a fixed tendon: the cost of C_FRICTION_DOF on the tendon's coefficient row */ };
 
 /* ------------------------------------------------------------------------------------------- */
 /* model blob                                                                                  */
@@ -81,6 +82,7 @@ typedef struct {
   int *tendon_adr, *tendon_num, *wrap_objid, *tendon_limited, *eq_obj1id;
   double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_length0, *tendon_invweight0, *eq_data, *eq_solref, *eq_solimp;
   double *tendon_stiffness, *tendon_damping, *tendon_lengthspring;   /* spring-damper on the tendon length (may be absent) */
+  double *tendon_frictionloss, *tendon_solref_fri, *tendon_solimp_fri; /* dry friction along the tendon (may be absent) */
 } rso_model;
 
 static void *blob_find(rso_model *m, const char *name, int *count) {
@@ -127,7 +129,7 @@ rso_model *rso_model_create(const void *blob, size_t len) {
   PI_(tendon_adr); PI_(tendon_num); PI_(wrap_objid); PI_(tendon_limited); PI_(eq_obj1id);
   PD_(wrap_prm); PD_(tendon_range); PD_(tendon_margin); PD_(tendon_solref_lim); PD_(tendon_solimp_lim); PD_(tendon_length0); PD_(tendon_invweight0);
   PD_(eq_data); PD_(eq_solref); PD_(eq_solimp);
-  PD_(tendon_stiffness); PD_(tendon_damping); PD_(tendon_lengthspring);
+  PD_(tendon_stiffness); PD_(tendon_damping); PD_(tendon_lengthspring); PD_(tendon_frictionloss); PD_(tendon_solref_fri); PD_(tendon_solimp_fri);
   /* mean diagonal inertia at qpos0 (MuJoCo stat.meaninertia [3P]) */
   double s = 0;
   for (int i = 0; i < m->nv; i++) s += m->dof_M0[i];
@@ -1131,6 +1133,16 @@ static void make_constraint(rso_data *d) {
       d->efc_J[(size_t)r * nv + i] = 1;
       add_row(d, C_FRICTION_DOF, i, 0, 0, m->dof_frictionloss[i], m->dof_solref + 2 * i, m->dof_solimp + 5 * i, m->dof_invweight0[i]);
     }
+  /* tendon friction loss (mj_instantiateFriction [3P]: dofs first, then tendons; diagApprox = tendon_invweight0, solreffriction / solimpfriction) */
+  if (m->tendon_frictionloss)
+    for (int t = 0; t < m->ntendon; t++)
+      if (m->tendon_frictionloss[t] > 0) {
+        int r = d->nefc;
+        double *J = d->efc_J + (size_t)r * nv;
+        memset(J, 0, sizeof(double) * nv);
+        for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) J[m->jnt_dofadr[m->wrap_objid[w]]] += m->wrap_prm[w];
+        add_row(d, C_FRICTION_TENDON, t, 0, 0, m->tendon_frictionloss[t], m->tendon_solref_fri + 2 * t, m->tendon_solimp_fri + 5 * t, m->tendon_invweight0[t]);
+      }
   /* joint limits (hinge / slide) */
   for (int j = 0; j < m->njnt; j++) {
     if (!m->jnt_limited[j] || (m->jnt_type[j] != JNT_HINGE && m->jnt_type[j] != JNT_SLIDE)) continue;
@@ -1273,6 +1285,7 @@ static double dual_cost(rso_data *d, const double *f) {
 static void primal_force(rso_data *d, const double *jar, double *f) {
   for (int i = 0; i < d->nefc; i++) {
     switch (d->efc_type[i]) {
+      case C_FRICTION_TENDON:
       case C_FRICTION_DOF: {
         double v = -d->efc_D[i] * jar[i], fl = d->efc_frictionloss[i];
         f[i] = v > fl ? fl : (v < -fl ? -fl : v);
@@ -1353,7 +1366,7 @@ static void solve_pgs(rso_data *d) {
       }
       if (dim == 1) {
         double v = f[i] - res[0] / Athis[0];
-        if (type == C_FRICTION_DOF) { double fl = d->efc_frictionloss[i]; v = v > fl ? fl : (v < -fl ? -fl : v); }
+        if (type == C_FRICTION_DOF || type == C_FRICTION_TENDON) { double fl = d->efc_frictionloss[i]; v = v > fl ? fl : (v < -fl ? -fl : v); }
         else if (type == C_EQUALITY) { /* bilateral: unbounded */ }
         else if (v < 0) v = 0;
         f[i] = v;
@@ -1421,6 +1434,7 @@ static double constraint_update(rso_data *d, const double *jar, double *force, i
   for (int i = 0; i < d->nefc; i++) {
     double D = d->efc_D[i], R = d->efc_R[i];
     switch (d->efc_type[i]) {
+      case C_FRICTION_TENDON:
       case C_FRICTION_DOF: {
         double fl = d->efc_frictionloss[i];
         if (jar[i] <= -R * fl) { state[i] = ST_LINEARNEG; force[i] = fl; cost += fl * (-0.5 * R * fl - jar[i]); }
@@ -1482,6 +1496,7 @@ static void ls_eval(rso_data *d, const double *jar, const double *jv, const doub
   for (int i = 0; i < d->nefc; i++) {
     double D = d->efc_D[i], R = d->efc_R[i], x = jar[i] + alpha * jv[i], v = jv[i];
     switch (d->efc_type[i]) {
+      case C_FRICTION_TENDON:
       case C_FRICTION_DOF: {
         double fl = d->efc_frictionloss[i];
         if (x <= -R * fl) { c += fl * (-0.5 * R * fl - x); c1 -= fl * v; }

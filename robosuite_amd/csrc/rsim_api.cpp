@@ -432,6 +432,8 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
     };
     pushopt(FO_tendon_stiffness, "tendon_stiffness", nt, 0.0); pushopt(FO_tendon_damping, "tendon_damping", nt, 0.0);
     pushopt(FO_tendon_lspring, "tendon_lengthspring", 2 * nt, 0.0);
+    pushopt(FO_tendon_fl, "tendon_frictionloss", nt, 0.0); pushopt(FO_tendon_solref_fri, "tendon_solref_fri", 2 * nt, 0.0);
+    pushopt(FO_tendon_solimp_fri, "tendon_solimp_fri", 5 * nt, 0.0);
   }
   m->fo[FO_opt] = (int)ft.size(); m->fcount[FO_opt] = 10;
   {

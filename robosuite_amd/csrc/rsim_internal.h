@@ -30,6 +30,7 @@ enum {
   FO_wrap_prm, FO_tendon_range, FO_tendon_margin, FO_tendon_solref, FO_tendon_solimp, FO_tendon_len0, FO_tendon_invw,
   FO_eq_data0 /* polycoef[0] */, FO_eq_solref, FO_eq_solimp,
   FO_tendon_stiffness, FO_tendon_damping, FO_tendon_lspring /* 2 per tendon */,
+  FO_tendon_fl /* frictionloss */, FO_tendon_solref_fri /* 2 */, FO_tendon_solimp_fri /* 5 */,
   FO_COUNT
 };
 

@@ -58,7 +58,8 @@ typedef unsigned long long u64;
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
 enum { G_PLANE = 0, G_HFIELD, G_SPHERE, G_CAPSULE, G_ELLIPSOID, G_CYLINDER, G_BOX, G_MESH };
 enum { C_FRICTION_DOF = 0, C_LIMIT_JOINT = 1, C_CONTACT_FRICTIONLESS = 2, C_CONTACT_ELLIPTIC = 3,
-       C_EQUALITY = 4 /* equality/tendon: bilateral, always quadratic */, C_LIMIT_TENDON = 5 /* limit on a fixed tendon's length */ };
+       C_EQUALITY = 4 /* equality/tendon: bilateral, always quadratic */, C_LIMIT_TENDON = 5 /* limit on a fixed tendon's length */,
+       C_FRICTION_TENDON = 6 /* friction loss along a fixed tendon: the solver sees it as C_FRICTION_DOF on the tendon's coefficient row */ };
 enum { ST_SATISFIED = 0, ST_QUADRATIC = 1, ST_LINEARNEG = 2, ST_LINEARPOS = 3, ST_CONE = 4 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1765,6 +1766,23 @@ struct Sim {
       nefc += __popcll(mk);
       if (nefc > NEFCAP) nefc = NEFCAP;   // rows beyond the capacity (64 or 128) are dropped
     }
+    // (1b) friction loss along fixed tendons (after the dof rows, mj_instantiateFriction [3P]): lane t owns tendon t
+    if (TENDONS && m.ntendon) {
+      const int tl = lane < m.ntendon ? lane : 0;
+      const bool act = lane < m.ntendon && FP(FO_tendon_fl, tl) > 0.f;
+      const u64 mk = __ballot(act);
+      if (act) {
+        const int r = nefc + __popcll(mk & lanemask_lt(lane));
+        const float solref[2] = {FP(FO_tendon_solref_fri, 2 * tl), FP(FO_tendon_solref_fri, 2 * tl + 1)};
+        float solimp[5];
+        for (int k = 0; k < 5; k++) solimp[k] = FP(FO_tendon_solimp_fri, 5 * tl + k);
+        float R, Bd, Kt;
+        row_scalars(0.f, 0.f, solref, solimp, FP(FO_tendon_invw, tl), R, Bd, Kt);
+        if (r < NEFCAP) { sm.e_desc[r] = C_FRICTION_TENDON | (lane << 4); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = 0.f; }
+      }
+      nefc += __popcll(mk);
+      if (nefc > NEFCAP) nefc = NEFCAP;
+    }
     // (2) joint limits: dof lane i owns its hinge / slide joint; lower side before upper side
     {
       const bool lim = isdof && ((K.dinfo >> 9) & 1) && (jt == JNT_HINGE || jt == JNT_SLIDE);
@@ -1879,7 +1897,7 @@ struct Sim {
         const float sg = kk ? -1.f : 1.f;  // lower limit: +dq increases the distance; upper: decreases it
 #pragma unroll
         for (int k = 0; k < NV16; k++) Jr[k] = k == id ? sg : 0.f;
-      } else if (TENDONS && valid && (type == C_EQUALITY || type == C_LIMIT_TENDON)) {
+      } else if (TENDONS && valid && (type == C_EQUALITY || type == C_LIMIT_TENDON || type == C_FRICTION_TENDON)) {
         // row of a fixed tendon: its coefficients on the dofs of its (at most four) joints; an upper limit takes the negative row
         const float sg = (type == C_LIMIT_TENDON && kk) ? -1.f : 1.f;
         const int adr = IT(IO_tendon_adr, id), num = IT(IO_tendon_num, id);
@@ -2462,7 +2480,9 @@ struct Sim {
       }
       const int desc = w_.valid ? sm.e_desc[r] : 0;
       w_.type = w_.valid ? (desc & 15) : -1;
-      w_.R = sm.e_R[r]; w_.D = 1.0f / w_.R; w_.aref = w_.valid ? sm.e_aref[r] : 0.f; w_.fl = w_.type == C_FRICTION_DOF ? sm.fricFl[(desc >> 4) & 255] : 0.f;
+      const bool tfric = TENDONS && w_.type == C_FRICTION_TENDON;   // a tendon friction row behaves as a dof friction row from here on
+      if (tfric) w_.type = C_FRICTION_DOF;
+      w_.R = sm.e_R[r]; w_.D = 1.0f / w_.R; w_.aref = w_.valid ? sm.e_aref[r] : 0.f; w_.fl = tfric ? FP(FO_tendon_fl, (desc >> 4) & 255) : (w_.type == C_FRICTION_DOF ? sm.fricFl[(desc >> 4) & 255] : 0.f);
       w_.ell = w_.type == C_CONTACT_ELLIPTIC;
       const int c = w_.ell ? (desc >> 4) & 255 : 0;
       w_.kk = w_.ell ? (desc >> 12) & 15 : 0; w_.head = row - w_.kk; w_.dim = w_.ell ? sm.cdim[c] : 1;

@@ -1026,8 +1026,6 @@ def compile_mjcf(xml: str, asset_dir: str | None = None, max_hull_vert: int = 0)
         for t in tend:
             if t.tag != "fixed":
                 raise MJCFError("spatial tendons are not supported (only <tendon><fixed>)")
-            if t.get("frictionloss") is not None and any(abs(x) > 0 for x in _floats(t.get("frictionloss"))):
-                raise MJCFError("tendon attribute frictionloss is not supported")
             sl = _floats(t.get("springlength"), None, [-1.0])     # one value = no deadband; -1 = the length at qpos0 (set in _set_const)
             sl = [sl[0], sl[0]] if len(sl) == 1 else list(sl[:2])
             wraps = [(jname2id[w.get("joint")], float(w.get("coef", "1"))) for w in t.findall("joint")]
@@ -1038,7 +1036,10 @@ def compile_mjcf(xml: str, asset_dir: str | None = None, max_hull_vert: int = 0)
             limited = t.get("limited")
             tendons.append(dict(name=t.get("name"), wraps=wraps, range=rng, stiffness=float(t.get("stiffness", "0")), damping=float(t.get("damping", "0")), lengthspring=sl, limited=1 if (limited == "true" or (limited in (None, "auto") and t.get("range") is not None and compiler["autolimits"])) else 0,
                                 margin=float(t.get("margin", "0")), solref=_floats(t.get("solreflimit"), 2, [0.02, 1.0]),
-                                solimp=_floats(t.get("solimplimit"), 5, [0.9, 0.95, 0.001, 0.5, 2.0])))
+                                solimp=_floats(t.get("solimplimit"), 5, [0.9, 0.95, 0.001, 0.5, 2.0]),
+                                # dry friction along the tendon (Jaco fingers, jaco_three_finger_gripper.xml:17-29): one friction-loss row per tendon
+                                frictionloss=float(t.get("frictionloss", "0")), solref_fri=_floats(t.get("solreffriction"), 2, [0.02, 1.0]),
+                                solimp_fri=_floats(t.get("solimpfriction"), 5, [0.9, 0.95, 0.001, 0.5, 2.0])))
     ntendon = len(tendons)
     eqs = []
     eq = root.find("equality")
@@ -1071,6 +1072,9 @@ def compile_mjcf(xml: str, asset_dir: str | None = None, max_hull_vert: int = 0)
     m.set("tendon_lengthspring", np.array([t["lengthspring"] for t in tendons], dtype=F64).reshape(ntendon, 2), F64)
     m.set("tendon_solref_lim", np.array([t["solref"] for t in tendons], dtype=F64).reshape(ntendon, 2), F64)
     m.set("tendon_solimp_lim", np.array([t["solimp"] for t in tendons], dtype=F64).reshape(ntendon, 5), F64)
+    m.set("tendon_frictionloss", np.array([t["frictionloss"] for t in tendons], dtype=F64), F64)
+    m.set("tendon_solref_fri", np.array([t["solref_fri"] for t in tendons], dtype=F64).reshape(ntendon, 2), F64)
+    m.set("tendon_solimp_fri", np.array([t["solimp_fri"] for t in tendons], dtype=F64).reshape(ntendon, 5), F64)
     m.set("eq_obj1id", np.array([e["tendon"] for e in eqs], dtype=I32), I32)
     m.set("eq_data", np.array([e["polycoef"] for e in eqs], dtype=F64).reshape(neq, 5), F64)
     m.set("eq_solref", np.array([e["solref"] for e in eqs], dtype=F64).reshape(neq, 2), F64)

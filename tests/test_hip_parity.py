@@ -503,6 +503,37 @@ def test_lift_ur5e_with_spring_tendon_gripper():
         assert dq[~fingers].max() < 1e-3 and dq[fingers].max() < 0.1, t
 
 
+def test_lift_jaco_with_tendon_friction_rows():
+    """Lift / Jaco + three-finger gripper: equality, spring, limit AND friction-loss rows on the three finger tendons.  Constraint rows
+    (count, forces) and accelerations on the device against the oracle at recorded states, then the fused control step against the oracle loop."""
+    g, cfg, flat = load_golden("seed0", "lift_jaco")
+    nq = flat.nq
+    om, od, oc = make_oracle(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=2)
+    for i in (0, 6, 19):
+        s = g["states"][i]
+        od.qpos[:] = s[1:1 + nq]; od.qvel[:] = s[1 + nq:]; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0; od.forward()
+        hb.set("qpos", s[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0); hb.forward()
+        assert hb.get("nefc")[0] == od.nefc and od.efc_types().count(6) == 3
+        assert np.abs(hb.get("qfrc_passive")[0] - od.qfrc_passive).max() < 1e-5 * max(1.0, np.abs(od.qfrc_passive).max())
+        # the friction-loss rows of the tendons are rows 3 + (#dof friction rows) ...: forces of all rows against the oracle's
+        f_h, f_o = hb.get("efc_force")[0][:od.nefc], np.asarray(od.efc_force[:od.nefc])
+        assert np.abs(f_h - f_o).max() < 2e-3 * max(1.0, np.abs(f_o).max()), i
+        fing = np.zeros(flat.nv, dtype=bool); fing[cfg["grip_dof_idx"]] = True
+        da = np.abs(hb.get("qacc")[0] - od.qacc)
+        assert da[~fing].max() < 2e-3 * max(1.0, np.abs(od.qacc).max()) and da[fing].max() < 5e-2 * max(1.0, np.abs(od.qacc).max()), i
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0; od.forward(); oc.reset(od)
+    hb.set("qpos", s0[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    fingers = np.zeros(nq, dtype=bool); fingers[cfg["grip_qpos_idx"]] = True
+    for t in range(len(g["actions"])):
+        hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 2, 0), dtype=torch.float32, device="cuda"), 25)
+        oc.env_step(od, g["actions"][t], 25)
+        dq = np.abs(hb.get("qpos")[0] - od.qpos)
+        assert dq[~fingers].max() < 1e-3 and dq[fingers].max() < 0.1, t
+
+
 def test_replay_is_bitwise_deterministic():
     """The reference's only numeric assert on sim state is bitwise replay equality (test_action_playback.py:46-68)."""
     g, cfg, flat = load_golden("seed1_full")

@@ -145,6 +145,27 @@ def test_lift_ur5e_robotiq85_fixture_replays_on_the_oracle():
         assert dq[~fingers].max() < 5e-5 and dq[fingers].max() < 5e-2, t     # undamped finger links under kp = 20 actuators amplify 1e-6 of ctrl
 
 
+def test_lift_jaco_three_finger_fixture_replays_on_the_oracle():
+    """Lift / Jaco + three-finger gripper (jaco_three_finger_gripper.xml:15-42): three fixed tendons, each with an equality/tendon row, a spring,
+    a length limit and frictionloss = 0.4 -> friction-loss rows on tendon coefficient rows (after the dof friction rows).  The oracle loop
+    replays the fixture recorded from the reference env loop and builds the rows in MuJoCo's order."""
+    g, cfg, flat = load_golden("seed0", "lift_jaco")
+    assert int(flat.ntendon) == 3 and int(flat.neq) == 3 and flat.tendon_frictionloss.tolist() == [0.4, 0.4, 0.4]
+    om, od, oc = make_oracle(flat, cfg)
+    nq = flat.nq
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0
+    od.forward(); oc.reset(od)
+    types = od.efc_types()
+    nfd = int((np.asarray(flat.dof_frictionloss) > 0).sum())
+    assert types[:3] == [4, 4, 4] and types[3:3 + nfd] == [0] * nfd and types[3 + nfd:6 + nfd] == [6, 6, 6]
+    fingers = np.zeros(nq, dtype=bool); fingers[cfg["grip_qpos_idx"]] = True
+    for t in range(len(g["actions"])):
+        oc.env_step(od, g["actions"][t], 25)
+        dq = np.abs(od.qpos - g["states"][t + 1][1:1 + nq])
+        assert dq[~fingers].max() < 5e-5 and dq[fingers].max() < 5e-3, t
+
+
 def test_reset_path_known_answers():
     """values produced by the reference's own reset code (placement_samplers.py:221-309,
     robots/robot.py:247-259, lift.py:311-318) for seed 0, re-derived from the documented draw order."""

@@ -247,7 +247,8 @@ def record_baxter(seed, n_steps, action_scale, ctype):
 
 
 # format_action direction tables (panda_gripper.py:55-57, robotiq_140_gripper.py:66-68, robotiq_85_gripper.py:65-67)
-GRIPPER_SIGNS = {"PandaGripper": [-1.0, 1.0], "Robotiq140Gripper": [1.0, -1.0], "Robotiq85Gripper": [1.0, 1.0]}
+GRIPPER_SIGNS = {"PandaGripper": [-1.0, 1.0], "Robotiq140Gripper": [1.0, -1.0], "Robotiq85Gripper": [1.0, 1.0],
+                 "JacoThreeFingerGripper": [-1.0, -1.0, -1.0]}   # jaco_three_finger_gripper.py:57-71: current_action - speed * sign(action)
 
 
 def record_pickplace(seed, n_steps, action_scale, tag):
@@ -418,6 +419,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--ur5e-only" in sys.argv:
         record_lift_robot("UR5e", 0, 20, 1.0)
+        sys.exit(0)
+    if "--jaco-only" in sys.argv:
+        record_lift_robot("Jaco", 0, 20, 1.0)
         sys.exit(0)
     if "--baxter-model-only" in sys.argv:
         record_baxter_model(1)
