@@ -27,7 +27,7 @@ from robosuite_amd import lift, mjcf, shard  # noqa: E402
 ENVS_PER_GPU = 4096
 N_SUB = 25
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
-VALU_PER_ENV_SUBSTEP = 8700.0  # SQ_INSTS_VALU / (4096 envs x 25 substeps), profiles/r01_c_pmc_sq1.txt (bench workload, steps 1-4 of an episode)
+VALU_PER_ENV_SUBSTEP = 7360.0  # SQ_INSTS_VALU / (4096 envs x 25 substeps), profiles/r01_e_pmc_sq1.txt (bench workload, steps 1-4 of an episode)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4  # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles at 2.4 GHz
 
 
