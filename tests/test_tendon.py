@@ -1,6 +1,6 @@
 """Fixed tendons, equality/tendon constraints and tendon limits in the MJCF compiler and the CPU oracle (the Robotiq coupling pattern of
-BASELINE configs[4], reference models/assets/grippers/robotiq_gripper_140.xml:15-44).  The fused kernel does not carry these rows yet:
-`rsim_batch_create` refuses such models (tested in test_abi)."""
+BASELINE configs[4], reference models/assets/grippers/robotiq_gripper_140.xml:15-44; spring and friction-loss attributes as on the Robotiq85
+and Jaco fingers).  Device-side counterparts: tests/test_hip_parity.py (PickPlace / UR5e / Jaco fixtures)."""
 import os
 
 import numpy as np
@@ -58,3 +58,35 @@ def test_tendon_limit_stops_the_uncoupled_finger():
     od.forward()
     types = list(od.efc_types())
     assert types == [4, 5]                                # equality, then the tendon limit row
+
+
+def test_tendon_frictionloss_row_sticks_and_saturates():
+    """Dry friction along a fixed tendon (jaco_three_finger_gripper.xml:17: frictionloss on the finger tendons): a friction-loss row on the
+    tendon's coefficient row, placed after the dof friction rows.  Below the limit the tendon sticks; above it the row force saturates at
+    -frictionloss * sign(velocity), i.e. the joint feels coef * frictionloss."""
+    def model(fl):
+        return mjcf.compile_mjcf(XML.replace('<fixed name="lim_only" range="-0.3 0.3" limited="true">',
+                                             f'<fixed name="lim_only" range="-0.3 0.3" limited="true" frictionloss="{fl}">'))
+    m = model(0.6)
+    assert m.tendon_frictionloss.tolist() == [0.0, 0.6] and m.tendon_solref_fri.tolist()[1] == [0.02, 1.0]
+    om, od, _ = make_oracle(m)
+    for t in range(300):
+        od.ctrl[:] = [0.0, 0.5]                            # 0.5 N m on the joint < coef * frictionloss = 1.2 N m: the row does not saturate
+        od.step()
+    od.forward()
+    assert list(od.efc_types()) == [4, 6]                  # equality, then the tendon friction row
+    # soft constraint: in the unsaturated regime the row is a damper, force = -D B v with D = 1 / R, R = (1 - d0) / d0 * invweight0,
+    # B = 2 / (dmax * timeconst) [3P: mj_makeImpedance, K = 0 for friction rows]; torque balance on the joint gives the creep velocity
+    R, Bv = (1 - 0.9) / 0.9 * m.tendon_invweight0[1], 2 / (0.95 * 0.02)
+    v_pred = 0.5 / (2 * 2 * Bv / R + 0.05)                 # 0.5 = coef * (B / R) * (coef * qvel) + damping * qvel
+    assert od.qvel[2] == pytest.approx(v_pred, rel=2e-2)
+    assert od.qfrc_constraint[2] == pytest.approx(-(0.5 - 0.05 * od.qvel[2]), abs=2e-3)
+    m = model(0.2)
+    om, od, _ = make_oracle(m)
+    od.ctrl[:] = [0.0, 0.5]
+    for t in range(20):
+        od.step()
+    od.forward()
+    assert od.qvel[2] > 1e-2                                # 0.5 > 2 * 0.2: it slides ...
+    assert od.qfrc_constraint[2] == pytest.approx(-0.4, abs=1e-6)   # ... against the saturated row: coef * frictionloss
+    assert od.efc_force[1] == pytest.approx(-0.2, abs=1e-6)
