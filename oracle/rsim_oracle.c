@@ -11,13 +11,14 @@
  *       controllers/parts/controller.py:149-232, controllers/parts/gripper/simple_grip.py:110-186,
  *       models/grippers/panda_gripper.py:43-58, robots/fixed_base_robot.py:121-153
  *     plus the other arm parts generic/joint_pos.py:200-266, generic/joint_tor.py:111-167, generic/joint_vel.py:129-209, the
- *     variable-impedance action layouts (osc.py:243-253, joint_pos.py:204-214) and utils/traj_utils.py:25-155 (LinearInterpolator),
+ *     variable-impedance action layouts (osc.py:243-253, joint_pos.py:204-214) and utils/traj_utils.py:25-155 (LinearInterpolator, incl. the
+ *     Euler / slerp orientation interpolator of OSC_POSE, osc.py:277-283, 433-437),
  *     and is PINNED against golden vectors produced by importing that Python (tests/golden/).
  *   - physics half: the reference delegates to the third-party `mujoco` wheel (setup.py:18,
  *     >=3.3.0,<3.10) which is absent here and has no source under /root/reference.  This file
  *     restates MuJoCo's published algorithm ("Computation" chapter of its documentation: kinematics,
- *     CRBA, RNE, soft-constraint model with solref/solimp impedance, elliptic cones, fixed tendons with equality/tendon and
- *     tendon-limit rows, the primal Newton solver with exact line search (and PGS on the dual as a cross-check),
+ *     CRBA, RNE, soft-constraint model with solref/solimp impedance, elliptic cones, fixed tendons with equality/tendon,
+ *     tendon-limit and tendon friction-loss rows and their passive spring / damper, the primal Newton solver with exact line search (and PGS on the dual as a cross-check),
  *     semi-implicit Euler with implicit joint damping) anchored on the reference call sites
  *     utils/binding_utils.py:1089-1107 and environments/base.py:467-521.
  *     ==> physics parity with MuJoCo is UNPINNED (no MuJoCo binary, no golden vectors in the
