@@ -248,7 +248,9 @@ struct Smem {
   static constexpr int NCON_ = NCON;
   static constexpr int NEFC_ = NEFC;                    // constraint-row capacity: 64 (one row per lane) or 128 (two)
   static constexpr bool HAS_LE_ = NV <= 32;             // keep the factor of M + hD next to the one of M (else Euler factors it again)
-  static constexpr int HULLPOOL_ = NV <= 32 ? RSIM_HULL_POOL : 0;   // LDS-resident hull vertices
+  // LDS-resident hull vertices.  The 64-body x 16-dof configuration keeps 192 so that three environments fit a CU (53.7 KB each; with the
+  // full pool it was 57.6 KB = two per CU); the host assigns pool slots for the largest pool and load_constants() drops what does not fit
+  static constexpr int HULLPOOL_ = NV > 32 ? 0 : ((NB == 64 && NV == 16) ? 192 : RSIM_HULL_POOL);
   static constexpr int NB_ = NB;
   float qpos[NV + 8], qvel[NV], qacc[NV], qacc_ws[NV], ctrl[NV];
   float xpos[NB * 3], xquat[NB * 4];
@@ -840,7 +842,10 @@ struct Sim {
         for (int k = 0; k < 8; k++) sm.gcap[8 * g + k] = FP(FO_cg_capsule, 8 * g + k);
         sm.gcp[g] = IT(IO_cg_condim, g) | (IT(IO_cg_priority, g) << 8);
         sm.gmesh[g] = IT(IO_cg_meshadr, g) | (IT(IO_cg_meshnum, g) << 16);
-        sm.ghull[g] = SM::HULLPOOL_ ? lt[LT_ghull * 64 + lane] : -1;   // configurations without a resident pool scan every hull from global memory
+        {   // configurations with a smaller (or no) resident pool scan the hulls that do not fit from global memory
+          const int hs = lt[LT_ghull * 64 + lane];
+          sm.ghull[g] = (hs >= 0 && hs + IT(IO_cg_meshnum, g) <= SM::HULLPOOL_) ? hs : -1;
+        }
         float* gp = sm.gpar + 12 * g;
         for (int k = 0; k < 3; k++) gp[k] = FP(FO_cg_friction, 3 * g + k);
         gp[3] = FP(FO_cg_solref, 2 * g); gp[4] = FP(FO_cg_solref, 2 * g + 1);
