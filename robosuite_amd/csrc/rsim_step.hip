@@ -247,10 +247,12 @@ struct Smem {
   static constexpr int CD_ = 4;       // largest contact dimension this configuration handles (condim 1, 3, 4)
   static constexpr int NCON_ = NCON;
   static constexpr int NEFC_ = NEFC;                    // constraint-row capacity: 64 (one row per lane) or 128 (two)
-  static constexpr bool HAS_LE_ = NV <= 32;             // keep the factor of M + hD next to the one of M (else Euler factors it again)
-  // LDS-resident hull vertices.  The 64-body x 16-dof configuration keeps 192 so that three environments fit a CU (53.7 KB each; with the
-  // full pool it was 57.6 KB = two per CU); the host assigns pool slots for the largest pool and load_constants() drops what does not fit
-  static constexpr int HULLPOOL_ = NV > 32 ? 0 : ((NB == 64 && NV == 16) ? 192 : RSIM_HULL_POOL);
+  static constexpr bool HAS_LE_ = NV <= 16;             // keep the factor of M + hD next to the one of M (else Euler factors it again)
+  // LDS-resident hull vertices.  Occupancy is LDS-bound (one wavefront per SIMD up to four environments per CU), so the two middle
+  // configurations trade pool for a third environment per CU: 64 x 16 keeps 192 vertices (53.7 KB; 57.6 KB = two per CU with the full pool),
+  // 32 x 32 keeps 64 and factors M + hD again at the Euler step instead of keeping it (53.6 KB instead of 63.2 KB).  The host assigns pool
+  // slots for the largest pool and load_constants() drops what does not fit.
+  static constexpr int HULLPOOL_ = NV > 32 ? 0 : (NV == 32 ? 64 : ((NB == 64 && NV == 16) ? 192 : RSIM_HULL_POOL));
   static constexpr int NB_ = NB;
   float qpos[NV + 8], qvel[NV], qacc[NV], qacc_ws[NV], ctrl[NV];
   float xpos[NB * 3], xquat[NB * 4];
