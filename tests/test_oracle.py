@@ -75,7 +75,10 @@ def test_other_part_controllers_match_reference_loop(tag):
         assert np.abs(od.qvel - g["states"][t + 1][1 + nq:]).max() < vtol
 
 
-@pytest.mark.parametrize("tag", ("ctl_joint_position", "ctl_joint_torque", "ctl_joint_velocity"))
+@pytest.mark.parametrize("tag", ("ctl_joint_position", "ctl_joint_torque", "ctl_joint_velocity",
+                                 # Baxter's default: one OSC_POSE object per arm, each around its own "<arm>_center" site (oracle only so far: the kernel's
+                                 # OSC path drives one arm)
+                                 "ctl_osc_pose"))
 def test_two_arm_joint_space_controllers_match_reference_loop(tag):
     """TwoArmPegInHole / Baxter (BASELINE configs[3] model), one part controller per arm (composite_controller.py:70-121): the oracle loop
     with two controller objects replays the env.step fixture recorded with the reference's own classes.  JOINT_VELOCITY (the type BASELINE

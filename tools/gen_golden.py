@@ -224,6 +224,10 @@ def record_baxter(seed, n_steps, action_scale, ctype):
                   grip_act=[], grip_sign=[], grip_speed=0.0, damping_ratio=1.0)
         if ctype in ("JOINT_POSITION", "JOINT_VELOCITY"):
             pc["kp"] = [float(x) for x in np.atleast_1d(ctl.kp)]
+        if ctype in ("OSC_POSE", "OSC_POSITION"):   # one OSC object per arm (Baxter's default), each with its own eef / base ("<arm>_center") sites
+            pc.update(kp=[float(x) for x in np.atleast_1d(ctl.kp)], kd=[float(x) for x in np.atleast_1d(ctl.kd)], uncouple=int(ctl.uncoupling),
+                      eef_site=int(sim.model.site_name2id(ctl.ref_name)),
+                      base_site=int(sim.model.site_name2id(f"{ctl.naming_prefix}{ctl.part_name}_center")))
         if ctype == "JOINT_VELOCITY" and ctl.velocity_limits is not None:
             lo, hi = np.broadcast_to(ctl.velocity_limits[0], (len(pc["qpos_idx"]),)), np.broadcast_to(ctl.velocity_limits[1], (len(pc["qpos_idx"]),))
             pc["velocity_limits"] = [[float(x) for x in lo], [float(x) for x in hi]]
@@ -437,6 +441,9 @@ if __name__ == "__main__":
         record_lift_controller(seed=3, n_steps=30, action_scale=1.0, ctype="OSC_POSE", impedance_mode="variable")
         record_lift_controller(seed=3, n_steps=30, action_scale=1.0, ctype="OSC_POSE", impedance_mode="variable_kp")
         record_lift_controller(seed=3, n_steps=30, action_scale=1.0, ctype="JOINT_POSITION", impedance_mode="variable")
+        sys.exit(0)
+    if "--baxter-osc-only" in sys.argv:
+        record_baxter(seed=0, n_steps=30, action_scale=0.5, ctype="OSC_POSE")
         sys.exit(0)
     if "--baxter-only" in sys.argv:
         record_baxter(seed=0, n_steps=30, action_scale=1.0, ctype="JOINT_POSITION")
