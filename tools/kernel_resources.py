@@ -1,0 +1,60 @@
+"""Resource usage of every kernel in robosuite_amd/librsim_hip.so, read from the code objects embedded in the library (no GPU, no rebuild):
+LDS bytes per workgroup, private-segment (scratch) bytes, VGPR / AGPR / SGPR counts.  The occupancy of the fused kernel is LDS-bound
+(DESIGN.md section 5), so these numbers are the budget the kernel configurations are designed to: tests/test_kernel_resources.py pins them.
+Usage: python tools/kernel_resources.py [path/to/librsim_hip.so]"""
+import os, re, struct, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def code_objects(lib):
+    """gfx950 ELF code objects of the clang offload bundles in the library's .hip_fatbin section (one bundle per translation unit)."""
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", lib, os.path.join(td, "copy.so")])
+        data = open(fat, "rb").read()
+    out = []
+    for m in re.finditer(MAGIC, data):
+        base = m.start()
+        (n,) = struct.unpack_from("<Q", data, base + len(MAGIC))
+        p = base + len(MAGIC) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, p)
+            triple = data[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if "gfx950" in triple and size:
+                out.append(data[base + off:base + off + size])
+    return out
+
+
+def kernels(lib=None):
+    """{kernel name: {lds, scratch, vgpr, agpr, sgpr}} over all code objects of the library."""
+    lib = lib or os.path.join(ROOT, "robosuite_amd", "librsim_hip.so")
+    res = {}
+    for co in code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co); f.flush()
+            notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", f.name], text=True)
+        cur = {}
+        for line in notes.splitlines():
+            m = re.match(r"\s*-?\s*\.(agpr_count|group_segment_fixed_size|private_segment_fixed_size|sgpr_count|vgpr_count|name):\s*(\S+)", line)
+            if not m:
+                continue
+            key, val = m.groups()
+            if key == "name" and not val.startswith("_Z") and not val.startswith("k_"):
+                continue   # argument names
+            cur[key] = val
+            if all(k in cur for k in ("name", "group_segment_fixed_size", "private_segment_fixed_size", "vgpr_count", "sgpr_count")):
+                res[cur["name"]] = dict(lds=int(cur["group_segment_fixed_size"]), scratch=int(cur["private_segment_fixed_size"]),
+                                        vgpr=int(cur["vgpr_count"]), agpr=int(cur.get("agpr_count", 0)), sgpr=int(cur["sgpr_count"]))
+                cur = {}
+    return res
+
+
+if __name__ == "__main__":
+    ks = kernels(sys.argv[1] if len(sys.argv) > 1 else None)
+    for name, r in sorted(ks.items()):
+        print(f"{name[:70]:70s} LDS {r['lds']:6d} B  scratch {r['scratch']:4d} B  VGPR {r['vgpr']:3d} AGPR {r['agpr']:3d} SGPR {r['sgpr']:3d}"
+              f"  -> {min(4, 163840 // max(1, r['lds'])) if r['lds'] else '-'} workgroups / CU by LDS")
