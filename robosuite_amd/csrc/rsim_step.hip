@@ -306,6 +306,9 @@ struct Smem {
   // per-lane model constants, one row per field (LaneConst below); phases fetch the handful they need instead of pinning ~80 VGPRs
   float kc[RSIM_KC_WORDS(NB, NV, NGW_, NS, NPAIR)];
   int ncon, nefc, niter;
+  // root body of each articulated tree, staged for the eight-tree configuration: its COM loop is not fully unrolled, and a run-time index into
+  // the by-value DModel (m.dynroot[r]) makes the compiler keep a 1.9 KB copy of DModel in the private segment and read every model scalar from it
+  int dynroot[NROOT_ > 4 ? NROOT_ : 1];
 };
 
 // The one per-workgroup LDS object, declared at file scope so that every access is a direct LDS (ds_*) instruction with an
@@ -874,6 +877,12 @@ struct Sim {
     for (int e = lane; e < SM_NB * 10 + 16; e += 64) sm.cinert[e] = 0.f;
     for (int e = lane; e < NV16 * CS6; e += 64) sm.cdof[e] = 0.f;
     if (lane < (NROOT + 1) * 3) sm.rootcom[lane] = 0.f;
+    if constexpr (NROOT > 4) {
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < NROOT; r++) sm.dynroot[r] = m.dynroot[r];   // compile-time indices
+      }
+    }
     kxfer<true>(K);
     SYNC();
     // resident hull pool: one pass per pooled mesh, lane-parallel over its vertices
@@ -958,7 +967,8 @@ struct Sim {
 #pragma unroll
     for (int r = 0; r < NROOT; r++) {
       if (r >= m.ndynroot) break;
-      const int rb = m.dynroot[r];
+      int rb;
+      if constexpr (NROOT > 4) rb = sm.dynroot[r]; else rb = m.dynroot[r];
       const float w = (b < nb && root == rb) ? K.mass : 0.f;
       const float sw = wave_sum(w), sx = wave_sum(w * xip.x), sy = wave_sum(w * xip.y), sz = wave_sum(w * xip.z);
       const float iw = sw > 1e-15f ? 1.0f / sw : 0.f;

@@ -28,8 +28,9 @@ def test_fused_kernel_configurations_keep_their_lds_and_register_budgets():
         assert envs * (-(-r["lds"] // 512) * 512) <= LDS_PER_CU, (name, r)
         assert (envs + 1) * r["lds"] > LDS_PER_CU or envs == 4          # the table above states the real occupancy, not a lower bound
         assert r["vgpr"] <= 512                                        # VGPR + AGPR of one wavefront per SIMD
-        if envs > 1:
-            assert r["scratch"] == 0, (name, r)                        # no private-segment traffic in the tuned configurations
+        # no private segment: besides spills, a run-time index into the by-value DModel kernel argument makes the compiler keep a 1.9 KB
+        # copy of it there and read every model scalar from that copy (the eight-tree configuration did, through m.dynroot[r])
+        assert r["scratch"] == 0, (name, r)
 
 
 def test_auxiliary_kernels_use_no_scratch():

@@ -10,9 +10,12 @@ from robosuite_amd.vec_env import VecEnv
 from tests.util import load_golden
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+only = sys.argv[2:]   # optional task names
 out = {}
 for name, tag, model, B in (("Stack", "seed0_full", "stack_panda", 4096), ("TwoArmPegInHole", "ctl_joint_velocity", "peg_baxter", 2048),
                             ("PickPlace", "seed0_full", "pickplace_iiwa", 2048)):
+    if only and name not in only:
+        continue
     g, cfg, flat = load_golden(tag, model)
     env = VecEnv(name, B, flat, cfg, seed=0, horizon=500, bank_episodes=2)
     env.reset()
