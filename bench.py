@@ -86,11 +86,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one process per GPU under torch.distributed.run (RCCL rendezvous on 127.0.0.1),
+        # same arguments; rank 0 of the child job prints the JSON line, this process only forwards the exit code
+        import socket
+        import subprocess
+
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
     rank, local_rank, world = shard.init_process_group()
-    if world != args.gpus and not (world == 1 and args.gpus == 1):
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
+        print(f"bench.py rank {rank}/{world}: no GPU visible (the HIP backend has no CPU fallback)", file=sys.stderr, flush=True)
+        raise SystemExit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

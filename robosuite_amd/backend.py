@@ -378,6 +378,10 @@ class HipBatch:
         else:
             if not actions.is_cuda or actions.dtype.is_floating_point is False:
                 raise RsimError("actions must be a CUDA float32 tensor")
+            # reference: `assert len(action) == self.action_dim` (environments/robot_env.py:586); a narrower tensor would be read out of bounds on the device
+            adim = self._L.rsim_model_int(self.model.ptr, b"action_dim")
+            if tuple(actions.shape) != (self.B, adim):
+                raise RsimError(f"actions must have shape ({self.B}, {adim}) = (n_envs, action_dim), got {tuple(actions.shape)}")
             actions = actions.contiguous().float()
             self._keep = actions
             ptr = actions.data_ptr()

@@ -755,9 +755,21 @@ extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) {
   return 0;
 }
 
+// The controller may be re-configured on the model after the batch exists (gains, limits, even the type), but the per-env controller
+// state buffer was sized when the batch was created: the kernels stride it by b->cs, so a controller that needs more state than that
+// is refused instead of running past the end of the buffer.
+static int sync_controller(rsim_batch* b) {
+  b->dm.ctrl = b->m->ctrl;
+  if (b->m->ctrl.enabled && b->m->ctrl.cs_size > b->cs)
+    return fail("the controller configured on the model needs %d floats of per-env state but the batch was created with %d: call rsim_model_set_controller "
+                "before rsim_batch_create (or create a new batch)", b->m->ctrl.cs_size, b->cs);
+  b->dm.ctrl.cs_size = b->cs;
+  return 0;
+}
+
 static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   HIPCHK(hipSetDevice(b->device));
-  b->dm.ctrl = b->m->ctrl;
+  if (sync_controller(b)) return 1;
   if ((flags & RF_OBS) && !b->dm.task.enabled) return fail("the task (observation / reward epilogue) was configured after the batch was created");
   if ((flags & RF_CTRL) && !b->dm.ctrl.enabled) return fail("no controller configured (rsim_model_set_controller)");
   b->db.order = nullptr; b->db.cost = nullptr;
@@ -843,7 +855,7 @@ extern "C" int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uin
 extern "C" int rsim_ctrl_reset(rsim_batch* b, const uint8_t* mask) {
   HIPCHK(hipSetDevice(b->device));
   if (!b->m->ctrl.enabled) return fail("no controller configured");
-  b->dm.ctrl = b->m->ctrl;
+  if (sync_controller(b)) return 1;
   const unsigned char* dmask = nullptr;
   if (mask) {
     HIPCHK(hipMemcpyAsync(b->d_mask, mask, (size_t)b->B, hipMemcpyHostToDevice, b->stream));

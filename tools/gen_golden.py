@@ -24,6 +24,8 @@ shim.install(OracleBackend)
 import robosuite as suite  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
+if "--out" in sys.argv:   # write somewhere else (tests/test_golden_recipe.py regenerates a fixture into a scratch directory and compares)
+    GOLD = sys.argv[sys.argv.index("--out") + 1]
 os.makedirs(GOLD, exist_ok=True)
 
 
@@ -406,9 +408,6 @@ def record_lift(seed, n_steps, action_scale, tag):
     np.savez_compressed(os.path.join(GOLD, f"lift_panda_{tag}.npz"), **out)
     mjcf.save_model(flat, os.path.join(GOLD, f"lift_panda_{tag}.rsim"))
     cfg = controller_cfg(env)
-    if interpolation is not None:
-        ip = getattr(ctl, "interpolator", None) or ctl.interpolator_pos
-        cfg["interp_steps"] = int(ip.total_steps)      # ceil(ramp_ratio * controller_freq / policy_freq), traj_utils.py:55-57
     cfg["obs_keys"] = [k for k in keys if not k.endswith("-state")]
     cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in cfg["obs_keys"]]
     with open(os.path.join(GOLD, f"lift_panda_{tag}.cfg.json"), "w") as f:
@@ -461,6 +460,8 @@ if __name__ == "__main__":
         sys.exit(0)
     # gentle actions (reference test convention test_action_playback.py:48) and full-range actions
     record_lift(seed=0, n_steps=40, action_scale=0.1, tag="seed0_gentle")
+    if "--gentle-only" in sys.argv:
+        sys.exit(0)
     record_lift(seed=1, n_steps=40, action_scale=1.0, tag="seed1_full")
     if "--controllers" in sys.argv:
         for ct in ("JOINT_POSITION", "JOINT_TORQUE", "OSC_POSITION"):
