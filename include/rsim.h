@@ -161,6 +161,10 @@ enum rsim_field {
   RSIM_DIVERGED,       /* [B] int32    how often the env hit MuJoCo's bad-state guard: after a substep that leaves a non-finite or > 1e10 qpos / qvel
                         *               entry the env is put back to qpos0 with zero velocity, control and time, as mj_checkPos / mj_checkVel +
                         *               mj_resetData do [3P]; robosuite never reads the corresponding mjData warning, this counter makes it visible */
+  RSIM_OVERFLOW,       /* [B] int32    contacts + constraint rows the env had to DROP since the batch was created because a substep found more than the
+                        *               compiled capacity (rsim_batch_limits: 16 contacts / 64 rows in the Lift configuration, 128 rows in the largest).
+                        *               MuJoCo's nconmax = 5000 (models/assets/base.xml:5) never truncates; a non-zero count marks results that can differ
+                        *               from the reference for that reason */
   RSIM_FIELD_COUNT
 };
 

@@ -33,6 +33,18 @@ typedef int (*creset_fn)(const DModel*, const DBatch*, const unsigned char*, hip
 typedef int (*limits_fn)(int*);
 static const step_fn k_step_launch[RSIM_NCFG] = {rsim_launch_step_cfg0, rsim_launch_step_cfg1, rsim_launch_step_cfg2, rsim_launch_step_cfg3};
 static const creset_fn k_creset_launch[RSIM_NCFG] = {rsim_launch_ctrl_reset_cfg0, rsim_launch_ctrl_reset_cfg1, rsim_launch_ctrl_reset_cfg2, rsim_launch_ctrl_reset_cfg3};
+extern "C" int rsim_launch_prepare_cfg0(const DModel* m, const DBatch* b, int nblocks, int reset_only, hipStream_t stream);
+extern "C" int rsim_cmem_bytes_cfg0(void);
+extern "C" int rsim_launch_prepare_cfg1(const DModel* m, const DBatch* b, int nblocks, int reset_only, hipStream_t stream);
+extern "C" int rsim_cmem_bytes_cfg1(void);
+extern "C" int rsim_launch_prepare_cfg2(const DModel* m, const DBatch* b, int nblocks, int reset_only, hipStream_t stream);
+extern "C" int rsim_cmem_bytes_cfg2(void);
+extern "C" int rsim_launch_prepare_cfg3(const DModel* m, const DBatch* b, int nblocks, int reset_only, hipStream_t stream);
+extern "C" int rsim_cmem_bytes_cfg3(void);
+typedef int (*prepare_fn)(const DModel*, const DBatch*, int, int, hipStream_t);
+typedef int (*cmem_fn)(void);
+static const prepare_fn k_prepare_launch[RSIM_NCFG] = {rsim_launch_prepare_cfg0, rsim_launch_prepare_cfg1, rsim_launch_prepare_cfg2, rsim_launch_prepare_cfg3};
+static const cmem_fn k_cmem_bytes[RSIM_NCFG] = {rsim_cmem_bytes_cfg0, rsim_cmem_bytes_cfg1, rsim_cmem_bytes_cfg2, rsim_cmem_bytes_cfg3};
 static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1, rsim_limits_cfg2, rsim_limits_cfg3};
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream);
 extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStream_t stream);
@@ -108,6 +120,11 @@ struct rsim_batch {
   int cs;    // floats of controller state per env (fixed when the batch is created)
   int* d_order;       // longest-job-first dispatch order of rsim_control_step
   unsigned* d_cost;
+  // constant blocks (the kernel configuration's Cmem): one shared block, or one per env once a float-table field has per-env values
+  void* d_cm;
+  size_t cm_bytes;
+  int cm_dirty;       // a model parameter / the controller changed since the blocks were built
+  DCtrl cm_ctrl;      // controller the blocks were built for
   int have_cost;      // d_cost holds the costs of a previous control step
   int schedule;       // 1 = reorder before every control step (default), 0 = identity order
   // host cache for jacobians
@@ -636,6 +653,10 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   if (dalloc(&b->d_mesh, m->mesh_vert.size())) return 1;
   HIPCHK(hipMemcpy(b->d_mesh, m->mesh_vert.data(), m->mesh_vert.size() * sizeof(float), hipMemcpyHostToDevice));
   if (dalloc(&b->d_mask, (size_t)B)) return 1;
+  b->cm_bytes = (size_t)k_cmem_bytes[b->cfg]();
+  if (dalloc((char**)&b->d_cm, b->cm_bytes * (1 + (b->per_env ? (size_t)B : 0)))) return 1;   // block 0: shared; blocks 1..B: per env
+  b->db.cm = b->d_cm; b->db.cm_env = (char*)b->d_cm + b->cm_bytes; b->db.cm_stride = 0; b->cm_dirty = 1;
+  memset(&b->cm_ctrl, 0, sizeof(b->cm_ctrl));
   b->d_order = nullptr; b->d_cost = nullptr; b->schedule = 1; b->have_cost = 0;
   if (dalloc(&b->d_order, (size_t)B)) return 1;
   if (dalloc(&b->d_cost, (size_t)B)) return 1;
@@ -694,7 +715,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
       {RSIM_NCON, (void**)&db.ncon, (size_t)B, 1}, {RSIM_NEFC, (void**)&db.nefc, (size_t)B, 1}, {RSIM_NITER, (void**)&db.niter, (size_t)B, 1},
       {RSIM_OBS, (void**)&db.obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0}, {RSIM_REWARD, (void**)&db.reward, (size_t)B, 0},
       {RSIM_SUCCESS, (void**)&db.success, (size_t)B, 1}, {RSIM_DONE, (void**)&db.done, (size_t)B, 1}, {RSIM_EP_STEP, (void**)&db.ep_step, (size_t)B, 1},
-      {RSIM_EP_INDEX, (void**)&db.ep_index, (size_t)B, 1}, {RSIM_DIVERGED, (void**)&db.diverged, (size_t)B, 1}};
+      {RSIM_EP_INDEX, (void**)&db.ep_index, (size_t)B, 1}, {RSIM_DIVERGED, (void**)&db.diverged, (size_t)B, 1}, {RSIM_OVERFLOW, (void**)&db.overflow, (size_t)B, 1}};
   for (auto& fd : fields) {
     if (dalloc((float**)fd.p, fd.n)) return 1;
     b->fptr[fd.id] = *fd.p; b->fcount[fd.id] = fd.n; b->fis_int[fd.id] = fd.is_int;
@@ -708,6 +729,7 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   hipSetDevice(b->device);
   hipStreamSynchronize(b->stream);
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
+  hipFree(b->d_cm);
   hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_ft0); if (b->d_obsprog) hipFree(b->d_obsprog);
   if (b->d_bank) hipFree(b->d_bank); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); if (b->d_ft_base) hipFree(b->d_ft_base); hipFree(b->d_mesh); hipFree(b->d_mask);
   if (b->d_order) hipFree(b->d_order); if (b->d_cost) hipFree(b->d_cost);
@@ -767,9 +789,31 @@ static int sync_controller(rsim_batch* b) {
   return 0;
 }
 
+// (Re)build the constant blocks when a model parameter or the controller changed since they were built: one block while every env reads the
+// shared float table, one per env from the moment a field has per-env values (per-episode object sizes, domain randomisation).
+static int ensure_constants(rsim_batch* b) {
+  if (!b->cm_dirty && !memcmp(&b->cm_ctrl, &b->dm.ctrl, sizeof(DCtrl))) return 0;
+  const bool per_env = b->per_env && b->dm.fenv != 0;
+  b->db.cm_stride = per_env ? (long long)b->cm_bytes : 0;
+  {   // the shared block: every field from the shared float table
+    DModel dm0 = b->dm; DBatch db0 = b->db;
+    dm0.fenv = 0; db0.cm_env = b->d_cm; db0.cm_stride = 0;
+    int e = k_prepare_launch[b->cfg](&dm0, &db0, 1, 0, b->stream);
+    if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  }
+  if (per_env) {
+    int e = k_prepare_launch[b->cfg](&b->dm, &b->db, b->B, 0, b->stream);
+    if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  }
+  b->cm_ctrl = b->dm.ctrl;
+  b->cm_dirty = 0;
+  return 0;
+}
+
 static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   HIPCHK(hipSetDevice(b->device));
   if (sync_controller(b)) return 1;
+  if (ensure_constants(b)) return 1;
   if ((flags & RF_OBS) && !b->dm.task.enabled) return fail("the task (observation / reward epilogue) was configured after the batch was created");
   if ((flags & RF_CTRL) && !b->dm.ctrl.enabled) return fail("no controller configured (rsim_model_set_controller)");
   b->db.order = nullptr; b->db.cost = nullptr;
@@ -784,6 +828,11 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   }
   int e = k_step_launch[b->cfg](&b->dm, &b->db, actions, n_sub, flags, b->stream);
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  if ((flags & RF_EPISODE) && b->db.bank && b->db.bank_P > 0 && b->db.horizon > 0 && b->db.cm_stride) {
+    // envs whose episode just ended were re-initialised from the reset bank, float-table patches included: rebuild their constant blocks
+    e = k_prepare_launch[b->cfg](&b->dm, &b->db, b->B, 1, b->stream);
+    if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  }
   b->gen++;
   return 0;
 }
@@ -826,6 +875,7 @@ extern "C" int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, c
   for (int p2 = 0; p2 < n_patch; p2++)
     for (int f = 0; f < FO_COUNT; f++)
       if (patch_idx[p2] >= m->fo[f] && patch_idx[p2] < m->fo[f] + m->fcount[f]) b->dm.fenv |= 1ull << f;
+  b->cm_dirty = 1;
   return 0;
 }
 
@@ -848,6 +898,7 @@ extern "C" int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uin
                 (1ull << FO_cg_solref) | (1ull << FO_cg_solimp) | (1ull << FO_dof_frictionloss) | (1ull << FO_dof_damping) | (1ull << FO_dof_armature);
   int e = rsim_launch_randomize(&b->dm, &b->db, &dd, seed, step, b->stream);
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  b->cm_dirty = 1;   // the next launch rebuilds the constant blocks from the re-drawn tables (same stream: ordered after this kernel)
   b->gen++;
   return 0;
 }
@@ -856,6 +907,7 @@ extern "C" int rsim_ctrl_reset(rsim_batch* b, const uint8_t* mask) {
   HIPCHK(hipSetDevice(b->device));
   if (!b->m->ctrl.enabled) return fail("no controller configured");
   if (sync_controller(b)) return 1;
+  if (ensure_constants(b)) return 1;
   const unsigned char* dmask = nullptr;
   if (mask) {
     HIPCHK(hipMemcpyAsync(b->d_mask, mask, (size_t)b->B, hipMemcpyHostToDevice, b->stream));
@@ -1044,6 +1096,7 @@ extern "C" int rsim_model_param_set(rsim_batch* b, const char* field, int env0, 
   HIPCHK(hipMemcpy2D(b->d_ft + base + m->fo[mp->fo], fs * sizeof(float), tmp.data(), n * sizeof(float), n * sizeof(float), (size_t)envs, hipMemcpyHostToDevice));
   if (b->per_env) b->dm.fenv |= 1ull << mp->fo;   // from now on the kernel reads this field from the env's own table
   else HIPCHK(hipMemcpy(b->d_ft0 + m->fo[mp->fo], tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  b->cm_dirty = 1;
   b->gen++;
   return 0;
 }

@@ -109,6 +109,7 @@ struct DCtrl {
 #ifndef RSIM_CS_MAX
 #define RSIM_CS_MAX 200
 #endif
+#define RSIM_CS_LDS 64         /* controller-state floats staged in LDS by the step kernel (the OSC and plain joint-space layouts entirely); slots beyond stay in global memory */
 
 // observation / reward epilogue (include/rsim.h rsim_task_desc), device form
 struct DTask {
@@ -162,6 +163,10 @@ struct DBatch {
   float* ft_rw;          // writable alias of the float tables (per-env patches)
   float* ft_base;        // saved defaults of the float tables (domain randomisation), may be null
   // longest-job-first dispatch: workgroup i steps env order[i]; cost[env] = shader-clock ticks the env's wavefront took in the previous launch
+  void* cm;              // constant block (Cmem of the kernel configuration) built from the shared float table by k_prepare
+  void* cm_env;          // per-env constant blocks [B] (used once a float-table field has per-env values)
+  long long cm_stride;   // bytes between the blocks of consecutive envs, 0 = no env has its own block yet
+  int* overflow;         // [B] contacts + constraint rows dropped for lack of capacity (null = not counted)
   const int* order;      // [B] or null (identity)
   unsigned* cost;        // [B] or null
   unsigned long long* prof;  // optional [RP_COUNT] phase-cycle / event accumulators (null = off)

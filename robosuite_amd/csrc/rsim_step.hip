@@ -226,7 +226,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // treated as generic and compile to flat_load
 typedef const float __attribute__((address_space(1)))* gcf;
 typedef const int __attribute__((address_space(1)))* gci;
+typedef float __attribute__((address_space(1)))* gwf;
 __device__ __forceinline__ V3 ld3(gcf p) { return v3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(gwf p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
 __device__ __forceinline__ Q4 ldq(gcf p) { Q4 q = {p[0], p[1], p[2], p[3]}; return q; }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -247,12 +249,12 @@ struct Smem {
   static constexpr int CD_ = 4;       // largest contact dimension this configuration handles (condim 1, 3, 4)
   static constexpr int NCON_ = NCON;
   static constexpr int NEFC_ = NEFC;                    // constraint-row capacity: 64 (one row per lane) or 128 (two)
-  static constexpr bool HAS_LE_ = NV <= 16;             // keep the factor of M + hD next to the one of M (else Euler factors it again)
+  static constexpr bool HAS_LE_ = false;                // the factor of M + hD is not kept: the Euler step factors it again (LDS bytes decide the occupancy)
   // LDS-resident hull vertices.  Occupancy is LDS-bound (one wavefront per SIMD up to four environments per CU), so the two middle
   // configurations trade pool for a third environment per CU: 64 x 16 keeps 192 vertices (53.7 KB; 57.6 KB = two per CU with the full pool),
   // 32 x 32 keeps 64 and factors M + hD again at the Euler step instead of keeping it (53.6 KB instead of 63.2 KB).  The host assigns pool
   // slots for the largest pool and load_constants() drops what does not fit.
-  static constexpr int HULLPOOL_ = NV > 32 ? 0 : (NV == 32 ? 64 : ((NB == 64 && NV == 16) ? 192 : RSIM_HULL_POOL));
+  static constexpr int HULLPOOL_ = (NV > 32 || (NB == 32 && NV == 16)) ? 0 : (NV == 32 ? 64 : 192);   // 32 x 16: 20 KB = eight environments per CU, hulls are scanned from global memory (L1-resident: every env of the CU scans the same vertices)
   static constexpr int NB_ = NB;
   float qpos[NV + 8], qvel[NV], qacc[NV], qacc_ws[NV], ctrl[NV];
   float xpos[NB * 3], xquat[NB * 4];
@@ -277,7 +279,30 @@ struct Smem {
   float invdiag[NV];
   float Le[HAS_LE_ ? NV * NVP : 1], invdiag_e[NV];   // Cholesky factor of M + h*diag(damping) (implicit-damping Euler), computed alongside L
   float qfrc_bias[NV], qfrc_passive[NV], qfrc_actuator[NV], qfrc_smooth[NV], qacc_smooth[NV], qfrc_constraint[NV];
-  // per-launch staged constants that are read by lanes other than their owner
+  float gpos[NG * 3], gmat[NG * 9], gcen[NG * 3];
+  float spos[NS * 3], smat[NS * 9];
+  // contacts
+  float cpos[NCON * 3], cframe[NCON * 9], cdist[NCON], cfri[NCON * 5], csolref[NCON * 2], csolimp[NCON * 5], cmu[NCON], cmargin[NCON];
+  int cg1[NCON], cg2[NCON], cdim[NCON], cefc[NCON];
+  // constraint rows
+  float J[NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
+  float e_R[NEFC], e_aref[NEFC], e_force[NEFC];   // e_force doubles as the row's velocity gain B between make_constraint's two halves
+  int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
+  float cstate[RSIM_CS_LDS];     // first RSIM_CS_LDS floats of the controller state (all of it for the OSC and plain joint-space types); the tail stays in global memory
+  float red[NV];
+  float hull[3 * HULLPOOL_ + 1];    // LDS-resident hull vertex pool (SoA x | y | z); filled once per launch
+  int ncon, nefc, niter;
+};
+
+// Model constants of one environment in the layout the kernel's lane roles read them: built by prepare_constants() (k_prepare, or the env's own
+// wavefront after an on-device episode reset patched its float table) into GLOBAL memory -- one block shared by all envs while no env has
+// overridden a float-table field, one per env otherwise -- and read with ordinary global loads.  It used to be rebuilt into LDS by every launch
+// (18 KB of the 40 KB that limited the 32 x 16 configuration to four environments per CU).
+template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
+struct Cmem {
+  typedef Smem<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> S;
+  typedef typename S::dmask_t dmask_t;
+  float opt[12];                 // timestep, gravity3, density, viscosity, impratio, wind3
   float arm[NV];                 // dof armature (1 on padding rows: keeps the padded matrices SPD)
   float fricR[NV], fricB[NV], fricFl[NV];  // dof friction-loss rows: regulariser, velocity gain, force limit
   float biw[NB * 2];             // body_invweight0
@@ -286,35 +311,23 @@ struct Smem {
   float gst[NG * 8];             // colliding geom statics: half-extents 3, box centre (geom frame) 3, rbound, margin
   float gcap[NG * 8];            // bounding capsule of mesh hulls in the geom frame: p3 q3 R (R < 0: none)
   int gtype[NG], gbody[NG], gcp[NG], gmesh[NG];   // type, body, condim | priority<<8, hull vertex adr | count<<16
-  float gpar[NG * 12];             // contact material per geom: friction3 solref2 solimp5 solmix gap
-  float gpos[NG * 3], gmat[NG * 9], gcen[NG * 3];
-  float spos[NS * 3], smat[NS * 9];
-  // contacts
-  float cpos[NCON * 3], cframe[NCON * 9], cdist[NCON], cfri[NCON * 5], csolref[NCON * 2], csolimp[NCON * 5], cmu[NCON], cmargin[NCON];
-  int cg1[NCON], cg2[NCON], cdim[NCON], cefc[NCON];
-  // constraint rows
-  float J[NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
-  float e_R[NEFC], e_aref[NEFC], e_force[NEFC], e_B[NEFC];
-  int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
-  float cstate[RSIM_CS_MAX];
-  float red[NV];
+  int ghull[NG];                 // first slot of geom g in the LDS-resident hull pool, -1: scanned from global memory
+  float gpar[NG * 12];           // contact material per geom: friction3 solref2 solimp5 solmix gap
   // wide configuration: tree incidence as bit masks (dof-ancestor set, dofs summed before dof i in the velocity recursion, body ancestors)
-  dmask_t dmask_anc[NM_], dmask_cvel[NM_];
-  unsigned long long bmask_anc[TREE_TILE_ ? 1 : NB];
-  float hull[3 * HULLPOOL_ + 1];    // LDS-resident hull vertex pool (SoA x | y | z); filled once per launch
-  int ghull[NG];                    // first pool slot of geom g, -1: not resident
+  dmask_t dmask_anc[S::NM_], dmask_cvel[S::NM_];
+  unsigned long long bmask_anc[S::TREE_TILE_ ? 1 : NB];
+  int dynroot[RSIM_MAXDYNROOT];  // root body of each articulated tree (a run-time index into the by-value DModel would put a copy of it into the private segment)
   // per-lane model constants, one row per field (LaneConst below); phases fetch the handful they need instead of pinning ~80 VGPRs
-  float kc[RSIM_KC_WORDS(NB, NV, NGW_, NS, NPAIR)];
-  int ncon, nefc, niter;
-  // root body of each articulated tree, staged for the eight-tree configuration: its COM loop is not fully unrolled, and a run-time index into
-  // the by-value DModel (m.dynroot[r]) makes the compiler keep a 1.9 KB copy of DModel in the private segment and read every model scalar from it
-  int dynroot[NROOT_ > 4 ? NROOT_ : 1];
+  float kc[RSIM_KC_WORDS(NB, NV, S::NGW_, NS, NPAIR)];
 };
 
 // The one per-workgroup LDS object, declared at file scope so that every access is a direct LDS (ds_*) instruction with an
 // immediate offset: routing it through a reference member made the compiler fall back to flat_* loads/stores.
 typedef Smem<RSIM_DIMS> Smem0;
 static __shared__ Smem0 sm;
+typedef Cmem<RSIM_DIMS> Cmem0;
+typedef const Cmem0 __attribute__((address_space(1)))* cmr_t;   // read view of an env's constant block (global_load, never flat_load)
+typedef Cmem0 __attribute__((address_space(1)))* cmw_t;         // write view (prepare_constants)
 
 #define IT(tab, i) (((gci)m.it)[m.io[tab] + (i)])
 // per-env value only for fields some env has overridden (per-episode object sizes, domain randomisation); everything else comes from the
@@ -585,10 +598,10 @@ __device__ __forceinline__ void spd_solve_small(const float* A, const float* b, 
 
 // support point of colliding geom g along world direction dir (wave-cooperative for meshes; result uniform).
 // A real function (not inlined into its ~10 call sites); it only touches the LDS object and the hull vertex table.
-__device__ __forceinline__ V3 geom_support(int g, V3 dir, gcf mesh_vert, int lane) {
-  const int t = sm.gtype[g];
+__device__ __forceinline__ V3 geom_support(cmr_t cm, cmr_t cmg, int g, V3 dir, gcf mesh_vert, int lane) {
+  const int t = cm->gtype[g];
   const M3 R = ldm(sm.gmat + 9 * g);
-  const V3 p = ld3(sm.gpos + 3 * g), h = ld3(sm.gst + 8 * g);
+  const V3 p = ld3(sm.gpos + 3 * g), h = ld3(cmg->gst + 8 * g);
   const V3 ld = mtv(R, dir);
   V3 lp = v3(0, 0, 0);
   if (t == G_BOX) lp = v3(ld.x >= 0 ? h.x : -h.x, ld.y >= 0 ? h.y : -h.y, ld.z >= 0 ? h.z : -h.z);
@@ -606,11 +619,11 @@ __device__ __forceinline__ V3 geom_support(int g, V3 dir, gcf mesh_vert, int lan
     float n = norm(tt);
     if (n > FMIN) lp = v3(tt.x / n * h.x, tt.y / n * h.y, tt.z / n * h.z);
   } else if (t == G_MESH) {
-    const int adr = sm.gmesh[g] & 0xffff, num = sm.gmesh[g] >> 16;
+    const int adr = cm->gmesh[g] & 0xffff, num = cm->gmesh[g] >> 16;
     float bv = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f;
     int bi = 0x7fffffff;
-    const int pool = sm.ghull[g];
-    if (pool >= 0) {
+    const int pool = Smem0::HULLPOOL_ > 0 ? cm->ghull[g] : -1;
+    if (Smem0::HULLPOOL_ > 0 && pool >= 0) {
       // hull resident in LDS: lane l scans vertices l, l+64, ... (at most 256 per hull in the pool)
       const float* hv = sm.hull + pool;
 #pragma unroll
@@ -691,7 +704,27 @@ struct Sim {
   const DModel& m;
   const float* fp;
   int lane;
+  // Constant blocks (read views): `cm` is the block every env shares (built from the shared float table), `ce` this env's own block (== cm while
+  // no float-table field has per-env values).  A field is read from `ce` only if one of the float-table fields it is derived from has been
+  // overridden (m.fenv, a uniform select per row): with per-episode object sizes or a partial domain randomisation almost every row still comes
+  // from the shared block, which stays resident in the CU's L1 because all its wavefronts read the same lines.
+  cmr_t cm, ce;
+  cmw_t cw = nullptr;                              // write view while prepare_constants() builds a block
+#define FM(x) (1ull << FO_##x)
+  static constexpr u64 MK_gst = FM(cg_size) | FM(cg_aabb) | FM(cg_rbound) | FM(cg_margin), MK_gcap = FM(cg_capsule),
+                       MK_gpar = FM(cg_friction) | FM(cg_solref) | FM(cg_solimp) | FM(cg_solmix) | FM(cg_gap), MK_arm = FM(dof_armature),
+                       MK_fricRB = FM(dof_solref) | FM(dof_solimp) | FM(dof_invweight0) | FM(opt), MK_fricFl = FM(dof_frictionloss),
+                       MK_biw = FM(body_invweight0), MK_opt = FM(opt);
+  u64 fenv;
+  long long ceoff;   // byte offset from the shared block to this env's block (an integer select: selecting between two POINTERS made the compiler
+                     // keep Sim -- and with it a copy of DModel -- in the private segment)
+  __device__ __forceinline__ cmr_t cmf(u64 mask) const {
+    const long long off = (fenv & mask) ? ceoff : 0ll;
+    return (cmr_t)((const char __attribute__((address_space(1)))*)cm + off);
+  }
+  float __attribute__((address_space(1)))* cst = nullptr;   // this env's controller-state record in global memory (slots >= RSIM_CS_LDS are used in place)
   Prof pf;
+  int ovf = 0;   // contacts / constraint rows this launch had to drop for lack of capacity (RSIM_OVERFLOW); MuJoCo's nconmax = 5000 never truncates
   float opt_h, opt_density, opt_viscosity, opt_impratio;
   V3 opt_grav, opt_wind;
   static constexpr int NVP = SM::NVP;
@@ -712,7 +745,18 @@ struct Sim {
   }
   static constexpr int NT = SM::NV_ / 16;       // 16-dof tiles per dimension of the dense nv x nv products
 
-  __device__ Sim(const DModel& m_, const float* fp_, int lane_, unsigned long long* prof) : m(m_), fp(fp_), lane(lane_) { pf.p = prof; pf.lane = lane_; pf.t0 = 0; }
+  __device__ Sim(const DModel& m_, const float* fp_, int lane_, unsigned long long* prof, const void* cm_, const void* ce_) : m(m_), fp(fp_), lane(lane_), cm((cmr_t)cm_), ce((cmr_t)ce_), fenv(m_.fenv), ceoff((const char*)ce_ - (const char*)cm_) { pf.p = prof; pf.lane = lane_; pf.t0 = 0; }
+  // Phase boundary for the register allocator: everything derived from the lane id (LDS addresses lane * stride, role predicates lane < n as
+  // 64-bit masks) is loop invariant, so the compiler hoists all of it out of the substep loop and keeps it alive across every phase -- some
+  // hundred registers at the pressure peaks.  A fresh (opaque) lane id per phase confines those values to the phase that uses them.
+  __device__ __forceinline__ void phase() {
+#ifndef RSIM_NO_PHASE_LANE
+    lane = opaque_lane(lane); pf.lane = lane;
+#endif
+  }
+  // global stores of this wavefront's lanes -> visible to its other lanes' loads (controller-state tail, constant block after an episode reset)
+  __device__ __forceinline__ void gsync() const { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+  __device__ __forceinline__ void cst_sync() const { if (m.ctrl.cs_size > RSIM_CS_LDS) gsync(); }
 
   // articulated-tree slot of a root body (NROOT = static tree, COM unused / zero)
   __device__ __forceinline__ int root_slot(int rootbody) const {
@@ -724,11 +768,12 @@ struct Sim {
   __device__ __forceinline__ u64 mask2(int tab, int i) const { return (u64)(uint32_t)IT(tab, 2 * i) | ((u64)(uint32_t)IT(tab, 2 * i + 1) << 32); }
 
   // ---------------------------------------------------------------- per-lane constants <-> LDS (row = field, column = lane of the role)
-  template <bool STORE> __device__ __forceinline__ void kio(float& x, int idx) const { if (STORE) sm.kc[idx] = x; else x = sm.kc[idx]; }
-  template <bool STORE> __device__ __forceinline__ void kio(int& x, int idx) const { if (STORE) sm.kc[idx] = __builtin_bit_cast(float, x); else x = __builtin_bit_cast(int, sm.kc[idx]); }
-  template <bool STORE> __device__ __forceinline__ void kio(unsigned& x, int idx) const { if (STORE) sm.kc[idx] = __builtin_bit_cast(float, x); else x = __builtin_bit_cast(unsigned, sm.kc[idx]); }
-  template <bool STORE> __device__ __forceinline__ void kio(V3& x, int idx, int stride) const { kio<STORE>(x.x, idx); kio<STORE>(x.y, idx + stride); kio<STORE>(x.z, idx + 2 * stride); }
-  template <bool STORE> __device__ __forceinline__ void kio(Q4& x, int idx, int stride) const { kio<STORE>(x.w, idx); kio<STORE>(x.x, idx + stride); kio<STORE>(x.y, idx + 2 * stride); kio<STORE>(x.z, idx + 3 * stride); }
+  // MK = float-table fields the row is derived from (0: lane-table / controller constants, always shared)
+  template <bool STORE, u64 MK = 0> __device__ __forceinline__ void kio(float& x, int idx) const { if (STORE) cw->kc[idx] = x; else x = (MK ? cmf(MK) : cm)->kc[idx]; }
+  template <bool STORE, u64 MK = 0> __device__ __forceinline__ void kio(int& x, int idx) const { if (STORE) cw->kc[idx] = __builtin_bit_cast(float, x); else x = __builtin_bit_cast(int, (MK ? cmf(MK) : cm)->kc[idx]); }
+  template <bool STORE, u64 MK = 0> __device__ __forceinline__ void kio(unsigned& x, int idx) const { if (STORE) cw->kc[idx] = __builtin_bit_cast(float, x); else x = __builtin_bit_cast(unsigned, (MK ? cmf(MK) : cm)->kc[idx]); }
+  template <bool STORE, u64 MK = 0> __device__ __forceinline__ void kio(V3& x, int idx, int stride) const { kio<STORE, MK>(x.x, idx); kio<STORE, MK>(x.y, idx + stride); kio<STORE, MK>(x.z, idx + 2 * stride); }
+  template <bool STORE, u64 MK = 0> __device__ __forceinline__ void kio(Q4& x, int idx, int stride) const { kio<STORE, MK>(x.w, idx); kio<STORE, MK>(x.x, idx + stride); kio<STORE, MK>(x.y, idx + 2 * stride); kio<STORE, MK>(x.z, idx + 3 * stride); }
   // STORE: called once by load_constants (lanes outside a role's width skip it); fetch: every lane reads its (wrapped) column and the
   // compiler drops the rows a phase does not use
   template <bool STORE> __device__ __forceinline__ void kxfer(LaneConst& K) const {
@@ -737,37 +782,37 @@ struct Sim {
       const int l = lane & (SM_NB - 1), W = SM_NB;
       if (!STORE || lane < W) {
         kio<STORE>(K.part, o + 0 * W + l); kio<STORE>(K.part4, o + 1 * W + l); kio<STORE>(K.binfo, o + 2 * W + l); kio<STORE>(K.bdofs, o + 3 * W + l);
-        kio<STORE>(K.bpos, o + 4 * W + l, W); kio<STORE>(K.bquat, o + 7 * W + l, W); kio<STORE>(K.jpos, o + 11 * W + l, W); kio<STORE>(K.jaxis, o + 14 * W + l, W);
-        kio<STORE>(K.q0, o + 17 * W + l); kio<STORE>(K.ipos, o + 18 * W + l, W); kio<STORE>(K.iquat, o + 21 * W + l, W); kio<STORE>(K.mass, o + 25 * W + l);
-        kio<STORE>(K.inertia, o + 26 * W + l, W);
+        kio<STORE, FM(body_pos)>(K.bpos, o + 4 * W + l, W); kio<STORE, FM(body_quat)>(K.bquat, o + 7 * W + l, W); kio<STORE, FM(jnt_pos)>(K.jpos, o + 11 * W + l, W); kio<STORE, FM(jnt_axis)>(K.jaxis, o + 14 * W + l, W);
+        kio<STORE, FM(qpos0)>(K.q0, o + 17 * W + l); kio<STORE, FM(body_ipos)>(K.ipos, o + 18 * W + l, W); kio<STORE, FM(body_iquat)>(K.iquat, o + 21 * W + l, W); kio<STORE, FM(body_mass)>(K.mass, o + 25 * W + l);
+        kio<STORE, FM(body_inertia)>(K.inertia, o + 26 * W + l, W);
       }
       o += 29 * W;
     }
     {  // dof role, NV columns
       const int l = lane & (NV16 - 1), W = NV16;
       if (!STORE || lane < W) {
-        kio<STORE>(K.dinfo, o + 0 * W + l); kio<STORE>(K.damping, o + 1 * W + l); kio<STORE>(K.jr0, o + 2 * W + l); kio<STORE>(K.jr1, o + 3 * W + l);
-        kio<STORE>(K.jmargin, o + 4 * W + l); kio<STORE>(K.jsr0, o + 5 * W + l); kio<STORE>(K.jsr1, o + 6 * W + l); kio<STORE>(K.jsi0, o + 7 * W + l);
-        kio<STORE>(K.jsi1, o + 8 * W + l); kio<STORE>(K.jsi2, o + 9 * W + l); kio<STORE>(K.jsi3, o + 10 * W + l); kio<STORE>(K.jsi4, o + 11 * W + l);
-        kio<STORE>(K.dinvw, o + 12 * W + l);
+        kio<STORE>(K.dinfo, o + 0 * W + l); kio<STORE, FM(dof_damping)>(K.damping, o + 1 * W + l); kio<STORE, FM(jnt_range)>(K.jr0, o + 2 * W + l); kio<STORE, FM(jnt_range)>(K.jr1, o + 3 * W + l);
+        kio<STORE, FM(jnt_margin)>(K.jmargin, o + 4 * W + l); kio<STORE, FM(jnt_solref)>(K.jsr0, o + 5 * W + l); kio<STORE, FM(jnt_solref)>(K.jsr1, o + 6 * W + l); kio<STORE, FM(jnt_solimp)>(K.jsi0, o + 7 * W + l);
+        kio<STORE, FM(jnt_solimp)>(K.jsi1, o + 8 * W + l); kio<STORE, FM(jnt_solimp)>(K.jsi2, o + 9 * W + l); kio<STORE, FM(jnt_solimp)>(K.jsi3, o + 10 * W + l); kio<STORE, FM(jnt_solimp)>(K.jsi4, o + 11 * W + l);
+        kio<STORE, FM(dof_invweight0)>(K.dinvw, o + 12 * W + l);
       }
       o += 13 * W;
     }
     {  // geom role, 32 or 64 columns
       const int l = lane & (SM::NGW_ - 1), W = SM::NGW_;
-      if (!STORE || lane < W) { kio<STORE>(K.ginfo, o + l); kio<STORE>(K.gp, o + 1 * W + l, W); kio<STORE>(K.gq, o + 4 * W + l, W); kio<STORE>(K.grc, o + 8 * W + l, W); }
+      if (!STORE || lane < W) { kio<STORE>(K.ginfo, o + l); kio<STORE, FM(cg_pos)>(K.gp, o + 1 * W + l, W); kio<STORE, FM(cg_quat)>(K.gq, o + 4 * W + l, W); kio<STORE, FM(cg_rcenter)>(K.grc, o + 8 * W + l, W); }
       o += 11 * W;
     }
     {  // site role, NS columns
       const int l = lane & (SM::NS_ - 1), W = SM::NS_;
-      if (!STORE || lane < W) { kio<STORE>(K.sbody, o + l); kio<STORE>(K.sp, o + 1 * W + l, W); kio<STORE>(K.sq, o + 4 * W + l, W); }
+      if (!STORE || lane < W) { kio<STORE>(K.sbody, o + l); kio<STORE, FM(site_pos)>(K.sp, o + 1 * W + l, W); kio<STORE, FM(site_quat)>(K.sq, o + 4 * W + l, W); }
       o += 8 * W;
     }
     {  // actuator role, 16 columns
       const int l = lane & 15, W = 16;
       if (!STORE || lane < W) {
-        kio<STORE>(K.ainfo, o + l); kio<STORE>(K.agear, o + 1 * W + l); kio<STORE>(K.again, o + 2 * W + l); kio<STORE>(K.ab0, o + 3 * W + l); kio<STORE>(K.ab1, o + 4 * W + l);
-        kio<STORE>(K.ab2, o + 5 * W + l); kio<STORE>(K.acr0, o + 6 * W + l); kio<STORE>(K.acr1, o + 7 * W + l); kio<STORE>(K.afr0, o + 8 * W + l); kio<STORE>(K.afr1, o + 9 * W + l);
+        kio<STORE>(K.ainfo, o + l); kio<STORE, FM(act_gear)>(K.agear, o + 1 * W + l); kio<STORE, FM(act_gainprm)>(K.again, o + 2 * W + l); kio<STORE, FM(act_biasprm)>(K.ab0, o + 3 * W + l); kio<STORE, FM(act_biasprm)>(K.ab1, o + 4 * W + l);
+        kio<STORE, FM(act_biasprm)>(K.ab2, o + 5 * W + l); kio<STORE, FM(act_ctrlrange)>(K.acr0, o + 6 * W + l); kio<STORE, FM(act_ctrlrange)>(K.acr1, o + 7 * W + l); kio<STORE, FM(act_forcerange)>(K.afr0, o + 8 * W + l); kio<STORE, FM(act_forcerange)>(K.afr1, o + 9 * W + l);
       }
       o += 10 * W;
     }
@@ -782,8 +827,33 @@ struct Sim {
   }
   __device__ __forceinline__ LaneConst fetchK() const { LaneConst K; kxfer<false>(K); return K; }
 
-  // ---------------------------------------------------------------- once per launch: constants -> LDS
-  __device__ __forceinline__ void load_constants() {
+  // ---------------------------------------------------------------- once per launch: the few uniform options, LDS padding, resident hulls
+  __device__ __forceinline__ void load_opt() {
+    opt_h = cmf(MK_opt)->opt[0]; opt_grav = v3(cmf(MK_opt)->opt[1], cmf(MK_opt)->opt[2], cmf(MK_opt)->opt[3]); opt_density = cmf(MK_opt)->opt[4]; opt_viscosity = cmf(MK_opt)->opt[5];
+    opt_impratio = cmf(MK_opt)->opt[6]; opt_wind = v3(cmf(MK_opt)->opt[7], cmf(MK_opt)->opt[8], cmf(MK_opt)->opt[9]);
+  }
+  __device__ __forceinline__ void init_lds() {
+    // zero the LDS regions whose padding lanes / columns are read but never written
+    for (int e = lane; e < SM_NB * 10 + 16; e += 64) sm.cinert[e] = 0.f;
+    for (int e = lane; e < NV16 * CS6; e += 64) sm.cdof[e] = 0.f;
+    if (lane < (NROOT + 1) * 3) sm.rootcom[lane] = 0.f;
+    if constexpr (SM::HULLPOOL_ > 0) {
+      // resident hull pool: one pass per pooled mesh, lane-parallel over its vertices
+      for (int g = 0; g < m.ncg; g++) {
+        const int pool = cm->ghull[g];
+        if (pool < 0) continue;
+        const int adr = cm->gmesh[g] & 0xffff, num = cm->gmesh[g] >> 16;
+        gcf mvp = (gcf)m.mesh_vert + 3 * adr;
+        for (int i = lane; i < num; i += 64) { sm.hull[pool + i] = mvp[3 * i]; sm.hull[SM::HULLPOOL_ + pool + i] = mvp[3 * i + 1]; sm.hull[2 * SM::HULLPOOL_ + pool + i] = mvp[3 * i + 2]; }
+      }
+    }
+    SYNC();
+  }
+
+  // ---------------------------------------------------------------- when the model parameters of this env change: constants -> its global block
+  // (k_prepare for all envs; the env's own wavefront after an on-device episode reset patched its float table)
+  __device__ __forceinline__ void prepare_constants(cmw_t out) {
+    cw = out;
     LaneConst K;
     gci lt = (gci)m.lt;
     K.part = lt[LT_part * 64 + lane]; K.part4 = lt[LT_part4 * 64 + lane]; K.binfo = lt[LT_binfo * 64 + lane]; K.bdofs = (unsigned)lt[LT_bdofs * 64 + lane];
@@ -791,8 +861,8 @@ struct Sim {
 #pragma unroll
     for (int t = 0; t < NPT; t++) K.pair[t] = lt[(t < 3 ? LT_pair0 + t : (t < 5 ? LT_pair3 + (t - 3) : LT_pair5 + (t - 5))) * 64 + lane];
     K.mfbits = (unsigned)lt[LT_mfbits * 64 + lane];
-    opt_h = FP(FO_opt, 0); opt_grav = v3(FP(FO_opt, 1), FP(FO_opt, 2), FP(FO_opt, 3)); opt_density = FP(FO_opt, 4); opt_viscosity = FP(FO_opt, 5);
-    opt_impratio = FP(FO_opt, 6); opt_wind = v3(FP(FO_opt, 7), FP(FO_opt, 8), FP(FO_opt, 9));
+    opt_h = FP(FO_opt, 0);   // row_scalars() below needs the timestep
+    if (lane < 10) cw->opt[lane] = FP(FO_opt, lane);
     const int nb = m.nbody, nv = m.nv;
     {  // body role
       const int b = lane < nb ? lane : 0;
@@ -804,8 +874,8 @@ struct Sim {
       K.jpos = ld3(&FP(FO_jnt_pos, 3 * j)); K.jaxis = ld3(&FP(FO_jnt_axis, 3 * j));
       K.q0 = FP(FO_qpos0, (K.binfo >> 4) & 255);
       if (lane >= nb) { K.part = 0; K.part4 = 0; K.binfo = 15; K.bdofs = 0; K.mass = 0.f; }
-      if (lane < SM_NB) { sm.biw[2 * lane] = lane < nb ? FP(FO_body_invweight0, 2 * b) : 0.f; sm.biw[2 * lane + 1] = lane < nb ? FP(FO_body_invweight0, 2 * b + 1) : 0.f;
-                          sm.bdofs[lane] = lane < nb ? dmask_load(IO_body_dofmask, b) : (dmask_t)0; sm.broot[lane] = root_slot((K.binfo >> 20) & 255); }
+      if (lane < SM_NB) { cw->biw[2 * lane] = lane < nb ? FP(FO_body_invweight0, 2 * b) : 0.f; cw->biw[2 * lane + 1] = lane < nb ? FP(FO_body_invweight0, 2 * b + 1) : 0.f;
+                          cw->bdofs[lane] = lane < nb ? dmask_load(IO_body_dofmask, b) : (dmask_t)0; cw->broot[lane] = root_slot((K.binfo >> 20) & 255); }
     }
     {  // dof role
       const int i = lane < nv ? lane : 0, j = (K.dinfo >> 18) & 255;
@@ -815,19 +885,19 @@ struct Sim {
       K.jsi0 = FP(FO_jnt_solimp, 5 * j); K.jsi1 = FP(FO_jnt_solimp, 5 * j + 1); K.jsi2 = FP(FO_jnt_solimp, 5 * j + 2); K.jsi3 = FP(FO_jnt_solimp, 5 * j + 3); K.jsi4 = FP(FO_jnt_solimp, 5 * j + 4);
       K.dinvw = FP(FO_dof_invweight0, i);
       if (lane < NV16) {
-        sm.arm[lane] = lane < nv ? FP(FO_dof_armature, i) : 1.0f;
+        cw->arm[lane] = lane < nv ? FP(FO_dof_armature, i) : 1.0f;
         // friction-loss row of this dof: position term is identically 0, so R, the velocity gain and the limit are constants
         const float fl = lane < nv ? FP(FO_dof_frictionloss, i) : 0.f;
         float solref[2] = {FP(FO_dof_solref, 2 * i), FP(FO_dof_solref, 2 * i + 1)}, solimp[5];
         for (int k = 0; k < 5; k++) solimp[k] = FP(FO_dof_solimp, 5 * i + k);
         float R, Bd, Kimp;
         row_scalars(0.f, 0.f, solref, solimp, K.dinvw, R, Bd, Kimp);
-        sm.fricR[lane] = R; sm.fricB[lane] = Bd; sm.fricFl[lane] = fl;
+        cw->fricR[lane] = R; cw->fricB[lane] = Bd; cw->fricFl[lane] = fl;
       }
       if (lane >= nv) K.dinfo = 0;
       if constexpr (!TREE) {
-        if (lane < NV16) { sm.dmask_anc[lane] = lane < nv ? dmask_load(IO_dof_ancmask, i) : (dmask_t)0; sm.dmask_cvel[lane] = lane < nv ? dmask_load(IO_dof_cvelmask, i) : (dmask_t)0; }
-        if (lane < SM_NB) sm.bmask_anc[lane] = lane < nb ? mask2(IO_body_ancmask, lane) : 0ull;
+        if (lane < NV16) { cw->dmask_anc[lane] = lane < nv ? dmask_load(IO_dof_ancmask, i) : (dmask_t)0; cw->dmask_cvel[lane] = lane < nv ? dmask_load(IO_dof_cvelmask, i) : (dmask_t)0; }
+        if (lane < SM_NB) cw->bmask_anc[lane] = lane < nb ? mask2(IO_body_ancmask, lane) : 0ull;
       }
     }
     {  // geom role
@@ -841,17 +911,17 @@ struct Sim {
         else if (t == G_SPHERE) h = v3(sz.x, sz.x, sz.x);
         else if (t == G_CAPSULE) h = v3(sz.x, sz.x, sz.x + sz.y);
         else if (t == G_CYLINDER) h = v3(sz.x, sz.x, sz.y);
-        float* o = sm.gst + 8 * g;
-        st3(o, h); st3(o + 3, c); o[6] = FP(FO_cg_rbound, g); o[7] = FP(FO_cg_margin, g);
-        sm.gtype[g] = t; sm.gbody[g] = K.ginfo & 255;
-        for (int k = 0; k < 8; k++) sm.gcap[8 * g + k] = FP(FO_cg_capsule, 8 * g + k);
-        sm.gcp[g] = IT(IO_cg_condim, g) | (IT(IO_cg_priority, g) << 8);
-        sm.gmesh[g] = IT(IO_cg_meshadr, g) | (IT(IO_cg_meshnum, g) << 16);
+        float __attribute__((address_space(1)))* o = cw->gst + 8 * g;
+        o[0] = h.x; o[1] = h.y; o[2] = h.z; o[3] = c.x; o[4] = c.y; o[5] = c.z; o[6] = FP(FO_cg_rbound, g); o[7] = FP(FO_cg_margin, g);
+        cw->gtype[g] = t; cw->gbody[g] = K.ginfo & 255;
+        for (int k = 0; k < 8; k++) cw->gcap[8 * g + k] = FP(FO_cg_capsule, 8 * g + k);
+        cw->gcp[g] = IT(IO_cg_condim, g) | (IT(IO_cg_priority, g) << 8);
+        cw->gmesh[g] = IT(IO_cg_meshadr, g) | (IT(IO_cg_meshnum, g) << 16);
         {   // configurations with a smaller (or no) resident pool scan the hulls that do not fit from global memory
           const int hs = lt[LT_ghull * 64 + lane];
-          sm.ghull[g] = (hs >= 0 && hs + IT(IO_cg_meshnum, g) <= SM::HULLPOOL_) ? hs : -1;
+          cw->ghull[g] = (hs >= 0 && hs + IT(IO_cg_meshnum, g) <= SM::HULLPOOL_) ? hs : -1;
         }
-        float* gp = sm.gpar + 12 * g;
+        float __attribute__((address_space(1)))* gp = cw->gpar + 12 * g;
         for (int k = 0; k < 3; k++) gp[k] = FP(FO_cg_friction, 3 * g + k);
         gp[3] = FP(FO_cg_solref, 2 * g); gp[4] = FP(FO_cg_solref, 2 * g + 1);
         for (int k = 0; k < 5; k++) gp[5 + k] = FP(FO_cg_solimp, 5 * g + k);
@@ -873,27 +943,11 @@ struct Sim {
       K.cq = seli(c.qpos_idx, lane); K.cd = seli(c.dof_idx, lane); K.ca = seli(c.act_idx, lane);
       K.cga = seli(c.grip_act, lane); K.cgs = sel(c.grip_sign, lane);
     }
-    // zero the LDS regions whose padding lanes / columns are read but never written
-    for (int e = lane; e < SM_NB * 10 + 16; e += 64) sm.cinert[e] = 0.f;
-    for (int e = lane; e < NV16 * CS6; e += 64) sm.cdof[e] = 0.f;
-    if (lane < (NROOT + 1) * 3) sm.rootcom[lane] = 0.f;
-    if constexpr (NROOT > 4) {
-      if (lane == 0) {
+    if (lane == 0) {
 #pragma unroll
-        for (int r = 0; r < NROOT; r++) sm.dynroot[r] = m.dynroot[r];   // compile-time indices
-      }
+      for (int r = 0; r < RSIM_MAXDYNROOT; r++) cw->dynroot[r] = m.dynroot[r];   // compile-time indices
     }
     kxfer<true>(K);
-    SYNC();
-    // resident hull pool: one pass per pooled mesh, lane-parallel over its vertices
-    for (int g = 0; g < m.ncg; g++) {
-      const int pool = sm.ghull[g];
-      if (pool < 0) continue;
-      const int adr = sm.gmesh[g] & 0xffff, num = sm.gmesh[g] >> 16;
-      gcf mvp = (gcf)m.mesh_vert + 3 * adr;
-      for (int i = lane; i < num; i += 64) { sm.hull[pool + i] = mvp[3 * i]; sm.hull[SM::HULLPOOL_ + pool + i] = mvp[3 * i + 1]; sm.hull[2 * SM::HULLPOOL_ + pool + i] = mvp[3 * i + 2]; }
-    }
-    SYNC();
   }
 
   // ---------------------------------------------------------------- kinematics: pointer jumping over the body tree
@@ -968,7 +1022,7 @@ struct Sim {
     for (int r = 0; r < NROOT; r++) {
       if (r >= m.ndynroot) break;
       int rb;
-      if constexpr (NROOT > 4) rb = sm.dynroot[r]; else rb = m.dynroot[r];
+      if constexpr (NROOT > 4) rb = cm->dynroot[r]; else rb = m.dynroot[r];
       const float w = (b < nb && root == rb) ? K.mass : 0.f;
       const float sw = wave_sum(w), sx = wave_sum(w * xip.x), sy = wave_sum(w * xip.y), sz = wave_sum(w * xip.z);
       const float iw = sw > 1e-15f ? 1.0f / sw : 0.f;
@@ -1031,7 +1085,7 @@ struct Sim {
       const int bi = K.dinfo & 255;
       if (lane < nv)
         for (int d = 1; d < nb; d++) {
-          const float w = (float)((sm.bmask_anc[d] >> bi) & 1);
+          const float w = (float)((cm->bmask_anc[d] >> bi) & 1);
 #pragma unroll
           for (int k = 0; k < 10; k++) acc[k] = fmaf(w, sm.cinert[10 * d + k], acc[k]);
         }
@@ -1051,10 +1105,10 @@ struct Sim {
       const int i = e / NV16, j = e - i * NV16;
       float mij = 0.f;
       if (i < nv && j < nv) {
-        if ((sm.dmask_anc[i] >> j) & 1) mij = dot6(ld6(sm.u.c.fpad + CS6 * i), ld6(sm.cdof + CS6 * j));
-        else if ((sm.dmask_anc[j] >> i) & 1) mij = dot6(ld6(sm.cdof + CS6 * i), ld6(sm.u.c.fpad + CS6 * j));
+        if ((cm->dmask_anc[i] >> j) & 1) mij = dot6(ld6(sm.u.c.fpad + CS6 * i), ld6(sm.cdof + CS6 * j));
+        else if ((cm->dmask_anc[j] >> i) & 1) mij = dot6(ld6(sm.cdof + CS6 * i), ld6(sm.u.c.fpad + CS6 * j));
       }
-      if (i == j) mij += sm.arm[i];
+      if (i == j) mij += cmf(MK_arm)->arm[i];
       sm.M[i * NVP + j] = mij;
     }
     SYNC();
@@ -1109,24 +1163,23 @@ struct Sim {
     for (int v = 0; v < 4; v++) {
       const int i = 4 * q + v;
       float mij = bitf(K.mfbits, 20 + v) * R1[v] + bitf(K.mfbits, 24 + v) * R2[v];
-      if (i == r) mij += sm.arm[i];
+      if (i == r) mij += cmf(MK_arm)->arm[i];
       sm.M[i * NVP + r] = mij;
     }
     SYNC();
     {
-      // two independent factorisations in one instruction stream (M for the smooth acceleration, M + hD for the integrator):
-      // the dependent rsqrt/broadcast chains of one fill the latency bubbles of the other
-      float mr[NV16], minv[NV16], er[NV16], einv[NV16];
-      const float hd = r < nv ? opt_h * K.damping : 0.f;   // dof lanes: lane & 15 = dof (K is fetched per 16-lane row)
+      // factor of M for the smooth acceleration (the factor of M + hD for the integrator is made by euler(): keeping both cost 1 KB of LDS,
+      // and with two wavefronts per SIMD the second dependent rsqrt / broadcast chain no longer needs this one to hide behind)
+      float mr[NV16], minv[NV16];
 #pragma unroll
-      for (int k = 0; k < NV16; k++) { mr[k] = sm.M[r * NVP + k]; er[k] = mr[k] + (k == r ? hd : 0.f); }
+      for (int k = 0; k < NV16; k++) mr[k] = sm.M[r * NVP + k];
       const int ro = opaque_lane(r);
-      const float mown = rchol_factor_own<NV16>(mr, minv, ro), eown = rchol_factor_own<NV16>(er, einv, ro);
-      rchol_mask_lower<NV16>(mr, ro); rchol_mask_lower<NV16>(er, ro);   // stored strictly lower: rows and columns read back ready for rchol_solve_m
+      const float mown = rchol_factor_own<NV16>(mr, minv, ro);
+      rchol_mask_lower<NV16>(mr, ro);   // stored strictly lower: rows and columns read back ready for rchol_solve_m
       if (lane < NV16) {
 #pragma unroll
-        for (int k = 0; k < NV16; k++) { sm.L[lane * NVP + k] = mr[k]; sm.Le[lane * NVP + k] = er[k]; }
-        sm.invdiag[lane] = mown; sm.invdiag_e[lane] = eown;
+        for (int k = 0; k < NV16; k++) sm.L[lane * NVP + k] = mr[k];
+        sm.invdiag[lane] = mown;
       }
     }
     SYNC();
@@ -1163,8 +1216,8 @@ struct Sim {
     }
     } else {
       // wide configuration: lane b sums the dofs that move body b, lane i the dofs summed before dof i (mask-guided loops)
-      masked_dof_sum(sm.cdof, lane < SM_NB && lane < nb ? sm.bdofs[lane] : (dmask_t)0, lane < SM_NB, sm.u.v.cvel);
-      masked_dof_sum(sm.cdof, lane < nv ? sm.dmask_cvel[lane] : (dmask_t)0, lane < NV16, sm.u.v.cvb);
+      masked_dof_sum(sm.cdof, lane < SM_NB && lane < nb ? cm->bdofs[lane] : (dmask_t)0, lane < SM_NB, sm.u.v.cvel);
+      masked_dof_sum(sm.cdof, lane < nv ? cm->dmask_cvel[lane] : (dmask_t)0, lane < NV16, sm.u.v.cvb);
     }
     SYNC();
     if (lane < NV16) {
@@ -1190,7 +1243,7 @@ struct Sim {
     } else {
       // cacc aliases cvb/cdd: every lane finishes its sum in registers before any lane stores
       S6 ca = {v3(0, 0, 0), v3(0, 0, 0)};
-      const dmask_t mk = lane < SM_NB && lane < nb ? sm.bdofs[lane] : (dmask_t)0;
+      const dmask_t mk = lane < SM_NB && lane < nb ? cm->bdofs[lane] : (dmask_t)0;
       for (int i = 0; i < nv; i++) if ((mk >> i) & 1) ca = ca + ld6(sm.u.v.cdd + CS6 * i) * sm.qvel[i];
       SYNC();
       if (lane < SM_NB) { float* o = sm.u.v.cacc + CS6 * lane; st3(o, ca.a); st3(o + 3, ca.l); }
@@ -1212,7 +1265,7 @@ struct Sim {
           const M3 R = q2m(qmul(xq, K.iquat));
           const float bx = sqrtf(fmaxf(1e-15f, I.y + I.z - I.x) / mass * 6.0f), by = sqrtf(fmaxf(1e-15f, I.x + I.z - I.y) / mass * 6.0f),
                       bz = sqrtf(fmaxf(1e-15f, I.x + I.y - I.z) / mass * 6.0f);
-          const V3 off = xp + qrot(xq, K.ipos) - ld3(sm.rootcom + 3 * sm.broot[b]);
+          const V3 off = xp + qrot(xq, K.ipos) - ld3(sm.rootcom + 3 * cm->broot[b]);
           const V3 gl = cv.l + cross(cv.a, off) - opt_wind;
           const V3 la = mtv(R, cv.a), ll = mtv(R, gl);
           V3 ft = v3(0, 0, 0), ff = v3(0, 0, 0);
@@ -1254,7 +1307,7 @@ struct Sim {
       const int bi = K.dinfo & 255;
       if (lane < nv)
         for (int d = 1; d < nb; d++) {
-          const float w = (float)((sm.bmask_anc[d] >> bi) & 1);
+          const float w = (float)((cm->bmask_anc[d] >> bi) & 1);
 #pragma unroll
           for (int k = 0; k < 12; k++) acc[k] = fmaf(w, sm.u.v.cf[d * FS + k], acc[k]);
         }
@@ -1298,9 +1351,9 @@ struct Sim {
   // Jacobian column of world point p attached to body `b` for dof i: returns [jacr; jacp] or zero if i does not move b
   __device__ __forceinline__ S6 jac_col(int b, V3 p, int i) const {
     S6 z = {v3(0, 0, 0), v3(0, 0, 0)};
-    if (!((sm.bdofs[b] >> i) & 1)) return z;
+    if (!((cm->bdofs[b] >> i) & 1)) return z;
     S6 cd = ld6(sm.cdof + CS6 * i);
-    V3 off = p - ld3(sm.rootcom + 3 * sm.broot[b]);
+    V3 off = p - ld3(sm.rootcom + 3 * cm->broot[b]);
     S6 rr = {cd.a, cd.l + cross(cd.a, off)};
     return rr;
   }
@@ -1316,7 +1369,7 @@ struct Sim {
     st3(frame, n); st3(frame + 3, y); st3(frame + 6, z);
   }
 
-  __device__ __forceinline__ V3 support(int g, V3 dir, int slot = -1) { pf.count(RP_N_SUPPORT, 1); return geom_support(g, dir, (gcf)m.mesh_vert, lane); }
+  __device__ __forceinline__ V3 support(int g, V3 dir, int slot = -1) { pf.count(RP_N_SUPPORT, 1); return geom_support(cm, cmf(MK_gst), g, dir, (gcf)m.mesh_vert, lane); }
 
   // contact parameters of a geom pair (MuJoCo's mixing rules: priority, solmix-weighted solref/solimp, max friction);
   // evaluated once per candidate pair, uniformly by every lane, from the per-geom table staged in LDS
@@ -1324,12 +1377,12 @@ struct Sim {
   __device__ __forceinline__ CPar contact_params(int g1, int g2, float margin, float gap) const {
     CPar cp;
     cp.margin_gap = margin - gap;
-    const float* a = sm.gpar + 12 * g1;
-    const float* b = sm.gpar + 12 * g2;
-    const int c1 = sm.gcp[g1], c2 = sm.gcp[g2];
+    gcf a = cmf(MK_gpar)->gpar + 12 * g1;
+    gcf b = cmf(MK_gpar)->gpar + 12 * g2;
+    const int c1 = cm->gcp[g1], c2 = cm->gcp[g2];
     const int p1 = c1 >> 8, p2 = c2 >> 8, d1 = c1 & 255, d2 = c2 & 255;
     if (p1 != p2) {
-      const float* w = p1 > p2 ? a : b;
+      gcf w = p1 > p2 ? a : b;
       cp.dim = p1 > p2 ? d1 : d2;
       for (int k = 0; k < 3; k++) cp.fr[k] = w[k];
       for (int k = 0; k < 2; k++) cp.solref[k] = w[3 + k];
@@ -1356,7 +1409,7 @@ struct Sim {
     const int base = sm.ncon;
     int total = __popcll(mk);
     if (total > cap) total = cap;
-    if (base + total > SM::NCON_) total = SM::NCON_ - base;
+    if (base + total > SM::NCON_) { ovf += base + total - SM::NCON_; total = SM::NCON_ - base; }
     if (has && rank < total) {
       const int c = base + rank;
       sm.cdist[c] = dist;
@@ -1384,7 +1437,7 @@ struct Sim {
   __device__ __forceinline__ void box_box(int g1, int g2, float margin, const CPar& cp) {
     const V3 pa = ld3(sm.gpos + 3 * g1), pb = ld3(sm.gpos + 3 * g2);
     const M3 Ra = ldm(sm.gmat + 9 * g1), Rb = ldm(sm.gmat + 9 * g2);
-    const V3 ha = ld3(sm.gst + 8 * g1), hb = ld3(sm.gst + 8 * g2);
+    const V3 ha = ld3(cmf(MK_gst)->gst + 8 * g1), hb = ld3(cmf(MK_gst)->gst + 8 * g2);
     const V3 A0 = col(Ra, 0), A1 = col(Ra, 1), A2 = col(Ra, 2), B0 = col(Rb, 0), B1 = col(Rb, 1), B2 = col(Rb, 2);
     const V3 dab = pb - pa;
     // ---- one axis per lane
@@ -1583,7 +1636,7 @@ struct Sim {
 
   // oriented bounding box of colliding geom g: world centre o, half extents h along the columns of gmat
   __device__ __forceinline__ void geom_obb(int g, const M3& R, V3& o, V3& h) const {
-    const float* st = sm.gst + 8 * g;
+    gcf st = cmf(MK_gst)->gst + 8 * g;
     h = ld3(st);
     o = ld3(sm.gpos + 3 * g) + mv(R, ld3(st + 3));
   }
@@ -1618,14 +1671,14 @@ struct Sim {
       bool pass = false;
       if ((pr >> 16) & 1) {
         const int g1 = pr & 255, g2 = (pr >> 8) & 255;
-        const float* st1 = sm.gst + 8 * g1;
-        const float* st2 = sm.gst + 8 * g2;
+        gcf st1 = cmf(MK_gst)->gst + 8 * g1;
+        gcf st2 = cmf(MK_gst)->gst + 8 * g2;
         const float margin = fmaxf(st1[7], st2[7]);
         const V3 c2 = ld3(sm.gcen + 3 * g2);
         const M3 R2 = ldm(sm.gmat + 9 * g2);
         V3 o2, h2;
         geom_obb(g2, R2, o2, h2);
-        if (sm.gtype[g1] == G_PLANE) {
+        if (cm->gtype[g1] == G_PLANE) {
           const V3 nrm = v3(sm.gmat[9 * g1 + 2], sm.gmat[9 * g1 + 5], sm.gmat[9 * g1 + 8]);
           const V3 pp = ld3(sm.gpos + 3 * g1);
           pass = dot(c2 - pp, nrm) - st2[6] <= margin;
@@ -1648,8 +1701,8 @@ struct Sim {
                                      fabsf(tb.z) - (h2.z + h1.x * fabsf(C.m[2]) + h1.y * fabsf(C.m[5]) + h1.z * fabsf(C.m[8])));
             pass = fmaxf(sepa, sepb) <= margin + 1e-6f;
             // bounding capsules (mesh hulls): distance between the two axis segments against the radii
-            const float* k1 = sm.gcap + 8 * g1;
-            const float* k2 = sm.gcap + 8 * g2;
+            gcf k1 = cmf(MK_gcap)->gcap + 8 * g1;
+            gcf k2 = cmf(MK_gcap)->gcap + 8 * g2;
             if (pass && k1[6] >= 0.f && k2[6] >= 0.f) {
               const V3 gp1 = ld3(sm.gpos + 3 * g1), gp2 = ld3(sm.gpos + 3 * g2);
               const V3 p1 = gp1 + mv(R1, ld3(k1)), q1 = gp1 + mv(R1, ld3(k1 + 3)), p2 = gp2 + mv(R2, ld3(k2)), q2 = gp2 + mv(R2, ld3(k2 + 3));
@@ -1667,10 +1720,11 @@ struct Sim {
     pf.mark(RP_BROAD);
     pf.count(RP_N_CAND, ncand);
     for (int ci = 0; ci < ncand; ci++) {
+      phase();
       int p = uni(sm.u.b.cand[ci]);
       int g1 = uni(IT(IO_pair_g1, p)), g2 = uni(IT(IO_pair_g2, p));
-      int t1 = uni(sm.gtype[g1]), t2 = uni(sm.gtype[g2]);
-      const float margin = fmaxf(sm.gst[8 * g1 + 7], sm.gst[8 * g2 + 7]), gap = fmaxf(sm.gpar[12 * g1 + 11], sm.gpar[12 * g2 + 11]);
+      int t1 = uni(cm->gtype[g1]), t2 = uni(cm->gtype[g2]);
+      const float margin = fmaxf(cmf(MK_gst)->gst[8 * g1 + 7], cmf(MK_gst)->gst[8 * g2 + 7]), gap = fmaxf(cmf(MK_gpar)->gpar[12 * g1 + 11], cmf(MK_gpar)->gpar[12 * g2 + 11]);
       const CPar cp = contact_params(g1, g2, margin, gap);
       const int sup0 = pf.c_support;
       if (t1 == G_PLANE && t2 == G_BOX) {
@@ -1679,7 +1733,7 @@ struct Sim {
         V3 wp = v3(0, 0, 0);
         bool hit = false;
         if (lane < 8) {
-          const V3 sz = ld3(sm.gst + 8 * g2);
+          const V3 sz = ld3(cmf(MK_gst)->gst + 8 * g2);
           const V3 lp = v3((lane & 1) ? sz.x : -sz.x, (lane & 2) ? sz.y : -sz.y, (lane & 4) ? sz.z : -sz.z);
           wp = ld3(sm.gpos + 3 * g2) + mv(ldm(sm.gmat + 9 * g2), lp);
           dist = dot(wp - ld3(sm.gpos + 3 * g1), nrm);
@@ -1768,20 +1822,20 @@ struct Sim {
         float R, Bd, Kt;
         row_scalars(pos, 0.f, solref, solimp, FP(FO_tendon_invw, t), R, Bd, Kt);
         sm.e_desc[lane] = C_EQUALITY | (t << 4);
-        sm.e_R[lane] = R; sm.e_B[lane] = Bd; sm.e_aref[lane] = Kt;
+        sm.e_R[lane] = R; sm.e_force[lane] = Bd; sm.e_aref[lane] = Kt;
       }
       nefc += m.neq;
     }
     // (1) friction loss
     {
-      const bool act = isdof && sm.fricFl[lane] > 0.f;
+      const bool act = isdof && cmf(MK_fricFl)->fricFl[lane] > 0.f;
       const u64 mk = __ballot(act);
       if (act) {
         const int r = nefc + __popcll(mk & lanemask_lt(lane));
-        if (r < NEFCAP) { sm.e_desc[r] = C_FRICTION_DOF | (lane << 4); sm.e_R[r] = sm.fricR[lane]; sm.e_B[r] = sm.fricB[lane]; sm.e_aref[r] = 0.f; }
+        if (r < NEFCAP) { sm.e_desc[r] = C_FRICTION_DOF | (lane << 4); sm.e_R[r] = cmf(MK_fricRB)->fricR[lane]; sm.e_force[r] = cmf(MK_fricRB)->fricB[lane]; sm.e_aref[r] = 0.f; }
       }
       nefc += __popcll(mk);
-      if (nefc > NEFCAP) nefc = NEFCAP;   // rows beyond the capacity (64 or 128) are dropped
+      if (nefc > NEFCAP) { ovf += nefc - NEFCAP; nefc = NEFCAP; }   // rows beyond the capacity (64 or 128) are dropped, and counted
     }
     // (1b) friction loss along fixed tendons (after the dof rows, mj_instantiateFriction [3P]): lane t owns tendon t
     if (TENDONS && m.ntendon) {
@@ -1795,10 +1849,10 @@ struct Sim {
         for (int k = 0; k < 5; k++) solimp[k] = FP(FO_tendon_solimp_fri, 5 * tl + k);
         float R, Bd, Kt;
         row_scalars(0.f, 0.f, solref, solimp, FP(FO_tendon_invw, tl), R, Bd, Kt);
-        if (r < NEFCAP) { sm.e_desc[r] = C_FRICTION_TENDON | (lane << 4); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = 0.f; }
+        if (r < NEFCAP) { sm.e_desc[r] = C_FRICTION_TENDON | (lane << 4); sm.e_R[r] = R; sm.e_force[r] = Bd; sm.e_aref[r] = 0.f; }
       }
       nefc += __popcll(mk);
-      if (nefc > NEFCAP) nefc = NEFCAP;
+      if (nefc > NEFCAP) { ovf += nefc - NEFCAP; nefc = NEFCAP; }
     }
     // (2) joint limits: dof lane i owns its hinge / slide joint; lower side before upper side
     {
@@ -1813,16 +1867,16 @@ struct Sim {
         const int r = nefc + before;
         float R, Bd, Kt;
         row_scalars(dlo, K.jmargin, solref, solimp, K.dinvw, R, Bd, Kt);
-        if (r < NEFCAP) { sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (0 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
+        if (r < NEFCAP) { sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (0 << 12); sm.e_R[r] = R; sm.e_force[r] = Bd; sm.e_aref[r] = Kt; }
       }
       if (ahi) {
         const int r = nefc + before + (alo ? 1 : 0);
         float R, Bd, Kt;
         row_scalars(dhi, K.jmargin, solref, solimp, K.dinvw, R, Bd, Kt);
-        if (r < NEFCAP) { sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (1 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
+        if (r < NEFCAP) { sm.e_desc[r] = C_LIMIT_JOINT | (lane << 4) | (1 << 12); sm.e_R[r] = R; sm.e_force[r] = Bd; sm.e_aref[r] = Kt; }
       }
       nefc += __popcll(mlo) + __popcll(mhi);
-      if (nefc > NEFCAP) nefc = NEFCAP;
+      if (nefc > NEFCAP) { ovf += nefc - NEFCAP; nefc = NEFCAP; }
     }
     // (2b) limits on fixed-tendon lengths: lane t owns tendon t, lower side before upper side
     if (TENDONS && m.ntendon) {
@@ -1841,16 +1895,16 @@ struct Sim {
         const int r = nefc + before;
         float R, Bd, Kt;
         row_scalars(dlo, margin, solref, solimp, invw, R, Bd, Kt);
-        if (r < NEFCAP) { sm.e_desc[r] = C_LIMIT_TENDON | (lane << 4) | (0 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
+        if (r < NEFCAP) { sm.e_desc[r] = C_LIMIT_TENDON | (lane << 4) | (0 << 12); sm.e_R[r] = R; sm.e_force[r] = Bd; sm.e_aref[r] = Kt; }
       }
       if (ahi) {
         const int r = nefc + before + (alo ? 1 : 0);
         float R, Bd, Kt;
         row_scalars(dhi, margin, solref, solimp, invw, R, Bd, Kt);
-        if (r < NEFCAP) { sm.e_desc[r] = C_LIMIT_TENDON | (lane << 4) | (1 << 12); sm.e_R[r] = R; sm.e_B[r] = Bd; sm.e_aref[r] = Kt; }
+        if (r < NEFCAP) { sm.e_desc[r] = C_LIMIT_TENDON | (lane << 4) | (1 << 12); sm.e_R[r] = R; sm.e_force[r] = Bd; sm.e_aref[r] = Kt; }
       }
       nefc += __popcll(mlo) + __popcll(mhi);
-      if (nefc > NEFCAP) nefc = NEFCAP;
+      if (nefc > NEFCAP) { ovf += nefc - NEFCAP; nefc = NEFCAP; }
     }
     // (3) contacts: lane c owns contact c; exclusive scan of the active dimensions gives the first row of each block
     {
@@ -1868,11 +1922,12 @@ struct Sim {
       // a block that does not fit is dropped together with everything after it (rows must stay contiguous)
       const u64 bad = __ballot(active && !fits);
       const bool keep = fits && (bad == 0 || lane < (__ffsll((long long)bad) - 1));
+      ovf += __popcll(__ballot(active && !keep));
       if (has) sm.cefc[lane] = keep ? first : -1;
       if (keep) {
         const int g1 = sm.cg1[lane], g2 = sm.cg2[lane];
-        const int b1 = sm.gbody[g1], b2 = sm.gbody[g2];
-        const float tran = sm.biw[2 * b1] + sm.biw[2 * b2], rot = sm.biw[2 * b1 + 1] + sm.biw[2 * b2 + 1];
+        const int b1 = cm->gbody[g1], b2 = cm->gbody[g2];
+        const float tran = cmf(MK_biw)->biw[2 * b1] + cmf(MK_biw)->biw[2 * b2], rot = cmf(MK_biw)->biw[2 * b1 + 1] + cmf(MK_biw)->biw[2 * b2 + 1];
         float R0, Bd, Kt;
         row_scalars(sm.cdist[lane], sm.cmargin[lane], sm.csolref + 2 * lane, sm.csolimp + 5 * lane, tran, R0, Bd, Kt);
         const int type = dim == 1 ? C_CONTACT_FRICTIONLESS : C_CONTACT_ELLIPTIC;
@@ -1885,7 +1940,7 @@ struct Sim {
             const int r = first + k;
             sm.e_desc[r] = type | (lane << 4) | (k << 12);
             sm.e_R[r] = k == 0 ? R0 : (k == 1 ? R1 : R1 * f[0] * f[0] / fmaxf(1e-15f, f[k - 1] * f[k - 1]));
-            sm.e_B[r] = Bd; sm.e_aref[r] = k == 0 ? Kt : 0.f;
+            sm.e_force[r] = Bd; sm.e_aref[r] = k == 0 ? Kt : 0.f;
           }
         }
         sm.cmu[lane] = dim > 1 ? f[0] * sqrtf(R1 / R0) : 0.f;
@@ -1927,11 +1982,11 @@ struct Sim {
       } else if (valid) {
         const int c = id;
         const int g1 = sm.cg1[c], g2 = sm.cg2[c];
-        const int b1 = sm.gbody[g1], b2 = sm.gbody[g2];
-        const dmask_t d1 = sm.bdofs[b1], d2 = sm.bdofs[b2];
+        const int b1 = cm->gbody[g1], b2 = cm->gbody[g2];
+        const dmask_t d1 = cm->bdofs[b1], d2 = cm->bdofs[b2];
         const V3 pos = ld3(sm.cpos + 3 * c);
         const V3 ax = ld3(sm.cframe + 9 * c + 3 * (kk < 3 ? kk : kk - 3));
-        const V3 o1 = pos - ld3(sm.rootcom + 3 * sm.broot[b1]), o2 = pos - ld3(sm.rootcom + 3 * sm.broot[b2]);
+        const V3 o1 = pos - ld3(sm.rootcom + 3 * cm->broot[b1]), o2 = pos - ld3(sm.rootcom + 3 * cm->broot[b2]);
         const V3 t1 = cross(o1, ax), t2 = cross(o2, ax);  // ax . (ca x o) = ca . (o x ax)
         const bool lin = kk < 3;
 #pragma unroll
@@ -1946,7 +2001,7 @@ struct Sim {
       float jv = 0.f;
 #pragma unroll
       for (int k = 0; k < NV16; k++) { sm.J[row * JS + k] = Jr[k]; jv = fmaf(Jr[k], sm.qvel[k], jv); }
-      if (valid) sm.e_aref[row] = -sm.e_B[row] * jv - sm.e_aref[row];
+      if (valid) sm.e_aref[row] = -sm.e_force[row] * jv - sm.e_aref[row];
     }
     SYNC();
   }
@@ -2003,11 +2058,25 @@ struct Sim {
       qa = chol_solve<NVP>(sm.H, sm.invdiag_e, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, nv, lane);
     } else if constexpr (!FAST) qa = chol_solve<NVP>(sm.Le, sm.invdiag_e, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, nv, lane);
     else {
-      float lr[NV16], lt[NV16], linv[NV16];
+      // register Cholesky of M + h diag(damping) (row r in lanes r, 16 + r, ...: K is fetched per 16-lane row); the transposed rows go through
+      // the solver's work matrix, which is dead by now
+      float er[NV16], einv[NV16], et[NV16];
       const int rr = lane & (NV16 - 1);
+      const float hd = rr < nv ? h * K.damping : 0.f;
 #pragma unroll
-      for (int k = 0; k < NV16; k++) { lr[k] = sm.Le[rr * NVP + k]; lt[k] = sm.Le[k * NVP + rr]; linv[k] = sm.invdiag_e[k]; }
-      qa = rchol_solve_m<NV16>(lr, lt, linv, sm.invdiag_e[rr], lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f);
+      for (int k = 0; k < NV16; k++) er[k] = sm.M[rr * NVP + k] + (k == rr ? hd : 0.f);
+      const int ro = opaque_lane(rr);
+      const float eown = rchol_factor_own<NV16>(er, einv, ro);
+      rchol_mask_lower<NV16>(er, ro);
+      SYNC();
+      if (lane < NV16) {
+#pragma unroll
+        for (int k = 0; k < NV16; k++) sm.H[lane * NVP + k] = er[k];
+      }
+      SYNC();
+#pragma unroll
+      for (int k = 0; k < NV16; k++) et[k] = sm.H[k * NVP + rr];
+      qa = rchol_solve_m<NV16>(er, et, einv, eown, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f);
     }
     if (lane < nv) { sm.qvel[lane] += h * qa; sm.qacc_ws[lane] = sm.qacc[lane]; }
     SYNC();
@@ -2041,8 +2110,8 @@ struct Sim {
       if (lane < c.nimp) {
         const float kp = fmaxf(kmin, fminf(kmax, action[(c.imp_mode == 1 ? c.nimp : 0) + lane]));
         const float dr = c.imp_mode == 1 ? fmaxf(dmin, fminf(dmax, action[lane])) : 1.f;
-        sm.cstate[RSIM_CS_KP + lane] = kp;
-        sm.cstate[RSIM_CS_KD + lane] = 2.f * sqrtf(kp) * dr;
+        cst[RSIM_CS_KP + lane] = kp;
+        cst[RSIM_CS_KD + lane] = 2.f * sqrtf(kp) * dr;
       }
       action += c.nimp * (c.imp_mode == 1 ? 2 : 1);
     }
@@ -2053,7 +2122,7 @@ struct Sim {
       const float imin = sel(c.in_min, li), imax = sel(c.in_max, li), omin = sel(c.out_min, li), omax = sel(c.out_max, li);
       const float tlo = sel(c.tl_lo, li), thi = sel(c.tl_hi, li);
       if (lane < c.ndof) {
-        if (c.interp_steps) sm.cstate[RSIM_CS_ISTART + lane] = sm.cstate[RSIM_CS_GOALQ + lane];   // LinearInterpolator.set_goal: start := previous goal
+        if (c.interp_steps) cst[RSIM_CS_ISTART + lane] = sm.cstate[RSIM_CS_GOALQ + lane];   // LinearInterpolator.set_goal: start := previous goal
         const float scale = fabsf(omax - omin) / fabsf(imax - imin);
         const float a = fmaxf(imin, fminf(imax, action[lane]));
         const float sv = (a - 0.5f * (imax + imin)) * scale + 0.5f * (omax + omin);
@@ -2064,8 +2133,9 @@ struct Sim {
         const float a = action[c.cdim], sg = a > 0 ? 1.f : (a < 0 ? -1.f : 0.f);
         sm.cstate[RSIM_CS_GRIP + lane] = fmaxf(-1.f, fminf(1.f, sm.cstate[RSIM_CS_GRIP + lane] + K.cgs * c.grip_speed * sg));
       }
-      if (c.interp_steps && lane == 0) sm.cstate[RSIM_CS_ISTEP] = 0.f;
+      if (c.interp_steps && lane == 0) cst[RSIM_CS_ISTEP] = 0.f;
       SYNC();
+      cst_sync();
       return;
     }
     float sc[6];
@@ -2095,10 +2165,10 @@ struct Sim {
     SYNC();
     if (lane == 0) {
       if (c.interp_steps) {
-        st3(sm.cstate + RSIM_CS_ISTART, ld3(sm.cstate + RSIM_CS_GOALPOS)); sm.cstate[RSIM_CS_ISTEP] = 0.f;
+        st3(cst + RSIM_CS_ISTART, ld3(sm.cstate + RSIM_CS_GOALPOS)); cst[RSIM_CS_ISTEP] = 0.f;
         if (c.type == RSIM_CTRL_OSC_POSE) {   // osc.py:277-283: ori_ref = current eef orientation, goal = error of the (base-frame) goal_ori against it
-          st3(sm.cstate + RSIM_CS_ISTART_ORI, ld3(sm.cstate + RSIM_CS_IGOAL_ORI));
-          st3(sm.cstate + RSIM_CS_IGOAL_ORI, (cross(col(eR, 0), col(go, 0)) + cross(col(eR, 1), col(go, 1)) + cross(col(eR, 2), col(go, 2))) * 0.5f);
+          st3(cst + RSIM_CS_ISTART_ORI, ld3(cst + RSIM_CS_IGOAL_ORI));
+          st3(cst + RSIM_CS_IGOAL_ORI, (cross(col(eR, 0), col(go, 0)) + cross(col(eR, 1), col(go, 1)) + cross(col(eR, 2), col(go, 2))) * 0.5f);
         }
       }
       st3(sm.cstate + RSIM_CS_GOALPOS, gp);
@@ -2109,6 +2179,7 @@ struct Sim {
       sm.cstate[RSIM_CS_GRIP + lane] = fmaxf(-1.f, fminf(1.f, sm.cstate[RSIM_CS_GRIP + lane] + K.cgs * c.grip_speed * sg));
     }
     SYNC();
+    cst_sync();
   }
 
   // reset_goal + initial_joint capture (Controller.__init__ / OSC.reset_goal)
@@ -2119,19 +2190,20 @@ struct Sim {
     if (c.imp_mode) {   // the constructor's gains stay in force until the first set_goal
       const int li = lane & (RSIM_JNT_MAX - 1);
       const float kp0 = sel(c.kp, li), kd0 = sel(c.kd, li);
-      if (lane < c.nimp) { sm.cstate[RSIM_CS_KP + lane] = kp0; sm.cstate[RSIM_CS_KD + lane] = kd0; }
+      if (lane < c.nimp) { cst[RSIM_CS_KP + lane] = kp0; cst[RSIM_CS_KD + lane] = kd0; }
     }
     if (c.type >= RSIM_CTRL_JOINT_POSITION) {   // joint_pos.py:268-276 (goal_qpos = joint_pos), joint_tor.py:170-178 (goal_torque = 0)
       if (lane < c.ndof) sm.cstate[RSIM_CS_GOALQ + lane] = c.type == RSIM_CTRL_JOINT_POSITION ? sm.qpos[K.cq] : 0.f;
       if (lane < RSIM_GRIP_MAX) sm.cstate[RSIM_CS_GRIP + lane] = 0.f;
       // JOINT_VELOCITY: fresh PID state (joint_vel.py:105-110; RingBuffer starts with ptr = length - 1, size 0); the caller zeroed the block
-      if (c.type == RSIM_CTRL_JOINT_VELOCITY && lane == 0) sm.cstate[RSIM_CS_JV_PTR] = 4.f;
+      if (c.type == RSIM_CTRL_JOINT_VELOCITY && lane == 0) cst[RSIM_CS_JV_PTR] = 4.f;
     } else if (lane == 0) {
       st3(sm.cstate + RSIM_CS_GOALPOS, ld3(sm.spos + 3 * c.eef_site));
       for (int k = 0; k < 9; k++) sm.cstate[RSIM_CS_GOALORI + k] = sm.smat[9 * c.eef_site + k];
       for (int i = 0; i < RSIM_GRIP_MAX; i++) sm.cstate[RSIM_CS_GRIP + i] = 0.f;
     }
     SYNC();
+    cst_sync();
   }
 
   // OperationalSpaceController.run_controller (osc.py:403-495) + SimpleGripController, tau clipped into ctrl.
@@ -2148,6 +2220,7 @@ struct Sim {
     const float glo = __shfl(K.acr0, K.cga), ghi = __shfl(K.acr1, K.cga);
     if (lane < c.ngrip) sm.ctrl[K.cga] = fmaxf(glo, fminf(ghi, 0.5f * (ghi + glo) + 0.5f * (ghi - glo) * sm.cstate[RSIM_CS_GRIP + lane]));
     SYNC();
+    cst_sync();
   }
 
   // JointPositionController.run_controller (joint_pos.py:238-266): tau = M_arm (kp (goal - q) - kd qd) + qfrc_bias[arm];
@@ -2160,14 +2233,14 @@ struct Sim {
     const int di = lane < n ? K.cd : 0, qi = lane < n ? K.cq : 0;
     float goal = lane < n ? sm.cstate[RSIM_CS_GOALQ + lane] : 0.f;
     if (c.interp_steps) {   // LinearInterpolator.get_interpolated_goal (traj_utils.py:118-155)
-      const float step = sm.cstate[RSIM_CS_ISTEP], start = lane < n ? sm.cstate[RSIM_CS_ISTART + lane] : 0.f;
+      const float step = cst[RSIM_CS_ISTEP], start = lane < n ? cst[RSIM_CS_ISTART + lane] : 0.f;
       goal = start + (goal - start) / ((float)c.interp_steps - step);
       SYNC();
-      if (lane == 0 && step < (float)(c.interp_steps - 1)) sm.cstate[RSIM_CS_ISTEP] = step + 1.f;
+      if (lane == 0 && step < (float)(c.interp_steps - 1)) cst[RSIM_CS_ISTEP] = step + 1.f;
     }
     float tq = lane < n ? sm.qfrc_bias[di] : 0.f;
     if (c.type == RSIM_CTRL_JOINT_POSITION) {
-      const float kpj = c.imp_mode ? sm.cstate[RSIM_CS_KP + li] : sel(c.kp, li), kdj = c.imp_mode ? sm.cstate[RSIM_CS_KD + li] : sel(c.kd, li);
+      const float kpj = c.imp_mode ? cst[RSIM_CS_KP + li] : sel(c.kp, li), kdj = c.imp_mode ? cst[RSIM_CS_KD + li] : sel(c.kd, li);
       const float des = lane < n ? kpj * (goal - sm.qpos[qi]) - kdj * sm.qvel[di] : 0.f;
       const int mypart = seli(c.part_of, li);
 #pragma unroll
@@ -2179,18 +2252,18 @@ struct Sim {
       // joint_vel.py:166-198: err = goal - qd; derr ring (5) mean; integrator frozen while this part saturated on the previous call
       const float kp = sel(c.kp, li), alo = __shfl(K.acr0, K.ca), ahi = __shfl(K.acr1, K.ca);
       const int mypart = seli(c.part_of, li);
-      const int ptr = ((int)sm.cstate[RSIM_CS_JV_PTR] + 1) % 5, size = min((int)sm.cstate[RSIM_CS_JV_SIZE] + 1, 5);
+      const int ptr = ((int)cst[RSIM_CS_JV_PTR] + 1) % 5, size = min((int)cst[RSIM_CS_JV_SIZE] + 1, 5);
       float pid = 0.f;
       bool over = false;
       if (lane < n) {
         const float err = goal - sm.qvel[di], derr = err - sm.cstate[RSIM_CS_JV_LASTERR + lane];
         sm.cstate[RSIM_CS_JV_LASTERR + lane] = err;
-        sm.cstate[RSIM_CS_JV_RING + 16 * ptr + lane] = derr;
-        float summed = sm.cstate[RSIM_CS_JV_SUMMED + lane];
-        if (sm.cstate[RSIM_CS_JV_SAT + mypart] == 0.f) summed += err;
-        sm.cstate[RSIM_CS_JV_SUMMED + lane] = summed;
+        cst[RSIM_CS_JV_RING + 16 * ptr + lane] = derr;
+        float summed = cst[RSIM_CS_JV_SUMMED + lane];
+        if (cst[RSIM_CS_JV_SAT + mypart] == 0.f) summed += err;
+        cst[RSIM_CS_JV_SUMMED + lane] = summed;
         float avg = 0.f;
-        for (int k = 0; k < size; k++) avg += sm.cstate[RSIM_CS_JV_RING + 16 * k + lane];   // RingBuffer.average: mean of buf[:size]
+        for (int k = 0; k < size; k++) avg += cst[RSIM_CS_JV_RING + 16 * k + lane];   // RingBuffer.average: mean of buf[:size]
         avg /= (float)size;
         pid = kp * err + 0.005f * kp * summed + 0.001f * kp * avg;
         const float raw = pid + tq;
@@ -2201,9 +2274,9 @@ struct Sim {
 #pragma unroll
       for (int p2 = 0; p2 < 4; p2++) {   // saturated = any clipped torque within the part (one controller object per arm)
         const bool any = __ballot(over && mypart == p2) != 0;
-        if (lane == 0) sm.cstate[RSIM_CS_JV_SAT + p2] = any ? 1.f : 0.f;
+        if (lane == 0) cst[RSIM_CS_JV_SAT + p2] = any ? 1.f : 0.f;
       }
-      if (lane == 0) { sm.cstate[RSIM_CS_JV_PTR] = (float)ptr; sm.cstate[RSIM_CS_JV_SIZE] = (float)size; }
+      if (lane == 0) { cst[RSIM_CS_JV_PTR] = (float)ptr; cst[RSIM_CS_JV_SIZE] = (float)size; }
     } else tq += goal;
     ctrl_write(K, tq);
   }
@@ -2279,26 +2352,26 @@ struct Sim {
     const V3 gpos = ld3(sm.cstate + RSIM_CS_GOALPOS);
     const M3 gori = ldm(sm.cstate + RSIM_CS_GOALORI);
     V3 perr = op + mv(oR, gpos) - ep;
-    const float istep = c.interp_steps ? sm.cstate[RSIM_CS_ISTEP] : 0.f;
+    const float istep = c.interp_steps ? cst[RSIM_CS_ISTEP] : 0.f;
     if (c.interp_steps) {
       // osc.py:418-423: with an interpolator the (base-frame) goal values, linearly ramped, ARE the desired world position
       const float step = istep;
-      const V3 start = ld3(sm.cstate + RSIM_CS_ISTART);
+      const V3 start = ld3(cst + RSIM_CS_ISTART);
       perr = start + (gpos - start) * (1.0f / ((float)c.interp_steps - step)) - ep;
       SYNC();
-      if (lane == 0 && step < (float)(c.interp_steps - 1)) sm.cstate[RSIM_CS_ISTEP] = step + 1.f;
+      if (lane == 0 && step < (float)(c.interp_steps - 1)) cst[RSIM_CS_ISTEP] = step + 1.f;
     }
     const M3 dori = mm(oR, gori);
     V3 oerr = (cross(col(eR, 0), col(dori, 0)) + cross(col(eR, 1), col(dori, 1)) + cross(col(eR, 2), col(dori, 2))) * 0.5f;
     if (c.interp_steps && c.type == RSIM_CTRL_OSC_POSE)   // osc.py:433-437: the ramped error vector replaces the measured one
-      oerr = euler_slerp(ld3(sm.cstate + RSIM_CS_ISTART_ORI), ld3(sm.cstate + RSIM_CS_IGOAL_ORI), (istep + 1.f) / (float)c.interp_steps);
+      oerr = euler_slerp(ld3(cst + RSIM_CS_ISTART_ORI), ld3(cst + RSIM_CS_IGOAL_ORI), (istep + 1.f) / (float)c.interp_steps);
     // site velocities from the body spatial velocities of the velocity stage: v = cvel.l + w x (p - com)
     const S6 ce = ld6(sm.u.v.cvel + CS6 * eb), cb = ld6(sm.u.v.cvel + CS6 * bb);
-    const V3 evl = ce.l + cross(ce.a, ep - ld3(sm.rootcom + 3 * sm.broot[eb])), bvl = cb.l + cross(cb.a, op - ld3(sm.rootcom + 3 * sm.broot[bb]));
+    const V3 evl = ce.l + cross(ce.a, ep - ld3(sm.rootcom + 3 * cm->broot[eb])), bvl = cb.l + cross(cb.a, op - ld3(sm.rootcom + 3 * cm->broot[bb]));
     const V3 dvl = evl - bvl, dva = ce.a - cb.a;
     float kp6[6], kd6[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) { kp6[i] = c.imp_mode ? sm.cstate[RSIM_CS_KP + i] : c.kp[i]; kd6[i] = c.imp_mode ? sm.cstate[RSIM_CS_KD + i] : c.kd[i]; }
+    for (int i = 0; i < 6; i++) { kp6[i] = c.imp_mode ? cst[RSIM_CS_KP + i] : c.kp[i]; kd6[i] = c.imp_mode ? cst[RSIM_CS_KD + i] : c.kd[i]; }
     float F[3] = {perr.x * kp6[0] - dvl.x * kd6[0], perr.y * kp6[1] - dvl.y * kd6[1], perr.z * kp6[2] - dvl.z * kd6[2]};
     float T[3] = {oerr.x * kp6[3] - dva.x * kd6[3], oerr.y * kp6[4] - dva.y * kd6[4], oerr.z * kp6[5] - dva.z * kd6[5]};
     float wrench[6], z[6];
@@ -2499,7 +2572,7 @@ struct Sim {
       w_.type = w_.valid ? (desc & 15) : -1;
       const bool tfric = TENDONS && w_.type == C_FRICTION_TENDON;   // a tendon friction row behaves as a dof friction row from here on
       if (tfric) w_.type = C_FRICTION_DOF;
-      w_.R = sm.e_R[r]; w_.D = 1.0f / w_.R; w_.aref = w_.valid ? sm.e_aref[r] : 0.f; w_.fl = tfric ? FP(FO_tendon_fl, (desc >> 4) & 255) : (w_.type == C_FRICTION_DOF ? sm.fricFl[(desc >> 4) & 255] : 0.f);
+      w_.R = sm.e_R[r]; w_.D = 1.0f / w_.R; w_.aref = w_.valid ? sm.e_aref[r] : 0.f; w_.fl = tfric ? FP(FO_tendon_fl, (desc >> 4) & 255) : (w_.type == C_FRICTION_DOF ? cmf(MK_fricFl)->fricFl[(desc >> 4) & 255] : 0.f);
       w_.ell = w_.type == C_CONTACT_ELLIPTIC;
       const int c = w_.ell ? (desc >> 4) & 255 : 0;
       w_.kk = w_.ell ? (desc >> 12) & 15 : 0; w_.head = row - w_.kk; w_.dim = w_.ell ? sm.cdim[c] : 1;
@@ -2921,7 +2994,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   const int env = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
   const long long t_launch = b.cost ? clock64() : 0;
   const float* fp = m.ft + (size_t)env * m.fstride;
-  Sim<SM> sim(m, fp, lane, b.prof);
+  Sim<SM> sim(m, fp, lane, b.prof, b.cm, b.cm_stride ? (const char*)b.cm_env + (size_t)env * b.cm_stride : (const char*)b.cm);
   sim.pf.acc = b.prof_env < 0 || b.prof_env == env;
   if (b.prof) sim.pf.pairs = b.prof + RP_COUNT + 8 * (size_t)b.B;
   sim.pf.start();
@@ -2936,17 +3009,21 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   for (int i = lane; i < m.nv; i += 64) { sm.qvel[i] = b.qvel[(size_t)env * m.nv + i]; sm.qacc_ws[i] = b.qacc_ws[(size_t)env * m.nv + i]; }
   if (lane >= m.nv && lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.qacc[lane] = 0.f; }
   for (int i = lane; i < m.nu; i += 64) sm.ctrl[i] = b.ctrl[(size_t)env * m.nu + i];
-  const int cs = m.ctrl.cs_size;
-  for (int i = lane; i < cs; i += 64) sm.cstate[i] = b.cstate[(size_t)env * cs + i];
+  const int cs = m.ctrl.cs_size, csl = cs < RSIM_CS_LDS ? cs : RSIM_CS_LDS;
+  sim.cst = (gwf)(b.cstate + (size_t)env * cs);
+  if (lane < csl) sm.cstate[lane] = sim.cst[lane];
   if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; }
-  sim.load_constants();
+  sim.load_opt();
+  sim.init_lds();
   const float* act = actions ? actions + (size_t)env * m.ctrl.action_dim : nullptr;
   float time = b.time[env];
   if ((flags & RF_CTRL) && b.needs_reset[env]) {
     // this env was re-initialised on the device when its previous episode ended: fresh controller objects (robots/robot.py:271)
     V3 xp0; Q4 xq0;
-    for (int i = lane; i < cs; i += 64) sm.cstate[i] = 0.f;
+    if (lane < csl) sm.cstate[lane] = 0.f;
+    for (int i = RSIM_CS_LDS + lane; i < cs; i += 64) sim.cst[i] = 0.f;
     SYNC();
+    sim.cst_sync();
     sim.kinematics(xp0, xq0);
     sim.geom_site_frames();
     sim.ctrl_reset();
@@ -2955,33 +3032,44 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   sim.pf.mark(RP_LOAD);
   for (int sub = 0; sub < n_sub; sub++) {
     V3 xp; Q4 xq;
+    sim.phase();
     sim.kinematics(xp, xq);
+    sim.phase();
     sim.geom_site_frames();
     sim.pf.mark(RP_KIN);
+    sim.phase();
     sim.com_pos(xp, xq);
     sim.pf.mark(RP_COM);
+    sim.phase();
     sim.crb();
     sim.pf.mark(RP_CRB);
+    sim.phase();
     sim.collision();
     sim.pf.mark(RP_NARROW);
+    sim.phase();
     sim.make_constraint();
     sim.pf.mark(RP_MAKEC);
+    sim.phase();
     sim.velocity(xp, xq);
     sim.pf.mark(RP_VEL);
     if (flags & RF_CTRL) {
+      sim.phase();
       if ((flags & RF_SETGOAL) && sub == 0 && act) sim.ctrl_set_goal(act);
       sim.ctrl_run();
       sim.pf.mark(RP_CTRL);
     }
     if (flags & RF_ACTSOLVE) {
+      sim.phase();
       sim.actuation_acceleration();
       sim.pf.mark(RP_ACT);
+      sim.phase();
       sim.fwd_constraint();
       sim.pf.mark(RP_SOLVE);
       sim.pf.count(RP_N_CON, sm.ncon);
       sim.pf.count(RP_N_EFC, sm.nefc);
     }
     if (flags & RF_INTEGRATE) {
+      sim.phase();
       sim.euler();
       sim.pf.mark(RP_EULER);
       time += sim.opt_h;
@@ -3027,6 +3115,8 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
       }
       if (lane == 0) { b.ep_index[env] = ep; b.needs_reset[env] = 1; }
       SYNC();
+      // the patched float-table entries change this env's constant block: the host follows this launch with k_prepare over the envs whose
+      // needs_reset flag is set (inlining prepare_constants() here makes the compiler keep a private copy of DModel)
     }
     if (lane == 0) { b.done[env] = done ? 1 : 0; b.ep_step[env] = st; }
   }
@@ -3034,8 +3124,9 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   for (int i = lane; i < m.nq; i += 64) b.qpos[(size_t)env * m.nq + i] = sm.qpos[i];
   for (int i = lane; i < m.nv; i += 64) { b.qvel[(size_t)env * m.nv + i] = sm.qvel[i]; b.qacc_ws[(size_t)env * m.nv + i] = sm.qacc_ws[i]; }
   for (int i = lane; i < m.nu; i += 64) b.ctrl[(size_t)env * m.nu + i] = sm.ctrl[i];
-  for (int i = lane; i < cs; i += 64) b.cstate[(size_t)env * cs + i] = sm.cstate[i];
+  if (lane < csl) sim.cst[lane] = sm.cstate[lane];
   if (lane == 0) b.time[env] = time;
+  if (b.overflow && lane == 0 && sim.ovf) b.overflow[env] += sim.ovf;
   if (b.cost && lane == 0) b.cost[env] = (unsigned)((clock64() - t_launch) >> 6);
   if (b.prof && lane == 0) {
     unsigned long long* wl = b.prof + RP_COUNT + 8 * (size_t)env;
@@ -3043,7 +3134,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   }
   if (flags & RF_DEBUG) {
     const int nb = m.nbody, nv = m.nv;
-    for (int i = lane; i < nb * 3; i += 64) { b.xpos[(size_t)env * nb * 3 + i] = sm.xpos[i]; b.rootcom[(size_t)env * nb * 3 + i] = sm.rootcom[3 * sm.broot[i / 3] + i % 3]; }
+    for (int i = lane; i < nb * 3; i += 64) { b.xpos[(size_t)env * nb * 3 + i] = sm.xpos[i]; b.rootcom[(size_t)env * nb * 3 + i] = sm.rootcom[3 * sim.cm->broot[i / 3] + i % 3]; }
     for (int i = lane; i < nb * 4; i += 64) b.xquat[(size_t)env * nb * 4 + i] = sm.xquat[i];
     for (int e = lane; e < nv * nv; e += 64) { int i = e / nv, j = e - i * nv; b.qM[(size_t)env * nv * nv + e] = sm.M[i * SM::NVP + j]; }
     for (int e = lane; e < nv * 6; e += 64) b.cdof[(size_t)env * nv * 6 + e] = sm.cdof[(e / 6) * 9 + e % 6];
@@ -3076,16 +3167,35 @@ __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const uns
   if (env >= b.B) return;
   if (mask && !mask[env]) return;
   const float* fp = m.ft + (size_t)env * m.fstride;
-  Sim<SM> sim(m, fp, lane, nullptr);
+  Sim<SM> sim(m, fp, lane, nullptr, b.cm, b.cm_stride ? (const char*)b.cm_env + (size_t)env * b.cm_stride : (const char*)b.cm);
   for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = b.qpos[(size_t)env * m.nq + i];
-  const int cs = m.ctrl.cs_size;
-  for (int i = lane; i < cs; i += 64) sm.cstate[i] = 0.f;
-  sim.load_constants();
+  const int cs = m.ctrl.cs_size, csl = cs < RSIM_CS_LDS ? cs : RSIM_CS_LDS;
+  sim.cst = (gwf)(b.cstate + (size_t)env * cs);
+  if (lane < csl) sm.cstate[lane] = 0.f;
+  for (int i = RSIM_CS_LDS + lane; i < cs; i += 64) sim.cst[i] = 0.f;
+  sim.cst_sync();
+  sim.load_opt();
+  sim.init_lds();
   V3 xp; Q4 xq;
   sim.kinematics(xp, xq);
   sim.geom_site_frames();
   sim.ctrl_reset();
-  for (int i = lane; i < cs; i += 64) b.cstate[(size_t)env * cs + i] = sm.cstate[i];
+  if (lane < csl) sim.cst[lane] = sm.cstate[lane];
+}
+
+// constant blocks (Cmem) of envs [0, grid): built from the float / int / lane tables whenever a model parameter changed (model ingest,
+// rsim_model_param_set, domain randomisation, a new controller); one workgroup per block.  reset_only: just the envs that the preceding
+// control step re-initialised from the reset bank (their float tables were patched).
+template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
+__global__ __launch_bounds__(64) void k_prepare(DModel m, DBatch b, int reset_only) {
+  typedef Smem<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> SM;
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (reset_only && !b.needs_reset[env]) return;
+  const float* fp = m.ft + (size_t)env * m.fstride;
+  // the host passes the blocks to build as b.cm_env / b.cm_stride (the shared block: one workgroup, m.fenv = 0, stride 0)
+  char* const cmb = (char*)b.cm_env + (size_t)env * b.cm_stride;
+  Sim<SM> sim(m, fp, lane, nullptr, cmb, cmb);
+  sim.prepare_constants((cmw_t)cmb);
 }
 
 
@@ -3244,6 +3354,7 @@ extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out,
 // explicit instantiations + launchers (one set per configuration build) ----------------------------------------------------------
 template __global__ void k_step<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
 template __global__ void k_ctrl_reset<RSIM_DIMS>(DModel, DBatch, const unsigned char*);
+template __global__ void k_prepare<RSIM_DIMS>(DModel, DBatch, int);
 
 extern "C" int RSIM_SYM(rsim_launch_step)(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream) {
   hipLaunchKernelGGL((k_step<RSIM_DIMS>), dim3(b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
@@ -3253,6 +3364,11 @@ extern "C" int RSIM_SYM(rsim_launch_ctrl_reset)(const DModel* m, const DBatch* b
   hipLaunchKernelGGL((k_ctrl_reset<RSIM_DIMS>), dim3(b->B), dim3(64), 0, stream, *m, *b, mask);
   return (int)hipGetLastError();
 }
+extern "C" int RSIM_SYM(rsim_launch_prepare)(const DModel* m, const DBatch* b, int nblocks, int reset_only, hipStream_t stream) {
+  hipLaunchKernelGGL((k_prepare<RSIM_DIMS>), dim3(nblocks), dim3(64), 0, stream, *m, *b, reset_only);
+  return (int)hipGetLastError();
+}
+extern "C" int RSIM_SYM(rsim_cmem_bytes)(void) { return (int)((sizeof(Cmem0) + 255) & ~(size_t)255); }
 // {nbody, njnt, nv, ncgeom, nsite, ncon, nefc, npair, articulated trees, tendon / equality rows (0 / 1)}
 extern "C" int RSIM_SYM(rsim_limits)(int* lim) {
   const int dims[8] = {RSIM_DIMS};
