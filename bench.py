@@ -8,9 +8,17 @@ per-env seeded episodes (cube size, arm noise, cube pose) and per-env action str
 N>1: every rank owns 4096 envs of the global index range (weak scaling, no data-path collective; one stats all-reduce
 after the timed region).  Inputs (state, model tables, the whole action tape) are resident in HBM before the timed region.
 
+Episode phase.  A launch gets slower along an episode (random actions bring the hand to the table: more narrow-phase pairs and Newton
+iterations; +30 % from step 0 to step 250), so timing the first steps of 4096 synchronised episodes measures the cheap part only.  By
+default the envs are therefore put at episode steps spread uniformly over the horizon before anything is timed: env i starts with its
+step counter at o_i = (197 i) mod 500 and `horizon` untimed launches are run, so every env passes its horizon once (on-device reset from
+the bank) and then sits o_i genuine steps into its second episode.  Every timed launch then sees the steady-state mix of an RL rollout,
+including the ~B/500 on-device episode resets per launch.  `--phase fresh` times synchronised episodes from their first step instead.
+
 Prints ONE JSON line on rank 0.  See DESIGN.md section 6 for the roofline / cpu_baseline definitions.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -22,12 +30,12 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from robosuite_amd import lift, mjcf, shard  # noqa: E402
+from robosuite_amd import backend, lift, mjcf, shard  # noqa: E402
 
 ENVS_PER_GPU = 4096
 N_SUB = 25
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
-VALU_PER_ENV_SUBSTEP = 7360.0  # SQ_INSTS_VALU / (4096 envs x 25 substeps), profiles/r01_e_pmc_sq1.txt (bench workload, steps 1-4 of an episode)
+HORIZON = 500
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4  # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles at 2.4 GHz
 
 
@@ -80,10 +88,11 @@ def cpu_baseline(flat, cfg, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)   # 200 timed steps after 20 warm-up steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phase", choices=("staggered", "fresh"), default="staggered", help="episode phase of the envs when the timed region starts (module docstring)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -111,15 +120,21 @@ def main():
     cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
     B = args.envs_per_gpu
     ids = shard.env_block(B * world, rank, world)
-    env = lift.LiftBatch(flat, cfg, ids, device=local_rank, seed0=0, horizon=500, bank_episodes=2)  # config 2: episodes auto-reset at horizon 500
     K, W = args.steps, args.warmup
-    tape = torch.tensor(lift.env_actions(ids, K + W), device=dev)  # whole action tape resident in HBM
+    P = HORIZON if args.phase == "staggered" else 0   # untimed pre-roll launches
+    env = lift.LiftBatch(flat, cfg, ids, device=local_rank, seed0=0, horizon=HORIZON, bank_episodes=2 + (P + W + K) // HORIZON)  # config 2: episodes auto-reset at horizon 500
+    tape = torch.tensor(lift.env_actions(ids, P + K + W), device=dev)  # whole action tape resident in HBM
     stream = torch.cuda.ExternalStream(env.batch.stream(), device=dev)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
+    if P:
+        env.batch.set("ep_step", ((197 * ids) % HORIZON).astype(np.int32))   # keyed by the GLOBAL env id: independent of the GPU count
+        for t in range(P):
+            env.step(tape[t])
+        tape = tape[P:]
     for t in range(W):
         env.step(tape[t])
     env.batch.sync(); torch.cuda.synchronize(); barrier()
@@ -141,6 +156,7 @@ def main():
     # envs that hit the bad-state guard (RSIM_DIVERGED, MuJoCo's mj_checkPos semantics) or hold a non-finite coordinate
     st.add(env_steps=B * K, diverged=int((~torch.isfinite(q).all(dim=1)).sum().item()) + int((env.batch.tensor("diverged") > 0).sum().item()),
            reward_sum=float(env.reward().sum().item()), successes=int(env.success().sum().item()))
+    overflow_envs = shard.max_over_ranks(float((env.batch.tensor("overflow") > 0).sum().item()), dev)   # envs that ever dropped a contact / constraint row
     if hasattr(env, "rollout_totals"):
         st.add(**env.rollout_totals())
     tot = st.allreduce()
@@ -149,27 +165,38 @@ def main():
         OBS_DIM_REPORT = env.model.nobs
         abytes = algorithmic_bytes_per_env_step(flat, env.model.action_dim) * B
         ach = abytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived bytes per launch, written by tools/pmc_traffic.py
-        if os.path.exists(tf):
+        # PMC-derived figures are only valid for the library build they were measured on: the files carry the sha of that build
+        lib_sha = hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16]
+
+        def pmc(name, key):
             try:
-                traffic = json.load(open(tf)).get("bytes_per_launch")
+                d = json.load(open(os.path.join(ROOT, "profiles", name)))
+                return d.get(key) if d.get("lib_sha16") == lib_sha else None
             except Exception:
-                traffic = None
+                return None
+
+        traffic = pmc("hbm_traffic.json", "bytes_per_launch")            # tools/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE passes)
+        valu = pmc("valu_count.json", "valu_per_env_substep")            # tools/pmc_valu.py (SQ_INSTS_VALU pass on this workload)
+        issue = None
+        if valu:
+            issue = {"bound": "valu-issue", "valu_instr_per_env_substep": valu, "achieved": valu * B * N_SUB / (kern_ms * 1e-3) / 1e9,
+                     "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instr/s", "frac": valu * B * N_SUB / (kern_ms * 1e-3) / VALU_ISSUE_PEAK,
+                     "source": "profiles/valu_count.json (rocprofv3 --pmc SQ_INSTS_VALU on this build, same workload)"}
         out = {
             "metric": "env-steps/sec (whole node), Lift/Panda/OSC_POSE @4096 envs/GPU", "value": tot["env_steps"] / dt, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Lift/Panda/OSC_POSE, 25 substeps x dt 0.002 + OSC_POSE/GRIP per substep, fused in one launch (BASELINE configs[1])",
-                       "envs_per_gpu": B, "global_envs": B * world, "n_sub": N_SUB, "per_env_seeded_reset": True, "horizon": 500, "on_device_auto_reset": True, "obs_dim": OBS_DIM_REPORT, "sharding": f"env-block x{world}",
+                       "envs_per_gpu": B, "global_envs": B * world, "n_sub": N_SUB, "per_env_seeded_reset": True, "horizon": HORIZON, "on_device_auto_reset": True,
+                       "episode_phase": ("uniform over the horizon: step counters offset by (197 i) mod 500, then 500 untimed pre-roll launches" if P else "fresh: all envs at step W of their first episode"),
+                       "overflow_envs": int(overflow_envs), "lib_sha16": lib_sha, "obs_dim": OBS_DIM_REPORT, "sharding": f"env-block x{world}",
                        "diverged_envs": int(tot["diverged"]), "reward_sum": tot["reward_sum"], "successes": int(tot["successes"])},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes,
                          "note": "latency/VALU/LDS-bound by design (state LDS-resident for 25 substeps); see DESIGN.md section 6",
-                         # the fraction that describes this kernel: VALU issue slots used (PMC instruction count x measured rate), one wave per SIMD
-                         "issue": {"bound": "valu-issue", "valu_instr_per_env_substep": VALU_PER_ENV_SUBSTEP,
-                                   "achieved": VALU_PER_ENV_SUBSTEP * B * N_SUB / (kern_ms * 1e-3) / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instr/s",
-                                   "frac": VALU_PER_ENV_SUBSTEP * B * N_SUB / (kern_ms * 1e-3) / VALU_ISSUE_PEAK}},
+                         # the fraction that describes this kernel: VALU issue slots used (PMC instruction count of THIS build x measured rate); null
+                         # when profiles/valu_count.json was measured on another build
+                         "issue": issue},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(flat, cfg)
