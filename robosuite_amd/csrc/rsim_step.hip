@@ -308,8 +308,8 @@ struct Cmem {
   float biw[NB * 2];             // body_invweight0
   dmask_t bdofs[NB];
   int broot[NB];
-  float gst[NG * 8];             // colliding geom statics: half-extents 3, box centre (geom frame) 3, rbound, margin
-  float gcap[NG * 8];            // bounding capsule of mesh hulls in the geom frame: p3 q3 R (R < 0: none)
+  alignas(16) float gst[NG * 8];   // colliding geom statics: half-extents 3, box centre (geom frame) 3, rbound, margin (read as two 16-byte loads)
+  alignas(16) float gcap[NG * 8];  // bounding capsule of mesh hulls in the geom frame: p3 q3 R (R < 0: none)
   int gtype[NG], gbody[NG], gcp[NG], gmesh[NG];   // type, body, condim | priority<<8, hull vertex adr | count<<16
   int ghull[NG];                 // first slot of geom g in the LDS-resident hull pool, -1: scanned from global memory
   float gpar[NG * 12];           // contact material per geom: friction3 solref2 solimp5 solmix gap
@@ -1373,10 +1373,11 @@ struct Sim {
 
   // contact parameters of a geom pair (MuJoCo's mixing rules: priority, solmix-weighted solref/solimp, max friction);
   // evaluated once per candidate pair, uniformly by every lane, from the per-geom table staged in LDS
-  struct CPar { int dim; float solref[2], solimp[5], fr[3]; float margin_gap; };
+  struct CPar { int dim; float solref[2], solimp[5], fr[3]; float margin_gap; int b1, b2; };
   __device__ __forceinline__ CPar contact_params(int g1, int g2, float margin, float gap) const {
     CPar cp;
     cp.margin_gap = margin - gap;
+    cp.b1 = cm->gbody[g1]; cp.b2 = cm->gbody[g2];   // stored with the contact (geom | body << 8): the row builders need the body, not a second dependent global load
     gcf a = cmf(MK_gpar)->gpar + 12 * g1;
     gcf b = cmf(MK_gpar)->gpar + 12 * g2;
     const int c1 = cm->gcp[g1], c2 = cm->gcp[g2];
@@ -1415,7 +1416,7 @@ struct Sim {
       sm.cdist[c] = dist;
       st3(sm.cpos + 3 * c, pos);
       make_frame(nrm, sm.cframe + 9 * c);
-      sm.cg1[c] = g1; sm.cg2[c] = g2; sm.cdim[c] = cp.dim;
+      sm.cg1[c] = g1 | (cp.b1 << 8); sm.cg2[c] = g2 | (cp.b2 << 8); sm.cdim[c] = cp.dim;
       sm.cmargin[c] = cp.margin_gap;
       sm.csolref[2 * c] = cp.solref[0]; sm.csolref[2 * c + 1] = cp.solref[1];
       for (int k = 0; k < 5; k++) sm.csolimp[5 * c + k] = cp.solimp[k];
@@ -1669,28 +1670,31 @@ struct Sim {
       if (64 * t >= m.npair) break;
       const int pr = K.pair[t];
       bool pass = false;
+      // all constants of the pair first, as eight 16-byte global loads in flight at once (they used to be LDS reads issued where needed; from
+      // global memory three dependent stages per round would be three round trips)
+      const int g1 = pr & 255, g2 = (pr >> 8) & 255;   // lanes without a pair read geom 0
+      typedef const v4f __attribute__((address_space(1)))* gc4;
+      gc4 st1 = (gc4)(cmf(MK_gst)->gst + 8 * g1), st2 = (gc4)(cmf(MK_gst)->gst + 8 * g2);
+      gc4 kp1 = (gc4)(cmf(MK_gcap)->gcap + 8 * g1), kp2 = (gc4)(cmf(MK_gcap)->gcap + 8 * g2);
+      const v4f s1a = st1[0], s1b = st1[1], s2a = st2[0], s2b = st2[1], k1a = kp1[0], k1b = kp1[1], k2a = kp2[0], k2b = kp2[1];
+      const int t1 = cm->gtype[g1];
       if ((pr >> 16) & 1) {
-        const int g1 = pr & 255, g2 = (pr >> 8) & 255;
-        gcf st1 = cmf(MK_gst)->gst + 8 * g1;
-        gcf st2 = cmf(MK_gst)->gst + 8 * g2;
-        const float margin = fmaxf(st1[7], st2[7]);
+        const float margin = fmaxf(s1b[3], s2b[3]);
         const V3 c2 = ld3(sm.gcen + 3 * g2);
         const M3 R2 = ldm(sm.gmat + 9 * g2);
-        V3 o2, h2;
-        geom_obb(g2, R2, o2, h2);
-        if (cm->gtype[g1] == G_PLANE) {
+        const V3 h2 = v3(s2a[0], s2a[1], s2a[2]), o2 = ld3(sm.gpos + 3 * g2) + mv(R2, v3(s2a[3], s2b[0], s2b[1]));
+        if (t1 == G_PLANE) {
           const V3 nrm = v3(sm.gmat[9 * g1 + 2], sm.gmat[9 * g1 + 5], sm.gmat[9 * g1 + 8]);
           const V3 pp = ld3(sm.gpos + 3 * g1);
-          pass = dot(c2 - pp, nrm) - st2[6] <= margin;
+          pass = dot(c2 - pp, nrm) - s2b[2] <= margin;
           if (pass) pass = dot(o2 - pp, nrm) - (h2.x * fabsf(dot(nrm, col(R2, 0))) + h2.y * fabsf(dot(nrm, col(R2, 1))) + h2.z * fabsf(dot(nrm, col(R2, 2)))) <= margin;
         } else {
           const V3 rel = c2 - ld3(sm.gcen + 3 * g1);
-          const float bound = st1[6] + st2[6] + margin;
+          const float bound = s1b[2] + s2b[2] + margin;
           pass = dot(rel, rel) <= bound * bound;
           if (pass) {
             const M3 R1 = ldm(sm.gmat + 9 * g1);
-            V3 o1, h1;
-            geom_obb(g1, R1, o1, h1);
+            const V3 h1 = v3(s1a[0], s1a[1], s1a[2]), o1 = ld3(sm.gpos + 3 * g1) + mv(R1, v3(s1a[3], s1b[0], s1b[1]));
             const M3 C = mtm(R1, R2);  // C[i][j] = A_i . B_j
             const V3 tt = o2 - o1, ta = mtv(R1, tt), tb = mtv(R2, tt);
             const float sepa = fmaxf(fmaxf(fabsf(ta.x) - (h1.x + h2.x * fabsf(C.m[0]) + h2.y * fabsf(C.m[1]) + h2.z * fabsf(C.m[2])),
@@ -1701,12 +1705,11 @@ struct Sim {
                                      fabsf(tb.z) - (h2.z + h1.x * fabsf(C.m[2]) + h1.y * fabsf(C.m[5]) + h1.z * fabsf(C.m[8])));
             pass = fmaxf(sepa, sepb) <= margin + 1e-6f;
             // bounding capsules (mesh hulls): distance between the two axis segments against the radii
-            gcf k1 = cmf(MK_gcap)->gcap + 8 * g1;
-            gcf k2 = cmf(MK_gcap)->gcap + 8 * g2;
-            if (pass && k1[6] >= 0.f && k2[6] >= 0.f) {
+            if (pass && k1b[2] >= 0.f && k2b[2] >= 0.f) {
               const V3 gp1 = ld3(sm.gpos + 3 * g1), gp2 = ld3(sm.gpos + 3 * g2);
-              const V3 p1 = gp1 + mv(R1, ld3(k1)), q1 = gp1 + mv(R1, ld3(k1 + 3)), p2 = gp2 + mv(R2, ld3(k2)), q2 = gp2 + mv(R2, ld3(k2 + 3));
-              const float reach = k1[6] + k2[6] + margin + 1e-6f;
+              const V3 p1 = gp1 + mv(R1, v3(k1a[0], k1a[1], k1a[2])), q1 = gp1 + mv(R1, v3(k1a[3], k1b[0], k1b[1])),
+                       p2 = gp2 + mv(R2, v3(k2a[0], k2a[1], k2a[2])), q2 = gp2 + mv(R2, v3(k2a[3], k2b[0], k2b[1]));
+              const float reach = k1b[2] + k2b[2] + margin + 1e-6f;
               pass = segment_dist2(p1, q1, p2, q2) <= reach * reach;
             }
           }
@@ -1925,8 +1928,7 @@ struct Sim {
       ovf += __popcll(__ballot(active && !keep));
       if (has) sm.cefc[lane] = keep ? first : -1;
       if (keep) {
-        const int g1 = sm.cg1[lane], g2 = sm.cg2[lane];
-        const int b1 = cm->gbody[g1], b2 = cm->gbody[g2];
+        const int b1 = sm.cg1[lane] >> 8, b2 = sm.cg2[lane] >> 8;
         const float tran = cmf(MK_biw)->biw[2 * b1] + cmf(MK_biw)->biw[2 * b2], rot = cmf(MK_biw)->biw[2 * b1 + 1] + cmf(MK_biw)->biw[2 * b2 + 1];
         float R0, Bd, Kt;
         row_scalars(sm.cdist[lane], sm.cmargin[lane], sm.csolref + 2 * lane, sm.csolimp + 5 * lane, tran, R0, Bd, Kt);
@@ -1981,8 +1983,7 @@ struct Sim {
         for (int k = 0; k < NV16; k++) Jr[k] = (wd[0] == k ? wc[0] : 0.f) + (wd[1] == k ? wc[1] : 0.f) + (wd[2] == k ? wc[2] : 0.f) + (wd[3] == k ? wc[3] : 0.f);
       } else if (valid) {
         const int c = id;
-        const int g1 = sm.cg1[c], g2 = sm.cg2[c];
-        const int b1 = cm->gbody[g1], b2 = cm->gbody[g2];
+        const int b1 = sm.cg1[c] >> 8, b2 = sm.cg2[c] >> 8;
         const dmask_t d1 = cm->bdofs[b1], d2 = cm->bdofs[b2];
         const V3 pos = ld3(sm.cpos + 3 * c);
         const V3 ax = ld3(sm.cframe + 9 * c + 3 * (kk < 3 ? kk : kk - 3));
@@ -2898,7 +2899,7 @@ struct Sim {
       for (int k = 0; k < 4; k++) if ((act_mask >> k) & 1ull) ageoms |= t.obj_geoms[k];
       bool lc = false, rc = false;
       if (lane < sm.ncon) {
-        const u64 b1 = 1ull << sm.cg1[lane], b2 = 1ull << sm.cg2[lane];
+        const u64 b1 = 1ull << (sm.cg1[lane] & 255), b2 = 1ull << (sm.cg2[lane] & 255);
         const bool o1 = (ageoms & b1) != 0, o2 = (ageoms & b2) != 0;
         lc = (o1 && (t.left_pad & b2)) || (o2 && (t.left_pad & b1));
         rc = (o1 && (t.right_pad & b2)) || (o2 && (t.right_pad & b1));
@@ -2937,7 +2938,7 @@ struct Sim {
       // grasp: both finger-pad geom groups touch the object (contact list of the last substep)
       bool lc = false, rc = false, oo = false;
       if (lane < sm.ncon) {
-        const unsigned long long b1 = 1ull << sm.cg1[lane], b2 = 1ull << sm.cg2[lane];
+        const unsigned long long b1 = 1ull << (sm.cg1[lane] & 255), b2 = 1ull << (sm.cg2[lane] & 255);
         const bool obj1 = (t.object_geoms & b1) != 0, obj2 = (t.object_geoms & b2) != 0;
         lc = (obj1 && (t.left_pad & b2)) || (obj2 && (t.left_pad & b1));
         rc = (obj1 && (t.right_pad & b2)) || (obj2 && (t.right_pad & b1));
@@ -3149,7 +3150,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
       r[0] = sm.cdist[c];
       for (int k = 0; k < 3; k++) r[1 + k] = sm.cpos[3 * c + k];
       for (int k = 0; k < 9; k++) r[4 + k] = sm.cframe[9 * c + k];
-      r[13] = (float)IT(IO_cg_geomid, sm.cg1[c]); r[14] = (float)IT(IO_cg_geomid, sm.cg2[c]); r[15] = (float)sm.cdim[c]; r[16] = (float)sm.cefc[c];
+      r[13] = (float)IT(IO_cg_geomid, sm.cg1[c] & 255); r[14] = (float)IT(IO_cg_geomid, sm.cg2[c] & 255); r[15] = (float)sm.cdim[c]; r[16] = (float)sm.cefc[c];
       r[17] = ((flags & RF_ACTSOLVE) && sm.cefc[c] >= 0) ? sm.e_force[sm.cefc[c]] : 0.f;
       for (int k = 0; k < 5; k++) r[18 + k] = sm.cfri[5 * c + k];
     }
