@@ -598,10 +598,13 @@ __device__ __forceinline__ void spd_solve_small(const float* A, const float* b, 
 
 // support point of colliding geom g along world direction dir (wave-cooperative for meshes; result uniform).
 // A real function (not inlined into its ~10 call sites); it only touches the LDS object and the hull vertex table.
-__device__ __forceinline__ V3 geom_support(cmr_t cm, cmr_t cmg, int g, V3 dir, gcf mesh_vert, int lane) {
+// `org`: origin the result is expressed in.  MPR passes the first geom's position, so that its portal algebra runs on centimetre-sized coordinates
+// (rounding ~4e-9 m) instead of metre-sized world coordinates (~1e-7 m): which facet of the Minkowski difference the origin ray leaves through is
+// then decided by the geometry, not by fp32 noise (fine meshes in deep penetration ended on neighbouring facets, degrees apart, in half of the cases).
+__device__ __forceinline__ V3 geom_support(cmr_t cm, cmr_t cmg, int g, V3 dir, gcf mesh_vert, int lane, V3 org) {
   const int t = cm->gtype[g];
   const M3 R = ldm(sm.gmat + 9 * g);
-  const V3 p = ld3(sm.gpos + 3 * g), h = ld3(cmg->gst + 8 * g);
+  const V3 p = ld3(sm.gpos + 3 * g) - org, h = ld3(cmg->gst + 8 * g);
   const V3 ld = mtv(R, dir);
   V3 lp = v3(0, 0, 0);
   if (t == G_BOX) lp = v3(ld.x >= 0 ? h.x : -h.x, ld.y >= 0 ? h.y : -h.y, ld.z >= 0 ? h.z : -h.z);
@@ -1369,7 +1372,7 @@ struct Sim {
     st3(frame, n); st3(frame + 3, y); st3(frame + 6, z);
   }
 
-  __device__ __forceinline__ V3 support(int g, V3 dir, int slot = -1) { pf.count(RP_N_SUPPORT, 1); return geom_support(cm, cmf(MK_gst), g, dir, (gcf)m.mesh_vert, lane); }
+  __device__ __forceinline__ V3 support(int g, V3 dir, V3 org = {0.f, 0.f, 0.f}) { pf.count(RP_N_SUPPORT, 1); return geom_support(cm, cmf(MK_gst), g, dir, (gcf)m.mesh_vert, lane, org); }
 
   // contact parameters of a geom pair (MuJoCo's mixing rules: priority, solmix-weighted solref/solimp, max friction);
   // evaluated once per candidate pair, uniformly by every lane, from the per-geom table staged in LDS
@@ -1576,19 +1579,20 @@ struct Sim {
   // Minkowski Portal Refinement (uniform control flow; support() is wave-cooperative)
   __device__ __forceinline__ void convex_convex(int g1, int g2, float margin, const CPar& cp) {
     const float tol = 1e-6f;
-    V3 v0 = ld3(sm.gcen + 3 * g1) - ld3(sm.gcen + 3 * g2);
+    const V3 org = ld3(sm.gpos + 3 * g1);   // all support points relative to the first geom's position (see geom_support)
+    V3 v0 = (ld3(sm.gcen + 3 * g1) - org) - (ld3(sm.gcen + 3 * g2) - org);
     if (norm(v0) < 1e-9f) v0.x = 1e-5f;
     V3 dir = normalized(-v0);
-    V3 p11 = support(g1, dir, 0), p12 = support(g2, -dir, 1), v1 = p11 - p12;
+    V3 p11 = support(g1, dir, org), p12 = support(g2, -dir, org), v1 = p11 - p12;
     if (dot(v1, dir) <= 0) return;
     dir = cross(v0, v1);
     if (norm(dir) < 1e-12f) {
       V3 n = normalized(v1 - v0);
-      emit_contacts(lane == 0, 1, -dot(v1, n), (p11 + p12) * 0.5f, n, g1, g2, cp);
+      emit_contacts(lane == 0, 1, -dot(v1, n), org + (p11 + p12) * 0.5f, n, g1, g2, cp);
       return;
     }
     dir = normalized(dir);
-    V3 p21 = support(g1, dir, 0), p22 = support(g2, -dir, 1), v2 = p21 - p22;
+    V3 p21 = support(g1, dir, org), p22 = support(g2, -dir, org), v2 = p21 - p22;
     if (dot(v2, dir) <= 0) return;
     dir = cross(v1 - v0, v2 - v0);
     if (dot(dir, v0) > 0) {
@@ -1602,7 +1606,7 @@ struct Sim {
       float len;
       dir = normalized(dir, &len);
       if (len < FMIN) return;
-      p31 = support(g1, dir, 0); p32 = support(g2, -dir, 1); v3_ = p31 - p32;
+      p31 = support(g1, dir, org); p32 = support(g2, -dir, org); v3_ = p31 - p32;
       if (dot(v3_, dir) <= 0) return;
       if (dot(cross(v1, v3_), v0) < -1e-14f) { v2 = v3_; p21 = p31; p22 = p32; dir = cross(v1 - v0, v3_ - v0); continue; }
       if (dot(cross(v3_, v2), v0) < -1e-14f) { v1 = v3_; p11 = p31; p12 = p32; dir = cross(v3_ - v0, v2 - v0); continue; }
@@ -1614,7 +1618,7 @@ struct Sim {
       dir = normalized(cross(v2 - v1, v3_ - v1), &len);
       if (len < FMIN) break;
       if (dot(dir, v1) >= 0) hit = true;
-      V3 p41 = support(g1, dir, 0), p42 = support(g2, -dir, 1), v4 = p41 - p42;
+      V3 p41 = support(g1, dir, org), p42 = support(g2, -dir, org), v4 = p41 - p42;
       float dv4 = dot(v4, dir);
       if (dv4 < 0 && !hit) return;
       float delta = dv4 - dot(v3_, dir);
@@ -1631,8 +1635,17 @@ struct Sim {
     V3 cpt = tri_closest_origin(v1, v2, v3_, bw);
     float depth = norm(cpt);
     V3 n = depth > 1e-12f ? cpt * (1.0f / depth) : dir;
+    // fp32: the closest point of the portal to the origin is a difference of nearly equal support points (rounding ~1e-7 m on metre-sized
+    // coordinates), so its DIRECTION is only good to 1e-7 / depth -- degrees for the micrometre penetrations of a resting contact.  When the
+    // point is interior to the portal triangle it is the foot of the perpendicular, i.e. the direction is the plane normal, which comes from
+    // centimetre-sized edges and is good to 1e-5 rad; same point, same depth in exact arithmetic (the fp64 oracle keeps the one formula).
+    if (bw.x > 0.f && bw.y > 0.f && bw.z > 0.f && norm(dir) > 0.5f) {
+      const float dn = dot(dir, v1);
+      n = dn >= 0.f ? dir : -dir;
+      depth = fabsf(dn);
+    }
     V3 w1 = p11 * bw.x + p21 * bw.y + p31 * bw.z, w2 = p12 * bw.x + p22 * bw.y + p32 * bw.z;
-    emit_contacts(lane == 0, 1, -depth, (w1 + w2) * 0.5f, n, g1, g2, cp);
+    emit_contacts(lane == 0, 1, -depth, org + (w1 + w2) * 0.5f, n, g1, g2, cp);
   }
 
   // oriented bounding box of colliding geom g: world centre o, half extents h along the columns of gmat

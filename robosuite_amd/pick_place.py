@@ -95,7 +95,7 @@ def episode_setup(cfg, nq: int, seed0: int, env_ids, block: int = 0):
 class PickPlaceBatch:
     """B PickPlace/IIWA+Robotiq140 environments on one GPU (64 x 64 kernel configuration).  `env_ids` are GLOBAL indices."""
 
-    def __init__(self, flat, cfg, env_ids, device: int = 0, seed0: int = 0, horizon: int = 0, bank_episodes: int = 0):
+    def __init__(self, flat, cfg, env_ids, device: int = 0, seed0: int = 0, horizon: int = 0, bank_episodes: int = 0, per_env_params: bool = False):
         from .backend import HipBatch, HipModel
 
         self.flat, self.cfg = flat, cfg
@@ -104,7 +104,7 @@ class PickPlaceBatch:
         self.model = HipModel(flat)
         self.model.set_controller(cfg)
         self.model.set_task(pick_place_task(flat, cfg))
-        self.batch = HipBatch(self.model, self.B, device, per_env_params=False)
+        self.batch = HipBatch(self.model, self.B, device, per_env_params=per_env_params)   # per-env float tables: dynamics randomisation
         self.seed0 = seed0
         self.reset()
         if horizon:
