@@ -68,6 +68,14 @@ typedef struct rsim_ctrl_desc {
                                        * (traj_utils.py:129-146: the error vectors are handled as Euler angles). */
   int32_t part_of[RSIM_JNT_MAX];      /* joint-space types: which part controller (arm) owns joint i; JOINT_POSITION multiplies by that part's own
                                        * mass-matrix block only (joint_pos.py:256-259 uses Controller.mass_matrix of the part) */
+  int32_t narm;                       /* OSC types: number of arm parts, 1 (0 is read as 1) or 2.  Two = one OperationalSpaceController object per arm, as
+                                       * CompositeController builds them for a bimanual robot (composite_controller.py:70-121, default_baxter.json): each
+                                       * arm runs its own torque law on its own mass-matrix block (Controller.mass_matrix of the part, controller.py:226-233),
+                                       * around its own "<arm>_center" origin site.  The second arm's joints / gains / action limits sit at entries
+                                       * [8, 8 + ndof2) of qpos_idx / dof_idx / act_idx and [8, 14) of kp / input_* / output_*; its slice of the action row follows
+                                       * the first arm's control_dim entries (and that arm's gripper entry).  damping_ratio, uncouple_pos_ori and nullspace_kp
+                                       * are shared.  Not combined with impedance modes or interpolators. */
+  int32_t ndof2, eef_site2, base_site2;
 } rsim_ctrl_desc;
 
 /* On-device observation / reward epilogue of the fused control step.

@@ -43,7 +43,8 @@ class CtrlDesc(C.Structure):
                 ("ngrip", C.c_int32), ("grip_act", C.c_int32 * 4), ("grip_sign", C.c_float * 4), ("grip_speed", C.c_float),
                 ("type", C.c_int32), ("torque_min", C.c_float * JNT_MAX), ("torque_max", C.c_float * JNT_MAX), ("impedance_mode", C.c_int32),
                 ("kp_min", C.c_float * JNT_MAX), ("kp_max", C.c_float * JNT_MAX), ("damping_min", C.c_float * JNT_MAX), ("damping_max", C.c_float * JNT_MAX),
-                ("interp_steps", C.c_int32), ("part_of", C.c_int32 * JNT_MAX)]
+                ("interp_steps", C.c_int32), ("part_of", C.c_int32 * JNT_MAX), ("narm", C.c_int32), ("ndof2", C.c_int32), ("eef_site2", C.c_int32),
+                ("base_site2", C.c_int32)]
 
 
 # arm part-controller types with an in-kernel implementation (include/rsim.h enum rsim_ctrl_type; names = the reference's config "type" strings)
@@ -84,8 +85,26 @@ DEFAULT_DYNAMICS_ARGS = dict(density_ratio=0.1, viscosity_ratio=0.1, position_si
                              friction_ratio=0.1, solref_ratio=0.1, solimp_ratio=0.1, frictionloss_size=0.05, damping_size=0.01, armature_size=0.01)
 
 
+def two_arm_osc_desc(cfg: dict) -> CtrlDesc:
+    """Two OSC arm parts (cfg["parts"], `robot.arms` order): the second arm's entries at offset 8 of the per-joint / per-axis arrays (include/rsim.h)."""
+    a, b = cfg["parts"]
+    d = ctrl_desc({**a, "part_of": [0] * len(a["qpos_idx"])})
+    d.narm, d.ndof2, d.eef_site2, d.base_site2 = 2, len(b["qpos_idx"]), b["eef_site"], b["base_site"]
+    if b.get("grip_act"):
+        raise RsimError("two OSC arm parts: a gripper is only supported on the first arm")
+    for i in range(d.ndof2):
+        d.qpos_idx[8 + i], d.dof_idx[8 + i], d.act_idx[8 + i] = b["qpos_idx"][i], b["dof_idx"][i], b["act_idx"][i]
+    for i in range(control_dim(b)):
+        d.input_min[8 + i], d.input_max[8 + i], d.output_min[8 + i], d.output_max[8 + i] = b["input_min"][i], b["input_max"][i], b["output_min"][i], b["output_max"][i]
+    for i, v in enumerate(b["kp"][:6]):
+        d.kp[8 + i] = v
+    return d
+
+
 def ctrl_desc(cfg: dict) -> CtrlDesc:
     """Build the C struct from the dict form used by tests/golden/*.cfg.json and robosuite_amd.env."""
+    if cfg.get("type", "OSC_POSE").startswith("OSC") and len(cfg.get("parts", [])) == 2 and all(p.get("type", "").startswith("OSC") for p in cfg["parts"]):
+        return two_arm_osc_desc(cfg)
     d = CtrlDesc()
     n = len(cfg["qpos_idx"])
     d.ndof = n
@@ -214,7 +233,7 @@ class HipModel:
         d = ctrl_desc(cfg)
         _chk(self._L.rsim_model_set_controller(self.ptr, C.byref(d)))
         self.ctrl_cfg = cfg
-        self.action_dim = control_dim(cfg) + gain_dim(cfg) + (1 if cfg.get("grip_act") else 0)
+        self.action_dim = self._L.rsim_model_int(self.ptr, b"action_dim")   # control_dim (x arm parts) + gain entries + gripper entry
         self.cstate_size = self._L.rsim_model_int(self.ptr, b"cstate_size")
 
     def set_task(self, task: dict):

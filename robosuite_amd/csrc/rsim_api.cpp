@@ -502,6 +502,21 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
   if (!jointspace && (d->eef_site < 0 || d->eef_site >= m->nsite || d->base_site < 0 || d->base_site >= m->nsite)) return fail("controller: bad site id");
   c.eef_site = jointspace ? 0 : d->eef_site; c.base_site = jointspace ? 0 : d->base_site;
   c.type = d->type;
+  c.narm = d->narm == 2 ? 2 : 1;
+  if (d->narm < 0 || d->narm > 2) return fail("controller: narm = %d (1 or 2 arm parts)", d->narm);
+  if (c.narm == 2) {
+    if (jointspace) return fail("controller: joint-space types concatenate the arms into one part (ndof <= 16, part_of[]), narm must be 1");
+    if (d->impedance_mode || d->interp_steps) return fail("controller: two OSC arm parts cannot be combined with variable impedance or an interpolator");
+    if (d->ndof2 < 1 || d->ndof2 > RSIM_ARM_MAX) return fail("controller: bad ndof2 (%d)", d->ndof2);
+    if (d->eef_site2 < 0 || d->eef_site2 >= m->nsite || d->base_site2 < 0 || d->base_site2 >= m->nsite) return fail("controller: bad site id (second arm)");
+    c.ndof2 = d->ndof2; c.eef_site2 = d->eef_site2; c.base_site2 = d->base_site2;
+    for (int i = 0; i < d->ndof2; i++) {
+      const int k = RSIM_ARM_MAX + i;
+      if (d->qpos_idx[k] < 0 || d->qpos_idx[k] >= m->nq || d->dof_idx[k] < 0 || d->dof_idx[k] >= m->nv || d->act_idx[k] < 0 || d->act_idx[k] >= m->nu)
+        return fail("controller: index out of range (second arm)");
+      c.qpos_idx[k] = d->qpos_idx[k]; c.dof_idx[k] = d->dof_idx[k]; c.act_idx[k] = d->act_idx[k];
+    }
+  }
   c.cs_size = d->type == RSIM_CTRL_JOINT_VELOCITY ? RSIM_CS_SIZE_JVEL : (jointspace ? RSIM_CS_SIZE_JOINT : RSIM_CS_SIZE);
   if (d->impedance_mode < 0 || d->impedance_mode > 2) return fail("controller: impedance_mode %d", d->impedance_mode);
   if (d->impedance_mode && (d->type == RSIM_CTRL_JOINT_TORQUE || d->type == RSIM_CTRL_JOINT_VELOCITY)) return fail("controller: this part type has no variable-impedance mode");
@@ -511,6 +526,7 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
   if (d->interp_steps < 0 || d->interp_steps > 1000) return fail("controller: interp_steps %d", d->interp_steps);
   c.interp_steps = d->interp_steps;
   if (c.interp_steps) c.cs_size = RSIM_CS_SIZE_INTERP;
+  if (c.narm == 2) c.cs_size = 2 * RSIM_CS_SIZE;   // one OSC state block per arm
   for (int i = 0; i < c.nimp; i++) {
     if (!(d->kp_max[i] >= d->kp_min[i]) || !(d->kp_min[i] >= 0.f) || !(d->damping_max[i] >= d->damping_min[i])) return fail("controller: bad kp / damping_ratio limits");
     c.kp_min[i] = d->kp_min[i]; c.kp_max[i] = d->kp_max[i]; c.dr_min[i] = d->damping_min[i]; c.dr_max[i] = d->damping_max[i];
@@ -528,6 +544,18 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
   for (int i = 0; i < c.cdim; i++) {
     if (!(d->input_max[i] > d->input_min[i])) return fail("controller: input_max <= input_min");
     c.in_min[i] = d->input_min[i]; c.in_max[i] = d->input_max[i]; c.out_min[i] = d->output_min[i]; c.out_max[i] = d->output_max[i];
+  }
+  if (c.narm == 2) {
+    for (int i = 0; i < 6; i++) {
+      const int k = RSIM_ARM_MAX + i;
+      if (!(d->kp[k] >= 0.f)) return fail("controller: negative / NaN kp (second arm)");
+      c.kp[k] = d->kp[k]; c.kd[k] = 2.f * sqrtf(d->kp[k]) * d->damping_ratio;
+    }
+    for (int i = 0; i < c.cdim; i++) {
+      const int k = RSIM_ARM_MAX + i;
+      if (!(d->input_max[k] > d->input_min[k])) return fail("controller: input_max <= input_min (second arm)");
+      c.in_min[k] = d->input_min[k]; c.in_max[k] = d->input_max[k]; c.out_min[k] = d->output_min[k]; c.out_max[k] = d->output_max[k];
+    }
   }
   {
     bool given = false;   // torque_limits=None -> actuator ctrlrange (joint_tor.py:95-96, controller.py:313-322)
@@ -549,7 +577,7 @@ extern "C" int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* d)
     c.grip_act[i] = d->grip_act[i]; c.grip_sign[i] = d->grip_sign[i];
   }
   c.grip_speed = d->grip_speed;
-  c.action_dim = c.cdim + c.nimp * (c.imp_mode == 1 ? 2 : 1) + (d->ngrip > 0 ? 1 : 0);
+  c.action_dim = c.cdim * c.narm + c.nimp * (c.imp_mode == 1 ? 2 : 1) + (d->ngrip > 0 ? 1 : 0);
   return 0;
 }
 
@@ -609,7 +637,7 @@ static int pick_config(const rsim_model* m, int* lim_out) {
     k_limits[c](lim);
     const bool tendons = m->ntendon > 0 || m->neq > 0;
     if (!(m->nbody > lim[0] || m->njnt > lim[1] || m->nv > lim[2] || m->nq > lim[2] + 8 || m->nu > 16 || ncg > lim[3] || m->nsite > lim[4] || m->npair > lim[7] ||
-          m->ndynroot > lim[8] || (tendons && !lim[9]))) {
+          m->ndynroot > lim[8] || (tendons && !(lim[9] & 1)) || (m->ctrl.enabled && m->ctrl.narm == 2 && !(lim[9] & 2)))) {
       if (lim_out) memcpy(lim_out, lim, sizeof(lim));
       return c;
     }

@@ -63,6 +63,7 @@ struct DCtrl {
   int ndof;
   int qpos_idx[RSIM_JNT_MAX], dof_idx[RSIM_JNT_MAX], act_idx[RSIM_JNT_MAX];
   int eef_site, base_site;
+  int narm, ndof2, eef_site2, base_site2;   // OSC types: a second arm part (its joints / gains / limits sit at offset RSIM_ARM_MAX of the 16-entry arrays, its state at RSIM_CS_SIZE)
   float kp[RSIM_JNT_MAX], kd[RSIM_JNT_MAX], in_min[RSIM_JNT_MAX], in_max[RSIM_JNT_MAX], out_min[RSIM_JNT_MAX], out_max[RSIM_JNT_MAX];
   float tl_lo[RSIM_JNT_MAX], tl_hi[RSIM_JNT_MAX];
   int part_of[RSIM_JNT_MAX];

@@ -742,6 +742,7 @@ struct Sim {
   static constexpr int NSLOT = SM::NEFC_ / 64;  // constraint rows per lane (row r lives in lane r & 63, slot r >> 6)
   static constexpr int NEFCAP = SM::NEFC_;
   static constexpr bool TENDONS = SM::TENDONS_;
+  static constexpr bool TWO_ARMS = SM::NB_ > 32;   // a second OSC arm part is compiled into the 64-body configurations only (bimanual robots need them anyway)
   typedef typename SM::dmask_t dmask_t;
   __device__ __forceinline__ dmask_t dmask_load(int tab, int i) const {   // dof bit mask i of an int-table entry stored as two 32-bit words
     if constexpr (sizeof(dmask_t) == 8) return mask2(tab, i); else return (dmask_t)(unsigned)IT(tab, 2 * i);
@@ -779,7 +780,8 @@ struct Sim {
   template <bool STORE, u64 MK = 0> __device__ __forceinline__ void kio(Q4& x, int idx, int stride) const { kio<STORE, MK>(x.w, idx); kio<STORE, MK>(x.x, idx + stride); kio<STORE, MK>(x.y, idx + 2 * stride); kio<STORE, MK>(x.z, idx + 3 * stride); }
   // STORE: called once by load_constants (lanes outside a role's width skip it); fetch: every lane reads its (wrapped) column and the
   // compiler drops the rows a phase does not use
-  template <bool STORE> __device__ __forceinline__ void kxfer(LaneConst& K) const {
+  // ARM: which arm part's controller columns a fetch reads (OSC types: arm a keeps its joints in columns 8a .. 8a + 7 and reads them into lanes 0 .. 7)
+  template <bool STORE, int ARM = 0> __device__ __forceinline__ void kxfer(LaneConst& K) const {
     int o = 0;
     {  // body role, NB columns
       const int l = lane & (SM_NB - 1), W = SM_NB;
@@ -819,8 +821,8 @@ struct Sim {
       }
       o += 10 * W;
     }
-    {  // controller role, 16 columns (joint-space parts drive up to 16 joints; the OSC types use the first 8)
-      const int l = lane & 15, W = 16;
+    {  // controller role, 16 columns (joint-space parts drive up to 16 joints; the OSC types use 8 per arm)
+      const int l = ARM ? (lane & 7) + 8 * ARM : (lane & 15), W = 16;
       if (!STORE || lane < W) { kio<STORE>(K.cq, o + l); kio<STORE>(K.cd, o + W + l); kio<STORE>(K.ca, o + 2 * W + l); kio<STORE>(K.cga, o + 3 * W + l); kio<STORE>(K.cgs, o + 4 * W + l); }
       o += 5 * W;
     }
@@ -828,7 +830,7 @@ struct Sim {
     for (int t = 0; t < NPT; t++) kio<STORE>(K.pair[t], o + 64 * t + lane);
     kio<STORE>(K.mfbits, o + 64 * NPT + lane);
   }
-  __device__ __forceinline__ LaneConst fetchK() const { LaneConst K; kxfer<false>(K); return K; }
+  template <int ARM = 0> __device__ __forceinline__ LaneConst fetchK() const { LaneConst K; kxfer<false, ARM>(K); return K; }
 
   // ---------------------------------------------------------------- once per launch: the few uniform options, LDS padding, resident hulls
   __device__ __forceinline__ void load_opt() {
@@ -2152,17 +2154,29 @@ struct Sim {
       cst_sync();
       return;
     }
+    ctrl_set_goal_osc<0>(K, action);
+    // a second arm part (Baxter's default: one OSC object per arm, composite_controller.py:97-116): its slice of the action follows the first
+    // arm's (and that arm's gripper entry)
+    if constexpr (TWO_ARMS) { if (c.narm == 2) ctrl_set_goal_osc<1>(fetchK<1>(), action + c.cdim + (c.ngrip > 0 ? 1 : 0)); }
+  }
+  // OSC set_goal of arm ARM (osc.py:225-300).  The arm index is a template constant: every access to the by-value controller description
+  // keeps a compile-time index (a run-time arm index would put a copy of DModel into the private segment)
+  template <int ARM>
+  __device__ __forceinline__ void ctrl_set_goal_osc(const LaneConst& K, const float* action) {
+    const DCtrl& c = m.ctrl;
+    constexpr int AO = RSIM_ARM_MAX * ARM, CO = RSIM_CS_SIZE * ARM;
+    const int eef_site = ARM ? c.eef_site2 : c.eef_site, base_site = ARM ? c.base_site2 : c.base_site;
     float sc[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {   // OSC_POSITION (cdim 3): zero orientation delta, osc.py:255-263
       if (i < c.cdim) {
-        float scale = fabsf(c.out_max[i] - c.out_min[i]) / fabsf(c.in_max[i] - c.in_min[i]);
-        float a = fmaxf(c.in_min[i], fminf(c.in_max[i], action[i]));
-        sc[i] = (a - 0.5f * (c.in_max[i] + c.in_min[i])) * scale + 0.5f * (c.out_max[i] + c.out_min[i]);
+        float scale = fabsf(c.out_max[AO + i] - c.out_min[AO + i]) / fabsf(c.in_max[AO + i] - c.in_min[AO + i]);
+        float a = fmaxf(c.in_min[AO + i], fminf(c.in_max[AO + i], action[i]));
+        sc[i] = (a - 0.5f * (c.in_max[AO + i] + c.in_min[AO + i])) * scale + 0.5f * (c.out_max[AO + i] + c.out_min[AO + i]);
       } else sc[i] = 0.f;
     }
-    V3 op = ld3(sm.spos + 3 * c.base_site), ep = ld3(sm.spos + 3 * c.eef_site);
-    M3 oR = ldm(sm.smat + 9 * c.base_site), eR = ldm(sm.smat + 9 * c.eef_site);
+    V3 op = ld3(sm.spos + 3 * base_site), ep = ld3(sm.spos + 3 * eef_site);
+    M3 oR = ldm(sm.smat + 9 * base_site), eR = ldm(sm.smat + 9 * eef_site);
     V3 gp = mtv(oR, ep - op) + v3(sc[0], sc[1], sc[2]);
     V3 d = v3(sc[3], sc[4], sc[5]);
     float ang = norm(d);
@@ -2179,16 +2193,16 @@ struct Sim {
     SYNC();
     if (lane == 0) {
       if (c.interp_steps) {
-        st3(cst + RSIM_CS_ISTART, ld3(sm.cstate + RSIM_CS_GOALPOS)); cst[RSIM_CS_ISTEP] = 0.f;
+        st3(cst + RSIM_CS_ISTART, ld3(sm.cstate + CO + RSIM_CS_GOALPOS)); cst[RSIM_CS_ISTEP] = 0.f;
         if (c.type == RSIM_CTRL_OSC_POSE) {   // osc.py:277-283: ori_ref = current eef orientation, goal = error of the (base-frame) goal_ori against it
           st3(cst + RSIM_CS_ISTART_ORI, ld3(cst + RSIM_CS_IGOAL_ORI));
           st3(cst + RSIM_CS_IGOAL_ORI, (cross(col(eR, 0), col(go, 0)) + cross(col(eR, 1), col(go, 1)) + cross(col(eR, 2), col(go, 2))) * 0.5f);
         }
       }
-      st3(sm.cstate + RSIM_CS_GOALPOS, gp);
-      stm(sm.cstate + RSIM_CS_GOALORI, go);
+      st3(sm.cstate + CO + RSIM_CS_GOALPOS, gp);
+      stm(sm.cstate + CO + RSIM_CS_GOALORI, go);
     }
-    if (lane < c.ngrip) {
+    if (ARM == 0 && lane < c.ngrip) {
       const float a = action[c.cdim], sg = a > 0 ? 1.f : (a < 0 ? -1.f : 0.f);
       sm.cstate[RSIM_CS_GRIP + lane] = fmaxf(-1.f, fminf(1.f, sm.cstate[RSIM_CS_GRIP + lane] + K.cgs * c.grip_speed * sg));
     }
@@ -2201,6 +2215,14 @@ struct Sim {
     const LaneConst K = fetchK();
     const DCtrl& c = m.ctrl;
     if (c.type < RSIM_CTRL_JOINT_POSITION && lane < c.ndof) sm.cstate[RSIM_CS_Q0 + lane] = sm.qpos[K.cq];
+    if (TWO_ARMS && c.type < RSIM_CTRL_JOINT_POSITION && c.narm == 2) {   // second arm part: its own initial_joint / goal block
+      const LaneConst K1 = fetchK<1>();
+      if (lane < c.ndof2) sm.cstate[RSIM_CS_SIZE + RSIM_CS_Q0 + lane] = sm.qpos[K1.cq];
+      if (lane == 0) {
+        st3(sm.cstate + RSIM_CS_SIZE + RSIM_CS_GOALPOS, ld3(sm.spos + 3 * c.eef_site2));
+        for (int k = 0; k < 9; k++) sm.cstate[RSIM_CS_SIZE + RSIM_CS_GOALORI + k] = sm.smat[9 * c.eef_site2 + k];
+      }
+    }
     if (c.imp_mode) {   // the constructor's gains stay in force until the first set_goal
       const int li = lane & (RSIM_JNT_MAX - 1);
       const float kp0 = sel(c.kp, li), kd0 = sel(c.kd, li);
@@ -2224,15 +2246,16 @@ struct Sim {
   // Lambda^-1 = J Ma^-1 J^T = Y^T Y with Y = La^-1 J^T (register Cholesky of the arm block, 6 forward solves);
   // N^T Ma tmp = Ma tmp - J^T Lambda (J tmp), so no explicit inverse of Ma is ever formed.
   // arm torques -> clipped ctrl (fixed_base_robot.py:143-153) + SimpleGripController output (simple_grip.py:150-186)
+  template <int ARM = 0>
   __device__ __forceinline__ void ctrl_write(const LaneConst& K, float tq) {
     const DCtrl& c = m.ctrl;
     const float alo = __shfl(K.acr0, K.ca), ahi = __shfl(K.acr1, K.ca);
-    if (lane < c.ndof) {
-      sm.cstate[(c.type >= RSIM_CTRL_JOINT_POSITION ? RSIM_CS_TAU_JOINT : RSIM_CS_TAU) + lane] = tq;
+    if (lane < (ARM ? c.ndof2 : c.ndof)) {
+      sm.cstate[RSIM_CS_SIZE * ARM + (c.type >= RSIM_CTRL_JOINT_POSITION ? RSIM_CS_TAU_JOINT : RSIM_CS_TAU) + lane] = tq;
       sm.ctrl[K.ca] = fmaxf(alo, fminf(ahi, tq));
     }
     const float glo = __shfl(K.acr0, K.cga), ghi = __shfl(K.acr1, K.cga);
-    if (lane < c.ngrip) sm.ctrl[K.cga] = fmaxf(glo, fminf(ghi, 0.5f * (ghi + glo) + 0.5f * (ghi - glo) * sm.cstate[RSIM_CS_GRIP + lane]));
+    if (ARM == 0 && lane < c.ngrip) sm.ctrl[K.cga] = fmaxf(glo, fminf(ghi, 0.5f * (ghi + glo) + 0.5f * (ghi - glo) * sm.cstate[RSIM_CS_GRIP + lane]));
     SYNC();
     cst_sync();
   }
@@ -2296,19 +2319,27 @@ struct Sim {
   }
 
   __device__ __forceinline__ void ctrl_run() {
-    const LaneConst K = fetchK();
     const DCtrl& c = m.ctrl;
-    if (c.type >= RSIM_CTRL_JOINT_POSITION) { ctrl_run_joint(K); return; }
-    const int n = c.ndof;
+    if (c.type >= RSIM_CTRL_JOINT_POSITION) { ctrl_run_joint(fetchK()); return; }
+    ctrl_run_osc<0>();
+    if constexpr (TWO_ARMS) { if (c.narm == 2) { phase(); ctrl_run_osc<1>(); } }   // one OSC object per arm (composite_controller.py:97-116), each on its own mass-matrix block
+  }
+  template <int ARM>
+  __device__ __forceinline__ void ctrl_run_osc() {
+    const LaneConst K = fetchK<ARM>();
+    const DCtrl& c = m.ctrl;
+    constexpr int AO = RSIM_ARM_MAX * ARM, CO = RSIM_CS_SIZE * ARM;
+    const int n = ARM ? c.ndof2 : c.ndof;
+    const int eef_site = ARM ? c.eef_site2 : c.eef_site, base_site = ARM ? c.base_site2 : c.base_site;
     constexpr int NA = RSIM_ARM_MAX;
     float* Li = sm.u.k.Li;             // [6][6]   Lambda^-1
     float* vv = sm.u.k.vv;             // 6: J tmp
-    const int eb = __shfl(K.sbody, c.eef_site), bb = __shfl(K.sbody, c.base_site);
-    const V3 ep = ld3(sm.spos + 3 * c.eef_site), op = ld3(sm.spos + 3 * c.base_site);
+    const int eb = __shfl(K.sbody, eef_site), bb = __shfl(K.sbody, base_site);
+    const V3 ep = ld3(sm.spos + 3 * eef_site), op = ld3(sm.spos + 3 * base_site);
     // this lane's arm dof (lanes 0..n-1) and its joint-space quantities
     const int di = lane < n ? K.cd : 0, qi = lane < n ? K.cq : 0;
     const float qd_i = lane < n ? sm.qvel[di] : 0.f;
-    const float tmp_i = lane < n ? c.nullspace_kp * (sm.cstate[RSIM_CS_Q0 + lane] - sm.qpos[qi]) - 2.f * sqrtf(c.nullspace_kp) * qd_i : 0.f;
+    const float tmp_i = lane < n ? c.nullspace_kp * (sm.cstate[CO + RSIM_CS_Q0 + lane] - sm.qpos[qi]) - 2.f * sqrtf(c.nullspace_kp) * qd_i : 0.f;
     // Jacobian column of the eef site for this lane's dof
     S6 jc = {v3(0, 0, 0), v3(0, 0, 0)};
     if (lane < n) jc = jac_col(eb, ep, di);
@@ -2318,7 +2349,7 @@ struct Sim {
     {
       int dk[NA];
 #pragma unroll
-      for (int k = 0; k < NA; k++) dk[k] = k < n ? c.dof_idx[k] : 0;
+      for (int k = 0; k < NA; k++) dk[k] = k < n ? c.dof_idx[AO + k] : 0;
 #pragma unroll
       for (int k = 0; k < NA; k++) { const float v = sm.M[di * NVP + dk[k]]; mr[k] = (lane < n && k < n) ? v : (row8 == k ? 1.f : 0.f); }   // di = 0 on padding lanes
     }
@@ -2362,9 +2393,9 @@ struct Sim {
     SYNC();
     SUBMARK(RP_X8);
     // operational-space errors and wrench (uniform small algebra)
-    const M3 oR = ldm(sm.smat + 9 * c.base_site), eR = ldm(sm.smat + 9 * c.eef_site);
-    const V3 gpos = ld3(sm.cstate + RSIM_CS_GOALPOS);
-    const M3 gori = ldm(sm.cstate + RSIM_CS_GOALORI);
+    const M3 oR = ldm(sm.smat + 9 * base_site), eR = ldm(sm.smat + 9 * eef_site);
+    const V3 gpos = ld3(sm.cstate + CO + RSIM_CS_GOALPOS);
+    const M3 gori = ldm(sm.cstate + CO + RSIM_CS_GOALORI);
     V3 perr = op + mv(oR, gpos) - ep;
     const float istep = c.interp_steps ? cst[RSIM_CS_ISTEP] : 0.f;
     if (c.interp_steps) {
@@ -2385,7 +2416,7 @@ struct Sim {
     const V3 dvl = evl - bvl, dva = ce.a - cb.a;
     float kp6[6], kd6[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) { kp6[i] = c.imp_mode ? cst[RSIM_CS_KP + i] : c.kp[i]; kd6[i] = c.imp_mode ? cst[RSIM_CS_KD + i] : c.kd[i]; }
+    for (int i = 0; i < 6; i++) { kp6[i] = c.imp_mode ? cst[RSIM_CS_KP + i] : c.kp[AO + i]; kd6[i] = c.imp_mode ? cst[RSIM_CS_KD + i] : c.kd[AO + i]; }
     float F[3] = {perr.x * kp6[0] - dvl.x * kd6[0], perr.y * kp6[1] - dvl.y * kd6[1], perr.z * kp6[2] - dvl.z * kd6[2]};
     float T[3] = {oerr.x * kp6[3] - dva.x * kd6[3], oerr.y * kp6[4] - dva.y * kd6[4], oerr.z * kp6[5] - dva.z * kd6[5]};
     float wrench[6], z[6];
@@ -2430,7 +2461,7 @@ struct Sim {
 #pragma unroll
       for (int r = 0; r < 6; r++) tq = fmaf(comp6(jc, r < 3 ? r + 3 : r - 3), wrench[r] - z[r], tq);
     }
-    ctrl_write(K, tq);
+    ctrl_write<ARM>(K, tq);
   }
 
   // ---------------------------------------------------------------- Newton solver (primal): lane r owns constraint row r
@@ -3387,6 +3418,6 @@ extern "C" int RSIM_SYM(rsim_cmem_bytes)(void) { return (int)((sizeof(Cmem0) + 2
 extern "C" int RSIM_SYM(rsim_limits)(int* lim) {
   const int dims[8] = {RSIM_DIMS};
   for (int i = 0; i < 8; i++) lim[i] = dims[i];
-  lim[8] = Smem0::NROOT_; lim[9] = Smem0::TENDONS_ ? 1 : 0;
+  lim[8] = Smem0::NROOT_; lim[9] = (Smem0::TENDONS_ ? 1 : 0) | (Smem0::NB_ > 32 ? 2 : 0);   // bit 1: two OSC arm parts
   return 0;
 }

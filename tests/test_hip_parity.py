@@ -828,3 +828,31 @@ def test_grasp_and_lift_replay_matches_oracle_and_sets_success():
     assert succ[-1] == 1 and abs(rewards[-1] - 1.0) < 1e-6       # success => 2.25 * reward_scale / 2.25
     assert any(abs(r - (1 - np.tanh(0)) / 2.25) < 0.2 and r > 1.0 / 2.25 for r in rewards)   # reaching (~1) + grasp bonus 0.25 seen before lift-off
     assert np.isfinite(hb.get("qvel")).all()
+
+
+def test_baxter_two_osc_arm_parts_track_the_reference_loop():
+    """Baxter's default controller (default_baxter.json): one OperationalSpaceController per arm, each on its own mass-matrix block and its own
+    "<arm>_center" origin (composite_controller.py:70-121, osc.py:403-495).  Both arm parts run inside the fused kernel (arm index = template
+    constant); checked against the fixture recorded from the reference's own classes and against the oracle loop with two controller objects,
+    at the tolerances of the single-arm OSC test."""
+    from oracle.oracle import env_step_parts
+    from tests.util import make_oracle_parts
+    g, cfg, flat = load_golden("ctl_osc_pose", "peg_baxter")
+    nq = flat.nq
+    om, od, parts = make_oracle_parts(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=3)
+    assert hm.action_dim == 12 and hb.get("cstate").shape == (3, 64)
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0; od.forward()
+    for c, _ in parts:
+        c.reset(od)
+    hb.set("qpos", s0[1:1 + nq][None].repeat(3, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(3, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    for t in range(len(g["actions"])):
+        hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 3, 0), dtype=torch.float32, device="cuda"), 25)
+        env_step_parts(od, parts, g["actions"][t], 25)
+        hq, hv = hb.get("qpos")[0], hb.get("qvel")[0]
+        assert np.abs(hq - od.qpos).max() < 5e-4 and np.abs(hv - od.qvel).max() < 5e-3, t
+        assert np.abs(hq - g["states"][t + 1][1:1 + nq]).max() < 5e-4 and np.abs(hv - g["states"][t + 1][1 + nq:]).max() < 5e-3, t
+        assert np.abs(hb.get("ctrl")[0] - g["ctrl"][t]).max() < 2e-3 * max(1.0, np.abs(g["ctrl"][t]).max()), t
+    assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[2])

@@ -76,8 +76,8 @@ def test_other_part_controllers_match_reference_loop(tag):
 
 
 @pytest.mark.parametrize("tag", ("ctl_joint_position", "ctl_joint_torque", "ctl_joint_velocity",
-                                 # Baxter's default: one OSC_POSE object per arm, each around its own "<arm>_center" site (oracle only so far: the kernel's
-                                 # OSC path drives one arm)
+                                 # Baxter's default: one OSC_POSE object per arm, each around its own "<arm>_center" site (the kernel runs both arm
+                                 # parts too: tests/test_hip_parity.py::test_baxter_two_osc_arm_parts_track_the_reference_loop)
                                  "ctl_osc_pose"))
 def test_two_arm_joint_space_controllers_match_reference_loop(tag):
     """TwoArmPegInHole / Baxter (BASELINE configs[3] model), one part controller per arm (composite_controller.py:70-121): the oracle loop
