@@ -165,7 +165,7 @@ enum rsim_field {
   RSIM_SUCCESS,        /* [B] int32    _check_success() after the last control step          */
   RSIM_DONE,           /* [B] int32    timestep >= horizon after the last control step (base.py:532-548) */
   RSIM_EP_STEP,        /* [B] int32    MujocoEnv.timestep of the running episode            */
-  RSIM_EP_INDEX,       /* [B] int32    which entry of the reset bank the running episode came from */
+  RSIM_EP_INDEX,       /* [B] int32    number of the running episode (0, 1, 2, ...; its reset came from bank slot number % n_episodes) */
   RSIM_DIVERGED,       /* [B] int32    how often the env hit MuJoCo's bad-state guard: after a substep that leaves a non-finite or > 1e10 qpos / qvel
                         *               entry the env is put back to qpos0 with zero velocity, control and time, as mj_checkPos / mj_checkVel +
                         *               mj_resetData do [3P]; robosuite never reads the corresponding mjData warning, this counter makes it visible */
@@ -173,6 +173,11 @@ enum rsim_field {
                         *               compiled capacity (rsim_batch_limits: 16 contacts / 64 rows in the Lift configuration, 128 rows in the largest).
                         *               MuJoCo's nconmax = 5000 (models/assets/base.xml:5) never truncates; a non-zero count marks results that can differ
                         *               from the reference for that reason */
+  RSIM_BANK_STALE,     /* [B] int32    on-device resets that found a reset-bank slot the host had not refilled in time (the stale entry was used):
+                        *               0 as long as rsim_refill_reset_bank keeps up, i.e. no reset is ever replayed */
+  RSIM_TERMINAL_OBS,   /* [B,nobs]     observation record of the control step that ENDED an env's episode (valid where RSIM_DONE was reported); with a reset
+                        *               bank installed RSIM_OBS of such an env already holds the observation MujocoEnv.reset() returns for its next
+                        *               episode (gym auto-reset convention), the reward / success flags stay those of the terminal step */
   RSIM_FIELD_COUNT
 };
 
@@ -225,11 +230,18 @@ int rsim_observe(rsim_batch* b);
  * RSIM_DONE when it reaches `horizon` (0 = never).  With a reset bank installed, a finished env is re-initialised ON THE DEVICE at the
  * end of that same launch: qpos := bank entry, qvel/ctrl/warm start/time := 0, the listed float-table entries (per-episode model edits
  * such as the Lift cube size, lift.py:311-318) are patched, and the controller is re-created at the start of the next launch
- * (robots/robot.py:271).  The bank holds `n_episodes` pre-drawn resets per env (drawn by the host in the reference's RNG order);
- * entries are used cyclically.  bank: HOST float32 [B, n_episodes, nq + n_patch]; patch_idx: HOST int32 [n_patch] offsets into the
- * env's float table (rsim_param_offset).  Requires per_env_params when n_patch > 0. */
+ * (robots/robot.py:271).  The same call then produces the observation MujocoEnv.reset() returns (forward + observables on the reset state)
+ * in RSIM_OBS and keeps the finished episode's last record in RSIM_TERMINAL_OBS.
+ * The bank is a RING of `n_episodes` (>= 2) slots per env: episode k of an env is read from slot k % n_episodes (RSIM_EP_INDEX counts
+ * episodes for ever).  rsim_set_reset_bank fills slots with episodes 0 .. n_episodes-1 (drawn by the host in the reference's RNG order);
+ * rsim_refill_reset_bank overwrites consumed slots with later episodes, so that every reset of every env is a fresh draw, as the
+ * reference's hard reset is (base.py:277-347).  A reset that finds a slot not holding its episode is counted in RSIM_BANK_STALE.
+ * bank: HOST float32 [B, n_episodes, nq + n_patch]; patch_idx: HOST int32 [n_patch] offsets into the env's float table
+ * (rsim_param_offset).  Requires per_env_params when n_patch > 0.
+ * rsim_refill_reset_bank: rows[i] (HOST float32 [n, nq + n_patch]) = reset `episode[i]` of env `env[i]`. */
 int rsim_set_episode(rsim_batch* b, int horizon);
 int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, const int32_t* patch_idx, const float* bank);
+int rsim_refill_reset_bank(rsim_batch* b, int n, const int32_t* env, const int32_t* episode, const float* rows);
 /* offset of element `elem` of model float array `field` ("geom_size", "body_mass", ...) inside an env's float table, -1 if unknown */
 int rsim_param_offset(const rsim_batch* b, const char* field, int elem);
 

@@ -19,9 +19,9 @@ _LIB = None
 # enum rsim_field (include/rsim.h)
 FIELDS = ["qpos", "qvel", "qacc_warmstart", "ctrl", "time", "cstate", "xpos", "xquat", "qM", "qfrc_bias", "qfrc_passive", "qfrc_actuator",
           "qfrc_constraint", "qacc", "cdof", "rootcom", "contact", "efc_force", "ncon", "nefc", "niter", "obs", "reward", "success", "done", "ep_step",
-          "ep_index", "diverged", "overflow"]
+          "ep_index", "diverged", "overflow", "bank_stale", "terminal_obs"]
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
-INT_FIELDS = {"ncon", "nefc", "niter", "success", "done", "ep_step", "ep_index", "diverged", "overflow"}
+INT_FIELDS = {"ncon", "nefc", "niter", "success", "done", "ep_step", "ep_index", "diverged", "overflow", "bank_stale"}
 CON_REC = 24
 CSTATE = 32
 OBS_MAX = 128
@@ -177,6 +177,7 @@ def lib():
         L.rsim_randomize_dynamics.argtypes = [vp, C.POINTER(DrDesc), C.c_uint64, C.c_uint64]
         L.rsim_set_episode.argtypes = [vp, C.c_int]
         L.rsim_set_reset_bank.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+        L.rsim_refill_reset_bank.argtypes = [vp, C.c_int, vp, vp, vp]
         L.rsim_param_offset.argtypes = [vp, C.c_char_p, C.c_int]
         for f in ("rsim_forward", "rsim_step1", "rsim_step2", "rsim_step", "rsim_sync", "rsim_observe"):
             getattr(L, f).argtypes = [vp]
@@ -310,7 +311,7 @@ class HipBatch:
                        "xpos": (B, nb, 3), "xquat": (B, nb, 4), "qM": (B, nv, nv), "qfrc_bias": (B, nv), "qfrc_passive": (B, nv),
                        "qfrc_actuator": (B, nv), "qfrc_constraint": (B, nv), "qacc": (B, nv), "cdof": (B, nv, 6), "rootcom": (B, nb, 3),
                        "contact": (B, self.maxcon, CON_REC), "efc_force": (B, self.maxefc), "ncon": (B,), "nefc": (B,), "niter": (B,),
-                       "obs": (B, model.nobs), "reward": (B,), "success": (B,), "done": (B,), "ep_step": (B,), "ep_index": (B,), "diverged": (B,), "overflow": (B,)}
+                       "obs": (B, model.nobs), "reward": (B,), "success": (B,), "done": (B,), "ep_step": (B,), "ep_index": (B,), "diverged": (B,), "overflow": (B,), "bank_stale": (B,), "terminal_obs": (B, model.nobs)}
 
     # ---- state access (host copies) --------------------------------------------------------
     def get(self, name):
@@ -386,6 +387,14 @@ class HipBatch:
         bank = q if len(idx) == 0 else np.concatenate([q, np.asarray(patch_val, dtype=np.float32).reshape(B, E, len(idx))], axis=2)
         bank = np.ascontiguousarray(bank, dtype=np.float32)
         _chk(self._L.rsim_set_reset_bank(self.ptr, E, len(idx), idx.ctypes.data if len(idx) else None, bank.ctypes.data))
+
+    def refill_reset_bank(self, env, episode, qpos, patch_val=None):
+        """Overwrite ring slots: reset `episode[i]` of env `env[i]` := qpos[i] (+ patch_val[i]); see include/rsim.h rsim_refill_reset_bank."""
+        env = np.ascontiguousarray(env, dtype=np.int32); episode = np.ascontiguousarray(episode, dtype=np.int32)
+        q = np.asarray(qpos, dtype=np.float32).reshape(len(env), -1)
+        rows = q if patch_val is None or np.size(patch_val) == 0 else np.concatenate([q, np.asarray(patch_val, dtype=np.float32).reshape(len(env), -1)], axis=1)
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        _chk(self._L.rsim_refill_reset_bank(self.ptr, len(env), env.ctypes.data, episode.ctypes.data, rows.ctypes.data))
 
     def ctrl_reset(self, mask=None):
         _chk(self._L.rsim_ctrl_reset(self.ptr, None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).tobytes()))

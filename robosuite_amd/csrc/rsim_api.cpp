@@ -48,6 +48,7 @@ static const cmem_fn k_cmem_bytes[RSIM_NCFG] = {rsim_cmem_bytes_cfg0, rsim_cmem_
 static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1, rsim_limits_cfg2, rsim_limits_cfg3};
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream);
 extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStream_t stream);
+extern "C" int rsim_launch_bank_scatter(float* bank, int* tag, const int* env, const int* episode, const float* rows, int n, int E, int W, hipStream_t stream);
 extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr* d, unsigned long long seed, unsigned long long step, hipStream_t stream);
 
 struct rsim_model;
@@ -104,6 +105,7 @@ struct rsim_batch {
   int* d_lt;
   int* d_obsprog;
   float* d_bank;
+  int* d_bank_tag;
   int* d_patch;
   float* d_ft_base;
   float* d_ft;
@@ -657,7 +659,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   b->m = m; b->B = B; b->device = device; b->per_env = per_env ? 1 : 0;
   b->gen = 1; b->cache_gen = 0; b->cache_env = -1;
   b->db.prof_env = -1;
-  b->d_bank = nullptr; b->d_patch = nullptr; b->d_ft_base = nullptr;
+  b->d_bank = nullptr; b->d_bank_tag = nullptr; b->d_patch = nullptr; b->d_ft_base = nullptr;
   const int ncg = (int)m->cg.size();
   b->cfg = pick_config(m, b->lim);
   if (b->cfg < 0) {
@@ -743,7 +745,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
       {RSIM_NCON, (void**)&db.ncon, (size_t)B, 1}, {RSIM_NEFC, (void**)&db.nefc, (size_t)B, 1}, {RSIM_NITER, (void**)&db.niter, (size_t)B, 1},
       {RSIM_OBS, (void**)&db.obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0}, {RSIM_REWARD, (void**)&db.reward, (size_t)B, 0},
       {RSIM_SUCCESS, (void**)&db.success, (size_t)B, 1}, {RSIM_DONE, (void**)&db.done, (size_t)B, 1}, {RSIM_EP_STEP, (void**)&db.ep_step, (size_t)B, 1},
-      {RSIM_EP_INDEX, (void**)&db.ep_index, (size_t)B, 1}, {RSIM_DIVERGED, (void**)&db.diverged, (size_t)B, 1}, {RSIM_OVERFLOW, (void**)&db.overflow, (size_t)B, 1}};
+      {RSIM_EP_INDEX, (void**)&db.ep_index, (size_t)B, 1}, {RSIM_DIVERGED, (void**)&db.diverged, (size_t)B, 1}, {RSIM_OVERFLOW, (void**)&db.overflow, (size_t)B, 1},
+      {RSIM_BANK_STALE, (void**)&db.bank_stale, (size_t)B, 1}, {RSIM_TERMINAL_OBS, (void**)&db.term_obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0}};
   for (auto& fd : fields) {
     if (dalloc((float**)fd.p, fd.n)) return 1;
     b->fptr[fd.id] = *fd.p; b->fcount[fd.id] = fd.n; b->fis_int[fd.id] = fd.is_int;
@@ -759,7 +762,7 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
   hipFree(b->d_cm);
   hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_ft0); if (b->d_obsprog) hipFree(b->d_obsprog);
-  if (b->d_bank) hipFree(b->d_bank); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); if (b->d_ft_base) hipFree(b->d_ft_base); hipFree(b->d_mesh); hipFree(b->d_mask);
+  if (b->d_bank) hipFree(b->d_bank); if (b->d_bank_tag) hipFree(b->d_bank_tag); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); if (b->d_ft_base) hipFree(b->d_ft_base); hipFree(b->d_mesh); hipFree(b->d_mask);
   if (b->d_order) hipFree(b->d_order); if (b->d_cost) hipFree(b->d_cost);
   if (b->db.prof) hipFree(b->db.prof);
   hipStreamDestroy(b->stream);
@@ -856,10 +859,20 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   }
   int e = k_step_launch[b->cfg](&b->dm, &b->db, actions, n_sub, flags, b->stream);
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-  if ((flags & RF_EPISODE) && b->db.bank && b->db.bank_P > 0 && b->db.horizon > 0 && b->db.cm_stride) {
-    // envs whose episode just ended were re-initialised from the reset bank, float-table patches included: rebuild their constant blocks
-    e = k_prepare_launch[b->cfg](&b->dm, &b->db, b->B, 1, b->stream);
-    if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  if ((flags & RF_EPISODE) && b->db.bank && b->db.horizon > 0) {
+    if (b->db.bank_P > 0 && b->db.cm_stride) {
+      // envs whose episode just ended were re-initialised from the reset bank, float-table patches included: rebuild their constant blocks
+      e = k_prepare_launch[b->cfg](&b->dm, &b->db, b->B, 1, b->stream);
+      if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
+    if (b->dm.task.enabled) {
+      // ... and their observation record becomes the one MujocoEnv.reset() returns (base.py:298-347): sim.forward() + observables on the reset
+      // state, no reward.  The terminal record of the finished episode was moved to RSIM_TERMINAL_OBS by the control step.
+      DBatch db2 = b->db;
+      db2.order = nullptr; db2.cost = nullptr;
+      e = k_step_launch[b->cfg](&b->dm, &db2, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_OBS | RF_RESET_ONLY, b->stream);
+      if (e) return fail("reset-observation kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
   }
   b->gen++;
   return 0;
@@ -893,17 +906,44 @@ extern "C" int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, c
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   if (b->d_bank) { hipFree(b->d_bank); b->d_bank = nullptr; }
+  if (b->d_bank_tag) { hipFree(b->d_bank_tag); b->d_bank_tag = nullptr; }
   if (b->d_patch) { hipFree(b->d_patch); b->d_patch = nullptr; }
   const size_t stride = (size_t)m->nq + n_patch, total = (size_t)b->B * n_episodes * stride;
   if (dalloc(&b->d_bank, total)) return 1;
   HIPCHK(hipMemcpy(b->d_bank, bank, total * sizeof(float), hipMemcpyHostToDevice));
   if (dalloc(&b->d_patch, (size_t)(n_patch ? n_patch : 1))) return 1;
   if (n_patch) HIPCHK(hipMemcpy(b->d_patch, patch_idx, n_patch * sizeof(int), hipMemcpyHostToDevice));
-  b->db.bank = b->d_bank; b->db.patch_idx = b->d_patch; b->db.bank_E = n_episodes; b->db.bank_P = n_patch;
+  {   // slot s of every env starts out holding episode s
+    std::vector<int> tags((size_t)b->B * n_episodes);
+    for (size_t i = 0; i < tags.size(); i++) tags[i] = (int)(i % (size_t)n_episodes);
+    if (dalloc(&b->d_bank_tag, tags.size())) return 1;
+    HIPCHK(hipMemcpy(b->d_bank_tag, tags.data(), tags.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  b->db.bank = b->d_bank; b->db.bank_tag = b->d_bank_tag; b->db.patch_idx = b->d_patch; b->db.bank_E = n_episodes; b->db.bank_P = n_patch;
   for (int p2 = 0; p2 < n_patch; p2++)
     for (int f = 0; f < FO_COUNT; f++)
       if (patch_idx[p2] >= m->fo[f] && patch_idx[p2] < m->fo[f] + m->fcount[f]) b->dm.fenv |= 1ull << f;
   b->cm_dirty = 1;
+  return 0;
+}
+
+extern "C" int rsim_refill_reset_bank(rsim_batch* b, int n, const int32_t* env, const int32_t* episode, const float* rows) {
+  if (!b->d_bank) return fail("rsim_refill_reset_bank: no reset bank installed (rsim_set_reset_bank)");
+  if (n < 0) return fail("rsim_refill_reset_bank: n < 0");
+  if (n == 0) return 0;
+  for (int i = 0; i < n; i++) if (env[i] < 0 || env[i] >= b->B || episode[i] < 0) return fail("rsim_refill_reset_bank: entry %d out of range", i);
+  HIPCHK(hipSetDevice(b->device));
+  const int W = b->m->nq + b->db.bank_P;
+  // staging buffers live until the scatter kernel has run: allocate per call, free after a stream sync (refills are rare: once per episode and env)
+  int *d_env = nullptr, *d_ep = nullptr; float* d_rows = nullptr;
+  if (dalloc(&d_env, (size_t)n) || dalloc(&d_ep, (size_t)n) || dalloc(&d_rows, (size_t)n * W)) return 1;
+  HIPCHK(hipMemcpyAsync(d_env, env, (size_t)n * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(d_ep, episode, (size_t)n * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(d_rows, rows, (size_t)n * W * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  int e = rsim_launch_bank_scatter(b->d_bank, b->d_bank_tag, d_env, d_ep, d_rows, n, b->db.bank_E, W, b->stream);
+  HIPCHK(hipStreamSynchronize(b->stream));
+  hipFree(d_env); hipFree(d_ep); hipFree(d_rows);
+  if (e) return fail("bank scatter kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return 0;
 }
 

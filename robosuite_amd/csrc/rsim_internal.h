@@ -159,7 +159,10 @@ struct DBatch {
   // episode bookkeeping / on-device reset
   int *done, *ep_step, *ep_index, *needs_reset;   // [B]
   int horizon, bank_E, bank_P;
-  const float* bank;     // [B][bank_E][nq + bank_P]
+  const float* bank;     // [B][bank_E][nq + bank_P]: ring of pre-drawn resets, slot = episode number % bank_E
+  const int* bank_tag;   // [B][bank_E] episode number each slot holds
+  int* bank_stale;       // [B] resets that found a slot the host had not refilled in time
+  float* term_obs;       // [B, nobs] observation record of the control step that ended an episode (valid where done was reported)
   const int* patch_idx;  // [bank_P] offsets into the env's float table
   float* ft_rw;          // writable alias of the float tables (per-env patches)
   float* ft_base;        // saved defaults of the float tables (domain randomisation), may be null
@@ -192,4 +195,5 @@ enum {
   RF_DEBUG = 32,     // write compat/debug arrays
   RF_OBS = 64,       // observation / reward epilogue after the last substep
   RF_EPISODE = 128,  // episode step counter, done flag, on-device reset from the bank
+  RF_RESET_ONLY = 256,  // only the envs whose needs_reset flag is set (the reset-observation pass after a control step)
 };

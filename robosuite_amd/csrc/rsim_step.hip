@@ -2964,8 +2964,7 @@ struct Sim {
         const int nin = __popcll(in_mask);
         float r = (float)nin;
         if (t.reward_shaping) r += fmaxf(fmaxf(r_reach, r_grasp), fmaxf(r_lift, r_hover));
-        *reward = r * t.reward_scale / 4.0f;
-        *success = nin == t.nobj ? 1 : 0;
+        if (reward) { *reward = r * t.reward_scale / 4.0f; *success = nin == t.nobj ? 1 : 0; }
       }
     } else if (t.task == 3) {
       if (lane == 0) {
@@ -2975,8 +2974,7 @@ struct Sim {
           const float dist = norm(ld3(sm.xpos + 3 * t.object_body) - ld3(sm.xpos + 3 * t.object2_body));
           r += (1.f - tanhf(dist)) + (1.f - tanhf(peg_d)) + (1.f - tanhf(fabsf(peg_t))) + peg_c;
         } else r *= 5.f;
-        *reward = r * t.reward_scale / 5.0f;
-        *success = succ ? 1 : 0;
+        if (reward) { *reward = r * t.reward_scale / 5.0f; *success = succ ? 1 : 0; }
       }
     } else if (t.task >= 1) {
       // grasp: both finger-pad geom groups touch the object (contact list of the last substep)
@@ -3000,8 +2998,7 @@ struct Sim {
         if (lifted) { const float dx = cA.x - cB.x, dy = cA.y - cB.y; r_lift += 0.5f * (1.f - tanhf(sqrtf(dx * dx + dy * dy))); }
         const float r_stack = (!grasp && r_lift > 0.f && touching) ? 2.f : 0.f;
         const float r = t.reward_shaping ? fmaxf(r_reach, fmaxf(r_lift, r_stack)) : r_stack;
-        *reward = r * t.reward_scale / 2.0f;
-        *success = r_stack > 0.f ? 1 : 0;
+        if (reward) { *reward = r * t.reward_scale / 2.0f; *success = r_stack > 0.f ? 1 : 0; }
       }
       if (lane == 0 && t.task == 1) {
         const V3 cube = ld3(sm.xpos + 3 * t.object_body), grip = ld3(sm.spos + 3 * t.grip_site);
@@ -3009,8 +3006,7 @@ struct Sim {
         float r = 0.f;
         if (succ) r = 2.25f;
         else if (t.reward_shaping) { r = 1.f - tanhf(10.f * norm(cube - grip)); if (grasp) r += 0.25f; }
-        *reward = r * t.reward_scale / 2.25f;
-        *success = succ ? 1 : 0;
+        if (reward) { *reward = r * t.reward_scale / 2.25f; *success = succ ? 1 : 0; }
       }
     }
   }
@@ -3037,6 +3033,9 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   // workgroups are dispatched in index order: handing the envs that were slowest in the previous launch to the first workgroups
   // (contact-rich envs stay contact-rich for many control steps) keeps the last wave of envs short
   const int env = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
+  // RF_RESET_ONLY: the pass that follows a control step and produces the observation MujocoEnv.reset() returns (forward + epilogue, no reward)
+  // for the envs that step re-initialised from the reset bank; every other workgroup leaves at once
+  if ((flags & RF_RESET_ONLY) && !b.needs_reset[env]) return;
   const long long t_launch = b.cost ? clock64() : 0;
   const float* fp = m.ft + (size_t)env * m.fstride;
   Sim<SM> sim(m, fp, lane, b.prof, b.cm, b.cm_stride ? (const char*)b.cm_env + (size_t)env * b.cm_stride : (const char*)b.cm);
@@ -3134,14 +3133,21 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
     }
     sim.pf.count(RP_N_SUB, 1);
   }
-  if ((flags & RF_OBS) && m.task.enabled) sim.obs_reward(b.obs + (size_t)env * m.task.nobs, b.reward + env, b.success + env, !(flags & RF_CTRL));
+  if ((flags & RF_OBS) && m.task.enabled)
+    sim.obs_reward(b.obs + (size_t)env * m.task.nobs, (flags & RF_RESET_ONLY) ? nullptr : b.reward + env, b.success + env, !(flags & RF_CTRL));
   if (flags & RF_EPISODE) {
     // MujocoEnv.step: timestep += 1; done = timestep >= horizon (base.py:508, 532-548); optional on-device reset from the bank
     int st = b.ep_step[env] + 1;
     const bool done = b.horizon > 0 && st >= b.horizon;
     if (done && b.bank) {
-      const int ep = (b.ep_index[env] + 1) % b.bank_E;
-      const float* src = b.bank + ((size_t)env * b.bank_E + ep) * (m.nq + b.bank_P);
+      // episodes are numbered for ever; the bank is a ring of bank_E slots per env that the host keeps refilling (rsim_refill_reset_bank), so no
+      // reset is ever replayed.  A slot whose tag is not the episode about to start was not refilled in time: counted (RSIM_BANK_STALE), still used.
+      const int ep = b.ep_index[env] + 1, slot = ep % b.bank_E;
+      const float* src = b.bank + ((size_t)env * b.bank_E + slot) * (m.nq + b.bank_P);
+      if (lane == 0 && b.bank_tag && b.bank_tag[(size_t)env * b.bank_E + slot] != ep) b.bank_stale[env] += 1;
+      // gym auto-reset convention: the record of the step that ended the episode moves to RSIM_TERMINAL_OBS; RSIM_OBS receives the reset
+      // observation from the reset-only pass that follows this launch (same lanes wrote these floats in obs_reward above)
+      if (b.term_obs && m.task.enabled) for (int i = lane; i < m.task.nobs; i += 64) b.term_obs[(size_t)env * m.task.nobs + i] = b.obs[(size_t)env * m.task.nobs + i];
       SYNC();
       for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = src[i];
       if (lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.ctrl[lane] = 0.f; }
@@ -3151,13 +3157,6 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
       }
       time = 0.f;
       st = 0;
-      if (m.task.enabled && m.task.task == 4 && lane < m.task.nobj) {
-        // PickPlace relative-pose sensors read the object's pose from the observation cache: after reset() that is the reset pose
-        const int qa = IT(IO_jnt_qposadr, IT(IO_body_jntadr, seli(m.task.obj_body, lane)));
-        float* o = b.obs + (size_t)env * m.task.nobs + seli(m.task.pos_slot, lane);
-        const Q4 q = qnorm(ldq(src + qa + 3));
-        o[0] = src[qa]; o[1] = src[qa + 1]; o[2] = src[qa + 2]; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
-      }
       if (lane == 0) { b.ep_index[env] = ep; b.needs_reset[env] = 1; }
       SYNC();
       // the patched float-table entries change this env's constant block: the host follows this launch with k_prepare over the envs whose
@@ -3385,6 +3384,19 @@ __global__ __launch_bounds__(1024) void k_order(const unsigned* __restrict__ cos
   if (tid == 0) { int acc = 0; for (int k = 0; k < 256; k++) { base[k] = acc; acc += hist[k]; } }
   __syncthreads();
   for (int i = tid; i < B; i += 1024) order[atomicAdd(&base[(int)((float)(hi - cost[i]) * scale)], 1)] = i;
+}
+// refill of the reset-bank ring: row i of `rows` -> slot (episode[i] % E) of env[i], and the slot's tag := episode[i]
+__global__ __launch_bounds__(64) void k_bank_scatter(float* bank, int* tag, const int* env, const int* episode, const float* rows, int n, int E, int W) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const int e = env[i], slot = episode[i] % E;
+  float* dst = bank + ((size_t)e * E + slot) * W;
+  for (int k = threadIdx.x; k < W; k += 64) dst[k] = rows[(size_t)i * W + k];
+  if (threadIdx.x == 0) tag[(size_t)e * E + slot] = episode[i];
+}
+extern "C" int rsim_launch_bank_scatter(float* bank, int* tag, const int* env, const int* episode, const float* rows, int n, int E, int W, hipStream_t stream) {
+  hipLaunchKernelGGL(k_bank_scatter, dim3(n), dim3(64), 0, stream, bank, tag, env, episode, rows, n, E, W);
+  return (int)hipGetLastError();
 }
 extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStream_t stream) {
   hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, cost, order, B);

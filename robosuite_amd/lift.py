@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .reset_bank import ResetBankMixin
+
 PANDA_INIT_QPOS = np.array([0, np.pi / 16.0, 0.00, -np.pi / 2.0 - np.pi / 3.0, 0.00, np.pi - 0.2, np.pi / 4])  # panda_robot.py:37
 PANDA_GRIPPER_INIT_QPOS = np.array([0.020833, -0.020833])  # panda_gripper.py:36
 TABLE_OFFSET = np.array([0.0, 0.0, 0.8])  # lift.py:153
@@ -139,7 +141,7 @@ def lift_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool = True)
                 object_geoms=[g.index("cube_g0")])
 
 
-class LiftBatch:
+class LiftBatch(ResetBankMixin):
     """B Lift/Panda/OSC_POSE environments resident on one GPU, stepped by the fused HIP control-step kernel.
 
     `env_ids` are GLOBAL env indices (results do not depend on how envs are sharded over GPUs)."""
@@ -156,36 +158,37 @@ class LiftBatch:
         self.batch = HipBatch(self.model, self.B, device, per_env_params=per_env_cube)
         self.per_env_cube = per_env_cube
         self.seed0 = seed0
+        self.horizon = horizon
         self.reset()
         if horizon:
             self.batch.set_episode(horizon)
         if bank_episodes:
+            # hard resets drawn ahead per env (block k of each env's generator = its episode k, the reference's draw order): when an env reaches
+            # the horizon the kernel re-initialises it in place (MujocoEnv.reset with hard_reset, base.py:277-347); reset_bank.py keeps the ring filled
             self.install_reset_bank(bank_episodes)
 
-    def install_reset_bank(self, n_episodes: int):
-        """Pre-draw `n_episodes` hard resets per env (blocks 0..n-1 of each env's generator, the reference's draw order) and hand them to
-        the device: when an env reaches the horizon the kernel re-initialises it in place (MujocoEnv.reset with hard_reset, base.py:277-347)
-        without a host round trip.  Entry 0 is the episode the batch was constructed with."""
-        b = self.batch
-        fields = cube_model_rows(self.flat, self.sizes[:1])  # which float-table slots depend on the cube size
-        base = {k: np.asarray(self.flat.arrays[k], dtype=np.float64).ravel() for k in fields}
-        slots = []  # (field, element) pairs whose value changes with the cube
-        probe = cube_model_rows(self.flat, np.array([[0.0201, 0.0213, 0.0207]]))
-        for k, rows in probe.items():
-            for e in np.nonzero(np.abs(rows[0] - base[k]) > 0)[0]:
-                off = b.param_offset(k, int(e))
-                if off >= 0:
-                    slots.append((k, int(e), off))
-        qbank = np.zeros((self.B, n_episodes, self.flat.nq), dtype=np.float32)
-        pbank = np.zeros((self.B, n_episodes, len(slots)), dtype=np.float32)
-        for ep in range(n_episodes):
-            sizes, qpos = episode_setup(self.seed0, self.env_ids, ep)
-            rows = cube_model_rows(self.flat, sizes)
-            qbank[:, ep] = qpos
-            for j, (k, e, _) in enumerate(slots):
-                pbank[:, ep, j] = rows[k][:, e]
-        b.set_reset_bank(qbank, [o for _, _, o in slots], pbank)
-        self.bank_episodes = n_episodes
+    def _bank_slots(self):
+        if not hasattr(self, "_slots"):
+            slots = []  # (field, element, float-table offset) of every entry that changes with the per-episode cube size
+            if self.per_env_cube:
+                base = {k: np.asarray(self.flat.arrays[k], dtype=np.float64).ravel() for k in cube_model_rows(self.flat, self.sizes[:1])}
+                probe = cube_model_rows(self.flat, np.array([[0.0201, 0.0213, 0.0207]]))
+                for k, rows in probe.items():
+                    for e in np.nonzero(np.abs(rows[0] - base[k]) > 0)[0]:
+                        off = self.batch.param_offset(k, int(e))
+                        if off >= 0:
+                            slots.append((k, int(e), off))
+            self._slots = slots
+        return self._slots
+
+    def _bank_patch_offsets(self):
+        return [o for _, _, o in self._bank_slots()]
+
+    def _bank_rows(self, idx, episode):
+        sizes, qpos = episode_setup(self.seed0, self.env_ids[idx], episode)
+        rows = cube_model_rows(self.flat, sizes) if self._bank_slots() else {}
+        patch = np.stack([rows[k][:, e] for k, e, _ in self._bank_slots()], axis=1) if self._bank_slots() else np.zeros((len(idx), 0))
+        return qpos, patch
 
     def reset(self, block: int = 0):
         sizes, qpos = episode_setup(self.seed0, self.env_ids, block)
@@ -205,6 +208,7 @@ class LiftBatch:
     def step(self, actions, n_sub: int = 25):
         """One env.step for every env: fused physics + controllers + observation / reward epilogue (results stay on the device)."""
         self.batch.control_step(actions, n_sub)
+        self._bank_tick()
 
     def obs(self):
         return self.batch.tensor("obs")
@@ -216,53 +220,16 @@ class LiftBatch:
         return self.batch.tensor("success")
 
 
-class LiftVecEnv:
-    """Vectorised `suite.make("Lift", robots="Panda", ...)`: the batched counterpart of the reference's Gym-style loop
-    (`obs = env.reset(); obs, reward, done, info = env.step(action)`, environments/base.py:277-347, 467-521; key selection / flattening
-    as wrappers/gym_wrapper.py:45-163 with the default keys object-state + robot0_proprio-state).  All returned tensors alias device
-    memory owned by the backend; envs that reach `horizon` restart on the device (ignore_done=False semantics: `done` is reported once).
-    """
+def LiftVecEnv(n_envs: int, device: int = 0, seed: int = 0, horizon: int = 500, env_ids=None, bank_episodes: int = 4, flat=None, cfg=None):
+    """Vectorised `suite.make("Lift", robots="Panda", ...)` on the packaged model: `vec_env.VecEnv("Lift", ...)` (one facade for all tasks)."""
+    import json
+    import os
 
-    def __init__(self, n_envs: int, device: int = 0, seed: int = 0, horizon: int = 500, env_ids=None, bank_episodes: int = 4, flat=None, cfg=None):
-        import json
-        import os
+    from . import mjcf
+    from .vec_env import VecEnv
 
-        from . import mjcf
-
-        if flat is None:
-            adir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
-            flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim"))
-            cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
-        ids = np.arange(n_envs) if env_ids is None else np.asarray(env_ids)
-        self.env = LiftBatch(flat, cfg, ids, device=device, seed0=seed, horizon=horizon, bank_episodes=bank_episodes)
-        self.n_envs, self.horizon = len(ids), horizon
-        self.action_dim = self.env.model.action_dim
-        self.obs_dim = self.env.model.nobs
-        keys, dims = cfg["obs_keys"], cfg["obs_dims"]
-        off = np.cumsum([0] + list(dims))
-        self.obs_slices = {k: slice(int(off[i]), int(off[i + 1])) for i, k in enumerate(keys)}
-        # GymWrapper default flattening: ["object-state", "robot0_proprio-state"] (gym_wrapper.py:56-64)
-        self._object_keys = [k for k in keys if not k.startswith("robot0_")]
-        self._proprio_keys = [k for k in keys if k.startswith("robot0_")]
-
-    @property
-    def action_spec(self):
-        return -np.ones(self.action_dim), np.ones(self.action_dim)
-
-    def reset(self):
-        """Hard reset of every env to its first pre-drawn episode; returns the observation record [n_envs, obs_dim]."""
-        self.env.reset(block=0)
-        self.env.batch.set("ep_step", 0); self.env.batch.set("ep_index", 0); self.env.batch.set("done", 0)
-        self.env.batch.observe()
-        return self.env.obs()
-
-    def step(self, actions):
-        """actions: CUDA float32 [n_envs, action_dim] in [-1, 1].  Returns (obs, reward, done, info) as device tensors."""
-        self.env.step(actions)
-        return self.env.obs(), self.env.reward(), self.env.batch.tensor("done"), {"success": self.env.success()}
-
-    def flat_obs(self, obs):
-        """GymWrapper layout: object-state keys first, then the robot proprio keys."""
-        import torch
-
-        return torch.cat([obs[:, self.obs_slices[k]] for k in self._object_keys + self._proprio_keys], dim=1)
+    if flat is None:
+        adir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+        flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim"))
+        cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
+    return VecEnv("Lift", n_envs, flat, cfg, device=device, seed=seed, horizon=horizon, env_ids=env_ids, bank_episodes=bank_episodes)

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .reset_bank import ResetBankMixin  # noqa: E402
+
 
 def peg_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool = True):
     names = flat.names
@@ -55,7 +57,7 @@ def episode_setup(seed0: int, env_ids, block: int = 0, with_radius: bool = False
     return (np.array(out), np.array(rad)) if with_radius else np.array(out)
 
 
-class PegBatch:
+class PegBatch(ResetBankMixin):
     """B TwoArmPegInHole/Baxter environments on one GPU (64-body kernel configuration, joint-space part controllers).  With `per_env_peg`
     (default) every env carries its own peg radius, redrawn per episode like the reference's hard reset (closed-form model rows,
     `peg_model_rows`); without it all envs keep the radius of the model the batch was built from."""
@@ -72,34 +74,36 @@ class PegBatch:
         self.per_env_peg = per_env_peg
         self.batch = HipBatch(self.model, self.B, device, per_env_params=per_env_peg)
         self.seed0 = seed0
+        self.horizon = horizon
         self.reset()
         if horizon:
             self.batch.set_episode(horizon)
         if bank_episodes:
-            self.install_reset_bank(bank_episodes)
+            self.install_reset_bank(bank_episodes)   # qpos plus, with per-env pegs, the float-table slots that depend on the radius (reset_bank.py)
 
-    def install_reset_bank(self, n_episodes: int):
-        """Pre-drawn hard resets per env for the on-device restart: qpos plus, with per-env pegs, the float-table slots that depend on the radius."""
-        b = self.batch
-        qbank = np.zeros((self.B, n_episodes, self.flat.nq), dtype=np.float32)
-        slots = []
-        if self.per_env_peg:
-            base = peg_model_rows(self.flat, [0.02])
-            probe = peg_model_rows(self.flat, [0.0271])
-            for k in base:
-                for e in np.nonzero(np.abs(probe[k][0] - base[k][0]) > 0)[0]:
-                    off = b.param_offset(k, int(e))
-                    if off >= 0:
-                        slots.append((k, int(e), off))
-        pbank = np.zeros((self.B, n_episodes, len(slots)), dtype=np.float32)
-        for ep in range(n_episodes):
-            qpos, radii = episode_setup(self.seed0, self.env_ids, ep, with_radius=True)
-            qbank[:, ep] = qpos
-            if slots:
-                rows = peg_model_rows(self.flat, radii)
-                for j, (k, e, _) in enumerate(slots):
-                    pbank[:, ep, j] = rows[k][:, e]
-        b.set_reset_bank(qbank, [o for _, _, o in slots], pbank)
+    def _bank_slots(self):
+        if not hasattr(self, "_slots"):
+            slots = []
+            if self.per_env_peg:
+                base = peg_model_rows(self.flat, [0.02])
+                probe = peg_model_rows(self.flat, [0.0271])
+                for k in base:
+                    for e in np.nonzero(np.abs(probe[k][0] - base[k][0]) > 0)[0]:
+                        off = self.batch.param_offset(k, int(e))
+                        if off >= 0:
+                            slots.append((k, int(e), off))
+            self._slots = slots
+        return self._slots
+
+    def _bank_patch_offsets(self):
+        return [o for _, _, o in self._bank_slots()]
+
+    def _bank_rows(self, idx, episode):
+        qpos, radii = episode_setup(self.seed0, self.env_ids[idx], episode, with_radius=True)
+        if not self._bank_slots():
+            return qpos, np.zeros((len(idx), 0))
+        rows = peg_model_rows(self.flat, radii)
+        return qpos, np.stack([rows[k][:, e] for k, e, _ in self._bank_slots()], axis=1)
 
     def reset(self, block: int = 0):
         qpos, radii = episode_setup(self.seed0, self.env_ids, block, with_radius=True)
@@ -113,6 +117,7 @@ class PegBatch:
 
     def step(self, actions, n_sub: int = 25):
         self.batch.control_step(actions, n_sub)
+        self._bank_tick()
 
     def obs(self):
         return self.batch.tensor("obs")

@@ -37,6 +37,8 @@ def pick_place_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool =
 
 import numpy as np  # noqa: E402
 
+from .reset_bank import ResetBankMixin  # noqa: E402
+
 
 def reset_draws(rng: np.random.Generator, placement: dict):
     """One hard-reset block of the env generator in the reference's order (pick_place.py:670-700 -> robots/robot.py:247-259,
@@ -92,7 +94,7 @@ def episode_setup(cfg, nq: int, seed0: int, env_ids, block: int = 0):
     return np.array(out)
 
 
-class PickPlaceBatch:
+class PickPlaceBatch(ResetBankMixin):
     """B PickPlace/IIWA+Robotiq140 environments on one GPU (64 x 64 kernel configuration).  `env_ids` are GLOBAL indices."""
 
     def __init__(self, flat, cfg, env_ids, device: int = 0, seed0: int = 0, horizon: int = 0, bank_episodes: int = 0, per_env_params: bool = False):
@@ -109,9 +111,15 @@ class PickPlaceBatch:
         self.reset()
         if horizon:
             self.batch.set_episode(horizon)
+        self.horizon = horizon
         if bank_episodes:
-            qbank = np.stack([episode_setup(cfg, flat.nq, seed0, self.env_ids, ep) for ep in range(bank_episodes)], axis=1).astype(np.float32)
-            self.batch.set_reset_bank(qbank, [], np.zeros((self.B, bank_episodes, 0), dtype=np.float32))
+            self.install_reset_bank(bank_episodes)
+
+    def _bank_patch_offsets(self):
+        return []
+
+    def _bank_rows(self, idx, episode):
+        return episode_setup(self.cfg, self.flat.nq, self.seed0, self.env_ids[idx], episode), np.zeros((len(idx), 0))
 
     def reset(self, block: int = 0):
         qpos = episode_setup(self.cfg, self.flat.nq, self.seed0, self.env_ids, block)
@@ -122,6 +130,7 @@ class PickPlaceBatch:
 
     def step(self, actions, n_sub: int = 25):
         self.batch.control_step(actions, n_sub)
+        self._bank_tick()
 
     def obs(self):
         return self.batch.tensor("obs")

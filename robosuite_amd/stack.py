@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .reset_bank import ResetBankMixin
+
 from .lift import PANDA_GRIPPER_INIT_QPOS, PANDA_INIT_QPOS, TABLE_OFFSET, env_actions  # noqa: F401  (same robot, arena and action streams)
 
 CUBE_HALF = {"cubeA": 0.02, "cubeB": 0.025}   # stack.py:324-337
@@ -99,7 +101,7 @@ def stack_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool = True
                 object_geoms=[g.index("cubeA_g0")], object2_geoms=[g.index("cubeB_g0")])
 
 
-class StackBatch:
+class StackBatch(ResetBankMixin):
     """B Stack/Panda/OSC_POSE environments resident on one GPU (32-dof configuration of the fused kernel).  `env_ids` are GLOBAL indices."""
 
     def __init__(self, flat, cfg, env_ids, device: int = 0, seed0: int = 0, horizon: int = 0, bank_episodes: int = 0):
@@ -116,9 +118,15 @@ class StackBatch:
         self.reset()
         if horizon:
             self.batch.set_episode(horizon)
+        self.horizon = horizon
         if bank_episodes:
-            qbank = np.stack([episode_setup(seed0, self.env_ids, ep) for ep in range(bank_episodes)], axis=1).astype(np.float32)
-            self.batch.set_reset_bank(qbank, [], np.zeros((self.B, bank_episodes, 0), dtype=np.float32))
+            self.install_reset_bank(bank_episodes)
+
+    def _bank_patch_offsets(self):
+        return []
+
+    def _bank_rows(self, idx, episode):
+        return episode_setup(self.seed0, self.env_ids[idx], episode), np.zeros((len(idx), 0))
 
     def reset(self, block: int = 0):
         qpos = episode_setup(self.seed0, self.env_ids, block)
@@ -130,6 +138,7 @@ class StackBatch:
 
     def step(self, actions, n_sub: int = 25):
         self.batch.control_step(actions, n_sub)
+        self._bank_tick()
 
     def obs(self):
         return self.batch.tensor("obs")

@@ -47,7 +47,9 @@ class VecEnv:
 
     def step(self, actions):
         self.env.step(actions)
-        return self.env.obs(), self.env.reward(), self.env.batch.tensor("done"), {"success": self.env.success()}
+        # gym auto-reset convention: for an env whose episode just ended, `obs` is already the reset observation of its next episode and the
+        # last record of the finished one is in info["terminal_obs"] (rows of envs that did not finish are stale)
+        return self.env.obs(), self.env.reward(), self.env.batch.tensor("done"), {"success": self.env.success(), "terminal_obs": self.env.batch.tensor("terminal_obs")}
 
     def key(self, obs, name: str):
         return obs[:, self.obs_slices[name]]

@@ -677,6 +677,15 @@ def test_on_device_episode_reset_equals_a_fresh_host_reset():
     fresh = lift.LiftBatch(flat, cfg, ids, seed0=0)
     fresh.reset(block=1)
     assert np.array_equal(auto.batch.get("qpos"), fresh.batch.get("qpos"))
+    # gym auto-reset convention: RSIM_OBS of the finished envs is what MujocoEnv.reset() returns for the new episode (forward + observables on the
+    # reset state, base.py:298-347) and the finished episode's last record sits in RSIM_TERMINAL_OBS; reward / success stay the terminal step's
+    fresh.batch.observe()
+    assert np.array_equal(auto.batch.get("obs"), fresh.batch.get("obs"))
+    plain = lift.LiftBatch(flat, cfg, ids, seed0=0)            # same episode, no horizon: its record after H steps is the terminal one
+    for t in range(H):
+        plain.step(torch.tensor(acts[t], device="cuda"))
+    assert np.array_equal(auto.batch.get("terminal_obs"), plain.batch.get("obs")) and np.array_equal(auto.batch.get("reward"), plain.batch.get("reward"))
+    fresh.reset(block=1)
     for t in range(H, H + 3):
         a = torch.tensor(acts[t], device="cuda")
         auto.step(a); fresh.step(a)
@@ -687,6 +696,29 @@ def test_on_device_episode_reset_equals_a_fresh_host_reset():
     fresh2.batch.observe()
     o = fresh2.batch.get("obs")
     assert np.isfinite(o).all() and np.abs(o[:, :7] - fresh2.qpos0[:, :7]).max() < 1e-6
+
+
+def test_reset_bank_ring_never_repeats_an_episode():
+    """Every reset of every env is a fresh draw, as the reference's hard reset is (base.py:277-347): episode k of env i equals
+    episode_setup(seed, i, k) for k far beyond the ring size (2 slots), the cube size patches included, and no reset ever found a stale slot."""
+    g, cfg, flat = load_golden("seed1_full")
+    ids = np.array([5, 77, 1030, 4000])
+    H, E = 2, 2
+    env = lift.LiftBatch(flat, cfg, ids, seed0=3, horizon=H, bank_episodes=E)
+    acts = torch.tensor(lift.env_actions(ids, 2 * 14, scale=0.2), device="cuda")
+    cube = flat.name2id("geom", "cube_g0")
+    seen = []
+    for t in range(2 * 14):
+        env.step(acts[t])
+        if (t + 1) % H == 0:
+            k = (t + 1) // H
+            assert env.batch.get("ep_index").tolist() == [k] * 4
+            sizes, qpos = lift.episode_setup(3, ids, k)
+            assert np.array_equal(env.batch.get("qpos"), qpos.astype(np.float32)), k
+            assert np.abs(env.batch.param_get("geom_size")[:, cube] - sizes).max() < 1e-7, k
+            seen.append(env.batch.get("qpos").copy())
+    assert len(seen) == 14 and all(not np.array_equal(seen[a], seen[b]) for a in range(14) for b in range(a))
+    assert int(env.batch.get("bank_stale").sum()) == 0
 
 
 def test_vectorised_env_facade():
