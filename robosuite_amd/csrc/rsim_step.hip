@@ -669,6 +669,90 @@ __device__ __forceinline__ V3 geom_support(cmr_t cm, cmr_t cmg, int g, V3 dir, g
   return p + mv(R, lp);
 }
 
+// One geom of an MPR run, loaded ONCE: type, frame, position relative to the run's origin, size, and -- for hulls of up to 256 vertices --
+// the vertices themselves, four per lane in registers.  A support evaluation then touches no memory at all (it used to re-read the type, the
+// hull address and the vertices in three dependent round trips, ~0.7 us of the ~1 us an MPR iteration took); MPR-heavy envs are the critical
+// path of a launch (3-4x the median env), so this is launch time, not just instruction count.
+struct SupGeom {
+  int t, adr, num;
+  M3 R;
+  V3 p, h;
+  float vx[4], vy[4], vz[4];
+  bool regs;
+};
+__device__ __forceinline__ SupGeom sup_load(cmr_t cm, cmr_t cmg, int g, gcf mesh_vert, int lane, V3 org) {
+  SupGeom s;
+  s.t = cm->gtype[g];
+  const int gm = cm->gmesh[g];
+  s.adr = gm & 0xffff; s.num = gm >> 16;
+  s.R = ldm(sm.gmat + 9 * g);
+  s.p = ld3(sm.gpos + 3 * g) - org; s.h = ld3(cmg->gst + 8 * g);
+  s.regs = s.t == G_MESH && s.num <= 256;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {   // issued unconditionally (index clamped): the loads overlap the type / size loads above instead of waiting for them
+    const int i = 64 * u + lane;
+    gcf v = mesh_vert + 3 * (s.adr + ((s.t == G_MESH && i < s.num) ? i : 0));
+    s.vx[u] = v[0]; s.vy[u] = v[1]; s.vz[u] = v[2];
+  }
+  return s;
+}
+__device__ __forceinline__ V3 sup_eval(const SupGeom& s, V3 dir, gcf mesh_vert, int lane) {
+  const int t = s.t;
+  const V3 h = s.h, ld = mtv(s.R, dir);
+  V3 lp = v3(0, 0, 0);
+  if (t == G_BOX) lp = v3(ld.x >= 0 ? h.x : -h.x, ld.y >= 0 ? h.y : -h.y, ld.z >= 0 ? h.z : -h.z);
+  else if (t == G_SPHERE) { float n = norm(ld); if (n > FMIN) lp = ld * (h.x / n); }
+  else if (t == G_CYLINDER) {
+    float n = sqrtf(ld.x * ld.x + ld.y * ld.y);
+    if (n > FMIN) { lp.x = ld.x / n * h.x; lp.y = ld.y / n * h.x; }
+    lp.z = ld.z >= 0 ? h.z : -h.z;
+  } else if (t == G_CAPSULE) {
+    float n = norm(ld);
+    if (n > FMIN) lp = ld * (h.x / n);
+    lp.z += ld.z >= 0 ? (h.z - h.x) : -(h.z - h.x);
+  } else if (t == G_ELLIPSOID) {
+    V3 tt = v3(ld.x * h.x, ld.y * h.y, ld.z * h.z);
+    float n = norm(tt);
+    if (n > FMIN) lp = v3(tt.x / n * h.x, tt.y / n * h.y, tt.z / n * h.z);
+  } else if (t == G_MESH) {
+    const int adr = s.adr, num = s.num;
+    float bv = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f;
+    int bi = 0x7fffffff;
+    if (s.regs) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = 64 * u + lane;
+        const float val = s.vx[u] * ld.x + s.vy[u] * ld.y + s.vz[u] * ld.z;
+        if (i < num && val > bv) { bv = val; bi = i; bx = s.vx[u]; by = s.vy[u]; bz = s.vz[u]; }
+      }
+    } else {
+      for (int base = 0; base < num; base += 256) {
+        float vx[4], vy[4], vz[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = base + 64 * u + lane;
+          gcf v = mesh_vert + 3 * (adr + (i < num ? i : 0));
+          vx[u] = v[0]; vy[u] = v[1]; vz[u] = v[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = base + 64 * u + lane;
+          const float val = vx[u] * ld.x + vy[u] * ld.y + vz[u] * ld.z;
+          if (i < num && val > bv) { bv = val; bi = i; bx = vx[u]; by = vy[u]; bz = vz[u]; }
+        }
+      }
+    }
+    // wave arg-max, lowest index wins ties (same rule as geom_support)
+    const float mx = wave_max(bv);
+    const u64 tie = __ballot(bv == mx);
+    int win = __ffsll((long long)tie) - 1;
+    if (__popcll(tie) > 1) win = wave_min_i(bv == mx ? bi : 0x7fffffff) & 63;
+    win = uni(win);
+    lp = v3(bcast(bx, win), bcast(by, win), bcast(bz, win));
+  }
+  return s.p + mv(s.R, lp);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // per-lane model constants, loaded once per launch and kept in registers for all substeps
 // ------------------------------------------------------------------------------------------------------------
@@ -1374,6 +1458,7 @@ struct Sim {
     st3(frame, n); st3(frame + 3, y); st3(frame + 6, z);
   }
 
+  __device__ __forceinline__ V3 sup(const SupGeom& sg, V3 dir) { pf.count(RP_N_SUPPORT, 1); return sup_eval(sg, dir, (gcf)m.mesh_vert, lane); }
   __device__ __forceinline__ V3 support(int g, V3 dir, V3 org = {0.f, 0.f, 0.f}) { pf.count(RP_N_SUPPORT, 1); return geom_support(cm, cmf(MK_gst), g, dir, (gcf)m.mesh_vert, lane, org); }
 
   // contact parameters of a geom pair (MuJoCo's mixing rules: priority, solmix-weighted solref/solimp, max friction);
@@ -1582,10 +1667,11 @@ struct Sim {
   __device__ __forceinline__ void convex_convex(int g1, int g2, float margin, const CPar& cp) {
     const float tol = 1e-6f;
     const V3 org = ld3(sm.gpos + 3 * g1);   // all support points relative to the first geom's position (see geom_support)
+    const SupGeom sg1 = sup_load(cm, cmf(MK_gst), g1, (gcf)m.mesh_vert, lane, org), sg2 = sup_load(cm, cmf(MK_gst), g2, (gcf)m.mesh_vert, lane, org);
     V3 v0 = (ld3(sm.gcen + 3 * g1) - org) - (ld3(sm.gcen + 3 * g2) - org);
     if (norm(v0) < 1e-9f) v0.x = 1e-5f;
     V3 dir = normalized(-v0);
-    V3 p11 = support(g1, dir, org), p12 = support(g2, -dir, org), v1 = p11 - p12;
+    V3 p11 = sup(sg1, dir), p12 = sup(sg2, -dir), v1 = p11 - p12;
     if (dot(v1, dir) <= 0) return;
     dir = cross(v0, v1);
     if (norm(dir) < 1e-12f) {
@@ -1594,7 +1680,7 @@ struct Sim {
       return;
     }
     dir = normalized(dir);
-    V3 p21 = support(g1, dir, org), p22 = support(g2, -dir, org), v2 = p21 - p22;
+    V3 p21 = sup(sg1, dir), p22 = sup(sg2, -dir), v2 = p21 - p22;
     if (dot(v2, dir) <= 0) return;
     dir = cross(v1 - v0, v2 - v0);
     if (dot(dir, v0) > 0) {
@@ -1608,7 +1694,7 @@ struct Sim {
       float len;
       dir = normalized(dir, &len);
       if (len < FMIN) return;
-      p31 = support(g1, dir, org); p32 = support(g2, -dir, org); v3_ = p31 - p32;
+      p31 = sup(sg1, dir); p32 = sup(sg2, -dir); v3_ = p31 - p32;
       if (dot(v3_, dir) <= 0) return;
       if (dot(cross(v1, v3_), v0) < -1e-14f) { v2 = v3_; p21 = p31; p22 = p32; dir = cross(v1 - v0, v3_ - v0); continue; }
       if (dot(cross(v3_, v2), v0) < -1e-14f) { v1 = v3_; p11 = p31; p12 = p32; dir = cross(v3_ - v0, v2 - v0); continue; }
@@ -1620,7 +1706,7 @@ struct Sim {
       dir = normalized(cross(v2 - v1, v3_ - v1), &len);
       if (len < FMIN) break;
       if (dot(dir, v1) >= 0) hit = true;
-      V3 p41 = support(g1, dir, org), p42 = support(g2, -dir, org), v4 = p41 - p42;
+      V3 p41 = sup(sg1, dir), p42 = sup(sg2, -dir), v4 = p41 - p42;
       float dv4 = dot(v4, dir);
       if (dv4 < 0 && !hit) return;
       float delta = dv4 - dot(v3_, dir);
