@@ -1,0 +1,95 @@
+"""Record the exact `mujoco`-surface call trace robosuite makes for make -> reset -> N x env.step on Lift/Panda (build container only).
+
+The UNMODIFIED reference runs over robosuite_amd.shim with the CPU oracle as arithmetic backend, wrapped in a tracer: every backend call
+robosuite issues through utils/binding_utils.py:1059-1192 (mj_forward / mj_step1 / mj_step2 / mj_resetData), controllers/parts/controller.py:
+226-227 (mj_fullM) and binding_utils.py:681-851 (mj_jacSite / mj_jacBody) is logged with
+  * the state robosuite had written through its numpy views right before the call (qpos, qvel, ctrl, qacc_warmstart, time), and
+  * everything it can read back afterwards (state, body / site / geom frames, qfrc_bias, qacc, ncon, the Jacobian or mass matrix returned).
+tests/test_hip_shim_trace.py replays the trace on the GPU box (no reference checkout there) through HipShimBackend, call by call from the
+recorded inputs, and compares every returned array.
+
+Writes tests/golden/shim_trace_lift.npz.   Usage: python tools/gen_shim_trace.py [n_steps]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from robosuite_amd import mjcf, shim  # noqa: E402
+from oracle.shim_backend import OracleBackend  # noqa: E402
+
+PRE = ("qpos", "qvel", "ctrl", "qacc_warmstart", "time")
+POST = ("qpos", "qvel", "qacc_warmstart", "time", "xpos", "xquat", "xmat", "site_xpos", "site_xmat", "geom_xpos", "qfrc_bias", "qacc")
+OPS = ("reset", "forward", "step1", "step2", "step", "jac_site", "jac_body", "full_M")
+
+EVENTS = []     # (op code, model index, int argument)
+ROWS = {}       # per op: list of flat float32 rows  [pre..., post..., extra...]
+MODELS = []     # blobs, one per backend instance
+
+
+class TracingBackend:
+    def __init__(self, flat):
+        self.inner = OracleBackend(flat)
+        self.mi = len(MODELS)
+        MODELS.append(np.frombuffer(mjcf.to_blob(flat), dtype=np.uint8).copy())
+
+    def __getattr__(self, k):          # model_array / data_array / sync_model / ncon / contacts pass through
+        return getattr(self.inner, k)
+
+    def _log(self, op, arg, pre, extra=()):
+        post = [np.asarray(self.inner.data_array(k), dtype=np.float64).ravel() for k in POST]
+        row = np.concatenate(pre + post + [np.array([float(self.inner.ncon)])] + [np.asarray(e, dtype=np.float64).ravel() for e in extra])
+        ROWS.setdefault((op, self.mi), []).append(row.astype(np.float32) if op.startswith("jac") or op == "full_M" else row)
+        EVENTS.append((OPS.index(op), self.mi, int(arg)))
+
+    def _pre(self):
+        return [np.asarray(self.inner.data_array(k), dtype=np.float64).ravel().copy() for k in PRE]
+
+    def _run(self, op):
+        pre = self._pre()
+        getattr(self.inner, op)()
+        self._log(op, 0, pre)
+
+    def forward(self): self._run("forward")
+    def step1(self): self._run("step1")
+    def step2(self): self._run("step2")
+    def step(self): self._run("step")
+    def reset(self): self._run("reset")
+
+    def jac(self, kind, idx):
+        pre = self._pre()
+        jp, jr = self.inner.jac(kind, idx)
+        self._log("jac_" + kind, idx, pre, (jp, jr))
+        return jp, jr
+
+    def full_M(self):
+        pre = self._pre()
+        M = self.inner.full_M()
+        self._log("full_M", 0, pre, (M,))
+        return M
+
+
+if __name__ == "__main__":
+    n_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    shim.install(TracingBackend)
+    import robosuite as suite
+
+    env = suite.make("Lift", robots="Panda", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
+                     reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=0)
+    env.reset()
+    rng = np.random.default_rng(10**6)
+    for t in range(n_steps):
+        env.step(rng.uniform(-1, 1, env.action_dim))
+    out = dict(events=np.array(EVENTS, dtype=np.int32), ops=np.array(OPS), pre=np.array(PRE), post=np.array(POST), n_models=len(MODELS))
+    for i, b in enumerate(MODELS):
+        out[f"model{i}"] = b
+    for (op, mi), rows in ROWS.items():
+        out[f"rows_{op}_{mi}"] = np.stack(rows)
+    path = os.path.join(ROOT, "tests", "golden", "shim_trace_lift.npz")
+    np.savez_compressed(path, **out)
+    names = {i: MODELS[i].size for i in range(len(MODELS))}
+    print("events", len(EVENTS), {OPS[k]: int((out["events"][:, 0] == k).sum()) for k in range(len(OPS))}, "models", names, "bytes", os.path.getsize(path))
