@@ -136,3 +136,33 @@ def test_long_random_rollouts_stay_finite_on_every_configuration(name, tag, mode
     # out, the fp32 kernel occasionally does not; the guard then puts the env back to qpos0 as MuJoCo does with a diverged state.
     nbad = int((env.env.batch.get("diverged") > 0).sum())
     assert nbad == 0 if name != "PickPlace" else nbad <= max(2, B // 50)
+
+
+def test_contact_and_row_overflow_is_counted_not_silent():
+    """MuJoCo's nconmax = 5000 (models/assets/base.xml:5) never truncates; the fused kernel has 16 contact slots and 64 constraint rows in the
+    Lift configuration.  A constructed state (cube jammed between the closed finger pads, the hand and the table: 26 contacts, 94 rows on the
+    oracle) must come out as the FIRST 16 contacts in detection order, a row count within capacity, finite accelerations -- and a non-zero
+    RSIM_OVERFLOW count, which the bench reports as `overflow_envs`."""
+    from tests.util import load_golden, make_hip, make_oracle
+    g, cfg, flat = load_golden("seed1_full")
+    q = np.array([-3.310503761e-03, 9.595607741e-01, -4.905636198e-03, -2.424200342e+00, 9.327601525e-03, 3.760863028e+00, 8.123742675e-01, 5.613262166e-05,
+                  -5.613262166e-05, -1.113625582e-01, 4.773980294e-03, 8.007105292e-01, 9.982068450e-01, -2.683816807e-02, 1.416109385e-02, 5.159719647e-02])
+    om, od, _ = make_oracle(flat, cfg)
+    od.qpos[:] = q; od.qvel[:] = 0; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0; od.forward()
+    assert od.ncon > 16 and od.nefc > 64
+    hm, hb = make_hip(flat, cfg, B=2)
+    assert int(hb.get("overflow").sum()) == 0
+    hb.set("qpos", np.stack([q, flat.qpos0.ravel()])); hb.set("qvel", 0); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward()
+    ov = hb.get("overflow")
+    assert hb.get("ncon")[0] == hb.maxcon == 16 and hb.get("nefc")[0] <= hb.maxefc == 64
+    # dropped contacts (and the contact blocks whose rows no longer fit) are counted, for env 0 only; one contact of this jammed state sits on
+    # a margin boundary and exists in fp64 only
+    assert ov[0] >= od.ncon - 16 - 2 and ov[1] == 0
+    # order-preserving truncation: the kernel's 16 contacts are, in order, a subsequence of the head of the oracle's list (the knife-edge
+    # contact above may be missing from it)
+    it = iter([(b["geom1"], b["geom2"], b["dim"]) for b in od.contacts()[:19]])
+    assert all(any(key == o for o in it) for key in [(a["geom1"], a["geom2"], a["dim"]) for a in hb.contacts(0)])
+    assert np.isfinite(hb.get("qacc")).all()
+    hb.forward()
+    assert hb.get("overflow")[0] == 2 * ov[0]                         # the counter accumulates over launches
