@@ -577,6 +577,128 @@ __device__ __forceinline__ float chol_solve(const float* L, const float* invdiag
   return x;
 }
 
+// ---- blocked Cholesky on the LDS matrix for the configurations beyond one 16 x 16 tile (nv up to 64) ----------------------------------------
+// The column-by-column factorisation above pays one LDS round trip and one dependent dot-product chain per column (37 of them for the
+// PickPlace model, three factorisations per substep plus one per Newton iteration).  Here the matrix is walked in 16-column blocks:
+//   (1) the diagonal block is factored in registers (the DPP Cholesky of the one-tile configurations, every index a compile-time constant),
+//   (2) the rows below it are solved against that block, one row per lane (x L_bb^T = a: 16 steps on uniform factor entries),
+//   (3) the trailing tiles take A_IJ -= L_Ib L_Jb^T on the matrix cores (16 x 16 x 4 f32 MFMA, four per tile),
+// i.e. three block steps and ~a dozen LDS round trips for 48 dofs.  Layout and conventions of chol_inplace(): strictly lower triangle = L,
+// invdiag[k] = 1 / L[k][k]; rows / columns n .. 16 ceil(n / 16) - 1 must hold identity padding (every caller's matrix does).
+template <int J>
+struct RcholStepF {   // RcholStep with chol_inplace()'s fp32 safeguard: a pivot that cancelled below 1e-6 of its original diagonal entry is floored there
+  static __device__ __forceinline__ void run(float (&a)[16], float (&inv)[16], int row, float& own, float d0) {
+    if constexpr (J < 16) {
+      const float piv = fmaxf(rbcast<J>(a[J]), 1.0e-6f * rbcast<J>(d0));
+      const float iv = rsqrtf(fmaxf(piv, FMIN));
+      inv[J] = iv;
+      own = row == J ? iv : own;
+      const float lij = a[J] * iv;
+      a[J] = lij;
+      RcholUpd<16, J, J + 1>::run(a, lij);
+      RcholStepF<J + 1>::run(a, inv, row, own, d0);
+    }
+  }
+};
+template <int NVP>
+__device__ __forceinline__ void bchol_inplace(float* H, float* invdiag, int n, int lane) {
+  const int nb = (n + 15) >> 4, r = lane & 15, q = lane >> 4;
+  const float dorig = H[(lane < 16 * nb ? lane : 0) * NVP + (lane < 16 * nb ? lane : 0)];   // original diagonal (pivot floor)
+  for (int b = 0; b < nb; b++) {
+    const int c0 = 16 * b;
+    // (1) diagonal block: row r in lanes r, 16 + r, 32 + r, 48 + r
+    float hr[16], hinv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) hr[k] = H[(c0 + r) * NVP + c0 + k];
+    const int ro = opaque_lane(r);
+    float own = 0.f;
+    RcholStepF<0>::run(hr, hinv, ro, own, __shfl(dorig, c0 + r));
+    rchol_mask_lower<16>(hr, ro);
+    SYNC();
+    if (lane < 16) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) H[(c0 + lane) * NVP + c0 + k] = hr[k];   // strictly lower part of L_bb (diagonal and above: zeros, never read)
+      invdiag[c0 + lane] = own;
+    }
+    if (b + 1 == nb) break;
+    // (2) panel below the block: lane = row c0 + 16 + lane; x_k = (a_k - sum_{m<k} x_m L[k][m]) / L[k][k], factor entries from the holder lanes
+    const int prow = c0 + 16 + lane;
+    const bool pact = prow < 16 * nb;
+    float x[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = H[(pact ? prow : 0) * NVP + c0 + k];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+#pragma unroll
+      for (int mm = 0; mm < k; mm++) x[k] = fmaf(-x[mm], bcast(hr[mm], k), x[k]);   // hr[mm] of lane k = L[k][mm]
+      x[k] *= hinv[k];
+    }
+    SYNC();
+    if (pact) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) H[prow * NVP + c0 + k] = x[k];
+    }
+    SYNC();
+    // (3) trailing tiles (I, J), b < J <= I < nb: A_IJ -= L_Ib L_Jb^T
+    for (int I = b + 1; I < nb; I++)
+      for (int Jb = b + 1; Jb <= I; Jb++) {
+        v4f acc;
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[v] = H[(16 * I + 4 * q + v) * NVP + 16 * Jb + r];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(-H[(16 * I + r) * NVP + c0 + 4 * c + q], H[(16 * Jb + r) * NVP + c0 + 4 * c + q], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; v++) H[(16 * I + 4 * q + v) * NVP + 16 * Jb + r] = acc[v];
+      }
+    SYNC();
+  }
+  SYNC();
+}
+// x: per-lane value (lane i < n holds b_i, 0 beyond); returns (L L^T)^-1 b, component i in lane i.  Block forward / backward substitution on the
+// factor bchol_inplace() left in LDS: the 16 x 16 diagonal solves run in registers (mask-free DPP steps), the off-diagonal parts are 16-term
+// row / column products per lane.
+template <int NVP>
+__device__ __forceinline__ float bchol_solve(const float* H, const float* invdiag, float x, int n, int lane) {
+  const int nb = (n + 15) >> 4, r = lane & 15;
+  if (lane >= n) x = 0.f;
+  // forward: L y = b
+  for (int b = 0; b < nb; b++) {
+    const int c0 = 16 * b;
+    float lr[16], inv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lr[k] = H[(c0 + r) * NVP + c0 + k]; inv[k] = invdiag[c0 + k]; }
+    const float yb = rchol_fwd_m<16>(lr, inv, invdiag[c0 + r], __shfl(x, c0 + r));   // component r of block b in every lane with lane & 15 == r
+    if ((lane >> 4) == b) x = yb;
+    if (b + 1 < nb) {   // rows below the block: x_i -= sum_k L[i][c0 + k] y_k  (y_k = lane k of the caller's own 16-lane row)
+      const bool below = lane >= c0 + 16 && lane < 16 * nb;
+      float row[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) row[k] = H[(below ? lane : c0) * NVP + c0 + k];
+      const float acc = dot_rows<16>(row, yb);
+      if (below) x -= acc;
+    }
+  }
+  // backward: L^T z = y
+  for (int b = nb - 1; b >= 0; b--) {
+    const int c0 = 16 * b;
+    float lt[16], inv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lt[k] = k > r ? H[(c0 + k) * NVP + c0 + r] : 0.f; inv[k] = invdiag[c0 + k]; }
+    const float zb = RcholBwdM<16, 15>::run(lt, inv, __shfl(x, c0 + r)) * invdiag[c0 + r];
+    if ((lane >> 4) == b) x = zb;
+    if (b > 0) {        // rows above the block: x_i -= sum_k L[c0 + k][i] z_k
+      const bool above = lane < c0;
+      float colv[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) colv[k] = H[(c0 + k) * NVP + (above ? lane : 0)];
+      const float acc = dot_rows<16>(colv, zb);
+      if (above) x -= acc;
+    }
+  }
+  return lane < n ? x : 0.f;
+}
+
 // solve SPD N x N system A x = b in registers (N <= 6), evaluated uniformly by every lane
 template <int N>
 __device__ __forceinline__ void spd_solve_small(const float* A, const float* b, float* x) {
@@ -1202,19 +1324,14 @@ struct Sim {
     }
     SYNC();
     const float hd = lane < nv ? opt_h * K.damping : 0.f;
-    for (int e = lane; e < nv * nv; e += 64) {
-      const int i = e / nv, j = e - i * nv;
-      const float v = sm.M[i * NVP + j];
-      sm.L[i * NVP + j] = v;
-      if constexpr (SM::HAS_LE_) sm.Le[i * NVP + j] = v;
+    (void)hd;
+    const int nvt = (nv + 15) & ~15;   // whole 16-column blocks (the padding rows / columns of M are identity): what the blocked factorisation walks
+    for (int e = lane; e < nvt * nvt; e += 64) {
+      const int i = e / nvt, j = e - i * nvt;
+      sm.L[i * NVP + j] = sm.M[i * NVP + j];
     }
     SYNC();
-    if constexpr (SM::HAS_LE_) {
-      if (lane < nv) sm.Le[lane * NVP + lane] += hd;
-      SYNC();
-    }
-    chol_inplace<NVP>(sm.L, sm.invdiag, nv, lane);
-    if constexpr (SM::HAS_LE_) chol_inplace<NVP>(sm.Le, sm.invdiag_e, nv, lane);
+    bchol_inplace<NVP>(sm.L, sm.invdiag, nv, lane);
   }
 
   __device__ __forceinline__ void crb() {
@@ -2130,7 +2247,7 @@ struct Sim {
       sm.qfrc_smooth[lane] = qs;
     }
     float as;
-    if constexpr (!FAST) as = chol_solve<NVP>(sm.L, sm.invdiag, lane < nv ? qs : 0.f, nv, lane);
+    if constexpr (!FAST) as = bchol_solve<NVP>(sm.L, sm.invdiag, lane < nv ? qs : 0.f, nv, lane);
     else {
       float lr[NV16], lt[NV16], linv[NV16];
       const int rr = lane & (NV16 - 1);
@@ -2152,12 +2269,13 @@ struct Sim {
       // the factor of M + h diag(damping) is not kept in this configuration: build it in the solver's (now free) work matrix
       const float hd = lane < nv ? h * K.damping : 0.f;
       SYNC();
-      for (int e = lane; e < nv * nv; e += 64) { const int i = e / nv, j = e - i * nv; sm.H[i * NVP + j] = sm.M[i * NVP + j]; }
+      const int nvt = (nv + 15) & ~15;
+      for (int e = lane; e < nvt * nvt; e += 64) { const int i = e / nvt, j = e - i * nvt; sm.H[i * NVP + j] = sm.M[i * NVP + j]; }
       SYNC();
       if (lane < nv) sm.H[lane * NVP + lane] += hd;
       SYNC();
-      chol_inplace<NVP>(sm.H, sm.invdiag_e, nv, lane);
-      qa = chol_solve<NVP>(sm.H, sm.invdiag_e, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, nv, lane);
+      bchol_inplace<NVP>(sm.H, sm.invdiag_e, nv, lane);
+      qa = bchol_solve<NVP>(sm.H, sm.invdiag_e, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, nv, lane);
     } else if constexpr (!FAST) qa = chol_solve<NVP>(sm.Le, sm.invdiag_e, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, nv, lane);
     else {
       // register Cholesky of M + h diag(damping) (row r in lanes r, 16 + r, ...: K is fetched per 16-lane row); the transposed rows go through
@@ -2661,6 +2779,7 @@ struct Sim {
   __device__ __forceinline__ float jt_times_force(int nch) {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
+      if (t > 0 && 16 * t >= m.nv) continue;   // tile without dofs
       v4f acc = {0.f, 0.f, 0.f, 0.f};
       if constexpr (FAST) {   // four row chunks per trip (rows >= nefc of J and e_force are zero up to row 63)
         for (int c0 = 0; c0 < nch; c0 += 4) {
@@ -2683,7 +2802,7 @@ struct Sim {
 
   __device__ __forceinline__ void solve_newton() {
     const int nv = m.nv, n = sm.nefc;
-    const int nch = (n + 3) >> 2;
+    const int nch = (n + 3) >> 2, nvt = (nv + 15) & ~15;
     const float scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
     const float tolerance = m.tolerance;
     // ---- per-lane row data (NSLOT rows per lane)
@@ -2806,7 +2925,7 @@ struct Sim {
           const float* Jo = sm.J + w_.row * JS;
           const float* Jh = sm.J + (state[s] == ST_CONE ? w_.head : w_.row) * JS;
           float* Wo = sm.u.W + w_.row * JS;
-          for (int k = 0; k < NV16; k++) {
+          for (int k = 0; k < nvt; k++) {   // only the 16-column tiles that hold dofs (the products below skip the others)
             float w = dq * Jo[k];
 #pragma unroll
             for (int k2 = 0; k2 < CD; k2++) if (k2 < w_.dim) w = fmaf(hk[k2], Jh[k2 * JS + k], w);   // hk = 0 outside the cone state
@@ -2818,11 +2937,13 @@ struct Sim {
       float sk;
       SUBMARK(RP_X3);
       if constexpr (!FAST) {
-        // H = M + J^T W as NT x NT MFMA tiles, factorised in place on the LDS matrix (H aliases the dead factor of M)
+        // H = M + J^T W as NT x NT MFMA tiles, factorised in place on the LDS matrix (H aliases the dead factor of M); tiles beyond the
+        // model's dofs (37 of 64 in the PickPlace model: 7 of 16 tile pairs) are neither formed nor read
 #pragma unroll
         for (int ti = 0; ti < NT; ti++)
 #pragma unroll
           for (int tj = 0; tj < NT; tj++) {
+            if (16 * ti >= nv || 16 * tj >= nv) continue;
             v4f acc;
 #pragma unroll
             for (int v = 0; v < 4; v++) acc[v] = sm.M[(16 * ti + 4 * (lane >> 4) + v) * NVP + 16 * tj + (lane & 15)];
@@ -2832,8 +2953,8 @@ struct Sim {
             for (int v = 0; v < 4; v++) sm.H[(16 * ti + 4 * (lane >> 4) + v) * NVP + 16 * tj + (lane & 15)] = acc[v];
           }
         SYNC();
-        chol_inplace<NVP>(sm.H, sm.invdiag, nv, lane);
-        sk = chol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -gk : 0.f, nv, lane);
+        bchol_inplace<NVP>(sm.H, sm.invdiag, nv, lane);
+        sk = bchol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -gk : 0.f, nv, lane);
         if (lane >= nv) sk = 0.f;
       } else {
         v4f acc = Macc;
