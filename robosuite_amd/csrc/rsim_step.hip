@@ -2264,7 +2264,14 @@ struct Sim {
     const LaneConst K = fetchK();
     const int nv = m.nv;
     const float h = opt_h;
+    // Implicit joint damping (MuJoCo's Euler [3P]): qacc' = (M + hD)^-1 (qfrc_smooth + qfrc_constraint).  At the solver's optimum the right-hand side
+    // IS M qacc, so qacc' = qacc - (M + hD)^-1 (hD qacc) -- the form used here.  In exact arithmetic and with a converged solver the two are the
+    // same number; in fp32 they are not equally good: constraint forces are f = -D (J qacc - aref) with D up to 1e6 on a residual that cancels
+    // to 1e-7 relative, i.e. good to ~1 % on a stiff contact, and Jt f divided by the 1e-4 kg m^2 inertia of an object (or the 5e-5 of a
+    // Robotiq link) turned that into hundreds of rad/s^2 -- the traced cause of the PickPlace envs that hit the bad-state guard.  qacc itself
+    // comes out of the Newton solve filtered by H^-1 (H = M + Jt D J, large in exactly those directions) and is accurate to rounding.
     float qa;
+    const float acc_own = lane < nv ? sm.qacc[lane] : 0.f;
     if constexpr (!FAST && !SM::HAS_LE_) {
       // the factor of M + h diag(damping) is not kept in this configuration: build it in the solver's (now free) work matrix
       const float hd = lane < nv ? h * K.damping : 0.f;
@@ -2275,7 +2282,7 @@ struct Sim {
       if (lane < nv) sm.H[lane * NVP + lane] += hd;
       SYNC();
       bchol_inplace<NVP>(sm.H, sm.invdiag_e, nv, lane);
-      qa = bchol_solve<NVP>(sm.H, sm.invdiag_e, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, nv, lane);
+      qa = acc_own - bchol_solve<NVP>(sm.H, sm.invdiag_e, hd * acc_own, nv, lane);
     } else if constexpr (!FAST) qa = chol_solve<NVP>(sm.Le, sm.invdiag_e, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, nv, lane);
     else {
       // register Cholesky of M + h diag(damping) (row r in lanes r, 16 + r, ...: K is fetched per 16-lane row); the transposed rows go through
@@ -2296,7 +2303,7 @@ struct Sim {
       SYNC();
 #pragma unroll
       for (int k = 0; k < NV16; k++) et[k] = sm.H[k * NVP + rr];
-      qa = rchol_solve_m<NV16>(er, et, einv, eown, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f);
+      qa = acc_own - rchol_solve_m<NV16>(er, et, einv, eown, lane < nv ? hd * acc_own : 0.f);
     }
     if (lane < nv) { sm.qvel[lane] += h * qa; sm.qacc_ws[lane] = sm.qacc[lane]; }
     SYNC();

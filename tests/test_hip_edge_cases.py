@@ -131,11 +131,10 @@ def test_long_random_rollouts_stay_finite_on_every_configuration(name, tag, mode
             assert float(rew.min()) >= 0.0 and float(rew.max()) <= 1.0 + 1e-6
     assert ndone == B                                  # one horizon crossing per env
     assert np.isfinite(env.env.batch.get("qpos")).all() and np.isfinite(env.env.batch.get("qvel")).all()
-    # MuJoCo's bad-state guard (RSIM_DIVERGED) must stay silent on the table-top tasks.  PickPlace under full-range random actions drives the
-    # closed Robotiq gripper (5e-5 kg m^2 links, no damping) into the bin at > 10 rad/s with 80 constraint rows: the fp64 oracle rides such states
-    # out, the fp32 kernel occasionally does not; the guard then puts the env back to qpos0 as MuJoCo does with a diverged state.
-    nbad = int((env.env.batch.get("diverged") > 0).sum())
-    assert nbad == 0 if name != "PickPlace" else nbad <= max(2, B // 50)
+    # MuJoCo's bad-state guard (RSIM_DIVERGED) must stay silent on every configuration, PickPlace included (the closed Robotiq gripper rammed into
+    # the bins with 80 constraint rows used to lose 1 env in 128: constraint forces good to 1 % only in fp32, divided by 5e-5 kg m^2 in the
+    # integrator; the Euler step now integrates the solver's acceleration)
+    assert int((env.env.batch.get("diverged") > 0).sum()) == 0
 
 
 def test_contact_and_row_overflow_is_counted_not_silent():

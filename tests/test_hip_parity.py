@@ -242,7 +242,7 @@ def test_baxter_model_forward_quantities_with_contacts_match_oracle():
             # differently in fp32 and fp64 and the two runs end on different (equally valid) portals.  So: most contacts agree to rounding,
             # every contact agrees to 5% of its depth + 0.5 mm.
             d = abs(a["dist"] - b["dist"])
-            assert d < 5e-4 + 5e-2 * abs(b["dist"]), (it, a["geom1"], a["geom2"])
+            assert d < 5e-5 + 2e-2 * abs(b["dist"]), (it, a["geom1"], a["geom2"])   # measured: max 5.7e-3 relative (median 3.5e-6) with MPR in geom-relative coordinates
             tight += d < 2e-6 + 1e-4 * abs(b["dist"]); total += 1
         if od.ncon == 0:
             assert np.abs(hb.get("qacc")[0] - od.qacc).max() < 2e-4 * max(1.0, np.abs(od.qacc).max())
@@ -411,7 +411,8 @@ def test_pickplace_iiwa_robotiq_model_on_the_64_dof_configuration():
         # arm and objects to the usual tolerance; the undamped 5e-5 kg m^2 finger links under kp = 20 actuators amplify rounding (see the CPU test)
         # ... and the four objects rest on single MPR contact points (MuJoCo's convex-convex default), where they rock at rounding level
         # (the chattering fingers sit at the end of the arm: its joints inherit a fraction of their error)
-        assert dq[arm].max() < 2e-3 and dq[fingers].max() < 5e-2 and dq[~(arm | fingers)].max() < 5e-3, t
+        # measured after the fp32-robust Euler form and the MPR fixes of round 2: arm 1.3e-5, fingers 1.1e-3, objects 1.6e-3
+        assert dq[arm].max() < 2e-4 and dq[fingers].max() < 1e-2 and dq[~(arm | fingers)].max() < 5e-3, t
     assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[1])
 
 
@@ -463,7 +464,7 @@ def test_pickplace_observation_and_reward_epilogue_matches_reference_env():
             if key.endswith("joint_acc"):
                 tol = 2e-2 * max(1.0, np.abs(ref).max())
             elif "gripper_q" in key:
-                tol = 5e-2 if key.endswith("qpos") else 3.0   # undamped 5e-5 kg m^2 finger links (see the physics test of this model)
+                tol = 1e-2 if key.endswith("qpos") else 0.3   # undamped 5e-5 kg m^2 finger links (see the physics test of this model); measured 1e-3 / 3e-2
             else:
                 tol = 5e-3 if (key.endswith("vel") or key[:4] in ("Milk", "Brea", "Cere", "Can_")) else 2e-3   # arm keys: see the physics test of this model
             if "quat" in key:
