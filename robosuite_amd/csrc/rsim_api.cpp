@@ -41,6 +41,12 @@ extern "C" int rsim_launch_prepare_cfg2(const DModel* m, const DBatch* b, int nb
 extern "C" int rsim_cmem_bytes_cfg2(void);
 extern "C" int rsim_launch_prepare_cfg3(const DModel* m, const DBatch* b, int nblocks, int reset_only, hipStream_t stream);
 extern "C" int rsim_cmem_bytes_cfg3(void);
+extern "C" int rsim_launch_reset_obs_cfg0(const DModel* m, const DBatch* b, hipStream_t stream);
+extern "C" int rsim_launch_reset_obs_cfg1(const DModel* m, const DBatch* b, hipStream_t stream);
+extern "C" int rsim_launch_reset_obs_cfg2(const DModel* m, const DBatch* b, hipStream_t stream);
+extern "C" int rsim_launch_reset_obs_cfg3(const DModel* m, const DBatch* b, hipStream_t stream);
+typedef int (*resetobs_fn)(const DModel*, const DBatch*, hipStream_t);
+static const resetobs_fn k_reset_obs_launch[4] = {rsim_launch_reset_obs_cfg0, rsim_launch_reset_obs_cfg1, rsim_launch_reset_obs_cfg2, rsim_launch_reset_obs_cfg3};
 typedef int (*prepare_fn)(const DModel*, const DBatch*, int, int, hipStream_t);
 typedef int (*cmem_fn)(void);
 static const prepare_fn k_prepare_launch[RSIM_NCFG] = {rsim_launch_prepare_cfg0, rsim_launch_prepare_cfg1, rsim_launch_prepare_cfg2, rsim_launch_prepare_cfg3};
@@ -870,7 +876,7 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
       // state, no reward.  The terminal record of the finished episode was moved to RSIM_TERMINAL_OBS by the control step.
       DBatch db2 = b->db;
       db2.order = nullptr; db2.cost = nullptr;
-      e = k_step_launch[b->cfg](&b->dm, &db2, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_OBS | RF_RESET_ONLY, b->stream);
+      e = k_reset_obs_launch[b->cfg](&b->dm, &db2, b->stream);
       if (e) return fail("reset-observation kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
   }

@@ -1040,8 +1040,11 @@ struct Sim {
 
   // ---------------------------------------------------------------- once per launch: the few uniform options, LDS padding, resident hulls
   __device__ __forceinline__ void load_opt() {
-    opt_h = cmf(MK_opt)->opt[0]; opt_grav = v3(cmf(MK_opt)->opt[1], cmf(MK_opt)->opt[2], cmf(MK_opt)->opt[3]); opt_density = cmf(MK_opt)->opt[4]; opt_viscosity = cmf(MK_opt)->opt[5];
-    opt_impratio = cmf(MK_opt)->opt[6]; opt_wind = v3(cmf(MK_opt)->opt[7], cmf(MK_opt)->opt[8], cmf(MK_opt)->opt[9]);
+    // wave-uniform options: made scalar (SGPR) explicitly -- as vector registers they stay live over the whole launch and push other values into the private segment
+    cmr_t co = cmf(MK_opt);
+    auto su = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
+    opt_h = su(co->opt[0]); opt_grav = v3(su(co->opt[1]), su(co->opt[2]), su(co->opt[3])); opt_density = su(co->opt[4]); opt_viscosity = su(co->opt[5]);
+    opt_impratio = su(co->opt[6]); opt_wind = v3(su(co->opt[7]), su(co->opt[8]), su(co->opt[9]));
   }
   __device__ __forceinline__ void init_lds() {
     // zero the LDS regions whose padding lanes / columns are read but never written
@@ -2381,9 +2384,13 @@ struct Sim {
 #pragma unroll
     for (int i = 0; i < 6; i++) {   // OSC_POSITION (cdim 3): zero orientation delta, osc.py:255-263
       if (i < c.cdim) {
-        float scale = fabsf(c.out_max[AO + i] - c.out_min[AO + i]) / fabsf(c.in_max[AO + i] - c.in_min[AO + i]);
-        float a = fmaxf(c.in_min[AO + i], fminf(c.in_max[AO + i], action[i]));
-        sc[i] = (a - 0.5f * (c.in_max[AO + i] + c.in_min[AO + i])) * scale + 0.5f * (c.out_max[AO + i] + c.out_min[AO + i]);
+        // the limits are kernel arguments: without the opaque copies the 18 derived constants are computed at kernel entry and parked in the
+        // private segment until this (once per launch) call -- 100 bytes of scratch per lane, 40 MB of HBM writes per launch
+        float omax = c.out_max[AO + i], omin = c.out_min[AO + i], imax = c.in_max[AO + i], imin = c.in_min[AO + i];
+        asm volatile("" : "+s"(omax), "+s"(omin), "+s"(imax), "+s"(imin));
+        float scale = fabsf(omax - omin) / fabsf(imax - imin);
+        float a = fmaxf(imin, fminf(imax, action[i]));
+        sc[i] = (a - 0.5f * (imax + imin)) * scale + 0.5f * (omax + omin);
       } else sc[i] = 0.f;
     }
     V3 op = ld3(sm.spos + 3 * base_site), ep = ld3(sm.spos + 3 * eef_site);
@@ -3240,17 +3247,17 @@ struct Sim {
 // the step kernel
 // ------------------------------------------------------------------------------------------------------------
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
-__global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
+__device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, const float* __restrict__ actions, int n_sub, int flags) {
   typedef Smem<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> SM;
   const int lane = threadIdx.x;
   if ((int)blockIdx.x >= b.B) return;
   // workgroups are dispatched in index order: handing the envs that were slowest in the previous launch to the first workgroups
   // (contact-rich envs stay contact-rich for many control steps) keeps the last wave of envs short
-  const int env = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
+  const int env = uni(b.order ? b.order[blockIdx.x] : (int)blockIdx.x);   // scalar: every per-env base address below then lives in SGPRs
   // RF_RESET_ONLY: the pass that follows a control step and produces the observation MujocoEnv.reset() returns (forward + epilogue, no reward)
   // for the envs that step re-initialised from the reset bank; every other workgroup leaves at once
   if ((flags & RF_RESET_ONLY) && !b.needs_reset[env]) return;
-  const long long t_launch = b.cost ? clock64() : 0;
+  const unsigned t_launch = b.cost ? (unsigned)uni((int)(clock64() >> 6)) : 0u;   // 64-tick units, scalar
   const float* fp = m.ft + (size_t)env * m.fstride;
   Sim<SM> sim(m, fp, lane, b.prof, b.cm, b.cm_stride ? (const char*)b.cm_env + (size_t)env * b.cm_stride : (const char*)b.cm);
   sim.pf.acc = b.prof_env < 0 || b.prof_env == env;
@@ -3274,7 +3281,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   sim.load_opt();
   sim.init_lds();
   const float* act = actions ? actions + (size_t)env * m.ctrl.action_dim : nullptr;
-  float time = b.time[env];
+  float time = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, b.time[env])));   // wave-uniform, carried over all substeps: a scalar register
   if ((flags & RF_CTRL) && b.needs_reset[env]) {
     // this env was re-initialised on the device when its previous episode ended: fresh controller objects (robots/robot.py:271)
     V3 xp0; Q4 xq0;
@@ -3312,7 +3319,11 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
     sim.pf.mark(RP_VEL);
     if (flags & RF_CTRL) {
       sim.phase();
-      if ((flags & RF_SETGOAL) && sub == 0 && act) sim.ctrl_set_goal(act);
+      if ((flags & RF_SETGOAL) && sub == 0 && act) {
+        const float* act0 = act;
+        asm volatile("" : "+s"(act0));   // opaque: keeps the action scaling from being precomputed at kernel entry and parked in the private segment until here
+        sim.ctrl_set_goal(act0);
+      }
       sim.ctrl_run();
       sim.pf.mark(RP_CTRL);
     }
@@ -3385,7 +3396,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
   if (lane < csl) sim.cst[lane] = sm.cstate[lane];
   if (lane == 0) b.time[env] = time;
   if (b.overflow && lane == 0 && sim.ovf) b.overflow[env] += sim.ovf;
-  if (b.cost && lane == 0) b.cost[env] = (unsigned)((clock64() - t_launch) >> 6);
+  if (b.cost && lane == 0) b.cost[env] = (unsigned)(clock64() >> 6) - t_launch;
   if (b.prof && lane == 0) {
     unsigned long long* wl = b.prof + RP_COUNT + 8 * (size_t)env;
     wl[3] = wall_clock64(); wl[4] = sim.pf.c_mpr; wl[5] = sim.pf.c_support; wl[6] = sim.pf.c_newton; wl[7] = sim.pf.c_cand;
@@ -3415,6 +3426,17 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
       for (int i = lane; i < sm.nefc; i += 64) b.efc_force[(size_t)env * NEFC + i] = sm.e_force[i];
     if (lane == 0) { b.ncon[env] = ncon; b.nefc[env] = sm.nefc; b.niter[env] = sm.niter; }
   }
+}
+
+template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
+__global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
+  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR>(m, b, actions, n_sub, flags);
+}
+// The reset-observation pass that follows a control step (forward + observables for the envs it re-initialised, no reward): the same body under
+// its own kernel name, so that per-kernel profiles of k_step hold control steps only (and the constant flags strip controller / integrator code)
+template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
+__global__ __launch_bounds__(64) void k_reset_obs(DModel m, DBatch b) {
+  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR>(m, b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_OBS | RF_RESET_ONLY);
 }
 
 // controller reset kernel: forward kinematics then OSC.reset_goal / initial_joint capture
@@ -3626,9 +3648,14 @@ extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out,
 template __global__ void k_step<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
 template __global__ void k_ctrl_reset<RSIM_DIMS>(DModel, DBatch, const unsigned char*);
 template __global__ void k_prepare<RSIM_DIMS>(DModel, DBatch, int);
+template __global__ void k_reset_obs<RSIM_DIMS>(DModel, DBatch);
 
 extern "C" int RSIM_SYM(rsim_launch_step)(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream) {
   hipLaunchKernelGGL((k_step<RSIM_DIMS>), dim3(b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
+  return (int)hipGetLastError();
+}
+extern "C" int RSIM_SYM(rsim_launch_reset_obs)(const DModel* m, const DBatch* b, hipStream_t stream) {
+  hipLaunchKernelGGL((k_reset_obs<RSIM_DIMS>), dim3(b->B), dim3(64), 0, stream, *m, *b);
   return (int)hipGetLastError();
 }
 extern "C" int RSIM_SYM(rsim_launch_ctrl_reset)(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream) {
