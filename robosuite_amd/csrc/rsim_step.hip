@@ -272,7 +272,7 @@ struct Smem {
     struct { float cvel[NB * 9]; union { struct { float cvb[NV * 9], cdd[NV * 9]; }; float cacc[NB * 9]; };
              union { float cf[NB * 17]; float F[NV * 17]; }; } v;                          // velocity(): later stages overwrite dead earlier ones
     struct { float cvel[NB * 9]; float Jm[48], Li[36], vv[8], Lt[64], Ys[128]; } k;                  // ctrl_run(): cvel stays live from velocity()
-    float W[NEFC * (NV + 1)];                                                              // solve_newton(): Hessian-weighted rows
+    float W[NV == 16 ? NEFC * (NV + 1) : NEFC * 5];                                        // solve_newton(): Hessian-weighted rows (one-tile configurations); wide: five words per row (four block coefficients, block head | dim | cone flag) from which the products form the weighted row on the fly
   } u;
   float M[NV * NVP];
   union { float L[NV * NVP]; float H[NV * NVP]; };  // L (factor of M) is dead once qacc_smooth exists; H is the solver / Euler work matrix
@@ -2696,20 +2696,27 @@ struct Sim {
   // sum_k r[k] * x_k.  One-tile configuration: x is replicated in every 16-lane row (DPP row broadcast); wide: x_k lives in lane k (readlane)
   __device__ __forceinline__ float row_dot(const Row& rw, float x) const {
     if constexpr (FAST) return dot_rows<NV16>(rw.J, x);
-    else {
-      const float* Jr = sm.J + rw.row * JS;
-      float acc = 0.f;
-      for (int k = 0; k < m.nv; k++) acc = fmaf(Jr[k], bcast(x, k), acc);
-      return acc;
+    else return lds_row_dot(sm.J + rw.row * JS, x);
+  }
+  // wide configurations: sum_k p[k] x_k over the 16-column tiles that hold dofs (columns nv .. 16 ceil(nv / 16) - 1 hold zeros, x_k = 0 there).
+  // One wavefront per SIMD and nothing else to switch to: a read-then-use loop pays the full LDS latency per element, so the sixteen reads of a
+  // tile are issued back to back and consumed afterwards.
+  __device__ __forceinline__ float lds_row_dot(const float* p, float x) const {
+    float acc = 0.f;
+    for (int k0 = 0; k0 < m.nv; k0 += 16) {
+      float a[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) a[u] = p[k0 + u];
+#pragma unroll
+      for (int u = 0; u < 16; u++) acc = fmaf(a[u], bcast(x, k0 + u), acc);
     }
+    return acc;
   }
   // (M x)_i for the dof of this lane
   __device__ __forceinline__ float mass_dot(const float (&Mr)[FAST ? NV16 : 1], float x) const {
     if constexpr (FAST) return dot_rows<NV16>(Mr, x);
     else {
-      const float* Mi = sm.M + (lane < m.nv ? lane : 0) * NVP;
-      float acc = 0.f;
-      for (int k = 0; k < m.nv; k++) acc = fmaf(Mi[k], bcast(x, k), acc);
+      const float acc = lds_row_dot(sm.M + (lane < m.nv ? lane : 0) * NVP, x);
       return lane < m.nv ? acc : 0.f;
     }
   }
@@ -2790,10 +2797,108 @@ struct Sim {
     }
   }
   // out_k (lane k < 16) = sum_r J[r][k] * f_r  on the matrix cores; f_r must already be in sm.e_force[0..4*nch)
+  // wide configurations: every dof tile of a row chunk from one batch of reads, two chunks per trip (rows nefc .. NEFC - 1 of J and e_force hold zeros)
+  template <int NBT>
+  __device__ __forceinline__ void jtf_wide(int nch) {
+    if constexpr (NBT <= NT) {
+      v4f acc[NBT];
+#pragma unroll
+      for (int t = 0; t < NBT; t++) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+      const int q = lane >> 4, col = lane & 15;
+      for (int c0 = 0; c0 < nch; c0 += 2) {
+        float ja[2][NBT], fb[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int r = 4 * (c0 + u) + q;
+          fb[u] = sm.e_force[r];
+#pragma unroll
+          for (int t = 0; t < NBT; t++) ja[u][t] = sm.J[r * JS + 16 * t + col];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+          for (int t = 0; t < NBT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ja[u][t], fb[u], acc[t], 0, 0, 0);
+      }
+      if (col == 0) {
+#pragma unroll
+        for (int t = 0; t < NBT; t++) { float* o = sm.red + 16 * t + 4 * q; o[0] = acc[t][0]; o[1] = acc[t][1]; o[2] = acc[t][2]; o[3] = acc[t][3]; }
+      }
+    }
+  }
+  // wide configurations: H = M + J^T W for the NBT (NBT + 1) / 2 lower tiles at once.  W is never stored: a chunk of four rows reads its
+  // staged coefficients (prefetched one chunk ahead), its J rows (the B operands, and the A operands of rows outside the cone state) and -- only
+  // if the chunk holds a cone-state row -- the other rows of those blocks, all in one batch, and then issues the tile products on independent
+  // accumulators.  Same products in the same order as the stored-W form it replaces.
+  template <int NBT>
+  __device__ __forceinline__ void hess_wide(int nch) {
+    if constexpr (NBT <= NT) {
+      constexpr int NTL = NBT * (NBT + 1) / 2;
+      const int q = lane >> 4, col = lane & 15;
+      v4f acc[NTL];
+      {
+        int t = 0;
+#pragma unroll
+        for (int ti = 0; ti < NBT; ti++)
+#pragma unroll
+          for (int tj = 0; tj <= ti; tj++, t++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[t][v] = sm.M[(16 * ti + 4 * q + v) * NVP + 16 * tj + col];
+      }
+      float cf[4];
+      int bd;
+      {
+        const float* o = sm.u.W + 5 * q;
+        cf[0] = o[0]; cf[1] = o[1]; cf[2] = o[2]; cf[3] = o[3]; bd = ((const int*)o)[4];
+      }
+      for (int c = 0; c < nch; c++) {
+        const int r = 4 * c + q;
+        float cfn[4];
+        int bdn;
+        {
+          const float* o = sm.u.W + 5 * (r + 4 < NEFCAP ? r + 4 : r);   // next chunk's coefficients
+          cfn[0] = o[0]; cfn[1] = o[1]; cfn[2] = o[2]; cfn[3] = o[3]; bdn = ((const int*)o)[4];
+        }
+        float bj[NBT], aj[NBT];
+#pragma unroll
+        for (int t = 0; t < NBT; t++) bj[t] = sm.J[r * JS + 16 * t + col];
+        if (__ballot((bd >> 16) & 1)) {
+          const int head = bd & 255, dm1 = ((bd >> 8) & 7) - 1;
+          const float* j0 = sm.J + head * JS + col;
+          const int o1 = (dm1 < 1 ? dm1 : 1) * JS, o2 = (dm1 < 2 ? dm1 : 2) * JS, o3 = (dm1 < 3 ? dm1 : 3) * JS;
+          float x0[NBT], x1[NBT], x2[NBT], x3[NBT];
+#pragma unroll
+          for (int t = 0; t < NBT; t++) { x0[t] = j0[16 * t]; x1[t] = j0[o1 + 16 * t]; x2[t] = j0[o2 + 16 * t]; x3[t] = j0[o3 + 16 * t]; }
+#pragma unroll
+          for (int t = 0; t < NBT; t++) aj[t] = fmaf(cf[3], x3[t], fmaf(cf[2], x2[t], fmaf(cf[1], x1[t], cf[0] * x0[t])));
+        } else {
+#pragma unroll
+          for (int t = 0; t < NBT; t++) aj[t] = cf[0] * bj[t];
+        }
+        {
+          int t = 0;
+#pragma unroll
+          for (int ti = 0; ti < NBT; ti++)
+#pragma unroll
+            for (int tj = 0; tj <= ti; tj++, t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[ti], bj[tj], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) cf[k] = cfn[k];
+        bd = bdn;
+      }
+      {
+        int t = 0;
+#pragma unroll
+        for (int ti = 0; ti < NBT; ti++)
+#pragma unroll
+          for (int tj = 0; tj <= ti; tj++, t++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) sm.H[(16 * ti + 4 * q + v) * NVP + 16 * tj + col] = acc[t][v];
+      }
+    }
+  }
   __device__ __forceinline__ float jt_times_force(int nch) {
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-      if (t > 0 && 16 * t >= m.nv) continue;   // tile without dofs
+    for (int t = 0; t < (FAST ? NT : 0); t++) {
       v4f acc = {0.f, 0.f, 0.f, 0.f};
       if constexpr (FAST) {   // four row chunks per trip (rows >= nefc of J and e_force are zero up to row 63)
         for (int c0 = 0; c0 < nch; c0 += 4) {
@@ -2803,10 +2908,16 @@ struct Sim {
 #pragma unroll
           for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ja[u], fb[u], acc, 0, 0, 0);
         }
-      } else
-      for (int c = 0; c < nch; c++)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.J[(4 * c + (lane >> 4)) * JS + 16 * t + (lane & 15)], sm.e_force[4 * c + (lane >> 4)], acc, 0, 0, 0);
-      if ((lane & 15) == 0) { float* o = sm.red + 16 * t + 4 * (lane >> 4); o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; }
+      }
+      if constexpr (FAST) if ((lane & 15) == 0) { float* o = sm.red + 16 * t + 4 * (lane >> 4); o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3]; }
+    }
+    if constexpr (!FAST) {
+      switch ((m.nv + 15) >> 4) {   // dof tiles of this model: a compile-time count keeps the reads of a trip in one batch (no branch per tile)
+        case 1: jtf_wide<1>(nch); break;
+        case 2: jtf_wide<2>(nch); break;
+        case 3: jtf_wide<3>(nch); break;
+        default: jtf_wide<4>(nch); break;
+      }
     }
     SYNC();
     float r = FAST ? sm.red[lane & 15] : (lane < NV16 ? sm.red[lane] : 0.f);
@@ -2819,6 +2930,7 @@ struct Sim {
     const int nch = (n + 3) >> 2, nvt = (nv + 15) & ~15;
     const float scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
     const float tolerance = m.tolerance;
+    const bool two = NSLOT > 1 && n > 64;   // rows in the lanes' second slot (128-row configuration): typical states have none, and then none of its work is done
     // ---- per-lane row data (NSLOT rows per lane)
     Row rw[NSLOT];
 #pragma unroll
@@ -2863,14 +2975,16 @@ struct Sim {
     const float a_sm = rr < nv ? sm.qacc_smooth[rr] : 0.f, a_ws = rr < nv ? sm.qacc_ws[rr] : 0.f, f_sm = rr < nv ? sm.qfrc_smooth[rr] : 0.f;
     float force[NSLOT], jar[NSLOT], uj[NSLOT][CD], T[NSLOT], g[NSLOT];
     int state[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) { force[s] = 0.f; jar[s] = 0.f; T[s] = 0.f; g[s] = 0.f; state[s] = ST_SATISFIED; }
     // residuals of all rows of this lane at acceleration x, then cost / force / state of each (the cone blocks gather their siblings first)
     auto evaluate = [&](float x) -> float {
 #pragma unroll
-      for (int s = 0; s < NSLOT; s++) jar[s] = row_dot(rw[s], x) - rw[s].aref;
+      for (int s = 0; s < NSLOT; s++) if (s == 0 || two) jar[s] = row_dot(rw[s], x) - rw[s].aref;
       gather(rw, jar, uj);
       float c = 0.f;
 #pragma unroll
-      for (int s = 0; s < NSLOT; s++) c += row_update(rw[s], jar[s], force[s], state[s], uj[s], T[s], g[s]);
+      for (int s = 0; s < NSLOT; s++) if (s == 0 || two) c += row_update(rw[s], jar[s], force[s], state[s], uj[s], T[s], g[s]);
       return c;
     };
     // ---- warm start: previous acceleration unless the unconstrained one is cheaper
@@ -2936,14 +3050,13 @@ struct Sim {
 #pragma unroll
           for (int k = 0; k < NV16; k++) sm.u.W[w_.row * JS + k] = w[k];
         } else {
-          const float* Jo = sm.J + w_.row * JS;
-          const float* Jh = sm.J + (state[s] == ST_CONE ? w_.head : w_.row) * JS;
-          float* Wo = sm.u.W + w_.row * JS;
-          for (int k = 0; k < nvt; k++) {   // only the 16-column tiles that hold dofs (the products below skip the others)
-            float w = dq * Jo[k];
-#pragma unroll
-            for (int k2 = 0; k2 < CD; k2++) if (k2 < w_.dim) w = fmaf(hk[k2], Jh[k2 * JS + k], w);   // hk = 0 outside the cone state
-            Wo[k] = w;
+          // weighted row r = sum_k2 coef[k2] J[head + min(k2, dim - 1)]: (D, 0, 0, 0) on the row itself outside the cone state, the row's line of
+          // the block Hessian on the block's rows inside it.  hess_wide() forms it while it feeds the matrix cores.
+          if (s == 0 || two) {
+            float* o = sm.u.W + 5 * w_.row;
+            const bool cone = state[s] == ST_CONE;
+            o[0] = cone ? hk[0] : dq; o[1] = hk[1]; o[2] = hk[2]; o[3] = hk[3];
+            ((int*)o)[4] = cone ? (w_.head | (w_.dim << 8) | (1 << 16)) : (w_.row | (1 << 8));
           }
         }
       }
@@ -2951,21 +3064,15 @@ struct Sim {
       float sk;
       SUBMARK(RP_X3);
       if constexpr (!FAST) {
-        // H = M + J^T W as NT x NT MFMA tiles, factorised in place on the LDS matrix (H aliases the dead factor of M); tiles beyond the
-        // model's dofs (37 of 64 in the PickPlace model: 7 of 16 tile pairs) are neither formed nor read
-#pragma unroll
-        for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-          for (int tj = 0; tj < NT; tj++) {
-            if (16 * ti >= nv || 16 * tj >= nv) continue;
-            v4f acc;
-#pragma unroll
-            for (int v = 0; v < 4; v++) acc[v] = sm.M[(16 * ti + 4 * (lane >> 4) + v) * NVP + 16 * tj + (lane & 15)];
-            for (int c = 0; c < nch; c++)
-              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sm.u.W[(4 * c + (lane >> 4)) * JS + 16 * ti + (lane & 15)], sm.J[(4 * c + (lane >> 4)) * JS + 16 * tj + (lane & 15)], acc, 0, 0, 0);
-#pragma unroll
-            for (int v = 0; v < 4; v++) sm.H[(16 * ti + 4 * (lane >> 4) + v) * NVP + 16 * tj + (lane & 15)] = acc[v];
-          }
+        // H = M + J^T W as MFMA tiles (lower triangle of tiles: the factorisation reads nothing above the diagonal blocks), factorised in place
+        // on the LDS matrix (H aliases the dead factor of M); tiles beyond the model's dofs (37 of 64 in the PickPlace model) are neither
+        // formed nor read
+        switch ((nv + 15) >> 4) {
+          case 1: hess_wide<1>(nch); break;
+          case 2: hess_wide<2>(nch); break;
+          case 3: hess_wide<3>(nch); break;
+          default: hess_wide<4>(nch); break;
+        }
         SYNC();
         bchol_inplace<NVP>(sm.H, sm.invdiag, nv, lane);
         sk = bchol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -gk : 0.f, nv, lane);
@@ -3005,7 +3112,7 @@ struct Sim {
       // ---- line search along sk
       float jv[NSLOT];
 #pragma unroll
-      for (int s = 0; s < NSLOT; s++) jv[s] = row_dot(rw[s], sk);
+      for (int s = 0; s < NSLOT; s++) jv[s] = (s == 0 || two) ? row_dot(rw[s], sk) : 0.f;
       const float mvv = mass_dot(Mr, sk);
       const float q1 = wave_sum(dofl ? sk * (ma - f_sm) : 0.f), q2 = wave_sum(dofl ? 0.5f * sk * mvv : 0.f), sn = sqrtf(wave_sum(dofl ? sk * sk : 0.f));
       if (sn < 1e-15f) break;
@@ -3018,7 +3125,7 @@ struct Sim {
       auto line = [&](float al, float& c, float& c1, float& c2) {
         c = c1 = c2 = 0.f;
 #pragma unroll
-        for (int s = 0; s < NSLOT; s++) { float t, t1, t2; row_ls(rw[s], jar[s], jv[s], g0[s], gvv[s], al, t, t1, t2); c += t; c1 += t1; c2 += t2; }
+        for (int s = 0; s < NSLOT; s++) if (s == 0 || two) { float t, t1, t2; row_ls(rw[s], jar[s], jv[s], g0[s], gvv[s], al, t, t1, t2); c += t; c1 += t1; c2 += t2; }
       };
       {
         float c, c1, c2;
