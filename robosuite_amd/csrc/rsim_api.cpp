@@ -15,7 +15,7 @@
 #include "rsim_internal.h"
 
 // one set of launchers per compiled kernel configuration (rsim_step.hip is built once per RSIM_CFG)
-#define RSIM_NCFG 4
+#define RSIM_NCFG 5
 extern "C" int rsim_launch_step_cfg0(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
 extern "C" int rsim_launch_ctrl_reset_cfg0(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
 extern "C" int rsim_limits_cfg0(int* lim);
@@ -26,13 +26,16 @@ extern "C" int rsim_launch_step_cfg2(const DModel* m, const DBatch* b, const flo
 extern "C" int rsim_launch_ctrl_reset_cfg2(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
 extern "C" int rsim_limits_cfg2(int* lim);
 extern "C" int rsim_launch_step_cfg3(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
+extern "C" int rsim_launch_step_cfg4(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
 extern "C" int rsim_launch_ctrl_reset_cfg3(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
+extern "C" int rsim_launch_ctrl_reset_cfg4(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
 extern "C" int rsim_limits_cfg3(int* lim);
+extern "C" int rsim_limits_cfg4(int* lim);
 typedef int (*step_fn)(const DModel*, const DBatch*, const float*, int, int, hipStream_t);
 typedef int (*creset_fn)(const DModel*, const DBatch*, const unsigned char*, hipStream_t);
 typedef int (*limits_fn)(int*);
-static const step_fn k_step_launch[RSIM_NCFG] = {rsim_launch_step_cfg0, rsim_launch_step_cfg1, rsim_launch_step_cfg2, rsim_launch_step_cfg3};
-static const creset_fn k_creset_launch[RSIM_NCFG] = {rsim_launch_ctrl_reset_cfg0, rsim_launch_ctrl_reset_cfg1, rsim_launch_ctrl_reset_cfg2, rsim_launch_ctrl_reset_cfg3};
+static const step_fn k_step_launch[RSIM_NCFG] = {rsim_launch_step_cfg0, rsim_launch_step_cfg1, rsim_launch_step_cfg2, rsim_launch_step_cfg3, rsim_launch_step_cfg4};
+static const creset_fn k_creset_launch[RSIM_NCFG] = {rsim_launch_ctrl_reset_cfg0, rsim_launch_ctrl_reset_cfg1, rsim_launch_ctrl_reset_cfg2, rsim_launch_ctrl_reset_cfg3, rsim_launch_ctrl_reset_cfg4};
 extern "C" int rsim_launch_prepare_cfg0(const DModel* m, const DBatch* b, int nblocks, int reset_only, hipStream_t stream);
 extern "C" int rsim_cmem_bytes_cfg0(void);
 extern "C" int rsim_launch_prepare_cfg1(const DModel* m, const DBatch* b, int nblocks, int reset_only, hipStream_t stream);
@@ -40,18 +43,21 @@ extern "C" int rsim_cmem_bytes_cfg1(void);
 extern "C" int rsim_launch_prepare_cfg2(const DModel* m, const DBatch* b, int nblocks, int reset_only, hipStream_t stream);
 extern "C" int rsim_cmem_bytes_cfg2(void);
 extern "C" int rsim_launch_prepare_cfg3(const DModel* m, const DBatch* b, int nblocks, int reset_only, hipStream_t stream);
+extern "C" int rsim_launch_prepare_cfg4(const DModel* m, const DBatch* b, int nblocks, int reset_only, hipStream_t stream);
 extern "C" int rsim_cmem_bytes_cfg3(void);
+extern "C" int rsim_cmem_bytes_cfg4(void);
 extern "C" int rsim_launch_reset_obs_cfg0(const DModel* m, const DBatch* b, hipStream_t stream);
 extern "C" int rsim_launch_reset_obs_cfg1(const DModel* m, const DBatch* b, hipStream_t stream);
 extern "C" int rsim_launch_reset_obs_cfg2(const DModel* m, const DBatch* b, hipStream_t stream);
 extern "C" int rsim_launch_reset_obs_cfg3(const DModel* m, const DBatch* b, hipStream_t stream);
+extern "C" int rsim_launch_reset_obs_cfg4(const DModel* m, const DBatch* b, hipStream_t stream);
 typedef int (*resetobs_fn)(const DModel*, const DBatch*, hipStream_t);
-static const resetobs_fn k_reset_obs_launch[4] = {rsim_launch_reset_obs_cfg0, rsim_launch_reset_obs_cfg1, rsim_launch_reset_obs_cfg2, rsim_launch_reset_obs_cfg3};
+static const resetobs_fn k_reset_obs_launch[RSIM_NCFG] = {rsim_launch_reset_obs_cfg0, rsim_launch_reset_obs_cfg1, rsim_launch_reset_obs_cfg2, rsim_launch_reset_obs_cfg3, rsim_launch_reset_obs_cfg4};
 typedef int (*prepare_fn)(const DModel*, const DBatch*, int, int, hipStream_t);
 typedef int (*cmem_fn)(void);
-static const prepare_fn k_prepare_launch[RSIM_NCFG] = {rsim_launch_prepare_cfg0, rsim_launch_prepare_cfg1, rsim_launch_prepare_cfg2, rsim_launch_prepare_cfg3};
-static const cmem_fn k_cmem_bytes[RSIM_NCFG] = {rsim_cmem_bytes_cfg0, rsim_cmem_bytes_cfg1, rsim_cmem_bytes_cfg2, rsim_cmem_bytes_cfg3};
-static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1, rsim_limits_cfg2, rsim_limits_cfg3};
+static const prepare_fn k_prepare_launch[RSIM_NCFG] = {rsim_launch_prepare_cfg0, rsim_launch_prepare_cfg1, rsim_launch_prepare_cfg2, rsim_launch_prepare_cfg3, rsim_launch_prepare_cfg4};
+static const cmem_fn k_cmem_bytes[RSIM_NCFG] = {rsim_cmem_bytes_cfg0, rsim_cmem_bytes_cfg1, rsim_cmem_bytes_cfg2, rsim_cmem_bytes_cfg3, rsim_cmem_bytes_cfg4};
+static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1, rsim_limits_cfg2, rsim_limits_cfg3, rsim_limits_cfg4};
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream);
 extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStream_t stream);
 extern "C" int rsim_launch_bank_scatter(float* bank, int* tag, const int* env, const int* episode, const float* rows, int n, int E, int W, hipStream_t stream);

@@ -32,10 +32,14 @@
 #elif RSIM_CFG == 2  // 64 bodies x 16 dofs (Baxter: 36 bodies, 29 colliding geoms, 17 sites, 299 candidate pairs): tree products as mask loops, dense ones on one tile
 #define RSIM_DIMS 64, 16, 16, 32, 32, 32, 64, 320
 #define RSIM_SYM(x) x##_cfg2
-#else  // 64 bodies x 64 dofs x 128 constraint rows (PickPlace / IIWA + Robotiq140: 36 bodies, 37 dofs, 41 colliding geoms, 622 candidate pairs,
-       // tendon rows; a closed Robotiq gripper alone holds ~30 rows of self-contact)
-#define RSIM_DIMS 64, 32, 64, 64, 32, 32, 128, 640
+#elif RSIM_CFG == 3  // 64 bodies x 48 dofs x 128 constraint rows (PickPlace / IIWA + Robotiq140: 36 bodies, 37 dofs, 41 colliding geoms, 622 candidate
+       // pairs, tendon rows; a closed Robotiq gripper alone holds ~30 rows of self-contact).  Three 16-dof tiles instead of four: the dense matrices
+       // (M, H, J) shrink to 75 KB of LDS per environment = TWO environments per CU
+#define RSIM_DIMS 64, 32, 48, 64, 32, 32, 128, 640
 #define RSIM_SYM(x) x##_cfg3
+#else  // 64 bodies x 64 dofs x 128 constraint rows: the widest configuration (one environment per CU)
+#define RSIM_DIMS 64, 32, 64, 64, 32, 32, 128, 640
+#define RSIM_SYM(x) x##_cfg4
 #endif
 
 #ifndef RSIM_MINWAVES
@@ -47,6 +51,13 @@ typedef unsigned long long u64;
 #define SUBMARK(id) pf.mark(id)
 #else
 #define SUBMARK(id)
+#endif
+#if defined(RSIM_SUBPROF) && RSIM_SUBPROF == 2   /* tools/subprof.sh 2: slots x7..x9 split the Hessian step (assembly | factorisation | solve) instead of the OSC controller */
+#define SUBMARK_OSC(id)
+#define SUBMARK_H(id) pf.mark(id)
+#else
+#define SUBMARK_OSC(id) SUBMARK(id)
+#define SUBMARK_H(id)
 #endif
 // One workgroup = one wavefront: LDS instructions of a wave execute in issue order, so cross-lane communication through LDS needs no
 // s_waitcnt / s_barrier, only a compiler-level ordering point (wavefront-scope fences emit no instructions; __syncthreads() would
@@ -236,8 +247,8 @@ __device__ __forceinline__ Q4 ldq(gcf p) { Q4 q = {p[0], p[1], p[2], p[3]}; retu
 // ------------------------------------------------------------------------------------------------------------
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 struct Smem {
-  static_assert((NB == 32 || NB == 64) && (NV == 16 || NV == 32 || NV == 64) && (NEFC == 64 || NEFC == 128) && NG <= 64 && (NS == 16 || NS == 32) && NPAIR % 64 == 0 && NPAIR <= 640,
-                "lane roles: body / site / dof columns are powers of two, one lane per constraint row, candidate pairs in rows of 64");
+  static_assert((NB == 32 || NB == 64) && (NV == 16 || NV == 32 || NV == 48 || NV == 64) && (NEFC == 64 || NEFC == 128) && NG <= 64 && (NS == 16 || NS == 32) && NPAIR % 64 == 0 && NPAIR <= 640,
+                "lane roles: body / site columns are powers of two, dofs whole 16-column tiles, one lane per constraint row, candidate pairs in rows of 64");
   static constexpr bool TREE_TILE_ = NB == 32 && NV == 16;   // tree products as 32-body x 16-dof incidence-matrix MFMAs
   static constexpr int NVP = NV + 1;  // padded row stride of the dense nv x nv matrices (conflict-free column reads)
   static constexpr int NV_ = NV;
@@ -1000,7 +1011,7 @@ struct Sim {
       o += 29 * W;
     }
     {  // dof role, NV columns
-      const int l = lane & (NV16 - 1), W = NV16;
+      const int W = NV16, l = lane < W ? lane : lane - W;   // 48 dof columns in the 64 x 48 configuration
       if (!STORE || lane < W) {
         kio<STORE>(K.dinfo, o + 0 * W + l); kio<STORE, FM(dof_damping)>(K.damping, o + 1 * W + l); kio<STORE, FM(jnt_range)>(K.jr0, o + 2 * W + l); kio<STORE, FM(jnt_range)>(K.jr1, o + 3 * W + l);
         kio<STORE, FM(jnt_margin)>(K.jmargin, o + 4 * W + l); kio<STORE, FM(jnt_solref)>(K.jsr0, o + 5 * W + l); kio<STORE, FM(jnt_solref)>(K.jsr1, o + 6 * W + l); kio<STORE, FM(jnt_solimp)>(K.jsi0, o + 7 * W + l);
@@ -2580,7 +2591,7 @@ struct Sim {
     float Y[6];
     Y[0] = rchol_fwd_m<NA>(mr, minv, mown, jc.l.x); Y[1] = rchol_fwd_m<NA>(mr, minv, mown, jc.l.y); Y[2] = rchol_fwd_m<NA>(mr, minv, mown, jc.l.z);
     Y[3] = rchol_fwd_m<NA>(mr, minv, mown, jc.a.x); Y[4] = rchol_fwd_m<NA>(mr, minv, mown, jc.a.y); Y[5] = rchol_fwd_m<NA>(mr, minv, mown, jc.a.z);
-    SUBMARK(RP_X7);
+    SUBMARK_OSC(RP_X7);
     // Lambda^-1[r][q] = sum_i Y[i][r] Y[i][q] and (J tmp)[r] = sum_i J[r][i] tmp_i in one 16 x 16 x 8 product on the matrix cores:
     // staging row i (arm joint) = [Y[i][0..5] | J[0..5][i] | tmp_i | 0 0 0]; A[a][i] = S[i][a], B[i][b] = (b < 6 ? S[i][b] : b == 6 ? tmp_i : 0)
     // => D[r][q] = Lambda^-1 (r, q < 6, exactly symmetric: same products in the same order) and D[6 + r][6] = (J tmp)[r]
@@ -2609,7 +2620,7 @@ struct Sim {
       }
     }
     SYNC();
-    SUBMARK(RP_X8);
+    SUBMARK_OSC(RP_X8);
     // operational-space errors and wrench (uniform small algebra)
     const M3 oR = ldm(sm.smat + 9 * base_site), eR = ldm(sm.smat + 9 * eef_site);
     const V3 gpos = ld3(sm.cstate + CO + RSIM_CS_GOALPOS);
@@ -2651,7 +2662,7 @@ struct Sim {
       solve3(lp, F, wrench);
       solve3(lo, T, wrench + 3);
     }
-    SUBMARK(RP_X9);
+    SUBMARK_OSC(RP_X9);
     const float own6 = rchol_factor_own<NA>(lr6, linv6, row8);
     rchol_mask_lower<NA>(lr6, row8);
     SYNC();
@@ -3074,9 +3085,12 @@ struct Sim {
           default: hess_wide<4>(nch); break;
         }
         SYNC();
+        SUBMARK_H(RP_X7);
         bchol_inplace<NVP>(sm.H, sm.invdiag, nv, lane);
+        SUBMARK_H(RP_X8);
         sk = bchol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -gk : 0.f, nv, lane);
         if (lane >= nv) sk = 0.f;
+        SUBMARK_H(RP_X9);
       } else {
         v4f acc = Macc;
         // four row chunks per trip: eight LDS reads in flight, then four MFMAs (rows >= nefc of W and J are zero up to row 63)

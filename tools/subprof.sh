@@ -4,5 +4,5 @@
 set -e
 R=/root/repo; T=/tmp/profbuild; rm -rf $T; mkdir -p $T/robosuite_amd/csrc $T/include
 cp $R/robosuite_amd/csrc/{rsim_step.hip,rsim_api.cpp,rsim_internal.h,Makefile} $T/robosuite_amd/csrc/; cp $R/include/rsim.h $T/include/
-make -s -j -C $T/robosuite_amd/csrc OUT=$R/robosuite_amd/librsim_hip_prof.so CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -Wno-unused-value -fno-hip-fp32-correctly-rounded-divide-sqrt -fgpu-flush-denormals-to-zero -DRSIM_SUBPROF" 2>&1 | grep -E " error |Error" || true
+make -s -j -C $T/robosuite_amd/csrc OUT=$R/robosuite_amd/librsim_hip_prof.so CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -Wno-unused-value -fno-hip-fp32-correctly-rounded-divide-sqrt -fgpu-flush-denormals-to-zero -DRSIM_SUBPROF=${1:-1}" 2>&1 | grep -E " error |Error" || true
 ls -la $R/robosuite_amd/librsim_hip_prof.so
