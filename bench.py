@@ -15,6 +15,13 @@ step counter at o_i = (197 i) mod 500 and `horizon` untimed launches are run, so
 the bank) and then sits o_i genuine steps into its second episode.  Every timed launch then sees the steady-state mix of an RL rollout,
 including the ~B/500 on-device episode resets per launch.  `--phase fresh` times synchronised episodes from their first step instead.
 
+Stream groups.  One launch lasts as long as its slowest env (contact-rich envs take 3-4 x the median; measured 3.9 ms against a mean slot
+load of 2.5 ms), and the envs are independent of each other.  By default the batch therefore steps as `--groups` (8) contiguous env blocks, each
+on its own HIP stream (include/rsim.h rsim_set_stream_groups): `env.step()` still enqueues one control step of all 4096 envs, but a block's
+step t + 1 starts when ITS slowest env has finished step t instead of waiting for the slowest env of the whole batch.  Same work, same results
+(tools/groups_sweep.py: the reached state is bit-identical for every group count); the timed region is still exactly K steps of every env
+between two full synchronisations.  `config.lockstep` reports the same K steps timed with `--groups 1` right after the main region.
+
 Prints ONE JSON line on rank 0.  See DESIGN.md section 6 for the roofline / cpu_baseline definitions.
 """
 import argparse
@@ -93,6 +100,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phase", choices=("staggered", "fresh"), default="staggered", help="episode phase of the envs when the timed region starts (module docstring)")
+    ap.add_argument("--groups", type=int, default=8, help="env blocks stepped on their own HIP streams (module docstring); 1 = one launch per step")
+    ap.add_argument("--no-lockstep", action="store_true", help="skip the second timed region (same K steps with one launch per step)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -122,9 +131,12 @@ def main():
     ids = shard.env_block(B * world, rank, world)
     K, W = args.steps, args.warmup
     P = HORIZON if args.phase == "staggered" else 0   # untimed pre-roll launches
-    env = lift.LiftBatch(flat, cfg, ids, device=local_rank, seed0=0, horizon=HORIZON, bank_episodes=2 + (P + W + K) // HORIZON)  # config 2: episodes auto-reset at horizon 500
-    tape = torch.tensor(lift.env_actions(ids, P + K + W), device=dev)  # whole action tape resident in HBM
-    stream = torch.cuda.ExternalStream(env.batch.stream(), device=dev)
+    G = max(1, args.groups)
+    K2 = 0 if (args.no_lockstep or G == 1) else K   # second region: the same number of steps, one launch per step
+    env = lift.LiftBatch(flat, cfg, ids, device=local_rank, seed0=0, horizon=HORIZON, bank_episodes=2 + (P + W + K + K2) // HORIZON)  # config 2: episodes auto-reset at horizon 500
+    tape = torch.tensor(lift.env_actions(ids, P + K + W + K2), device=dev)  # whole action tape resident in HBM
+    env.batch.set_stream_groups(G)
+    streams = [torch.cuda.ExternalStream(env.batch.group_stream(g), device=dev) for g in range(G)]   # the streams the fused kernel is launched on
 
     def barrier():
         if world > 1:
@@ -138,18 +150,29 @@ def main():
     for t in range(W):
         env.step(tape[t])
     env.batch.sync(); torch.cuda.synchronize(); barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    t0 = time.perf_counter()
-    for t in range(K):
-        ev[t][0].record(stream)
-        env.step(tape[W + t])
-        ev[t][1].record(stream)
-    env.batch.sync(); torch.cuda.synchronize(); barrier()
-    dt = time.perf_counter() - t0
-    dt = shard.max_over_ranks(dt, dev)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    def timed(first, n, strs):
+        ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in strs] for _ in range(n)]
+        t0 = time.perf_counter()
+        for t in range(n):
+            for g, s_ in enumerate(strs):
+                ev[t][g][0].record(s_)
+            env.step(tape[first + t])
+            for g, s_ in enumerate(strs):
+                ev[t][g][1].record(s_)
+        env.batch.sync(); torch.cuda.synchronize(); barrier()
+        dt_ = shard.max_over_ranks(time.perf_counter() - t0, dev)
+        return dt_, [[a.elapsed_time(b) for a, b in row] for row in ev]
+
+    dt, evms = timed(W, K, streams)
+    kern_ms = float(np.mean(evms))   # mean duration of one launch of the fused kernel (one env block of B / G envs) incl. its dispatch-order / reset passes
     if os.environ.get("RSIM_BENCH_TRACE"):
-        print("per-step ms:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in ev), file=sys.stderr)
+        print("per-step ms (group 0):", " ".join(f"{r[0]:.2f}" for r in evms), file=sys.stderr)
+    lockstep = None
+    if K2:
+        env.batch.set_stream_groups(1)
+        dt2, ev2 = timed(W + K, K2, [torch.cuda.ExternalStream(env.batch.stream(), device=dev)])
+        lockstep = {"value": B * world * K2 / dt2, "ms_per_step": 1e3 * dt2 / K2, "kernel_ms": float(np.mean(ev2)), "steps": K2,
+                    "note": "the next K steps of the same envs with one launch of all envs per step (--groups 1)"}
 
     st = shard.RolloutStats(dev)
     q = env.batch.tensor("qpos")
@@ -163,7 +186,7 @@ def main():
 
     if rank == 0:
         OBS_DIM_REPORT = env.model.nobs
-        abytes = algorithmic_bytes_per_env_step(flat, env.model.action_dim) * B
+        abytes = algorithmic_bytes_per_env_step(flat, env.model.action_dim) * B / G   # one launch = one env block
         ach = abytes / (kern_ms * 1e-3) / 1e9
         # PMC-derived figures are only valid for the library build they were measured on: the files carry the sha of that build
         lib_sha = hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16]
@@ -179,8 +202,9 @@ def main():
         valu = pmc("valu_count.json", "valu_per_env_substep")            # tools/pmc_valu.py (SQ_INSTS_VALU pass on this workload)
         issue = None
         if valu:
-            issue = {"bound": "valu-issue", "valu_instr_per_env_substep": valu, "achieved": valu * B * N_SUB / (kern_ms * 1e-3) / 1e9,
-                     "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instr/s", "frac": valu * B * N_SUB / (kern_ms * 1e-3) / VALU_ISSUE_PEAK,
+            rate = valu * B * N_SUB * K / dt   # wave-instructions per second of this GPU over the timed region (launches of different env blocks overlap)
+            issue = {"bound": "valu-issue", "valu_instr_per_env_substep": valu, "achieved": rate / 1e9,
+                     "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instr/s", "frac": rate / VALU_ISSUE_PEAK,
                      "source": "profiles/valu_count.json (rocprofv3 --pmc SQ_INSTS_VALU on this build, same workload)"}
         out = {
             "metric": "env-steps/sec (whole node), Lift/Panda/OSC_POSE @4096 envs/GPU", "value": tot["env_steps"] / dt, "unit": "env-steps/s",
@@ -188,11 +212,13 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Lift/Panda/OSC_POSE, 25 substeps x dt 0.002 + OSC_POSE/GRIP per substep, fused in one launch (BASELINE configs[1])",
                        "envs_per_gpu": B, "global_envs": B * world, "n_sub": N_SUB, "per_env_seeded_reset": True, "horizon": HORIZON, "on_device_auto_reset": True,
+                       "stream_groups": G, "lockstep": lockstep,
                        "episode_phase": ("uniform over the horizon: step counters offset by (197 i) mod 500, then 500 untimed pre-roll launches" if P else "fresh: all envs at step W of their first episode"),
                        "overflow_envs": int(overflow_envs), "lib_sha16": lib_sha, "obs_dim": OBS_DIM_REPORT, "sharding": f"env-block x{world}",
                        "diverged_envs": int(tot["diverged"]), "reward_sum": tot["reward_sum"], "successes": int(tot["successes"])},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes,
+                         "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes, "concurrent_launches": G,
+                         "aggregate_achieved": abytes * G * K / dt / 1e9,   # GB/s of all env blocks together (their launches overlap)
                          "note": "latency/VALU/LDS-bound by design (state LDS-resident for 25 substeps); see DESIGN.md section 6",
                          # the fraction that describes this kernel: VALU issue slots used (PMC instruction count of THIS build x measured rate); null
                          # when profiles/valu_count.json was measured on another build

@@ -249,6 +249,14 @@ int rsim_param_offset(const rsim_batch* b, const char* field, int elem);
  * longest in the previous control step (contact-rich envs stay so for many steps) are handed to the first workgroups, which shortens the
  * tail of a launch; 0: env i = workgroup i. */
 int rsim_set_schedule(rsim_batch* b, int longest_first);
+/* Stream groups of rsim_control_step (no reference counterpart; results do not depend on it).  A control step lasts as long as its slowest env
+ * (contact-rich envs take 3-4 x the median) and the envs are independent, so with groups = G > 1 the batch is stepped as G contiguous env
+ * blocks, each on its own HIP stream: block g's step t + 1 starts as soon as ITS envs have finished step t, filling the CUs that the other
+ * blocks' stragglers leave idle.  The caller's view is unchanged -- one call enqueues one step of all envs; rsim_sync() and every entry point
+ * that reads or writes batch state first wait for all groups; the actions buffer of a step must stay untouched until then.  1 = one launch
+ * on the batch's stream (default).  groups <= 32 and <= the batch size. */
+int rsim_set_stream_groups(rsim_batch* b, int groups);
+void* rsim_group_stream(rsim_batch* b, int group);   /* hipStream_t the control steps of env block `group` run on (for event timing) */
 
 /* Per-phase cycle accounting of the fused kernel (no reference counterpart: the reference has no profiling).
  * enable != 0 (re)arms and zeroes the accumulators, 0 disarms; if `out` is non-NULL the current accumulators are copied out first:

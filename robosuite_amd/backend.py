@@ -197,6 +197,8 @@ def lib():
         L.rsim_wavelog.argtypes = [vp, vp]
         L.rsim_pairlog.argtypes = [vp, vp]
         L.rsim_set_schedule.argtypes = [vp, C.c_int]
+        L.rsim_set_stream_groups.argtypes = [vp, C.c_int]
+        L.rsim_group_stream.restype = vp; L.rsim_group_stream.argtypes = [vp, C.c_int]
         L.rsim_profile_env.argtypes = [vp, C.c_int]
         L.rsim_osc_eval.argtypes = [C.POINTER(CtrlDesc), vp, vp, C.c_int, C.c_int]
         _LIB = L
@@ -434,6 +436,14 @@ class HipBatch:
     def set_schedule(self, longest_first=True):
         """Dispatch order of control_step: slowest envs of the previous step first (default) or identity."""
         _chk(self._L.rsim_set_schedule(self.ptr, int(bool(longest_first))))
+
+    def set_stream_groups(self, groups: int):
+        """Step the batch as `groups` env blocks on their own HIP streams (include/rsim.h rsim_set_stream_groups): a block's next control step no
+        longer waits for the slowest env of the whole batch.  Same results; 1 = one launch per step."""
+        _chk(self._L.rsim_set_stream_groups(self.ptr, int(groups)))
+
+    def group_stream(self, g: int):
+        return self._L.rsim_group_stream(self.ptr, int(g))
 
     def pairlog(self):
         """Per candidate pair {narrow-phase visits, support calls} since profiling was armed -> (visits[npair], supports[npair])."""

@@ -16,6 +16,7 @@
 
 // one set of launchers per compiled kernel configuration (rsim_step.hip is built once per RSIM_CFG)
 #define RSIM_NCFG 5
+#define RSIM_MAX_GROUPS 32
 extern "C" int rsim_launch_step_cfg0(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);
 extern "C" int rsim_launch_ctrl_reset_cfg0(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
 extern "C" int rsim_limits_cfg0(int* lim);
@@ -141,12 +142,17 @@ struct rsim_batch {
   DCtrl cm_ctrl;      // controller the blocks were built for
   int have_cost;      // d_cost holds the costs of a previous control step
   int schedule;       // 1 = reorder before every control step (default), 0 = identity order
+  // stream groups: control steps of env block g run on gstream[g]; `forked` = the group streams hold work the main stream has not waited for
+  int groups, ngroups, forked;   // streams created, groups in use (1 = everything on the main stream)
+  hipStream_t gstream[RSIM_MAX_GROUPS];
+  hipEvent_t gev[RSIM_MAX_GROUPS], mev;
   // host cache for jacobians
   long gen, cache_gen;
   int cache_env;
   std::vector<float> h_cdof, h_rootcom, h_xpos, h_xquat;
 };
 
+static int join_groups(rsim_batch* b);
 // ------------------------------------------------------------------------------------------------------------
 extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out) {
   if (!blob || len < 16 || memcmp(blob, "RSIMMDL1", 8) != 0) return fail("rsim_model_create: bad blob magic");
@@ -635,6 +641,7 @@ extern "C" int rsim_model_set_task(rsim_model* m, const rsim_task_desc* d) {
   return 0;
 }
 
+static int join_groups(rsim_batch* b);
 // ------------------------------------------------------------------------------------------------------------
 template <class T>
 static int dalloc(T** p, size_t n) {
@@ -770,7 +777,10 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
 extern "C" void rsim_batch_free(rsim_batch* b) {
   if (!b) return;
   hipSetDevice(b->device);
+  join_groups(b);
   hipStreamSynchronize(b->stream);
+  for (int g = 0; g < b->groups; g++) { hipStreamDestroy(b->gstream[g]); hipEventDestroy(b->gev[g]); }
+  if (b->mev) hipEventDestroy(b->mev);
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
   hipFree(b->d_cm);
   hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_ft0); if (b->d_obsprog) hipFree(b->d_obsprog);
@@ -783,9 +793,10 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
 extern "C" int rsim_batch_size(const rsim_batch* b) { return b->B; }
 extern "C" int rsim_batch_limits(const rsim_batch* b, int* maxcon, int* maxefc) { *maxcon = b->lim[5]; *maxefc = b->lim[6]; return 0; }
 extern "C" void* rsim_stream(rsim_batch* b) { return (void*)b->stream; }
-extern "C" int rsim_sync(rsim_batch* b) { HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return 0; }
+extern "C" void* rsim_group_stream(rsim_batch* b, int g) { return (b->ngroups > 1 && g >= 0 && g < b->ngroups) ? (void*)b->gstream[g] : (void*)b->stream; }
+extern "C" int rsim_sync(rsim_batch* b) { if (join_groups(b)) return 1; HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->stream)); return 0; }
 
-extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) {
+extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) { if (join_groups(b)) return 1;
   rsim_model* m = b->m;
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -817,6 +828,54 @@ extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) {
     }
   }
   b->gen++;
+  return 0;
+}
+
+// Stream groups.  A control step is one launch whose duration is that of its slowest environment (contact-rich envs take 3-4 x the median),
+// while the envs are independent of each other: with G groups, env block g steps on its own HIP stream, so block g's control step t + 1
+// starts when ITS slowest env has finished step t and fills the CUs the other blocks' stragglers leave idle.  Nothing changes for the caller:
+// rsim_control_step() still enqueues one step of all B envs and returns; every other entry point first makes the batch's main stream wait
+// for the group streams (join), and the first control step after that makes the group streams wait for the main stream (fork).
+static int join_groups(rsim_batch* b) {
+  if (!b->forked) return 0;
+  for (int g = 0; g < b->groups; g++) {
+    HIPCHK(hipEventRecord(b->gev[g], b->gstream[g]));
+    HIPCHK(hipStreamWaitEvent(b->stream, b->gev[g], 0));
+  }
+  b->forked = 0;
+  return 0;
+}
+static int fork_groups(rsim_batch* b) {
+  if (b->forked) return 0;
+  HIPCHK(hipEventRecord(b->mev, b->stream));
+  for (int g = 0; g < b->groups; g++) HIPCHK(hipStreamWaitEvent(b->gstream[g], b->mev, 0));
+  b->forked = 1;
+  return 0;
+}
+extern "C" int rsim_set_stream_groups(rsim_batch* b, int groups) {
+  if (groups < 1 || groups > RSIM_MAX_GROUPS || groups > b->B) return fail("rsim_set_stream_groups: groups must be in 1..%d and <= the batch size", RSIM_MAX_GROUPS);
+  HIPCHK(hipSetDevice(b->device));
+  if (join_groups(b)) return 1;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  for (int g = b->groups; g < groups; g++) {   // streams / events are created once and kept until the batch is freed
+    {
+      // a stream with a CU mask owns a hardware queue of its own; plain streams share the runtime's small pool of queues (GPU_MAX_HW_QUEUES,
+      // 4 by default, torch's own streams included), and kernels of two groups that land on one queue run back to back instead of side by side
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, b->device));
+      const uint32_t words = (uint32_t)((prop.multiProcessorCount + 31) / 32);
+      std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
+      if (getenv("RSIM_PLAIN_GROUP_STREAMS") || hipExtStreamCreateWithCUMask(&b->gstream[g], words, mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(hipStreamCreate(&b->gstream[g]));   // still correct, but groups that share a hardware queue serialise
+      }
+    }
+    HIPCHK(hipEventCreateWithFlags(&b->gev[g], hipEventDisableTiming));
+  }
+  if (!b->mev) HIPCHK(hipEventCreateWithFlags(&b->mev, hipEventDisableTiming));
+  if (groups > b->groups) b->groups = groups;
+  b->ngroups = groups;
+  b->have_cost = 0;
   return 0;
 }
 
@@ -856,10 +915,45 @@ static int ensure_constants(rsim_batch* b) {
 static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   HIPCHK(hipSetDevice(b->device));
   if (sync_controller(b)) return 1;
+  const bool grouped = (flags & RF_EPISODE) && b->ngroups > 1;
+  if (!grouped || b->cm_dirty || memcmp(&b->cm_ctrl, &b->dm.ctrl, sizeof(DCtrl))) { if (join_groups(b)) return 1; }   // main-stream work ahead
   if (ensure_constants(b)) return 1;
   if ((flags & RF_OBS) && !b->dm.task.enabled) return fail("the task (observation / reward epilogue) was configured after the batch was created");
   if ((flags & RF_CTRL) && !b->dm.ctrl.enabled) return fail("no controller configured (rsim_model_set_controller)");
   b->db.order = nullptr; b->db.cost = nullptr;
+  if (grouped) {
+    if (fork_groups(b)) return 1;
+    const bool sched = b->schedule && b->d_order;
+    for (int g = 0; g < b->ngroups; g++) {
+      const int e0 = (int)((long long)b->B * g / b->ngroups), e1 = (int)((long long)b->B * (g + 1) / b->ngroups);
+      DBatch db = b->db;
+      db.env0 = e0; db.nenv = e1 - e0;
+      if (sched) {
+        if (b->have_cost) {
+          int eo = rsim_launch_order(b->d_cost + e0, b->d_order + e0, e1 - e0, b->gstream[g]);
+          if (eo) return fail("dispatch-order kernel launch failed: %s", hipGetErrorString((hipError_t)eo));
+          db.order = b->d_order + e0;
+        }
+        db.cost = b->d_cost;
+      }
+      int e = k_step_launch[b->cfg](&b->dm, &db, actions, n_sub, flags, b->gstream[g]);
+      if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+      if (b->db.bank && b->db.horizon > 0) {
+        db.order = nullptr; db.cost = nullptr;
+        if (b->db.bank_P > 0 && b->db.cm_stride) {
+          e = k_prepare_launch[b->cfg](&b->dm, &db, e1 - e0, 1, b->gstream[g]);
+          if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        }
+        if (b->dm.task.enabled) {
+          e = k_reset_obs_launch[b->cfg](&b->dm, &db, b->gstream[g]);
+          if (e) return fail("reset-observation kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+        }
+      }
+    }
+    if (sched) b->have_cost = 1;
+    b->gen++;
+    return 0;
+  }
   if ((flags & RF_EPISODE) && b->schedule && b->d_order) {   // control steps only: forward()/step1()/step2() launches are one substep long
     if (b->have_cost) {
       int eo = rsim_launch_order(b->d_cost, b->d_order, b->B, b->stream);
@@ -910,7 +1004,7 @@ extern "C" int rsim_set_episode(rsim_batch* b, int horizon) {
 extern "C" int rsim_param_offset(const rsim_batch* b, const char* field, int elem) {
   return param_offset_impl(b->m, field, elem);
 }
-extern "C" int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, const int32_t* patch_idx, const float* bank) {
+extern "C" int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, const int32_t* patch_idx, const float* bank) { if (join_groups(b)) return 1;
   rsim_model* m = b->m;
   if (n_episodes < 1 || n_patch < 0) return fail("rsim_set_reset_bank: bad sizes");
   if (n_patch > 0 && !b->per_env) return fail("rsim_set_reset_bank: per-episode model patches need per_env_params");
@@ -939,7 +1033,7 @@ extern "C" int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, c
   return 0;
 }
 
-extern "C" int rsim_refill_reset_bank(rsim_batch* b, int n, const int32_t* env, const int32_t* episode, const float* rows) {
+extern "C" int rsim_refill_reset_bank(rsim_batch* b, int n, const int32_t* env, const int32_t* episode, const float* rows) { if (join_groups(b)) return 1;
   if (!b->d_bank) return fail("rsim_refill_reset_bank: no reset bank installed (rsim_set_reset_bank)");
   if (n < 0) return fail("rsim_refill_reset_bank: n < 0");
   if (n == 0) return 0;
@@ -959,7 +1053,7 @@ extern "C" int rsim_refill_reset_bank(rsim_batch* b, int n, const int32_t* env, 
   return 0;
 }
 
-extern "C" int rsim_dr_save_defaults(rsim_batch* b) {
+extern "C" int rsim_dr_save_defaults(rsim_batch* b) { if (join_groups(b)) return 1;
   if (!b->per_env) return fail("rsim_dr_save_defaults: the batch was created without per_env_params");
   HIPCHK(hipSetDevice(b->device));
   const size_t n = b->m->ftab.size() * (size_t)b->B;
@@ -968,7 +1062,7 @@ extern "C" int rsim_dr_save_defaults(rsim_batch* b) {
   b->db.ft_base = b->d_ft_base;
   return 0;
 }
-extern "C" int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uint64_t seed, uint64_t step) {
+extern "C" int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uint64_t seed, uint64_t step) { if (join_groups(b)) return 1;
   if (!b->per_env) return fail("rsim_randomize_dynamics: the batch was created without per_env_params");
   if (!b->d_ft_base) return fail("rsim_randomize_dynamics: call rsim_dr_save_defaults first");
   HIPCHK(hipSetDevice(b->device));
@@ -983,7 +1077,7 @@ extern "C" int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uin
   return 0;
 }
 
-extern "C" int rsim_ctrl_reset(rsim_batch* b, const uint8_t* mask) {
+extern "C" int rsim_ctrl_reset(rsim_batch* b, const uint8_t* mask) { if (join_groups(b)) return 1;
   HIPCHK(hipSetDevice(b->device));
   if (!b->m->ctrl.enabled) return fail("no controller configured");
   if (sync_controller(b)) return 1;
@@ -1000,7 +1094,7 @@ extern "C" int rsim_ctrl_reset(rsim_batch* b, const uint8_t* mask) {
   return 0;
 }
 
-extern "C" int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, int n_out) {
+extern "C" int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, int n_out) { if (join_groups(b)) return 1;
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   if (out && b->db.prof) {
@@ -1018,7 +1112,7 @@ extern "C" int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, 
 }
 
 extern "C" int rsim_set_schedule(rsim_batch* b, int longest_first) { b->schedule = longest_first ? 1 : 0; b->have_cost = 0; return 0; }
-extern "C" int rsim_pairlog(rsim_batch* b, unsigned long long* out) {
+extern "C" int rsim_pairlog(rsim_batch* b, unsigned long long* out) { if (join_groups(b)) return 1;
   if (!b->db.prof) return fail("rsim_pairlog: profiling is not armed (rsim_profile(b, 1, ...))");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -1027,7 +1121,7 @@ extern "C" int rsim_pairlog(rsim_batch* b, unsigned long long* out) {
 }
 extern "C" int rsim_profile_env(rsim_batch* b, int env) { b->db.prof_env = env; return 0; }
 
-extern "C" int rsim_wavelog(rsim_batch* b, unsigned long long* out) {
+extern "C" int rsim_wavelog(rsim_batch* b, unsigned long long* out) { if (join_groups(b)) return 1;
   if (!b->db.prof) return fail("rsim_wavelog: profiling is not enabled");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -1040,7 +1134,7 @@ extern "C" void* rsim_device_ptr(rsim_batch* b, int field, size_t* count) {
   if (count) *count = b->fcount[field];
   return b->fptr[field];
 }
-extern "C" int rsim_get_array(rsim_batch* b, int field, void* dst, size_t count) {
+extern "C" int rsim_get_array(rsim_batch* b, int field, void* dst, size_t count) { if (join_groups(b)) return 1;
   if (field < 0 || field >= RSIM_FIELD_COUNT) return fail("bad field id %d", field);
   if (count > b->fcount[field]) return fail("rsim_get_array: count %zu > field size %zu", count, b->fcount[field]);
   HIPCHK(hipSetDevice(b->device));
@@ -1048,7 +1142,7 @@ extern "C" int rsim_get_array(rsim_batch* b, int field, void* dst, size_t count)
   HIPCHK(hipMemcpy(dst, b->fptr[field], count * 4, hipMemcpyDeviceToHost));
   return 0;
 }
-extern "C" int rsim_set_array(rsim_batch* b, int field, const void* src, size_t count) {
+extern "C" int rsim_set_array(rsim_batch* b, int field, const void* src, size_t count) { if (join_groups(b)) return 1;
   if (field < 0 || field >= RSIM_FIELD_COUNT) return fail("bad field id %d", field);
   if (count > b->fcount[field]) return fail("rsim_set_array: count %zu > field size %zu", count, b->fcount[field]);
   HIPCHK(hipSetDevice(b->device));
@@ -1147,7 +1241,7 @@ static const ParamMap* param_maps(int* n) {
   return maps;
 }
 
-extern "C" int rsim_model_param_set(rsim_batch* b, const char* field, int env0, int nenv, const double* values, size_t cpe) {
+extern "C" int rsim_model_param_set(rsim_batch* b, const char* field, int env0, int nenv, const double* values, size_t cpe) { if (join_groups(b)) return 1;
   rsim_model* m = b->m;
   int nmaps = 0;
   const ParamMap* maps = param_maps(&nmaps);
@@ -1181,7 +1275,7 @@ extern "C" int rsim_model_param_set(rsim_batch* b, const char* field, int env0, 
   return 0;
 }
 
-extern "C" int rsim_model_param_get(rsim_batch* b, const char* field, int env0, int nenv, double* values, size_t cpe) {
+extern "C" int rsim_model_param_get(rsim_batch* b, const char* field, int env0, int nenv, double* values, size_t cpe) { if (join_groups(b)) return 1;
   rsim_model* m = b->m;
   int nmaps = 0;
   const ParamMap* maps = param_maps(&nmaps);

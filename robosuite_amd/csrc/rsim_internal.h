@@ -175,6 +175,9 @@ struct DBatch {
   unsigned* cost;        // [B] or null
   unsigned long long* prof;  // optional [RP_COUNT] phase-cycle / event accumulators (null = off)
   int prof_env;              // >= 0: only this env adds to the phase accumulators
+  // stream groups (rsim_set_stream_groups): this launch covers envs [env0, env0 + nenv) -- its own workgroup count, its own slice of
+  // order[] (indices relative to env0) -- while the arrays above stay those of the whole batch; nenv = 0: all B envs
+  int env0, nenv;
 };
 
 // profile slots (cycles of s_memtime summed over envs and substeps, then event counters)

@@ -1799,6 +1799,50 @@ struct Sim {
     const float tol = 1e-6f;
     const V3 org = ld3(sm.gpos + 3 * g1);   // all support points relative to the first geom's position (see geom_support)
     const SupGeom sg1 = sup_load(cm, cmf(MK_gst), g1, (gcf)m.mesh_vert, lane, org), sg2 = sup_load(cm, cmf(MK_gst), g2, (gcf)m.mesh_vert, lane, org);
+    // A box or cylinder against anything: MPR's own exit test (a direction D, oriented from geom 1 to geom 2, in which the first shape's
+    // farthest point does not reach the second's nearest) tried first on the primitive's most promising face / radial axis.  The table top or
+    // the mount pedestal against a gripper mesh hovering over it -- most narrow-phase visits of the Lift workload -- end here after ONE hull
+    // scan; from the centre-to-centre direction MPR needs ~6 portal steps (12.5 support calls) to find a separating direction of such a
+    // wide, flat pair.  A pair that does touch pays one extra support pair.  Same verdict as the full run for separated pairs (MPR is exact
+    // there), so the contact set is unchanged.
+    {
+      const int t1 = uni(sg1.t), t2 = uni(sg2.t);
+      const bool prim1 = t1 == G_BOX || t1 == G_CYLINDER, prim2 = t2 == G_BOX || t2 == G_CYLINDER;
+      if (prim1 || prim2) {
+        const bool first = prim1 && (!prim2 || t1 == G_BOX);   // two primitives: the box's axes
+        // the primitive's frame, picked field by field (a reference selected between the two structs would put both into the private segment)
+        struct { M3 R; V3 p, h; } sp;
+#pragma unroll
+        for (int k = 0; k < 9; k++) sp.R.m[k] = first ? sg1.R.m[k] : sg2.R.m[k];
+        sp.p = first ? sg1.p : sg2.p; sp.h = first ? sg1.h : sg2.h;
+        const int go = first ? g2 : g1, tp = first ? t1 : t2;
+        const M3 Ro = ldm(sm.gmat + 9 * go);
+        V3 oo, ho;
+        geom_obb(go, Ro, oo, ho);
+        const V3 tl = mtv(sp.R, (oo - org) - sp.p);   // the other shape's box centre in the primitive's frame
+        const M3 C = mtm(sp.R, Ro);
+        const float ex = ho.x * fabsf(C.m[0]) + ho.y * fabsf(C.m[1]) + ho.z * fabsf(C.m[2]), ey = ho.x * fabsf(C.m[3]) + ho.y * fabsf(C.m[4]) + ho.z * fabsf(C.m[5]),
+                    ez = ho.x * fabsf(C.m[6]) + ho.y * fabsf(C.m[7]) + ho.z * fabsf(C.m[8]);
+        V3 dl = v3(0, 0, tl.z >= 0 ? 1.f : -1.f);
+        float best = fabsf(tl.z) - sp.h.z - ez;
+        if (tp == G_BOX) {
+          const float bx = fabsf(tl.x) - sp.h.x - ex, by = fabsf(tl.y) - sp.h.y - ey;
+          if (bx > best) { best = bx; dl = v3(tl.x >= 0 ? 1.f : -1.f, 0, 0); }
+          if (by > best) { best = by; dl = v3(0, tl.y >= 0 ? 1.f : -1.f, 0); }
+        } else {
+          const float rho = sqrtf(tl.x * tl.x + tl.y * tl.y);
+          if (rho > 1e-6f) {
+            const V3 rl = v3(tl.x / rho, tl.y / rho, 0);
+            const float br = rho - sp.h.x - (ex * fabsf(rl.x) + ey * fabsf(rl.y));
+            if (br > best) { best = br; dl = rl; }
+          }
+        }
+        V3 D = mv(sp.R, dl);
+        if (!first) D = -D;
+        const V3 a1 = sup(sg1, D), a2 = sup(sg2, -D);
+        if (dot(a1 - a2, D) <= 0) return;
+      }
+    }
     V3 v0 = (ld3(sm.gcen + 3 * g1) - org) - (ld3(sm.gcen + 3 * g2) - org);
     if (norm(v0) < 1e-9f) v0.x = 1e-5f;
     V3 dir = normalized(-v0);
@@ -3371,10 +3415,10 @@ template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, const float* __restrict__ actions, int n_sub, int flags) {
   typedef Smem<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> SM;
   const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= b.B) return;
+  if ((int)blockIdx.x >= (b.nenv ? b.nenv : b.B)) return;
   // workgroups are dispatched in index order: handing the envs that were slowest in the previous launch to the first workgroups
   // (contact-rich envs stay contact-rich for many control steps) keeps the last wave of envs short
-  const int env = uni(b.order ? b.order[blockIdx.x] : (int)blockIdx.x);   // scalar: every per-env base address below then lives in SGPRs
+  const int env = uni((b.order ? b.order[blockIdx.x] : (int)blockIdx.x) + b.env0);   // scalar: every per-env base address below then lives in SGPRs
   // RF_RESET_ONLY: the pass that follows a control step and produces the observation MujocoEnv.reset() returns (forward + epilogue, no reward)
   // for the envs that step re-initialised from the reset bank; every other workgroup leaves at once
   if ((flags & RF_RESET_ONLY) && !b.needs_reset[env]) return;
@@ -3556,7 +3600,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
 // The reset-observation pass that follows a control step (forward + observables for the envs it re-initialised, no reward): the same body under
 // its own kernel name, so that per-kernel profiles of k_step hold control steps only (and the constant flags strip controller / integrator code)
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
-__global__ __launch_bounds__(64) void k_reset_obs(DModel m, DBatch b) {
+__global__ __launch_bounds__(64, 1) void k_reset_obs(DModel m, DBatch b) {
   step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR>(m, b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_OBS | RF_RESET_ONLY);
 }
 
@@ -3590,7 +3634,7 @@ __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const uns
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 __global__ __launch_bounds__(64) void k_prepare(DModel m, DBatch b, int reset_only) {
   typedef Smem<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> SM;
-  const int env = blockIdx.x, lane = threadIdx.x;
+  const int env = blockIdx.x + b.env0, lane = threadIdx.x;
   if (reset_only && !b.needs_reset[env]) return;
   const float* fp = m.ft + (size_t)env * m.fstride;
   // the host passes the blocks to build as b.cm_env / b.cm_stride (the shared block: one workgroup, m.fenv = 0, stride 0)
@@ -3772,11 +3816,11 @@ template __global__ void k_prepare<RSIM_DIMS>(DModel, DBatch, int);
 template __global__ void k_reset_obs<RSIM_DIMS>(DModel, DBatch);
 
 extern "C" int RSIM_SYM(rsim_launch_step)(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream) {
-  hipLaunchKernelGGL((k_step<RSIM_DIMS>), dim3(b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
+  hipLaunchKernelGGL((k_step<RSIM_DIMS>), dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
   return (int)hipGetLastError();
 }
 extern "C" int RSIM_SYM(rsim_launch_reset_obs)(const DModel* m, const DBatch* b, hipStream_t stream) {
-  hipLaunchKernelGGL((k_reset_obs<RSIM_DIMS>), dim3(b->B), dim3(64), 0, stream, *m, *b);
+  hipLaunchKernelGGL((k_reset_obs<RSIM_DIMS>), dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b);
   return (int)hipGetLastError();
 }
 extern "C" int RSIM_SYM(rsim_launch_ctrl_reset)(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream) {

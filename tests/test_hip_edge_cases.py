@@ -165,3 +165,31 @@ def test_contact_and_row_overflow_is_counted_not_silent():
     assert np.isfinite(hb.get("qacc")).all()
     hb.forward()
     assert hb.get("overflow")[0] == 2 * ov[0]                         # the counter accumulates over launches
+
+
+@pytest.mark.parametrize("groups", (3, 8))
+def test_stream_groups_do_not_change_any_result(groups):
+    """rsim_set_stream_groups: the batch stepped as env blocks on their own HIP streams reaches bit-identical states, observations, rewards and
+    episode counters -- through on-device episode resets (horizon 7), a mid-rollout read (which has to wait for every block) and a block count
+    that does not divide the batch."""
+    import json, os
+    from robosuite_amd import lift, mjcf
+    adir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "robosuite_amd", "assets")
+    flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim")); cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
+    B, T = 250, 20
+    ids = np.arange(B)
+    tape = torch.tensor(lift.env_actions(ids, T), device="cuda")
+    out = []
+    for G in (1, groups):
+        env = lift.LiftBatch(flat, cfg, ids, seed0=0, horizon=7, bank_episodes=4)
+        env.batch.set_stream_groups(G)
+        mid = None
+        for t in range(T):
+            env.step(tape[t])
+            if t == 9:
+                mid = env.batch.get("qpos")
+        env.batch.sync()
+        out.append({k: env.batch.get(k) for k in ("qpos", "qvel", "obs", "reward", "ep_index", "ep_step", "terminal_obs", "bank_stale")} | {"mid": mid})
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k
+    assert out[0]["ep_index"].min() >= 2 and out[0]["bank_stale"].sum() == 0

@@ -36,5 +36,7 @@ def test_fused_kernel_configurations_keep_their_lds_and_register_budgets():
 
 def test_auxiliary_kernels_use_no_scratch():
     for name, r in kernels(LIB).items():
-        if not name.startswith("_Z6k_step"):
+        if name.startswith("_Z11k_reset_obs"):
+            assert r["scratch"] <= 64, (name, r)   # the reset-observation pass shares the step body (a few envs per control step run it)
+        elif not name.startswith("_Z6k_step"):
             assert r["scratch"] == 0, (name, r)

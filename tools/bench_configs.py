@@ -28,4 +28,21 @@ for name, tag, model, B in (("Stack", "seed0_full", "stack_panda", 4096), ("TwoA
     out[name] = {"envs": B, "kernel_config": int(env.env.model.kernel_config()[0]), "ms_per_step": 1e3 * dt / steps, "env_steps_per_s": B * steps / dt}
     print(name, out[name], flush=True)
     del env
+if not only or "PickPlaceDR" in only:
+    # BASELINE configs[4] as stated: 8192 envs, dynamics randomisation re-drawn before every control step (per-env constant blocks rebuilt each time)
+    from robosuite_amd import pick_place
+    g, cfg, flat = load_golden("seed0_full", "pickplace_iiwa")
+    B = 8192
+    env = pick_place.PickPlaceBatch(flat, cfg, np.arange(B), seed0=0, horizon=500, bank_episodes=2, per_env_params=True)
+    b = env.batch
+    b.dr_save_defaults()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    acts = [torch.rand(B, env.model.action_dim, device="cuda", generator=gen) * 2 - 1 for _ in range(steps + 5)]
+    for t in range(5): b.randomize_dynamics(seed=11, step=t); env.step(acts[t])
+    b.sync(); t0 = time.perf_counter()
+    for t in range(5, 5 + steps): b.randomize_dynamics(seed=11, step=t); env.step(acts[t])
+    b.sync(); dt = time.perf_counter() - t0
+    out["PickPlaceDR"] = {"envs": B, "kernel_config": int(env.model.kernel_config()[0]), "ms_per_step": 1e3 * dt / steps, "env_steps_per_s": B * steps / dt,
+                          "diverged": int(b.get("diverged").sum()), "overflow_envs": int((b.get("overflow") > 0).sum())}
+    print("PickPlaceDR", out["PickPlaceDR"], flush=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)

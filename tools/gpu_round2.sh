@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 2500 gpurun_out/${tag}_bench.json
 rm -rf gpurun_out/prof_$tag
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o r -- python bench.py --no-cpu-baseline > gpurun_out/${tag}_prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o r -- python bench.py --no-cpu-baseline --no-lockstep > gpurun_out/${tag}_prof.log 2>&1
 cp $(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats.csv; cat gpurun_out/${tag}_kernel_stats.csv; rm -rf gpurun_out/prof_$tag
 KEEP=1 bash tools/pmc_pass.sh $tag sq1 hbm1 hbm2
 python tools/pmc_valu.py gpurun_out/$tag.sq1 4
