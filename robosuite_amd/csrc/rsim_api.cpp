@@ -1062,14 +1062,33 @@ extern "C" int rsim_dr_save_defaults(rsim_batch* b) { if (join_groups(b)) return
   b->db.ft_base = b->d_ft_base;
   return 0;
 }
-extern "C" int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uint64_t seed, uint64_t step) { if (join_groups(b)) return 1;
+extern "C" int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uint64_t seed, uint64_t step) {
   if (!b->per_env) return fail("rsim_randomize_dynamics: the batch was created without per_env_params");
   if (!b->d_ft_base) return fail("rsim_randomize_dynamics: call rsim_dr_save_defaults first");
   HIPCHK(hipSetDevice(b->device));
   DDr dd = {d->density_ratio, d->viscosity_ratio, d->position_size, d->quaternion_size, d->inertia_ratio, d->mass_ratio, d->friction_ratio, d->solref_ratio,
             d->solimp_ratio, d->frictionloss_size, d->damping_size, d->armature_size};
+  const unsigned long long fenv_before = b->dm.fenv;
   b->dm.fenv |= (1ull << FO_opt) | (1ull << FO_body_pos) | (1ull << FO_body_quat) | (1ull << FO_body_inertia) | (1ull << FO_body_mass) | (1ull << FO_cg_friction) |
                 (1ull << FO_cg_solref) | (1ull << FO_cg_solimp) | (1ull << FO_dof_frictionloss) | (1ull << FO_dof_damping) | (1ull << FO_dof_armature);
+  const unsigned long long want = (1ull << FO_opt) | (1ull << FO_body_pos) | (1ull << FO_body_quat) | (1ull << FO_body_inertia) | (1ull << FO_body_mass) | (1ull << FO_cg_friction) |
+                                  (1ull << FO_cg_solref) | (1ull << FO_cg_solimp) | (1ull << FO_dof_frictionloss) | (1ull << FO_dof_damping) | (1ull << FO_dof_armature);
+  if (b->ngroups > 1 && !b->cm_dirty && b->db.cm_stride && (fenv_before & want) == want && !memcmp(&b->cm_ctrl, &b->dm.ctrl, sizeof(DCtrl))) {
+    // stream groups, per-env constant blocks already in place: every env block re-draws its tables and rebuilds its own constant blocks on its
+    // own stream, ordered before its next control step -- the groups stay decoupled through a randomise-every-step rollout
+    if (fork_groups(b)) return 1;
+    for (int g = 0; g < b->ngroups; g++) {
+      const int e0 = (int)((long long)b->B * g / b->ngroups), e1 = (int)((long long)b->B * (g + 1) / b->ngroups);
+      DBatch db = b->db;
+      db.env0 = e0; db.nenv = e1 - e0;
+      int e = rsim_launch_randomize(&b->dm, &db, &dd, seed, step, b->gstream[g]);
+      if (!e) e = k_prepare_launch[b->cfg](&b->dm, &db, e1 - e0, 0, b->gstream[g]);
+      if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    }
+    b->gen++;
+    return 0;
+  }
+  if (join_groups(b)) return 1;
   int e = rsim_launch_randomize(&b->dm, &b->db, &dd, seed, step, b->stream);
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   b->cm_dirty = 1;   // the next launch rebuilds the constant blocks from the re-drawn tables (same stream: ordered after this kernel)

@@ -3716,7 +3716,7 @@ __device__ __forceinline__ float dr_uniform(unsigned long long seed, unsigned lo
   return (float)(z >> 40) * (2.0f / 16777216.0f) - 1.0f;   // U(-1, 1), 24-bit
 }
 __global__ __launch_bounds__(64) void k_randomize(DModel m, DBatch b, DDr d, unsigned long long seed, unsigned long long step) {
-  const int env = blockIdx.x, lane = threadIdx.x;
+  const int env = blockIdx.x + b.env0, lane = threadIdx.x;
   if (env >= b.B) return;
   const float* base = b.ft_base + (size_t)env * m.fstride;
   float* out = b.ft_rw + (size_t)env * m.fstride;
@@ -3761,7 +3761,7 @@ __global__ __launch_bounds__(64) void k_randomize(DModel m, DBatch b, DDr d, uns
   }
 }
 extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr* d, unsigned long long seed, unsigned long long step, hipStream_t stream) {
-  hipLaunchKernelGGL(k_randomize, dim3(b->B), dim3(64), 0, stream, *m, *b, *d, seed, step);
+  hipLaunchKernelGGL(k_randomize, dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b, *d, seed, step);
   return (int)hipGetLastError();
 }
 

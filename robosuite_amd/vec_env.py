@@ -20,13 +20,15 @@ TASKS = {"Lift": lift.LiftBatch, "Stack": stack.StackBatch, "TwoArmPegInHole": p
 
 
 class VecEnv:
-    def __init__(self, env_name: str, n_envs: int, flat, cfg, device: int = 0, seed: int = 0, horizon: int = 500, env_ids=None, bank_episodes: int = 4):
+    def __init__(self, env_name: str, n_envs: int, flat, cfg, device: int = 0, seed: int = 0, horizon: int = 500, env_ids=None, bank_episodes: int = 4, stream_groups: int = 1):
         if env_name not in TASKS:
             raise ValueError(f"{env_name!r} has no on-device task epilogue (have {sorted(TASKS)})")
         ids = np.arange(n_envs) if env_ids is None else np.asarray(env_ids)
         self.env_name = env_name
         self.env = TASKS[env_name](flat, cfg, ids, device=device, seed0=seed, horizon=horizon, bank_episodes=bank_episodes)
         self.n_envs, self.horizon = len(ids), horizon
+        if stream_groups > 1:   # env blocks stepped on their own HIP streams (rsim_set_stream_groups): same results, no whole-batch tail per step
+            self.env.batch.set_stream_groups(min(int(stream_groups), self.n_envs))
         self.action_dim, self.obs_dim = self.env.model.action_dim, self.env.model.nobs
         keys, dims = cfg["obs_keys"], cfg["obs_dims"]
         off = np.cumsum([0] + list(dims))

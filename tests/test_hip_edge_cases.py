@@ -167,11 +167,12 @@ def test_contact_and_row_overflow_is_counted_not_silent():
     assert hb.get("overflow")[0] == 2 * ov[0]                         # the counter accumulates over launches
 
 
-@pytest.mark.parametrize("groups", (3, 8))
-def test_stream_groups_do_not_change_any_result(groups):
+@pytest.mark.parametrize("groups,dr", ((3, False), (8, False), (4, True)))
+def test_stream_groups_do_not_change_any_result(groups, dr):
     """rsim_set_stream_groups: the batch stepped as env blocks on their own HIP streams reaches bit-identical states, observations, rewards and
     episode counters -- through on-device episode resets (horizon 7), a mid-rollout read (which has to wait for every block) and a block count
-    that does not divide the batch."""
+    that does not divide the batch; dr: with the dynamics re-drawn before every control step (each block re-draws and rebuilds its own constant
+    blocks on its own stream)."""
     import json, os
     from robosuite_amd import lift, mjcf
     adir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "robosuite_amd", "assets")
@@ -183,8 +184,12 @@ def test_stream_groups_do_not_change_any_result(groups):
     for G in (1, groups):
         env = lift.LiftBatch(flat, cfg, ids, seed0=0, horizon=7, bank_episodes=4)
         env.batch.set_stream_groups(G)
+        if dr:
+            env.batch.dr_save_defaults()
         mid = None
         for t in range(T):
+            if dr:
+                env.batch.randomize_dynamics(seed=3, step=t)
             env.step(tape[t])
             if t == 9:
                 mid = env.batch.get("qpos")

@@ -17,7 +17,7 @@ for name, tag, model, B in (("Stack", "seed0_full", "stack_panda", 4096), ("TwoA
     if only and name not in only:
         continue
     g, cfg, flat = load_golden(tag, model)
-    env = VecEnv(name, B, flat, cfg, seed=0, horizon=500, bank_episodes=2)
+    env = VecEnv(name, B, flat, cfg, seed=0, horizon=500, bank_episodes=2, stream_groups=int(os.environ.get("RSIM_GROUPS", 8)))
     env.reset()
     gen = torch.Generator(device="cuda"); gen.manual_seed(1)
     acts = [torch.rand(B, env.action_dim, device="cuda", generator=gen) * 2 - 1 for _ in range(steps + 5)]
@@ -36,6 +36,7 @@ if not only or "PickPlaceDR" in only:
     env = pick_place.PickPlaceBatch(flat, cfg, np.arange(B), seed0=0, horizon=500, bank_episodes=2, per_env_params=True)
     b = env.batch
     b.dr_save_defaults()
+    b.set_stream_groups(int(os.environ.get("RSIM_GROUPS", 8)))
     gen = torch.Generator(device="cuda"); gen.manual_seed(1)
     acts = [torch.rand(B, env.model.action_dim, device="cuda", generator=gen) * 2 - 1 for _ in range(steps + 5)]
     for t in range(5): b.randomize_dynamics(seed=11, step=t); env.step(acts[t])
