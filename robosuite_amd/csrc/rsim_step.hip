@@ -611,46 +611,47 @@ struct RcholStepF {   // RcholStep with chol_inplace()'s fp32 safeguard: a pivot
     }
   }
 };
+// One column block of the factorisation, right-looking over ALL rows from the block's first row down (lane i = row c0 + i): column J's pivot
+// comes from lane J, every lane scales its entry and takes the rank-1 update of its remaining 15 - J entries against the entries of lanes
+// J + 1 .. 15 (uniform v_readlane operands).  The diagonal block and the panel below it are the same 136 readlane + FMA pairs -- the separate
+// register factorisation of the diagonal block (four redundant copies, DPP chain) and its LDS round trip are gone.  Same products in the same
+// order as the two-stage form it replaces.
 template <int NVP>
 __device__ __forceinline__ void bchol_inplace(float* H, float* invdiag, int n, int lane) {
   const int nb = (n + 15) >> 4, r = lane & 15, q = lane >> 4;
   const float dorig = H[(lane < 16 * nb ? lane : 0) * NVP + (lane < 16 * nb ? lane : 0)];   // original diagonal (pivot floor)
   for (int b = 0; b < nb; b++) {
     const int c0 = 16 * b;
-    // (1) diagonal block: row r in lanes r, 16 + r, 32 + r, 48 + r
-    float hr[16], hinv[16];
+    const int row = c0 + lane;
+    const bool act = row < 16 * nb;
+    float x[16], iv[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) hr[k] = H[(c0 + r) * NVP + c0 + k];
-    const int ro = opaque_lane(r);
-    float own = 0.f;
-    RcholStepF<0>::run(hr, hinv, ro, own, __shfl(dorig, c0 + r));
-    rchol_mask_lower<16>(hr, ro);
+    for (int k = 0; k < 16; k++) x[k] = H[(act ? row : c0) * NVP + c0 + k];
+    const float dfl = 1.0e-6f * __shfl(dorig, c0 + r);   // lane J (J < 16) holds the floor of column c0 + J
+#pragma unroll
+    for (int J = 0; J < 16; J++) {
+      const float piv = fmaxf(bcast(x[J], J), bcast(dfl, J));   // a pivot that cancelled below 1e-6 of its original diagonal entry is floored there
+      const float ivj = rsqrtf(fmaxf(piv, FMIN));
+      iv[J] = ivj;
+      const float lij = x[J] * ivj;
+      x[J] = lij;
+#pragma unroll
+      for (int K = J + 1; K < 16; K++) x[K] = fmaf(-lij, bcast(lij, K), x[K]);
+    }
     SYNC();
-    if (lane < 16) {
+    if (act) {
 #pragma unroll
-      for (int k = 0; k < 16; k++) H[(c0 + lane) * NVP + c0 + k] = hr[k];   // strictly lower part of L_bb (diagonal and above: zeros, never read)
+      for (int k = 0; k < 16; k++) H[row * NVP + c0 + k] = (lane >= 16 || k < lane) ? x[k] : 0.f;   // diagonal block: strictly lower part (diagonal and above: zeros, never read)
+    }
+    if (lane < 16) {
+      float own = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; k++) own = lane == k ? iv[k] : own;
       invdiag[c0 + lane] = own;
     }
     if (b + 1 == nb) break;
-    // (2) panel below the block: lane = row c0 + 16 + lane; x_k = (a_k - sum_{m<k} x_m L[k][m]) / L[k][k], factor entries from the holder lanes
-    const int prow = c0 + 16 + lane;
-    const bool pact = prow < 16 * nb;
-    float x[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = H[(pact ? prow : 0) * NVP + c0 + k];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-#pragma unroll
-      for (int mm = 0; mm < k; mm++) x[k] = fmaf(-x[mm], bcast(hr[mm], k), x[k]);   // hr[mm] of lane k = L[k][mm]
-      x[k] *= hinv[k];
-    }
     SYNC();
-    if (pact) {
-#pragma unroll
-      for (int k = 0; k < 16; k++) H[prow * NVP + c0 + k] = x[k];
-    }
-    SYNC();
-    // (3) trailing tiles (I, J), b < J <= I < nb: A_IJ -= L_Ib L_Jb^T
+    // trailing tiles (I, J), b < J <= I < nb: A_IJ -= L_Ib L_Jb^T
     for (int I = b + 1; I < nb; I++)
       for (int Jb = b + 1; Jb <= I; Jb++) {
         v4f acc;
@@ -815,8 +816,8 @@ struct SupGeom {
 };
 __device__ __forceinline__ SupGeom sup_load(cmr_t cm, cmr_t cmg, int g, gcf mesh_vert, int lane, V3 org) {
   SupGeom s;
-  s.t = cm->gtype[g];
-  const int gm = cm->gmesh[g];
+  s.t = uni(cm->gtype[g]);          // scalar: the type dispatch of every support call becomes s_cbranch on an SGPR instead of exec-masked regions
+  const int gm = uni(cm->gmesh[g]);
   s.adr = gm & 0xffff; s.num = gm >> 16;
   s.R = ldm(sm.gmat + 9 * g);
   s.p = ld3(sm.gpos + 3 * g) - org; s.h = ld3(cmg->gst + 8 * g);
