@@ -105,7 +105,8 @@ typedef struct rsim_ctrl_desc {
  * task 3: reward = TwoArmPegInHole.reward (two_arm_peg_in_hole.py:240-290) with object = peg, object2 = hole: success (d < 0.06, -0.12 <= t <= 0.14,
  * cos > 0.95; :513-521) + reaching + perpendicular / parallel distance + alignment terms, scaled by reward_scale / 5.0.
  * task 4: reward = PickPlace.reward / staged_rewards / _check_success (pick_place.py:274-429, 737-762) over nobj objects (all-objects mode): objects
- * in their bins + max(reach, grasp, lift, hover) over the others, scaled by reward_scale / 4.0; success = every object in its bin. */
+ * in their bins + max(reach, grasp, lift, hover) over the others, scaled by reward_scale / 4.0; success = every object in its bin
+ * (single_object_mode != 0: scaled by reward_scale, success = any object in its bin). */
 enum { RSIM_OBS_QPOS = 0, RSIM_OBS_COS, RSIM_OBS_SIN, RSIM_OBS_QVEL, RSIM_OBS_QACC, RSIM_OBS_SITE_POS, RSIM_OBS_BODY_QUAT, RSIM_OBS_SITE_QUAT,
        RSIM_OBS_BODY_POS, RSIM_OBS_BODY_MINUS_SITE, RSIM_OBS_BODY_MINUS_BODY, RSIM_OBS_PEG_COS, RSIM_OBS_PEG_T, RSIM_OBS_PEG_D,
        RSIM_OBS_REL_POS, RSIM_OBS_REL_QUAT };
@@ -131,6 +132,9 @@ typedef struct rsim_task_desc {
   int32_t eef_body;                   /* body whose quaternion is `{arm}eef_quat` */
   float bin2_pos[3], bin_size[2];     /* pick_place.py:188-199 */
   float bin_target[8];                /* target_bin_placements[i][0..1] (pick_place.py:570-583) */
+  int32_t single_object_mode;         /* PickPlace: 0 = all objects; 2 = one fixed object (PickPlaceMilk / Bread / Cereal / Can, pick_place.py:800-847): the
+                                       * reward is not divided by 4 (:308-310) and success = any object in its bin (:757-759).  The other objects stay in the
+                                       * model -- the host's reset moves them to (10, 10, 10) (base.py:591-602) -- and in every sum of the reward, as in the reference */
 } rsim_task_desc;
 
 /* state / derived arrays addressable through rsim_get_array / rsim_set_array / rsim_device_ptr */

@@ -72,7 +72,7 @@ class TaskDesc(C.Structure):
                 ("table_height", C.c_float), ("lift_margin", C.c_float), ("reward_scale", C.c_float), ("reward_shaping", C.c_int32),
                 ("left_pad_geoms", C.c_uint64), ("right_pad_geoms", C.c_uint64), ("object_geoms", C.c_uint64), ("object2_body", C.c_int32),
                 ("object2_geoms", C.c_uint64), ("nobj", C.c_int32), ("obj_body", C.c_int32 * 4), ("obj_geoms", C.c_uint64 * 4), ("pos_slot", C.c_int32 * 4),
-                ("eef_body", C.c_int32), ("bin2_pos", C.c_float * 3), ("bin_size", C.c_float * 2), ("bin_target", C.c_float * 8)]
+                ("eef_body", C.c_int32), ("bin2_pos", C.c_float * 3), ("bin_size", C.c_float * 2), ("bin_target", C.c_float * 8), ("single_object_mode", C.c_int32)]
 
 
 class DrDesc(C.Structure):
@@ -267,6 +267,7 @@ class HipModel:
         d.object2_geoms = mask(task.get("object2_geoms", []))
         if d.task == 4:
             d.nobj, d.eef_body = len(task["obj_body"]), int(task["eef_body"])
+            d.single_object_mode = int(task.get("single_object_mode", 0))
             for i in range(d.nobj):
                 d.obj_body[i], d.pos_slot[i], d.obj_geoms[i] = int(task["obj_body"][i]), int(task["pos_slot"][i]), mask(task["obj_geoms"][i])
             for i in range(3):

@@ -629,6 +629,9 @@ extern "C" int rsim_model_set_task(rsim_model* m, const rsim_task_desc* d) {
   }
   if (d->task < 0 || d->task > 4) return fail("task: unknown task id %d", d->task);
   if (d->task == 4) {
+    if (d->single_object_mode != 0 && d->single_object_mode != 2)
+      return fail("task: PickPlace single_object_mode %d is not supported (0 = all objects, 2 = one fixed object; mode 1 draws the object per episode and "
+                  "would need a per-env object id in the observation program)", d->single_object_mode);
     if (d->nobj < 1 || d->nobj > 4 || d->eef_body < 0 || d->eef_body >= m->nbody || d->grip_site < 0 || d->grip_site >= m->nsite) return fail("task: bad PickPlace description");
     for (int i = 0; i < d->nobj; i++)
       if (d->obj_body[i] < 0 || d->obj_body[i] >= m->nbody || d->pos_slot[i] < 0 || d->pos_slot[i] + 7 > d->nobs) return fail("task: bad PickPlace object %d", i);
@@ -744,7 +747,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
     dm.task.reward_shaping = t.reward_shaping; dm.task.table_height = t.table_height; dm.task.lift_margin = t.lift_margin; dm.task.reward_scale = t.reward_scale;
     dm.task.left_pad = t.left_pad_geoms; dm.task.right_pad = t.right_pad_geoms; dm.task.object_geoms = t.object_geoms; dm.task.obs_prog = b->d_obsprog;
     dm.task.object2_body = t.object2_body; dm.task.object2_geoms = t.object2_geoms;
-    dm.task.nobj = t.nobj; dm.task.eef_body = t.eef_body;
+    dm.task.nobj = t.nobj; dm.task.eef_body = t.eef_body; dm.task.single_mode = t.single_object_mode;
     for (int i = 0; i < 4; i++) { dm.task.obj_body[i] = t.obj_body[i]; dm.task.pos_slot[i] = t.pos_slot[i]; dm.task.obj_geoms[i] = t.obj_geoms[i]; }
     for (int i = 0; i < 3; i++) dm.task.bin2_pos[i] = t.bin2_pos[i];
     for (int i = 0; i < 2; i++) dm.task.bin_size[i] = t.bin_size[i];

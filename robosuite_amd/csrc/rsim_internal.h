@@ -121,6 +121,7 @@ struct DTask {
   int nobj, obj_body[4], pos_slot[4], eef_body;
   unsigned long long obj_geoms[4];
   float bin2_pos[3], bin_size[2], bin_target[8];
+  int single_mode;       // PickPlace single-object modes: reward not divided by the object count, success = any object in its bin
   const int* obs_prog;   // device [nobs][3]
 };
 

@@ -3351,7 +3351,7 @@ struct Sim {
         const int nin = __popcll(in_mask);
         float r = (float)nin;
         if (t.reward_shaping) r += fmaxf(fmaxf(r_reach, r_grasp), fmaxf(r_lift, r_hover));
-        if (reward) { *reward = r * t.reward_scale / 4.0f; *success = nin == t.nobj ? 1 : 0; }
+        if (reward) { *reward = t.single_mode ? r * t.reward_scale : r * t.reward_scale / 4.0f; *success = (t.single_mode ? nin > 0 : nin == t.nobj) ? 1 : 0; }
       }
     } else if (t.task == 3) {
       if (lane == 0) {

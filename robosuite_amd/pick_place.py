@@ -5,8 +5,13 @@
                sensors precede the object's own pos / quat sensors in the Observable order and read them from the observation cache, so they
                see the object pose of the PREVIOUS control step against the current gripper pose (and zeros in the record reset() returns);
                the kernel reproduces that (include/rsim.h RSIM_OBS_REL_POS).
-  reward       pick_place.py:274-429 (all-objects mode), success :737-762
-The bin placement samplers (pick_place.py:431-513) and the visual-object bodies are not restated yet: batches start from given states.
+  reward       pick_place.py:274-429, success :737-762
+  single-object mode 2 (PickPlaceMilk / Bread / Cereal / Can, pick_place.py:800-847; cfg["task"]["single_object_mode"] = 2, ["object_id"]): the
+               observation record holds the chosen object's sensors only (:612-624), reset() moves the other three objects out of the scene
+               (clear_objects, base.py:591-602: free joint at (10, 10, 10), from where they fall for the rest of the episode -- they stay in the
+               reward's sums exactly as in the reference), the reward is not divided by 4 and success = the object is in its bin.
+               Mode 1 (PickPlaceSingle: the object is drawn per episode from a Python set, i.e. in hash order) is not restated.
+The visual-object bodies (pick_place.py:455-513, 703-706: static bodies without collision geoms) take no part in the dynamics and are not restated.
 """
 from __future__ import annotations
 
@@ -24,12 +29,16 @@ def pick_place_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool =
     obs += [("site_pos", gsite, k) for k in range(3)] + [("body_quat", eef_body, k) for k in range(4)] + [("site_quat", gsite, k) for k in range(4)]
     obs += [("qpos", q, 0) for q in gq] + [("qvel", d, 0) for d in gd]
     obj_body = [body.index(b) for b in t["object_bodies"]]
+    single, only = int(t.get("single_object_mode", 0)), int(t.get("object_id", -1))
     pos_slot = []
     for i, ob in enumerate(obj_body):
+        if single and i != only:      # pick_place.py:616-624: the other objects' sensors are disabled
+            pos_slot.append(0)
+            continue
         obs += [("rel_pos", i, k) for k in range(3)] + [("rel_quat", i, k) for k in range(4)]
         pos_slot.append(len(obs))
         obs += [("body_pos", ob, k) for k in range(3)] + [("body_quat", ob, k) for k in range(4)]
-    return dict(obs=obs, task="pick_place", grip_site=gsite, eef_body=eef_body, obj_body=obj_body, pos_slot=pos_slot,
+    return dict(obs=obs, task="pick_place", grip_site=gsite, eef_body=eef_body, obj_body=obj_body, pos_slot=pos_slot, single_object_mode=single,
                 obj_geoms=[[geom.index(g) for g in gs] for gs in t["object_geoms"]], bin2_pos=t["bin2_pos"], bin_size=t["bin_size"][:2],
                 bin_target=[r[:2] for r in t["target_bin_placements"]], left_pad_geoms=[geom.index(g) for g in t["left_pad"]],
                 right_pad_geoms=[geom.index(g) for g in t["right_pad"]], reward_scale=reward_scale, reward_shaping=reward_shaping)
@@ -72,12 +81,17 @@ def reset_draws(rng: np.random.Generator, placement: dict):
     return dict(arm=arm, objects=out)
 
 
-def initial_qpos(draw, placement: dict, nq: int) -> np.ndarray:
+def initial_qpos(draw, placement: dict, nq: int, only: int = -1) -> np.ndarray:
+    """only >= 0 (single-object mode 2): every object is placed by the sampler as usual, then all but object `only` are moved out of the scene
+    (pick_place.py:723-727 -> base.py:591-602)."""
     q = np.zeros(nq)
     q[placement["arm_qpos_idx"]] = draw["arm"]
     q[placement["gripper_qpos_idx"]] = placement["gripper_init_qpos"]
-    for o, (pos, yaw) in zip(placement["objects"], draw["objects"]):
+    for i, (o, (pos, yaw)) in enumerate(zip(placement["objects"], draw["objects"])):
         a = o["qposadr"]
+        if only >= 0 and i != only:
+            q[a:a + 7] = (10.0, 10.0, 10.0, 1.0, 0.0, 0.0, 0.0)
+            continue
         q[a:a + 3] = pos
         q[a + 3], q[a + 6] = np.cos(yaw / 2.0), np.sin(yaw / 2.0)
     return q
@@ -85,12 +99,13 @@ def initial_qpos(draw, placement: dict, nq: int) -> np.ndarray:
 
 def episode_setup(cfg, nq: int, seed0: int, env_ids, block: int = 0):
     pl = cfg["task"]["placement"]
+    only = int(cfg["task"].get("object_id", -1)) if int(cfg["task"].get("single_object_mode", 0)) == 2 else -1
     out = []
     for i in env_ids:
         rng = np.random.default_rng(seed0 + int(i))
         for _ in range(block + 1):
             d = reset_draws(rng, pl)
-        out.append(initial_qpos(d, pl, nq))
+        out.append(initial_qpos(d, pl, nq, only))
     return np.array(out)
 
 

@@ -17,6 +17,8 @@ import numpy as np
 from . import lift, peg_in_hole, pick_place, stack
 
 TASKS = {"Lift": lift.LiftBatch, "Stack": stack.StackBatch, "TwoArmPegInHole": peg_in_hole.PegBatch, "PickPlace": pick_place.PickPlaceBatch}
+# single-object mode 2 of PickPlace (pick_place.py:810-847): the model / task constants of the env's own fixture carry single_object_mode and object_id
+TASKS.update({n: pick_place.PickPlaceBatch for n in ("PickPlaceMilk", "PickPlaceBread", "PickPlaceCereal", "PickPlaceCan")})
 
 
 class VecEnv:

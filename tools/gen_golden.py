@@ -257,26 +257,28 @@ GRIPPER_SIGNS = {"PandaGripper": [-1.0, 1.0], "Robotiq140Gripper": [1.0, -1.0], 
                  "JacoThreeFingerGripper": [-1.0, -1.0, -1.0]}   # jaco_three_finger_gripper.py:57-71: current_action - speed * sign(action)
 
 
-def record_pickplace(seed, n_steps, action_scale, tag):
+def record_pickplace(seed, n_steps, action_scale, tag, env_name="PickPlace", stem="pickplace_iiwa"):
     """BASELINE configs[4] model: PickPlace / IIWA + Robotiq140 (nv 37, 4 fixed tendons under equality/tendon constraints, 41 colliding geoms).
     Runs on the CPU oracle only so far; the fixture pins the OSC / gripper restatement on this robot and is the target of the next kernel
     configuration."""
-    env = suite.make("PickPlace", robots="IIWA", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
+    env = suite.make(env_name, robots="IIWA", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
                      reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed)
+    make_qpos = np.array(env.sim.data.qpos)
     obs = env.reset()
     sim = env.sim
     flat = sim.model._model._flat
     rng = np.random.default_rng(10**6 + seed)
     keys = [k for k in obs.keys() if not k.endswith("-state")]
-    actions, states, rewards, obs_flat, ctrls = [], [sim.get_state().flatten()], [], [], []
+    actions, states, rewards, obs_flat, ctrls, succ = [], [sim.get_state().flatten()], [], [], [], []
     for t in range(n_steps):
         a = action_scale * rng.uniform(-1, 1, env.action_dim)
         obs, r, done, info = env.step(a)
-        ctrls.append(np.array(sim.data.ctrl)); actions.append(a); states.append(sim.get_state().flatten()); rewards.append(r)
+        ctrls.append(np.array(sim.data.ctrl)); actions.append(a); states.append(sim.get_state().flatten()); rewards.append(r); succ.append(int(env._check_success()))
         obs_flat.append(np.concatenate([np.atleast_1d(obs[k]).astype(np.float64) for k in keys]))
-    np.savez_compressed(os.path.join(GOLD, f"pickplace_iiwa_{tag}.npz"), actions=np.array(actions), states=np.array(states), rewards=np.array(rewards),
-                        obs=np.array(obs_flat), ctrl=np.array(ctrls))
-    mjcf.save_model(flat, os.path.join(GOLD, f"pickplace_iiwa_{tag}.rsim"))
+    extra = {} if stem == "pickplace_iiwa" else dict(make_qpos=make_qpos, success=np.array(succ))   # the all-objects fixture keeps its round-1 layout
+    np.savez_compressed(os.path.join(GOLD, f"{stem}_{tag}.npz"), actions=np.array(actions), states=np.array(states), rewards=np.array(rewards),
+                        obs=np.array(obs_flat), ctrl=np.array(ctrls), **extra)
+    mjcf.save_model(flat, os.path.join(GOLD, f"{stem}_{tag}.rsim"))
     cfg = controller_cfg(env)
     cfg["grip_sign"] = GRIPPER_SIGNS[type(env.robots[0].gripper["right"]).__name__]
     # task constants of PickPlace (pick_place.py:188-199, 560-583): object order, bin geometry, the gripper's finger-pad geom groups
@@ -286,6 +288,8 @@ def record_pickplace(seed, n_steps, action_scale, tag):
                        bin_size=[float(x) for x in env.bin_size], target_bin_placements=[[float(x) for x in r] for r in env.target_bin_placements],
                        left_pad=list(g.important_geoms["left_fingerpad"]), right_pad=list(g.important_geoms["right_fingerpad"]),
                        eef_body=env.robots[0].robot_model.eef_name["right"], grip_site=g.important_sites["grip_site"])
+    if env.single_object_mode:
+        cfg["task"].update(single_object_mode=int(env.single_object_mode), object_id=int(env.object_id))
     # reset path constants (pick_place.py:431-483, placement_samplers.py:221-309): bin the objects are dropped into, per-object footprint
     cfg["task"]["placement"] = dict(
         bin1_pos=[float(x) for x in env.bin1_pos], z_offset=float(env.z_offset), z_rotation=env.z_rotation,
@@ -296,7 +300,7 @@ def record_pickplace(seed, n_steps, action_scale, tag):
         arm_qpos_idx=[int(i) for i in env.robots[0]._ref_joint_pos_indexes], gripper_qpos_idx=[int(i) for i in env.robots[0]._ref_gripper_joint_pos_indexes["right"]])
     cfg["obs_keys"] = keys
     cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in keys]
-    with open(os.path.join(GOLD, f"pickplace_iiwa_{tag}.cfg.json"), "w") as f:
+    with open(os.path.join(GOLD, f"{stem}_{tag}.cfg.json"), "w") as f:
         json.dump(cfg, f, indent=1)
     print("pickplace", tag, "nv", flat.nv, "nbody", flat.nbody, "ntendon", int(flat.ntendon), "neq", int(flat.neq), "steps", n_steps, "reward", rewards[-1])
 
@@ -416,6 +420,9 @@ def record_lift(seed, n_steps, action_scale, tag):
 
 
 if __name__ == "__main__":
+    if "--pickplace-single-only" in sys.argv:   # single-object mode 2 (pick_place.py:840-847): the can only; seed 2 = both reset paths
+        record_pickplace(seed=2, n_steps=20, action_scale=1.0, tag="seed2_full", env_name="PickPlaceCan", stem="pickplace_can_iiwa")
+        sys.exit(0)
     if "--pickplace-only" in sys.argv:
         record_pickplace(seed=0, n_steps=20, action_scale=1.0, tag="seed0_full")
         record_pickplace_resets([0, 1, 2, 3])
