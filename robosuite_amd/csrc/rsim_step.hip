@@ -59,6 +59,15 @@ typedef unsigned long long u64;
 #define SUBMARK_OSC(id) SUBMARK(id)
 #define SUBMARK_H(id)
 #endif
+#if defined(RSIM_SUBPROF) && RSIM_SUBPROF == 3   /* tools/subprof.sh 3: slots x0..x7 split the CRB and velocity stages (wide configurations) instead of the solver */
+#undef SUBMARK
+#define SUBMARK(id)
+#undef SUBMARK_OSC
+#define SUBMARK_OSC(id)
+#define SUBMARK_T(id) pf.mark(id)
+#else
+#define SUBMARK_T(id)
+#endif
 // One workgroup = one wavefront: LDS instructions of a wave execute in issue order, so cross-lane communication through LDS needs no
 // s_waitcnt / s_barrier, only a compiler-level ordering point (wavefront-scope fences emit no instructions; __syncthreads() would
 // drain the LDS queue with s_waitcnt lgkmcnt(0) at every one of the ~110 sites).
@@ -328,6 +337,11 @@ struct Cmem {
   dmask_t dmask_anc[S::NM_], dmask_cvel[S::NM_];
   unsigned long long bmask_anc[S::TREE_TILE_ ? 1 : NB];
   int dynroot[RSIM_MAXDYNROOT];  // root body of each articulated tree (a run-time index into the by-value DModel would put a copy of it into the private segment)
+  // the same incidence relations as MFMA A operands (wide configurations, shared block only: topology, no float-table field): lane (q = lane >> 4,
+  // r = lane & 15), bit t * KS + c = relation(row 16 t + r, column 4 c + q) for row tile t and k-step c --
+  //   msub: dof row / body column: the body lies in the subtree of the dof's body (KS = NB / 4)
+  //   mbd:  body row / dof column: the dof moves the body (KS = NV / 4)      mcv: dof row / dof column: summed before the dof in the velocity recursion
+  unsigned long long msub[S::TREE_TILE_ ? 1 : 64], mbd[S::TREE_TILE_ ? 1 : 64], mcv[S::TREE_TILE_ ? 1 : 64];
   // per-lane model constants, one row per field (LaneConst below); phases fetch the handful they need instead of pinning ~80 VGPRs
   float kc[RSIM_KC_WORDS(NB, NV, S::NGW_, NS, NPAIR)];
 };
@@ -1124,6 +1138,26 @@ struct Sim {
       if constexpr (!TREE) {
         if (lane < NV16) { cw->dmask_anc[lane] = lane < nv ? dmask_load(IO_dof_ancmask, i) : (dmask_t)0; cw->dmask_cvel[lane] = lane < nv ? dmask_load(IO_dof_cvelmask, i) : (dmask_t)0; }
         if (lane < SM_NB) cw->bmask_anc[lane] = lane < nb ? mask2(IO_body_ancmask, lane) : 0ull;
+        if (m.fenv == 0) {   // the shared block (topology only; the env blocks never hold these)
+          constexpr int KB = SM_NB / 4, NBT = SM_NB / 16, KV = NV16 / 4;
+          const int r = lane & 15, q = lane >> 4;
+          u64 ms = 0, mb = 0, mc = 0;
+          for (int t = 0; t < NT; t++) {
+            const int di = 16 * t + r;
+            if (di >= nv) continue;
+            const int bi = IT(IO_dof_bodyid, di);
+            const u64 cv = (u64)dmask_load(IO_dof_cvelmask, di);
+            for (int c = 0; c < KB; c++) { const int d = 4 * c + q; if (d >= 1 && d < nb && ((mask2(IO_body_ancmask, d) >> bi) & 1ull)) ms |= 1ull << (t * KB + c); }
+            for (int c = 0; c < KV; c++) { const int j = 4 * c + q; if (j < nv && ((cv >> j) & 1ull)) mc |= 1ull << (t * KV + c); }
+          }
+          for (int t = 0; t < NBT; t++) {
+            const int b = 16 * t + r;
+            if (b >= nb) continue;
+            const u64 bd = (u64)dmask_load(IO_body_dofmask, b);
+            for (int c = 0; c < KV; c++) { const int j = 4 * c + q; if (j < nv && ((bd >> j) & 1ull)) mb |= 1ull << (t * KV + c); }
+          }
+          cw->msub[lane] = ms; cw->mbd[lane] = mb; cw->mcv[lane] = mc;
+        }
       }
     }
     {  // geom role
@@ -1301,6 +1335,88 @@ struct Sim {
   // f_i = crbD_i * cdof_i ;  M = (m1 o F C^T) + (m2 o C F^T) + diag(armature)        (F, C = 16 x 6 stacks of f_i, cdof_i)
   // wide configuration: the same products as mask-guided lane loops (lane i = dof i sums the bodies of its subtree; element-parallel M),
   // factorisations on the LDS matrix
+  // out tile t (rows 16 t .. 16 t + 15) = sum over k-steps c < kmax of Incidence(t, c) x B(c) on the matrix cores: the A operand is this lane's
+  // incidence bit (Cmem::msub / mbd / mcv), the B operand of k-step c -- bop(c), row 4 c + (lane >> 4), column lane & 15 -- is read once and
+  // serves every row tile.  Replaces the mask-guided lane loops of the wide configurations (one LDS round trip per body / dof and lane).
+  template <int NTILE, int KS, class BOP>
+  __device__ __forceinline__ void incidence_mfma(u64 mask, int kmax, BOP bop, v4f (&acc)[NTILE]) const {
+    unsigned mt[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; t++) { mt[t] = (unsigned)(mask >> (t * KS)) & ((KS < 32) ? ((1u << (KS & 31)) - 1u) : 0xFFFFFFFFu); acc[t] = v4f{0.f, 0.f, 0.f, 0.f}; }
+    for (int c0 = 0; c0 < kmax; c0 += 2) {   // two k-steps per trip: both B operands in flight before the products
+      const float b0 = bop(c0), b1 = bop(c0 + 1);
+#pragma unroll
+      for (int t = 0; t < NTILE; t++) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(mt[t] & 1u), b0, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)((mt[t] >> 1) & 1u), b1, acc[t], 0, 0, 0);
+        mt[t] >>= 2;
+      }
+    }
+  }
+  __device__ __forceinline__ void crb_composite_mfma() {
+    const int nv = m.nv, nb = m.nbody, q = lane >> 4, r = lane & 15;
+    constexpr int KB = SM_NB / 4;
+    v4f acc[NT];
+    const int kmax = ((nb + 7) >> 3) << 1;   // k-steps in pairs; rows nb .. NB - 1 of cinert are zero (init_lds) and their incidence bits clear
+    incidence_mfma<NT, KB>(cm->msub[lane], kmax < KB ? kmax : KB, [&](int c) { return sm.cinert[(4 * c + q) * 10 + r]; }, acc);
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) sm.u.c.crbD[(16 * t + 4 * q + v) * FS + r] = acc[t][v];
+    SYNC();
+    if (lane < NV16) {
+      S6 f = {v3(0, 0, 0), v3(0, 0, 0)};
+      if (lane < nv) f = mul_inert(sm.u.c.crbD + FS * lane, ld6(sm.cdof + CS6 * lane));
+      float* o = sm.u.c.fpad + CS6 * lane;
+      st3(o, f.a); st3(o + 3, f.l); o[6] = 0.f; o[7] = 0.f;
+    }
+    SYNC();
+  }
+  // M = m1 o (F C^T) + m2 o (C F^T) + diag(armature) tile by tile (F = composite-inertia forces, C = cdof, 6 components = two k-steps), masks
+  // from the dof-ancestor sets; written to M and, in the same pass, to the factorisation's work matrix
+  __device__ __forceinline__ void crb_mass_mfma() {
+    const int nv = m.nv, q = lane >> 4, r = lane & 15;
+    float fa[NT][2], ca[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+      for (int kc = 0; kc < 2; kc++) { fa[t][kc] = sm.u.c.fpad[(16 * t + r) * CS6 + 4 * kc + q]; ca[t][kc] = sm.cdof[(16 * t + r) * CS6 + 4 * kc + q]; }
+    dmask_t arow[NT][4], acol[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      acol[t] = cm->dmask_anc[16 * t + r];
+#pragma unroll
+      for (int v = 0; v < 4; v++) arow[t][v] = cm->dmask_anc[16 * t + 4 * q + v];
+    }
+#pragma unroll
+    for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+      for (int tj = 0; tj < NT; tj++) {
+        if (16 * ti >= nv || 16 * tj >= nv) {   // tile without dofs: identity padding
+#pragma unroll
+          for (int v = 0; v < 4; v++) { const int i = 16 * ti + 4 * q + v, j = 16 * tj + r; const float e = i == j ? cmf(MK_arm)->arm[i] : 0.f; sm.M[i * NVP + j] = e; sm.L[i * NVP + j] = e; }
+          continue;
+        }
+        v4f R1 = {0.f, 0.f, 0.f, 0.f}, R2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 2; kc++) {
+          R1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ti][kc], ca[tj][kc], R1, 0, 0, 0);
+          R2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[ti][kc], fa[tj][kc], R2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const int i = 16 * ti + 4 * q + v, j = 16 * tj + r;
+          const bool a1 = (arow[ti][v] >> j) & 1, a2 = (acol[tj] >> i) & 1;
+          float mij = a1 ? R1[v] : (a2 ? R2[v] : 0.f);
+          if (i == j) mij += cmf(MK_arm)->arm[i];
+          sm.M[i * NVP + j] = mij; sm.L[i * NVP + j] = mij;
+        }
+      }
+    SYNC();
+    SUBMARK_T(RP_X2);
+    bchol_inplace<NVP>(sm.L, sm.invdiag, nv, lane);
+    SUBMARK_T(RP_X3);
+  }
   __device__ __forceinline__ void crb_composite_loops() {
     const LaneConst K = fetchK();
     const int nv = m.nv, nb = m.nbody;
@@ -1338,6 +1454,7 @@ struct Sim {
       sm.M[i * NVP + j] = mij;
     }
     SYNC();
+    SUBMARK_T(RP_X1);
     const float hd = lane < nv ? opt_h * K.damping : 0.f;
     (void)hd;
     const int nvt = (nv + 15) & ~15;   // whole 16-column blocks (the padding rows / columns of M are identity): what the blocked factorisation walks
@@ -1346,12 +1463,15 @@ struct Sim {
       sm.L[i * NVP + j] = sm.M[i * NVP + j];
     }
     SYNC();
+    SUBMARK_T(RP_X2);
     bchol_inplace<NVP>(sm.L, sm.invdiag, nv, lane);
+    SUBMARK_T(RP_X3);
   }
 
   __device__ __forceinline__ void crb() {
-    if constexpr (TREE) crb_composite_tile(); else crb_composite_loops();
-    if constexpr (FAST) crb_mass_tile(); else crb_mass_loops();
+    if constexpr (TREE) crb_composite_tile(); else crb_composite_mfma();
+    SUBMARK_T(RP_X0);
+    if constexpr (FAST) crb_mass_tile(); else crb_mass_mfma();
   }
   __device__ __forceinline__ void crb_composite_tile() {
     const LaneConst K = fetchK();
@@ -1436,11 +1556,26 @@ struct Sim {
       for (int v = 0; v < 4; v++) { sm.u.v.cvel[(4 * q + v) * CS6 + r] = a0[v]; sm.u.v.cvel[(16 + 4 * q + v) * CS6 + r] = a1[v]; sm.u.v.cvb[(4 * q + v) * CS6 + r] = a2[v]; }
     }
     } else {
-      // wide configuration: lane b sums the dofs that move body b, lane i the dofs summed before dof i (mask-guided loops)
-      masked_dof_sum(sm.cdof, lane < SM_NB && lane < nb ? cm->bdofs[lane] : (dmask_t)0, lane < SM_NB, sm.u.v.cvel);
-      masked_dof_sum(sm.cdof, lane < nv ? cm->dmask_cvel[lane] : (dmask_t)0, lane < NV16, sm.u.v.cvb);
+      // wide configuration: cvel = BodyDof x (cdof qd), cvb = Before x (cdof qd) as incidence products sharing the B operands
+      constexpr int NBT = SM_NB / 16, KV = NV16 / 4;
+      const int kmax = ((nv + 7) >> 3) << 1;
+      auto bop = [&](int c) { const int i = 4 * c + q; return (r < 6 && i < nv) ? sm.cdof[i * CS6 + r] * sm.qvel[i] : 0.f; };
+      v4f ab[NBT], av[NT];
+      incidence_mfma<NBT, KV>(cm->mbd[lane], kmax < KV ? kmax : KV, bop, ab);
+      incidence_mfma<NT, KV>(cm->mcv[lane], kmax < KV ? kmax : KV, bop, av);
+      if (r < 8) {
+#pragma unroll
+        for (int t = 0; t < NBT; t++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) sm.u.v.cvel[(16 * t + 4 * q + v) * CS6 + r] = ab[t][v];
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) sm.u.v.cvb[(16 * t + 4 * q + v) * CS6 + r] = av[t][v];
+      }
     }
     SYNC();
+    SUBMARK_T(RP_X4);
     if (lane < NV16) {
       S6 cd = {v3(0, 0, 0), v3(0, 0, 0)};
       if (lane < nv && !((K.dinfo >> 8) & 1)) cd = cross_motion(ld6(sm.u.v.cvb + CS6 * lane), ld6(sm.cdof + CS6 * lane));
@@ -1462,14 +1597,21 @@ struct Sim {
       for (int v = 0; v < 4; v++) { sm.u.v.cacc[(4 * q + v) * CS6 + r] = a0[v]; sm.u.v.cacc[(16 + 4 * q + v) * CS6 + r] = a1[v]; }
     }
     } else {
-      // cacc aliases cvb/cdd: every lane finishes its sum in registers before any lane stores
-      S6 ca = {v3(0, 0, 0), v3(0, 0, 0)};
-      const dmask_t mk = lane < SM_NB && lane < nb ? cm->bdofs[lane] : (dmask_t)0;
-      for (int i = 0; i < nv; i++) if ((mk >> i) & 1) ca = ca + ld6(sm.u.v.cdd + CS6 * i) * sm.qvel[i];
+      // cacc aliases cvb / cdd: all B operands are read (products issued) before any lane stores
+      constexpr int NBT = SM_NB / 16, KV = NV16 / 4;
+      const int kmax = ((nv + 7) >> 3) << 1;
+      v4f ab[NBT];
+      incidence_mfma<NBT, KV>(cm->mbd[lane], kmax < KV ? kmax : KV, [&](int c) { const int i = 4 * c + q; return (r < 6 && i < nv) ? sm.u.v.cdd[i * CS6 + r] * sm.qvel[i] : 0.f; }, ab);
       SYNC();
-      if (lane < SM_NB) { float* o = sm.u.v.cacc + CS6 * lane; st3(o, ca.a); st3(o + 3, ca.l); }
+      if (r < 6) {
+#pragma unroll
+        for (int t = 0; t < NBT; t++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) sm.u.v.cacc[(16 * t + 4 * q + v) * CS6 + r] = ab[t][v];
+      }
     }
     SYNC();
+    SUBMARK_T(RP_X5);
     if (lane < SM_NB) {
       const int b = lane;
       S6 zero = {v3(0, 0, 0), v3(0, 0, 0)};
@@ -1514,6 +1656,7 @@ struct Sim {
       o[12] = o[13] = o[14] = o[15] = 0.f;
     }
     SYNC();
+    SUBMARK_T(RP_X6);
     if constexpr (TREE) {
     v4f af = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1521,24 +1664,19 @@ struct Sim {
 #pragma unroll
     for (int v = 0; v < 4; v++) sm.u.v.F[(4 * q + v) * FS + r] = af[v];
     } else {
-      // F aliases cf: sum in registers (lane i = dof i over the bodies of its subtree), then store
-      float acc[12];
-#pragma unroll
-      for (int k = 0; k < 12; k++) acc[k] = 0.f;
-      const int bi = K.dinfo & 255;
-      if (lane < nv)
-        for (int d = 1; d < nb; d++) {
-          const float w = (float)((cm->bmask_anc[d] >> bi) & 1);
-#pragma unroll
-          for (int k = 0; k < 12; k++) acc[k] = fmaf(w, sm.u.v.cf[d * FS + k], acc[k]);
-        }
+      // F = Sub x cf (F aliases cf: products first, then the stores)
+      constexpr int KB = SM_NB / 4;
+      const int kmax = ((nb + 7) >> 3) << 1;
+      v4f af[NT];
+      incidence_mfma<NT, KB>(cm->msub[lane], kmax < KB ? kmax : KB, [&](int c) { return sm.u.v.cf[(4 * c + q) * FS + r]; }, af);
       SYNC();
-      if (lane < NV16) {
 #pragma unroll
-        for (int k = 0; k < 12; k++) sm.u.v.F[lane * FS + k] = acc[k];
-      }
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) sm.u.v.F[(16 * t + 4 * q + v) * FS + r] = af[t][v];
     }
     SYNC();
+    SUBMARK_T(RP_X7);
     float tfrc = 0.f;
     if (TENDONS && m.ntendon) {
       // spring-damper on fixed-tendon lengths (mj_passive [3P]): force k (lo - len) / k (hi - len) outside the deadband minus damping on the
@@ -3771,21 +3909,21 @@ extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr
 __global__ __launch_bounds__(1024) void k_order(const unsigned* __restrict__ cost, int* __restrict__ order, int B) {
   __shared__ unsigned lo_hi[2];
   __shared__ int hist[256], base[256];
-  const int tid = threadIdx.x;
-  if (tid < 256) hist[tid] = 0;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int k = tid; k < 256; k += nt) hist[k] = 0;
   if (tid == 0) { lo_hi[0] = 0xFFFFFFFFu; lo_hi[1] = 0u; }
   __syncthreads();
   unsigned lo = 0xFFFFFFFFu, hi = 0u;
-  for (int i = tid; i < B; i += 1024) { const unsigned c = cost[i]; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+  for (int i = tid; i < B; i += nt) { const unsigned c = cost[i]; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
   atomicMin(&lo_hi[0], lo); atomicMax(&lo_hi[1], hi);
   __syncthreads();
   lo = lo_hi[0]; hi = lo_hi[1];
   const float scale = 255.0f / (float)(hi - lo + 1u);
-  for (int i = tid; i < B; i += 1024) atomicAdd(&hist[(int)((float)(hi - cost[i]) * scale)], 1);   // bin 0 = most expensive
+  for (int i = tid; i < B; i += nt) atomicAdd(&hist[(int)((float)(hi - cost[i]) * scale)], 1);   // bin 0 = most expensive
   __syncthreads();
   if (tid == 0) { int acc = 0; for (int k = 0; k < 256; k++) { base[k] = acc; acc += hist[k]; } }
   __syncthreads();
-  for (int i = tid; i < B; i += 1024) order[atomicAdd(&base[(int)((float)(hi - cost[i]) * scale)], 1)] = i;
+  for (int i = tid; i < B; i += nt) order[atomicAdd(&base[(int)((float)(hi - cost[i]) * scale)], 1)] = i;
 }
 // refill of the reset-bank ring: row i of `rows` -> slot (episode[i] % E) of env[i], and the slot's tag := episode[i]
 __global__ __launch_bounds__(64) void k_bank_scatter(float* bank, int* tag, const int* env, const int* episode, const float* rows, int n, int E, int W) {
@@ -3801,7 +3939,9 @@ extern "C" int rsim_launch_bank_scatter(float* bank, int* tag, const int* env, c
   return (int)hipGetLastError();
 }
 extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStream_t stream) {
-  hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, stream, cost, order, B);
+  // one wavefront for an env block of a stream group: its 26 registers fit next to the resident k_step waves of the other blocks, whereas a
+  // 1024-thread workgroup waits (0.24 ms measured) until a whole CU has room for sixteen more wavefronts
+  hipLaunchKernelGGL(k_order, dim3(1), dim3(B <= 1024 ? 64 : 1024), 0, stream, cost, order, B);
   return (int)hipGetLastError();
 }
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream) {

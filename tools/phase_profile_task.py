@@ -28,6 +28,9 @@ for e in (0, B // 2):
     b.sync(); w = b.wavelog(); p = b.profile(False)
     nsub = max(1, p["n_sub"])
     cyc = {k: v for k, v in p.items() if not k.startswith("n_") and k not in ("boxbox", "mpr", "plane") and not k.startswith("x")}
+    if os.environ.get("RSIM_SUBPROF_RAW"):   # RSIM_SUBPROF=3 build: x0 composite | x1 mass loops | x2 copy | x3 factor (crb slot: what is left) ; x4 cvel+cvb | x5 cdd+cacc | x6 body wrench | x7 subtree sums (vel slot: tendons, bias)
+        tot0 = sum(cyc.values()) + sum(v for k, v in p.items() if k.startswith("x"))
+        print("   raw slots per substep (same units): " + "  ".join(f"{k} {v / nsub:.0f}" for k, v in p.items() if (k.startswith("x") and v) or k in ("crb", "vel", "com", "kin", "makec", "broad", "euler", "solve")) + f"  | total {tot0 / nsub:.0f}")
     xs = {k: v for k, v in p.items() if k.startswith("x") and v}
     if xs:   # -DRSIM_SUBPROF build: x0 rows x1 warm start x2 evaluate + J^T f + gradient x3 Hessian weights x4 H, factor, solve x5 line-search setup x6 line search (x7-x9: OSC)
         print("   solver / controller sub-phases (share of the solve phase): " + "  ".join(f"{k} {100 * v / max(1, p['solve']):.1f}%" for k, v in xs.items()))
