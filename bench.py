@@ -16,7 +16,7 @@ the bank) and then sits o_i genuine steps into its second episode.  Every timed 
 including the ~B/500 on-device episode resets per launch.  `--phase fresh` times synchronised episodes from their first step instead.
 
 Stream groups.  One launch lasts as long as its slowest env (contact-rich envs take 3-4 x the median; measured 3.9 ms against a mean slot
-load of 2.5 ms), and the envs are independent of each other.  By default the batch therefore steps as `--groups` (8) contiguous env blocks, each
+load of 2.5 ms), and the envs are independent of each other.  By default the batch therefore steps as `--groups` (16) contiguous env blocks, each
 on its own HIP stream (include/rsim.h rsim_set_stream_groups): `env.step()` still enqueues one control step of all 4096 envs, but a block's
 step t + 1 starts when ITS slowest env has finished step t instead of waiting for the slowest env of the whole batch.  Same work, same results
 (tools/groups_sweep.py: the reached state is bit-identical for every group count); the timed region is still exactly K steps of every env
@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phase", choices=("staggered", "fresh"), default="staggered", help="episode phase of the envs when the timed region starts (module docstring)")
-    ap.add_argument("--groups", type=int, default=8, help="env blocks stepped on their own HIP streams (module docstring); 1 = one launch per step")
+    ap.add_argument("--groups", type=int, default=16, help="env blocks stepped on their own HIP streams (module docstring); 1 = one launch per step")
     ap.add_argument("--no-lockstep", action="store_true", help="skip the second timed region (same K steps with one launch per step)")
     args = ap.parse_args()
 
@@ -198,7 +198,10 @@ def main():
             except Exception:
                 return None
 
-        traffic = pmc("hbm_traffic.json", "bytes_per_launch")            # tools/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE passes)
+        traffic = pmc("hbm_traffic.json", "bytes_per_launch")            # tools/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE passes), one launch of all B envs
+        traffic_step = traffic
+        if traffic:
+            traffic = traffic / G                                         # per launch of one env block, like `achieved`
         valu = pmc("valu_count.json", "valu_per_env_substep")            # tools/pmc_valu.py (SQ_INSTS_VALU pass on this workload)
         issue = None
         if valu:
@@ -217,7 +220,7 @@ def main():
                        "overflow_envs": int(overflow_envs), "lib_sha16": lib_sha, "obs_dim": OBS_DIM_REPORT, "sharding": f"env-block x{world}",
                        "diverged_envs": int(tot["diverged"]), "reward_sum": tot["reward_sum"], "successes": int(tot["successes"])},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes, "concurrent_launches": G,
+                         "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes, "concurrent_launches": G, "traffic_per_control_step": traffic_step,
                          "aggregate_achieved": abytes * G * K / dt / 1e9,   # GB/s of all env blocks together (their launches overlap)
                          "note": "latency/VALU/LDS-bound by design (state LDS-resident for 25 substeps); see DESIGN.md section 6",
                          # the fraction that describes this kernel: VALU issue slots used (PMC instruction count of THIS build x measured rate); null
