@@ -68,6 +68,13 @@ typedef unsigned long long u64;
 #else
 #define SUBMARK_T(id)
 #endif
+#if defined(RSIM_SUBPROF) && RSIM_SUBPROF == 4   /* tools/subprof.sh 4: x0..x6 split constraint assembly, kinematics and geom frames; x7..x9 stay with the OSC controller */
+#undef SUBMARK
+#define SUBMARK(id)
+#define SUBMARK_U(id) pf.mark(id)
+#else
+#define SUBMARK_U(id)
+#endif
 // One workgroup = one wavefront: LDS instructions of a wave execute in issue order, so cross-lane communication through LDS needs no
 // s_waitcnt / s_barrier, only a compiler-level ordering point (wavefront-scope fences emit no instructions; __syncthreads() would
 // drain the LDS queue with s_waitcnt lgkmcnt(0) at every one of the ~110 sites).
@@ -1232,6 +1239,7 @@ struct Sim {
       lp = K.bpos + qrot(K.bquat, K.jaxis) * (sm.qpos[qa] - K.q0);
     }
     if (b == 0) { lp = v3(0, 0, 0); lq.w = 1.f; lq.x = lq.y = lq.z = 0.f; }
+    SUBMARK_U(RP_X4);
     for (int r = 0; r < m.kin_rounds; r++) {
       if (b < SM_NB) { st3(sm.xpos + 3 * b, lp); stq(sm.xquat + 4 * b, lq); }
       SYNC();
@@ -1246,6 +1254,7 @@ struct Sim {
     xp = lp; xq = lq;
     if (b < SM_NB) { st3(sm.xpos + 3 * b, lp); stq(sm.xquat + 4 * b, lq); }
     SYNC();
+    SUBMARK_U(RP_X5);
   }
 
   // colliding geom and site frames (lane g = geom g, lane k = site k)
@@ -2324,6 +2333,7 @@ struct Sim {
       nefc += __popcll(mlo) + __popcll(mhi);
       if (nefc > NEFCAP) { ovf += nefc - NEFCAP; nefc = NEFCAP; }
     }
+    SUBMARK_U(RP_X0);
     // (3) contacts: lane c owns contact c; exclusive scan of the active dimensions gives the first row of each block
     {
       const int ncon = uni(sm.ncon);
@@ -2369,6 +2379,7 @@ struct Sim {
     }
     if (lane == 0) sm.nefc = nefc;
     SYNC();
+    SUBMARK_U(RP_X1);
     // ---- lane r builds row r (and row r + 64 in the 128-row configuration)
 #pragma unroll
     for (int slot = 0; slot < NSLOT; slot++) {
