@@ -299,6 +299,7 @@ struct Smem {
     struct { float cvel[NB * 9]; union { struct { float cvb[NV * 9], cdd[NV * 9]; }; float cacc[NB * 9]; };
              union { float cf[NB * 17]; float F[NV * 17]; }; } v;                          // velocity(): later stages overwrite dead earlier ones
     struct { float cvel[NB * 9]; float Jm[48], Li[36], vv[8], Lt[64], Ys[128]; } k;                  // ctrl_run(): cvel stays live from velocity()
+    float rowst[NV == 16 ? 1 : NEFC * 20];                                                 // make_constraint() (wide): per contact row the two 6-vectors (padded to 8) that multiply cdof, and the two bodies' dof masks
     float W[NV == 16 ? NEFC * (NV + 1) : NEFC * 5];                                        // solve_newton(): Hessian-weighted rows (one-tile configurations); wide: five words per row (four block coefficients, block head | dim | cone flag) from which the products form the weighted row on the fly
   } u;
   float M[NV * NVP];
@@ -1083,6 +1084,7 @@ struct Sim {
     // zero the LDS regions whose padding lanes / columns are read but never written
     for (int e = lane; e < SM_NB * 10 + 16; e += 64) sm.cinert[e] = 0.f;
     for (int e = lane; e < NV16 * CS6; e += 64) sm.cdof[e] = 0.f;
+    if constexpr (!FAST) { for (int e = lane; e < NEFCAP * JS; e += 64) sm.J[e] = 0.f; }   // rows beyond the last written 16-row tile are read (and ignored) by the lanes that own no row: keep them finite
     if (lane < (NROOT + 1) * 3) sm.rootcom[lane] = 0.f;
     if constexpr (SM::HULLPOOL_ > 0) {
       // resident hull pool: one pass per pooled mesh, lane-parallel over its vertices
@@ -2380,6 +2382,7 @@ struct Sim {
     if (lane == 0) sm.nefc = nefc;
     SYNC();
     SUBMARK_U(RP_X1);
+    if constexpr (!FAST) { make_rows_wide(nefc); return; }
     // ---- lane r builds row r (and row r + 64 in the 128-row configuration)
 #pragma unroll
     for (int slot = 0; slot < NSLOT; slot++) {
@@ -2429,6 +2432,112 @@ struct Sim {
 #pragma unroll
       for (int k = 0; k < NV16; k++) { sm.J[row * JS + k] = Jr[k]; jv = fmaf(Jr[k], sm.qvel[k], jv); }
       if (valid) sm.e_aref[row] = -sm.e_force[row] * jv - sm.e_aref[row];
+    }
+    SYNC();
+  }
+
+  // Wide configurations: the Jacobian rows on the matrix cores.  A contact row is J[r][k] = s2(r, k) (w2_r . cdof_k) - s1(r, k) (w1_r . cdof_k) with
+  // w = (o x ax | ax) for a translational axis, (ax | 0) for a rotational one, and s = "dof k moves the row's body": two 6-component products per
+  // 16 x 16 tile (K = 6 in two k-steps) and a mask from the two bodies' dof sets, instead of nv unrolled cdof reads per row and lane.  The sparse
+  // rows (friction loss, limits, tendons) stage zeros and write their one to four entries afterwards.
+  __device__ __forceinline__ void make_rows_wide(int nefc) {
+    const int nv = m.nv, q = lane >> 4, r = lane & 15;
+    float* st = sm.u.rowst;   // [row][20]: w2[8] | -w1[8] | mask2 lo hi | mask1 lo hi
+    const bool two = NSLOT > 1 && nefc > 64;
+#pragma unroll
+    for (int slot = 0; slot < NSLOT; slot++) {
+      if (slot > 0 && !two) continue;
+      const int row = lane + 64 * slot;
+      const bool valid = row < nefc;
+      const int desc = valid ? sm.e_desc[row] : 0;
+      const int type = desc & 15, id = (desc >> 4) & 255, kk = (desc >> 12) & 15;
+      float w2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, w1[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      u64 m1 = 0, m2 = 0;
+      if (valid && (type == C_CONTACT_FRICTIONLESS || type == C_CONTACT_ELLIPTIC)) {
+        const int c = id;
+        const int b1 = sm.cg1[c] >> 8, b2 = sm.cg2[c] >> 8;
+        m1 = (u64)cm->bdofs[b1]; m2 = (u64)cm->bdofs[b2];
+        const V3 pos = ld3(sm.cpos + 3 * c);
+        const V3 ax = ld3(sm.cframe + 9 * c + 3 * (kk < 3 ? kk : kk - 3));
+        if (kk < 3) {
+          const V3 t1 = cross(pos - ld3(sm.rootcom + 3 * cm->broot[b1]), ax), t2 = cross(pos - ld3(sm.rootcom + 3 * cm->broot[b2]), ax);   // ax . (ca x o) = ca . (o x ax)
+          w1[0] = -t1.x; w1[1] = -t1.y; w1[2] = -t1.z; w1[3] = -ax.x; w1[4] = -ax.y; w1[5] = -ax.z;
+          w2[0] = t2.x; w2[1] = t2.y; w2[2] = t2.z; w2[3] = ax.x; w2[4] = ax.y; w2[5] = ax.z;
+        } else {
+          w1[0] = -ax.x; w1[1] = -ax.y; w1[2] = -ax.z;
+          w2[0] = ax.x; w2[1] = ax.y; w2[2] = ax.z;
+        }
+      }
+      float* o = st + 20 * row;
+#pragma unroll
+      for (int k = 0; k < 6; k++) { o[k] = w2[k]; o[8 + k] = w1[k]; }
+      o[6] = 0.f; o[7] = 0.f; o[14] = 0.f; o[15] = 0.f;
+      ((unsigned*)o)[16] = (unsigned)m2; ((unsigned*)o)[17] = (unsigned)(m2 >> 32); ((unsigned*)o)[18] = (unsigned)m1; ((unsigned*)o)[19] = (unsigned)(m1 >> 32);
+    }
+    SYNC();
+    {
+      float cb[NT][2];   // B operands: cdof rows of every dof tile, components 4 kc + q (6 and 7 are the zero padding of the stride-9 rows)
+#pragma unroll
+      for (int ct = 0; ct < NT; ct++)
+#pragma unroll
+        for (int kc = 0; kc < 2; kc++) cb[ct][kc] = sm.cdof[(16 * ct + r) * CS6 + 4 * kc + q];
+      const int nrt = (nefc + 15) >> 4;
+      for (int rt = 0; rt < nrt; rt++) {
+        const float* o = st + 20 * (16 * rt + r);
+        const float a2[2] = {o[q], o[4 + q]}, a1[2] = {o[8 + q], o[12 + q]};
+        u64 k2[4], k1[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const unsigned* w = (const unsigned*)(st + 20 * (16 * rt + 4 * q + v)) + 16;
+          k2[v] = (u64)w[0] | ((u64)w[1] << 32); k1[v] = (u64)w[2] | ((u64)w[3] << 32);
+        }
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++) {
+          if (16 * ct >= nv) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) sm.J[(16 * rt + 4 * q + v) * JS + 16 * ct + r] = 0.f;
+            continue;
+          }
+          v4f P2 = {0.f, 0.f, 0.f, 0.f}, P1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kc = 0; kc < 2; kc++) {
+            P2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kc], cb[ct][kc], P2, 0, 0, 0);
+            P1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kc], cb[ct][kc], P1, 0, 0, 0);
+          }
+#pragma unroll
+          for (int v = 0; v < 4; v++) {
+            const int k = 16 * ct + r;
+            sm.J[(16 * rt + 4 * q + v) * JS + k] = (((k2[v] >> k) & 1ull) ? P2[v] : 0.f) + (((k1[v] >> k) & 1ull) ? P1[v] : 0.f);
+          }
+        }
+      }
+    }
+    SYNC();
+    const float qv = lane < nv ? sm.qvel[lane] : 0.f;
+#pragma unroll
+    for (int slot = 0; slot < NSLOT; slot++) {
+      if (slot > 0 && !two) continue;
+      const int row = lane + 64 * slot;
+      const bool valid = row < nefc;
+      const int desc = valid ? sm.e_desc[row] : 0;
+      const int type = desc & 15, id = (desc >> 4) & 255, kk = (desc >> 12) & 15;
+      float* Jr = sm.J + row * JS;
+      if (valid && type == C_FRICTION_DOF) Jr[id] = 1.f;
+      else if (valid && type == C_LIMIT_JOINT) Jr[id] = kk ? -1.f : 1.f;   // lower limit: +dq increases the distance; upper: decreases it
+      else if (TENDONS && valid && (type == C_EQUALITY || type == C_LIMIT_TENDON || type == C_FRICTION_TENDON)) {
+        // row of a fixed tendon: its coefficients on the dofs of its (at most four) joints; an upper limit takes the negative row
+        const float sg = (type == C_LIMIT_TENDON && kk) ? -1.f : 1.f;
+        const int adr = IT(IO_tendon_adr, id), num = IT(IO_tendon_num, id);
+        for (int w = 0; w < num && w < 4; w++) Jr[IT(IO_wrap_dof, adr + w)] += sg * FP(FO_wrap_prm, adr + w);
+      }
+    }
+    SYNC();
+#pragma unroll
+    for (int slot = 0; slot < NSLOT; slot++) {
+      if (slot > 0 && !two) continue;
+      const int row = lane + 64 * slot;
+      const float jv = lds_row_dot(sm.J + row * JS, qv);
+      if (row < nefc) sm.e_aref[row] = -sm.e_force[row] * jv - sm.e_aref[row];
     }
     SYNC();
   }
