@@ -245,6 +245,30 @@ def test_equation_of_motion_residual():
         assert np.abs(res).max() < 1e-6 * max(1.0, np.abs(od.qfrc_bias).max())
 
 
+@pytest.mark.parametrize("tag,model", (("seed1_full", "lift_panda"), ("seed0_full", "stack_panda"), ("seed0_full", "pickplace_iiwa")))
+def test_primal_newton_and_dual_pgs_solve_the_same_constraint_problem(tag, model):
+    """Independent check of the constraint solver: the oracle's primal Newton method (the path's solver, rsim_oracle.c solve_newton) and its
+    projected Gauss-Seidel on the dual (solve_pgs: A = J M^-1 J' + R, elliptic cones projected block-wise) are different algorithms for the same
+    convex problem; at recorded contact states (cube on the table under the gripper, two stacked cubes, the PickPlace bins with the Robotiq's
+    self-contacts and tendon equality rows) their accelerations must coincide."""
+    g, cfg, flat = load_golden(tag, model)
+    dual = flat.copy()
+    dual.arrays["solver"][:] = 0; dual.arrays["iterations"][:] = 50000; dual.arrays["tolerance"][:] = 0
+    om, od, _ = make_oracle(flat)
+    om2, od2, _ = make_oracle(dual)
+    nq = flat.nq
+    newton_iters = 0
+    for i in (1, 5, 10, 15, len(g["states"]) - 1):
+        s = g["states"][i]
+        for d in (od, od2):
+            d.qpos[:] = s[1:1 + nq]; d.qvel[:] = s[1 + nq:]; d.ctrl[:] = g["ctrl"][min(i, len(g["ctrl"]) - 1)]; d.qacc_warmstart[:] = 0
+            d.forward()
+        assert od.nefc == od2.nefc and od.nefc > 0
+        assert np.abs(od.qacc - od2.qacc).max() < 1e-6 * max(1.0, np.abs(od.qacc).max()), (i, od.solver_iter, od2.solver_iter)
+        newton_iters += od.solver_iter
+    assert newton_iters >= 5
+
+
 def test_free_fall_energy_and_momentum():
     """Cube in free flight (no contact, fluid off): linear acceleration = g exactly, angular momentum conserved by Euler to O(h)."""
     g, cfg, flat = load_golden("seed1_full")
