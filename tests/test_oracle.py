@@ -310,6 +310,62 @@ def test_resting_contact_normal_forces_balance_weight():
     assert np.abs(od.qvel[9:15]).max() < 1e-4
 
 
+def test_gravity_bias_is_the_gradient_of_the_potential_energy():
+    """Known answer from mechanics: at rest, qfrc_bias = dV/dq with V = sum_b m_b g z_com,b.  The right-hand side uses only the body frames of the
+    forward kinematics and the model's masses / COM offsets; the left-hand side is the recursive Newton-Euler pass."""
+    g, cfg, flat = load_golden("seed1_full")
+    f2 = flat.copy()
+    f2.arrays["density"][:] = 0; f2.arrays["viscosity"][:] = 0
+    om, od, _ = make_oracle(f2)
+    nq = flat.nq
+
+    def rot(q, v):
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        return R @ v
+
+    def potential(q):
+        od.qpos[:] = q; od.qvel[:] = 0; od.forward()
+        xp, xq = np.array(od.xpos).reshape(-1, 3), np.array(od.xquat).reshape(-1, 4)
+        return sum(flat.body_mass[b] * 9.81 * (xp[b] + rot(xq[b], flat.body_ipos[b]))[2] for b in range(flat.nbody))
+
+    for i in (0, 5, 30):
+        q0 = g["states"][i][1:1 + nq].copy()
+        od.qpos[:] = q0; od.qvel[:] = 0; od.forward()
+        bias = np.array(od.qfrc_bias).copy()
+        for j in range(9):                      # arm hinges and finger slides (qpos index = dof index for these)
+            qp, qm = q0.copy(), q0.copy()
+            qp[j] += 1e-6; qm[j] -= 1e-6
+            assert bias[j] == pytest.approx((potential(qp) - potential(qm)) / 2e-6, abs=2e-6 * max(1.0, np.abs(bias).max())), (i, j)
+
+
+def test_friction_cone_sticks_below_and_slides_above_the_coulomb_limit():
+    """Known answer from mechanics, not from any simulator: with gravity tilted by theta about the table, the cube (friction mu = 0.3 against the
+    table, elliptic cone, impratio 20) stays put while tan(theta) < mu and slides with a = g (sin(theta) - mu cos(theta)) above it."""
+    g, cfg, flat = load_golden("seed0_gentle")
+    cube, table = flat.name2id("geom", "cube_g0"), flat.name2id("geom", "table_collision")
+    mu = 0.3
+    for fac, slides in ((0.5, False), (0.9, False), (1.2, True), (2.0, True)):
+        th = np.arctan(fac * mu)
+        f2 = flat.copy()
+        f2.arrays["gravity"][:] = 9.81 * np.array([np.sin(th), 0.0, -np.cos(th)]); f2.arrays["density"][:] = 0; f2.arrays["viscosity"][:] = 0
+        f2.arrays["geom_friction"][cube][0] = mu; f2.arrays["geom_friction"][table][0] = mu
+        om, od, _ = make_oracle(f2)
+        od.qpos[:] = g["states"][0][1:1 + flat.nq]; od.qvel[:] = 0
+        vx = []
+        for _ in range(150):
+            od.step1()
+            od.ctrl[:7] = od.qfrc_bias[:7]; od.ctrl[7:9] = [0.04, -0.04]      # arm held by gravity compensation, fingers open
+            od.step2()
+            vx.append(od.qvel[9])
+        if not slides:
+            assert abs(vx[-1]) < 1e-3 and od.ncon == 4, (fac, vx[-1])          # soft contacts creep at ~1e-5 m/s, they do not slide
+        else:
+            a = (vx[-1] - vx[-51]) / (50 * 0.002)
+            assert a == pytest.approx(9.81 * (np.sin(th) - mu * np.cos(th)), rel=0.05), (fac, a)
+
+
 def test_scripted_grasp_lifts_the_cube():
     """Behavioural anchor of the contact / friction model (reference shape: GripperTester raises unless the cube is lifted,
     models/grippers/gripper_tester.py:204-226 via tests/test_grippers/test_panda_gripper.py): hover, descend, close, lift."""
