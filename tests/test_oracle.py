@@ -340,6 +340,46 @@ def test_gravity_bias_is_the_gradient_of_the_potential_energy():
             assert bias[j] == pytest.approx((potential(qp) - potential(qm)) / 2e-6, abs=2e-6 * max(1.0, np.abs(bias).max())), (i, j)
 
 
+def test_energy_is_conserved_to_first_order_in_the_timestep():
+    """Known answer from mechanics: without damping, friction loss, fluid or actuation the arm falling under gravity trades potential for kinetic
+    energy, E = 1/2 qd' M qd + sum m g z.  Semi-implicit Euler keeps E to O(h): the drift is a percent of the kinetic energy at h = 2 ms and halves
+    with the step.  Ties the Coriolis / centrifugal terms of the bias force to the mass matrix and the kinematics."""
+    g, cfg, flat = load_golden("seed1_full")
+    nq = flat.nq
+
+    def rot(q, v):
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        return R @ v
+
+    drift = {}
+    for h, n in ((0.002, 150), (0.001, 300)):
+        f2 = flat.copy()
+        for k in ("density", "viscosity", "dof_damping", "dof_frictionloss"):
+            f2.arrays[k][:] = 0
+        f2.arrays["timestep"][:] = h
+        om, od, _ = make_oracle(f2)
+
+        def energy():
+            od.forward()
+            xp, xq, v = np.array(od.xpos).reshape(-1, 3), np.array(od.xquat).reshape(-1, 4), np.array(od.qvel)
+            V = sum(flat.body_mass[b] * 9.81 * (xp[b] + rot(xq[b], flat.body_ipos[b]))[2] for b in range(flat.nbody))
+            return 0.5 * v @ od.full_M() @ v, V
+
+        od.qpos[:] = g["states"][0][1:1 + nq]; od.qvel[:] = 0; od.ctrl[:] = 0
+        T0, V0 = energy()
+        for _ in range(n):
+            od.step1()
+            od.ctrl[7:9] = od.qpos[7:9]          # the fingers' position actuators stay unloaded
+            od.step2()
+        T, V = energy()
+        assert T > 5.0 and V0 - V == pytest.approx(T, rel=0.02)          # 6 J moved from potential to kinetic
+        drift[h] = (T + V) - (T0 + V0)
+    assert abs(drift[0.002]) < 0.015 * 6.0
+    assert drift[0.002] / drift[0.001] == pytest.approx(2.0, rel=0.2)
+
+
 def test_friction_cone_sticks_below_and_slides_above_the_coulomb_limit():
     """Known answer from mechanics, not from any simulator: with gravity tilted by theta about the table, the cube (friction mu = 0.3 against the
     table, elliptic cone, impratio 20) stays put while tan(theta) < mu and slides with a = g (sin(theta) - mu cos(theta)) above it."""
