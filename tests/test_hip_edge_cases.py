@@ -198,3 +198,30 @@ def test_stream_groups_do_not_change_any_result(groups, dr):
     for k in out[0]:
         assert np.array_equal(out[0][k], out[1][k]), k
     assert out[0]["ep_index"].min() >= 2 and out[0]["bank_stale"].sum() == 0
+
+
+def test_friction_cone_on_the_device_matches_coulomb():
+    """The same known answer from mechanics as tests/test_oracle.py, on the fp32 kernel: gravity tilted by theta, cube friction mu = 0.3 -- at rest below
+    tan(theta) = mu, sliding with a = g (sin(theta) - mu cos(theta)) above."""
+    g, cfg, flat = load_golden("seed0_gentle")
+    cube, table = flat.name2id("geom", "cube_g0"), flat.name2id("geom", "table_collision")
+    mu = 0.3
+    for fac, slides in ((0.5, False), (0.9, False), (1.2, True), (2.0, True)):
+        th = np.arctan(fac * mu)
+        f2 = flat.copy()
+        f2.arrays["gravity"][:] = 9.81 * np.array([np.sin(th), 0.0, -np.cos(th)]); f2.arrays["density"][:] = 0; f2.arrays["viscosity"][:] = 0
+        f2.arrays["geom_friction"][cube][0] = mu; f2.arrays["geom_friction"][table][0] = mu
+        hm, hb = make_hip(f2, None, B=1)
+        hb.set("qpos", g["states"][0][1:1 + flat.nq][None]); hb.set("qvel", 0); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+        vx = []
+        for _ in range(150):
+            hb.step1()
+            c = np.zeros(flat.nu); c[:7] = hb.get("qfrc_bias")[0][:7]; c[7:9] = [0.04, -0.04]
+            hb.set("ctrl", c[None])
+            hb.step2()
+            vx.append(float(hb.get("qvel")[0][9]))
+        if not slides:
+            assert abs(vx[-1]) < 1e-3 and hb.get("ncon")[0] == 4, (fac, vx[-1])
+        else:
+            a = (vx[-1] - vx[-51]) / (50 * 0.002)
+            assert a == pytest.approx(9.81 * (np.sin(th) - mu * np.cos(th)), rel=0.05), (fac, a)
