@@ -618,21 +618,6 @@ __device__ __forceinline__ float chol_solve(const float* L, const float* invdiag
 //   (3) the trailing tiles take A_IJ -= L_Ib L_Jb^T on the matrix cores (16 x 16 x 4 f32 MFMA, four per tile),
 // i.e. three block steps and ~a dozen LDS round trips for 48 dofs.  Layout and conventions of chol_inplace(): strictly lower triangle = L,
 // invdiag[k] = 1 / L[k][k]; rows / columns n .. 16 ceil(n / 16) - 1 must hold identity padding (every caller's matrix does).
-template <int J>
-struct RcholStepF {   // RcholStep with chol_inplace()'s fp32 safeguard: a pivot that cancelled below 1e-6 of its original diagonal entry is floored there
-  static __device__ __forceinline__ void run(float (&a)[16], float (&inv)[16], int row, float& own, float d0) {
-    if constexpr (J < 16) {
-      const float piv = fmaxf(rbcast<J>(a[J]), 1.0e-6f * rbcast<J>(d0));
-      const float iv = rsqrtf(fmaxf(piv, FMIN));
-      inv[J] = iv;
-      own = row == J ? iv : own;
-      const float lij = a[J] * iv;
-      a[J] = lij;
-      RcholUpd<16, J, J + 1>::run(a, lij);
-      RcholStepF<J + 1>::run(a, inv, row, own, d0);
-    }
-  }
-};
 // One column block of the factorisation, right-looking over ALL rows from the block's first row down (lane i = row c0 + i): column J's pivot
 // comes from lane J, every lane scales its entry and takes the rank-1 update of its remaining 15 - J entries against the entries of lanes
 // J + 1 .. 15 (uniform v_readlane operands).  The diagonal block and the panel below it are the same 136 readlane + FMA pairs -- the separate
@@ -1344,8 +1329,7 @@ struct Sim {
   // ---------------------------------------------------------------- CRBA on the matrix cores
   // composite inertia per dof  crbD = Sub x cinert           (Sub = subtree incidence, 16 x 32, 0/1 constants)
   // f_i = crbD_i * cdof_i ;  M = (m1 o F C^T) + (m2 o C F^T) + diag(armature)        (F, C = 16 x 6 stacks of f_i, cdof_i)
-  // wide configuration: the same products as mask-guided lane loops (lane i = dof i sums the bodies of its subtree; element-parallel M),
-  // factorisations on the LDS matrix
+  // wide configurations: the same products tile by tile for any bodies x dofs (incidence_mfma below), factorisations on the LDS matrix
   // out tile t (rows 16 t .. 16 t + 15) = sum over k-steps c < kmax of Incidence(t, c) x B(c) on the matrix cores: the A operand is this lane's
   // incidence bit (Cmem::msub / mbd / mcv), the B operand of k-step c -- bop(c), row 4 c + (lane >> 4), column lane & 15 -- is read once and
   // serves every row tile.  Replaces the mask-guided lane loops of the wide configurations (one LDS round trip per body / dof and lane).
@@ -1428,57 +1412,6 @@ struct Sim {
     bchol_inplace<NVP>(sm.L, sm.invdiag, nv, lane);
     SUBMARK_T(RP_X3);
   }
-  __device__ __forceinline__ void crb_composite_loops() {
-    const LaneConst K = fetchK();
-    const int nv = m.nv, nb = m.nbody;
-    if (lane < NV16) {
-      float acc[10];
-#pragma unroll
-      for (int k = 0; k < 10; k++) acc[k] = 0.f;
-      const int bi = K.dinfo & 255;
-      if (lane < nv)
-        for (int d = 1; d < nb; d++) {
-          const float w = (float)((cm->bmask_anc[d] >> bi) & 1);
-#pragma unroll
-          for (int k = 0; k < 10; k++) acc[k] = fmaf(w, sm.cinert[10 * d + k], acc[k]);
-        }
-#pragma unroll
-      for (int k = 0; k < 10; k++) sm.u.c.crbD[lane * FS + k] = acc[k];
-      S6 f = {v3(0, 0, 0), v3(0, 0, 0)};
-      if (lane < nv) f = mul_inert(acc, ld6(sm.cdof + CS6 * lane));
-      float* o = sm.u.c.fpad + CS6 * lane;
-      st3(o, f.a); st3(o + 3, f.l); o[6] = 0.f; o[7] = 0.f;
-    }
-    SYNC();
-  }
-  __device__ __forceinline__ void crb_mass_loops() {
-    const LaneConst K = fetchK();
-    const int nv = m.nv;
-    for (int e = lane; e < NV16 * NV16; e += 64) {
-      const int i = e / NV16, j = e - i * NV16;
-      float mij = 0.f;
-      if (i < nv && j < nv) {
-        if ((cm->dmask_anc[i] >> j) & 1) mij = dot6(ld6(sm.u.c.fpad + CS6 * i), ld6(sm.cdof + CS6 * j));
-        else if ((cm->dmask_anc[j] >> i) & 1) mij = dot6(ld6(sm.cdof + CS6 * i), ld6(sm.u.c.fpad + CS6 * j));
-      }
-      if (i == j) mij += cmf(MK_arm)->arm[i];
-      sm.M[i * NVP + j] = mij;
-    }
-    SYNC();
-    SUBMARK_T(RP_X1);
-    const float hd = lane < nv ? opt_h * K.damping : 0.f;
-    (void)hd;
-    const int nvt = (nv + 15) & ~15;   // whole 16-column blocks (the padding rows / columns of M are identity): what the blocked factorisation walks
-    for (int e = lane; e < nvt * nvt; e += 64) {
-      const int i = e / nvt, j = e - i * nvt;
-      sm.L[i * NVP + j] = sm.M[i * NVP + j];
-    }
-    SYNC();
-    SUBMARK_T(RP_X2);
-    bchol_inplace<NVP>(sm.L, sm.invdiag, nv, lane);
-    SUBMARK_T(RP_X3);
-  }
-
   __device__ __forceinline__ void crb() {
     if constexpr (TREE) crb_composite_tile(); else crb_composite_mfma();
     SUBMARK_T(RP_X0);
@@ -1540,14 +1473,6 @@ struct Sim {
   // ---------------------------------------------------------------- velocity stage (RNE) on the matrix cores
   // cvel = BodyDof x (cdof qd) ; cdof_dot_i = cvel_before(i) x cdof_i ; cacc = BodyDof x (cdof_dot qd) - g ;
   // body wrench cf = I cacc + cvel x* I cvel (+ fluid) ; F = Sub x cf ; bias_i = cdof_i . F_i
-  // out[row] = sum over dofs i in mask of cdof_i * qvel_i (wide configuration); rows are written by the lanes with `store`
-  __device__ __forceinline__ void masked_dof_sum(const float* cdofs, dmask_t mask, bool store, float* out) {
-    S6 acc = {v3(0, 0, 0), v3(0, 0, 0)};
-    const int nv = m.nv;
-    for (int i = 0; i < nv; i++) if ((mask >> i) & 1) acc = acc + ld6(cdofs + CS6 * i) * sm.qvel[i];
-    if (store) { float* o = out + CS6 * lane; st3(o, acc.a); st3(o + 3, acc.l); o[6] = 0.f; o[7] = 0.f; }
-  }
-
   __device__ __forceinline__ void velocity(V3 xp, Q4 xq) {
     const LaneConst K = fetchK();
     const int nb = m.nbody, nv = m.nv, q = lane >> 4, r = lane & 15;
