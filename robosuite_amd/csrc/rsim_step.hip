@@ -15,11 +15,12 @@
 #include "../../include/rsim.h"
 #include "rsim_internal.h"
 
-// Three builds of this file: RSIM_CFG 0 = 32 bodies x 16 dofs (Lift/Panda; tree products as incidence-matrix MFMAs, every dense nv x nv
-// product on one 16x16 MFMA tile, register-resident Cholesky), RSIM_CFG 1 = 32 bodies x 32 dofs (Stack/Panda: two free cubes),
-// RSIM_CFG 2 = 64 bodies x 16 dofs (Baxter).  The larger builds keep the lane roles, the collision pipeline, the constraint rows and the
-// Newton algorithm; beyond 32 x 16 the tree products run as mask-guided lane loops, beyond 16 dofs the dense products as 2 x 2 MFMA
-// tiles with the factorisations on the LDS matrix.  `sm` is one file-scope LDS object, so each configuration is its own translation unit.
+// Five builds of this file: RSIM_CFG 0 = 32 bodies x 16 dofs (Lift/Panda; tree products as incidence-matrix MFMAs with compile-time bit
+// fields, every dense nv x nv product on one 16x16 MFMA tile, register-resident Cholesky), 1 = 32 x 32 (Stack/Panda: two free cubes),
+// 2 = 64 x 16 (Baxter), 3 = 64 x 48 (PickPlace / IIWA + Robotiq140), 4 = 64 x 64.  The larger builds keep the lane roles, the collision
+// pipeline, the constraint rows and the Newton algorithm; beyond 32 x 16 the tree products use per-lane 64-bit incidence words
+// (incidence_mfma), beyond 16 dofs the dense products run tile by tile with the factorisations on the LDS matrix.  `sm` is one file-scope
+// LDS object, so each configuration is its own translation unit.
 #ifndef RSIM_CFG
 #define RSIM_CFG 0
 #endif

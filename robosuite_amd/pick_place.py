@@ -1,4 +1,4 @@
-"""PickPlace / IIWA + Robotiq140 (BASELINE configs[4]) host side for the fused kernel's 64 x 64 configuration: the task program.
+"""PickPlace / IIWA + Robotiq140 (BASELINE configs[4]) host side for the fused kernel's 64-body x 48-dof configuration: the task program.
 
   robot keys   robots/robot.py:334-484 (one arm; the Robotiq gripper has six finger joints)
   object keys  pick_place.py:585-668, per object: {obj}_to_robot0_eef_pos, {obj}_to_robot0_eef_quat, {obj}_pos, {obj}_quat.  The relative
@@ -110,7 +110,7 @@ def episode_setup(cfg, nq: int, seed0: int, env_ids, block: int = 0):
 
 
 class PickPlaceBatch(ResetBankMixin):
-    """B PickPlace/IIWA+Robotiq140 environments on one GPU (64 x 64 kernel configuration).  `env_ids` are GLOBAL indices."""
+    """B PickPlace/IIWA+Robotiq140 environments on one GPU (64-body x 48-dof kernel configuration).  `env_ids` are GLOBAL indices."""
 
     def __init__(self, flat, cfg, env_ids, device: int = 0, seed0: int = 0, horizon: int = 0, bank_episodes: int = 0, per_env_params: bool = False):
         from .backend import HipBatch, HipModel
