@@ -64,3 +64,51 @@ class VecEnv:
 
         keys = self._object_keys + self._proprio_keys if keys is None else keys
         return torch.cat([obs[:, self.obs_slices[k]] for k in keys], dim=1)
+
+
+class _Box:
+    """Stand-in for gymnasium.spaces.Box when gymnasium is not installed (same attribute names)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low, self.high, self.shape, self.dtype = np.broadcast_to(np.asarray(low, dtype=dtype), shape), np.broadcast_to(np.asarray(high, dtype=dtype), shape), tuple(shape), dtype
+
+
+def _box(low, high, shape):
+    try:
+        from gymnasium import spaces
+
+        return spaces.Box(low=np.broadcast_to(np.float32(low), shape).copy(), high=np.broadcast_to(np.float32(high), shape).copy(), dtype=np.float32)
+    except ImportError:
+        return _Box(low, high, shape)
+
+
+class GymVecEnv:
+    """gymnasium.vector-shaped face of VecEnv, with the conventions of the reference's single-env GymWrapper (wrappers/gym_wrapper.py:45-163):
+    flattened observation = the chosen keys concatenated (default `object-state` then `robot0_proprio-state`), reward range (0, reward_scale),
+    the horizon reports `terminated` (the reference passes its `done` there) and `truncated` is always False.  Episodes restart on the device:
+    after a terminated step `obs` is already the reset observation (gymnasium's autoreset) and info["final_observation"] holds the last record of
+    the finished episode for the envs flagged in info["_final_observation"]."""
+
+    def __init__(self, env: VecEnv, keys=None):
+        self.env, self.keys = env, keys
+        self.num_envs = env.n_envs
+        dim = int(env.flat_obs(env.env.obs(), keys).shape[1]) if keys is not None else env.obs_dim
+        lo, hi = env.action_spec
+        self.single_observation_space, self.single_action_space = _box(-np.inf, np.inf, (dim,)), _box(lo[0], hi[0], (env.action_dim,))
+        self.observation_space, self.action_space = _box(-np.inf, np.inf, (self.num_envs, dim)), _box(lo[0], hi[0], (self.num_envs, env.action_dim))
+
+    def reset(self, seed=None, options=None):
+        if seed is not None and not isinstance(seed, int):
+            raise TypeError("Seed must be an integer type!")      # gym_wrapper.py:139-143; the per-env episode streams are keyed by VecEnv's seed
+        return self.env.flat_obs(self.env.reset(), self.keys), {}
+
+    def step(self, actions):
+        import torch
+
+        obs, reward, done, info = self.env.step(actions)
+        term = done.to(torch.bool)
+        return (self.env.flat_obs(obs, self.keys), reward, term, torch.zeros_like(term),
+                {"success": info["success"], "final_observation": self.env.flat_obs(info["terminal_obs"], self.keys), "_final_observation": term})
+
+    def close(self):
+        pass

@@ -225,3 +225,27 @@ def test_friction_cone_on_the_device_matches_coulomb():
         else:
             a = (vx[-1] - vx[-51]) / (50 * 0.002)
             assert a == pytest.approx(9.81 * (np.sin(th) - mu * np.cos(th)), rel=0.05), (fac, a)
+
+
+def test_gymnasium_vector_shaped_facade():
+    """GymVecEnv: reset / step signatures and conventions of gymnasium.vector with the reference GymWrapper's flattening (object keys, then robot keys),
+    autoreset with the finished episode's last observation in info["final_observation"]."""
+    from robosuite_amd.vec_env import GymVecEnv, VecEnv
+    g, cfg, flat = load_golden("seed0_full", "stack_panda")
+    B = 8
+    venv = VecEnv("Stack", B, flat, cfg, seed=0, horizon=3, bank_episodes=4)
+    genv = GymVecEnv(venv)
+    obs, info = genv.reset(seed=0)
+    assert info == {} and tuple(obs.shape) == (B, venv.obs_dim) == genv.observation_space.shape and genv.single_action_space.shape == (venv.action_dim,)
+    raw = venv.env.obs()
+    nobj = sum(cfg["obs_dims"][i] for i, k in enumerate(cfg["obs_keys"]) if not k.startswith("robot0_"))
+    k0 = next(k for k in cfg["obs_keys"] if not k.startswith("robot0_"))
+    assert torch.equal(obs[:, :cfg["obs_dims"][cfg["obs_keys"].index(k0)]], venv.key(raw, k0)) and nobj > 0     # object-state first
+    a = torch.zeros(B, venv.action_dim, device="cuda")
+    for t in range(3):
+        obs, rew, term, trunc, info = genv.step(a)
+        assert tuple(rew.shape) == (B,) and term.dtype == torch.bool and not trunc.any()
+    assert term.all() and info["_final_observation"].all() and tuple(info["final_observation"].shape) == tuple(obs.shape)
+    assert not torch.equal(info["final_observation"], obs)                 # obs is the next episode's reset observation
+    with pytest.raises(TypeError):
+        genv.reset(seed="0")
