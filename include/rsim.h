@@ -246,6 +246,19 @@ int rsim_observe(rsim_batch* b);
 int rsim_set_episode(rsim_batch* b, int horizon);
 int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, const int32_t* patch_idx, const float* bank);
 int rsim_refill_reset_bank(rsim_batch* b, int n, const int32_t* env, const int32_t* episode, const float* rows);
+/* The same upkeep without ever stalling the control steps (the reference has no counterpart: its reset is a blocking recompile, base.py:277-347).
+ * All three run on a side stream of the batch and neither wait for the control steps in flight nor make them wait; they may be called from a second
+ * host thread while the first one keeps stepping (one upkeep thread per batch).
+ *   rsim_bank_poll_begin          starts an asynchronous copy of RSIM_EP_INDEX into pinned host memory (at most one in flight);
+ *   rsim_bank_poll                1 + the counters in ep_index[B] once that copy has landed, 0 while it is in flight (wait != 0: block), -1 on error.
+ *                                 The counters only grow, so a copy taken beside running control steps is at worst slightly old;
+ *   rsim_refill_reset_bank_async  like rsim_refill_reset_bank, through pinned staging, returns without waiting.  Only slots whose episode the env
+ *                                 has already STARTED (episode <= polled counter) may be overwritten; the slot's tag is published after its row;
+ *   rsim_bank_flush               returns when every refill issued so far is in the ring (tests, shutdown). */
+int rsim_bank_poll_begin(rsim_batch* b);
+int rsim_bank_poll(rsim_batch* b, int32_t* ep_index, int wait);
+int rsim_refill_reset_bank_async(rsim_batch* b, int n, const int32_t* env, const int32_t* episode, const float* rows);
+int rsim_bank_flush(rsim_batch* b);
 /* offset of element `elem` of model float array `field` ("geom_size", "body_mass", ...) inside an env's float table, -1 if unknown */
 int rsim_param_offset(const rsim_batch* b, const char* field, int elem);
 

@@ -178,6 +178,10 @@ def lib():
         L.rsim_set_episode.argtypes = [vp, C.c_int]
         L.rsim_set_reset_bank.argtypes = [vp, C.c_int, C.c_int, vp, vp]
         L.rsim_refill_reset_bank.argtypes = [vp, C.c_int, vp, vp, vp]
+        L.rsim_bank_poll_begin.argtypes = [vp]
+        L.rsim_bank_poll.argtypes = [vp, vp, C.c_int]
+        L.rsim_refill_reset_bank_async.argtypes = [vp, C.c_int, vp, vp, vp]
+        L.rsim_bank_flush.argtypes = [vp]
         L.rsim_param_offset.argtypes = [vp, C.c_char_p, C.c_int]
         for f in ("rsim_forward", "rsim_step1", "rsim_step2", "rsim_step", "rsim_sync", "rsim_observe"):
             getattr(L, f).argtypes = [vp]
@@ -399,6 +403,27 @@ class HipBatch:
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         _chk(self._L.rsim_refill_reset_bank(self.ptr, len(env), env.ctypes.data, episode.ctypes.data, rows.ctypes.data))
 
+    def refill_reset_bank_async(self, env, episode, qpos, patch_val=None):
+        """refill_reset_bank on the batch's side stream, through pinned staging, without waiting (include/rsim.h rsim_refill_reset_bank_async)."""
+        env = np.ascontiguousarray(env, dtype=np.int32); episode = np.ascontiguousarray(episode, dtype=np.int32)
+        q = np.asarray(qpos, dtype=np.float32).reshape(len(env), -1)
+        rows = q if patch_val is None or np.size(patch_val) == 0 else np.concatenate([q, np.asarray(patch_val, dtype=np.float32).reshape(len(env), -1)], axis=1)
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        _chk(self._L.rsim_refill_reset_bank_async(self.ptr, len(env), env.ctypes.data, episode.ctypes.data, rows.ctypes.data))
+
+    def bank_poll_begin(self):
+        _chk(self._L.rsim_bank_poll_begin(self.ptr))
+
+    def bank_poll(self, out: np.ndarray, wait: bool = False) -> bool:
+        """True + RSIM_EP_INDEX (as of the poll) in `out` (int32 [B]) once the asynchronous copy has landed."""
+        r = self._L.rsim_bank_poll(self.ptr, out.ctypes.data, int(bool(wait)))
+        if r < 0:
+            raise RsimError(self._L.rsim_last_error().decode())
+        return r == 1
+
+    def bank_flush(self):
+        _chk(self._L.rsim_bank_flush(self.ptr))
+
     def ctrl_reset(self, mask=None):
         _chk(self._L.rsim_ctrl_reset(self.ptr, None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).tobytes()))
 
@@ -414,12 +439,26 @@ class HipBatch:
             if tuple(actions.shape) != (self.B, adim):
                 raise RsimError(f"actions must have shape ({self.B}, {adim}) = (n_envs, action_dim), got {tuple(actions.shape)}")
             actions = actions.contiguous().float()
-            self._keep = actions
+            # The step reads `actions` on the batch's own stream(s) after this call has returned (include/rsim.h: the buffer must stay untouched until
+            # the groups join).  Tell torch's caching allocator so: a tensor the caller drops right away is not handed out again before the work
+            # queued on those streams has run -- whatever stream the caller allocates from, however far an env block lags behind.
+            for s_ in self._step_streams():
+                actions.record_stream(s_)
             ptr = actions.data_ptr()
         _chk(self._L.rsim_control_step(self.ptr, C.c_void_p(ptr), int(n_sub)))
 
     def stream(self):
         return self._L.rsim_stream(self.ptr)
+
+    def _step_streams(self):
+        """torch views of the HIP streams control steps run on (the main stream, or one per env block with stream groups); cached per group count."""
+        import torch
+
+        key = getattr(self, "_ngroups", 1)
+        if getattr(self, "_ext_key", None) != key:
+            ptrs = [self.group_stream(g) for g in range(key)] if key > 1 else [self.stream()]
+            self._ext, self._ext_key = [torch.cuda.ExternalStream(p, device=f"cuda:{self.device}") for p in ptrs], key
+        return self._ext
 
     PROFILE_SLOTS = ("load", "kin", "com", "crb", "broad", "narrow", "makec", "vel", "ctrl", "act", "solve", "euler", "store",
                      "n_sub", "n_cand", "n_con", "n_efc", "n_newton", "n_ls", "boxbox", "mpr", "plane", "n_boxbox", "n_mpr", "n_support",
@@ -442,6 +481,7 @@ class HipBatch:
         """Step the batch as `groups` env blocks on their own HIP streams (include/rsim.h rsim_set_stream_groups): a block's next control step no
         longer waits for the slowest env of the whole batch.  Same results; 1 = one launch per step."""
         _chk(self._L.rsim_set_stream_groups(self.ptr, int(groups)))
+        self._ngroups = int(groups)
 
     def group_stream(self, g: int):
         return self._L.rsim_group_stream(self.ptr, int(g))

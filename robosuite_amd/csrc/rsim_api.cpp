@@ -146,6 +146,13 @@ struct rsim_batch {
   int groups, ngroups, forked;   // streams created, groups in use (1 = everything on the main stream)
   hipStream_t gstream[RSIM_MAX_GROUPS];
   hipEvent_t gev[RSIM_MAX_GROUPS], mev;
+  // asynchronous reset-bank upkeep (rsim_bank_poll_begin / _poll / rsim_refill_reset_bank_async): a side stream of its own, pinned staging
+  hipStream_t bstream;
+  hipEvent_t bev;
+  int* h_epidx;            // pinned [B]: episode counters as of the last poll
+  int bank_poll_pending;
+  struct Stage { void* host; void* dev; size_t bytes; hipEvent_t done; int busy; } bstage[4];   // pinned + device staging ring of the async refills
+  int bstage_next;
   // host cache for jacobians
   long gen, cache_gen;
   int cache_env;
@@ -153,6 +160,7 @@ struct rsim_batch {
 };
 
 static int join_groups(rsim_batch* b);
+extern "C" int rsim_bank_flush(rsim_batch* b);
 // ------------------------------------------------------------------------------------------------------------
 extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out) {
   if (!blob || len < 16 || memcmp(blob, "RSIMMDL1", 8) != 0) return fail("rsim_model_create: bad blob magic");
@@ -682,6 +690,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   b->gen = 1; b->cache_gen = 0; b->cache_env = -1;
   b->db.prof_env = -1;
   b->d_bank = nullptr; b->d_bank_tag = nullptr; b->d_patch = nullptr; b->d_ft_base = nullptr;
+  b->bstream = nullptr; b->bev = nullptr; b->h_epidx = nullptr; b->bank_poll_pending = 0; b->bstage_next = 0;
+  memset(b->bstage, 0, sizeof(b->bstage));
   const int ncg = (int)m->cg.size();
   b->cfg = pick_config(m, b->lim);
   if (b->cfg < 0) {
@@ -790,6 +800,10 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   if (b->d_bank) hipFree(b->d_bank); if (b->d_bank_tag) hipFree(b->d_bank_tag); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); if (b->d_ft_base) hipFree(b->d_ft_base); hipFree(b->d_mesh); hipFree(b->d_mask);
   if (b->d_order) hipFree(b->d_order); if (b->d_cost) hipFree(b->d_cost);
   if (b->db.prof) hipFree(b->db.prof);
+  if (b->bstream) { hipStreamSynchronize(b->bstream); hipStreamDestroy(b->bstream); }
+  if (b->bev) hipEventDestroy(b->bev);
+  if (b->h_epidx) hipHostFree(b->h_epidx);
+  for (auto& st : b->bstage) { if (st.host) hipHostFree(st.host); if (st.dev) hipFree(st.dev); if (st.done) hipEventDestroy(st.done); }
   hipStreamDestroy(b->stream);
   delete b;
 }
@@ -1014,6 +1028,8 @@ extern "C" int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, c
   for (int p2 = 0; p2 < n_patch; p2++) if (patch_idx[p2] < 0 || patch_idx[p2] >= (int)m->ftab.size()) return fail("rsim_set_reset_bank: patch offset out of range");
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
+  if (rsim_bank_flush(b)) return 1;
+  b->bank_poll_pending = 0;
   if (b->d_bank) { hipFree(b->d_bank); b->d_bank = nullptr; }
   if (b->d_bank_tag) { hipFree(b->d_bank_tag); b->d_bank_tag = nullptr; }
   if (b->d_patch) { hipFree(b->d_patch); b->d_patch = nullptr; }
@@ -1053,6 +1069,84 @@ extern "C" int rsim_refill_reset_bank(rsim_batch* b, int n, const int32_t* env, 
   HIPCHK(hipStreamSynchronize(b->stream));
   hipFree(d_env); hipFree(d_ep); hipFree(d_rows);
   if (e) return fail("bank scatter kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  return 0;
+}
+
+// Asynchronous upkeep of the reset ring.  Nothing here waits for, or is waited for by, the control steps: the copies and the scatter kernel run
+// on a side stream of their own, so a refill costs the stepping thread nothing and may be driven from a second host thread.  Why that is safe:
+//  * RSIM_EP_INDEX only ever grows, so a copy taken while control steps are in flight is at worst a little old, and an old counter only makes
+//    the host refill a slot later than it could have;
+//  * a slot is overwritten only once its env has moved past the episode it held (episode <= the polled counter), so no control step reads it
+//    any more, and the slot's tag is written after its row (device-scope fence in k_bank_scatter): a reset that sees the new tag sees the new row.
+static int bank_side_stream(rsim_batch* b) {
+  if (b->bstream) return 0;
+  HIPCHK(hipStreamCreateWithFlags(&b->bstream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&b->bev, hipEventDisableTiming));
+  HIPCHK(hipHostMalloc((void**)&b->h_epidx, (size_t)b->B * sizeof(int), hipHostMallocDefault));
+  return 0;
+}
+extern "C" int rsim_bank_poll_begin(rsim_batch* b) {
+  if (!b->d_bank) return fail("rsim_bank_poll_begin: no reset bank installed (rsim_set_reset_bank)");
+  HIPCHK(hipSetDevice(b->device));
+  if (bank_side_stream(b)) return 1;
+  if (b->bank_poll_pending) return 0;   // one poll in flight at a time
+  HIPCHK(hipMemcpyAsync(b->h_epidx, b->db.ep_index, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost, b->bstream));
+  HIPCHK(hipEventRecord(b->bev, b->bstream));
+  b->bank_poll_pending = 1;
+  return 0;
+}
+// returns 1 and fills ep_index[B] when the poll has completed, 0 while it is still in flight (wait != 0: block until it has), -1 on error
+extern "C" int rsim_bank_poll(rsim_batch* b, int32_t* ep_index, int wait) {
+  if (!b->bank_poll_pending) { fail("rsim_bank_poll: no poll in flight (rsim_bank_poll_begin)"); return -1; }
+  if (hipSetDevice(b->device) != hipSuccess) { fail("rsim_bank_poll: hipSetDevice failed"); return -1; }
+  if (wait) { if (hipEventSynchronize(b->bev) != hipSuccess) { fail("rsim_bank_poll: event wait failed"); return -1; } }
+  else {
+    hipError_t q = hipEventQuery(b->bev);
+    if (q == hipErrorNotReady) return 0;
+    if (q != hipSuccess) { fail("rsim_bank_poll: %s", hipGetErrorString(q)); return -1; }
+  }
+  memcpy(ep_index, b->h_epidx, (size_t)b->B * sizeof(int));
+  b->bank_poll_pending = 0;
+  return 1;
+}
+extern "C" int rsim_refill_reset_bank_async(rsim_batch* b, int n, const int32_t* env, const int32_t* episode, const float* rows) {
+  if (!b->d_bank) return fail("rsim_refill_reset_bank_async: no reset bank installed (rsim_set_reset_bank)");
+  if (n < 0) return fail("rsim_refill_reset_bank_async: n < 0");
+  if (n == 0) return 0;
+  for (int i = 0; i < n; i++) if (env[i] < 0 || env[i] >= b->B || episode[i] < 0) return fail("rsim_refill_reset_bank_async: entry %d out of range", i);
+  HIPCHK(hipSetDevice(b->device));
+  if (bank_side_stream(b)) return 1;
+  const int W = b->m->nq + b->db.bank_P;
+  const size_t bytes = (size_t)n * (2 * sizeof(int) + (size_t)W * sizeof(float));
+  rsim_batch::Stage& st = b->bstage[b->bstage_next];
+  b->bstage_next = (b->bstage_next + 1) % 4;
+  if (st.busy) { HIPCHK(hipEventSynchronize(st.done)); st.busy = 0; }   // only when four refills are in flight at once
+  if (st.bytes < bytes) {
+    if (st.host) hipHostFree(st.host);
+    if (st.dev) hipFree(st.dev);
+    st.bytes = bytes + bytes / 2;
+    HIPCHK(hipHostMalloc(&st.host, st.bytes, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&st.dev, st.bytes));
+  }
+  if (!st.done) HIPCHK(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+  char* h = (char*)st.host;
+  memcpy(h, env, (size_t)n * sizeof(int));
+  memcpy(h + (size_t)n * sizeof(int), episode, (size_t)n * sizeof(int));
+  memcpy(h + (size_t)n * 2 * sizeof(int), rows, (size_t)n * W * sizeof(float));
+  HIPCHK(hipMemcpyAsync(st.dev, st.host, bytes, hipMemcpyHostToDevice, b->bstream));
+  const int* d_env = (const int*)st.dev; const int* d_ep = d_env + n; const float* d_rows = (const float*)(d_ep + n);
+  int e = rsim_launch_bank_scatter(b->d_bank, b->d_bank_tag, d_env, d_ep, d_rows, n, b->db.bank_E, W, b->bstream);
+  if (e) return fail("bank scatter kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  HIPCHK(hipEventRecord(st.done, b->bstream));
+  st.busy = 1;
+  return 0;
+}
+// all asynchronous refills issued so far have landed in the ring
+extern "C" int rsim_bank_flush(rsim_batch* b) {
+  if (!b->bstream) return 0;
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->bstream));
+  for (auto& st : b->bstage) st.busy = 0;
   return 0;
 }
 

@@ -76,6 +76,11 @@ typedef unsigned long long u64;
 #else
 #define SUBMARK_U(id)
 #endif
+#ifdef RSIM_MPRSTAT   /* profiling build (tools/subprof.sh mpr): how MPR runs end -> event counters in slots x0..x7 (tools/tail_report.py) */
+#define MPRSTAT(slot, v) pf.count(RP_X0 + (slot), (v))
+#else
+#define MPRSTAT(slot, v)
+#endif
 // One workgroup = one wavefront: LDS instructions of a wave execute in issue order, so cross-lane communication through LDS needs no
 // s_waitcnt / s_barrier, only a compiler-level ordering point (wavefront-scope fences emit no instructions; __syncthreads() would
 // drain the LDS queue with s_waitcnt lgkmcnt(0) at every one of the ~110 sites).
@@ -1873,6 +1878,7 @@ struct Sim {
   // Minkowski Portal Refinement (uniform control flow; support() is wave-cooperative)
   __device__ __forceinline__ void convex_convex(int g1, int g2, float margin, const CPar& cp) {
     const float tol = 1e-6f;
+    const int mprstat_s0 = pf.c_support; (void)mprstat_s0;
     const V3 org = ld3(sm.gpos + 3 * g1);   // all support points relative to the first geom's position (see geom_support)
     const SupGeom sg1 = sup_load(cm, cmf(MK_gst), g1, (gcf)m.mesh_vert, lane, org), sg2 = sup_load(cm, cmf(MK_gst), g2, (gcf)m.mesh_vert, lane, org);
     // A box or cylinder against anything: MPR's own exit test (a direction D, oriented from geom 1 to geom 2, in which the first shape's
@@ -1916,14 +1922,14 @@ struct Sim {
         V3 D = mv(sp.R, dl);
         if (!first) D = -D;
         const V3 a1 = sup(sg1, D), a2 = sup(sg2, -D);
-        if (dot(a1 - a2, D) <= 0) return;
+        if (dot(a1 - a2, D) <= 0) { MPRSTAT(0, 1); return; }
       }
     }
     V3 v0 = (ld3(sm.gcen + 3 * g1) - org) - (ld3(sm.gcen + 3 * g2) - org);
     if (norm(v0) < 1e-9f) v0.x = 1e-5f;
     V3 dir = normalized(-v0);
     V3 p11 = sup(sg1, dir), p12 = sup(sg2, -dir), v1 = p11 - p12;
-    if (dot(v1, dir) <= 0) return;
+    if (dot(v1, dir) <= 0) { MPRSTAT(1, 1); return; }
     dir = cross(v0, v1);
     if (norm(dir) < 1e-12f) {
       V3 n = normalized(v1 - v0);
@@ -1932,7 +1938,7 @@ struct Sim {
     }
     dir = normalized(dir);
     V3 p21 = sup(sg1, dir), p22 = sup(sg2, -dir), v2 = p21 - p22;
-    if (dot(v2, dir) <= 0) return;
+    if (dot(v2, dir) <= 0) { MPRSTAT(2, 1); return; }
     dir = cross(v1 - v0, v2 - v0);
     if (dot(dir, v0) > 0) {
       V3 t;
@@ -1946,7 +1952,7 @@ struct Sim {
       dir = normalized(dir, &len);
       if (len < FMIN) return;
       p31 = sup(sg1, dir); p32 = sup(sg2, -dir); v3_ = p31 - p32;
-      if (dot(v3_, dir) <= 0) return;
+      if (dot(v3_, dir) <= 0) { MPRSTAT(3, 1); MPRSTAT(7, pf.c_support - mprstat_s0); return; }
       if (dot(cross(v1, v3_), v0) < -1e-14f) { v2 = v3_; p21 = p31; p22 = p32; dir = cross(v1 - v0, v3_ - v0); continue; }
       if (dot(cross(v3_, v2), v0) < -1e-14f) { v1 = v3_; p11 = p31; p12 = p32; dir = cross(v3_ - v0, v2 - v0); continue; }
       break;
@@ -1959,7 +1965,7 @@ struct Sim {
       if (dot(dir, v1) >= 0) hit = true;
       V3 p41 = sup(sg1, dir), p42 = sup(sg2, -dir), v4 = p41 - p42;
       float dv4 = dot(v4, dir);
-      if (dv4 < 0 && !hit) return;
+      if (dv4 < 0 && !hit) { MPRSTAT(4, 1); MPRSTAT(7, pf.c_support - mprstat_s0); return; }
       float delta = dv4 - dot(v3_, dir);
       if (delta <= tol || it == 127) break;
       V3 t = cross(v4, v0);
@@ -1969,7 +1975,8 @@ struct Sim {
         if (dot(v3_, t) > 0) { v2 = v4; p21 = p41; p22 = p42; } else { v1 = v4; p11 = p41; p12 = p42; }
       }
     }
-    if (!hit) return;
+    if (!hit) { MPRSTAT(4, 1); MPRSTAT(7, pf.c_support - mprstat_s0); return; }
+    MPRSTAT(5, 1); MPRSTAT(6, pf.c_support - mprstat_s0);
     V3 bw;
     V3 cpt = tri_closest_origin(v1, v2, v3_, bw);
     float depth = norm(cpt);
@@ -3610,7 +3617,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   const unsigned t_launch = b.cost ? (unsigned)uni((int)(clock64() >> 6)) : 0u;   // 64-tick units, scalar
   const float* fp = m.ft + (size_t)env * m.fstride;
   Sim<SM> sim(m, fp, lane, b.prof, b.cm, b.cm_stride ? (const char*)b.cm_env + (size_t)env * b.cm_stride : (const char*)b.cm);
-  sim.pf.acc = b.prof_env < 0 || b.prof_env == env;
+  sim.pf.acc = b.prof_env == -1 || b.prof_env == env;   // -1: every env, -2: none (undistorted wave log)
   if (b.prof) sim.pf.pairs = b.prof + RP_COUNT + 8 * (size_t)b.B;
   sim.pf.start();
   if (b.prof && lane == 0) {
@@ -3978,6 +3985,9 @@ __global__ __launch_bounds__(64) void k_bank_scatter(float* bank, int* tag, cons
   const int e = env[i], slot = episode[i] % E;
   float* dst = bank + ((size_t)e * E + slot) * W;
   for (int k = threadIdx.x; k < W; k += 64) dst[k] = rows[(size_t)i * W + k];
+  // the tag after the row, device-wide: a control step running beside an asynchronous refill that reads the new tag also reads the new row
+  __threadfence();
+  __syncthreads();
   if (threadIdx.x == 0) tag[(size_t)e * E + slot] = episode[i];
 }
 extern "C" int rsim_launch_bank_scatter(float* bank, int* tag, const int* env, const int* episode, const float* rows, int n, int E, int W, hipStream_t stream) {

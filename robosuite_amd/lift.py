@@ -184,14 +184,21 @@ class LiftBatch(ResetBankMixin):
     def _bank_patch_offsets(self):
         return [o for _, _, o in self._bank_slots()]
 
+    _draw_fn = staticmethod(reset_draws)
+
+    def _episode(self, idx, episode):
+        """(cube sizes, qpos) of episode `episode` for the LOCAL env indices idx; equals episode_setup(seed0, env_ids[idx], episode), one block per call."""
+        d = self.episode_draws(idx, episode)
+        return np.array([x["size"] for x in d]).reshape(-1, 3), np.array([initial_qpos(x) for x in d]).reshape(-1, 16)
+
     def _bank_rows(self, idx, episode):
-        sizes, qpos = episode_setup(self.seed0, self.env_ids[idx], episode)
+        sizes, qpos = self._episode(idx, episode)
         rows = cube_model_rows(self.flat, sizes) if self._bank_slots() else {}
         patch = np.stack([rows[k][:, e] for k, e, _ in self._bank_slots()], axis=1) if self._bank_slots() else np.zeros((len(idx), 0))
         return qpos, patch
 
     def reset(self, block: int = 0):
-        sizes, qpos = episode_setup(self.seed0, self.env_ids, block)
+        sizes, qpos = self._episode(np.arange(self.B), block)
         b = self.batch
         if self.per_env_cube:
             for field, rows in cube_model_rows(self.flat, sizes).items():

@@ -98,15 +98,21 @@ class PegBatch(ResetBankMixin):
     def _bank_patch_offsets(self):
         return [o for _, _, o in self._bank_slots()]
 
+    _draw_fn = staticmethod(reset_draws)
+
+    def _episode(self, idx, episode):
+        d = self.episode_draws(idx, episode)
+        return np.array([x["qpos"] for x in d]).reshape(-1, 14), np.array([x["peg_radius"] for x in d])
+
     def _bank_rows(self, idx, episode):
-        qpos, radii = episode_setup(self.seed0, self.env_ids[idx], episode, with_radius=True)
+        qpos, radii = self._episode(idx, episode)
         if not self._bank_slots():
             return qpos, np.zeros((len(idx), 0))
         rows = peg_model_rows(self.flat, radii)
         return qpos, np.stack([rows[k][:, e] for k, e, _ in self._bank_slots()], axis=1)
 
     def reset(self, block: int = 0):
-        qpos, radii = episode_setup(self.seed0, self.env_ids, block, with_radius=True)
+        qpos, radii = self._episode(np.arange(self.B), block)
         b = self.batch
         if self.per_env_peg:
             for field, rows in peg_model_rows(self.flat, radii).items():

@@ -123,21 +123,29 @@ class PickPlaceBatch(ResetBankMixin):
         self.model.set_task(pick_place_task(flat, cfg))
         self.batch = HipBatch(self.model, self.B, device, per_env_params=per_env_params)   # per-env float tables: dynamics randomisation
         self.seed0 = seed0
+        self.horizon = horizon
         self.reset()
         if horizon:
             self.batch.set_episode(horizon)
-        self.horizon = horizon
         if bank_episodes:
             self.install_reset_bank(bank_episodes)
 
     def _bank_patch_offsets(self):
         return []
 
+    def _draw_fn(self, rng):
+        return reset_draws(rng, self.cfg["task"]["placement"])
+
+    def _episode(self, idx, episode):
+        t = self.cfg["task"]
+        only = int(t.get("object_id", -1)) if int(t.get("single_object_mode", 0)) == 2 else -1
+        return np.array([initial_qpos(d, t["placement"], self.flat.nq, only) for d in self.episode_draws(idx, episode)]).reshape(-1, self.flat.nq)
+
     def _bank_rows(self, idx, episode):
-        return episode_setup(self.cfg, self.flat.nq, self.seed0, self.env_ids[idx], episode), np.zeros((len(idx), 0))
+        return self._episode(idx, episode), np.zeros((len(idx), 0))
 
     def reset(self, block: int = 0):
-        qpos = episode_setup(self.cfg, self.flat.nq, self.seed0, self.env_ids, block)
+        qpos = self._episode(np.arange(self.B), block)
         b = self.batch
         b.set("qpos", qpos); b.set("qvel", 0.0); b.set("ctrl", 0.0); b.set("time", 0.0); b.set("qacc_warmstart", 0.0)
         b.forward(); b.ctrl_reset()

@@ -115,21 +115,26 @@ class StackBatch(ResetBankMixin):
         self.model.set_task(stack_task(flat, cfg))
         self.batch = HipBatch(self.model, self.B, device, per_env_params=False)   # cube sizes are fixed: one shared model
         self.seed0 = seed0
+        self.horizon = horizon
         self.reset()
         if horizon:
             self.batch.set_episode(horizon)
-        self.horizon = horizon
         if bank_episodes:
             self.install_reset_bank(bank_episodes)
 
     def _bank_patch_offsets(self):
         return []
 
+    _draw_fn = staticmethod(reset_draws)
+
+    def _episode(self, idx, episode):
+        return np.array([initial_qpos(d) for d in self.episode_draws(idx, episode)]).reshape(-1, 23)
+
     def _bank_rows(self, idx, episode):
-        return episode_setup(self.seed0, self.env_ids[idx], episode), np.zeros((len(idx), 0))
+        return self._episode(idx, episode), np.zeros((len(idx), 0))
 
     def reset(self, block: int = 0):
-        qpos = episode_setup(self.seed0, self.env_ids, block)
+        qpos = self._episode(np.arange(self.B), block)
         b = self.batch
         b.set("qpos", qpos); b.set("qvel", 0.0); b.set("ctrl", 0.0); b.set("time", 0.0); b.set("qacc_warmstart", 0.0)
         b.forward()        # MujocoEnv.reset: sim.forward() (base.py:298-303)

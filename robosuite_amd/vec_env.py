@@ -18,7 +18,8 @@ from . import lift, peg_in_hole, pick_place, stack
 
 TASKS = {"Lift": lift.LiftBatch, "Stack": stack.StackBatch, "TwoArmPegInHole": peg_in_hole.PegBatch, "PickPlace": pick_place.PickPlaceBatch}
 # single-object mode 2 of PickPlace (pick_place.py:810-847): the model / task constants of the env's own fixture carry single_object_mode and object_id
-TASKS.update({n: pick_place.PickPlaceBatch for n in ("PickPlaceMilk", "PickPlaceBread", "PickPlaceCereal", "PickPlaceCan")})
+_SINGLE_OBJECT = {"PickPlaceMilk": 0, "PickPlaceBread": 1, "PickPlaceCereal": 2, "PickPlaceCan": 3}   # object_to_id, pick_place.py:218
+TASKS.update({n: pick_place.PickPlaceBatch for n in _SINGLE_OBJECT})
 
 
 class VecEnv:
@@ -26,9 +27,16 @@ class VecEnv:
         if env_name not in TASKS:
             raise ValueError(f"{env_name!r} has no on-device task epilogue (have {sorted(TASKS)})")
         ids = np.arange(n_envs) if env_ids is None else np.asarray(env_ids)
+        if env_name in _SINGLE_OBJECT:
+            # PickPlaceMilk / Bread / Cereal / Can are PickPlace with single_object_mode = 2 and the named object (pick_place.py:810-847): a cfg that
+            # does not say so would silently run the four-object task under a single-object name
+            t = cfg.get("task", {})
+            if int(t.get("single_object_mode", 0)) != 2 or int(t.get("object_id", -1)) != _SINGLE_OBJECT[env_name]:
+                raise ValueError(f"{env_name}: cfg['task'] must carry single_object_mode = 2 and object_id = {_SINGLE_OBJECT[env_name]} "
+                                 f"(got {t.get('single_object_mode')}, {t.get('object_id')}); build the cfg from a {env_name} env")
         self.env_name = env_name
         self.env = TASKS[env_name](flat, cfg, ids, device=device, seed0=seed, horizon=horizon, bank_episodes=bank_episodes)
-        self.n_envs, self.horizon = len(ids), horizon
+        self.n_envs, self.horizon, self.bank_episodes = len(ids), horizon, bank_episodes
         if stream_groups > 1:   # env blocks stepped on their own HIP streams (rsim_set_stream_groups): same results, no whole-batch tail per step
             self.env.batch.set_stream_groups(min(int(stream_groups), self.n_envs))
         self.action_dim, self.obs_dim = self.env.model.action_dim, self.env.model.nobs
@@ -42,12 +50,19 @@ class VecEnv:
     def action_spec(self):
         return -np.ones(self.action_dim), np.ones(self.action_dim)
 
-    def reset(self):
-        self.env.reset(block=0)
-        b = self.env.batch
+    def reset(self, seed=None):
+        """Every env back to episode 0 of its stream (with `seed`: of the streams keyed by that seed, env i = default_rng(seed + i)).  The reset ring is re-installed for episodes 0 .. E-1: it has moved on by then, and resets
+        read from slots that still held later episodes would silently break `episode k of env i = episode_setup(seed, i, k)`."""
+        e = self.env
+        if seed is not None and int(seed) != e.seed0:
+            e.seed0, e._streams = int(seed), None
+        e.reset(block=0)
+        b = e.batch
         b.set("ep_step", 0); b.set("ep_index", 0); b.set("done", 0)
+        if self.bank_episodes:
+            e.install_reset_bank(self.bank_episodes)
         b.observe()
-        return self.env.obs()
+        return e.obs()
 
     def step(self, actions):
         self.env.step(actions)
@@ -99,8 +114,10 @@ class GymVecEnv:
 
     def reset(self, seed=None, options=None):
         if seed is not None and not isinstance(seed, int):
-            raise TypeError("Seed must be an integer type!")      # gym_wrapper.py:139-143; the per-env episode streams are keyed by VecEnv's seed
-        return self.env.flat_obs(self.env.reset(), self.keys), {}
+            raise TypeError("Seed must be an integer type!")      # gym_wrapper.py:139-143
+        # the reference's wrapper seeds numpy's global generator with it (gym_wrapper.py:136-143); the batched envs have one generator each, so a
+        # seed re-keys them: env i's episode stream becomes default_rng(seed + i).  Same seed -> same episodes, another seed -> other episodes.
+        return self.env.flat_obs(self.env.reset(seed=seed), self.keys), {}
 
     def step(self, actions):
         import torch

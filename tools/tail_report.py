@@ -1,0 +1,54 @@
+"""What sets the length of a lockstep launch: per-env wavefront durations of ONE control step of the bench workload (4096 Lift envs, all at
+episode step `nskip`), their percentiles, the event counts of the slowest envs, and the per-phase profile of the slowest / p99 / median env.
+With a -DRSIM_MPRSTAT build (tools/subprof.sh mpr) slots x0..x7 say how the MPR runs end.
+Usage (GPU box): [RSIM_LIB=...] python tools/tail_report.py [nskip=200] [B=4096]"""
+import json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from robosuite_amd import lift, mjcf
+nskip = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+adir = os.path.join(ROOT, "robosuite_amd", "assets")
+flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim")); cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
+tape = torch.tensor(lift.env_actions(np.arange(B), nskip + 1), device="cuda")
+MPR_SLOTS = ("x0 exit pre-test", "x1 exit 1st support", "x2 exit 2nd support", "x3 exit portal discovery", "x4 exit refinement", "x5 contact", "x6 supports of contacts", "x7 supports of late exits")
+
+
+def run(filter_env):
+    env = lift.LiftBatch(flat, cfg, np.arange(B), seed0=0)
+    for t in range(nskip): env.step(tape[t])
+    env.batch.sync(); env.batch.profile(True); env.batch.profile_env(filter_env)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s = torch.cuda.ExternalStream(env.batch.stream())
+    e0.record(s); env.step(tape[nskip]); e1.record(s); env.batch.sync(); torch.cuda.synchronize()
+    return env.batch.wavelog(), env.batch.profile(False), e0.elapsed_time(e1)
+
+
+w, p, ms = run(-2)   # -2: no env adds to the shared accumulators (undistorted durations)
+dur = (w[:, 3].astype(np.int64) - w[:, 2].astype(np.int64)) / 100.0
+cnt = w[:, 4:8].astype(np.int64)
+order = np.argsort(-dur)
+print(f"step {nskip}, B={B}: launch {ms*1e3:.0f} us; env wavefront duration us: mean {dur.mean():.0f} p50 {np.percentile(dur,50):.0f} p90 {np.percentile(dur,90):.0f} "
+      f"p99 {np.percentile(dur,99):.0f} p99.9 {np.percentile(dur,99.9):.0f} max {dur.max():.0f}; sum/2048 slots = {dur.sum()/2048:.0f} us")
+print("per launch (25 substeps): n_mpr n_support n_newton n_cand -- mean", cnt.mean(0).round(1).tolist(), "p99", np.percentile(cnt, 99, axis=0).round(0).tolist(), "max", cnt.max(0).tolist())
+print("corr(dur, n_mpr) %.3f  corr(dur, n_support) %.3f  corr(dur, n_newton) %.3f" % tuple(np.corrcoef(dur, cnt[:, k])[0, 1] for k in (0, 1, 2)))
+A = np.stack([np.ones(B), cnt[:, 0], cnt[:, 1], cnt[:, 2], cnt[:, 3]], 1).astype(np.float64)
+coef = np.linalg.lstsq(A, dur, rcond=None)[0]
+print("least squares: dur_us = %.0f + %.2f n_mpr + %.2f n_support + %.2f n_newton + %.2f n_cand" % tuple(coef))
+print("slowest envs: dur_us [n_mpr n_support n_newton n_cand]")
+for i in order[:10]: print(f"  env {i}: {dur[i]:.0f}  {cnt[i].tolist()}")
+_, pa, _ = run(-1)
+ns = max(1, pa["n_sub"])
+print("whole batch, per env-substep:", {k[2:]: round(pa[k] / ns, 3) for k in pa if k.startswith("n_") and k != "n_sub"})
+xs = {MPR_SLOTS[i]: round(pa[f"x{i}"] / ns, 3) for i in range(8) if pa[f"x{i}"]}
+if xs: print("whole batch MPR outcomes per env-substep:", xs)
+for which, e in (("slowest", int(order[0])), ("p99", int(order[B // 100])), ("median", int(order[B // 2]))):
+    w2, p, _ = run(e)
+    nsub = max(1, p["n_sub"])
+    cyc = {k: int(v / nsub) for k, v in p.items() if not k.startswith("n_") and not k.startswith("x") and k not in ("boxbox", "mpr", "plane") and v}
+    print(f"{which} env {e} ({dur[e]:.0f} us): ticks/substep total {sum(cyc.values())}:", cyc)
+    print("    narrow split: boxbox %d mpr %d other %d | per substep:" % (p["boxbox"] / nsub, p["mpr"] / nsub, p["plane"] / nsub),
+          {k[2:]: round(p[k] / nsub, 2) for k in p if k.startswith("n_") and k != "n_sub"})
+    xs = {MPR_SLOTS[i]: round(p[f"x{i}"] / nsub, 2) for i in range(8) if p[f"x{i}"]}
+    if xs: print("    MPR outcomes per substep:", xs)
