@@ -1,26 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the fused control-step hot path on MI355X (BASELINE.json metric).
 
-One "step" = one robosuite `env.step(action)` for every env of the batch = ONE launch of the fused kernel
-(25 physics substeps at dt=0.002 + 25 OSC_POSE/GRIP controller evaluations + set_goal; reference
-environments/base.py:467-521).  Workload at N=1 = BASELINE configs[1]: Lift / Panda / OSC_POSE, 4096 envs on one GPU,
-per-env seeded episodes (cube size, arm noise, cube pose) and per-env action streams.
-N>1: every rank owns 4096 envs of the global index range (weak scaling, no data-path collective; one stats all-reduce
-after the timed region).  Inputs (state, model tables, the whole action tape) are resident in HBM before the timed region.
+One "step" = one robosuite `env.step(action)` for every env of the batch (25 physics substeps at dt = 0.002 + 25 controller evaluations +
+set_goal + observation / reward; reference environments/base.py:467-521), i.e. one launch of the fused kernel per env.
+Workload at N = 1 = BASELINE configs[1]: Lift / Panda / OSC_POSE, 4096 envs on one GPU, per-env seeded episodes (cube size, arm noise, cube
+pose) and per-env action streams.  `--config stack | peg | pickplace` runs BASELINE configs[2..4] under the same
+protocol and JSON contract (Stack 4096 envs, TwoArmPegInHole / Baxter / JOINT_VELOCITY 2048, PickPlace / IIWA 8192 with the dynamics re-drawn
+before every control step).  N > 1: every rank owns `envs-per-gpu` envs of the global index range (weak scaling, no data-path collective; one
+stats all-reduce after the timed region).  State, model tables and the whole action tape are resident in HBM before the timed region.
+
+`value` is the LOCKSTEP figure: every control step is handed the actions of ALL envs and the next one starts when all of them have finished --
+what a closed-loop policy that consumes the whole observation batch gets.  (Round 2 reported the stream-groups figure as `value`; that one is
+`config.open_loop` now: env blocks on their own streams run ahead of each other, which only an action tape recorded beforehand allows.)
 
 Episode phase.  A launch gets slower along an episode (random actions bring the hand to the table: more narrow-phase pairs and Newton
-iterations; +30 % from step 0 to step 250), so timing the first steps of 4096 synchronised episodes measures the cheap part only.  By
-default the envs are therefore put at episode steps spread uniformly over the horizon before anything is timed: env i starts with its
-step counter at o_i = (197 i) mod 500 and `horizon` untimed launches are run, so every env passes its horizon once (on-device reset from
-the bank) and then sits o_i genuine steps into its second episode.  Every timed launch then sees the steady-state mix of an RL rollout,
-including the ~B/500 on-device episode resets per launch.  `--phase fresh` times synchronised episodes from their first step instead.
+iterations; +30 % from step 0 to step 250), so timing the first steps of synchronised episodes measures the cheap part only.  By default the
+envs are therefore put at episode steps spread uniformly over the horizon before anything is timed: env i starts with its step counter at
+o_i = (197 i) mod 500 and `--preroll` (default: the horizon) untimed launches are run, so every env passes its horizon once (on-device reset
+from the ring) and then sits o_i genuine steps into its second episode.  Every timed launch then sees the steady-state mix of an RL rollout,
+including the ~B/500 on-device episode resets per launch and the asynchronous upkeep of the reset ring (`config.reset_ring`).
 
-Stream groups.  One launch lasts as long as its slowest env (contact-rich envs take 3-4 x the median; measured 3.9 ms against a mean slot
-load of 2.5 ms), and the envs are independent of each other.  By default the batch therefore steps as `--groups` (16) contiguous env blocks, each
-on its own HIP stream (include/rsim.h rsim_set_stream_groups): `env.step()` still enqueues one control step of all 4096 envs, but a block's
-step t + 1 starts when ITS slowest env has finished step t instead of waiting for the slowest env of the whole batch.  Same work, same results
-(tools/groups_sweep.py: the reached state is bit-identical for every group count); the timed region is still exactly K steps of every env
-between two full synchronisations.  `config.lockstep` reports the same K steps timed with `--groups 1` right after the main region.
+Solo envs (`--solo`, default B / 32).  A launch lasts as long as its slowest env; the envs that were slowest in the previous step run on a build
+of the same kernel that keeps their SIMD to themselves, launched beside the main kernel (include/rsim.h rsim_set_solo_envs).  Bit-identical results.
 
 Prints ONE JSON line on rank 0.  See DESIGN.md section 6 for the roofline / cpu_baseline definitions.
 """
@@ -37,49 +38,99 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from robosuite_amd import backend, lift, mjcf, shard  # noqa: E402
+from robosuite_amd import backend, factory, lift, mjcf, shard  # noqa: E402
 
-ENVS_PER_GPU = 4096
 N_SUB = 25
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 HORIZON = 500
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4  # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles at 2.4 GHz
+# VALU wave-instructions per second the chip can issue.  MEASURED (tools/ubench/valu_peak.hip, profiles/r03_a_valu_peak.txt): independent v_fma_f32
+# streams at 8 wavefronts per SIMD reach 1177.8 G/s = one wave64 instruction per 2.09 cycles and SIMD; the guide's figure (MI355X_MICROARCH.md, wave
+# scheduling: SIMD-32, a wave64 VALU instruction issues over 2 cycles) is 256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1228.8 G/s.  Rounds 1-2 used 614 G/s
+# (4 cycles per instruction, the SIMD-16 figure of earlier parts), which overstated every issue fraction 2x.
+VALU_ISSUE_PEAK = 1177.8e9
+VALU_ISSUE_PEAK_THEORY = 256 * 4 * 2.4e9 / 2
+
+# BASELINE configs[1..4]: name -> (task class name for the report, asset stem, envs per GPU, per-step dynamics randomisation)
+CONFIGS = {
+    "lift": ("Lift/Panda/OSC_POSE", "lift_panda", 4096, False, "configs[1]"),
+    "stack": ("Stack/Panda/OSC_POSE", "stack_panda", 4096, False, "configs[2]"),
+    "peg": ("TwoArmPegInHole/Baxter/JOINT_VELOCITY", "peg_baxter_joint_velocity", 2048, False, "configs[3]"),
+    "pickplace": ("PickPlace/IIWA+Robotiq140/OSC_POSE + per-step dynamics randomisation", "pickplace_iiwa", 8192, True, "configs[4]"),
+}
 
 
-def algorithmic_bytes_per_env_step(flat, action_dim):
+def build_env(config, flat, cfg, ids, device, episodes):
+    from robosuite_amd import peg_in_hole, pick_place, stack
+
+    if config == "lift":
+        return lift.LiftBatch(flat, cfg, ids, device=device, seed0=0, horizon=HORIZON, bank_episodes=episodes)  # episodes auto-reset at horizon 500
+    if config == "stack":
+        return stack.StackBatch(flat, cfg, ids, device=device, seed0=0, horizon=HORIZON, bank_episodes=episodes)
+    if config == "peg":
+        return peg_in_hole.PegBatch(flat, cfg, ids, device=device, seed0=0, horizon=HORIZON, bank_episodes=episodes)
+    env = pick_place.PickPlaceBatch(flat, cfg, ids, device=device, seed0=0, horizon=HORIZON, bank_episodes=episodes, per_env_params=True)
+    env.batch.dr_save_defaults()
+    return env
+
+
+def algorithmic_bytes_per_env_step(env, flat, dr):
     """Compulsory HBM bytes one env-step moves through the fused kernel (fp32 words x 4), DESIGN.md section 6:
-    read  action + qpos + qvel + qacc_warmstart + ctrl + time + controller state + per-env model deltas (cube: size3 rbound1 mass1 inertia3 subtree1 invw2 dofinvw6)
-    write qpos + qvel + qacc_warmstart + ctrl + time + controller state + observation record + reward/done."""
-    from robosuite_amd.backend import CSTATE
-    OBS_DIM = len(lift.lift_task(flat, json.load(open(os.path.join(ROOT, "robosuite_amd", "assets", "lift_panda.cfg.json"))))["obs"])
+    read  action + qpos + qvel + qacc_warmstart + ctrl + time + controller state + the per-env model values that change per episode
+    write qpos + qvel + qacc_warmstart + ctrl + time + controller state + observation record + reward/done.
+    With per-step dynamics randomisation every env's float table is re-drawn (read defaults, write table) and its constant block rebuilt
+    (write) and read once by the control step."""
     nq, nv, nu = flat.nq, flat.nv, flat.nu
-    rd = action_dim + nq + nv + nv + nu + 1 + CSTATE + 17
-    wr = nq + nv + nv + nu + 1 + CSTATE + OBS_DIM + 2
-    return 4 * (rd + wr)
+    cs, nobs, adim = env.model.cstate_size, env.model.nobs, env.model.action_dim
+    per_episode = len(env._bank_patch_offsets())
+    rd = adim + nq + nv + nv + nu + 1 + cs + per_episode
+    wr = nq + nv + nv + nu + 1 + cs + nobs + 2
+    words = rd + wr
+    if dr:
+        words += 2 * env.model.int("float_table_size") + 2 * (env.model.int("constant_block_bytes") // 4)
+    return 4 * words
 
 
-def cpu_baseline(flat, cfg, budget_s=12.0):
-    """The CPU oracle (oracle/rsim_oracle.c: same pipeline, fp64, serial C) timed on this host's cores on a bounded sample of the
-    same workload: `cores` threads (ctypes releases the GIL), each stepping its own seeded Lift env with its own action stream."""
+def cpu_baseline(config, flat, cfg, budget_s=12.0):
+    """The CPU oracle (oracle/rsim_oracle.c: same pipeline, fp64, serial C) timed on this host's cores on a bounded sample of the same workload:
+    `cores` threads (ctypes releases the GIL), each stepping its own env of the configuration's model with its own action stream."""
     import threading
 
-    from oracle.oracle import OracleController, OracleData, OracleModel
+    from oracle.oracle import OracleController, OracleData, OracleModel, env_step_parts
+    from robosuite_amd import peg_in_hole, pick_place, stack
 
     cores = os.cpu_count() or 1
     counts = [0] * cores
     stop = time.perf_counter() + budget_s
-
     def work(k):
-        sizes, qpos = lift.episode_setup(0, [k])
-        f = flat.copy()
-        for field, rows in lift.cube_model_rows(flat, sizes).items():
-            f.arrays[field] = rows[0].reshape(f.arrays[field].shape)
-        om = OracleModel(mjcf.to_blob(f)); od = OracleData(om); oc = OracleController(cfg)
-        od.qpos[:] = qpos[0]; od.qvel[:] = 0; od.qacc_warmstart[:] = 0; od.forward(); oc.reset(od)
-        acts = lift.env_actions([k], 4000)[:, 0].astype(np.float64)
+        f = flat
+        if config == "lift":
+            sizes, qpos = lift.episode_setup(0, [k])
+            f = flat.copy()
+            for field, rows in lift.cube_model_rows(flat, sizes).items():
+                f.arrays[field] = rows[0].reshape(f.arrays[field].shape)
+            q0 = qpos[0]
+        elif config == "stack":
+            q0 = stack.episode_setup(0, [k])[0]
+        elif config == "peg":
+            q0 = peg_in_hole.episode_setup(0, [k])[0]
+        else:
+            q0 = pick_place.episode_setup(cfg, flat.nq, 0, [k])[0]
+        om = OracleModel(mjcf.to_blob(f)); od = OracleData(om)
+        od.qpos[:] = q0; od.qvel[:] = 0; od.qacc_warmstart[:] = 0; od.forward()
+        if "parts" in cfg and not str(cfg.get("type", "")).startswith("OSC"):
+            parts = [(OracleController(p), len(p["input_min"])) for p in cfg["parts"]]
+            for c, _ in parts:
+                c.reset(od)
+            na = sum(n for _, n in parts)
+            step = lambda a: env_step_parts(od, parts, a, N_SUB)   # noqa: E731
+        else:
+            oc = OracleController(cfg); oc.reset(od)
+            na = len(cfg["input_min"]) + (1 if cfg.get("grip_act") else 0)
+            step = lambda a: oc.env_step(od, a, N_SUB)   # noqa: E731
+        acts = lift.env_actions([k], 4000, action_dim=na)[:, 0].astype(np.float64)
         n = 0
         while time.perf_counter() < stop and n < len(acts):
-            oc.env_step(od, acts[n], N_SUB)
+            step(acts[n])
             n += 1
         counts[k] = n
 
@@ -89,7 +140,8 @@ def cpu_baseline(flat, cfg, budget_s=12.0):
     [t.join() for t in th]
     dt = time.perf_counter() - t0
     return {"value": sum(counts) / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{sum(counts)} env.steps of Lift/Panda/OSC_POSE ({cores} envs x ~{sum(counts)//cores} steps, {cores} threads, fp64 C oracle incl. C controllers) in {dt:.1f} s"}
+            "sample": f"{sum(counts)} env.steps of {CONFIGS[config][0].split(' +')[0]} ({cores} envs x ~{sum(counts)//cores} steps, {cores} threads, fp64 C oracle incl. C controllers"
+                      f"{'' if config != 'pickplace' else ', without the per-step dynamics randomisation'}) in {dt:.1f} s"}
 
 
 def main():
@@ -97,11 +149,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)   # 200 timed steps after 20 warm-up steps
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="lift", help="BASELINE configuration (module docstring); the driver's default is lift = configs[1]")
+    ap.add_argument("--envs-per-gpu", type=int, default=0, help="default: the configuration's BASELINE batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phase", choices=("staggered", "fresh"), default="staggered", help="episode phase of the envs when the timed region starts (module docstring)")
-    ap.add_argument("--groups", type=int, default=16, help="env blocks stepped on their own HIP streams (module docstring); 1 = one launch per step")
-    ap.add_argument("--no-lockstep", action="store_true", help="skip the second timed region (same K steps with one launch per step)")
+    ap.add_argument("--preroll", type=int, default=-1, help="untimed launches before the warm-up in the staggered phase (default: the horizon)")
+    ap.add_argument("--solo", type=int, default=-1, help="envs per step on the one-wavefront-per-SIMD build (rsim_set_solo_envs); default B / 32 for lift, 0 otherwise")
+    ap.add_argument("--groups", type=int, default=16, help="env blocks on their own HIP streams for the secondary open-loop figure; 1 = skip it")
+    ap.add_argument("--no-open-loop", action="store_true", help="skip the second timed region (the same K steps with stream groups)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -124,19 +179,25 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    adir = os.path.join(ROOT, "robosuite_amd", "assets")
-    flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim"))
-    cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
-    B = args.envs_per_gpu
+    label, stem, b_default, dr, which = CONFIGS[args.config]
+    flat, cfg = factory.load_shipped(stem)
+    B = args.envs_per_gpu or b_default
     ids = shard.env_block(B * world, rank, world)
     K, W = args.steps, args.warmup
-    P = HORIZON if args.phase == "staggered" else 0   # untimed pre-roll launches
+    P = (HORIZON if args.preroll < 0 else args.preroll) if args.phase == "staggered" else 0   # untimed pre-roll launches
     G = max(1, args.groups)
-    K2 = 0 if (args.no_lockstep or G == 1) else K   # second region: the same number of steps, one launch per step
-    env = lift.LiftBatch(flat, cfg, ids, device=local_rank, seed0=0, horizon=HORIZON, bank_episodes=2 + (P + W + K + K2) // HORIZON)  # config 2: episodes auto-reset at horizon 500
-    tape = torch.tensor(lift.env_actions(ids, P + K + W + K2), device=dev)  # whole action tape resident in HBM
-    env.batch.set_stream_groups(G)
-    streams = [torch.cuda.ExternalStream(env.batch.group_stream(g), device=dev) for g in range(G)]   # the streams the fused kernel is launched on
+    K2 = 0 if (args.no_open_loop or G == 1) else K   # second region: the same number of steps with stream groups (open loop)
+    env = build_env(args.config, flat, cfg, ids, local_rank, 3 + (P + W + K + K2) // HORIZON)
+    adim = env.model.action_dim
+    tape = torch.tensor(lift.env_actions(ids, P + K + W + K2, action_dim=adim), device=dev)  # whole action tape resident in HBM
+    nsolo = args.solo if args.solo >= 0 else (B // 32 if args.config == "lift" else 0)
+    env.batch.set_solo_envs(nsolo)
+    dr_step = [0]
+
+    def step(t):
+        if dr:
+            env.batch.randomize_dynamics(seed=11, step=dr_step[0]); dr_step[0] += 1
+        env.step(tape[t])
 
     def barrier():
         if world > 1:
@@ -145,34 +206,40 @@ def main():
     if P:
         env.batch.set("ep_step", ((197 * ids) % HORIZON).astype(np.int32))   # keyed by the GLOBAL env id: independent of the GPU count
         for t in range(P):
-            env.step(tape[t])
+            step(t)
         tape = tape[P:]
     for t in range(W):
-        env.step(tape[t])
+        step(t)
     env.batch.sync(); torch.cuda.synchronize(); barrier()
+    ring0 = env.bank_stats()
+
     def timed(first, n, strs):
         ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in strs] for _ in range(n)]
         t0 = time.perf_counter()
         for t in range(n):
             for g, s_ in enumerate(strs):
                 ev[t][g][0].record(s_)
-            env.step(tape[first + t])
+            step(first + t)
             for g, s_ in enumerate(strs):
                 ev[t][g][1].record(s_)
         env.batch.sync(); torch.cuda.synchronize(); barrier()
         dt_ = shard.max_over_ranks(time.perf_counter() - t0, dev)
         return dt_, [[a.elapsed_time(b) for a, b in row] for row in ev]
 
-    dt, evms = timed(W, K, streams)
-    kern_ms = float(np.mean(evms))   # mean duration of one launch of the fused kernel (one env block of B / G envs) incl. its dispatch-order / reset passes
+    # ---- the headline region: one control step of all envs at a time, events on the stream the fused kernel is launched on
+    dt, evms = timed(W, K, [torch.cuda.ExternalStream(env.batch.stream(), device=dev)])
+    kern_ms = float(np.mean(evms))   # one control step of all B envs: dispatch order + k_step (+ the solo launch beside it) + reset passes
+    ring1 = env.bank_stats()
     if os.environ.get("RSIM_BENCH_TRACE"):
-        print("per-step ms (group 0):", " ".join(f"{r[0]:.2f}" for r in evms), file=sys.stderr)
-    lockstep = None
+        print("per-step ms:", " ".join(f"{r[0]:.2f}" for r in evms), file=sys.stderr)
+    open_loop = None
     if K2:
+        env.batch.set_stream_groups(G)
+        dt2, ev2 = timed(W + K, K2, [torch.cuda.ExternalStream(env.batch.group_stream(g), device=dev) for g in range(G)])
         env.batch.set_stream_groups(1)
-        dt2, ev2 = timed(W + K, K2, [torch.cuda.ExternalStream(env.batch.stream(), device=dev)])
-        lockstep = {"value": B * world * K2 / dt2, "ms_per_step": 1e3 * dt2 / K2, "kernel_ms": float(np.mean(ev2)), "steps": K2,
-                    "note": "the next K steps of the same envs with one launch of all envs per step (--groups 1)"}
+        open_loop = {"value": B * world * K2 / dt2, "ms_per_step": 1e3 * dt2 / K2, "kernel_ms_per_env_block": float(np.mean(ev2)), "steps": K2, "stream_groups": G,
+                     "note": "the next K steps of the same envs as G env blocks on their own HIP streams (rsim_set_stream_groups): a block's step t + 1 does not wait "
+                             "for the other blocks' step t -- reachable only with actions known in advance (an action tape), not by a closed-loop policy"}
 
     st = shard.RolloutStats(dev)
     q = env.batch.tensor("qpos")
@@ -180,16 +247,15 @@ def main():
     st.add(env_steps=B * K, diverged=int((~torch.isfinite(q).all(dim=1)).sum().item()) + int((env.batch.tensor("diverged") > 0).sum().item()),
            reward_sum=float(env.reward().sum().item()), successes=int(env.success().sum().item()))
     overflow_envs = shard.max_over_ranks(float((env.batch.tensor("overflow") > 0).sum().item()), dev)   # envs that ever dropped a contact / constraint row
-    if hasattr(env, "rollout_totals"):
-        st.add(**env.rollout_totals())
+    bank_stale = shard.max_over_ranks(float(env.batch.tensor("bank_stale").sum().item()), dev)
     tot = st.allreduce()
 
     if rank == 0:
-        OBS_DIM_REPORT = env.model.nobs
-        abytes = algorithmic_bytes_per_env_step(flat, env.model.action_dim) * B / G   # one launch = one env block
+        abytes = algorithmic_bytes_per_env_step(env, flat, dr) * B   # one control step = one launch of all B envs
         ach = abytes / (kern_ms * 1e-3) / 1e9
         # PMC-derived figures are only valid for the library build they were measured on: the files carry the sha of that build
         lib_sha = hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16]
+        sfx = "" if args.config == "lift" else "_" + args.config
 
         def pmc(name, key):
             try:
@@ -198,37 +264,42 @@ def main():
             except Exception:
                 return None
 
-        traffic = pmc("hbm_traffic.json", "bytes_per_launch")            # tools/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE passes), one launch of all B envs
-        traffic_step = traffic
-        if traffic:
-            traffic = traffic / G                                         # per launch of one env block, like `achieved`
-        valu = pmc("valu_count.json", "valu_per_env_substep")            # tools/pmc_valu.py (SQ_INSTS_VALU pass on this workload)
+        traffic = pmc(f"hbm_traffic{sfx}.json", "bytes_per_launch")      # tools/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE passes), one launch of all B envs
+        valu = pmc(f"valu_count{sfx}.json", "valu_per_env_substep")      # tools/pmc_valu.py (SQ_INSTS_VALU pass on this workload)
         issue = None
         if valu:
-            rate = valu * B * N_SUB * K / dt   # wave-instructions per second of this GPU over the timed region (launches of different env blocks overlap)
+            rate = valu * B * N_SUB * K / dt   # wave-instructions per second of this GPU over the timed region
             issue = {"bound": "valu-issue", "valu_instr_per_env_substep": valu, "achieved": rate / 1e9,
                      "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instr/s", "frac": rate / VALU_ISSUE_PEAK,
-                     "source": "profiles/valu_count.json (rocprofv3 --pmc SQ_INSTS_VALU on this build, same workload)"}
+                     "peak_source": "measured: tools/ubench/valu_peak.hip, 8 wavefronts per SIMD of independent v_fma_f32 (profiles/r03_a_valu_peak.txt); "
+                                    f"guide figure {VALU_ISSUE_PEAK_THEORY / 1e9:.1f} (one wave64 VALU instruction per 2 cycles and SIMD)",
+                     "source": f"profiles/valu_count{sfx}.json (rocprofv3 --pmc SQ_INSTS_VALU on this build, same workload)"}
+        dsteps = max(1, ring1["steps"] - ring0["steps"])
         out = {
-            "metric": "env-steps/sec (whole node), Lift/Panda/OSC_POSE @4096 envs/GPU", "value": tot["env_steps"] / dt, "unit": "env-steps/s",
+            "metric": f"env-steps/sec (whole node), {label.split(' +')[0]} @{B} envs/GPU", "value": tot["env_steps"] / dt, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Lift/Panda/OSC_POSE, 25 substeps x dt 0.002 + OSC_POSE/GRIP per substep, fused in one launch (BASELINE configs[1])",
+            "config": {"workload": f"{label}, 25 substeps x dt 0.002 + controllers per substep, fused in one launch per env (BASELINE {which})",
                        "envs_per_gpu": B, "global_envs": B * world, "n_sub": N_SUB, "per_env_seeded_reset": True, "horizon": HORIZON, "on_device_auto_reset": True,
-                       "stream_groups": G, "lockstep": lockstep,
-                       "episode_phase": ("uniform over the horizon: step counters offset by (197 i) mod 500, then 500 untimed pre-roll launches" if P else "fresh: all envs at step W of their first episode"),
-                       "overflow_envs": int(overflow_envs), "lib_sha16": lib_sha, "obs_dim": OBS_DIM_REPORT, "sharding": f"env-block x{world}",
+                       "protocol": "lockstep: one control step of all envs per call, the next starts when all have finished (closed-loop compatible)",
+                       "solo_envs": nsolo, "open_loop": open_loop, "dynamics_randomisation": "re-drawn before every control step" if dr else None,
+                       "episode_phase": (f"uniform over the horizon: step counters offset by (197 i) mod 500, then {P} untimed pre-roll launches" if P else "fresh: all envs at step W of their first episode"),
+                       "reset_ring": {"bank_stale": int(bank_stale), "polls_in_region": ring1["polls"] - ring0["polls"], "rows_refilled_in_region": ring1["rows"] - ring0["rows"],
+                                      "stepping_thread_ms_per_1000_steps": 1e6 * (ring1["tick_s"] - ring0["tick_s"]) / dsteps,
+                                      "upkeep_thread_ms_per_1000_steps": 1e6 * (ring1["upkeep_s"] - ring0["upkeep_s"]) / dsteps,
+                                      "note": "asynchronous: episode counters polled on a side stream, rows drawn by a host thread from persistent per-env generators, "
+                                              "scattered through pinned staging (reset_bank.py); the stepping thread never reads the device"},
+                       "overflow_envs": int(overflow_envs), "lib_sha16": lib_sha, "obs_dim": env.model.nobs, "action_dim": adim, "sharding": f"env-block x{world}",
                        "diverged_envs": int(tot["diverged"]), "reward_sum": tot["reward_sum"], "successes": int(tot["successes"])},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes, "concurrent_launches": G, "traffic_per_control_step": traffic_step,
-                         "aggregate_achieved": abytes * G * K / dt / 1e9,   # GB/s of all env blocks together (their launches overlap)
+                         "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes,
                          "note": "latency/VALU/LDS-bound by design (state LDS-resident for 25 substeps); see DESIGN.md section 6",
                          # the fraction that describes this kernel: VALU issue slots used (PMC instruction count of THIS build x measured rate); null
                          # when profiles/valu_count.json was measured on another build
                          "issue": issue},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(flat, cfg)
+            out["cpu_baseline"] = cpu_baseline(args.config, flat, cfg)
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

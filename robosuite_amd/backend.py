@@ -202,6 +202,7 @@ def lib():
         L.rsim_pairlog.argtypes = [vp, vp]
         L.rsim_set_schedule.argtypes = [vp, C.c_int]
         L.rsim_set_stream_groups.argtypes = [vp, C.c_int]
+        L.rsim_set_solo_envs.argtypes = [vp, C.c_int]
         L.rsim_group_stream.restype = vp; L.rsim_group_stream.argtypes = [vp, C.c_int]
         L.rsim_profile_env.argtypes = [vp, C.c_int]
         L.rsim_osc_eval.argtypes = [C.POINTER(CtrlDesc), vp, vp, C.c_int, C.c_int]
@@ -482,6 +483,10 @@ class HipBatch:
         longer waits for the slowest env of the whole batch.  Same results; 1 = one launch per step."""
         _chk(self._L.rsim_set_stream_groups(self.ptr, int(groups)))
         self._ngroups = int(groups)
+
+    def set_solo_envs(self, n: int):
+        """The n slowest envs of the previous step get a SIMD to themselves in the next one (include/rsim.h rsim_set_solo_envs).  Same results; 0 = off."""
+        _chk(self._L.rsim_set_solo_envs(self.ptr, int(n)))
 
     def group_stream(self, g: int):
         return self._L.rsim_group_stream(self.ptr, int(g))

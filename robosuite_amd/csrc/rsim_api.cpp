@@ -59,6 +59,7 @@ typedef int (*cmem_fn)(void);
 static const prepare_fn k_prepare_launch[RSIM_NCFG] = {rsim_launch_prepare_cfg0, rsim_launch_prepare_cfg1, rsim_launch_prepare_cfg2, rsim_launch_prepare_cfg3, rsim_launch_prepare_cfg4};
 static const cmem_fn k_cmem_bytes[RSIM_NCFG] = {rsim_cmem_bytes_cfg0, rsim_cmem_bytes_cfg1, rsim_cmem_bytes_cfg2, rsim_cmem_bytes_cfg3, rsim_cmem_bytes_cfg4};
 static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1, rsim_limits_cfg2, rsim_limits_cfg3, rsim_limits_cfg4};
+extern "C" int rsim_launch_step_cfg0s(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);   // one wavefront per SIMD
 extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream);
 extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStream_t stream);
 extern "C" int rsim_launch_bank_scatter(float* bank, int* tag, const int* env, const int* episode, const float* rows, int n, int E, int W, hipStream_t stream);
@@ -146,6 +147,10 @@ struct rsim_batch {
   int groups, ngroups, forked;   // streams created, groups in use (1 = everything on the main stream)
   hipStream_t gstream[RSIM_MAX_GROUPS];
   hipEvent_t gev[RSIM_MAX_GROUPS], mev;
+  // solo envs (rsim_set_solo_envs): the slowest envs of the previous step run on the one-wavefront-per-SIMD build of the kernel, on a stream of their own
+  int solo_n;
+  hipStream_t sstream;
+  hipEvent_t sev0, sev1;
   // asynchronous reset-bank upkeep (rsim_bank_poll_begin / _poll / rsim_refill_reset_bank_async): a side stream of its own, pinned staging
   hipStream_t bstream;
   hipEvent_t bev;
@@ -506,10 +511,13 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
 
 extern "C" void rsim_model_free(rsim_model* m) { delete m; }
 
+static int pick_config(const rsim_model* m, int* lim_out);
 extern "C" int rsim_model_int(const rsim_model* m, const char* name) {
   if (!strcmp(name, "ncgeom")) return (int)m->cg.size();
   if (!strcmp(name, "cstate_size")) return m->ctrl.enabled ? m->ctrl.cs_size : RSIM_CS_SIZE;
   if (!strcmp(name, "action_dim")) return m->ctrl.enabled ? m->ctrl.action_dim : 0;
+  if (!strcmp(name, "float_table_size")) return (int)m->ftab.size();                              // floats of one env's model float table
+  if (!strcmp(name, "constant_block_bytes")) { const int c = pick_config(m, nullptr); return c < 0 ? -1 : k_cmem_bytes[c](); }   // one env's constant block
   const int* v = m->I(name);
   return v ? v[0] : -1;
 }
@@ -690,6 +698,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   b->gen = 1; b->cache_gen = 0; b->cache_env = -1;
   b->db.prof_env = -1;
   b->d_bank = nullptr; b->d_bank_tag = nullptr; b->d_patch = nullptr; b->d_ft_base = nullptr;
+  b->solo_n = 0; b->sstream = nullptr; b->sev0 = nullptr; b->sev1 = nullptr;
   b->bstream = nullptr; b->bev = nullptr; b->h_epidx = nullptr; b->bank_poll_pending = 0; b->bstage_next = 0;
   memset(b->bstage, 0, sizeof(b->bstage));
   const int ncg = (int)m->cg.size();
@@ -723,6 +732,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   if (dalloc(&b->d_order, (size_t)B)) return 1;
   if (dalloc(&b->d_cost, (size_t)B)) return 1;
   if (dalloc(&b->db.needs_reset, (size_t)B)) return 1;
+  b->db.mprc = nullptr;
+  if (!getenv("RSIM_NO_MPR_WARMSTART") && m->npair > 0 && dalloc(&b->db.mprc, (size_t)B * m->npair * 4)) return 1;
   b->db.ft_rw = b->d_ft;
   DModel& dm = b->dm;
   dm.nq = m->nq; dm.nv = m->nv; dm.nu = m->nu; dm.nbody = m->nbody; dm.njnt = m->njnt; dm.ncg = ncg; dm.nsite = m->nsite; dm.npair = m->npair;
@@ -796,10 +807,12 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   if (b->mev) hipEventDestroy(b->mev);
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
   hipFree(b->d_cm);
+  if (b->db.mprc) hipFree(b->db.mprc);
   hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_ft0); if (b->d_obsprog) hipFree(b->d_obsprog);
   if (b->d_bank) hipFree(b->d_bank); if (b->d_bank_tag) hipFree(b->d_bank_tag); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); if (b->d_ft_base) hipFree(b->d_ft_base); hipFree(b->d_mesh); hipFree(b->d_mask);
   if (b->d_order) hipFree(b->d_order); if (b->d_cost) hipFree(b->d_cost);
   if (b->db.prof) hipFree(b->db.prof);
+  if (b->sstream) { hipStreamSynchronize(b->sstream); hipStreamDestroy(b->sstream); hipEventDestroy(b->sev0); hipEventDestroy(b->sev1); }
   if (b->bstream) { hipStreamSynchronize(b->bstream); hipStreamDestroy(b->bstream); }
   if (b->bev) hipEventDestroy(b->bev);
   if (b->h_epidx) hipHostFree(b->h_epidx);
@@ -844,6 +857,7 @@ extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) { if (join_groups(
       HIPCHK(hipMemset(b->db.ep_step + e, 0, sizeof(int))); HIPCHK(hipMemset(b->db.done + e, 0, sizeof(int))); HIPCHK(hipMemset(b->db.needs_reset + e, 0, sizeof(int)));
     }
   }
+  if (b->db.mprc) HIPCHK(hipMemset(b->db.mprc, 0, (size_t)B * m->npair * 4 * sizeof(float)));   // no warm start carried into a reset state (bitwise replays)
   b->gen++;
   return 0;
 }
@@ -893,6 +907,12 @@ extern "C" int rsim_set_stream_groups(rsim_batch* b, int groups) {
   if (groups > b->groups) b->groups = groups;
   b->ngroups = groups;
   b->have_cost = 0;
+  return 0;
+}
+
+extern "C" int rsim_set_solo_envs(rsim_batch* b, int n) {
+  if (n < 0) return fail("rsim_set_solo_envs: n < 0");
+  b->solo_n = n;
   return 0;
 }
 
@@ -980,8 +1000,37 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
     b->db.cost = b->d_cost;
     b->have_cost = 1;
   }
-  int e = k_step_launch[b->cfg](&b->dm, &b->db, actions, n_sub, flags, b->stream);
-  if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  int e;
+  const int nsolo = ((flags & RF_EPISODE) && b->cfg == 0 && b->db.order) ? (b->solo_n < b->B / 2 ? b->solo_n : b->B / 2) : 0;
+  if (nsolo > 0) {
+    // Two launches side by side: the first `nsolo` entries of the dispatch order (the envs that took longest in the previous step) on the build of the
+    // kernel that leaves no room for a second wavefront on its SIMD, the rest on the regular one.  The solo launch goes first: each of its
+    // workgroups needs a SIMD with nothing on it.  Same per-env arithmetic in both builds (tests/test_hip_edge_cases.py checks bitwise equality).
+    if (!b->sstream) {
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, b->device));
+      const uint32_t words = (uint32_t)((prop.multiProcessorCount + 31) / 32);
+      std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
+      if (hipExtStreamCreateWithCUMask(&b->sstream, words, mask.data()) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamCreate(&b->sstream)); }   // CU mask = a hardware queue of its own
+      HIPCHK(hipEventCreateWithFlags(&b->sev0, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&b->sev1, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(b->sev0, b->stream));   // the dispatch order (and whatever the caller queued before this step)
+    HIPCHK(hipStreamWaitEvent(b->sstream, b->sev0, 0));
+    DBatch ds = b->db;
+    ds.nenv = nsolo; ds.env0 = 0;
+    e = rsim_launch_step_cfg0s(&b->dm, &ds, actions, n_sub, flags, b->sstream);
+    if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    HIPCHK(hipEventRecord(b->sev1, b->sstream));
+    DBatch dr = b->db;
+    dr.order = b->db.order + nsolo; dr.nenv = b->B - nsolo; dr.env0 = 0;
+    e = k_step_launch[b->cfg](&b->dm, &dr, actions, n_sub, flags, b->stream);
+    if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    HIPCHK(hipStreamWaitEvent(b->stream, b->sev1, 0));
+  } else {
+    e = k_step_launch[b->cfg](&b->dm, &b->db, actions, n_sub, flags, b->stream);
+    if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  }
   if ((flags & RF_EPISODE) && b->db.bank && b->db.horizon > 0) {
     if (b->db.bank_P > 0 && b->db.cm_stride) {
       // envs whose episode just ended were re-initialised from the reset bank, float-table patches included: rebuild their constant blocks
@@ -1264,6 +1313,8 @@ extern "C" int rsim_set_array(rsim_batch* b, int field, const void* src, size_t 
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipMemcpy(b->fptr[field], src, count * 4, hipMemcpyHostToDevice));
+  // positions written by the host: the narrow phase's warm-start directions belong to the states before (a replay from this state must not depend on them)
+  if (field == RSIM_QPOS && b->db.mprc) HIPCHK(hipMemset(b->db.mprc, 0, (size_t)b->B * b->m->npair * 4 * sizeof(float)));
   b->gen++;
   return 0;
 }

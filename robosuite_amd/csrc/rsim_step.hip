@@ -26,7 +26,17 @@
 #endif
 #if RSIM_CFG == 0
 #define RSIM_DIMS 32, 16, 16, 24, 16, 16, 64, 192
+#ifdef RSIM_SOLO
+// Sixth build: the control-step kernel of configuration 0 once more, compiled so that NO second wavefront fits on its SIMD (amdgpu_waves_per_eu(1, 1):
+// the register allocation is padded past half the file).  A launch lasts as long as its slowest env, and a wavefront alone on a SIMD runs ~1.4x
+// faster than one that shares it: rsim_control_step hands the few envs that were slowest in the previous step to this kernel, on a second stream
+// beside the main launch (rsim_set_solo_envs).  Only k_step is compiled here.
+#define RSIM_SYM(x) x##_cfg0s
+#define RSIM_KSTEP k_step_solo
+#define RSIM_KSTEP_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+#else
 #define RSIM_SYM(x) x##_cfg0
+#endif
 #elif RSIM_CFG == 1
 #define RSIM_DIMS 32, 16, 32, 24, 16, 32, 64, 192
 #define RSIM_SYM(x) x##_cfg1
@@ -45,6 +55,11 @@
 
 #ifndef RSIM_MINWAVES
 #define RSIM_MINWAVES 1  /* waves per SIMD the register allocator must leave room for (1: 512 registers, 2: 256) */
+#endif
+
+#ifndef RSIM_KSTEP
+#define RSIM_KSTEP k_step
+#define RSIM_KSTEP_BOUNDS __launch_bounds__(64, RSIM_MINWAVES)
 #endif
 
 typedef unsigned long long u64;
@@ -956,6 +971,7 @@ struct Sim {
     const long long off = (fenv & mask) ? ceoff : 0ll;
     return (cmr_t)((const char __attribute__((address_space(1)))*)cm + off);
   }
+  float __attribute__((address_space(1)))* mprc = nullptr;  // this env's narrow-phase warm-start record [npair][4] in global memory (DBatch.mprc), or null
   float __attribute__((address_space(1)))* cst = nullptr;   // this env's controller-state record in global memory (slots >= RSIM_CS_LDS are used in place)
   Prof pf;
   int ovf = 0;   // contacts / constraint rows this launch had to drop for lack of capacity (RSIM_OVERFLOW); MuJoCo's nconmax = 5000 never truncates
@@ -1876,11 +1892,24 @@ struct Sim {
   }
 
   // Minkowski Portal Refinement (uniform control flow; support() is wave-cooperative)
-  __device__ __forceinline__ void convex_convex(int g1, int g2, float margin, const CPar& cp) {
+  // Warm start (`wd`, valid if `wh`; `wout` = the pair's record, may be null).  A run that ends without contact ends on a SEPARATING direction -- the
+  // first shape's farthest point along it does not reach the second's nearest -- and a hand hovering over the table keeps such pairs alive for
+  // hundreds of substeps: each of them cost ~18 support evaluations per substep to rediscover (portal refinement down to the tolerance before the
+  // sign shows), and they are what makes the slowest env of a launch 3x the median (tools/tail_report.py).  The direction the previous substep's run
+  // ended on is tried first: two support evaluations, and if it still separates the pair is done.  Separation along ANY direction is proof that the
+  // shapes are disjoint, so the verdict is the one the full run reaches (MPR is exact for separated pairs); contacts always come from the full run.
+  __device__ __forceinline__ void mpr_store(gwf wout, V3 d, float valid) const {
+    if (wout && lane == 0) { typedef v4f __attribute__((address_space(1)))* gw4; *(gw4)wout = v4f{d.x, d.y, d.z, valid}; }
+  }
+  __device__ __forceinline__ void convex_convex(int g1, int g2, float margin, const CPar& cp, V3 wd, bool wh, gwf wout) {
     const float tol = 1e-6f;
     const int mprstat_s0 = pf.c_support; (void)mprstat_s0;
     const V3 org = ld3(sm.gpos + 3 * g1);   // all support points relative to the first geom's position (see geom_support)
     const SupGeom sg1 = sup_load(cm, cmf(MK_gst), g1, (gcf)m.mesh_vert, lane, org), sg2 = sup_load(cm, cmf(MK_gst), g2, (gcf)m.mesh_vert, lane, org);
+    if (wh) {
+      const V3 a1 = sup(sg1, wd), a2 = sup(sg2, -wd);
+      if (dot(a1 - a2, wd) <= 0) { MPRSTAT(8, 1); return; }
+    }
     // A box or cylinder against anything: MPR's own exit test (a direction D, oriented from geom 1 to geom 2, in which the first shape's
     // farthest point does not reach the second's nearest) tried first on the primitive's most promising face / radial axis.  The table top or
     // the mount pedestal against a gripper mesh hovering over it -- most narrow-phase visits of the Lift workload -- end here after ONE hull
@@ -1922,14 +1951,14 @@ struct Sim {
         V3 D = mv(sp.R, dl);
         if (!first) D = -D;
         const V3 a1 = sup(sg1, D), a2 = sup(sg2, -D);
-        if (dot(a1 - a2, D) <= 0) { MPRSTAT(0, 1); return; }
+        if (dot(a1 - a2, D) <= 0) { MPRSTAT(0, 1); mpr_store(wout, D, 1.f); return; }
       }
     }
     V3 v0 = (ld3(sm.gcen + 3 * g1) - org) - (ld3(sm.gcen + 3 * g2) - org);
     if (norm(v0) < 1e-9f) v0.x = 1e-5f;
     V3 dir = normalized(-v0);
     V3 p11 = sup(sg1, dir), p12 = sup(sg2, -dir), v1 = p11 - p12;
-    if (dot(v1, dir) <= 0) { MPRSTAT(1, 1); return; }
+    if (dot(v1, dir) <= 0) { MPRSTAT(1, 1); mpr_store(wout, dir, 1.f); return; }
     dir = cross(v0, v1);
     if (norm(dir) < 1e-12f) {
       V3 n = normalized(v1 - v0);
@@ -1938,7 +1967,7 @@ struct Sim {
     }
     dir = normalized(dir);
     V3 p21 = sup(sg1, dir), p22 = sup(sg2, -dir), v2 = p21 - p22;
-    if (dot(v2, dir) <= 0) { MPRSTAT(2, 1); return; }
+    if (dot(v2, dir) <= 0) { MPRSTAT(2, 1); mpr_store(wout, dir, 1.f); return; }
     dir = cross(v1 - v0, v2 - v0);
     if (dot(dir, v0) > 0) {
       V3 t;
@@ -1952,7 +1981,7 @@ struct Sim {
       dir = normalized(dir, &len);
       if (len < FMIN) return;
       p31 = sup(sg1, dir); p32 = sup(sg2, -dir); v3_ = p31 - p32;
-      if (dot(v3_, dir) <= 0) { MPRSTAT(3, 1); MPRSTAT(7, pf.c_support - mprstat_s0); return; }
+      if (dot(v3_, dir) <= 0) { MPRSTAT(3, 1); MPRSTAT(7, pf.c_support - mprstat_s0); mpr_store(wout, dir, 1.f); return; }
       if (dot(cross(v1, v3_), v0) < -1e-14f) { v2 = v3_; p21 = p31; p22 = p32; dir = cross(v1 - v0, v3_ - v0); continue; }
       if (dot(cross(v3_, v2), v0) < -1e-14f) { v1 = v3_; p11 = p31; p12 = p32; dir = cross(v3_ - v0, v2 - v0); continue; }
       break;
@@ -1965,7 +1994,7 @@ struct Sim {
       if (dot(dir, v1) >= 0) hit = true;
       V3 p41 = sup(sg1, dir), p42 = sup(sg2, -dir), v4 = p41 - p42;
       float dv4 = dot(v4, dir);
-      if (dv4 < 0 && !hit) { MPRSTAT(4, 1); MPRSTAT(7, pf.c_support - mprstat_s0); return; }
+      if (dv4 < 0 && !hit) { MPRSTAT(4, 1); MPRSTAT(7, pf.c_support - mprstat_s0); mpr_store(wout, dir, 1.f); return; }
       float delta = dv4 - dot(v3_, dir);
       if (delta <= tol || it == 127) break;
       V3 t = cross(v4, v0);
@@ -1977,6 +2006,7 @@ struct Sim {
     }
     if (!hit) { MPRSTAT(4, 1); MPRSTAT(7, pf.c_support - mprstat_s0); return; }
     MPRSTAT(5, 1); MPRSTAT(6, pf.c_support - mprstat_s0);
+    mpr_store(wout, v3(0.f, 0.f, 0.f), 0.f);   // in contact: the next run starts cold
     V3 bw;
     V3 cpt = tri_closest_origin(v1, v2, v3_, bw);
     float depth = norm(cpt);
@@ -2081,6 +2111,9 @@ struct Sim {
     SYNC();
     pf.mark(RP_BROAD);
     pf.count(RP_N_CAND, ncand);
+    // warm-start records of the candidates, one per lane, in flight while the first pairs are processed (candidates beyond 64 start cold)
+    v4f wc = {0.f, 0.f, 0.f, 0.f};
+    if (mprc && lane < ncand) { typedef const v4f __attribute__((address_space(1)))* gc4; wc = *(gc4)(mprc + 4 * sm.u.b.cand[lane]); }
     for (int ci = 0; ci < ncand; ci++) {
       phase();
       int p = uni(sm.u.b.cand[ci]);
@@ -2113,7 +2146,10 @@ struct Sim {
         pf.mark(RP_BOXBOX); pf.count(RP_N_BOXBOX, 1);
       } else {
         pf.mark(RP_PLANE);
-        convex_convex(g1, g2, margin, cp);
+        V3 wd = v3(0.f, 0.f, 0.f);
+        bool wh = false;
+        if (mprc && ci < 64) { wd = v3(bcast(wc[0], ci), bcast(wc[1], ci), bcast(wc[2], ci)); wh = bcast(wc[3], ci) != 0.f; }
+        convex_convex(g1, g2, margin, cp, wd, wh, mprc ? mprc + 4 * p : nullptr);
         pf.mark(RP_MPR); pf.count(RP_N_MPR, 1);
       }
       if (pf.pairs && lane == 0) { atomicAdd(pf.pairs + p, 1ull); atomicAdd(pf.pairs + RSIM_PAIR_MAX + p, (unsigned long long)(pf.c_support - sup0)); }
@@ -3633,6 +3669,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   for (int i = lane; i < m.nu; i += 64) sm.ctrl[i] = b.ctrl[(size_t)env * m.nu + i];
   const int cs = m.ctrl.cs_size, csl = cs < RSIM_CS_LDS ? cs : RSIM_CS_LDS;
   sim.cst = (gwf)(b.cstate + (size_t)env * cs);
+  if (b.mprc) sim.mprc = (gwf)(b.mprc + (size_t)env * 4 * m.npair);
   if (lane < csl) sm.cstate[lane] = sim.cst[lane];
   if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; }
   sim.load_opt();
@@ -3739,6 +3776,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
       }
       time = 0.f;
       st = 0;
+      if (sim.mprc) for (int p2 = lane; p2 < m.npair; p2 += 64) sim.mprc[4 * p2 + 3] = 0.f;   // the new episode's narrow phase starts cold, as after a host reset
       if (lane == 0) { b.ep_index[env] = ep; b.needs_reset[env] = 1; }
       SYNC();
       // the patched float-table entries change this env's constant block: the host follows this launch with k_prepare over the envs whose
@@ -3786,9 +3824,10 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
 }
 
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
-__global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
+__global__ RSIM_KSTEP_BOUNDS void RSIM_KSTEP(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
   step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR>(m, b, actions, n_sub, flags);
 }
+#ifndef RSIM_SOLO
 // The reset-observation pass that follows a control step (forward + observables for the envs it re-initialised, no reward): the same body under
 // its own kernel name, so that per-kernel profiles of k_step hold control steps only (and the constant flags strip controller / integrator code)
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
@@ -4006,16 +4045,19 @@ extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out,
 }
 #endif  // RSIM_CFG == 0
 
+#endif  // !RSIM_SOLO (everything between k_step and here)
+
 // explicit instantiations + launchers (one set per configuration build) ----------------------------------------------------------
-template __global__ void k_step<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
+template __global__ void RSIM_KSTEP<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
+extern "C" int RSIM_SYM(rsim_launch_step)(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream) {
+  hipLaunchKernelGGL((RSIM_KSTEP<RSIM_DIMS>), dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
+  return (int)hipGetLastError();
+}
+#ifndef RSIM_SOLO
 template __global__ void k_ctrl_reset<RSIM_DIMS>(DModel, DBatch, const unsigned char*);
 template __global__ void k_prepare<RSIM_DIMS>(DModel, DBatch, int);
 template __global__ void k_reset_obs<RSIM_DIMS>(DModel, DBatch);
 
-extern "C" int RSIM_SYM(rsim_launch_step)(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream) {
-  hipLaunchKernelGGL((k_step<RSIM_DIMS>), dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
-  return (int)hipGetLastError();
-}
 extern "C" int RSIM_SYM(rsim_launch_reset_obs)(const DModel* m, const DBatch* b, hipStream_t stream) {
   hipLaunchKernelGGL((k_reset_obs<RSIM_DIMS>), dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b);
   return (int)hipGetLastError();
@@ -4036,3 +4078,4 @@ extern "C" int RSIM_SYM(rsim_limits)(int* lim) {
   lim[8] = Smem0::NROOT_; lim[9] = (Smem0::TENDONS_ ? 1 : 0) | (Smem0::NB_ > 32 ? 2 : 0);   // bit 1: two OSC arm parts
   return 0;
 }
+#endif  // !RSIM_SOLO

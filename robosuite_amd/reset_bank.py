@@ -169,10 +169,13 @@ class ResetBankMixin:
         t0 = time.perf_counter()
         self._bank_steps += 1
         self._bank_stat["steps"] += 1
-        every = self.bank_poll_steps or max(1, int(getattr(self, "horizon", 0) or 1) // 4)
+        horizon = int(getattr(self, "horizon", 0) or 1)
+        # short episodes (tests: horizons of 2 .. 7 steps with two slots) leave an upkeep thread no slack: they refill from this thread, blocking
+        sync = self.sync_bank or horizon < 32
+        every = self.bank_poll_steps or max(1, horizon // (2 if sync else 4))
         if self._bank_steps >= every:
             self._bank_steps = 0
-            if self.sync_bank:
+            if sync:
                 self.refill_bank()
             else:
                 if getattr(self, "_bank_thread", None) is None:

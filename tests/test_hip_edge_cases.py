@@ -249,3 +249,103 @@ def test_gymnasium_vector_shaped_facade():
     assert not torch.equal(info["final_observation"], obs)                 # obs is the next episode's reset observation
     with pytest.raises(TypeError):
         genv.reset(seed="0")
+
+
+def _lift_assets():
+    import json, os
+    from robosuite_amd import mjcf
+    adir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "robosuite_amd", "assets")
+    return mjcf.load_model(os.path.join(adir, "lift_panda.rsim")), json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
+
+
+def test_asynchronous_ring_upkeep_keeps_every_reset_a_fresh_draw():
+    """The upkeep thread (reset_bank.py: asynchronous poll of the episode counters + pinned-staging refill on a side stream) keeps the ring ahead
+    of the envs without the stepping thread ever reading the device: episode k of env i is still episode_setup(seed, i, k) after several ring
+    revolutions, no reset found a stale slot, and step() spent (next to) no time on the upkeep."""
+    from robosuite_amd import lift
+    flat, cfg = _lift_assets()
+    ids = np.array([2, 9, 300, 2047, 4095])
+    H, E, T = 40, 3, 40 * 7
+    env = lift.LiftBatch(flat, cfg, ids, seed0=5, horizon=H, bank_episodes=E)
+    env.bank_poll_steps = 8
+    acts = torch.tensor(lift.env_actions(ids, T, scale=0.3), device="cuda")
+    for t in range(T):
+        env.step(acts[t])
+        if (t + 1) % H == 0:
+            k = (t + 1) // H
+            env.batch.sync()
+            assert env.batch.get("ep_index").tolist() == [k] * len(ids)
+            sizes, qpos = lift.episode_setup(5, ids, k)
+            assert np.array_equal(env.batch.get("qpos"), qpos.astype(np.float32)), k
+    env.bank_quiesce()
+    st = env.bank_stats()
+    assert int(env.batch.get("bank_stale").sum()) == 0
+    assert st["polls"] >= 7 and st["rows"] >= 7 * len(ids) - len(ids) and env._bank_thread is not None
+    assert st["tick_ms_per_1000_steps"] < 50.0, st       # the stepping thread only counts steps and sets an event
+
+
+def test_reset_after_the_ring_has_moved_on_starts_the_episode_streams_again():
+    """VecEnv.reset() re-installs the ring (round-2 review): after envs have run past their horizon a reset() must put episode 0 back and the
+    next on-device reset must be episode 1 again, not whatever the ring held; a different seed re-keys the streams."""
+    from robosuite_amd import lift
+    flat, cfg = _lift_assets()
+    env = lift.LiftVecEnv(5, seed=2, horizon=3, bank_episodes=2)
+    a = torch.zeros(5, 7, device="cuda")
+    for t in range(3 * 3 + 1):
+        env.step(a)
+    assert env.env.batch.get("ep_index").tolist() == [3] * 5
+    env.reset()
+    q0 = lift.episode_setup(2, np.arange(5), 0)[1].astype(np.float32)
+    assert np.array_equal(env.env.batch.get("qpos"), q0) and env.env.batch.get("ep_index").tolist() == [0] * 5
+    for t in range(3):
+        env.step(a)
+    q1 = lift.episode_setup(2, np.arange(5), 1)[1].astype(np.float32)
+    assert np.array_equal(env.env.batch.get("qpos"), q1)
+    for t in range(3):
+        env.step(a)
+    assert np.array_equal(env.env.batch.get("qpos"), lift.episode_setup(2, np.arange(5), 2)[1].astype(np.float32))
+    assert int(env.env.batch.get("bank_stale").sum()) == 0
+    env.reset(seed=11)
+    assert np.array_equal(env.env.batch.get("qpos"), lift.episode_setup(11, np.arange(5), 0)[1].astype(np.float32))
+    for t in range(3):
+        env.step(a)
+    assert np.array_equal(env.env.batch.get("qpos"), lift.episode_setup(11, np.arange(5), 1)[1].astype(np.float32))
+
+
+def _contact_rich_rollout(B, T, solo=0, warm=True, groups=1):
+    """Lift envs under full-range random actions from step 150 of their episodes (hands on the table: the MPR- and Newton-heavy states)."""
+    import os
+    from robosuite_amd import lift
+    flat, cfg = _lift_assets()
+    ids = np.arange(B)
+    tape = torch.tensor(lift.env_actions(ids, T), device="cuda")
+    if not warm:
+        os.environ["RSIM_NO_MPR_WARMSTART"] = "1"
+    try:
+        env = lift.LiftBatch(flat, cfg, ids, seed0=0, horizon=60, bank_episodes=3)
+    finally:
+        os.environ.pop("RSIM_NO_MPR_WARMSTART", None)
+    env.batch.set_stream_groups(groups)
+    env.batch.set_solo_envs(solo)
+    for t in range(T):
+        env.step(tape[t])
+    env.batch.sync()
+    return {k: env.batch.get(k) for k in ("qpos", "qvel", "obs", "reward", "ep_index", "ep_step", "diverged")}
+
+
+def test_solo_envs_do_not_change_any_result():
+    """rsim_set_solo_envs: the slowest envs of a step run on the one-wavefront-per-SIMD build of the kernel beside the main launch.  Which envs
+    those are depends on timing, so the two builds must produce bit-identical results for every env: checked over 130 contact-rich control
+    steps (episode resets included) with 40 of 512 envs on the solo build."""
+    a, b = _contact_rich_rollout(512, 130, solo=0), _contact_rich_rollout(512, 130, solo=40)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["ep_index"].min() == 2 and a["diverged"].sum() == 0
+
+
+def test_mpr_warm_start_does_not_change_the_contact_set():
+    """The convex narrow phase first tries the separating direction the pair's previous run ended on (rsim_step.hip convex_convex); separation
+    along any direction proves the shapes disjoint, so every contact -- and with it every state -- is what the cold run produces."""
+    a, b = _contact_rich_rollout(384, 130, warm=True), _contact_rich_rollout(384, 130, warm=False)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k

@@ -29,26 +29,7 @@ if "--out" in sys.argv:   # write somewhere else (tests/test_golden_recipe.py re
 os.makedirs(GOLD, exist_ok=True)
 
 
-def controller_cfg(env):
-    """Extract the index tables / gains the native controller needs from the reference objects."""
-    robot = env.robots[0]
-    osc = robot.part_controllers["right"]
-    grip = robot.part_controllers["right_gripper"]
-    sim = env.sim
-    return dict(
-        qpos_idx=[int(i) for i in osc.qpos_index], dof_idx=[int(i) for i in osc.qvel_index],
-        act_idx=[int(i) for i in robot._ref_actuators_indexes_dict["right"]],
-        eef_site=int(sim.model.site_name2id(osc.ref_name)),
-        base_site=int(sim.model.site_name2id(f"{osc.naming_prefix}{osc.part_name}_center")),
-        kp=[float(x) for x in osc.kp], damping_ratio=1.0,
-        input_min=[float(x) for x in osc.input_min], input_max=[float(x) for x in osc.input_max],
-        output_min=[float(x) for x in osc.output_min], output_max=[float(x) for x in osc.output_max],
-        uncouple=int(osc.uncoupling),
-        grip_act=[int(i) for i in robot._ref_actuators_indexes_dict["right_gripper"]],
-        grip_sign=[-1.0, 1.0], grip_speed=float(robot.gripper["right"].speed),
-        grip_qpos_idx=[int(i) for i in robot._ref_gripper_joint_pos_indexes["right"]],
-        grip_dof_idx=[int(i) for i in robot._ref_gripper_joint_vel_indexes["right"]],
-    )
+from robosuite_amd.factory import GRIPPER_SIGNS, controller_cfg, controller_cfg_generic, patch_joint_velocity_defect, pickplace_task_cfg, two_arm_cfg  # noqa: E402,F401  (the extraction helpers live in the package: robosuite_amd.make() uses the same ones)
 
 
 def record_lift_controller(seed, n_steps, action_scale, ctype, impedance_mode="fixed", interpolation=None):
@@ -99,36 +80,6 @@ def record_lift_controller(seed, n_steps, action_scale, ctype, impedance_mode="f
     print(tag, "action_dim", adim, "steps", n_steps, "final cube z", states[-1][1 + 11])
 
 
-def controller_cfg_generic(env, ctype):
-    robot = env.robots[0]
-    ctl = robot.part_controllers["right"]
-    sim = env.sim
-    base = dict(
-        type=ctype,
-        qpos_idx=[int(i) for i in ctl.qpos_index], dof_idx=[int(i) for i in ctl.qvel_index],
-        act_idx=[int(i) for i in robot._ref_actuators_indexes_dict["right"]],
-        eef_site=int(sim.model.site_name2id(ctl.ref_name)),
-        base_site=int(sim.model.site_name2id(f"{ctl.naming_prefix}{ctl.part_name}_center")),
-        input_min=[float(x) for x in ctl.input_min], input_max=[float(x) for x in ctl.input_max],
-        output_min=[float(x) for x in ctl.output_min], output_max=[float(x) for x in ctl.output_max],
-        grip_act=[int(i) for i in robot._ref_actuators_indexes_dict["right_gripper"]],
-        grip_sign=[-1.0, 1.0], grip_speed=float(robot.gripper["right"].speed),
-        grip_qpos_idx=[int(i) for i in robot._ref_gripper_joint_pos_indexes["right"]],
-        grip_dof_idx=[int(i) for i in robot._ref_gripper_joint_vel_indexes["right"]],
-    )
-    if ctype in ("JOINT_POSITION", "OSC_POSITION", "OSC_POSE"):
-        base["kp"] = [float(x) for x in np.atleast_1d(ctl.kp)]   # variable-impedance recordings overwrite this with the constructor value
-        base["kd"] = [float(x) for x in np.atleast_1d(ctl.kd)]
-        base["damping_ratio"] = 1.0
-    if ctype in ("OSC_POSITION", "OSC_POSE"):
-        base["uncouple"] = int(ctl.uncoupling)
-    if ctype == "JOINT_TORQUE":
-        base["torque_limits"] = [[float(x) for x in ctl.torque_limits[0]], [float(x) for x in ctl.torque_limits[1]]]
-    if ctype in ("JOINT_POSITION", "JOINT_TORQUE"):
-        base["use_torque_compensation"] = int(getattr(ctl, "use_torque_compensation", True))
-    return base
-
-
 def record_stack(seed, n_steps, action_scale, tag):
     """BASELINE configs[2] model: Stack / Panda / OSC_POSE (nv = 21, two free cubes).  Same recording as record_lift_controller plus the
     per-substep trajectory of the first env.step (forward-quantity parity cases)."""
@@ -157,33 +108,6 @@ def record_stack(seed, n_steps, action_scale, tag):
     with open(os.path.join(GOLD, f"stack_panda_{tag}.cfg.json"), "w") as f:
         json.dump(cfg, f, indent=1)
     print("stack", tag, "nv", flat.nv, "nbody", flat.nbody, "steps", n_steps, "reward", rewards[-1])
-
-
-def patch_joint_velocity_defect():
-    """JointVelocityController cannot be constructed in the surveyed snapshot: joint_vel.py:118 assigns `self.torque_compensation = ...`
-    although `torque_compensation` is a read-only property of Controller (controller.py:303-311), and run_controller then tests the truth
-    value of that 7-vector (joint_vel.py:186).  SURVEY.md section 8 (config 4) resolves the defect as use_torque_compensation = True.
-    This patch does exactly that and nothing else: the property accepts (and ignores) the assignment and returns qfrc_bias[qvel_index] wrapped
-    in an object whose truth value is True and which adds to an ndarray as a plain ndarray; set_goal / run_controller / RingBuffer / the
-    saturation logic stay the reference's own code."""
-    from robosuite.controllers.parts.generic.joint_vel import JointVelocityController
-
-    class _Compensation:
-        """qfrc_bias[qvel_index] with truth value True; adds to an ndarray as a plain ndarray (so later comparisons keep numpy semantics)."""
-
-        def __init__(self, v):
-            self.v = np.array(v, dtype=np.float64)
-
-        def __bool__(self):
-            return True
-
-        def __array__(self, dtype=None, copy=None):
-            return self.v if dtype is None else self.v.astype(dtype)
-
-    def getter(self):
-        return _Compensation(self.sim.data.qfrc_bias[self.qvel_index])
-
-    JointVelocityController.torque_compensation = property(getter, lambda self, value: None)
 
 
 def record_baxter(seed, n_steps, action_scale, ctype):
@@ -216,45 +140,10 @@ def record_baxter(seed, n_steps, action_scale, ctype):
     np.savez_compressed(os.path.join(GOLD, f"peg_baxter_{tag}.npz"), actions=np.array(actions), states=np.array(states), rewards=np.array(rewards),
                         obs=np.array(obs_flat), ctrl=np.array(ctrls), ncon=np.array(ncon))
     mjcf.save_model(flat, os.path.join(GOLD, f"peg_baxter_{tag}.rsim"))
-    parts = []
-    for arm in robot.arms:
-        ctl = robot.part_controllers[arm]
-        pc = dict(type=ctype, qpos_idx=[int(i) for i in ctl.qpos_index], dof_idx=[int(i) for i in ctl.qvel_index],
-                  act_idx=[int(i) for i in robot._ref_actuators_indexes_dict[arm]], eef_site=0, base_site=0,
-                  input_min=[float(x) for x in ctl.input_min], input_max=[float(x) for x in ctl.input_max],
-                  output_min=[float(x) for x in ctl.output_min], output_max=[float(x) for x in ctl.output_max],
-                  grip_act=[], grip_sign=[], grip_speed=0.0, damping_ratio=1.0)
-        if ctype in ("JOINT_POSITION", "JOINT_VELOCITY"):
-            pc["kp"] = [float(x) for x in np.atleast_1d(ctl.kp)]
-        if ctype in ("OSC_POSE", "OSC_POSITION"):   # one OSC object per arm (Baxter's default), each with its own eef / base ("<arm>_center") sites
-            pc.update(kp=[float(x) for x in np.atleast_1d(ctl.kp)], kd=[float(x) for x in np.atleast_1d(ctl.kd)], uncouple=int(ctl.uncoupling),
-                      eef_site=int(sim.model.site_name2id(ctl.ref_name)),
-                      base_site=int(sim.model.site_name2id(f"{ctl.naming_prefix}{ctl.part_name}_center")))
-        if ctype == "JOINT_VELOCITY" and ctl.velocity_limits is not None:
-            lo, hi = np.broadcast_to(ctl.velocity_limits[0], (len(pc["qpos_idx"]),)), np.broadcast_to(ctl.velocity_limits[1], (len(pc["qpos_idx"]),))
-            pc["velocity_limits"] = [[float(x) for x in lo], [float(x) for x in hi]]
-        if ctype == "JOINT_TORQUE":
-            pc["torque_limits"] = [[float(x) for x in ctl.torque_limits[0]], [float(x) for x in ctl.torque_limits[1]]]
-        parts.append(pc)
-    cat = lambda k: sum((p[k] for p in parts), [])
-    cfg = dict(type=ctype, parts=parts, qpos_idx=cat("qpos_idx"), dof_idx=cat("dof_idx"), act_idx=cat("act_idx"), input_min=cat("input_min"),
-               input_max=cat("input_max"), output_min=cat("output_min"), output_max=cat("output_max"), grip_act=[], grip_sign=[], grip_speed=0.0,
-               damping_ratio=1.0, part_of=sum(([k] * len(p["qpos_idx"]) for k, p in enumerate(parts)), []), obs_keys=keys,
-               obs_dims=[int(np.atleast_1d(obs[k]).size) for k in keys])
-    if ctype in ("JOINT_POSITION", "JOINT_VELOCITY"):
-        cfg["kp"] = cat("kp")
-    if ctype == "JOINT_VELOCITY" and "velocity_limits" in parts[0]:
-        cfg["velocity_limits"] = [sum((p["velocity_limits"][0] for p in parts), []), sum((p["velocity_limits"][1] for p in parts), [])]
-    if ctype == "JOINT_TORQUE":
-        cfg["torque_limits"] = [sum((p["torque_limits"][0] for p in parts), []), sum((p["torque_limits"][1] for p in parts), [])]
+    cfg = two_arm_cfg(env, ctype, keys, obs)
     with open(os.path.join(GOLD, f"peg_baxter_{tag}.cfg.json"), "w") as f:
         json.dump(cfg, f, indent=1)
     print("baxter", tag, "nbody", flat.nbody, "nv", flat.nv, "steps", n_steps, "max ncon", max(ncon), "reward", rewards[-1])
-
-
-# format_action direction tables (panda_gripper.py:55-57, robotiq_140_gripper.py:66-68, robotiq_85_gripper.py:65-67)
-GRIPPER_SIGNS = {"PandaGripper": [-1.0, 1.0], "Robotiq140Gripper": [1.0, -1.0], "Robotiq85Gripper": [1.0, 1.0],
-                 "JacoThreeFingerGripper": [-1.0, -1.0, -1.0]}   # jaco_three_finger_gripper.py:57-71: current_action - speed * sign(action)
 
 
 def record_pickplace(seed, n_steps, action_scale, tag, env_name="PickPlace", stem="pickplace_iiwa"):
@@ -281,23 +170,7 @@ def record_pickplace(seed, n_steps, action_scale, tag, env_name="PickPlace", ste
     mjcf.save_model(flat, os.path.join(GOLD, f"{stem}_{tag}.rsim"))
     cfg = controller_cfg(env)
     cfg["grip_sign"] = GRIPPER_SIGNS[type(env.robots[0].gripper["right"]).__name__]
-    # task constants of PickPlace (pick_place.py:188-199, 560-583): object order, bin geometry, the gripper's finger-pad geom groups
-    g = env.robots[0].gripper["right"]
-    cfg["task"] = dict(objects=[o.name for o in env.objects], object_bodies=[o.root_body for o in env.objects],
-                       object_geoms=[list(o.contact_geoms) for o in env.objects], bin2_pos=[float(x) for x in env.bin2_pos],
-                       bin_size=[float(x) for x in env.bin_size], target_bin_placements=[[float(x) for x in r] for r in env.target_bin_placements],
-                       left_pad=list(g.important_geoms["left_fingerpad"]), right_pad=list(g.important_geoms["right_fingerpad"]),
-                       eef_body=env.robots[0].robot_model.eef_name["right"], grip_site=g.important_sites["grip_site"])
-    if env.single_object_mode:
-        cfg["task"].update(single_object_mode=int(env.single_object_mode), object_id=int(env.object_id))
-    # reset path constants (pick_place.py:431-483, placement_samplers.py:221-309): bin the objects are dropped into, per-object footprint
-    cfg["task"]["placement"] = dict(
-        bin1_pos=[float(x) for x in env.bin1_pos], z_offset=float(env.z_offset), z_rotation=env.z_rotation,
-        x_half=float(env.model.mujoco_arena.table_full_size[0] / 2 - 0.05), y_half=float(env.model.mujoco_arena.table_full_size[1] / 2 - 0.05),
-        objects=[dict(name=o.name, horizontal_radius=float(o.horizontal_radius), bottom_z=float(o.bottom_offset[-1]), top_z=float(o.top_offset[-1]),
-                      qposadr=int(sim.model.get_joint_qpos_addr(o.joints[0])[0])) for o in env.objects],
-        arm_init_qpos=[float(x) for x in env.robots[0].init_qpos], gripper_init_qpos=[float(x) for x in g.init_qpos],
-        arm_qpos_idx=[int(i) for i in env.robots[0]._ref_joint_pos_indexes], gripper_qpos_idx=[int(i) for i in env.robots[0]._ref_gripper_joint_pos_indexes["right"]])
+    cfg["task"] = pickplace_task_cfg(env)
     cfg["obs_keys"] = keys
     cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in keys]
     with open(os.path.join(GOLD, f"{stem}_{tag}.cfg.json"), "w") as f:

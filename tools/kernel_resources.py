@@ -53,8 +53,18 @@ def kernels(lib=None):
     return res
 
 
+def residency(r):
+    """One-wavefront workgroups per CU: (by LDS, by registers, the smaller of the two and the 32-wave cap).  Registers: the unified VGPR + AGPR file
+    is allocated in granules of 8 per lane, 512 per SIMD, four SIMDs per CU (MI355X_MICROARCH.md, register files); `vgpr` of the notes is the total."""
+    by_lds = 163840 // r["lds"] if r["lds"] else 32
+    alloc = -(-max(1, r["vgpr"]) // 8) * 8
+    by_reg = 4 * min(8, 512 // alloc)
+    return by_lds, by_reg, min(by_lds, by_reg, 32)
+
+
 if __name__ == "__main__":
     ks = kernels(sys.argv[1] if len(sys.argv) > 1 else None)
     for name, r in sorted(ks.items()):
-        print(f"{name[:70]:70s} LDS {r['lds']:6d} B  scratch {r['scratch']:4d} B  VGPR {r['vgpr']:3d} AGPR {r['agpr']:3d} SGPR {r['sgpr']:3d}"
-              f"  -> {min(4, 163840 // max(1, r['lds'])) if r['lds'] else '-'} workgroups / CU by LDS")
+        bl, br, n = residency(r)
+        print(f"{name[:70]:70s} LDS {r['lds']:6d} B  scratch {r['scratch']:4d} B  VGPR+AGPR {r['vgpr']:3d} (AGPR {r['agpr']:3d}) SGPR {r['sgpr']:3d}"
+              f"  -> workgroups / CU: {bl} by LDS, {br} by registers = {n}")

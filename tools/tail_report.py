@@ -12,7 +12,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 adir = os.path.join(ROOT, "robosuite_amd", "assets")
 flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim")); cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
 tape = torch.tensor(lift.env_actions(np.arange(B), nskip + 1), device="cuda")
-MPR_SLOTS = ("x0 exit pre-test", "x1 exit 1st support", "x2 exit 2nd support", "x3 exit portal discovery", "x4 exit refinement", "x5 contact", "x6 supports of contacts", "x7 supports of late exits")
+MPR_SLOTS = ("x0 exit pre-test", "x1 exit 1st support", "x2 exit 2nd support", "x3 exit portal discovery", "x4 exit refinement", "x5 contact", "x6 supports of contacts", "x7 supports of late exits", "x8 exit warm start")
 
 
 def run(filter_env):
@@ -41,7 +41,7 @@ for i in order[:10]: print(f"  env {i}: {dur[i]:.0f}  {cnt[i].tolist()}")
 _, pa, _ = run(-1)
 ns = max(1, pa["n_sub"])
 print("whole batch, per env-substep:", {k[2:]: round(pa[k] / ns, 3) for k in pa if k.startswith("n_") and k != "n_sub"})
-xs = {MPR_SLOTS[i]: round(pa[f"x{i}"] / ns, 3) for i in range(8) if pa[f"x{i}"]}
+xs = {MPR_SLOTS[i]: round(pa[f"x{i}"] / ns, 3) for i in range(9) if pa[f"x{i}"]}
 if xs: print("whole batch MPR outcomes per env-substep:", xs)
 for which, e in (("slowest", int(order[0])), ("p99", int(order[B // 100])), ("median", int(order[B // 2]))):
     w2, p, _ = run(e)
@@ -50,5 +50,5 @@ for which, e in (("slowest", int(order[0])), ("p99", int(order[B // 100])), ("me
     print(f"{which} env {e} ({dur[e]:.0f} us): ticks/substep total {sum(cyc.values())}:", cyc)
     print("    narrow split: boxbox %d mpr %d other %d | per substep:" % (p["boxbox"] / nsub, p["mpr"] / nsub, p["plane"] / nsub),
           {k[2:]: round(p[k] / nsub, 2) for k in p if k.startswith("n_") and k != "n_sub"})
-    xs = {MPR_SLOTS[i]: round(p[f"x{i}"] / nsub, 2) for i in range(8) if p[f"x{i}"]}
+    xs = {MPR_SLOTS[i]: round(p[f"x{i}"] / nsub, 2) for i in range(9) if p[f"x{i}"]}
     if xs: print("    MPR outcomes per substep:", xs)
