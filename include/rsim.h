@@ -223,6 +223,11 @@ int rsim_step(rsim_batch* b);
  * n_sub x { step1; control(action, policy_step = first); step2 } in ONE launch.  `actions_dev` is a DEVICE pointer
  * to [B, action_dim] float32 (action_dim = control_dim(type) + (ngrip>0); rsim_model_int(m, "action_dim")). */
 int rsim_control_step(rsim_batch* b, const float* actions_dev, int n_sub);
+/* CompositeController.run_controller() alone (composite_controller.py:109-116 -> osc.py:403-495, joint_pos.py:238-266, joint_vel.py:129-209,
+ * simple_grip.py:150-186; the clip into ctrl: fixed_base_robot.py:143-153): mj_step1-equivalent position / velocity stage on the current state, then ONE
+ * evaluation of the part controllers from RSIM_CSTATE as it stands (goals, initial joints, gripper action, PID state) -- no set_goal, no actuation, no
+ * integration.  Results: RSIM_CTRL and the torque slots of RSIM_CSTATE (un-clipped tau, layout at enum rsim_field). */
+int rsim_run_controller(rsim_batch* b);
 /* Robot.reset's controller re-creation (robots/robot.py:271 -> controller.py:125-131, osc.py:520-532):
  * forward kinematics, initial_joint := q, goal := current eef pose, gripper action := 0 */
 int rsim_ctrl_reset(rsim_batch* b, const uint8_t* host_mask);

@@ -183,7 +183,7 @@ def lib():
         L.rsim_refill_reset_bank_async.argtypes = [vp, C.c_int, vp, vp, vp]
         L.rsim_bank_flush.argtypes = [vp]
         L.rsim_param_offset.argtypes = [vp, C.c_char_p, C.c_int]
-        for f in ("rsim_forward", "rsim_step1", "rsim_step2", "rsim_step", "rsim_sync", "rsim_observe"):
+        for f in ("rsim_forward", "rsim_step1", "rsim_step2", "rsim_step", "rsim_sync", "rsim_observe", "rsim_run_controller"):
             getattr(L, f).argtypes = [vp]
         L.rsim_control_step.argtypes = [vp, vp, C.c_int]
         L.rsim_ctrl_reset.argtypes = [vp, C.c_char_p]
@@ -361,6 +361,10 @@ class HipBatch:
     def sync(self):
         _chk(self._L.rsim_sync(self.ptr))
 
+    def run_controller(self):
+        """One evaluation of the in-kernel part controllers on the current state and controller state (include/rsim.h rsim_run_controller)."""
+        _chk(self._L.rsim_run_controller(self.ptr))
+
     def observe(self):
         """forward() + observation / reward epilogue without advancing time (the observation `env.reset()` returns)."""
         _chk(self._L.rsim_observe(self.ptr))
@@ -440,16 +444,38 @@ class HipBatch:
             if tuple(actions.shape) != (self.B, adim):
                 raise RsimError(f"actions must have shape ({self.B}, {adim}) = (n_envs, action_dim), got {tuple(actions.shape)}")
             actions = actions.contiguous().float()
-            # The step reads `actions` on the batch's own stream(s) after this call has returned (include/rsim.h: the buffer must stay untouched until
-            # the groups join).  Tell torch's caching allocator so: a tensor the caller drops right away is not handed out again before the work
-            # queued on those streams has run -- whatever stream the caller allocates from, however far an env block lags behind.
-            for s_ in self._step_streams():
-                actions.record_stream(s_)
+            self._hold(actions)
             ptr = actions.data_ptr()
         _chk(self._L.rsim_control_step(self.ptr, C.c_void_p(ptr), int(n_sub)))
 
     def stream(self):
         return self._L.rsim_stream(self.ptr)
+
+    def _hold(self, actions):
+        """The step reads `actions` on the batch's own stream(s) after control_step() has returned (include/rsim.h: the buffer must stay untouched
+        until the step has run), and an env block of a stream group may lag many steps behind.  Keep a reference to every tensor until the streams
+        have passed a marker recorded after it (one set of events every 32 steps), so that a tensor the caller drops right away is not handed out
+        again by torch's caching allocator while a step still reads it -- whatever stream the caller allocates from.  (Tensor.record_stream would say
+        the same to the allocator, but then the allocator touches the batch's streams when the tensor is freed, possibly after the batch is gone.)"""
+        import collections
+
+        import torch
+
+        if not hasattr(self, "_held"):
+            self._held, self._marks, self._nstep = collections.deque(), collections.deque(), 0
+        self._nstep += 1
+        self._held.append((self._nstep, actions))
+        if self._nstep % 32 == 0:
+            evs = []
+            for s_ in self._step_streams():
+                e = torch.cuda.Event()
+                e.record(s_)
+                evs.append(e)
+            self._marks.append((self._nstep, evs))
+        while self._marks and all(e.query() for e in self._marks[0][1]):
+            n, _ = self._marks.popleft()
+            while self._held and self._held[0][0] <= n:
+                self._held.popleft()
 
     def _step_streams(self):
         """torch views of the HIP streams control steps run on (the main stream, or one per env block with stream groups); cached per group count."""

@@ -743,6 +743,9 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.ls_iterations = 50; dm.cone = m->I("cone") ? m->I("cone")[0] : 1; dm.solver = 1;
   dm.tolerance = m->D("tolerance") ? (float)m->D("tolerance")[0] : 1e-8f;
   dm.meaninertia = m->meaninertia;
+  dm.newton_ns = getenv("RSIM_NEWTON_NS") ? (float)atof(getenv("RSIM_NEWTON_NS")) : RSIM_NEWTON_NS;
+  dm.newton_na = getenv("RSIM_NEWTON_NA") ? (float)atof(getenv("RSIM_NEWTON_NA")) : RSIM_NEWTON_NA;
+  dm.newton_ng = getenv("RSIM_NEWTON_NG") ? (float)atof(getenv("RSIM_NEWTON_NG")) : RSIM_NEWTON_NG;
   if (m->multijoint) { int r = fail("rsim_batch_create: bodies with more than one joint are not supported by the fused kernel"); delete b; return r; }
 
   if (m->maxcondim > 4) { int r = fail("rsim_batch_create: condim %d contacts are not supported by the compiled kernel configuration (max 4)", m->maxcondim); delete b; return r; }
@@ -1015,17 +1018,21 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
       HIPCHK(hipEventCreateWithFlags(&b->sev0, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&b->sev1, hipEventDisableTiming));
     }
+    // The solo launch goes on the batch's own stream, straight behind the dispatch-order kernel; the main launch goes on the side stream behind an
+    // event recorded BEFORE the solo launch, and so reaches the dispatcher a cross-queue signal later than the solo workgroups.  The other way
+    // round the main kernel won that race, filled every SIMD with two wavefronts, kept refilling freed slots from its 2000 pending workgroups, and
+    // the solo workgroups (which need a SIMD with nothing on it) ran only after it had drained: 5.1 ms per step instead of 3.75 (profiles/r03_b).
     HIPCHK(hipEventRecord(b->sev0, b->stream));   // the dispatch order (and whatever the caller queued before this step)
     HIPCHK(hipStreamWaitEvent(b->sstream, b->sev0, 0));
     DBatch ds = b->db;
     ds.nenv = nsolo; ds.env0 = 0;
-    e = rsim_launch_step_cfg0s(&b->dm, &ds, actions, n_sub, flags, b->sstream);
+    e = rsim_launch_step_cfg0s(&b->dm, &ds, actions, n_sub, flags, b->stream);
     if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-    HIPCHK(hipEventRecord(b->sev1, b->sstream));
     DBatch dr = b->db;
     dr.order = b->db.order + nsolo; dr.nenv = b->B - nsolo; dr.env0 = 0;
-    e = k_step_launch[b->cfg](&b->dm, &dr, actions, n_sub, flags, b->stream);
+    e = k_step_launch[b->cfg](&b->dm, &dr, actions, n_sub, flags, b->sstream);
     if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    HIPCHK(hipEventRecord(b->sev1, b->sstream));
     HIPCHK(hipStreamWaitEvent(b->stream, b->sev1, 0));
   } else {
     e = k_step_launch[b->cfg](&b->dm, &b->db, actions, n_sub, flags, b->stream);
@@ -1058,6 +1065,10 @@ extern "C" int rsim_control_step(rsim_batch* b, const float* actions_dev, int n_
   if (!actions_dev) return fail("rsim_control_step: actions_dev is NULL");
   return launch(b, actions_dev, n_sub, RF_POSVEL | RF_CTRL | RF_SETGOAL | RF_ACTSOLVE | RF_INTEGRATE | (b->m->has_task ? RF_OBS : 0) | RF_EPISODE);
 }
+// CompositeController.run_controller() between step1 and step2 (composite_controller.py:109-116, fixed_base_robot.py:143-153): the position /
+// velocity stage, then ONE evaluation of the in-kernel part controllers from the controller state as it stands -- no set_goal, no integration.
+// Writes RSIM_CTRL (clipped) and the torque slots of RSIM_CSTATE: the door the parity tests pin the in-kernel control laws through.
+extern "C" int rsim_run_controller(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL | RF_CTRL | RF_DEBUG); }
 extern "C" int rsim_observe(rsim_batch* b) {
   if (!b->m->has_task) return fail("rsim_observe: no task configured");
   return launch(b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_OBS | RF_DEBUG);

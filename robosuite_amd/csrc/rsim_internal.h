@@ -130,6 +130,7 @@ struct DModel {
   int ntendon, neq;   // fixed tendons, equality/tendon constraints
   int iterations, ls_iterations, cone, solver;
   float tolerance, meaninertia;
+  float newton_ns, newton_na, newton_ng;   // fp32 stopping rules of the Newton solver (solve_newton): relative / absolute step floor, gradient noise factor
   const int* it;
   const float* ft;
   const float* ft0;            // shared copy of the float table (read for every field no env has overridden)
@@ -182,6 +183,13 @@ struct DBatch {
   // order[] (indices relative to env0) -- while the arrays above stay those of the whole batch; nenv = 0: all B envs
   int env0, nenv;
 };
+
+// Newton solver, fp32 stopping rules (0 = rule off; experiments: RSIM_NEWTON_NS / _NA / _NG in the environment when the batch is created)
+#ifndef RSIM_NEWTON_NS
+#define RSIM_NEWTON_NS 0.f
+#define RSIM_NEWTON_NA 0.f
+#define RSIM_NEWTON_NG 0.f
+#endif
 
 // profile slots (cycles of s_memtime summed over envs and substeps, then event counters)
 enum { RP_LOAD, RP_KIN, RP_COM, RP_CRB, RP_BROAD, RP_NARROW, RP_MAKEC, RP_VEL, RP_CTRL, RP_ACT, RP_SOLVE, RP_EULER, RP_STORE,

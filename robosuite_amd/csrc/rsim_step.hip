@@ -3293,6 +3293,11 @@ struct Sim {
       const float gn = wave_sum(dofl ? gk * gk : 0.f);
       SUBMARK(RP_X2);
       if (iter >= m.iterations || scale * sqrtf(gn) < tolerance) break;
+      // fp32: the gradient is a difference of O(100) N m terms, good to ~1e-7 of THEIR size -- MuJoCo's 1e-8 (scaled) is below that floor for every
+      // loaded arm, so the fp64 test above never fires here and the loop used to run until a step happened not to lower the (equally noisy) cost:
+      // 150-230 iterations per control step where the fp64 oracle takes 25-80 on the same states (tools/newton_iters.py), half the run time of the
+      // slowest envs of a launch.  A gradient whose every component is within the rounding noise of its own three terms is converged.
+      if (m.newton_ng > 0.f && !__ballot(dofl && rr < nv && fabsf(gk) > m.newton_ng * (fabsf(ma) + fabsf(f_sm) + fabsf(jf)))) break;
       // ---- Hessian weights W (row r): D J_r (quadratic), 0 (linear / satisfied), cone block Hc J_block
 #pragma unroll
       for (int s = 0; s < NSLOT; s++) {
@@ -3446,9 +3451,13 @@ struct Sim {
       }
       SUBMARK(RP_X6);
       if (!(p < p0)) break;
-      a = fmaf(alpha, sk, a);
+      const float a_new = fmaf(alpha, sk, a);
+      // fp32: a step that moves no component of the acceleration by more than a few units in its last place (plus an absolute floor) cannot be
+      // improved on by another factorisation
+      const bool settled = m.newton_ns > 0.f && !__ballot(dofl && rr < nv && fabsf(alpha * sk) > m.newton_ns * fabsf(a_new) + m.newton_na);
+      a = a_new;
       iter++;
-      if (scale * (p0 - p) < tolerance) {
+      if (scale * (p0 - p) < tolerance || settled) {
         evaluate(a);
         break;
       }

@@ -31,6 +31,110 @@ def test_osc_kernel_matches_reference_python_controller(tag):
     assert np.abs(out[:, :7] - g["tau"][idx]).max() < 2e-4 * max(1.0, np.abs(g["tau"][idx]).max())
 
 
+CALL_FIXTURES = (("lift_panda", "seed0_gentle"), ("lift_panda", "seed1_full"), ("lift_panda", "ctl_osc_position"), ("lift_panda", "ctl_osc_pose_variable"),
+                 ("lift_panda", "ctl_osc_pose_variable_kp"), ("lift_panda", "ctl_joint_position"), ("lift_panda", "ctl_joint_position_variable"),
+                 ("lift_panda", "ctl_joint_torque"), ("peg_baxter", "ctl_osc_pose"), ("peg_baxter", "ctl_joint_position"), ("peg_baxter", "ctl_joint_torque"),
+                 ("peg_baxter", "ctl_joint_velocity"))
+
+
+@pytest.mark.parametrize("model,tag", CALL_FIXTURES)
+def test_in_kernel_controllers_match_the_reference_classes_call_by_call(model, tag):
+    """The control laws the FUSED kernel runs (ctrl_run_osc<ARM>, ctrl_run_joint; not the standalone k_osc_eval), pinned open loop through the
+    front door: for every recorded call of the reference's own part controllers (tools/gen_golden.py hook_part_controllers: the state the
+    controller read, its goals / initial joints / gains / PID state before the call, the torques it returned) the same state and controller state
+    are written into a batch env, rsim_run_controller evaluates the controllers ONCE, and the torque slots of RSIM_CSTATE are compared.  Nothing
+    integrates, so nothing drifts: OSC_POSE / OSC_POSITION / both variable-impedance layouts / both Baxter arms at 2e-4 of the largest torque,
+    the joint-space laws likewise, JOINT_VELOCITY at its DEFAULT gains (kp = 3 x the torque range: the closed loop chatters after three control
+    steps, the law itself does not) on the clipped torques the reference returns."""
+    g, cfg, flat = load_golden(tag, model)
+    two = "parts" in cfg
+    ctype = cfg.get("type", "OSC_POSE")
+    osc = ctype.startswith("OSC")
+    arms = ("right", "left") if two else ("right",)
+    lift_fixture = tag.startswith("seed")                      # the two primary Lift fixtures use the older array names
+    n = len(g["sub_qpos"])
+    idx = np.arange(0, n, 3)
+    B = len(idx)
+    hm, hb = make_hip(flat, cfg, B=B)
+    cs = hm.cstate_size
+    rows = np.zeros((B, cs), dtype=np.float32)
+    na = [len(p["qpos_idx"]) for p in cfg["parts"]] if two else [len(cfg["qpos_idx"])]
+    off = 0
+    for a, arm in enumerate(arms):
+        key = (lambda k: k) if lift_fixture else (lambda k, arm=arm: f"sub_{k}_{arm}")
+        if osc:
+            base = 32 * a
+            rows[:, base:base + 3] = g[key("goal_pos")][idx]
+            rows[:, base + 3:base + 12] = g[key("goal_ori")][idx].reshape(B, 9)
+            rows[:, base + 12:base + 12 + na[a]] = g[key("q0")][idx]
+            if cfg.get("impedance_mode", "fixed") != "fixed":
+                rows[:, 96:102] = g[key("kp")][idx]; rows[:, 112:118] = g[key("kd")][idx]
+        else:
+            rows[:, off:off + na[a]] = g[key("goal")][idx]
+            if ctype == "JOINT_POSITION" and cfg.get("impedance_mode", "fixed") != "fixed":
+                rows[:, 96 + off:96 + off + na[a]] = g[key("kp")][idx]; rows[:, 112 + off:112 + off + na[a]] = g[key("kd")][idx]
+            if ctype == "JOINT_VELOCITY":
+                rows[:, 48 + off:48 + off + na[a]] = g[key("last_err")][idx]
+                rows[:, 64 + off:64 + off + na[a]] = g[key("summed_err")][idx]
+                for r in range(5):
+                    rows[:, 80 + 16 * r + off:80 + 16 * r + off + na[a]] = g[key("ring")][idx][:, r]
+                # one ring pointer / fill count for the whole block: the two arms' controllers are called in lockstep
+                rows[:, 160] = g[key("ring_ptr")][idx]; rows[:, 161] = g[key("ring_size")][idx]
+                rows[:, 164 + a] = g[key("saturated")][idx]
+        off += na[a]
+    hb.set("qpos", g["sub_qpos"][idx]); hb.set("qvel", g["sub_qvel"][idx]); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.set("cstate", rows)
+    hb.run_controller()
+    out = hb.get("cstate")
+    ctrl = hb.get("ctrl")
+    assert int(hb.get("diverged").sum()) == 0
+    off = 0
+    worst = 0.0
+    for a, arm in enumerate(arms):
+        ref = g["tau" if lift_fixture else f"sub_tau_{arm}"][idx]
+        if ctype == "JOINT_VELOCITY":
+            got = ctrl[:, [cfg["parts"][a]["act_idx"][k] for k in range(na[a])]]          # the reference returns the clipped torques (joint_vel.py:200-203)
+        elif osc:
+            got = out[:, 32 * a + 24:32 * a + 24 + na[a]]
+        else:
+            got = out[:, 32 + off:32 + off + na[a]]
+        err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+        worst = max(worst, err)
+        assert err < 2e-4, (arm, err, np.unravel_index(np.abs(got - ref).argmax(), ref.shape))
+        off += na[a]
+    print(f"{model} {tag}: {B} calls, worst relative torque error {worst:.2e}")
+
+
+def test_osc_at_the_pandas_worst_conditioned_configurations():
+    """Where the reference pseudo-inverts (np.linalg.pinv of J M^-1 J^T, its position and orientation blocks: utils/control_utils.py:74-76) the
+    kernel solves with Cholesky factors of the same matrices (ctrl_run_osc; pivots floored at 1e-20, so nothing is ever NaN).  The two agree as
+    long as the matrices have full rank to working precision.  tests/golden/lift_panda_singular (tools/gen_golden.py --singular-only) samples the
+    Panda where its Jacobian is worst: elbow against its limit, wrist axes aligned, arm straight up, elbow exactly straight PAST the limit, plus
+    random configurations -- the 7-dof arm with its joint offsets and rotor armatures never gets J_pos M^-1 J_pos^T above cond 1.2e3, the full
+    6 x 6 matrix (nullspace projector only, with the default uncoupled law) reaches 9e5.  Asserted: finite torques everywhere, 2e-4 of the
+    largest torque wherever cond < 2e4, 5e-3 up to 1e6 (fp32: cond x 1e-7 on the nullspace term), no env put back by the bad-state guard."""
+    g, cfg, flat = load_golden("singular")
+    n = len(g["tau"])
+    hm, hb = make_hip(flat, cfg, B=n)
+    rows = np.zeros((n, hm.cstate_size), dtype=np.float32)
+    rows[:, 0:3] = g["goal_pos"]; rows[:, 3:12] = g["goal_ori"].reshape(n, 9); rows[:, 12:19] = g["q0"]
+    hb.set("qpos", g["qpos"]); hb.set("qvel", g["qvel"]); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0); hb.set("cstate", rows)
+    hb.run_controller()
+    tau = hb.get("cstate")[:, 24:31]
+    assert np.isfinite(tau).all() and np.isfinite(hb.get("ctrl")).all() and int(hb.get("diverged").sum()) == 0
+    err = np.abs(tau - g["tau"]).max(axis=1) / np.maximum(1.0, np.abs(g["tau"]).max(axis=1))
+    cond = np.maximum(g["cond_full"], np.maximum(g["cond_pos"], g["cond_ori"]))
+    for lo, hi in ((0, 2e4), (2e4, 1e6)):
+        m = (cond >= lo) & (cond < hi)
+        if m.any():
+            print(f"cond in [{lo:.0e}, {hi:.0e}): {int(m.sum())} samples, worst relative torque error {err[m].max():.2e}")
+    assert err[cond < 2e4].max() < 2e-4 and err.max() < 5e-3, (err.max(), cond[err.argmax()])
+    # the clipped commands (what reaches the actuators, fixed_base_robot.py:149-153) of every sample
+    lim = np.asarray(flat.actuator_ctrlrange)[cfg["act_idx"]]
+    ref_ctrl = np.clip(g["tau"], lim[:, 0], lim[:, 1])
+    assert np.abs(hb.get("ctrl")[:, cfg["act_idx"]] - ref_ctrl).max() < 5e-3 * np.abs(lim).max()
+
+
 @pytest.mark.parametrize("tag", TAGS)
 def test_forward_quantities_match_oracle(tag):
     g, cfg, flat = load_golden(tag)

@@ -417,3 +417,71 @@ def test_scripted_grasp_lifts_the_cube():
     cube = flat.names["geom"].index("cube_g0")
     touching = {c["geom1"] if c["geom2"] == cube else c["geom2"] for c in od.contacts() if cube in (c["geom1"], c["geom2"])}
     assert pads <= touching                               # held by both finger pads (ManipulationEnv._check_grasp)
+
+
+def _documented_impedance(solimp, r):
+    """d(r) of MuJoCo's documentation (Computation > Soft constraints > solimp = d0, dwidth, width, midpoint, power), written from the text:
+    x = |r| / width; y(x) = a x^p for x <= midpoint, 1 - b (1 - x)^p above, a = 1 / midpoint^(p-1), b = 1 / (1 - midpoint)^(p-1); d = d0 + y (dwidth - d0)."""
+    d0, dw, width, mid, p = solimp
+    x = min(1.0, abs(r) / width)
+    if x >= 1.0:
+        return dw
+    y = x if p == 1 else (x ** p / mid ** (p - 1) if x <= mid else 1.0 - (1.0 - x) ** p / (1.0 - mid) ** (p - 1))
+    return d0 + y * (dw - d0)
+
+
+@pytest.mark.parametrize("solimp,depth", (((0.9, 0.95, 0.001, 0.5, 2.0), 0.0005), ((0.9, 0.95, 0.001, 0.5, 2.0), 0.0002), ((0.9, 0.95, 0.001, 0.5, 2.0), 0.0008),
+                                          ((0.8, 0.99, 0.002, 0.3, 3.0), 0.0011), ((0.9, 0.95, 0.001, 0.5, 1.0), 0.0004), ((0.9, 0.95, 0.001, 0.5, 2.0), 0.003)))
+def test_documented_constraint_model_known_answers(solimp, depth):
+    """The soft-constraint quantities the solver consumes, against MuJoCo's DOCUMENTED formulas evaluated by hand here (no simulator involved; these
+    were only exercised end to end before).  A cube pushed `depth` into the table while moving down at 0.1 m/s:
+      impedance d(r) from solimp; solref = (timeconst, dampratio) -> b = 2 / (dmax timeconst), k = d(r) / (dmax^2 timeconst^2 dampratio^2);
+      reference acceleration aref = -b v - k r;  regulariser R = (1 - d) / d x diagApprox, D = 1 / R, diagApprox of a contact's normal row =
+      translational inverse weights of the two bodies (1 / m for a free body, 0 for the world); the friction rows of an elliptic cone carry
+      R / impratio (impratio = 20, models/assets/base.xml:4).
+    Also a joint friction-loss row (r = 0: d = d0, aref = -b qd) and a violated joint limit (finger slide 1 mm below its range)."""
+    g, cfg, flat = load_golden("seed0_gentle")
+    f2 = flat.copy()
+    cube, table = flat.name2id("geom", "cube_g0"), flat.name2id("geom", "table_collision")
+    solref = (0.02, 1.0)
+    for gg in (cube, table):
+        f2.arrays["geom_solref"][gg] = solref; f2.arrays["geom_solimp"][gg] = solimp
+    om, od, _ = make_oracle(f2)
+    q = g["states"][0][1:1 + flat.nq].copy()
+    half = flat.geom_size[cube]
+    q[12:16] = (1, 0, 0, 0)
+    q[11] = 0.8 + half[2] - depth                    # table top at z = 0.8 (lift.py:153): the four bottom corners are `depth` inside
+    q[7] = -0.001                                    # finger_joint1 (range [0, 0.04]) one millimetre past its lower limit
+    v = np.zeros(flat.nv); v[11] = -0.1; v[3] = 0.7; v[7] = -0.02
+    od.qpos[:] = q; od.qvel[:] = v; od.forward()
+    types = od.efc_types()
+    R, D, aref, pos = np.array(od.efc_R), np.array(od.efc_D), np.array(od.efc_aref), np.array(od.efc_pos)
+    # ---- contact rows: four corner contacts, condim 3, elliptic: rows (normal, tangent, tangent) per contact
+    con = [c for c in od.contacts() if {c["geom1"], c["geom2"]} == {cube, table}]
+    assert len(con) == 4 and all(c["dim"] == 3 for c in con)
+    mass = 1000.0 * 8 * half[0] * half[1] * half[2]
+    d = _documented_impedance(solimp, depth)
+    dmax = solimp[1]
+    b, k = 2.0 / (dmax * solref[0]), d / (dmax ** 2 * solref[0] ** 2 * solref[1] ** 2)
+    for c in con:
+        r0 = c["efc_address"]
+        assert types[r0] == 3 and pos[r0] == pytest.approx(-depth, abs=1e-12)
+        Rn = (1.0 - d) / d * (1.0 / mass)
+        assert R[r0] == pytest.approx(Rn, rel=1e-9) and D[r0] == pytest.approx(1.0 / Rn, rel=1e-9)
+        assert aref[r0] == pytest.approx(-b * (-0.1) - k * (-depth), rel=1e-9)
+        assert R[r0 + 1] == pytest.approx(Rn / 20.0, rel=1e-9) and R[r0 + 2] == pytest.approx(Rn / 20.0, rel=1e-9)
+    # ---- friction-loss row of arm joint 4 (dof 3): r = 0 -> d = d0 of the dof's solimp, aref = -b qd
+    fr = [i for i, t in enumerate(types) if t == 0]
+    assert len(fr) == 9
+    ds, dr = flat.dof_solimp[3], flat.dof_solref[3]
+    d0 = _documented_impedance(ds, 0.0)
+    assert R[fr[3]] == pytest.approx((1 - d0) / d0 * flat.dof_invweight0[3], rel=1e-9)
+    assert aref[fr[3]] == pytest.approx(-2.0 / (ds[1] * max(dr[0], 2 * 0.002)) * 0.7, rel=1e-9)
+    # ---- the violated lower limit of the finger slide: r = q - lower = -1 mm, J = +1
+    lim = [i for i, t in enumerate(types) if t == 1]
+    assert len(lim) == 1 and pos[lim[0]] == pytest.approx(-0.001, abs=1e-12)
+    js, jr = flat.jnt_solimp[7], flat.jnt_solref[7]
+    dl = _documented_impedance(js, 0.001)
+    tc = max(jr[0], 2 * 0.002)
+    assert R[lim[0]] == pytest.approx((1 - dl) / dl * flat.dof_invweight0[7], rel=1e-9)
+    assert aref[lim[0]] == pytest.approx(-2.0 / (js[1] * tc) * (-0.02) - dl / (js[1] ** 2 * tc ** 2 * jr[1] ** 2) * (-0.001), rel=1e-9)

@@ -32,6 +32,42 @@ os.makedirs(GOLD, exist_ok=True)
 from robosuite_amd.factory import GRIPPER_SIGNS, controller_cfg, controller_cfg_generic, patch_joint_velocity_defect, pickplace_task_cfg, two_arm_cfg  # noqa: E402,F401  (the extraction helpers live in the package: robosuite_amd.make() uses the same ones)
 
 
+
+def hook_part_controllers(env):
+    """Record what every arm part controller is handed and what it returns, per call of run_controller() (= once per substep and arm): the state it
+    reads (`sub_qpos`, `sub_qvel`, once per substep), its own internal state BEFORE the call (goals, initial joints, gains in force, PID state) and
+    the torques it returns.  All of it is the reference's own Python; the HIP test sets the same state and controller state, calls rsim_run_controller
+    once and compares (tests/test_hip_parity.py::test_in_kernel_controllers_match_the_reference_classes_call_by_call)."""
+    sim, robot = env.sim, env.robots[0]
+    rec = {"sub_qpos": [], "sub_qvel": []}
+    first = robot.arms[0]
+    for arm in robot.arms:
+        ctl = robot.part_controllers[arm]
+        orig = ctl.run_controller
+
+        def wrapped(ctl=ctl, arm=arm, orig=orig):
+            def put(k, v):
+                rec.setdefault(f"sub_{k}_{arm}", []).append(np.array(v, dtype=np.float64))
+            if arm == first:
+                rec["sub_qpos"].append(np.array(sim.data.qpos)); rec["sub_qvel"].append(np.array(sim.data.qvel))
+            name = ctl.name
+            if name.startswith("OSC"):
+                put("goal_pos", ctl.goal_pos); put("goal_ori", ctl.goal_ori); put("q0", ctl.initial_joint); put("kp", ctl.kp); put("kd", ctl.kd)
+            elif name == "JOINT_POSITION":
+                put("goal", ctl.goal_qpos if ctl.goal_qpos is not None else ctl.joint_pos); put("kp", ctl.kp); put("kd", ctl.kd)
+            elif name == "JOINT_TORQUE":
+                put("goal", ctl.goal_torque if ctl.goal_torque is not None else np.zeros(ctl.joint_dim))
+            elif name == "JOINT_VELOCITY":
+                put("goal", ctl.goal_vel if ctl.goal_vel is not None else np.zeros(ctl.joint_dim)); put("last_err", ctl.last_err); put("summed_err", ctl.summed_err)
+                put("ring", ctl.derr_buf.buf); put("ring_ptr", ctl.derr_buf.ptr); put("ring_size", ctl.derr_buf._size); put("saturated", float(ctl.saturated))
+            tau = orig()
+            put("tau", tau)
+            return tau
+
+        ctl.run_controller = wrapped
+    return rec
+
+
 def record_lift_controller(seed, n_steps, action_scale, ctype, impedance_mode="fixed", interpolation=None):
     """Env-level fixture for another arm part-controller type (JOINT_POSITION / JOINT_TORQUE / OSC_POSITION): the reference's own
     controller classes drive the env; only states / ctrl / obs / rewards are recorded (the controller is pinned end to end)."""
@@ -47,6 +83,7 @@ def record_lift_controller(seed, n_steps, action_scale, ctype, impedance_mode="f
     obs = env.reset()
     sim, robot = env.sim, env.robots[0]
     ctl = robot.part_controllers["right"]
+    sub = hook_part_controllers(env) if interpolation is None else {}   # per-call controller I/O (the interpolators' ramp state is not recorded)
     flat = sim.model._model._flat
     adim = env.action_dim
     rng = np.random.default_rng(10**6 + seed)
@@ -60,7 +97,8 @@ def record_lift_controller(seed, n_steps, action_scale, ctype, impedance_mode="f
         obs_flat.append(np.concatenate([np.atleast_1d(obs[k]).astype(np.float64) for k in keys if not k.endswith("-state")]))
     tag = f"ctl_{ctype.lower()}" + ("" if impedance_mode == "fixed" else f"_{impedance_mode}") + ("" if interpolation is None else f"_{interpolation}")
     np.savez_compressed(os.path.join(GOLD, f"lift_panda_{tag}.npz"), actions=np.array(actions), states=np.array(states), rewards=np.array(rewards),
-                        obs=np.array(obs_flat), ctrl=np.array(ctrls), cube_size=flat.geom_size[flat.name2id("geom", "cube_g0")])
+                        obs=np.array(obs_flat), ctrl=np.array(ctrls), cube_size=flat.geom_size[flat.name2id("geom", "cube_g0")],
+                        **{k: np.array(v) for k, v in sub.items()})
     mjcf.save_model(flat, os.path.join(GOLD, f"lift_panda_{tag}.rsim"))
     cfg = controller_cfg_generic(env, ctype)
     if impedance_mode != "fixed":
@@ -127,6 +165,7 @@ def record_baxter(seed, n_steps, action_scale, ctype):
                      control_freq=20, horizon=500, ignore_done=True, seed=seed)
     obs = env.reset()
     sim, robot = env.sim, env.robots[0]
+    sub = hook_part_controllers(env)
     flat = sim.model._model._flat
     rng = np.random.default_rng(10**6 + seed)
     keys = [k for k in obs.keys() if not k.endswith("-state")]
@@ -138,7 +177,7 @@ def record_baxter(seed, n_steps, action_scale, ctype):
         obs_flat.append(np.concatenate([np.atleast_1d(obs[k]).astype(np.float64) for k in keys]))
     tag = f"ctl_{ctype.lower()}"
     np.savez_compressed(os.path.join(GOLD, f"peg_baxter_{tag}.npz"), actions=np.array(actions), states=np.array(states), rewards=np.array(rewards),
-                        obs=np.array(obs_flat), ctrl=np.array(ctrls), ncon=np.array(ncon))
+                        obs=np.array(obs_flat), ctrl=np.array(ctrls), ncon=np.array(ncon), **{k: np.array(v) for k, v in sub.items()})
     mjcf.save_model(flat, os.path.join(GOLD, f"peg_baxter_{tag}.rsim"))
     cfg = two_arm_cfg(env, ctype, keys, obs)
     with open(os.path.join(GOLD, f"peg_baxter_{tag}.cfg.json"), "w") as f:
@@ -292,7 +331,62 @@ def record_lift(seed, n_steps, action_scale, tag):
     print(tag, "steps", n_steps, "substeps recorded", len(out["tau"]), "final cube z", states[-1][1 + 11])
 
 
+def record_lift_singular(seed=0):
+    """OSC_POSE at and around the Panda's kinematic singularities (elbow stretched against its limit, wrist axes aligned, shoulder over the base),
+    where J M^-1 J^T loses rank and the reference's `np.linalg.pinv` (utils/control_utils.py:74-76, rcond 1e-15) is all that stands between the
+    controller and a division by ~0.  For each hand-made arm configuration: state, goal, the torques the reference's OperationalSpaceController
+    returns, and the condition numbers of the three matrices it pseudo-inverts.  No dynamics involved beyond forward()."""
+    env = suite.make("Lift", robots="Panda", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
+                     reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed)
+    env.reset()
+    sim, robot = env.sim, env.robots[0]
+    osc = robot.part_controllers["right"]
+    flat = sim.model._model._flat
+    rng = np.random.default_rng(77)
+    lo, hi = flat.jnt_range[:7, 0], flat.jnt_range[:7, 1]
+    base = np.array(robot.init_qpos)
+    cases = []
+    for eps in (0.0, 1e-6, 1e-4, 1e-3, 1e-2, 3e-2, 0.1, 0.3):
+        q = base.copy(); q[3] = hi[3] - eps; q[1] = 0.3; cases.append(("elbow stretched", q))                     # joint 4 at its upper limit (-0.07): arm nearly straight
+        q = base.copy(); q[5] = max(lo[5], 0.0) + eps; cases.append(("wrist aligned", q))                          # joint 6 -> 0: axes of joints 5 and 7 line up
+        q = base.copy(); q[1] = eps; q[3] = hi[3] - eps; q[5] = max(lo[5], 0.0) + eps; cases.append(("straight up", q))   # everything aligned over the base
+    for _ in range(12):
+        q = lo + (hi - lo) * rng.uniform(0.02, 0.98, 7); cases.append(("random", q))
+    # beyond the joint limits (the controller never asks): the elbow exactly straight, where J_pos M^-1 J_pos^T is rank deficient and pinv truncates
+    for eps in (0.0, 1e-7, 1e-5, 1e-3, 1e-2):
+        q = base.copy(); q[3] = -eps; q[1] = 0.4; q[5] = 1.0; cases.append(("elbow straight (past the limit)", q))
+    rec = {k: [] for k in ("qpos", "qvel", "goal_pos", "goal_ori", "q0", "tau", "cond_full", "cond_pos", "cond_ori", "action")}
+    names = []
+    for name, q in cases:
+        for trial in range(2):
+            sim.data.qpos[:7] = q
+            sim.data.qvel[:] = 0.0 if trial == 0 else 0.3 * rng.standard_normal(flat.nv) * (np.arange(flat.nv) < 7)
+            sim.forward()
+            osc.update(force=True)
+            osc.update_initial_joints(np.array(base))
+            osc.reset_goal()
+            a = rng.uniform(-1, 1, 6)
+            osc.set_goal(a)
+            tau = osc.run_controller()
+            Minv = np.linalg.inv(osc.mass_matrix)
+            cf = np.linalg.cond(osc.J_full @ Minv @ osc.J_full.T); cp = np.linalg.cond(osc.J_pos @ Minv @ osc.J_pos.T); co = np.linalg.cond(osc.J_ori @ Minv @ osc.J_ori.T)
+            for k, v in (("qpos", sim.data.qpos), ("qvel", sim.data.qvel), ("goal_pos", osc.goal_pos), ("goal_ori", osc.goal_ori), ("q0", osc.initial_joint),
+                         ("tau", tau), ("cond_full", cf), ("cond_pos", cp), ("cond_ori", co), ("action", a)):
+                rec[k].append(np.array(v, dtype=np.float64))
+            names.append(name)
+    np.savez_compressed(os.path.join(GOLD, "lift_panda_singular.npz"), case=np.array(names), **{k: np.array(v) for k, v in rec.items()})
+    mjcf.save_model(flat, os.path.join(GOLD, "lift_panda_singular.rsim"))
+    cfg = controller_cfg(env)
+    with open(os.path.join(GOLD, "lift_panda_singular.cfg.json"), "w") as f:
+        json.dump(cfg, f, indent=1)
+    c = np.array(rec["cond_pos"])
+    print("singular", len(names), "samples; cond(J_pos M^-1 J_pos^T) min %.1e median %.1e max %.1e; |tau| max %.1e" % (c.min(), np.median(c), c.max(), np.abs(np.array(rec["tau"])).max()))
+
+
 if __name__ == "__main__":
+    if "--singular-only" in sys.argv:
+        record_lift_singular()
+        sys.exit(0)
     if "--pickplace-single-only" in sys.argv:   # single-object mode 2 (pick_place.py:840-847): the can only; seed 2 = both reset paths
         record_pickplace(seed=2, n_steps=20, action_scale=1.0, tag="seed2_full", env_name="PickPlaceCan", stem="pickplace_can_iiwa")
         sys.exit(0)

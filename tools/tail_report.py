@@ -51,4 +51,5 @@ for which, e in (("slowest", int(order[0])), ("p99", int(order[B // 100])), ("me
     print("    narrow split: boxbox %d mpr %d other %d | per substep:" % (p["boxbox"] / nsub, p["mpr"] / nsub, p["plane"] / nsub),
           {k[2:]: round(p[k] / nsub, 2) for k in p if k.startswith("n_") and k != "n_sub"})
     xs = {MPR_SLOTS[i]: round(p[f"x{i}"] / nsub, 2) for i in range(9) if p[f"x{i}"]}
-    if xs: print("    MPR outcomes per substep:", xs)
+    if xs and os.environ.get("RSIM_XSLOTS") != "ticks": print("    MPR outcomes per substep:", xs)
+    if os.environ.get("RSIM_XSLOTS") == "ticks": print("    sub-phase ticks/substep (x0..x9 of a -DRSIM_SUBPROF build):", {f"x{i}": int(p[f"x{i}"] / nsub) for i in range(10) if p[f"x{i}"]})
