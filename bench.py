@@ -20,9 +20,6 @@ o_i = (197 i) mod 500 and `--preroll` (default: the horizon) untimed launches ar
 from the ring) and then sits o_i genuine steps into its second episode.  Every timed launch then sees the steady-state mix of an RL rollout,
 including the ~B/500 on-device episode resets per launch and the asynchronous upkeep of the reset ring (`config.reset_ring`).
 
-Solo envs (`--solo`, default B / 32).  A launch lasts as long as its slowest env; the envs that were slowest in the previous step run on a build
-of the same kernel that keeps their SIMD to themselves, launched beside the main kernel (include/rsim.h rsim_set_solo_envs).  Bit-identical results.
-
 Prints ONE JSON line on rank 0.  See DESIGN.md section 6 for the roofline / cpu_baseline definitions.
 """
 import argparse
@@ -154,7 +151,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phase", choices=("staggered", "fresh"), default="staggered", help="episode phase of the envs when the timed region starts (module docstring)")
     ap.add_argument("--preroll", type=int, default=-1, help="untimed launches before the warm-up in the staggered phase (default: the horizon)")
-    ap.add_argument("--solo", type=int, default=-1, help="envs per step on the one-wavefront-per-SIMD build (rsim_set_solo_envs); default B / 32 for lift, 0 otherwise")
     ap.add_argument("--groups", type=int, default=16, help="env blocks on their own HIP streams for the secondary open-loop figure; 1 = skip it")
     ap.add_argument("--no-open-loop", action="store_true", help="skip the second timed region (the same K steps with stream groups)")
     args = ap.parse_args()
@@ -190,8 +186,6 @@ def main():
     env = build_env(args.config, flat, cfg, ids, local_rank, 3 + (P + W + K + K2) // HORIZON)
     adim = env.model.action_dim
     tape = torch.tensor(lift.env_actions(ids, P + K + W + K2, action_dim=adim), device=dev)  # whole action tape resident in HBM
-    nsolo = args.solo if args.solo >= 0 else (B // 32 if args.config == "lift" else 0)
-    env.batch.set_solo_envs(nsolo)
     dr_step = [0]
 
     def step(t):
@@ -228,7 +222,7 @@ def main():
 
     # ---- the headline region: one control step of all envs at a time, events on the stream the fused kernel is launched on
     dt, evms = timed(W, K, [torch.cuda.ExternalStream(env.batch.stream(), device=dev)])
-    kern_ms = float(np.mean(evms))   # one control step of all B envs: dispatch order + k_step (+ the solo launch beside it) + reset passes
+    kern_ms = float(np.mean(evms))   # one control step of all B envs: dispatch order + k_step + reset passes
     ring1 = env.bank_stats()
     if os.environ.get("RSIM_BENCH_TRACE"):
         print("per-step ms:", " ".join(f"{r[0]:.2f}" for r in evms), file=sys.stderr)
@@ -282,7 +276,7 @@ def main():
             "config": {"workload": f"{label}, 25 substeps x dt 0.002 + controllers per substep, fused in one launch per env (BASELINE {which})",
                        "envs_per_gpu": B, "global_envs": B * world, "n_sub": N_SUB, "per_env_seeded_reset": True, "horizon": HORIZON, "on_device_auto_reset": True,
                        "protocol": "lockstep: one control step of all envs per call, the next starts when all have finished (closed-loop compatible)",
-                       "solo_envs": nsolo, "open_loop": open_loop, "dynamics_randomisation": "re-drawn before every control step" if dr else None,
+                       "open_loop": open_loop, "dynamics_randomisation": "re-drawn before every control step" if dr else None,
                        "episode_phase": (f"uniform over the horizon: step counters offset by (197 i) mod 500, then {P} untimed pre-roll launches" if P else "fresh: all envs at step W of their first episode"),
                        "reset_ring": {"bank_stale": int(bank_stale), "polls_in_region": ring1["polls"] - ring0["polls"], "rows_refilled_in_region": ring1["rows"] - ring0["rows"],
                                       "stepping_thread_ms_per_1000_steps": 1e6 * (ring1["tick_s"] - ring0["tick_s"]) / dsteps,

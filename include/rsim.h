@@ -278,12 +278,6 @@ int rsim_set_schedule(rsim_batch* b, int longest_first);
  * that reads or writes batch state first wait for all groups; the actions buffer of a step must stay untouched until then.  1 = one launch
  * on the batch's stream (default).  groups <= 32 and <= the batch size. */
 int rsim_set_stream_groups(rsim_batch* b, int groups);
-/* Solo envs of rsim_control_step (no reference counterpart; results do not depend on it).  A launch lasts as long as its slowest env, and a wavefront
- * that has its SIMD to itself runs ~1.4x faster than one that shares it with a second env.  With n > 0 the n envs that took longest in the previous
- * control step are stepped by a second build of the same kernel whose register allocation leaves no room for another wavefront on the SIMD, launched
- * beside the regular kernel on a stream of its own; the other B - n envs run two per SIMD as before.  Costs ~n of the chip's 2048 wavefront slots.
- * Applies to one-launch-per-step batches (stream groups = 1) of kernel configuration 0; 0 = off (default).  n is clamped to B / 2. */
-int rsim_set_solo_envs(rsim_batch* b, int n);
 void* rsim_group_stream(rsim_batch* b, int group);   /* hipStream_t the control steps of env block `group` run on (for event timing) */
 
 /* Per-phase cycle accounting of the fused kernel (no reference counterpart: the reference has no profiling).
@@ -335,10 +329,6 @@ typedef struct rsim_dr_desc {
 int rsim_dr_save_defaults(rsim_batch* b);
 int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uint64_t seed, uint64_t step);
 
-/* Standalone OSC torque law on explicit inputs (unit-test entry for OperationalSpaceController.run_controller,
- * osc.py:403-495).  in: HOST float32 [B,192] packed as ep3 eR9 ev6 op3 oR9 bv6 goal_pos3 goal_ori9 J[6x8] M[8x8] bias8 q8 qd8 q0_8;
- * out: HOST float32 [B,8] pre-clip torques. */
-int rsim_osc_eval(const rsim_ctrl_desc* desc, const float* in, float* out, int B, int device);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,10 @@ def lib():
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [vp]
         L.rso_contact_get.argtypes = [vp, C.c_int, dp]
+        L.rso_cost.restype = C.c_double
+        L.rso_cost.argtypes = [vp, dp, dp]
+        L.rso_forward_with_contact_geometry.restype = C.c_int
+        L.rso_forward_with_contact_geometry.argtypes = [vp, C.c_int, dp]
         L.rso_efc_type.restype = C.c_int
         L.rso_efc_type.argtypes = [vp, C.c_int]
         L.rso_ctrl_create.restype = vp
@@ -133,6 +137,21 @@ class OracleData:
 
     def step(self):
         self._L.rso_step(self.ptr)
+
+    def cost(self, qacc, with_gradient=False):
+        """The constraint solver's objective (and optionally its gradient) at acceleration `qacc`, for the rows of the last forward()."""
+        a = np.ascontiguousarray(qacc, dtype=np.float64)
+        g = np.zeros(self.nv)
+        c = self._L.rso_cost(self.ptr, _dp(a), _dp(g) if with_gradient else None)
+        return (c, g) if with_gradient else c
+
+    def forward_with_contact_geometry(self, contacts) -> bool:
+        """forward() with dist / pos / frame of every contact taken from `contacts` (dicts as returned by contacts(), e.g. the HIP batch's list of the
+        same state; the list must have the oracle's own length and order).  True if the geometry was applied."""
+        geo = np.zeros((len(contacts), 13))
+        for i, c in enumerate(contacts):
+            geo[i, 0], geo[i, 1:4], geo[i, 4:13] = c["dist"], c["pos"], np.asarray(c["frame"]).ravel()
+        return self._L.rso_forward_with_contact_geometry(self.ptr, len(contacts), _dp(np.ascontiguousarray(geo))) == 0
 
     def jac(self, kind, idx):
         jp = np.zeros((3, self.nv))

@@ -1713,6 +1713,52 @@ static void fwd_velocity(rso_data *d) {
 void rso_step1(rso_data *d) { fwd_position(d); fwd_velocity(d); }
 void rso_step2(rso_data *d) { fwd_actuation(d); fwd_acceleration(d); fwd_constraint(d); euler(d); }
 void rso_forward(rso_data *d) { fwd_position(d); fwd_velocity(d); fwd_actuation(d); fwd_acceleration(d); fwd_constraint(d); }
+/* The solver's own objective at an acceleration `a` of the caller's, for the constraint rows of the last forward():
+ *   cost(a) = 1/2 (a - a_smooth)' M (a - a_smooth) + sum_i s_i(J a - aref), and (if grad != NULL) its gradient M a - qfrc_smooth - J' f(a).
+ * Test infrastructure: two accelerations are compared in the metric the solver minimises -- the minimiser is unique, but where the Hessian is nearly
+ * flat (a 1e-4 kg m^2 object under stiff contacts) accelerations far apart have costs equal to working precision. */
+double rso_cost(rso_data *d, const double *a, double *grad) {
+  rso_model *m = d->m;
+  const int nv = m->nv, n = d->nefc;
+  double *jar = (double *)malloc(sizeof(double) * (n ? n : 1)), *f = (double *)malloc(sizeof(double) * (n ? n : 1));
+  int *state = (int *)malloc(sizeof(int) * (n ? n : 1));
+  for (int i = 0; i < n; i++) {
+    double sj = 0;
+    for (int k = 0; k < nv; k++) sj += d->efc_J[(size_t)i * nv + k] * a[k];
+    jar[i] = sj - d->efc_aref[i];
+  }
+  double cost = constraint_update(d, jar, f, state, NULL);
+  for (int i = 0; i < nv; i++) {
+    double ma = 0;
+    for (int k = 0; k < nv; k++) ma += d->qM[(size_t)i * nv + k] * a[k];
+    cost += 0.5 * (ma - d->qfrc_smooth[i]) * (a[i] - d->qacc_smooth[i]);
+    if (grad) {
+      double g = ma - d->qfrc_smooth[i];
+      for (int r = 0; r < n; r++) g -= d->efc_J[(size_t)r * nv + i] * f[r];
+      grad[i] = g;
+    }
+  }
+  free(jar); free(f); free(state);
+  return cost;
+}
+
+/* forward() with the contact GEOMETRY given by the caller: the collision pass runs as usual (pairs, dimensions, mixed friction / solref / solimp),
+ * then contact i takes dist = geo[13 i], pos = geo[13 i + 1 .. 3], frame = geo[13 i + 4 .. 12] before the constraint rows are built.  Test
+ * infrastructure for the solver / dynamics half of a parity check: fed the kernel's own contact list, everything downstream of the narrow phase is
+ * compared on identical inputs (the narrow phases themselves are compared separately).  n must equal the oracle's own contact count; returns 0 on
+ * success, -1 (and leaves the plain forward() result) otherwise. */
+int rso_forward_with_contact_geometry(rso_data *d, int n, const double *geo) {
+  kinematics(d); com_pos(d); crb(d); collision(d);
+  if (n != d->ncon) { make_constraint(d); fwd_velocity(d); fwd_actuation(d); fwd_acceleration(d); fwd_constraint(d); return -1; }
+  for (int i = 0; i < n; i++) {
+    rso_contact *c = &d->contact[i];
+    c->dist = geo[13 * i];
+    memcpy(c->pos, geo + 13 * i + 1, 3 * sizeof(double));
+    memcpy(c->frame, geo + 13 * i + 4, 9 * sizeof(double));
+  }
+  make_constraint(d); fwd_velocity(d); fwd_actuation(d); fwd_acceleration(d); fwd_constraint(d);
+  return 0;
+}
 void rso_step(rso_data *d) { rso_step1(d); rso_step2(d); }
 
 /* mj_jacSite (utils/binding_utils.py:826-851): jacp, jacr 3 x nv row-major, either may be NULL */

@@ -202,10 +202,8 @@ def lib():
         L.rsim_pairlog.argtypes = [vp, vp]
         L.rsim_set_schedule.argtypes = [vp, C.c_int]
         L.rsim_set_stream_groups.argtypes = [vp, C.c_int]
-        L.rsim_set_solo_envs.argtypes = [vp, C.c_int]
         L.rsim_group_stream.restype = vp; L.rsim_group_stream.argtypes = [vp, C.c_int]
         L.rsim_profile_env.argtypes = [vp, C.c_int]
-        L.rsim_osc_eval.argtypes = [C.POINTER(CtrlDesc), vp, vp, C.c_int, C.c_int]
         _LIB = L
     return _LIB
 
@@ -510,10 +508,6 @@ class HipBatch:
         _chk(self._L.rsim_set_stream_groups(self.ptr, int(groups)))
         self._ngroups = int(groups)
 
-    def set_solo_envs(self, n: int):
-        """The n slowest envs of the previous step get a SIMD to themselves in the next one (include/rsim.h rsim_set_solo_envs).  Same results; 0 = off."""
-        _chk(self._L.rsim_set_solo_envs(self.ptr, int(n)))
-
     def group_stream(self, g: int):
         return self._L.rsim_group_stream(self.ptr, int(g))
 
@@ -561,24 +555,3 @@ class HipBatch:
                 self._L.rsim_batch_free(self.ptr)
         except Exception:
             pass
-
-
-def osc_eval(cfg: dict, packed: np.ndarray, device=0) -> np.ndarray:
-    """Batched OSC torque law on explicit inputs ([B,192] float32, layout in include/rsim.h) -> [B,8] torques."""
-    d = ctrl_desc(cfg)
-    a = np.ascontiguousarray(packed, dtype=np.float32)
-    out = np.zeros((a.shape[0], 8), dtype=np.float32)
-    _chk(lib().rsim_osc_eval(C.byref(d), a.ctypes.data, out.ctypes.data, a.shape[0], device))
-    return out
-
-
-def pack_osc_inputs(ep, eR, ev, op, oR, bv, goal_pos, goal_ori, J, M, bias, q, qd, q0):
-    """Pack one sample into the 192-float record of rsim_osc_eval."""
-    n = len(q)
-    r = np.zeros(192, dtype=np.float32)
-    r[0:3], r[3:12], r[12:18], r[18:21], r[21:30], r[30:36], r[36:39], r[39:48] = ep, np.ravel(eR), ev, op, np.ravel(oR), bv, goal_pos, np.ravel(goal_ori)
-    Jp = np.zeros((6, 8)); Jp[:, :n] = J
-    Mp = np.zeros((8, 8)); Mp[:n, :n] = M
-    r[48:96], r[96:160] = Jp.ravel(), Mp.ravel()
-    r[160:160 + n], r[168:168 + n], r[176:176 + n], r[184:184 + n] = bias, q, qd, q0
-    return r

@@ -59,8 +59,6 @@ typedef int (*cmem_fn)(void);
 static const prepare_fn k_prepare_launch[RSIM_NCFG] = {rsim_launch_prepare_cfg0, rsim_launch_prepare_cfg1, rsim_launch_prepare_cfg2, rsim_launch_prepare_cfg3, rsim_launch_prepare_cfg4};
 static const cmem_fn k_cmem_bytes[RSIM_NCFG] = {rsim_cmem_bytes_cfg0, rsim_cmem_bytes_cfg1, rsim_cmem_bytes_cfg2, rsim_cmem_bytes_cfg3, rsim_cmem_bytes_cfg4};
 static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1, rsim_limits_cfg2, rsim_limits_cfg3, rsim_limits_cfg4};
-extern "C" int rsim_launch_step_cfg0s(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream);   // one wavefront per SIMD
-extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream);
 extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStream_t stream);
 extern "C" int rsim_launch_bank_scatter(float* bank, int* tag, const int* env, const int* episode, const float* rows, int n, int E, int W, hipStream_t stream);
 extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr* d, unsigned long long seed, unsigned long long step, hipStream_t stream);
@@ -142,15 +140,20 @@ struct rsim_batch {
   int cm_dirty;       // a model parameter / the controller changed since the blocks were built
   DCtrl cm_ctrl;      // controller the blocks were built for
   int have_cost;      // d_cost holds the costs of a previous control step
+  // one-launch-per-step batches: the dispatch order of step t + 1 is sorted from the costs of step t - 1 on a side stream WHILE step t runs (envs that are
+  // slow stay slow for hundreds of steps, so costs one step old order as well), which takes the sort and its two kernel boundaries off the critical
+  // path of a control step.  Double-buffered: step t reads order2[t & 1], writes cost2[t & 1]; the sort beside it reads cost2[(t - 1) & 1], writes order2[(t + 1) & 1].
+  int* d_order2[2];
+  unsigned* d_cost2[2];
+  hipStream_t ostream;
+  hipEvent_t step_done[2], ord_done[2];
+  int ord_valid[2];   // order2[k] holds a dispatch order (its event has been recorded)
+  long nstep;         // one-launch control steps issued since the schedule was (re)started
   int schedule;       // 1 = reorder before every control step (default), 0 = identity order
   // stream groups: control steps of env block g run on gstream[g]; `forked` = the group streams hold work the main stream has not waited for
   int groups, ngroups, forked;   // streams created, groups in use (1 = everything on the main stream)
   hipStream_t gstream[RSIM_MAX_GROUPS];
   hipEvent_t gev[RSIM_MAX_GROUPS], mev;
-  // solo envs (rsim_set_solo_envs): the slowest envs of the previous step run on the one-wavefront-per-SIMD build of the kernel, on a stream of their own
-  int solo_n;
-  hipStream_t sstream;
-  hipEvent_t sev0, sev1;
   // asynchronous reset-bank upkeep (rsim_bank_poll_begin / _poll / rsim_refill_reset_bank_async): a side stream of its own, pinned staging
   hipStream_t bstream;
   hipEvent_t bev;
@@ -698,7 +701,6 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   b->gen = 1; b->cache_gen = 0; b->cache_env = -1;
   b->db.prof_env = -1;
   b->d_bank = nullptr; b->d_bank_tag = nullptr; b->d_patch = nullptr; b->d_ft_base = nullptr;
-  b->solo_n = 0; b->sstream = nullptr; b->sev0 = nullptr; b->sev1 = nullptr;
   b->bstream = nullptr; b->bev = nullptr; b->h_epidx = nullptr; b->bank_poll_pending = 0; b->bstage_next = 0;
   memset(b->bstage, 0, sizeof(b->bstage));
   const int ncg = (int)m->cg.size();
@@ -731,6 +733,11 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   b->d_order = nullptr; b->d_cost = nullptr; b->schedule = 1; b->have_cost = 0;
   if (dalloc(&b->d_order, (size_t)B)) return 1;
   if (dalloc(&b->d_cost, (size_t)B)) return 1;
+  b->ostream = nullptr; b->nstep = 0;
+  for (int k = 0; k < 2; k++) {
+    b->d_order2[k] = nullptr; b->d_cost2[k] = nullptr; b->step_done[k] = nullptr; b->ord_done[k] = nullptr; b->ord_valid[k] = 0;
+    if (dalloc(&b->d_order2[k], (size_t)B) || dalloc(&b->d_cost2[k], (size_t)B)) return 1;
+  }
   if (dalloc(&b->db.needs_reset, (size_t)B)) return 1;
   b->db.mprc = nullptr;
   if (!getenv("RSIM_NO_MPR_WARMSTART") && m->npair > 0 && dalloc(&b->db.mprc, (size_t)B * m->npair * 4)) return 1;
@@ -814,8 +821,12 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_ft0); if (b->d_obsprog) hipFree(b->d_obsprog);
   if (b->d_bank) hipFree(b->d_bank); if (b->d_bank_tag) hipFree(b->d_bank_tag); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); if (b->d_ft_base) hipFree(b->d_ft_base); hipFree(b->d_mesh); hipFree(b->d_mask);
   if (b->d_order) hipFree(b->d_order); if (b->d_cost) hipFree(b->d_cost);
+  if (b->ostream) { hipStreamSynchronize(b->ostream); hipStreamDestroy(b->ostream); }
+  for (int k = 0; k < 2; k++) {
+    if (b->d_order2[k]) hipFree(b->d_order2[k]); if (b->d_cost2[k]) hipFree(b->d_cost2[k]);
+    if (b->step_done[k]) hipEventDestroy(b->step_done[k]); if (b->ord_done[k]) hipEventDestroy(b->ord_done[k]);
+  }
   if (b->db.prof) hipFree(b->db.prof);
-  if (b->sstream) { hipStreamSynchronize(b->sstream); hipStreamDestroy(b->sstream); hipEventDestroy(b->sev0); hipEventDestroy(b->sev1); }
   if (b->bstream) { hipStreamSynchronize(b->bstream); hipStreamDestroy(b->bstream); }
   if (b->bev) hipEventDestroy(b->bev);
   if (b->h_epidx) hipHostFree(b->h_epidx);
@@ -913,12 +924,6 @@ extern "C" int rsim_set_stream_groups(rsim_batch* b, int groups) {
   return 0;
 }
 
-extern "C" int rsim_set_solo_envs(rsim_batch* b, int n) {
-  if (n < 0) return fail("rsim_set_solo_envs: n < 0");
-  b->solo_n = n;
-  return 0;
-}
-
 // The controller may be re-configured on the model after the batch exists (gains, limits, even the type), but the per-env controller
 // state buffer was sized when the batch was created: the kernels stride it by b->cs, so a controller that needs more state than that
 // is refused instead of running past the end of the buffer.
@@ -994,49 +999,28 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
     b->gen++;
     return 0;
   }
-  if ((flags & RF_EPISODE) && b->schedule && b->d_order) {   // control steps only: forward()/step1()/step2() launches are one substep long
-    if (b->have_cost) {
-      int eo = rsim_launch_order(b->d_cost, b->d_order, b->B, b->stream);
-      if (eo) return fail("dispatch-order kernel launch failed: %s", hipGetErrorString((hipError_t)eo));
-      b->db.order = b->d_order;
+  const bool sched1 = (flags & RF_EPISODE) && b->schedule && b->d_order;   // control steps only: forward()/step1()/step2() launches are one substep long
+  const int cur = (int)(b->nstep & 1), prev = cur ^ 1;
+  if (sched1) {
+    if (!b->ostream) {
+      HIPCHK(hipStreamCreateWithFlags(&b->ostream, hipStreamNonBlocking));
+      for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&b->step_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b->ord_done[k], hipEventDisableTiming)); }
     }
-    b->db.cost = b->d_cost;
-    b->have_cost = 1;
+    if (b->ord_valid[cur]) { HIPCHK(hipStreamWaitEvent(b->stream, b->ord_done[cur], 0)); b->db.order = b->d_order2[cur]; }
+    b->db.cost = b->d_cost2[cur];
   }
-  int e;
-  const int nsolo = ((flags & RF_EPISODE) && b->cfg == 0 && b->db.order) ? (b->solo_n < b->B / 2 ? b->solo_n : b->B / 2) : 0;
-  if (nsolo > 0) {
-    // Two launches side by side: the first `nsolo` entries of the dispatch order (the envs that took longest in the previous step) on the build of the
-    // kernel that leaves no room for a second wavefront on its SIMD, the rest on the regular one.  The solo launch goes first: each of its
-    // workgroups needs a SIMD with nothing on it.  Same per-env arithmetic in both builds (tests/test_hip_edge_cases.py checks bitwise equality).
-    if (!b->sstream) {
-      hipDeviceProp_t prop;
-      HIPCHK(hipGetDeviceProperties(&prop, b->device));
-      const uint32_t words = (uint32_t)((prop.multiProcessorCount + 31) / 32);
-      std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
-      if (hipExtStreamCreateWithCUMask(&b->sstream, words, mask.data()) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamCreate(&b->sstream)); }   // CU mask = a hardware queue of its own
-      HIPCHK(hipEventCreateWithFlags(&b->sev0, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&b->sev1, hipEventDisableTiming));
+  int e = k_step_launch[b->cfg](&b->dm, &b->db, actions, n_sub, flags, b->stream);
+  if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (sched1) {
+    HIPCHK(hipEventRecord(b->step_done[cur], b->stream));
+    if (b->nstep >= 1) {   // beside the step just launched: sort the costs of the PREVIOUS step into the order of the NEXT one
+      HIPCHK(hipStreamWaitEvent(b->ostream, b->step_done[prev], 0));
+      int eo = rsim_launch_order(b->d_cost2[prev], b->d_order2[prev], b->B, b->ostream);   // order2[(t + 1) & 1] == order2[prev]
+      if (eo) return fail("dispatch-order kernel launch failed: %s", hipGetErrorString((hipError_t)eo));
+      HIPCHK(hipEventRecord(b->ord_done[prev], b->ostream));
+      b->ord_valid[prev] = 1;
     }
-    // The solo launch goes on the batch's own stream, straight behind the dispatch-order kernel; the main launch goes on the side stream behind an
-    // event recorded BEFORE the solo launch, and so reaches the dispatcher a cross-queue signal later than the solo workgroups.  The other way
-    // round the main kernel won that race, filled every SIMD with two wavefronts, kept refilling freed slots from its 2000 pending workgroups, and
-    // the solo workgroups (which need a SIMD with nothing on it) ran only after it had drained: 5.1 ms per step instead of 3.75 (profiles/r03_b).
-    HIPCHK(hipEventRecord(b->sev0, b->stream));   // the dispatch order (and whatever the caller queued before this step)
-    HIPCHK(hipStreamWaitEvent(b->sstream, b->sev0, 0));
-    DBatch ds = b->db;
-    ds.nenv = nsolo; ds.env0 = 0;
-    e = rsim_launch_step_cfg0s(&b->dm, &ds, actions, n_sub, flags, b->stream);
-    if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-    DBatch dr = b->db;
-    dr.order = b->db.order + nsolo; dr.nenv = b->B - nsolo; dr.env0 = 0;
-    e = k_step_launch[b->cfg](&b->dm, &dr, actions, n_sub, flags, b->sstream);
-    if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-    HIPCHK(hipEventRecord(b->sev1, b->sstream));
-    HIPCHK(hipStreamWaitEvent(b->stream, b->sev1, 0));
-  } else {
-    e = k_step_launch[b->cfg](&b->dm, &b->db, actions, n_sub, flags, b->stream);
-    if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    b->nstep++;
   }
   if ((flags & RF_EPISODE) && b->db.bank && b->db.horizon > 0) {
     if (b->db.bank_P > 0 && b->db.cm_stride) {
@@ -1287,7 +1271,12 @@ extern "C" int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, 
   return 0;
 }
 
-extern "C" int rsim_set_schedule(rsim_batch* b, int longest_first) { b->schedule = longest_first ? 1 : 0; b->have_cost = 0; return 0; }
+extern "C" int rsim_set_schedule(rsim_batch* b, int longest_first) {
+  b->schedule = longest_first ? 1 : 0; b->have_cost = 0;
+  if (b->ostream) { HIPCHK(hipSetDevice(b->device)); HIPCHK(hipStreamSynchronize(b->ostream)); }
+  b->nstep = 0; b->ord_valid[0] = b->ord_valid[1] = 0;
+  return 0;
+}
 extern "C" int rsim_pairlog(rsim_batch* b, unsigned long long* out) { if (join_groups(b)) return 1;
   if (!b->db.prof) return fail("rsim_pairlog: profiling is not armed (rsim_profile(b, 1, ...))");
   HIPCHK(hipSetDevice(b->device));
@@ -1482,24 +1471,3 @@ extern "C" int rsim_model_param_get(rsim_batch* b, const char* field, int env0, 
   return 0;
 }
 
-extern "C" int rsim_osc_eval(const rsim_ctrl_desc* d, const float* in, float* out, int B, int device) {
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("rsim_osc_eval: no HIP device visible");
-  HIPCHK(hipSetDevice(device));
-  DCtrl c;
-  memset(&c, 0, sizeof(c));
-  c.ndof = d->ndof;
-  for (int i = 0; i < 6; i++) { c.kp[i] = d->kp[i]; c.kd[i] = 2.f * sqrtf(d->kp[i]) * d->damping_ratio; }
-  c.uncouple = d->uncouple_pos_ori; c.nullspace_kp = d->nullspace_kp > 0 ? d->nullspace_kp : 10.f;
-  float *din = nullptr, *dout = nullptr;
-  HIPCHK(hipMalloc((void**)&din, (size_t)B * 192 * 4));
-  HIPCHK(hipMalloc((void**)&dout, (size_t)B * 8 * 4));
-  HIPCHK(hipMemcpy(din, in, (size_t)B * 192 * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemset(dout, 0, (size_t)B * 8 * 4));
-  int e = rsim_launch_osc_eval(&c, din, dout, B, 0);
-  if (e) return fail("osc launch failed: %s", hipGetErrorString((hipError_t)e));
-  HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out, dout, (size_t)B * 8 * 4, hipMemcpyDeviceToHost));
-  hipFree(din); hipFree(dout);
-  return 0;
-}

@@ -184,10 +184,14 @@ struct DBatch {
   int env0, nenv;
 };
 
-// Newton solver, fp32 stopping rules (0 = rule off; experiments: RSIM_NEWTON_NS / _NA / _NG in the environment when the batch is created)
+// Newton solver, fp32 stopping rules (0 = rule off; experiments: RSIM_NEWTON_NS / _NA / _NG in the environment when the batch is created).
+// Defaults from tools/newton_sweep.py (profiles/r03_d_newton_sweep.txt, r03_e_newton_sweep.txt): a step that moves no acceleration component by more
+// than 1e-5 of its value + 1e-5 ends the solve.  On 78 reached states (the Newton-heaviest of a launch included) forces and accelerations against the
+// oracle are unchanged to the printed digits (5.7e-4 / 3.3e-4 of the env's largest, same as without the rule), the p99 of the iterations per control step
+// drops from 126 to 85 and the maximum from 238 to 140.  The gradient-noise rule (NG) made no difference and stays off.
 #ifndef RSIM_NEWTON_NS
-#define RSIM_NEWTON_NS 0.f
-#define RSIM_NEWTON_NA 0.f
+#define RSIM_NEWTON_NS 1e-5f
+#define RSIM_NEWTON_NA 1e-5f
 #define RSIM_NEWTON_NG 0.f
 #endif
 

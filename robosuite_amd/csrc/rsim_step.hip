@@ -26,17 +26,7 @@
 #endif
 #if RSIM_CFG == 0
 #define RSIM_DIMS 32, 16, 16, 24, 16, 16, 64, 192
-#ifdef RSIM_SOLO
-// Sixth build: the control-step kernel of configuration 0 once more, compiled so that NO second wavefront fits on its SIMD (amdgpu_waves_per_eu(1, 1):
-// the register allocation is padded past half the file).  A launch lasts as long as its slowest env, and a wavefront alone on a SIMD runs ~1.4x
-// faster than one that shares it: rsim_control_step hands the few envs that were slowest in the previous step to this kernel, on a second stream
-// beside the main launch (rsim_set_solo_envs).  Only k_step is compiled here.
-#define RSIM_SYM(x) x##_cfg0s
-#define RSIM_KSTEP k_step_solo
-#define RSIM_KSTEP_BOUNDS __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-#else
 #define RSIM_SYM(x) x##_cfg0
-#endif
 #elif RSIM_CFG == 1
 #define RSIM_DIMS 32, 16, 32, 24, 16, 32, 64, 192
 #define RSIM_SYM(x) x##_cfg1
@@ -55,11 +45,6 @@
 
 #ifndef RSIM_MINWAVES
 #define RSIM_MINWAVES 1  /* waves per SIMD the register allocator must leave room for (1: 512 registers, 2: 256) */
-#endif
-
-#ifndef RSIM_KSTEP
-#define RSIM_KSTEP k_step
-#define RSIM_KSTEP_BOUNDS __launch_bounds__(64, RSIM_MINWAVES)
 #endif
 
 typedef unsigned long long u64;
@@ -3833,10 +3818,9 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
 }
 
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
-__global__ RSIM_KSTEP_BOUNDS void RSIM_KSTEP(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
+__global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
   step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR>(m, b, actions, n_sub, flags);
 }
-#ifndef RSIM_SOLO
 // The reset-observation pass that follows a control step (forward + observables for the envs it re-initialised, no reward): the same body under
 // its own kernel name, so that per-kernel profiles of k_step hold control steps only (and the constant flags strip controller / integrator code)
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
@@ -3884,71 +3868,7 @@ __global__ __launch_bounds__(64) void k_prepare(DModel m, DBatch b, int reset_on
 }
 
 
-// ------------------------------------------------------------------------------------------------------------
-// standalone batched OSC torque law on explicit inputs (unit-test entry: parity against the reference's own
-// OperationalSpaceController.run_controller).  One wave per sample.
-// in: [B, 128] floats: ep3 eR9 ev6 op3 oR9 bv6 goal_pos3 goal_ori9 J(6x7) M(7x7) bias7 q7 qd7 q0 7 (=168?) -> packed by host
-// ------------------------------------------------------------------------------------------------------------
 #if RSIM_CFG == 0
-#define OSC_IN 192
-__global__ __launch_bounds__(64) void k_osc_eval(DCtrl c, const float* __restrict__ in, float* __restrict__ out, int B) {
-  const int env = blockIdx.x, lane = threadIdx.x;
-  if (env >= B) return;
-  __shared__ float sh[OSC_IN];
-  __shared__ float Lm[8 * 9], invd[8], X[8 * 6];
-  for (int i = lane; i < OSC_IN; i += 64) sh[i] = in[(size_t)env * OSC_IN + i];
-  SYNC();
-  const int n = c.ndof;
-  const float *ep = sh, *eR = sh + 3, *ev = sh + 12, *op = sh + 18, *oR = sh + 21, *bv = sh + 30, *gp = sh + 36, *go = sh + 39, *J = sh + 48,
-              *M = sh + 48 + 6 * 8, *bias = M + 64, *q = bias + 8, *qd = q + 8, *q0 = qd + 8;
-  // Cholesky of the arm mass block (stride 8 in, stride 9 factor)
-  float* A9 = Lm;
-  __shared__ float Ain[8 * 9];
-  for (int e = lane; e < n * n; e += 64) { int i = e / n, j = e - i * n; Ain[i * 9 + j] = M[i * 8 + j]; }
-  SYNC();
-  chol_factor<9>(A9, invd, Ain, n, lane);
-  {
-    int r = lane >> 3, i = lane & 7;
-    float x = (r < 6 && i < n) ? J[r * 8 + i] : 0.f;
-    for (int k = 0; k < n; k++) { float xk = __shfl(x, (lane & ~7) + k) * invd[k]; if (i == k) x = xk; else if (i > k && i < n) x -= A9[i * 9 + k] * xk; }
-    for (int k = n - 1; k >= 0; k--) { float xk = __shfl(x, (lane & ~7) + k) * invd[k]; if (i == k) x = xk; else if (i < k) x -= A9[k * 9 + i] * xk; }
-    if (r < 6 && i < n) X[i * 6 + r] = x;
-  }
-  SYNC();
-  float lfi[36];
-  for (int r = 0; r < 6; r++) for (int p = 0; p < 6; p++) { float sv = 0; for (int k = 0; k < n; k++) sv += J[r * 8 + k] * X[k * 6 + p]; lfi[r * 6 + p] = sv; }
-  M3 oRm = ldm(oR), eRm = ldm(eR), gom = ldm(go);
-  V3 perr = ld3(op) + mv(oRm, ld3(gp)) - ld3(ep);
-  M3 dori = mm(oRm, gom);
-  V3 oerr = (cross(col(eRm, 0), col(dori, 0)) + cross(col(eRm, 1), col(dori, 1)) + cross(col(eRm, 2), col(dori, 2))) * 0.5f;
-  float pe[3] = {perr.x, perr.y, perr.z}, oe[3] = {oerr.x, oerr.y, oerr.z}, F[3], T[3];
-  for (int k = 0; k < 3; k++) { F[k] = pe[k] * c.kp[k] - (ev[k] - bv[k]) * c.kd[k]; T[k] = oe[k] * c.kp[3 + k] - (ev[3 + k] - bv[3 + k]) * c.kd[3 + k]; }
-  float wrench[6];
-  if (c.uncouple) {
-    float lp[9], lo[9];
-    for (int r = 0; r < 3; r++) for (int p = 0; p < 3; p++) { lp[r * 3 + p] = lfi[r * 6 + p]; lo[r * 3 + p] = lfi[(3 + r) * 6 + 3 + p]; }
-    spd_solve_small<3>(lp, F, wrench);
-    spd_solve_small<3>(lo, T, wrench + 3);
-  } else {
-    float w[6] = {F[0], F[1], F[2], T[0], T[1], T[2]};
-    spd_solve_small<6>(lfi, w, wrench);
-  }
-  float kv = sqrtf(c.nullspace_kp) * 2, tmp[8], jt[6], z[6];
-  for (int i = 0; i < n; i++) tmp[i] = c.nullspace_kp * (q0[i] - q[i]) - kv * qd[i];
-  for (int r = 0; r < 6; r++) { float sv = 0; for (int k = 0; k < n; k++) sv += J[r * 8 + k] * tmp[k]; jt[r] = sv; }
-  spd_solve_small<6>(lfi, jt, z);
-  if (lane < n) {
-    float tq = bias[lane];
-    for (int r = 0; r < 6; r++) tq += J[r * 8 + lane] * (wrench[r] - z[r]);
-    for (int k = 0; k < n; k++) tq += M[lane * 8 + k] * tmp[k];
-    out[(size_t)env * 8 + lane] = tq;
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------------------
-// dynamics domain randomisation (include/rsim.h rsim_randomize_dynamics): one workgroup per env rewrites that env's float table
-// ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dr_uniform(unsigned long long seed, unsigned long long step, unsigned env, unsigned item) {
   unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (step + 1) + ((unsigned long long)env << 32 | item);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;   // splitmix64 finaliser
@@ -4048,21 +3968,14 @@ extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStr
   hipLaunchKernelGGL(k_order, dim3(1), dim3(B <= 1024 ? 64 : 1024), 0, stream, cost, order, B);
   return (int)hipGetLastError();
 }
-extern "C" int rsim_launch_osc_eval(const DCtrl* c, const float* in, float* out, int B, hipStream_t stream) {
-  hipLaunchKernelGGL(k_osc_eval, dim3(B), dim3(64), 0, stream, *c, in, out, B);
-  return (int)hipGetLastError();
-}
 #endif  // RSIM_CFG == 0
 
-#endif  // !RSIM_SOLO (everything between k_step and here)
-
 // explicit instantiations + launchers (one set per configuration build) ----------------------------------------------------------
-template __global__ void RSIM_KSTEP<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
+template __global__ void k_step<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
 extern "C" int RSIM_SYM(rsim_launch_step)(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream) {
-  hipLaunchKernelGGL((RSIM_KSTEP<RSIM_DIMS>), dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
+  hipLaunchKernelGGL((k_step<RSIM_DIMS>), dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
   return (int)hipGetLastError();
 }
-#ifndef RSIM_SOLO
 template __global__ void k_ctrl_reset<RSIM_DIMS>(DModel, DBatch, const unsigned char*);
 template __global__ void k_prepare<RSIM_DIMS>(DModel, DBatch, int);
 template __global__ void k_reset_obs<RSIM_DIMS>(DModel, DBatch);
@@ -4087,4 +4000,3 @@ extern "C" int RSIM_SYM(rsim_limits)(int* lim) {
   lim[8] = Smem0::NROOT_; lim[9] = (Smem0::TENDONS_ ? 1 : 0) | (Smem0::NB_ > 32 ? 2 : 0);   // bit 1: two OSC arm parts
   return 0;
 }
-#endif  // !RSIM_SOLO

@@ -34,17 +34,9 @@ def test_fused_kernel_configurations_keep_their_lds_and_register_budgets():
         assert r["scratch"] <= scratch, (name, r)
 
 
-def test_solo_build_leaves_no_room_for_a_second_wavefront_on_its_simd():
-    """k_step_solo (rsim_set_solo_envs): same LDS object as the regular 32 x 16 kernel, more than half of a SIMD's 512 registers, no private segment."""
-    ks = kernels(LIB)
-    (solo,) = [r for n, r in ks.items() if n.startswith("_Z11k_step_solo")]
-    (reg,) = [r for n, r in ks.items() if n.startswith("_Z6k_step") and "ILi32ELi16ELi16E" in n]
-    assert solo["lds"] == reg["lds"] and -(-solo["vgpr"] // 8) * 8 > 256 and solo["scratch"] == 0, solo
-
-
 def test_auxiliary_kernels_use_no_scratch():
     for name, r in kernels(LIB).items():
         if name.startswith("_Z11k_reset_obs"):
             assert r["scratch"] <= 64, (name, r)   # the reset-observation pass shares the step body (a few envs per control step run it)
-        elif not name.startswith("_Z6k_step") and not name.startswith("_Z11k_step_solo"):
+        elif not name.startswith("_Z6k_step"):
             assert r["scratch"] == 0, (name, r)
