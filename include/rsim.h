@@ -228,6 +228,11 @@ int rsim_control_step(rsim_batch* b, const float* actions_dev, int n_sub);
  * evaluation of the part controllers from RSIM_CSTATE as it stands (goals, initial joints, gripper action, PID state) -- no set_goal, no actuation, no
  * integration.  Results: RSIM_CTRL and the torque slots of RSIM_CSTATE (un-clipped tau, layout at enum rsim_field). */
 int rsim_run_controller(rsim_batch* b);
+/* The last rsim_step2 of a control step driven from the host side -- user part controllers evaluated on [B, ...] device tensors between rsim_step1 and
+ * rsim_step2 of the whole batch (robosuite_amd/controllers.py, the batched form of the Controller plugin API, controllers/parts/controller.py:35-44,
+ * 140-147): the substep's actuation / solve / integration, then what MujocoEnv.step does after its loop (base.py:508-548: timestep, reward, done) and
+ * the observation record, with the on-device episode restart of rsim_control_step.  RSIM_DONE tells the caller which envs restarted. */
+int rsim_step2_last(rsim_batch* b);
 /* Robot.reset's controller re-creation (robots/robot.py:271 -> controller.py:125-131, osc.py:520-532):
  * forward kinematics, initial_joint := q, goal := current eef pose, gripper action := 0 */
 int rsim_ctrl_reset(rsim_batch* b, const uint8_t* host_mask);

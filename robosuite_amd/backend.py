@@ -183,7 +183,7 @@ def lib():
         L.rsim_refill_reset_bank_async.argtypes = [vp, C.c_int, vp, vp, vp]
         L.rsim_bank_flush.argtypes = [vp]
         L.rsim_param_offset.argtypes = [vp, C.c_char_p, C.c_int]
-        for f in ("rsim_forward", "rsim_step1", "rsim_step2", "rsim_step", "rsim_sync", "rsim_observe", "rsim_run_controller"):
+        for f in ("rsim_forward", "rsim_step1", "rsim_step2", "rsim_step", "rsim_sync", "rsim_observe", "rsim_run_controller", "rsim_step2_last"):
             getattr(L, f).argtypes = [vp]
         L.rsim_control_step.argtypes = [vp, vp, C.c_int]
         L.rsim_ctrl_reset.argtypes = [vp, C.c_char_p]
@@ -358,6 +358,10 @@ class HipBatch:
 
     def sync(self):
         _chk(self._L.rsim_sync(self.ptr))
+
+    def step2_last(self):
+        """Last step2 of a host-driven control step: + observation / reward / horizon epilogue (include/rsim.h rsim_step2_last)."""
+        _chk(self._L.rsim_step2_last(self.ptr))
 
     def run_controller(self):
         """One evaluation of the in-kernel part controllers on the current state and controller state (include/rsim.h rsim_run_controller)."""

@@ -740,7 +740,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   }
   if (dalloc(&b->db.needs_reset, (size_t)B)) return 1;
   b->db.mprc = nullptr;
-  if (!getenv("RSIM_NO_MPR_WARMSTART") && m->npair > 0 && dalloc(&b->db.mprc, (size_t)B * m->npair * 4)) return 1;
+  if (!getenv("RSIM_NO_MPR_WARMSTART") && m->npair > 0 && dalloc(&b->db.mprc, (size_t)B * m->npair * 12)) return 1;
+  b->db.mprc_portal = getenv("RSIM_NO_MPR_PORTAL_WARMSTART") ? 0 : 1;
   b->db.ft_rw = b->d_ft;
   DModel& dm = b->dm;
   dm.nq = m->nq; dm.nv = m->nv; dm.nu = m->nu; dm.nbody = m->nbody; dm.njnt = m->njnt; dm.ncg = ncg; dm.nsite = m->nsite; dm.npair = m->npair;
@@ -871,7 +872,7 @@ extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) { if (join_groups(
       HIPCHK(hipMemset(b->db.ep_step + e, 0, sizeof(int))); HIPCHK(hipMemset(b->db.done + e, 0, sizeof(int))); HIPCHK(hipMemset(b->db.needs_reset + e, 0, sizeof(int)));
     }
   }
-  if (b->db.mprc) HIPCHK(hipMemset(b->db.mprc, 0, (size_t)B * m->npair * 4 * sizeof(float)));   // no warm start carried into a reset state (bitwise replays)
+  if (b->db.mprc) HIPCHK(hipMemset(b->db.mprc, 0, (size_t)B * m->npair * 12 * sizeof(float)));   // no warm start carried into a reset state (bitwise replays)
   b->gen++;
   return 0;
 }
@@ -960,7 +961,7 @@ static int ensure_constants(rsim_batch* b) {
 static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   HIPCHK(hipSetDevice(b->device));
   if (sync_controller(b)) return 1;
-  const bool grouped = (flags & RF_EPISODE) && b->ngroups > 1;
+  const bool grouped = (flags & RF_EPISODE) && (flags & RF_CTRL) && b->ngroups > 1;
   if (!grouped || b->cm_dirty || memcmp(&b->cm_ctrl, &b->dm.ctrl, sizeof(DCtrl))) { if (join_groups(b)) return 1; }   // main-stream work ahead
   if (ensure_constants(b)) return 1;
   if ((flags & RF_OBS) && !b->dm.task.enabled) return fail("the task (observation / reward epilogue) was configured after the batch was created");
@@ -999,7 +1000,7 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
     b->gen++;
     return 0;
   }
-  const bool sched1 = (flags & RF_EPISODE) && b->schedule && b->d_order;   // control steps only: forward()/step1()/step2() launches are one substep long
+  const bool sched1 = (flags & RF_EPISODE) && (flags & RF_CTRL) && b->schedule && b->d_order;   // fused control steps only: forward()/step1()/step2() launches are one substep long
   const int cur = (int)(b->nstep & 1), prev = cur ^ 1;
   if (sched1) {
     if (!b->ostream) {
@@ -1053,6 +1054,16 @@ extern "C" int rsim_control_step(rsim_batch* b, const float* actions_dev, int n_
 // velocity stage, then ONE evaluation of the in-kernel part controllers from the controller state as it stands -- no set_goal, no integration.
 // Writes RSIM_CTRL (clipped) and the torque slots of RSIM_CSTATE: the door the parity tests pin the in-kernel control laws through.
 extern "C" int rsim_run_controller(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL | RF_CTRL | RF_DEBUG); }
+// The LAST mj_step2 of a control step whose controllers run on the host side of the boundary (robosuite_amd/controllers.py): actuation, solve and
+// integration of the substep, then everything MujocoEnv.step does after its loop -- observation record, reward, success, timestep / horizon, on-device
+// episode restart (base.py:501-548) -- exactly as rsim_control_step does after its last substep.  No in-kernel controller runs, so the flags that mark
+// freshly restarted envs for it are cleared here; the caller learns about restarts from RSIM_DONE.
+extern "C" int rsim_step2_last(rsim_batch* b) {
+  if (!b->m->has_task) return fail("rsim_step2_last: no task configured");
+  if (launch(b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_INTEGRATE | RF_OBS | RF_EPISODE | RF_DEBUG)) return 1;
+  HIPCHK(hipMemsetAsync(b->db.needs_reset, 0, (size_t)b->B * sizeof(int), b->stream));
+  return 0;
+}
 extern "C" int rsim_observe(rsim_batch* b) {
   if (!b->m->has_task) return fail("rsim_observe: no task configured");
   return launch(b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_OBS | RF_DEBUG);
@@ -1314,7 +1325,7 @@ extern "C" int rsim_set_array(rsim_batch* b, int field, const void* src, size_t 
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipMemcpy(b->fptr[field], src, count * 4, hipMemcpyHostToDevice));
   // positions written by the host: the narrow phase's warm-start directions belong to the states before (a replay from this state must not depend on them)
-  if (field == RSIM_QPOS && b->db.mprc) HIPCHK(hipMemset(b->db.mprc, 0, (size_t)b->B * b->m->npair * 4 * sizeof(float)));
+  if (field == RSIM_QPOS && b->db.mprc) HIPCHK(hipMemset(b->db.mprc, 0, (size_t)b->B * b->m->npair * 12 * sizeof(float)));
   b->gen++;
   return 0;
 }

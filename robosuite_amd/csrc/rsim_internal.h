@@ -173,7 +173,8 @@ struct DBatch {
   void* cm_env;          // per-env constant blocks [B] (used once a float-table field has per-env values)
   long long cm_stride;   // bytes between the blocks of consecutive envs, 0 = no env has its own block yet
   int* overflow;         // [B] contacts + constraint rows dropped for lack of capacity (null = not counted)
-  float* mprc;           // [B][npair][4] or null: the separating direction (x, y, z, valid) each candidate pair's last convex narrow-phase run ended on
+  int mprc_portal;       // 0: keep only the (exact) separating-direction warm start
+  float* mprc;           // [B][npair][12] or null: the separating direction (x, y, z, valid) each candidate pair's last convex narrow-phase run ended on
                          // (warm start of the next substep's run, see convex_convex); zeroed whenever the host writes positions
   const int* order;      // [B] or null (identity)
   unsigned* cost;        // [B] or null

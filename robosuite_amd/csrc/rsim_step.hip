@@ -956,7 +956,8 @@ struct Sim {
     const long long off = (fenv & mask) ? ceoff : 0ll;
     return (cmr_t)((const char __attribute__((address_space(1)))*)cm + off);
   }
-  float __attribute__((address_space(1)))* mprc = nullptr;  // this env's narrow-phase warm-start record [npair][4] in global memory (DBatch.mprc), or null
+  float __attribute__((address_space(1)))* mprc = nullptr;  // this env's narrow-phase warm-start record [npair][MPRC] in global memory (DBatch.mprc), or null
+  bool mpr_portal = true;                                   // contacts leave their portal directions in the record (flag 2)
   float __attribute__((address_space(1)))* cst = nullptr;   // this env's controller-state record in global memory (slots >= RSIM_CS_LDS are used in place)
   Prof pf;
   int ovf = 0;   // contacts / constraint rows this launch had to drop for lack of capacity (RSIM_OVERFLOW); MuJoCo's nconmax = 5000 never truncates
@@ -1883,18 +1884,55 @@ struct Sim {
   // sign shows), and they are what makes the slowest env of a launch 3x the median (tools/tail_report.py).  The direction the previous substep's run
   // ended on is tried first: two support evaluations, and if it still separates the pair is done.  Separation along ANY direction is proof that the
   // shapes are disjoint, so the verdict is the one the full run reaches (MPR is exact for separated pairs); contacts always come from the full run.
+  // A pair IN contact keeps its contact for hundreds of substeps too (a finger resting on the table), and its run is the expensive one: ~5 portal
+  // discovery steps and ~9 refinement steps, 28 support evaluations, every substep, to arrive at (nearly) the portal of the substep before.  The
+  // record therefore also keeps the three DIRECTIONS whose supports span the final portal of a contact (flag 2).  The next run evaluates the
+  // supports along them (6 evaluations); if they still form a portal -- every support beyond the origin along its direction, the origin ray inside
+  // the three side planes: the invariant the discovery loop ends on -- discovery is skipped and the refinement, started next to its fixed point,
+  // ends after one or two steps.  Unlike the separating-direction test this is a different (equally valid) path to the contact: depth and normal
+  // are those of the same facet of the Minkowski difference, the contact POINT is a barycentric blend over a possibly different triangle of that
+  // facet (it slides by rounding-level amounts along the contact face; bounds in tests/test_hip_edge_cases.py).  RSIM_NO_MPR_PORTAL_WARMSTART=1
+  // (read when the batch is created) keeps only the exact separating-direction part.
+  static constexpr int MPRC = 12;   // floats per candidate pair in DBatch.mprc: (d1 | separating direction, flag) (d2, -) (d3, -)
   __device__ __forceinline__ void mpr_store(gwf wout, V3 d, float valid) const {
     if (wout && lane == 0) { typedef v4f __attribute__((address_space(1)))* gw4; *(gw4)wout = v4f{d.x, d.y, d.z, valid}; }
   }
-  __device__ __forceinline__ void convex_convex(int g1, int g2, float margin, const CPar& cp, V3 wd, bool wh, gwf wout) {
+  // The three directions live in LDS while a run is under way (lane 0 writes a slot when a portal vertex is replaced: nine registers less in the
+  // phase with the highest register pressure of the kernel); LDS operations of one lane execute in program order, so no fence is needed.
+  __device__ __forceinline__ float* mpr_dirs() const { return sm.u.b.poly + 48; }   // [3][3] behind the box-box clip polygons (16 x 3 floats)
+  __device__ __forceinline__ void mpr_setd(int k, V3 d) const { if (lane == 0) st3(mpr_dirs() + 3 * k, d); }
+  __device__ __forceinline__ void mpr_store_portal(gwf wout) const {
+    if (wout && lane == 0) {
+      typedef v4f __attribute__((address_space(1)))* gw4;
+      const float* q = mpr_dirs();
+      ((gw4)wout)[0] = v4f{q[0], q[1], q[2], mpr_portal ? 2.f : 0.f}; ((gw4)wout)[1] = v4f{q[3], q[4], q[5], 0.f}; ((gw4)wout)[2] = v4f{q[6], q[7], q[8], 0.f};
+    }
+  }
+  __device__ __forceinline__ void convex_convex(int g1, int g2, float margin, const CPar& cp, V3 wd, int wh, gwf wout) {
     const float tol = 1e-6f;
     const int mprstat_s0 = pf.c_support; (void)mprstat_s0;
     const V3 org = ld3(sm.gpos + 3 * g1);   // all support points relative to the first geom's position (see geom_support)
     const SupGeom sg1 = sup_load(cm, cmf(MK_gst), g1, (gcf)m.mesh_vert, lane, org), sg2 = sup_load(cm, cmf(MK_gst), g2, (gcf)m.mesh_vert, lane, org);
-    if (wh) {
+    if (wh == 1) {
       const V3 a1 = sup(sg1, wd), a2 = sup(sg2, -wd);
       if (dot(a1 - a2, wd) <= 0) { MPRSTAT(8, 1); return; }
     }
+    V3 v0 = (ld3(sm.gcen + 3 * g1) - org) - (ld3(sm.gcen + 3 * g2) - org);
+    if (norm(v0) < 1e-9f) v0.x = 1e-5f;
+    V3 dir, v1, v2, v3_, p11, p12, p21, p22, p31, p32;   // portal vertices and their witness points on the two shapes (the directions they are supports of: mpr_dirs())
+    bool warm = false;
+    if (wh == 2) {
+      typedef const v4f __attribute__((address_space(1)))* gc4;
+      const v4f r1 = ((gc4)wout)[1], r2 = ((gc4)wout)[2];
+      const V3 d1 = wd, d2 = v3(r1[0], r1[1], r1[2]), d3 = v3(r2[0], r2[1], r2[2]);
+      mpr_setd(0, d1); mpr_setd(1, d2); mpr_setd(2, d3);
+      p11 = sup(sg1, d1); p12 = sup(sg2, -d1); v1 = p11 - p12;
+      p21 = sup(sg1, d2); p22 = sup(sg2, -d2); v2 = p21 - p22;
+      p31 = sup(sg1, d3); p32 = sup(sg2, -d3); v3_ = p31 - p32;
+      warm = dot(v1, d1) > 0.f && dot(v2, d2) > 0.f && dot(v3_, d3) > 0.f && dot(cross(v1, v3_), v0) >= 0.f && dot(cross(v3_, v2), v0) >= 0.f && dot(cross(v2, v1), v0) >= 0.f;
+      MPRSTAT(9, warm ? 1 : 0);
+    }
+    if (!warm) {
     // A box or cylinder against anything: MPR's own exit test (a direction D, oriented from geom 1 to geom 2, in which the first shape's
     // farthest point does not reach the second's nearest) tried first on the primitive's most promising face / radial axis.  The table top or
     // the mount pedestal against a gripper mesh hovering over it -- most narrow-phase visits of the Lift workload -- end here after ONE hull
@@ -1939,10 +1977,8 @@ struct Sim {
         if (dot(a1 - a2, D) <= 0) { MPRSTAT(0, 1); mpr_store(wout, D, 1.f); return; }
       }
     }
-    V3 v0 = (ld3(sm.gcen + 3 * g1) - org) - (ld3(sm.gcen + 3 * g2) - org);
-    if (norm(v0) < 1e-9f) v0.x = 1e-5f;
-    V3 dir = normalized(-v0);
-    V3 p11 = sup(sg1, dir), p12 = sup(sg2, -dir), v1 = p11 - p12;
+    dir = normalized(-v0);
+    p11 = sup(sg1, dir); p12 = sup(sg2, -dir); v1 = p11 - p12; mpr_setd(0, dir);
     if (dot(v1, dir) <= 0) { MPRSTAT(1, 1); mpr_store(wout, dir, 1.f); return; }
     dir = cross(v0, v1);
     if (norm(dir) < 1e-12f) {
@@ -1951,15 +1987,15 @@ struct Sim {
       return;
     }
     dir = normalized(dir);
-    V3 p21 = sup(sg1, dir), p22 = sup(sg2, -dir), v2 = p21 - p22;
+    p21 = sup(sg1, dir); p22 = sup(sg2, -dir); v2 = p21 - p22; mpr_setd(1, dir);
     if (dot(v2, dir) <= 0) { MPRSTAT(2, 1); mpr_store(wout, dir, 1.f); return; }
     dir = cross(v1 - v0, v2 - v0);
     if (dot(dir, v0) > 0) {
       V3 t;
       t = v1; v1 = v2; v2 = t; t = p11; p11 = p21; p21 = t; t = p12; p12 = p22; p22 = t;
+      if (lane == 0) { float* q = mpr_dirs(); const V3 a = ld3(q), b2 = ld3(q + 3); st3(q, b2); st3(q + 3, a); }
       dir = -dir;
     }
-    V3 v3_, p31, p32;
     for (int it = 0;; it++) {
       if (it > 100) return;
       float len;
@@ -1967,10 +2003,12 @@ struct Sim {
       if (len < FMIN) return;
       p31 = sup(sg1, dir); p32 = sup(sg2, -dir); v3_ = p31 - p32;
       if (dot(v3_, dir) <= 0) { MPRSTAT(3, 1); MPRSTAT(7, pf.c_support - mprstat_s0); mpr_store(wout, dir, 1.f); return; }
-      if (dot(cross(v1, v3_), v0) < -1e-14f) { v2 = v3_; p21 = p31; p22 = p32; dir = cross(v1 - v0, v3_ - v0); continue; }
-      if (dot(cross(v3_, v2), v0) < -1e-14f) { v1 = v3_; p11 = p31; p12 = p32; dir = cross(v3_ - v0, v2 - v0); continue; }
+      if (dot(cross(v1, v3_), v0) < -1e-14f) { v2 = v3_; p21 = p31; p22 = p32; mpr_setd(1, dir); dir = cross(v1 - v0, v3_ - v0); continue; }
+      if (dot(cross(v3_, v2), v0) < -1e-14f) { v1 = v3_; p11 = p31; p12 = p32; mpr_setd(0, dir); dir = cross(v3_ - v0, v2 - v0); continue; }
+      mpr_setd(2, dir);
       break;
     }
+    }   // !warm
     bool hit = false;
     for (int it = 0; it < 128; it++) {
       float len;
@@ -1984,14 +2022,13 @@ struct Sim {
       if (delta <= tol || it == 127) break;
       V3 t = cross(v4, v0);
       if (dot(v1, t) > 0) {
-        if (dot(v2, t) > 0) { v1 = v4; p11 = p41; p12 = p42; } else { v3_ = v4; p31 = p41; p32 = p42; }
+        if (dot(v2, t) > 0) { v1 = v4; p11 = p41; p12 = p42; mpr_setd(0, dir); } else { v3_ = v4; p31 = p41; p32 = p42; mpr_setd(2, dir); }
       } else {
-        if (dot(v3_, t) > 0) { v2 = v4; p21 = p41; p22 = p42; } else { v1 = v4; p11 = p41; p12 = p42; }
+        if (dot(v3_, t) > 0) { v2 = v4; p21 = p41; p22 = p42; mpr_setd(1, dir); } else { v1 = v4; p11 = p41; p12 = p42; mpr_setd(0, dir); }
       }
     }
-    if (!hit) { MPRSTAT(4, 1); MPRSTAT(7, pf.c_support - mprstat_s0); return; }
+    if (!hit) { MPRSTAT(4, 1); MPRSTAT(7, pf.c_support - mprstat_s0); mpr_store(wout, v3(0.f, 0.f, 0.f), 0.f); return; }
     MPRSTAT(5, 1); MPRSTAT(6, pf.c_support - mprstat_s0);
-    mpr_store(wout, v3(0.f, 0.f, 0.f), 0.f);   // in contact: the next run starts cold
     V3 bw;
     V3 cpt = tri_closest_origin(v1, v2, v3_, bw);
     float depth = norm(cpt);
@@ -2004,6 +2041,22 @@ struct Sim {
       const float dn = dot(dir, v1);
       n = dn >= 0.f ? dir : -dir;
       depth = fabsf(dn);
+    }
+    // in contact: the next run starts from this portal -- for a BOX against a hull, up to 5 mm deep.  What the restart relies on is that the cached
+    // directions give back a well-shaped portal on the facet the origin ray leaves through:
+    //  * curved shapes (cylinder, capsule, sphere) fail it: the three directions of a converged portal are nearly parallel, their supports nearly
+    //    coincide and the restarted portal is a sliver whose plane normal is rounding noise (Baxter's elbow cylinders on the torso hull lost 15 % of
+    //    their normals to > 0.1 degree that way);
+    //  * two fine meshes, or anything interpenetrating by a centimetre (the Robotiq's finger / knuckle links, in every pose), have several
+    //    near-coplanar facets around the origin ray; which one a run ends on depends on its path, a restarted run keeps choosing its own, and the
+    //    finger links -- 5e-5 kg m^2, no damping -- then follow another trajectory than the cold-started oracle (UR5e / PickPlace finger tracking went
+    //    from 0.04 to 0.17 rad over 20 control steps).
+    // A table, bin wall or cube face against a gripper or object hull is the case that matters (the hand held against the table is what makes the
+    // slowest envs of a Lift launch) and the well-posed one: one large flat facet.
+    {
+      const int ta = uni(sg1.t), tb = uni(sg2.t);
+      if (((ta == G_BOX && tb == G_MESH) || (ta == G_MESH && tb == G_BOX)) && depth < 5e-3f) mpr_store_portal(wout);
+      else mpr_store(wout, v3(0.f, 0.f, 0.f), 0.f);
     }
     V3 w1 = p11 * bw.x + p21 * bw.y + p31 * bw.z, w2 = p12 * bw.x + p22 * bw.y + p32 * bw.z;
     emit_contacts(lane == 0, 1, -depth, org + (w1 + w2) * 0.5f, n, g1, g2, cp);
@@ -2098,7 +2151,7 @@ struct Sim {
     pf.count(RP_N_CAND, ncand);
     // warm-start records of the candidates, one per lane, in flight while the first pairs are processed (candidates beyond 64 start cold)
     v4f wc = {0.f, 0.f, 0.f, 0.f};
-    if (mprc && lane < ncand) { typedef const v4f __attribute__((address_space(1)))* gc4; wc = *(gc4)(mprc + 4 * sm.u.b.cand[lane]); }
+    if (mprc && lane < ncand) { typedef const v4f __attribute__((address_space(1)))* gc4; wc = *(gc4)(mprc + MPRC * sm.u.b.cand[lane]); }
     for (int ci = 0; ci < ncand; ci++) {
       phase();
       int p = uni(sm.u.b.cand[ci]);
@@ -2132,9 +2185,9 @@ struct Sim {
       } else {
         pf.mark(RP_PLANE);
         V3 wd = v3(0.f, 0.f, 0.f);
-        bool wh = false;
-        if (mprc && ci < 64) { wd = v3(bcast(wc[0], ci), bcast(wc[1], ci), bcast(wc[2], ci)); wh = bcast(wc[3], ci) != 0.f; }
-        convex_convex(g1, g2, margin, cp, wd, wh, mprc ? mprc + 4 * p : nullptr);
+        int wh = 0;
+        if (mprc && ci < 64) { wd = v3(bcast(wc[0], ci), bcast(wc[1], ci), bcast(wc[2], ci)); wh = uni((int)bcast(wc[3], ci)); if (wh == 2 && !mpr_portal) wh = 0; }
+        convex_convex(g1, g2, margin, cp, wd, wh, mprc ? mprc + MPRC * p : nullptr);
         pf.mark(RP_MPR); pf.count(RP_N_MPR, 1);
       }
       if (pf.pairs && lane == 0) { atomicAdd(pf.pairs + p, 1ull); atomicAdd(pf.pairs + RSIM_PAIR_MAX + p, (unsigned long long)(pf.c_support - sup0)); }
@@ -3439,7 +3492,10 @@ struct Sim {
       const float a_new = fmaf(alpha, sk, a);
       // fp32: a step that moves no component of the acceleration by more than a few units in its last place (plus an absolute floor) cannot be
       // improved on by another factorisation
-      const bool settled = m.newton_ns > 0.f && !__ballot(dofl && rr < nv && fabsf(alpha * sk) > m.newton_ns * fabsf(a_new) + m.newton_na);
+      // (one-tile configurations only: on the wide models -- Robotiq finger links of 5e-5 kg m^2 under stiff contacts -- the Hessian's Cholesky factor
+      // resolves the soft directions poorly, the iteration creeps along them in many small steps, and cutting those off cost a factor of ten in how
+      // closely the finger joints track the oracle)
+      const bool settled = FAST && m.newton_ns > 0.f && !__ballot(dofl && rr < nv && fabsf(alpha * sk) > m.newton_ns * fabsf(a_new) + m.newton_na);
       a = a_new;
       iter++;
       if (scale * (p0 - p) < tolerance || settled) {
@@ -3663,7 +3719,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   for (int i = lane; i < m.nu; i += 64) sm.ctrl[i] = b.ctrl[(size_t)env * m.nu + i];
   const int cs = m.ctrl.cs_size, csl = cs < RSIM_CS_LDS ? cs : RSIM_CS_LDS;
   sim.cst = (gwf)(b.cstate + (size_t)env * cs);
-  if (b.mprc) sim.mprc = (gwf)(b.mprc + (size_t)env * 4 * m.npair);
+  if (b.mprc) { sim.mprc = (gwf)(b.mprc + (size_t)env * Sim<SM>::MPRC * m.npair); sim.mpr_portal = b.mprc_portal != 0; }
   if (lane < csl) sm.cstate[lane] = sim.cst[lane];
   if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; }
   sim.load_opt();
@@ -3770,7 +3826,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
       }
       time = 0.f;
       st = 0;
-      if (sim.mprc) for (int p2 = lane; p2 < m.npair; p2 += 64) sim.mprc[4 * p2 + 3] = 0.f;   // the new episode's narrow phase starts cold, as after a host reset
+      if (sim.mprc) for (int p2 = lane; p2 < m.npair; p2 += 64) sim.mprc[Sim<SM>::MPRC * p2 + 3] = 0.f;   // the new episode's narrow phase starts cold, as after a host reset
       if (lane == 0) { b.ep_index[env] = ep; b.needs_reset[env] = 1; }
       SYNC();
       // the patched float-table entries change this env's constant block: the host follows this launch with k_prepare over the envs whose

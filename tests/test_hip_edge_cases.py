@@ -312,29 +312,63 @@ def test_reset_after_the_ring_has_moved_on_starts_the_episode_streams_again():
     assert np.array_equal(env.env.batch.get("qpos"), lift.episode_setup(11, np.arange(5), 1)[1].astype(np.float32))
 
 
-def _contact_rich_rollout(B, T, warm=True, groups=1):
-    """Lift envs under full-range random actions from step 150 of their episodes (hands on the table: the MPR- and Newton-heavy states)."""
+def _contact_rich_rollout(B, T, warm="all", groups=1, keep=False):
+    """Lift envs under full-range random actions (hands on the table: the MPR- and Newton-heavy states).  warm: "all" = separating-direction and
+    portal warm start of the convex narrow phase (the default build), "exact" = separating direction only, "none" = every run cold."""
     import os
     from robosuite_amd import lift
     flat, cfg = _lift_assets()
     ids = np.arange(B)
     tape = torch.tensor(lift.env_actions(ids, T), device="cuda")
-    if not warm:
-        os.environ["RSIM_NO_MPR_WARMSTART"] = "1"
+    var = {"none": "RSIM_NO_MPR_WARMSTART", "exact": "RSIM_NO_MPR_PORTAL_WARMSTART"}.get(warm)
+    if var:
+        os.environ[var] = "1"
     try:
         env = lift.LiftBatch(flat, cfg, ids, seed0=0, horizon=60, bank_episodes=3)
     finally:
-        os.environ.pop("RSIM_NO_MPR_WARMSTART", None)
+        if var:
+            os.environ.pop(var, None)
     env.batch.set_stream_groups(groups)
     for t in range(T):
         env.step(tape[t])
     env.batch.sync()
-    return {k: env.batch.get(k) for k in ("qpos", "qvel", "obs", "reward", "ep_index", "ep_step", "diverged")}
+    out = {k: env.batch.get(k) for k in ("qpos", "qvel", "obs", "reward", "ep_index", "ep_step", "diverged")}
+    return (out, env) if keep else out
 
 
-def test_mpr_warm_start_does_not_change_the_contact_set():
+def test_mpr_separating_direction_warm_start_does_not_change_the_contact_set():
     """The convex narrow phase first tries the separating direction the pair's previous run ended on (rsim_step.hip convex_convex); separation
-    along any direction proves the shapes disjoint, so every contact -- and with it every state -- is what the cold run produces."""
-    a, b = _contact_rich_rollout(384, 130, warm=True), _contact_rich_rollout(384, 130, warm=False)
+    along any direction proves the shapes disjoint, so every contact -- and with it every state -- is what the cold run produces: bitwise, over
+    130 contact-rich control steps with episode resets."""
+    a, b = _contact_rich_rollout(384, 130, warm="exact"), _contact_rich_rollout(384, 130, warm="none")
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+    assert a["ep_index"].min() == 2 and a["diverged"].sum() == 0
+
+
+def test_mpr_portal_warm_start_reaches_the_same_contacts():
+    """Pairs in contact restart MPR from the directions of their previous portal.  That is another path to the same facet of the Minkowski
+    difference: same pairs, same depth and normal, the contact point within the rounding-level slide along the contact face that any two portals
+    on one facet differ by.  Checked on the states a contact-rich rollout reaches: forward() with the records as the rollout left them against
+    forward() after the positions were written back (which clears the records: a cold run)."""
+    out, env = _contact_rich_rollout(1024, 58, warm="all", keep=True)
+    b = env.batch
+    st = {k: b.get(k) for k in ("qpos", "qvel", "qacc_warmstart", "ctrl")}
+    b.forward()
+    warm = dict(ncon=b.get("ncon"), con=b.get("contact"), qacc=b.get("qacc"))
+    for k, v in st.items():
+        b.set(k, v)                                  # rsim_set_array(RSIM_QPOS) clears the warm-start records
+    b.forward()
+    cold = dict(ncon=b.get("ncon"), con=b.get("contact"), qacc=b.get("qacc"))
+    assert np.array_equal(warm["ncon"], cold["ncon"]) and int((warm["ncon"] > 4).sum()) >= 10      # envs with finger / hand contacts beside the cube's four
+    worst = dict(dist=0.0, ang=0.0, pos=0.0, qacc=0.0)
+    for e in np.nonzero(warm["ncon"] > 0)[0]:
+        n = int(warm["ncon"][e])
+        w, c = warm["con"][e][:n].astype(np.float64), cold["con"][e][:n].astype(np.float64)
+        assert np.array_equal(w[:, 13:16], c[:, 13:16]), e                                           # geom pairs and dimensions, in order
+        worst["dist"] = max(worst["dist"], float(np.abs(w[:, 0] - c[:, 0]).max()))
+        worst["ang"] = max(worst["ang"], float(np.degrees(np.arccos(np.clip((w[:, 4:7] * c[:, 4:7]).sum(1), -1, 1))).max()))
+        worst["pos"] = max(worst["pos"], float(np.abs(w[:, 1:4] - c[:, 1:4]).max()))
+        worst["qacc"] = max(worst["qacc"], float(np.abs(warm["qacc"][e] - cold["qacc"][e]).max() / max(1.0, np.abs(cold["qacc"][e]).max())))
+    print("portal warm start vs cold run on the same states:", worst)
+    assert worst["dist"] < 5e-6 and worst["ang"] < 0.1 and worst["pos"] < 2e-3 and worst["qacc"] < 5e-3, worst

@@ -128,3 +128,77 @@ def test_recompile_reference_xml_is_deterministic():
     g, cfg, m = load_golden("seed0_gentle")
     # the golden blob carries no XML; recompile through the generator's path is covered by tools/gen_golden.py.
     assert m.npair > 100 and m.nmeshvert > 1000
+
+
+def _write_stl(path, verts, faces):
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"\0" * 80 + struct.pack("<I", len(faces)))
+        for fc in faces:
+            a, b, c = verts[fc[0]], verts[fc[1]], verts[fc[2]]
+            n = np.cross(b - a, c - a)
+            f.write(struct.pack("<12fH", *(n / max(1e-30, np.linalg.norm(n))), *a, *b, *c, 0))
+
+
+def _tessellated(kind):
+    """(verts, faces, closed-form volume, COM, principal inertia about the COM at unit density) of an off-centre, tessellated primitive."""
+    from scipy.spatial import ConvexHull
+    c = np.array([0.03, -0.02, 0.05])
+    if kind == "box":
+        h = np.array([0.04, 0.025, 0.07])
+        v = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=float) * h
+        vol = 8 * h.prod()
+        I = vol / 3.0 * np.array([h[1] ** 2 + h[2] ** 2, h[0] ** 2 + h[2] ** 2, h[0] ** 2 + h[1] ** 2])
+    elif kind == "cylinder":
+        r, hh, n = 0.03, 0.06, 720
+        a = 2 * np.pi * np.arange(n) / n
+        ring = np.stack([r * np.cos(a), r * np.sin(a)], 1)
+        v = np.vstack([np.c_[ring, np.full(n, -hh)], np.c_[ring, np.full(n, hh)]])
+        area = 0.5 * n * r * r * np.sin(2 * np.pi / n)                               # the inscribed n-gon, exactly
+        vol = area * 2 * hh
+        j = r * r * (2 + np.cos(2 * np.pi / n)) / 6.0                               # second polar moment of the n-gon per unit area: J / A
+        I = vol * np.array([j / 2 + hh * hh / 3, j / 2 + hh * hh / 3, j])
+    else:
+        r = 0.045
+        # icosphere by hull of many points on the sphere: compared with the sphere's closed form at the tessellation's accuracy
+        g = np.random.default_rng(0).standard_normal((4000, 3))
+        v = r * g / np.linalg.norm(g, axis=1, keepdims=True)
+        vol = 4.0 / 3.0 * np.pi * r ** 3
+        I = np.full(3, 0.4 * vol * r * r)
+    hull = ConvexHull(v)
+    faces = hull.simplices.copy()
+    cc = v.mean(0)
+    for k, fc in enumerate(faces):
+        if np.dot(np.cross(v[fc[1]] - v[fc[0]], v[fc[2]] - v[fc[0]]), v[fc[0]] - cc) < 0:
+            faces[k] = fc[::-1]
+    return v + c, faces, vol, c, I
+
+
+@pytest.mark.parametrize("kind,tol", (("box", 1e-6), ("cylinder", 1e-6), ("sphere", 1e-2)))
+def test_mesh_bodies_compile_to_closed_form_mass_properties(kind, tol, tmp_path):
+    """The mesh path every Panda / IIWA / Robotiq link and every PickPlace object takes (STL file -> vertices -> convex hull -> volume, centre of
+    mass, inertia -> body_mass / body_ipos / body_inertia / invweight0 of the compiled model), on tessellated primitives whose answers are known in
+    closed form: a box and a 720-gon prism exactly (the prism against the polygon's own area and second moment), a 4000-point sphere to the
+    accuracy of its tessellation.  Before round 3 this path was checked on a unit cube only."""
+    v, f, vol, com, I = _tessellated(kind)
+    _write_stl(tmp_path / "shape.stl", v.astype(np.float32).astype(np.float64), f)
+    density = 730.0
+    xml = f"""<mujoco><compiler meshdir="{tmp_path}"/><asset><mesh name="m" file="shape.stl"/></asset><worldbody>
+      <body name="b" pos="0.1 0.2 0.3"><joint type="free"/><geom name="g" type="mesh" mesh="m" density="{density}"/></body></worldbody></mujoco>"""
+    m = mjcf.compile_mjcf(xml)
+    b = m.name2id("body", "b")
+    assert m.body_mass[b] == pytest.approx(density * vol, rel=max(tol, 2e-6))
+    # MuJoCo re-centres a mesh on its centre of mass and aligns it with its principal axes; however the compiler expresses that, the body's inertial
+    # frame must sit at the shape's centre of mass (body frame) with the principal moments of the closed form
+    assert np.abs(m.body_ipos[b] - com).max() < max(tol, 2e-6) * 0.1
+    assert np.sort(m.body_inertia[b]) == pytest.approx(np.sort(density * I), rel=max(tol, 5e-6))
+    # free body: translational inverse weight 1 / m, rotational = mean of 1 / I
+    assert m.body_invweight0[b][0] == pytest.approx(1.0 / (density * vol), rel=max(tol, 2e-6))
+    assert m.body_invweight0[b][1] == pytest.approx(np.mean(1.0 / (density * I)), rel=max(tol, 5e-6))
+    # the hull the narrow phase scans: its vertices span the shape (support along +-x, +-y, +-z in the geom frame equals the extents about the COM)
+    g = m.name2id("geom", "g")
+    adr, num = int(m.mesh_vertadr[m.geom_dataid[g]]), int(m.mesh_vertnum[m.geom_dataid[g]])
+    hv = np.asarray(m.mesh_vert).reshape(-1, 3)[adr:adr + num]
+    R = mjcf.quat2mat(m.geom_quat[g])
+    world = m.geom_pos[g] + hv @ R.T                       # hull vertices in the body frame
+    assert np.abs(world.max(0) - v.max(0)).max() < 2e-6 + tol * 0.05 and np.abs(world.min(0) - v.min(0)).max() < 2e-6 + tol * 0.05

@@ -8,7 +8,9 @@ robosuite issues through utils/binding_utils.py:1059-1192 (mj_forward / mj_step1
 tests/test_hip_shim_trace.py replays the trace on the GPU box (no reference checkout there) through HipShimBackend, call by call from the
 recorded inputs, and compares every returned array.
 
-Writes tests/golden/shim_trace_lift.npz.   Usage: python tools/gen_shim_trace.py [n_steps]
+Writes tests/golden/shim_trace_lift.npz.   Usage: python tools/gen_shim_trace.py [n_steps] [--playback]
+--playback: the trace of the reference's action-playback determinism test instead (get_xml -> reset_from_xml_string -> set_state_from_flattened ->
+replay; tests/golden/shim_trace_lift_playback.npz).
 """
 import os
 import sys
@@ -74,7 +76,7 @@ class TracingBackend:
 
 
 if __name__ == "__main__":
-    n_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    n_steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10
     shim.install(TracingBackend)
     import robosuite as suite
 
@@ -82,14 +84,44 @@ if __name__ == "__main__":
                      reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=0)
     env.reset()
     rng = np.random.default_rng(10**6)
-    for t in range(n_steps):
-        env.step(rng.uniform(-1, 1, env.action_dim))
-    out = dict(events=np.array(EVENTS, dtype=np.int32), ops=np.array(OPS), pre=np.array(PRE), post=np.array(POST), n_models=len(MODELS))
+    playback = "--playback" in sys.argv
+    extra_out = {}
+    if not playback:
+        for t in range(n_steps):
+            env.step(rng.uniform(-1, 1, env.action_dim))
+    else:
+        # the reference's own determinism test (tests/test_environments/test_action_playback.py:17-71): record states, then rebuild the env from
+        # sim.model.get_xml() (binding_utils.py:504-509 -> mj_saveLastXML), restore the first flattened state (binding_utils.py:1172-1184) and replay the
+        # actions; the replayed states must equal the recorded ones BITWISE.  Only the playback half is traced (new model instance included).
+        xml0 = env.sim.model.get_xml()
+        state0 = np.array(env.sim.get_state().flatten())
+
+        def restore():
+            env.reset_from_xml_string(xml0)
+            env.sim.reset()
+            env.sim.set_state_from_flattened(state0)
+            env.sim.forward()
+
+        restore()                                        # "trick for ensuring that we can play MuJoCo demonstrations back deterministically" (:40-45)
+        acts = [0.1 * rng.uniform(-1, 1, env.action_dim) for _ in range(n_steps)]
+        states = []
+        for a in acts:
+            env.step(a); states.append(np.array(env.sim.get_state().flatten()))
+        env.reset()
+        del EVENTS[:]; ROWS.clear()                      # keep the model blobs (indices stay valid), trace from here on
+        restore()
+        replay = []
+        for a in acts:
+            env.step(a); replay.append(np.array(env.sim.get_state().flatten()))
+        same = all(np.array_equal(a, b) for a, b in zip(states, replay))
+        assert same, "playback over the shim (oracle backend) is not bitwise"
+        extra_out = dict(playback_states=np.array(replay), playback_bitwise=np.array(int(same)), state0=state0)
+    out = dict(events=np.array(EVENTS, dtype=np.int32), ops=np.array(OPS), pre=np.array(PRE), post=np.array(POST), n_models=len(MODELS), **extra_out)
     for i, b in enumerate(MODELS):
         out[f"model{i}"] = b
     for (op, mi), rows in ROWS.items():
         out[f"rows_{op}_{mi}"] = np.stack(rows)
-    path = os.path.join(ROOT, "tests", "golden", "shim_trace_lift.npz")
+    path = os.path.join(ROOT, "tests", "golden", "shim_trace_lift_playback.npz" if playback else "shim_trace_lift.npz")
     np.savez_compressed(path, **out)
     names = {i: MODELS[i].size for i in range(len(MODELS))}
     print("events", len(EVENTS), {OPS[k]: int((out["events"][:, 0] == k).sum()) for k in range(len(OPS))}, "models", names, "bytes", os.path.getsize(path))
