@@ -61,6 +61,7 @@ typedef struct {
   blob_entry *entries;
   /* sizes */
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nmesh, npair, nmocap, cone, iterations, solver;
+  int nsensor, *sensor_type, *sensor_objid, *sensor_dim;   /* force (0) / torque (1) sensors at a site; anything else reads zero */
   double timestep, density, viscosity, impratio, tolerance, meaninertia;
   double *gravity, *wind;
   int *body_parentid, *body_rootid, *body_weldid, *body_mocapid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
@@ -126,7 +127,8 @@ rso_model *rso_model_create(const void *blob, size_t len) {
   PI_(actuator_trnid); PI_(actuator_biastype); PI_(actuator_ctrllimited); PI_(actuator_forcelimited);
   PD_(actuator_gear); PD_(actuator_gainprm); PD_(actuator_biasprm); PD_(actuator_ctrlrange); PD_(actuator_forcerange);
   PI_(pair_geom1); PI_(pair_geom2);
-  GI(ntendon); GI(neq);
+  GI(ntendon); GI(neq); GI(nsensor);
+  PI_(sensor_type); PI_(sensor_objid); PI_(sensor_dim);
   PI_(tendon_adr); PI_(tendon_num); PI_(wrap_objid); PI_(tendon_limited); PI_(eq_obj1id);
   PD_(wrap_prm); PD_(tendon_range); PD_(tendon_margin); PD_(tendon_solref_lim); PD_(tendon_solimp_lim); PD_(tendon_length0); PD_(tendon_invweight0);
   PD_(eq_data); PD_(eq_solref); PD_(eq_solimp);
@@ -169,6 +171,8 @@ typedef struct {
   double *qpos, *qvel, *qacc, *qacc_warmstart, *ctrl, *qfrc_applied, *mocap_pos, *mocap_quat;
   double *xpos, *xquat, *xmat, *xipos, *ximat, *geom_xpos, *geom_xmat, *site_xpos, *site_xmat, *xanchor, *xaxis;
   double *subtree_com, *cinert, *crb, *cdof, *cdof_dot, *cvel, *cacc, *cfrc;
+  double *cfrc_int, *cfrc_ext, *sensordata;   /* sensor_acc() */
+  int nsensordata;
   double *qM, *qL, *qLD; /* dense M, chol(M), chol(M + h*D) */
   double *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qfrc_constraint, *actuator_force;
   int ncon, nefc;
@@ -198,6 +202,9 @@ rso_data *rso_data_create(rso_model *m) {
   d->xanchor = dalloc(3 * m->njnt); d->xaxis = dalloc(3 * m->njnt);
   d->subtree_com = dalloc(3 * nb); d->cinert = dalloc(10 * nb); d->crb = dalloc(10 * nb); d->cdof = dalloc(6 * nv); d->cdof_dot = dalloc(6 * nv);
   d->cvel = dalloc(6 * nb); d->cacc = dalloc(6 * nb); d->cfrc = dalloc(6 * nb);
+  d->cfrc_int = dalloc(6 * nb); d->cfrc_ext = dalloc(6 * nb);
+  for (int i = 0; i < m->nsensor; i++) d->nsensordata += m->sensor_dim[i];
+  d->sensordata = dalloc(d->nsensordata);
   d->qM = dalloc(nv * nv); d->qL = dalloc(nv * nv); d->qLD = dalloc(nv * nv);
   d->qfrc_bias = dalloc(nv); d->qfrc_passive = dalloc(nv); d->qfrc_actuator = dalloc(nv); d->qfrc_smooth = dalloc(nv); d->qacc_smooth = dalloc(nv);
   d->qfrc_constraint = dalloc(nv); d->actuator_force = dalloc(m->nu);
@@ -210,7 +217,8 @@ void rso_data_free(rso_data *d) {
   double **p[] = {&d->qpos, &d->qvel, &d->qacc, &d->qacc_warmstart, &d->ctrl, &d->qfrc_applied, &d->mocap_pos, &d->mocap_quat, &d->xpos, &d->xquat, &d->xmat,
                   &d->xipos, &d->ximat, &d->geom_xpos, &d->geom_xmat, &d->site_xpos, &d->site_xmat, &d->xanchor, &d->xaxis, &d->subtree_com, &d->cinert,
                   &d->crb, &d->cdof, &d->cdof_dot, &d->cvel, &d->cacc, &d->cfrc, &d->qM, &d->qL, &d->qLD, &d->qfrc_bias, &d->qfrc_passive, &d->qfrc_actuator,
-                  &d->qfrc_smooth, &d->qacc_smooth, &d->qfrc_constraint, &d->actuator_force, &d->efc_J, &d->efc_AR, &d->efc_MinvJT};
+                  &d->qfrc_smooth, &d->qacc_smooth, &d->qfrc_constraint, &d->actuator_force, &d->efc_J, &d->efc_AR, &d->efc_MinvJT, &d->cfrc_int, &d->cfrc_ext,
+                  &d->sensordata};
   for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
   free(d);
 }
@@ -1704,6 +1712,74 @@ static void euler(rso_data *d) {
   free(qa);
 }
 
+/* Acceleration-stage sensors: mj_sensorAcc -> mj_rnePostConstraint [3P] for the two sensor types robosuite's grippers define
+ * (models/assets/grippers/xml: <force site="ft_frame"/>, <torque site="ft_frame"/>; read by robots/robot.py:739-751, 795-815).
+ *   cfrc_ext[b]  = wrench the contacts apply to body b (contact force in the contact frame -> world, -on geom1's body, +on geom2's), about the
+ *                  subtree COM of b's kinematic tree (the frame of every c-quantity here);
+ *   cacc[b]      = cacc[parent] + cdof_dot qvel + cdof qacc, cacc[world] = -gravity  (the acceleration the solver ended on, not zero as in rne_bias);
+ *   cfrc_int[b]  = sum over b's subtree of (cinert cacc + cvel x* (cinert cvel) - cfrc_ext): what b's parent exerts on b through their joint;
+ *   force sensor = linear part of cfrc_int[site body] in the site frame; torque sensor = its moment about the site, in the site frame.
+ * Equality (connect / weld) forces would enter cfrc_ext too; the models of this path have none.  Evaluated by forward() and step2() before the
+ * integrator moves the state, as mj_forward / mj_step2 do. */
+static void sensor_acc(rso_data *d) {
+  rso_model *m = d->m;
+  if (m->nsensor == 0) return;
+  int nb = m->nbody;
+  memset(d->cfrc_ext, 0, sizeof(double) * 6 * nb);
+  for (int i = 0; i < d->ncon; i++) {
+    rso_contact *c = &d->contact[i];
+    if (c->efc_address < 0) continue;
+    const double *f = d->efc_force + c->efc_address;
+    double fw[3] = {0, 0, 0}, tw[3] = {0, 0, 0};
+    for (int k = 0; k < 3 && k < c->dim; k++) for (int r = 0; r < 3; r++) fw[r] += f[k] * c->frame[3 * k + r];
+    for (int k = 3; k < c->dim; k++) for (int r = 0; r < 3; r++) tw[r] += f[k] * c->frame[3 * (k - 3) + r];
+    for (int side = 0; side < 2; side++) {
+      int b = m->geom_bodyid[side ? c->geom2 : c->geom1];
+      if (b == 0) continue;
+      double off[3], t[3], sgn = side ? 1.0 : -1.0;
+      for (int k = 0; k < 3; k++) off[k] = c->pos[k] - d->subtree_com[3 * m->body_rootid[b] + k];
+      cross3(t, off, fw);
+      for (int k = 0; k < 3; k++) { d->cfrc_ext[6 * b + k] += sgn * (tw[k] + t[k]); d->cfrc_ext[6 * b + 3 + k] += sgn * fw[k]; }
+    }
+  }
+  memset(d->cacc, 0, 6 * sizeof(double));
+  for (int k = 0; k < 3; k++) d->cacc[3 + k] = -m->gravity[k];
+  memset(d->cfrc_int, 0, 6 * sizeof(double));
+  for (int b = 1; b < nb; b++) {
+    double *ca = d->cacc + 6 * b, t1[6], t2[6], t3[6];
+    memcpy(ca, d->cacc + 6 * m->body_parentid[b], 6 * sizeof(double));
+    for (int i = m->body_dofadr[b]; i >= 0 && i < m->body_dofadr[b] + m->body_dofnum[b]; i++)
+      for (int r = 0; r < 6; r++) ca[r] += d->cdof_dot[6 * i + r] * d->qvel[i] + d->cdof[6 * i + r] * d->qacc[i];
+    mul_inert_vec(t1, d->cinert + 10 * b, ca);
+    mul_inert_vec(t2, d->cinert + 10 * b, d->cvel + 6 * b);
+    cross_force(t3, d->cvel + 6 * b, t2);
+    for (int r = 0; r < 6; r++) d->cfrc_int[6 * b + r] = t1[r] + t3[r] - d->cfrc_ext[6 * b + r];
+  }
+  for (int b = nb - 1; b > 0; b--)
+    if (m->body_parentid[b] > 0)
+      for (int r = 0; r < 6; r++) d->cfrc_int[6 * m->body_parentid[b] + r] += d->cfrc_int[6 * b + r];
+  int adr = 0;
+  for (int i = 0; i < m->nsensor; i++) {
+    int dim = m->sensor_dim[i], type = m->sensor_type[i], site = m->sensor_objid[i];
+    for (int k = 0; k < dim; k++) d->sensordata[adr + k] = 0;
+    if ((type == 0 || type == 1) && site >= 0 && dim == 3) {
+      int b = m->site_bodyid[site];
+      const double *w = d->cfrc_int + 6 * b, *R = d->site_xmat + 9 * site;
+      if (type == 0) matT_vec3(d->sensordata + adr, R, w + 3);
+      else {
+        double off[3], t[3], tq[3];
+        for (int k = 0; k < 3; k++) off[k] = d->site_xpos[3 * site + k] - d->subtree_com[3 * m->body_rootid[b] + k];
+        cross3(t, off, w + 3);
+        for (int k = 0; k < 3; k++) tq[k] = w[k] - t[k];
+        matT_vec3(d->sensordata + adr, R, tq);
+      }
+    }
+    adr += dim;
+  }
+}
+int rso_nsensordata(rso_data *d) { return d->nsensordata; }
+const double *rso_sensordata(rso_data *d) { return d->sensordata; }
+
 /* mj_step1 / mj_step2 / mj_forward / mj_step (utils/binding_utils.py:1089-1107) */
 static void fwd_position(rso_data *d) { kinematics(d); com_pos(d); crb(d); collision(d); make_constraint(d); }
 static void fwd_velocity(rso_data *d) {
@@ -1711,8 +1787,8 @@ static void fwd_velocity(rso_data *d) {
   /* efc_vel / aref depend on qvel only through make_constraint, already evaluated with current qvel */
 }
 void rso_step1(rso_data *d) { fwd_position(d); fwd_velocity(d); }
-void rso_step2(rso_data *d) { fwd_actuation(d); fwd_acceleration(d); fwd_constraint(d); euler(d); }
-void rso_forward(rso_data *d) { fwd_position(d); fwd_velocity(d); fwd_actuation(d); fwd_acceleration(d); fwd_constraint(d); }
+void rso_step2(rso_data *d) { fwd_actuation(d); fwd_acceleration(d); fwd_constraint(d); sensor_acc(d); euler(d); }
+void rso_forward(rso_data *d) { fwd_position(d); fwd_velocity(d); fwd_actuation(d); fwd_acceleration(d); fwd_constraint(d); sensor_acc(d); }
 /* The solver's own objective at an acceleration `a` of the caller's, for the constraint rows of the last forward():
  *   cost(a) = 1/2 (a - a_smooth)' M (a - a_smooth) + sum_i s_i(J a - aref), and (if grad != NULL) its gradient M a - qfrc_smooth - J' f(a).
  * Test infrastructure: two accelerations are compared in the metric the solver minimises -- the minimiser is unique, but where the Hessian is nearly
@@ -1779,6 +1855,7 @@ double *rso_data_field(rso_data *d, const char *name, int *count) {
   F(subtree_com, 3 * m->nbody) F(cinert, 10 * m->nbody) F(cdof, 6 * m->nv) F(cvel, 6 * m->nbody) F(cdof_dot, 6 * m->nv)
   F(qM, m->nv * m->nv) F(qfrc_bias, m->nv) F(qfrc_passive, m->nv) F(qfrc_actuator, m->nv) F(qfrc_smooth, m->nv) F(qacc_smooth, m->nv)
   F(qfrc_constraint, m->nv) F(actuator_force, m->nu) F(efc_J, d->nefc * m->nv)
+  F(sensordata, d->nsensordata) F(cfrc_int, 6 * m->nbody) F(cfrc_ext, 6 * m->nbody) F(cacc, 6 * m->nbody)
 #undef F
 #define FA(n, c) if (!strcmp(name, #n)) { *count = (c); return d->n; }
   FA(efc_pos, d->nefc) FA(efc_R, d->nefc) FA(efc_D, d->nefc) FA(efc_aref, d->nefc) FA(efc_force, d->nefc) FA(efc_vel, d->nefc) FA(efc_b, d->nefc)

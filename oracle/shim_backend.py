@@ -11,7 +11,6 @@ class OracleBackend:
         self.flat = flat
         self.om = OracleModel(mjcf.to_blob(flat))
         self.d = OracleData(self.om)
-        self._sensordata = np.zeros(int(flat.arrays["sensor_dim"].sum()) if flat.nsensor else 0)
 
     def model_array(self, name):
         try:
@@ -23,8 +22,6 @@ class OracleBackend:
         pass
 
     def data_array(self, name):
-        if name == "sensordata":
-            return self._sensordata
         return self.d.field(name)
 
     def forward(self):

@@ -742,6 +742,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   b->db.mprc = nullptr;
   if (!getenv("RSIM_NO_MPR_WARMSTART") && m->npair > 0 && dalloc(&b->db.mprc, (size_t)B * m->npair * 12)) return 1;
   b->db.mprc_portal = getenv("RSIM_NO_MPR_PORTAL_WARMSTART") ? 0 : 1;
+  b->db.bpl = nullptr;
+  if (m->npair > 0 && m->cg.size() <= 64 && dalloc(&b->db.bpl, (size_t)B * 320)) return 1;   // broadphase pair list (lane = colliding geom: 64 at most)
   b->db.ft_rw = b->d_ft;
   DModel& dm = b->dm;
   dm.nq = m->nq; dm.nv = m->nv; dm.nu = m->nu; dm.nbody = m->nbody; dm.njnt = m->njnt; dm.ncg = ncg; dm.nsite = m->nsite; dm.npair = m->npair;
@@ -753,6 +755,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.meaninertia = m->meaninertia;
   dm.newton_ns = getenv("RSIM_NEWTON_NS") ? (float)atof(getenv("RSIM_NEWTON_NS")) : RSIM_NEWTON_NS;
   dm.newton_na = getenv("RSIM_NEWTON_NA") ? (float)atof(getenv("RSIM_NEWTON_NA")) : RSIM_NEWTON_NA;
+  dm.bp_reach = getenv("RSIM_BP_REACH") ? (float)atof(getenv("RSIM_BP_REACH")) : RSIM_BP_REACH;
+  dm.newton_ls = getenv("RSIM_NEWTON_LS") ? (float)atof(getenv("RSIM_NEWTON_LS")) : RSIM_NEWTON_LS;
   dm.newton_ng = getenv("RSIM_NEWTON_NG") ? (float)atof(getenv("RSIM_NEWTON_NG")) : RSIM_NEWTON_NG;
   if (m->multijoint) { int r = fail("rsim_batch_create: bodies with more than one joint are not supported by the fused kernel"); delete b; return r; }
 
@@ -819,6 +823,7 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
   hipFree(b->d_cm);
   if (b->db.mprc) hipFree(b->db.mprc);
+  if (b->db.bpl) hipFree(b->db.bpl);
   hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_ft0); if (b->d_obsprog) hipFree(b->d_obsprog);
   if (b->d_bank) hipFree(b->d_bank); if (b->d_bank_tag) hipFree(b->d_bank_tag); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); if (b->d_ft_base) hipFree(b->d_ft_base); hipFree(b->d_mesh); hipFree(b->d_mask);
   if (b->d_order) hipFree(b->d_order); if (b->d_cost) hipFree(b->d_cost);

@@ -130,7 +130,8 @@ struct DModel {
   int ntendon, neq;   // fixed tendons, equality/tendon constraints
   int iterations, ls_iterations, cone, solver;
   float tolerance, meaninertia;
-  float newton_ns, newton_na, newton_ng;   // fp32 stopping rules of the Newton solver (solve_newton): relative / absolute step floor, gradient noise factor
+  float bp_reach;      // broadphase active pair list: bounding-sphere gap (m) up to which a pair is listed; 0: every pair every substep
+  float newton_ns, newton_na, newton_ng, newton_ls;   // fp32 stopping rules of the Newton solver (solve_newton): relative / absolute step floor, gradient noise factor
   const int* it;
   const float* ft;
   const float* ft0;            // shared copy of the float table (read for every field no env has overridden)
@@ -174,6 +175,7 @@ struct DBatch {
   long long cm_stride;   // bytes between the blocks of consecutive envs, 0 = no env has its own block yet
   int* overflow;         // [B] contacts + constraint rows dropped for lack of capacity (null = not counted)
   int mprc_portal;       // 0: keep only the (exact) separating-direction warm start
+  int* bpl;              // [B][5][64] or null: broadphase pair list (rsim_step.hip collision(): sphere centres at build time, packed pair constants, pair indices)
   float* mprc;           // [B][npair][12] or null: the separating direction (x, y, z, valid) each candidate pair's last convex narrow-phase run ended on
                          // (warm start of the next substep's run, see convex_convex); zeroed whenever the host writes positions
   const int* order;      // [B] or null (identity)
@@ -190,7 +192,13 @@ struct DBatch {
 // than 1e-5 of its value + 1e-5 ends the solve.  On 78 reached states (the Newton-heaviest of a launch included) forces and accelerations against the
 // oracle are unchanged to the printed digits (5.7e-4 / 3.3e-4 of the env's largest, same as without the rule), the p99 of the iterations per control step
 // drops from 126 to 85 and the maximum from 238 to 140.  The gradient-noise rule (NG) made no difference and stays off.
+#ifndef RSIM_NEWTON_LS
+#define RSIM_NEWTON_LS 1.0f    // line search: a correction of alpha below this multiple of the step rule's threshold ends it (0: relative 1e-6 only)
+#endif
 #ifndef RSIM_NEWTON_NS
+#ifndef RSIM_BP_REACH
+#define RSIM_BP_REACH 0.04f   // broadphase active pair list (rsim_step.hip collision()): listed up to this bounding-sphere gap; valid while no geom centre moved reach / 2
+#endif
 #define RSIM_NEWTON_NS 1e-5f
 #define RSIM_NEWTON_NA 1e-5f
 #define RSIM_NEWTON_NG 0.f

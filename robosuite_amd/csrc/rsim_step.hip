@@ -2086,65 +2086,126 @@ struct Sim {
     return dot(dd, dd);
   }
 
-  __device__ __forceinline__ void collision() {
+  // Active pair list of the broadphase.  Of the ~140 candidate pairs of the Lift model some 90 are never closer than decimetres (arm links against
+  // the floor, the mount against the cube ...), yet every substep tested all of them: three rows of 64 lanes, each row paying its full path (13 % of a
+  // contact-free substep).  When the list is (re)built, every pair whose bounding spheres (sphere and plane) are within `reach` of touching goes
+  // onto it, and lane g remembers where the centre of geom g's bounding sphere was.  While no centre has moved by more than reach / 2 since, a pair
+  // that is NOT on the list still has a positive gap, i.e. still fails the first test of the broadphase -- so the other substeps test ONE row,
+  // lane i = i-th listed pair (in pair order: candidate order, and with it the contact order, is unchanged) and get exactly the candidates the full
+  // rows would give.  No velocity bound is involved: the displacement is measured every substep (an episode reset inside the launch is just a
+  // large displacement).  More than 64 near pairs: no list, full rows.
+  // The list lives in global memory (DBatch.bpl, 5 x 64 words per env, L2-resident): five more registers alive across the whole substep loop cost
+  // the 256-register build more in spills than the list saves.
+  int act_n = -1;                       // pairs on the list (-1: none)
+  int __attribute__((address_space(1)))* bpl = nullptr;   // [0..2][lane g]: centre of geom g's bounding sphere when the list was built; [3][lane i]: packed
+                                                          // constants (geom1 | geom2 << 8 | enabled << 16) of the i-th listed pair; [4][lane i]: its index
+  // one candidate pair: does it pass the broadphase now (pass), could it within `reach` (near: bounding spheres / plane distance only)
+  __device__ __forceinline__ void bp_test(int pr, float reach, bool& pass, bool& near) const {
+    pass = false; near = false;
+    // all constants of the pair first, as eight 16-byte global loads in flight at once (they used to be LDS reads issued where needed; from
+    // global memory three dependent stages per round would be three round trips)
+    const int g1 = pr & 255, g2 = (pr >> 8) & 255;   // lanes without a pair read geom 0
+    typedef const v4f __attribute__((address_space(1)))* gc4;
+    gc4 st1 = (gc4)(cmf(MK_gst)->gst + 8 * g1), st2 = (gc4)(cmf(MK_gst)->gst + 8 * g2);
+    gc4 kp1 = (gc4)(cmf(MK_gcap)->gcap + 8 * g1), kp2 = (gc4)(cmf(MK_gcap)->gcap + 8 * g2);
+    const v4f s1a = st1[0], s1b = st1[1], s2a = st2[0], s2b = st2[1], k1a = kp1[0], k1b = kp1[1], k2a = kp2[0], k2b = kp2[1];
+    const int t1 = cm->gtype[g1];
+    if ((pr >> 16) & 1) {
+      const float margin = fmaxf(s1b[3], s2b[3]);
+      const V3 c2 = ld3(sm.gcen + 3 * g2);
+      const M3 R2 = ldm(sm.gmat + 9 * g2);
+      const V3 h2 = v3(s2a[0], s2a[1], s2a[2]), o2 = ld3(sm.gpos + 3 * g2) + mv(R2, v3(s2a[3], s2b[0], s2b[1]));
+      if (t1 == G_PLANE) {
+        const V3 nrm = v3(sm.gmat[9 * g1 + 2], sm.gmat[9 * g1 + 5], sm.gmat[9 * g1 + 8]);
+        const V3 pp = ld3(sm.gpos + 3 * g1);
+        const float gap = dot(c2 - pp, nrm) - s2b[2] - margin;
+        pass = gap <= 0.f;
+        near = gap <= reach;
+        if (pass) pass = dot(o2 - pp, nrm) - (h2.x * fabsf(dot(nrm, col(R2, 0))) + h2.y * fabsf(dot(nrm, col(R2, 1))) + h2.z * fabsf(dot(nrm, col(R2, 2)))) <= margin;
+      } else {
+        const V3 rel = c2 - ld3(sm.gcen + 3 * g1);
+        const float bound = s1b[2] + s2b[2] + margin, d2 = dot(rel, rel);
+        pass = d2 <= bound * bound;
+        near = d2 <= (bound + reach) * (bound + reach);
+        if (pass) {
+          const M3 R1 = ldm(sm.gmat + 9 * g1);
+          const V3 h1 = v3(s1a[0], s1a[1], s1a[2]), o1 = ld3(sm.gpos + 3 * g1) + mv(R1, v3(s1a[3], s1b[0], s1b[1]));
+          const M3 C = mtm(R1, R2);  // C[i][j] = A_i . B_j
+          const V3 tt = o2 - o1, ta = mtv(R1, tt), tb = mtv(R2, tt);
+          const float sepa = fmaxf(fmaxf(fabsf(ta.x) - (h1.x + h2.x * fabsf(C.m[0]) + h2.y * fabsf(C.m[1]) + h2.z * fabsf(C.m[2])),
+                                         fabsf(ta.y) - (h1.y + h2.x * fabsf(C.m[3]) + h2.y * fabsf(C.m[4]) + h2.z * fabsf(C.m[5]))),
+                                   fabsf(ta.z) - (h1.z + h2.x * fabsf(C.m[6]) + h2.y * fabsf(C.m[7]) + h2.z * fabsf(C.m[8])));
+          const float sepb = fmaxf(fmaxf(fabsf(tb.x) - (h2.x + h1.x * fabsf(C.m[0]) + h1.y * fabsf(C.m[3]) + h1.z * fabsf(C.m[6])),
+                                         fabsf(tb.y) - (h2.y + h1.x * fabsf(C.m[1]) + h1.y * fabsf(C.m[4]) + h1.z * fabsf(C.m[7]))),
+                                   fabsf(tb.z) - (h2.z + h1.x * fabsf(C.m[2]) + h1.y * fabsf(C.m[5]) + h1.z * fabsf(C.m[8])));
+          pass = fmaxf(sepa, sepb) <= margin + 1e-6f;
+          // bounding capsules (mesh hulls): distance between the two axis segments against the radii
+          if (pass && k1b[2] >= 0.f && k2b[2] >= 0.f) {
+            const V3 gp1 = ld3(sm.gpos + 3 * g1), gp2 = ld3(sm.gpos + 3 * g2);
+            const V3 p1 = gp1 + mv(R1, v3(k1a[0], k1a[1], k1a[2])), q1 = gp1 + mv(R1, v3(k1a[3], k1b[0], k1b[1])),
+                     p2 = gp2 + mv(R2, v3(k2a[0], k2a[1], k2a[2])), q2 = gp2 + mv(R2, v3(k2a[3], k2b[0], k2b[1]));
+            const float rch = k1b[2] + k2b[2] + margin + 1e-6f;
+            pass = segment_dist2(p1, q1, p2, q2) <= rch * rch;
+          }
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void collision(int sub_left) {
     const LaneConst K = fetchK();
     if (lane == 0) sm.ncon = 0;
     // broadphase: lane p tests candidate pair p (bounding spheres, then the 6 face axes of the two oriented boxes);
     // order-preserving compaction of the survivors
     int ncand = 0;
+    bool valid = act_n >= 0;
+    typedef const float __attribute__((address_space(1)))* gcf1;
+    if (valid) {
+      // a plane that is not fixed to the world can tilt without its centre moving: such a geom counts as moved
+      gcf1 c0 = (gcf1)bpl;
+      const V3 d = ld3(sm.gcen + 3 * (lane < m.ncg ? lane : 0)) - v3(c0[lane], c0[64 + lane], c0[128 + lane]);
+      const bool moved = lane < m.ncg && (dot(d, d) > 0.25f * m.bp_reach * m.bp_reach || (cm->gtype[lane] == G_PLANE && (K.ginfo & 255) != 0));
+      valid = !__ballot(moved);
+    }
+    if (valid) {
+      // ---- one row over the listed pairs
+      const int pr = bpl[192 + lane], pi = bpl[256 + lane];
+      bool pass, near;
+      bp_test(lane < act_n ? pr : 0, 0.f, pass, near);
+      pass = pass && lane < act_n;
+      const u64 mk = __ballot(pass);
+      if (pass) sm.u.b.cand[__popcll(mk & lanemask_lt(lane))] = pi;
+      ncand = __popcll(mk);
+    } else {
+      // ---- all rows; with a list to build: the near pairs, compacted in pair order
+      const bool build = bpl && m.bp_reach > 0.f && sub_left > 1;
+      int na = 0;
+      int* alist = (int*)sm.u.b.poly;   // 64 pair indices (the clip polygons are not in use during the broadphase)
 #pragma unroll
-    for (int t = 0; t < NPT; t++) {
-      if (64 * t >= m.npair) break;
-      const int pr = K.pair[t];
-      bool pass = false;
-      // all constants of the pair first, as eight 16-byte global loads in flight at once (they used to be LDS reads issued where needed; from
-      // global memory three dependent stages per round would be three round trips)
-      const int g1 = pr & 255, g2 = (pr >> 8) & 255;   // lanes without a pair read geom 0
-      typedef const v4f __attribute__((address_space(1)))* gc4;
-      gc4 st1 = (gc4)(cmf(MK_gst)->gst + 8 * g1), st2 = (gc4)(cmf(MK_gst)->gst + 8 * g2);
-      gc4 kp1 = (gc4)(cmf(MK_gcap)->gcap + 8 * g1), kp2 = (gc4)(cmf(MK_gcap)->gcap + 8 * g2);
-      const v4f s1a = st1[0], s1b = st1[1], s2a = st2[0], s2b = st2[1], k1a = kp1[0], k1b = kp1[1], k2a = kp2[0], k2b = kp2[1];
-      const int t1 = cm->gtype[g1];
-      if ((pr >> 16) & 1) {
-        const float margin = fmaxf(s1b[3], s2b[3]);
-        const V3 c2 = ld3(sm.gcen + 3 * g2);
-        const M3 R2 = ldm(sm.gmat + 9 * g2);
-        const V3 h2 = v3(s2a[0], s2a[1], s2a[2]), o2 = ld3(sm.gpos + 3 * g2) + mv(R2, v3(s2a[3], s2b[0], s2b[1]));
-        if (t1 == G_PLANE) {
-          const V3 nrm = v3(sm.gmat[9 * g1 + 2], sm.gmat[9 * g1 + 5], sm.gmat[9 * g1 + 8]);
-          const V3 pp = ld3(sm.gpos + 3 * g1);
-          pass = dot(c2 - pp, nrm) - s2b[2] <= margin;
-          if (pass) pass = dot(o2 - pp, nrm) - (h2.x * fabsf(dot(nrm, col(R2, 0))) + h2.y * fabsf(dot(nrm, col(R2, 1))) + h2.z * fabsf(dot(nrm, col(R2, 2)))) <= margin;
-        } else {
-          const V3 rel = c2 - ld3(sm.gcen + 3 * g1);
-          const float bound = s1b[2] + s2b[2] + margin;
-          pass = dot(rel, rel) <= bound * bound;
-          if (pass) {
-            const M3 R1 = ldm(sm.gmat + 9 * g1);
-            const V3 h1 = v3(s1a[0], s1a[1], s1a[2]), o1 = ld3(sm.gpos + 3 * g1) + mv(R1, v3(s1a[3], s1b[0], s1b[1]));
-            const M3 C = mtm(R1, R2);  // C[i][j] = A_i . B_j
-            const V3 tt = o2 - o1, ta = mtv(R1, tt), tb = mtv(R2, tt);
-            const float sepa = fmaxf(fmaxf(fabsf(ta.x) - (h1.x + h2.x * fabsf(C.m[0]) + h2.y * fabsf(C.m[1]) + h2.z * fabsf(C.m[2])),
-                                           fabsf(ta.y) - (h1.y + h2.x * fabsf(C.m[3]) + h2.y * fabsf(C.m[4]) + h2.z * fabsf(C.m[5]))),
-                                     fabsf(ta.z) - (h1.z + h2.x * fabsf(C.m[6]) + h2.y * fabsf(C.m[7]) + h2.z * fabsf(C.m[8])));
-            const float sepb = fmaxf(fmaxf(fabsf(tb.x) - (h2.x + h1.x * fabsf(C.m[0]) + h1.y * fabsf(C.m[3]) + h1.z * fabsf(C.m[6])),
-                                           fabsf(tb.y) - (h2.y + h1.x * fabsf(C.m[1]) + h1.y * fabsf(C.m[4]) + h1.z * fabsf(C.m[7]))),
-                                     fabsf(tb.z) - (h2.z + h1.x * fabsf(C.m[2]) + h1.y * fabsf(C.m[5]) + h1.z * fabsf(C.m[8])));
-            pass = fmaxf(sepa, sepb) <= margin + 1e-6f;
-            // bounding capsules (mesh hulls): distance between the two axis segments against the radii
-            if (pass && k1b[2] >= 0.f && k2b[2] >= 0.f) {
-              const V3 gp1 = ld3(sm.gpos + 3 * g1), gp2 = ld3(sm.gpos + 3 * g2);
-              const V3 p1 = gp1 + mv(R1, v3(k1a[0], k1a[1], k1a[2])), q1 = gp1 + mv(R1, v3(k1a[3], k1b[0], k1b[1])),
-                       p2 = gp2 + mv(R2, v3(k2a[0], k2a[1], k2a[2])), q2 = gp2 + mv(R2, v3(k2a[3], k2b[0], k2b[1]));
-              const float reach = k1b[2] + k2b[2] + margin + 1e-6f;
-              pass = segment_dist2(p1, q1, p2, q2) <= reach * reach;
-            }
-          }
+      for (int t = 0; t < NPT; t++) {
+        if (64 * t >= m.npair) break;
+        bool pass, near;
+        bp_test(K.pair[t], m.bp_reach, pass, near);
+        const u64 mk = __ballot(pass);
+        if (pass) sm.u.b.cand[ncand + __popcll(mk & lanemask_lt(lane))] = 64 * t + lane;
+        ncand += __popcll(mk);
+        if (build) {
+          const u64 nk = __ballot(near);
+          const int at = na + __popcll(nk & lanemask_lt(lane));
+          if (near && at < 64) alist[at] = 64 * t + lane;
+          na += __popcll(nk);
         }
       }
-      const u64 mk = __ballot(pass);
-      if (pass) sm.u.b.cand[ncand + __popcll(mk & lanemask_lt(lane))] = 64 * t + lane;
-      ncand += __popcll(mk);
+      act_n = -1;
+      if (build && na <= 64) {
+        SYNC();
+        const int pi = lane < na ? alist[lane] : 0;
+        bpl[256 + lane] = pi;
+        bpl[192 + lane] = lane < na ? (IT(IO_pair_g1, pi) | (IT(IO_pair_g2, pi) << 8) | (1 << 16)) : 0;
+        const V3 c = ld3(sm.gcen + 3 * (lane < m.ncg ? lane : 0));
+        float __attribute__((address_space(1)))* c0 = (float __attribute__((address_space(1)))*)bpl;
+        c0[lane] = c.x; c0[64 + lane] = c.y; c0[128 + lane] = c.z;
+        act_n = na;
+      }
     }
     SYNC();
     pf.mark(RP_BROAD);
@@ -3467,6 +3528,12 @@ struct Sim {
       // fp32 line search: stop when the directional derivative has dropped below MuJoCo's gtol, by 1e6 relative to its
       // start value (single-precision noise floor), or when the safeguarded Newton update no longer moves alpha
       const float dtol = fmaxf(gtol, 1e-6f * fabsf(d0));
+      // ... or moves it by less than what the step rule below calls settled: a correction of alpha that changes no component of the acceleration by
+      // more than newton_ns |a_i| + newton_na is not worth an evaluation (one-tile configurations, as the step rule).  `p` always belongs to
+      // the alpha the loop ends on: the exits keep the point they evaluated, so nothing is evaluated twice.
+      const float atol = (FAST && m.newton_ls > 0.f && m.newton_ns > 0.f)
+                             ? m.newton_ls * wave_min_f((dofl && rr < nv && sk != 0.f) ? (m.newton_ns * fabsf(a) + m.newton_na) / fabsf(sk) : 3.0e38f) : 0.f;
+      bool at_alpha = false;
       for (int ls = 0; ls < m.ls_iterations; ls++) {
         pf.count(RP_N_LS, 1);
         float c, c1, c2;
@@ -3474,15 +3541,17 @@ struct Sim {
         p = gauss + alpha * q1 + alpha * alpha * q2 + wave_sum(c);
         dp = q1 + 2 * alpha * q2 + wave_sum(c1);
         hp = 2 * q2 + wave_sum(c2);
+        at_alpha = true;
         if (fabsf(dp) < dtol) break;
         if (dp < 0) lo = alpha; else hi = alpha;
         float next = hp > 0 ? alpha - dp / hp : -1.f;
         if (hi < 0) { if (next <= lo) next = 2 * alpha + 1e-12f; }
         else if (next <= lo || next >= hi) next = 0.5f * (lo + hi);
-        if (fabsf(next - alpha) <= 1e-6f * fabsf(alpha)) { alpha = next; break; }
+        if (fabsf(next - alpha) <= fmaxf(1e-6f * fabsf(alpha), atol)) break;
         alpha = next;
+        at_alpha = false;
       }
-      {
+      if (!at_alpha) {   // the evaluation budget ran out on a fresh alpha
         float c, c1, c2;
         line(alpha, c, c1, c2);
         p = gauss + alpha * q1 + alpha * alpha * q2 + wave_sum(c);
@@ -3719,6 +3788,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   for (int i = lane; i < m.nu; i += 64) sm.ctrl[i] = b.ctrl[(size_t)env * m.nu + i];
   const int cs = m.ctrl.cs_size, csl = cs < RSIM_CS_LDS ? cs : RSIM_CS_LDS;
   sim.cst = (gwf)(b.cstate + (size_t)env * cs);
+  if (b.bpl) sim.bpl = (int __attribute__((address_space(1)))*)(b.bpl + (size_t)env * 320);
   if (b.mprc) { sim.mprc = (gwf)(b.mprc + (size_t)env * Sim<SM>::MPRC * m.npair); sim.mpr_portal = b.mprc_portal != 0; }
   if (lane < csl) sm.cstate[lane] = sim.cst[lane];
   if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; }
@@ -3753,7 +3823,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
     sim.crb();
     sim.pf.mark(RP_CRB);
     sim.phase();
-    sim.collision();
+    sim.collision(n_sub - sub);
     sim.pf.mark(RP_NARROW);
     sim.phase();
     sim.make_constraint();

@@ -312,7 +312,7 @@ def test_reset_after_the_ring_has_moved_on_starts_the_episode_streams_again():
     assert np.array_equal(env.env.batch.get("qpos"), lift.episode_setup(11, np.arange(5), 1)[1].astype(np.float32))
 
 
-def _contact_rich_rollout(B, T, warm="all", groups=1, keep=False):
+def _contact_rich_rollout(B, T, warm="all", groups=1, keep=False, env_vars=None):
     """Lift envs under full-range random actions (hands on the table: the MPR- and Newton-heavy states).  warm: "all" = separating-direction and
     portal warm start of the convex narrow phase (the default build), "exact" = separating direction only, "none" = every run cold."""
     import os
@@ -321,13 +321,15 @@ def _contact_rich_rollout(B, T, warm="all", groups=1, keep=False):
     ids = np.arange(B)
     tape = torch.tensor(lift.env_actions(ids, T), device="cuda")
     var = {"none": "RSIM_NO_MPR_WARMSTART", "exact": "RSIM_NO_MPR_PORTAL_WARMSTART"}.get(warm)
+    env_vars = dict(env_vars or {})
     if var:
-        os.environ[var] = "1"
+        env_vars[var] = "1"
+    os.environ.update(env_vars)
     try:
         env = lift.LiftBatch(flat, cfg, ids, seed0=0, horizon=60, bank_episodes=3)
     finally:
-        if var:
-            os.environ.pop(var, None)
+        for k in env_vars:
+            os.environ.pop(k, None)
     env.batch.set_stream_groups(groups)
     for t in range(T):
         env.step(tape[t])
@@ -344,6 +346,18 @@ def test_mpr_separating_direction_warm_start_does_not_change_the_contact_set():
     for k in a:
         assert np.array_equal(a[k], b[k]), k
     assert a["ep_index"].min() == 2 and a["diverged"].sum() == 0
+
+
+def test_broadphase_pair_list_gives_the_candidates_of_the_full_broadphase():
+    """collision() tests only the pairs whose bounding spheres were within RSIM_BP_REACH of touching when the list was built, for as long as no
+    geom centre has moved half that far (rsim_step.hip, "Active pair list").  Every pair left out still fails the sphere test, so the candidates,
+    contacts and states are those of testing every pair every substep (RSIM_BP_REACH=0): bitwise, over 130 contact-rich control steps with
+    episode resets inside the launches, and for a reach so small that the list is rebuilt all the time."""
+    full = _contact_rich_rollout(384, 130, warm="exact", env_vars={"RSIM_BP_REACH": "0"})
+    for reach in (None, "0.005", "0.3"):
+        a = _contact_rich_rollout(384, 130, warm="exact", env_vars={} if reach is None else {"RSIM_BP_REACH": reach})
+        for k in a:
+            assert np.array_equal(a[k], full[k]), (reach, k)
 
 
 def test_mpr_portal_warm_start_reaches_the_same_contacts():

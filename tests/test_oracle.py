@@ -485,3 +485,107 @@ def test_documented_constraint_model_known_answers(solimp, depth):
     tc = max(jr[0], 2 * 0.002)
     assert R[lim[0]] == pytest.approx((1 - dl) / dl * flat.dof_invweight0[7], rel=1e-9)
     assert aref[lim[0]] == pytest.approx(-2.0 / (js[1] * tc) * (-0.02) - dl / (js[1] ** 2 * tc ** 2 * jr[1] ** 2) * (-0.001), rel=1e-9)
+
+
+# ---- force / torque sensors (mj_sensorAcc -> mj_rnePostConstraint; robots/robot.py:739-751, 795-815) --------------------------------------------
+def _subtree(flat, b):
+    out = []
+    for i in range(flat.nbody):
+        k = i
+        while k > 0 and k != b:
+            k = int(flat.body_parentid[k])
+        if k == b and b > 0:
+            out.append(i)
+    return out
+
+
+def _sensor_site(flat):
+    st, so = flat.arrays["sensor_type"], flat.arrays["sensor_objid"]
+    assert list(st[:2]) == [0, 1] and so[0] == so[1]          # <force site="ft_frame"/> <torque site="ft_frame"/> of the gripper XMLs
+    return int(so[0])
+
+
+def test_force_torque_sensor_reads_the_weight_it_carries_when_nothing_accelerates():
+    """Known answer from statics: with every generalised force cancelled (qacc = 0, qvel = 0) the gripper's wrist sensor must read the weight of
+    everything outboard of it, as the support force +m g z and its moment about the sensor site, both in the site frame."""
+    g, cfg, flat = load_golden("seed0_gentle")
+    om, od, _ = make_oracle(flat)
+    od.qpos[:] = g["states"][0][1:1 + flat.nq]; od.qvel[:] = 0; od.ctrl[:] = 0; od.qacc_warmstart[:] = 0
+    od.forward()
+    od.qfrc_applied[:] = -(np.array(od.qfrc_passive) - np.array(od.qfrc_bias) + np.array(od.qfrc_actuator))
+    od.forward()
+    robot = np.concatenate([cfg["dof_idx"], cfg["grip_dof_idx"]])
+    assert np.abs(np.array(od.qacc)[robot]).max() < 1e-8
+    site = _sensor_site(flat)
+    sub = _subtree(flat, int(flat.site_bodyid[site]))
+    mass = np.asarray(flat.body_mass)[sub]
+    assert len(sub) >= 3 and mass.sum() == pytest.approx(float(flat.body_subtreemass[flat.site_bodyid[site]]), rel=1e-12)
+    com = (np.array(od.xipos).reshape(-1, 3)[sub] * mass[:, None]).sum(0) / mass.sum()
+    R, P = np.array(od.site_xmat).reshape(-1, 3, 3)[site], np.array(od.site_xpos).reshape(-1, 3)[site]
+    W = mass.sum() * np.array([0, 0, 9.81])
+    s = np.array(od.sensordata)
+    assert s[:3] == pytest.approx(R.T @ W, abs=1e-9) and s[3:6] == pytest.approx(R.T @ np.cross(com - P, W), abs=1e-9)
+    assert np.linalg.norm(s[:3]) == pytest.approx(mass.sum() * 9.81, rel=1e-12)
+
+
+def test_force_torque_sensor_equals_momentum_rate_minus_gravity_and_contacts_while_holding_the_cube():
+    """Newton-Euler for the bodies outboard of the sensor, from positions alone: the wrench the wrist transmits = d/dt (linear, angular momentum about
+    the sensor site) of those bodies - their weight - the contact wrenches acting on them.  Momenta come from central differences of the
+    oracle's KINEMATICS along q(t) = q + v t + a t^2 / 2 (no velocity or force quantity of the oracle enters), contact forces from the solver's
+    rows.  State: the scripted grasp, cube between the pads and moving up -- pad contacts (external to the subtree) carry the cube."""
+    from tests.util import scripted_grasp_and_lift
+    g, cfg, flat = load_golden("seed1_full")
+    acts, qs, cube_z, od = scripted_grasp_and_lift(flat, cfg, g["states"][0][1:1 + flat.nq])
+    od.forward()
+    site = _sensor_site(flat)
+    sub = _subtree(flat, int(flat.site_bodyid[site]))
+    P = np.array(od.site_xpos).reshape(-1, 3)[site].copy()
+    R = np.array(od.site_xmat).reshape(-1, 3, 3)[site].copy()
+    q0, v0, a0 = np.array(od.qpos).copy(), np.array(od.qvel).copy(), np.array(od.qacc).copy()
+    scalar = [(int(flat.jnt_qposadr[j]), int(flat.jnt_dofadr[j])) for j in range(flat.njnt) if flat.jnt_type[j] in (2, 3)]
+    _, ok, _ = make_oracle(flat)
+    mass, inertia = np.asarray(flat.body_mass), np.asarray(flat.body_inertia).reshape(-1, 3)
+
+    def frames(t):
+        q = q0.copy()
+        for qa, da in scalar:                      # the free cube is not outboard of the wrist: its pose may stay put
+            q[qa] = q0[qa] + v0[da] * t + 0.5 * a0[da] * t * t
+        ok.qpos[:] = q; ok.qvel[:] = 0; ok.forward()
+        return np.array(ok.xipos).reshape(-1, 3)[sub].copy(), np.array(ok.ximat).reshape(-1, 3, 3)[sub].copy()
+
+    def momenta(t, d=2e-4):
+        (xp, Rp), (xm, Rm), (x, Rm0) = frames(t + d), frames(t - d), frames(t)
+        lin, ang = np.zeros(3), np.zeros(3)
+        for k, b in enumerate(sub):
+            v = (xp[k] - xm[k]) / (2 * d)
+            S = Rp[k] @ Rm[k].T                   # rotation over 2 d: axis-angle
+            w = np.array([S[2, 1] - S[1, 2], S[0, 2] - S[2, 0], S[1, 0] - S[0, 1]]) / 2.0
+            n = np.linalg.norm(w)
+            w = w * (np.arcsin(min(1.0, n)) / n if n > 1e-300 else 1.0) / (2 * d)
+            lin += mass[b] * v
+            ang += np.cross(x[k] - P, mass[b] * v) + Rm0[k] @ (inertia[b] * (Rm0[k].T @ w))
+        return lin, ang
+
+    e = 2e-4
+    (lp, ap), (lm, am) = momenta(e), momenta(-e)
+    F, T = (lp - lm) / (2 * e), (ap - am) / (2 * e)
+    x0, _ = frames(0.0)
+    for k, b in enumerate(sub):                    # minus the weight
+        F -= mass[b] * np.array([0, 0, -9.81]); T -= np.cross(x0[k] - P, mass[b] * np.array([0, 0, -9.81]))
+    n_ext = 0
+    for c in od.contacts():                        # minus the contact wrenches on outboard bodies (contacts between two of them cancel)
+        if c["efc_address"] < 0:
+            continue
+        f = np.array(od.efc_force)[c["efc_address"]:c["efc_address"] + c["dim"]]
+        fr = np.array(c["frame"]).reshape(3, 3)
+        fw = fr[:min(3, c["dim"])].T @ f[:3]
+        tw = fr[:c["dim"] - 3].T @ f[3:] if c["dim"] > 3 else np.zeros(3)
+        for gid, sgn in ((c["geom1"], -1.0), (c["geom2"], 1.0)):
+            if int(flat.geom_bodyid[gid]) in sub:
+                F -= sgn * fw; T -= sgn * (tw + np.cross(np.array(c["pos"]) - P, fw)); n_ext += 1
+    s = np.array(od.sensordata)
+    assert n_ext >= 2 and np.abs(a0).max() > 0.1                         # pads on the cube, and the state is not static
+    assert R @ s[:3] == pytest.approx(F, abs=2e-5 * max(1.0, np.abs(F).max())), (R @ s[:3], F)
+    assert R @ s[3:6] == pytest.approx(T, abs=2e-5 * max(1.0, np.abs(T).max())), (R @ s[3:6], T)
+    # and it carries more than the gripper alone: the cube's weight comes in through the pads
+    assert (R @ s[:3])[2] > (mass[sub].sum() + 0.5 * float(flat.body_mass[flat.names["body"].index("cube_main")])) * 9.81

@@ -31,6 +31,17 @@ cnt = w[:, 4:8].astype(np.int64)
 order = np.argsort(-dur)
 print(f"step {nskip}, B={B}: launch {ms*1e3:.0f} us; env wavefront duration us: mean {dur.mean():.0f} p50 {np.percentile(dur,50):.0f} p90 {np.percentile(dur,90):.0f} "
       f"p99 {np.percentile(dur,99):.0f} p99.9 {np.percentile(dur,99.9):.0f} max {dur.max():.0f}; sum/2048 slots = {dur.sum()/2048:.0f} us")
+# the launch as a schedule: 4096 envs on 2048 resident slots (8 per CU), dispatched in decreasing cost of the previous step
+t0, t1 = w[:, 2].astype(np.int64), w[:, 3].astype(np.int64)
+st, en, span = (t0 - t0.min()) / 100.0, (t1 - t0.min()) / 100.0, (t1.max() - t0.min()) / 100.0
+ev = np.concatenate([np.stack([st, np.ones(B)], 1), np.stack([en, -np.ones(B)], 1)]); ev = ev[np.argsort(ev[:, 0], kind="stable")]
+conc = np.cumsum(ev[:, 1])
+at = lambda t: int(conc[max(0, np.searchsorted(ev[:, 0], t, side="right") - 1)])
+print(f"schedule: span {span:.0f} us; resident envs at 10..100 % of it:", [at(span * k / 10 - 1e-3) for k in range(1, 11)],
+      f"; start times us p50 {np.percentile(st, 50):.0f} p75 {np.percentile(st, 75):.0f} p90 {np.percentile(st, 90):.0f} p99 {np.percentile(st, 99):.0f} last {st.max():.0f}"
+      f"; envs started in the first 100 us {int((st < 100).sum())}; mean duration of envs started then {dur[st < 100].mean():.0f}, of the others {dur[st >= 100].mean():.0f} us")
+late = np.argsort(-en)[:6]
+print("last envs to finish: [env, start us, duration us, dispatch rank]", [[int(e), int(st[e]), int(dur[e]), int(np.argsort(np.argsort(st, kind='stable'), kind='stable')[e])] for e in late])
 print("per launch (25 substeps): n_mpr n_support n_newton n_cand -- mean", cnt.mean(0).round(1).tolist(), "p99", np.percentile(cnt, 99, axis=0).round(0).tolist(), "max", cnt.max(0).tolist())
 print("corr(dur, n_mpr) %.3f  corr(dur, n_support) %.3f  corr(dur, n_newton) %.3f" % tuple(np.corrcoef(dur, cnt[:, k])[0, 1] for k in (0, 1, 2)))
 A = np.stack([np.ones(B), cnt[:, 0], cnt[:, 1], cnt[:, 2], cnt[:, 3]], 1).astype(np.float64)
