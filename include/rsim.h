@@ -182,6 +182,11 @@ enum rsim_field {
   RSIM_TERMINAL_OBS,   /* [B,nobs]     observation record of the control step that ENDED an env's episode (valid where RSIM_DONE was reported); with a reset
                         *               bank installed RSIM_OBS of such an env already holds the observation MujocoEnv.reset() returns for its next
                         *               episode (gym auto-reset convention), the reward / success flags stay those of the terminal step */
+  RSIM_SENSORDATA,     /* [B,nsensordata] mjData.sensordata (binding_utils.py:935-938; Robot.get_sensor_measurement, robots/robot.py:739-751): the <force> and
+                        *               <torque> sensors at a site (the grippers' ft_frame) as mj_sensorAcc evaluates them -- the wrench the site body's
+                        *               parent transmits to it, from the solved accelerations and contact forces, in the site frame -- written by
+                        *               rsim_forward / rsim_step2 / rsim_step (the values of the last substep, before its integration).  Sensors of
+                        *               other types read zero.  rsim_model_int("nsensordata") gives the row length */
   RSIM_FIELD_COUNT
 };
 

@@ -1825,14 +1825,14 @@ double rso_cost(rso_data *d, const double *a, double *grad) {
  * success, -1 (and leaves the plain forward() result) otherwise. */
 int rso_forward_with_contact_geometry(rso_data *d, int n, const double *geo) {
   kinematics(d); com_pos(d); crb(d); collision(d);
-  if (n != d->ncon) { make_constraint(d); fwd_velocity(d); fwd_actuation(d); fwd_acceleration(d); fwd_constraint(d); return -1; }
+  if (n != d->ncon) { make_constraint(d); fwd_velocity(d); fwd_actuation(d); fwd_acceleration(d); fwd_constraint(d); sensor_acc(d); return -1; }
   for (int i = 0; i < n; i++) {
     rso_contact *c = &d->contact[i];
     c->dist = geo[13 * i];
     memcpy(c->pos, geo + 13 * i + 1, 3 * sizeof(double));
     memcpy(c->frame, geo + 13 * i + 4, 9 * sizeof(double));
   }
-  make_constraint(d); fwd_velocity(d); fwd_actuation(d); fwd_acceleration(d); fwd_constraint(d);
+  make_constraint(d); fwd_velocity(d); fwd_actuation(d); fwd_acceleration(d); fwd_constraint(d); sensor_acc(d);
   return 0;
 }
 void rso_step(rso_data *d) { rso_step1(d); rso_step2(d); }

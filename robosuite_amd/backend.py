@@ -19,7 +19,7 @@ _LIB = None
 # enum rsim_field (include/rsim.h)
 FIELDS = ["qpos", "qvel", "qacc_warmstart", "ctrl", "time", "cstate", "xpos", "xquat", "qM", "qfrc_bias", "qfrc_passive", "qfrc_actuator",
           "qfrc_constraint", "qacc", "cdof", "rootcom", "contact", "efc_force", "ncon", "nefc", "niter", "obs", "reward", "success", "done", "ep_step",
-          "ep_index", "diverged", "overflow", "bank_stale", "terminal_obs"]
+          "ep_index", "diverged", "overflow", "bank_stale", "terminal_obs", "sensordata"]
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
 INT_FIELDS = {"ncon", "nefc", "niter", "success", "done", "ep_step", "ep_index", "diverged", "overflow", "bank_stale"}
 CON_REC = 24
@@ -317,7 +317,8 @@ class HipBatch:
                        "xpos": (B, nb, 3), "xquat": (B, nb, 4), "qM": (B, nv, nv), "qfrc_bias": (B, nv), "qfrc_passive": (B, nv),
                        "qfrc_actuator": (B, nv), "qfrc_constraint": (B, nv), "qacc": (B, nv), "cdof": (B, nv, 6), "rootcom": (B, nb, 3),
                        "contact": (B, self.maxcon, CON_REC), "efc_force": (B, self.maxefc), "ncon": (B,), "nefc": (B,), "niter": (B,),
-                       "obs": (B, model.nobs), "reward": (B,), "success": (B,), "done": (B,), "ep_step": (B,), "ep_index": (B,), "diverged": (B,), "overflow": (B,), "bank_stale": (B,), "terminal_obs": (B, model.nobs)}
+                       "obs": (B, model.nobs), "reward": (B,), "success": (B,), "done": (B,), "ep_step": (B,), "ep_index": (B,), "diverged": (B,), "overflow": (B,), "bank_stale": (B,), "terminal_obs": (B, model.nobs),
+                       "sensordata": (B, int(m.arrays["sensor_dim"].sum()) if getattr(m, "nsensor", 0) else 0)}
 
     # ---- state access (host copies) --------------------------------------------------------
     def get(self, name):

@@ -99,7 +99,7 @@ struct rsim_model {
   std::vector<u64> body_dofmask;
   std::vector<int> lanetab;   // [LT_COUNT][64]
   int kin_rounds, ndynroot, dynroot[RSIM_MAXDYNROOT], maxcondim, multijoint;
-  int ntendon, neq;
+  int ntendon, neq, nsensor, nsensordata;
   DCtrl ctrl;
   rsim_task_desc task;
   int has_task;
@@ -376,6 +376,17 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
     push(IO_tendon_adr, vec("tendon_adr", m->ntendon)); push(IO_tendon_num, vec("tendon_num", m->ntendon)); push(IO_tendon_limited, vec("tendon_limited", m->ntendon));
     push(IO_wrap_dof, wd); push(IO_wrap_qadr, wq); push(IO_eq_tendon, vec("eq_obj1id", m->neq));
   }
+  // force / torque sensors at a site (gripper XMLs: <force site="ft_frame"/>, <torque site="ft_frame"/>); any other type reads zero
+  {
+    m->nsensor = m->I("nsensor") ? m->I("nsensor")[0] : 0;
+    if (m->nsensor > 64) { delete m; return fail("rsim_model_create: more than 64 sensors"); }
+    std::vector<int> st(m->nsensor), ss(m->nsensor), sa(m->nsensor + 1, 0);
+    for (int i = 0; i < m->nsensor; i++) {
+      st[i] = m->I("sensor_type")[i]; ss[i] = m->I("sensor_objid")[i]; sa[i + 1] = sa[i] + m->I("sensor_dim")[i];
+    }
+    m->nsensordata = sa[m->nsensor];
+    push(IO_sensor_type, st); push(IO_sensor_site, ss); push(IO_sensor_adr, sa);
+  }
   // ---- float table
   auto& ft = m->ftab;
   auto pushf = [&](int id, const char* k, size_t n_) {
@@ -519,6 +530,7 @@ extern "C" int rsim_model_int(const rsim_model* m, const char* name) {
   if (!strcmp(name, "ncgeom")) return (int)m->cg.size();
   if (!strcmp(name, "cstate_size")) return m->ctrl.enabled ? m->ctrl.cs_size : RSIM_CS_SIZE;
   if (!strcmp(name, "action_dim")) return m->ctrl.enabled ? m->ctrl.action_dim : 0;
+  if (!strcmp(name, "nsensordata")) return m->nsensordata;
   if (!strcmp(name, "float_table_size")) return (int)m->ftab.size();                              // floats of one env's model float table
   if (!strcmp(name, "constant_block_bytes")) { const int c = pick_config(m, nullptr); return c < 0 ? -1 : k_cmem_bytes[c](); }   // one env's constant block
   const int* v = m->I(name);
@@ -748,7 +760,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   DModel& dm = b->dm;
   dm.nq = m->nq; dm.nv = m->nv; dm.nu = m->nu; dm.nbody = m->nbody; dm.njnt = m->njnt; dm.ncg = ncg; dm.nsite = m->nsite; dm.npair = m->npair;
   dm.maxdepth = m->maxdepth; dm.nroot = m->nroot;
-  dm.ntendon = m->ntendon; dm.neq = m->neq;
+  dm.ntendon = m->ntendon; dm.neq = m->neq; dm.nsensor = m->nsensor; dm.nsensordata = m->nsensordata;
   dm.iterations = m->I("iterations") ? m->I("iterations")[0] : 100;
   dm.ls_iterations = 50; dm.cone = m->I("cone") ? m->I("cone")[0] : 1; dm.solver = 1;
   dm.tolerance = m->D("tolerance") ? (float)m->D("tolerance")[0] : 1e-8f;
@@ -804,7 +816,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
       {RSIM_OBS, (void**)&db.obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0}, {RSIM_REWARD, (void**)&db.reward, (size_t)B, 0},
       {RSIM_SUCCESS, (void**)&db.success, (size_t)B, 1}, {RSIM_DONE, (void**)&db.done, (size_t)B, 1}, {RSIM_EP_STEP, (void**)&db.ep_step, (size_t)B, 1},
       {RSIM_EP_INDEX, (void**)&db.ep_index, (size_t)B, 1}, {RSIM_DIVERGED, (void**)&db.diverged, (size_t)B, 1}, {RSIM_OVERFLOW, (void**)&db.overflow, (size_t)B, 1},
-      {RSIM_BANK_STALE, (void**)&db.bank_stale, (size_t)B, 1}, {RSIM_TERMINAL_OBS, (void**)&db.term_obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0}};
+      {RSIM_BANK_STALE, (void**)&db.bank_stale, (size_t)B, 1}, {RSIM_TERMINAL_OBS, (void**)&db.term_obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0},
+      {RSIM_SENSORDATA, (void**)&db.sensordata, (size_t)B * m->nsensordata, 0}};
   for (auto& fd : fields) {
     if (dalloc((float**)fd.p, fd.n)) return 1;
     b->fptr[fd.id] = *fd.p; b->fcount[fd.id] = fd.n; b->fis_int[fd.id] = fd.is_int;

@@ -14,6 +14,7 @@ enum {
   IO_site_bodyid,
   IO_act_trnid, IO_act_biastype, IO_act_ctrllimited, IO_act_forcelimited,
   IO_tendon_adr, IO_tendon_num, IO_tendon_limited, IO_wrap_dof, IO_wrap_qadr, IO_eq_tendon,   /* fixed tendons + equality/tendon rows */
+  IO_sensor_type /* 0 force, 1 torque, -1 other (reads zero) */, IO_sensor_site, IO_sensor_adr /* nsensor + 1 entries */,
   IO_COUNT
 };
 // ---- packed float tables (per-env stride `fstride`, 0 = shared) -------------------------------------------
@@ -128,6 +129,7 @@ struct DTask {
 struct DModel {
   int nq, nv, nu, nbody, njnt, ncg, nsite, npair, maxdepth, nroot;
   int ntendon, neq;   // fixed tendons, equality/tendon constraints
+  int nsensor, nsensordata;
   int iterations, ls_iterations, cone, solver;
   float tolerance, meaninertia;
   float bp_reach;      // broadphase active pair list: bounding-sphere gap (m) up to which a pair is listed; 0: every pair every substep
@@ -175,6 +177,7 @@ struct DBatch {
   long long cm_stride;   // bytes between the blocks of consecutive envs, 0 = no env has its own block yet
   int* overflow;         // [B] contacts + constraint rows dropped for lack of capacity (null = not counted)
   int mprc_portal;       // 0: keep only the (exact) separating-direction warm start
+  float* sensordata;     // [B][nsensordata] (debug build of the kernel: rsim_step.hip sensor_acc)
   int* bpl;              // [B][5][64] or null: broadphase pair list (rsim_step.hip collision(): sphere centres at build time, packed pair constants, pair indices)
   float* mprc;           // [B][npair][12] or null: the separating direction (x, y, z, valid) each candidate pair's last convex narrow-phase run ended on
                          // (warm start of the next substep's run, see convex_convex); zeroed whenever the host writes positions

@@ -1651,6 +1651,65 @@ struct Sim {
     SYNC();
   }
 
+  // Acceleration-stage sensors of the compatibility path (mj_sensorAcc -> mj_rnePostConstraint [3P]; robots/robot.py:739-751, 795-815): the <force> and
+  // <torque> sensors at the gripper's ft_frame site.  Runs after the constraint solve of the LAST substep, before the integrator, in the debug
+  // build of the kernel only (k_step_dbg: B = 1 shim entries, forward()).  cvel and the velocity part of cacc are phase-local, so the velocity stage
+  // is simply run again (the state has not changed); then lane = body:
+  //   cacc_b += sum over the dofs that move b of cdof_i qacc_i;  f_b = cinert_b (cacc_b - g) + cvel_b x* (cinert_b cvel_b) - (contact wrenches on b),
+  // all about the subtree COM of b's tree; lane = sensor sums f over the site body's subtree (ancestor masks) and expresses the force / the moment
+  // about the site in the site frame.
+  __device__ __forceinline__ void sensor_acc(V3 xp, Q4 xq, float* out) {
+    velocity(xp, xq);
+    const LaneConst K = fetchK();
+    const int nb = m.nbody, nv = m.nv;
+    S6 frc = {v3(0, 0, 0), v3(0, 0, 0)};
+    if (lane < nb && ((K.binfo >> 28) & 1)) {
+      const int b = lane;
+      S6 ca = ld6(sm.u.v.cacc + CS6 * b);
+      ca.l = ca.l - opt_grav;
+      const u64 dm = (u64)dmask_load(IO_body_dofmask, b);
+      for (int i = 0; i < nv; i++)
+        if ((dm >> i) & 1ull) { const S6 cd = ld6(sm.cdof + CS6 * i); const float a = sm.qacc[i]; ca.a = ca.a + cd.a * a; ca.l = ca.l + cd.l * a; }
+      const S6 cv = ld6(sm.u.v.cvel + CS6 * b);
+      frc = mul_inert(sm.cinert + 10 * b, ca) + cross_force(cv, mul_inert(sm.cinert + 10 * b, cv));
+      const V3 rc = ld3(sm.rootcom + 3 * cm->broot[b]);
+      for (int c = 0; c < sm.ncon; c++) {
+        const int ea = sm.cefc[c], dim = sm.cdim[c];
+        if (ea < 0) continue;
+        const int b1 = IT(IO_cg_bodyid, sm.cg1[c] & 255), b2 = IT(IO_cg_bodyid, sm.cg2[c] & 255);
+        if (b1 != b && b2 != b) continue;
+        V3 fw = v3(0, 0, 0), tw = v3(0, 0, 0);
+        for (int k = 0; k < dim; k++) {
+          const V3 ax = ld3(sm.cframe + 9 * c + 3 * (k < 3 ? k : k - 3));
+          if (k < 3) fw = fw + ax * sm.e_force[ea + k]; else tw = tw + ax * sm.e_force[ea + k];
+        }
+        const float sgn = (b2 == b ? 1.f : 0.f) - (b1 == b ? 1.f : 0.f);
+        const V3 t = tw + cross(ld3(sm.cpos + 3 * c) - rc, fw);
+        frc.a = frc.a - t * sgn; frc.l = frc.l - fw * sgn;
+      }
+    }
+    SYNC();
+    if (lane < nb) { float* o = sm.u.v.cf + FS * lane; st3(o, frc.a); st3(o + 3, frc.l); }
+    SYNC();
+    if (lane < m.nsensor) {
+      const int type = IT(IO_sensor_type, lane), site = IT(IO_sensor_site, lane), adr = IT(IO_sensor_adr, lane), dim = IT(IO_sensor_adr, lane + 1) - adr;
+      V3 r = v3(0, 0, 0);
+      if ((type == 0 || type == 1) && site >= 0 && dim == 3) {
+        const int b0 = IT(IO_site_bodyid, site);
+        V3 wa = v3(0, 0, 0), wl = v3(0, 0, 0);
+        for (int d = 1; d < nb; d++)
+          if ((mask2(IO_body_ancmask, d) >> b0) & 1ull) { wa = wa + ld3(sm.u.v.cf + FS * d); wl = wl + ld3(sm.u.v.cf + FS * d + 3); }
+        const M3 R = ldm(sm.smat + 9 * site);
+        r = type == 0 ? mtv(R, wl) : mtv(R, wa - cross(ld3(sm.spos + 3 * site) - ld3(sm.rootcom + 3 * cm->broot[b0]), wl));
+      }
+      if (dim >= 1) out[adr] = r.x;
+      if (dim >= 2) out[adr + 1] = r.y;
+      if (dim >= 3) out[adr + 2] = r.z;
+      for (int k = 3; k < dim; k++) out[adr + k] = 0.f;
+    }
+    SYNC();
+  }
+
   // Jacobian column of world point p attached to body `b` for dof i: returns [jacr; jacp] or zero if i does not move b
   __device__ __forceinline__ S6 jac_col(int b, V3 p, int i) const {
     S6 z = {v3(0, 0, 0), v3(0, 0, 0)};
@@ -3758,7 +3817,7 @@ struct Sim {
 // ------------------------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------------------------
-template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
+template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR, bool DBG>
 __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, const float* __restrict__ actions, int n_sub, int flags) {
   typedef Smem<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> SM;
   const int lane = threadIdx.x;
@@ -3850,6 +3909,9 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
       sim.pf.mark(RP_SOLVE);
       sim.pf.count(RP_N_CON, sm.ncon);
       sim.pf.count(RP_N_EFC, sm.nefc);
+      if constexpr (DBG) {
+        if ((flags & RF_DEBUG) && b.sensordata && m.nsensor > 0 && sub == n_sub - 1) { sim.phase(); sim.sensor_acc(xp, xq, b.sensordata + (size_t)env * m.nsensordata); }
+      }
     }
     if (flags & RF_INTEGRATE) {
       sim.phase();
@@ -3916,7 +3978,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
     unsigned long long* wl = b.prof + RP_COUNT + 8 * (size_t)env;
     wl[3] = wall_clock64(); wl[4] = sim.pf.c_mpr; wl[5] = sim.pf.c_support; wl[6] = sim.pf.c_newton; wl[7] = sim.pf.c_cand;
   }
-  if (flags & RF_DEBUG) {
+  if constexpr (DBG) if (flags & RF_DEBUG) {
     const int nb = m.nbody, nv = m.nv;
     for (int i = lane; i < nb * 3; i += 64) { b.xpos[(size_t)env * nb * 3 + i] = sm.xpos[i]; b.rootcom[(size_t)env * nb * 3 + i] = sm.rootcom[3 * sim.cm->broot[i / 3] + i % 3]; }
     for (int i = lane; i < nb * 4; i += 64) b.xquat[(size_t)env * nb * 4 + i] = sm.xquat[i];
@@ -3945,13 +4007,19 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
 
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
-  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR>(m, b, actions, n_sub, flags);
+  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR, false>(m, b, actions, n_sub, flags);
+}
+// The compatibility / debug form (RF_DEBUG: the B = 1 shim entries, forward() of a batch for the parity tests): the same body plus the MuJoCo-shaped
+// derived arrays and the acceleration-stage sensors.  Its own kernel, so that none of this costs the control step a register.
+template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
+__global__ __launch_bounds__(64, 1) void k_step_dbg(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
+  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR, true>(m, b, actions, n_sub, flags);
 }
 // The reset-observation pass that follows a control step (forward + observables for the envs it re-initialised, no reward): the same body under
 // its own kernel name, so that per-kernel profiles of k_step hold control steps only (and the constant flags strip controller / integrator code)
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 __global__ __launch_bounds__(64, 1) void k_reset_obs(DModel m, DBatch b) {
-  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR>(m, b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_OBS | RF_RESET_ONLY);
+  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR, false>(m, b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_OBS | RF_RESET_ONLY);
 }
 
 // controller reset kernel: forward kinematics then OSC.reset_goal / initial_joint capture
@@ -4098,8 +4166,10 @@ extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStr
 
 // explicit instantiations + launchers (one set per configuration build) ----------------------------------------------------------
 template __global__ void k_step<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
+template __global__ void k_step_dbg<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
 extern "C" int RSIM_SYM(rsim_launch_step)(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream) {
-  hipLaunchKernelGGL((k_step<RSIM_DIMS>), dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
+  if (flags & RF_DEBUG) hipLaunchKernelGGL((k_step_dbg<RSIM_DIMS>), dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
+  else hipLaunchKernelGGL((k_step<RSIM_DIMS>), dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
   return (int)hipGetLastError();
 }
 template __global__ void k_ctrl_reset<RSIM_DIMS>(DModel, DBatch, const unsigned char*);

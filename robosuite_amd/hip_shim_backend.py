@@ -60,8 +60,10 @@ class HipShimBackend:
             b.set(k, self.d[k][None])
         b.set("time", self.d["time"])
 
-    def _pull(self, stepped):
+    def _pull(self, stepped, acc=True):
         b, d, m = self.batch, self.d, self.flat
+        if acc and len(d["sensordata"]):      # acceleration-stage sensors (mj_sensorAcc): force / torque at the gripper's ft_frame site
+            d["sensordata"][:] = b.get("sensordata")[0]
         if stepped:
             for k in ("qpos", "qvel", "qacc_warmstart"):
                 d[k][:] = b.get(k)[0]
@@ -89,7 +91,7 @@ class HipShimBackend:
         self._push(); self.batch.forward(); self._pull(False)
 
     def step1(self):
-        self._push(); self.batch.step1(); self._pull(False)
+        self._push(); self.batch.step1(); self._pull(False, acc=False)
 
     def step2(self):
         self._push(); self.batch.step2(); self._pull(True)

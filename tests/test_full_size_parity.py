@@ -23,11 +23,15 @@ pytestmark = pytest.mark.gpu
 # PickPlace @ 8192 with per-step dynamics randomisation, oracle fed the kernel's contact geometry (measured values: profiles/r03_*_full_size_parity_pickplace.txt)
 # What single precision delivers on this model: the Hessian M + J' D J spans 1e-5 (an object's or finger link's rotational inertia) to 1e6 (a squeezed
 # contact) and its Cholesky factor resolves the soft directions to a few per cent, so the kernel stops at an acceleration whose OBJECTIVE is optimal
-# to ~1e-5 (median 1e-11) while, in the worst env of a sample, the light bodies' accelerations and the forces that balance them differ by up to the
+# to ~1e-4 in the worst env of the batch (median 1e-11, 90th percentile 1e-8) while, in the worst env of a sample, the light bodies' accelerations and the forces that balance them differ by up to the
 # size of the env's largest (tools/pp_dump.py + tools/pp_solver_metric.py, profiles/r03_f_pickplace_solver_metric.txt: a 2 kN squeeze on the bread,
 # cost gap 2.1e-5, a gradient of 1.5 N m left on its 4 g body).  Asserted therefore: the objective gap on every env, the arm (armature >= 0.1) on every
 # env, and the MEDIAN env for the forces, the six gripper joints and the four objects (the maxima are printed).
-PP_COST_GAP = 1e-4
+# The gap is heavy-tailed: over 198 envs of the batch p50 5e-11, p90 2e-8 .. 4e-8, p99 1e-5 .. 8e-5, max 7e-5 .. 2e-4, the same for the builds before
+# and after the round-3 solver changes (tools/pp_gap_stats.py, profiles/r03_m_pickplace_gap_stats.txt); the maximum of a 32-env sample is whatever the
+# one worst-conditioned env in it gives (1.6e-7 and 3.6e-4 seen on consecutive builds), so the bound on it is loose and the 90th percentile carries the claim.
+PP_COST_GAP = 1e-3
+PP_COST_GAP_P90 = 1e-6
 PP_ARM_TOL = 5e-3
 PP_FORCE_MEDIAN = 2e-3
 PP_GROUP_MEDIAN = {"gripper": 5e-3, "objects": 2e-2}
@@ -260,7 +264,8 @@ def test_pickplace_8192_with_dynamics_randomisation_reached_states():
     # four free objects are compared on identical rows.  Bounds are relative to the env's largest force / each group's largest acceleration.
     fed = [r for r in ok if "g_qacc" in r]
     assert len(fed) == len(ok)
-    assert max(r["g_cost_gap"] for r in fed) < PP_COST_GAP and float(np.median([r["g_cost_gap"] for r in fed])) < 1e-7
+    gaps = np.array([r["g_cost_gap"] for r in fed])
+    assert gaps.max() < PP_COST_GAP and float(np.percentile(gaps, 90)) < PP_COST_GAP_P90 and float(np.median(gaps)) < 1e-7, np.percentile(gaps, [50, 90, 100])
     med = lambda xs: float(np.median(list(xs)))   # noqa: E731
     assert med(r["g_force"] / max(1.0, r["g_fscale"]) for r in fed) < PP_FORCE_MEDIAN
     assert max(r["g_groups"]["arm"][0] / max(1.0, r["g_groups"]["arm"][1]) for r in fed) < PP_ARM_TOL

@@ -802,13 +802,17 @@ def test_mujoco_shaped_shim_on_the_hip_backend_matches_the_oracle_backend():
             data.ctrl[7:9] = [0.02, -0.02]
             shim.mj_step2(model, data)
             out.append(dict(jp=jp, jr=jr, M=M, qpos=np.array(data.qpos), qvel=np.array(data.qvel), site=np.array(data.site_xpos[site]),
-                            smat=np.array(data.site_xmat[site]), bias=np.array(data.qfrc_bias), t=data.time, ncon=data.ncon))
+                            smat=np.array(data.site_xmat[site]), bias=np.array(data.qfrc_bias), t=data.time, ncon=data.ncon,
+                            # Robot.get_sensor_measurement (robots/robot.py:739-751): slices of data.sensordata by model.sensor_dim
+                            sens=np.array(data.sensordata[:int(np.sum(model.sensor_dim[:2]))])))
         h, o = out
         assert np.abs(h["jp"] - o["jp"]).max() < 5e-6 and np.abs(h["jr"] - o["jr"]).max() < 5e-6
         assert np.abs(h["M"] - o["M"]).max() < 1e-4 * np.abs(o["M"]).max()
         assert np.abs(h["site"] - o["site"]).max() < 5e-6 and np.abs(h["smat"] - o["smat"]).max() < 5e-6
         assert np.abs(h["qpos"] - o["qpos"]).max() < 2e-5 and np.abs(h["qvel"] - o["qvel"]).max() < 2e-3
         assert abs(h["t"] - o["t"]) < 1e-5 and h["ncon"] == o["ncon"]
+        # wrist force / torque of the substep just taken: 10 N of gripper weight plus its inertial load; trajectories have drifted by the qvel bound above
+        assert h["sens"].shape == (6,) and np.abs(o["sens"][:3]).max() > 3.0 and np.abs(h["sens"] - o["sens"]).max() < 2e-2 * max(1.0, np.abs(o["sens"]).max())
 
 
 def test_on_device_episode_reset_equals_a_fresh_host_reset():
@@ -1039,3 +1043,51 @@ def test_baxter_two_osc_arm_parts_track_the_reference_loop():
         assert np.abs(hq - g["states"][t + 1][1:1 + nq]).max() < 5e-4 and np.abs(hv - g["states"][t + 1][1 + nq:]).max() < 5e-3, t
         assert np.abs(hb.get("ctrl")[0] - g["ctrl"][t]).max() < 2e-3 * max(1.0, np.abs(g["ctrl"][t]).max()), t
     assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[2])
+
+
+def test_force_torque_sensors_match_the_oracle():
+    """RSIM_SENSORDATA (mjData.sensordata: the <force> / <torque> sensors at the grippers' ft_frame, robots/robot.py:739-751) from the debug build of
+    the fused kernel (sensor_acc) against the oracle's mj_sensorAcc restatement, which tests/test_oracle.py pins with known answers from mechanics.
+    Lift / Panda along the scripted grasp (free motion, fingers closing on the cube, cube carried upwards: the pads' contact forces are external to the
+    sensor's subtree); PickPlace / IIWA + Robotiq140 (wide configuration, tendon-coupled fingers with permanent finger / knuckle contacts INSIDE the
+    subtree) and Baxter (two grippers = four sensors, 64-body configuration) at states of their fixtures.  With contacts the oracle is handed the
+    kernel's contact geometry, so that the wrench is compared on identical rows."""
+    from tests.util import scripted_grasp_and_lift
+
+    def check(flat, states, ctrls, tol_free, tol_con, what):
+        om, od, _ = make_oracle(flat)
+        n = len(states)
+        hm, hb = make_hip(flat, None, B=n)
+        nsd = int(flat.arrays["sensor_dim"].sum())
+        assert hb.get("sensordata").shape == (n, nsd) and nsd >= 6
+        hb.set("qpos", states[:, :flat.nq]); hb.set("qvel", states[:, flat.nq:]); hb.set("qacc_warmstart", 0); hb.set("ctrl", ctrls)
+        hb.forward()
+        s = hb.get("sensordata")
+        worst, with_contacts = 0.0, 0
+        for k in range(n):
+            od.qpos[:] = states[k, :flat.nq]; od.qvel[:] = states[k, flat.nq:]; od.qacc_warmstart[:] = 0; od.ctrl[:] = ctrls[k]
+            od.forward()
+            if od.ncon:
+                if not od.forward_with_contact_geometry(hb.contacts(k)):
+                    continue
+                with_contacts += 1
+            ref = np.array(od.sensordata)
+            for a in range(0, nsd, 3):
+                e = np.abs(s[k, a:a + 3] - ref[a:a + 3]).max() / max(1.0, np.abs(ref[a:a + 3]).max())
+                worst = max(worst, e)
+                assert e < (tol_con if od.ncon else tol_free), (what, k, a, s[k], ref)
+        print(f"{what}: {n} states ({with_contacts} with contacts), worst relative sensor error {worst:.2e}")
+        return with_contacts
+
+    g, cfg, flat = load_golden("seed1_full")
+    acts, qs, cube_z, od = scripted_grasp_and_lift(flat, cfg, g["states"][0][1:1 + flat.nq])
+    picks = [5, 20, 40, 52, 58, 66, 79]
+    rng = np.random.default_rng(0)
+    ctrls = rng.uniform(-20, 20, (len(picks), flat.nu)); ctrls[:, -2:] = rng.uniform(-0.04, 0.04, (len(picks), 2))
+    assert check(flat, qs[picks], ctrls, 2e-4, 2e-3, "Lift / Panda, scripted grasp") >= 4          # measured 3e-5 / 4e-4
+    g, cfg, flat = load_golden("seed0_full", "pickplace_iiwa")
+    st = g["states"][[0, 5, 12, 20], 1:1 + flat.nq + flat.nv]
+    assert check(flat, st, g["ctrl"][[0, 5, 12, 19]], 2e-4, 5e-3, "PickPlace / IIWA + Robotiq140") >= 2
+    g, cfg, flat = load_golden("ctl_joint_torque", "peg_baxter")
+    st = np.concatenate([g["sub_qpos"], g["sub_qvel"]], axis=1)[[0, 300, 700]]
+    check(flat, st, rng.uniform(-5, 5, (3, flat.nu)), 2e-4, 5e-3, "TwoArmPegInHole / Baxter (four sensors)")
