@@ -109,7 +109,7 @@ typedef struct rsim_ctrl_desc {
  * (single_object_mode != 0: scaled by reward_scale, success = any object in its bin). */
 enum { RSIM_OBS_QPOS = 0, RSIM_OBS_COS, RSIM_OBS_SIN, RSIM_OBS_QVEL, RSIM_OBS_QACC, RSIM_OBS_SITE_POS, RSIM_OBS_BODY_QUAT, RSIM_OBS_SITE_QUAT,
        RSIM_OBS_BODY_POS, RSIM_OBS_BODY_MINUS_SITE, RSIM_OBS_BODY_MINUS_BODY, RSIM_OBS_PEG_COS, RSIM_OBS_PEG_T, RSIM_OBS_PEG_D,
-       RSIM_OBS_REL_POS, RSIM_OBS_REL_QUAT };
+       RSIM_OBS_REL_POS, RSIM_OBS_REL_QUAT, RSIM_OBS_TASK_OBJECT };
 #define RSIM_OBS_MAX 128
 typedef struct rsim_task_desc {
   int32_t nobs;                       /* floats in the observation record (<= RSIM_OBS_MAX) */
@@ -132,7 +132,12 @@ typedef struct rsim_task_desc {
   int32_t eef_body;                   /* body whose quaternion is `{arm}eef_quat` */
   float bin2_pos[3], bin_size[2];     /* pick_place.py:188-199 */
   float bin_target[8];                /* target_bin_placements[i][0..1] (pick_place.py:570-583) */
-  int32_t single_object_mode;         /* PickPlace: 0 = all objects; 2 = one fixed object (PickPlaceMilk / Bread / Cereal / Can, pick_place.py:800-847): the
+  int32_t single_object_mode;         /* PickPlace: 0 = all objects; 1 = one object, drawn anew at every reset (PickPlaceSingle, pick_place.py:717-722, 800-807):
+                                       * the env's current object id lives in RSIM_TASK_OBJECT -- set by the host's reset, and by the on-device episode reset
+                                       * from the reset-bank column whose patch index is RSIM_PATCH_TASK_OBJECT -- observation entries with a = -1
+                                       * (RSIM_OBS_REL_POS / REL_QUAT: object; RSIM_OBS_BODY_POS / BODY_QUAT: the object's root body) refer to it and
+                                       * RSIM_OBS_TASK_OBJECT is the `obj_id` observable (:626-635); all pos_slot entries name the one `{obj}_pos` slot;
+                                       * 2 = one fixed object (PickPlaceMilk / Bread / Cereal / Can, pick_place.py:800-847): the
                                        * reward is not divided by 4 (:308-310) and success = any object in its bin (:757-759).  The other objects stay in the
                                        * model -- the host's reset moves them to (10, 10, 10) (base.py:591-602) -- and in every sum of the reward, as in the reference */
 } rsim_task_desc;
@@ -187,8 +192,10 @@ enum rsim_field {
                         *               parent transmits to it, from the solved accelerations and contact forces, in the site frame -- written by
                         *               rsim_forward / rsim_step2 / rsim_step (the values of the last substep, before its integration).  Sensors of
                         *               other types read zero.  rsim_model_int("nsensordata") gives the row length */
+  RSIM_TASK_OBJECT,    /* [B] int32    PickPlace single-object mode 1: index of the object this env's current episode uses (see rsim_task_desc.single_object_mode) */
   RSIM_FIELD_COUNT
 };
+#define RSIM_PATCH_TASK_OBJECT (-1)   /* rsim_set_reset_bank patch index: this column of a reset row is the episode's RSIM_TASK_OBJECT, not a float-table entry */
 
 const char* rsim_last_error(void);
 

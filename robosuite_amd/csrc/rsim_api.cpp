@@ -647,22 +647,21 @@ extern "C" int rsim_model_set_task(rsim_model* m, const rsim_task_desc* d) {
       case RSIM_OBS_QVEL: case RSIM_OBS_QACC: ok = a >= 0 && a < m->nv; break;
       case RSIM_OBS_SITE_POS: ok = a >= 0 && a < m->nsite && b2 >= 0 && b2 < 3; break;
       case RSIM_OBS_SITE_QUAT: ok = a >= 0 && a < m->nsite && b2 >= 0 && b2 < 4; break;
-      case RSIM_OBS_BODY_QUAT: ok = a >= 0 && a < m->nbody && b2 >= 0 && b2 < 4; break;
-      case RSIM_OBS_BODY_POS: ok = a >= 0 && a < m->nbody && b2 >= 0 && b2 < 3; break;
+      case RSIM_OBS_BODY_QUAT: ok = ((a >= 0 && a < m->nbody) || (a == -1 && d->task == 4 && d->single_object_mode == 1)) && b2 >= 0 && b2 < 4; break;
+      case RSIM_OBS_BODY_POS: ok = ((a >= 0 && a < m->nbody) || (a == -1 && d->task == 4 && d->single_object_mode == 1)) && b2 >= 0 && b2 < 3; break;
       case RSIM_OBS_BODY_MINUS_SITE: ok = a >= 0 && a < m->nbody && (b2 & 3) < 3 && (b2 >> 2) >= 0 && (b2 >> 2) < m->nsite; break;
       case RSIM_OBS_BODY_MINUS_BODY: ok = a >= 0 && a < m->nbody && (b2 & 3) < 3 && (b2 >> 2) >= 0 && (b2 >> 2) < m->nbody; break;
       case RSIM_OBS_PEG_COS: case RSIM_OBS_PEG_T: case RSIM_OBS_PEG_D: ok = d->task == 3; break;
-      case RSIM_OBS_REL_POS: ok = d->task == 4 && a >= 0 && a < d->nobj && b2 >= 0 && b2 < 3; break;
-      case RSIM_OBS_REL_QUAT: ok = d->task == 4 && a >= 0 && a < d->nobj && b2 >= 0 && b2 < 4; break;
+      case RSIM_OBS_REL_POS: ok = d->task == 4 && ((a >= 0 && a < d->nobj) || (a == -1 && d->single_object_mode == 1)) && b2 >= 0 && b2 < 3; break;
+      case RSIM_OBS_REL_QUAT: ok = d->task == 4 && ((a >= 0 && a < d->nobj) || (a == -1 && d->single_object_mode == 1)) && b2 >= 0 && b2 < 4; break;
+      case RSIM_OBS_TASK_OBJECT: ok = d->task == 4 && d->single_object_mode == 1; break;
       default: ok = false;
     }
     if (!ok) return fail("task: observation entry %d (kind %d, a %d, b %d) is invalid for this model", i, kind, a, b2);
   }
   if (d->task < 0 || d->task > 4) return fail("task: unknown task id %d", d->task);
   if (d->task == 4) {
-    if (d->single_object_mode != 0 && d->single_object_mode != 2)
-      return fail("task: PickPlace single_object_mode %d is not supported (0 = all objects, 2 = one fixed object; mode 1 draws the object per episode and "
-                  "would need a per-env object id in the observation program)", d->single_object_mode);
+    if (d->single_object_mode < 0 || d->single_object_mode > 2) return fail("task: PickPlace single_object_mode %d (0 = all objects, 1 = one object drawn per episode, 2 = one fixed object)", d->single_object_mode);
     if (d->nobj < 1 || d->nobj > 4 || d->eef_body < 0 || d->eef_body >= m->nbody || d->grip_site < 0 || d->grip_site >= m->nsite) return fail("task: bad PickPlace description");
     for (int i = 0; i < d->nobj; i++)
       if (d->obj_body[i] < 0 || d->obj_body[i] >= m->nbody || d->pos_slot[i] < 0 || d->pos_slot[i] + 7 > d->nobs) return fail("task: bad PickPlace object %d", i);
@@ -817,7 +816,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
       {RSIM_SUCCESS, (void**)&db.success, (size_t)B, 1}, {RSIM_DONE, (void**)&db.done, (size_t)B, 1}, {RSIM_EP_STEP, (void**)&db.ep_step, (size_t)B, 1},
       {RSIM_EP_INDEX, (void**)&db.ep_index, (size_t)B, 1}, {RSIM_DIVERGED, (void**)&db.diverged, (size_t)B, 1}, {RSIM_OVERFLOW, (void**)&db.overflow, (size_t)B, 1},
       {RSIM_BANK_STALE, (void**)&db.bank_stale, (size_t)B, 1}, {RSIM_TERMINAL_OBS, (void**)&db.term_obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0},
-      {RSIM_SENSORDATA, (void**)&db.sensordata, (size_t)B * m->nsensordata, 0}};
+      {RSIM_SENSORDATA, (void**)&db.sensordata, (size_t)B * m->nsensordata, 0}, {RSIM_TASK_OBJECT, (void**)&db.task_object, (size_t)B, 1}};
   for (auto& fd : fields) {
     if (dalloc((float**)fd.p, fd.n)) return 1;
     b->fptr[fd.id] = *fd.p; b->fcount[fd.id] = fd.n; b->fis_int[fd.id] = fd.is_int;
@@ -1097,8 +1096,14 @@ extern "C" int rsim_param_offset(const rsim_batch* b, const char* field, int ele
 extern "C" int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, const int32_t* patch_idx, const float* bank) { if (join_groups(b)) return 1;
   rsim_model* m = b->m;
   if (n_episodes < 1 || n_patch < 0) return fail("rsim_set_reset_bank: bad sizes");
-  if (n_patch > 0 && !b->per_env) return fail("rsim_set_reset_bank: per-episode model patches need per_env_params");
-  for (int p2 = 0; p2 < n_patch; p2++) if (patch_idx[p2] < 0 || patch_idx[p2] >= (int)m->ftab.size()) return fail("rsim_set_reset_bank: patch offset out of range");
+  for (int p2 = 0; p2 < n_patch; p2++) {
+    if (patch_idx[p2] == RSIM_PATCH_TASK_OBJECT) {
+      if (!(m->has_task && m->task.task == 4 && m->task.single_object_mode == 1)) return fail("rsim_set_reset_bank: RSIM_PATCH_TASK_OBJECT needs the PickPlace task in single-object mode 1");
+      continue;
+    }
+    if (!b->per_env) return fail("rsim_set_reset_bank: per-episode model patches need per_env_params");
+    if (patch_idx[p2] < 0 || patch_idx[p2] >= (int)m->ftab.size()) return fail("rsim_set_reset_bank: patch offset out of range");
+  }
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   if (rsim_bank_flush(b)) return 1;
@@ -1120,7 +1125,7 @@ extern "C" int rsim_set_reset_bank(rsim_batch* b, int n_episodes, int n_patch, c
   b->db.bank = b->d_bank; b->db.bank_tag = b->d_bank_tag; b->db.patch_idx = b->d_patch; b->db.bank_E = n_episodes; b->db.bank_P = n_patch;
   for (int p2 = 0; p2 < n_patch; p2++)
     for (int f = 0; f < FO_COUNT; f++)
-      if (patch_idx[p2] >= m->fo[f] && patch_idx[p2] < m->fo[f] + m->fcount[f]) b->dm.fenv |= 1ull << f;
+      if (patch_idx[p2] >= 0 && patch_idx[p2] >= m->fo[f] && patch_idx[p2] < m->fo[f] + m->fcount[f]) b->dm.fenv |= 1ull << f;
   b->cm_dirty = 1;
   return 0;
 }

@@ -177,6 +177,7 @@ struct DBatch {
   long long cm_stride;   // bytes between the blocks of consecutive envs, 0 = no env has its own block yet
   int* overflow;         // [B] contacts + constraint rows dropped for lack of capacity (null = not counted)
   int mprc_portal;       // 0: keep only the (exact) separating-direction warm start
+  int* task_object;      // [B] PickPlace single-object mode 1: the object of the env's current episode (RSIM_TASK_OBJECT)
   float* sensordata;     // [B][nsensordata] (debug build of the kernel: rsim_step.hip sensor_acc)
   int* bpl;              // [B][5][64] or null: broadphase pair list (rsim_step.hip collision(): sphere centres at build time, packed pair constants, pair indices)
   float* mprc;           // [B][npair][12] or null: the separating direction (x, y, z, valid) each candidate pair's last convex narrow-phase run ended on

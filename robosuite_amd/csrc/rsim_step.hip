@@ -2155,6 +2155,7 @@ struct Sim {
   // large displacement).  More than 64 near pairs: no list, full rows.
   // The list lives in global memory (DBatch.bpl, 5 x 64 words per env, L2-resident): five more registers alive across the whole substep loop cost
   // the 256-register build more in spills than the list saves.
+  int task_obj = 0;                     // PickPlace single-object mode 1: this env's object (DBatch.task_object)
   int act_n = -1;                       // pairs on the list (-1: none)
   int __attribute__((address_space(1)))* bpl = nullptr;   // [0..2][lane g]: centre of geom g's bounding sphere when the list was built; [3][lane i]: packed
                                                           // constants (geom1 | geom2 << 8 | enabled << 16) of the i-th listed pair; [4][lane i]: its index
@@ -3691,13 +3692,14 @@ struct Sim {
       else if (kind == RSIM_OBS_QVEL) v = sm.qvel[a];
       else if (kind == RSIM_OBS_QACC) v = sm.qacc[a];
       else if (kind == RSIM_OBS_SITE_POS) v = sm.spos[3 * a + b2];
-      else if (kind == RSIM_OBS_BODY_POS) v = sm.xpos[3 * a + b2];
+      else if (kind == RSIM_OBS_BODY_POS) v = sm.xpos[3 * (a < 0 ? seli(t.obj_body, task_obj) : a) + b2];
+      else if (kind == RSIM_OBS_TASK_OBJECT) v = (float)task_obj;
       else if (kind == RSIM_OBS_BODY_MINUS_SITE) v = sm.xpos[3 * a + (b2 & 3)] - sm.spos[3 * (b2 >> 2) + (b2 & 3)];
       else if (kind == RSIM_OBS_BODY_MINUS_BODY) v = sm.xpos[3 * a + (b2 & 3)] - sm.xpos[3 * (b2 >> 2) + (b2 & 3)];
       else if (kind == RSIM_OBS_REL_POS || kind == RSIM_OBS_REL_QUAT) {
         // world_pose_in_gripper @ obj_pose (manipulation_env.py:244-303): gripper = {grip site position, eef body quaternion} now, object = cached
         if (!reset_obs) {
-          const float* o = prev + 7 * a;
+          const float* o = prev + 7 * (a < 0 ? task_obj : a);
           const Q4 qo = {o[6], o[3], o[4], o[5]};                       // record holds xyzw
           const M3 Re = q2m(ldq(sm.xquat + 4 * t.eef_body)), Ro = q2m(qnorm(qo));
           if (kind == RSIM_OBS_REL_POS) {
@@ -3713,7 +3715,7 @@ struct Sim {
       else if (kind == RSIM_OBS_PEG_COS) v = peg_c;
       else if (kind == RSIM_OBS_PEG_T) v = peg_t;
       else if (kind == RSIM_OBS_PEG_D) v = peg_d;
-      else if (kind == RSIM_OBS_BODY_QUAT) v = sm.xquat[4 * a + (b2 == 3 ? 0 : b2 + 1)];   // wxyz -> xyzw
+      else if (kind == RSIM_OBS_BODY_QUAT) v = sm.xquat[4 * (a < 0 ? seli(t.obj_body, task_obj) : a) + (b2 == 3 ? 0 : b2 + 1)];   // wxyz -> xyzw
       else if (kind == RSIM_OBS_SITE_QUAT) { const Q4 q = mat2quat_xyzw(sm.smat + 9 * a); v = b2 == 0 ? q.x : (b2 == 1 ? q.y : (b2 == 2 ? q.z : q.w)); }
       obs[i] = v;
     }
@@ -3934,8 +3936,10 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
     }
     sim.pf.count(RP_N_SUB, 1);
   }
-  if ((flags & RF_OBS) && m.task.enabled)
+  if ((flags & RF_OBS) && m.task.enabled) {
+    if (m.task.single_mode == 1) sim.task_obj = b.task_object[env] & 3;
     sim.obs_reward(b.obs + (size_t)env * m.task.nobs, (flags & RF_RESET_ONLY) ? nullptr : b.reward + env, b.success + env, !(flags & RF_CTRL));
+  }
   if (flags & RF_EPISODE) {
     // MujocoEnv.step: timestep += 1; done = timestep >= horizon (base.py:508, 532-548); optional on-device reset from the bank
     int st = b.ep_step[env] + 1;
@@ -3953,8 +3957,10 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
       for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = src[i];
       if (lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.ctrl[lane] = 0.f; }
       for (int p2 = lane; p2 < b.bank_P; p2 += 64) {
-        b.ft_rw[(size_t)env * m.fstride + b.patch_idx[p2]] = src[m.nq + p2];
-        if (b.ft_base) b.ft_base[(size_t)env * m.fstride + b.patch_idx[p2]] = src[m.nq + p2];
+        const int pi = b.patch_idx[p2];
+        if (pi < 0) { b.task_object[env] = (int)src[m.nq + p2]; continue; }   // RSIM_PATCH_TASK_OBJECT: the new episode's object (PickPlace single-object mode 1)
+        b.ft_rw[(size_t)env * m.fstride + pi] = src[m.nq + p2];
+        if (b.ft_base) b.ft_base[(size_t)env * m.fstride + pi] = src[m.nq + p2];
       }
       time = 0.f;
       st = 0;

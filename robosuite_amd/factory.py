@@ -228,6 +228,13 @@ def pickplace_task_cfg(env):
                 eef_body=env.robots[0].robot_model.eef_name["right"], grip_site=g.important_sites["grip_site"])
     if env.single_object_mode:
         task.update(single_object_mode=int(env.single_object_mode), object_id=int(env.object_id))
+    if env.single_object_mode == 1:
+        # _reset_internal draws with rng.choice(list(obj_names)), obj_names a SET of the object names (pick_place.py:716-722): what draw k means is
+        # this process's set order (string hashing), so it is recorded with the configuration
+        ids = []
+        for name in list({obj.name for obj in env.objects}):
+            ids.append(next(i for typ, i in env.object_to_id.items() if typ.lower() in name.lower()))
+        task["mode1_order"] = ids
     task["placement"] = dict(
         bin1_pos=[float(x) for x in env.bin1_pos], z_offset=float(env.z_offset), z_rotation=env.z_rotation,
         x_half=float(env.model.mujoco_arena.table_full_size[0] / 2 - 0.05), y_half=float(env.model.mujoco_arena.table_full_size[1] / 2 - 0.05),
@@ -310,6 +317,10 @@ def extract(env, obs=None):
         cfg["task"] = pickplace_task_cfg(env)
     cfg["obs_keys"] = keys
     cfg["obs_dims"] = [int(np.atleast_1d(obs[k]).size) for k in keys]
+    if name.startswith("PickPlace") and env.single_object_mode == 1:
+        # the object keys of the record are those of whichever object this episode drew (`Can_pos` ...): same slots every episode, named neutrally
+        used = env.obj_to_use
+        cfg["obs_keys"] = [k.replace(used + "_", "obj_", 1) if k.startswith(used + "_") else k for k in keys]
     if name == "Stack":
         cfg["table_height"] = float(env.table_offset[2])
     return flat, cfg

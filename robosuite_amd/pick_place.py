@@ -10,7 +10,11 @@
                observation record holds the chosen object's sensors only (:612-624), reset() moves the other three objects out of the scene
                (clear_objects, base.py:591-602: free joint at (10, 10, 10), from where they fall for the rest of the episode -- they stay in the
                reward's sums exactly as in the reference), the reward is not divided by 4 and success = the object is in its bin.
-               Mode 1 (PickPlaceSingle: the object is drawn per episode from a Python set, i.e. in hash order) is not restated.
+  single-object mode 1 (PickPlaceSingle, pick_place.py:717-722, 800-807): as mode 2, but every reset draws the object -- rng.choice over a Python SET
+               of the object names, i.e. one rng.integers(0, 4) whose meaning depends on the process's string-hash order.  cfg["task"]["mode1_order"]
+               (object indices in the order the reference process iterated the set; tools/gen_golden.py records it under PYTHONHASHSEED=0) fixes
+               that meaning, identity if absent.  The observation record holds the episode's object (the kernel selects it per env:
+               include/rsim.h RSIM_TASK_OBJECT, observation entries with a = -1) followed by the `obj_id` observable (:626-635).
 The visual-object bodies (pick_place.py:455-513, 703-706: static bodies without collision geoms) take no part in the dynamics and are not restated.
 """
 from __future__ import annotations
@@ -31,7 +35,11 @@ def pick_place_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool =
     obj_body = [body.index(b) for b in t["object_bodies"]]
     single, only = int(t.get("single_object_mode", 0)), int(t.get("object_id", -1))
     pos_slot = []
-    for i, ob in enumerate(obj_body):
+    if single == 1:                   # the episode's object, whichever it is (a = -1), then its id
+        obs += [("rel_pos", -1, k) for k in range(3)] + [("rel_quat", -1, k) for k in range(4)]
+        pos_slot = [len(obs)] * len(obj_body)
+        obs += [("body_pos", -1, k) for k in range(3)] + [("body_quat", -1, k) for k in range(4)] + [("task_object", 0, 0)]
+    for i, ob in enumerate(obj_body if single != 1 else []):
         if single and i != only:      # pick_place.py:616-624: the other objects' sensors are disabled
             pos_slot.append(0)
             continue
@@ -49,11 +57,12 @@ import numpy as np  # noqa: E402
 from .reset_bank import ResetBankMixin  # noqa: E402
 
 
-def reset_draws(rng: np.random.Generator, placement: dict):
+def reset_draws(rng: np.random.Generator, placement: dict, choose: bool = False):
     """One hard-reset block of the env generator in the reference's order (pick_place.py:670-700 -> robots/robot.py:247-259,
     utils/placement_samplers.py:221-309, 383-470): arm noise N(0,1) x 7 x 0.02; CollisionObjectSampler over the objects in list order
     (x, y uniform inside bin 1 shrunk by the object's horizontal radius, redrawn while it overlaps an already placed object, then a uniform yaw);
-    then one x and one y draw over a zero-width range per visual object (their rotation is fixed)."""
+    then one x and one y draw over a zero-width range per visual object (their rotation is fixed); `choose` (single-object mode 1): then the
+    object of the episode, rng.choice over the four names = one rng.integers(0, 4) (pick_place.py:717-718)."""
     arm = np.array(placement["arm_init_qpos"]) + rng.standard_normal(len(placement["arm_init_qpos"])) * 0.02
     bx, by, bz = placement["bin1_pos"]
     xh, yh = placement["x_half"], placement["y_half"]
@@ -78,7 +87,16 @@ def reset_draws(rng: np.random.Generator, placement: dict):
             raise RuntimeError("Cannot place all objects")
     for _ in placement["objects"]:        # the four visual twins: x and y over [c, c]
         rng.uniform(0.0, 0.0); rng.uniform(0.0, 0.0)
-    return dict(arm=arm, objects=out)
+    return dict(arm=arm, objects=out, pick=int(rng.integers(0, len(placement["objects"]))) if choose else -1)
+
+
+def active_object(task: dict, draw) -> int:
+    """Object index the episode uses: all (-1), the drawn one (mode 1, through the recorded set order), the fixed one (mode 2)."""
+    mode = int(task.get("single_object_mode", 0))
+    if mode == 1:
+        order = task.get("mode1_order") or list(range(len(task["placement"]["objects"])))
+        return int(order[draw["pick"]])
+    return int(task.get("object_id", -1)) if mode == 2 else -1
 
 
 def initial_qpos(draw, placement: dict, nq: int, only: int = -1) -> np.ndarray:
@@ -98,14 +116,14 @@ def initial_qpos(draw, placement: dict, nq: int, only: int = -1) -> np.ndarray:
 
 
 def episode_setup(cfg, nq: int, seed0: int, env_ids, block: int = 0):
-    pl = cfg["task"]["placement"]
-    only = int(cfg["task"].get("object_id", -1)) if int(cfg["task"].get("single_object_mode", 0)) == 2 else -1
+    t = cfg["task"]
+    pl = t["placement"]
     out = []
     for i in env_ids:
         rng = np.random.default_rng(seed0 + int(i))
         for _ in range(block + 1):
-            d = reset_draws(rng, pl)
-        out.append(initial_qpos(d, pl, nq, only))
+            d = reset_draws(rng, pl, int(t.get("single_object_mode", 0)) == 1)
+        out.append(initial_qpos(d, pl, nq, active_object(t, d)))
     return np.array(out)
 
 
@@ -130,23 +148,32 @@ class PickPlaceBatch(ResetBankMixin):
         if bank_episodes:
             self.install_reset_bank(bank_episodes)
 
+    @property
+    def _mode1(self):
+        return int(self.cfg["task"].get("single_object_mode", 0)) == 1
+
     def _bank_patch_offsets(self):
-        return []
+        return [-1] if self._mode1 else []        # RSIM_PATCH_TASK_OBJECT: the row's extra column is the episode's object
 
     def _draw_fn(self, rng):
-        return reset_draws(rng, self.cfg["task"]["placement"])
+        return reset_draws(rng, self.cfg["task"]["placement"], self._mode1)
 
     def _episode(self, idx, episode):
+        """(qpos rows, object of the episode per env: -1 outside the single-object modes)"""
         t = self.cfg["task"]
-        only = int(t.get("object_id", -1)) if int(t.get("single_object_mode", 0)) == 2 else -1
-        return np.array([initial_qpos(d, t["placement"], self.flat.nq, only) for d in self.episode_draws(idx, episode)]).reshape(-1, self.flat.nq)
+        draws = self.episode_draws(idx, episode)
+        obj = np.array([active_object(t, d) for d in draws], dtype=np.int64)
+        return np.array([initial_qpos(d, t["placement"], self.flat.nq, int(o)) for d, o in zip(draws, obj)]).reshape(-1, self.flat.nq), obj
 
     def _bank_rows(self, idx, episode):
-        return self._episode(idx, episode), np.zeros((len(idx), 0))
+        q, obj = self._episode(idx, episode)
+        return q, (obj[:, None].astype(np.float64) if self._mode1 else np.zeros((len(idx), 0)))
 
     def reset(self, block: int = 0):
-        qpos = self._episode(np.arange(self.B), block)
+        qpos, obj = self._episode(np.arange(self.B), block)
         b = self.batch
+        if self._mode1:
+            b.set("task_object", obj)
         b.set("qpos", qpos); b.set("qvel", 0.0); b.set("ctrl", 0.0); b.set("time", 0.0); b.set("qacc_warmstart", 0.0)
         b.forward(); b.ctrl_reset()
         self.qpos0 = qpos

@@ -20,6 +20,7 @@ TASKS = {"Lift": lift.LiftBatch, "Stack": stack.StackBatch, "TwoArmPegInHole": p
 # single-object mode 2 of PickPlace (pick_place.py:810-847): the model / task constants of the env's own fixture carry single_object_mode and object_id
 _SINGLE_OBJECT = {"PickPlaceMilk": 0, "PickPlaceBread": 1, "PickPlaceCereal": 2, "PickPlaceCan": 3}   # object_to_id, pick_place.py:218
 TASKS.update({n: pick_place.PickPlaceBatch for n in _SINGLE_OBJECT})
+TASKS["PickPlaceSingle"] = pick_place.PickPlaceBatch     # single_object_mode = 1: the object is drawn at every reset (pick_place.py:800-807)
 
 
 class VecEnv:
@@ -34,6 +35,8 @@ class VecEnv:
             if int(t.get("single_object_mode", 0)) != 2 or int(t.get("object_id", -1)) != _SINGLE_OBJECT[env_name]:
                 raise ValueError(f"{env_name}: cfg['task'] must carry single_object_mode = 2 and object_id = {_SINGLE_OBJECT[env_name]} "
                                  f"(got {t.get('single_object_mode')}, {t.get('object_id')}); build the cfg from a {env_name} env")
+        if env_name == "PickPlaceSingle" and int(cfg.get("task", {}).get("single_object_mode", 0)) != 1:
+            raise ValueError("PickPlaceSingle: cfg['task'] must carry single_object_mode = 1; build the cfg from a PickPlaceSingle env")
         self.env_name = env_name
         self.env = TASKS[env_name](flat, cfg, ids, device=device, seed0=seed, horizon=horizon, bank_episodes=bank_episodes)
         self.n_envs, self.horizon, self.bank_episodes = len(ids), horizon, bank_episodes

@@ -1091,3 +1091,63 @@ def test_force_torque_sensors_match_the_oracle():
     g, cfg, flat = load_golden("ctl_joint_torque", "peg_baxter")
     st = np.concatenate([g["sub_qpos"], g["sub_qvel"]], axis=1)[[0, 300, 700]]
     check(flat, st, rng.uniform(-5, 5, (3, flat.nu)), 2e-4, 5e-3, "TwoArmPegInHole / Baxter (four sensors)")
+
+
+def test_pickplace_single_object_mode_1_draws_the_object_at_every_reset():
+    """PickPlaceSingle (single_object_mode 1, pick_place.py:717-722, 800-807) against a fixture of four EPISODES recorded from the reference env
+    (objects Can, Bread, Cereal, Bread; tools/gen_golden.py --pickplace-mode1-only): the host reset reproduces each episode's object and qpos
+    (block e + 1 of the env generator; block 0 is make()'s own reset), the observation record holds that object's sensors and `obj_id`, rewards
+    and success follow the reference -- first with a host reset per episode, then with the episodes chained by the on-device reset (the object
+    id travels through the reset ring, RSIM_PATCH_TASK_OBJECT)."""
+    from robosuite_amd import pick_place
+    g, cfg, flat = load_golden("seed3", "pickplace_single_iiwa")
+    E, K = g["actions"].shape[:2]
+    nq = flat.nq
+    assert cfg["task"]["single_object_mode"] == 1 and sorted(cfg["task"]["mode1_order"]) == [0, 1, 2, 3] and len(set(g["ep_object"])) >= 3
+    dims = np.cumsum([0] + cfg["obs_dims"])
+    keys = cfg["obs_keys"]
+    assert keys[-5:] == ["obj_to_robot0_eef_pos", "obj_to_robot0_eef_quat", "obj_pos", "obj_quat", "obj_id"] and dims[-1] == 73
+
+    def check_record(obs, ref, where, reset=False):
+        for k, key in enumerate(keys):
+            r, o = ref[dims[k]:dims[k + 1]], obs[dims[k]:dims[k + 1]]
+            if key.endswith("joint_acc"):
+                tol = (5e-2 if reset else 2e-2) * max(1.0, np.abs(r).max())
+            elif "gripper_q" in key:
+                tol = 1e-2 if key.endswith("qpos") else 0.3
+            else:
+                tol = 5e-3 if (key.endswith("vel") or key.startswith("obj_")) else 2e-3
+            if "quat" in key:
+                o = o * np.sign(np.dot(o, r))
+            assert np.abs(o - r).max() < tol, (where, key, np.abs(o - r).max())
+
+    env = pick_place.PickPlaceBatch(flat, cfg, np.arange(2), seed0=3)
+    b = env.batch
+    assert np.abs(b.get("qpos")[0] - g["make_qpos"]).max() < 1e-6 and b.get("task_object")[0] == int(g["make_object"])
+    for e in range(E):
+        env.reset(block=e + 1)
+        assert b.get("task_object")[0] == g["ep_object"][e] and np.abs(b.get("qpos")[0] - g["ep_reset_qpos"][e]).max() < 1e-6, e
+        b.observe()
+        check_record(b.get("obs")[0], g["ep_reset_obs"][e], ("reset", e), reset=True)
+        assert b.get("obs")[0][-1] == g["ep_object"][e]
+        for t in range(K):
+            env.step(torch.tensor(np.repeat(g["actions"][e][t][None], 2, 0), dtype=torch.float32, device="cuda"))
+            check_record(b.get("obs")[0], g["obs"][e][t], (e, t))
+            assert abs(b.get("reward")[0] - g["rewards"][e][t]) < 2e-4 and b.get("success")[0] == g["success"][e][t], (e, t)
+    # the same four episodes chained on the device: horizon K, the ring refilled by the host, the env generator continuing from block 1
+    env = pick_place.PickPlaceBatch(flat, cfg, np.arange(2), seed0=3, horizon=K, bank_episodes=3)
+    b = env.batch
+    env.reset(block=1); b.set("ep_index", 1); b.observe()
+    for e in range(E):
+        assert b.get("task_object")[0] == g["ep_object"][e] and np.abs(b.get("qpos")[0] - g["ep_reset_qpos"][e]).max() < 1e-6, e
+        if e:
+            check_record(b.get("obs")[0], g["ep_reset_obs"][e], ("device reset", e), reset=True)     # gym auto-reset: RSIM_OBS is the new episode's first record
+        for t in range(K):
+            env.step(torch.tensor(np.repeat(g["actions"][e][t][None], 2, 0), dtype=torch.float32, device="cuda"))
+            if t < K - 1:
+                check_record(b.get("obs")[0], g["obs"][e][t], ("chained", e, t))
+            else:
+                check_record(b.get("terminal_obs")[0], g["obs"][e][t], ("terminal", e))
+            assert abs(b.get("reward")[0] - g["rewards"][e][t]) < 2e-4, (e, t)
+        assert b.get("done")[0] == 1 and b.get("ep_index")[0] == e + 2
+    assert int(b.get("bank_stale").sum()) == 0 and int(b.get("diverged").sum()) == 0

@@ -589,3 +589,22 @@ def test_force_torque_sensor_equals_momentum_rate_minus_gravity_and_contacts_whi
     assert R @ s[3:6] == pytest.approx(T, abs=2e-5 * max(1.0, np.abs(T).max())), (R @ s[3:6], T)
     # and it carries more than the gripper alone: the cube's weight comes in through the pads
     assert (R @ s[:3])[2] > (mass[sub].sum() + 0.5 * float(flat.body_mass[flat.names["body"].index("cube_main")])) * 9.81
+
+
+def test_pickplace_single_object_mode_1_reset_path_reproduces_the_reference_episodes():
+    """PickPlaceSingle draws the episode's object with rng.choice over a SET of the object names (pick_place.py:716-722): one rng.integers(0, 4) after
+    the placement draws, mapped through the set order of the recording process (cfg["task"]["mode1_order"]).  Block 0 of the env generator is
+    make()'s own reset, block e + 1 the e-th user reset: objects and qpos of four recorded episodes."""
+    from robosuite_amd import pick_place
+    g, cfg, flat = load_golden("seed3", "pickplace_single_iiwa")
+    t = cfg["task"]
+    rng = np.random.default_rng(3)
+    for block in range(1 + len(g["ep_object"])):
+        d = pick_place.reset_draws(rng, t["placement"], True)
+        obj = pick_place.active_object(t, d)
+        q = pick_place.initial_qpos(d, t["placement"], flat.nq, obj)
+        ref_obj, ref_q = (int(g["make_object"]), g["make_qpos"]) if block == 0 else (int(g["ep_object"][block - 1]), g["ep_reset_qpos"][block - 1])
+        assert obj == ref_obj and q == pytest.approx(ref_q, abs=1e-12), block
+        assert np.abs(pick_place.episode_setup(cfg, flat.nq, 3, [0], block)[0] - ref_q).max() < 1e-12
+    away = [o["qposadr"] for i, o in enumerate(t["placement"]["objects"]) if i != obj]
+    assert all(q[a] == 10.0 for a in away)

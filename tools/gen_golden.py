@@ -29,7 +29,7 @@ if "--out" in sys.argv:   # write somewhere else (tests/test_golden_recipe.py re
 os.makedirs(GOLD, exist_ok=True)
 
 
-from robosuite_amd.factory import GRIPPER_SIGNS, controller_cfg, controller_cfg_generic, patch_joint_velocity_defect, pickplace_task_cfg, two_arm_cfg  # noqa: E402,F401  (the extraction helpers live in the package: robosuite_amd.make() uses the same ones)
+from robosuite_amd.factory import GRIPPER_SIGNS, controller_cfg, extract, controller_cfg_generic, patch_joint_velocity_defect, pickplace_task_cfg, two_arm_cfg  # noqa: E402,F401  (the extraction helpers live in the package: robosuite_amd.make() uses the same ones)
 
 
 
@@ -383,7 +383,42 @@ def record_lift_singular(seed=0):
     print("singular", len(names), "samples; cond(J_pos M^-1 J_pos^T) min %.1e median %.1e max %.1e; |tau| max %.1e" % (c.min(), np.median(c), c.max(), np.abs(np.array(rec["tau"])).max()))
 
 
+def record_pickplace_episodes(seed, n_eps, n_steps, action_scale=1.0):
+    """PickPlaceSingle / IIWA (single-object mode 1, pick_place.py:717-722, 800-807): the object is drawn anew at every reset, so the fixture holds
+    several EPISODES -- per episode the reset qpos, the object id, the observation reset() returned, and n_steps of actions / states / observation
+    records / rewards.  The draw goes through a Python set of the object names: run with PYTHONHASHSEED=0 for a reproducible file; the set order
+    of the recording process is stored as cfg["task"]["mode1_order"] (factory.pickplace_task_cfg)."""
+    env = suite.make("PickPlaceSingle", robots="IIWA", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, use_object_obs=True,
+                     reward_shaping=True, control_freq=20, horizon=500, ignore_done=True, seed=seed)
+    rec = dict(make_qpos=np.array(env.sim.data.qpos), make_object=np.array(env.object_id), ep_reset_qpos=[], ep_object=[], ep_reset_obs=[], actions=[], states=[], obs=[],
+               rewards=[], success=[], ctrl=[])
+    rng = np.random.default_rng(10**6 + seed)
+    for ep in range(n_eps):
+        obs = env.reset()
+        sim = env.sim
+        keys = [k for k in obs.keys() if not k.endswith("-state")]
+        flat_obs = lambda o: np.concatenate([np.atleast_1d(o[k]).astype(np.float64) for k in keys])   # noqa: E731
+        rec["ep_reset_qpos"].append(np.array(sim.data.qpos)); rec["ep_object"].append(int(env.object_id)); rec["ep_reset_obs"].append(flat_obs(obs))
+        A, S, O, R, U, C = [], [sim.get_state().flatten()], [], [], [], []
+        for t in range(n_steps):
+            a = action_scale * rng.uniform(-1, 1, env.action_dim)
+            obs, r, done, info = env.step(a)
+            A.append(a); S.append(sim.get_state().flatten()); O.append(flat_obs(obs)); R.append(r); U.append(int(env._check_success())); C.append(np.array(sim.data.ctrl))
+        for k, v in zip(("actions", "states", "obs", "rewards", "success", "ctrl"), (A, S, O, R, U, C)):
+            rec[k].append(np.array(v))
+    flat, cfg = extract(env, obs)
+    stem = f"pickplace_single_iiwa_seed{seed}"
+    np.savez_compressed(os.path.join(GOLD, stem + ".npz"), **{k: np.array(v) for k, v in rec.items()})
+    mjcf.save_model(flat, os.path.join(GOLD, stem + ".rsim"))
+    with open(os.path.join(GOLD, stem + ".cfg.json"), "w") as f:
+        json.dump(cfg, f, indent=1)
+    print("pickplace single", "objects per episode", rec["ep_object"], "make", int(rec["make_object"]), "set order", cfg["task"]["mode1_order"], "obs", len(rec["obs"][0][0]))
+
+
 if __name__ == "__main__":
+    if "--pickplace-mode1-only" in sys.argv:
+        record_pickplace_episodes(seed=3, n_eps=4, n_steps=12)
+        sys.exit(0)
     if "--singular-only" in sys.argv:
         record_lift_singular()
         sys.exit(0)
