@@ -760,6 +760,15 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.nq = m->nq; dm.nv = m->nv; dm.nu = m->nu; dm.nbody = m->nbody; dm.njnt = m->njnt; dm.ncg = ncg; dm.nsite = m->nsite; dm.npair = m->npair;
   dm.maxdepth = m->maxdepth; dm.nroot = m->nroot;
   dm.ntendon = m->ntendon; dm.neq = m->neq; dm.nsensor = m->nsensor; dm.nsensordata = m->nsensordata;
+  {
+    // dofs are numbered tree by tree (depth first): the prefix that holds every tree with a damped joint
+    const int* dbody = m->I("dof_bodyid"); const int* root = m->I("body_rootid");
+    int last = -1;
+    for (int i = 0; i < m->nv; i++) if (m->D("dof_damping")[i] != 0.0) last = i;
+    int nd = last + 1;
+    while (nd < m->nv && last >= 0 && root[dbody[nd]] == root[dbody[last]]) nd++;
+    dm.nv_damped = getenv("RSIM_EULER_FULL") ? m->nv : nd;
+  }
   dm.iterations = m->I("iterations") ? m->I("iterations")[0] : 100;
   dm.ls_iterations = 50; dm.cone = m->I("cone") ? m->I("cone")[0] : 1; dm.solver = 1;
   dm.tolerance = m->D("tolerance") ? (float)m->D("tolerance")[0] : 1e-8f;

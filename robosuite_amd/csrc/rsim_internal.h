@@ -130,6 +130,7 @@ struct DModel {
   int nq, nv, nu, nbody, njnt, ncg, nsite, npair, maxdepth, nroot;
   int ntendon, neq;   // fixed tendons, equality/tendon constraints
   int nsensor, nsensordata;
+  int nv_damped;       // dofs 0 .. nv_damped - 1 cover every kinematic tree that has a damped joint (implicit-damping Euler factors only those)
   int iterations, ls_iterations, cone, solver;
   float tolerance, meaninertia;
   float bp_reach;      // broadphase active pair list: bounding-sphere gap (m) up to which a pair is listed; 0: every pair every substep

@@ -2719,15 +2719,23 @@ struct Sim {
     const float acc_own = lane < nv ? sm.qacc[lane] : 0.f;
     if constexpr (!FAST && !SM::HAS_LE_) {
       // the factor of M + h diag(damping) is not kept in this configuration: build it in the solver's (now free) work matrix
+      // Only the damped trees need it: M is block diagonal over the kinematic trees and the right-hand side hD qacc is zero on a tree without
+      // damping (the free objects: 24 of PickPlace's 37 dofs, 12 of Stack's 21), so the correction there is exactly zero.  m.nv_damped = dofs up
+      // to the last tree that has a damped joint in the model as ingested; a randomisation that gives a later dof damping falls back to all.
       const float hd = lane < nv ? h * K.damping : 0.f;
+      const int nd = __ballot(lane >= m.nv_damped && hd != 0.f) ? nv : m.nv_damped;
       SYNC();
-      const int nvt = (nv + 15) & ~15;
+      const int nvt = (nd + 15) & ~15;
       for (int e = lane; e < nvt * nvt; e += 64) { const int i = e / nvt, j = e - i * nvt; sm.H[i * NVP + j] = sm.M[i * NVP + j]; }
       SYNC();
-      if (lane < nv) sm.H[lane * NVP + lane] += hd;
+      if (lane < nd) sm.H[lane * NVP + lane] += hd;
       SYNC();
-      bchol_inplace<NVP>(sm.H, sm.invdiag_e, nv, lane);
-      qa = acc_own - bchol_solve<NVP>(sm.H, sm.invdiag_e, hd * acc_own, nv, lane);
+      qa = acc_own;
+      if (nd > 0) {
+        bchol_inplace<NVP>(sm.H, sm.invdiag_e, nd, lane);
+        const float corr = bchol_solve<NVP>(sm.H, sm.invdiag_e, lane < nd ? hd * acc_own : 0.f, nd, lane);
+        if (lane < nd) qa -= corr;
+      }
     } else if constexpr (!FAST) qa = chol_solve<NVP>(sm.Le, sm.invdiag_e, lane < nv ? sm.qfrc_smooth[lane] + sm.qfrc_constraint[lane] : 0.f, nv, lane);
     else {
       // register Cholesky of M + h diag(damping) (row r in lanes r, 16 + r, ...: K is fetched per 16-lane row); the transposed rows go through

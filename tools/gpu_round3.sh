@@ -6,6 +6,8 @@ set -x
 tag=${1:-r03}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout 600 python tools/box_probe.py > gpurun_out/${tag}_box_probe.txt 2>&1; rc=$?; cat gpurun_out/${tag}_box_probe.txt; if [ $rc -eq 3 ]; then echo 'faulty box: stopping'; exit 3; fi
+timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest_gpu.txt 2>&1; tail -3 gpurun_out/${tag}_pytest_gpu.txt
 # PMC first: profiles/valu_count.json and hbm_traffic.json must carry the sha of THIS build before the bench reads them
 KEEP=1 bash tools/pmc_pass.sh $tag sq1 hbm1 hbm2
 python tools/pmc_valu.py gpurun_out/$tag.sq1 4
