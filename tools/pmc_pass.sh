@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 run() { # name, counters
   rm -rf gpurun_out/$tag.$1
   timeout 600 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/$tag.$1 -o r -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --groups 1 --envs-per-gpu ${RSIM_B:-4096} > gpurun_out/$tag.$1.log 2>&1
-  python tools/pmc_sum.py gpurun_out/$tag.$1 k_step | tee gpurun_out/$tag.$1.txt; [ -n "$KEEP" ] || rm -rf gpurun_out/$tag.$1
+  python tools/pmc_sum.py gpurun_out/$tag.$1 'k_step<' | tee gpurun_out/$tag.$1.txt; [ -n "$KEEP" ] || rm -rf gpurun_out/$tag.$1
 }
 for s in $sets; do
 case $s in

@@ -10,7 +10,7 @@ def per_dispatch(d, counter):
     vals = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_step" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if "k_step<" in r["Kernel_Name"] and r["Counter_Name"] == counter:   # not k_step_dbg (forward / shim entries)
                 vals[int(r["Dispatch_Id"])] = vals.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
     return np.array([vals[k] for k in sorted(vals)])
 LAST = int(sys.argv[3]) if len(sys.argv) > 3 else 4

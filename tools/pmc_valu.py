@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 from robosuite_amd import backend  # noqa: E402
 
 
-def per_dispatch(d, counter, pat="k_step"):
+def per_dispatch(d, counter, pat="k_step<"):   # the control-step kernel, not k_step_dbg
     vals = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):

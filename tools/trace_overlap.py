@@ -1,6 +1,6 @@
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "k_step" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "k_step<" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 rows = rows[-16:]
 t0 = int(rows[0]["Start_Timestamp"])
