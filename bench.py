@@ -152,7 +152,8 @@ def main():
     ap.add_argument("--phase", choices=("staggered", "fresh"), default="staggered", help="episode phase of the envs when the timed region starts (module docstring)")
     ap.add_argument("--preroll", type=int, default=-1, help="untimed launches before the warm-up in the staggered phase (default: the horizon)")
     ap.add_argument("--groups", type=int, default=16, help="env blocks on their own HIP streams for the secondary open-loop figure; 1 = skip it")
-    ap.add_argument("--no-open-loop", action="store_true", help="skip the second timed region (the same K steps with stream groups)")
+    ap.add_argument("--no-open-loop", action="store_true", help="skip the second and third timed regions (the same K steps with stream groups; two half-batches alternating)")
+    ap.add_argument("--no-double-buffer", action="store_true", help="skip the third timed region (two half-batches stepped alternately, closed-loop compatible)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -235,6 +236,45 @@ def main():
                      "note": "the next K steps of the same envs as G env blocks on their own HIP streams (rsim_set_stream_groups): a block's step t + 1 does not wait "
                              "for the other blocks' step t -- reachable only with actions known in advance (an action tape), not by a closed-loop policy"}
 
+    # ---- double-buffered closed loop: the batch as two halves stepped alternately, each half's step t + 1 issued only after the HOST has seen its
+    # step t complete (stream synchronisation = the point where a policy would read that half's observations) -- while the other half is stepping
+    double_buffered = None
+    if K2 and not args.no_double_buffer:
+        halves = [ids[:len(ids) // 2], ids[len(ids) // 2:]]
+        envs2 = [build_env(args.config, flat, cfg, h, local_rank, 3 + (P + W + K) // HORIZON) for h in halves]
+        tapes2 = [torch.tensor(lift.env_actions(h, P + W + K, action_dim=adim), device=dev) for h in halves]
+        if P:
+            for e2, h in zip(envs2, halves):
+                e2.batch.set("ep_step", ((197 * h) % HORIZON).astype(np.int32))
+        drs = [0, 0]
+
+        def step2(k, t):
+            if dr:
+                envs2[k].batch.randomize_dynamics(seed=11, step=drs[k]); drs[k] += 1
+            envs2[k].step(tapes2[k][t])
+
+        for t in range(P + W):
+            for k in (0, 1):
+                step2(k, t)
+        for e2 in envs2:
+            e2.batch.sync()
+        torch.cuda.synchronize(); barrier()
+        t0 = time.perf_counter()
+        for t in range(K):
+            for k in (0, 1):
+                envs2[k].batch.sync()          # half k's observations of step t - 1 are complete: its policy can act
+                step2(k, P + W + t)
+        for e2 in envs2:
+            e2.batch.sync()
+        torch.cuda.synchronize(); barrier()
+        dt3 = shard.max_over_ranks(time.perf_counter() - t0, dev)
+        stale3 = sum(float(e2.batch.tensor("bank_stale").sum().item()) for e2 in envs2)
+        double_buffered = {"value": B * world * K / dt3, "ms_per_step": 1e3 * dt3 / K, "steps": K, "halves": [len(h) for h in halves], "bank_stale": int(stale3),
+                           "note": "closed-loop compatible: two half-batches (two rsim batches on their own streams) stepped alternately; the host waits for a half's "
+                                   "step t (its observations) before it issues that half's step t + 1, the other half steps meanwhile -- what a policy evaluated per "
+                                   "half can reach; `value` above is the stricter one-policy-call-per-step protocol"}
+        del envs2, tapes2
+
     st = shard.RolloutStats(dev)
     q = env.batch.tensor("qpos")
     # envs that hit the bad-state guard (RSIM_DIVERGED, MuJoCo's mj_checkPos semantics) or hold a non-finite coordinate
@@ -276,7 +316,7 @@ def main():
             "config": {"workload": f"{label}, 25 substeps x dt 0.002 + controllers per substep, fused in one launch per env (BASELINE {which})",
                        "envs_per_gpu": B, "global_envs": B * world, "n_sub": N_SUB, "per_env_seeded_reset": True, "horizon": HORIZON, "on_device_auto_reset": True,
                        "protocol": "lockstep: one control step of all envs per call, the next starts when all have finished (closed-loop compatible)",
-                       "open_loop": open_loop, "dynamics_randomisation": "re-drawn before every control step" if dr else None,
+                       "open_loop": open_loop, "double_buffered": double_buffered, "dynamics_randomisation": "re-drawn before every control step" if dr else None,
                        "episode_phase": (f"uniform over the horizon: step counters offset by (197 i) mod 500, then {P} untimed pre-roll launches" if P else "fresh: all envs at step W of their first episode"),
                        "reset_ring": {"bank_stale": int(bank_stale), "polls_in_region": ring1["polls"] - ring0["polls"], "rows_refilled_in_region": ring1["rows"] - ring0["rows"],
                                       "stepping_thread_ms_per_1000_steps": 1e6 * (ring1["tick_s"] - ring0["tick_s"]) / dsteps,

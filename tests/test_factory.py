@@ -54,6 +54,21 @@ def test_make_reads_model_and_controller_configuration_off_the_reference_objects
 
 
 @pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present (GPU box)")
+def test_make_extracts_pickplace_single_with_the_set_order_of_this_process():
+    """PickPlaceSingle (single_object_mode 1): the reference draws the episode's object from a Python set, so extract() records the order in which
+    THIS process iterates that set; the object keys of the observation table are named neutrally (they are the drawn object's, whichever it is);
+    everything else equals the fixture recorded under PYTHONHASHSEED=0."""
+    flat, cfg = factory.from_reference("PickPlaceSingle", "IIWA", seed=3)
+    g, gcfg, gflat = load_golden("seed3", "pickplace_single_iiwa")
+    t, gt = cfg["task"], gcfg["task"]
+    assert t["single_object_mode"] == 1 and sorted(t["mode1_order"]) == [0, 1, 2, 3]
+    assert {k: v for k, v in t.items() if k not in ("mode1_order", "object_id")} == {k: v for k, v in gt.items() if k not in ("mode1_order", "object_id")}
+    assert cfg["obs_keys"] == gcfg["obs_keys"] and cfg["obs_keys"][-5:] == ["obj_to_robot0_eef_pos", "obj_to_robot0_eef_quat", "obj_pos", "obj_quat", "obj_id"]
+    assert cfg["obs_dims"] == gcfg["obs_dims"] and sum(cfg["obs_dims"]) == 73
+    assert all(np.array_equal(np.ravel(flat.arrays[k]), np.ravel(gflat.arrays[k])) for k in gflat.arrays if k not in ("body_pos", "body_quat", "site_rgba"))   # visual twins (and their markers) follow the draw
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present (GPU box)")
 def test_kinematics_backend_serves_constructors_but_does_not_step():
     flat, _ = factory.load_shipped("lift_panda")
     kb = factory.KinematicsBackend(flat)
