@@ -378,14 +378,15 @@ def load_shipped(stem):
 
 
 def make(env_name, robots="Panda", n_envs=1, controller_configs=None, seed=0, horizon=500, device=0, bank_episodes=4, stream_groups=1, env_ids=None,
-         source="auto", reference_path=None, **kwargs):
+         source="auto", reference_path=None, alternating=False, **kwargs):
     """Batched counterpart of `robosuite.make(env_name, robots=..., controller_configs=..., **kwargs)` (environments/base.py:23-42): a
     `vec_env.VecEnv` of `n_envs` environments on `cuda:device`, env i seeded by `seed + i`.
 
     source: "assets" = only the shipped BASELINE configurations; "reference" = always construct the reference's env class and read the model and
     the controller configuration off it; "auto" (default) = shipped assets when (env_name, robots, controller type, kwargs) name one of them, the
-    reference otherwise.  Rendering-side kwargs default to the benchmark's (no renderer, no camera observations)."""
-    from .vec_env import VecEnv
+    reference otherwise.  Rendering-side kwargs default to the benchmark's (no renderer, no camera observations).
+    alternating=True: a `vec_env.AlternatingVecEnv` (two half-batches stepped alternately: closed-loop compatible, fills the drain of a lockstep launch)."""
+    from .vec_env import AlternatingVecEnv, VecEnv
 
     if not isinstance(robots, str):
         if len(robots) != 1:
@@ -401,6 +402,8 @@ def make(env_name, robots="Panda", n_envs=1, controller_configs=None, seed=0, ho
         flat, cfg = load_shipped(stem)
     else:
         flat, cfg = from_reference(env_name, robots, controller_configs, seed=seed, reference_path=reference_path, **kwargs)
+    if alternating:
+        return AlternatingVecEnv(env_name, n_envs, flat, cfg, device=device, seed=seed, horizon=horizon, env_ids=env_ids, bank_episodes=bank_episodes)
     return VecEnv(env_name, n_envs, flat, cfg, device=device, seed=seed, horizon=horizon, env_ids=env_ids, bank_episodes=bank_episodes, stream_groups=stream_groups)
 
 

@@ -386,3 +386,37 @@ def test_mpr_portal_warm_start_reaches_the_same_contacts():
         worst["qacc"] = max(worst["qacc"], float(np.abs(warm["qacc"][e] - cold["qacc"][e]).max() / max(1.0, np.abs(cold["qacc"][e]).max())))
     print("portal warm start vs cold run on the same states:", worst)
     assert worst["dist"] < 5e-6 and worst["ang"] < 0.1 and worst["pos"] < 2e-3 and worst["qacc"] < 5e-3, worst
+
+
+def test_alternating_half_batches_equal_the_whole_batch():
+    """vec_env.AlternatingVecEnv: two half-batches on their own rsim batches / streams, stepped alternately with the host waiting for a half's step t
+    before it issues that half's step t + 1.  Env i is env i of one big batch (seeding by global env id): observations, rewards, done flags and
+    terminal records equal the lockstep VecEnv's bitwise, through on-device episode restarts."""
+    from robosuite_amd.vec_env import AlternatingVecEnv, VecEnv
+    flat, cfg = _lift_assets()
+    B, T, H = 96, 23, 9
+    whole = VecEnv("Lift", B, flat, cfg, seed=5, horizon=H, bank_episodes=3)
+    alt = AlternatingVecEnv("Lift", B, flat, cfg, seed=5, horizon=H, bank_episodes=3)
+    from robosuite_amd import lift
+    tape = torch.tensor(lift.env_actions(np.arange(B), T), device="cuda")
+    o_w = whole.reset()
+    o_a = alt.reset()
+    h = B // 2
+    assert torch.equal(o_w[:h], o_a[0]) and torch.equal(o_w[h:], o_a[1])
+    ref = []
+    for t in range(T):
+        o, r, d, info = whole.step(tape[t])
+        whole.env.batch.sync()
+        ref.append((o.clone(), r.clone(), d.clone(), info["terminal_obs"].clone()))
+    for k, sl in ((0, slice(0, h)), (1, slice(h, B))):
+        alt.step_half(k, tape[0][sl])
+    for t in range(T):
+        for k, sl in ((0, slice(0, h)), (1, slice(h, B))):
+            o, r, d, info = alt.wait_half(k)
+            ro, rr, rd, rt = ref[t]
+            assert torch.equal(o, ro[sl]) and torch.equal(r, rr[sl]) and torch.equal(d, rd[sl]), (t, k)
+            if bool(d.any()):
+                assert torch.equal(info["terminal_obs"][d.bool()], rt[sl][d.bool()]), (t, k)
+            if t + 1 < T:
+                alt.step_half(k, tape[t + 1][sl])
+    assert sum(int(r[2].sum()) for r in ref) >= 2 * B      # every env restarted at least twice
