@@ -776,6 +776,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.newton_ns = getenv("RSIM_NEWTON_NS") ? (float)atof(getenv("RSIM_NEWTON_NS")) : RSIM_NEWTON_NS;
   dm.newton_na = getenv("RSIM_NEWTON_NA") ? (float)atof(getenv("RSIM_NEWTON_NA")) : RSIM_NEWTON_NA;
   dm.bp_reach = getenv("RSIM_BP_REACH") ? (float)atof(getenv("RSIM_BP_REACH")) : RSIM_BP_REACH;
+  dm.newton_wide = getenv("RSIM_NEWTON_WIDE") ? atoi(getenv("RSIM_NEWTON_WIDE")) : 1;
   dm.newton_ls = getenv("RSIM_NEWTON_LS") ? (float)atof(getenv("RSIM_NEWTON_LS")) : RSIM_NEWTON_LS;
   dm.newton_ng = getenv("RSIM_NEWTON_NG") ? (float)atof(getenv("RSIM_NEWTON_NG")) : RSIM_NEWTON_NG;
   if (m->multijoint) { int r = fail("rsim_batch_create: bodies with more than one joint are not supported by the fused kernel"); delete b; return r; }

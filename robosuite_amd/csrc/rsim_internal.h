@@ -134,7 +134,8 @@ struct DModel {
   int iterations, ls_iterations, cone, solver;
   float tolerance, meaninertia;
   float bp_reach;      // broadphase active pair list: bounding-sphere gap (m) up to which a pair is listed; 0: every pair every substep
-  float newton_ns, newton_na, newton_ng, newton_ls;   // fp32 stopping rules of the Newton solver (solve_newton): relative / absolute step floor, gradient noise factor
+  float newton_ns, newton_na, newton_ng, newton_ls;
+  int newton_wide;     // wide (nv > 16) configurations: 0 = neither fp32 rule, 1 = step rule and line-search exit as in the one-tile ones, 2 = line-search exit only   // fp32 stopping rules of the Newton solver (solve_newton): relative / absolute step floor, gradient noise factor
   const int* it;
   const float* ft;
   const float* ft0;            // shared copy of the float table (read for every field no env has overridden)

@@ -3597,9 +3597,9 @@ struct Sim {
       // start value (single-precision noise floor), or when the safeguarded Newton update no longer moves alpha
       const float dtol = fmaxf(gtol, 1e-6f * fabsf(d0));
       // ... or moves it by less than what the step rule below calls settled: a correction of alpha that changes no component of the acceleration by
-      // more than newton_ns |a_i| + newton_na is not worth an evaluation (one-tile configurations, as the step rule).  `p` always belongs to
+      // more than newton_ns |a_i| + newton_na is not worth an evaluation (the wide configurations: DModel.newton_wide, as the step rule).  `p` always belongs to
       // the alpha the loop ends on: the exits keep the point they evaluated, so nothing is evaluated twice.
-      const float atol = (FAST && m.newton_ls > 0.f && m.newton_ns > 0.f)
+      const float atol = ((FAST || m.newton_wide) && m.newton_ls > 0.f && m.newton_ns > 0.f)
                              ? m.newton_ls * wave_min_f((dofl && rr < nv && sk != 0.f) ? (m.newton_ns * fabsf(a) + m.newton_na) / fabsf(sk) : 3.0e38f) : 0.f;
       bool at_alpha = false;
       for (int ls = 0; ls < m.ls_iterations; ls++) {
@@ -3629,10 +3629,11 @@ struct Sim {
       const float a_new = fmaf(alpha, sk, a);
       // fp32: a step that moves no component of the acceleration by more than a few units in its last place (plus an absolute floor) cannot be
       // improved on by another factorisation
-      // (one-tile configurations only: on the wide models -- Robotiq finger links of 5e-5 kg m^2 under stiff contacts -- the Hessian's Cholesky factor
-      // resolves the soft directions poorly, the iteration creeps along them in many small steps, and cutting those off cost a factor of ten in how
-      // closely the finger joints track the oracle)
-      const bool settled = FAST && m.newton_ns > 0.f && !__ballot(dofl && rr < nv && fabsf(alpha * sk) > m.newton_ns * fabsf(a_new) + m.newton_na);
+      // (wide configurations: DModel.newton_wide.  An earlier form of the rule -- absolute floor 1e-6, before the line-search exit existed -- cost the
+      // Robotiq's 5e-5 kg m^2 finger links a factor of ten in how closely they track the oracle and was kept off the wide models; with the
+      // thresholds as they are the finger, arm and object tracking of the PickPlace / Stack / UR5e / Jaco fixtures is unchanged
+      // (tools/newton_wide_sweep.py, profiles/r03_r_newton_wide_sweep.txt) and Stack gains 9 %: on by default.)
+      const bool settled = (FAST || m.newton_wide == 1) && m.newton_ns > 0.f && !__ballot(dofl && rr < nv && fabsf(alpha * sk) > m.newton_ns * fabsf(a_new) + m.newton_na);
       a = a_new;
       iter++;
       if (scale * (p0 - p) < tolerance || settled) {
