@@ -1,12 +1,12 @@
 #!/bin/bash
-# PMC passes over the fused kernel (counters only: no trace domains besides kernel-trace).  Usage: tools/pmc_pass.sh <tag> [sets...]
+# PMC passes over the fused kernel (counters only: no trace domains besides kernel-trace).  Usage: [RSIM_CONFIG=stack|peg|pickplace] tools/pmc_pass.sh <tag> [sets...]
 tag=${1:-pmc}; shift
 sets=${@:-sq1 sq2 ic}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 run() { # name, counters
   rm -rf gpurun_out/$tag.$1
-  timeout 600 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/$tag.$1 -o r -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --groups 1 --envs-per-gpu ${RSIM_B:-4096} > gpurun_out/$tag.$1.log 2>&1
+  timeout ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/$tag.$1 -o r -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --groups 1 --config ${RSIM_CONFIG:-lift} ${RSIM_BENCH_EXTRA} > gpurun_out/$tag.$1.log 2>&1
   python tools/pmc_sum.py gpurun_out/$tag.$1 'k_step<' | tee gpurun_out/$tag.$1.txt; [ -n "$KEEP" ] || rm -rf gpurun_out/$tag.$1
 }
 for s in $sets; do

@@ -14,11 +14,13 @@ def per_dispatch(d, counter):
                 vals[int(r["Dispatch_Id"])] = vals.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
     return np.array([vals[k] for k in sorted(vals)])
 LAST = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+CONFIG = os.environ.get("RSIM_CONFIG", "lift")
+SFX = "" if CONFIG == "lift" else "_" + CONFIG
 rd, wr = per_dispatch(sys.argv[1], "FETCH_SIZE")[-LAST:], per_dispatch(sys.argv[2], "WRITE_SIZE")[-LAST:]
 # the timed control steps are the last dispatches of the run (before them: forward(), controller reset, the untimed pre-roll)
 out = {"bytes_per_launch": float((np.median(rd) + np.median(wr)) * 1024.0), "fetch_kb_median": float(np.median(rd)), "write_kb_median": float(np.median(wr)),
-       "dispatches": int(len(rd)), "lib_sha16": hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16], "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, KiB per dispatch; gfx950 FETCH_SIZE may under-report wide "
+       "dispatches": int(len(rd)), "config": CONFIG, "lib_sha16": hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16], "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, KiB per dispatch; gfx950 FETCH_SIZE may under-report wide "
        "coalesced reads by 2x (MI355X guide) - this kernel issues dword loads; reads include the whole float-table FIELDS that carry per-env values "
        "(cube size / mass / inertia / inverse weights: 273 floats per env, of which 17 differ), the shared tables stay L2-resident; writes are dominated by the private segment (156 B per lane x 64 lanes x one wavefront per env, written once per launch and evicted), the narrow-phase warm-start records and the broadphase pair list"}
-json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "hbm_traffic" + SFX + ".json"), "w"), indent=1)
 print(out)

@@ -20,14 +20,17 @@ def per_dispatch(d, counter, pat="k_step<"):   # the control-step kernel, not k_
 if __name__ == "__main__":
     d = sys.argv[1]
     last = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    B, n_sub = int(os.environ.get("RSIM_B", 4096)), 25
+    CONFIG = os.environ.get("RSIM_CONFIG", "lift")       # bench.py --config: the file becomes profiles/valu_count_<config>.json
+    SFX = "" if CONFIG == "lift" else "_" + CONFIG
+    B, n_sub = int(os.environ.get("RSIM_B", {"lift": 4096, "stack": 4096, "peg": 2048, "pickplace": 8192}[CONFIG])), 25
     v = per_dispatch(d, "SQ_INSTS_VALU")[-last:]        # the timed control steps are the last dispatches of the run
     out = {"valu_per_env_substep": float(np.mean(v) / (B * n_sub)), "dispatches": int(len(v)), "envs": B,
            "lib_sha16": hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16],
+           "config": CONFIG,
            "note": "rocprofv3 --pmc SQ_INSTS_VALU, mean over the last control-step dispatches of `bench.py --steps 4 --warmup 1` (steady-state episode phase)"}
     for c in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES"):
         x = per_dispatch(d, c)[-last:]
         if len(x):
             out[c.lower() + "_per_env_substep"] = float(np.mean(x) / (B * n_sub))
-    json.dump(out, open(os.path.join(ROOT, "profiles", "valu_count.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "valu_count" + SFX + ".json"), "w"), indent=1)
     print(out)
