@@ -35,3 +35,34 @@ def test_gen_golden_reproduces_the_committed_lift_fixture(tmp_path):
         assert v == new.names[k], k
     for k, a in old.arrays.items():
         assert np.array_equal(a, new.arrays[k]), k
+
+
+_SENSOR_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, "/root/reference")
+from robosuite_amd import shim
+from oracle.shim_backend import OracleBackend
+shim.install(OracleBackend)
+import robosuite as suite
+env = suite.make("Lift", robots="Panda", has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, control_freq=20, horizon=50, seed=0)
+env.reset()
+robot = env.robots[0]
+names = robot.gripper["right"].important_sensors
+for t in range(3):
+    env.step(np.array([0, 0, -0.3, 0, 0, 0, 1.0]))
+f = robot.get_sensor_measurement(names["force_ee"]); tq = robot.get_sensor_measurement(names["torque_ee"])
+sd = np.array(env.sim.data.sensordata)
+assert f.shape == (3,) and tq.shape == (3,) and np.array_equal(np.concatenate([f, tq]), sd[:6]), (f, tq, sd)
+sub = env.sim.model.body_subtreemass[env.sim.model.site_bodyid[env.sim.model.site_name2id(robot.gripper["right"].naming_prefix + "ft_frame")]]
+assert 0.3 * sub * 9.81 < np.linalg.norm(f) < 5.0 * sub * 9.81, (np.linalg.norm(f), sub)
+print("ok", f, tq, sub)
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/robosuite"), reason="reference checkout not present (GPU box)")
+def test_reference_robot_reads_the_wrist_force_torque_sensors_through_the_shim():
+    """Robot.get_sensor_measurement (robots/robot.py:739-751: slices of sim.data.sensordata by model.sensor_dim, names from the gripper model's
+    important_sensors) on the unmodified reference env over the shim: the values are the backend's acceleration-stage sensors (round 2: zeros),
+    a wrist force of the order of the gripper's weight while the arm moves down."""
+    r = subprocess.run([sys.executable, "-c", _SENSOR_SNIPPET % ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
