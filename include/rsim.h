@@ -95,6 +95,8 @@ typedef struct rsim_ctrl_desc {
  *                             object's own pos / quat sensors and read them from the observation cache) while the gripper pose is current; after
  *                             rsim_observe (reset) they are zero.  pos_slot[a] = offset of `{obj}_pos` (3 floats, followed by `{obj}_quat` xyzw)
  *                             in the observation record.
+ *   RSIM_OBS_TASK_OBJECT: the `obj_id` observable of PickPlace single-object mode 1 (pick_place.py:626-635): RSIM_TASK_OBJECT of the env as a float;
+ *                             in that mode a = -1 in REL_POS / REL_QUAT / BODY_POS / BODY_QUAT means "the env's current object" (its root body).
  * Sampling instants follow the reference exactly: after `reset()` every Observable samples on the LAST substep of a control step,
  * i.e. positions/orientations come from that substep's step1 kinematics, qpos/qvel from after its step2 (utils/observables.py:214-259).
  * task 1: reward = Lift.reward (environments/manipulation/lift.py:224-273), success = Lift._check_success (lift.py:433-444),
