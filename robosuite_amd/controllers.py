@@ -188,6 +188,116 @@ class TorchJointTorqueController(BatchedController):
         return self.goal_torque + self.torque_compensation
 
 
+class TorchOSCController(BatchedController):
+    """OperationalSpaceController (controllers/parts/arm/osc.py) as a batched plugin: OSC_POSE / OSC_POSITION with fixed impedance, delta inputs in the
+    robot-base frame, goals updated from the achieved pose -- the configuration of the reference's default robot configs
+    (controllers/config/default/parts/osc_pose.json) and of the in-kernel controller (rsim_step.hip ctrl_run_osc).
+
+      set_goal        osc.py:225-288, 306-401: scaled delta -> goal position / orientation in the base frame
+      run_controller  osc.py:403-495 with utils/control_utils.py:43-140: errors -> desired force / torque -> Lambda (pseudo-inverses of
+                      J M^-1 J^T and of its position / orientation blocks) -> J^T wrench + torque compensation + nullspace posture torques
+    eef_site / base_site: model site ids of `{gripper}grip_site` and `{robot}{part}_center` (controller.py:88-100)."""
+
+    name = "OSC_POSE"
+
+    def __init__(self, state, joint_indexes, actuator_range, eef_site, base_site, kp=150.0, damping_ratio=1.0, input_max=1, input_min=-1,
+                 output_max=(0.05, 0.05, 0.05, 0.5, 0.5, 0.5), output_min=(-0.05, -0.05, -0.05, -0.5, -0.5, -0.5), uncouple_pos_ori=True,
+                 control_ori=True, nullspace_kp=10.0, **kw):
+        import torch
+
+        super().__init__(state, joint_indexes, actuator_range, **kw)
+        self.eef_site, self.base_site, self.use_ori, self.uncoupling = int(eef_site), int(base_site), bool(control_ori), bool(uncouple_pos_ori)
+        self.control_dim = 6 if self.use_ori else 3
+        t = lambda v, n: torch.as_tensor(np.broadcast_to(np.asarray(v, dtype=np.float32), (n,)).copy(), device=state.device)   # noqa: E731
+        self.kp = t(kp, 6)
+        self.kd = 2.0 * torch.sqrt(self.kp) * t(damping_ratio, 6)
+        self.input_max, self.input_min = np.broadcast_to(np.asarray(input_max, dtype=np.float32), (self.control_dim,)), np.broadcast_to(np.asarray(input_min, dtype=np.float32), (self.control_dim,))
+        self.output_max, self.output_min = np.asarray(output_max, dtype=np.float32)[:self.control_dim], np.asarray(output_min, dtype=np.float32)[:self.control_dim]
+        self.nullspace_kp = float(nullspace_kp)
+        self.goal_pos = torch.zeros(state.B, 3, device=state.device)
+        self.goal_ori = torch.eye(3, device=state.device).repeat(state.B, 1, 1)
+        self.initial_joint = torch.zeros(state.B, self.joint_dim, device=state.device)
+
+    # ---- what Controller.update() reads (controller.py:170-232), for every env -------------------
+    def frames(self):
+        """(eef position, eef rotation, base position, base rotation)"""
+        ep, eR = self.state.site_pose(self.eef_site)
+        op, oR = self.state.site_pose(self.base_site)
+        return ep, eR, op, oR
+
+    def jacobians(self):
+        """(J_full [B, 6, n] over the part's dofs, eef velocity [B, 6], base velocity [B, 6])"""
+        import torch
+
+        jp, jr = self.state.site_jacobian(self.eef_site)
+        bp, br = self.state.site_jacobian(self.base_site)
+        qv = self.state.qvel
+        ev = torch.cat([torch.einsum("bij,bj->bi", jp, qv), torch.einsum("bij,bj->bi", jr, qv)], dim=1)
+        bv = torch.cat([torch.einsum("bij,bj->bi", bp, qv), torch.einsum("bij,bj->bi", br, qv)], dim=1)
+        return torch.cat([jp[:, :, self.qvel_index], jr[:, :, self.qvel_index]], dim=1), ev, bv
+
+    def reset_goal(self, mask=None):
+        """Controller construction at (re)set (robots/robot.py:271, controller.py:128-130, osc.py:520-532): initial_joint = joint positions, goal = current pose."""
+        import torch
+
+        ep, eR, op, oR = self.frames()
+        m = torch.ones(self.state.B, dtype=torch.bool, device=self.state.device) if mask is None else mask
+        self.initial_joint = torch.where(m[:, None], self.joint_pos, self.initial_joint)
+        self.goal_pos = torch.where(m[:, None], ep, self.goal_pos)
+        self.goal_ori = torch.where(m[:, None, None], eR, self.goal_ori)
+
+    def set_goal(self, action):
+        import torch
+
+        d = self.scale_action(action)
+        ep, eR, op, oR = self.frames()
+        self.goal_pos = torch.einsum("bji,bj->bi", oR, ep - op) + d[:, :3]                      # world_to_origin_frame(ref_pos) + delta (osc.py:306-345)
+        cur = torch.einsum("bji,bjk->bik", oR, eR)                                              # eef orientation in the base frame
+        if self.use_ori:
+            ang = torch.linalg.norm(d[:, 3:6], dim=1, keepdim=True)                             # axis-angle delta -> rotation (osc.py:347-401)
+            ax = d[:, 3:6] / torch.where(ang > 0, ang, torch.ones_like(ang))
+            w, v = torch.cos(0.5 * ang), ax * torch.sin(0.5 * ang)
+            w = torch.where(ang > 0, w, torch.ones_like(w))
+            Rerr = BatchState.quat2mat(torch.cat([w, v], dim=1))
+            self.goal_ori = torch.einsum("bij,bjk->bik", Rerr, cur)
+        else:
+            self.goal_ori = cur
+
+    def torques_from(self, ep, eR, ev, op, oR, bv, J, M, bias, q, qd):
+        """The torque law on explicit inputs ([B, ...] tensors): run_controller() gathers them from the batch state; tests feed recorded ones."""
+        import torch
+
+        # float64 inside: J M^-1 J^T of a 7-dof arm reaches condition numbers of 1e5-1e6 (tests/golden/lift_panda_singular), which a float32 inverse + pseudo-
+        # inverse turns into per-cent errors of the nullspace term; the fused kernel avoids that with Cholesky solves, a plugin can simply afford doubles
+        out_dtype = J.dtype
+        ep, eR, ev, op, oR, bv, J, M, bias, q, qd = (x.double() for x in (ep, eR, ev, op, oR, bv, J, M, bias, q, qd))
+        goal_pos, goal_ori, q0, kp, kd = self.goal_pos.double(), self.goal_ori.double(), self.initial_joint.double(), self.kp.double(), self.kd.double()
+        dpos = op + torch.einsum("bij,bj->bi", oR, goal_pos)
+        dori = torch.einsum("bij,bjk->bik", oR, goal_ori)
+        # orientation_error (control_utils.py:85-112): half the sum of the cross products of corresponding axes
+        oerr = 0.5 * sum(torch.cross(eR[:, :, c], dori[:, :, c], dim=1) for c in range(3))
+        F = (dpos - ep) * kp[:3] - (ev[:, :3] - bv[:, :3]) * kd[:3]
+        T = oerr * kp[3:] - (ev[:, 3:] - bv[:, 3:]) * kd[3:]
+        Minv = torch.linalg.inv(M)
+        MiJT = torch.einsum("bij,bkj->bik", Minv, J)                                            # M^-1 J^T  [B, n, 6]
+        lfi = torch.einsum("bij,bjk->bik", J, MiJT)                                             # J M^-1 J^T
+        lf = torch.linalg.pinv(lfi)
+        if self.uncoupling:
+            wrench = torch.cat([torch.einsum("bij,bj->bi", torch.linalg.pinv(lfi[:, :3, :3]), F), torch.einsum("bij,bj->bi", torch.linalg.pinv(lfi[:, 3:, 3:]), T)], dim=1)
+        else:
+            wrench = torch.einsum("bij,bj->bi", lf, torch.cat([F, T], dim=1))
+        tau = torch.einsum("bji,bj->bi", J, wrench) + bias
+        # nullspace_torques (control_utils.py:115-140): N^T M (kp (q0 - q) - 2 sqrt(kp) qd), N = I - Jbar J, Jbar = M^-1 J^T Lambda
+        N = torch.eye(J.shape[2], device=J.device, dtype=J.dtype)[None] - torch.einsum("bij,bjk->bik", torch.einsum("bij,bjk->bik", MiJT, lf), J)
+        pose = torch.einsum("bij,bj->bi", M, self.nullspace_kp * (q0 - q) - 2.0 * float(np.sqrt(self.nullspace_kp)) * qd)
+        return (tau + torch.einsum("bji,bj->bi", N, pose)).to(out_dtype)
+
+    def run_controller(self):
+        ep, eR, op, oR = self.frames()
+        J, ev, bv = self.jacobians()
+        return self.torques_from(ep, eR, ev, op, oR, bv, J, self.mass_matrix, self.torque_compensation, self.joint_pos, self.joint_vel)
+
+
 class TorchGripController(BatchedController):
     """PandaGripper.format_action + SimpleGripController (models/grippers/panda_gripper.py:43-58, controllers/parts/gripper/simple_grip.py:110-186): the
     one-dimensional action moves an internal state in [-1, 1] by `speed * sign(action)` per control step; the actuators' position targets are
@@ -242,9 +352,11 @@ class HostControlledEnv:
         self._lo = [torch.as_tensor(cr[p.actuator_ids, 0], device=self.state.device) for p in self.parts]
         self._hi = [torch.as_tensor(cr[p.actuator_ids, 1], device=self.state.device) for p in self.parts]
         self.action_dim = max(p.action_slice.stop for p in self.parts)
+        self._restarted = None
 
     def reset(self, block: int = 0):
         self.task.reset(block)
+        self._restarted = None
         for p in self.parts:
             p.controller.reset_goal()
 
@@ -256,14 +368,16 @@ class HostControlledEnv:
             b.step1()
             for p, ids, lo, hi in zip(self.parts, self._ids, self._lo, self._hi):
                 if i == 0:
+                    if self._restarted is not None:
+                        # envs restarted on the device by the previous step get fresh controllers (robots/robot.py:271) -- now, after the first step1
+                        # of their new episode: only then do the frames a task-space controller resets its goal from belong to the new state
+                        p.controller.reset_goal(self._restarted)
                     p.controller.set_goal(actions[:, p.action_slice])          # policy step: composite_controller.set_goal (composite_controller.py:97-103)
                 ctrl[:, ids] = torch.minimum(torch.maximum(p.controller.run_controller(), lo), hi)
             if i < self.n_sub - 1:
                 b.step2()
             else:
                 b.step2_last()
-        done = b.tensor("done").to(torch.bool)
-        for p in self.parts:                                                   # envs restarted on the device get fresh controllers (robots/robot.py:271)
-            p.controller.reset_goal(done)
+        self._restarted = b.tensor("done").to(torch.bool).clone()
         self.task._bank_tick()
         return self.task.obs(), self.task.reward(), b.tensor("done"), {"success": self.task.success()}

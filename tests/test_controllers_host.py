@@ -79,3 +79,45 @@ def test_scale_action_and_reset_masks_follow_the_reference_contract():
     assert (grip.current_action[0] == 0).all() and (grip.current_action[1] != 0).all()
     with pytest.raises(NotImplementedError):
         BatchedController(st, dict(joints=[0], qpos=[0], qvel=[0]), ([-1.0], [1.0])).run_controller()
+
+
+class RecordedState(CpuState):
+    """A state whose site frames are whatever the test puts there (the recorded inputs of the reference's controller calls)."""
+
+    def __init__(self, B, nq, nv):
+        super().__init__(B, nq, nv)
+        self.poses = {}
+
+    def site_pose(self, site):
+        return self.poses[site]
+
+
+@pytest.mark.parametrize("tag", ("seed0_gentle", "seed1_full"))
+def test_torch_osc_plugin_reproduces_the_reference_controller_on_its_recorded_inputs(tag):
+    """TorchOSCController against the reference's OperationalSpaceController: tests/golden/lift_panda_<tag> holds, for each of its 1000 run_controller()
+    calls, every input the class read (frames, velocities, Jacobian, mass matrix, bias, joint state, goals) and the torques it returned -- the batch
+    dimension of the plugin is used as "one env per recorded call".  Then set_goal(): the goals the reference held after each policy step from the
+    frames it saw."""
+    from robosuite_amd.controllers import TorchOSCController
+    g, cfg, flat = load_golden(tag)
+    n = len(g["tau"])
+    st = RecordedState(n, flat.nq, flat.nv)
+    f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)   # noqa: E731
+    cr = np.asarray(flat.actuator_ctrlrange)
+    jidx = dict(joints=cfg["qpos_idx"], qpos=cfg["qpos_idx"], qvel=cfg["dof_idx"])
+    c = TorchOSCController(st, jidx, (cr[cfg["act_idx"], 0], cr[cfg["act_idx"], 1]), cfg["eef_site"], cfg["base_site"], kp=cfg["kp"], damping_ratio=cfg["damping_ratio"],
+                           input_max=cfg["input_max"], input_min=cfg["input_min"], output_max=cfg["output_max"], output_min=cfg["output_min"],
+                           uncouple_pos_ori=bool(cfg["uncouple"]), nullspace_kp=cfg.get("nullspace_kp", 10.0))
+    c.goal_pos, c.goal_ori, c.initial_joint = f32(g["goal_pos"]), f32(g["goal_ori"]), f32(g["q0"])
+    tau = c.torques_from(f32(g["ep"]), f32(g["eR"]), f32(g["ev"]), f32(g["op"]), f32(g["oR"]), f32(g["bv"]), f32(g["J"]), f32(g["M"]), f32(g["bias"]), f32(g["q"]), f32(g["qd"]))
+    err = np.abs(tau.numpy() - g["tau"]).max(axis=1) / np.maximum(1.0, np.abs(g["tau"]).max(axis=1))
+    assert err.max() < 2e-4, (err.max(), int(err.argmax()))     # fp32 torch against the reference's float64 (the in-kernel law is held to the same bound)
+    # set_goal at every policy step: the state the reference saw is that of the first controller call of the step
+    n_sub = n // len(g["actions"])
+    k0 = np.arange(len(g["actions"])) * n_sub
+    st2 = RecordedState(len(k0), flat.nq, flat.nv)
+    c2 = TorchOSCController(st2, jidx, (cr[cfg["act_idx"], 0], cr[cfg["act_idx"], 1]), cfg["eef_site"], cfg["base_site"], kp=cfg["kp"], damping_ratio=cfg["damping_ratio"],
+                            input_max=cfg["input_max"], input_min=cfg["input_min"], output_max=cfg["output_max"], output_min=cfg["output_min"])
+    st2.poses = {cfg["eef_site"]: (f32(g["ep"][k0]), f32(g["eR"][k0])), cfg["base_site"]: (f32(g["op"][k0]), f32(g["oR"][k0]))}
+    c2.set_goal(f32(g["actions"][:, :6]))
+    assert np.abs(c2.goal_pos.numpy() - g["goal_pos"][k0]).max() < 2e-6 and np.abs(c2.goal_ori.numpy() - g["goal_ori"][k0]).max() < 2e-6

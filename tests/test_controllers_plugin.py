@@ -113,3 +113,42 @@ def test_a_user_defined_controller_runs_on_the_batch():
         obs, rew, done, info = env.step(a)
     q = task.batch.get("qpos")[:, :7]
     assert np.isfinite(q).all() and np.abs(q - q0).max() < 5e-3 and np.abs(task.batch.get("qvel")[:, :7]).max() < 5e-2
+
+
+def test_torch_osc_plugin_tracks_the_in_kernel_osc_controller():
+    """TorchOSCController (the reference's OperationalSpaceController re-expressed for the batched protocol, pinned on CPU against the reference's
+    recorded calls: tests/test_controllers_host.py) driven through rsim_step1 / rsim_step2 on device tensors -- frames, site Jacobians, mass matrix
+    and bias from BatchState -- against the OSC law inside the fused kernel, through an on-device episode restart (goals and initial_joint of a
+    restarted env are re-captured from its new state)."""
+    from robosuite_amd import lift
+    from robosuite_amd.controllers import BatchState, HostControlledEnv, Part, TorchGripController, TorchOSCController
+    from tests.util import load_golden
+    g, cfg, flat = load_golden("seed1_full")
+    B, T, H = 6, 8, 5
+    ids = np.arange(B)
+    fused = lift.LiftBatch(flat, cfg, ids, seed0=4, horizon=H, bank_episodes=3)
+    hosted = lift.LiftBatch(flat, cfg, ids, seed0=4, horizon=H, bank_episodes=3)
+    st = BatchState(hosted.batch)
+    cr = np.asarray(flat.actuator_ctrlrange)
+    arm = TorchOSCController(st, dict(joints=cfg["qpos_idx"], qpos=cfg["qpos_idx"], qvel=cfg["dof_idx"]), (cr[cfg["act_idx"], 0], cr[cfg["act_idx"], 1]),
+                             cfg["eef_site"], cfg["base_site"], kp=cfg["kp"], damping_ratio=cfg["damping_ratio"], input_max=cfg["input_max"], input_min=cfg["input_min"],
+                             output_max=cfg["output_max"], output_min=cfg["output_min"], uncouple_pos_ori=bool(cfg["uncouple"]))
+    grip = TorchGripController(st, dict(joints=cfg["grip_qpos_idx"], qpos=cfg["grip_qpos_idx"], qvel=cfg["grip_dof_idx"]),
+                               (cr[cfg["grip_act"], 0], cr[cfg["grip_act"], 1]), signs=cfg["grip_sign"], speed=cfg["grip_speed"])
+    env = HostControlledEnv(hosted, [Part(arm, slice(0, 6), cfg["act_idx"]), Part(grip, slice(6, 7), cfg["grip_act"])])
+    env.reset()
+    fused.reset()
+    acts = torch.tensor(0.5 * lift.env_actions(ids, T), device="cuda")
+    worst = {}
+    for t in range(T):
+        fused.step(acts[t])
+        env.step(acts[t])
+        for k in ("done", "ep_step", "ep_index"):
+            assert np.array_equal(fused.batch.get(k), hosted.batch.get(k)), (t, k)
+        for k, tol in (("qpos", 2e-6), ("qvel", 2e-5), ("ctrl", 1e-4), ("reward", 1e-6)):       # measured 8e-8, 9e-7, 6e-6, 3e-8
+            a, b = fused.batch.get(k), hosted.batch.get(k)
+            e = np.abs(a - b).max() / max(1.0, np.abs(a).max())
+            worst[k] = max(worst.get(k, 0.0), float(e))
+            assert e <= tol, (t, k, e)
+    print("torch OSC plugin vs in-kernel OSC, worst relative deviations over", T, "control steps:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert fused.batch.get("ep_index").tolist() == [1] * B
