@@ -66,3 +66,38 @@ def test_reference_robot_reads_the_wrist_force_torque_sensors_through_the_shim()
     a wrist force of the order of the gripper's weight while the arm moves down."""
     r = subprocess.run([sys.executable, "-c", _SENSOR_SNIPPET % ROOT], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
+
+
+_FAMILIES_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, "/root/reference")
+from robosuite_amd import shim, backend
+from oracle.shim_backend import OracleBackend
+shim.install(OracleBackend)
+import robosuite as suite
+cases = [("Door", "Panda", {}, 2), ("NutAssemblySquare", "Panda", {}, 3), ("Lift", "Sawyer", {}, 2), ("Lift", "Kinova3", {}, 3),
+         ("TwoArmLift", ["Panda", "Panda"], dict(env_configuration="opposed"), -1)]
+for name, robots, kw, want in cases:
+    env = suite.make(name, robots=robots, has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, control_freq=20, seed=0, **kw)
+    obs = env.reset()
+    spec = {k: np.atleast_1d(v).shape for k, v in obs.items()}
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        obs, r, d, info = env.step(rng.uniform(-1, 1, env.action_dim))
+        assert {k: np.atleast_1d(v).shape for k, v in obs.items()} == spec, name
+        assert all(np.isfinite(np.atleast_1d(v)).all() for v in obs.values()) and np.isfinite(r), name
+    flat = env.sim.model._model._flat
+    cid = backend.HipModel(flat).kernel_config()[0]
+    assert cid == want, (name, cid, want)
+    print("ok", name, robots, "nv", flat.nv, "cfg", cid)
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/robosuite"), reason="reference checkout not present (GPU box)")
+def test_reference_environment_families_run_over_the_shim_and_map_to_a_kernel_configuration():
+    """The shape of the reference's crash-only smoke test (tests/test_environments/test_all_environments.py:16-93: make, reset, random steps, observation
+    keys and shapes) for model families beyond the BASELINE configs, on the oracle backend: the MJCF the reference assembles compiles (hinged door,
+    nut on a peg, Sawyer and Kinova3 + Robotiq85 with spring tendons, two Pandas), steps with finite observations of constant shapes, and
+    rsim_model_config names the compiled kernel configuration that serves it (-1: more candidate pairs than the largest)."""
+    r = subprocess.run([sys.executable, "-c", _FAMILIES_SNIPPET % ROOT], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.count("ok ") == 5, (r.stdout[-800:], r.stderr[-1500:])
