@@ -131,3 +131,20 @@ def test_make_baxter_joint_velocity_from_assets_with_the_reference_kwargs():
     assert env.action_dim == 14 and tuple(obs.shape) == (4, 109)
     o, r, d, info = env.step(torch.zeros(4, 14, device="cuda"))
     assert torch.isfinite(o).all() and torch.isfinite(r).all()
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present (GPU box)")
+def test_two_makes_with_one_seed_agree_and_another_seed_differs():
+    """The reference's determinism test (tests/test_environments/test_env_determinism.py:27-114: two make(seed=s) + reset() -> identical XML and initial
+    state) at this boundary: two extractions of Lift / Panda with one seed give the same compiled model and configuration bit for bit and the same
+    host-side episode, another seed another cube."""
+    from robosuite_amd import lift
+    a_flat, a_cfg = factory.from_reference("Lift", "Panda", seed=7)
+    b_flat, b_cfg = factory.from_reference("Lift", "Panda", seed=7)
+    c_flat, c_cfg = factory.from_reference("Lift", "Panda", seed=8)
+    assert a_cfg == b_cfg and all(np.array_equal(a_flat.arrays[k], b_flat.arrays[k]) for k in a_flat.arrays)
+    cube = a_flat.names["geom"].index("cube_g0")
+    assert not np.array_equal(a_flat.geom_size[cube], c_flat.geom_size[cube])
+    (s1, q1), (s2, q2), (s3, q3) = lift.episode_setup(7, [0, 1]), lift.episode_setup(7, [0, 1]), lift.episode_setup(8, [0, 1])
+    assert np.array_equal(q1, q2) and np.array_equal(s1, s2) and not np.array_equal(q1, q3)
+    assert np.array_equal(q1[1], q3[0])                       # env i of seed s is default_rng(s + i): the streams are keyed by seed + global env id
