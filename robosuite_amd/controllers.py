@@ -188,6 +188,45 @@ class TorchJointTorqueController(BatchedController):
         return self.goal_torque + self.torque_compensation
 
 
+class TorchJointPositionController(BatchedController):
+    """JointPositionController (controllers/parts/generic/joint_pos.py:184-266, fixed impedance, delta inputs, no interpolator): goal_qpos = joint_pos +
+    scale_action(action), clipped to `qpos_limits` if given; torques = M_part (kp (goal - q) - kd qd) + torque_compensation."""
+
+    name = "JOINT_POSITION"
+
+    def __init__(self, state, joint_indexes, actuator_range, input_max=1, input_min=-1, output_max=0.05, output_min=-0.05, kp=50.0, damping_ratio=1.0,
+                 qpos_limits=None, use_torque_compensation=True, **kw):
+        import torch
+
+        super().__init__(state, joint_indexes, actuator_range, **kw)
+        self.input_max, self.input_min, self.output_max, self.output_min = input_max, input_min, output_max, output_min
+        t = lambda v: torch.as_tensor(np.broadcast_to(np.asarray(v, dtype=np.float32), (self.joint_dim,)).copy(), device=state.device)   # noqa: E731
+        self.kp = t(kp)
+        self.kd = 2.0 * torch.sqrt(self.kp) * t(damping_ratio)
+        self.limits = None if qpos_limits is None else (t(qpos_limits[0]), t(qpos_limits[1]))
+        self.use_torque_compensation = bool(use_torque_compensation)
+        self.goal_qpos = torch.zeros(state.B, self.joint_dim, device=state.device)
+
+    def reset_goal(self, mask=None):
+        import torch
+
+        self.goal_qpos = self.joint_pos.clone() if mask is None else torch.where(mask[:, None], self.joint_pos, self.goal_qpos)
+
+    def set_goal(self, action):
+        import torch
+
+        g = self.joint_pos + self.scale_action(action)
+        self.goal_qpos = g if self.limits is None else torch.minimum(torch.maximum(g, self.limits[0]), self.limits[1])
+
+    def run_controller(self):
+        import torch
+
+        want = (self.goal_qpos - self.joint_pos) * self.kp - self.joint_vel * self.kd
+        if not self.use_torque_compensation:
+            return want
+        return torch.einsum("bij,bj->bi", self.mass_matrix, want) + self.torque_compensation
+
+
 class TorchOSCController(BatchedController):
     """OperationalSpaceController (controllers/parts/arm/osc.py) as a batched plugin: OSC_POSE / OSC_POSITION with fixed impedance, delta inputs in the
     robot-base frame, goals updated from the achieved pose -- the configuration of the reference's default robot configs

@@ -121,3 +121,34 @@ def test_torch_osc_plugin_reproduces_the_reference_controller_on_its_recorded_in
     st2.poses = {cfg["eef_site"]: (f32(g["ep"][k0]), f32(g["eR"][k0])), cfg["base_site"]: (f32(g["op"][k0]), f32(g["oR"][k0]))}
     c2.set_goal(f32(g["actions"][:, :6]))
     assert np.abs(c2.goal_pos.numpy() - g["goal_pos"][k0]).max() < 2e-6 and np.abs(c2.goal_ori.numpy() - g["goal_ori"][k0]).max() < 2e-6
+
+
+def test_torch_joint_position_controller_reproduces_the_reference_class_call_by_call():
+    """TorchJointPositionController against every run_controller() call the reference's JointPositionController made in the env loop of
+    tests/golden/lift_panda_ctl_joint_position (state it saw, goal it held, torques it returned); the mass matrix and the bias come from the oracle
+    at the recorded state."""
+    from robosuite_amd.controllers import TorchJointPositionController
+    g, cfg, flat = load_golden("ctl_joint_position")
+    om, od, _ = make_oracle(flat)
+    n_sub = len(g["sub_qpos"]) // len(g["actions"])
+    st = CpuState(2, flat.nq, flat.nv)
+    cr = np.asarray(flat.actuator_ctrlrange)
+    c = TorchJointPositionController(st, dict(joints=cfg["qpos_idx"], qpos=cfg["qpos_idx"], qvel=cfg["dof_idx"]), (cr[cfg["act_idx"], 0], cr[cfg["act_idx"], 1]),
+                                     input_max=cfg["input_max"], input_min=cfg["input_min"], output_max=cfg["output_max"], output_min=cfg["output_min"],
+                                     kp=cfg["kp"], damping_ratio=cfg["damping_ratio"])
+    assert np.allclose(c.kd.numpy(), cfg["kd"], rtol=1e-6)
+    worst = 0.0
+    for t, a in enumerate(g["actions"]):
+        for s in range(n_sub):
+            k = t * n_sub + s
+            od.qpos[:] = g["sub_qpos"][k]; od.qvel[:] = g["sub_qvel"][k]; od.forward()
+            st.qpos[:] = torch.tensor(g["sub_qpos"][k], dtype=torch.float32); st.qvel[:] = torch.tensor(g["sub_qvel"][k], dtype=torch.float32)
+            st.qfrc_bias[:] = torch.tensor(np.array(od.qfrc_bias), dtype=torch.float32)
+            st.qM[:] = torch.tensor(od.full_M(), dtype=torch.float32)
+            if s == 0:                                           # set_goal at the policy step, from the state of its first substep
+                c.set_goal(torch.tensor(np.repeat(a[None, :7], 2, 0), dtype=torch.float32))
+            assert np.abs(c.goal_qpos[0].numpy() - g["sub_goal_right"][k]).max() < 2e-6, (t, s)
+            tau = c.run_controller()
+            e = np.abs(tau[0].numpy() - g["sub_tau_right"][k]).max() / max(1.0, np.abs(g["sub_tau_right"][k]).max())
+            worst = max(worst, float(e))
+    assert worst < 1e-4, worst                                   # fp32 state against the reference float64 (kp x rounding of q through the mass matrix)
