@@ -152,3 +152,38 @@ def test_torch_osc_plugin_tracks_the_in_kernel_osc_controller():
             assert e <= tol, (t, k, e)
     print("torch OSC plugin vs in-kernel OSC, worst relative deviations over", T, "control steps:", {k: f"{v:.1e}" for k, v in worst.items()})
     assert fused.batch.get("ep_index").tolist() == [1] * B
+
+
+def test_torch_joint_position_plugin_tracks_the_in_kernel_controller():
+    """TorchJointPositionController through rsim_step1 / rsim_step2 against JOINT_POSITION inside the fused kernel, through an on-device episode restart
+    (the goal of a restarted env is re-captured from its new joint positions)."""
+    from robosuite_amd import lift
+    from robosuite_amd.controllers import BatchState, HostControlledEnv, Part, TorchGripController, TorchJointPositionController
+    from tests.util import load_golden
+    g, cfg, flat = load_golden("ctl_joint_position")
+    B, T, H = 6, 8, 5
+    ids = np.arange(B)
+    fused = lift.LiftBatch(flat, cfg, ids, seed0=4, horizon=H, bank_episodes=3)
+    hosted = lift.LiftBatch(flat, cfg, ids, seed0=4, horizon=H, bank_episodes=3)
+    st = BatchState(hosted.batch)
+    cr = np.asarray(flat.actuator_ctrlrange)
+    arm = TorchJointPositionController(st, dict(joints=cfg["qpos_idx"], qpos=cfg["qpos_idx"], qvel=cfg["dof_idx"]), (cr[cfg["act_idx"], 0], cr[cfg["act_idx"], 1]),
+                                       input_max=cfg["input_max"], input_min=cfg["input_min"], output_max=cfg["output_max"], output_min=cfg["output_min"],
+                                       kp=cfg["kp"], damping_ratio=cfg["damping_ratio"])
+    grip = TorchGripController(st, dict(joints=cfg["grip_qpos_idx"], qpos=cfg["grip_qpos_idx"], qvel=cfg["grip_dof_idx"]),
+                               (cr[cfg["grip_act"], 0], cr[cfg["grip_act"], 1]), signs=cfg["grip_sign"], speed=cfg["grip_speed"])
+    env = HostControlledEnv(hosted, [Part(arm, slice(0, 7), cfg["act_idx"]), Part(grip, slice(7, 8), cfg["grip_act"])])
+    env.reset(); fused.reset()
+    acts = torch.tensor(lift.env_actions(ids, T, action_dim=8), device="cuda")
+    worst = {}
+    for t in range(T):
+        fused.step(acts[t]); env.step(acts[t])
+        for k in ("done", "ep_step", "ep_index"):
+            assert np.array_equal(fused.batch.get(k), hosted.batch.get(k)), (t, k)
+        for k, tol in (("qpos", 2e-6), ("qvel", 2e-5), ("ctrl", 1e-5), ("reward", 1e-6)):          # measured 8e-10, 3e-7, 1e-7, 0
+            a, b = fused.batch.get(k), hosted.batch.get(k)
+            e = np.abs(a - b).max() / max(1.0, np.abs(a).max())
+            worst[k] = max(worst.get(k, 0.0), float(e))
+            assert e <= tol, (t, k, e)
+    print("torch JOINT_POSITION plugin vs in-kernel, worst relative deviations:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert fused.batch.get("ep_index").tolist() == [1] * B
