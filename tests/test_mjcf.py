@@ -202,3 +202,101 @@ def test_mesh_bodies_compile_to_closed_form_mass_properties(kind, tol, tmp_path)
     R = mjcf.quat2mat(m.geom_quat[g])
     world = m.geom_pos[g] + hv @ R.T                       # hull vertices in the body frame
     assert np.abs(world.max(0) - v.max(0)).max() < 2e-6 + tol * 0.05 and np.abs(world.min(0) - v.min(0)).max() < 2e-6 + tol * 0.05
+
+
+# ---- documented MJCF semantics as closed forms (XML reference: geom / inertial / compiler / default; nothing here comes from a simulator) ---------------
+def _one_body(geoms, extra="", compiler='<compiler angle="radian"/>'):
+    xml = f"""<mujoco>{compiler}{extra}<worldbody><body name="b" pos="0.1 0.2 0.3"><freejoint name="f"/>{geoms}</body></worldbody></mujoco>"""
+    m = mjcf.compile_mjcf(xml)
+    return m, m.name2id("body", "b")
+
+
+def test_primitive_geoms_have_closed_form_mass_and_inertia():
+    """density x volume and the textbook inertia tensors of sphere, capsule (cylinder + two hemispherical caps), cylinder, ellipsoid, box."""
+    rho = 800.0
+    r, h = 0.03, 0.07                                           # MJCF sizes: radius, HALF length
+    m, b = _one_body(f'<geom type="sphere" size="{r}" density="{rho}"/>')
+    ms = rho * 4 / 3 * np.pi * r**3
+    assert m.body_mass[b] == pytest.approx(ms, rel=1e-12) and m.body_inertia[b] == pytest.approx([0.4 * ms * r * r] * 3, rel=1e-12)
+    m, b = _one_body(f'<geom type="cylinder" size="{r} {h}" density="{rho}"/>')
+    mc = rho * np.pi * r * r * 2 * h
+    assert m.body_mass[b] == pytest.approx(mc, rel=1e-12)
+    assert np.sort(m.body_inertia[b]) == pytest.approx(np.sort([mc * (3 * r * r + (2 * h)**2) / 12] * 2 + [0.5 * mc * r * r]), rel=1e-12)
+    m, b = _one_body(f'<geom type="capsule" size="{r} {h}" density="{rho}"/>')
+    mcyl, mhemi = rho * np.pi * r * r * 2 * h, rho * 2 / 3 * np.pi * r**3
+    Izz = 0.5 * mcyl * r * r + 2 * 0.4 * mhemi * r * r
+    # a hemisphere about its own COM (3r/8 from the flat face): (2/5 - 9/64) m r^2 transversal; then the parallel axis to the capsule's centre
+    Ixx = mcyl * (3 * r * r + (2 * h)**2) / 12 + 2 * (mhemi * (0.4 - 9 / 64) * r * r + mhemi * (h + 3 * r / 8)**2)
+    assert m.body_mass[b] == pytest.approx(mcyl + 2 * mhemi, rel=1e-12)
+    assert np.sort(m.body_inertia[b]) == pytest.approx(np.sort([Ixx, Ixx, Izz]), rel=1e-10)
+    a, bb, c = 0.02, 0.03, 0.05
+    m, b = _one_body(f'<geom type="ellipsoid" size="{a} {bb} {c}" density="{rho}"/>')
+    me = rho * 4 / 3 * np.pi * a * bb * c
+    assert m.body_mass[b] == pytest.approx(me, rel=1e-12)
+    assert m.body_inertia[b] == pytest.approx(me / 5 * np.array([bb * bb + c * c, a * a + c * c, a * a + bb * bb]), rel=1e-12)
+    m, b = _one_body(f'<geom type="box" size="{a} {bb} {c}" mass="0.7"/>')          # explicit mass overrides the density
+    assert m.body_mass[b] == pytest.approx(0.7) and m.body_inertia[b] == pytest.approx(0.7 / 3 * np.array([bb * bb + c * c, a * a + c * c, a * a + bb * bb]), rel=1e-12)
+
+
+def test_composite_body_inertia_follows_the_parallel_axis_theorem():
+    """Two offset, rotated geoms in one body: mass, centre of mass and the PRINCIPAL inertia (body_ipos / body_iquat / body_inertia) against a direct
+    numpy evaluation of sum_i R_i I_i R_i^T + m_i (|d|^2 1 - d d^T)."""
+    m, b = _one_body('<geom name="g1" type="box" size="0.02 0.03 0.05" pos="0.04 0 0.01" euler="0.3 -0.2 0.5" density="500"/>'
+                     '<geom name="g2" type="sphere" size="0.025" pos="-0.03 0.05 0" density="1500"/>')
+    m1 = 500 * 8 * 0.02 * 0.03 * 0.05
+    I1 = m1 / 3 * np.diag([0.03**2 + 0.05**2, 0.02**2 + 0.05**2, 0.02**2 + 0.03**2])
+    R1 = mjcf.quat2mat(m.geom_quat[m.name2id("geom", "g1")])
+    m2 = 1500 * 4 / 3 * np.pi * 0.025**3
+    I2 = 0.4 * m2 * 0.025**2 * np.eye(3)
+    p1, p2 = np.array([0.04, 0, 0.01]), np.array([-0.03, 0.05, 0])
+    com = (m1 * p1 + m2 * p2) / (m1 + m2)
+    I = np.zeros((3, 3))
+    for mi, Ii, Ri, pi in ((m1, I1, R1, p1), (m2, I2, np.eye(3), p2)):
+        d = pi - com
+        I += Ri @ Ii @ Ri.T + mi * (d @ d * np.eye(3) - np.outer(d, d))
+    assert m.body_mass[b] == pytest.approx(m1 + m2, rel=1e-12) and m.body_ipos[b] == pytest.approx(com, abs=1e-14)
+    Rq = mjcf.quat2mat(m.body_iquat[b])
+    assert Rq @ np.diag(m.body_inertia[b]) @ Rq.T == pytest.approx(I, abs=1e-12)
+    assert np.all(np.diff(m.body_inertia[b]) <= 1e-15)                      # MuJoCo orders the principal moments descending
+    # euler="0.3 -0.2 0.5" with the default sequence xyz (intrinsic rotations about x, then the new y, then the new z), radians by the compiler line
+    Rx = lambda t: np.array([[1, 0, 0], [0, np.cos(t), -np.sin(t)], [0, np.sin(t), np.cos(t)]])   # noqa: E731
+    Ry = lambda t: np.array([[np.cos(t), 0, np.sin(t)], [0, 1, 0], [-np.sin(t), 0, np.cos(t)]])   # noqa: E731
+    Rz = lambda t: np.array([[np.cos(t), -np.sin(t), 0], [np.sin(t), np.cos(t), 0], [0, 0, 1]])   # noqa: E731
+    assert R1 == pytest.approx(Rx(0.3) @ Ry(-0.2) @ Rz(0.5), abs=1e-12)
+
+
+def test_orientation_specifiers_and_angle_units():
+    """quat / euler (degrees unless the compiler says radian) / axisangle / xyaxes / zaxis / fromto name the same rotations."""
+    deg = '<compiler angle="degree"/>'
+    m, b = _one_body('<geom name="a" type="box" size="0.01 0.02 0.03" euler="0 0 90"/>'
+                     '<geom name="b" type="box" size="0.01 0.02 0.03" axisangle="0 0 1 90"/>'
+                     '<geom name="c" type="box" size="0.01 0.02 0.03" xyaxes="0 1 0 -1 0 0"/>'
+                     '<geom name="d" type="box" size="0.01 0.02 0.03" quat="0.7071067811865476 0 0 0.7071067811865476"/>'
+                     '<geom name="e" type="capsule" size="0.01" fromto="0 0 0 0 0.2 0"/>'
+                     '<geom name="f" type="cylinder" size="0.01 0.1" zaxis="0 1 0"/>', compiler=deg)
+    Rz90 = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]])
+    for n in "abcd":
+        assert mjcf.quat2mat(m.geom_quat[m.name2id("geom", n)]) == pytest.approx(Rz90, abs=1e-12), n
+    for n in "ef":
+        assert mjcf.quat2mat(m.geom_quat[m.name2id("geom", n)])[:, 2] == pytest.approx([0, 1, 0], abs=1e-12), n
+    e = m.name2id("geom", "e")
+    assert m.geom_pos[e] == pytest.approx([0, 0.1, 0]) and m.geom_size[e][:2] == pytest.approx([0.01, 0.1])
+    m2, _ = _one_body('<geom name="a" type="box" size="0.01 0.02 0.03" euler="0 0 1.5707963267948966"/>')      # radian compiler (helper default)
+    assert mjcf.quat2mat(m2.geom_quat[m2.name2id("geom", "a")]) == pytest.approx(Rz90, abs=1e-12)
+
+
+def test_default_classes_nest_and_childclass_applies_to_the_subtree():
+    xml = """<mujoco><default><geom friction="0.7 0.01 0.001" density="300"/><default class="soft"><geom solref="0.05 1" friction="0.2 0.01 0.001"/>
+             <default class="softer"><geom solimp="0.5 0.6 0.01"/></default></default></default>
+             <worldbody><body name="a" childclass="soft"><freejoint/><geom name="g0" type="sphere" size="0.01"/>
+               <body name="b"><joint type="hinge" axis="0 0 1"/><geom name="g1" type="sphere" size="0.01" pos="0.1 0 0"/>
+                 <geom name="g2" class="softer" type="sphere" size="0.01" pos="0.2 0 0"/><geom name="g3" type="sphere" size="0.01" pos="0.3 0 0" friction="0.9 0.01 0.001"/></body></body>
+               <body name="c"><freejoint/><geom name="g4" type="sphere" size="0.01"/></body></worldbody></mujoco>"""
+    m = mjcf.compile_mjcf(xml)
+    g = lambda n: m.name2id("geom", n)   # noqa: E731
+    assert m.geom_friction[g("g0")][0] == pytest.approx(0.2) and m.geom_solref[g("g0")] == pytest.approx([0.05, 1])      # childclass on the body
+    assert m.geom_friction[g("g1")][0] == pytest.approx(0.2)                                                              # ... and on its descendants
+    assert m.geom_solimp[g("g2")][:3] == pytest.approx([0.5, 0.6, 0.01]) and m.geom_solref[g("g2")] == pytest.approx([0.05, 1])   # nested class inherits its parent
+    assert m.geom_friction[g("g3")][0] == pytest.approx(0.9)                                                              # an explicit attribute wins
+    assert m.geom_friction[g("g4")][0] == pytest.approx(0.7) and m.geom_solref[g("g4")] == pytest.approx([0.02, 1])     # outside: the top-level default
+    assert m.body_mass[m.name2id("body", "c")] == pytest.approx(300 * 4 / 3 * np.pi * 0.01**3)                           # density from the top-level default
