@@ -300,3 +300,22 @@ def test_default_classes_nest_and_childclass_applies_to_the_subtree():
     assert m.geom_friction[g("g3")][0] == pytest.approx(0.9)                                                              # an explicit attribute wins
     assert m.geom_friction[g("g4")][0] == pytest.approx(0.7) and m.geom_solref[g("g4")] == pytest.approx([0.02, 1])     # outside: the top-level default
     assert m.body_mass[m.name2id("body", "c")] == pytest.approx(300 * 4 / 3 * np.pi * 0.01**3)                           # density from the top-level default
+
+
+def test_joint_units_and_bounding_radii():
+    """compiler angle="degree" (the MJCF default) converts hinge ranges / ref to radians and leaves slide joints in metres; geom_rbound is the radius
+    of the smallest sphere about the geom's centre that contains it (what the broadphase tests first)."""
+    xml = """<mujoco><worldbody><body name="a"><joint name="h" type="hinge" axis="0 1 0" range="-90 45" armature="0.1" damping="0.5" frictionloss="0.2"/>
+             <geom name="s" type="sphere" size="0.03"/>
+             <body name="b" pos="0.1 0 0"><joint name="p" type="slide" axis="1 0 0" range="-0.05 0.2"/>
+               <geom name="c" type="capsule" size="0.02 0.05"/><geom name="y" type="cylinder" size="0.02 0.05" pos="0 0.1 0"/>
+               <geom name="x" type="box" size="0.01 0.02 0.03" pos="0 0.2 0"/><geom name="e" type="ellipsoid" size="0.01 0.04 0.02" pos="0 0.3 0"/></body></body></worldbody></mujoco>"""
+    m = mjcf.compile_mjcf(xml)
+    h, p = m.name2id("joint", "h"), m.name2id("joint", "p")
+    assert m.jnt_range[h] == pytest.approx(np.radians([-90, 45])) and m.jnt_range[p] == pytest.approx([-0.05, 0.2])
+    assert list(m.jnt_limited) == [1, 1]                                         # autolimits: a range makes the joint limited
+    d = int(m.jnt_dofadr[h])
+    assert (m.dof_armature[d], m.dof_damping[d], m.dof_frictionloss[d]) == pytest.approx((0.1, 0.5, 0.2))
+    rb = {n: float(m.geom_rbound[m.name2id("geom", n)]) for n in "scyxe"}
+    assert rb["s"] == pytest.approx(0.03) and rb["c"] == pytest.approx(0.07) and rb["y"] == pytest.approx(np.hypot(0.02, 0.05))
+    assert rb["x"] == pytest.approx(np.linalg.norm([0.01, 0.02, 0.03])) and rb["e"] == pytest.approx(0.04)
