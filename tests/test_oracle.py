@@ -608,3 +608,52 @@ def test_pickplace_single_object_mode_1_reset_path_reproduces_the_reference_epis
         assert np.abs(pick_place.episode_setup(cfg, flat.nq, 3, [0], block)[0] - ref_q).max() < 1e-12
     away = [o["qposadr"] for i, o in enumerate(t["placement"]["objects"]) if i != obj]
     assert all(q[a] == 10.0 for a in away)
+
+
+def _documented_spring(solref, dmax, dt):
+    tc = max(solref[0], 2 * dt)
+    return 1.0 / (dmax * dmax * tc * tc * solref[1] * solref[1])
+
+
+@pytest.mark.parametrize("solref,solimp", (((0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2)), ((0.01, 0.7), (0.8, 0.8, 0.002, 0.5, 2)), ((0.003, 1.0), (0.95, 0.99, 0.0005, 0.3, 3))))
+def test_resting_depths_follow_from_the_documented_constraint_model(solref, solimp):
+    """End-to-end known answer of the soft-constraint model (MuJoCo documentation, "Computation: soft constraint model"), no simulator involved: a single
+    constraint at rest carries the load a0 it opposes, and with R = (1 - d) / d x A its reference acceleration a_ref = -k d r must equal
+    -a0 (1 - d) / d, i.e. the penetration solves r = a0 (1 - d(r)) / (k d(r)^2) with k from solref (refsafe: the time constant is at least 2 dt) and d(r)
+    the impedance curve.  (a) a sphere resting on a plane under gravity (one frictional contact: its normal row), (b) a pendulum lying against its joint
+    limit under a constant torque."""
+    dt, g0 = 0.002, 9.81
+    k = _documented_spring(solref, solimp[1], dt)
+
+    def depth(a0):
+        r = a0 / k
+        for _ in range(200):
+            d = _documented_impedance(solimp, r)
+            r = a0 * (1 - d) / (k * d * d)
+        return r
+
+    sr, si = " ".join(map(str, solref)), " ".join(map(str, solimp))
+    xml = f"""<mujoco><option timestep="{dt}" cone="elliptic"/><worldbody><geom name="floor" type="plane" size="1 1 0.1" solref="{sr}" solimp="{si}"/>
+              <body name="ball" pos="0 0 0.05"><freejoint/><geom name="ball" type="sphere" size="0.05" density="1000" solref="{sr}" solimp="{si}"/></body></worldbody></mujoco>"""
+    om, od, _ = make_oracle(mjcf.compile_mjcf(xml))
+    od.qpos[:] = om.field("qpos0"); od.qvel[:] = 0
+    for _ in range(3000):
+        od.step()
+    od.forward()
+    assert np.abs(od.qvel).max() < 1e-7 and od.ncon == 1
+    assert 0.05 - od.qpos[2] == pytest.approx(depth(g0), rel=1e-4)
+    assert od.contacts()[0]["normal_force"] == pytest.approx(1000 * 4 / 3 * np.pi * 0.05**3 * g0, rel=1e-6)
+    # (b) hinge about y with its limit at 0.3 rad, pushed into it by gravity on an off-axis mass
+    xml = f"""<mujoco><compiler angle="radian"/><option timestep="{dt}" gravity="0 0 0"/><worldbody><body name="p"><joint name="h" type="hinge" axis="0 1 0" range="-0.3 0.3" solreflimit="{sr}" solimplimit="{si}"/>
+              <geom type="sphere" size="0.02" pos="0.2 0 0" mass="0.5" contype="0" conaffinity="0"/></body></worldbody></mujoco>"""
+    flat = mjcf.compile_mjcf(xml)
+    om, od, _ = make_oracle(flat)
+    tau = 0.4
+    od.qpos[0] = 0.25; od.qvel[:] = 0
+    for _ in range(6000):
+        od.qfrc_applied[0] = tau
+        od.step()
+    od.forward()
+    inertia = float(od.full_M()[0, 0])
+    assert abs(od.qvel[0]) < 1e-7 and od.nefc == 1
+    assert od.qpos[0] - 0.3 == pytest.approx(depth(tau / inertia), rel=1e-4)
