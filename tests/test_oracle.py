@@ -657,3 +657,55 @@ def test_resting_depths_follow_from_the_documented_constraint_model(solref, soli
     inertia = float(od.full_M()[0, 0])
     assert abs(od.qvel[0]) < 1e-7 and od.nefc == 1
     assert od.qpos[0] - 0.3 == pytest.approx(depth(tau / inertia), rel=1e-4)
+
+
+def test_joint_friction_loss_damping_and_torsional_friction_known_answers():
+    """Three more closed forms of the documented model, each on a one-body system:
+    (a) frictionloss F on a hinge: under a torque below F the soft row lets the joint creep at tau R / b (closed form below), a torque above accelerates it
+        with (tau - F) / I (a bounded-force constraint);
+    (b) joint damping b integrated implicitly in velocity: one step takes v to v I / (I + h b) exactly (Euler with implicit damping);
+    (c) torsional friction (condim 4, second friction coefficient, a length): a ball spinning about the contact normal on a plane slips in torsion, so
+        the constraint force lies ON the elliptic cone (|f_torsion| = mu_t f_normal), and the ball's accelerations are Newton's and Euler's for exactly
+        those forces."""
+    h = 0.002
+    pend = """<mujoco><compiler angle="radian"/><option timestep="%g" gravity="0 0 0"/><worldbody><body><joint type="hinge" axis="0 0 1" %s/>
+              <geom type="box" size="0.1 0.02 0.02" mass="1.5" contype="0" conaffinity="0"/></body></worldbody></mujoco>"""
+    # (a)
+    om, od, _ = make_oracle(mjcf.compile_mjcf(pend % (h, 'frictionloss="0.3"')))
+    od.forward(); inertia = float(od.full_M()[0, 0])
+    od.qfrc_applied[0] = 0.25
+    for _ in range(400):
+        od.step()
+    # "rest" of a SOFT constraint: the row is in its quadratic zone, force = -(b v + a) / R with R = (1 - d0) / d0 x (1 / I) and b = 2 / (dmax tc) (no
+    # position term: friction has no reference position), so the joint creeps at the velocity where that force balances the torque: v = tau R / b
+    creep = 0.25 * (0.1 / 0.9) * (1.0 / inertia) / (2.0 / (0.95 * 0.02))
+    assert od.qvel[0] == pytest.approx(creep, rel=1e-6) and abs(od.qacc[0]) < 1e-9
+    od.qfrc_applied[0] = 0.8; od.forward()
+    assert od.qacc[0] == pytest.approx((0.8 - 0.3) / inertia, rel=2e-3)        # the soft bound is reached up to the constraint's regularisation
+    # (b)
+    b = 0.7
+    om, od, _ = make_oracle(mjcf.compile_mjcf(pend % (h, 'damping="%g"' % b)))
+    od.qvel[0] = 2.0
+    v = 2.0
+    for _ in range(50):
+        od.step(); v *= inertia / (inertia + h * b)
+        assert od.qvel[0] == pytest.approx(v, rel=1e-12)
+    # (c)
+    mu_t, r = 0.02, 0.05
+    xml = f"""<mujoco><option timestep="{h}" cone="elliptic" impratio="1"/><worldbody><geom type="plane" size="1 1 0.1" condim="4" friction="1 {mu_t} 0.0001"/>
+              <body name="ball" pos="0 0 {r}"><freejoint/><geom type="sphere" size="{r}" density="1000" condim="4" friction="1 {mu_t} 0.0001"/></body></worldbody></mujoco>"""
+    om, od, _ = make_oracle(mjcf.compile_mjcf(xml))
+    od.qpos[:] = om.field("qpos0")
+    for _ in range(1500):                                                     # settle into the resting depth first
+        od.step()
+    m_ball = 1000 * 4 / 3 * np.pi * r**3
+    od.qvel[:] = 0; od.qvel[5] = 30.0                                          # spin about z (world = body frame at rest)
+    od.forward()
+    c = od.contacts()[0]
+    f = np.array(od.efc_force)[c["efc_address"]:c["efc_address"] + c["dim"]]
+    assert c["dim"] == 4 and abs(f[1]) < 1e-9 and abs(f[2]) < 1e-9            # no translational slip
+    assert abs(f[3]) == pytest.approx(mu_t * f[0], rel=1e-9)                   # slipping in torsion: the force sits ON the elliptic cone, |f_torsion| = mu_t f_normal
+    a = np.array(od.qacc)
+    assert a[5] == pytest.approx(f[3] / (0.4 * m_ball * r * r), rel=1e-6)      # Euler's equation about the contact normal
+    assert m_ball * a[2] == pytest.approx(f[0] - m_ball * 9.81, rel=1e-6)      # Newton's, along it (the cone couples them: slipping raises the normal force)
+    assert np.abs(a[[0, 1, 3, 4]]).max() < 1e-6
