@@ -1,0 +1,94 @@
+"""The fused kernel against closed forms of MuJoCo's DOCUMENTED model -- not against the oracle: the same one-body systems tests/test_oracle.py holds the
+fp64 restatement to (soft-constraint resting depths of a contact and a joint limit, implicit joint damping, soft friction loss, torsional slip on the
+elliptic cone), run through the C-ABI's B = 1 entries (rsim_step / rsim_forward) on the MI355X.  What agrees here agrees with the documentation itself,
+whatever the oracle does."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+from robosuite_amd import mjcf  # noqa: E402
+from tests.test_oracle import _documented_impedance, _documented_spring  # noqa: E402
+from tests.util import make_hip  # noqa: E402
+
+H, G0 = 0.002, 9.81
+
+
+def _batch(xml):
+    flat = mjcf.compile_mjcf(xml)
+    hm, hb = make_hip(flat, None, B=1)
+    hb.set("qpos", np.asarray(flat.qpos0, dtype=np.float64)[None]); hb.set("qvel", 0.0); hb.set("ctrl", 0.0); hb.set("qacc_warmstart", 0.0)
+    return flat, hb
+
+
+def _depth(a0, solref, solimp):
+    k = _documented_spring(solref, solimp[1], H)
+    r = a0 / k
+    for _ in range(200):
+        d = _documented_impedance(solimp, r)
+        r = a0 * (1 - d) / (k * d * d)
+    return r
+
+
+@pytest.mark.parametrize("solref,solimp", (((0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2)), ((0.01, 0.7), (0.8, 0.8, 0.002, 0.5, 2)), ((0.003, 1.0), (0.95, 0.99, 0.0005, 0.3, 3))))
+def test_resting_depths_of_a_contact_and_a_joint_limit(solref, solimp):
+    sr, si = " ".join(map(str, solref)), " ".join(map(str, solimp))
+    flat, hb = _batch(f"""<mujoco><option timestep="{H}" cone="elliptic"/><worldbody><geom name="floor" type="plane" size="1 1 0.1" solref="{sr}" solimp="{si}"/>
+        <body name="ball" pos="0 0 0.05"><freejoint/><geom name="ball" type="sphere" size="0.05" density="1000" solref="{sr}" solimp="{si}"/></body></worldbody></mujoco>""")
+    for _ in range(3000):
+        hb.step()
+    hb.forward()
+    q, v = hb.get("qpos")[0], hb.get("qvel")[0]
+    want = _depth(G0, solref, solimp)
+    assert np.abs(v).max() < 1e-4 and hb.get("ncon")[0] == 1
+    assert 0.05 - q[2] == pytest.approx(want, rel=2e-3, abs=2e-7)               # fp32 position of a 5 cm ball: 4e-9 m of rounding on depths of 1e-5 .. 4e-4 m
+    assert hb.contacts(0)[0]["normal_force"] == pytest.approx(1000 * 4 / 3 * np.pi * 0.05**3 * G0, rel=1e-3)   # measured 2e-4 (fp32)
+    # a pendulum pushed against its joint limit by a motor
+    flat, hb = _batch(f"""<mujoco><compiler angle="radian"/><option timestep="{H}" gravity="0 0 0"/><worldbody><body name="p"><joint name="h" type="hinge" axis="0 1 0" range="-0.3 0.3" solreflimit="{sr}" solimplimit="{si}"/>
+        <geom type="sphere" size="0.02" pos="0.2 0 0" mass="0.5" contype="0" conaffinity="0"/></body></worldbody><actuator><motor joint="h" gear="1"/></actuator></mujoco>""")
+    hb.set("qpos", np.array([[0.25]])); hb.set("ctrl", np.array([[0.4]]))
+    for _ in range(6000):
+        hb.step()
+    hb.forward()
+    inertia = float(hb.get("qM")[0].ravel()[0])
+    assert abs(hb.get("qvel")[0][0]) < 1e-4 and hb.get("nefc")[0] == 1
+    assert hb.get("qpos")[0][0] - 0.3 == pytest.approx(_depth(0.4 / inertia, solref, solimp), rel=5e-3, abs=3e-7)
+
+
+def test_damping_friction_loss_and_torsional_slip():
+    pend = """<mujoco><compiler angle="radian"/><option timestep="%g" gravity="0 0 0"/><worldbody><body><joint name="h" type="hinge" axis="0 0 1" %s/>
+              <geom type="box" size="0.1 0.02 0.02" mass="1.5" contype="0" conaffinity="0"/></body></worldbody><actuator><motor joint="h" gear="1"/></actuator></mujoco>"""
+    # implicit joint damping: one step takes v to v I / (I + h b)
+    b = 0.7
+    flat, hb = _batch(pend % (H, 'damping="%g"' % b))
+    hb.forward(); inertia = float(hb.get("qM")[0].ravel()[0])
+    hb.set("qvel", np.array([[2.0]]))
+    v = 2.0
+    for _ in range(50):
+        hb.step(); v *= inertia / (inertia + H * b)
+        assert hb.get("qvel")[0][0] == pytest.approx(v, rel=2e-5)            # fp32 over 50 steps: measured 2e-6
+    # soft friction loss: creep at tau R / b below the bound, (tau - F) / I above it
+    flat, hb = _batch(pend % (H, 'frictionloss="0.3"'))
+    hb.set("ctrl", np.array([[0.25]]))
+    for _ in range(400):
+        hb.step()
+    creep = 0.25 * (0.1 / 0.9) * (1.0 / inertia) / (2.0 / (0.95 * 0.02))
+    assert hb.get("qvel")[0][0] == pytest.approx(creep, rel=1e-4)
+    hb.set("ctrl", np.array([[0.8]])); hb.forward()
+    assert hb.get("qacc")[0][0] == pytest.approx((0.8 - 0.3) / inertia, rel=2e-3)
+    # torsional slip: the force on the elliptic cone, Newton's and Euler's equations for it
+    mu_t, r = 0.02, 0.05
+    flat, hb = _batch(f"""<mujoco><option timestep="{H}" cone="elliptic" impratio="1"/><worldbody><geom type="plane" size="1 1 0.1" condim="4" friction="1 {mu_t} 0.0001"/>
+        <body name="ball" pos="0 0 {r}"><freejoint/><geom type="sphere" size="{r}" density="1000" condim="4" friction="1 {mu_t} 0.0001"/></body></worldbody></mujoco>""")
+    for _ in range(1500):
+        hb.step()
+    m_ball = 1000 * 4 / 3 * np.pi * r**3
+    v = np.zeros((1, 6)); v[0, 5] = 30.0
+    hb.set("qvel", v); hb.forward()
+    c = hb.contacts(0)[0]
+    f = hb.get("efc_force")[0][c["efc_address"]:c["efc_address"] + c["dim"]]
+    a = hb.get("qacc")[0]
+    assert c["dim"] == 4 and abs(f[1]) < 1e-4 and abs(f[2]) < 1e-4
+    assert abs(f[3]) == pytest.approx(mu_t * f[0], rel=1e-5)
+    assert a[5] == pytest.approx(f[3] / (0.4 * m_ball * r * r), rel=1e-4)
+    assert m_ball * a[2] == pytest.approx(f[0] - m_ball * G0, rel=1e-3)
