@@ -92,3 +92,54 @@ def test_damping_friction_loss_and_torsional_slip():
     assert abs(f[3]) == pytest.approx(mu_t * f[0], rel=1e-5)
     assert a[5] == pytest.approx(f[3] / (0.4 * m_ball * r * r), rel=1e-4)
     assert m_ball * a[2] == pytest.approx(f[0] - m_ball * G0, rel=1e-3)
+
+
+def test_free_flight_and_coulomb_threshold():
+    """Mechanics, no simulator: (a) a box in free flight follows the semi-implicit Euler recursion of constant gravity exactly (v_n = v_0 - g h n,
+    z_n = z_0 + v_0 h n - g h^2 n (n + 1) / 2) and keeps its angular velocity (isotropic inertia); (b) a flat box on a plane under gravity tilted by theta stays put
+    while tan(theta) < mu (elliptic cone, impratio 20, four corner contacts); above it every slipping contact's force sits on the cone, |f_t| = mu f_n against
+    the motion, and the box obeys Newton's equation for those forces."""
+    flat, hb = _batch(f"""<mujoco><option timestep="{H}"/><worldbody><body pos="0 0 1"><freejoint/><geom type="box" size="0.03 0.03 0.03" density="400"/></body></worldbody></mujoco>""")
+    v0 = np.array([[0.1, -0.2, 0.3, 1.0, 2.0, -1.5]])
+    hb.set("qvel", v0)
+    n = 200
+    for _ in range(n):
+        hb.step()
+    q, v = hb.get("qpos")[0], hb.get("qvel")[0]
+    assert v[:3] == pytest.approx([0.1, -0.2, 0.3 - G0 * H * n], rel=1e-5, abs=1e-6)
+    assert q[:3] == pytest.approx([0.1 * H * n, -0.2 * H * n, 1.0 + 0.3 * H * n - G0 * H * H * n * (n + 1) / 2], abs=2e-6)
+    assert v[3:] == pytest.approx(v0[0, 3:], rel=1e-5)
+    mu = 0.3
+    m_box = 400 * 0.2 * 0.2 * 0.02
+    for fac in (0.5, 0.9, 1.5):
+        th = np.arctan(fac * mu)
+        gx, gz = G0 * np.sin(th), -G0 * np.cos(th)
+        flat, hb = _batch(f"""<mujoco><option timestep="{H}" cone="elliptic" impratio="20" gravity="{gx} 0 {gz}"/><worldbody><geom type="plane" size="5 5 0.1" friction="{mu} 0.005 0.0001"/>
+            <body pos="0 0 0.01"><freejoint/><geom type="box" size="0.1 0.1 0.01" density="400" friction="{mu} 0.005 0.0001"/></body></worldbody></mujoco>""")
+        if fac < 1.0:                                           # below the Coulomb threshold: stays put (soft contacts creep at ~3e-5 m/s)
+            for _ in range(300):
+                hb.step()
+            assert abs(hb.get("qvel")[0][0]) < 1e-3 and hb.get("ncon")[0] == 4, fac
+            continue
+        # above it: settle under the normal component alone, then give it the downhill velocity and evaluate one forward(): every corner contact slips, its
+        # force lies ON the cone (|f_t| = mu f_n) against the motion, and the box obeys Newton's equation along the plane for exactly those forces.
+        # (A sustained slide is no clean known answer in this model: the primal cone couples friction into the normal direction and the box hops.)
+        flat0, hb0 = _batch(f"""<mujoco><option timestep="{H}" cone="elliptic" impratio="20" gravity="0 0 {gz}"/><worldbody><geom type="plane" size="5 5 0.1" friction="{mu} 0.005 0.0001"/>
+            <body pos="0 0 0.01"><freejoint/><geom type="box" size="0.1 0.1 0.01" density="400" friction="{mu} 0.005 0.0001"/></body></worldbody></mujoco>""")
+        for _ in range(1500):
+            hb0.step()
+        hb.set("qpos", hb0.get("qpos").astype(np.float64))
+        v = np.zeros((1, 6)); v[0, 0] = 0.5
+        hb.set("qvel", v); hb.forward()
+        ft_sum, fn_sum = 0.0, 0.0
+        cons = hb.contacts(0)
+        assert len(cons) == 4
+        for c in cons:
+            f = hb.get("efc_force")[0][c["efc_address"]:c["efc_address"] + c["dim"]]
+            t_world = c["frame"][1] * f[1] + c["frame"][2] * f[2]
+            assert np.linalg.norm(f[1:3]) == pytest.approx(mu * f[0], rel=1e-4)
+            assert t_world[0] < 0 and abs(t_world[1]) < 1e-3 * abs(t_world[0])       # against the motion
+            ft_sum += t_world[0]; fn_sum += f[0]
+        a = hb.get("qacc")[0]
+        assert m_box * a[0] == pytest.approx(m_box * gx + ft_sum, rel=1e-3)
+        assert m_box * a[2] == pytest.approx(m_box * gz + fn_sum, rel=1e-3, abs=1e-3)
