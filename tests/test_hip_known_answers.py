@@ -143,3 +143,27 @@ def test_free_flight_and_coulomb_threshold():
         a = hb.get("qacc")[0]
         assert m_box * a[0] == pytest.approx(m_box * gx + ft_sum, rel=1e-3)
         assert m_box * a[2] == pytest.approx(m_box * gz + fn_sum, rel=1e-3, abs=1e-3)
+
+
+def test_actuator_models_and_clamps():
+    """fwd_actuation as documented (XML reference: actuator/motor, actuator/position, ctrlrange, forcerange, gear): force = gain x clamp(ctrl) + bias . [1, length,
+    velocity], clamped to forcerange, times the gear on the joint -- one hinge per actuator, forward() accelerations against I^-1 x the expected torque."""
+    xml = f"""<mujoco><compiler angle="radian"/><option timestep="{H}" gravity="0 0 0"/><worldbody>
+      <body pos="0 0 0"><joint name="a" type="hinge" axis="0 0 1"/><geom type="box" size="0.1 0.02 0.02" mass="1.5" contype="0" conaffinity="0"/></body>
+      <body pos="0 1 0"><joint name="b" type="hinge" axis="0 0 1"/><geom type="box" size="0.1 0.02 0.02" mass="1.5" contype="0" conaffinity="0"/></body>
+      <body pos="0 2 0"><joint name="c" type="hinge" axis="0 0 1"/><geom type="box" size="0.1 0.02 0.02" mass="1.5" contype="0" conaffinity="0"/></body>
+      <body pos="0 3 0"><joint name="d" type="slide" axis="1 0 0"/><geom type="box" size="0.1 0.02 0.02" mass="1.5" contype="0" conaffinity="0"/></body></worldbody>
+      <actuator><motor joint="a" gear="3" ctrllimited="true" ctrlrange="-1 1"/><position joint="b" kp="20"/>
+                <position joint="c" kp="200" forcelimited="true" forcerange="-1 1"/><position joint="d" kp="50" ctrllimited="true" ctrlrange="0 0.04"/></actuator></mujoco>"""
+    flat, hb = _batch(xml)
+    hb.set("qpos", np.array([[0.2, 0.1, 0.1, 0.01]])); hb.set("ctrl", np.array([[5.0, 0.3, 0.3, 0.5]]))
+    hb.forward()
+    M = hb.get("qM")[0].reshape(4, 4)
+    inertia, mass = float(M[0, 0]), float(M[3, 3])
+    assert inertia == pytest.approx(1.5 / 3 * (0.1**2 + 0.02**2), rel=1e-5) and mass == pytest.approx(1.5, rel=1e-6)
+    want = np.array([3.0 * 1.0 / inertia,                      # motor: ctrl clamped to 1, gear 3
+                     20.0 * (0.3 - 0.1) / inertia,              # position servo: kp (ctrl - q)
+                     1.0 / inertia,                             # 200 x 0.2 = 40 N m clamped to the force range
+                     50.0 * (0.04 - 0.01) / mass])              # ctrl clamped to 0.04
+    assert hb.get("qacc")[0] == pytest.approx(want, rel=2e-5)
+    assert hb.get("qfrc_actuator")[0] == pytest.approx(want * np.array([inertia, inertia, inertia, mass]), rel=2e-5)
