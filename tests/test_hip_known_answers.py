@@ -167,3 +167,19 @@ def test_actuator_models_and_clamps():
                      50.0 * (0.04 - 0.01) / mass])              # ctrl clamped to 0.04
     assert hb.get("qacc")[0] == pytest.approx(want, rel=2e-5)
     assert hb.get("qfrc_actuator")[0] == pytest.approx(want * np.array([inertia, inertia, inertia, mass]), rel=2e-5)
+
+
+def test_planar_two_link_arm_has_the_textbook_mass_matrix_and_bias():
+    """The kernel's CRBA (incidence-matrix MFMAs) and RNE against the closed-form dynamics of the planar elbow manipulator, eight random states in one batch."""
+    from tests.test_oracle import planar_2r_closed_form, planar_2r_xml
+    flat = mjcf.compile_mjcf(planar_2r_xml())
+    hm, hb = make_hip(flat, None, B=8)
+    rng = np.random.default_rng(0)
+    q, qd = rng.uniform(-2, 2, (8, 2)), rng.uniform(-3, 3, (8, 2))
+    hb.set("qpos", q); hb.set("qvel", qd); hb.set("ctrl", 0.0); hb.set("qacc_warmstart", 0.0)
+    hb.forward()
+    for e in range(8):
+        M, bias = planar_2r_closed_form(q[e], qd[e])
+        assert hb.get("qM")[e].reshape(2, 2) == pytest.approx(M, rel=2e-6, abs=1e-7)
+        assert hb.get("qfrc_bias")[e] == pytest.approx(bias, rel=1e-5, abs=2e-6)
+        assert hb.get("qacc")[e] == pytest.approx(np.linalg.solve(M, -bias), rel=2e-5, abs=1e-4)

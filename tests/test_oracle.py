@@ -709,3 +709,33 @@ def test_joint_friction_loss_damping_and_torsional_friction_known_answers():
     assert a[5] == pytest.approx(f[3] / (0.4 * m_ball * r * r), rel=1e-6)      # Euler's equation about the contact normal
     assert m_ball * a[2] == pytest.approx(f[0] - m_ball * 9.81, rel=1e-6)      # Newton's, along it (the cone couples them: slipping raises the normal force)
     assert np.abs(a[[0, 1, 3, 4]]).max() < 1e-6
+
+
+def planar_2r_xml(l1=0.4, lc1=0.15, lc2=0.12, m1=1.2, m2=0.8, I1=0.02, I2=0.01):
+    return f"""<mujoco><compiler angle="radian"/><option timestep="0.002" gravity="0 -9.81 0"/><worldbody>
+      <body name="l1"><joint name="q1" type="hinge" axis="0 0 1"/><inertial pos="{lc1} 0 0" mass="{m1}" diaginertia="0.001 {I1} {I1}"/>
+        <body name="l2" pos="{l1} 0 0"><joint name="q2" type="hinge" axis="0 0 1"/><inertial pos="{lc2} 0 0" mass="{m2}" diaginertia="0.001 {I2} {I2}"/></body></body></worldbody></mujoco>"""
+
+
+def planar_2r_closed_form(q, qd, l1=0.4, lc1=0.15, lc2=0.12, m1=1.2, m2=0.8, I1=0.02, I2=0.01, g=9.81):
+    """Mass matrix and bias (Coriolis / centrifugal + gravity) of the planar two-link arm, the textbook example (e.g. Spong, Hutchinson, Vidyasagar,
+    "Robot Modeling and Control", planar elbow manipulator): angles from the x axis, gravity along -y."""
+    c2, s2 = np.cos(q[1]), np.sin(q[1])
+    m12 = m2 * (lc2**2 + l1 * lc2 * c2) + I2
+    M = np.array([[m1 * lc1**2 + m2 * (l1**2 + lc2**2 + 2 * l1 * lc2 * c2) + I1 + I2, m12], [m12, m2 * lc2**2 + I2]])
+    hh = -m2 * l1 * lc2 * s2
+    cor = np.array([hh * (2 * qd[0] * qd[1] + qd[1]**2), -hh * qd[0]**2])
+    grav = np.array([(m1 * lc1 + m2 * l1) * g * np.cos(q[0]) + m2 * lc2 * g * np.cos(q[0] + q[1]), m2 * lc2 * g * np.cos(q[0] + q[1])])
+    return M, cor + grav
+
+
+def test_planar_two_link_arm_has_the_textbook_mass_matrix_and_bias():
+    """CRBA and RNE against the closed-form dynamics of the planar elbow manipulator at random states (machine precision)."""
+    om, od, _ = make_oracle(mjcf.compile_mjcf(planar_2r_xml()))
+    rng = np.random.default_rng(0)
+    for _ in range(8):
+        q, qd = rng.uniform(-2, 2, 2), rng.uniform(-3, 3, 2)
+        od.qpos[:] = q; od.qvel[:] = qd; od.forward()
+        M, bias = planar_2r_closed_form(q, qd)
+        assert od.full_M() == pytest.approx(M, abs=1e-14) and np.array(od.qfrc_bias) == pytest.approx(bias, abs=1e-13)
+        assert np.array(od.qacc) == pytest.approx(np.linalg.solve(M, -bias), abs=1e-10)      # unforced: M qacc + bias = 0
