@@ -2,6 +2,8 @@
 import os
 import socket
 import subprocess
+
+import pytest
 import sys
 
 import numpy as np
@@ -52,10 +54,11 @@ def test_world_size_2_gloo(tmp_path):
     assert r["tmax"] == 2.0
 
 
-def test_bench_launches_its_own_ranks():
+@pytest.mark.parametrize("config", ("lift", "stack"))     # stack = BASELINE configs[2], the one BASELINE.json assigns to eight GPUs
+def test_bench_launches_its_own_ranks(config):
     """`python bench.py --gpus 2` (no torchrun around it) must spawn one rank per GPU itself; without a GPU every rank stops at the
     device check, after the process group came up (gloo here, RCCL on the GPU box)."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", config],
                          capture_output=True, text=True, timeout=600)
     import torch
     if torch.cuda.is_available():
