@@ -183,3 +183,14 @@ def test_planar_two_link_arm_has_the_textbook_mass_matrix_and_bias():
         assert hb.get("qM")[e].reshape(2, 2) == pytest.approx(M, rel=2e-6, abs=1e-7)
         assert hb.get("qfrc_bias")[e] == pytest.approx(bias, rel=1e-5, abs=2e-6)
         assert hb.get("qacc")[e] == pytest.approx(np.linalg.solve(M, -bias), rel=2e-5, abs=1e-4)
+
+
+def test_narrow_phase_against_elementary_geometry():
+    """The kernel's plane-box, plane-convex, box-box and MPR paths on the geometry cases of tests/test_oracle.py: depths, midpoints and normals of the contacts
+    in fp32 (support points relative to the first geom keep MPR's rounding at ~1e-8 m)."""
+    from tests.test_oracle import check_narrow_phase, narrow_phase_cases, narrow_phase_scene
+    for name, bodies, expected in narrow_phase_cases():
+        flat, hb = _batch(narrow_phase_scene(bodies))
+        hb.forward()
+        mpr = "sphere" in name and "plane" not in name or "capsule" in name
+        check_narrow_phase(hb.contacts(0), expected, 2e-6, 1e-4 if mpr else 5e-6, 2e-5 if mpr else 1e-5, name)

@@ -739,3 +739,53 @@ def test_planar_two_link_arm_has_the_textbook_mass_matrix_and_bias():
         M, bias = planar_2r_closed_form(q, qd)
         assert od.full_M() == pytest.approx(M, abs=1e-14) and np.array(od.qfrc_bias) == pytest.approx(bias, abs=1e-13)
         assert np.array(od.qacc) == pytest.approx(np.linalg.solve(M, -bias), abs=1e-10)      # unforced: M qacc + bias = 0
+
+
+# ---- narrow phase against geometry (the contact contract of the documentation: dist < 0 in penetration, the normal points from geom1 to geom2 -- pairs are
+# ordered by geom type, lower type first --, the position is the midpoint between the two surfaces) ------------------------------------------------------------
+def narrow_phase_scene(bodies):
+    b = "".join('<body name="b%d" pos="%s" %s><freejoint/><geom name="g%d" %s/></body>' % (i, p, ('quat="%s"' % q) if q else "", i, g) for i, (p, q, g) in enumerate(bodies))
+    return f'<mujoco><compiler angle="radian"/><option timestep="0.002"/><worldbody><geom name="floor" type="plane" size="2 2 0.1"/>{b}</worldbody></mujoco>'
+
+
+def narrow_phase_cases():
+    """(name, scene, expected contacts as (dist, pos, normal) in any order) -- every number below is elementary geometry."""
+    z = np.array([0.0, 0.0, 1.0])
+    c30, s30 = np.cos(np.pi / 6), np.sin(np.pi / 6)
+    qz = f"{np.cos(np.pi / 12)} 0 0 {np.sin(np.pi / 12)}"                     # 30 degrees about z
+    qx, qy = f"{np.cos(np.pi / 4)} {np.sin(np.pi / 4)} 0 0", f"{np.cos(np.pi / 4)} 0 {np.sin(np.pi / 4)} 0"
+    d = np.array([0.06, 0.03, 0.04]); dn = np.linalg.norm(d)
+    corners = [np.array([sx * 0.03 * c30 - sy * 0.03 * s30, sx * 0.03 * s30 + sy * 0.03 * c30, 1.0495]) for sx in (-1, 1) for sy in (-1, 1)]
+    return [
+        ("sphere on the plane, 1 mm deep", [("0.1 0.2 0.049", None, 'type="sphere" size="0.05"')], [(-0.001, [0.1, 0.2, -0.0005], z)]),
+        ("two spheres", [("0 0 1", None, 'type="sphere" size="0.05"'), ("0.06 0.03 1.04", None, 'type="sphere" size="0.04"')],
+         [(dn - 0.09, np.array([0, 0, 1.0]) + d / dn * (0.05 + 0.5 * (dn - 0.09)), d / dn)]),
+        ("sphere on a box face (sphere is geom1: lower type)", [("0 0 1", None, 'type="box" size="0.1 0.1 0.05"'), ("0.02 -0.03 1.089", None, 'type="sphere" size="0.04"')],
+         [(-0.001, [0.02, -0.03, 1.0495], -z)]),
+        ("box on the plane: its four lower corners", [("0 0 0.0495", None, 'type="box" size="0.05 0.03 0.05"')],
+         [(-0.0005, [sx * 0.05, sy * 0.03, -0.00025], z) for sx in (-1, 1) for sy in (-1, 1)]),
+        ("small box turned by 30 degrees on a big one: its four lower corners", [("0 0 1", None, 'type="box" size="0.1 0.1 0.05"'), ("0 0 1.079", qz, 'type="box" size="0.03 0.03 0.03"')],
+         [(-0.001, c, z) for c in corners]),
+        ("two crossed capsules", [("0 0 1", qx, 'type="capsule" size="0.02 0.1"'), ("0 0 1.035", qy, 'type="capsule" size="0.02 0.1"')], [(-0.005, [0, 0, 1.0175], z)]),
+    ]
+
+
+def check_narrow_phase(contacts, expected, tol_d, tol_p, tol_n, name):
+    assert len(contacts) == len(expected), (name, len(contacts))
+    left = list(expected)
+    for c in contacts:
+        k = int(np.argmin([np.linalg.norm(np.asarray(c["pos"]) - np.asarray(e[1])) for e in left]))
+        dist, pos, nrm = left.pop(k)
+        assert abs(c["dist"] - dist) < tol_d, (name, c["dist"], dist)
+        assert np.abs(np.asarray(c["pos"]) - np.asarray(pos)).max() < tol_p, (name, c["pos"], pos)
+        assert np.abs(np.asarray(c["frame"]).reshape(3, 3)[0] - np.asarray(nrm)).max() < tol_n, (name, c["frame"], nrm)
+
+
+def test_narrow_phase_against_elementary_geometry():
+    """plane-convex, plane-box, box-box and the MPR path (sphere-sphere, sphere-box, capsule-capsule) of the oracle: depths, midpoints and normals."""
+    for name, bodies, expected in narrow_phase_cases():
+        flat = mjcf.compile_mjcf(narrow_phase_scene(bodies))
+        om, od, _ = make_oracle(flat)
+        od.qpos[:] = om.field("qpos0"); od.forward()
+        mpr = "sphere" in name and "plane" not in name or "capsule" in name        # iterative (portal refinement to 1e-6); the other three are direct
+        check_narrow_phase(od.contacts(), expected, 1e-6 if mpr else 1e-9, 1e-4 if mpr else 1e-8, 1e-5 if mpr else 1e-8, name)
