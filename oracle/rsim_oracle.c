@@ -22,7 +22,13 @@
  *     semi-implicit Euler with implicit joint damping) anchored on the reference call sites
  *     utils/binding_utils.py:1089-1107 and environments/base.py:467-521.
  *     ==> physics parity with MuJoCo is UNPINNED (no MuJoCo binary, no golden vectors in the
- *     reference's tests); it is validated by analytic identities in tests/.
+ *     reference's tests); it is validated by analytic identities and by closed forms of the
+ *     documented model and of mechanics in tests/test_oracle.py: textbook mass matrix and bias of the planar two-link arm, gravity bias =
+ *     gradient of the potential energy, energy and momentum in free flight, the Coulomb stick threshold, solref -> (b, k), the impedance d(r),
+ *     R = (1 - d) / d x diagApprox, aref; resting depths of a contact and of a joint limit from r = a0 (1 - d) / (k d^2); soft friction-loss
+ *     creep and breakaway; implicit joint damping; forces on the elliptic cone when slipping; narrow phase against elementary geometry; force /
+ *     torque sensors from statics and from momentum rates; primal Newton against dual PGS.  tests/test_hip_known_answers.py holds the KERNEL to the
+ *     same closed forms directly.
  *
  * Collision narrow-phase (box-box manifold, MPR for convex pairs) is this project's own design of
  * the same contract (contacts = {pos, frame, dist} for penetrating geom pairs passing MuJoCo's
