@@ -282,6 +282,9 @@ def main():
            reward_sum=float(env.reward().sum().item()), successes=int(env.success().sum().item()))
     overflow_envs = shard.max_over_ranks(float((env.batch.tensor("overflow") > 0).sum().item()), dev)   # envs that ever dropped a contact / constraint row
     bank_stale = shard.max_over_ranks(float(env.batch.tensor("bank_stale").sum().item()), dev)
+    cn = env.batch.tensor("cap_need").view(B, 2)   # largest contact / row demand of any substep since the batch was created (pre-roll included)
+    need_con, need_efc = shard.max_over_ranks(float(cn[:, 0].max().item()), dev), shard.max_over_ranks(float(cn[:, 1].max().item()), dev)
+    need_hist = {f"contacts>{t}": int((cn[:, 0] > t).sum().item()) for t in (16, 24, 32, 48)} | {f"rows>{t}": int((cn[:, 1] > t).sum().item()) for t in (64, 80, 96, 128, 160)}   # rank-local
     tot = st.allreduce()
 
     if rank == 0:
@@ -323,7 +326,11 @@ def main():
                                       "upkeep_thread_ms_per_1000_steps": 1e6 * (ring1["upkeep_s"] - ring0["upkeep_s"]) / dsteps,
                                       "note": "asynchronous: episode counters polled on a side stream, rows drawn by a host thread from persistent per-env generators, "
                                               "scattered through pinned staging (reset_bank.py); the stepping thread never reads the device"},
-                       "overflow_envs": int(overflow_envs), "lib_sha16": lib_sha, "obs_dim": env.model.nobs, "action_dim": adim, "sharding": f"env-block x{world}",
+                       "overflow_envs": int(overflow_envs),
+                       "capacity": {"contacts": env.batch.maxcon, "rows": env.batch.maxefc, "max_contacts_needed": int(need_con), "max_rows_needed": int(need_efc), "envs_by_demand": need_hist,
+                                    "note": "compiled contact / constraint-row capacity per env against the largest demand of any substep of any env over pre-roll, warm-up and "
+                                            "timed region (RSIM_CAP_NEED); overflow_envs counts the envs that ever dropped one"},
+                       "lib_sha16": lib_sha, "obs_dim": env.model.nobs, "action_dim": adim, "sharding": f"env-block x{world}",
                        "diverged_envs": int(tot["diverged"]), "reward_sum": tot["reward_sum"], "successes": int(tot["successes"])},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes,

@@ -144,7 +144,11 @@ typedef struct rsim_task_desc {
                                        * model -- the host's reset moves them to (10, 10, 10) (base.py:591-602) -- and in every sum of the reward, as in the reference */
 } rsim_task_desc;
 
-/* state / derived arrays addressable through rsim_get_array / rsim_set_array / rsim_device_ptr */
+/* state / derived arrays addressable through rsim_get_array / rsim_set_array / rsim_device_ptr.
+ * The derived arrays RSIM_XPOS .. RSIM_NITER and RSIM_SENSORDATA are written by rsim_forward / rsim_step1 / rsim_step2 / rsim_step / rsim_run_controller /
+ * rsim_step2_last / rsim_observe; the fused rsim_control_step does not produce them.  Reading one of them (rsim_get_array, rsim_device_ptr, rsim_jac_*)
+ * after a fused control step first runs rsim_forward on the current state -- the sim.forward() robosuite itself issues before it reads derived
+ * quantities (base.py:298-303) -- so they are never the leftovers of an earlier launch. */
 enum rsim_field {
   RSIM_QPOS = 0,       /* [B,nq]  sim.data.qpos   (binding_utils.py MjData.qpos)            */
   RSIM_QVEL,           /* [B,nv]  sim.data.qvel                                              */
@@ -195,6 +199,9 @@ enum rsim_field {
                         *               rsim_forward / rsim_step2 / rsim_step (the values of the last substep, before its integration).  Sensors of
                         *               other types read zero.  rsim_model_int("nsensordata") gives the row length */
   RSIM_TASK_OBJECT,    /* [B] int32    PickPlace single-object mode 1: index of the object this env's current episode uses (see rsim_task_desc.single_object_mode) */
+  RSIM_CAP_NEED,       /* [B,2] int32  largest number of contacts / constraint rows any substep of the env has asked for since the batch was created (what
+                        *               RSIM_OVERFLOW's drops are measured against: a value above rsim_batch_limits means that substep was truncated);
+                        *               sizes the compiled capacities against a workload (bench.py reports the maxima) */
   RSIM_FIELD_COUNT
 };
 #define RSIM_PATCH_TASK_OBJECT (-1)   /* rsim_set_reset_bank patch index: this column of a reset row is the episode's RSIM_TASK_OBJECT, not a float-table entry */

@@ -112,6 +112,7 @@ struct rsim_model {
 struct rsim_batch {
   rsim_model* m;
   int B, device, per_env;
+  int derived_stale;   // the last launch was a fused control step: the MuJoCo-shaped derived arrays (RSIM_XPOS .. RSIM_NITER, RSIM_SENSORDATA) still hold an older state
   hipStream_t stream;
   int* d_it;
   int* d_lt;
@@ -826,7 +827,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
       {RSIM_SUCCESS, (void**)&db.success, (size_t)B, 1}, {RSIM_DONE, (void**)&db.done, (size_t)B, 1}, {RSIM_EP_STEP, (void**)&db.ep_step, (size_t)B, 1},
       {RSIM_EP_INDEX, (void**)&db.ep_index, (size_t)B, 1}, {RSIM_DIVERGED, (void**)&db.diverged, (size_t)B, 1}, {RSIM_OVERFLOW, (void**)&db.overflow, (size_t)B, 1},
       {RSIM_BANK_STALE, (void**)&db.bank_stale, (size_t)B, 1}, {RSIM_TERMINAL_OBS, (void**)&db.term_obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0},
-      {RSIM_SENSORDATA, (void**)&db.sensordata, (size_t)B * m->nsensordata, 0}, {RSIM_TASK_OBJECT, (void**)&db.task_object, (size_t)B, 1}};
+      {RSIM_SENSORDATA, (void**)&db.sensordata, (size_t)B * m->nsensordata, 0}, {RSIM_TASK_OBJECT, (void**)&db.task_object, (size_t)B, 1},
+      {RSIM_CAP_NEED, (void**)&db.cap_need, (size_t)B * 2, 1}};
   for (auto& fd : fields) {
     if (dalloc((float**)fd.p, fd.n)) return 1;
     b->fptr[fd.id] = *fd.p; b->fcount[fd.id] = fd.n; b->fis_int[fd.id] = fd.is_int;
@@ -1025,6 +1027,7 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
     }
     if (sched) b->have_cost = 1;
     b->gen++;
+    b->derived_stale = 1;
     return 0;
   }
   const bool sched1 = (flags & RF_EPISODE) && (flags & RF_CTRL) && b->schedule && b->d_order;   // fused control steps only: forward()/step1()/step2() launches are one substep long
@@ -1066,8 +1069,15 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
     }
   }
   b->gen++;
+  b->derived_stale = (flags & RF_DEBUG) ? 0 : 1;
   return 0;
 }
+// The derived arrays are written by the debug form of the kernel only (rsim_forward / step1 / step2 / step / run_controller / step2_last / observe); the fused
+// control step leaves them alone.  A read of one of them after a fused step first brings them up to the CURRENT state with rsim_forward -- what
+// robosuite's own sim.forward() before such a read does -- instead of handing out the values of some earlier launch.
+static bool derived_field(int f) { return (f >= RSIM_XPOS && f <= RSIM_NITER) || f == RSIM_SENSORDATA; }
+extern "C" int rsim_forward(rsim_batch* b);
+static int refresh_derived(rsim_batch* b, int field) { return (derived_field(field) && b->derived_stale) ? rsim_forward(b) : 0; }
 extern "C" int rsim_forward(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_DEBUG); }
 extern "C" int rsim_step1(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL | RF_DEBUG); }
 extern "C" int rsim_step2(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_INTEGRATE | RF_DEBUG); }
@@ -1341,11 +1351,13 @@ extern "C" int rsim_wavelog(rsim_batch* b, unsigned long long* out) { if (join_g
 extern "C" void* rsim_device_ptr(rsim_batch* b, int field, size_t* count) {
   if (field < 0 || field >= RSIM_FIELD_COUNT) { fail("bad field id %d", field); return nullptr; }
   if (count) *count = b->fcount[field];
+  if (refresh_derived(b, field)) return nullptr;
   return b->fptr[field];
 }
 extern "C" int rsim_get_array(rsim_batch* b, int field, void* dst, size_t count) { if (join_groups(b)) return 1;
   if (field < 0 || field >= RSIM_FIELD_COUNT) return fail("bad field id %d", field);
   if (count > b->fcount[field]) return fail("rsim_get_array: count %zu > field size %zu", count, b->fcount[field]);
+  if (refresh_derived(b, field)) return 1;
   HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipStreamSynchronize(b->stream));
   HIPCHK(hipMemcpy(dst, b->fptr[field], count * 4, hipMemcpyDeviceToHost));
@@ -1364,6 +1376,7 @@ extern "C" int rsim_set_array(rsim_batch* b, int field, const void* src, size_t 
 }
 
 static int refresh_cache(rsim_batch* b, int env) {
+  if (b->derived_stale && rsim_forward(b)) return 1;   // Jacobians after a fused control step: of the current state
   if (b->cache_gen == b->gen && b->cache_env == env) return 0;
   rsim_model* m = b->m;
   HIPCHK(hipSetDevice(b->device));

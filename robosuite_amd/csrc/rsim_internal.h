@@ -178,6 +178,7 @@ struct DBatch {
   void* cm_env;          // per-env constant blocks [B] (used once a float-table field has per-env values)
   long long cm_stride;   // bytes between the blocks of consecutive envs, 0 = no env has its own block yet
   int* overflow;         // [B] contacts + constraint rows dropped for lack of capacity (null = not counted)
+  int* cap_need;         // [B][2] largest number of contacts / constraint rows any substep of the env asked for (RSIM_CAP_NEED), null = not tracked
   int mprc_portal;       // 0: keep only the (exact) separating-direction warm start
   int* task_object;      // [B] PickPlace single-object mode 1: the object of the env's current episode (RSIM_TASK_OBJECT)
   float* sensordata;     // [B][nsensordata] (debug build of the kernel: rsim_step.hip sensor_acc)

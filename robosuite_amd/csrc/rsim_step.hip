@@ -961,6 +961,7 @@ struct Sim {
   float __attribute__((address_space(1)))* cst = nullptr;   // this env's controller-state record in global memory (slots >= RSIM_CS_LDS are used in place)
   Prof pf;
   int ovf = 0;   // contacts / constraint rows this launch had to drop for lack of capacity (RSIM_OVERFLOW); MuJoCo's nconmax = 5000 never truncates
+  int con_raw = 0, need_con = 0, need_efc = 0;   // contacts this substep's narrow phase found (before the capacity clamp); largest contact / row demand of any substep of this launch (RSIM_CAP_NEED)
   float opt_h, opt_density, opt_viscosity, opt_impratio;
   V3 opt_grav, opt_wind;
   static constexpr int NVP = SM::NVP;
@@ -1773,6 +1774,7 @@ struct Sim {
     const int base = sm.ncon;
     int total = __popcll(mk);
     if (total > cap) total = cap;
+    con_raw += total;
     if (base + total > SM::NCON_) { ovf += base + total - SM::NCON_; total = SM::NCON_ - base; }
     if (has && rank < total) {
       const int c = base + rank;
@@ -2214,6 +2216,7 @@ struct Sim {
   __device__ __forceinline__ void collision(int sub_left) {
     const LaneConst K = fetchK();
     if (lane == 0) sm.ncon = 0;
+    con_raw = 0;
     // broadphase: lane p tests candidate pair p (bounding spheres, then the 6 face axes of the two oriented boxes);
     // order-preserving compaction of the survivors
     int ncand = 0;
@@ -2505,6 +2508,11 @@ struct Sim {
       const u64 kept = __ballot(keep);
       const int lastc = kept ? 63 - __clzll((long long)kept) : -1;
       const int add = lastc >= 0 ? __shfl(first + dim, lastc) - nefc : 0;
+      // demand of this substep, had nothing been dropped (RSIM_CAP_NEED): the rows before the contacts (those stages drop only when they alone exceed
+      // the capacity), the rows of every active contact in the list, and the largest contact dimension for each contact the narrow phase could not store
+      const int want = nefc + __shfl(incl, SM::NCON_ - 1) + (con_raw - ncon) * m.maxcondim;
+      need_efc = want > need_efc ? want : need_efc;
+      need_con = con_raw > need_con ? con_raw : need_con;
       nefc += add;
     }
     if (lane == 0) sm.nefc = nefc;
@@ -3947,7 +3955,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   }
   if ((flags & RF_OBS) && m.task.enabled) {
     if (m.task.single_mode == 1) sim.task_obj = b.task_object[env] & 3;
-    sim.obs_reward(b.obs + (size_t)env * m.task.nobs, (flags & RF_RESET_ONLY) ? nullptr : b.reward + env, b.success + env, !(flags & RF_CTRL));
+    sim.obs_reward(b.obs + (size_t)env * m.task.nobs, (flags & RF_RESET_ONLY) ? nullptr : b.reward + env, b.success + env, !(flags & RF_INTEGRATE));   // a record taken without advancing time is the one reset() returns (rsim_observe, k_reset_obs); rsim_step2_last integrates and runs no in-kernel controller
   }
   if (flags & RF_EPISODE) {
     // MujocoEnv.step: timestep += 1; done = timestep >= horizon (base.py:508, 532-548); optional on-device reset from the bank
@@ -3988,6 +3996,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   if (lane < csl) sim.cst[lane] = sm.cstate[lane];
   if (lane == 0) b.time[env] = time;
   if (b.overflow && lane == 0 && sim.ovf) b.overflow[env] += sim.ovf;
+  if (b.cap_need && lane == 0) { int* cn = b.cap_need + 2 * (size_t)env; if (sim.need_con > cn[0]) cn[0] = sim.need_con; if (sim.need_efc > cn[1]) cn[1] = sim.need_efc; }
   if (b.cost && lane == 0) b.cost[env] = (unsigned)(clock64() >> 6) - t_launch;
   if (b.prof && lane == 0) {
     unsigned long long* wl = b.prof + RP_COUNT + 8 * (size_t)env;

@@ -48,6 +48,29 @@ GRIPPER_SIGNS = {"PandaGripper": [-1.0, 1.0], "Robotiq140Gripper": [1.0, -1.0], 
                  "JacoThreeFingerGripper": [-1.0, -1.0, -1.0]}   # jaco_three_finger_gripper.py:57-71: current_action - speed * sign(action)
 
 
+def gripper_signs(gripper):
+    """Direction table of `gripper.format_action` (models/grippers/*.py: current_action = clip(current_action + d * speed * sign(action), -1, 1), the
+    array handed to the actuators): known classes from the table above, any other single-action gripper of that family by PROBING its format_action
+    with +1 from rest -- the returned vector is speed * d.  Grippers whose format_action is not of that form (the dexterous hands) are refused."""
+    name = type(gripper).__name__
+    if name in GRIPPER_SIGNS:
+        return list(GRIPPER_SIGNS[name])
+    if int(getattr(gripper, "dof", 0)) != 1 or not hasattr(gripper, "speed"):
+        raise NotImplementedError(f"gripper {name}: only single-action grippers with the clip(current + d * speed * sign(a)) law have an in-kernel GRIP part")
+    saved = np.array(gripper.current_action, dtype=np.float64).copy()
+    try:
+        gripper.current_action = np.zeros_like(saved)
+        plus = np.array(gripper.format_action(np.array([1.0])), dtype=np.float64)
+        gripper.current_action = np.zeros_like(saved)
+        minus = np.array(gripper.format_action(np.array([-1.0])), dtype=np.float64)
+    finally:
+        gripper.current_action = saved
+    d = plus / float(gripper.speed)
+    if not (np.allclose(np.abs(d), 1.0) and np.allclose(minus, -plus)):
+        raise NotImplementedError(f"gripper {name}: format_action is not clip(current + d * speed * sign(a)) (probe gave {plus}, {minus})")
+    return [float(x) for x in np.round(d)]
+
+
 # ------------------------------------------------------------------------------------------------------------------------------------------
 # shim backend for model / configuration extraction
 # ------------------------------------------------------------------------------------------------------------------------------------------
@@ -240,9 +263,80 @@ def pickplace_task_cfg(env):
         x_half=float(env.model.mujoco_arena.table_full_size[0] / 2 - 0.05), y_half=float(env.model.mujoco_arena.table_full_size[1] / 2 - 0.05),
         objects=[dict(name=o.name, horizontal_radius=float(o.horizontal_radius), bottom_z=float(o.bottom_offset[-1]), top_z=float(o.top_offset[-1]),
                       qposadr=int(sim.model.get_joint_qpos_addr(o.joints[0])[0])) for o in env.objects],
+        noise=dict(type=str(env.robots[0].initialization_noise["type"]), magnitude=float(env.robots[0].initialization_noise["magnitude"])),
         arm_init_qpos=[float(x) for x in env.robots[0].init_qpos], gripper_init_qpos=[float(x) for x in g.init_qpos],
         arm_qpos_idx=[int(i) for i in env.robots[0]._ref_joint_pos_indexes], gripper_qpos_idx=[int(i) for i in env.robots[0]._ref_gripper_joint_pos_indexes["right"]])
     return task
+
+
+def env_cfg(env):
+    """The constructor arguments that change what a control step MEANS and that live on the env object, not in the model: reward flavour
+    (lift.py:158-159, 256-271; reward_scale = None: no normalisation), the substeps of a control step (base.py:212-218: control_timestep /
+    model_timestep) and the horizon."""
+    n_sub = env.control_timestep / env.model_timestep
+    if abs(n_sub - round(n_sub)) > 1e-9 or round(n_sub) < 1:
+        raise NotImplementedError(f"control_freq {env.control_freq}: control_timestep / model_timestep = {n_sub} is not a whole number of substeps")
+    return dict(reward_shaping=bool(getattr(env, "reward_shaping", False)), reward_scale=(None if getattr(env, "reward_scale", 1.0) is None else float(env.reward_scale)),
+                control_freq=float(env.control_freq), n_sub=int(round(n_sub)), horizon=int(env.horizon), ignore_done=bool(env.ignore_done), hard_reset=bool(env.hard_reset))
+
+
+def _sampler_cfg(sampler, sim, env_rng=None):
+    """A UniformRandomSampler as data (utils/placement_samplers.py:87-309).  Anything else (a SequentialCompositeSampler the user passed, a custom
+    class) has its own draw order and is refused -- silently replacing it with the default would be the bug this function exists to prevent."""
+    from robosuite.utils.placement_samplers import UniformRandomSampler
+
+    if type(sampler) is not UniformRandomSampler:
+        raise NotImplementedError(f"placement_initializer of type {type(sampler).__name__}: only UniformRandomSampler is restated on the host side (lift.py / stack.py)")
+    rot = sampler.rotation
+    objs = []
+    for o in sampler.mujoco_objects:
+        objs.append(dict(name=o.name, horizontal_radius=float(o.horizontal_radius), bottom_z=float(o.bottom_offset[-1]), top_z=float(o.top_offset[-1]),
+                         qposadr=int(sim.model.get_joint_qpos_addr(o.joints[0])[0]), init_quat=([float(x) for x in o.init_quat] if hasattr(o, "init_quat") else None)))
+    return dict(x_range=[float(x) for x in sampler.x_range], y_range=[float(x) for x in sampler.y_range],
+                rotation=(None if rot is None else ([float(x) for x in rot] if hasattr(rot, "__iter__") else float(rot))), rotation_axis=str(sampler.rotation_axis),
+                z_offset=float(sampler.z_offset), reference_pos=[float(x) for x in sampler.reference_pos],
+                ensure_object_boundary_in_range=bool(sampler.ensure_object_boundary_in_range), ensure_valid_placement=bool(sampler.ensure_valid_placement), objects=objs,
+                # a sampler the user built without rng= draws from an unseeded generator of its own (placement_samplers.py:44-47), not from the env's stream
+                own_rng=bool(env_rng is not None and sampler.rng is not env_rng))
+
+
+def reset_cfg(env):
+    """What the env's hard reset draws and where it writes it (robots/robot.py:107-113, 247-259: init_qpos + noise; lift.py:311-333, stack.py:324-357:
+    object sizes and the placement sampler; two_arm_peg_in_hole.py:343-351: peg radius), read off the live objects so that constructor kwargs
+    (`initialization_noise`, `placement_initializer`, another robot's init_qpos) reach the host-side restatement."""
+    robot, sim = env.robots[0], env.sim
+    noise = robot.initialization_noise
+    spec = dict(nq=int(sim.model.nq), arm_init_qpos=[float(x) for x in robot.init_qpos], arm_qpos_idx=[int(i) for i in robot._ref_joint_pos_indexes],
+                noise=dict(type=str(noise["type"]), magnitude=float(noise["magnitude"])), grippers=[])
+    if noise["type"] not in ("gaussian", "uniform"):
+        raise ValueError("Error: Invalid noise type specified. Options are 'gaussian' or 'uniform'.")   # robots/robot.py:257
+    for arm in robot.arms:
+        if robot.has_gripper[arm]:
+            spec["grippers"].append(dict(init_qpos=[float(x) for x in robot.gripper[arm].init_qpos], qpos_idx=[int(i) for i in robot._ref_gripper_joint_pos_indexes[arm]]))
+    name = type(env).__name__
+    if name == "Lift":
+        c = env.cube
+        # the size range is a literal of Lift._load_model (lift.py:311-318: BoxObject(size_min=[0.020] * 3, size_max=[0.022] * 3)), not a constructor
+        # argument, and BoxObject keeps only the drawn size; the density is the object's
+        spec["cube"] = dict(size_min=[0.020] * 3, size_max=[0.022] * 3, density=float(getattr(c, "density", 1000.0)))
+        if not np.all((np.array(c.size) >= 0.020 - 1e-12) & (np.array(c.size) <= 0.022 + 1e-12)):
+            raise NotImplementedError(f"Lift cube of size {c.size}: outside the size range this restatement of lift.py:311-318 draws from")
+        spec["sampler"] = _sampler_cfg(env.placement_initializer, sim, env.rng)
+    elif name == "Stack":
+        spec["sampler"] = _sampler_cfg(env.placement_initializer, sim, env.rng)
+    elif name == "TwoArmPegInHole":
+        spec["peg"] = dict(radius=[float(x) for x in env.peg_radius], length=float(env.peg_length))
+    return spec
+
+
+def grasp_cfg(env):
+    """Geom groups of ManipulationEnv._check_grasp (manipulation_env.py:361-362) and the eef names of the single-arm observation record."""
+    robot = env.robots[0]
+    if len(robot.arms) != 1 or not robot.has_gripper[robot.arms[0]]:
+        return None
+    g = robot.gripper[robot.arms[0]]
+    return dict(left_pad=list(g.important_geoms["left_fingerpad"]), right_pad=list(g.important_geoms["right_fingerpad"]),
+                grip_site=g.important_sites["grip_site"], eef_body=robot.robot_model.eef_name[robot.arms[0]])
 
 
 def patch_joint_velocity_defect():
@@ -296,7 +390,9 @@ def extract(env, obs=None):
     if len(robot.arms) == 2:
         if any(robot.has_gripper[a] for a in robot.arms) if isinstance(robot.has_gripper, dict) else robot.has_gripper:
             raise NotImplementedError("bimanual robots are carried without grippers (gripper_types=None)")
-        return flat, two_arm_cfg(env, ctype, keys, obs)
+        cfg = two_arm_cfg(env, ctype, keys, obs)
+        cfg["env"], cfg["reset"] = env_cfg(env), reset_cfg(env)
+        return flat, cfg
     ctl = robot.part_controllers["right"]
     mode = getattr(ctl, "impedance_mode", "fixed")
     interp = getattr(ctl, "interpolator", None) or getattr(ctl, "interpolator_pos", None)
@@ -311,8 +407,9 @@ def extract(env, obs=None):
         cfg["input_min"], cfg["input_max"] = [float(x) for x in ctl.input_min], [float(x) for x in ctl.input_max]
     if interp is not None:
         cfg["interp_steps"] = int(interp.total_steps)      # ceil(ramp_ratio * controller_freq / policy_freq), traj_utils.py:55-57
-    cfg["grip_sign"] = GRIPPER_SIGNS[type(robot.gripper["right"]).__name__]
+    cfg["grip_sign"] = gripper_signs(robot.gripper["right"])
     name = type(env).__name__
+    cfg["env"], cfg["reset"], cfg["grasp"] = env_cfg(env), reset_cfg(env), grasp_cfg(env)
     if name.startswith("PickPlace"):
         cfg["task"] = pickplace_task_cfg(env)
     cfg["obs_keys"] = keys
@@ -321,8 +418,8 @@ def extract(env, obs=None):
         # the object keys of the record are those of whichever object this episode drew (`Can_pos` ...): same slots every episode, named neutrally
         used = env.obj_to_use
         cfg["obs_keys"] = [k.replace(used + "_", "obj_", 1) if k.startswith(used + "_") else k for k in keys]
-    if name == "Stack":
-        cfg["table_height"] = float(env.table_offset[2])
+    if name in ("Stack", "Lift"):
+        cfg["table_height"] = float(env.model.mujoco_arena.table_offset[2])     # lift.py:441, stack.py:276: the height _check_success / staged_rewards measure from
     return flat, cfg
 
 
@@ -361,14 +458,15 @@ def controller_type_of(controller_configs, robot: str) -> str:
     return str(controller_configs.get("type", "OSC_POSE"))
 
 
-def from_reference(env_name, robots="Panda", controller_configs=None, seed=0, reference_path=None, **kwargs):
-    """(flat, cfg) by constructing the reference's own env class (needs a reachable robosuite checkout)."""
+def from_reference(env_name, robots="Panda", controller_configs=None, seed=0, reference_path=None, defaults=None, **kwargs):
+    """(flat, cfg) by constructing the reference's own env class (needs a reachable robosuite checkout).  `defaults`: constructor kwargs under the
+    caller's (None = BENCH_KWARGS, what the shipped assets and the fixtures were recorded with)."""
     suite = _import_reference(reference_path)
     if suite is None:
         raise ImportError("robosuite is not importable and no checkout was found (reference_path=, $ROBOSUITE_PATH)")
     if controller_type_of(controller_configs, str(robots)) == "JOINT_VELOCITY":
         patch_joint_velocity_defect()
-    kw = {**BENCH_KWARGS, **kwargs}
+    kw = {**(BENCH_KWARGS if defaults is None else defaults), **kwargs}
     env = suite.make(env_name, robots=robots, controller_configs=controller_configs, seed=seed, **kw)
     return extract(env)
 
@@ -377,14 +475,73 @@ def load_shipped(stem):
     return mjcf.load_model(os.path.join(ASSETS, stem + ".rsim")), json.load(open(os.path.join(ASSETS, stem + ".cfg.json")))
 
 
-def make(env_name, robots="Panda", n_envs=1, controller_configs=None, seed=0, horizon=500, device=0, bank_episodes=4, stream_groups=1, env_ids=None,
+# ---- what make() does with the reference constructor's kwargs ---------------------------------------------------------------------------------
+# Rendering: the batched path has none.  These may be passed with their "off" values (or any value where nothing is rendered anyway); asking
+# for a renderer or camera observations raises.
+RENDER_OFF = dict(has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False)
+RENDER_IGNORED = {"render_camera", "render_collision_mesh", "render_visual_mesh", "render_gpu_device_id", "camera_names", "camera_heights", "camera_widths",
+                  "camera_depths", "camera_segmentations", "renderer", "renderer_config"}
+# Consumed on the host side of the boundary: extract() reads them off the live env into cfg["env"] / cfg["reset"] (or, for a shipped
+# configuration, make() patches the shipped cfg): reward flavour, robot joint noise, substeps per control step.
+HOST_KWARGS = ("reward_shaping", "reward_scale", "initialization_noise", "control_freq")
+# The reference's own defaults for those (environments/manipulation/lift.py:150-166 and the other task constructors; robots/robot.py:107-111)
+REFERENCE_DEFAULTS = dict(reward_shaping=False, reward_scale=1.0, initialization_noise="default", control_freq=20, use_object_obs=True, hard_reset=True,
+                          lite_physics=True, ignore_done=False)
+
+
+def _noise_cfg(noise):
+    """robots/robot.py:107-113"""
+    if noise is None:
+        return dict(type="gaussian", magnitude=0.0)
+    if noise == "default":
+        return dict(type="gaussian", magnitude=0.02)
+    if noise["type"] not in ("gaussian", "uniform"):
+        raise ValueError("Error: Invalid noise type specified. Options are 'gaussian' or 'uniform'.")
+    return dict(type=str(noise["type"]), magnitude=float(noise["magnitude"]) if noise["magnitude"] else 0.0)
+
+
+def apply_host_kwargs(flat, cfg, host):
+    """A shipped configuration under other host-side constructor arguments: the same edits extract() would have read off a live env."""
+    cfg = json.loads(json.dumps(cfg))
+    env = cfg.setdefault("env", {})
+    if "reward_shaping" in host:
+        env["reward_shaping"] = bool(host["reward_shaping"])
+    if "reward_scale" in host:
+        env["reward_scale"] = None if host["reward_scale"] is None else float(host["reward_scale"])
+    if "control_freq" in host:
+        h = float(np.asarray(flat.arrays["timestep"]).ravel()[0])
+        n_sub = (1.0 / float(host["control_freq"])) / h          # base.py:212-218: control_timestep = 1 / control_freq
+        if abs(n_sub - round(n_sub)) > 1e-9 or round(n_sub) < 1:
+            raise ValueError(f"control_freq {host['control_freq']}: {n_sub} substeps of {h} s per control step is not a whole number")
+        env["control_freq"], env["n_sub"] = float(host["control_freq"]), int(round(n_sub))
+    if "initialization_noise" in host:
+        n = _noise_cfg(host["initialization_noise"])
+        if "reset" in cfg:
+            cfg["reset"]["noise"] = n
+        if "placement" in cfg.get("task", {}):
+            cfg["task"]["placement"]["noise"] = n
+    return cfg
+
+
+def make(env_name, robots="Panda", n_envs=1, controller_configs=None, seed=0, horizon=1000, device=0, bank_episodes=4, stream_groups=1, env_ids=None,
          source="auto", reference_path=None, alternating=False, **kwargs):
     """Batched counterpart of `robosuite.make(env_name, robots=..., controller_configs=..., **kwargs)` (environments/base.py:23-42): a
     `vec_env.VecEnv` of `n_envs` environments on `cuda:device`, env i seeded by `seed + i`.
 
-    source: "assets" = only the shipped BASELINE configurations; "reference" = always construct the reference's env class and read the model and
-    the controller configuration off it; "auto" (default) = shipped assets when (env_name, robots, controller type, kwargs) name one of them, the
-    reference otherwise.  Rendering-side kwargs default to the benchmark's (no renderer, no camera observations).
+    kwargs are the reference constructor's, with the reference's defaults (sparse reward: reward_shaping=False, reward_scale=1.0, control_freq=20,
+    horizon=1000, initialization_noise="default", ...).  What happens to each:
+      * model kwargs (robots, gripper_types, env_configuration, table_full_size, table_friction, single_object_mode, ...) reach the reference's
+        own model assembly; the compiled model carries them;
+      * reward_shaping / reward_scale / initialization_noise / placement_initializer / control_freq / use_object_obs are read off the constructed env
+        into cfg["env"] / cfg["reset"] / the observation program and honoured by the host-side reset and the on-device epilogue;
+      * horizon: the vectorised env reports `done` there and restarts the env on the device (gym auto-reset), whatever `ignore_done` says;
+      * rendering kwargs: there is no renderer; has_renderer / has_offscreen_renderer / use_camera_obs = True raise, the rest is ignored;
+      * hard_reset=False raises (every restart is a hard reset: sizes and placements are redrawn, base.py:277-347);
+      * anything else raises TypeError -- no kwarg is dropped silently.
+
+    source: "assets" = only the shipped BASELINE configurations (with host-side kwargs patched into their cfg); "reference" = always construct the
+    reference's env class and read the model and the configuration off it; "auto" (default) = shipped assets when (env_name, robots, controller
+    type, model kwargs) name one of them, the reference otherwise.
     alternating=True: a `vec_env.AlternatingVecEnv` (two half-batches stepped alternately: closed-loop compatible, fills the drain of a lockstep launch)."""
     from .vec_env import AlternatingVecEnv, VecEnv
 
@@ -392,16 +549,26 @@ def make(env_name, robots="Panda", n_envs=1, controller_configs=None, seed=0, ho
         if len(robots) != 1:
             raise NotImplementedError("one robot per env (the two-arm tasks are carried as single-robot bimanual configurations)")
         robots = robots[0]
+    for k, off in RENDER_OFF.items():
+        if kwargs.get(k, off) != off:
+            raise NotImplementedError(f"{k}={kwargs[k]!r}: the batched path has no renderer and no camera observations (render from a reference env over robosuite_amd.shim)")
+    if not kwargs.get("hard_reset", True):
+        raise NotImplementedError("hard_reset=False: every restart of a batched env is a hard reset (object sizes and placements are redrawn)")
+    model_kw = {k: v for k, v in kwargs.items() if k not in RENDER_OFF and k not in RENDER_IGNORED and k not in HOST_KWARGS and k not in ("hard_reset", "ignore_done", "lite_physics")}
+    host_kw = {k: kwargs.get(k, REFERENCE_DEFAULTS[k]) for k in HOST_KWARGS}
     key = (env_name, robots, controller_type_of(controller_configs, robots))
     stem = SHIPPED.get(key)
-    extra = {k: v for k, v in kwargs.items() if BENCH_KWARGS.get(k, object()) != v}
+    extra = {k: v for k, v in model_kw.items() if REFERENCE_DEFAULTS.get(k, object()) != v}
     shipped_ok = stem is not None and extra == SHIPPED_KWARGS.get(stem, {}) and os.path.exists(os.path.join(ASSETS, stem + ".rsim"))
     if source == "assets" or (source == "auto" and shipped_ok):
         if not shipped_ok:
             raise ValueError(f"no shipped assets for {key} with kwargs {extra}; shipped: {sorted(SHIPPED)} (use source='reference' with a robosuite checkout)")
         flat, cfg = load_shipped(stem)
+        cfg = apply_host_kwargs(flat, cfg, host_kw)
     else:
-        flat, cfg = from_reference(env_name, robots, controller_configs, seed=seed, reference_path=reference_path, **kwargs)
+        # the reference constructor sees every kwarg (an unknown one raises TypeError there, as in suite.make); extract() reads the result
+        ref_kw = {**RENDER_OFF, **{k: v for k, v in kwargs.items() if k not in RENDER_OFF}, "horizon": horizon}
+        flat, cfg = from_reference(env_name, robots, controller_configs, seed=seed, reference_path=reference_path, defaults={}, **ref_kw)
     if alternating:
         return AlternatingVecEnv(env_name, n_envs, flat, cfg, device=device, seed=seed, horizon=horizon, env_ids=env_ids, bank_episodes=bank_episodes)
     return VecEnv(env_name, n_envs, flat, cfg, device=device, seed=seed, horizon=horizon, env_ids=env_ids, bank_episodes=bank_episodes, stream_groups=stream_groups)

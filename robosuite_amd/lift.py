@@ -11,6 +11,8 @@ Pinned by tests/test_lift_host.py against fixtures recorded from the reference's
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 
 from .reset_bank import ResetBankMixin
@@ -21,26 +23,112 @@ TABLE_OFFSET = np.array([0.0, 0.0, 0.8])  # lift.py:153
 CUBE_DENSITY = 1000.0  # models/objects/generated_objects.py:680-699 (PrimitiveObject default)
 
 
-def reset_draws(rng: np.random.Generator):
-    """One hard-reset block of draws from the env's generator, in the reference's order."""
-    size = rng.uniform(0.020, 0.022, 3)  # BoxObject(size_min, size_max), one U per axis via np.array low/high
-    arm = PANDA_INIT_QPOS + rng.standard_normal(7) * 0.02
-    x = rng.uniform(-0.03, 0.03)
-    y = rng.uniform(-0.03, 0.03)
-    yaw = rng.uniform(0.0, 2.0 * np.pi)
-    return dict(size=size, arm=arm, xy=np.array([x, y]), yaw=yaw)
+def default_reset_spec():
+    """The reset of `suite.make("Lift", robots="Panda")` with the reference's defaults, as the data `factory.reset_cfg` reads off a live env
+    (cfg["reset"]): robot init_qpos + noise (robots/robot.py:107-113, 247-259), gripper init_qpos, cube size range (lift.py:311-318), the
+    UniformRandomSampler of lift.py:321-333."""
+    return dict(nq=16, arm_init_qpos=[float(x) for x in PANDA_INIT_QPOS], arm_qpos_idx=list(range(7)), noise=dict(type="gaussian", magnitude=0.02),
+                grippers=[dict(init_qpos=[float(x) for x in PANDA_GRIPPER_INIT_QPOS], qpos_idx=[7, 8])],
+                cube=dict(size_min=[0.020] * 3, size_max=[0.022] * 3, density=CUBE_DENSITY),
+                sampler=dict(x_range=[-0.03, 0.03], y_range=[-0.03, 0.03], rotation=None, rotation_axis="z", z_offset=0.01,
+                             reference_pos=[float(x) for x in TABLE_OFFSET], ensure_object_boundary_in_range=False, ensure_valid_placement=True,
+                             objects=[dict(name="cube", horizontal_radius=None, bottom_z=None, top_z=None, qposadr=9, init_quat=None)]))
 
 
-def initial_qpos(draw) -> np.ndarray:
-    """qpos[16] = [arm x7, finger x2, cube xyz, cube quat wxyz] after Robot.reset + placement (lift.py:401-415)."""
-    q = np.zeros(16)
-    q[:7] = draw["arm"]
-    q[7:9] = PANDA_GRIPPER_INIT_QPOS
-    half_z = draw["size"][2]
-    q[9:11] = TABLE_OFFSET[:2] + draw["xy"]
-    q[11] = TABLE_OFFSET[2] + 0.01 + half_z  # z_offset=0.01, minus object bottom_offset (= -half height)
-    q[12] = np.cos(draw["yaw"] / 2.0)
-    q[15] = np.sin(draw["yaw"] / 2.0)
+def arm_noise(rng: np.random.Generator, spec) -> np.ndarray:
+    """Robot.reset's joint noise (robots/robot.py:247-259).  The draw is made even at magnitude 0 (`initialization_noise=None`), as there."""
+    n, noise = len(spec["arm_init_qpos"]), spec["noise"]
+    if noise["type"] == "gaussian":
+        z = rng.standard_normal(n)
+    elif noise["type"] == "uniform":
+        z = rng.uniform(-1.0, 1.0, n)
+    else:
+        raise ValueError("Error: Invalid noise type specified. Options are 'gaussian' or 'uniform'.")
+    return np.array(spec["arm_init_qpos"], dtype=np.float64) + z * noise["magnitude"]
+
+
+def sample_quat(rng: np.random.Generator, sampler) -> np.ndarray:
+    """UniformRandomSampler._sample_quat (placement_samplers.py:191-219): rotation None = uniform yaw over the full circle, a pair = uniform inside it,
+    a number = fixed (no draw)."""
+    rot = sampler["rotation"]
+    if rot is None:
+        ang = rng.uniform(high=2 * np.pi, low=0)
+    elif isinstance(rot, (list, tuple)):
+        ang = rng.uniform(high=max(rot), low=min(rot))
+    else:
+        ang = rot
+    k = {"x": 1, "y": 2, "z": 3}[sampler["rotation_axis"]]
+    q = np.zeros(4)
+    q[0], q[k] = np.cos(ang / 2), np.sin(ang / 2)
+    return q
+
+
+def quat_multiply_raw(quaternion1, quaternion0):
+    """utils/transform_utils.py:67-93 on the raw 4-arrays it is handed.  The sampler passes its (w, x, y, z) draw and the object's init_quat to this
+    (x, y, z, w) routine and uses the float32 result as (w, x, y, z) again (placement_samplers.py:287-289); restated as it is."""
+    x0, y0, z0, w0 = quaternion0
+    x1, y1, z1, w1 = quaternion1
+    return np.array((x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0, -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0, x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0,
+                     -x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0), dtype=np.float32)
+
+
+def sample_objects(rng: np.random.Generator, sampler, geometry):
+    """UniformRandomSampler.sample (placement_samplers.py:221-309) over the sampler's objects in order.  geometry[i] = (horizontal_radius, bottom_z,
+    top_z) of object i.  Returns [(pos3, quat wxyz)]."""
+    ref = sampler["reference_pos"]
+    placed, out = [], []
+    for o, (radius, bottom, top) in zip(sampler["objects"], geometry):
+        for _ in range(5000):
+            lo, hi = sampler["x_range"]
+            if sampler["ensure_object_boundary_in_range"]:
+                lo, hi = lo + radius, hi - radius
+            x = rng.uniform(high=hi, low=lo) + ref[0]
+            lo, hi = sampler["y_range"]
+            if sampler["ensure_object_boundary_in_range"]:
+                lo, hi = lo + radius, hi - radius
+            y = rng.uniform(high=hi, low=lo) + ref[1]
+            z = sampler["z_offset"] + ref[2] - bottom
+            ok = True
+            if sampler["ensure_valid_placement"]:
+                for (px, py, pz, pr, ptop) in placed:
+                    if np.linalg.norm((x - px, y - py)) <= pr + radius and z - pz <= ptop - bottom:
+                        ok = False
+                        break
+            if ok:
+                quat = sample_quat(rng, sampler)
+                if o.get("init_quat") is not None:
+                    quat = quat_multiply_raw(quat, np.array(o["init_quat"]))
+                placed.append((x, y, z, radius, top))
+                out.append((np.array([x, y, z]), quat))
+                break
+        else:
+            raise RuntimeError("Cannot place all objects ):")   # RandomizationError in the reference
+    return out
+
+
+def reset_draws(rng: np.random.Generator, spec=None, aux=None):
+    """One hard-reset block of draws from the env's generator, in the reference's order: cube size (one U per axis, mjcf_utils.py:470-504), robot
+    joint noise, then the placement sampler (x U, y U, rotation).  `spec` = cfg["reset"] (factory.reset_cfg); None = the Panda defaults.
+    `aux`: the generator a sampler with `own_rng` draws from (a user's placement_initializer built without rng= owns one, placement_samplers.py:44-47)."""
+    spec = default_reset_spec() if spec is None else spec
+    c = spec["cube"]
+    size = rng.uniform(np.array(c["size_min"], dtype=np.float64), np.array(c["size_max"], dtype=np.float64))  # BoxObject(size_min, size_max): one U per axis
+    arm = arm_noise(rng, spec)
+    srng = aux if (spec["sampler"].get("own_rng") and aux is not None) else rng
+    (pos, quat), = sample_objects(srng, spec["sampler"], [(float(np.linalg.norm(size[:2])), -float(size[2]), float(size[2]))])   # BoxObject: horizontal_radius, bottom / top offsets
+    return dict(size=size, arm=arm, pos=pos, quat=quat)
+
+
+def initial_qpos(draw, spec=None) -> np.ndarray:
+    """qpos after Robot.reset + placement (lift.py:401-415): arm joints, gripper init_qpos, the cube's free joint (pos, quat wxyz)."""
+    spec = default_reset_spec() if spec is None else spec
+    q = np.zeros(int(spec["nq"]))
+    q[spec["arm_qpos_idx"]] = draw["arm"]
+    for g in spec["grippers"]:
+        q[g["qpos_idx"]] = g["init_qpos"]
+    a = int(spec["sampler"]["objects"][0]["qposadr"])
+    q[a:a + 3] = draw["pos"]
+    q[a + 3:a + 7] = draw["quat"]
     return q
 
 
@@ -94,16 +182,16 @@ def cube_model_rows(flat, sizes: np.ndarray, density: float = CUBE_DENSITY):
     }
 
 
-def episode_setup(seed0: int, env_ids, block: int = 0):
+def episode_setup(seed0: int, env_ids, block: int = 0, spec=None):
     """Draws for the global env ids `env_ids`: env i uses default_rng(seed0 + i); `block` selects which
     hard-reset block of that generator (0 = the state after make(), 1 = after the first user reset(), ...)."""
     sizes, qpos = [], []
     for i in env_ids:
         rng = np.random.default_rng(seed0 + int(i))
         for _ in range(block + 1):
-            d = reset_draws(rng)
+            d = reset_draws(rng, spec)
         sizes.append(d["size"])
-        qpos.append(initial_qpos(d))
+        qpos.append(initial_qpos(d, spec))
     return np.array(sizes), np.array(qpos)
 
 
@@ -115,16 +203,23 @@ def env_actions(env_ids, n_steps: int, scale: float = 1.0, action_dim: int = 7):
     return out
 
 
-def lift_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool = True):
-    """Observation program + reward description of Lift/Panda for the on-device epilogue (include/rsim.h rsim_task_desc).
+REWARD_NORM = {"lift": 2.25, "stack": 2.0, "peg_in_hole": 5.0}   # lift.py:270-271, stack.py:263-264, two_arm_peg_in_hole.py:287-288: reward *= reward_scale / norm
 
-    Key order = the reference's `_get_observations` order for use_object_obs=True, use_camera_obs=False:
-    robot0_joint_pos, _cos, _sin, joint_vel, joint_acc, eef_pos, eef_quat (BODY robot0_right_hand, xyzw), eef_quat_site, gripper_qpos,
-    gripper_qvel (robots/robot.py:334-484), cube_pos, cube_quat, gripper_to_cube_pos (lift.py:356-399)."""
-    names = flat.names
-    site = int(cfg["eef_site"])                      # gripper0_right_grip_site
-    eef_body = names["body"].index("robot0_right_hand")
-    cube_body = names["body"].index("cube_main")
+
+def task_env_args(cfg, task: str, reward_scale=None, reward_shaping=None):
+    """(reward_scale, reward_shaping) of the on-device epilogue: explicit arguments, else cfg["env"] (what the reference constructor was given,
+    factory.env_cfg), else the benchmark's (1.0, dense).  reward_scale = None in the reference means "no normalisation" (the raw sum): the epilogue
+    multiplies by reward_scale / norm, so it is handed the norm."""
+    e = cfg.get("env", {})
+    shaping = bool(e.get("reward_shaping", True)) if reward_shaping is None else bool(reward_shaping)
+    scale = e.get("reward_scale", 1.0) if reward_scale is None and "reward_scale" in e else (1.0 if reward_scale is None else reward_scale)
+    if scale is None:
+        scale = REWARD_NORM[task]
+    return float(scale), shaping
+
+
+def robot_obs_program(cfg, site, eef_body):
+    """Observation entries of the single-arm robot keys in `_get_observations` order (robots/robot.py:334-484)."""
     qi, di = cfg["qpos_idx"], cfg["dof_idx"]
     gq, gd = cfg["grip_qpos_idx"], cfg["grip_dof_idx"]
     obs = []
@@ -132,13 +227,38 @@ def lift_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool = True)
     obs += [("qvel", d, 0) for d in di] + [("qacc", d, 0) for d in di]
     obs += [("site_pos", site, k) for k in range(3)] + [("body_quat", eef_body, k) for k in range(4)] + [("site_quat", site, k) for k in range(4)]
     obs += [("qpos", q, 0) for q in gq] + [("qvel", d, 0) for d in gd]
-    obs += [("body_pos", cube_body, k) for k in range(3)] + [("body_quat", cube_body, k) for k in range(4)]
-    obs += [("body_minus_site", cube_body, k | (site << 2)) for k in range(3)]
-    g = names["geom"]
-    return dict(obs=obs, task="lift", object_body=cube_body, grip_site=site, table_height=float(TABLE_OFFSET[2]), lift_margin=0.04,
-                reward_scale=reward_scale, reward_shaping=reward_shaping,
-                left_pad_geoms=[g.index("gripper0_right_finger1_pad_collision")], right_pad_geoms=[g.index("gripper0_right_finger2_pad_collision")],
-                object_geoms=[g.index("cube_g0")])
+    return obs
+
+
+def grasp_groups(flat, cfg):
+    """(eef body id, left pad geom ids, right pad geom ids) of ManipulationEnv._check_grasp: from cfg["grasp"] (factory.grasp_cfg: the gripper's
+    important_geoms), else the Panda gripper's names."""
+    names = flat.names
+    g = cfg.get("grasp") or dict(left_pad=["gripper0_right_finger1_pad_collision"], right_pad=["gripper0_right_finger2_pad_collision"], eef_body="robot0_right_hand")
+    geom = names["geom"]
+    return names["body"].index(g["eef_body"]), [geom.index(n) for n in g["left_pad"]], [geom.index(n) for n in g["right_pad"]]
+
+
+def lift_task(flat, cfg, reward_scale=None, reward_shaping=None):
+    """Observation program + reward description of Lift for the on-device epilogue (include/rsim.h rsim_task_desc).
+
+    Key order = the reference's `_get_observations` order for use_camera_obs=False:
+    robot0_joint_pos, _cos, _sin, joint_vel, joint_acc, eef_pos, eef_quat (BODY robot0_right_hand, xyzw), eef_quat_site, gripper_qpos,
+    gripper_qvel (robots/robot.py:334-484), and with use_object_obs cube_pos, cube_quat, gripper_to_cube_pos (lift.py:356-399).  Reward flavour and
+    scale: cfg["env"] (what the reference's constructor was given; lift.py:158-159, 256-271)."""
+    names = flat.names
+    site = int(cfg["eef_site"])                      # gripper0_right_grip_site
+    eef_body, lpad, rpad = grasp_groups(flat, cfg)
+    cube_body = names["body"].index("cube_main")
+    obs = robot_obs_program(cfg, site, eef_body)
+    if "cube_pos" in cfg.get("obs_keys", ["cube_pos"]):       # use_object_obs (lift.py:356)
+        obs += [("body_pos", cube_body, k) for k in range(3)] + [("body_quat", cube_body, k) for k in range(4)]
+        obs += [("body_minus_site", cube_body, k | (site << 2)) for k in range(3)]
+    if sum(cfg.get("obs_dims", [len(obs)])) != len(obs):
+        raise NotImplementedError(f"Lift observation record: the reference env returned {sum(cfg['obs_dims'])} floats under keys {cfg['obs_keys']}, the on-device program has {len(obs)}")
+    scale, shaping = task_env_args(cfg, "lift", reward_scale, reward_shaping)
+    return dict(obs=obs, task="lift", object_body=cube_body, grip_site=site, table_height=float(cfg.get("table_height", TABLE_OFFSET[2])), lift_margin=0.04,
+                reward_scale=scale, reward_shaping=shaping, left_pad_geoms=lpad, right_pad_geoms=rpad, object_geoms=[names["geom"].index("cube_g0")])
 
 
 class LiftBatch(ResetBankMixin):
@@ -155,6 +275,10 @@ class LiftBatch(ResetBankMixin):
         self.model = HipModel(flat)
         self.model.set_controller(cfg)
         self.model.set_task(lift_task(flat, cfg))
+        self.spec = cfg.get("reset") or default_reset_spec()     # cfg["reset"]: the reference env's own reset configuration (factory.reset_cfg)
+        self.n_sub = int(cfg.get("env", {}).get("n_sub", 25))    # control_timestep / model_timestep (base.py:212-218)
+        self._draw_fn = functools.partial(reset_draws, spec=self.spec)
+        self._draw_aux = bool(self.spec["sampler"].get("own_rng"))
         self.batch = HipBatch(self.model, self.B, device, per_env_params=per_env_cube)
         self.per_env_cube = per_env_cube
         self.seed0 = seed0
@@ -171,8 +295,9 @@ class LiftBatch(ResetBankMixin):
         if not hasattr(self, "_slots"):
             slots = []  # (field, element, float-table offset) of every entry that changes with the per-episode cube size
             if self.per_env_cube:
-                base = {k: np.asarray(self.flat.arrays[k], dtype=np.float64).ravel() for k in cube_model_rows(self.flat, self.sizes[:1])}
-                probe = cube_model_rows(self.flat, np.array([[0.0201, 0.0213, 0.0207]]))
+                dens = float(self.spec["cube"]["density"])
+                base = {k: np.asarray(self.flat.arrays[k], dtype=np.float64).ravel() for k in cube_model_rows(self.flat, self.sizes[:1], dens)}
+                probe = cube_model_rows(self.flat, np.array([[0.0201, 0.0213, 0.0207]]), dens)
                 for k, rows in probe.items():
                     for e in np.nonzero(np.abs(rows[0] - base[k]) > 0)[0]:
                         off = self.batch.param_offset(k, int(e))
@@ -184,16 +309,14 @@ class LiftBatch(ResetBankMixin):
     def _bank_patch_offsets(self):
         return [o for _, _, o in self._bank_slots()]
 
-    _draw_fn = staticmethod(reset_draws)
-
     def _episode(self, idx, episode):
-        """(cube sizes, qpos) of episode `episode` for the LOCAL env indices idx; equals episode_setup(seed0, env_ids[idx], episode), one block per call."""
+        """(cube sizes, qpos) of episode `episode` for the LOCAL env indices idx; equals episode_setup(seed0, env_ids[idx], episode, spec), one block per call."""
         d = self.episode_draws(idx, episode)
-        return np.array([x["size"] for x in d]).reshape(-1, 3), np.array([initial_qpos(x) for x in d]).reshape(-1, 16)
+        return np.array([x["size"] for x in d]).reshape(-1, 3), np.array([initial_qpos(x, self.spec) for x in d]).reshape(-1, int(self.spec["nq"]))
 
     def _bank_rows(self, idx, episode):
         sizes, qpos = self._episode(idx, episode)
-        rows = cube_model_rows(self.flat, sizes) if self._bank_slots() else {}
+        rows = cube_model_rows(self.flat, sizes, float(self.spec["cube"]["density"])) if self._bank_slots() else {}
         patch = np.stack([rows[k][:, e] for k, e, _ in self._bank_slots()], axis=1) if self._bank_slots() else np.zeros((len(idx), 0))
         return qpos, patch
 
@@ -201,7 +324,7 @@ class LiftBatch(ResetBankMixin):
         sizes, qpos = self._episode(np.arange(self.B), block)
         b = self.batch
         if self.per_env_cube:
-            for field, rows in cube_model_rows(self.flat, sizes).items():
+            for field, rows in cube_model_rows(self.flat, sizes, float(self.spec["cube"]["density"])).items():
                 b.param_set(field, rows)
         b.set("qpos", qpos)
         b.set("qvel", 0.0)
@@ -212,9 +335,10 @@ class LiftBatch(ResetBankMixin):
         b.ctrl_reset()                                # fresh controller objects per reset (robots/robot.py:271)
         self.sizes, self.qpos0 = sizes, qpos
 
-    def step(self, actions, n_sub: int = 25):
-        """One env.step for every env: fused physics + controllers + observation / reward epilogue (results stay on the device)."""
-        self.batch.control_step(actions, n_sub)
+    def step(self, actions, n_sub: int = 0):
+        """One env.step for every env: fused physics + controllers + observation / reward epilogue (results stay on the device).  n_sub = 0: the
+        env's own control_timestep / model_timestep (cfg["env"]["n_sub"]; 25 at the default control_freq of 20 Hz)."""
+        self.batch.control_step(actions, n_sub or self.n_sub)
         self._bank_tick()
 
     def obs(self):

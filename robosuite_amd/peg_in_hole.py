@@ -10,12 +10,17 @@ The reset path of this env places no objects (peg and hole are welded to the han
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 
 from .reset_bank import ResetBankMixin  # noqa: E402
 
 
-def peg_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool = True):
+def peg_task(flat, cfg, reward_scale=None, reward_shaping=None):
+    from .lift import task_env_args
+
+    reward_scale, reward_shaping = task_env_args(cfg, "peg_in_hole", reward_scale, reward_shaping)     # cfg["env"]: two_arm_peg_in_hole.py:163-164, 284-288
     names = flat.names
     body = names["body"]
     peg, hole = body.index("peg_main"), body.index("hole_main")
@@ -39,20 +44,31 @@ PEG_RADIUS = (0.015, 0.03)   # two_arm_peg_in_hole.py:175
 PEG_LENGTH = 0.13            # two_arm_peg_in_hole.py:176
 
 
-def reset_draws(rng: np.random.Generator):
+def default_reset_spec():
+    """The reset of TwoArmPegInHole / Baxter (single-robot, no grippers) with the reference's defaults, in the form factory.reset_cfg reads off a live env."""
+    return dict(nq=14, arm_init_qpos=[float(x) for x in BAXTER_INIT_QPOS], arm_qpos_idx=list(range(14)), noise=dict(type="gaussian", magnitude=0.02), grippers=[],
+                peg=dict(radius=list(PEG_RADIUS), length=PEG_LENGTH))
+
+
+def reset_draws(rng: np.random.Generator, spec=None):
     """One hard-reset block of the env generator, in the reference's order: CylinderObject size (radius U, length U over a zero-width range,
-    utils/mjcf_utils.py:470-504 via two_arm_peg_in_hole.py:343-351), then the arm noise N(0,1) x 14 x 0.02 (robots/robot.py:247-259)."""
-    radius = rng.uniform(*PEG_RADIUS)
-    rng.uniform(PEG_LENGTH, PEG_LENGTH)
-    return dict(peg_radius=radius, qpos=BAXTER_INIT_QPOS + rng.standard_normal(14) * 0.02)
+    utils/mjcf_utils.py:470-504 via two_arm_peg_in_hole.py:343-351), then the arm noise (robots/robot.py:247-259).  `spec` = cfg["reset"]."""
+    from .lift import arm_noise
+
+    spec = default_reset_spec() if spec is None else spec
+    radius = rng.uniform(*spec["peg"]["radius"])
+    rng.uniform(spec["peg"]["length"], spec["peg"]["length"])
+    q = np.zeros(int(spec["nq"]))
+    q[spec["arm_qpos_idx"]] = arm_noise(rng, spec)
+    return dict(peg_radius=radius, qpos=q)
 
 
-def episode_setup(seed0: int, env_ids, block: int = 0, with_radius: bool = False):
+def episode_setup(seed0: int, env_ids, block: int = 0, with_radius: bool = False, spec=None):
     out, rad = [], []
     for i in env_ids:
         rng = np.random.default_rng(seed0 + int(i))
         for _ in range(block + 1):
-            d = reset_draws(rng)
+            d = reset_draws(rng, spec)
         out.append(d["qpos"]); rad.append(d["peg_radius"])
     return (np.array(out), np.array(rad)) if with_radius else np.array(out)
 
@@ -71,6 +87,9 @@ class PegBatch(ResetBankMixin):
         self.model = HipModel(flat)
         self.model.set_controller(cfg)
         self.model.set_task(peg_task(flat, cfg))
+        self.spec = cfg.get("reset") or default_reset_spec()
+        self.n_sub = int(cfg.get("env", {}).get("n_sub", 25))
+        self._draw_fn = functools.partial(reset_draws, spec=self.spec)
         self.per_env_peg = per_env_peg
         self.batch = HipBatch(self.model, self.B, device, per_env_params=per_env_peg)
         self.seed0 = seed0
@@ -98,11 +117,9 @@ class PegBatch(ResetBankMixin):
     def _bank_patch_offsets(self):
         return [o for _, _, o in self._bank_slots()]
 
-    _draw_fn = staticmethod(reset_draws)
-
     def _episode(self, idx, episode):
         d = self.episode_draws(idx, episode)
-        return np.array([x["qpos"] for x in d]).reshape(-1, 14), np.array([x["peg_radius"] for x in d])
+        return np.array([x["qpos"] for x in d]).reshape(-1, int(self.spec["nq"])), np.array([x["peg_radius"] for x in d])
 
     def _bank_rows(self, idx, episode):
         qpos, radii = self._episode(idx, episode)
@@ -121,8 +138,8 @@ class PegBatch(ResetBankMixin):
         b.forward(); b.ctrl_reset()
         self.qpos0, self.radii = qpos, radii
 
-    def step(self, actions, n_sub: int = 25):
-        self.batch.control_step(actions, n_sub)
+    def step(self, actions, n_sub: int = 0):
+        self.batch.control_step(actions, n_sub or self.n_sub)
         self._bank_tick()
 
     def obs(self):

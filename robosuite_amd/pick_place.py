@@ -20,8 +20,14 @@ The visual-object bodies (pick_place.py:455-513, 703-706: static bodies without 
 from __future__ import annotations
 
 
-def pick_place_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool = True):
+def pick_place_task(flat, cfg, reward_scale=None, reward_shaping=None):
     names, t = flat.names, cfg["task"]
+    e = cfg.get("env", {})      # what the reference constructor was given (pick_place.py:177-178, 305-310); absent: the benchmark's (1.0, dense)
+    reward_shaping = bool(e.get("reward_shaping", True)) if reward_shaping is None else bool(reward_shaping)
+    if reward_scale is None:
+        reward_scale = e.get("reward_scale", 1.0)
+        if reward_scale is None:   # reward_scale=None: the raw sum, not divided by four either (pick_place.py:307-310); the epilogue divides by 4 in the all-objects mode
+            reward_scale = 1.0 if int(t.get("single_object_mode", 0)) else 4.0
     body, geom, site = names["body"], names["geom"], names["site"]
     gsite = site.index(t["grip_site"])
     eef_body = body.index(t["eef_body"])
@@ -52,6 +58,8 @@ def pick_place_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool =
                 right_pad_geoms=[geom.index(g) for g in t["right_pad"]], reward_scale=reward_scale, reward_shaping=reward_shaping)
 
 
+import functools  # noqa: E402
+
 import numpy as np  # noqa: E402
 
 from .reset_bank import ResetBankMixin  # noqa: E402
@@ -63,7 +71,14 @@ def reset_draws(rng: np.random.Generator, placement: dict, choose: bool = False)
     (x, y uniform inside bin 1 shrunk by the object's horizontal radius, redrawn while it overlaps an already placed object, then a uniform yaw);
     then one x and one y draw over a zero-width range per visual object (their rotation is fixed); `choose` (single-object mode 1): then the
     object of the episode, rng.choice over the four names = one rng.integers(0, 4) (pick_place.py:717-718)."""
-    arm = np.array(placement["arm_init_qpos"]) + rng.standard_normal(len(placement["arm_init_qpos"])) * 0.02
+    noise = placement.get("noise") or dict(type="gaussian", magnitude=0.02)     # robots/robot.py:107-113 (`initialization_noise`), 247-259
+    if noise["type"] == "gaussian":
+        z = rng.standard_normal(len(placement["arm_init_qpos"]))
+    elif noise["type"] == "uniform":
+        z = rng.uniform(-1.0, 1.0, len(placement["arm_init_qpos"]))
+    else:
+        raise ValueError("Error: Invalid noise type specified. Options are 'gaussian' or 'uniform'.")
+    arm = np.array(placement["arm_init_qpos"]) + z * noise["magnitude"]
     bx, by, bz = placement["bin1_pos"]
     xh, yh = placement["x_half"], placement["y_half"]
     placed, out = [], []
@@ -139,6 +154,10 @@ class PickPlaceBatch(ResetBankMixin):
         self.model = HipModel(flat)
         self.model.set_controller(cfg)
         self.model.set_task(pick_place_task(flat, cfg))
+        self.n_sub = int(cfg.get("env", {}).get("n_sub", 25))
+        # no bound method here: env -> EpisodeStreams -> bound method -> env would be a reference cycle that keeps the batch's device memory (and the
+        # upkeep thread) alive until the cyclic collector runs
+        self._draw_fn = functools.partial(reset_draws, placement=cfg["task"]["placement"], choose=int(cfg["task"].get("single_object_mode", 0)) == 1)
         self.batch = HipBatch(self.model, self.B, device, per_env_params=per_env_params)   # per-env float tables: dynamics randomisation
         self.seed0 = seed0
         self.horizon = horizon
@@ -154,9 +173,6 @@ class PickPlaceBatch(ResetBankMixin):
 
     def _bank_patch_offsets(self):
         return [-1] if self._mode1 else []        # RSIM_PATCH_TASK_OBJECT: the row's extra column is the episode's object
-
-    def _draw_fn(self, rng):
-        return reset_draws(rng, self.cfg["task"]["placement"], self._mode1)
 
     def _episode(self, idx, episode):
         """(qpos rows, object of the episode per env: -1 outside the single-object modes)"""
@@ -178,8 +194,8 @@ class PickPlaceBatch(ResetBankMixin):
         b.forward(); b.ctrl_reset()
         self.qpos0 = qpos
 
-    def step(self, actions, n_sub: int = 25):
-        self.batch.control_step(actions, n_sub)
+    def step(self, actions, n_sub: int = 0):
+        self.batch.control_step(actions, n_sub or self.n_sub)
         self._bank_tick()
 
     def obs(self):

@@ -28,9 +28,13 @@ class EpisodeStreams:
     by one block; the last block of each env is kept, so asking for it again is free; anything else re-seeds and replays (as the first version
     always did)."""
 
-    def __init__(self, seed0: int, env_ids, draw_fn):
+    def __init__(self, seed0: int, env_ids, draw_fn, aux: bool = False):
         self.seed0, self.env_ids, self.draw_fn = int(seed0), np.asarray(env_ids, dtype=np.int64), draw_fn
         n = len(self.env_ids)
+        # aux: a second persistent generator per env, handed to draw_fn as `aux=` -- for parts of a reset the reference draws from a generator of
+        # their own (a user-supplied placement sampler built with rng=None owns an unseeded default_rng(): only its distribution can be matched)
+        self.aux = bool(aux)
+        self._aux = [None] * n
         self._rng = [None] * n
         self._next = np.zeros(n, dtype=np.int64)     # episode number the generator draws next
         self._last = [None] * n                      # draw of episode _next - 1
@@ -39,12 +43,14 @@ class EpisodeStreams:
         episode = int(episode)
         if self._rng[k] is None or episode < self._next[k] - 1:
             self._rng[k] = np.random.default_rng(self.seed0 + int(self.env_ids[k]))
+            if self.aux:
+                self._aux[k] = np.random.default_rng([self.seed0 + int(self.env_ids[k]), 0x5A3F])
             self._next[k] = 0
         if episode == self._next[k] - 1:
             return self._last[k]
         d = None
         while self._next[k] <= episode:
-            d = self.draw_fn(self._rng[k])
+            d = self.draw_fn(self._rng[k], aux=self._aux[k]) if self.aux else self.draw_fn(self._rng[k])
             self._next[k] += 1
         self._last[k] = d
         return d
@@ -82,7 +88,7 @@ class ResetBankMixin:
     def episode_draws(self, idx, episode: int):
         """The task's reset_draws() block `episode` for the LOCAL env indices idx, from the persistent per-env generators (self._draw_fn: rng -> draw)."""
         if getattr(self, "_streams", None) is None:
-            self._streams = EpisodeStreams(self.seed0, self.env_ids, self._draw_fn)
+            self._streams = EpisodeStreams(self.seed0, self.env_ids, self._draw_fn, aux=bool(getattr(self, "_draw_aux", False)))
         return self._streams.draws(idx, episode)
 
     def install_reset_bank(self, n_episodes: int):

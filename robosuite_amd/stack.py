@@ -11,93 +11,86 @@ Pinned by tests/test_stack_host.py against reset states recorded from the refere
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 
 from .reset_bank import ResetBankMixin
 
-from .lift import PANDA_GRIPPER_INIT_QPOS, PANDA_INIT_QPOS, TABLE_OFFSET, env_actions  # noqa: F401  (same robot, arena and action streams)
+from .lift import (PANDA_GRIPPER_INIT_QPOS, PANDA_INIT_QPOS, TABLE_OFFSET, arm_noise, env_actions, grasp_groups, robot_obs_program, sample_objects,  # noqa: F401  (same robot, arena and action streams)
+                   task_env_args)
 
 CUBE_HALF = {"cubeA": 0.02, "cubeB": 0.025}   # stack.py:324-337
 XY_RANGE = 0.08                                # stack.py:350-351
 Z_OFFSET = 0.01                                # stack.py:356
 
 
-def reset_draws(rng: np.random.Generator):
-    """One hard-reset block of draws from the env's generator, in the reference's order."""
-    arm = PANDA_INIT_QPOS + rng.standard_normal(7) * 0.02
-    placed = []   # (x, y, z, half)
-    out = {}
-    for name in ("cubeA", "cubeB"):
-        half = CUBE_HALF[name]
-        radius = np.linalg.norm([half, half])
-        for _ in range(5000):
-            x = rng.uniform(-XY_RANGE, XY_RANGE) + TABLE_OFFSET[0]
-            y = rng.uniform(-XY_RANGE, XY_RANGE) + TABLE_OFFSET[1]
-            z = Z_OFFSET + TABLE_OFFSET[2] + half
-            ok = True
-            for (px, py, pz, ph) in placed:
-                if np.linalg.norm((x - px, y - py)) <= np.linalg.norm([ph, ph]) + radius and z - pz <= ph + half:
-                    ok = False
-                    break
-            if ok:
-                yaw = rng.uniform(0.0, 2.0 * np.pi)
-                placed.append((x, y, z, half))
-                out[name] = (np.array([x, y, z]), yaw)
-                break
-        else:
-            raise RuntimeError("Cannot place all objects")   # RandomizationError in the reference
-    return dict(arm=arm, **out)
+def default_reset_spec():
+    """The reset of `suite.make("Stack", robots="Panda")` with the reference's defaults, in the form factory.reset_cfg reads off a live env."""
+    objs = [dict(name=n, horizontal_radius=float(np.linalg.norm([h, h])), bottom_z=-h, top_z=h, qposadr=9 + 7 * k, init_quat=None) for k, (n, h) in enumerate(CUBE_HALF.items())]
+    return dict(nq=23, arm_init_qpos=[float(x) for x in PANDA_INIT_QPOS], arm_qpos_idx=list(range(7)), noise=dict(type="gaussian", magnitude=0.02),
+                grippers=[dict(init_qpos=[float(x) for x in PANDA_GRIPPER_INIT_QPOS], qpos_idx=[7, 8])],
+                sampler=dict(x_range=[-XY_RANGE, XY_RANGE], y_range=[-XY_RANGE, XY_RANGE], rotation=None, rotation_axis="z", z_offset=Z_OFFSET,
+                             reference_pos=[float(x) for x in TABLE_OFFSET], ensure_object_boundary_in_range=False, ensure_valid_placement=True, objects=objs))
 
 
-def initial_qpos(draw) -> np.ndarray:
-    """qpos[23] = [arm x7, finger x2, cubeA xyz + quat wxyz, cubeB xyz + quat wxyz] after Robot.reset + placement (stack.py:403-415)."""
-    q = np.zeros(23)
-    q[:7] = draw["arm"]
-    q[7:9] = PANDA_GRIPPER_INIT_QPOS
-    for k, name in enumerate(("cubeA", "cubeB")):
-        pos, yaw = draw[name]
-        o = 9 + 7 * k
-        q[o:o + 3] = pos
-        q[o + 3] = np.cos(yaw / 2.0)
-        q[o + 6] = np.sin(yaw / 2.0)
+def reset_draws(rng: np.random.Generator, spec=None, aux=None):
+    """One hard-reset block of draws from the env's generator, in the reference's order: robot joint noise, then the sampler over its objects
+    (placement_samplers.py:221-309).  `spec` = cfg["reset"] (factory.reset_cfg); None = the Panda defaults."""
+    spec = default_reset_spec() if spec is None else spec
+    arm = arm_noise(rng, spec)
+    sm = spec["sampler"]
+    placed = sample_objects(aux if (sm.get("own_rng") and aux is not None) else rng, sm, [(o["horizontal_radius"], o["bottom_z"], o["top_z"]) for o in sm["objects"]])
+    return dict(arm=arm, objects=placed)
+
+
+def initial_qpos(draw, spec=None) -> np.ndarray:
+    """qpos after Robot.reset + placement (stack.py:403-415): arm joints, gripper init_qpos, each cube's free joint (pos, quat wxyz)."""
+    spec = default_reset_spec() if spec is None else spec
+    q = np.zeros(int(spec["nq"]))
+    q[spec["arm_qpos_idx"]] = draw["arm"]
+    for g in spec["grippers"]:
+        q[g["qpos_idx"]] = g["init_qpos"]
+    for o, (pos, quat) in zip(spec["sampler"]["objects"], draw["objects"]):
+        a = int(o["qposadr"])
+        q[a:a + 3] = pos
+        q[a + 3:a + 7] = quat
     return q
 
 
-def episode_setup(seed0: int, env_ids, block: int = 0):
+def episode_setup(seed0: int, env_ids, block: int = 0, spec=None):
     """qpos for the global env ids: env i uses default_rng(seed0 + i); `block` selects the hard-reset block of that generator."""
     qpos = []
     for i in env_ids:
         rng = np.random.default_rng(seed0 + int(i))
         for _ in range(block + 1):
-            d = reset_draws(rng)
-        qpos.append(initial_qpos(d))
+            d = reset_draws(rng, spec)
+        qpos.append(initial_qpos(d, spec))
     return np.array(qpos)
 
 
-def stack_task(flat, cfg, reward_scale: float = 1.0, reward_shaping: bool = True):
-    """Observation program + reward description of Stack/Panda for the on-device epilogue (include/rsim.h rsim_task_desc, task 2).
+def stack_task(flat, cfg, reward_scale=None, reward_shaping=None):
+    """Observation program + reward description of Stack for the on-device epilogue (include/rsim.h rsim_task_desc, task 2).
 
     Key order = the reference's `_get_observations` order: the robot keys of Lift (robots/robot.py:334-484), then cubeA_pos, cubeA_quat,
-    cubeB_pos, cubeB_quat, cubeA_to_cubeB (= cubeB_pos - cubeA_pos), gripper_to_cubeA, gripper_to_cubeB (stack.py:417-461)."""
+    cubeB_pos, cubeB_quat, cubeA_to_cubeB (= cubeB_pos - cubeA_pos), gripper_to_cubeA, gripper_to_cubeB (stack.py:417-461).  Reward flavour and scale:
+    cfg["env"] (stack.py:161-162, 258-264)."""
     names = flat.names
     site = int(cfg["eef_site"])
-    eef_body = names["body"].index("robot0_right_hand")
+    eef_body, lpad, rpad = grasp_groups(flat, cfg)
     A, B = names["body"].index("cubeA_main"), names["body"].index("cubeB_main")
-    qi, di = cfg["qpos_idx"], cfg["dof_idx"]
-    gq, gd = cfg["grip_qpos_idx"], cfg["grip_dof_idx"]
-    obs = []
-    obs += [("qpos", q, 0) for q in qi] + [("cos", q, 0) for q in qi] + [("sin", q, 0) for q in qi]
-    obs += [("qvel", d, 0) for d in di] + [("qacc", d, 0) for d in di]
-    obs += [("site_pos", site, k) for k in range(3)] + [("body_quat", eef_body, k) for k in range(4)] + [("site_quat", site, k) for k in range(4)]
-    obs += [("qpos", q, 0) for q in gq] + [("qvel", d, 0) for d in gd]
-    for body in (A, B):
-        obs += [("body_pos", body, k) for k in range(3)] + [("body_quat", body, k) for k in range(4)]
-    obs += [("body_minus_body", B, k | (A << 2)) for k in range(3)]
-    obs += [("body_minus_site", A, k | (site << 2)) for k in range(3)] + [("body_minus_site", B, k | (site << 2)) for k in range(3)]
+    obs = robot_obs_program(cfg, site, eef_body)
+    if "cubeA_pos" in cfg.get("obs_keys", ["cubeA_pos"]):     # use_object_obs (stack.py:417)
+        for body in (A, B):
+            obs += [("body_pos", body, k) for k in range(3)] + [("body_quat", body, k) for k in range(4)]
+        obs += [("body_minus_body", B, k | (A << 2)) for k in range(3)]
+        obs += [("body_minus_site", A, k | (site << 2)) for k in range(3)] + [("body_minus_site", B, k | (site << 2)) for k in range(3)]
+    if sum(cfg.get("obs_dims", [len(obs)])) != len(obs):
+        raise NotImplementedError(f"Stack observation record: the reference env returned {sum(cfg['obs_dims'])} floats under keys {cfg['obs_keys']}, the on-device program has {len(obs)}")
+    scale, shaping = task_env_args(cfg, "stack", reward_scale, reward_shaping)
     g = names["geom"]
     return dict(obs=obs, task="stack", object_body=A, object2_body=B, grip_site=site, table_height=float(cfg.get("table_height", TABLE_OFFSET[2])),
-                lift_margin=0.04, reward_scale=reward_scale, reward_shaping=reward_shaping,
-                left_pad_geoms=[g.index("gripper0_right_finger1_pad_collision")], right_pad_geoms=[g.index("gripper0_right_finger2_pad_collision")],
+                lift_margin=0.04, reward_scale=scale, reward_shaping=shaping, left_pad_geoms=lpad, right_pad_geoms=rpad,
                 object_geoms=[g.index("cubeA_g0")], object2_geoms=[g.index("cubeB_g0")])
 
 
@@ -113,6 +106,10 @@ class StackBatch(ResetBankMixin):
         self.model = HipModel(flat)
         self.model.set_controller(cfg)
         self.model.set_task(stack_task(flat, cfg))
+        self.spec = cfg.get("reset") or default_reset_spec()     # cfg["reset"]: the reference env's own reset configuration (factory.reset_cfg)
+        self.n_sub = int(cfg.get("env", {}).get("n_sub", 25))
+        self._draw_fn = functools.partial(reset_draws, spec=self.spec)
+        self._draw_aux = bool(self.spec["sampler"].get("own_rng"))
         self.batch = HipBatch(self.model, self.B, device, per_env_params=False)   # cube sizes are fixed: one shared model
         self.seed0 = seed0
         self.horizon = horizon
@@ -125,10 +122,8 @@ class StackBatch(ResetBankMixin):
     def _bank_patch_offsets(self):
         return []
 
-    _draw_fn = staticmethod(reset_draws)
-
     def _episode(self, idx, episode):
-        return np.array([initial_qpos(d) for d in self.episode_draws(idx, episode)]).reshape(-1, 23)
+        return np.array([initial_qpos(d, self.spec) for d in self.episode_draws(idx, episode)]).reshape(-1, int(self.spec["nq"]))
 
     def _bank_rows(self, idx, episode):
         return self._episode(idx, episode), np.zeros((len(idx), 0))
@@ -141,8 +136,8 @@ class StackBatch(ResetBankMixin):
         b.ctrl_reset()     # fresh controller objects per reset (robots/robot.py:271)
         self.qpos0 = qpos
 
-    def step(self, actions, n_sub: int = 25):
-        self.batch.control_step(actions, n_sub)
+    def step(self, actions, n_sub: int = 0):
+        self.batch.control_step(actions, n_sub or self.n_sub)
         self._bank_tick()
 
     def obs(self):

@@ -57,6 +57,7 @@ class VecEnv:
         """Every env back to episode 0 of its stream (with `seed`: of the streams keyed by that seed, env i = default_rng(seed + i)).  The reset ring is re-installed for episodes 0 .. E-1: it has moved on by then, and resets
         read from slots that still held later episodes would silently break `episode k of env i = episode_setup(seed, i, k)`."""
         e = self.env
+        e._bank_stop()      # the upkeep thread draws from the same per-env generators (EpisodeStreams): it must be gone before they are re-keyed / replayed
         if seed is not None and int(seed) != e.seed0:
             e.seed0, e._streams = int(seed), None
         e.reset(block=0)

@@ -187,3 +187,43 @@ def test_torch_joint_position_plugin_tracks_the_in_kernel_controller():
             assert e <= tol, (t, k, e)
     print("torch JOINT_POSITION plugin vs in-kernel, worst relative deviations:", {k: f"{v:.1e}" for k, v in worst.items()})
     assert fused.batch.get("ep_index").tolist() == [1] * B
+
+
+def test_pickplace_record_of_a_host_controlled_step_is_a_step_record_not_a_reset_record():
+    """rsim_step2_last on PickPlace: the `{obj}_to_robot0_eef_pos / _quat` entries of the observation record (RSIM_OBS_REL_POS / REL_QUAT) are those of a
+    control step -- the object pose of the previous record against the current gripper pose -- as rsim_control_step writes them; they read zero only in
+    the record reset() returns.  (Round 3 derived "reset record" from "no in-kernel controller ran" and zeroed them under plugin controllers.)  The torch
+    OSC + GRIP plugins against the in-kernel ones on the IIWA + Robotiq140 model, observation records compared entry by entry."""
+    from robosuite_amd import pick_place
+    from robosuite_amd.controllers import BatchState, HostControlledEnv, Part, TorchGripController, TorchOSCController
+    g, cfg, flat = load_golden("seed0_full", "pickplace_iiwa")
+    B, T = 4, 3
+    ids = np.arange(B)
+    fused = pick_place.PickPlaceBatch(flat, cfg, ids, seed0=2)
+    hosted = pick_place.PickPlaceBatch(flat, cfg, ids, seed0=2)
+    st = BatchState(hosted.batch)
+    cr = np.asarray(flat.actuator_ctrlrange)
+    arm = TorchOSCController(st, dict(joints=cfg["qpos_idx"], qpos=cfg["qpos_idx"], qvel=cfg["dof_idx"]), (cr[cfg["act_idx"], 0], cr[cfg["act_idx"], 1]),
+                             cfg["eef_site"], cfg["base_site"], kp=cfg["kp"], damping_ratio=cfg["damping_ratio"], input_max=cfg["input_max"], input_min=cfg["input_min"],
+                             output_max=cfg["output_max"], output_min=cfg["output_min"], uncouple_pos_ori=bool(cfg["uncouple"]))
+    grip = TorchGripController(st, dict(joints=cfg["grip_qpos_idx"], qpos=cfg["grip_qpos_idx"], qvel=cfg["grip_dof_idx"]),
+                               (cr[cfg["grip_act"], 0], cr[cfg["grip_act"], 1]), signs=cfg["grip_sign"], speed=cfg["grip_speed"])
+    env = HostControlledEnv(hosted, [Part(arm, slice(0, 6), cfg["act_idx"]), Part(grip, slice(6, 7), cfg["grip_act"])])
+    env.reset(); fused.reset()
+    fused.batch.observe(); hosted.batch.observe()
+    dims = np.cumsum([0] + cfg["obs_dims"])
+    rel = [k for k, key in enumerate(cfg["obs_keys"]) if key.endswith("_to_robot0_eef_pos")]
+    assert len(rel) == 4 and all(np.all(hosted.batch.get("obs")[:, dims[k]:dims[k + 1]] == 0) for k in rel)      # the reset record: empty observation cache
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    for t in range(T):
+        a = 0.3 * (torch.rand(B, 7, device="cuda", generator=gen) * 2 - 1)
+        fused.step(a); env.step(a)
+        of, oh = fused.batch.get("obs"), hosted.batch.get("obs")
+        for k in rel:
+            assert np.abs(oh[:, dims[k]:dims[k + 1]]).max() > 0.05, (t, cfg["obs_keys"][k])            # objects are decimetres away from the gripper
+        for k, key in enumerate(cfg["obs_keys"]):
+            x, y = of[:, dims[k]:dims[k + 1]], oh[:, dims[k]:dims[k + 1]]
+            if key.endswith("quat") or key.endswith("quat_site"):
+                y = y * np.sign(np.sum(x * y, axis=1, keepdims=True))
+            tol = 0.5 if key.endswith("joint_acc") else (2e-2 if key.endswith("vel") else 2e-3)          # the Robotiq's undamped finger links track loosely
+            assert np.abs(x - y).max() < tol, (t, key, np.abs(x - y).max())

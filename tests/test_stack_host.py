@@ -24,7 +24,7 @@ def test_reset_draws_reproduce_the_reference_reset_states():
 def test_placement_keeps_the_cubes_apart():
     for seed in range(50):
         d = stack.reset_draws(np.random.default_rng(seed))
-        (pa, _), (pb, _) = d["cubeA"], d["cubeB"]
+        (pa, _), (pb, _) = d["objects"]
         assert np.linalg.norm(pa[:2] - pb[:2]) > np.hypot(0.02, 0.02) + np.hypot(0.025, 0.025)
         assert abs(pa[2] - 0.83) < 1e-12 and abs(pb[2] - 0.835) < 1e-12
 

@@ -266,6 +266,48 @@ def record_lift_robot(robot, seed, n_steps, action_scale):
     print(tag, "nv", flat.nv, "nbody", flat.nbody, "ntendon", int(flat.ntendon), "jnt_stiffness max", float(np.abs(flat.jnt_stiffness).max()), "grip_sign", cfg["grip_sign"])
 
 
+def record_make(stem, env_name, robot, seed, n_steps, policy="random", action_scale=1.0, **kwargs):
+    """A fixture of the make() boundary: the reference env constructed with the caller's kwargs (reference defaults otherwise -- sparse reward,
+    reward_scale 1, 20 Hz, default noise), cfg = factory.extract(env) in full (cfg["env"], ["reset"], ["grasp"]: what robosuite_amd.make() builds a
+    VecEnv from), the qpos after make() and after reset() (reset draw blocks 0 and 1 of default_rng(seed)), and an episode of env.step() with the
+    returned observations, rewards and success flags.  policy "lift": closed-loop hover -> descend -> close -> lift from the returned observations."""
+    env = suite.make(env_name, robots=robot, has_renderer=False, has_offscreen_renderer=False, use_camera_obs=False, seed=seed, **kwargs)
+    make_qpos = np.array(env.sim.data.qpos)
+    obs = env.reset()
+    sim = env.sim
+    flat, cfg = extract(env, obs)
+    keys = cfg["obs_keys"]
+    rng = np.random.default_rng(10**6 + seed)
+    actions, states, rewards, obs_flat, ctrls, succ = [], [sim.get_state().flatten()], [], [], [], []
+    phase, hold = 0, 0
+    for t in range(n_steps):
+        if policy == "lift":
+            e, c = np.array(obs["robot0_eef_pos"]), np.array(obs["cube_pos"])
+            a = np.zeros(env.action_dim)
+            if phase == 0:
+                d = c + np.array([0, 0, 0.08]) - e; a[:3] = np.clip(d / 0.05, -1, 1); a[-1] = -1
+                if np.linalg.norm(d) < 0.01: phase = 1
+            elif phase == 1:
+                d = c - e; a[:3] = np.clip(d / 0.05, -1, 1); a[-1] = -1
+                if np.linalg.norm(d) < 0.008: phase = 2
+            elif phase == 2:
+                a[-1] = 1; hold += 1
+                if hold > 12: phase = 3
+            else:
+                a[2] = 0.6; a[-1] = 1
+        else:
+            a = action_scale * rng.uniform(-1, 1, env.action_dim)
+        obs, r, done, info = env.step(a)
+        ctrls.append(np.array(sim.data.ctrl)); actions.append(a); states.append(sim.get_state().flatten()); rewards.append(r); succ.append(int(env._check_success()))
+        obs_flat.append(np.concatenate([np.atleast_1d(obs[k]).astype(np.float64) for k in keys]))
+    np.savez_compressed(os.path.join(GOLD, f"{stem}.npz"), actions=np.array(actions), states=np.array(states), rewards=np.array(rewards), obs=np.array(obs_flat),
+                        ctrl=np.array(ctrls), success=np.array(succ), make_qpos=make_qpos, reset_qpos=states[0][1:1 + flat.nq], seed=seed)
+    mjcf.save_model(flat, os.path.join(GOLD, f"{stem}.rsim"))
+    with open(os.path.join(GOLD, f"{stem}.cfg.json"), "w") as f:
+        json.dump(cfg, f, indent=1)
+    print(stem, "nq", flat.nq, "nv", flat.nv, "steps", n_steps, "reward max", max(rewards), "successes", int(np.sum(succ)), "env", cfg["env"], "noise", cfg["reset"]["noise"])
+
+
 def record_stack_resets(seeds):
     """Reset-path fixture (physics independent): qpos after make() (draw block 0) and after the first user reset() (block 1) per seed."""
     out = {}
@@ -428,6 +470,12 @@ if __name__ == "__main__":
     if "--pickplace-only" in sys.argv:
         record_pickplace(seed=0, n_steps=20, action_scale=1.0, tag="seed0_full")
         record_pickplace_resets([0, 1, 2, 3])
+        sys.exit(0)
+    if "--make-only" in sys.argv:
+        # the make() boundary: constructor kwargs that change what a step means (sparse reward scaled by 3, no joint noise, 10 Hz control), another robot
+        record_make("make_lift_panda_sparse", "Lift", "Panda", seed=5, n_steps=70, policy="lift", reward_shaping=False, reward_scale=3.0, initialization_noise=None,
+                    control_freq=10, horizon=200)
+        record_make("make_lift_sawyer", "Lift", "Sawyer", seed=2, n_steps=20, reward_shaping=True, initialization_noise={"magnitude": 0.05, "type": "uniform"})
         sys.exit(0)
     if "--ur5e-only" in sys.argv:
         record_lift_robot("UR5e", 0, 20, 1.0)
