@@ -257,6 +257,12 @@ class OracleController:
         g = np.ctypeslib.as_array(self._L.rso_ctrl_goal(self.ptr), shape=(12,))
         return g[:3], g[3:].reshape(3, 3)
 
+    @property
+    def state(self):
+        """goal_pos[3] goal_ori[9] initial_joint[8] grip_action[4] grip_goal[4] as ONE writable view (the members are adjacent doubles in rso_ctrl): a
+        test that continues a kernel episode on the oracle copies the kernel's RSIM_CSTATE record in here (same order: goal, q0, gripper action)."""
+        return np.ctypeslib.as_array(self._L.rso_ctrl_goal(self.ptr), shape=(28,))
+
     def env_step(self, data: OracleData, action, n_sub=25):
         a = np.ascontiguousarray(action, dtype=np.float64)
         self._L.rso_env_step(self.ptr, data.ptr, _dp(a), int(n_sub))

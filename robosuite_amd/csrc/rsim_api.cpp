@@ -32,6 +32,16 @@ extern "C" int rsim_launch_ctrl_reset_cfg3(const DModel* m, const DBatch* b, con
 extern "C" int rsim_launch_ctrl_reset_cfg4(const DModel* m, const DBatch* b, const unsigned char* mask, hipStream_t stream);
 extern "C" int rsim_limits_cfg3(int* lim);
 extern "C" int rsim_limits_cfg4(int* lim);
+// configuration 5 serves no model of its own: it is the capacity tier above configuration 3 (64 contacts x 256 rows, rsim_step.hip)
+#define RSIM_NCFG_ALL 8
+#define RSIM_TIER_DECL(c) \
+  extern "C" int rsim_limits_cfg##c(int* lim); extern "C" int rsim_cmem_bytes_cfg##c(void); \
+  extern "C" int rsim_launch_prepare_cfg##c(const DModel* m, const DBatch* b, int nblocks, int reset_only, hipStream_t stream); \
+  extern "C" int rsim_launch_step_list_cfg##c(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, int grid, hipStream_t stream);
+RSIM_TIER_DECL(5) RSIM_TIER_DECL(6) RSIM_TIER_DECL(7)
+extern "C" int rsim_launch_step_list_cfg3(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, int grid, hipStream_t stream);
+extern "C" int rsim_launch_tier_list(const int* tier, int* list, int* count, int* zero_next, int env0, int n, hipStream_t stream);
+typedef int (*step_list_fn)(const DModel*, const DBatch*, const float*, int, int, int, hipStream_t);
 typedef int (*step_fn)(const DModel*, const DBatch*, const float*, int, int, hipStream_t);
 typedef int (*creset_fn)(const DModel*, const DBatch*, const unsigned char*, hipStream_t);
 typedef int (*limits_fn)(int*);
@@ -58,7 +68,18 @@ typedef int (*prepare_fn)(const DModel*, const DBatch*, int, int, hipStream_t);
 typedef int (*cmem_fn)(void);
 static const prepare_fn k_prepare_launch[RSIM_NCFG] = {rsim_launch_prepare_cfg0, rsim_launch_prepare_cfg1, rsim_launch_prepare_cfg2, rsim_launch_prepare_cfg3, rsim_launch_prepare_cfg4};
 static const cmem_fn k_cmem_bytes[RSIM_NCFG] = {rsim_cmem_bytes_cfg0, rsim_cmem_bytes_cfg1, rsim_cmem_bytes_cfg2, rsim_cmem_bytes_cfg3, rsim_cmem_bytes_cfg4};
-static const limits_fn k_limits[RSIM_NCFG] = {rsim_limits_cfg0, rsim_limits_cfg1, rsim_limits_cfg2, rsim_limits_cfg3, rsim_limits_cfg4};
+static const limits_fn k_limits[RSIM_NCFG_ALL] = {rsim_limits_cfg0, rsim_limits_cfg1, rsim_limits_cfg2, rsim_limits_cfg3, rsim_limits_cfg4, rsim_limits_cfg5, rsim_limits_cfg6, rsim_limits_cfg7};
+// the configurations that can serve as the upper capacity tier of a batch, walked in this order: the same lane roles and dense algebra with more
+// contacts / rows first (6 above 0, 7 above 1 -- an env on its tier then runs about as fast as on its native configuration, which matters because the
+// envs that need the tier are the slowest of a launch), then the wide ones
+static const int k_tier_cfgs[4] = {6, 7, 3, 5};
+static step_list_fn step_list_launch(int c) {
+  return c == 3 ? rsim_launch_step_list_cfg3 : (c == 5 ? rsim_launch_step_list_cfg5 : (c == 6 ? rsim_launch_step_list_cfg6 : (c == 7 ? rsim_launch_step_list_cfg7 : nullptr)));
+}
+static prepare_fn prepare_launch_any(int c);
+static int cmem_bytes_any(int c);
+static prepare_fn prepare_launch_any(int c) { return c == 5 ? rsim_launch_prepare_cfg5 : (c == 6 ? rsim_launch_prepare_cfg6 : (c == 7 ? rsim_launch_prepare_cfg7 : k_prepare_launch[c])); }
+static int cmem_bytes_any(int c) { return c == 5 ? rsim_cmem_bytes_cfg5() : (c == 6 ? rsim_cmem_bytes_cfg6() : (c == 7 ? rsim_cmem_bytes_cfg7() : k_cmem_bytes[c]())); }
 extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStream_t stream);
 extern "C" int rsim_launch_bank_scatter(float* bank, int* tag, const int* env, const int* episode, const float* rows, int n, int E, int W, hipStream_t stream);
 extern "C" int rsim_launch_randomize(const DModel* m, const DBatch* b, const DDr* d, unsigned long long seed, unsigned long long step, hipStream_t stream);
@@ -140,6 +161,24 @@ struct rsim_batch {
   size_t cm_bytes;
   int cm_dirty;       // a model parameter / the controller changed since the blocks were built
   DCtrl cm_ctrl;      // controller the blocks were built for
+  // Capacity tiers of the fused control step.  MuJoCo never drops a contact (nconmax = 5000, models/assets/base.xml:5); a kernel configuration has a
+  // fixed contact / row capacity that decides its LDS footprint and with it the occupancy of the whole batch.  Instead of sizing every env for the
+  // worst substep of the worst env, an env whose substep needs more than the native capacity is stepped -- for as long as it does -- by a WIDER
+  // configuration (cfg_w: the same source compiled with more contacts / rows) from the same DModel / DBatch: envs near the native capacity move up
+  // between steps (tier_next), an env that runs out of capacity in mid-step commits nothing and is redone by the wide configuration inside the same
+  // rsim_control_step (redo list).  -1: no tier above this batch's configuration.
+  int cfg_w;
+  int lim_w[10];
+  void* d_cm_w;       // constant blocks of the wide configuration: one shared, one per env (built on demand for the envs a wide pass steps)
+  size_t cm_bytes_w;
+  int* d_tier[2];     // [B] each: tier of every env for the current / the next control step (swapped after every step)
+  int tier_flip;
+  int* d_wlist[2];    // [B] each: envs of the wide pass (tier 1), redo list
+  int* d_wcount;      // [2][2 + 2 * RSIM_MAX_GROUPS]: list lengths, double-buffered by the parity of the control step (whole batch: 0, 1; env block g: 2 + 2 g, 3 + 2 g);
+                      // the tier-list kernel of a step zeroes the lengths of the next one
+  hipStream_t wstream;
+  hipEvent_t wfork, wjoin;
+  int tier_mode;      // 0 (default): the wide pass beside the native one, on its own stream; 1 (RSIM_TIER_MODE=1, measurements): before it, on the batch's stream
   int have_cost;      // d_cost holds the costs of a previous control step
   // one-launch-per-step batches: the dispatch order of step t + 1 is sorted from the costs of step t - 1 on a side stream WHILE step t runs (envs that are
   // slow stay slow for hundreds of steps, so costs one step old order as well), which takes the sort and its two kernel boundaries off the critical
@@ -684,18 +723,32 @@ static int dalloc(T** p, size_t n) {
   return 0;
 }
 
+static bool config_holds(const rsim_model* m, const int* lim) {
+  const int ncg = (int)m->cg.size();
+  const bool tendons = m->ntendon > 0 || m->neq > 0;
+  return !(m->nbody > lim[0] || m->njnt > lim[1] || m->nv > lim[2] || m->nq > lim[2] + 8 || m->nu > 16 || ncg > lim[3] || m->nsite > lim[4] || m->npair > lim[7] ||
+           m->ndynroot > lim[8] || (tendons && !(lim[9] & 1)) || (m->ctrl.enabled && m->ctrl.narm == 2 && !(lim[9] & 2)));
+}
 // smallest compiled kernel configuration whose lane roles hold the model, -1 if none does; lim (10 ints, may be null) receives its limits
 static int pick_config(const rsim_model* m, int* lim_out) {
-  const int ncg = (int)m->cg.size();
   for (int c = 0; c < RSIM_NCFG; c++) {
     int lim[10];
     k_limits[c](lim);
-    const bool tendons = m->ntendon > 0 || m->neq > 0;
-    if (!(m->nbody > lim[0] || m->njnt > lim[1] || m->nv > lim[2] || m->nq > lim[2] + 8 || m->nu > 16 || ncg > lim[3] || m->nsite > lim[4] || m->npair > lim[7] ||
-          m->ndynroot > lim[8] || (tendons && !(lim[9] & 1)) || (m->ctrl.enabled && m->ctrl.narm == 2 && !(lim[9] & 2)))) {
+    if (config_holds(m, lim)) {
       if (lim_out) memcpy(lim_out, lim, sizeof(lim));
       return c;
     }
+  }
+  return -1;
+}
+// the configuration that steps the envs of a batch of configuration `cfg` which outgrow its contact / row capacity: the first tier configuration
+// that holds the model and more contacts or rows; -1 if there is none (or RSIM_NO_TIERS is set: drops are then counted in RSIM_OVERFLOW, as before round 4)
+static int pick_wide(const rsim_model* m, int cfg, const int* lim, int* lim_out) {
+  if (getenv("RSIM_NO_TIERS")) return -1;
+  for (int c : k_tier_cfgs) {
+    int lw[10];
+    k_limits[c](lw);
+    if (c != cfg && config_holds(m, lw) && lw[5] >= lim[5] && lw[6] >= lim[6] && (lw[5] > lim[5] || lw[6] > lim[6])) { memcpy(lim_out, lw, sizeof(lw)); return c; }
   }
   return -1;
 }
@@ -795,6 +848,24 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.ctrl = m->ctrl;
   b->cs = m->ctrl.enabled ? m->ctrl.cs_size : RSIM_CS_SIZE;
   dm.ctrl.cs_size = b->cs;
+  // capacity tiers: only for controllers whose state lives in LDS for the whole launch (a step that is handed over must not have written anything)
+  b->cfg_w = b->cs <= RSIM_CS_LDS ? pick_wide(m, b->cfg, b->lim, b->lim_w) : -1;
+  b->d_cm_w = nullptr; b->d_tier[0] = b->d_tier[1] = nullptr; b->d_wlist[0] = b->d_wlist[1] = nullptr; b->d_wcount = nullptr; b->wstream = nullptr; b->tier_flip = 0;
+  if (b->cfg_w >= 0) {
+    b->cm_bytes_w = (size_t)cmem_bytes_any(b->cfg_w);
+    if (dalloc((char**)&b->d_cm_w, b->cm_bytes_w * (1 + (b->per_env ? (size_t)B : 0)))) return 1;
+    for (int k = 0; k < 2; k++) if (dalloc(&b->d_tier[k], (size_t)B) || dalloc(&b->d_wlist[k], (size_t)B)) return 1;
+    if (dalloc(&b->d_wcount, (size_t)2 * (2 + 2 * RSIM_MAX_GROUPS))) return 1;
+    {
+      // the wide pass runs beside the native one on a stream of the highest priority (its few workgroups are the slowest envs of the step)
+      int lo = 0, hi = 0;
+      HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      HIPCHK(hipStreamCreateWithPriority(&b->wstream, hipStreamNonBlocking, hi));
+    }
+    b->tier_mode = getenv("RSIM_TIER_MODE") ? atoi(getenv("RSIM_TIER_MODE")) : 0;
+    HIPCHK(hipEventCreateWithFlags(&b->wfork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&b->wjoin, hipEventDisableTiming));
+  }
   b->d_obsprog = nullptr;
   memset(&dm.task, 0, sizeof(dm.task));
   if (m->has_task) {
@@ -846,6 +917,11 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   if (b->mev) hipEventDestroy(b->mev);
   for (int i = 0; i < RSIM_FIELD_COUNT; i++) if (b->fptr[i]) hipFree(b->fptr[i]);
   hipFree(b->d_cm);
+  if (b->cfg_w >= 0) {
+    hipStreamSynchronize(b->wstream); hipStreamDestroy(b->wstream); hipEventDestroy(b->wfork); hipEventDestroy(b->wjoin);
+    hipFree(b->d_cm_w); hipFree(b->d_wcount);
+    for (int k = 0; k < 2; k++) { hipFree(b->d_tier[k]); hipFree(b->d_wlist[k]); }
+  }
   if (b->db.mprc) hipFree(b->db.mprc);
   if (b->db.bpl) hipFree(b->db.bpl);
   hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_ft0); if (b->d_obsprog) hipFree(b->d_obsprog);
@@ -949,6 +1025,7 @@ extern "C" int rsim_set_stream_groups(rsim_batch* b, int groups) {
   }
   if (!b->mev) HIPCHK(hipEventCreateWithFlags(&b->mev, hipEventDisableTiming));
   if (groups > b->groups) b->groups = groups;
+  if (b->cfg_w >= 0) HIPCHK(hipMemset(b->d_wcount, 0, (size_t)2 * (2 + 2 * RSIM_MAX_GROUPS) * sizeof(int)));   // another partition of the batch: no list length of the old one survives
   b->ngroups = groups;
   b->have_cost = 0;
   return 0;
@@ -982,14 +1059,44 @@ static int ensure_constants(rsim_batch* b) {
     int e = k_prepare_launch[b->cfg](&b->dm, &b->db, b->B, 0, b->stream);
     if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   }
+  if (b->cfg_w >= 0) {   // the shared block of the wide configuration (its per-env blocks are built on demand, right before a wide pass)
+    DModel dm0 = b->dm; DBatch db0 = b->db;
+    dm0.fenv = 0; db0.cm_env = b->d_cm_w; db0.cm_stride = 0;
+    int e = prepare_launch_any(b->cfg_w)(&dm0, &db0, 1, 0, b->stream);
+    if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  }
   b->cm_ctrl = b->dm.ctrl;
   b->cm_dirty = 0;
   return 0;
 }
 
+// One wide pass of a tiered control step on `stream`: the constant blocks of the listed envs (only when envs have blocks of their own), then the step.
+// pass 1 = the envs whose tier is 1 (list built by rsim_launch_tier_list), pass 2 = the redo list the native pass appended to.
+static int wide_pass(rsim_batch* b, const float* actions, int n_sub, int flags, int pass, const int* list, const int* count, hipStream_t stream) {
+  DBatch dw = b->db;
+  dw.cm = b->d_cm_w; dw.cm_env = (char*)b->d_cm_w + b->cm_bytes_w; dw.cm_stride = b->db.cm_stride ? (long long)b->cm_bytes_w : 0;
+  dw.order = nullptr; dw.cost = nullptr; dw.env0 = 0; dw.nenv = 0;
+  dw.tier_pass = pass; dw.wlist = list; dw.wcount = count; dw.tier_con = b->lim[5]; dw.tier_efc = b->lim[6];
+  const int grid = b->B < 512 ? b->B : 512;
+  if (dw.cm_stride) {
+    int e = prepare_launch_any(b->cfg_w)(&b->dm, &dw, grid, 2, stream);
+    if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  }
+  int e = step_list_launch(b->cfg_w)(&b->dm, &dw, actions, n_sub, flags, grid, stream);
+  if (e) return fail("wide-tier kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  return 0;
+}
+
 static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
+  const int WCN = 2 + 2 * RSIM_MAX_GROUPS;   // list lengths per step parity
   HIPCHK(hipSetDevice(b->device));
   if (sync_controller(b)) return 1;
+  // capacity tiers apply to the fused control step only (the debug entries keep the native capacity and count what they drop in RSIM_OVERFLOW)
+  const bool tiered = b->cfg_w >= 0 && (flags & RF_EPISODE) && (flags & RF_CTRL) && !(flags & RF_DEBUG);
+  b->db.tier_cur = tiered ? b->d_tier[b->tier_flip] : nullptr; b->db.tier_next = tiered ? b->d_tier[b->tier_flip ^ 1] : nullptr;
+  b->db.tier_up_con = getenv("RSIM_TIER_UP_CON") ? atoi(getenv("RSIM_TIER_UP_CON")) : 2;
+  b->db.tier_up_efc = getenv("RSIM_TIER_UP_EFC") ? atoi(getenv("RSIM_TIER_UP_EFC")) : 6;
+  b->db.tier_pass = tiered ? 0 : -1; b->db.wlist = nullptr; b->db.wcount = nullptr; b->db.wlist2 = nullptr; b->db.wcount2 = nullptr;
   const bool grouped = (flags & RF_EPISODE) && (flags & RF_CTRL) && b->ngroups > 1;
   if (!grouped || b->cm_dirty || memcmp(&b->cm_ctrl, &b->dm.ctrl, sizeof(DCtrl))) { if (join_groups(b)) return 1; }   // main-stream work ahead
   if (ensure_constants(b)) return 1;
@@ -1011,8 +1118,19 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
         }
         db.cost = b->d_cost;
       }
+      if (tiered) {   // this env block's lists; every pass of the block runs on the block's own stream, one after the other
+        int* cnt = b->d_wcount + b->tier_flip * WCN + 2 + 2 * g;
+        int el = rsim_launch_tier_list(b->db.tier_cur, b->d_wlist[0] + e0, cnt, b->d_wcount + (b->tier_flip ^ 1) * WCN + 2 + 2 * g, e0, e1 - e0, b->gstream[g]);
+        if (el) return fail("tier-list kernel launch failed: %s", hipGetErrorString((hipError_t)el));
+        db.wlist2 = b->d_wlist[1] + e0; db.wcount2 = cnt + 1;
+      }
       int e = k_step_launch[b->cfg](&b->dm, &db, actions, n_sub, flags, b->gstream[g]);
       if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+      if (tiered) {
+        int* cnt = b->d_wcount + b->tier_flip * WCN + 2 + 2 * g;
+        if (wide_pass(b, actions, n_sub, flags, 1, b->d_wlist[0] + e0, cnt, b->gstream[g])) return 1;
+        if (wide_pass(b, actions, n_sub, flags, 2, b->d_wlist[1] + e0, cnt + 1, b->gstream[g])) return 1;
+      }
       if (b->db.bank && b->db.horizon > 0) {
         db.order = nullptr; db.cost = nullptr;
         if (b->db.bank_P > 0 && b->db.cm_stride) {
@@ -1026,6 +1144,7 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
       }
     }
     if (sched) b->have_cost = 1;
+    if (tiered) b->tier_flip ^= 1;
     b->gen++;
     b->derived_stale = 1;
     return 0;
@@ -1040,8 +1159,31 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
     if (b->ord_valid[cur]) { HIPCHK(hipStreamWaitEvent(b->stream, b->ord_done[cur], 0)); b->db.order = b->d_order2[cur]; }
     b->db.cost = b->d_cost2[cur];
   }
+  if (tiered) {
+    // beside the native pass, on a stream of its own: the envs whose tier is 1 (they were close to the native capacity, or beyond it, last step)
+    int* cnt = b->d_wcount + b->tier_flip * WCN;
+    if (b->tier_mode == 1) {   // everything on the batch's stream: list, wide pass, then the native pass
+      int el = rsim_launch_tier_list(b->db.tier_cur, b->d_wlist[0], cnt, b->d_wcount + (b->tier_flip ^ 1) * WCN, 0, b->B, b->stream);
+      if (el) return fail("tier-list kernel launch failed: %s", hipGetErrorString((hipError_t)el));
+      if (wide_pass(b, actions, n_sub, flags, 1, b->d_wlist[0], cnt, b->stream)) return 1;
+    } else {
+      HIPCHK(hipEventRecord(b->wfork, b->stream));
+      HIPCHK(hipStreamWaitEvent(b->wstream, b->wfork, 0));
+      int el = rsim_launch_tier_list(b->db.tier_cur, b->d_wlist[0], cnt, b->d_wcount + (b->tier_flip ^ 1) * WCN, 0, b->B, b->wstream);
+      if (el) return fail("tier-list kernel launch failed: %s", hipGetErrorString((hipError_t)el));
+      if (wide_pass(b, actions, n_sub, flags, 1, b->d_wlist[0], cnt, b->wstream)) return 1;
+      HIPCHK(hipEventRecord(b->wjoin, b->wstream));
+    }
+    b->db.wlist2 = b->d_wlist[1]; b->db.wcount2 = cnt + 1;
+  }
   int e = k_step_launch[b->cfg](&b->dm, &b->db, actions, n_sub, flags, b->stream);
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (tiered) {
+    // after both: the envs the native pass had to hand over in mid-step (rare: most move up between steps), redone from their unchanged state
+    if (b->tier_mode != 1) HIPCHK(hipStreamWaitEvent(b->stream, b->wjoin, 0));
+    if (wide_pass(b, actions, n_sub, flags, 2, b->d_wlist[1], b->d_wcount + b->tier_flip * WCN + 1, b->stream)) return 1;
+    b->tier_flip ^= 1;
+  }
   if (sched1) {
     HIPCHK(hipEventRecord(b->step_done[cur], b->stream));
     if (b->nstep >= 1) {   // beside the step just launched: sort the costs of the PREVIOUS step into the order of the NEXT one

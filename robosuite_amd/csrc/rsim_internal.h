@@ -178,6 +178,16 @@ struct DBatch {
   void* cm_env;          // per-env constant blocks [B] (used once a float-table field has per-env values)
   long long cm_stride;   // bytes between the blocks of consecutive envs, 0 = no env has its own block yet
   int* overflow;         // [B] contacts + constraint rows dropped for lack of capacity (null = not counted)
+  // capacity tiers (rsim_api.cpp launch()): tier_cur[env] (read-only during a control step) says which configuration steps the env, every pass that
+  // commits an env's step writes tier_next[env]; the host swaps the two after the step.  wlist / wcount: the env list a wide pass walks; wlist2 /
+  // wcount2: the redo list pass 0 appends to.  tier_con / tier_efc: the NATIVE capacities (the wide pass decides against them when an env may go back)
+  const int* tier_cur;
+  int* tier_next;
+  const int* wlist; const int* wcount;
+  int* wlist2; int* wcount2;
+  int tier_pass;         // -1 (or tier_cur == null): no tiers; 0: native pass; 1 / 2: wide pass over wlist
+  int tier_con, tier_efc;
+  int tier_up_con, tier_up_efc;   // an env moves up once a substep came within this many contacts / rows of the native capacity (and back down 2 / 8 below that)
   int* cap_need;         // [B][2] largest number of contacts / constraint rows any substep of the env asked for (RSIM_CAP_NEED), null = not tracked
   int mprc_portal;       // 0: keep only the (exact) separating-direction warm start
   int* task_object;      // [B] PickPlace single-object mode 1: the object of the env's current episode (RSIM_TASK_OBJECT)

@@ -15,7 +15,7 @@
 #include "../../include/rsim.h"
 #include "rsim_internal.h"
 
-// Five builds of this file: RSIM_CFG 0 = 32 bodies x 16 dofs (Lift/Panda; tree products as incidence-matrix MFMAs with compile-time bit
+// Eight builds of this file (0-4 serve models, 5-7 are the capacity tiers above 3, 0 and 1): RSIM_CFG 0 = 32 bodies x 16 dofs (Lift/Panda; tree products as incidence-matrix MFMAs with compile-time bit
 // fields, every dense nv x nv product on one 16x16 MFMA tile, register-resident Cholesky), 1 = 32 x 32 (Stack/Panda: two free cubes),
 // 2 = 64 x 16 (Baxter), 3 = 64 x 48 (PickPlace / IIWA + Robotiq140), 4 = 64 x 64.  The larger builds keep the lane roles, the collision
 // pipeline, the constraint rows and the Newton algorithm; beyond 32 x 16 the tree products use per-lane 64-bit incidence words
@@ -38,9 +38,20 @@
        // (M, H, J) shrink to 75 KB of LDS per environment = TWO environments per CU
 #define RSIM_DIMS 64, 32, 48, 64, 32, 32, 128, 640
 #define RSIM_SYM(x) x##_cfg3
-#else  // 64 bodies x 64 dofs x 128 constraint rows: the widest configuration (one environment per CU)
+#elif RSIM_CFG == 4  // 64 bodies x 64 dofs x 128 constraint rows: the widest configuration (one environment per CU)
 #define RSIM_DIMS 64, 32, 64, 64, 32, 32, 128, 640
 #define RSIM_SYM(x) x##_cfg4
+#elif RSIM_CFG == 6  // capacity tier above configuration 0 (Lift class: 32 bodies x 16 dofs): 32 contacts x 128 rows, the same one-tile algebra with two rows per lane
+#define RSIM_DIMS 32, 16, 16, 24, 16, 32, 128, 192
+#define RSIM_SYM(x) x##_cfg6
+#elif RSIM_CFG == 7  // capacity tier above configuration 1 (Stack class: 32 bodies x 32 dofs): 32 contacts x 128 rows
+#define RSIM_DIMS 32, 16, 32, 24, 16, 32, 128, 192
+#define RSIM_SYM(x) x##_cfg7
+#else  // 64 bodies x 48 dofs with 64 contacts x 256 constraint rows (four per lane), one environment per CU: the capacity tier ABOVE configuration 3.  No
+       // model is assigned to it; the PickPlace envs whose substep asks for more than 32 contacts / 128 rows (a handful of 8192 at any time: objects
+       // wedged between fingers, bin walls and each other) are stepped by it for as long as they do (rsim_api.cpp launch(): capacity tiers)
+#define RSIM_DIMS 64, 32, 48, 64, 32, 64, 256, 640
+#define RSIM_SYM(x) x##_cfg5
 #endif
 
 #ifndef RSIM_MINWAVES
@@ -269,7 +280,7 @@ __device__ __forceinline__ Q4 ldq(gcf p) { Q4 q = {p[0], p[1], p[2], p[3]}; retu
 // ------------------------------------------------------------------------------------------------------------
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 struct Smem {
-  static_assert((NB == 32 || NB == 64) && (NV == 16 || NV == 32 || NV == 48 || NV == 64) && (NEFC == 64 || NEFC == 128) && NG <= 64 && (NS == 16 || NS == 32) && NPAIR % 64 == 0 && NPAIR <= 640,
+  static_assert((NB == 32 || NB == 64) && (NV == 16 || NV == 32 || NV == 48 || NV == 64) && (NEFC == 64 || NEFC == 128 || NEFC == 256) && NCON <= 64 && NG <= 64 && (NS == 16 || NS == 32) && NPAIR % 64 == 0 && NPAIR <= 640,
                 "lane roles: body / site columns are powers of two, dofs whole 16-column tiles, one lane per constraint row, candidate pairs in rows of 64");
   static constexpr bool TREE_TILE_ = NB == 32 && NV == 16;   // tree products as 32-body x 16-dof incidence-matrix MFMAs
   static constexpr int NVP = NV + 1;  // padded row stride of the dense nv x nv matrices (conflict-free column reads)
@@ -2579,10 +2590,9 @@ struct Sim {
   __device__ __forceinline__ void make_rows_wide(int nefc) {
     const int nv = m.nv, q = lane >> 4, r = lane & 15;
     float* st = sm.u.rowst;   // [row][20]: w2[8] | -w1[8] | mask2 lo hi | mask1 lo hi
-    const bool two = NSLOT > 1 && nefc > 64;
 #pragma unroll
     for (int slot = 0; slot < NSLOT; slot++) {
-      if (slot > 0 && !two) continue;
+      if (64 * slot >= nefc) continue;   // this slot of the lanes holds no row (the 128 / 256-row configurations at the usual row counts)
       const int row = lane + 64 * slot;
       const bool valid = row < nefc;
       const int desc = valid ? sm.e_desc[row] : 0;
@@ -2652,7 +2662,7 @@ struct Sim {
     const float qv = lane < nv ? sm.qvel[lane] : 0.f;
 #pragma unroll
     for (int slot = 0; slot < NSLOT; slot++) {
-      if (slot > 0 && !two) continue;
+      if (64 * slot >= nefc) continue;
       const int row = lane + 64 * slot;
       const bool valid = row < nefc;
       const int desc = valid ? sm.e_desc[row] : 0;
@@ -2670,7 +2680,7 @@ struct Sim {
     SYNC();
 #pragma unroll
     for (int slot = 0; slot < NSLOT; slot++) {
-      if (slot > 0 && !two) continue;
+      if (64 * slot >= nefc) continue;
       const int row = lane + 64 * slot;
       const float jv = lds_row_dot(sm.J + row * JS, qv);
       if (row < nefc) sm.e_aref[row] = -sm.e_force[row] * jv - sm.e_aref[row];
@@ -3189,7 +3199,8 @@ struct Sim {
       for (int j = 0; j < CD; j++) {
         const int R = rw[s].head + j;
         float t = __shfl(u[0], R & 63);
-        if constexpr (NSLOT > 1) { const float t1 = __shfl(u[NSLOT - 1], R & 63); t = (R >> 6) ? t1 : t; }
+#pragma unroll
+        for (int s2 = 1; s2 < NSLOT; s2++) { const float t1 = __shfl(u[s2], R & 63); t = (R >> 6) == s2 ? t1 : t; }
         out[s][j] = (rw[s].ell && j < rw[s].dim) ? t : 0.f;
       }
   }
@@ -3388,7 +3399,8 @@ struct Sim {
     const int nch = (n + 3) >> 2, nvt = (nv + 15) & ~15;
     const float scale = 1.0f / (m.meaninertia * (nv > 1 ? nv : 1));
     const float tolerance = m.tolerance;
-    const bool two = NSLOT > 1 && n > 64;   // rows in the lanes' second slot (128-row configuration): typical states have none, and then none of its work is done
+    // rows in the lanes' further slots (128 / 256-row configurations): slot s holds rows iff n > 64 s; typical states have none there, and then none of that work is done
+#define SLOT_ON(s) (64 * (s) < n || (s) == 0)
     // ---- per-lane row data (NSLOT rows per lane)
     Row rw[NSLOT];
 #pragma unroll
@@ -3438,11 +3450,11 @@ struct Sim {
     // residuals of all rows of this lane at acceleration x, then cost / force / state of each (the cone blocks gather their siblings first)
     auto evaluate = [&](float x) -> float {
 #pragma unroll
-      for (int s = 0; s < NSLOT; s++) if (s == 0 || two) jar[s] = row_dot(rw[s], x) - rw[s].aref;
+      for (int s = 0; s < NSLOT; s++) if SLOT_ON(s) jar[s] = row_dot(rw[s], x) - rw[s].aref;
       gather(rw, jar, uj);
       float c = 0.f;
 #pragma unroll
-      for (int s = 0; s < NSLOT; s++) if (s == 0 || two) c += row_update(rw[s], jar[s], force[s], state[s], uj[s], T[s], g[s]);
+      for (int s = 0; s < NSLOT; s++) if SLOT_ON(s) c += row_update(rw[s], jar[s], force[s], state[s], uj[s], T[s], g[s]);
       return c;
     };
     // ---- warm start: previous acceleration unless the unconstrained one is cheaper
@@ -3515,7 +3527,7 @@ struct Sim {
         } else {
           // weighted row r = sum_k2 coef[k2] J[head + min(k2, dim - 1)]: (D, 0, 0, 0) on the row itself outside the cone state, the row's line of
           // the block Hessian on the block's rows inside it.  hess_wide() forms it while it feeds the matrix cores.
-          if (s == 0 || two) {
+          if SLOT_ON(s) {
             float* o = sm.u.W + 5 * w_.row;
             const bool cone = state[s] == ST_CONE;
             o[0] = cone ? hk[0] : dq; o[1] = hk[1]; o[2] = hk[2]; o[3] = hk[3];
@@ -3578,7 +3590,7 @@ struct Sim {
       // ---- line search along sk
       float jv[NSLOT];
 #pragma unroll
-      for (int s = 0; s < NSLOT; s++) jv[s] = (s == 0 || two) ? row_dot(rw[s], sk) : 0.f;
+      for (int s = 0; s < NSLOT; s++) jv[s] = SLOT_ON(s) ? row_dot(rw[s], sk) : 0.f;
       const float mvv = mass_dot(Mr, sk);
       const float q1 = wave_sum(dofl ? sk * (ma - f_sm) : 0.f), q2 = wave_sum(dofl ? 0.5f * sk * mvv : 0.f), sn = sqrtf(wave_sum(dofl ? sk * sk : 0.f));
       if (sn < 1e-15f) break;
@@ -3591,7 +3603,7 @@ struct Sim {
       auto line = [&](float al, float& c, float& c1, float& c2) {
         c = c1 = c2 = 0.f;
 #pragma unroll
-        for (int s = 0; s < NSLOT; s++) if (s == 0 || two) { float t, t1, t2; row_ls(rw[s], jar[s], jv[s], g0[s], gvv[s], al, t, t1, t2); c += t; c1 += t1; c2 += t2; }
+        for (int s = 0; s < NSLOT; s++) if SLOT_ON(s) { float t, t1, t2; row_ls(rw[s], jar[s], jv[s], g0[s], gvv[s], al, t, t1, t2); c += t; c1 += t1; c2 += t2; }
       };
       {
         float c, c1, c2;
@@ -3657,6 +3669,7 @@ struct Sim {
     if (lane == 0) sm.niter = iter;
     pf.count(RP_N_NEWTON, iter);
     SYNC();
+#undef SLOT_ON
   }
 
 
@@ -3837,16 +3850,21 @@ struct Sim {
 // the step kernel
 // ------------------------------------------------------------------------------------------------------------
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR, bool DBG>
-__device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, const float* __restrict__ actions, int n_sub, int flags) {
+__device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, const float* __restrict__ actions, int n_sub, int flags, int slot) {
   typedef Smem<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> SM;
   const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= (b.nenv ? b.nenv : b.B)) return;
+  // Capacity tiers (DBatch.tier_pass >= 0, rsim_api.cpp launch()): pass 0 = this configuration steps the envs whose tier is 0 and hands an env that
+  // runs out of contact / row capacity to the redo list WITHOUT committing anything of the step; passes 1 / 2 = a wider configuration steps the
+  // envs of a list (1: the envs that were close to the native capacity last step, 2: the redo list), `slot` = index into that list.
+  const int tpass = (!DBG && b.tier_cur) ? b.tier_pass : -1;
+  if (tpass <= 0 && slot >= (b.nenv ? b.nenv : b.B)) return;
   // workgroups are dispatched in index order: handing the envs that were slowest in the previous launch to the first workgroups
   // (contact-rich envs stay contact-rich for many control steps) keeps the last wave of envs short
-  const int env = uni((b.order ? b.order[blockIdx.x] : (int)blockIdx.x) + b.env0);   // scalar: every per-env base address below then lives in SGPRs
+  const int env = uni(tpass > 0 ? b.wlist[slot] : (b.order ? b.order[slot] : slot) + b.env0);   // scalar: every per-env base address below then lives in SGPRs
   // RF_RESET_ONLY: the pass that follows a control step and produces the observation MujocoEnv.reset() returns (forward + epilogue, no reward)
   // for the envs that step re-initialised from the reset bank; every other workgroup leaves at once
   if ((flags & RF_RESET_ONLY) && !b.needs_reset[env]) return;
+  if (tpass == 0 && b.tier_cur[env] != 0) return;    // stepped by the wide configuration in this control step
   const unsigned t_launch = b.cost ? (unsigned)uni((int)(clock64() >> 6)) : 0u;   // 64-tick units, scalar
   const float* fp = m.ft + (size_t)env * m.fstride;
   Sim<SM> sim(m, fp, lane, b.prof, b.cm, b.cm_stride ? (const char*)b.cm_env + (size_t)env * b.cm_stride : (const char*)b.cm);
@@ -3874,6 +3892,8 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   sim.init_lds();
   const float* act = actions ? actions + (size_t)env * m.ctrl.action_dim : nullptr;
   float time = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, b.time[env])));   // wave-uniform, carried over all substeps: a scalar register
+  bool fresh_ctrl = false;
+  int ndiverged = 0;
   if ((flags & RF_CTRL) && b.needs_reset[env]) {
     // this env was re-initialised on the device when its previous episode ended: fresh controller objects (robots/robot.py:271)
     V3 xp0; Q4 xq0;
@@ -3884,7 +3904,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
     sim.kinematics(xp0, xq0);
     sim.geom_site_frames();
     sim.ctrl_reset();
-    if (lane == 0) b.needs_reset[env] = 0;
+    fresh_ctrl = true;   // the flag is cleared when the step is committed (a step handed to the wide configuration must find it still set)
   }
   sim.pf.mark(RP_LOAD);
   for (int sub = 0; sub < n_sub; sub++) {
@@ -3947,11 +3967,28 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
         for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = FP(FO_qpos0, i);
         if (lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.qacc[lane] = 0.f; sm.ctrl[lane] = 0.f; }
         time = 0.f;
-        if (lane == 0) b.diverged[env] += 1;
+        ndiverged++;
         SYNC();
       }
     }
     sim.pf.count(RP_N_SUB, 1);
+  }
+  if (tpass == 0 && sim.ovf) {
+    // a substep asked for more contacts / rows than this configuration holds: nothing of this control step is committed (state, controller
+    // state, episode counters, observation record are as they were); the env goes on the redo list and the wide configuration steps it from the
+    // same state later in this same rsim_control_step.  The caches this pass touched (warm-start records, broadphase list) validate themselves.
+    if (lane == 0) { b.wlist2[atomicAdd(b.wcount2, 1)] = env; b.tier_next[env] = 1; }
+    if (b.cost && lane == 0) b.cost[env] = (unsigned)(clock64() >> 6) - t_launch;
+    return;
+  }
+  if (fresh_ctrl && lane == 0) b.needs_reset[env] = 0;
+  if (ndiverged && lane == 0) b.diverged[env] += ndiverged;
+  if (tpass >= 0 && lane == 0) {
+    // next step's tier: up when a substep came within a few contacts / rows of the native capacity (so that most hand-overs happen between steps,
+    // without a redo), down again once the demand has dropped well below it
+    const bool up = tpass == 0 ? (sim.need_con > SM::NCON_ - b.tier_up_con || sim.need_efc > SM::NEFC_ - b.tier_up_efc)
+                               : !(sim.need_con <= b.tier_con - b.tier_up_con - 2 && sim.need_efc <= b.tier_efc - b.tier_up_efc - 8);
+    b.tier_next[env] = up ? 1 : 0;
   }
   if ((flags & RF_OBS) && m.task.enabled) {
     if (m.task.single_mode == 1) sim.task_obj = b.task_object[env] & 3;
@@ -3995,7 +4032,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   for (int i = lane; i < m.nu; i += 64) b.ctrl[(size_t)env * m.nu + i] = sm.ctrl[i];
   if (lane < csl) sim.cst[lane] = sm.cstate[lane];
   if (lane == 0) b.time[env] = time;
-  if (b.overflow && lane == 0 && sim.ovf) b.overflow[env] += sim.ovf;
+  if (b.overflow && lane == 0 && sim.ovf) b.overflow[env] += sim.ovf;   // with capacity tiers: drops of the WIDE configuration only (pass 0 left above)
   if (b.cap_need && lane == 0) { int* cn = b.cap_need + 2 * (size_t)env; if (sim.need_con > cn[0]) cn[0] = sim.need_con; if (sim.need_efc > cn[1]) cn[1] = sim.need_efc; }
   if (b.cost && lane == 0) b.cost[env] = (unsigned)(clock64() >> 6) - t_launch;
   if (b.prof && lane == 0) {
@@ -4031,19 +4068,29 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
 
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
-  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR, false>(m, b, actions, n_sub, flags);
+  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR, false>(m, b, actions, n_sub, flags, (int)blockIdx.x);
+}
+// The same control step as the upper capacity tier of a batch whose model belongs to a narrower configuration: a fixed, small grid walks the list
+// of envs this pass steps (DBatch.wlist / wcount, filled on the device), so a control step in which no env needs the tier costs one empty launch.
+template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
+__global__ __launch_bounds__(64, 1) void k_step_list(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
+  const int n = *b.wcount;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR, false>(m, b, actions, n_sub, flags, i);
+    __syncthreads();
+  }
 }
 // The compatibility / debug form (RF_DEBUG: the B = 1 shim entries, forward() of a batch for the parity tests): the same body plus the MuJoCo-shaped
 // derived arrays and the acceleration-stage sensors.  Its own kernel, so that none of this costs the control step a register.
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 __global__ __launch_bounds__(64, 1) void k_step_dbg(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
-  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR, true>(m, b, actions, n_sub, flags);
+  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR, true>(m, b, actions, n_sub, flags, (int)blockIdx.x);
 }
 // The reset-observation pass that follows a control step (forward + observables for the envs it re-initialised, no reward): the same body under
 // its own kernel name, so that per-kernel profiles of k_step hold control steps only (and the constant flags strip controller / integrator code)
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 __global__ __launch_bounds__(64, 1) void k_reset_obs(DModel m, DBatch b) {
-  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR, false>(m, b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_OBS | RF_RESET_ONLY);
+  step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR, false>(m, b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_OBS | RF_RESET_ONLY, (int)blockIdx.x);
 }
 
 // controller reset kernel: forward kinematics then OSC.reset_goal / initial_joint capture
@@ -4076,7 +4123,18 @@ __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const uns
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 __global__ __launch_bounds__(64) void k_prepare(DModel m, DBatch b, int reset_only) {
   typedef Smem<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> SM;
-  const int env = blockIdx.x + b.env0, lane = threadIdx.x;
+  const int lane = threadIdx.x;
+  if (reset_only == 2) {   // the envs of a capacity-tier list (their blocks of the WIDE configuration are built on demand, right before that configuration steps them)
+    const int n = *b.wcount;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+      const int env = b.wlist[i];
+      char* const cmb = (char*)b.cm_env + (size_t)env * b.cm_stride;
+      Sim<SM> sim(m, m.ft + (size_t)env * m.fstride, lane, nullptr, cmb, cmb);
+      sim.prepare_constants((cmw_t)cmb);
+    }
+    return;
+  }
+  const int env = blockIdx.x + b.env0;
   if (reset_only && !b.needs_reset[env]) return;
   const float* fp = m.ft + (size_t)env * m.fstride;
   // the host passes the blocks to build as b.cm_env / b.cm_stride (the shared block: one workgroup, m.fenv = 0, stride 0)
@@ -4164,6 +4222,17 @@ __global__ __launch_bounds__(1024) void k_order(const unsigned* __restrict__ cos
   __syncthreads();
   for (int i = tid; i < B; i += nt) order[atomicAdd(&base[(int)((float)(hi - cost[i]) * scale)], 1)] = i;
 }
+// capacity tiers: the envs [env0, env0 + n) whose tier is 1, compacted (any order: results never depend on it) -- the list the wide configuration walks
+// `zero_next`: the two list lengths of the NEXT control step (the lengths are double-buffered by step parity, so that no launch of a step has to wait for a memset)
+__global__ __launch_bounds__(256) void k_tier_list(const int* __restrict__ tier, int* __restrict__ list, int* __restrict__ count, int* __restrict__ zero_next, int env0, int n) {
+  if (blockIdx.x == 0 && threadIdx.x < 2) zero_next[threadIdx.x] = 0;
+  for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < n; i += blockDim.x * gridDim.x)
+    if (tier[env0 + i] == 1) list[atomicAdd(count, 1)] = env0 + i;
+}
+extern "C" int rsim_launch_tier_list(const int* tier, int* list, int* count, int* zero_next, int env0, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(k_tier_list, dim3((n + 255) / 256 < 64 ? (n + 255) / 256 : 64), dim3(256), 0, stream, tier, list, count, zero_next, env0, n);
+  return (int)hipGetLastError();
+}
 // refill of the reset-bank ring: row i of `rows` -> slot (episode[i] % E) of env[i], and the slot's tag := episode[i]
 __global__ __launch_bounds__(64) void k_bank_scatter(float* bank, int* tag, const int* env, const int* episode, const float* rows, int n, int E, int W) {
   const int i = blockIdx.x;
@@ -4191,6 +4260,13 @@ extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStr
 // explicit instantiations + launchers (one set per configuration build) ----------------------------------------------------------
 template __global__ void k_step<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
 template __global__ void k_step_dbg<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
+#if RSIM_CFG == 3 || RSIM_CFG >= 5   // the configurations that serve as the upper capacity tier of narrower ones (rsim_api.cpp pick_wide)
+template __global__ void k_step_list<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
+extern "C" int RSIM_SYM(rsim_launch_step_list)(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL((k_step_list<RSIM_DIMS>), dim3(grid), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
+  return (int)hipGetLastError();
+}
+#endif
 extern "C" int RSIM_SYM(rsim_launch_step)(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, hipStream_t stream) {
   if (flags & RF_DEBUG) hipLaunchKernelGGL((k_step_dbg<RSIM_DIMS>), dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);
   else hipLaunchKernelGGL((k_step<RSIM_DIMS>), dim3(b->nenv ? b->nenv : b->B), dim3(64), 0, stream, *m, *b, actions, n_sub, flags);

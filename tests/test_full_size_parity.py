@@ -139,6 +139,38 @@ def summarize(name, res):
     return ok
 
 
+def continue_on_the_oracle(name, flat, cfg, env, pick, actions, dq, dv, min_over=1):
+    """ONE more control step of the whole batch through the fused path (capacity tiers included), and for the picked envs the same control step on the fp64
+    oracle from the kernel's own state: positions, velocities, warm start, actuator commands and the controller record (goal, initial joints, gripper
+    action) are copied over, so the comparison covers what the debug entry rsim_forward cannot -- a step in which the env needs MORE contacts / rows
+    than the native configuration holds (the oracle holds 64 contacts).  Asserts the bounds on the envs whose step did exceed the native capacity
+    (at least `min_over` of them) and prints all."""
+    from tests.util import make_oracle
+
+    b = env.batch
+    pre = {k: b.get(k) for k in ("qpos", "qvel", "qacc_warmstart", "ctrl", "cstate", "time")}
+    b.set("cap_need", 0)
+    env.step(actions)
+    q1, v1, need = b.get("qpos"), b.get("qvel"), b.get("cap_need")
+    over = 0
+    for e in pick:
+        e = int(e)
+        om, od, oc = make_oracle(flat, cfg)
+        od.qpos[:] = pre["qpos"][e]; od.qvel[:] = pre["qvel"][e]; od.qacc_warmstart[:] = pre["qacc_warmstart"][e]; od.ctrl[:] = pre["ctrl"][e]
+        od.forward(); oc.reset(od)
+        st = oc.state
+        st[:20] = pre["cstate"][e][:20]; st[20:24] = pre["cstate"][e][20:24]; st[24:28] = pre["cstate"][e][20:24]
+        oc.env_step(od, actions[e].cpu().numpy().astype(np.float64), env.n_sub)
+        eq, ev = float(np.abs(q1[e] - od.qpos).max()), float(np.abs(v1[e] - od.qvel).max())
+        beyond = need[e, 0] > b.maxcon or need[e, 1] > b.maxefc
+        print(f"   [{name}] env {e}: demand {need[e, 0]} contacts / {need[e, 1]} rows (native {b.maxcon} / {b.maxefc}){' -> stepped by the wide configuration' if beyond else ''}: one control step vs the oracle |dq| {eq:.1e} |dv| {ev:.1e}")
+        if beyond:
+            over += 1
+            assert eq < dq and ev < dv, (e, eq, ev)
+    assert over >= min_over, f"{name}: none of the picked envs exceeded the native capacity in this step"
+    assert int(b.get("overflow").sum()) == 0
+
+
 def spread(B, n=32):
     return np.unique(np.concatenate([[0, 1, 63, 64, B // 2 - 1, B // 2, B - 2, B - 1], np.linspace(0, B - 1, n).astype(int)]))
 
@@ -165,7 +197,7 @@ def test_lift_4096_late_episode_states_of_the_bench_workload():
                 worst["dist"] = max(worst["dist"], r["dist"]); worst["pos"] = max(worst["pos"], r["pos"])
                 worst["force"] = max(worst["force"], r["force"] / max(1.0, r["fscale"])); worst["qacc"] = max(worst["qacc"], r["qacc"] / max(1.0, r["ascale"]))
                 worst["cost_gap"] = max(worst["cost_gap"], r.get("g_cost_gap", 0.0))
-    assert int((env.batch.get("diverged") > 0).sum()) == 0
+    assert int((env.batch.get("diverged") > 0).sum()) == 0 and int(env.batch.get("overflow").sum()) == 0
     assert checked >= 72 and agree >= checked - 2, (checked, agree)          # contact / row structure: at most 2 knife-edge envs in ~90
     # contact geometry: depth to 5e-6 m everywhere; the POINT of an MPR contact is a barycentric blend of the portal's witness points, which on a
     # thin portal (finger hull flat on the table) slides along the contact face at rounding level: position to 1e-4 m (measured 2e-5; depth 1e-7)
@@ -182,8 +214,12 @@ def test_stack_4096_reached_states():
     ids = np.arange(B)
     env = stack.StackBatch(flat, cfg, ids, seed0=0, horizon=500, bank_episodes=2)
     tape = torch.tensor(lift.env_actions(ids, 50), device="cuda")
-    for t in range(50):
+    for t in range(49):
         env.step(tape[t])
+    # capacity tiers: no contact or constraint row is dropped at this size, although some envs need more than the native 64 rows (models/assets/base.xml:5: nconmax = 5000)
+    need = env.batch.get("cap_need")
+    assert int(env.batch.get("overflow").sum()) == 0 and (need[:, 1] > 64).sum() >= 1, (int(env.batch.get("overflow").sum()), int(need[:, 1].max()))
+    continue_on_the_oracle("Stack", flat, cfg, env, np.nonzero(need[:, 1] > 60)[0][:48], tape[49], dq=2e-4, dv=2e-2)      # the 50th control step
     res = compare_reached_states(flat, env.batch, spread(B, 32))
     ok = summarize("Stack step 50", res)
     assert int((env.batch.get("diverged") > 0).sum()) == 0
@@ -254,6 +290,10 @@ def test_pickplace_8192_with_dynamics_randomisation_reached_states():
     res = compare_reached_states(flat, b, spread(B, 32), ignore_pair=lambda g1, g2: g1 in grip and g2 in grip, dof_groups=groups)
     ok = summarize("PickPlace step 50", res)
     assert np.isfinite(b.get("qpos")).all() and np.isfinite(b.get("obs")).all()
+    # capacity tiers: the envs whose substeps asked for more than the native 32 contacts / 128 rows were stepped by the 64 x 256 configuration; nothing was dropped
+    need = b.get("cap_need")
+    print(f"   PickPlace demand: max {need[:, 0].max()} contacts / {need[:, 1].max()} rows; envs beyond the native capacity so far: {int(((need[:, 0] > 32) | (need[:, 1] > 128)).sum())}")
+    assert int(b.get("overflow").sum()) == 0
     assert len(res) >= 32 and len(ok) >= len(res) - 4
     good = [r for r in ok if r["geom_ok"]]
     assert len(good) >= 0.8 * len(ok), (len(good), len(ok))

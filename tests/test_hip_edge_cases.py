@@ -420,3 +420,88 @@ def test_alternating_half_batches_equal_the_whole_batch():
             if t + 1 < T:
                 alt.step_half(k, tape[t + 1][sl])
     assert sum(int(r[2].sum()) for r in ref) >= 2 * B      # every env restarted at least twice
+
+
+def _jammed_lift_state():
+    """Cube jammed between the closed finger pads, the hand and the table: 26 contacts / 94 constraint rows on the oracle (16 / 64 fit the Lift configuration)."""
+    return np.array([-3.310503761e-03, 9.595607741e-01, -4.905636198e-03, -2.424200342e+00, 9.327601525e-03, 3.760863028e+00, 8.123742675e-01, 5.613262166e-05,
+                     -5.613262166e-05, -1.113625582e-01, 4.773980294e-03, 8.007105292e-01, 9.982068450e-01, -2.683816807e-02, 1.416109385e-02, 5.159719647e-02])
+
+
+def test_capacity_tiers_step_an_env_beyond_the_native_capacity_without_dropping_a_contact(monkeypatch):
+    """MuJoCo never drops a contact (nconmax = 5000, models/assets/base.xml:5).  rsim_control_step hands an env whose substep needs more than the native
+    16 contacts / 64 rows to the wider configuration (32 / 128): in the step in which it happens nothing of the native pass is committed and the wide
+    configuration redoes the step from the same state (redo list); from the next step on the env is on the wide pass's list until its demand has
+    dropped.  Checked on the round-3 overflow state: RSIM_OVERFLOW stays 0, RSIM_CAP_NEED shows the demand, the states after three control steps
+    agree with the fp64 oracle (which holds 64 contacts) as closely as an ordinary contact state does -- and differ from what the truncating build
+    (RSIM_NO_TIERS) computes; an env that never leaves the native capacity is bitwise what it is without tiers."""
+    from tests.util import load_golden, make_hip, make_oracle
+    g, cfg, flat = load_golden("seed1_full")
+    q, q0 = _jammed_lift_state(), flat.qpos0.ravel()
+    om, od, oc = make_oracle(flat, cfg)
+    od.qpos[:] = q; od.qvel[:] = 0; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0; od.forward(); oc.reset(od)
+    assert od.ncon > 16 and od.nefc > 64
+    a = np.array([0.05, -0.02, -0.3, 0.0, 0.0, 0.0, 1.0])     # press down, fingers closing
+
+    def run(no_tiers):
+        if no_tiers:
+            monkeypatch.setenv("RSIM_NO_TIERS", "1")
+        else:
+            monkeypatch.delenv("RSIM_NO_TIERS", raising=False)
+        hm, hb = make_hip(flat, cfg, B=3)
+        hb.set("qpos", np.stack([q, q0, q])); hb.set("qvel", 0); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+        hb.forward(); hb.ctrl_reset()
+        hb.set("overflow", 0)          # forward() is a debug entry: native capacity, drops counted (test above); from here on only control steps
+        out = []
+        act = torch.tensor(np.repeat(a[None], 3, 0), dtype=torch.float32, device="cuda")
+        for t in range(3):
+            hb.control_step(act, 25)
+            out.append((hb.get("qpos").copy(), hb.get("qvel").copy()))
+        return hb, out
+
+    hb, tiered = run(False)
+    need, ov = hb.get("cap_need"), hb.get("overflow")
+    assert need[0, 0] > 16 and need[0, 1] > 64 and need[1, 0] <= 16 and need[1, 1] <= 64, need
+    assert ov.tolist() == [0, 0, 0] and int(hb.get("diverged").sum()) == 0
+    assert np.array_equal(tiered[-1][0][0], tiered[-1][0][2])                       # the same state twice: the same result, whatever the list order
+    hb2, trunc = run(True)
+    assert hb2.get("overflow")[0] > 0 and hb2.get("overflow")[1] == 0
+    assert np.array_equal(trunc[-1][0][1], tiered[-1][0][1]) and np.array_equal(trunc[-1][1][1], tiered[-1][1][1])   # the env inside the native capacity
+    errs = []
+    for t in range(3):
+        oc.env_step(od, a, 25)
+        errs.append((np.abs(tiered[t][0][0] - od.qpos).max(), np.abs(tiered[t][1][0] - od.qvel).max(), np.abs(trunc[t][0][0] - od.qpos).max()))
+    print("jammed Lift state, 3 control steps vs the fp64 oracle: tiered |dq| |dv|, truncating build |dq|:", [tuple(f"{x:.1e}" for x in e) for e in errs])
+    # measured: 3e-5 / 1e-4 after the first control step (the redo path), 1e-4 / 1e-2 after the second (the env on the wide pass's list); the jam then
+    # lets go (the cube squirts out from under the fingers) and the two trajectories separate like any chaotic contact event
+    assert errs[0][0] < 2e-4 and errs[0][1] < 2e-3 and errs[1][0] < 1e-3, errs
+    assert errs[0][2] > 50 * errs[0][0], errs          # dropping 10 of 26 contacts is a different problem: 1e-2 after one control step
+
+
+def test_capacity_tiers_with_per_env_model_parameters_and_stream_groups():
+    """The wide configuration reads an env's OWN constant block (per-episode cube sizes: built on demand right before the wide pass steps the env);
+    with stream groups every env block runs its own native pass, wide pass and redo pass on its own stream.  Same envs, same results."""
+    import json, os
+    from robosuite_amd import lift, mjcf
+    adir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "robosuite_amd", "assets")
+    flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim")); cfg = json.load(open(os.path.join(adir, "lift_panda.cfg.json")))
+    ids = np.array([7, 3, 7, 11, 3, 5])
+    q = _jammed_lift_state()
+    res = []
+    for G in (1, 3):
+        env = lift.LiftBatch(flat, cfg, ids, seed0=0, horizon=0)          # per-env cube sizes (env 0 and 2, 1 and 4 share theirs)
+        if G > 1:
+            env.batch.set_stream_groups(G)
+        b = env.batch
+        qq = b.get("qpos"); qq[[0, 2, 4]] = q
+        b.set("qpos", qq); b.set("qvel", 0); b.set("qacc_warmstart", 0); b.set("ctrl", 0); b.forward(); b.ctrl_reset()
+        b.set("overflow", 0)           # the debug entry forward() keeps the native capacity and counts its drops
+        act = torch.zeros(len(ids), 7, device="cuda"); act[:, 2] = -0.3; act[:, 6] = 1.0
+        for t in range(4):
+            env.step(act)
+        need = b.get("cap_need")
+        assert (need[[0, 2, 4], 1] > 64).all() and (need[[1, 3, 5], 1] <= 64).all() and int(b.get("overflow").sum()) == 0, need
+        res.append((b.get("qpos").copy(), b.get("qvel").copy()))
+        assert np.isfinite(res[-1][0]).all() and np.array_equal(res[-1][0][0], res[-1][0][2])
+        assert not np.array_equal(res[-1][0][0], res[-1][0][4])            # another cube size: another block was built and read
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
