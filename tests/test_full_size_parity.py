@@ -169,6 +169,7 @@ def continue_on_the_oracle(name, flat, cfg, env, pick, actions, dq, dv, min_over
             assert eq < dq and ev < dv, (e, eq, ev)
     assert over >= min_over, f"{name}: none of the picked envs exceeded the native capacity in this step"
     assert int(b.get("overflow").sum()) == 0
+    return over
 
 
 def spread(B, n=32):
@@ -190,7 +191,9 @@ def test_lift_4096_late_episode_states_of_the_bench_workload():
     for t in range(250):
         env.step(tape[t])
         if t in (199, 224, 249):
+            assert int(env.batch.get("overflow").sum()) == 0          # control steps never drop a contact (capacity tiers) ...
             res = compare_reached_states(flat, env.batch, spread(B, 24))
+            env.batch.set("overflow", 0)                                # ... rsim_forward in there is a debug entry: native capacity, drops counted
             ok = summarize(f"Lift step {t + 1}", res)
             checked += len(res); agree += len(ok)
             for r in ok:
@@ -213,19 +216,28 @@ def test_stack_4096_reached_states():
     B = 4096
     ids = np.arange(B)
     env = stack.StackBatch(flat, cfg, ids, seed0=0, horizon=500, bank_episodes=2)
-    tape = torch.tensor(lift.env_actions(ids, 50), device="cuda")
-    for t in range(49):
+    tape = torch.tensor(lift.env_actions(ids, 400), device="cuda")
+    for t in range(50):
         env.step(tape[t])
-    # capacity tiers: no contact or constraint row is dropped at this size, although some envs need more than the native 64 rows (models/assets/base.xml:5: nconmax = 5000)
-    need = env.batch.get("cap_need")
-    assert int(env.batch.get("overflow").sum()) == 0 and (need[:, 1] > 64).sum() >= 1, (int(env.batch.get("overflow").sum()), int(need[:, 1].max()))
-    continue_on_the_oracle("Stack", flat, cfg, env, np.nonzero(need[:, 1] > 60)[0][:48], tape[49], dq=2e-4, dv=2e-2)      # the 50th control step
     res = compare_reached_states(flat, env.batch, spread(B, 32))
     ok = summarize("Stack step 50", res)
     assert int((env.batch.get("diverged") > 0).sum()) == 0
     assert len(res) >= 32 and len(ok) >= len(res) - 1
     assert max(r["dist"] for r in ok) < 5e-6 and max(r["pos"] for r in ok) < 5e-6
     assert max(r["force"] / max(1.0, r["fscale"]) for r in ok) < 2e-3 and max(r["qacc"] / max(1.0, r["ascale"]) for r in ok) < 2e-3
+    # capacity tiers: later in the episodes (the hand pressing a cube onto the other or the table) some envs need more than the native 64 rows; none is ever
+    # truncated (models/assets/base.xml:5: nconmax = 5000), and a control step of such an env agrees with the oracle's
+    env.batch.set("overflow", 0)           # rsim_forward above is a debug entry: native capacity
+    over, t, seen = 0, 50, 0
+    while over == 0 and t < 399:
+        env.batch.set("cap_need", 0)
+        env.step(tape[t]); t += 1
+        need = env.batch.get("cap_need")     # demand of this one control step
+        seen = max(seen, int(need[:, 1].max()))
+        if (need[:, 1] > 58).any():           # envs at or beyond the native capacity right now: their next control step on the oracle as well
+            over = continue_on_the_oracle("Stack", flat, cfg, env, np.nonzero(need[:, 1] > 58)[0][:16], tape[t], dq=2e-4, dv=2e-2, min_over=0); t += 1
+    print(f"   Stack: largest single-step demand seen {seen} rows up to control step {t}")
+    assert over >= 1 and int(env.batch.get("overflow").sum()) == 0
 
 
 def test_baxter_joint_velocity_2048_reached_states_with_contacts():
@@ -287,13 +299,13 @@ def test_pickplace_8192_with_dynamics_randomisation_reached_states():
     grip = {i for i in range(flat.ngeom) if (flat.names["geom"][i] or "").startswith("gripper0_")}
     arm, fing = np.asarray(cfg["dof_idx"]), np.asarray(cfg["grip_dof_idx"])
     groups = {"arm": arm, "gripper": fing, "objects": np.setdiff1d(np.arange(flat.nv), np.concatenate([arm, fing]))}
-    res = compare_reached_states(flat, b, spread(B, 32), ignore_pair=lambda g1, g2: g1 in grip and g2 in grip, dof_groups=groups)
-    ok = summarize("PickPlace step 50", res)
-    assert np.isfinite(b.get("qpos")).all() and np.isfinite(b.get("obs")).all()
     # capacity tiers: the envs whose substeps asked for more than the native 32 contacts / 128 rows were stepped by the 64 x 256 configuration; nothing was dropped
     need = b.get("cap_need")
     print(f"   PickPlace demand: max {need[:, 0].max()} contacts / {need[:, 1].max()} rows; envs beyond the native capacity so far: {int(((need[:, 0] > 32) | (need[:, 1] > 128)).sum())}")
-    assert int(b.get("overflow").sum()) == 0
+    assert int(b.get("overflow").sum()) == 0          # (before rsim_forward below: a debug entry, native capacity, drops counted)
+    res = compare_reached_states(flat, b, spread(B, 32), ignore_pair=lambda g1, g2: g1 in grip and g2 in grip, dof_groups=groups)
+    ok = summarize("PickPlace step 50", res)
+    assert np.isfinite(b.get("qpos")).all() and np.isfinite(b.get("obs")).all()
     assert len(res) >= 32 and len(ok) >= len(res) - 4
     good = [r for r in ok if r["geom_ok"]]
     assert len(good) >= 0.8 * len(ok), (len(good), len(ok))

@@ -197,3 +197,18 @@ def test_narrow_phase_against_elementary_geometry():
         # sqrt(2 tol / r) ~ 6e-3 rad (measured 4e-3 on the two spheres; the fp64 oracle happens to start on the centre line and is exact) and the
         # point by r times that; depths are good to the tolerance itself
         check_narrow_phase(hb.contacts(0), expected, 3e-6, 1e-3 if mpr else 5e-6, 2e-2 if mpr else 1e-5, name)
+
+
+def test_mesh_narrow_phase_against_elementary_geometry(tmp_path):
+    """The kernel's plane-hull and MPR-on-hull paths (hull vertices in registers, support scans as wave arg-max, coordinates relative to the first geom) on the
+    mesh cases of tests/test_oracle.py: a hull vertex in the plane and in a box face, a hull flat on a box, two hulls edge on edge, a 64-gon prism, a geodesic
+    sphere of 642 vertices (scanned from global memory: more than 256), a sphere primitive on a hull.  One contact per convex pair; depth, normal and -- where
+    the geometry determines it -- the point, in fp32."""
+    from tests.test_oracle import check_mesh_contacts, check_mesh_patch, mesh_narrow_phase_cases, mesh_scene
+    for name, bodies, expected, tol in mesh_narrow_phase_cases(tmp_path):
+        flat, hb = _batch(mesh_scene(str(tmp_path), bodies))
+        hb.forward()
+        cs = hb.contacts(0)
+        # fp32: depths to 3e-6 m (MPR's own tolerance is 1e-6), points of vertex / edge contacts to 1e-4 m, normals to 2e-3
+        check_mesh_contacts(cs, expected, (max(tol[0], 3e-6), None if tol[1] is None else max(tol[1], 2e-4), max(tol[2], 2e-3)), name)
+        check_mesh_patch(cs, bodies, name, tol=2e-5)

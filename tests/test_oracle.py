@@ -6,6 +6,8 @@ on top of the mujoco-shaped shim.  Everything under ep/eR/.../tau is output of t
 Python, so those tests PIN the controller restatement.  The physics half is pinned only by identities
 (no MuJoCo binary exists here: SURVEY.md section 8c, "parity unpinned").
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -789,3 +791,109 @@ def test_narrow_phase_against_elementary_geometry():
         od.qpos[:] = om.field("qpos0"); od.forward()
         mpr = "sphere" in name and "plane" not in name or "capsule" in name        # iterative (portal refinement to 1e-6); the other three are direct
         check_narrow_phase(od.contacts(), expected, 1e-6 if mpr else 1e-9, 1e-4 if mpr else 1e-8, 1e-5 if mpr else 1e-8, name)
+
+
+# ---- mesh hulls in the narrow phase (every Panda / IIWA / Robotiq link, every PickPlace object; the slowest and most-used path): tessellated primitives whose
+# contacts with planes, boxes and each other are elementary geometry.  Convention stated here as a test: ONE contact per convex pair -- the deepest point along
+# the normal for plane-hull, MPR's penetration along the origin ray otherwise (MuJoCo's libccd / MPR default without multiccd [3P]); a flat-on-flat contact has
+# its depth and normal determined, its POINT only up to the contact patch.
+def _mesh_assets(tmp):
+    """STL files of a box (8 vertices), a 64-gon prism and a geodesic sphere (642 vertices), centred and axis-aligned; (half extents, radius / half height, radius)."""
+    from scipy.spatial import ConvexHull
+    from tests.test_mjcf import _write_stl
+
+    def hull_faces(v):
+        fs = ConvexHull(v).simplices.copy()
+        for k, fc in enumerate(fs):
+            if np.dot(np.cross(v[fc[1]] - v[fc[0]], v[fc[2]] - v[fc[0]]), v[fc[0]]) < 0:
+                fs[k] = fc[::-1]
+        return fs
+    h = np.array([0.04, 0.025, 0.03])
+    box = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=float) * h
+    a = 2 * np.pi * np.arange(64) / 64
+    ring = np.stack([0.03 * np.cos(a), 0.03 * np.sin(a)], 1)
+    prism = np.vstack([np.c_[ring, np.full(64, -0.05)], np.c_[ring, np.full(64, 0.05)]])
+    # geodesic sphere: icosahedron subdivided three times (642 vertices on the sphere of radius 0.045)
+    t = (1 + 5 ** 0.5) / 2
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    v = np.array(v, dtype=float); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    for _ in range(3):
+        fs = ConvexHull(v).simplices
+        mid = {tuple(sorted(e)) for f in fs for e in ((f[0], f[1]), (f[1], f[2]), (f[0], f[2]))}
+        m = np.array([(v[i] + v[j]) / 2 for i, j in mid]); m /= np.linalg.norm(m, axis=1, keepdims=True)
+        v = np.vstack([v, m])
+    ball = 0.045 * v
+    for name, vv in (("mbox", box), ("mprism", prism), ("mball", ball)):
+        vv32 = vv.astype(np.float32).astype(np.float64)
+        _write_stl(os.path.join(tmp, name + ".stl"), vv32, hull_faces(vv32))
+    return h, (0.03, 0.05), 0.045, len(ball)
+
+
+def mesh_scene(tmp, bodies):
+    b = "".join('<body name="b%d" pos="%s" %s><freejoint/><geom name="g%d" %s/></body>' % (i, p, ('quat="%s"' % q) if q else "", i, g) for i, (p, q, g) in enumerate(bodies))
+    return (f'<mujoco><compiler angle="radian" meshdir="{tmp}"/><option timestep="0.002"/><asset><mesh name="mbox" file="mbox.stl"/><mesh name="mprism" file="mprism.stl"/>'
+            f'<mesh name="mball" file="mball.stl"/></asset><worldbody><geom name="floor" type="plane" size="2 2 0.1"/>{b}</worldbody></mujoco>')
+
+
+def mesh_narrow_phase_cases(tmp):
+    """(name, scene, expected (dist, pos or None, normal), (tol dist, tol pos, tol normal) for an exact-arithmetic implementation of the contract)."""
+    h, (pr, ph), br, nball = _mesh_assets(str(tmp))
+    z = np.array([0.0, 0.0, 1.0])
+    qx45 = f"{np.cos(np.pi / 8)} {np.sin(np.pi / 8)} 0 0"       # 45 degrees about x: an edge of the box points down / up
+    qy45 = f"{np.cos(np.pi / 8)} 0 {np.sin(np.pi / 8)} 0"
+    # box mesh tilted about x and y so that ONE vertex is lowest: R = Rx(0.3) Ry(-0.4); the lowest vertex is the one minimising (R v).z
+    cx, sx, cy, sy = np.cos(0.3), np.sin(0.3), np.cos(-0.4), np.sin(-0.4)
+    R = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    from robosuite_amd.mjcf import mat2quat
+    qt = " ".join(f"{x:.12f}" for x in mat2quat(R))
+    verts = np.array([[a, b, c] for a in (-1, 1) for b in (-1, 1) for c in (-1, 1)], dtype=float) * h
+    low = (R @ verts.T).T
+    low = low[np.argmin(low[:, 2])]
+    sag = br * (1 - np.cos(0.5 * np.arccos(1 - 2.0 / nball) ))   # a facet of a geodesic sphere lies at most ~r (1 - cos(half the vertex spacing)) inside the sphere
+    return [
+        ("mesh box flat on the plane, 1 mm deep: one contact at a lowest vertex", [("0.1 0.2 %.6f" % (h[2] - 0.001), None, 'type="mesh" mesh="mbox"')],
+         [(-0.001, None, z)], (1e-7, None, 1e-9)),
+        ("tilted mesh box, one vertex 2 mm into the plane", [("0 0 %.9f" % (-low[2] - 0.002), qt, 'type="mesh" mesh="mbox"')],
+         [(-0.002, [low[0], low[1], -0.001], z)], (1e-7, 1e-7, 1e-9)),
+        ("the same vertex 2 mm into the top face of a box", [("0 0 1", None, 'type="box" size="0.2 0.2 0.05"'), ("0 0 %.9f" % (1.05 - low[2] - 0.002), qt, 'type="mesh" mesh="mbox"')],
+         [(-0.002, [low[0], low[1], 1.049], z)], (2e-6, 2e-4, 1e-4)),
+        ("mesh box flat on a box, 1 mm deep: depth and normal of the primitive pair, the point anywhere in the patch", [("0 0 1", None, 'type="box" size="0.2 0.2 0.05"'), ("0.01 -0.02 %.6f" % (1.05 + h[2] - 0.001), None, 'type="mesh" mesh="mbox"')],
+         [(-0.001, None, z)], (2e-6, None, 1e-4)),
+        ("two mesh boxes, edge on edge (crossed at 90 degrees), 1 mm deep", [("0 0 1", qx45, 'type="mesh" mesh="mbox"'), ("0 0 %.9f" % (1 + (h[1] + h[2]) / 2 ** 0.5 + (h[0] + h[2]) / 2 ** 0.5 - 0.001), qy45, 'type="mesh" mesh="mbox"')],
+         [(-0.001, [(h[0] - h[2]) / 2 ** 0.5, (h[1] - h[2]) / 2 ** 0.5, 1 + (h[1] + h[2]) / 2 ** 0.5 - 0.0005], z)], (2e-6, 2e-4, 1e-4)),   # where the upper box's lowest edge (along y, at x = (hx - hz) / sqrt 2) crosses the lower box's highest (along x)
+        ("64-gon prism mesh standing on a box, 1 mm deep", [("0 0 1", None, 'type="box" size="0.2 0.2 0.05"'), ("0.03 0.01 %.6f" % (1.05 + ph - 0.001), None, 'type="mesh" mesh="mprism"')],
+         [(-0.001, None, z)], (2e-6, None, 1e-4)),
+        ("geodesic sphere mesh on a box: the sphere's answer to the accuracy of its tessellation", [("0 0 1", None, 'type="box" size="0.2 0.2 0.05"'), ("0.02 -0.01 %.6f" % (1.05 + br - 0.002), None, 'type="mesh" mesh="mball"')],
+         [(-0.002, [0.02, -0.01, 1.049], z)], (sag + 2e-6, 0.006, 0.08)),
+        ("sphere primitive on the top face of a mesh box (sphere is geom1)", [("0 0 1", None, 'type="mesh" mesh="mbox"'), ("0.02 -0.01 %.6f" % (1 + h[2] + 0.04 - 0.001), None, 'type="sphere" size="0.04"')],
+         [(-0.001, [0.02, -0.01, 1 + h[2] - 0.0005], -z)], (2e-6, 2e-4, 1e-3)),
+    ]
+
+
+def check_mesh_contacts(contacts, expected, tol, name, slack=1.0):
+    assert len(contacts) == len(expected) == 1, (name, len(contacts))          # one contact per convex pair
+    c, (dist, pos, nrm), (td, tp, tn) = contacts[0], expected[0], tol
+    assert abs(c["dist"] - dist) < td * slack, (name, c["dist"], dist)
+    assert np.abs(np.asarray(c["frame"]).reshape(3, 3)[0] - np.asarray(nrm)).max() < max(tn * slack, 1e-7), (name, c["frame"], nrm)
+    if pos is not None:
+        assert np.abs(np.asarray(c["pos"]) - np.asarray(pos)).max() < tp * slack, (name, c["pos"], pos)
+
+
+def test_mesh_narrow_phase_against_elementary_geometry(tmp_path):
+    """Hull vertex on the plane / on a box face, hull flat on a box, hull edge on hull edge, a 64-gon prism and a geodesic sphere as meshes, a sphere primitive on a
+    hull: depth, normal and (where the geometry determines it) contact point of the oracle's plane-hull and MPR paths."""
+    for name, bodies, expected, tol in mesh_narrow_phase_cases(tmp_path):
+        flat = mjcf.compile_mjcf(mesh_scene(str(tmp_path), bodies))
+        om, od, _ = make_oracle(flat)
+        od.qpos[:] = om.field("qpos0"); od.forward()
+        cs = od.contacts()
+        check_mesh_contacts(cs, expected, tol, name)
+        check_mesh_patch(cs, bodies, name)
+
+
+def check_mesh_patch(cs, bodies, name, tol=1e-5):
+    """The point of a flat-on-flat contact: halfway between the two surfaces, somewhere inside the footprint of the upper body."""
+    if "flat on" in name or "standing" in name:
+        p = np.asarray(cs[0]["pos"])
+        centre = np.array([float(x) for x in bodies[-1][0].split()])
+        assert abs(p[2] - (-0.0005 if len(bodies) == 1 else 1.0495)) < tol and np.abs(p[:2] - centre[:2]).max() < 0.0401, (name, p)
