@@ -218,6 +218,12 @@ int rsim_model_int(const rsim_model* m, const char* name);
  * 3 = 64 x 64 with tendon rows (PickPlace/IIWA+Robotiq140); -1 = none (rsim_batch_create would refuse it).  limits, if not NULL, receives 10 ints: {nbody, njnt, nv, ncgeom, nsite, ncon, nefc, npair, articulated trees} maxima
  * and whether the configuration carries tendon / equality rows (the 32 x 16 one does not: such models go to the next larger one). */
 int rsim_model_config(const rsim_model* m, int* limits);
+/* mj_name2id / mj_id2name as robosuite's MjModel wrapper uses them (binding_utils.py:296-360: body_name2id, joint_name2id, geom_name2id, site_name2id,
+ * actuator_name2id, camera_name2id, sensor_name2id, ... and the id2name inverses).  kind = "body" | "joint" | "geom" | "site" | "actuator" | "camera" | "light" |
+ * "sensor" | "tendon" | "equality" | "mesh"; the names ride in the model blob (entries "names:<kind>").  rsim_name2id: id, or -1 if there is no such name;
+ * rsim_id2name: the name (owned by the model, valid until rsim_model_free), or NULL for an unnamed object / a bad id. */
+int rsim_name2id(const rsim_model* m, const char* kind, const char* name);
+const char* rsim_id2name(const rsim_model* m, const char* kind, int id);
 /* controller_factory (controllers/parts/controller_factory.py:73-159) for the built-in arm part (rsim_ctrl_type) + GRIP pair */
 int rsim_model_set_controller(rsim_model* m, const rsim_ctrl_desc* desc);
 /* observation / reward epilogue of rsim_control_step (must be set before rsim_batch_create) */
@@ -329,6 +335,18 @@ void* rsim_stream(rsim_batch* b);
  * Valid after forward/step1. */
 int rsim_jac_site(rsim_batch* b, int env, int site, double* jacp, double* jacr);
 int rsim_jac_body(rsim_batch* b, int env, int body, double* jacp, double* jacr);
+
+/* mj_fullM (controllers/parts/controller.py:226-227): dense joint-space inertia of one env, HOST float64 [nv, nv].  Valid after forward / step1 (after a fused
+ * control step it is brought up to the current state first, like every derived quantity). */
+int rsim_full_M(rsim_batch* b, int env, double* M);
+/* sim.data.contact[:ncon] of one env (binding_utils.py:1008-1035; what utils/sim_utils.py:8-40 check_contact and manipulation_env.py:331-376 _check_grasp walk):
+ * fills out[0 .. n), returns n = min(ncon, max_out), -1 on error.  geom1 / geom2 are MODEL geom ids; frame = rows {normal (geom1 -> geom2), tangent 1, tangent 2};
+ * efc_address = first constraint row of the contact (-1: within the margin but not active); normal_force = constraint force along the normal of the last solve. */
+typedef struct rsim_contact {
+  double dist, pos[3], frame[9], friction[5], normal_force;
+  int32_t geom1, geom2, dim, efc_address;
+} rsim_contact;
+int rsim_contacts(rsim_batch* b, int env, int max_out, rsim_contact* out);
 
 /* DynamicsModder / per-episode model edits (utils/mjmod.py:1705-1964, lift.py:311-318): overwrite a float model array
  * (blob field name, e.g. "geom_size", "body_mass", "dof_damping") for envs [env0, env0+nenv). `values` is HOST float64

@@ -47,6 +47,11 @@ class CtrlDesc(C.Structure):
                 ("base_site2", C.c_int32)]
 
 
+class RsimContact(C.Structure):     # include/rsim.h rsim_contact
+    _fields_ = [("dist", C.c_double), ("pos", C.c_double * 3), ("frame", C.c_double * 9), ("friction", C.c_double * 5), ("normal_force", C.c_double),
+                ("geom1", C.c_int32), ("geom2", C.c_int32), ("dim", C.c_int32), ("efc_address", C.c_int32)]
+
+
 # arm part-controller types with an in-kernel implementation (include/rsim.h enum rsim_ctrl_type; names = the reference's config "type" strings)
 CTRL_TYPES = {"OSC_POSE": 0, "OSC_POSITION": 1, "JOINT_POSITION": 2, "JOINT_TORQUE": 3, "JOINT_VELOCITY": 4}
 
@@ -204,6 +209,10 @@ def lib():
         L.rsim_set_stream_groups.argtypes = [vp, C.c_int]
         L.rsim_group_stream.restype = vp; L.rsim_group_stream.argtypes = [vp, C.c_int]
         L.rsim_profile_env.argtypes = [vp, C.c_int]
+        L.rsim_name2id.argtypes = [vp, C.c_char_p, C.c_char_p]
+        L.rsim_id2name.argtypes = [vp, C.c_char_p, C.c_int]; L.rsim_id2name.restype = C.c_char_p
+        L.rsim_full_M.argtypes = [vp, C.c_int, vp]
+        L.rsim_contacts.argtypes = [vp, C.c_int, C.c_int, vp]
         _LIB = L
     return _LIB
 
@@ -228,6 +237,15 @@ class HipModel:
 
     def int(self, name):
         return self._L.rsim_model_int(self.ptr, name.encode())
+
+    def name2id(self, kind: str, name: str) -> int:
+        """mj_name2id through the C-ABI (rsim_name2id): -1 if there is no such name."""
+        return self._L.rsim_name2id(self.ptr, kind.encode(), name.encode())
+
+    def id2name(self, kind: str, i: int):
+        """mj_id2name through the C-ABI (rsim_id2name): None for an unnamed object or a bad id."""
+        r = self._L.rsim_id2name(self.ptr, kind.encode(), int(i))
+        return None if r is None else r.decode()
 
     def kernel_config(self):
         """(config id, limits dict) of the compiled kernel configuration that serves this model; id -1 = unsupported size."""
@@ -547,6 +565,22 @@ class HipBatch:
             v = v[None]
         v = v.reshape(v.shape[0], -1)
         _chk(self._L.rsim_model_param_set(self.ptr, field.encode(), int(env0), v.shape[0], v.ctypes.data, v.shape[1]))
+
+    def full_M(self, env=0):
+        """mj_fullM of one env through the C-ABI (rsim_full_M): float64 [nv, nv]."""
+        nv = self.model.flat.nv
+        M = np.empty((nv, nv), dtype=np.float64)
+        _chk(self._L.rsim_full_M(self.ptr, int(env), M.ctypes.data))
+        return M
+
+    def contacts_abi(self, env=0):
+        """sim.data.contact[:ncon] of one env through the C-ABI (rsim_contacts), as dicts."""
+        buf = (RsimContact * self.maxcon)()
+        n = self._L.rsim_contacts(self.ptr, int(env), self.maxcon, C.cast(buf, C.c_void_p))
+        if n < 0:
+            raise RsimError(self._L.rsim_last_error().decode())
+        return [dict(dist=c.dist, pos=np.array(c.pos), frame=np.array(c.frame).reshape(3, 3), geom1=c.geom1, geom2=c.geom2, dim=c.dim, efc_address=c.efc_address,
+                     normal_force=c.normal_force, friction=np.array(c.friction)) for c in buf[:n]]
 
     def contacts(self, env=0):
         n = int(self.get("ncon")[env])

@@ -125,6 +125,7 @@ struct rsim_model {
   rsim_task_desc task;
   int has_task;
   float meaninertia;
+  std::map<std::string, std::vector<std::string>> names;   // kind -> names in id order (blob entries "names:<kind>"); empty string = unnamed
   const int* I(const char* n) const { auto it = f.find(n); return it == f.end() ? nullptr : (const int*)it->second.ptr; }
   const double* D(const char* n) const { auto it = f.find(n); return it == f.end() ? nullptr : (const double*)it->second.ptr; }
   size_t count(const char* n) const { auto it = f.find(n); return it == f.end() ? 0 : it->second.count; }
@@ -227,6 +228,13 @@ extern "C" int rsim_model_create(const void* blob, size_t len, rsim_model** out)
     size_t bytes = (size_t)cnt * (dtype == 0 ? 4 : 8);
     if (off + bytes > len) { delete m; return fail("rsim_model_create: field %s out of range", name); }
     m->f[name] = Entry{(int)dtype, cnt, p + off};
+  }
+  for (auto& kv : m->f) {
+    if (kv.first.compare(0, 6, "names:") != 0 || kv.second.dtype != 0) continue;
+    std::vector<std::string>& out = m->names[kv.first.substr(6)];
+    std::string cur;
+    const int* c = (const int*)kv.second.ptr;
+    for (size_t i = 0; i < kv.second.count; i++) { if (c[i] == 0) { out.push_back(cur); cur.clear(); } else cur.push_back((char)c[i]); }
   }
   auto geti = [&](const char* k) { const int* v = m->I(k); return v ? v[0] : 0; };
   m->nq = geti("nq"); m->nv = geti("nv"); m->nu = geti("nu"); m->nbody = geti("nbody"); m->njnt = geti("njnt");
@@ -753,6 +761,20 @@ static int pick_wide(const rsim_model* m, int cfg, const int* lim, int* lim_out)
   return -1;
 }
 extern "C" int rsim_model_config(const rsim_model* m, int* limits) { return pick_config(m, limits); }
+
+// mj_name2id / mj_id2name (binding_utils.py:296-360: body_name2id, joint_name2id, geom_name2id, site_name2id, actuator_name2id, ... and their inverses)
+extern "C" int rsim_name2id(const rsim_model* m, const char* kind, const char* name) {
+  if (!kind || !name || !*name) return -1;
+  auto it = m->names.find(kind);
+  if (it == m->names.end()) { fail("rsim_name2id: the model blob carries no names of kind '%s'", kind); return -1; }
+  for (size_t i = 0; i < it->second.size(); i++) if (it->second[i] == name) return (int)i;
+  return -1;
+}
+extern "C" const char* rsim_id2name(const rsim_model* m, const char* kind, int id) {
+  auto it = m->names.find(kind ? kind : "");
+  if (it == m->names.end() || id < 0 || id >= (int)it->second.size() || it->second[id].empty()) return nullptr;
+  return it->second[id].c_str();
+}
 
 extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, rsim_batch** out) {
   if (B < 1) return fail("rsim_batch_create: B < 1");
@@ -1515,6 +1537,44 @@ extern "C" int rsim_set_array(rsim_batch* b, int field, const void* src, size_t 
   if (field == RSIM_QPOS && b->db.mprc) HIPCHK(hipMemset(b->db.mprc, 0, (size_t)b->B * b->m->npair * 12 * sizeof(float)));
   b->gen++;
   return 0;
+}
+
+// mj_fullM (controllers/parts/controller.py:226-227: `mujoco.mj_fullM(model, mass_matrix, data.qM)`): the dense joint-space inertia of one env
+extern "C" int rsim_full_M(rsim_batch* b, int env, double* M) {
+  if (join_groups(b)) return 1;
+  if (env < 0 || env >= b->B || !M) return fail("rsim_full_M: bad env %d / null output", env);
+  if (refresh_derived(b, RSIM_QM)) return 1;
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  const int nv = b->m->nv;
+  std::vector<float> h((size_t)nv * nv);
+  HIPCHK(hipMemcpy(h.data(), b->db.qM + (size_t)env * nv * nv, h.size() * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < h.size(); i++) M[i] = h[i];
+  return 0;
+}
+// sim.data.contact[:ncon] of one env (binding_utils.py:1008-1035; utils/sim_utils.py:8-40 check_contact, manipulation_env.py:331-376): returns the number of
+// contacts written (<= max_out), -1 on error
+extern "C" int rsim_contacts(rsim_batch* b, int env, int max_out, rsim_contact* out) {
+  if (join_groups(b)) return -1;
+  if (env < 0 || env >= b->B || (max_out > 0 && !out)) { fail("rsim_contacts: bad env %d / null output", env); return -1; }
+  if (refresh_derived(b, RSIM_CONTACT)) return -1;
+  if (hipSetDevice(b->device) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) { fail("rsim_contacts: device error"); return -1; }
+  int n = 0;
+  if (hipMemcpy(&n, b->db.ncon + env, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { fail("rsim_contacts: copy failed"); return -1; }
+  if (n > max_out) n = max_out;
+  std::vector<float> h((size_t)(n > 0 ? n : 1) * RSIM_CON_REC);
+  if (n > 0 && hipMemcpy(h.data(), b->db.contact + (size_t)env * b->lim[5] * RSIM_CON_REC, (size_t)n * RSIM_CON_REC * 4, hipMemcpyDeviceToHost) != hipSuccess) { fail("rsim_contacts: copy failed"); return -1; }
+  for (int c = 0; c < n; c++) {
+    const float* r = h.data() + (size_t)c * RSIM_CON_REC;
+    rsim_contact& o = out[c];
+    o.dist = r[0];
+    for (int k = 0; k < 3; k++) o.pos[k] = r[1 + k];
+    for (int k = 0; k < 9; k++) o.frame[k] = r[4 + k];
+    o.geom1 = (int)r[13]; o.geom2 = (int)r[14]; o.dim = (int)r[15]; o.efc_address = (int)r[16];
+    o.normal_force = r[17];
+    for (int k = 0; k < 5; k++) o.friction[k] = r[18 + k];
+  }
+  return n;
 }
 
 static int refresh_cache(rsim_batch* b, int env) {

@@ -1298,8 +1298,14 @@ def to_blob(m: FlatModel) -> bytes:
     count u32, offset u64} and 8-byte aligned payloads.  See include/rsim.h."""
     entries = []
     payload = bytearray()
-    header_len = 16 + 48 * len(m.arrays)
-    for name, a in m.arrays.items():
+    arrays = dict(m.arrays)
+    # name tables (mjModel.names + name_<kind>adr, binding_utils.py:296-360): per kind one int32 entry "names:<kind>" = the UTF-8 bytes of the names, each
+    # terminated by 0 (an unnamed object is the empty string), in id order -- what rsim_name2id / rsim_id2name of the C-ABI read
+    for kind, names in (getattr(m, "names", None) or {}).items():
+        raw = b"".join(((n or "").encode("utf-8") + b"\0") for n in names)
+        arrays["names:" + kind] = np.frombuffer(raw, dtype=np.uint8).astype(np.int32)
+    header_len = 16 + 48 * len(arrays)
+    for name, a in arrays.items():
         if a.dtype == np.int32:
             dt = 0
         elif a.dtype == np.float64:
@@ -1327,7 +1333,11 @@ def from_blob(blob: bytes) -> FlatModel:
         name, dt, cnt, off = struct.unpack_from("<32sIIQ", blob, 16 + 48 * i)
         name = name.rstrip(b"\0").decode()
         dtype = np.int32 if dt == 0 else np.float64
-        m.arrays[name] = np.frombuffer(blob, dtype=dtype, count=cnt, offset=off).copy()
+        a = np.frombuffer(blob, dtype=dtype, count=cnt, offset=off).copy()
+        if name.startswith("names:"):
+            m.names[name[6:]] = [(x.decode("utf-8") or None) for x in bytes(a.astype(np.uint8)).split(b"\0")[:-1]]
+            continue
+        m.arrays[name] = a
     _reshape(m)
     return m
 

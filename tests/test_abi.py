@@ -90,3 +90,21 @@ def test_models_with_tendons_are_ingested_but_flagged():
     assert m.int("ntendon") == 2 and m.int("neq") == 1
     cid, lim = m.kernel_config()
     assert cid == 1 and lim["tendons"] == 1
+
+
+def test_names_ride_in_the_blob_and_resolve_through_the_c_abi():
+    """rsim_name2id / rsim_id2name (binding_utils.py:296-360): every named object of every kind round-trips; unnamed objects and unknown names are -1 / NULL;
+    a blob without name tables (the fixtures' .rsim files written before round 4 carry theirs in a side file) says so instead of guessing."""
+    _, cfg, flat = load_golden("seed1_full")
+    m = backend.HipModel(flat)
+    for kind, names in flat.names.items():
+        for i, n in enumerate(names):
+            if n:
+                assert m.name2id(kind, n) == names.index(n) and m.id2name(kind, i) == n, (kind, n)
+            else:
+                assert m.id2name(kind, i) is None
+    assert m.name2id("body", "no_such_body") == -1 and m.id2name("geom", 10 ** 6) is None and m.name2id("site", "") == -1
+    assert m.name2id("site", "gripper0_right_grip_site") == cfg["eef_site"]
+    bare = mjcf.FlatModel(); bare.arrays = dict(flat.arrays); bare.names = {}
+    m2 = backend.HipModel(mjcf.to_blob(bare))
+    assert m2.name2id("body", "cube_main") == -1 and b"no names" in backend.lib().rsim_last_error()

@@ -505,3 +505,30 @@ def test_capacity_tiers_with_per_env_model_parameters_and_stream_groups():
         assert np.isfinite(res[-1][0]).all() and np.array_equal(res[-1][0][0], res[-1][0][2])
         assert not np.array_equal(res[-1][0][0], res[-1][0][4])            # another cube size: another block was built and read
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_full_M_and_contacts_exports_of_the_c_abi():
+    """rsim_full_M (mj_fullM, controllers/parts/controller.py:226-227) and rsim_contacts (sim.data.contact[:ncon]) against the array fields they are views of,
+    and against the oracle; after a FUSED control step both describe the current state (the derived arrays are refreshed on read)."""
+    from tests.util import load_golden, make_hip, make_oracle
+    g, cfg, flat = load_golden("seed1_full")
+    nq = flat.nq
+    hm, hb = make_hip(flat, cfg, B=2)
+    s = g["states"][30]
+    hb.set("qpos", s[1:1 + nq][None].repeat(2, 0)); hb.set("qvel", s[1 + nq:][None].repeat(2, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    om, od, _ = make_oracle(flat, cfg)
+    od.qpos[:] = s[1:1 + nq]; od.qvel[:] = s[1 + nq:]; od.forward()
+    M = hb.full_M(1)
+    assert M.shape == (flat.nv, flat.nv) and np.array_equal(M.astype(np.float32), hb.get("qM")[1]) and np.abs(M - od.full_M()).max() < 1e-5 * np.abs(M).max()
+    ca, cb = hb.contacts_abi(0), hb.contacts(0)
+    assert len(ca) == len(cb) == od.ncon > 0
+    for a, b, o in zip(ca, cb, od.contacts()):
+        assert (a["geom1"], a["geom2"], a["dim"], a["efc_address"]) == (b["geom1"], b["geom2"], b["dim"], b["efc_address"]) == (o["geom1"], o["geom2"], o["dim"], o["efc_address"])
+        assert a["dist"] == b["dist"] and np.array_equal(a["frame"], b["frame"]) and abs(a["dist"] - o["dist"]) < 1e-6
+    hb.control_step(torch.zeros(2, 7, device="cuda"), 25)
+    q1 = hb.get("qpos")[0].astype(np.float64)
+    od.qpos[:] = q1; od.qvel[:] = hb.get("qvel")[0]; od.forward()
+    assert np.abs(hb.full_M(0) - od.full_M()).max() < 1e-5 * np.abs(od.full_M()).max()      # of the state AFTER the control step
+    with pytest.raises(Exception):
+        hb.full_M(5)
