@@ -369,6 +369,12 @@ typedef struct rsim_dr_desc {
   float position_size, quaternion_size, inertia_ratio, mass_ratio;        /* 0.0015, 0.003, 0.02, 0.02 */
   float friction_ratio, solref_ratio, solimp_ratio;                       /* 0.1, 0.1, 0.1 */
   float frictionloss_size, damping_size, armature_size;                   /* 0.05, 0.01, 0.01 */
+  float stiffness_ratio;                                                  /* 0.1 (domain_randomization_wrapper.py:73,77).  Accepted for completeness: DynamicsModder.mod_stiffness
+                                                                           * skips joints whose stiffness is 0 (mjmod.py:1907-1909) and rsim_batch_create refuses models
+                                                                           * with joint springs, so there is never a joint for it to act on */
+  uint64_t body_mask, geom_mask, joint_mask;                              /* `body_names` / `geom_names` / `joint_names` of the wrapper (:55,64,71) as bit sets: bit b = body id b,
+                                                                           * bit g = colliding-geom index g (rsim_model_cgeom), bit j = joint id j; 0 = every body / geom / joint
+                                                                           * (the wrapper's None).  Elements outside a subset keep the values they have */
 } rsim_dr_desc;
 int rsim_dr_save_defaults(rsim_batch* b);
 int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uint64_t seed, uint64_t step);

@@ -82,12 +82,32 @@ class TaskDesc(C.Structure):
 
 class DrDesc(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("density_ratio", "viscosity_ratio", "position_size", "quaternion_size", "inertia_ratio", "mass_ratio",
-                                         "friction_ratio", "solref_ratio", "solimp_ratio", "frictionloss_size", "damping_size", "armature_size")]
+                                         "friction_ratio", "solref_ratio", "solimp_ratio", "frictionloss_size", "damping_size", "armature_size", "stiffness_ratio")] + \
+               [(n, C.c_uint64) for n in ("body_mask", "geom_mask", "joint_mask")]
 
 
-# DEFAULT_DYNAMICS_ARGS of the reference (wrappers/domain_randomization_wrapper.py:47-81)
+# DEFAULT_DYNAMICS_ARGS of the reference (wrappers/domain_randomization_wrapper.py:47-81); masks 0 = all bodies / geoms / joints (the wrapper's `*_names=None`)
 DEFAULT_DYNAMICS_ARGS = dict(density_ratio=0.1, viscosity_ratio=0.1, position_size=0.0015, quaternion_size=0.003, inertia_ratio=0.02, mass_ratio=0.02,
-                             friction_ratio=0.1, solref_ratio=0.1, solimp_ratio=0.1, frictionloss_size=0.05, damping_size=0.01, armature_size=0.01)
+                             friction_ratio=0.1, solref_ratio=0.1, solimp_ratio=0.1, frictionloss_size=0.05, damping_size=0.01, armature_size=0.01,
+                             stiffness_ratio=0.1, body_mask=0, geom_mask=0, joint_mask=0)
+
+
+def dr_masks(model, body_names=None, geom_names=None, joint_names=None) -> dict:
+    """`body_names` / `geom_names` / `joint_names` of the reference wrapper as the bit sets of rsim_dr_desc (geoms by colliding-geom index; a geom that never
+    collides has no dynamics parameter that matters and is left out).  None = all, as there."""
+    flat = model.flat
+    out = {}
+    if body_names is not None:
+        out["body_mask"] = sum(1 << flat.name2id("body", n) for n in body_names)
+    if joint_names is not None:
+        out["joint_mask"] = sum(1 << flat.name2id("joint", n) for n in joint_names)
+    if geom_names is not None:
+        cg = [model._L.rsim_model_cgeom(model.ptr, flat.name2id("geom", n)) for n in geom_names]
+        out["geom_mask"] = sum(1 << c for c in cg if c >= 0)
+    for k, v in out.items():
+        if v == 0:
+            raise ValueError(f"{k}: the subset selects nothing (an empty set cannot be told from `all`; set the magnitudes to 0 instead)")
+    return out
 
 
 def two_arm_osc_desc(cfg: dict) -> CtrlDesc:

@@ -856,6 +856,10 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.newton_ls = getenv("RSIM_NEWTON_LS") ? (float)atof(getenv("RSIM_NEWTON_LS")) : RSIM_NEWTON_LS;
   dm.newton_ng = getenv("RSIM_NEWTON_NG") ? (float)atof(getenv("RSIM_NEWTON_NG")) : RSIM_NEWTON_NG;
   if (m->multijoint) { int r = fail("rsim_batch_create: bodies with more than one joint are not supported by the fused kernel"); delete b; return r; }
+  if (m->D("jnt_stiffness")) for (int j = 0; j < m->njnt; j++) if (m->D("jnt_stiffness")[j] != 0.0) {
+    int r = fail("rsim_batch_create: joint %d has a spring (stiffness %g): passive joint springs are not implemented in the fused kernel (tendon springs are)", j, m->D("jnt_stiffness")[j]);
+    delete b; return r;
+  }
 
   if (m->maxcondim > 4) { int r = fail("rsim_batch_create: condim %d contacts are not supported by the compiled kernel configuration (max 4)", m->maxcondim); delete b; return r; }
   for (int j = 0; j < m->njnt; j++) if (m->I("jnt_type")[j] == 1) { int r = fail("rsim_batch_create: ball joints are not supported by the fused kernel"); delete b; return r; }
@@ -1426,7 +1430,10 @@ extern "C" int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uin
   if (!b->d_ft_base) return fail("rsim_randomize_dynamics: call rsim_dr_save_defaults first");
   HIPCHK(hipSetDevice(b->device));
   DDr dd = {d->density_ratio, d->viscosity_ratio, d->position_size, d->quaternion_size, d->inertia_ratio, d->mass_ratio, d->friction_ratio, d->solref_ratio,
-            d->solimp_ratio, d->frictionloss_size, d->damping_size, d->armature_size};
+            d->solimp_ratio, d->frictionloss_size, d->damping_size, d->armature_size,
+            d->body_mask ? d->body_mask : ~0ull, d->geom_mask ? d->geom_mask : ~0ull, d->joint_mask ? d->joint_mask : ~0ull};
+  // stiffness_ratio: DynamicsModder.mod_stiffness leaves joints without a spring alone (mjmod.py:1907-1909), and models with joint springs are
+  // refused by rsim_batch_create (no passive joint spring in the kernel): the draw has nothing to act on
   const unsigned long long fenv_before = b->dm.fenv;
   b->dm.fenv |= (1ull << FO_opt) | (1ull << FO_body_pos) | (1ull << FO_body_quat) | (1ull << FO_body_inertia) | (1ull << FO_body_mass) | (1ull << FO_cg_friction) |
                 (1ull << FO_cg_solref) | (1ull << FO_cg_solimp) | (1ull << FO_dof_frictionloss) | (1ull << FO_dof_damping) | (1ull << FO_dof_armature);

@@ -227,7 +227,8 @@ enum { RP_LOAD, RP_KIN, RP_COM, RP_CRB, RP_BROAD, RP_NARROW, RP_MAKEC, RP_VEL, R
        RP_X0, RP_X1, RP_X2, RP_X3, RP_X4, RP_X5, RP_X6, RP_X7, RP_X8, RP_X9, /* ad-hoc sub-phase cycle slots */ RP_COUNT };
 
 // device form of rsim_dr_desc
-struct DDr { float density, viscosity, pos, quat, inertia, mass, friction, solref, solimp, frictionloss, damping, armature; };
+struct DDr { float density, viscosity, pos, quat, inertia, mass, friction, solref, solimp, frictionloss, damping, armature;
+             unsigned long long body_mask, geom_mask, joint_mask; };   // bit set = this body / colliding geom / joint is randomised (rsim_dr_desc: 0 = all)
 
 // flags for the step kernel
 enum {

@@ -4168,6 +4168,7 @@ __global__ __launch_bounds__(64) void k_randomize(DModel m, DBatch b, DDr d, uns
   if (lane == 0) { ratio(m.fo[FO_opt] + 4, d.density, 0.f, INF, 1); ratio(m.fo[FO_opt] + 5, d.viscosity, 0.f, INF, 2); }
   item = 16;
   for (int bd = 1 + lane; bd < m.nbody; bd += 64) {
+    if (!((d.body_mask >> bd) & 1ull)) continue;       // body_names subset (domain_randomization_wrapper.py:55)
     const unsigned id = item + 16u * bd;
     for (int k = 0; k < 3; k++) size_(m.fo[FO_body_pos] + 3 * bd + k, d.pos, -INF, id + k);
     if (d.quat > 0.f) {
@@ -4181,6 +4182,7 @@ __global__ __launch_bounds__(64) void k_randomize(DModel m, DBatch b, DDr d, uns
   }
   item += 16u * 64;
   for (int g = lane; g < m.ncg; g += 64) {
+    if (!((d.geom_mask >> g) & 1ull)) continue;        // geom_names subset (:64)
     const unsigned id = item + 16u * g;
     for (int k = 0; k < 3; k++) ratio(m.fo[FO_cg_friction] + 3 * g + k, d.friction, 0.f, INF, id + k);
     for (int k = 0; k < 2; k++) ratio(m.fo[FO_cg_solref] + 2 * g + k, d.solref, 0.f, 1.0f, id + 3 + k);
@@ -4190,6 +4192,7 @@ __global__ __launch_bounds__(64) void k_randomize(DModel m, DBatch b, DDr d, uns
   for (int i = lane; i < m.nv; i += 64) {
     const int j = it[m.io[IO_dof_jntid] + i];
     if (it[m.io[IO_jnt_type] + j] == JNT_FREE) continue;   // mjmod.py:1927: free joints keep their values
+    if (!((d.joint_mask >> j) & 1ull)) continue;           // joint_names subset (:71)
     const unsigned id = item + 4u * i;
     size_(m.fo[FO_dof_frictionloss] + i, d.frictionloss, 0.f, id);
     size_(m.fo[FO_dof_damping] + i, d.damping, 0.f, id + 1);
