@@ -35,16 +35,28 @@ def default_reset_spec():
                              objects=[dict(name="cube", horizontal_radius=None, bottom_z=None, top_z=None, qposadr=9, init_quat=None)]))
 
 
+def prepared(spec):
+    """The spec's lists as numpy arrays, built once per spec object (the reset-ring upkeep draws thousands of episodes per second of rollout: no per-draw
+    list -> array conversions)."""
+    p = spec.get("_np")
+    if p is None:
+        p = dict(arm=np.array(spec["arm_init_qpos"], dtype=np.float64))
+        if "cube" in spec:
+            p["size_min"], p["size_max"] = np.array(spec["cube"]["size_min"], dtype=np.float64), np.array(spec["cube"]["size_max"], dtype=np.float64)
+        spec["_np"] = p
+    return p
+
+
 def arm_noise(rng: np.random.Generator, spec) -> np.ndarray:
     """Robot.reset's joint noise (robots/robot.py:247-259).  The draw is made even at magnitude 0 (`initialization_noise=None`), as there."""
-    n, noise = len(spec["arm_init_qpos"]), spec["noise"]
+    arm, noise = prepared(spec)["arm"], spec["noise"]
     if noise["type"] == "gaussian":
-        z = rng.standard_normal(n)
+        z = rng.standard_normal(len(arm))
     elif noise["type"] == "uniform":
-        z = rng.uniform(-1.0, 1.0, n)
+        z = rng.uniform(-1.0, 1.0, len(arm))
     else:
         raise ValueError("Error: Invalid noise type specified. Options are 'gaussian' or 'uniform'.")
-    return np.array(spec["arm_init_qpos"], dtype=np.float64) + z * noise["magnitude"]
+    return arm + z * noise["magnitude"]
 
 
 def sample_quat(rng: np.random.Generator, sampler) -> np.ndarray:
@@ -91,7 +103,7 @@ def sample_objects(rng: np.random.Generator, sampler, geometry):
             ok = True
             if sampler["ensure_valid_placement"]:
                 for (px, py, pz, pr, ptop) in placed:
-                    if np.linalg.norm((x - px, y - py)) <= pr + radius and z - pz <= ptop - bottom:
+                    if float(np.linalg.norm((x - px, y - py))) <= pr + radius and z - pz <= ptop - bottom:
                         ok = False
                         break
             if ok:
@@ -111,12 +123,50 @@ def reset_draws(rng: np.random.Generator, spec=None, aux=None):
     joint noise, then the placement sampler (x U, y U, rotation).  `spec` = cfg["reset"] (factory.reset_cfg); None = the Panda defaults.
     `aux`: the generator a sampler with `own_rng` draws from (a user's placement_initializer built without rng= owns one, placement_samplers.py:44-47)."""
     spec = default_reset_spec() if spec is None else spec
-    c = spec["cube"]
-    size = rng.uniform(np.array(c["size_min"], dtype=np.float64), np.array(c["size_max"], dtype=np.float64))  # BoxObject(size_min, size_max): one U per axis
+    p = prepared(spec)
+    size = rng.uniform(p["size_min"], p["size_max"])  # BoxObject(size_min, size_max): one U per axis
     arm = arm_noise(rng, spec)
     srng = aux if (spec["sampler"].get("own_rng") and aux is not None) else rng
-    (pos, quat), = sample_objects(srng, spec["sampler"], [(float(np.linalg.norm(size[:2])), -float(size[2]), float(size[2]))])   # BoxObject: horizontal_radius, bottom / top offsets
+    sx, sy, sz = float(size[0]), float(size[1]), float(size[2])
+    (pos, quat), = sample_objects(srng, spec["sampler"], [((sx * sx + sy * sy) ** 0.5, -sz, sz)])   # BoxObject: horizontal_radius (= |size[:2]|), bottom / top offsets
     return dict(size=size, arm=arm, pos=pos, quat=quat)
+
+
+def reset_draws_fast(rng: np.random.Generator, spec):
+    """reset_draws for the usual shape of the Lift reset (one object, the env's own generator, no init_quat), with the generator's scalar / vector
+    calls written out: low + (high - low) * rng.random() is what Generator.uniform computes (numpy/random/_generator.pyx: loc + scale * next_double),
+    without its argument checking -- bit for bit the same draws (tests/test_lift_host.py), a third of the time.  The reset ring draws ~8 episodes per
+    control step of a 4096-env rollout, on the host, beside the control steps."""
+    p = prepared(spec)
+    lo, hi = p["size_min"], p["size_max"]
+    size = lo + (hi - lo) * rng.random(3)
+    noise, sm = spec["noise"], spec["sampler"]
+    n = len(p["arm"])
+    z = rng.standard_normal(n) if noise["type"] == "gaussian" else (-1.0 + 2.0 * rng.random(n))
+    arm = p["arm"] + z * noise["magnitude"]
+    sx, sy, sz = float(size[0]), float(size[1]), float(size[2])
+    ref, (xlo, xhi), (ylo, yhi) = sm["reference_pos"], sm["x_range"], sm["y_range"]
+    if sm["ensure_object_boundary_in_range"]:
+        r = (sx * sx + sy * sy) ** 0.5
+        xlo, xhi, ylo, yhi = xlo + r, xhi - r, ylo + r, yhi - r
+    x = xlo + (xhi - xlo) * rng.random() + ref[0]
+    y = ylo + (yhi - ylo) * rng.random() + ref[1]
+    z0 = sm["z_offset"] + ref[2] - (-sz)
+    rot = sm["rotation"]
+    if rot is None:
+        ang = 0 + (2 * np.pi - 0) * rng.random()
+    elif isinstance(rot, (list, tuple)):
+        ang = min(rot) + (max(rot) - min(rot)) * rng.random()
+    else:
+        ang = rot
+    quat = np.zeros(4)
+    quat[0], quat[{"x": 1, "y": 2, "z": 3}[sm["rotation_axis"]]] = np.cos(ang / 2), np.sin(ang / 2)
+    return dict(size=size, arm=arm, pos=np.array([x, y, z0]), quat=quat)
+
+
+def fast_path_ok(spec) -> bool:
+    sm = spec["sampler"]
+    return len(sm["objects"]) == 1 and not sm.get("own_rng") and sm["objects"][0].get("init_quat") is None and spec["noise"]["type"] in ("gaussian", "uniform")
 
 
 def initial_qpos(draw, spec=None) -> np.ndarray:
@@ -130,6 +180,29 @@ def initial_qpos(draw, spec=None) -> np.ndarray:
     q[a:a + 3] = draw["pos"]
     q[a + 3:a + 7] = draw["quat"]
     return q
+
+
+def cube_model_entries(flat, sizes: np.ndarray, density: float = CUBE_DENSITY):
+    """The compiled-model ENTRIES that depend on the cube half-sizes, for n envs at once: {field: (flat element indices, values [n, len(indices)])} -- the
+    closed forms of cube_model_rows without tiling the whole arrays (the reset-ring upkeep needs these few numbers per episode, nothing else)."""
+    sizes = np.asarray(sizes, dtype=np.float64).reshape(-1, 3)
+    cb, g0, gv = flat.name2id("body", "cube_main"), flat.name2id("geom", "cube_g0"), flat.name2id("geom", "cube_g0_vis")
+    d0 = int(flat.jnt_dofadr[int(flat.body_jntadr[cb])])
+    sx, sy, sz = sizes[:, 0], sizes[:, 1], sizes[:, 2]
+    mass = density * 8.0 * sx * sy * sz
+    inertia = np.stack([mass / 3.0 * (sy**2 + sz**2), mass / 3.0 * (sx**2 + sz**2), mass / 3.0 * (sx**2 + sy**2)], axis=1)
+    rb = np.linalg.norm(sizes, axis=1)
+    minv, iinv = 1.0 / mass, np.mean(1.0 / inertia, axis=1)
+    sub_world, old_mass = float(np.asarray(flat.body_subtreemass).ravel()[0]), float(np.asarray(flat.body_mass).ravel()[cb])
+    return {
+        "geom_size": (np.array([3 * g0, 3 * g0 + 1, 3 * g0 + 2, 3 * gv, 3 * gv + 1, 3 * gv + 2]), np.concatenate([sizes, sizes], axis=1)),
+        "geom_rbound": (np.array([g0, gv]), np.stack([rb, rb], axis=1)),
+        "body_mass": (np.array([cb]), mass[:, None]),
+        "body_inertia": (np.array([3 * cb, 3 * cb + 1, 3 * cb + 2]), inertia),
+        "body_subtreemass": (np.array([0, cb]), np.stack([sub_world + (mass - old_mass), mass], axis=1)),
+        "body_invweight0": (np.array([2 * cb, 2 * cb + 1]), np.stack([minv, iinv], axis=1)),
+        "dof_invweight0": (np.arange(d0, d0 + 6), np.stack([minv, minv, minv, iinv, iinv, iinv], axis=1)),
+    }
 
 
 def cube_model_rows(flat, sizes: np.ndarray, density: float = CUBE_DENSITY):
@@ -277,7 +350,7 @@ class LiftBatch(ResetBankMixin):
         self.model.set_task(lift_task(flat, cfg))
         self.spec = cfg.get("reset") or default_reset_spec()     # cfg["reset"]: the reference env's own reset configuration (factory.reset_cfg)
         self.n_sub = int(cfg.get("env", {}).get("n_sub", 25))    # control_timestep / model_timestep (base.py:212-218)
-        self._draw_fn = functools.partial(reset_draws, spec=self.spec)
+        self._draw_fn = functools.partial(reset_draws_fast if fast_path_ok(self.spec) else reset_draws, spec=self.spec)
         self._draw_aux = bool(self.spec["sampler"].get("own_rng"))
         self.batch = HipBatch(self.model, self.B, device, per_env_params=per_env_cube)
         self.per_env_cube = per_env_cube
@@ -316,9 +389,13 @@ class LiftBatch(ResetBankMixin):
 
     def _bank_rows(self, idx, episode):
         sizes, qpos = self._episode(idx, episode)
-        rows = cube_model_rows(self.flat, sizes, float(self.spec["cube"]["density"])) if self._bank_slots() else {}
-        patch = np.stack([rows[k][:, e] for k, e, _ in self._bank_slots()], axis=1) if self._bank_slots() else np.zeros((len(idx), 0))
-        return qpos, patch
+        slots = self._bank_slots()
+        if not slots:
+            return qpos, np.zeros((len(idx), 0))
+        ent = cube_model_entries(self.flat, sizes, float(self.spec["cube"]["density"]))
+        if not hasattr(self, "_slot_src"):      # slot -> (field, column of that field's entry values)
+            self._slot_src = [(k, int(np.nonzero(ent[k][0] == e)[0][0])) for k, e, _ in slots]
+        return qpos, np.stack([ent[k][1][:, c] for k, c in self._slot_src], axis=1)
 
     def reset(self, block: int = 0):
         sizes, qpos = self._episode(np.arange(self.B), block)

@@ -85,8 +85,9 @@ def reset_draws(rng: np.random.Generator, placement: dict, choose: bool = False)
     for o in placement["objects"]:
         r, bot = o["horizontal_radius"], o["bottom_z"]
         for _ in range(5000):
-            x = rng.uniform(-xh + r, xh - r) + bx
-            y = rng.uniform(-yh + r, yh - r) + by
+            # low + (high - low) * rng.random() is Generator.uniform(low, high) without its argument checks: the same double, a third of the time
+            x = (-xh + r) + ((xh - r) - (-xh + r)) * rng.random() + bx
+            y = (-yh + r) + ((yh - r) - (-yh + r)) * rng.random() + by
             z = placement["z_offset"] + bz - bot
             ok = True
             for (px, py, pz, pr, ptop) in placed:
@@ -94,14 +95,14 @@ def reset_draws(rng: np.random.Generator, placement: dict, choose: bool = False)
                     ok = False
                     break
             if ok:
-                yaw = rng.uniform(0.0, 2.0 * np.pi)
+                yaw = 0.0 + (2.0 * np.pi - 0.0) * rng.random()
                 placed.append((x, y, z, r, o["top_z"]))
                 out.append((np.array([x, y, z]), yaw))
                 break
         else:
             raise RuntimeError("Cannot place all objects")
     for _ in placement["objects"]:        # the four visual twins: x and y over [c, c]
-        rng.uniform(0.0, 0.0); rng.uniform(0.0, 0.0)
+        rng.random(); rng.random()
     return dict(arm=arm, objects=out, pick=int(rng.integers(0, len(placement["objects"]))) if choose else -1)
 
 

@@ -33,3 +33,24 @@ def test_action_streams_are_keyed_by_global_env_id():
     b = lift.env_actions([7], 4)
     assert a.shape == (4, 3, 7) and np.array_equal(a[:, 2], b[:, 0])
     assert np.abs(a).max() <= 1.0
+
+
+def test_fast_draw_path_is_bit_equal_to_the_general_one():
+    """reset_draws_fast (what the reset ring's upkeep thread runs: Generator.uniform written out as low + (high - low) * random()) against reset_draws, for the
+    default spec, uniform joint noise with a bounded rotation and the object kept inside the range, and a fixed rotation about another axis."""
+    import copy
+    from robosuite_amd import factory
+    _, cfg = factory.load_shipped("lift_panda")
+    specs = [cfg["reset"]]
+    s2 = copy.deepcopy(cfg["reset"]); s2.pop("_np", None); s2["noise"] = dict(type="uniform", magnitude=0.05)
+    s2["sampler"].update(rotation=[0.1, 0.4], ensure_object_boundary_in_range=True, x_range=[-0.1, 0.1], y_range=[-0.1, 0.2]); specs.append(s2)
+    s3 = copy.deepcopy(cfg["reset"]); s3.pop("_np", None); s3["sampler"].update(rotation=0.3, rotation_axis="y"); specs.append(s3)
+    for spec in specs:
+        assert lift.fast_path_ok(spec)
+        for seed in range(60):
+            r1, r2 = np.random.default_rng(seed), np.random.default_rng(seed)
+            for _ in range(3):
+                a, b = lift.reset_draws(r1, spec), lift.reset_draws_fast(r2, spec)
+                assert all(np.array_equal(a[k], b[k]) for k in a)
+    own = copy.deepcopy(cfg["reset"]); own["sampler"]["own_rng"] = True
+    assert not lift.fast_path_ok(own)
