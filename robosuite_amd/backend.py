@@ -415,7 +415,8 @@ class HipBatch:
 
     def randomize_dynamics(self, seed: int, step: int, **args):
         """Re-draw the dynamics parameters of every env around the saved defaults (reference DynamicsModder.randomize)."""
-        d = DrDesc(**{**DEFAULT_DYNAMICS_ARGS, **args})
+        a = {**DEFAULT_DYNAMICS_ARGS, **args}
+        d = DrDesc(**{k: (int(v) if k.endswith("_mask") else float(v)) for k, v in a.items()})
         _chk(self._L.rsim_randomize_dynamics(self.ptr, C.byref(d), int(seed), int(step)))
 
     def param_get(self, field, env0=0, nenv=None):

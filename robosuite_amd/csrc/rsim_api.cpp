@@ -854,6 +854,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.bp_reach = getenv("RSIM_BP_REACH") ? (float)atof(getenv("RSIM_BP_REACH")) : RSIM_BP_REACH;
   dm.newton_wide = getenv("RSIM_NEWTON_WIDE") ? atoi(getenv("RSIM_NEWTON_WIDE")) : 1;
   dm.newton_ls = getenv("RSIM_NEWTON_LS") ? (float)atof(getenv("RSIM_NEWTON_LS")) : RSIM_NEWTON_LS;
+  dm.newton_exact = getenv("RSIM_NEWTON_EXACT") ? atoi(getenv("RSIM_NEWTON_EXACT")) : 1;
   dm.newton_ng = getenv("RSIM_NEWTON_NG") ? (float)atof(getenv("RSIM_NEWTON_NG")) : RSIM_NEWTON_NG;
   if (m->multijoint) { int r = fail("rsim_batch_create: bodies with more than one joint are not supported by the fused kernel"); delete b; return r; }
   if (m->D("jnt_stiffness")) for (int j = 0; j < m->njnt; j++) if (m->D("jnt_stiffness")[j] != 0.0) {

@@ -138,8 +138,13 @@ def test_device_randomisation_equals_its_host_mirror():
                 want = o[k].astype(np.float64).reshape(got.shape)
                 if extra and step == 4:      # subsets: untouched elements keep the PREVIOUS draw (step 0), as in the reference where they are simply not visited
                     prev = dr.randomize_host(flat, cg, ARGS, 21, 0, e)[k].astype(np.float64).reshape(got.shape)
-                    mask = np.abs(want - np.asarray(flat.arrays[k], dtype=np.float64).reshape(got.shape)) > 0
-                    want = np.where(mask, want, prev)
+                    if k.startswith("body_"):
+                        sel = np.array([(extra["body_mask"] >> b) & 1 for b in range(flat.nbody)], dtype=bool)
+                    elif k.startswith("geom_"):
+                        sel = np.zeros(flat.ngeom, dtype=bool); sel[[g for c, g in enumerate(cg) if (extra["geom_mask"] >> c) & 1]] = True
+                    else:
+                        sel = np.array([(extra["joint_mask"] >> int(flat.dof_jntid[i])) & 1 for i in range(flat.nv)], dtype=bool)
+                    want = np.where(sel.reshape((-1,) + (1,) * (got.ndim - 1)), want, prev)
                 assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), (step, e, k, np.abs(got - want).max())
             opt = hb.param_get("opt", e, 1)[0]
             assert abs(opt[4] - float(o["density"][0])) < 1e-5 * max(1.0, abs(opt[4])) and abs(opt[5] - float(o["viscosity"][0])) < 1e-9 + 1e-5 * abs(opt[5])
