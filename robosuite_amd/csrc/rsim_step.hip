@@ -2325,7 +2325,7 @@ struct Sim {
         convex_convex(g1, g2, margin, cp, wd, wh, mprc ? mprc + MPRC * p : nullptr);
         pf.mark(RP_MPR); pf.count(RP_N_MPR, 1);
       }
-      if (pf.pairs && lane == 0) { atomicAdd(pf.pairs + p, 1ull); atomicAdd(pf.pairs + RSIM_PAIR_MAX + p, (unsigned long long)(pf.c_support - sup0)); }
+      if (pf.pairs && lane == 0 && pf.acc) { atomicAdd(pf.pairs + p, 1ull); atomicAdd(pf.pairs + RSIM_PAIR_MAX + p, (unsigned long long)(pf.c_support - sup0)); }
       SYNC();
     }
   }

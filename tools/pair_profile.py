@@ -10,7 +10,9 @@ flat = mjcf.load_model(os.path.join(adir, "lift_panda.rsim")); cfg = json.load(o
 tape = torch.tensor(lift.env_actions(np.arange(B), nskip + 1), device="cuda")
 env = lift.LiftBatch(flat, cfg, np.arange(B), seed0=0)
 for t in range(nskip): env.step(tape[t])
-env.batch.sync(); env.batch.profile(True); env.batch.profile_env(0); env.step(tape[nskip]); env.batch.sync()
+only = int(sys.argv[2]) if len(sys.argv) > 2 else -1      # restrict the pair counters to one env (-1: all envs)
+env.batch.sync(); env.batch.profile(True); env.batch.profile_env(only); env.step(tape[nskip]); env.batch.sync()
+if only >= 0: B = 1
 vis, sup = env.batch.pairlog()
 g1, g2 = flat.arrays["pair_geom1"], flat.arrays["pair_geom2"]
 names = flat.names["geom"]
