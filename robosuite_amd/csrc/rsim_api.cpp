@@ -854,6 +854,9 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.bp_reach = getenv("RSIM_BP_REACH") ? (float)atof(getenv("RSIM_BP_REACH")) : RSIM_BP_REACH;
   dm.newton_wide = getenv("RSIM_NEWTON_WIDE") ? atoi(getenv("RSIM_NEWTON_WIDE")) : 1;
   dm.newton_ls = getenv("RSIM_NEWTON_LS") ? (float)atof(getenv("RSIM_NEWTON_LS")) : RSIM_NEWTON_LS;
+  // refinement passes with an fp64 gradient: on for the models of the 64 x 48 class and beyond (PickPlace: mesh objects and Robotiq links of 1e-5 .. 4e-3 kg m^2
+  // under condim-4 contacts at the refsafe limit); Stack-class models reach 2e-5 of the oracle without it and would pay 13 % for it
+  dm.newton_refine = getenv("RSIM_NEWTON_REFINE") ? atoi(getenv("RSIM_NEWTON_REFINE")) : (b->cfg >= 3 ? 1 : 0);
   dm.newton_exact = getenv("RSIM_NEWTON_EXACT") ? atoi(getenv("RSIM_NEWTON_EXACT")) : 1;
   dm.newton_ng = getenv("RSIM_NEWTON_NG") ? (float)atof(getenv("RSIM_NEWTON_NG")) : RSIM_NEWTON_NG;
   if (m->multijoint) { int r = fail("rsim_batch_create: bodies with more than one joint are not supported by the fused kernel"); delete b; return r; }

@@ -135,6 +135,7 @@ struct DModel {
   float tolerance, meaninertia;
   float bp_reach;      // broadphase active pair list: bounding-sphere gap (m) up to which a pair is listed; 0: every pair every substep
   float newton_ns, newton_na, newton_ng, newton_ls;
+  int newton_refine;   // wide configurations: refinement passes of the solution with an fp64 gradient (solve_newton), 0 = none
   int newton_exact;    // 1: a Newton step that leaves every row's state where it was (and no row on the cone) ends the solve -- the objective is quadratic on that piece, the step is its minimiser
   int newton_wide;     // wide (nv > 16) configurations: 0 = neither fp32 rule, 1 = step rule and line-search exit as in the one-tile ones, 2 = line-search exit only   // fp32 stopping rules of the Newton solver (solve_newton): relative / absolute step floor, gradient noise factor
   const int* it;

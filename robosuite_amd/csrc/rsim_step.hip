@@ -128,6 +128,11 @@ __device__ __forceinline__ float wave_sum(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 #endif
 }
+__device__ __forceinline__ double wave_sum_f64(double x) {   // butterfly over the 64 lanes (the refinement pass of the wide Newton solver: a handful of calls per substep)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
 // DPP steps that leave lanes without a source unchanged (reductions whose identity is not 0)
 template <int CTRL>
 __device__ __forceinline__ int dpp_keep_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false); }
@@ -3180,6 +3185,20 @@ struct Sim {
     }
     return acc;
   }
+  // Residual J_r . (x + xl) - aref of a constraint row with the products summed in fp64 (the refinement pass of the wide Newton solver).  J's entries and both
+  // parts of the acceleration are floats, so every product is exact in fp64.
+  __device__ __forceinline__ double lds_row_res64(const float* p, float x, float xl, float aref) const {
+    double acc = -(double)aref;
+    float lo = 0.f;
+    for (int k0 = 0; k0 < m.nv; k0 += 16) {
+      float a[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) a[u] = p[k0 + u];
+#pragma unroll
+      for (int u = 0; u < 16; u++) { acc = fma((double)a[u], (double)bcast(x, k0 + u), acc); lo = fmaf(a[u], bcast(xl, k0 + u), lo); }
+    }
+    return acc + (double)lo;
+  }
   // (M x)_i for the dof of this lane
   __device__ __forceinline__ float mass_dot(const float (&Mr)[FAST ? NV16 : 1], float x) const {
     if constexpr (FAST) return dot_rows<NV16>(Mr, x);
@@ -3467,6 +3486,7 @@ struct Sim {
     SUBMARK(RP_X1);
     float a = cost_ws < cost_sm ? a_ws : a_sm;
     int iter = 0;
+    bool factored = false;    // sm.H holds a Cholesky factor of a Hessian of this solve (wide configurations)
     bool have_eval = false;   // the rows are already evaluated at `a` (cost_pre)
     float cost_pre = 0.f;
     for (;;) {
@@ -3557,6 +3577,7 @@ struct Sim {
         SYNC();
         SUBMARK_H(RP_X7);
         bchol_inplace<NVP>(sm.H, sm.invdiag, nv, lane);
+        factored = true;
         SUBMARK_H(RP_X8);
         sk = bchol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -gk : 0.f, nv, lane);
         if (lane >= nv) sk = 0.f;
@@ -3678,6 +3699,113 @@ struct Sim {
 #pragma unroll
         for (int s = 0; s < NSLOT; s++) if SLOT_ON(s) moved |= rw[s].valid && (state[s] != state0[s] || state0[s] == ST_CONE);
         if (!__ballot(moved)) break;
+      }
+    }
+    if constexpr (!FAST) {
+      // ---- refinement of the solution with an fp64 gradient (wide configurations).  What fp32 cannot resolve on these models: a direction of 1e-5 ..
+      // 4e-3 kg m^2 (an object's or a Robotiq link's own rotation) beside contact rows of D ~ 1e6.  The cost is flat there to fp32 (half H_soft da^2 of
+      // 1e-3 in a cost of 1e3), so the iteration above stops a hundred rad/s^2 short -- optimal to 1e-6 in its own objective, which is all round 3 could
+      // assert per env.  The GRADIENT tells the directions apart if its parts are kept apart: residuals J a - aref, the forces they give and J^T f
+      // summed in fp64 from the float data (every product exact), the acceleration carried as a pair of floats.  Classic iterative refinement then:
+      // da = -H^-1 g with the fp32 factor already in LDS (it resolves the soft directions to a few per cent, so every pass gains a factor of ~20),
+      // no new factorisation, states as the last evaluation left them.
+      const int R = m.newton_refine;
+      if (R > 0 && factored && n > 0) {
+        float a_lo = 0.f, a_keep = a, alo_keep = 0.f, force_keep[NSLOT];
+        double err_keep = 1.0e300;
+        const float a_in = a;
+        float force_in[NSLOT];
+        int state_in[NSLOT];
+#pragma unroll
+        for (int s = 0; s < NSLOT; s++) { force_keep[s] = force[s]; force_in[s] = force[s]; state_in[s] = state[s]; }
+        for (int it = 0;; it++) {
+          double jr[NSLOT], u64[NSLOT], c64 = 0.0;   // c64: this lane's share of the objective at a + a_lo, in fp64 (same pieces as row_update)
+#pragma unroll
+          for (int s = 0; s < NSLOT; s++) { jr[s] = SLOT_ON(s) ? lds_row_res64(sm.J + rw[s].row * JS, a, a_lo, rw[s].aref) : 0.0; u64[s] = jr[s] * (double)rw[s].fr_own; }
+#pragma unroll
+          for (int s = 0; s < NSLOT; s++) {
+            const Row& w_ = rw[s];
+            double uj64[CD];
+#pragma unroll
+            for (int j = 0; j < CD; j++) {        // the block's friction-scaled residuals (gather() in fp64)
+              const int Rr = w_.head + j;
+              double t = __shfl(u64[0], Rr & 63);
+#pragma unroll
+              for (int s2 = 1; s2 < NSLOT; s2++) { const double t1 = __shfl(u64[s2], Rr & 63); t = (Rr >> 6) == s2 ? t1 : t; }
+              uj64[j] = (w_.ell && j < w_.dim) ? t : 0.0;
+            }
+            double f = 0.0;
+            if (w_.valid && SLOT_ON(s)) {
+              if (state[s] == ST_QUADRATIC) { f = -(double)w_.D * jr[s]; c64 += 0.5 * (double)w_.D * jr[s] * jr[s]; }
+              else if (state[s] == ST_LINEARNEG) { f = (double)w_.fl; c64 += (double)w_.fl * (-0.5 * (double)w_.R * (double)w_.fl - jr[s]); }
+              else if (state[s] == ST_LINEARPOS) { f = -(double)w_.fl; c64 += (double)w_.fl * (-0.5 * (double)w_.R * (double)w_.fl + jr[s]); }
+              else if (state[s] == ST_CONE) {
+                double T2 = 0.0;
+#pragma unroll
+                for (int j = 1; j < CD; j++) T2 = fma(uj64[j], uj64[j], T2);
+                const double Tn = sqrt(T2), gg = uj64[0] - (double)w_.mu * Tn, f0 = -(double)w_.Dm * gg * (double)w_.mu;
+                f = w_.kk == 0 ? f0 : -f0 / Tn * u64[s] * (double)w_.fr_own;
+                if (w_.kk == 0) c64 += 0.5 * (double)w_.Dm * gg * gg;
+              }
+            }
+            force[s] = (float)f;
+            sm.u.W[w_.row] = force[s];                                  // the force as hi + lo floats for the dof lanes
+            sm.u.W[NEFCAP + w_.row] = (float)(f - (double)force[s]);
+          }
+          SYNC();
+          double gk = 0.0;
+          if (lane < nv) {
+            double ma = 0.0, jf = 0.0;
+            for (int j = 0; j < nv; j++) ma = fma((double)sm.M[lane * NVP + j], (double)bcast(a, j) + (double)bcast(a_lo, j), ma);
+            for (int r = 0; r < n; r++) jf = fma((double)sm.J[r * JS + lane], (double)sm.u.W[r] + (double)sm.u.W[NEFCAP + r], jf);
+            gk = ma - (double)f_sm - jf;
+          }
+          // the objective itself, in fp64: rows + Gauss term half (M a - f_smooth) . (a - a_smooth).  A pass that does not lower it (the factor in LDS belongs to
+          // another active set than the point the iteration ended on, or resolves none of the direction the gradient points in) is undone, and the refinement ends.
+          {
+            double ma = 0.0;
+            if (lane < nv) for (int j = 0; j < nv; j++) ma = fma((double)sm.M[lane * NVP + j], (double)bcast(a, j) + (double)bcast(a_lo, j), ma);
+            if (lane < nv) c64 += 0.5 * (ma - (double)f_sm) * ((double)a + (double)a_lo - (double)a_sm);
+          }
+          const double err = wave_sum_f64(c64);
+          if (!(err < err_keep)) {
+            a = a_keep; a_lo = alo_keep;
+#pragma unroll
+            for (int s = 0; s < NSLOT; s++) force[s] = force_keep[s];
+            break;
+          }
+          a_keep = a; alo_keep = a_lo; err_keep = err;
+#pragma unroll
+          for (int s = 0; s < NSLOT; s++) force_keep[s] = force[s];
+          if (it == R) break;
+          const float dk = bchol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -(float)gk : 0.f, nv, lane);
+          {
+            const float sm_ = __fadd_rn(a, dk), bb = __fsub_rn(sm_, a), se = __fadd_rn(__fsub_rn(a, __fsub_rn(sm_, bb)), __fsub_rn(dk, bb));   // a + dk = sm_ + se exactly
+            const float lo = __fadd_rn(a_lo, se);
+            a = __fadd_rn(sm_, lo);
+            a_lo = __fsub_rn(lo, __fsub_rn(a, sm_));
+          }
+          SYNC();
+        }
+        // the passes held every row in the state the iteration left it in: the refined point is only kept if the rows ARE in those states there (a
+        // refinement that walks across a state boundary has minimised the wrong piece)
+        if (a != a_in) {
+          float fr_[NSLOT];
+#pragma unroll
+          for (int s = 0; s < NSLOT; s++) fr_[s] = force[s];
+          evaluate(a);
+          bool moved = false;
+#pragma unroll
+          for (int s = 0; s < NSLOT; s++) if SLOT_ON(s) moved |= rw[s].valid && state[s] != state_in[s];
+          if (__ballot(moved)) {
+            a = a_in;
+#pragma unroll
+            for (int s = 0; s < NSLOT; s++) { force[s] = force_in[s]; state[s] = state_in[s]; }
+          } else {
+#pragma unroll
+            for (int s = 0; s < NSLOT; s++) force[s] = fr_[s];
+          }
+        }
       }
     }
 #pragma unroll
