@@ -1,6 +1,6 @@
 #!/bin/bash
 # The library of another commit as robosuite_amd/librsim_hip_prev.so, for same-box A/Bs (RSIM_LIB=... selects it: backend.py).  Boxes differ by +-15 %, so
-# every before / after number in profiles/ comes from ONE gpurun session that runs both builds (tools/gpu_r3_k.sh, _l, _m, _n).
+# every before / after number in profiles/ comes from ONE gpurun session that runs both builds (tools/gpu_session.sh <tag> ab:<libA>:<libB>).
 # Usage: tools/build_prev.sh [commit=HEAD~1]
 set -e
 c=${1:-HEAD~1}; R=$(git rev-parse --show-toplevel); T=/tmp/prevbuild; rm -rf $T; mkdir -p $T
