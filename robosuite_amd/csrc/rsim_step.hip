@@ -387,7 +387,8 @@ typedef Cmem0 __attribute__((address_space(1)))* cmw_t;         // write view (p
 #define IT(tab, i) (((gci)m.it)[m.io[tab] + (i)])
 // per-env value only for fields some env has overridden (per-episode object sizes, domain randomisation); everything else comes from the
 // shared copy, which stays L2-resident instead of being streamed from HBM once per env and launch
-#define FP(tab, i) (((gcf)(((m.fenv >> (tab)) & 1ull) ? fp : m.ft0))[m.fo[tab] + (i)])
+#define FP(tab, i) (((gcf)(((fenv >> (tab)) & 1ull) ? fp : m.ft0))[m.fo[tab] + (i)])    // inside Sim: `fenv` is re-laundered at every phase()
+#define FPM(tab, i) (((gcf)(((m.fenv >> (tab)) & 1ull) ? fp : m.ft0))[m.fo[tab] + (i)])
 
 // Register-resident Cholesky: lane i owns row (i & 15) of the SPD matrix in a[0..N) (the four 16-lane rows of the wave hold identical
 // copies); all loops unroll so every index is a compile-time register and every broadcast is a DPP row_newbcast operand.
@@ -1006,6 +1007,11 @@ struct Sim {
   __device__ __forceinline__ void phase() {
 #ifndef RSIM_NO_PHASE_LANE
     lane = opaque_lane(lane); pf.lane = lane;
+#endif
+    // the same for the field-override mask: with a loop-invariant `fenv` every `bit ? env table : shared table` select of FP() -- some seventy
+    // 64-bit pointers -- is computed before the substep loop and parked in spilled SGPRs (v_writelane / v_readlane) for the whole kernel
+#ifdef RSIM_PHASE_FENV
+    asm volatile("" : "+s"(fenv));
 #endif
   }
   // global stores of this wavefront's lanes -> visible to its other lanes' loads (controller-state tail, constant block after an episode reset)
@@ -4107,12 +4113,17 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
       // MuJoCo's bad-state guard (mj_checkPos / mj_checkVel -> mj_resetData [3P]): a non-finite or absurdly large coordinate puts the env back
       // to qpos0 with zero velocity / control / time instead of letting NaNs run on.  Controller state is the caller's (robosuite objects).
       bool bad = false;
-      for (int i = lane; i < m.nq; i += 64) bad |= !(fabsf(sm.qpos[i]) < 1.0e10f);
-      if (lane < m.nv) bad |= !(fabsf(sm.qvel[lane]) < 1.0e10f);
+#ifdef RSIM_GUARD_LANE
+      const int gl = sim.lane;   // the phase's opaque lane id (phase() above): with the kernel's own `lane` the LDS addresses below are computed before the substep loop and spilled across it
+#else
+      const int gl = lane;
+#endif
+      for (int i = gl; i < m.nq; i += 64) bad |= !(fabsf(sm.qpos[i]) < 1.0e10f);
+      if (gl < m.nv) bad |= !(fabsf(sm.qvel[gl]) < 1.0e10f);
       if (__ballot(bad)) {
         SYNC();
-        for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = FP(FO_qpos0, i);
-        if (lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.qacc[lane] = 0.f; sm.ctrl[lane] = 0.f; }
+        for (int i = gl; i < m.nq; i += 64) sm.qpos[i] = FPM(FO_qpos0, i);
+        if (gl < NV) { sm.qvel[gl] = 0.f; sm.qacc_ws[gl] = 0.f; sm.qacc[gl] = 0.f; sm.ctrl[gl] = 0.f; }
         time = 0.f;
         ndiverged++;
         SYNC();
