@@ -380,6 +380,24 @@ int rsim_dr_save_defaults(rsim_batch* b);
 int rsim_randomize_dynamics(rsim_batch* b, const rsim_dr_desc* d, uint64_t seed, uint64_t step);
 
 
+/* Rollout statistics across the GPUs of a job (SURVEY section 8(b) `rsim_allreduce_stats`, 8(e)): the path's only collective.  Environments are
+ * independent worlds, sharded as contiguous blocks over one process per GPU (no data-path exchange); what a training loop sums over ranks once
+ * per rollout is a handful of scalars -- env-steps, reward sum, successes, overflow / diverged counts (robosuite itself has no counterpart: its
+ * envs are single-process, environments/base.py:23-42).  RCCL (librccl.so, resolved at run time from the process -- the copy PyTorch-ROCm loads --
+ * so the library has no link-time dependency on it) over xGMI.
+ *   rsim_comm_unique_id   rank 0 draws the 128-byte id (ncclGetUniqueId) and hands it to the other ranks out of band (file, env, torch store ...)
+ *   rsim_comm_create      every rank, same id: ncclCommInitRank on `device`; world == 1 is valid (a one-rank communicator)
+ *   rsim_allreduce_stats  HOST float64 [n] in, the reduction over all ranks out (op 0 = sum, 1 = max); blocks until the result is on the host
+ * The Python host (robosuite_amd/shard.py) uses torch.distributed for the same reduction ("nccl" = RCCL on ROCm, gloo on CPU); this entry is for
+ * binders without torch. */
+typedef struct rsim_comm rsim_comm;
+#define RSIM_COMM_ID_BYTES 128
+int rsim_comm_unique_id(void* id_out, size_t bytes);
+int rsim_comm_create(const void* id, size_t bytes, int rank, int world, int device, rsim_comm** out);
+int rsim_allreduce_stats(rsim_comm* c, double* inout, int n, int op);
+void rsim_comm_free(rsim_comm* c);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,6 +233,10 @@ def lib():
         L.rsim_id2name.argtypes = [vp, C.c_char_p, C.c_int]; L.rsim_id2name.restype = C.c_char_p
         L.rsim_full_M.argtypes = [vp, C.c_int, vp]
         L.rsim_contacts.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.rsim_comm_unique_id.argtypes = [vp, C.c_size_t]
+        L.rsim_comm_create.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.rsim_allreduce_stats.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.rsim_comm_free.argtypes = [vp]; L.rsim_comm_free.restype = None
         _LIB = L
     return _LIB
 
@@ -240,6 +244,42 @@ def lib():
 def _chk(rc):
     if rc != 0:
         raise RsimError(lib().rsim_last_error().decode())
+
+
+class HipComm:
+    """rsim_comm handle (include/rsim.h): RCCL communicator for the rollout-statistics reduction, for hosts without torch.distributed.
+    `HipComm.unique_id()` on rank 0, hand the 128 bytes to every rank, then `HipComm(uid, rank, world, device)` on all of them."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(HipComm.ID_BYTES)
+        _chk(lib().rsim_comm_unique_id(C.cast(buf, C.c_void_p), HipComm.ID_BYTES))
+        return buf.raw
+
+    def __init__(self, uid: bytes, rank: int, world: int, device: int = 0):
+        self.ptr = C.c_void_p()
+        self.rank, self.world = int(rank), int(world)
+        buf = C.create_string_buffer(bytes(uid), len(uid))
+        _chk(lib().rsim_comm_create(C.cast(buf, C.c_void_p), len(uid), self.rank, self.world, int(device), C.byref(self.ptr)))
+
+    def allreduce(self, values, op: str = "sum"):
+        """Reduction of a float64 vector over all ranks (op: "sum" | "max"); returns a new array."""
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        _chk(lib().rsim_allreduce_stats(self.ptr, v.ctypes.data_as(C.c_void_p), v.size, {"sum": 0, "max": 1}[op]))
+        return v
+
+    def close(self):
+        if self.ptr:
+            lib().rsim_comm_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
 
 
 class HipModel:

@@ -1,5 +1,7 @@
 // rsim_api.cpp -- host side of the C-ABI (include/rsim.h): model blob ingest, table packing, batch memory, launches.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only: the functions are resolved with dlsym from the librccl.so the process already holds
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -1741,3 +1743,74 @@ extern "C" int rsim_model_param_get(rsim_batch* b, const char* field, int env0, 
   return 0;
 }
 
+
+
+// ---- rollout statistics across GPUs: the one collective of the path (include/rsim.h) -----------------------------------------------------------
+struct rsim_comm { ncclComm_t comm; int rank, world, device; hipStream_t stream; double* dbuf; int cap; };
+static void* rccl_sym(const char* name) {
+  static void* h = [] {
+    void* x = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);        // PyTorch-ROCm's copy, if the process has it: one process, one RCCL
+    if (!x) x = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    if (!x) x = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!x) x = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    return x;
+  }();
+  return h ? dlsym(h, name) : nullptr;
+}
+#define RCCL_FN(var, name, type) type var = (type)rccl_sym(name); if (!var) return fail("%s: librccl.so / %s not found in the process (%s)", __func__, name, dlerror() ? dlerror() : "no dlerror")
+typedef ncclResult_t (*fn_uid)(ncclUniqueId*);
+typedef ncclResult_t (*fn_init)(ncclComm_t*, int, ncclUniqueId, int);
+typedef ncclResult_t (*fn_allreduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+typedef ncclResult_t (*fn_destroy)(ncclComm_t);
+typedef const char* (*fn_errstr)(ncclResult_t);
+static const char* rccl_err(ncclResult_t r) { fn_errstr f = (fn_errstr)rccl_sym("ncclGetErrorString"); return f ? f(r) : "?"; }
+
+extern "C" int rsim_comm_unique_id(void* id_out, size_t bytes) {
+  static_assert(sizeof(ncclUniqueId) == RSIM_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  if (!id_out || bytes < sizeof(ncclUniqueId)) return fail("rsim_comm_unique_id: need a %zu-byte buffer", sizeof(ncclUniqueId));
+  RCCL_FN(f, "ncclGetUniqueId", fn_uid);
+  ncclUniqueId id;
+  ncclResult_t r = f(&id);
+  if (r != ncclSuccess) return fail("ncclGetUniqueId: %s", rccl_err(r));
+  memcpy(id_out, &id, sizeof id);
+  return 0;
+}
+
+extern "C" int rsim_comm_create(const void* id, size_t bytes, int rank, int world, int device, rsim_comm** out) {
+  if (!id || bytes < sizeof(ncclUniqueId) || !out || world < 1 || rank < 0 || rank >= world) return fail("rsim_comm_create: bad arguments (rank %d of %d, %zu id bytes)", rank, world, bytes);
+  RCCL_FN(f, "ncclCommInitRank", fn_init);
+  HIPCHK(hipSetDevice(device));
+  rsim_comm* c = new rsim_comm{};
+  c->rank = rank; c->world = world; c->device = device; c->cap = 64;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  ncclResult_t r = f(&c->comm, world, uid, rank);
+  if (r != ncclSuccess) { delete c; return fail("ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, device, rccl_err(r)); }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->dbuf, c->cap * sizeof(double)) != hipSuccess) {
+    rsim_comm_free(c);
+    return fail("rsim_comm_create: stream / buffer allocation failed on device %d", device);
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int rsim_allreduce_stats(rsim_comm* c, double* inout, int n, int op) {
+  if (!c || !inout || n < 1 || n > c->cap || (op != 0 && op != 1)) return fail("rsim_allreduce_stats: bad arguments (n %d of at most %d, op %d)", n, c ? c->cap : 0, op);
+  RCCL_FN(f, "ncclAllReduce", fn_allreduce);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(c->dbuf, inout, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  ncclResult_t r = f(c->dbuf, c->dbuf, (size_t)n, ncclFloat64, op == 0 ? ncclSum : ncclMax, c->comm, c->stream);
+  if (r != ncclSuccess) return fail("ncclAllReduce: %s", rccl_err(r));
+  HIPCHK(hipMemcpyAsync(inout, c->dbuf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" void rsim_comm_free(rsim_comm* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->comm) { fn_destroy f = (fn_destroy)rccl_sym("ncclCommDestroy"); if (f) f(c->comm); }
+  if (c->dbuf) hipFree(c->dbuf);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
