@@ -189,6 +189,7 @@ struct rsim_batch {
   int* d_order2[2];
   unsigned* d_cost2[2];
   hipStream_t ostream;
+  int order_fresh;    // 1: the dispatch order of step t is sorted on the batch's stream from the costs of step t - 1 (RSIM_ORDER_FRESH, default); 0: beside step t - 1 from the costs of step t - 2
   hipEvent_t step_done[2], ord_done[2];
   int ord_valid[2];   // order2[k] holds a dispatch order (its event has been recorded)
   long nstep;         // one-launch control steps issued since the schedule was (re)started
@@ -823,6 +824,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   if (dalloc(&b->d_order, (size_t)B)) return 1;
   if (dalloc(&b->d_cost, (size_t)B)) return 1;
   b->ostream = nullptr; b->nstep = 0;
+  { const char* e = getenv("RSIM_ORDER_FRESH"); b->order_fresh = e ? atoi(e) : 1; }
   for (int k = 0; k < 2; k++) {
     b->d_order2[k] = nullptr; b->d_cost2[k] = nullptr; b->step_done[k] = nullptr; b->ord_done[k] = nullptr; b->ord_valid[k] = 0;
     if (dalloc(&b->d_order2[k], (size_t)B) || dalloc(&b->d_cost2[k], (size_t)B)) return 1;
@@ -1104,6 +1106,30 @@ static int ensure_constants(rsim_batch* b) {
 
 // One wide pass of a tiered control step on `stream`: the constant blocks of the listed envs (only when envs have blocks of their own), then the step.
 // pass 1 = the envs whose tier is 1 (list built by rsim_launch_tier_list), pass 2 = the redo list the native pass appended to.
+
+// RSIM_TRACE_STEPS=N: HIP events at fixed points of the main stream in N consecutive control steps, mean intervals printed to stderr once -- where the time
+// between two control-step kernels goes WITHOUT a profiler attached (rocprofv3 changes the cross-queue behaviour it is supposed to show)
+struct StepTrace { int n = -1, k = 0; std::vector<hipEvent_t> ev; bool done = false; };
+static StepTrace g_tr;
+static const char* TR_NAMES[8] = {"step start", "order sorted", "k_step launched (fork + wide chain enqueued before it)", "k_step done", "wide pass joined", "redo pass done", "reset constants done", "reset observations done"};
+static void tr_mark(rsim_batch* b, int point) {
+  if (g_tr.n < 0) { const char* e = getenv("RSIM_TRACE_STEPS"); g_tr.n = e ? atoi(e) : 0; if (g_tr.n > 0) { g_tr.ev.resize((size_t)g_tr.n * 8); for (auto& x : g_tr.ev) hipEventCreate(&x); } }
+  if (g_tr.n <= 0 || g_tr.done || g_tr.k >= g_tr.n) return;
+  hipEventRecord(g_tr.ev[(size_t)g_tr.k * 8 + point], b->stream);
+  if (point == 7 && ++g_tr.k == g_tr.n) {
+    hipStreamSynchronize(b->stream);
+    double acc[8] = {0}; int cnt = 0;
+    for (int k = g_tr.n / 4; k + 1 < g_tr.n; k++, cnt++) {
+      for (int i = 0; i < 7; i++) { float ms = 0; hipEventElapsedTime(&ms, g_tr.ev[(size_t)k * 8 + i], g_tr.ev[(size_t)k * 8 + i + 1]); acc[i] += ms; }
+      float ms = 0; hipEventElapsedTime(&ms, g_tr.ev[(size_t)k * 8 + 7], g_tr.ev[(size_t)(k + 1) * 8]); acc[7] += ms;
+    }
+    fprintf(stderr, "[rsim trace] mean over %d control steps, us between main-stream points:\n", cnt);
+    for (int i = 0; i < 8; i++) fprintf(stderr, "[rsim trace]   %-78s -> %8.1f\n", TR_NAMES[i], 1e3 * acc[i] / cnt);
+    g_tr.done = true;
+  }
+}
+
+static inline bool sched1_trace(int flags) { return (flags & RF_EPISODE) && (flags & RF_CTRL); }
 static int wide_pass(rsim_batch* b, const float* actions, int n_sub, int flags, int pass, const int* list, const int* count, hipStream_t stream) {
   DBatch dw = b->db;
   dw.cm = b->d_cm_w; dw.cm_env = (char*)b->d_cm_w + b->cm_bytes_w; dw.cm_stride = b->db.cm_stride ? (long long)b->cm_bytes_w : 0;
@@ -1126,8 +1152,13 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   // capacity tiers apply to the fused control step only (the debug entries keep the native capacity and count what they drop in RSIM_OVERFLOW)
   const bool tiered = b->cfg_w >= 0 && (flags & RF_EPISODE) && (flags & RF_CTRL) && !(flags & RF_DEBUG);
   b->db.tier_cur = tiered ? b->d_tier[b->tier_flip] : nullptr; b->db.tier_next = tiered ? b->d_tier[b->tier_flip ^ 1] : nullptr;
-  b->db.tier_up_con = getenv("RSIM_TIER_UP_CON") ? atoi(getenv("RSIM_TIER_UP_CON")) : 2;
-  b->db.tier_up_efc = getenv("RSIM_TIER_UP_EFC") ? atoi(getenv("RSIM_TIER_UP_EFC")) : 6;
+  // how close to its native capacity an env moves up BEFORE it overflows.  A flagged env is stepped by the wide pass, whose workgroups only find room once the
+  // native launch has no workgroup pending (a freed 20 KB slot never fits a 32 - 116 KB workgroup): it starts ~2 ms into the step and, being one of the most
+  // contact-rich envs, ends after it.  An env that overflows unflagged costs more (its step is redone after the native pass), but on the 32 x 16 build (Lift)
+  // flagged-and-never-overflowing env-steps outnumber overflows by orders of magnitude (largest demand 16 contacts / 63-66 rows of 16 / 64), so that build
+  // flags nothing in advance: 3.42 -> 3.31 ms per control step; Stack is flat between 0 / 0 and 2 / 6 (profiles/r04_x_tier_overhead.txt)
+  b->db.tier_up_con = getenv("RSIM_TIER_UP_CON") ? atoi(getenv("RSIM_TIER_UP_CON")) : (b->cfg == 0 ? 0 : 2);
+  b->db.tier_up_efc = getenv("RSIM_TIER_UP_EFC") ? atoi(getenv("RSIM_TIER_UP_EFC")) : (b->cfg == 0 ? 0 : 6);
   b->db.tier_pass = tiered ? 0 : -1; b->db.wlist = nullptr; b->db.wcount = nullptr; b->db.wlist2 = nullptr; b->db.wcount2 = nullptr;
   const bool grouped = (flags & RF_EPISODE) && (flags & RF_CTRL) && b->ngroups > 1;
   if (!grouped || b->cm_dirty || memcmp(&b->cm_ctrl, &b->dm.ctrl, sizeof(DCtrl))) { if (join_groups(b)) return 1; }   // main-stream work ahead
@@ -1183,14 +1214,27 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   }
   const bool sched1 = (flags & RF_EPISODE) && (flags & RF_CTRL) && b->schedule && b->d_order;   // fused control steps only: forward()/step1()/step2() launches are one substep long
   const int cur = (int)(b->nstep & 1), prev = cur ^ 1;
+  const bool traced = sched1_trace(flags);
+  if (traced) tr_mark(b, 0);
   if (sched1) {
     if (!b->ostream) {
       HIPCHK(hipStreamCreateWithFlags(&b->ostream, hipStreamNonBlocking));
       for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&b->step_done[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b->ord_done[k], hipEventDisableTiming)); }
     }
-    if (b->ord_valid[cur]) { HIPCHK(hipStreamWaitEvent(b->stream, b->ord_done[cur], 0)); b->db.order = b->d_order2[cur]; }
+    if (b->order_fresh) {
+      // on the batch's stream, from the costs of the step just before this one: 12-16 us on the critical path, no cross-stream dependency.  The side-stream
+      // form below sorts the costs of step t - 2; an env's duration correlates 0.55 with its duration one step earlier and 0.40-0.52 with two steps
+      // earlier, and replaying the measured durations through a list scheduler puts the launch 3.4 % (Lift) / 3.7 % (Stack) shorter with the fresher
+      // order (tools/sched_study.py, profiles/r04_x3_sched_study.txt)
+      if (b->nstep >= 1) {
+        int eo = rsim_launch_order(b->d_cost2[prev], b->d_order2[cur], b->B, b->stream);
+        if (eo) return fail("dispatch-order kernel launch failed: %s", hipGetErrorString((hipError_t)eo));
+        b->db.order = b->d_order2[cur];
+      }
+    } else if (b->ord_valid[cur]) { HIPCHK(hipStreamWaitEvent(b->stream, b->ord_done[cur], 0)); b->db.order = b->d_order2[cur]; }
     b->db.cost = b->d_cost2[cur];
   }
+  if (traced) tr_mark(b, 1);
   if (tiered) {
     // beside the native pass, on a stream of its own: the envs whose tier is 1 (they were close to the native capacity, or beyond it, last step)
     int* cnt = b->d_wcount + b->tier_flip * WCN;
@@ -1208,17 +1252,21 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
     }
     b->db.wlist2 = b->d_wlist[1]; b->db.wcount2 = cnt + 1;
   }
+  if (traced) tr_mark(b, 2);
   int e = k_step_launch[b->cfg](&b->dm, &b->db, actions, n_sub, flags, b->stream);
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (traced) tr_mark(b, 3);
   if (tiered) {
     // after both: the envs the native pass had to hand over in mid-step (rare: most move up between steps), redone from their unchanged state
     if (b->tier_mode != 1) HIPCHK(hipStreamWaitEvent(b->stream, b->wjoin, 0));
+    if (traced) tr_mark(b, 4);
     if (wide_pass(b, actions, n_sub, flags, 2, b->d_wlist[1], b->d_wcount + b->tier_flip * WCN + 1, b->stream)) return 1;
     b->tier_flip ^= 1;
-  }
+  } else if (traced) tr_mark(b, 4);
+  if (traced) tr_mark(b, 5);
   if (sched1) {
-    HIPCHK(hipEventRecord(b->step_done[cur], b->stream));
-    if (b->nstep >= 1) {   // beside the step just launched: sort the costs of the PREVIOUS step into the order of the NEXT one
+    if (!b->order_fresh) HIPCHK(hipEventRecord(b->step_done[cur], b->stream));
+    if (!b->order_fresh && b->nstep >= 1) {   // beside the step just launched: sort the costs of the PREVIOUS step into the order of the NEXT one
       HIPCHK(hipStreamWaitEvent(b->ostream, b->step_done[prev], 0));
       int eo = rsim_launch_order(b->d_cost2[prev], b->d_order2[prev], b->B, b->ostream);   // order2[(t + 1) & 1] == order2[prev]
       if (eo) return fail("dispatch-order kernel launch failed: %s", hipGetErrorString((hipError_t)eo));
@@ -1233,6 +1281,7 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
       e = k_prepare_launch[b->cfg](&b->dm, &b->db, b->B, 1, b->stream);
       if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
+    if (traced) tr_mark(b, 6);
     if (b->dm.task.enabled) {
       // ... and their observation record becomes the one MujocoEnv.reset() returns (base.py:298-347): sim.forward() + observables on the reset
       // state, no reward.  The terminal record of the finished episode was moved to RSIM_TERMINAL_OBS by the control step.
@@ -1241,6 +1290,7 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
       e = k_reset_obs_launch[b->cfg](&b->dm, &db2, b->stream);
       if (e) return fail("reset-observation kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
+    if (traced) tr_mark(b, 7);
   }
   b->gen++;
   b->derived_stale = (flags & RF_DEBUG) ? 0 : 1;
