@@ -1556,6 +1556,9 @@ static void ls_eval(rso_data *d, const double *jar, const double *jv, const doub
   *p = c; *dp = c1; *ddp = c2;
 }
 
+/* RSO_DEBUG=1: say why the Newton iteration ended (stderr) */
+static int rso_debug(void) { static int v = -1; if (v < 0) v = getenv("RSO_DEBUG") ? 1 : 0; return v; }
+
 static void solve_newton(rso_data *d) {
   rso_model *m = d->m;
   int nv = m->nv, n = d->nefc;
@@ -1590,7 +1593,7 @@ static void solve_newton(rso_data *d) {
       for (int i = 0; i < n; i++) s -= d->efc_J[(size_t)i * nv + k] * f[i];
       grad[k] = s; gn += s * s;
     }
-    if (iter >= m->iterations || scale * sqrt(gn) < m->tolerance) break;
+    if (iter >= m->iterations || scale * sqrt(gn) < m->tolerance) { if (rso_debug()) fprintf(stderr, "[rso newton] iter %d exit: gradient %.3e (scaled) cost %.6e\n", iter, scale * sqrt(gn), cost); break; }
     /* Hessian */
     memcpy(H, d->qM, sizeof(double) * nv * nv);
     for (int i = 0; i < n; i++) {
@@ -1618,23 +1621,32 @@ static void solve_newton(rso_data *d) {
     for (int i = 0; i < nv; i++) { double s = 0; for (int k = 0; k < nv; k++) s += d->qM[i * nv + k] * search[k]; Mv[i] = s; }
     for (int i = 0; i < nv; i++) { quadGauss[1] += search[i] * (Ma[i] - d->qfrc_smooth[i]); quadGauss[2] += 0.5 * search[i] * Mv[i]; snorm += search[i] * search[i]; }
     snorm = sqrt(snorm);
-    if (snorm < MINVAL) break;
+    if (snorm < MINVAL) { if (rso_debug()) fprintf(stderr, "[rso newton] iter %d exit: zero search\n", iter); break; }
     double gtol = m->tolerance * 0.01 * snorm / scale; /* tolerance * ls_tolerance * |search| * meaninertia * nv */
     double p0, d0, h0, p, dp, hp, lo = 0, hi = -1, alpha;
     ls_eval(d, jar, jv, quadGauss, 0, &p0, &d0, &h0);
-    if (d0 >= 0 || h0 <= 0) break;
+    if (d0 >= 0 || h0 <= 0) { if (rso_debug()) fprintf(stderr, "[rso newton] iter %d exit: not a descent direction d0 %.3e h0 %.3e cost %.6e\n", iter, d0, h0, cost); break; }
     alpha = -d0 / h0;
+    double last_step = alpha;
     for (int ls = 0; ls < 50; ls++) {
       ls_eval(d, jar, jv, quadGauss, alpha, &p, &dp, &hp);
       if (fabs(dp) < gtol) break;
       if (dp < 0) lo = alpha; else hi = alpha;
       double next = hp > 0 ? alpha - dp / hp : -1;
       if (hi < 0) { if (next <= lo) next = 2 * alpha + 1e-12; }
-      else if (next <= lo || next >= hi) next = 0.5 * (lo + hi);
+      else {
+        /* bracketed: a Newton candidate that is out of the bracket, or that moves alpha by more than half of what the step before moved it, is replaced by the
+         * midpoint (the rule of Numerical Recipes' rtsafe).  The derivative of this objective is monotone but far from linear (rows switch on along the
+         * line), and plain safeguarded Newton can creep in from both ends in large alternating jumps -- 50 evaluations without reaching the minimiser on
+         * stacked-cube states, after which the step was rejected for not lowering the cost (found in round 4: profiles/r04_x10_line_search.txt).  MuJoCo's
+         * own search evaluates the midpoint next to both Newton candidates for the same reason (engine_solver.c PrimalSearch [3P]). */
+        if (next <= lo || next >= hi || (ls >= 8 && fabs(next - alpha) > 0.5 * last_step)) next = 0.5 * (lo + hi);   /* ls >= 8: an ordinary search is over by then, and takes the path it always took */
+      }
+      last_step = fabs(next - alpha);
       alpha = next;
     }
     ls_eval(d, jar, jv, quadGauss, alpha, &p, &dp, &hp);
-    if (!(p < p0)) break;
+    if (!(p < p0)) { if (rso_debug()) fprintf(stderr, "[rso newton] iter %d exit: line search found no lower point p0 %.9e p %.9e alpha %.3e d0 %.3e h0 %.3e\n", iter, p0, p, alpha, d0, h0); break; }
     for (int k = 0; k < nv; k++) a[k] += alpha * search[k];
     iter++;
     if (scale * (p0 - p) < m->tolerance) {
