@@ -349,3 +349,49 @@ def test_pickplace_8192_with_dynamics_randomisation_reached_states():
         env2.batch.randomize_dynamics(seed=11, step=t, solimp_ratio=0.0)
         env2.step(tape[t][:2048])
     assert int(env2.batch.get("diverged").sum()) == 0
+
+
+def test_stack_one_whole_control_step_of_the_slowest_envs_against_the_oracle():
+    """The envs a Stack launch waits for: the 48 Newton-heaviest envs of control step 300 of the 4096-env bench workload plus 48 envs spread over the batch
+    (tests/golden/stack_hard_envs_step300.npz: their states, warm starts, commands, controller records and actions before that step, recorded by
+    tools/newton_hard_envs.py).  ONE whole control step -- 25 substeps with set_goal, both controllers, up to 10 contacts and 8 Newton iterations per substep --
+    through the fused kernel and through the oracle from identical inputs.  Typical env to rounding; the tail is bounded by what one contact's MPR facet choice
+    in fp32 does to a light cube (profiles/r04_x10_line_search.txt: with the kernel's contact geometry the two solvers agree to 3e-9)."""
+    import json
+
+    from robosuite_amd import mjcf
+
+    adir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "robosuite_amd", "assets")
+    flat = mjcf.load_model(os.path.join(adir, "stack_panda.rsim"))
+    cfg = json.load(open(os.path.join(adir, "stack_panda.cfg.json")))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stack_hard_envs_step300.npz"))
+    n, n_sub = len(z["envs"]), int(z["n_sub"])
+    from tests.util import make_hip, make_oracle
+
+    hm, hb = make_hip(flat, cfg, B=n)
+    for f in ("qpos", "qvel", "qacc_warmstart", "ctrl", "cstate"):
+        hb.set(f, z[f])
+    hb.control_step(torch.tensor(z["actions"], dtype=torch.float32, device="cuda"), n_sub)
+    q1 = hb.get("qpos")
+    assert int(hb.get("overflow").sum()) == 0 and int(hb.get("diverged").sum()) == 0
+    dq, it = [], []
+    for i in range(n):
+        om, od, oc = make_oracle(flat, cfg)
+        od.qpos[:] = z["qpos"][i]; od.qvel[:] = z["qvel"][i]; od.qacc_warmstart[:] = z["qacc_warmstart"][i]; od.ctrl[:] = z["ctrl"][i]
+        od.forward(); oc.reset(od)
+        st, cs = oc.state, z["cstate"][i]
+        st[:20] = cs[:20]; st[20:24] = cs[20:24]; st[24:28] = cs[20:24]
+        a = z["actions"][i].astype(np.float64)
+        k = 0
+        for s in range(n_sub):
+            od.step1()
+            if s == 0:
+                oc.set_goal(od, a)
+            oc.run(od)
+            od.step2()
+            k += od.solver_iter
+        dq.append(float(np.abs(q1[i] - od.qpos).max())); it.append(k / n_sub)
+    dq, it = np.array(dq), np.array(it)
+    print(f"   [Stack, slowest envs] |dq| after one control step: p50 {np.median(dq):.1e} p90 {np.percentile(dq, 90):.1e} max {dq.max():.1e}; oracle Newton iterations per substep "
+          f"mean {it.mean():.2f} max {it.max():.2f} (kernel, recorded: {z['newton'].mean() / n_sub:.2f} / {z['newton'].max() / n_sub:.2f})")
+    assert np.median(dq) < 5e-6 and np.percentile(dq, 90) < 2e-4 and dq.max() < 5e-2, (np.median(dq), np.percentile(dq, 90), dq.max())

@@ -897,3 +897,25 @@ def check_mesh_patch(cs, bodies, name, tol=1e-5):
         p = np.asarray(cs[0]["pos"])
         centre = np.array([float(x) for x in bodies[-1][0].split()])
         assert abs(p[2] - (-0.0005 if len(bodies) == 1 else 1.0495)) < tol and np.abs(p[:2] - centre[:2]).max() < 0.0401, (name, p)
+
+
+def test_line_search_does_not_creep_on_a_stacked_cube_state():
+    """A state of the Stack bench workload (env 871 of 4096, control step 300, substep 18: two cubes stacked under a grasp) on which the oracle's line search used
+    to creep in from both ends of its bracket for all 50 evaluations, end above its start and make the Newton iteration give up at iteration 0 -- found in round 4
+    because the KERNEL's acceleration had the lower objective (profiles/r04_x10_line_search.txt).  The oracle must converge here, and at least as low as that point."""
+    import json
+
+    from robosuite_amd import mjcf
+
+    adir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "robosuite_amd", "assets")
+    flat = mjcf.load_model(os.path.join(adir, "stack_panda.rsim"))
+    cfg = json.load(open(os.path.join(adir, "stack_panda.cfg.json")))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stack_line_search_case.npz"))
+    om, od, _ = make_oracle(flat, cfg)
+    od.qpos[:] = z["qpos"]; od.qvel[:] = z["qvel"]; od.qacc_warmstart[:] = z["qacc_warmstart"]; od.ctrl[:] = z["ctrl"]
+    od.forward()
+    own, at_kernel = od.cost(od.qacc.copy()), od.cost(z["qacc_kernel"])
+    assert od.solver_iter >= 2, od.solver_iter
+    assert own <= at_kernel + 1e-6 * abs(at_kernel), (own, at_kernel)          # 730.08 against 695.86 before the fix
+    c, g = od.cost(od.qacc.copy(), with_gradient=True)
+    assert np.abs(g).max() < 1e-6 * max(1.0, abs(c)), np.abs(g).max()           # a stationary point of the convex objective
