@@ -831,6 +831,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   }
   if (dalloc(&b->db.needs_reset, (size_t)B)) return 1;
   b->db.mprc = nullptr;
+  b->db.jg = nullptr;
   if (!getenv("RSIM_NO_MPR_WARMSTART") && m->npair > 0 && dalloc(&b->db.mprc, (size_t)B * m->npair * 12)) return 1;
   b->db.mprc_portal = getenv("RSIM_NO_MPR_PORTAL_WARMSTART") ? 0 : 1;
   b->db.bpl = nullptr;
@@ -884,6 +885,13 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.ctrl.cs_size = b->cs;
   // capacity tiers: only for controllers whose state lives in LDS for the whole launch (a step that is handed over must not have written anything)
   b->cfg_w = b->cs <= RSIM_CS_LDS ? pick_wide(m, b->cfg, b->lim, b->lim_w) : -1;
+  {
+    // builds that keep the constraint Jacobian in global memory (RSIM_JGLOBAL: limits bit 2) get their per-env buffer, [B][NEFC * (NV + 1)] floats
+    size_t jgf = 0;
+    if (b->lim[9] & 4) jgf = (size_t)b->lim[6] * (size_t)(b->lim[2] + 1);
+    if (b->cfg_w >= 0 && (b->lim_w[9] & 4)) jgf = std::max(jgf, (size_t)b->lim_w[6] * (size_t)(b->lim_w[2] + 1));
+    if (jgf && dalloc(&b->db.jg, (size_t)B * jgf)) return 1;
+  }
   b->d_cm_w = nullptr; b->d_tier[0] = b->d_tier[1] = nullptr; b->d_wlist[0] = b->d_wlist[1] = nullptr; b->d_wcount = nullptr; b->wstream = nullptr; b->tier_flip = 0;
   if (b->cfg_w >= 0) {
     b->cm_bytes_w = (size_t)cmem_bytes_any(b->cfg_w);
@@ -957,6 +965,7 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
     for (int k = 0; k < 2; k++) { hipFree(b->d_tier[k]); hipFree(b->d_wlist[k]); }
   }
   if (b->db.mprc) hipFree(b->db.mprc);
+  if (b->db.jg) hipFree(b->db.jg);
   if (b->db.bpl) hipFree(b->db.bpl);
   hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_ft0); if (b->d_obsprog) hipFree(b->d_obsprog);
   if (b->d_bank) hipFree(b->d_bank); if (b->d_bank_tag) hipFree(b->d_bank_tag); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); if (b->d_ft_base) hipFree(b->d_ft_base); hipFree(b->d_mesh); hipFree(b->d_mask);

@@ -195,6 +195,7 @@ struct DBatch {
   int* task_object;      // [B] PickPlace single-object mode 1: the object of the env's current episode (RSIM_TASK_OBJECT)
   float* sensordata;     // [B][nsensordata] (debug build of the kernel: rsim_step.hip sensor_acc)
   int* bpl;              // [B][5][64] or null: broadphase pair list (rsim_step.hip collision(): sphere centres at build time, packed pair constants, pair indices)
+  float* jg;             // RSIM_JGLOBAL builds: [B][NEFC * (NV + 1)] constraint Jacobians (the kernel's per-env scratch; null otherwise)
   float* mprc;           // [B][npair][12] or null: the separating direction (x, y, z, valid) each candidate pair's last convex narrow-phase run ended on
                          // (warm start of the next substep's run, see convex_convex); zeroed whenever the host writes positions
   const int* order;      // [B] or null (identity)

@@ -95,6 +95,11 @@ typedef unsigned long long u64;
 // One workgroup = one wavefront: LDS instructions of a wave execute in issue order, so cross-lane communication through LDS needs no
 // s_waitcnt / s_barrier, only a compiler-level ordering point (wavefront-scope fences emit no instructions; __syncthreads() would
 // drain the LDS queue with s_waitcnt lgkmcnt(0) at every one of the ~110 sites).
+#ifdef RSIM_JGLOBAL
+#define RSIM_JG_ENABLED 1
+#else
+#define RSIM_JG_ENABLED 0
+#endif
 #define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define FMIN 1e-20f
 #define PI_F 3.14159265358979f
@@ -335,7 +340,10 @@ struct Smem {
   float cpos[NCON * 3], cframe[NCON * 9], cdist[NCON], cfri[NCON * 5], csolref[NCON * 2], csolimp[NCON * 5], cmu[NCON], cmargin[NCON];
   int cg1[NCON], cg2[NCON], cdim[NCON], cefc[NCON];
   // constraint rows
-  float J[NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
+  // RSIM_JGLOBAL (64 x 48 build with 128 rows only): the constraint Jacobian lives in a per-env buffer in GLOBAL memory (DBatch.jg; 25 KB per env, L2-resident
+  // for the resident envs of an XCD) instead of LDS: 74.8 -> 49.7 KB = three environments per CU instead of two
+  static constexpr bool JG_ = RSIM_JG_ENABLED && NV == 48 && NEFC == 128;
+  float J[JG_ ? 4 : NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
   float e_R[NEFC], e_aref[NEFC], e_force[NEFC];   // e_force doubles as the row's velocity gain B between make_constraint's two halves
   int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
   float cstate[RSIM_CS_LDS];     // first RSIM_CS_LDS floats of the controller state (all of it for the OSC and plain joint-space types); the tail stays in global memory
@@ -973,6 +981,16 @@ struct Sim {
     const long long off = (fenv & mask) ? ceoff : 0ll;
     return (cmr_t)((const char __attribute__((address_space(1)))*)cm + off);
   }
+  static constexpr bool JG = SM::JG_;
+  gwf Jg = nullptr;                                         // JG builds: this env's constraint Jacobian [NEFC][JS] in global memory (DBatch.jg)
+  __device__ __forceinline__ float Jrd(int i) const { if constexpr (JG) return Jg[i]; else return sm.J[i]; }
+  __device__ __forceinline__ void Jwr(int i, float v) const { if constexpr (JG) Jg[i] = v; else sm.J[i] = v; }
+  // J written by some lanes, read by others of the same wavefront: LDS needs the wavefront fence of SYNC(); global memory needs the stores to have left the
+  // wavefront (workgroup scope: s_waitcnt vmcnt(0); the CU's L1 is coherent for its own waves)
+  __device__ __forceinline__ void jsync() const {
+    if constexpr (JG) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+    else SYNC();
+  }
   float __attribute__((address_space(1)))* mprc = nullptr;  // this env's narrow-phase warm-start record [npair][MPRC] in global memory (DBatch.mprc), or null
   bool mpr_portal = true;                                   // contacts leave their portal directions in the record (flag 2)
   float __attribute__((address_space(1)))* cst = nullptr;   // this env's controller-state record in global memory (slots >= RSIM_CS_LDS are used in place)
@@ -1100,7 +1118,7 @@ struct Sim {
     // zero the LDS regions whose padding lanes / columns are read but never written
     for (int e = lane; e < SM_NB * 10 + 16; e += 64) sm.cinert[e] = 0.f;
     for (int e = lane; e < NV16 * CS6; e += 64) sm.cdof[e] = 0.f;
-    if constexpr (!FAST) { for (int e = lane; e < NEFCAP * JS; e += 64) sm.J[e] = 0.f; }   // rows beyond the last written 16-row tile are read (and ignored) by the lanes that own no row: keep them finite
+    if constexpr (!FAST) { for (int e = lane; e < NEFCAP * JS; e += 64) Jwr(e, 0.f); if constexpr (JG) jsync(); }   // rows beyond the last written 16-row tile are read (and ignored) by the lanes that own no row: keep them finite
     if (lane < (NROOT + 1) * 3) sm.rootcom[lane] = 0.f;
     if constexpr (SM::HULLPOOL_ > 0) {
       // resident hull pool: one pass per pooled mesh, lane-parallel over its vertices
@@ -2652,7 +2670,7 @@ struct Sim {
         for (int ct = 0; ct < NT; ct++) {
           if (16 * ct >= nv) {
 #pragma unroll
-            for (int v = 0; v < 4; v++) sm.J[(16 * rt + 4 * q + v) * JS + 16 * ct + r] = 0.f;
+            for (int v = 0; v < 4; v++) Jwr((16 * rt + 4 * q + v) * JS + 16 * ct + r, 0.f);
             continue;
           }
           v4f P2 = {0.f, 0.f, 0.f, 0.f}, P1 = {0.f, 0.f, 0.f, 0.f};
@@ -2664,12 +2682,12 @@ struct Sim {
 #pragma unroll
           for (int v = 0; v < 4; v++) {
             const int k = 16 * ct + r;
-            sm.J[(16 * rt + 4 * q + v) * JS + k] = (((k2[v] >> k) & 1ull) ? P2[v] : 0.f) + (((k1[v] >> k) & 1ull) ? P1[v] : 0.f);
+            Jwr((16 * rt + 4 * q + v) * JS + k, (((k2[v] >> k) & 1ull) ? P2[v] : 0.f) + (((k1[v] >> k) & 1ull) ? P1[v] : 0.f));
           }
         }
       }
     }
-    SYNC();
+    jsync();
     const float qv = lane < nv ? sm.qvel[lane] : 0.f;
 #pragma unroll
     for (int slot = 0; slot < NSLOT; slot++) {
@@ -2678,22 +2696,22 @@ struct Sim {
       const bool valid = row < nefc;
       const int desc = valid ? sm.e_desc[row] : 0;
       const int type = desc & 15, id = (desc >> 4) & 255, kk = (desc >> 12) & 15;
-      float* Jr = sm.J + row * JS;
-      if (valid && type == C_FRICTION_DOF) Jr[id] = 1.f;
-      else if (valid && type == C_LIMIT_JOINT) Jr[id] = kk ? -1.f : 1.f;   // lower limit: +dq increases the distance; upper: decreases it
+      const int jr0 = row * JS;
+      if (valid && type == C_FRICTION_DOF) Jwr(jr0 + id, 1.f);
+      else if (valid && type == C_LIMIT_JOINT) Jwr(jr0 + id, kk ? -1.f : 1.f);   // lower limit: +dq increases the distance; upper: decreases it
       else if (TENDONS && valid && (type == C_EQUALITY || type == C_LIMIT_TENDON || type == C_FRICTION_TENDON)) {
         // row of a fixed tendon: its coefficients on the dofs of its (at most four) joints; an upper limit takes the negative row
         const float sg = (type == C_LIMIT_TENDON && kk) ? -1.f : 1.f;
         const int adr = IT(IO_tendon_adr, id), num = IT(IO_tendon_num, id);
-        for (int w = 0; w < num && w < 4; w++) Jr[IT(IO_wrap_dof, adr + w)] += sg * FP(FO_wrap_prm, adr + w);
+        for (int w = 0; w < num && w < 4; w++) { const int at = jr0 + IT(IO_wrap_dof, adr + w); Jwr(at, Jrd(at) + sg * FP(FO_wrap_prm, adr + w)); }
       }
     }
-    SYNC();
+    jsync();
 #pragma unroll
     for (int slot = 0; slot < NSLOT; slot++) {
       if (64 * slot >= nefc) continue;
       const int row = lane + 64 * slot;
-      const float jv = lds_row_dot(sm.J + row * JS, qv);
+      const float jv = j_row_dot(row * JS, qv);
       if (row < nefc) sm.e_aref[row] = -sm.e_force[row] * jv - sm.e_aref[row];
     }
     SYNC();
@@ -3175,11 +3193,37 @@ struct Sim {
   // sum_k r[k] * x_k.  One-tile configuration: x is replicated in every 16-lane row (DPP row broadcast); wide: x_k lives in lane k (readlane)
   __device__ __forceinline__ float row_dot(const Row& rw, float x) const {
     if constexpr (FAST) return dot_rows<NV16>(rw.J, x);
-    else return lds_row_dot(sm.J + rw.row * JS, x);
+    else return j_row_dot(rw.row * JS, x);
   }
   // wide configurations: sum_k p[k] x_k over the 16-column tiles that hold dofs (columns nv .. 16 ceil(nv / 16) - 1 hold zeros, x_k = 0 there).
   // One wavefront per SIMD and nothing else to switch to: a read-then-use loop pays the full LDS latency per element, so the sixteen reads of a
   // tile are issued back to back and consumed afterwards.
+  // row of J at element offset `base` times x (JG builds: the row comes from global memory, all its tiles in one batch of loads)
+  __device__ __forceinline__ float j_row_dot(int base, float x) const {
+    if constexpr (!JG) return lds_row_dot(sm.J + base, x);
+    else {
+      float a[NV16];
+#pragma unroll
+      for (int u = 0; u < NV16; u++) a[u] = Jg[base + u];
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < NV16; u++) acc = fmaf(a[u], bcast(x, u), acc);   // columns nv .. NV16 - 1 hold zeros
+      return acc;
+    }
+  }
+  __device__ __forceinline__ double j_row_res64(int base, float x, float xl, float aref) const {
+    if constexpr (!JG) return lds_row_res64(sm.J + base, x, xl, aref);
+    else {
+      float a[NV16];
+#pragma unroll
+      for (int u = 0; u < NV16; u++) a[u] = Jg[base + u];
+      double acc = -(double)aref;
+      float lo = 0.f;
+#pragma unroll
+      for (int u = 0; u < NV16; u++) { acc = fma((double)a[u], (double)bcast(x, u), acc); lo = fmaf(a[u], bcast(xl, u), lo); }
+      return acc + (double)lo;
+    }
+  }
   __device__ __forceinline__ float lds_row_dot(const float* p, float x) const {
     float acc = 0.f;
     for (int k0 = 0; k0 < m.nv; k0 += 16) {
@@ -3306,7 +3350,7 @@ struct Sim {
           const int r = 4 * (c0 + u) + q;
           fb[u] = sm.e_force[r];
 #pragma unroll
-          for (int t = 0; t < NBT; t++) ja[u][t] = sm.J[r * JS + 16 * t + col];
+          for (int t = 0; t < NBT; t++) ja[u][t] = Jrd(r * JS + 16 * t + col);
         }
 #pragma unroll
         for (int u = 0; u < 2; u++)
@@ -3354,14 +3398,14 @@ struct Sim {
         }
         float bj[NBT], aj[NBT];
 #pragma unroll
-        for (int t = 0; t < NBT; t++) bj[t] = sm.J[r * JS + 16 * t + col];
+        for (int t = 0; t < NBT; t++) bj[t] = Jrd(r * JS + 16 * t + col);
         if (__ballot((bd >> 16) & 1)) {
           const int head = bd & 255, dm1 = ((bd >> 8) & 7) - 1;
-          const float* j0 = sm.J + head * JS + col;
+          const int j0 = head * JS + col;
           const int o1 = (dm1 < 1 ? dm1 : 1) * JS, o2 = (dm1 < 2 ? dm1 : 2) * JS, o3 = (dm1 < 3 ? dm1 : 3) * JS;
           float x0[NBT], x1[NBT], x2[NBT], x3[NBT];
 #pragma unroll
-          for (int t = 0; t < NBT; t++) { x0[t] = j0[16 * t]; x1[t] = j0[o1 + 16 * t]; x2[t] = j0[o2 + 16 * t]; x3[t] = j0[o3 + 16 * t]; }
+          for (int t = 0; t < NBT; t++) { x0[t] = Jrd(j0 + 16 * t); x1[t] = Jrd(j0 + o1 + 16 * t); x2[t] = Jrd(j0 + o2 + 16 * t); x3[t] = Jrd(j0 + o3 + 16 * t); }
 #pragma unroll
           for (int t = 0; t < NBT; t++) aj[t] = fmaf(cf[3], x3[t], fmaf(cf[2], x2[t], fmaf(cf[1], x1[t], cf[0] * x0[t])));
         } else {
@@ -3727,7 +3771,7 @@ struct Sim {
         for (int it = 0;; it++) {
           double jr[NSLOT], u64[NSLOT], c64 = 0.0;   // c64: this lane's share of the objective at a + a_lo, in fp64 (same pieces as row_update)
 #pragma unroll
-          for (int s = 0; s < NSLOT; s++) { jr[s] = SLOT_ON(s) ? lds_row_res64(sm.J + rw[s].row * JS, a, a_lo, rw[s].aref) : 0.0; u64[s] = jr[s] * (double)rw[s].fr_own; }
+          for (int s = 0; s < NSLOT; s++) { jr[s] = SLOT_ON(s) ? j_row_res64(rw[s].row * JS, a, a_lo, rw[s].aref) : 0.0; u64[s] = jr[s] * (double)rw[s].fr_own; }
 #pragma unroll
           for (int s = 0; s < NSLOT; s++) {
             const Row& w_ = rw[s];
@@ -3763,7 +3807,7 @@ struct Sim {
           if (lane < nv) {
             double ma = 0.0, jf = 0.0;
             for (int j = 0; j < nv; j++) ma = fma((double)sm.M[lane * NVP + j], (double)bcast(a, j) + (double)bcast(a_lo, j), ma);
-            for (int r = 0; r < n; r++) jf = fma((double)sm.J[r * JS + lane], (double)sm.u.W[r] + (double)sm.u.W[NEFCAP + r], jf);
+            for (int r = 0; r < n; r++) jf = fma((double)Jrd(r * JS + lane), (double)sm.u.W[r] + (double)sm.u.W[NEFCAP + r], jf);
             gk = ma - (double)f_sm - jf;
           }
           // the objective itself, in fp64: rows + Gauss term half (M a - f_smooth) . (a - a_smooth).  A pass that does not lower it (the factor in LDS belongs to
@@ -4039,6 +4083,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   sim.cst = (gwf)(b.cstate + (size_t)env * cs);
   if (b.bpl) sim.bpl = (int __attribute__((address_space(1)))*)(b.bpl + (size_t)env * 320);
   if (b.mprc) { sim.mprc = (gwf)(b.mprc + (size_t)env * Sim<SM>::MPRC * m.npair); sim.mpr_portal = b.mprc_portal != 0; }
+  if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * (SM::NEFC_ * SM::JS_));
   if (lane < csl) sm.cstate[lane] = sim.cst[lane];
   if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; }
   sim.load_opt();
@@ -4263,6 +4308,7 @@ __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const uns
   for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = b.qpos[(size_t)env * m.nq + i];
   const int cs = m.ctrl.cs_size, csl = cs < RSIM_CS_LDS ? cs : RSIM_CS_LDS;
   sim.cst = (gwf)(b.cstate + (size_t)env * cs);
+  if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * (SM::NEFC_ * SM::JS_));
   if (lane < csl) sm.cstate[lane] = 0.f;
   for (int i = RSIM_CS_LDS + lane; i < cs; i += 64) sim.cst[i] = 0.f;
   sim.cst_sync();
@@ -4454,6 +4500,6 @@ extern "C" int RSIM_SYM(rsim_cmem_bytes)(void) { return (int)((sizeof(Cmem0) + 2
 extern "C" int RSIM_SYM(rsim_limits)(int* lim) {
   const int dims[8] = {RSIM_DIMS};
   for (int i = 0; i < 8; i++) lim[i] = dims[i];
-  lim[8] = Smem0::NROOT_; lim[9] = (Smem0::TENDONS_ ? 1 : 0) | (Smem0::NB_ > 32 ? 2 : 0);   // bit 1: two OSC arm parts
+  lim[8] = Smem0::NROOT_; lim[9] = (Smem0::TENDONS_ ? 1 : 0) | (Smem0::NB_ > 32 ? 2 : 0) | (Smem0::JG_ ? 4 : 0);   // bit 2: the constraint Jacobian lives in DBatch.jg (NEFC * (NV + 1) floats per env)   // bit 1: two OSC arm parts
   return 0;
 }
