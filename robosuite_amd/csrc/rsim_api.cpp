@@ -888,8 +888,13 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   {
     // builds that keep the constraint Jacobian in global memory (RSIM_JGLOBAL: limits bit 2) get their per-env buffer, [B][NEFC * (NV + 1)] floats
     size_t jgf = 0;
+#ifdef RSIM_MGLOBAL   // prepared, not enabled: limits bit 3 = the mass matrix behind J in the same buffer, NV * (NV + 1) floats more
+    if (b->lim[9] & 4) jgf = (size_t)b->lim[6] * (size_t)(b->lim[2] + 1) + ((b->lim[9] & 8) ? (size_t)b->lim[2] * (size_t)(b->lim[2] + 1) : 0);
+    if (b->cfg_w >= 0 && (b->lim_w[9] & 4)) jgf = std::max(jgf, (size_t)b->lim_w[6] * (size_t)(b->lim_w[2] + 1) + ((b->lim_w[9] & 8) ? (size_t)b->lim_w[2] * (size_t)(b->lim_w[2] + 1) : 0));
+#else
     if (b->lim[9] & 4) jgf = (size_t)b->lim[6] * (size_t)(b->lim[2] + 1);
     if (b->cfg_w >= 0 && (b->lim_w[9] & 4)) jgf = std::max(jgf, (size_t)b->lim_w[6] * (size_t)(b->lim_w[2] + 1));
+#endif
     if (jgf && dalloc(&b->db.jg, (size_t)B * jgf)) return 1;
   }
   b->d_cm_w = nullptr; b->d_tier[0] = b->d_tier[1] = nullptr; b->d_wlist[0] = b->d_wlist[1] = nullptr; b->d_wcount = nullptr; b->wstream = nullptr; b->tier_flip = 0;

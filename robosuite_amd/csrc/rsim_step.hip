@@ -100,6 +100,11 @@ typedef unsigned long long u64;
 #else
 #define RSIM_JG_ENABLED 0
 #endif
+#ifdef RSIM_MGLOBAL
+#define RSIM_MG_ENABLED 1
+#else
+#define RSIM_MG_ENABLED 0
+#endif
 #define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define FMIN 1e-20f
 #define PI_F 3.14159265358979f
@@ -329,7 +334,10 @@ struct Smem {
     float rowst[NV == 16 ? 1 : NEFC * 20];                                                 // make_constraint() (wide): per contact row the two 6-vectors (padded to 8) that multiply cdof, and the two bodies' dof masks
     float W[NV == 16 ? NEFC * (NV + 1) : NEFC * 5];                                        // solve_newton(): Hessian-weighted rows (one-tile configurations); wide: five words per row (four block coefficients, block head | dim | cone flag) from which the products form the weighted row on the fly
   } u;
-  float M[NV * NVP];
+  // RSIM_MGLOBAL (on top of RSIM_JGLOBAL; NOT enabled, not yet run on hardware -- prepared at the end of round 4): the mass matrix
+  // behind J in the same per-env global buffer: 49.7 -> 40.3 KB = FOUR environments per CU, one wavefront per SIMD
+  static constexpr bool MG_ = RSIM_MG_ENABLED && RSIM_JG_ENABLED && NV == 48 && NEFC == 128;
+  float M[MG_ ? 4 : NV * NVP];
   union { float L[NV * NVP]; float H[NV * NVP]; };  // L (factor of M) is dead once qacc_smooth exists; H is the solver / Euler work matrix
   float invdiag[NV];
   float Le[HAS_LE_ ? NV * NVP : 1], invdiag_e[NV];   // Cholesky factor of M + h*diag(damping) (implicit-damping Euler), computed alongside L
@@ -983,6 +991,10 @@ struct Sim {
   }
   static constexpr bool JG = SM::JG_;
   gwf Jg = nullptr;                                         // JG builds: this env's constraint Jacobian [NEFC][JS] in global memory (DBatch.jg)
+  static constexpr bool MG = SM::MG_;
+  gwf Mg = nullptr;                                         // MG builds: this env's mass matrix [NV][NVP] in global memory (behind J in DBatch.jg)
+  __device__ __forceinline__ float Mrd(int i) const { if constexpr (MG) return Mg[i]; else return sm.M[i]; }
+  __device__ __forceinline__ void Mwr(int i, float v) const { if constexpr (MG) Mg[i] = v; else sm.M[i] = v; }
   __device__ __forceinline__ float Jrd(int i) const { if constexpr (JG) return Jg[i]; else return sm.J[i]; }
   __device__ __forceinline__ void Jwr(int i, float v) const { if constexpr (JG) Jg[i] = v; else sm.J[i] = v; }
   // J written by some lanes, read by others of the same wavefront: LDS needs the wavefront fence of SYNC(); global memory needs the stores to have left the
@@ -1438,7 +1450,7 @@ struct Sim {
       for (int tj = 0; tj < NT; tj++) {
         if (16 * ti >= nv || 16 * tj >= nv) {   // tile without dofs: identity padding
 #pragma unroll
-          for (int v = 0; v < 4; v++) { const int i = 16 * ti + 4 * q + v, j = 16 * tj + r; const float e = i == j ? cmf(MK_arm)->arm[i] : 0.f; sm.M[i * NVP + j] = e; sm.L[i * NVP + j] = e; }
+          for (int v = 0; v < 4; v++) { const int i = 16 * ti + 4 * q + v, j = 16 * tj + r; const float e = i == j ? cmf(MK_arm)->arm[i] : 0.f; Mwr(i * NVP + j, e); sm.L[i * NVP + j] = e; }
           continue;
         }
         v4f R1 = {0.f, 0.f, 0.f, 0.f}, R2 = {0.f, 0.f, 0.f, 0.f};
@@ -1453,9 +1465,10 @@ struct Sim {
           const bool a1 = (arow[ti][v] >> j) & 1, a2 = (acol[tj] >> i) & 1;
           float mij = a1 ? R1[v] : (a2 ? R2[v] : 0.f);
           if (i == j) mij += cmf(MK_arm)->arm[i];
-          sm.M[i * NVP + j] = mij; sm.L[i * NVP + j] = mij;
+          Mwr(i * NVP + j, mij); sm.L[i * NVP + j] = mij;
         }
       }
+    if constexpr (MG) jsync();   // the stores of M have left the wavefront before any lane reads it back from global memory
     SYNC();
     SUBMARK_T(RP_X2);
     bchol_inplace<NVP>(sm.L, sm.invdiag, nv, lane);
@@ -2773,7 +2786,7 @@ struct Sim {
       const int nd = __ballot(lane >= m.nv_damped && hd != 0.f) ? nv : m.nv_damped;
       SYNC();
       const int nvt = (nd + 15) & ~15;
-      for (int e = lane; e < nvt * nvt; e += 64) { const int i = e / nvt, j = e - i * nvt; sm.H[i * NVP + j] = sm.M[i * NVP + j]; }
+      for (int e = lane; e < nvt * nvt; e += 64) { const int i = e / nvt, j = e - i * nvt; sm.H[i * NVP + j] = Mrd(i * NVP + j); }
       SYNC();
       if (lane < nd) sm.H[lane * NVP + lane] += hd;
       SYNC();
@@ -2997,7 +3010,7 @@ struct Sim {
       const int mypart = seli(c.part_of, li);
 #pragma unroll
       for (int k = 0; k < NA; k++) {   // the part's own mass-matrix block (each arm of a multi-arm robot is its own controller object)
-        const float mk = (lane < n && k < n && c.part_of[k] == mypart) ? sm.M[di * NVP + c.dof_idx[k]] : 0.f;
+        const float mk = (lane < n && k < n && c.part_of[k] == mypart) ? Mrd(di * NVP + c.dof_idx[k]) : 0.f;
         tq = fmaf(mk, bcast(des, k), tq);
       }
     } else if (c.type == RSIM_CTRL_JOINT_VELOCITY) {
@@ -3066,7 +3079,7 @@ struct Sim {
 #pragma unroll
       for (int k = 0; k < NA; k++) dk[k] = k < n ? c.dof_idx[AO + k] : 0;
 #pragma unroll
-      for (int k = 0; k < NA; k++) { const float v = sm.M[di * NVP + dk[k]]; mr[k] = (lane < n && k < n) ? v : (row8 == k ? 1.f : 0.f); }   // di = 0 on padding lanes
+      for (int k = 0; k < NA; k++) { const float v = Mrd(di * NVP + dk[k]); mr[k] = (lane < n && k < n) ? v : (row8 == k ? 1.f : 0.f); }   // di = 0 on padding lanes
     }
     float matmp = 0.f;   // (Ma tmp)_i
 #pragma unroll
@@ -3253,7 +3266,16 @@ struct Sim {
   __device__ __forceinline__ float mass_dot(const float (&Mr)[FAST ? NV16 : 1], float x) const {
     if constexpr (FAST) return dot_rows<NV16>(Mr, x);
     else {
-      const float acc = lds_row_dot(sm.M + (lane < m.nv ? lane : 0) * NVP, x);
+      float acc;
+      if constexpr (MG) {
+        float a[NV16];
+        const int base = (lane < m.nv ? lane : 0) * NVP;
+#pragma unroll
+        for (int u = 0; u < NV16; u++) a[u] = Mg[base + u];
+        acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < NV16; u++) acc = fmaf(a[u], bcast(x, u), acc);   // columns nv .. NV16 - 1 of a dof row hold zeros (identity padding sits on the diagonal of the padding ROWS)
+      } else acc = lds_row_dot(sm.M + (lane < m.nv ? lane : 0) * NVP, x);
       return lane < m.nv ? acc : 0.f;
     }
   }
@@ -3380,7 +3402,7 @@ struct Sim {
 #pragma unroll
           for (int tj = 0; tj <= ti; tj++, t++)
 #pragma unroll
-            for (int v = 0; v < 4; v++) acc[t][v] = sm.M[(16 * ti + 4 * q + v) * NVP + 16 * tj + col];
+            for (int v = 0; v < 4; v++) acc[t][v] = Mrd((16 * ti + 4 * q + v) * NVP + 16 * tj + col);
       }
       float cf[4];
       int bd;
@@ -3806,7 +3828,7 @@ struct Sim {
           double gk = 0.0;
           if (lane < nv) {
             double ma = 0.0, jf = 0.0;
-            for (int j = 0; j < nv; j++) ma = fma((double)sm.M[lane * NVP + j], (double)bcast(a, j) + (double)bcast(a_lo, j), ma);
+            for (int j = 0; j < nv; j++) ma = fma((double)Mrd(lane * NVP + j), (double)bcast(a, j) + (double)bcast(a_lo, j), ma);
             for (int r = 0; r < n; r++) jf = fma((double)Jrd(r * JS + lane), (double)sm.u.W[r] + (double)sm.u.W[NEFCAP + r], jf);
             gk = ma - (double)f_sm - jf;
           }
@@ -3814,7 +3836,7 @@ struct Sim {
           // another active set than the point the iteration ended on, or resolves none of the direction the gradient points in) is undone, and the refinement ends.
           {
             double ma = 0.0;
-            if (lane < nv) for (int j = 0; j < nv; j++) ma = fma((double)sm.M[lane * NVP + j], (double)bcast(a, j) + (double)bcast(a_lo, j), ma);
+            if (lane < nv) for (int j = 0; j < nv; j++) ma = fma((double)Mrd(lane * NVP + j), (double)bcast(a, j) + (double)bcast(a_lo, j), ma);
             if (lane < nv) c64 += 0.5 * (ma - (double)f_sm) * ((double)a + (double)a_lo - (double)a_sm);
           }
           const double err = wave_sum_f64(c64);
@@ -4083,7 +4105,8 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   sim.cst = (gwf)(b.cstate + (size_t)env * cs);
   if (b.bpl) sim.bpl = (int __attribute__((address_space(1)))*)(b.bpl + (size_t)env * 320);
   if (b.mprc) { sim.mprc = (gwf)(b.mprc + (size_t)env * Sim<SM>::MPRC * m.npair); sim.mpr_portal = b.mprc_portal != 0; }
-  if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * (SM::NEFC_ * SM::JS_));
+  if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * (SM::NEFC_ * SM::JS_ + (SM::MG_ ? SM::NV_ * SM::NVP : 0)));
+  if constexpr (Sim<SM>::MG) sim.Mg = sim.Jg + SM::NEFC_ * SM::JS_;
   if (lane < csl) sm.cstate[lane] = sim.cst[lane];
   if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; }
   sim.load_opt();
@@ -4246,7 +4269,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
     const int nb = m.nbody, nv = m.nv;
     for (int i = lane; i < nb * 3; i += 64) { b.xpos[(size_t)env * nb * 3 + i] = sm.xpos[i]; b.rootcom[(size_t)env * nb * 3 + i] = sm.rootcom[3 * sim.cm->broot[i / 3] + i % 3]; }
     for (int i = lane; i < nb * 4; i += 64) b.xquat[(size_t)env * nb * 4 + i] = sm.xquat[i];
-    for (int e = lane; e < nv * nv; e += 64) { int i = e / nv, j = e - i * nv; b.qM[(size_t)env * nv * nv + e] = sm.M[i * SM::NVP + j]; }
+    for (int e = lane; e < nv * nv; e += 64) { int i = e / nv, j = e - i * nv; b.qM[(size_t)env * nv * nv + e] = sim.Mrd(i * SM::NVP + j); }
     for (int e = lane; e < nv * 6; e += 64) b.cdof[(size_t)env * nv * 6 + e] = sm.cdof[(e / 6) * 9 + e % 6];
     for (int i = lane; i < nv; i += 64) {
       size_t o = (size_t)env * nv + i;
@@ -4308,7 +4331,8 @@ __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const uns
   for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = b.qpos[(size_t)env * m.nq + i];
   const int cs = m.ctrl.cs_size, csl = cs < RSIM_CS_LDS ? cs : RSIM_CS_LDS;
   sim.cst = (gwf)(b.cstate + (size_t)env * cs);
-  if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * (SM::NEFC_ * SM::JS_));
+  if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * (SM::NEFC_ * SM::JS_ + (SM::MG_ ? SM::NV_ * SM::NVP : 0)));
+  if constexpr (Sim<SM>::MG) sim.Mg = sim.Jg + SM::NEFC_ * SM::JS_;
   if (lane < csl) sm.cstate[lane] = 0.f;
   for (int i = RSIM_CS_LDS + lane; i < cs; i += 64) sim.cst[i] = 0.f;
   sim.cst_sync();
@@ -4500,6 +4524,6 @@ extern "C" int RSIM_SYM(rsim_cmem_bytes)(void) { return (int)((sizeof(Cmem0) + 2
 extern "C" int RSIM_SYM(rsim_limits)(int* lim) {
   const int dims[8] = {RSIM_DIMS};
   for (int i = 0; i < 8; i++) lim[i] = dims[i];
-  lim[8] = Smem0::NROOT_; lim[9] = (Smem0::TENDONS_ ? 1 : 0) | (Smem0::NB_ > 32 ? 2 : 0) | (Smem0::JG_ ? 4 : 0);   // bit 2: the constraint Jacobian lives in DBatch.jg (NEFC * (NV + 1) floats per env)   // bit 1: two OSC arm parts
+  lim[8] = Smem0::NROOT_; lim[9] = (Smem0::TENDONS_ ? 1 : 0) | (Smem0::NB_ > 32 ? 2 : 0) | (Smem0::JG_ ? 4 : 0) | (Smem0::MG_ ? 8 : 0);   // bit 2: the constraint Jacobian lives in DBatch.jg (NEFC * (NV + 1) floats per env)   // bit 1: two OSC arm parts
   return 0;
 }
