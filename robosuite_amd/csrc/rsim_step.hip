@@ -100,6 +100,11 @@ typedef unsigned long long u64;
 #else
 #define RSIM_JG_ENABLED 0
 #endif
+#ifdef RSIM_JROWS
+#define RSIM_JROWS_ENABLED 1
+#else
+#define RSIM_JROWS_ENABLED 0
+#endif
 #ifdef RSIM_MGLOBAL
 #define RSIM_MG_ENABLED 1
 #else
@@ -992,6 +997,9 @@ struct Sim {
   static constexpr bool JG = SM::JG_;
   gwf Jg = nullptr;                                         // JG builds: this env's constraint Jacobian [NEFC][JS] in global memory (DBatch.jg)
   static constexpr bool MG = SM::MG_;
+  // RSIM_JROWS (JG builds; prepared like RSIM_MGLOBAL, not yet run on hardware): a lane keeps the Jacobian rows it owns in registers for the duration of the solve
+  // (NSLOT x NV floats) instead of fetching them from the global buffer for every residual / direction product
+  static constexpr bool JROWS = RSIM_JROWS_ENABLED && SM::JG_;
   gwf Mg = nullptr;                                         // MG builds: this env's mass matrix [NV][NVP] in global memory (behind J in DBatch.jg)
   __device__ __forceinline__ float Mrd(int i) const { if constexpr (MG) return Mg[i]; else return sm.M[i]; }
   __device__ __forceinline__ void Mwr(int i, float v) const { if constexpr (MG) Mg[i] = v; else sm.M[i] = v; }
@@ -3197,7 +3205,7 @@ struct Sim {
   // H = M + J^T W and J^T f run on the matrix cores (v_mfma_f32_16x16x4_f32, 4 rows per instruction); the Hessian
   // factorisation is the register-resident Cholesky above.  Algorithm = oracle solve_newton (MuJoCo's primal Newton).
   struct Row {
-    float J[FAST ? NV16 : 1];   // one-tile configuration: the Jacobian row stays in registers; wide configurations read it from LDS
+    float J[(FAST || JROWS) ? NV16 : 1];   // one-tile configuration: the Jacobian row stays in registers; wide configurations read it from LDS (JROWS builds: registers too)
     float D, R, aref, fl, mu, fr_own, Dm;
     float fj[CD - 1];
     int row, type, head, kk, dim;
@@ -3206,7 +3214,12 @@ struct Sim {
   // sum_k r[k] * x_k.  One-tile configuration: x is replicated in every 16-lane row (DPP row broadcast); wide: x_k lives in lane k (readlane)
   __device__ __forceinline__ float row_dot(const Row& rw, float x) const {
     if constexpr (FAST) return dot_rows<NV16>(rw.J, x);
-    else return j_row_dot(rw.row * JS, x);
+    else if constexpr (JROWS) {
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < NV16; u++) acc = fmaf(rw.J[u], bcast(x, u), acc);
+      return acc;
+    } else return j_row_dot(rw.row * JS, x);
   }
   // wide configurations: sum_k p[k] x_k over the 16-column tiles that hold dofs (columns nv .. 16 ceil(nv / 16) - 1 hold zeros, x_k = 0 there).
   // One wavefront per SIMD and nothing else to switch to: a read-then-use loop pays the full LDS latency per element, so the sixteen reads of a
@@ -3223,6 +3236,15 @@ struct Sim {
       for (int u = 0; u < NV16; u++) acc = fmaf(a[u], bcast(x, u), acc);   // columns nv .. NV16 - 1 hold zeros
       return acc;
     }
+  }
+  __device__ __forceinline__ double row_res64(const Row& rw, float x, float xl) const {
+    if constexpr (JROWS) {
+      double acc = -(double)rw.aref;
+      float lo = 0.f;
+#pragma unroll
+      for (int u = 0; u < NV16; u++) { acc = fma((double)rw.J[u], (double)bcast(x, u), acc); lo = fmaf(rw.J[u], bcast(xl, u), lo); }
+      return acc + (double)lo;
+    } else return j_row_res64(rw.row * JS, x, xl, rw.aref);
   }
   __device__ __forceinline__ double j_row_res64(int base, float x, float xl, float aref) const {
     if constexpr (!JG) return lds_row_res64(sm.J + base, x, xl, aref);
@@ -3504,6 +3526,10 @@ struct Sim {
       if constexpr (FAST) {
 #pragma unroll
         for (int k = 0; k < NV16; k++) w_.J[k] = sm.J[row * JS + k];  // rows >= n were written as zeros
+      }
+      if constexpr (JROWS) {
+#pragma unroll
+        for (int k = 0; k < NV16; k++) w_.J[k] = SLOT_ON(s) ? Jg[row * JS + k] : 0.f;   // rows >= n of an active slot were written as zeros
       }
       const int desc = w_.valid ? sm.e_desc[r] : 0;
       w_.type = w_.valid ? (desc & 15) : -1;
@@ -3793,7 +3819,7 @@ struct Sim {
         for (int it = 0;; it++) {
           double jr[NSLOT], u64[NSLOT], c64 = 0.0;   // c64: this lane's share of the objective at a + a_lo, in fp64 (same pieces as row_update)
 #pragma unroll
-          for (int s = 0; s < NSLOT; s++) { jr[s] = SLOT_ON(s) ? j_row_res64(rw[s].row * JS, a, a_lo, rw[s].aref) : 0.0; u64[s] = jr[s] * (double)rw[s].fr_own; }
+          for (int s = 0; s < NSLOT; s++) { jr[s] = SLOT_ON(s) ? row_res64(rw[s], a, a_lo) : 0.0; u64[s] = jr[s] * (double)rw[s].fr_own; }
 #pragma unroll
           for (int s = 0; s < NSLOT; s++) {
             const Row& w_ = rw[s];
