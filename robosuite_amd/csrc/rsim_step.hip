@@ -100,6 +100,11 @@ typedef unsigned long long u64;
 #else
 #define RSIM_JG_ENABLED 0
 #endif
+#ifdef RSIM_JG256
+#define RSIM_JG256_ENABLED 1
+#else
+#define RSIM_JG256_ENABLED 0
+#endif
 #ifdef RSIM_JROWS
 #define RSIM_JROWS_ENABLED 1
 #else
@@ -355,7 +360,8 @@ struct Smem {
   // constraint rows
   // RSIM_JGLOBAL (64 x 48 build with 128 rows only): the constraint Jacobian lives in a per-env buffer in GLOBAL memory (DBatch.jg; 25 KB per env, L2-resident
   // for the resident envs of an XCD) instead of LDS: 74.8 -> 49.7 KB = three environments per CU instead of two
-  static constexpr bool JG_ = RSIM_JG_ENABLED && NV == 48 && NEFC == 128;
+  // (RSIM_JG256, prepared and not enabled: the 256-row tier of the same shape as well -- 116 -> 66 KB, two jumbo envs per CU instead of one)
+  static constexpr bool JG_ = RSIM_JG_ENABLED && NV == 48 && (NEFC == 128 || (RSIM_JG256_ENABLED && NEFC == 256));
   float J[JG_ ? 4 : NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
   float e_R[NEFC], e_aref[NEFC], e_force[NEFC];   // e_force doubles as the row's velocity gain B between make_constraint's two halves
   int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
