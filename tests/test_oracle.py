@@ -919,3 +919,13 @@ def test_line_search_does_not_creep_on_a_stacked_cube_state():
     assert own <= at_kernel + 1e-6 * abs(at_kernel), (own, at_kernel)          # 730.08 against 695.86 before the fix
     c, g = od.cost(od.qacc.copy(), with_gradient=True)
     assert np.abs(g).max() < 1e-6 * max(1.0, abs(c)), np.abs(g).max()           # a stationary point of the convex objective
+    # ... and the one an independent algorithm finds: projected Gauss-Seidel on the dual of the same problem (solve_pgs).  The kernel's fp32 acceleration of
+    # that substep, which exposed the defect by having the lower objective, sits at the same point to fp32 accuracy.
+    dual = flat.copy()
+    dual.arrays["solver"][:] = 0; dual.arrays["iterations"][:] = 50000; dual.arrays["tolerance"][:] = 0
+    om2, od2, _ = make_oracle(dual)
+    od2.qpos[:] = z["qpos"]; od2.qvel[:] = z["qvel"]; od2.qacc_warmstart[:] = z["qacc_warmstart"]; od2.ctrl[:] = z["ctrl"]
+    od2.forward()
+    scale = max(1.0, np.abs(od.qacc).max())
+    assert np.abs(od.qacc - od2.qacc).max() < 1e-6 * scale, np.abs(od.qacc - od2.qacc).max()
+    assert np.abs(z["qacc_kernel"] - od2.qacc).max() < 1e-4 * scale, np.abs(z["qacc_kernel"] - od2.qacc).max()
