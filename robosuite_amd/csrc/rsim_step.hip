@@ -100,6 +100,11 @@ typedef unsigned long long u64;
 #else
 #define RSIM_JG_ENABLED 0
 #endif
+#ifdef RSIM_JPREFETCH
+#define RSIM_JPF_ENABLED 1
+#else
+#define RSIM_JPF_ENABLED 0
+#endif
 #ifdef RSIM_JG256
 #define RSIM_JG256_ENABLED 1
 #else
@@ -1006,6 +1011,9 @@ struct Sim {
   // RSIM_JROWS (JG builds; prepared like RSIM_MGLOBAL, not yet run on hardware): a lane keeps the Jacobian rows it owns in registers for the duration of the solve
   // (NSLOT x NV floats) instead of fetching them from the global buffer for every residual / direction product
   static constexpr bool JROWS = RSIM_JROWS_ENABLED && SM::JG_;
+  // RSIM_JPREFETCH (JG builds; prepared, not yet run on hardware): the MFMA operand loads of J^T f and H = M + J^T W J are issued for several row chunks at
+  // once -- an L2 round trip is ~5 x an LDS one, and the loops below wait for one chunk's operands before they issue the next chunk's loads
+  static constexpr bool JPF = RSIM_JPF_ENABLED && SM::JG_;
   gwf Mg = nullptr;                                         // MG builds: this env's mass matrix [NV][NVP] in global memory (behind J in DBatch.jg)
   __device__ __forceinline__ float Mrd(int i) const { if constexpr (MG) return Mg[i]; else return sm.M[i]; }
   __device__ __forceinline__ void Mwr(int i, float v) const { if constexpr (MG) Mg[i] = v; else sm.M[i] = v; }
@@ -3393,6 +3401,23 @@ struct Sim {
 #pragma unroll
       for (int t = 0; t < NBT; t++) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
       const int q = lane >> 4, col = lane & 15;
+      if constexpr (JPF) {
+        for (int c0 = 0; c0 < nch; c0 += 8) {
+          float ja[8][NBT], fb[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const bool on = c0 + u < nch;                 // chunks past the last one: row 0 with a zero force (no read past the buffers)
+            const int r = on ? 4 * (c0 + u) + q : 0;
+            fb[u] = on ? sm.e_force[r] : 0.f;
+#pragma unroll
+            for (int t = 0; t < NBT; t++) ja[u][t] = Jg[r * JS + 16 * t + col];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int t = 0; t < NBT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ja[u][t], fb[u], acc[t], 0, 0, 0);
+        }
+      } else
       for (int c0 = 0; c0 < nch; c0 += 2) {
         float ja[2][NBT], fb[2];
 #pragma unroll
@@ -3438,6 +3463,7 @@ struct Sim {
         const float* o = sm.u.W + 5 * q;
         cf[0] = o[0]; cf[1] = o[1]; cf[2] = o[2]; cf[3] = o[3]; bd = ((const int*)o)[4];
       }
+      float bjn[JPF ? 4 : 1][NBT];
       for (int c = 0; c < nch; c++) {
         const int r = 4 * c + q;
         float cfn[4];
@@ -3447,8 +3473,22 @@ struct Sim {
           cfn[0] = o[0]; cfn[1] = o[1]; cfn[2] = o[2]; cfn[3] = o[3]; bdn = ((const int*)o)[4];
         }
         float bj[NBT], aj[NBT];
+        if constexpr (JPF) {
+          // B operands of this chunk and the next three in one batch of loads, every fourth chunk (the group's registers are indexed at compile time)
+          if ((c & 3) == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int ru = (c + u < nch) ? 4 * (c + u) + q : r;
+#pragma unroll
+              for (int t = 0; t < NBT; t++) bjn[u][t] = Jg[ru * JS + 16 * t + col];
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < NBT; t++) bj[t] = (c & 3) == 0 ? bjn[0][t] : ((c & 3) == 1 ? bjn[1][t] : ((c & 3) == 2 ? bjn[2][t] : bjn[3][t]));
+        } else {
 #pragma unroll
         for (int t = 0; t < NBT; t++) bj[t] = Jrd(r * JS + 16 * t + col);
+        }
         if (__ballot((bd >> 16) & 1)) {
           const int head = bd & 255, dm1 = ((bd >> 8) & 7) - 1;
           const int j0 = head * JS + col;
