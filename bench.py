@@ -141,6 +141,62 @@ def cpu_baseline(config, flat, cfg, budget_s=12.0):
                       f"{'' if config != 'pickplace' else ', without the per-step dynamics randomisation'}) in {dt:.1f} s"}
 
 
+def pmc_evidence(name, key, lib_sha):
+    """A PMC-derived figure from profiles/<name>, valid only for the library build it was measured on (the file carries that build's sha).  Evidence of
+    another build is reported as the string "stale:<its sha>", a missing file as "absent" -- never as a silent null (round-4 review)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return "absent"
+    return d.get(key) if d.get("lib_sha16") == lib_sha else f"stale:{d.get('lib_sha16')}"
+
+
+def secondary_region(config, rank, local_rank, world, dev, K, P):
+    """K lockstep control steps of another BASELINE configuration at its stated batch size, after P untimed launches from staggered episode steps (same
+    protocol as the headline region, shorter): ms per step, env-steps/s, dropped / diverged envs and the VALU issue fraction when PMC evidence of this
+    build exists."""
+    label, stem, B, dr, which = CONFIGS[config]
+    flat, cfg = factory.load_shipped(stem)
+    ids = shard.env_block(B * world, rank, world)
+    env = build_env(config, flat, cfg, ids, local_rank, 3 + (P + K) // HORIZON)
+    tape = torch.tensor(lift.env_actions(ids, P + K, action_dim=env.model.action_dim), device=dev)
+    n = [0]
+
+    def step(t):
+        if dr:
+            env.batch.randomize_dynamics(seed=11, step=n[0]); n[0] += 1
+        env.step(tape[t])
+
+    env.batch.set("ep_step", ((197 * ids) % HORIZON).astype(np.int32))
+    for t in range(P):
+        step(t)
+    env.batch.sync(); torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for t in range(K):
+        step(P + t)
+    env.batch.sync(); torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = shard.max_over_ranks(time.perf_counter() - t0, dev)
+    q = env.batch.tensor("qpos")
+    div = shard.max_over_ranks(float(int((~torch.isfinite(q).all(dim=1)).sum().item()) + int((env.batch.tensor("diverged") > 0).sum().item())), dev)
+    ovf = shard.max_over_ranks(float((env.batch.tensor("overflow") > 0).sum().item()), dev)
+    cn = env.batch.tensor("cap_need").view(B, 2)
+    lib_sha = hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16]
+    valu = pmc_evidence(f"valu_count_{config}.json", "valu_per_env_substep", lib_sha)
+    issue = valu if isinstance(valu, str) or valu is None else valu * B * world * N_SUB * K / dt / (world * VALU_ISSUE_PEAK)
+    env.bank_quiesce(); env._bank_stop()
+    out = {"workload": f"{label} (BASELINE {which})", "envs_per_gpu": B, "steps": K, "preroll": P, "value": B * world * K / dt, "unit": "env-steps/s",
+           "ms_per_step": 1e3 * dt / K, "overflow_envs": int(ovf), "diverged_envs": int(div),
+           "max_contacts_needed": int(cn[:, 0].max().item()), "max_rows_needed": int(cn[:, 1].max().item()), "capacity": [env.batch.maxcon, env.batch.maxefc],
+           "issue_frac": issue, "dynamics_randomisation": "re-drawn before every control step" if dr else None}
+    del env, tape
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +210,9 @@ def main():
     ap.add_argument("--groups", type=int, default=16, help="env blocks on their own HIP streams for the secondary open-loop figure; 1 = skip it")
     ap.add_argument("--no-open-loop", action="store_true", help="skip the second and third timed regions (the same K steps with stream groups; two half-batches alternating)")
     ap.add_argument("--no-double-buffer", action="store_true", help="skip the third timed region (two half-batches stepped alternately, closed-loop compatible)")
+    ap.add_argument("--no-other-configs", action="store_true", help="lift only: skip the short secondary regions of BASELINE configs[2..4] (config.other_configs)")
+    ap.add_argument("--other-steps", type=int, default=10, help="timed lockstep control steps of each secondary configuration")
+    ap.add_argument("--other-preroll", type=int, default=50, help="untimed launches before each secondary region (episode steps staggered as in the headline region)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -275,7 +334,18 @@ def main():
                                    "half can reach; `value` above is the stricter one-policy-call-per-step protocol"}
         del envs2, tapes2
 
-    st = shard.RolloutStats(dev)
+    # the end-of-rollout statistics go through the C-ABI's own collective (rsim_comm_* / rsim_allreduce_stats over RCCL) when there is more than one rank; if
+    # that communicator cannot be formed the job's torch process group carries them and the line says so (config.stats_allreduce)
+    comm, comm_note = None, None
+    if world > 1:
+        try:
+            comm = shard.hip_comm(rank, world, local_rank)
+        except Exception as e:   # noqa: BLE001
+            comm_note = f"rsim_comm_create failed ({type(e).__name__}: {e})"
+        ok = shard.max_over_ranks(0.0 if comm is not None else 1.0, dev) == 0.0   # all ranks or none
+        if not ok:
+            comm = None
+    st = shard.RolloutStats(dev, comm=comm)
     q = env.batch.tensor("qpos")
     # envs that hit the bad-state guard (RSIM_DIVERGED, MuJoCo's mj_checkPos semantics) or hold a non-finite coordinate
     st.add(env_steps=B * K, diverged=int((~torch.isfinite(q).all(dim=1)).sum().item()) + int((env.batch.tensor("diverged") > 0).sum().item()),
@@ -287,6 +357,18 @@ def main():
     need_hist = {f"contacts>{t}": int((cn[:, 0] > t).sum().item()) for t in (16, 24, 32, 48)} | {f"rows>{t}": int((cn[:, 1] > t).sum().item()) for t in (64, 80, 96, 128, 160)}   # rank-local
     tot = st.allreduce()
 
+    # ---- secondary regions: BASELINE configs[2..4] at their stated batch sizes, a short lockstep region each, so that the clock of whoever runs the
+    # default command also covers them.  After the headline region (which they cannot disturb); every rank takes part (weak scaling like the headline).
+    other = None
+    if args.config == "lift" and not args.no_other_configs:
+        env.bank_quiesce()
+        other = {}
+        for oc in ("stack", "peg", "pickplace"):
+            try:
+                other[oc] = secondary_region(oc, rank, local_rank, world, dev, args.other_steps, args.other_preroll)
+            except Exception as e:   # a failing secondary region is reported, it does not take the headline line with it
+                other[oc] = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         abytes = algorithmic_bytes_per_env_step(env, flat, dr) * B   # one control step = one launch of all B envs
         ach = abytes / (kern_ms * 1e-3) / 1e9
@@ -294,17 +376,10 @@ def main():
         lib_sha = hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16]
         sfx = "" if args.config == "lift" else "_" + args.config
 
-        def pmc(name, key):
-            try:
-                d = json.load(open(os.path.join(ROOT, "profiles", name)))
-                return d.get(key) if d.get("lib_sha16") == lib_sha else None
-            except Exception:
-                return None
-
-        traffic = pmc(f"hbm_traffic{sfx}.json", "bytes_per_launch")      # tools/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE passes), one launch of all B envs
-        valu = pmc(f"valu_count{sfx}.json", "valu_per_env_substep")      # tools/pmc_valu.py (SQ_INSTS_VALU pass on this workload)
-        issue = None
-        if valu:
+        traffic = pmc_evidence(f"hbm_traffic{sfx}.json", "bytes_per_launch", lib_sha)      # tools/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE passes), one launch of all B envs
+        valu = pmc_evidence(f"valu_count{sfx}.json", "valu_per_env_substep", lib_sha)      # tools/pmc_valu.py (SQ_INSTS_VALU pass on this workload)
+        issue = valu if isinstance(valu, str) else None       # "stale:<sha>" / "absent": said out loud, never a silent null
+        if valu and not isinstance(valu, str):
             rate = valu * B * N_SUB * K / dt   # wave-instructions per second of this GPU over the timed region
             issue = {"bound": "valu-issue", "valu_instr_per_env_substep": valu, "achieved": rate / 1e9,
                      "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instr/s", "frac": rate / VALU_ISSUE_PEAK,
@@ -330,7 +405,9 @@ def main():
                        "capacity": {"contacts": env.batch.maxcon, "rows": env.batch.maxefc, "max_contacts_needed": int(need_con), "max_rows_needed": int(need_efc), "envs_by_demand": need_hist,
                                     "note": "compiled contact / constraint-row capacity per env against the largest demand of any substep of any env over pre-roll, warm-up and "
                                             "timed region (RSIM_CAP_NEED); overflow_envs counts the envs that ever dropped one"},
+                       "other_configs": other,
                        "lib_sha16": lib_sha, "obs_dim": env.model.nobs, "action_dim": adim, "sharding": f"env-block x{world}",
+                       "stats_allreduce": st.path + (f"; {comm_note}" if comm_note else ""),
                        "diverged_envs": int(tot["diverged"]), "reward_sum": tot["reward_sum"], "successes": int(tot["successes"])},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes,

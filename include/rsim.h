@@ -202,15 +202,31 @@ enum rsim_field {
   RSIM_CAP_NEED,       /* [B,2] int32  largest number of contacts / constraint rows any substep of the env has asked for since the batch was created (what
                         *               RSIM_OVERFLOW's drops are measured against: a value above rsim_batch_limits means that substep was truncated);
                         *               sizes the compiled capacities against a workload (bench.py reports the maxima) */
+  RSIM_QFRC_APPLIED,   /* [B,nv]       mjData.qfrc_applied: user-specified generalised forces, added to the smooth forces by rsim_forward / rsim_step1 / rsim_step2 /
+                        *               rsim_step (the B = 1 compatibility entries: models/grippers/gripper_tester.py:197-202 writes its gravity compensation
+                        *               there); zeroed by rsim_reset.  The fused rsim_control_step does not read it -- nothing on robosuite's env.step path
+                        *               writes qfrc_applied */
   RSIM_FIELD_COUNT
 };
 #define RSIM_PATCH_TASK_OBJECT (-1)   /* rsim_set_reset_bank patch index: this column of a reset row is the episode's RSIM_TASK_OBJECT, not a float-table entry */
 
 const char* rsim_last_error(void);
 
-/* mujoco.MjModel.from_xml_string (binding_utils.py:1079): the MJCF->flat-model compile happens in the host language
- * (robosuite_amd/mjcf.py); this call ingests the resulting blob ("RSIMMDL1", see mjcf.to_blob). Host only, no GPU. */
+/* Ingests a compiled model blob ("RSIMMDL1": magic, entry table {name[32], dtype, count, offset}, 8-byte aligned payloads; written by rsim_mjcf_to_blob
+ * below and by robosuite_amd.mjcf.to_blob).  Host only, no GPU. */
 int rsim_model_create(const void* blob, size_t len, rsim_model** out);
+/* mujoco.MjModel.from_xml_string itself (binding_utils.py:1077-1080; MujocoXML.get_model, models/base.py:125-147; the per-reset rebuild of
+ * environments/base.py:262-269) for a host WITHOUT Python: the MJCF string robosuite assembles goes in, a model handle comes out.  The compiler is
+ * robosuite_amd/csrc/rsim_mjcf.cpp (defaults classes, bodies / joints / geoms / sites, mesh loading + convex hulls + mesh inertia, inertia from geoms,
+ * actuators, fixed tendons + tendon equalities, the collision pair list, names, the constants at qpos0: subtree masses and inverse weights); the Python
+ * compiler robosuite_amd/mjcf.py is kept as its checker (tests/test_mjcf_cpp.py).  asset_dir (NULL = none) is what relative mesh file names are resolved
+ * against, after <compiler meshdir>; robosuite writes absolute paths.  Malformed or unsupported MJCF fails with the reason in rsim_last_error(), as
+ * MuJoCo's compiler raises.  Host only, no GPU.
+ * rsim_mjcf_to_blob is the same compile stopping at the blob (what rsim_model_create ingests, what robosuite_amd.mjcf.to_blob writes): *blob is
+ * malloc'ed and released with rsim_blob_free -- for binders that cache compiled models or ship them to other ranks. */
+int rsim_model_compile(const char* xml, size_t len, const char* asset_dir, rsim_model** out);
+int rsim_mjcf_to_blob(const char* xml, size_t len, const char* asset_dir, void** blob, size_t* blob_len);
+void rsim_blob_free(void* blob);
 void rsim_model_free(rsim_model* m);
 /* scalar / size query by blob field name ("nq", "nv", ...); returns -1 if unknown */
 int rsim_model_int(const rsim_model* m, const char* name);

@@ -51,3 +51,12 @@ class OracleBackend:
 
     def contacts(self):
         return self.d.contacts()
+
+    @property
+    def nefc(self):
+        return self.d.nefc
+
+    def efc_array(self, name):
+        if name == "efc_type":
+            return np.array(self.d.efc_types(), dtype=np.int32)
+        return np.array(self.d.field(name)[: self.d.nefc])

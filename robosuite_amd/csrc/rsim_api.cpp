@@ -96,6 +96,8 @@ static int fail(const char* fmt, ...) {
   va_end(ap);
   return 1;
 }
+// for the other translation units of the library (rsim_mjcf.cpp): set the message rsim_last_error() returns.  Not part of include/rsim.h.
+extern "C" int rsim_set_error(const char* msg) { return fail("%s", msg ? msg : "error"); }
 extern "C" const char* rsim_last_error(void) { return g_err; }
 #define HIPCHK(x)                                                                  \
   do {                                                                             \
@@ -887,14 +889,11 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   b->cfg_w = b->cs <= RSIM_CS_LDS ? pick_wide(m, b->cfg, b->lim, b->lim_w) : -1;
   {
     // builds that keep the constraint Jacobian in global memory (RSIM_JGLOBAL: limits bit 2) get their per-env buffer, [B][NEFC * (NV + 1)] floats
+    // limits bit 3 (RSIM_MGLOBAL): the mass matrix behind J in the same buffer, NV * (NV + 1) floats more.  One stride for the native and the wide configuration.
     size_t jgf = 0;
-#ifdef RSIM_MGLOBAL   // prepared, not enabled: limits bit 3 = the mass matrix behind J in the same buffer, NV * (NV + 1) floats more
     if (b->lim[9] & 4) jgf = (size_t)b->lim[6] * (size_t)(b->lim[2] + 1) + ((b->lim[9] & 8) ? (size_t)b->lim[2] * (size_t)(b->lim[2] + 1) : 0);
     if (b->cfg_w >= 0 && (b->lim_w[9] & 4)) jgf = std::max(jgf, (size_t)b->lim_w[6] * (size_t)(b->lim_w[2] + 1) + ((b->lim_w[9] & 8) ? (size_t)b->lim_w[2] * (size_t)(b->lim_w[2] + 1) : 0));
-#else
-    if (b->lim[9] & 4) jgf = (size_t)b->lim[6] * (size_t)(b->lim[2] + 1);
-    if (b->cfg_w >= 0 && (b->lim_w[9] & 4)) jgf = std::max(jgf, (size_t)b->lim_w[6] * (size_t)(b->lim_w[2] + 1));
-#endif
+    b->db.jg_stride = (long long)jgf;
     if (jgf && dalloc(&b->db.jg, (size_t)B * jgf)) return 1;
   }
   b->d_cm_w = nullptr; b->d_tier[0] = b->d_tier[1] = nullptr; b->d_wlist[0] = b->d_wlist[1] = nullptr; b->d_wcount = nullptr; b->wstream = nullptr; b->tier_flip = 0;
@@ -946,7 +945,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
       {RSIM_EP_INDEX, (void**)&db.ep_index, (size_t)B, 1}, {RSIM_DIVERGED, (void**)&db.diverged, (size_t)B, 1}, {RSIM_OVERFLOW, (void**)&db.overflow, (size_t)B, 1},
       {RSIM_BANK_STALE, (void**)&db.bank_stale, (size_t)B, 1}, {RSIM_TERMINAL_OBS, (void**)&db.term_obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0},
       {RSIM_SENSORDATA, (void**)&db.sensordata, (size_t)B * m->nsensordata, 0}, {RSIM_TASK_OBJECT, (void**)&db.task_object, (size_t)B, 1},
-      {RSIM_CAP_NEED, (void**)&db.cap_need, (size_t)B * 2, 1}};
+      {RSIM_CAP_NEED, (void**)&db.cap_need, (size_t)B * 2, 1}, {RSIM_QFRC_APPLIED, (void**)&db.qfrc_applied, (size_t)B * nv, 0}};
   for (auto& fd : fields) {
     if (dalloc((float**)fd.p, fd.n)) return 1;
     b->fptr[fd.id] = *fd.p; b->fcount[fd.id] = fd.n; b->fis_int[fd.id] = fd.is_int;
@@ -1009,6 +1008,7 @@ extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) { if (join_groups(
     HIPCHK(hipMemset(b->db.qvel, 0, (size_t)B * nv * sizeof(float)));
     HIPCHK(hipMemset(b->db.qacc_ws, 0, (size_t)B * nv * sizeof(float)));
     HIPCHK(hipMemset(b->db.ctrl, 0, (size_t)B * nu * sizeof(float)));
+    HIPCHK(hipMemset(b->db.qfrc_applied, 0, (size_t)B * nv * sizeof(float)));
     HIPCHK(hipMemset(b->db.time, 0, (size_t)B * sizeof(float)));
     HIPCHK(hipMemset(b->db.cstate, 0, (size_t)B * b->cs * sizeof(float)));
     HIPCHK(hipMemset(b->db.ep_step, 0, (size_t)B * sizeof(int))); HIPCHK(hipMemset(b->db.ep_index, 0, (size_t)B * sizeof(int)));
@@ -1020,6 +1020,7 @@ extern "C" int rsim_reset(rsim_batch* b, const uint8_t* mask) { if (join_groups(
       HIPCHK(hipMemset(b->db.qvel + (size_t)e * nv, 0, nv * sizeof(float)));
       HIPCHK(hipMemset(b->db.qacc_ws + (size_t)e * nv, 0, nv * sizeof(float)));
       HIPCHK(hipMemset(b->db.ctrl + (size_t)e * nu, 0, nu * sizeof(float)));
+      HIPCHK(hipMemset(b->db.qfrc_applied + (size_t)e * nv, 0, nv * sizeof(float)));
       HIPCHK(hipMemset(b->db.time + e, 0, sizeof(float)));
       HIPCHK(hipMemset(b->db.cstate + (size_t)e * b->cs, 0, b->cs * sizeof(float)));
       HIPCHK(hipMemset(b->db.ep_step + e, 0, sizeof(int))); HIPCHK(hipMemset(b->db.done + e, 0, sizeof(int))); HIPCHK(hipMemset(b->db.needs_reset + e, 0, sizeof(int)));
@@ -1215,6 +1216,8 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
           if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
         }
         if (b->dm.task.enabled) {
+          // the reset-observation pass is no tier pass: an env that ended its episode on the wide tier gets its record from the native build like every other
+          db.tier_cur = nullptr; db.tier_next = nullptr; db.tier_pass = -1; db.wlist = nullptr; db.wcount = nullptr; db.wlist2 = nullptr; db.wcount2 = nullptr;
           e = k_reset_obs_launch[b->cfg](&b->dm, &db, b->gstream[g]);
           if (e) return fail("reset-observation kernel launch failed: %s", hipGetErrorString((hipError_t)e));
         }
@@ -1301,6 +1304,9 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
       // state, no reward.  The terminal record of the finished episode was moved to RSIM_TERMINAL_OBS by the control step.
       DBatch db2 = b->db;
       db2.order = nullptr; db2.cost = nullptr;
+      // not a tier pass: with tier_cur set the native-pass branch of step_body would skip every env that ended its episode on the wide tier (its
+      // RSIM_OBS would keep the terminal record) and could append to a redo list nobody walks any more
+      db2.tier_cur = nullptr; db2.tier_next = nullptr; db2.tier_pass = -1; db2.wlist = nullptr; db2.wcount = nullptr; db2.wlist2 = nullptr; db2.wcount2 = nullptr;
       e = k_reset_obs_launch[b->cfg](&b->dm, &db2, b->stream);
       if (e) return fail("reset-observation kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     }
@@ -1315,7 +1321,18 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
 // robosuite's own sim.forward() before such a read does -- instead of handing out the values of some earlier launch.
 static bool derived_field(int f) { return (f >= RSIM_XPOS && f <= RSIM_NITER) || f == RSIM_SENSORDATA; }
 extern "C" int rsim_forward(rsim_batch* b);
-static int refresh_derived(rsim_batch* b, int field) { return (derived_field(field) && b->derived_stale) ? rsim_forward(b) : 0; }
+// The refresh is a READ: it must not change what later control steps compute, nor what the drop / demand metrics say (round-4 advisor finding).  The debug
+// forward therefore runs without the overflow / cap_need counters (it has the native capacity only: for an env the wide tier is stepping, the derived
+// contact / force arrays hold the first NCON contacts / NEFC rows of the native configuration -- documented in include/rsim.h), without the narrow phase's
+// warm-start records and broadphase list (a cold run: same contacts to the MPR tolerance) and without writing the state arrays back (RF_NOSTORE).
+static int refresh_forward(rsim_batch* b) {
+  DBatch keep = b->db;
+  b->db.overflow = nullptr; b->db.cap_need = nullptr; b->db.mprc = nullptr; b->db.bpl = nullptr;
+  const int r = launch(b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_DEBUG | RF_NOSTORE);
+  b->db.overflow = keep.overflow; b->db.cap_need = keep.cap_need; b->db.mprc = keep.mprc; b->db.bpl = keep.bpl;
+  return r;
+}
+static int refresh_derived(rsim_batch* b, int field) { return (derived_field(field) && b->derived_stale) ? refresh_forward(b) : 0; }
 extern "C" int rsim_forward(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_DEBUG); }
 extern "C" int rsim_step1(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL | RF_DEBUG); }
 extern "C" int rsim_step2(rsim_batch* b) { return launch(b, nullptr, 1, RF_POSVEL | RF_ACTSOLVE | RF_INTEGRATE | RF_DEBUG); }
@@ -1655,7 +1672,7 @@ extern "C" int rsim_contacts(rsim_batch* b, int env, int max_out, rsim_contact* 
 }
 
 static int refresh_cache(rsim_batch* b, int env) {
-  if (b->derived_stale && rsim_forward(b)) return 1;   // Jacobians after a fused control step: of the current state
+  if (b->derived_stale && refresh_forward(b)) return 1;   // Jacobians after a fused control step: of the current state
   if (b->cache_gen == b->gen && b->cache_env == env) return 0;
   rsim_model* m = b->m;
   HIPCHK(hipSetDevice(b->device));
@@ -1821,7 +1838,8 @@ static void* rccl_sym(const char* name) {
   }();
   return h ? dlsym(h, name) : nullptr;
 }
-#define RCCL_FN(var, name, type) type var = (type)rccl_sym(name); if (!var) return fail("%s: librccl.so / %s not found in the process (%s)", __func__, name, dlerror() ? dlerror() : "no dlerror")
+// (dlerror() clears the pending message when it is read: capture it once)
+#define RCCL_FN(var, name, type) type var = (type)rccl_sym(name); if (!var) { const char* de_ = dlerror(); return fail("%s: librccl.so / %s not found in the process (%s)", __func__, name, de_ ? de_ : "no dlerror"); }
 typedef ncclResult_t (*fn_uid)(ncclUniqueId*);
 typedef ncclResult_t (*fn_init)(ncclComm_t*, int, ncclUniqueId, int);
 typedef ncclResult_t (*fn_allreduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);

@@ -195,7 +195,10 @@ struct DBatch {
   int* task_object;      // [B] PickPlace single-object mode 1: the object of the env's current episode (RSIM_TASK_OBJECT)
   float* sensordata;     // [B][nsensordata] (debug build of the kernel: rsim_step.hip sensor_acc)
   int* bpl;              // [B][5][64] or null: broadphase pair list (rsim_step.hip collision(): sphere centres at build time, packed pair constants, pair indices)
-  float* jg;             // RSIM_JGLOBAL builds: [B][NEFC * (NV + 1)] constraint Jacobians (the kernel's per-env scratch; null otherwise)
+  float* qfrc_applied;   // [B][nv] mjData.qfrc_applied: added to the smooth forces by the debug form of the kernel (rsim_forward / step1 / step2 / step); the fused control step ignores it
+  float* jg;             // RSIM_JGLOBAL builds: per-env scratch in global memory, [B][jg_stride] floats: the constraint Jacobian, NEFC * (NV + 1), then (RSIM_MGLOBAL) the mass matrix, NV * (NV + 1); null otherwise
+  long long jg_stride;   // floats per env = the largest need of the configurations that step this batch (native and wide tier): ONE stride for all of them --
+                         // with per-configuration strides the wide pass's env i overlapped the native pass's envs 2 i, 2 i + 1 while both passes were running
   float* mprc;           // [B][npair][12] or null: the separating direction (x, y, z, valid) each candidate pair's last convex narrow-phase run ended on
                          // (warm start of the next substep's run, see convex_convex); zeroed whenever the host writes positions
   const int* order;      // [B] or null (identity)
@@ -244,4 +247,5 @@ enum {
   RF_OBS = 64,       // observation / reward epilogue after the last substep
   RF_EPISODE = 128,  // episode step counter, done flag, on-device reset from the bank
   RF_RESET_ONLY = 256,  // only the envs whose needs_reset flag is set (the reset-observation pass after a control step)
+  RF_NOSTORE = 512,     // debug form only: leave the state arrays (qpos .. time, warm start, controller state) as they are -- the refresh of the derived arrays on read
 };

@@ -1,0 +1,1432 @@
+// rsim_mjcf.cpp -- MJCF -> flat model compiler behind rsim_model_compile / rsim_mjcf_to_blob (include/rsim.h).
+//
+// Replaces mujoco.MjModel.from_xml_string (reference call sites utils/binding_utils.py:1077-1080, models/base.py:125-147, robots/robot.py:217-223) for a
+// binder that has no Python: robosuite assembles ONE MJCF string per reset (environments/base.py:262-269) and this file turns that string into the
+// "RSIMMDL1" blob rsim_model_create ingests.  Host only, no GPU, no dependency beyond the C++ standard library.
+//
+// It is the C++ restatement of robosuite_amd/mjcf.py (compile_mjcf + _set_const + to_blob), which stays in the tree as the CHECKER: tests/test_mjcf_cpp.py holds
+// the blob written here to mjcf.to_blob field by field -- integers, names and every float that comes straight out of the XML bit for bit, derived floats
+// (inertia frames through a 3 x 3 eigen-decomposition, inverse weights through M^-1, convex hulls) to rounding.  Same MJCF subset, same conventions (MuJoCo
+// documentation, XML reference / "Computation" chapter [3P]): ids in depth-first document order, world body 0, quaternions (w, x, y, z), defaults classes,
+// inertiagrouprange, autolimits, angle / eulerseq.  Two third-party routines of the Python compiler are written out here: the 3-d convex hull (scipy / qhull
+// there, a quickhull with per-facet outside sets below) and the symmetric eigen-solver / matrix inverse (LAPACK there, Jacobi rotations and a Cholesky
+// factorisation below).
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rsim.h"
+
+namespace {
+
+struct MjcfError : std::runtime_error { using std::runtime_error::runtime_error; };
+[[noreturn]] void err(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  throw MjcfError(buf);
+}
+constexpr double MINVAL = 1e-15;
+enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
+enum { GEOM_PLANE = 0, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH };
+typedef std::vector<double> vecd;
+
+// ------------------------------------------------------------------------------------------------------------------ XML (elements + attributes; text ignored)
+struct Xml {
+  std::string tag;
+  std::vector<std::pair<std::string, std::string>> attr;   // document order, last assignment wins
+  std::vector<std::unique_ptr<Xml>> kids;
+  const std::string* get(const std::string& k) const { for (auto& a : attr) if (a.first == k) return &a.second; return nullptr; }
+  std::string gets(const std::string& k, const std::string& dflt) const { const std::string* s = get(k); return s ? *s : dflt; }
+  void set(const std::string& k, const std::string& v) { for (auto& a : attr) if (a.first == k) { a.second = v; return; } attr.emplace_back(k, v); }
+  const Xml* find(const std::string& t) const { for (auto& c : kids) if (c->tag == t) return c.get(); return nullptr; }
+};
+struct XmlParser {
+  const char* s; size_t n, p = 0;
+  XmlParser(const char* s_, size_t n_) : s(s_), n(n_) {}
+  bool starts(const char* lit) const { size_t l = strlen(lit); return p + l <= n && memcmp(s + p, lit, l) == 0; }
+  void skip_ws() { while (p < n && (s[p] == ' ' || s[p] == '\t' || s[p] == '\r' || s[p] == '\n')) p++; }
+  void skip_until(const char* lit) { size_t l = strlen(lit); while (p + l <= n && memcmp(s + p, lit, l) != 0) p++; if (p + l > n) err("XML parse error: unterminated construct"); p += l; }
+  void skip_misc() {   // whitespace, comments, processing instructions, doctype, character data between elements
+    for (;;) {
+      while (p < n && s[p] != '<') p++;
+      if (p >= n) return;
+      if (starts("<!--")) skip_until("-->");
+      else if (starts("<?")) skip_until("?>");
+      else if (starts("<![CDATA[")) skip_until("]]>");
+      else if (starts("<!")) skip_until(">");
+      else return;
+    }
+  }
+  static bool name_char(char c) { return isalnum((unsigned char)c) || c == '_' || c == '-' || c == '.' || c == ':'; }
+  std::string name() { size_t a = p; while (p < n && name_char(s[p])) p++; if (p == a) err("XML parse error: name expected at offset %zu", p); return std::string(s + a, p - a); }
+  static std::string decode(const std::string& v) {
+    if (v.find('&') == std::string::npos) return v;
+    std::string o;
+    for (size_t i = 0; i < v.size(); i++) {
+      if (v[i] != '&') { o.push_back(v[i]); continue; }
+      size_t e = v.find(';', i);
+      if (e == std::string::npos) err("XML parse error: bad entity");
+      std::string ent = v.substr(i + 1, e - i - 1);
+      if (ent == "lt") o.push_back('<'); else if (ent == "gt") o.push_back('>'); else if (ent == "amp") o.push_back('&'); else if (ent == "quot") o.push_back('"');
+      else if (ent == "apos") o.push_back('\'');
+      else if (!ent.empty() && ent[0] == '#') {
+        long c = ent.size() > 1 && (ent[1] == 'x' || ent[1] == 'X') ? strtol(ent.c_str() + 2, nullptr, 16) : strtol(ent.c_str() + 1, nullptr, 10);
+        if (c < 0x80) o.push_back((char)c);
+        else if (c < 0x800) { o.push_back((char)(0xC0 | (c >> 6))); o.push_back((char)(0x80 | (c & 0x3F))); }
+        else { o.push_back((char)(0xE0 | (c >> 12))); o.push_back((char)(0x80 | ((c >> 6) & 0x3F))); o.push_back((char)(0x80 | (c & 0x3F))); }
+      } else err("XML parse error: unknown entity &%s;", ent.c_str());
+      i = e;
+    }
+    return o;
+  }
+  std::unique_ptr<Xml> element() {
+    if (p >= n || s[p] != '<') err("XML parse error: '<' expected at offset %zu", p);
+    p++;
+    std::unique_ptr<Xml> e(new Xml());
+    e->tag = name();
+    for (;;) {
+      skip_ws();
+      if (p >= n) err("XML parse error: unexpected end inside <%s>", e->tag.c_str());
+      if (s[p] == '/') { if (p + 1 >= n || s[p + 1] != '>') err("XML parse error: '/>' expected"); p += 2; return e; }
+      if (s[p] == '>') { p++; break; }
+      std::string k = name();
+      skip_ws();
+      if (p >= n || s[p] != '=') err("XML parse error: '=' expected after attribute %s", k.c_str());
+      p++; skip_ws();
+      if (p >= n || (s[p] != '"' && s[p] != '\'')) err("XML parse error: quoted value expected for attribute %s", k.c_str());
+      char q = s[p++];
+      size_t a = p;
+      while (p < n && s[p] != q) p++;
+      if (p >= n) err("XML parse error: unterminated attribute value");
+      if (e->get(k)) err("XML parse error: duplicate attribute %s", k.c_str());
+      e->attr.emplace_back(k, decode(std::string(s + a, p - a)));
+      p++;
+    }
+    for (;;) {
+      skip_misc();
+      if (p >= n) err("XML parse error: missing </%s>", e->tag.c_str());
+      if (starts("</")) {
+        p += 2;
+        std::string t = name();
+        if (t != e->tag) err("XML parse error: mismatched tag </%s> for <%s>", t.c_str(), e->tag.c_str());
+        skip_ws();
+        if (p >= n || s[p] != '>') err("XML parse error: '>' expected");
+        p++;
+        return e;
+      }
+      e->kids.push_back(element());
+    }
+  }
+  std::unique_ptr<Xml> document() {
+    skip_misc();
+    if (p >= n) err("XML parse error: no element found");
+    std::unique_ptr<Xml> r = element();
+    skip_misc();
+    if (p < n) err("XML parse error: junk after document element");
+    return r;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------------ numbers, small math
+std::vector<std::string> split_ws(const std::string& s) {
+  std::vector<std::string> o;
+  size_t i = 0;
+  while (i < s.size()) {
+    while (i < s.size() && isspace((unsigned char)s[i])) i++;
+    size_t a = i;
+    while (i < s.size() && !isspace((unsigned char)s[i])) i++;
+    if (i > a) o.push_back(s.substr(a, i - a));
+  }
+  return o;
+}
+double to_double(const std::string& t) {
+  std::vector<std::string> w = split_ws(t);
+  if (w.size() != 1) err("could not convert string to float: '%s'", t.c_str());
+  char* e = nullptr;
+  double v = strtod(w[0].c_str(), &e);
+  if (e == w[0].c_str() || *e) err("could not convert string to float: '%s'", t.c_str());
+  return v;
+}
+long to_int(const std::string& t) {
+  std::vector<std::string> w = split_ws(t);
+  if (w.size() != 1) err("invalid literal for int(): '%s'", t.c_str());
+  char* e = nullptr;
+  long v = strtol(w[0].c_str(), &e, 10);
+  if (e == w[0].c_str() || *e) err("invalid literal for int(): '%s'", t.c_str());
+  return v;
+}
+// mjcf._floats: n < 0 = any length; with a default, a shorter list overwrites its head
+bool floats(const std::string* s, int n, const vecd* dflt, vecd& out) {
+  if (!s) { if (!dflt) return false; out = *dflt; return true; }
+  out.clear();
+  for (auto& w : split_ws(*s)) out.push_back(to_double(w));
+  if (n >= 0 && (int)out.size() != n) {
+    if (dflt && (int)out.size() < n) { vecd o = *dflt; for (size_t i = 0; i < out.size(); i++) o[i] = out[i]; out = o; return true; }
+    err("expected %d numbers, got '%s'", n, s->c_str());
+  }
+  return true;
+}
+vecd floats_d(const Xml& e, const char* k, int n, std::initializer_list<double> d) { vecd dv(d), o; floats(e.get(k), n, &dv, o); return o; }
+double attr_d(const Xml& e, const char* k, double d) { const std::string* s = e.get(k); return s ? to_double(*s) : d; }
+long attr_i(const Xml& e, const char* k, long d) { const std::string* s = e.get(k); return s ? to_int(*s) : d; }
+
+struct Q { double w, x, y, z; };
+struct V3 { double x, y, z; };
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// numpy.linalg.norm of a short vector: sqrt of the plain sum of squares
+inline double norm(V3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+Q qmul(Q a, Q b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+          a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+Q qnormalize(Q q) {
+  double nn = std::sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  if (nn < MINVAL) return {1, 0, 0, 0};
+  return {q.w / nn, q.x / nn, q.y / nn, q.z / nn};
+}
+struct M3 { double m[3][3]; };
+M3 q2m(Q q) {
+  double w = q.w, x = q.x, y = q.y, z = q.z;
+  M3 R = {{{w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)},
+           {2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)},
+           {2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z}}};
+  return R;
+}
+Q m2q(const M3& R) {
+  double t = R.m[0][0] + R.m[1][1] + R.m[2][2];
+  Q q;
+  if (t > 0) { double s = std::sqrt(t + 1.0) * 2; q = {0.25 * s, (R.m[2][1] - R.m[1][2]) / s, (R.m[0][2] - R.m[2][0]) / s, (R.m[1][0] - R.m[0][1]) / s}; }
+  else if (R.m[0][0] > R.m[1][1] && R.m[0][0] > R.m[2][2]) {
+    double s = std::sqrt(1.0 + R.m[0][0] - R.m[1][1] - R.m[2][2]) * 2;
+    q = {(R.m[2][1] - R.m[1][2]) / s, 0.25 * s, (R.m[0][1] + R.m[1][0]) / s, (R.m[0][2] + R.m[2][0]) / s};
+  } else if (R.m[1][1] > R.m[2][2]) {
+    double s = std::sqrt(1.0 + R.m[1][1] - R.m[0][0] - R.m[2][2]) * 2;
+    q = {(R.m[0][2] - R.m[2][0]) / s, (R.m[0][1] + R.m[1][0]) / s, 0.25 * s, (R.m[1][2] + R.m[2][1]) / s};
+  } else {
+    double s = std::sqrt(1.0 + R.m[2][2] - R.m[0][0] - R.m[1][1]) * 2;
+    q = {(R.m[1][0] - R.m[0][1]) / s, (R.m[0][2] + R.m[2][0]) / s, (R.m[1][2] + R.m[2][1]) / s, 0.25 * s};
+  }
+  return qnormalize(q);
+}
+Q axisangle2quat(V3 axis, double angle) {
+  double nn = norm(axis);
+  if (nn < MINVAL) return {1, 0, 0, 0};
+  axis = {axis.x / nn, axis.y / nn, axis.z / nn};
+  double c = std::cos(angle / 2), s = std::sin(angle / 2);
+  return {c, axis.x * s, axis.y * s, axis.z * s};
+}
+Q quat_z2vec(V3 v) {
+  double nn = norm(v);
+  if (nn < MINVAL) return {1, 0, 0, 0};
+  v = {v.x / nn, v.y / nn, v.z / nn};
+  V3 ax = cross({0, 0, 1}, v);
+  double s = norm(ax);
+  if (s < 1e-10) return v.z > 0 ? Q{1, 0, 0, 0} : Q{0, 1, 0, 0};
+  double ang = std::atan2(s, v.z);
+  return axisangle2quat({ax.x / s, ax.y / s, ax.z / s}, ang);
+}
+V3 mv(const M3& R, V3 v) { return {R.m[0][0] * v.x + R.m[0][1] * v.y + R.m[0][2] * v.z, R.m[1][0] * v.x + R.m[1][1] * v.y + R.m[1][2] * v.z, R.m[2][0] * v.x + R.m[2][1] * v.y + R.m[2][2] * v.z}; }
+M3 mm(const M3& A, const M3& B) { M3 C; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += A.m[i][k] * B.m[k][j]; C.m[i][j] = s; } return C; }
+M3 mt(const M3& A) { M3 C; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C.m[i][j] = A.m[j][i]; return C; }
+double det3(const M3& A) {
+  return A.m[0][0] * (A.m[1][1] * A.m[2][2] - A.m[1][2] * A.m[2][1]) - A.m[0][1] * (A.m[1][0] * A.m[2][2] - A.m[1][2] * A.m[2][0]) + A.m[0][2] * (A.m[1][0] * A.m[2][1] - A.m[1][1] * A.m[2][0]);
+}
+// symmetric 3 x 3 eigen-decomposition (cyclic Jacobi); eigenvalues DESCENDING, V's columns the eigenvectors, det V = +1 (numpy.linalg.eigh + the compiler's
+// reordering).  The eigenvectors' signs are a convention LAPACK does not document: here each of the first two columns is made to have its largest-magnitude
+// component positive.  The frame differs from the Python compiler's by axis flips at most -- the same inertia ellipsoid (tests compare the tensors).
+void eigh3_desc(const M3& A, double w[3], M3& V) {
+  double a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a[i][j] = 0.5 * (A.m[i][j] + A.m[j][i]);
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    double dg = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+    if (off <= 1e-32 * dg || off == 0.0) break;
+    for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
+      if (a[p][q] == 0.0) continue;
+      double th = (a[q][q] - a[p][p]) / (2 * a[p][q]);
+      double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+      double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+      for (int k = 0; k < 3; k++) { double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq; }
+      for (int k = 0; k < 3; k++) { double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk; }
+      for (int k = 0; k < 3; k++) { double vkp = v[k][p], vkq = v[k][q]; v[k][p] = c * vkp - s * vkq; v[k][q] = s * vkp + c * vkq; }
+    }
+  }
+  int ord[3] = {0, 1, 2};
+  std::stable_sort(ord, ord + 3, [&](int i, int j) { return a[i][i] > a[j][j]; });
+  for (int c = 0; c < 3; c++) { w[c] = a[ord[c]][ord[c]]; for (int r = 0; r < 3; r++) V.m[r][c] = v[r][ord[c]]; }
+  for (int c = 0; c < 2; c++) {
+    int big = 0;
+    for (int r = 1; r < 3; r++) if (std::fabs(V.m[r][c]) > std::fabs(V.m[big][c])) big = r;
+    if (V.m[big][c] < 0) for (int r = 0; r < 3; r++) V.m[r][c] = -V.m[r][c];
+  }
+  if (det3(V) < 0) for (int r = 0; r < 3; r++) V.m[r][2] = -V.m[r][2];
+}
+
+// ------------------------------------------------------------------------------------------------------------------ meshes
+struct Mesh3 { std::vector<V3> v; std::vector<std::array<int, 3>> f; };
+std::string read_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) err("mesh file not found: %s", path.c_str());
+  return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+inline bool lex_less(const V3& a, const V3& b) { return a.x != b.x ? a.x < b.x : (a.y != b.y ? a.y < b.y : a.z < b.z); }
+// numpy.unique(rows, axis=0, return_inverse=True): unique vertices in lexicographic order
+void unique_rows(const std::vector<V3>& flat, std::vector<V3>& uniq, std::vector<int>& inv) {
+  std::vector<int> ord(flat.size());
+  for (size_t i = 0; i < ord.size(); i++) ord[i] = (int)i;
+  std::sort(ord.begin(), ord.end(), [&](int a, int b) { return lex_less(flat[a], flat[b]); });
+  inv.assign(flat.size(), 0);
+  uniq.clear();
+  for (size_t k = 0; k < ord.size(); k++) {
+    const V3& p = flat[ord[k]];
+    if (uniq.empty() || uniq.back().x != p.x || uniq.back().y != p.y || uniq.back().z != p.z) uniq.push_back(p);
+    inv[ord[k]] = (int)uniq.size() - 1;
+  }
+}
+Mesh3 load_stl(const std::string& path) {
+  std::string d = read_file(path);
+  std::vector<V3> flat;
+  bool binary = false;
+  if (d.size() >= 84) {
+    uint32_t ntri; memcpy(&ntri, d.data() + 80, 4);
+    if (84 + (size_t)ntri * 50 == d.size()) {
+      binary = true;
+      flat.reserve(3 * (size_t)ntri);
+      for (uint32_t t = 0; t < ntri; t++) {
+        float v[9]; memcpy(v, d.data() + 84 + 50 * (size_t)t + 12, 36);
+        for (int k = 0; k < 3; k++) flat.push_back({(double)v[3 * k], (double)v[3 * k + 1], (double)v[3 * k + 2]});
+      }
+    }
+  }
+  if (!binary) {
+    size_t i = 0;
+    while (i < d.size()) {
+      size_t e = d.find('\n', i); if (e == std::string::npos) e = d.size();
+      std::string line = d.substr(i, e - i);
+      i = e + 1;
+      std::vector<std::string> w = split_ws(line);
+      if (!w.empty() && w[0].compare(0, 6, "vertex") == 0 && w.size() >= 4) flat.push_back({to_double(w[1]), to_double(w[2]), to_double(w[3])});
+    }
+  }
+  Mesh3 m;
+  std::vector<int> inv;
+  unique_rows(flat, m.v, inv);
+  for (size_t t = 0; t + 2 < inv.size(); t += 3) m.f.push_back({inv[t], inv[t + 1], inv[t + 2]});
+  return m;
+}
+Mesh3 load_obj(const std::string& path) {
+  std::string d = read_file(path);
+  Mesh3 m;
+  size_t i = 0;
+  while (i < d.size()) {
+    size_t e = d.find('\n', i); if (e == std::string::npos) e = d.size();
+    std::vector<std::string> w = split_ws(d.substr(i, e - i));
+    i = e + 1;
+    if (w.empty()) continue;
+    if (w[0] == "v" && w.size() >= 4) m.v.push_back({to_double(w[1]), to_double(w[2]), to_double(w[3])});
+    else if (w[0] == "f") {
+      std::vector<int> idx;
+      for (size_t k = 1; k < w.size(); k++) idx.push_back((int)to_int(w[k].substr(0, w[k].find('/'))) - 1);
+      for (size_t k = 1; k + 1 < idx.size(); k++) m.f.push_back({idx[0], idx[k], idx[k + 1]});
+    }
+  }
+  return m;
+}
+Mesh3 load_msh(const std::string& path) {
+  std::string d = read_file(path);
+  if (d.size() < 16) err("bad .msh file: %s", path.c_str());
+  int32_t h[4]; memcpy(h, d.data(), 16);
+  size_t off = 16;
+  Mesh3 m;
+  if (off + 12 * (size_t)h[0] > d.size()) err("bad .msh file: %s", path.c_str());
+  for (int i = 0; i < h[0]; i++) { float v[3]; memcpy(v, d.data() + off + 12 * (size_t)i, 12); m.v.push_back({(double)v[0], (double)v[1], (double)v[2]}); }
+  off += 12 * (size_t)h[0] + 12 * (size_t)h[1] + 8 * (size_t)h[2];
+  if (off + 12 * (size_t)h[3] > d.size()) err("bad .msh file: %s", path.c_str());
+  for (int i = 0; i < h[3]; i++) { int32_t f[3]; memcpy(f, d.data() + off + 12 * (size_t)i, 12); m.f.push_back({f[0], f[1], f[2]}); }
+  return m;
+}
+Mesh3 load_mesh(const std::string& path) {
+  size_t dot_ = path.rfind('.');
+  std::string ext = dot_ == std::string::npos ? "" : path.substr(dot_);
+  for (auto& c : ext) c = (char)tolower((unsigned char)c);
+  if (ext == ".stl") return load_stl(path);
+  if (ext == ".obj") return load_obj(path);
+  if (ext == ".msh") return load_msh(path);
+  err("unsupported mesh format: %s", path.c_str());
+}
+
+// 3-d convex hull: quickhull with per-facet outside sets.  Returns the indices (ascending) of the input points that are hull vertices and the triangles over
+// those indices, oriented outwards.  A point enters the hull only if it lies farther than `eps` outside a facet (points on a facet or on an edge, the common
+// case in CAD meshes, never do -- what qhull's merged facets amount to).
+struct Hull { std::vector<int> vert; std::vector<std::array<int, 3>> tri; };
+Hull quickhull(const std::vector<V3>& P);
+// The hull's vertices are the EXTREME points only: a point that quickhull picked up on the way and that ends up inside a flat facet or on a straight edge of the
+// final hull (its incident triangles lie in fewer than three distinct planes) is dropped and the hull of the rest is taken again -- what qhull's facet merging
+// does to such points, and fewer vertices for the kernel's support scans.
+Hull convex_hull(const std::vector<V3>& P) {
+  std::vector<int> idx(P.size());
+  for (size_t i = 0; i < idx.size(); i++) idx[i] = (int)i;
+  std::vector<V3> pts = P;
+  for (int round = 0; round < 8; round++) {
+    Hull h = quickhull(pts);
+    V3 lo = pts[0], hi = pts[0];
+    for (auto& p : pts) { lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)}; hi = {std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z)}; }
+    const double scale = std::max({std::fabs(lo.x), std::fabs(lo.y), std::fabs(lo.z), std::fabs(hi.x), std::fabs(hi.y), std::fabs(hi.z), 1e-300});
+    const double tol = 64 * 2.220446049250313e-16 * scale;
+    std::vector<std::vector<int>> inc(pts.size());
+    for (size_t t = 0; t < h.tri.size(); t++) for (int k = 0; k < 3; k++) inc[h.tri[t][k]].push_back((int)t);
+    std::vector<V3> nrm(h.tri.size());
+    std::vector<double> off(h.tri.size());
+    for (size_t t = 0; t < h.tri.size(); t++) {
+      V3 nn = cross(pts[h.tri[t][1]] - pts[h.tri[t][0]], pts[h.tri[t][2]] - pts[h.tri[t][0]]);
+      double l = norm(nn);
+      nrm[t] = l > 0 ? nn * (1.0 / l) : V3{0, 0, 0};
+      off[t] = dot(nrm[t], pts[h.tri[t][0]]);
+    }
+    std::vector<char> drop(pts.size(), 0);
+    int ndrop = 0;
+    for (int v : h.vert) {
+      std::vector<int> planes;   // representative triangles of the distinct planes around v
+      for (int t : inc[v]) {
+        bool same = false;
+        for (int r : planes) {
+          if (dot(nrm[r], nrm[t]) < 0.5) continue;
+          double far = 0;
+          for (int k = 0; k < 3; k++) far = std::max(far, std::fabs(dot(nrm[r], pts[h.tri[t][k]]) - off[r]));
+          if (far <= tol) { same = true; break; }
+        }
+        if (!same) planes.push_back(t);
+      }
+      if (planes.size() < 3) { drop[v] = 1; ndrop++; }
+    }
+    if (!ndrop || round == 7) {
+      Hull out;
+      for (int v : h.vert) out.vert.push_back(idx[v]);
+      for (auto& t : h.tri) out.tri.push_back({idx[t[0]], idx[t[1]], idx[t[2]]});
+      std::sort(out.vert.begin(), out.vert.end());
+      return out;
+    }
+    std::vector<V3> np; std::vector<int> ni;
+    for (int v : h.vert) if (!drop[v]) { np.push_back(pts[v]); ni.push_back(idx[v]); }
+    pts.swap(np); idx.swap(ni);
+  }
+  err("convex hull: internal error");
+}
+Hull quickhull(const std::vector<V3>& P) {
+  const int n = (int)P.size();
+  if (n < 4) err("convex hull: fewer than 4 points");
+  V3 lo = P[0], hi = P[0];
+  for (auto& p : P) { lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)}; hi = {std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z)}; }
+  const double scale = std::max({std::fabs(lo.x), std::fabs(lo.y), std::fabs(lo.z), std::fabs(hi.x), std::fabs(hi.y), std::fabs(hi.z), 1e-300});
+  const double eps = 64 * 2.220446049250313e-16 * scale;
+  struct Face { int v[3]; int adj[3]; V3 n; double d; bool alive; std::vector<int> out; };   // adj[k]: face across edge (v[k], v[(k + 1) % 3]); unit normal n, plane n . x = d
+  std::vector<Face> F;
+  auto make = [&](int a, int b, int c) {
+    Face f; f.v[0] = a; f.v[1] = b; f.v[2] = c; f.adj[0] = f.adj[1] = f.adj[2] = -1; f.alive = true;
+    V3 nn = cross(P[b] - P[a], P[c] - P[a]);
+    double l = norm(nn);
+    f.n = l > 0 ? nn * (1.0 / l) : V3{0, 0, 0};
+    f.d = dot(f.n, P[a]);
+    F.push_back(f);
+    return (int)F.size() - 1;
+  };
+  auto dist = [&](const Face& f, int p) { return dot(f.n, P[p]) - f.d; };
+  // initial simplex: extreme points along x, farthest from that line, farthest from that plane
+  int i0 = 0, i1 = 0;
+  for (int i = 0; i < n; i++) { if (lex_less(P[i], P[i0])) i0 = i; if (lex_less(P[i1], P[i])) i1 = i; }
+  int i2 = -1; double best = -1;
+  { V3 u = P[i1] - P[i0]; double ul = norm(u); if (ul == 0) err("convex hull: degenerate point set"); u = u * (1.0 / ul);
+    for (int i = 0; i < n; i++) { V3 w = P[i] - P[i0]; V3 r = w - u * dot(w, u); double dd = dot(r, r); if (dd > best) { best = dd; i2 = i; } } }
+  if (best <= eps * eps) err("convex hull: points are collinear");
+  int i3 = -1; best = -1;
+  { V3 nn = cross(P[i1] - P[i0], P[i2] - P[i0]); nn = nn * (1.0 / norm(nn));
+    for (int i = 0; i < n; i++) { double dd = std::fabs(dot(nn, P[i] - P[i0])); if (dd > best) { best = dd; i3 = i; } } }
+  if (best <= eps) err("convex hull: points are coplanar");
+  { V3 nn = cross(P[i1] - P[i0], P[i2] - P[i0]); if (dot(nn, P[i3] - P[i0]) > 0) std::swap(i1, i2); }   // (i0, i1, i2) faces away from i3
+  int f0 = make(i0, i1, i2), f1 = make(i0, i3, i1), f2 = make(i1, i3, i2), f3 = make(i2, i3, i0);
+  auto link = [&](int a, int b) {   // set adjacency of faces a and b across their shared edge
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+      if (F[a].v[i] == F[b].v[(j + 1) % 3] && F[a].v[(i + 1) % 3] == F[b].v[j]) { F[a].adj[i] = b; F[b].adj[j] = a; }
+  };
+  link(f0, f1); link(f0, f2); link(f0, f3); link(f1, f2); link(f2, f3); link(f3, f1);
+  for (int p = 0; p < n; p++) {
+    if (p == i0 || p == i1 || p == i2 || p == i3) continue;
+    int bf = -1; double bd = eps;
+    for (int f = 0; f < 4; f++) { double dd = dist(F[f], p); if (dd > bd) { bd = dd; bf = f; } }
+    if (bf >= 0) F[bf].out.push_back(p);
+  }
+  std::vector<int> stack = {f0, f1, f2, f3};
+  std::vector<int> visible, mark;
+  while (!stack.empty()) {
+    int fi = stack.back(); stack.pop_back();
+    if (!F[fi].alive || F[fi].out.empty()) continue;
+    int apex = -1; double bd = -1;
+    for (int p : F[fi].out) { double dd = dist(F[fi], p); if (dd > bd) { bd = dd; apex = p; } }
+    // faces visible from the apex (flood fill over adjacency), horizon edges in order
+    visible.clear();
+    mark.assign(F.size(), 0);
+    std::vector<int> todo = {fi};
+    mark[fi] = 1;
+    while (!todo.empty()) {
+      int f = todo.back(); todo.pop_back();
+      visible.push_back(f);
+      for (int k = 0; k < 3; k++) { int g = F[f].adj[k]; if (g >= 0 && !mark[g] && F[g].alive && dist(F[g], apex) > eps) { mark[g] = 1; todo.push_back(g); } }
+    }
+    struct Edge { int a, b, across; };
+    std::vector<Edge> horizon;
+    for (int f : visible) for (int k = 0; k < 3; k++) { int g = F[f].adj[k]; if (g < 0 || !mark[g]) horizon.push_back({F[f].v[k], F[f].v[(k + 1) % 3], g}); }
+    std::vector<int> orphans;
+    for (int f : visible) { F[f].alive = false; for (int p : F[f].out) if (p != apex) orphans.push_back(p); F[f].out.clear(); }
+    std::vector<int> fresh;
+    std::map<int, int> from, to;    // new faces by the horizon vertex their edge starts / ends at
+    for (auto& e : horizon) {
+      int nf = make(e.a, e.b, apex);
+      fresh.push_back(nf);
+      F[nf].adj[0] = e.across;
+      if (e.across >= 0) for (int k = 0; k < 3; k++) if (F[e.across].v[k] == e.b && F[e.across].v[(k + 1) % 3] == e.a) F[e.across].adj[k] = nf;
+      from[e.a] = nf; to[e.b] = nf;
+    }
+    for (int nf : fresh) {          // edge 1 = (b, apex) borders the new face whose edge starts at b; edge 2 = (apex, a) the one whose edge ends at a
+      F[nf].adj[1] = from.count(F[nf].v[1]) ? from[F[nf].v[1]] : -1;
+      F[nf].adj[2] = to.count(F[nf].v[0]) ? to[F[nf].v[0]] : -1;
+    }
+    for (int p : orphans) {
+      int bf = -1; double bd2 = eps;
+      for (int nf : fresh) { double dd = dist(F[nf], p); if (dd > bd2) { bd2 = dd; bf = nf; } }
+      if (bf >= 0) F[bf].out.push_back(p);
+    }
+    for (int nf : fresh) if (!F[nf].out.empty()) stack.push_back(nf);
+  }
+  Hull h;
+  std::set<int> vs;
+  for (auto& f : F) if (f.alive) { h.tri.push_back({f.v[0], f.v[1], f.v[2]}); vs.insert(f.v[0]); vs.insert(f.v[1]); vs.insert(f.v[2]); }
+  h.vert.assign(vs.begin(), vs.end());
+  return h;
+}
+// volume, centre of mass, inertia about the COM (unit density) of a closed triangle mesh: signed tetrahedra with the origin (mjcf.mesh_volume_props)
+void mesh_volume_props(const std::vector<V3>& v, const std::vector<std::array<int, 3>>& faces, double& vol, V3& com, M3& inertia) {
+  vol = 0; com = {0, 0, 0};
+  double C[3][3] = {{0}};
+  const double canon[3][3] = {{2.0 / 120, 1.0 / 120, 1.0 / 120}, {1.0 / 120, 2.0 / 120, 1.0 / 120}, {1.0 / 120, 1.0 / 120, 2.0 / 120}};
+  for (auto& fc : faces) {
+    double A[3][3];   // columns are the vertices
+    for (int k = 0; k < 3; k++) { A[0][k] = v[fc[k]].x; A[1][k] = v[fc[k]].y; A[2][k] = v[fc[k]].z; }
+    M3 Am; memcpy(Am.m, A, sizeof(A));
+    double det = det3(Am);
+    vol += det / 6.0;
+    com = com + V3{A[0][0] + A[0][1] + A[0][2], A[1][0] + A[1][1] + A[1][2], A[2][0] + A[2][1] + A[2][2]} * (det / 24.0);
+    double AC[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += A[i][k] * canon[k][j]; AC[i][j] = s; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += AC[i][k] * A[j][k]; C[i][j] += det * s; }
+  }
+  if (std::fabs(vol) < MINVAL) err("mesh volume is zero");
+  com = com * (1.0 / vol);
+  double c3[3] = {com.x, com.y, com.z};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[i][j] -= vol * c3[i] * c3[j];
+  double tr = C[0][0] + C[1][1] + C[2][2];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) inertia.m[i][j] = (i == j ? tr : 0.0) - C[i][j];
+  if (vol < 0) { vol = -vol; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) inertia.m[i][j] = -inertia.m[i][j]; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ flat model = ordered name -> array table
+struct Field { std::string name; int dtype; std::vector<int32_t> i; vecd d; };   // dtype 0 = int32, 1 = float64
+struct Flat {
+  std::vector<Field> f;
+  std::vector<std::pair<std::string, std::vector<std::string>>> names;   // kind -> names in id order ("" = unnamed)
+  Field* find(const std::string& k) { for (auto& x : f) if (x.name == k) return &x; return nullptr; }
+  void seti(const std::string& k, const std::vector<int32_t>& v) { Field* p = find(k); if (!p) { f.push_back({k, 0, {}, {}}); p = &f.back(); } p->dtype = 0; p->i = v; }
+  void setd(const std::string& k, const vecd& v) { Field* p = find(k); if (!p) { f.push_back({k, 1, {}, {}}); p = &f.back(); } p->dtype = 1; p->d = v; }
+  void seti1(const std::string& k, long v) { seti(k, {(int32_t)v}); }
+  void setd1(const std::string& k, double v) { setd(k, {v}); }
+  const std::vector<int32_t>& I(const std::string& k) { Field* p = find(k); if (!p || p->dtype != 0) err("internal: no int field %s", k.c_str()); return p->i; }
+  const vecd& D(const std::string& k) { Field* p = find(k); if (!p || p->dtype != 1) err("internal: no float field %s", k.c_str()); return p->d; }
+};
+// mjcf.to_blob: magic(8) nentries(u32) pad(u32), entries {name[32], dtype u32, count u32, offset u64}, 8-byte aligned payloads; name tables as int32 entries
+// "names:<kind>" (one int per UTF-8 byte, each name terminated by 0)
+std::vector<unsigned char> to_blob(const Flat& m) {
+  std::vector<Field> all = m.f;
+  for (auto& kv : m.names) {
+    Field nf{"names:" + kv.first, 0, {}, {}};
+    for (auto& nm : kv.second) { for (unsigned char c : nm) nf.i.push_back((int32_t)c); nf.i.push_back(0); }
+    all.push_back(nf);
+  }
+  const size_t header = 16 + 48 * all.size();
+  std::vector<unsigned char> payload, out(header, 0);
+  memcpy(out.data(), "RSIMMDL1", 8);
+  uint32_t n = (uint32_t)all.size();
+  memcpy(out.data() + 8, &n, 4);
+  for (size_t k = 0; k < all.size(); k++) {
+    const Field& a = all[k];
+    unsigned char* e = out.data() + 16 + 48 * k;
+    memcpy(e, a.name.data(), std::min<size_t>(31, a.name.size()));
+    uint32_t dt = (uint32_t)a.dtype, cnt = (uint32_t)(a.dtype == 0 ? a.i.size() : a.d.size());
+    uint64_t off = header + payload.size();
+    memcpy(e + 32, &dt, 4); memcpy(e + 36, &cnt, 4); memcpy(e + 40, &off, 8);
+    const unsigned char* src = a.dtype == 0 ? (const unsigned char*)a.i.data() : (const unsigned char*)a.d.data();
+    payload.insert(payload.end(), src, src + (size_t)cnt * (a.dtype == 0 ? 4 : 8));
+    while (payload.size() % 8) payload.push_back(0);
+  }
+  out.insert(out.end(), payload.begin(), payload.end());
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ compiler
+struct Compiler {
+  std::string angle = "degree", eulerseq = "xyz", meshdir, inertiafromgeom = "auto";
+  bool autolimits = true;
+  int glo = 0, ghi = 5;
+  double boundmass = 0, boundinertia = 0;
+};
+Q orientation(const Xml& e, const Compiler& c) {
+  vecd v;
+  if (e.get("quat")) { floats(e.get("quat"), 4, nullptr, v); return qnormalize({v[0], v[1], v[2], v[3]}); }
+  const double scale = c.angle == "radian" ? 1.0 : M_PI / 180.0;
+  if (e.get("euler")) {
+    floats(e.get("euler"), 3, nullptr, v);
+    Q q{1, 0, 0, 0};
+    for (size_t k = 0; k < c.eulerseq.size() && k < 3; k++) {
+      char ch = c.eulerseq[k];
+      int ax = (int)std::string("xyz").find((char)tolower((unsigned char)ch));
+      if (ax < 0 || ax > 2) err("bad eulerseq '%s'", c.eulerseq.c_str());
+      Q qk = axisangle2quat({ax == 0 ? 1.0 : 0.0, ax == 1 ? 1.0 : 0.0, ax == 2 ? 1.0 : 0.0}, v[k] * scale);
+      q = islower((unsigned char)ch) ? qmul(q, qk) : qmul(qk, q);   // lower-case = intrinsic (rotating frame): post-multiply; upper = extrinsic
+    }
+    return qnormalize(q);
+  }
+  if (e.get("axisangle")) { floats(e.get("axisangle"), 4, nullptr, v); return axisangle2quat({v[0], v[1], v[2]}, v[3] * scale); }
+  if (e.get("xyaxes")) {
+    floats(e.get("xyaxes"), 6, nullptr, v);
+    V3 x{v[0], v[1], v[2]}, y{v[3], v[4], v[5]};
+    x = x * (1.0 / norm(x)); y = y - x * dot(y, x); y = y * (1.0 / norm(y));
+    V3 z = cross(x, y);
+    M3 R = {{{x.x, y.x, z.x}, {x.y, y.y, z.y}, {x.z, y.z, z.z}}};
+    return m2q(R);
+  }
+  if (e.get("zaxis")) { floats(e.get("zaxis"), 3, nullptr, v); return quat_z2vec({v[0], v[1], v[2]}); }
+  return {1, 0, 0, 0};
+}
+// <default> classes: class name -> element tag -> attributes (inherited ones included)
+typedef std::vector<std::pair<std::string, std::string>> Attrs;
+struct Defaults {
+  std::map<std::string, std::map<std::string, Attrs>> classes;
+  static void update(Attrs& dst, const Attrs& src) { for (auto& a : src) { bool hit = false; for (auto& d : dst) if (d.first == a.first) { d.second = a.second; hit = true; } if (!hit) dst.push_back(a); } }
+  void walk(const Xml& node, const std::string& name, const std::map<std::string, Attrs>& inherited) {
+    std::map<std::string, Attrs> cur = inherited;
+    for (auto& ch : node.kids) if (ch->tag != "default") update(cur[ch->tag], ch->attr);
+    classes[name] = cur;
+    for (auto& ch : node.kids) if (ch->tag == "default") { const std::string* cn = ch->get("class"); walk(*ch, cn ? *cn : "None", cur); }
+  }
+  explicit Defaults(const Xml& root) { classes["main"] = {}; const Xml* d = root.find("default"); if (d) walk(*d, "main", {}); }
+  // the element with its class's attributes underneath its own (children are not needed by any caller)
+  Xml apply(const Xml& e, const std::string& tag, const std::string* childclass) const {
+    Xml out; out.tag = e.tag;
+    const std::string* own = e.get("class");
+    std::string cls = (own && !own->empty()) ? *own : ((childclass && !childclass->empty()) ? *childclass : "main");
+    auto ci = classes.find(cls);
+    if (ci != classes.end()) { auto ti = ci->second.find(tag); if (ti != ci->second.end()) out.attr = ti->second; }
+    update(out.attr, e.attr);
+    return out;
+  }
+};
+
+struct Body { std::string name; bool named; int parent; V3 pos; Q quat; bool mocap; const Xml* inertial; std::vector<int> jnts, geoms; };
+struct Joint { std::string name; bool named; int body, type; V3 pos, axis; bool limited; double range[2], damping, armature, frictionloss, stiffness, margin, ref, springref;
+               double solreflimit[2], solimplimit[5], solreffriction[2], solimpfriction[5]; int qposadr, dofadr; };
+struct Geom { std::string name; bool named; int body, type; std::string mesh; bool has_mesh; V3 size, pos; Q quat; int contype, conaffinity, condim, group, priority; double friction[3], solref[2], solimp[5],
+              solmix, margin, gap, density, mass; bool has_mass; double rgba[4]; int dataid; };
+struct Site { std::string name; bool named; int body; V3 pos; Q quat; double size[3], rgba[4]; };
+struct Named { std::string name; bool named; int body; };
+struct MeshAsset { std::string name, file; bool has_file; double scale[3]; bool loaded; std::vector<V3> hull_vert; double volume; V3 com; M3 inertia; };
+
+void name_of(const Xml& e, std::string& name, bool& named) { const std::string* s = e.get("name"); named = s != nullptr; name = s ? *s : ""; }
+void geom_volume_inertia(int t, V3 s, double& vol, double idiag[3]) {
+  const double pi = M_PI;
+  idiag[0] = idiag[1] = idiag[2] = 0; vol = 0;
+  if (t == GEOM_SPHERE) { double r = s.x; vol = 4.0 / 3.0 * pi * (r * r * r); idiag[0] = idiag[1] = idiag[2] = 0.4 * vol * r * r; }
+  else if (t == GEOM_BOX) { double a = s.x, b = s.y, c = s.z; vol = 8 * a * b * c; idiag[0] = vol / 3.0 * (b * b + c * c); idiag[1] = vol / 3.0 * (a * a + c * c); idiag[2] = vol / 3.0 * (a * a + b * b); }
+  else if (t == GEOM_CYLINDER) { double r = s.x, h = s.y; vol = pi * r * r * 2 * h; double ixx = vol * (3 * r * r + 4 * h * h) / 12.0; idiag[0] = idiag[1] = ixx; idiag[2] = vol * r * r / 2.0; }
+  else if (t == GEOM_ELLIPSOID) { double a = s.x, b = s.y, c = s.z; vol = 4.0 / 3.0 * pi * a * b * c; idiag[0] = vol / 5.0 * (b * b + c * c); idiag[1] = vol / 5.0 * (a * a + c * c); idiag[2] = vol / 5.0 * (a * a + b * b); }
+  else if (t == GEOM_CAPSULE) {
+    double r = s.x, h = s.y, vc = pi * r * r * 2 * h, vs = 4.0 / 3.0 * pi * (r * r * r);
+    vol = vc + vs;
+    double izz = vc * r * r / 2 + vs * 0.4 * r * r, ixx = vc * (3 * r * r + 4 * h * h) / 12.0 + vs * (0.4 * r * r + h * h + 0.75 * r * h);
+    idiag[0] = idiag[1] = ixx; idiag[2] = izz;
+  }
+}
+std::string path_join(const std::string& a, const std::string& b) {   // os.path.join for two parts
+  if (!b.empty() && b[0] == '/') return b;
+  if (a.empty() || a.back() == '/') return a + b;
+  return a + "/" + b;
+}
+std::string basename_noext(const std::string& f) {
+  size_t sl = f.rfind('/'); std::string b = sl == std::string::npos ? f : f.substr(sl + 1);
+  size_t d = b.rfind('.'); if (d != std::string::npos && d > 0) b = b.substr(0, d);
+  return b;
+}
+
+struct Kin { std::vector<V3> xpos, xipos, xanchor, xaxis; std::vector<Q> xquat; std::vector<M3> xmat, ximat; };
+
+Flat compile(const char* xml, size_t len, const std::string& asset_dir) {
+  std::unique_ptr<Xml> rootp;
+  rootp = XmlParser(xml, len).document();
+  const Xml& root = *rootp;
+  if (root.tag != "mujoco") err("root element must be <mujoco>");
+  Compiler comp;
+  if (const Xml* c = root.find("compiler")) {
+    comp.angle = c->gets("angle", "degree"); comp.eulerseq = c->gets("eulerseq", "xyz"); comp.autolimits = c->gets("autolimits", "true") == "true";
+    if (const std::string* g = c->get("inertiagrouprange")) if (!g->empty()) { std::vector<std::string> w = split_ws(*g); if (w.size() != 2) err("bad inertiagrouprange"); comp.glo = (int)to_int(w[0]); comp.ghi = (int)to_int(w[1]); }
+    comp.meshdir = c->gets("meshdir", ""); comp.inertiafromgeom = c->gets("inertiafromgeom", "auto");
+    comp.boundmass = attr_d(*c, "boundmass", 0); comp.boundinertia = attr_d(*c, "boundinertia", 0);
+  }
+  const double ang_scale = comp.angle == "radian" ? 1.0 : M_PI / 180.0;
+  Defaults defaults(root);
+  Xml none; none.tag = "option";
+  const Xml& o = root.find("option") ? *root.find("option") : none;
+  const double timestep = attr_d(o, "timestep", 0.002);
+  vecd gravity = floats_d(o, "gravity", 3, {0, 0, -9.81}), wind = floats_d(o, "wind", 3, {0, 0, 0});
+  const double density = attr_d(o, "density", 0), viscosity = attr_d(o, "viscosity", 0), impratio = attr_d(o, "impratio", 1);
+  int cone, solver;
+  { std::string c = o.gets("cone", "pyramidal"); if (c == "pyramidal") cone = 0; else if (c == "elliptic") cone = 1; else err("KeyError: '%s'", c.c_str()); }
+  const long iterations = attr_i(o, "iterations", 100);
+  const double tolerance = attr_d(o, "tolerance", 1e-8);
+  { std::string s = o.gets("solver", "Newton"); if (s == "PGS") solver = 0; else if (s == "CG" || s == "Newton") solver = 1; else err("KeyError: '%s'", s.c_str()); }
+  { std::string in = o.gets("integrator", "Euler"); if (in != "Euler") err("integrator '%s' not supported (robosuite uses the default Euler)", in.c_str()); }
+
+  // ---- assets: meshes
+  std::vector<MeshAsset> meshes;
+  auto mesh_index = [&](const std::string& nm) { for (size_t i = 0; i < meshes.size(); i++) if (meshes[i].name == nm) return (int)i; return -1; };
+  if (const Xml* asset = root.find("asset")) {
+    for (auto& me0 : asset->kids) {
+      if (me0->tag != "mesh") continue;
+      Xml me = defaults.apply(*me0, "mesh", nullptr);
+      MeshAsset ma{};
+      const std::string *nm = me.get("name"), *fl = me.get("file");
+      ma.has_file = fl != nullptr; ma.file = fl ? *fl : "";
+      ma.name = nm ? *nm : (fl ? basename_noext(*fl) : "");
+      vecd sc = floats_d(me, "scale", 3, {1, 1, 1});
+      for (int k = 0; k < 3; k++) ma.scale[k] = sc[k];
+      ma.loaded = false;
+      int at = mesh_index(ma.name);
+      if (at >= 0) meshes[at] = ma; else meshes.push_back(ma);    // OrderedDict: a repeated name keeps its first position
+    }
+  }
+  auto load_mesh_asset = [&](int mi) -> MeshAsset& {
+    MeshAsset& m = meshes[mi];
+    if (m.loaded) return m;
+    if (!m.has_file) err("mesh '%s' has no file", m.name.c_str());
+    std::string path = m.file;
+    if (path.empty() || path[0] != '/') path = path_join(path_join(asset_dir, comp.meshdir), path);
+    Mesh3 raw = load_mesh(path);
+    for (auto& p : raw.v) p = {p.x * m.scale[0], p.y * m.scale[1], p.z * m.scale[2]};
+    Hull h = convex_hull(raw.v);
+    std::vector<int> remap(raw.v.size(), -1);
+    for (size_t k = 0; k < h.vert.size(); k++) { remap[h.vert[k]] = (int)k; m.hull_vert.push_back(raw.v[h.vert[k]]); }
+    std::vector<std::array<int, 3>> faces;
+    for (auto& t : h.tri) faces.push_back({remap[t[0]], remap[t[1]], remap[t[2]]});
+    mesh_volume_props(m.hull_vert, faces, m.volume, m.com, m.inertia);
+    m.loaded = true;
+    return m;
+  };
+
+  // ---- kinematic tree
+  std::vector<Body> bodies;
+  std::vector<Joint> joints;
+  std::vector<Geom> geoms;
+  std::vector<Site> sites;
+  std::vector<Named> cams, lights;
+  bodies.push_back({"world", true, 0, {0, 0, 0}, {1, 0, 0, 0}, false, nullptr, {}, {}});
+
+  auto parse_geom = [&](const Xml& ge0, int bid, const std::string* cc) {
+    Xml ge = defaults.apply(ge0, "geom", cc);
+    static const std::map<std::string, int> types = {{"plane", 0}, {"hfield", 1}, {"sphere", 2}, {"capsule", 3}, {"ellipsoid", 4}, {"cylinder", 5}, {"box", 6}, {"mesh", 7}};
+    std::string tn = ge.gets("type", "sphere");
+    auto ti = types.find(tn);
+    if (ti == types.end()) err("KeyError: '%s'", tn.c_str());
+    Geom g{};
+    g.type = ti->second;
+    if (g.type == GEOM_HFIELD) err("hfield geoms not supported");
+    name_of(ge, g.name, g.named);
+    g.body = bid;
+    vecd size; bool has_size = floats(ge.get("size"), -1, nullptr, size);
+    vecd pos = floats_d(ge, "pos", 3, {0, 0, 0});
+    g.pos = {pos[0], pos[1], pos[2]};
+    g.quat = orientation(ge, comp);
+    if (ge.get("fromto")) {
+      vecd ft; floats(ge.get("fromto"), 6, nullptr, ft);
+      V3 a{ft[0], ft[1], ft[2]}, b{ft[3], ft[4], ft[5]};
+      g.pos = (a + b) * 0.5;
+      g.quat = quat_z2vec(b - a);
+      double half = 0.5 * norm(b - a);
+      if (!has_size || size.empty()) err("geom with fromto needs a size");
+      if (g.type == GEOM_CAPSULE || g.type == GEOM_CYLINDER) size = {size[0], half};
+      else if (g.type == GEOM_BOX || g.type == GEOM_ELLIPSOID) size = {size[0], size.size() > 1 ? size[1] : size[0], half};
+    }
+    double s3[3] = {0, 0, 0};
+    if (has_size) for (size_t k = 0; k < std::min<size_t>(3, size.size()); k++) s3[k] = size[k];
+    g.size = {s3[0], s3[1], s3[2]};
+    g.has_mesh = false;
+    if (g.type == GEOM_MESH) {
+      const std::string* mn = ge.get("mesh");
+      if (!mn || mesh_index(*mn) < 0) err("geom references unknown mesh '%s'", mn ? mn->c_str() : "None");
+      g.mesh = *mn; g.has_mesh = true;
+    }
+    g.contype = (int)attr_i(ge, "contype", 1); g.conaffinity = (int)attr_i(ge, "conaffinity", 1); g.condim = (int)attr_i(ge, "condim", 3);
+    g.group = (int)attr_i(ge, "group", 0); g.priority = (int)attr_i(ge, "priority", 0);
+    vecd v = floats_d(ge, "friction", 3, {1, 0.005, 0.0001}); for (int k = 0; k < 3; k++) g.friction[k] = v[k];
+    v = floats_d(ge, "solref", 2, {0.02, 1.0}); for (int k = 0; k < 2; k++) g.solref[k] = v[k];
+    v = floats_d(ge, "solimp", 5, {0.9, 0.95, 0.001, 0.5, 2.0}); for (int k = 0; k < 5; k++) g.solimp[k] = v[k];
+    g.solmix = attr_d(ge, "solmix", 1); g.margin = attr_d(ge, "margin", 0); g.gap = attr_d(ge, "gap", 0); g.density = attr_d(ge, "density", 1000);
+    g.has_mass = ge.get("mass") != nullptr; g.mass = g.has_mass ? to_double(*ge.get("mass")) : 0;
+    v = floats_d(ge, "rgba", 4, {0.5, 0.5, 0.5, 1}); for (int k = 0; k < 4; k++) g.rgba[k] = v[k];
+    g.dataid = -1;
+    geoms.push_back(g);
+  };
+  auto parse_site = [&](const Xml& se0, int bid, const std::string* cc) {
+    Xml se = defaults.apply(se0, "site", cc);
+    Site s{};
+    name_of(se, s.name, s.named);
+    s.body = bid;
+    vecd size; bool has = floats(se.get("size"), -1, nullptr, size);
+    for (int k = 0; k < 3; k++) s.size[k] = 0.005;
+    if (has) for (size_t k = 0; k < std::min<size_t>(3, size.size()); k++) s.size[k] = size[k];
+    vecd p = floats_d(se, "pos", 3, {0, 0, 0}); s.pos = {p[0], p[1], p[2]};
+    s.quat = orientation(se, comp);
+    vecd c = floats_d(se, "rgba", 4, {0.5, 0.5, 0.5, 1}); for (int k = 0; k < 4; k++) s.rgba[k] = c[k];
+    sites.push_back(s);
+  };
+  auto parse_joint = [&](const Xml& je0, int bid, const std::string* cc) {
+    Joint j{};
+    Xml je;
+    if (je0.tag == "freejoint") { j.type = JNT_FREE; je.tag = je0.tag; je.attr = je0.attr; }
+    else {
+      je = defaults.apply(je0, "joint", cc);
+      static const std::map<std::string, int> types = {{"free", 0}, {"ball", 1}, {"slide", 2}, {"hinge", 3}};
+      std::string tn = je.gets("type", "hinge");
+      auto ti = types.find(tn);
+      if (ti == types.end()) err("KeyError: '%s'", tn.c_str());
+      j.type = ti->second;
+    }
+    vecd rng = floats_d(je, "range", 2, {0, 0});
+    std::string lim = je.gets("limited", "auto");
+    bool limited;
+    if (lim == "auto") {
+      limited = comp.autolimits && je.get("range") != nullptr;
+      if (!comp.autolimits && je.get("range") != nullptr) err("range specified without limited and autolimits=false");
+    } else limited = lim == "true";
+    if (j.type == JNT_HINGE || j.type == JNT_BALL) { rng[0] *= ang_scale; rng[1] *= ang_scale; }
+    vecd ax = floats_d(je, "axis", 3, {0, 0, 1});
+    V3 axis{ax[0], ax[1], ax[2]};
+    double an = norm(axis);
+    axis = an > MINVAL ? V3{axis.x / an, axis.y / an, axis.z / an} : V3{0, 0, 1};
+    name_of(je, j.name, j.named);
+    j.body = bid;
+    vecd p = floats_d(je, "pos", 3, {0, 0, 0}); j.pos = {p[0], p[1], p[2]};
+    j.axis = axis;
+    j.limited = limited && (j.type == JNT_HINGE || j.type == JNT_SLIDE || j.type == JNT_BALL);
+    j.range[0] = rng[0]; j.range[1] = rng[1];
+    j.damping = attr_d(je, "damping", 0); j.armature = attr_d(je, "armature", 0); j.frictionloss = attr_d(je, "frictionloss", 0);
+    j.stiffness = attr_d(je, "stiffness", 0); j.margin = attr_d(je, "margin", 0);
+    j.ref = attr_d(je, "ref", 0) * (j.type == JNT_HINGE ? ang_scale : 1.0);
+    j.springref = attr_d(je, "springref", 0) * (j.type == JNT_HINGE ? ang_scale : 1.0);
+    vecd v = floats_d(je, "solreflimit", 2, {0.02, 1.0}); for (int k = 0; k < 2; k++) j.solreflimit[k] = v[k];
+    v = floats_d(je, "solimplimit", 5, {0.9, 0.95, 0.001, 0.5, 2.0}); for (int k = 0; k < 5; k++) j.solimplimit[k] = v[k];
+    v = floats_d(je, "solreffriction", 2, {0.02, 1.0}); for (int k = 0; k < 2; k++) j.solreffriction[k] = v[k];
+    v = floats_d(je, "solimpfriction", 5, {0.9, 0.95, 0.001, 0.5, 2.0}); for (int k = 0; k < 5; k++) j.solimpfriction[k] = v[k];
+    joints.push_back(j);
+  };
+  struct Walker {
+    std::vector<Body>& bodies; std::vector<Named>&cams, &lights; const Compiler& comp;
+    decltype(parse_geom)& pg; decltype(parse_site)& ps; decltype(parse_joint)& pj;
+    void walk(const Xml& be, int bid, const std::string* childclass) {
+      const std::string* own = be.get("childclass");
+      const std::string* cc = (own && !own->empty()) ? own : childclass;
+      for (auto& ch : be.kids) {
+        if (ch->tag == "joint" || ch->tag == "freejoint") pj(*ch, bid, cc);
+        else if (ch->tag == "geom") pg(*ch, bid, cc);
+        else if (ch->tag == "site") ps(*ch, bid, cc);
+        else if (ch->tag == "camera") { Named c{}; name_of(*ch, c.name, c.named); c.body = bid; cams.push_back(c); }
+        else if (ch->tag == "light") { Named c{}; name_of(*ch, c.name, c.named); c.body = bid; lights.push_back(c); }
+        else if (ch->tag == "inertial") bodies[bid].inertial = ch.get();
+      }
+      for (auto& ch : be.kids) {
+        if (ch->tag != "body") continue;
+        int nb = (int)bodies.size();
+        Body b{};
+        name_of(*ch, b.name, b.named);
+        b.parent = bid;
+        vecd p = floats_d(*ch, "pos", 3, {0, 0, 0}); b.pos = {p[0], p[1], p[2]};
+        b.quat = orientation(*ch, comp);
+        b.mocap = ch->gets("mocap", "false") == "true";
+        b.inertial = nullptr;
+        bodies.push_back(b);
+        walk(*ch, nb, cc);
+      }
+    }
+  } walker{bodies, cams, lights, comp, parse_geom, parse_site, parse_joint};
+  if (const Xml* wb = root.find("worldbody")) walker.walk(*wb, 0, nullptr);
+  const int nbody = (int)bodies.size(), njnt = (int)joints.size(), ngeom = (int)geoms.size(), nsite = (int)sites.size();
+
+  // MuJoCo orders geoms / sites / joints by owning body id (document order within a body)
+  auto reorder = [](auto& items) { std::stable_sort(items.begin(), items.end(), [](const auto& a, const auto& b) { return a.body < b.body; }); };
+  reorder(geoms); reorder(sites); reorder(joints); reorder(cams); reorder(lights);
+  for (int i = 0; i < njnt; i++) bodies[joints[i].body].jnts.push_back(i);
+  for (int i = 0; i < ngeom; i++) bodies[geoms[i].body].geoms.push_back(i);
+
+  int nq = 0, nv = 0;
+  auto nqof = [](int t) { return t == JNT_FREE ? 7 : (t == JNT_BALL ? 4 : 1); };
+  auto nvof = [](int t) { return t == JNT_FREE ? 6 : (t == JNT_BALL ? 3 : 1); };
+  for (auto& j : joints) { j.qposadr = nq; j.dofadr = nv; nq += nqof(j.type); nv += nvof(j.type); }
+  for (int bi = 1; bi < nbody; bi++) for (int ji : bodies[bi].jnts)
+    if (joints[ji].type == JNT_FREE && (bodies[bi].parent != 0 || bodies[bi].jnts.size() != 1)) err("free joint must be the only joint of a top-level body");
+
+  // ---- mesh geoms: hull vertices in the geom frame
+  std::vector<int> used_mesh;       // asset index, in order of first use
+  std::vector<int32_t> mesh_vertadr, mesh_vertnum;
+  std::vector<std::vector<V3>> mesh_vert;
+  for (auto& g : geoms) {
+    if (g.type != GEOM_MESH) { g.dataid = -1; continue; }
+    if (g.contype == 0 && g.conaffinity == 0 && !(comp.glo <= g.group && g.group <= comp.ghi && bodies[g.body].inertial == nullptr)) { g.dataid = -1; continue; }   // visual-only: never loaded
+    int mi = mesh_index(g.mesh);
+    int at = -1;
+    for (size_t k = 0; k < used_mesh.size(); k++) if (used_mesh[k] == mi) at = (int)k;
+    if (at < 0) {
+      MeshAsset& md = load_mesh_asset(mi);
+      at = (int)used_mesh.size();
+      used_mesh.push_back(mi);
+      int sum = 0; for (int x : mesh_vertnum) sum += x;
+      mesh_vertadr.push_back(sum);
+      mesh_vertnum.push_back((int)md.hull_vert.size());
+      mesh_vert.push_back(md.hull_vert);
+    }
+    g.dataid = at;
+  }
+
+  // ---- body inertial properties
+  vecd body_mass(nbody, 0.0), body_inertia(3 * nbody, 0.0), body_ipos(3 * nbody, 0.0), body_iquat(4 * nbody, 0.0);
+  for (int b = 0; b < nbody; b++) body_iquat[4 * b] = 1.0;
+  auto set_iquat = [&](int b, Q q) { body_iquat[4 * b] = q.w; body_iquat[4 * b + 1] = q.x; body_iquat[4 * b + 2] = q.y; body_iquat[4 * b + 3] = q.z; };
+  struct Part { double mass; V3 c; M3 I; const Geom* g; bool centred; };
+  for (int bi = 0; bi < nbody; bi++) {
+    const Xml* ie = bodies[bi].inertial;
+    const bool use_geoms = comp.inertiafromgeom == "true" || (comp.inertiafromgeom == "auto" && ie == nullptr);
+    if (ie != nullptr && !use_geoms) {
+      body_mass[bi] = attr_d(*ie, "mass", 0);
+      vecd p = floats_d(*ie, "pos", 3, {0, 0, 0});
+      for (int k = 0; k < 3; k++) body_ipos[3 * bi + k] = p[k];
+      Q iq = orientation(*ie, comp);
+      if (ie->get("fullinertia")) {
+        vecd f; floats(ie->get("fullinertia"), 6, nullptr, f);
+        M3 Im = {{{f[0], f[3], f[4]}, {f[3], f[1], f[5]}, {f[4], f[5], f[2]}}};
+        double w[3]; M3 V;
+        eigh3_desc(Im, w, V);
+        for (int k = 0; k < 3; k++) body_inertia[3 * bi + k] = w[k];
+        iq = qmul(iq, m2q(V));
+      } else {
+        vecd di = floats_d(*ie, "diaginertia", 3, {0, 0, 0});
+        for (int k = 0; k < 3; k++) body_inertia[3 * bi + k] = di[k];
+      }
+      set_iquat(bi, qnormalize(iq));
+    } else if (use_geoms && bi > 0) {
+      std::vector<Part> parts;
+      for (int gi : bodies[bi].geoms) {
+        const Geom& g = geoms[gi];
+        if (!(comp.glo <= g.group && g.group <= comp.ghi)) continue;
+        double mass; V3 coff{0, 0, 0}; M3 Ig = {{{0}}};
+        if (g.type == GEOM_MESH) {
+          MeshAsset& md = load_mesh_asset(mesh_index(g.mesh));
+          mass = g.has_mass ? g.mass : g.density * md.volume;
+          coff = md.com;
+          for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ig.m[i][j] = md.inertia.m[i][j] * (mass / md.volume);
+        } else {
+          double vol, idg[3];
+          geom_volume_inertia(g.type, g.size, vol, idg);
+          if (vol <= 0) mass = 0;
+          else { mass = g.has_mass ? g.mass : g.density * vol; for (int k = 0; k < 3; k++) Ig.m[k][k] = idg[k] * (mass / vol); }
+        }
+        if (mass <= 0) continue;
+        M3 R = q2m(g.quat);
+        const bool centred = std::fabs(coff.x) <= 1e-8 && std::fabs(coff.y) <= 1e-8 && std::fabs(coff.z) <= 1e-8;   // numpy.allclose(coff, 0)
+        parts.push_back({mass, g.pos + mv(R, coff), mm(mm(R, Ig), mt(R)), &g, centred});
+      }
+      if (parts.size() == 1 && parts[0].centred) {
+        const Part& p = parts[0];
+        body_mass[bi] = p.mass;
+        body_ipos[3 * bi] = p.c.x; body_ipos[3 * bi + 1] = p.c.y; body_ipos[3 * bi + 2] = p.c.z;
+        set_iquat(bi, p.g->quat);
+        M3 Rg = q2m(p.g->quat);
+        M3 D = mm(mm(mt(Rg), p.I), Rg);
+        for (int k = 0; k < 3; k++) body_inertia[3 * bi + k] = D.m[k][k];
+      } else if (!parts.empty()) {
+        double mt_ = 0; for (auto& p : parts) mt_ += p.mass;
+        V3 c{0, 0, 0}; for (auto& p : parts) c = c + p.c * p.mass;
+        c = c * (1.0 / mt_);
+        M3 It = {{{0}}};
+        for (auto& p : parts) {
+          V3 d = p.c - c;
+          double dd = dot(d, d), d3[3] = {d.x, d.y, d.z};
+          for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) It.m[i][j] += p.I.m[i][j] + p.mass * ((i == j ? dd : 0.0) - d3[i] * d3[j]);
+        }
+        double w[3]; M3 V;
+        eigh3_desc(It, w, V);
+        body_mass[bi] = mt_;
+        body_ipos[3 * bi] = c.x; body_ipos[3 * bi + 1] = c.y; body_ipos[3 * bi + 2] = c.z;
+        for (int k = 0; k < 3; k++) body_inertia[3 * bi + k] = w[k];
+        set_iquat(bi, m2q(V));
+      }
+    }
+    if (comp.boundmass > 0 && bi > 0) body_mass[bi] = std::max(body_mass[bi], comp.boundmass);
+    if (comp.boundinertia > 0 && bi > 0) for (int k = 0; k < 3; k++) body_inertia[3 * bi + k] = std::max(body_inertia[3 * bi + k], comp.boundinertia);
+  }
+
+  // ---- tree bookkeeping
+  std::vector<int32_t> body_parentid(nbody), body_rootid(nbody, 0), body_weldid(nbody, 0), body_mocapid(nbody, -1), body_jntadr(nbody), body_jntnum(nbody), body_dofadr(nbody, -1),
+      body_dofnum(nbody, 0), dof_bodyid(nv, 0), dof_jntid(nv, 0), dof_parentid(nv, -1), body_geomadr(nbody), body_geomnum(nbody);
+  int nmocap = 0;
+  for (int b = 0; b < nbody; b++) body_parentid[b] = bodies[b].parent;
+  for (int bi = 1; bi < nbody; bi++) {
+    int p = body_parentid[bi];
+    body_rootid[bi] = p == 0 ? bi : body_rootid[p];
+    body_weldid[bi] = !bodies[bi].jnts.empty() ? bi : body_weldid[p];
+    if (bodies[bi].mocap) {
+      if (p != 0 || !bodies[bi].jnts.empty()) err("mocap body must be a jointless child of the world");
+      body_mocapid[bi] = nmocap++;
+    }
+  }
+  for (int b = 0; b < nbody; b++) {
+    body_jntadr[b] = bodies[b].jnts.empty() ? -1 : bodies[b].jnts[0]; body_jntnum[b] = (int)bodies[b].jnts.size();
+    body_geomadr[b] = bodies[b].geoms.empty() ? -1 : bodies[b].geoms[0]; body_geomnum[b] = (int)bodies[b].geoms.size();
+  }
+  for (int ji = 0; ji < njnt; ji++) {
+    const Joint& j = joints[ji];
+    int nd = nvof(j.type);
+    if (body_dofadr[j.body] < 0) body_dofadr[j.body] = j.dofadr;
+    body_dofnum[j.body] += nd;
+    for (int k = 0; k < nd; k++) { dof_bodyid[j.dofadr + k] = j.body; dof_jntid[j.dofadr + k] = ji; }
+  }
+  for (int d = 0; d < nv; d++) {
+    int b = dof_bodyid[d];
+    if (d > body_dofadr[b]) dof_parentid[d] = d - 1;
+    else {
+      int p = body_parentid[b];
+      while (p > 0 && body_dofnum[p] == 0) p = body_parentid[p];
+      if (p > 0) dof_parentid[d] = body_dofadr[p] + body_dofnum[p] - 1;
+    }
+  }
+
+  Flat m;
+  m.seti1("nq", nq); m.seti1("nv", nv); m.seti1("nbody", nbody); m.seti1("njnt", njnt); m.seti1("ngeom", ngeom); m.seti1("nsite", nsite);
+  m.seti1("ncam", (long)cams.size()); m.seti1("nlight", (long)lights.size()); m.seti1("nmocap", nmocap);
+  m.setd1("timestep", timestep); m.setd("gravity", gravity); m.setd("wind", wind); m.setd1("density", density); m.setd1("viscosity", viscosity); m.setd1("impratio", impratio);
+  m.seti1("cone", cone); m.seti1("iterations", iterations); m.setd1("tolerance", tolerance); m.seti1("solver", solver);
+  m.seti("body_parentid", body_parentid); m.seti("body_rootid", body_rootid); m.seti("body_weldid", body_weldid); m.seti("body_mocapid", body_mocapid);
+  m.seti("body_jntadr", body_jntadr); m.seti("body_jntnum", body_jntnum); m.seti("body_dofadr", body_dofadr); m.seti("body_dofnum", body_dofnum);
+  m.seti("body_geomadr", body_geomadr); m.seti("body_geomnum", body_geomnum);
+  { vecd bp, bq; for (auto& b : bodies) { bp.insert(bp.end(), {b.pos.x, b.pos.y, b.pos.z}); bq.insert(bq.end(), {b.quat.w, b.quat.x, b.quat.y, b.quat.z}); } m.setd("body_pos", bp); m.setd("body_quat", bq); }
+  m.setd("body_ipos", body_ipos); m.setd("body_iquat", body_iquat); m.setd("body_mass", body_mass); m.setd("body_inertia", body_inertia);
+
+  // ---- joints / dofs
+  {
+    std::vector<int32_t> jt, jq, jd, jb, jl; vecd jp, ja, jr, js, jm, jsr, jsi;
+    for (auto& j : joints) {
+      jt.push_back(j.type); jq.push_back(j.qposadr); jd.push_back(j.dofadr); jb.push_back(j.body); jl.push_back(j.limited ? 1 : 0);
+      jp.insert(jp.end(), {j.pos.x, j.pos.y, j.pos.z}); ja.insert(ja.end(), {j.axis.x, j.axis.y, j.axis.z}); jr.insert(jr.end(), {j.range[0], j.range[1]});
+      js.push_back(j.stiffness); jm.push_back(j.margin); jsr.insert(jsr.end(), j.solreflimit, j.solreflimit + 2); jsi.insert(jsi.end(), j.solimplimit, j.solimplimit + 5);
+    }
+    m.seti("jnt_type", jt); m.seti("jnt_qposadr", jq); m.seti("jnt_dofadr", jd); m.seti("jnt_bodyid", jb); m.setd("jnt_pos", jp); m.setd("jnt_axis", ja);
+    m.seti("jnt_limited", jl); m.setd("jnt_range", jr); m.setd("jnt_stiffness", js); m.setd("jnt_margin", jm); m.setd("jnt_solref", jsr); m.setd("jnt_solimp", jsi);
+  }
+  vecd qpos0(nq, 0.0), qpos_spring(nq, 0.0);
+  for (auto& j : joints) {
+    int a = j.qposadr;
+    if (j.type == JNT_FREE) {
+      const Body& b = bodies[j.body];
+      double v[7] = {b.pos.x, b.pos.y, b.pos.z, b.quat.w, b.quat.x, b.quat.y, b.quat.z};
+      for (int k = 0; k < 7; k++) { qpos0[a + k] = v[k]; qpos_spring[a + k] = v[k]; }
+    } else if (j.type == JNT_BALL) { qpos0[a] = 1; qpos_spring[a] = 1; }
+    else { qpos0[a] = j.ref; qpos_spring[a] = j.springref; }
+  }
+  m.setd("qpos0", qpos0); m.setd("qpos_spring", qpos_spring);
+  m.seti("dof_bodyid", dof_bodyid); m.seti("dof_jntid", dof_jntid); m.seti("dof_parentid", dof_parentid);
+  {
+    vecd da, dd, df, dsr, dsi;
+    for (int d = 0; d < nv; d++) {
+      const Joint& j = joints[dof_jntid[d]];
+      da.push_back(j.armature); dd.push_back(j.damping); df.push_back(j.frictionloss);
+      dsr.insert(dsr.end(), j.solreffriction, j.solreffriction + 2); dsi.insert(dsi.end(), j.solimpfriction, j.solimpfriction + 5);
+    }
+    m.setd("dof_armature", da); m.setd("dof_damping", dd); m.setd("dof_frictionloss", df); m.setd("dof_solref", dsr); m.setd("dof_solimp", dsi);
+  }
+  // ---- geoms
+  {
+    std::vector<int32_t> gt, gb, gct, gca, gcd, gpr, ggr, gdi; vecd gs, gp, gq, gf, gsr, gsi, gsm, gmg, ggp, grg;
+    for (auto& g : geoms) {
+      gt.push_back(g.type); gb.push_back(g.body); gct.push_back(g.contype); gca.push_back(g.conaffinity); gcd.push_back(g.condim); gpr.push_back(g.priority);
+      ggr.push_back(g.group); gdi.push_back(g.dataid);
+      gs.insert(gs.end(), {g.size.x, g.size.y, g.size.z}); gp.insert(gp.end(), {g.pos.x, g.pos.y, g.pos.z}); gq.insert(gq.end(), {g.quat.w, g.quat.x, g.quat.y, g.quat.z});
+      gf.insert(gf.end(), g.friction, g.friction + 3); gsr.insert(gsr.end(), g.solref, g.solref + 2); gsi.insert(gsi.end(), g.solimp, g.solimp + 5);
+      gsm.push_back(g.solmix); gmg.push_back(g.margin); ggp.push_back(g.gap); grg.insert(grg.end(), g.rgba, g.rgba + 4);
+    }
+    m.seti("geom_type", gt); m.seti("geom_bodyid", gb); m.seti("geom_contype", gct); m.seti("geom_conaffinity", gca); m.seti("geom_condim", gcd); m.seti("geom_priority", gpr);
+    m.seti("geom_group", ggr); m.seti("geom_dataid", gdi); m.setd("geom_size", gs); m.setd("geom_pos", gp); m.setd("geom_quat", gq); m.setd("geom_friction", gf);
+    m.setd("geom_solref", gsr); m.setd("geom_solimp", gsi); m.setd("geom_solmix", gsm); m.setd("geom_margin", gmg); m.setd("geom_gap", ggp); m.setd("geom_rgba", grg);
+  }
+  {
+    vecd mvv; int tot = 0;
+    for (auto& hv : mesh_vert) for (auto& p : hv) { mvv.insert(mvv.end(), {p.x, p.y, p.z}); tot++; }
+    m.seti1("nmesh", (long)used_mesh.size()); m.seti1("nmeshvert", tot); m.seti("mesh_vertadr", mesh_vertadr); m.seti("mesh_vertnum", mesh_vertnum); m.setd("mesh_vert", mvv);
+  }
+  {
+    vecd rbound(ngeom, 0.0), rcenter(3 * ngeom, 0.0);
+    for (int gi = 0; gi < ngeom; gi++) {
+      const Geom& g = geoms[gi];
+      const V3 s = g.size;
+      if (g.type == GEOM_SPHERE) rbound[gi] = s.x;
+      else if (g.type == GEOM_CAPSULE) rbound[gi] = s.x + s.y;
+      else if (g.type == GEOM_CYLINDER) rbound[gi] = std::sqrt(s.x * s.x + s.y * s.y);
+      else if (g.type == GEOM_ELLIPSOID) rbound[gi] = std::max({s.x, s.y, s.z});
+      else if (g.type == GEOM_BOX) rbound[gi] = norm(s);
+      else if (g.type == GEOM_MESH && g.dataid >= 0) {
+        const std::vector<V3>& hv = mesh_vert[g.dataid];
+        V3 lo = hv[0], hi = hv[0];
+        for (auto& p : hv) { lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)}; hi = {std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z)}; }
+        V3 c = (lo + hi) * 0.5;
+        rcenter[3 * gi] = c.x; rcenter[3 * gi + 1] = c.y; rcenter[3 * gi + 2] = c.z;
+        double r = 0; for (auto& p : hv) r = std::max(r, norm(p - c));
+        rbound[gi] = r;
+      }
+    }
+    m.setd("geom_rbound", rbound); m.setd("geom_rcenter", rcenter);
+  }
+  // ---- sites
+  {
+    std::vector<int32_t> sb; vecd sp, sq, ss, sr;
+    for (auto& s : sites) { sb.push_back(s.body); sp.insert(sp.end(), {s.pos.x, s.pos.y, s.pos.z}); sq.insert(sq.end(), {s.quat.w, s.quat.x, s.quat.y, s.quat.z}); ss.insert(ss.end(), s.size, s.size + 3); sr.insert(sr.end(), s.rgba, s.rgba + 4); }
+    m.seti("site_bodyid", sb); m.setd("site_pos", sp); m.setd("site_quat", sq); m.setd("site_size", ss); m.setd("site_rgba", sr);
+  }
+  // ---- actuators
+  std::vector<std::pair<std::string, bool>> act_names;
+  {
+    std::vector<int32_t> trn, bt, cl, fl; vecd gear, gain, bias, cr, fr;
+    std::map<std::string, int> jname2id;
+    for (int i = 0; i < njnt; i++) if (joints[i].named) jname2id[joints[i].name] = i;
+    if (const Xml* act = root.find("actuator")) for (auto& ae0 : act->kids) {
+      Xml ae = defaults.apply(*ae0, ae0->tag, nullptr);
+      const std::string& tag = ae.tag;
+      if (tag != "motor" && tag != "position" && tag != "velocity" && tag != "general") err("actuator type '%s' not supported", tag.c_str());
+      const std::string* jn = ae.get("joint");
+      if (!jn || !jname2id.count(*jn)) err("actuator '%s' needs a valid joint transmission", ae.gets("name", "None").c_str());
+      int jid = jname2id[*jn];
+      if (joints[jid].type != JNT_HINGE && joints[jid].type != JNT_SLIDE) err("only hinge/slide joint transmissions supported");
+      vecd gv; double gr = floats(ae.get("gear"), -1, nullptr, gv) ? (gv.empty() ? (err("empty gear"), 0.0) : gv[0]) : 1.0;
+      double gp[3] = {0, 0, 0}, bp[3] = {0, 0, 0};
+      int biastype = 0;
+      if (tag == "motor") gp[0] = 1.0;
+      else if (tag == "position") { double kp = attr_d(ae, "kp", 1), kv = attr_d(ae, "kv", 0); gp[0] = kp; bp[0] = 0; bp[1] = -kp; bp[2] = -kv; biastype = 1; }
+      else if (tag == "velocity") { double kv = attr_d(ae, "kv", 1); gp[0] = kv; bp[2] = -kv; biastype = 1; }
+      else {
+        vecd g2, b2; bool hg = floats(ae.get("gainprm"), -1, nullptr, g2), hb = floats(ae.get("biasprm"), -1, nullptr, b2);
+        gp[0] = 1.0;
+        if (hg) for (size_t k = 0; k < std::min<size_t>(3, g2.size()); k++) gp[k] = g2[k];
+        if (hb) for (size_t k = 0; k < std::min<size_t>(3, b2.size()); k++) bp[k] = b2[k];
+        if (ae.gets("gaintype", "fixed") != "fixed" || ae.gets("dyntype", "none") != "none") err("only fixed-gain, stateless general actuators supported");
+        std::string bts = ae.gets("biastype", "none");
+        if (bts == "none") biastype = 0; else if (bts == "affine") biastype = 1; else err("KeyError: '%s'", bts.c_str());
+      }
+      auto lim = [&](const char* flag, const char* rng) { std::string v = ae.gets(flag, "auto"); if (v == "auto") return comp.autolimits && ae.get(rng) != nullptr; return v == "true"; };
+      std::string nm; bool named; name_of(ae, nm, named);
+      act_names.emplace_back(nm, named);
+      trn.push_back(jid); gear.push_back(gr); gain.insert(gain.end(), gp, gp + 3); bias.insert(bias.end(), bp, bp + 3); bt.push_back(biastype);
+      cl.push_back(lim("ctrllimited", "ctrlrange") ? 1 : 0); vecd c2 = floats_d(ae, "ctrlrange", 2, {0, 0}); cr.insert(cr.end(), c2.begin(), c2.end());
+      fl.push_back(lim("forcelimited", "forcerange") ? 1 : 0); vecd f2 = floats_d(ae, "forcerange", 2, {0, 0}); fr.insert(fr.end(), f2.begin(), f2.end());
+    }
+    m.seti1("nu", (long)trn.size());
+    m.seti("actuator_trnid", trn); m.setd("actuator_gear", gear); m.setd("actuator_gainprm", gain); m.setd("actuator_biasprm", bias); m.seti("actuator_biastype", bt);
+    m.seti("actuator_ctrllimited", cl); m.setd("actuator_ctrlrange", cr); m.seti("actuator_forcelimited", fl); m.setd("actuator_forcerange", fr);
+  }
+  // ---- sensors: names + dims; force / torque at a site carry their site
+  std::vector<std::pair<std::string, bool>> sens_names;
+  {
+    std::vector<int32_t> sdim, sobj, stype;
+    static const std::map<std::string, int> dims = {{"force", 3}, {"torque", 3}, {"touch", 1}, {"framepos", 3}, {"framequat", 4}, {"jointpos", 1}, {"jointvel", 1}};
+    // the Python compiler maps sites by name through a dict built over ALL sites (an unnamed site is the key None; a later site of the same name wins)
+    if (const Xml* se = root.find("sensor")) for (auto& s : se->kids) {
+      std::string nm; bool named; name_of(*s, nm, named);
+      sens_names.emplace_back(nm, named);
+      auto di = dims.find(s->tag);
+      sdim.push_back(di == dims.end() ? 1 : di->second);
+      const std::string* sn = s->get("site");
+      int sid = -1;
+      for (int i = 0; i < nsite; i++) if (sn ? (sites[i].named && sites[i].name == *sn) : !sites[i].named) sid = i;
+      sobj.push_back(sid);
+      stype.push_back(s->tag == "force" ? 0 : (s->tag == "torque" ? 1 : -1));
+    }
+    m.seti1("nsensor", (long)sdim.size()); m.seti("sensor_dim", sdim); m.seti("sensor_objid", sobj); m.seti("sensor_type", stype);
+  }
+  // ---- fixed tendons, tendon equality constraints
+  struct Tendon { std::string name; bool named; std::vector<std::pair<int, double>> wraps; double range[2], stiffness, damping, ls[2], margin, solref[2], solimp[5], frictionloss, solref_fri[2], solimp_fri[5]; int limited; };
+  struct Eq { std::string name; bool named; int tendon; double polycoef[5], solref[2], solimp[5]; };
+  std::vector<Tendon> tendons;
+  std::vector<Eq> eqs;
+  {
+    auto jfind = [&](const std::string* nm) { int hit = -1; for (int i = 0; i < njnt; i++) if (nm ? (joints[i].named && joints[i].name == *nm) : !joints[i].named) hit = i; if (hit < 0) err("KeyError: '%s'", nm ? nm->c_str() : "None"); return hit; };
+    if (const Xml* tend = root.find("tendon")) for (auto& t : tend->kids) {
+      if (t->tag != "fixed") err("spatial tendons are not supported (only <tendon><fixed>)");
+      Tendon T{};
+      name_of(*t, T.name, T.named);
+      vecd sl = floats_d(*t, "springlength", -1, {-1.0});
+      if (sl.empty()) err("empty springlength");
+      T.ls[0] = sl[0]; T.ls[1] = sl.size() == 1 ? sl[0] : sl[1];
+      for (auto& w : t->kids) if (w->tag == "joint") { int jid = jfind(w->get("joint")); T.wraps.emplace_back(jid, to_double(w->gets("coef", "1"))); }
+      for (auto& w : T.wraps) if (joints[w.first].type != JNT_HINGE && joints[w.first].type != JNT_SLIDE) err("fixed tendons over ball / free joints are not supported");
+      vecd r = floats_d(*t, "range", 2, {0.0, 0.0}); T.range[0] = r[0]; T.range[1] = r[1];
+      const std::string* lim = t->get("limited");
+      T.limited = ((lim && *lim == "true") || ((!lim || *lim == "auto") && t->get("range") != nullptr && comp.autolimits)) ? 1 : 0;
+      T.stiffness = to_double(t->gets("stiffness", "0")); T.damping = to_double(t->gets("damping", "0")); T.margin = to_double(t->gets("margin", "0"));
+      vecd v = floats_d(*t, "solreflimit", 2, {0.02, 1.0}); for (int k = 0; k < 2; k++) T.solref[k] = v[k];
+      v = floats_d(*t, "solimplimit", 5, {0.9, 0.95, 0.001, 0.5, 2.0}); for (int k = 0; k < 5; k++) T.solimp[k] = v[k];
+      T.frictionloss = to_double(t->gets("frictionloss", "0"));
+      v = floats_d(*t, "solreffriction", 2, {0.02, 1.0}); for (int k = 0; k < 2; k++) T.solref_fri[k] = v[k];
+      v = floats_d(*t, "solimpfriction", 5, {0.9, 0.95, 0.001, 0.5, 2.0}); for (int k = 0; k < 5; k++) T.solimp_fri[k] = v[k];
+      tendons.push_back(T);
+    }
+    if (const Xml* eq = root.find("equality")) for (auto& e : eq->kids) {
+      if (e->tag != "tendon" || e->get("tendon2") != nullptr) err("equality/%s is not supported (only equality/tendon with one tendon)", e->tag.c_str());
+      if (e->gets("active", "true") != "true") continue;
+      Eq E{};
+      name_of(*e, E.name, E.named);
+      const std::string* t1 = e->get("tendon1");
+      E.tendon = -1;
+      for (size_t i = 0; i < tendons.size(); i++) if (t1 ? (tendons[i].named && tendons[i].name == *t1) : !tendons[i].named) E.tendon = (int)i;
+      if (E.tendon < 0) err("KeyError: '%s'", t1 ? t1->c_str() : "None");
+      vecd v = floats_d(*e, "polycoef", 5, {0.0, 1.0, 0.0, 0.0, 0.0}); for (int k = 0; k < 5; k++) E.polycoef[k] = v[k];
+      v = floats_d(*e, "solref", 2, {0.02, 1.0}); for (int k = 0; k < 2; k++) E.solref[k] = v[k];
+      v = floats_d(*e, "solimp", 5, {0.9, 0.95, 0.001, 0.5, 2.0}); for (int k = 0; k < 5; k++) E.solimp[k] = v[k];
+      eqs.push_back(E);
+    }
+    const int nt = (int)tendons.size(), ne = (int)eqs.size();
+    m.seti1("ntendon", nt); m.seti1("neq", ne);
+    std::vector<int32_t> adr, num, wj, tl, eo; vecd wc, tr, tm, ts, td, tls, tsr, tsi, tf, tfr, tfi, ed, esr, esi;
+    for (auto& T : tendons) {
+      adr.push_back((int)wj.size()); num.push_back((int)T.wraps.size());
+      for (auto& w : T.wraps) { wj.push_back(w.first); wc.push_back(w.second); }
+      tl.push_back(T.limited); tr.insert(tr.end(), T.range, T.range + 2); tm.push_back(T.margin); ts.push_back(T.stiffness); td.push_back(T.damping); tls.insert(tls.end(), T.ls, T.ls + 2);
+      tsr.insert(tsr.end(), T.solref, T.solref + 2); tsi.insert(tsi.end(), T.solimp, T.solimp + 5); tf.push_back(T.frictionloss);
+      tfr.insert(tfr.end(), T.solref_fri, T.solref_fri + 2); tfi.insert(tfi.end(), T.solimp_fri, T.solimp_fri + 5);
+    }
+    for (auto& E : eqs) { eo.push_back(E.tendon); ed.insert(ed.end(), E.polycoef, E.polycoef + 5); esr.insert(esr.end(), E.solref, E.solref + 2); esi.insert(esi.end(), E.solimp, E.solimp + 5); }
+    m.seti("tendon_adr", adr); m.seti("tendon_num", num); m.seti("wrap_objid", wj); m.setd("wrap_prm", wc); m.seti("tendon_limited", tl); m.setd("tendon_range", tr);
+    m.setd("tendon_margin", tm); m.setd("tendon_stiffness", ts); m.setd("tendon_damping", td); m.setd("tendon_lengthspring", tls); m.setd("tendon_solref_lim", tsr);
+    m.setd("tendon_solimp_lim", tsi); m.setd("tendon_frictionloss", tf); m.setd("tendon_solref_fri", tfr); m.setd("tendon_solimp_fri", tfi);
+    m.seti("eq_obj1id", eo); m.setd("eq_data", ed); m.setd("eq_solref", esr); m.setd("eq_solimp", esi);
+  }
+  // ---- collision pair list (MuJoCo filter rules, docs "Collision detection")
+  {
+    std::set<std::pair<int, int>> excl;
+    if (const Xml* con = root.find("contact")) {
+      auto bfind = [&](const std::string* nm) { int hit = -1; for (int i = 0; i < nbody; i++) if (nm ? (bodies[i].named && bodies[i].name == *nm) : !bodies[i].named) hit = i; if (hit < 0) err("KeyError: '%s'", nm ? nm->c_str() : "None"); return hit; };
+      for (auto& e : con->kids) if (e->tag == "exclude") { int a = bfind(e->get("body1")), b = bfind(e->get("body2")); excl.insert({std::min(a, b), std::max(a, b)}); }
+      for (auto& e : con->kids) if (e->tag == "pair") err("explicit <contact><pair> not supported");
+    }
+    std::vector<int32_t> p1, p2;
+    for (int g1 = 0; g1 < ngeom; g1++) {
+      const Geom& a = geoms[g1];
+      if (a.contype == 0 && a.conaffinity == 0) continue;
+      for (int g2 = g1 + 1; g2 < ngeom; g2++) {
+        const Geom& b = geoms[g2];
+        if (!((a.contype & b.conaffinity) || (b.contype & a.conaffinity))) continue;
+        int b1 = a.body, b2 = b.body;
+        if (b1 == b2) continue;
+        int w1 = body_weldid[b1], w2 = body_weldid[b2];
+        if (w1 == w2) continue;
+        if (excl.count({std::min(b1, b2), std::max(b1, b2)})) continue;
+        int wp1 = body_weldid[body_parentid[w1]], wp2 = body_weldid[body_parentid[w2]];
+        if ((w1 != 0 && w2 == wp1 && w2 != 0) || (w2 != 0 && w1 == wp2 && w1 != 0)) continue;   // parent-child filter (not applied when the parent is welded to the world)
+        if (a.type == GEOM_PLANE && b.type == GEOM_PLANE) continue;
+        if (a.type > b.type) { p1.push_back(g2); p2.push_back(g1); } else { p1.push_back(g1); p2.push_back(g2); }
+      }
+    }
+    m.seti1("npair", (long)p1.size()); m.seti("pair_geom1", p1); m.seti("pair_geom2", p2);
+  }
+  // ---- names (an unnamed object is the empty string in the blob)
+  {
+    auto col = [](const auto& items) { std::vector<std::string> o; for (auto& x : items) o.push_back(x.named ? x.name : ""); return o; };
+    m.names.emplace_back("body", col(bodies)); m.names.emplace_back("joint", col(joints)); m.names.emplace_back("geom", col(geoms)); m.names.emplace_back("site", col(sites));
+    m.names.emplace_back("camera", col(cams)); m.names.emplace_back("light", col(lights));
+    std::vector<std::string> an, sn; for (auto& a : act_names) an.push_back(a.second ? a.first : ""); for (auto& a : sens_names) sn.push_back(a.second ? a.first : "");
+    m.names.emplace_back("actuator", an); m.names.emplace_back("sensor", sn);
+    m.names.emplace_back("tendon", col(tendons)); m.names.emplace_back("equality", col(eqs));
+    std::vector<std::string> mn; for (auto& a : meshes) mn.push_back(a.name);
+    m.names.emplace_back("mesh", mn);
+  }
+
+  // ---- constants at qpos0 (mj_setConst [3P]): subtree masses, body / dof / tendon inverse weights through M^-1
+  {
+    vecd sub = body_mass;
+    for (int b = nbody - 1; b > 0; b--) sub[body_parentid[b]] += sub[b];
+    m.setd("body_subtreemass", sub);
+    vecd binv(2 * nbody, 0.0), dinv(nv, 0.0), dM0(nv, 0.0), Minv((size_t)nv * nv, 0.0);
+    if (nv > 0) {
+      // kinematics at qpos0 (mjcf.kinematics_np)
+      Kin k;
+      k.xpos.assign(nbody, {0, 0, 0}); k.xquat.assign(nbody, {1, 0, 0, 0}); k.xanchor.assign(njnt, {0, 0, 0}); k.xaxis.assign(njnt, {0, 0, 0});
+      for (int b = 1; b < nbody; b++) {
+        int p = body_parentid[b], jadr = body_jntadr[b], jnum = body_jntnum[b];
+        if (jnum == 1 && joints[jadr].type == JNT_FREE) {
+          int a = joints[jadr].qposadr;
+          k.xpos[b] = {qpos0[a], qpos0[a + 1], qpos0[a + 2]};
+          k.xquat[b] = qnormalize({qpos0[a + 3], qpos0[a + 4], qpos0[a + 5], qpos0[a + 6]});
+          k.xanchor[jadr] = k.xpos[b]; k.xaxis[jadr] = {0, 0, 1};
+          continue;
+        }
+        M3 Rp = q2m(k.xquat[p]);
+        V3 pos = k.xpos[p] + mv(Rp, bodies[b].pos);
+        Q quat = qmul(k.xquat[p], bodies[b].quat);
+        for (int j = jadr; j < jadr + jnum; j++) {
+          M3 R = q2m(quat);
+          k.xanchor[j] = pos + mv(R, joints[j].pos);
+          k.xaxis[j] = mv(R, joints[j].axis);
+          int a = joints[j].qposadr, t = joints[j].type;
+          if (t == JNT_HINGE) { quat = qmul(quat, axisangle2quat(joints[j].axis, qpos0[a] - qpos0[a])); pos = k.xanchor[j] - mv(q2m(quat), joints[j].pos); }
+          else if (t == JNT_SLIDE) pos = pos + k.xaxis[j] * (qpos0[a] - qpos0[a]);
+          else if (t == JNT_BALL) { quat = qmul(quat, qnormalize({qpos0[a], qpos0[a + 1], qpos0[a + 2], qpos0[a + 3]})); pos = k.xanchor[j] - mv(q2m(quat), joints[j].pos); }
+        }
+        k.xpos[b] = pos; k.xquat[b] = qnormalize(quat);
+      }
+      k.xmat.resize(nbody); k.xipos.resize(nbody); k.ximat.resize(nbody);
+      for (int b = 0; b < nbody; b++) {
+        k.xmat[b] = q2m(k.xquat[b]);
+        k.xipos[b] = k.xpos[b] + mv(k.xmat[b], {body_ipos[3 * b], body_ipos[3 * b + 1], body_ipos[3 * b + 2]});
+        k.ximat[b] = q2m(qmul(k.xquat[b], {body_iquat[4 * b], body_iquat[4 * b + 1], body_iquat[4 * b + 2], body_iquat[4 * b + 3]}));
+      }
+      // 6 x nv Jacobian [linear; angular] of a point attached to a body (mjcf.body_jacobian_np)
+      auto jac = [&](int body, V3 point, vecd& jp, vecd& jr) {
+        jp.assign((size_t)3 * nv, 0.0); jr.assign((size_t)3 * nv, 0.0);
+        auto setc = [&](vecd& J, int d, V3 v) { J[d] = v.x; J[nv + d] = v.y; J[2 * nv + d] = v.z; };
+        for (int b = body; b > 0; b = body_parentid[b]) {
+          for (int j = body_jntadr[b]; j < body_jntadr[b] + body_jntnum[b]; j++) {
+            int d = joints[j].dofadr, t = joints[j].type;
+            if (t == JNT_FREE) {
+              setc(jp, d, {1, 0, 0}); setc(jp, d + 1, {0, 1, 0}); setc(jp, d + 2, {0, 0, 1});
+              for (int c = 0; c < 3; c++) { V3 ax{k.xmat[b].m[0][c], k.xmat[b].m[1][c], k.xmat[b].m[2][c]}; setc(jr, d + 3 + c, ax); setc(jp, d + 3 + c, cross(ax, point - k.xpos[b])); }
+            } else if (t == JNT_BALL) {
+              for (int c = 0; c < 3; c++) { V3 ax{k.xmat[b].m[0][c], k.xmat[b].m[1][c], k.xmat[b].m[2][c]}; setc(jr, d + c, ax); setc(jp, d + c, cross(ax, point - k.xanchor[j])); }
+            } else if (t == JNT_SLIDE) setc(jp, d, k.xaxis[j]);
+            else { setc(jr, d, k.xaxis[j]); setc(jp, d, cross(k.xaxis[j], point - k.xanchor[j])); }
+          }
+        }
+      };
+      // M = sum_b J^T diag(m, I) J + armature (mjcf.mass_matrix_np)
+      vecd M((size_t)nv * nv, 0.0), jp, jr;
+      for (int b = 1; b < nbody; b++) {
+        if (body_mass[b] <= 0 && !(body_inertia[3 * b] > 0 || body_inertia[3 * b + 1] > 0 || body_inertia[3 * b + 2] > 0)) continue;
+        jac(b, k.xipos[b], jp, jr);
+        M3 D = {{{body_inertia[3 * b], 0, 0}, {0, body_inertia[3 * b + 1], 0}, {0, 0, body_inertia[3 * b + 2]}}};
+        M3 Iw = mm(mm(k.ximat[b], D), mt(k.ximat[b]));
+        for (int i = 0; i < nv; i++) {
+          double li[3] = {jp[i], jp[nv + i], jp[2 * nv + i]}, ri[3] = {jr[i], jr[nv + i], jr[2 * nv + i]};
+          if (li[0] == 0 && li[1] == 0 && li[2] == 0 && ri[0] == 0 && ri[1] == 0 && ri[2] == 0) continue;
+          double Ir[3]; for (int r = 0; r < 3; r++) Ir[r] = Iw.m[0][r] * ri[0] + Iw.m[1][r] * ri[1] + Iw.m[2][r] * ri[2];   // (ri^T Iw)_r
+          for (int j = 0; j < nv; j++) {
+            double s = body_mass[b] * (li[0] * jp[j] + li[1] * jp[nv + j] + li[2] * jp[2 * nv + j]) + Ir[0] * jr[j] + Ir[1] * jr[nv + j] + Ir[2] * jr[2 * nv + j];
+            M[(size_t)i * nv + j] += s;
+          }
+        }
+      }
+      const vecd& arm = m.D("dof_armature");
+      for (int i = 0; i < nv; i++) M[(size_t)i * nv + i] += arm[i];
+      for (int i = 0; i < nv; i++) dM0[i] = M[(size_t)i * nv + i];
+      // M^-1 through a Cholesky factorisation (numpy.linalg.inv there)
+      vecd L = M;
+      for (int j = 0; j < nv; j++) {
+        double s = L[(size_t)j * nv + j];
+        for (int c = 0; c < j; c++) s -= L[(size_t)j * nv + c] * L[(size_t)j * nv + c];
+        if (!(s > 0)) err("mass matrix at qpos0 is not positive definite (dof %d)", j);
+        double ljj = std::sqrt(s);
+        L[(size_t)j * nv + j] = ljj;
+        for (int i = j + 1; i < nv; i++) { double t = L[(size_t)i * nv + j]; for (int c = 0; c < j; c++) t -= L[(size_t)i * nv + c] * L[(size_t)j * nv + c]; L[(size_t)i * nv + j] = t / ljj; }
+      }
+      for (int c = 0; c < nv; c++) {
+        vecd y(nv, 0.0);
+        for (int i = 0; i < nv; i++) { double t = i == c ? 1.0 : 0.0; for (int q = 0; q < i; q++) t -= L[(size_t)i * nv + q] * y[q]; y[i] = t / L[(size_t)i * nv + i]; }
+        for (int i = nv - 1; i >= 0; i--) { double t = y[i]; for (int q = i + 1; q < nv; q++) t -= L[(size_t)q * nv + i] * Minv[(size_t)q * nv + c]; Minv[(size_t)i * nv + c] = t / L[(size_t)i * nv + i]; }
+      }
+      auto quad_trace = [&](const vecd& J) {   // trace(J Minv J^T) over the 3 rows
+        double tr = 0;
+        for (int r = 0; r < 3; r++) for (int i = 0; i < nv; i++) { double ji = J[(size_t)r * nv + i]; if (ji == 0) continue; double s = 0; for (int j = 0; j < nv; j++) s += Minv[(size_t)i * nv + j] * J[(size_t)r * nv + j]; tr += ji * s; }
+        return tr;
+      };
+      for (int b = 1; b < nbody; b++) {
+        if (body_weldid[b] == 0) continue;
+        jac(b, k.xipos[b], jp, jr);
+        binv[2 * b] = quad_trace(jp) / 3.0; binv[2 * b + 1] = quad_trace(jr) / 3.0;
+      }
+      for (int j = 0; j < njnt; j++) {
+        int d = joints[j].dofadr, t = joints[j].type;
+        auto dg = [&](int i) { return Minv[(size_t)i * nv + i]; };
+        if (t == JNT_FREE) { double a = (dg(d) + dg(d + 1) + dg(d + 2)) / 3.0, b2 = (dg(d + 3) + dg(d + 4) + dg(d + 5)) / 3.0; for (int q = 0; q < 3; q++) { dinv[d + q] = a; dinv[d + 3 + q] = b2; } }
+        else if (t == JNT_BALL) { double a = (dg(d) + dg(d + 1) + dg(d + 2)) / 3.0; for (int q = 0; q < 3; q++) dinv[d + q] = a; }
+        else dinv[d] = dg(d);
+      }
+    }
+    m.setd("body_invweight0", binv); m.setd("dof_invweight0", dinv); m.setd("dof_M0", dM0);
+    const int nt = (int)tendons.size();
+    vecd len0(nt, 0.0), tinv(nt, 0.0);
+    for (int t = 0; t < nt; t++) {
+      vecd J(nv, 0.0);
+      for (auto& w : tendons[t].wraps) { len0[t] += w.second * qpos0[joints[w.first].qposadr]; J[joints[w.first].dofadr] += w.second; }
+      double s = 0;
+      for (int i = 0; i < nv; i++) { if (J[i] == 0) continue; double r = 0; for (int j = 0; j < nv; j++) r += Minv[(size_t)i * nv + j] * J[j]; s += J[i] * r; }
+      tinv[t] = s;
+    }
+    m.setd("tendon_length0", len0); m.setd("tendon_invweight0", tinv);
+    if (nt) {   // springlength -1: rest length = length at qpos0
+      vecd ls = m.D("tendon_lengthspring");
+      for (int t = 0; t < nt; t++) if (ls[2 * t] == -1.0 && ls[2 * t + 1] == -1.0) { ls[2 * t] = len0[t]; ls[2 * t + 1] = len0[t]; }
+      m.setd("tendon_lengthspring", ls);
+    }
+  }
+  return m;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------ C-ABI (declared in include/rsim.h)
+extern "C" int rsim_set_error(const char* msg);   // rsim_api.cpp: the message rsim_last_error() returns; always returns 1
+static int fail_msg(const std::string& s) { return rsim_set_error(s.c_str()); }
+extern "C" int rsim_mjcf_to_blob(const char* xml, size_t len, const char* asset_dir, void** blob, size_t* blob_len) {
+  if (!xml || !blob || !blob_len) return fail_msg("rsim_mjcf_to_blob: NULL argument");
+  try {
+    Flat m = compile(xml, len, asset_dir ? asset_dir : "");
+    std::vector<unsigned char> b = to_blob(m);
+    void* p = malloc(b.size());
+    if (!p) return fail_msg("rsim_mjcf_to_blob: out of memory");
+    memcpy(p, b.data(), b.size());
+    *blob = p; *blob_len = b.size();
+    return 0;
+  } catch (const std::exception& e) { return fail_msg(std::string("MJCF compile error: ") + e.what()); }
+}
+extern "C" void rsim_blob_free(void* blob) { free(blob); }
+extern "C" int rsim_model_compile(const char* xml, size_t len, const char* asset_dir, rsim_model** out) {
+  if (!out) return fail_msg("rsim_model_compile: NULL argument");
+  void* blob = nullptr; size_t n = 0;
+  if (rsim_mjcf_to_blob(xml, len, asset_dir, &blob, &n)) return 1;
+  const int r = rsim_model_create(blob, n, out);
+  free(blob);
+  return r;
+}

@@ -100,20 +100,10 @@ typedef unsigned long long u64;
 #else
 #define RSIM_JG_ENABLED 0
 #endif
-#ifdef RSIM_JPREFETCH
-#define RSIM_JPF_ENABLED 1
-#else
-#define RSIM_JPF_ENABLED 0
-#endif
 #ifdef RSIM_JG256
 #define RSIM_JG256_ENABLED 1
 #else
 #define RSIM_JG256_ENABLED 0
-#endif
-#ifdef RSIM_JROWS
-#define RSIM_JROWS_ENABLED 1
-#else
-#define RSIM_JROWS_ENABLED 0
 #endif
 #ifdef RSIM_MGLOBAL
 #define RSIM_MG_ENABLED 1
@@ -349,8 +339,8 @@ struct Smem {
     float rowst[NV == 16 ? 1 : NEFC * 20];                                                 // make_constraint() (wide): per contact row the two 6-vectors (padded to 8) that multiply cdof, and the two bodies' dof masks
     float W[NV == 16 ? NEFC * (NV + 1) : NEFC * 5];                                        // solve_newton(): Hessian-weighted rows (one-tile configurations); wide: five words per row (four block coefficients, block head | dim | cone flag) from which the products form the weighted row on the fly
   } u;
-  // RSIM_MGLOBAL (on top of RSIM_JGLOBAL; NOT enabled, not yet run on hardware -- prepared at the end of round 4): the mass matrix
-  // behind J in the same per-env global buffer: 49.7 -> 40.3 KB = FOUR environments per CU, one wavefront per SIMD
+  // RSIM_MGLOBAL (on top of RSIM_JGLOBAL): the mass matrix behind J in the same per-env global buffer: 49.7 -> 40.3 KB = FOUR environments per CU, one wavefront
+  // per SIMD.  PickPlace @8192 + DR: 112.4 -> 89.5 ms per control step (+25.6 %, five round-robin reps, profiles/r05_a_ab_variants_pickplace.txt)
   static constexpr bool MG_ = RSIM_MG_ENABLED && RSIM_JG_ENABLED && NV == 48 && NEFC == 128;
   float M[MG_ ? 4 : NV * NVP];
   union { float L[NV * NVP]; float H[NV * NVP]; };  // L (factor of M) is dead once qacc_smooth exists; H is the solver / Euler work matrix
@@ -365,7 +355,7 @@ struct Smem {
   // constraint rows
   // RSIM_JGLOBAL (64 x 48 build with 128 rows only): the constraint Jacobian lives in a per-env buffer in GLOBAL memory (DBatch.jg; 25 KB per env, L2-resident
   // for the resident envs of an XCD) instead of LDS: 74.8 -> 49.7 KB = three environments per CU instead of two
-  // (RSIM_JG256, prepared and not enabled: the 256-row tier of the same shape as well -- 116 -> 66 KB, two jumbo envs per CU instead of one)
+  // (RSIM_JG256: the 256-row tier of the same shape as well -- 116 -> 66 KB, two jumbo envs per CU instead of one)
   static constexpr bool JG_ = RSIM_JG_ENABLED && NV == 48 && (NEFC == 128 || (RSIM_JG256_ENABLED && NEFC == 256));
   float J[JG_ ? 4 : NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
   float e_R[NEFC], e_aref[NEFC], e_force[NEFC];   // e_force doubles as the row's velocity gain B between make_constraint's two halves
@@ -1008,12 +998,6 @@ struct Sim {
   static constexpr bool JG = SM::JG_;
   gwf Jg = nullptr;                                         // JG builds: this env's constraint Jacobian [NEFC][JS] in global memory (DBatch.jg)
   static constexpr bool MG = SM::MG_;
-  // RSIM_JROWS (JG builds; prepared like RSIM_MGLOBAL, not yet run on hardware): a lane keeps the Jacobian rows it owns in registers for the duration of the solve
-  // (NSLOT x NV floats) instead of fetching them from the global buffer for every residual / direction product
-  static constexpr bool JROWS = RSIM_JROWS_ENABLED && SM::JG_;
-  // RSIM_JPREFETCH (JG builds; prepared, not yet run on hardware): the MFMA operand loads of J^T f and H = M + J^T W J are issued for several row chunks at
-  // once -- an L2 round trip is ~5 x an LDS one, and the loops below wait for one chunk's operands before they issue the next chunk's loads
-  static constexpr bool JPF = RSIM_JPF_ENABLED && SM::JG_;
   gwf Mg = nullptr;                                         // MG builds: this env's mass matrix [NV][NVP] in global memory (behind J in DBatch.jg)
   __device__ __forceinline__ float Mrd(int i) const { if constexpr (MG) return Mg[i]; else return sm.M[i]; }
   __device__ __forceinline__ void Mwr(int i, float v) const { if constexpr (MG) Mg[i] = v; else sm.M[i] = v; }
@@ -2234,6 +2218,7 @@ struct Sim {
   // the 256-register build more in spills than the list saves.
   int task_obj = 0;                     // PickPlace single-object mode 1: this env's object (DBatch.task_object)
   int act_n = -1;                       // pairs on the list (-1: none)
+  float applied = 0.f;   // this lane's dof: mjData.qfrc_applied (RSIM_QFRC_APPLIED), read by the debug form of the kernel only (step_body)
   int __attribute__((address_space(1)))* bpl = nullptr;   // [0..2][lane g]: centre of geom g's bounding sphere when the list was built; [3][lane i]: packed
                                                           // constants (geom1 | geom2 << 8 | enabled << 16) of the i-th listed pair; [4][lane i]: its index
   // one candidate pair: does it pass the broadphase now (pass), could it within `reach` (near: bounding spheres / plane distance only)
@@ -2770,7 +2755,7 @@ struct Sim {
     SYNC();
     float qs = 0.f;
     if (lane < nv) {
-      qs = sm.qfrc_passive[lane] - sm.qfrc_bias[lane] + sm.qfrc_actuator[lane];
+      qs = sm.qfrc_passive[lane] - sm.qfrc_bias[lane] + sm.qfrc_actuator[lane] + applied;   // mjData.qfrc_applied: the debug form only (0 in the fused kernels)
       sm.qfrc_smooth[lane] = qs;
     }
     float as;
@@ -3219,7 +3204,7 @@ struct Sim {
   // H = M + J^T W and J^T f run on the matrix cores (v_mfma_f32_16x16x4_f32, 4 rows per instruction); the Hessian
   // factorisation is the register-resident Cholesky above.  Algorithm = oracle solve_newton (MuJoCo's primal Newton).
   struct Row {
-    float J[(FAST || JROWS) ? NV16 : 1];   // one-tile configuration: the Jacobian row stays in registers; wide configurations read it from LDS (JROWS builds: registers too)
+    float J[FAST ? NV16 : 1];   // one-tile configuration: the Jacobian row stays in registers; wide configurations read it from LDS / the global buffer
     float D, R, aref, fl, mu, fr_own, Dm;
     float fj[CD - 1];
     int row, type, head, kk, dim;
@@ -3228,12 +3213,7 @@ struct Sim {
   // sum_k r[k] * x_k.  One-tile configuration: x is replicated in every 16-lane row (DPP row broadcast); wide: x_k lives in lane k (readlane)
   __device__ __forceinline__ float row_dot(const Row& rw, float x) const {
     if constexpr (FAST) return dot_rows<NV16>(rw.J, x);
-    else if constexpr (JROWS) {
-      float acc = 0.f;
-#pragma unroll
-      for (int u = 0; u < NV16; u++) acc = fmaf(rw.J[u], bcast(x, u), acc);
-      return acc;
-    } else return j_row_dot(rw.row * JS, x);
+    else return j_row_dot(rw.row * JS, x);
   }
   // wide configurations: sum_k p[k] x_k over the 16-column tiles that hold dofs (columns nv .. 16 ceil(nv / 16) - 1 hold zeros, x_k = 0 there).
   // One wavefront per SIMD and nothing else to switch to: a read-then-use loop pays the full LDS latency per element, so the sixteen reads of a
@@ -3252,13 +3232,7 @@ struct Sim {
     }
   }
   __device__ __forceinline__ double row_res64(const Row& rw, float x, float xl) const {
-    if constexpr (JROWS) {
-      double acc = -(double)rw.aref;
-      float lo = 0.f;
-#pragma unroll
-      for (int u = 0; u < NV16; u++) { acc = fma((double)rw.J[u], (double)bcast(x, u), acc); lo = fmaf(rw.J[u], bcast(xl, u), lo); }
-      return acc + (double)lo;
-    } else return j_row_res64(rw.row * JS, x, xl, rw.aref);
+    return j_row_res64(rw.row * JS, x, xl, rw.aref);
   }
   __device__ __forceinline__ double j_row_res64(int base, float x, float xl, float aref) const {
     if constexpr (!JG) return lds_row_res64(sm.J + base, x, xl, aref);
@@ -3401,23 +3375,6 @@ struct Sim {
 #pragma unroll
       for (int t = 0; t < NBT; t++) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
       const int q = lane >> 4, col = lane & 15;
-      if constexpr (JPF) {
-        for (int c0 = 0; c0 < nch; c0 += 8) {
-          float ja[8][NBT], fb[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const bool on = c0 + u < nch;                 // chunks past the last one: row 0 with a zero force (no read past the buffers)
-            const int r = on ? 4 * (c0 + u) + q : 0;
-            fb[u] = on ? sm.e_force[r] : 0.f;
-#pragma unroll
-            for (int t = 0; t < NBT; t++) ja[u][t] = Jg[r * JS + 16 * t + col];
-          }
-#pragma unroll
-          for (int u = 0; u < 8; u++)
-#pragma unroll
-            for (int t = 0; t < NBT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ja[u][t], fb[u], acc[t], 0, 0, 0);
-        }
-      } else
       for (int c0 = 0; c0 < nch; c0 += 2) {
         float ja[2][NBT], fb[2];
 #pragma unroll
@@ -3463,7 +3420,6 @@ struct Sim {
         const float* o = sm.u.W + 5 * q;
         cf[0] = o[0]; cf[1] = o[1]; cf[2] = o[2]; cf[3] = o[3]; bd = ((const int*)o)[4];
       }
-      float bjn[JPF ? 4 : 1][NBT];
       for (int c = 0; c < nch; c++) {
         const int r = 4 * c + q;
         float cfn[4];
@@ -3473,22 +3429,8 @@ struct Sim {
           cfn[0] = o[0]; cfn[1] = o[1]; cfn[2] = o[2]; cfn[3] = o[3]; bdn = ((const int*)o)[4];
         }
         float bj[NBT], aj[NBT];
-        if constexpr (JPF) {
-          // B operands of this chunk and the next three in one batch of loads, every fourth chunk (the group's registers are indexed at compile time)
-          if ((c & 3) == 0) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const int ru = (c + u < nch) ? 4 * (c + u) + q : r;
-#pragma unroll
-              for (int t = 0; t < NBT; t++) bjn[u][t] = Jg[ru * JS + 16 * t + col];
-            }
-          }
-#pragma unroll
-          for (int t = 0; t < NBT; t++) bj[t] = (c & 3) == 0 ? bjn[0][t] : ((c & 3) == 1 ? bjn[1][t] : ((c & 3) == 2 ? bjn[2][t] : bjn[3][t]));
-        } else {
 #pragma unroll
         for (int t = 0; t < NBT; t++) bj[t] = Jrd(r * JS + 16 * t + col);
-        }
         if (__ballot((bd >> 16) & 1)) {
           const int head = bd & 255, dm1 = ((bd >> 8) & 7) - 1;
           const int j0 = head * JS + col;
@@ -3573,10 +3515,6 @@ struct Sim {
 #pragma unroll
         for (int k = 0; k < NV16; k++) w_.J[k] = sm.J[row * JS + k];  // rows >= n were written as zeros
       }
-      if constexpr (JROWS) {
-#pragma unroll
-        for (int k = 0; k < NV16; k++) w_.J[k] = SLOT_ON(s) ? Jg[row * JS + k] : 0.f;   // rows >= n of an active slot were written as zeros
-      }
       const int desc = w_.valid ? sm.e_desc[r] : 0;
       w_.type = w_.valid ? (desc & 15) : -1;
       const bool tfric = TENDONS && w_.type == C_FRICTION_TENDON;   // a tendon friction row behaves as a dof friction row from here on
@@ -3620,42 +3558,9 @@ struct Sim {
       for (int s = 0; s < NSLOT; s++) if SLOT_ON(s) c += row_update(rw[s], jar[s], force[s], state[s], uj[s], T[s], g[s]);
       return c;
     };
-    // ---- warm start: previous acceleration unless the unconstrained one is cheaper
-    float cost_sm = wave_sum(evaluate(a_sm));
-    float cost_ws = wave_sum(evaluate(a_ws));
-    {
-      const float dws = a_ws - a_sm, sv = mass_dot(Mr, dws);
-      cost_ws += wave_sum(dofl ? 0.5f * sv * dws : 0.f);
-    }
-    SUBMARK(RP_X1);
-    float a = cost_ws < cost_sm ? a_ws : a_sm;
-    int iter = 0;
-    bool factored = false;    // sm.H holds a Cholesky factor of a Hessian of this solve (wide configurations)
-    bool have_eval = false;   // the rows are already evaluated at `a` (cost_pre)
-    float cost_pre = 0.f;
-    for (;;) {
-      float cost = have_eval ? cost_pre : wave_sum(evaluate(a));
-      have_eval = false;
-      int state0[NSLOT];
-#pragma unroll
-      for (int s = 0; s < NSLOT; s++) state0[s] = state[s];
-      const float ma = mass_dot(Mr, a);
-      const float gauss = wave_sum(dofl ? 0.5f * (ma - f_sm) * (a - a_sm) : 0.f);
-      cost += gauss;
-#pragma unroll
-      for (int s = 0; s < NSLOT; s++) sm.e_force[lane + 64 * s] = force[s];
-      SYNC();
-      const float jf = jt_times_force(nch);
-      float gk = rr < nv ? ma - f_sm - jf : 0.f;
-      const float gn = wave_sum(dofl ? gk * gk : 0.f);
-      SUBMARK(RP_X2);
-      if (iter >= m.iterations || scale * sqrtf(gn) < tolerance) break;
-      // fp32: the gradient is a difference of O(100) N m terms, good to ~1e-7 of THEIR size -- MuJoCo's 1e-8 (scaled) is below that floor for every
-      // loaded arm, so the fp64 test above never fires here and the loop used to run until a step happened not to lower the (equally noisy) cost:
-      // 150-230 iterations per control step where the fp64 oracle takes 25-80 on the same states (tools/newton_iters.py), half the run time of the
-      // slowest envs of a launch.  A gradient whose every component is within the rounding noise of its own three terms is converged.
-      if (m.newton_ng > 0.f && !__ballot(dofl && rr < nv && fabsf(gk) > m.newton_ng * (fabsf(ma) + fabsf(f_sm) + fabsf(jf)))) break;
-      // ---- Hessian weights W (row r): D J_r (quadratic), 0 (linear / satisfied), cone block Hc J_block
+    // Hessian weights W (row r): D J_r (quadratic), 0 (linear / satisfied), cone block Hc J_block -- from the rows' states and residuals as the last evaluation
+    // left them (state, jar, uj, T, g); written to LDS for the matrix-core product.  Used by the iteration and by the fp64-evaluated passes behind it.
+    auto weights = [&]() {
 #pragma unroll
       for (int s = 0; s < NSLOT; s++) {
         const Row& w_ = rw[s];
@@ -3705,13 +3610,15 @@ struct Sim {
           }
         }
       }
-      SYNC();
-      float sk;
-      SUBMARK(RP_X3);
+    };
+    // wide configurations: H = M + J^T W as MFMA tiles (lower triangle of tiles: the factorisation reads nothing above the diagonal blocks), factorised in place
+    // on the LDS matrix (H aliases the dead factor of M); tiles beyond the model's dofs (37 of 64 in the PickPlace model) are neither formed nor read
+    bool factored = false;    // sm.H holds a Cholesky factor of a Hessian of this solve (wide configurations)
+    int fst[NSLOT];           // ... built on these row states
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) fst[s] = ST_SATISFIED;
+    auto factorize = [&]() {
       if constexpr (!FAST) {
-        // H = M + J^T W as MFMA tiles (lower triangle of tiles: the factorisation reads nothing above the diagonal blocks), factorised in place
-        // on the LDS matrix (H aliases the dead factor of M); tiles beyond the model's dofs (37 of 64 in the PickPlace model) are neither
-        // formed nor read
         switch ((nv + 15) >> 4) {
           case 1: hess_wide<1>(nch); break;
           case 2: hess_wide<2>(nch); break;
@@ -3722,7 +3629,51 @@ struct Sim {
         SUBMARK_H(RP_X7);
         bchol_inplace<NVP>(sm.H, sm.invdiag, nv, lane);
         factored = true;
+#pragma unroll
+        for (int s = 0; s < NSLOT; s++) fst[s] = state[s];
         SUBMARK_H(RP_X8);
+      }
+    };
+    // ---- warm start: previous acceleration unless the unconstrained one is cheaper
+    float cost_sm = wave_sum(evaluate(a_sm));
+    float cost_ws = wave_sum(evaluate(a_ws));
+    {
+      const float dws = a_ws - a_sm, sv = mass_dot(Mr, dws);
+      cost_ws += wave_sum(dofl ? 0.5f * sv * dws : 0.f);
+    }
+    SUBMARK(RP_X1);
+    float a = cost_ws < cost_sm ? a_ws : a_sm;
+    int iter = 0;
+    bool have_eval = false;   // the rows are already evaluated at `a` (cost_pre)
+    float cost_pre = 0.f;
+    for (;;) {
+      float cost = have_eval ? cost_pre : wave_sum(evaluate(a));
+      have_eval = false;
+      int state0[NSLOT];
+#pragma unroll
+      for (int s = 0; s < NSLOT; s++) state0[s] = state[s];
+      const float ma = mass_dot(Mr, a);
+      const float gauss = wave_sum(dofl ? 0.5f * (ma - f_sm) * (a - a_sm) : 0.f);
+      cost += gauss;
+#pragma unroll
+      for (int s = 0; s < NSLOT; s++) sm.e_force[lane + 64 * s] = force[s];
+      SYNC();
+      const float jf = jt_times_force(nch);
+      float gk = rr < nv ? ma - f_sm - jf : 0.f;
+      const float gn = wave_sum(dofl ? gk * gk : 0.f);
+      SUBMARK(RP_X2);
+      if (iter >= m.iterations || scale * sqrtf(gn) < tolerance) break;
+      // fp32: the gradient is a difference of O(100) N m terms, good to ~1e-7 of THEIR size -- MuJoCo's 1e-8 (scaled) is below that floor for every
+      // loaded arm, so the fp64 test above never fires here and the loop used to run until a step happened not to lower the (equally noisy) cost:
+      // 150-230 iterations per control step where the fp64 oracle takes 25-80 on the same states (tools/newton_iters.py), half the run time of the
+      // slowest envs of a launch.  A gradient whose every component is within the rounding noise of its own three terms is converged.
+      if (m.newton_ng > 0.f && !__ballot(dofl && rr < nv && fabsf(gk) > m.newton_ng * (fabsf(ma) + fabsf(f_sm) + fabsf(jf)))) break;
+      weights();
+      SYNC();
+      float sk;
+      SUBMARK(RP_X3);
+      if constexpr (!FAST) {
+        factorize();
         sk = bchol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -gk : 0.f, nv, lane);
         if (lane >= nv) sk = 0.f;
         SUBMARK_H(RP_X9);
@@ -3846,23 +3797,33 @@ struct Sim {
       }
     }
     if constexpr (!FAST) {
-      // ---- refinement of the solution with an fp64 gradient (wide configurations).  What fp32 cannot resolve on these models: a direction of 1e-5 ..
-      // 4e-3 kg m^2 (an object's or a Robotiq link's own rotation) beside contact rows of D ~ 1e6.  The cost is flat there to fp32 (half H_soft da^2 of
-      // 1e-3 in a cost of 1e3), so the iteration above stops a hundred rad/s^2 short -- optimal to 1e-6 in its own objective, which is all round 3 could
-      // assert per env.  The GRADIENT tells the directions apart if its parts are kept apart: residuals J a - aref, the forces they give and J^T f
-      // summed in fp64 from the float data (every product exact), the acceleration carried as a pair of floats.  Classic iterative refinement then:
-      // da = -H^-1 g with the fp32 factor already in LDS (it resolves the soft directions to a few per cent, so every pass gains a factor of ~20),
-      // no new factorisation, states as the last evaluation left them.
+      // ---- polish of the solution with everything that DECIDES evaluated in fp64 (wide configurations).  What fp32 cannot resolve on these models: a direction
+      // of 1e-5 .. 4e-3 kg m^2 (an object's or a Robotiq link's own rotation) beside contact rows of D ~ 1e6.  The cost is flat there to fp32 (half H_soft da^2 of
+      // 1e-3 in a cost of 1e3), so the iteration above stops a hundred rad/s^2 short, or on the wrong side of a row's state change.  The GRADIENT tells the
+      // directions apart if its parts are kept apart: residuals J a - aref, the row states and forces they give, the objective and J^T f summed in fp64 from the
+      // float data (every product exact), the acceleration carried as a pair of floats.  Each pass is then a Newton step of the TRUE objective:
+      //   * rows are re-classified from the fp64 residuals (rounds 3-4 froze them where the fp32 iteration had left them and threw the pass away when a row turned
+      //     out to sit in another state: exactly the envs of the tail, whose per-env deviation from the fp64 oracle stayed at 1e-1 of the largest acceleration);
+      //   * the direction is -H^-1 g with the fp32 factor in LDS (it resolves the soft directions to a few per cent: a pass gains a factor of ~20); when the
+      //     rows' states are no longer the ones the factor was built on, H is formed and factorised again (fp32, matrix cores) from the fp64-decided states;
+      //   * a step is kept only if it lowers the fp64 objective; one that does not (it crossed a state boundary) is halved, at most three times;
+      //   * passes end on MuJoCo's own criteria, evaluated in fp64: scaled gradient or scaled improvement below `tolerance`, or after `newton_refine` passes.
       const int R = m.newton_refine;
       if (R > 0 && factored && n > 0) {
-        float a_lo = 0.f, a_keep = a, alo_keep = 0.f, force_keep[NSLOT];
+        float a_lo = 0.f, a_keep = a, alo_keep = 0.f, force_keep[NSLOT], dk = 0.f;
+        int state_keep[NSLOT];
         double err_keep = 1.0e300;
-        const float a_in = a;
-        float force_in[NSLOT];
-        int state_in[NSLOT];
+        int nback = 0;
 #pragma unroll
-        for (int s = 0; s < NSLOT; s++) { force_keep[s] = force[s]; force_in[s] = force[s]; state_in[s] = state[s]; }
-        for (int it = 0;; it++) {
+        for (int s = 0; s < NSLOT; s++) { force_keep[s] = force[s]; state_keep[s] = state[s]; }
+        // (hi, lo) += d, exactly up to the pair's precision
+        auto dfadd = [](float& hi, float& lo, float d) {
+          const float sm_ = __fadd_rn(hi, d), bb = __fsub_rn(sm_, hi), se = __fadd_rn(__fsub_rn(hi, __fsub_rn(sm_, bb)), __fsub_rn(d, bb));   // hi + d = sm_ + se exactly
+          const float l2 = __fadd_rn(lo, se);
+          hi = __fadd_rn(sm_, l2);
+          lo = __fsub_rn(l2, __fsub_rn(hi, sm_));
+        };
+        for (int it = 0;;) {
           double jr[NSLOT], u64[NSLOT], c64 = 0.0;   // c64: this lane's share of the objective at a + a_lo, in fp64 (same pieces as row_update)
 #pragma unroll
           for (int s = 0; s < NSLOT; s++) { jr[s] = SLOT_ON(s) ? row_res64(rw[s], a, a_lo) : 0.0; u64[s] = jr[s] * (double)rw[s].fr_own; }
@@ -3878,23 +3839,47 @@ struct Sim {
               for (int s2 = 1; s2 < NSLOT; s2++) { const double t1 = __shfl(u64[s2], Rr & 63); t = (Rr >> 6) == s2 ? t1 : t; }
               uj64[j] = (w_.ell && j < w_.dim) ? t : 0.0;
             }
-            double f = 0.0;
+            // force / state / cost of the row at its fp64 residual: row_update() in double
+            double f = 0.0, Tn = 0.0, gg = 0.0;
+            int st = ST_SATISFIED;
             if (w_.valid && SLOT_ON(s)) {
-              if (state[s] == ST_QUADRATIC) { f = -(double)w_.D * jr[s]; c64 += 0.5 * (double)w_.D * jr[s] * jr[s]; }
-              else if (state[s] == ST_LINEARNEG) { f = (double)w_.fl; c64 += (double)w_.fl * (-0.5 * (double)w_.R * (double)w_.fl - jr[s]); }
-              else if (state[s] == ST_LINEARPOS) { f = -(double)w_.fl; c64 += (double)w_.fl * (-0.5 * (double)w_.R * (double)w_.fl + jr[s]); }
-              else if (state[s] == ST_CONE) {
+              const double x = jr[s], D = (double)w_.D;
+              if (w_.type == C_FRICTION_DOF) {
+                const double fl = (double)w_.fl, lim = (double)w_.R * fl;
+                if (x <= -lim) { st = ST_LINEARNEG; f = fl; c64 += fl * (-0.5 * lim - x); }
+                else if (x >= lim) { st = ST_LINEARPOS; f = -fl; c64 += fl * (-0.5 * lim + x); }
+                else { st = ST_QUADRATIC; f = -D * x; c64 += 0.5 * D * x * x; }
+              } else if (TENDONS && w_.type == C_EQUALITY) {
+                st = ST_QUADRATIC; f = -D * x; c64 += 0.5 * D * x * x;
+              } else if (!w_.ell) {
+                if (x < 0) { st = ST_QUADRATIC; f = -D * x; c64 += 0.5 * D * x * x; }
+              } else {
+                const double N = uj64[0], mu = (double)w_.mu;
                 double T2 = 0.0;
 #pragma unroll
                 for (int j = 1; j < CD; j++) T2 = fma(uj64[j], uj64[j], T2);
-                const double Tn = sqrt(T2), gg = uj64[0] - (double)w_.mu * Tn, f0 = -(double)w_.Dm * gg * (double)w_.mu;
-                f = w_.kk == 0 ? f0 : -f0 / Tn * u64[s] * (double)w_.fr_own;
-                if (w_.kk == 0) c64 += 0.5 * (double)w_.Dm * gg * gg;
+                Tn = sqrt(T2);
+                if (N >= mu * Tn || (Tn <= 0 && N >= 0)) {
+                } else if (mu * N + Tn <= 0 || (Tn <= 0 && N < 0)) {
+                  st = ST_QUADRATIC; f = -D * x; c64 += 0.5 * D * x * x;
+                } else {
+                  gg = N - mu * Tn;
+                  const double f0 = -(double)w_.Dm * gg * mu;
+                  st = ST_CONE;
+                  if (w_.kk == 0) { f = f0; c64 += 0.5 * (double)w_.Dm * gg * gg; }
+                  else f = -f0 / Tn * u64[s] * (double)w_.fr_own;
+                }
               }
             }
+            // what weights() reads, should this point's states ask for another factor
+            state[s] = st; jar[s] = (float)jr[s]; T[s] = (float)Tn; g[s] = (float)gg;
+#pragma unroll
+            for (int j = 0; j < CD; j++) uj[s][j] = (float)uj64[j];
             force[s] = (float)f;
-            sm.u.W[w_.row] = force[s];                                  // the force as hi + lo floats for the dof lanes
-            sm.u.W[NEFCAP + w_.row] = (float)(f - (double)force[s]);
+            if SLOT_ON(s) {
+              sm.u.W[w_.row] = force[s];                                  // the force as hi + lo floats for the dof lanes
+              sm.u.W[NEFCAP + w_.row] = (float)(f - (double)force[s]);
+            }
           }
           SYNC();
           double gk = 0.0;
@@ -3903,52 +3888,45 @@ struct Sim {
             for (int j = 0; j < nv; j++) ma = fma((double)Mrd(lane * NVP + j), (double)bcast(a, j) + (double)bcast(a_lo, j), ma);
             for (int r = 0; r < n; r++) jf = fma((double)Jrd(r * JS + lane), (double)sm.u.W[r] + (double)sm.u.W[NEFCAP + r], jf);
             gk = ma - (double)f_sm - jf;
-          }
-          // the objective itself, in fp64: rows + Gauss term half (M a - f_smooth) . (a - a_smooth).  A pass that does not lower it (the factor in LDS belongs to
-          // another active set than the point the iteration ended on, or resolves none of the direction the gradient points in) is undone, and the refinement ends.
-          {
-            double ma = 0.0;
-            if (lane < nv) for (int j = 0; j < nv; j++) ma = fma((double)Mrd(lane * NVP + j), (double)bcast(a, j) + (double)bcast(a_lo, j), ma);
-            if (lane < nv) c64 += 0.5 * (ma - (double)f_sm) * ((double)a + (double)a_lo - (double)a_sm);
+            // the objective's Gauss term half (M a - f_smooth) . (a - a_smooth)
+            c64 += 0.5 * (ma - (double)f_sm) * ((double)a + (double)a_lo - (double)a_sm);
           }
           const double err = wave_sum_f64(c64);
           if (!(err < err_keep)) {
+            // not lower (or not a number): half the step from the kept point, unless the difference is rounding of the objective itself
+            if (it > 0 && nback < 3 && err - err_keep > 1e-13 * fabs(err_keep)) {
+              nback++;
+              dk *= 0.5f;
+              a = a_keep; a_lo = alo_keep;
+              dfadd(a, a_lo, dk);
+              SYNC();
+              continue;
+            }
             a = a_keep; a_lo = alo_keep;
 #pragma unroll
-            for (int s = 0; s < NSLOT; s++) force[s] = force_keep[s];
+            for (int s = 0; s < NSLOT; s++) { force[s] = force_keep[s]; state[s] = state_keep[s]; }
             break;
           }
-          a_keep = a; alo_keep = a_lo; err_keep = err;
+          const double gain = err_keep - err;
+          a_keep = a; alo_keep = a_lo; err_keep = err; nback = 0;
 #pragma unroll
-          for (int s = 0; s < NSLOT; s++) force_keep[s] = force[s];
-          if (it == R) break;
-          const float dk = bchol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -(float)gk : 0.f, nv, lane);
-          {
-            const float sm_ = __fadd_rn(a, dk), bb = __fsub_rn(sm_, a), se = __fadd_rn(__fsub_rn(a, __fsub_rn(sm_, bb)), __fsub_rn(dk, bb));   // a + dk = sm_ + se exactly
-            const float lo = __fadd_rn(a_lo, se);
-            a = __fadd_rn(sm_, lo);
-            a_lo = __fsub_rn(lo, __fsub_rn(a, sm_));
-          }
+          for (int s = 0; s < NSLOT; s++) { force_keep[s] = force[s]; state_keep[s] = state[s]; }
+          const double gn = wave_sum_f64(lane < nv ? gk * gk : 0.0);
+          if (it >= R || (double)scale * sqrt(gn) < (double)tolerance || (it > 0 && (double)scale * gain < (double)tolerance)) break;
+          it++;
+          bool other = false;
+#pragma unroll
+          for (int s = 0; s < NSLOT; s++) if SLOT_ON(s) other |= rw[s].valid && state[s] != fst[s];
           SYNC();
-        }
-        // the passes held every row in the state the iteration left it in: the refined point is only kept if the rows ARE in those states there (a
-        // refinement that walks across a state boundary has minimised the wrong piece)
-        if (a != a_in) {
-          float fr_[NSLOT];
-#pragma unroll
-          for (int s = 0; s < NSLOT; s++) fr_[s] = force[s];
-          evaluate(a);
-          bool moved = false;
-#pragma unroll
-          for (int s = 0; s < NSLOT; s++) if SLOT_ON(s) moved |= rw[s].valid && state[s] != state_in[s];
-          if (__ballot(moved)) {
-            a = a_in;
-#pragma unroll
-            for (int s = 0; s < NSLOT; s++) { force[s] = force_in[s]; state[s] = state_in[s]; }
-          } else {
-#pragma unroll
-            for (int s = 0; s < NSLOT; s++) force[s] = fr_[s];
+          if (__ballot(other)) {   // the factor in LDS belongs to another active set: H from these states
+            weights();
+            SYNC();
+            factorize();
           }
+          dk = bchol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -(float)gk : 0.f, nv, lane);
+          if (lane >= nv) dk = 0.f;
+          dfadd(a, a_lo, dk);
+          SYNC();
         }
       }
     }
@@ -4177,9 +4155,10 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   sim.cst = (gwf)(b.cstate + (size_t)env * cs);
   if (b.bpl) sim.bpl = (int __attribute__((address_space(1)))*)(b.bpl + (size_t)env * 320);
   if (b.mprc) { sim.mprc = (gwf)(b.mprc + (size_t)env * Sim<SM>::MPRC * m.npair); sim.mpr_portal = b.mprc_portal != 0; }
-  if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * (SM::NEFC_ * SM::JS_ + (SM::MG_ ? SM::NV_ * SM::NVP : 0)));
+  if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * b.jg_stride);   // one stride for every configuration that steps envs of this batch (the native and the wide pass run side by side)
   if constexpr (Sim<SM>::MG) sim.Mg = sim.Jg + SM::NEFC_ * SM::JS_;
   if (lane < csl) sm.cstate[lane] = sim.cst[lane];
+  if constexpr (DBG) if (b.qfrc_applied && lane < m.nv) sim.applied = b.qfrc_applied[(size_t)env * m.nv + lane];   // user forces of the B = 1 shim entries (GripperTester's gravity compensation)
   if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; }
   sim.load_opt();
   sim.init_lds();
@@ -4324,12 +4303,14 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
     }
     if (lane == 0) { b.done[env] = done ? 1 : 0; b.ep_step[env] = st; }
   }
-  // ---- store state
-  for (int i = lane; i < m.nq; i += 64) b.qpos[(size_t)env * m.nq + i] = sm.qpos[i];
-  for (int i = lane; i < m.nv; i += 64) { b.qvel[(size_t)env * m.nv + i] = sm.qvel[i]; b.qacc_ws[(size_t)env * m.nv + i] = sm.qacc_ws[i]; }
-  for (int i = lane; i < m.nu; i += 64) b.ctrl[(size_t)env * m.nu + i] = sm.ctrl[i];
-  if (lane < csl) sim.cst[lane] = sm.cstate[lane];
-  if (lane == 0) b.time[env] = time;
+  // ---- store state (the debug form under RF_NOSTORE -- the refresh of the derived arrays when the host reads one after a fused step -- leaves it alone)
+  if (!DBG || !(flags & RF_NOSTORE)) {
+    for (int i = lane; i < m.nq; i += 64) b.qpos[(size_t)env * m.nq + i] = sm.qpos[i];
+    for (int i = lane; i < m.nv; i += 64) { b.qvel[(size_t)env * m.nv + i] = sm.qvel[i]; b.qacc_ws[(size_t)env * m.nv + i] = sm.qacc_ws[i]; }
+    for (int i = lane; i < m.nu; i += 64) b.ctrl[(size_t)env * m.nu + i] = sm.ctrl[i];
+    if (lane < csl) sim.cst[lane] = sm.cstate[lane];
+    if (lane == 0) b.time[env] = time;
+  }
   if (b.overflow && lane == 0 && sim.ovf) b.overflow[env] += sim.ovf;   // with capacity tiers: drops of the WIDE configuration only (pass 0 left above)
   if (b.cap_need && lane == 0) { int* cn = b.cap_need + 2 * (size_t)env; if (sim.need_con > cn[0]) cn[0] = sim.need_con; if (sim.need_efc > cn[1]) cn[1] = sim.need_efc; }
   if (b.cost && lane == 0) b.cost[env] = (unsigned)(clock64() >> 6) - t_launch;
@@ -4403,7 +4384,7 @@ __global__ __launch_bounds__(64) void k_ctrl_reset(DModel m, DBatch b, const uns
   for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = b.qpos[(size_t)env * m.nq + i];
   const int cs = m.ctrl.cs_size, csl = cs < RSIM_CS_LDS ? cs : RSIM_CS_LDS;
   sim.cst = (gwf)(b.cstate + (size_t)env * cs);
-  if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * (SM::NEFC_ * SM::JS_ + (SM::MG_ ? SM::NV_ * SM::NVP : 0)));
+  if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * b.jg_stride);   // one stride for every configuration that steps envs of this batch (the native and the wide pass run side by side)
   if constexpr (Sim<SM>::MG) sim.Mg = sim.Jg + SM::NEFC_ * SM::JS_;
   if (lane < csl) sm.cstate[lane] = 0.f;
   for (int i = RSIM_CS_LDS + lane; i < cs; i += 64) sim.cst[i] = 0.f;

@@ -56,7 +56,7 @@ class HipShimBackend:
 
     def _push(self):
         b = self.batch
-        for k in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+        for k in ("qpos", "qvel", "ctrl", "qacc_warmstart", "qfrc_applied"):
             b.set(k, self.d[k][None])
         b.set("time", self.d["time"])
 
@@ -122,3 +122,13 @@ class HipShimBackend:
 
     def contacts(self):
         return self._contacts
+
+    @property
+    def nefc(self):
+        return int(self.batch.get("nefc")[0])
+
+    def efc_array(self, name):
+        """Constraint rows of the last evaluation (shim.MjData.efc_*).  The kernel exports the forces; aref / R / type live in LDS only."""
+        if name != "efc_force":
+            raise KeyError(f"the HIP backend does not export {name} (constraint forces only: RSIM_EFC_FORCE)")
+        return self.batch.get("efc_force")[0][: self.nefc].astype(np.float64)

@@ -35,16 +35,21 @@ def default_reset_spec():
                              objects=[dict(name="cube", horizontal_radius=None, bottom_z=None, top_z=None, qposadr=9, init_quat=None)]))
 
 
+_PREPARED = {}
+
+
 def prepared(spec):
     """The spec's lists as numpy arrays, built once per spec object (the reset-ring upkeep draws thousands of episodes per second of rollout: no per-draw
     list -> array conversions)."""
-    p = spec.get("_np")
-    if p is None:
+    hit = _PREPARED.get(id(spec))
+    if hit is None or hit[0] is not spec:
         p = dict(arm=np.array(spec["arm_init_qpos"], dtype=np.float64))
         if "cube" in spec:
             p["size_min"], p["size_max"] = np.array(spec["cube"]["size_min"], dtype=np.float64), np.array(spec["cube"]["size_max"], dtype=np.float64)
-        spec["_np"] = p
-    return p
+        # kept beside the spec, not inside it: the spec is part of a cfg that stays JSON-serialisable (factory.extract, tools/gen_golden.py dump it) and is
+        # shared between the envs built from it (round-4 advisor finding).  The entry holds the spec itself, so its id cannot be reused while cached.
+        hit = _PREPARED[id(spec)] = (spec, p)
+    return hit[1]
 
 
 def arm_noise(rng: np.random.Generator, spec) -> np.ndarray:

@@ -48,13 +48,35 @@ def init_process_group(backend: str | None = None):
     return rank, local_rank, world
 
 
-class RolloutStats:
-    """Per-rank rollout accumulators; `allreduce()` returns the whole-job totals (float64 on the wire)."""
+def hip_comm(rank: int, world: int, device: int):
+    """The C-ABI's own RCCL communicator (include/rsim.h rsim_comm_*, backend.HipComm) for a job that was launched under torch.distributed: rank 0 draws the
+    unique id, the job's process group carries its 128 bytes to the other ranks, every rank joins.  Returns None for world size 1."""
+    import torch
+    import torch.distributed as dist
 
-    def __init__(self, device="cpu"):
+    from .backend import HipComm
+
+    if world == 1:
+        return None
+    dev = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
+    buf = torch.zeros(HipComm.ID_BYTES, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        buf.copy_(torch.frombuffer(bytearray(HipComm.unique_id()), dtype=torch.uint8))
+    dist.broadcast(buf, src=0)
+    return HipComm(bytes(buf.cpu().numpy().tobytes()), rank, world, device)
+
+
+class RolloutStats:
+    """Per-rank rollout accumulators; `allreduce()` returns the whole-job totals (float64 on the wire).  With `comm` (a backend.HipComm, see hip_comm above)
+    the reduction is the C-ABI's rsim_allreduce_stats -- the entry a binder without torch.distributed calls -- otherwise the job's torch process group
+    (RCCL under backend "nccl", gloo in the CPU tests).  `path` says which one ran."""
+
+    def __init__(self, device="cpu", comm=None):
         import torch
 
         self.t = torch.zeros(len(STAT_FIELDS), dtype=torch.float64, device=device)
+        self.comm = comm
+        self.path = "local (world size 1)"
 
     def add(self, **kw):
         for k, v in kw.items():
@@ -63,9 +85,13 @@ class RolloutStats:
     def allreduce(self):
         import torch.distributed as dist
 
+        if self.comm is not None:
+            self.path = "rsim_allreduce_stats (C-ABI, RCCL)"
+            return dict(zip(STAT_FIELDS, self.comm.allreduce(self.t.cpu().numpy(), "sum").tolist()))
         t = self.t.clone()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            self.path = f"torch.distributed ({dist.get_backend()})"
         return dict(zip(STAT_FIELDS, t.tolist()))
 
 

@@ -15,6 +15,7 @@ Backend protocol (duck-typed):
     backend.forward() / step() / step1() / step2() / reset()
     backend.jac(kind, idx) -> (jacp[3,nv], jacr[3,nv]);  backend.full_M() -> [nv,nv]
     backend.ncon (int); backend.contacts() -> list of dict(geom1, geom2, dist, pos, frame)
+    optional: backend.nefc (int); backend.efc_array("efc_force" | "efc_aref" | "efc_R" | "efc_type") -> array of nefc entries
 """
 from __future__ import annotations
 
@@ -227,6 +228,27 @@ class MjData:
     @property
     def contact(self):
         return [_Contact(c) for c in self._backend.contacts()]
+
+    @property
+    def nefc(self):
+        return int(self._backend.nefc)
+
+    # constraint rows (mjData.efc_*): read by tools/gen_golden_with_mujoco.py only; a backend that does not keep them raises
+    @property
+    def efc_force(self):
+        return self._backend.efc_array("efc_force")
+
+    @property
+    def efc_aref(self):
+        return self._backend.efc_array("efc_aref")
+
+    @property
+    def efc_R(self):
+        return self._backend.efc_array("efc_R")
+
+    @property
+    def efc_type(self):
+        return self._backend.efc_array("efc_type")
 
 
 for _f in _DATA_FIELDS:

@@ -141,6 +141,9 @@ def summarize(name, res):
               f"  solver objective above its minimum, relative: max {max(r['g_cost_gap'] for r in gg):.1e} median {float(np.median([r['g_cost_gap'] for r in gg])):.1e}")
         for k in (gg[0].get("g_groups") or {}):
             print(f"      {k}: max |dqacc| {max(r['g_groups'][k][0] for r in gg):.2e}  relative to the group's largest {max(r['g_groups'][k][0] / max(1.0, r['g_groups'][k][1]) for r in gg):.1e}")
+            print(f"      {k} per env, relative, sorted:", " ".join(f"{x:.0e}" for x in sorted(r['g_groups'][k][0] / max(1.0, r['g_groups'][k][1]) for r in gg)))
+        print("      objective gap per env, sorted:", " ".join(f"{x:.0e}" for x in sorted(r['g_cost_gap'] for r in gg)))
+        print("      rel dforce per env, sorted:", " ".join(f"{x:.0e}" for x in sorted(r['g_force'] / max(1.0, r['g_fscale']) for r in gg)))
     for r in res:
         if not r["same"]:
             print("   structure differs:", r)
@@ -318,7 +321,7 @@ def test_pickplace_8192_with_dynamics_randomisation_reached_states():
     # seen): only such an env may have dropped anything, and at most a handful of them
     ov = np.nonzero(b.get("overflow") > 0)[0]
     assert len(ov) <= 3 and all(need[e, 0] > 64 or need[e, 1] > 256 for e in ov), (ov, need[ov])
-    res = compare_reached_states(flat, b, spread(B, 32), ignore_pair=lambda g1, g2: g1 in grip and g2 in grip, dof_groups=groups)
+    res = compare_reached_states(flat, b, spread(B, int(os.environ.get("RSIM_PARITY_SAMPLE", "32"))), ignore_pair=lambda g1, g2: g1 in grip and g2 in grip, dof_groups=groups)
     ok = summarize("PickPlace step 50", res)
     assert np.isfinite(b.get("qpos")).all() and np.isfinite(b.get("obs")).all()
     assert len(res) >= 32 and len(ok) >= len(res) - 4

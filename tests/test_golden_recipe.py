@@ -101,3 +101,28 @@ def test_reference_environment_families_run_over_the_shim_and_map_to_a_kernel_co
     rsim_model_config names the compiled kernel configuration that serves it (-1: more candidate pairs than the largest)."""
     r = subprocess.run([sys.executable, "-c", _FAMILIES_SNIPPET % ROOT], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.count("ok ") == 5, (r.stdout[-800:], r.stderr[-1500:])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/robosuite"), reason="reference checkout not present (GPU box)")
+@pytest.mark.parametrize("name", ("panda", "robotiq140", "rethink"))
+def test_reference_gripper_tests_pass_over_the_shim_and_reproduce_the_committed_traces(name, tmp_path):
+    """tools/gen_shim_trace.py --gripper runs the reference's own GripperTester.loop(test_y=True) (tests/test_grippers/test_panda_gripper.py:8-24,
+    test_robotiq_140.py, test_rethink_gripper.py) over the shim with the fp64 oracle: the cube must end above y_baseline (the recorder exits non-zero
+    otherwise), and the trace the GPU test replays (tests/test_hip_shim_trace.py) must be what the recipe produces today."""
+    import shutil
+
+    scratch = tmp_path / "repo_golden"
+    scratch.mkdir()
+    old = np.load(os.path.join(GOLD, f"shim_trace_gripper_{name}.npz"))
+    keep = os.path.join(GOLD, f"shim_trace_gripper_{name}.npz")
+    backup = str(scratch / "committed.npz")
+    shutil.copy(keep, backup)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_shim_trace.py"), "--gripper", name], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        new = np.load(keep)
+        assert float(new["height"][-1]) > float(new["y_baseline"])
+        for k in old.files:
+            assert np.array_equal(old[k], new[k]), k
+    finally:
+        shutil.copy(backup, keep)

@@ -507,6 +507,66 @@ def test_capacity_tiers_with_per_env_model_parameters_and_stream_groups():
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
+def test_reset_observation_of_an_env_that_ends_its_episode_on_the_wide_tier():
+    """Round-4 advisor finding: the reset-observation pass that follows a control step ran as a native tier pass and skipped every env whose tier was 1,
+    so an env that hit its horizon while the wide configuration stepped it kept the TERMINAL record in RSIM_OBS.  Horizon 2: step 1 takes the jammed envs
+    through the redo list, step 2 steps them from the wide pass's list and ends every episode; RSIM_OBS must then be what rsim_observe computes on the
+    reset state (MujocoEnv.reset(): forward + observables, base.py:298-347), for the tier-1 envs as for the others, on one stream and with stream groups."""
+    from robosuite_amd import lift
+    flat, cfg = _lift_assets()
+    ids = np.array([7, 3, 7, 11, 3, 5])
+    q = _jammed_lift_state()
+    for G in (1, 3):
+        env = lift.LiftBatch(flat, cfg, ids, seed0=0, horizon=2, bank_episodes=3)
+        if G > 1:
+            env.batch.set_stream_groups(G)
+        b = env.batch
+        qq = b.get("qpos"); qq[[0, 2, 4]] = q
+        b.set("qpos", qq); b.set("qvel", 0); b.set("qacc_warmstart", 0); b.set("ctrl", 0); b.forward(); b.ctrl_reset()
+        b.set("overflow", 0)
+        act = torch.zeros(len(ids), 7, device="cuda"); act[:, 2] = -0.3; act[:, 6] = 1.0
+        env.step(act)
+        assert b.get("done").tolist() == [0] * len(ids)
+        env.step(act)
+        b.sync()
+        need = b.get("cap_need")
+        assert (need[[0, 2, 4], 1] > 64).all() and (need[[1, 3, 5], 1] <= 64).all() and int(b.get("overflow").sum()) == 0, need
+        assert b.get("done").tolist() == [1] * len(ids) and b.get("ep_index").tolist() == [1] * len(ids)
+        assert np.array_equal(b.get("qpos"), lift.episode_setup(0, ids, 1)[1].astype(np.float32))
+        obs, term = b.get("obs").copy(), b.get("terminal_obs").copy()
+        b.observe()
+        ref = b.get("obs").copy()
+        assert np.abs(obs - ref).max() < 1e-6, (G, np.abs(obs - ref).max(axis=1))
+        assert (np.abs(obs - term).max(axis=1) > 1e-3).all()          # the terminal record went to RSIM_TERMINAL_OBS, not into RSIM_OBS
+        assert int(b.get("overflow").sum()) == 0
+
+
+def test_reading_derived_arrays_between_fused_steps_changes_nothing():
+    """Round-4 advisor finding: a read of a derived array after a fused control step refreshes it with a debug forward; that forward used to rewrite the
+    narrow phase's warm-start records and the warm start of the solver and to count into RSIM_OVERFLOW / RSIM_CAP_NEED, so a rollout depended on whether
+    the host had looked.  Two rollouts of the same contact-rich envs, one of them reading positions, contacts, forces, M and a Jacobian after every step:
+    bitwise the same states, the same demand and drop counters."""
+    from robosuite_amd import lift
+    flat, cfg = _lift_assets()
+    ids = np.arange(6)
+    T = 40
+    tape = torch.tensor(lift.env_actions(ids, T), device="cuda")
+    out = []
+    for look in (False, True):
+        env = lift.LiftBatch(flat, cfg, ids, seed0=0, horizon=0)
+        b = env.batch
+        for t in range(T):
+            env.step(tape[t])
+            if look:
+                b.get("xpos"); b.get("efc_force"); b.get("qacc"); b.full_M(1); b.contacts_abi(2); b.contacts(3)
+                b.jac_site(4, 0)
+        b.sync()
+        out.append({k: b.get(k).copy() for k in ("qpos", "qvel", "qacc_warmstart", "ctrl", "time", "overflow", "cap_need")})
+    assert out[1]["cap_need"][:, 0].max() >= 3          # hands on the table: there is a narrow phase to disturb
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k
+
+
 def test_full_M_and_contacts_exports_of_the_c_abi():
     """rsim_full_M (mj_fullM, controllers/parts/controller.py:226-227) and rsim_contacts (sim.data.contact[:ncon]) against the array fields they are views of,
     and against the oracle; after a FUSED control step both describe the current state (the derived arrays are refreshed on read)."""

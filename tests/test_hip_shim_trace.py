@@ -87,3 +87,52 @@ def test_binding_utils_call_trace_of_the_reference_replays_on_the_hip_shim_backe
         assert worst[name] < 1.5e-6, (name, worst[name])          # measured 2e-7 .. 4e-7 (fp32 kernel, fp64 record)
     assert worst["jac"] < 2e-6 and worst["full_M"] < 3e-6 and worst["qfrc_bias"] < 3e-6   # measured 4e-7, 7e-7, 6e-7
     assert worst["qacc"] < 5e-4 and worst["qpos"] < 1e-6 and worst["qvel"] < 5e-6         # measured 2e-5 (2e-4 on the playback trace: step2 with the cube's four contacts), 2e-7, 1.4e-6
+
+
+@pytest.mark.parametrize("name", ("panda", "robotiq140", "rethink"))
+def test_gripper_tester_of_the_reference_on_the_hip_shim_backend(name):
+    """The reference's gripper behaviour tests (tests/test_grippers/test_panda_gripper.py:8-24, test_robotiq_140.py, test_rethink_gripper.py ->
+    models/grippers/gripper_tester.py:204-226) on the HIP backend.  tools/gen_shim_trace.py --gripper ran the UNMODIFIED GripperTester over the shim (oracle
+    arithmetic) and recorded its 4 x 400 sim.step() calls: a gripper on a position-actuated vertical slide above a cube on a table -- lower, grip, raise --
+    with ctrl and the gravity-compensating qfrc_applied (= qfrc_bias of the slide) written before every step.
+    (1) call by call: every 8th recorded step replayed from its recorded inputs through HipShimBackend.step(), state after it compared;
+    (2) the behaviour test itself, closed loop: the same 1600 steps on the HIP backend from the recorded initial state, the gravity compensation taken from the
+        backend's OWN qfrc_bias as GripperTester._apply_gravity_compensation does, and the reference test's verdict asserted: the cube ends above y_baseline."""
+    from robosuite_amd.hip_shim_backend import HipShimBackend
+
+    g = np.load(os.path.join(GOLD, f"shim_trace_gripper_{name}.npz"))
+    hb = HipShimBackend(mjcf.from_blob(g["model"].tobytes()))
+    f = hb.flat
+    PRE, POST = [str(x) for x in g["pre"]], [str(x) for x in g["post"]]
+    sizes = dict(qpos=f.nq, qvel=f.nv, ctrl=f.nu, qacc_warmstart=f.nv, time=1, qfrc_applied=f.nv, xpos=3 * f.nbody, xquat=4 * f.nbody, xmat=9 * f.nbody, site_xpos=3 * f.nsite,
+                 site_xmat=9 * f.nsite, geom_xpos=3 * f.ngeom, qfrc_bias=f.nv, qacc=f.nv)
+    worst = {"qpos": 0.0, "qvel": 0.0, "xpos": 0.0}
+    for row in np.asarray(g["rows_step"], dtype=np.float64):
+        o = 0
+        for k in PRE:
+            hb.d[k][:] = row[o:o + sizes[k]]; o += sizes[k]
+        post = {}
+        for k in POST:
+            post[k] = row[o:o + sizes[k]]; o += sizes[k]
+        hb.step()
+        worst["qpos"] = max(worst["qpos"], float(np.abs(hb.d["qpos"] - post["qpos"]).max()))
+        worst["qvel"] = max(worst["qvel"], float(np.abs(hb.d["qvel"] - post["qvel"]).max() / max(1.0, np.abs(post["qvel"]).max())))
+        worst["xpos"] = max(worst["xpos"], float(np.abs(hb.d["xpos"] - post["xpos"]).max()))
+    print(f"{name}: worst one-step deviations over {len(g['rows_step'])} recorded steps:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert worst["qpos"] < 2e-5 and worst["qvel"] < 2e-3 and worst["xpos"] < 2e-5, worst
+    # ---- the behaviour test, closed loop
+    nq, zd, ob = int(g["nq"]), int(g["z_dof"]), int(g["object_body"])
+    s0 = np.asarray(g["state0"], dtype=np.float64)
+    hb.reset()
+    hb.d["time"][:] = s0[0]; hb.d["qpos"][:] = s0[1:1 + nq]; hb.d["qvel"][:] = s0[1 + nq:1 + nq + f.nv]        # MjSim.set_state (binding_utils.py:1150-1170)
+    heights = []
+    for t in range(len(g["ctrl"])):
+        hb.d["ctrl"][:] = g["ctrl"][t]                              # the lower / grip / raise schedule (gripper_tester.py:171-180, 204-214)
+        hb.d["qfrc_applied"][:] = 0.0
+        hb.d["qfrc_applied"][zd] = hb.d["qfrc_bias"][zd]            # _apply_gravity_compensation (gripper_tester.py:197-202)
+        hb.step()
+        heights.append(float(hb.d["xpos"].reshape(-1, 3)[ob][2] - float(g["object_default_z"])))
+    ref = np.asarray(g["height"])
+    print(f"{name}: cube height after lower / grip / raise: HIP {heights[-1]:.4f} m, recorded (oracle) {ref[-1]:.4f} m; largest difference along the way {np.abs(np.array(heights) - ref).max():.2e}")
+    assert heights[-1] > float(g["y_baseline"])                     # the reference test's own assertion (gripper_tester.py:216-220)
+    assert abs(heights[-1] - ref[-1]) < 5e-3

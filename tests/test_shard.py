@@ -24,8 +24,16 @@ st = shard.RolloutStats()
 st.add(env_steps=len(ids) * 3, reward_sum=float(acts.sum()), episodes=len(ids))
 tot = st.allreduce()
 tmax = shard.max_over_ranks(1.0 + rank)
+class StandInComm:      # same call signature as backend.HipComm.allreduce (the C-ABI's rsim_allreduce_stats), carried by gloo here
+    def allreduce(self, values, op="sum"):
+        t = torch.tensor(np.asarray(values, dtype=np.float64))
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM if op == "sum" else torch.distributed.ReduceOp.MAX)
+        return t.numpy()
+st2 = shard.RolloutStats(comm=StandInComm())
+st2.add(env_steps=len(ids) * 3, successes=rank + 1)
+tot2 = st2.allreduce()
 if rank == 0:
-    print(json.dumps(dict(tot=tot, tmax=tmax, n0=len(ids))))
+    print(json.dumps(dict(tot=tot, tmax=tmax, n0=len(ids), path=st.path, tot2=tot2, path2=st2.path)))
 torch.distributed.destroy_process_group()
 """
 
@@ -52,6 +60,9 @@ def test_world_size_2_gloo(tmp_path):
     assert r["tot"]["env_steps"] == 33 and r["tot"]["episodes"] == 11 and r["n0"] == 6
     assert abs(r["tot"]["reward_sum"] - float(lift.env_actions(np.arange(11), 3).sum())) < 1e-4
     assert r["tmax"] == 2.0
+    # the same fields through a communicator object (bench.py hands RolloutStats the C-ABI's RCCL communicator when there is more than one rank)
+    assert r["path"] == "torch.distributed (gloo)" and r["path2"].startswith("rsim_allreduce_stats")
+    assert r["tot2"]["env_steps"] == 33 and r["tot2"]["successes"] == 3
 
 
 @pytest.mark.parametrize("config", ("lift", "stack"))     # stack = BASELINE configs[2], the one BASELINE.json assigns to eight GPUs

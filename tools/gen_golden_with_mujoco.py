@@ -15,7 +15,14 @@ controllers/parts/controller.py:226-227 mj_fullM):
 into tests/golden/mujoco_<task>_<robot>_seed<k>.npz (+ .xml).  tests/test_mujoco_pin.py then holds the fp64 oracle to those files
 (skipped while they are absent).  Nothing here imports the oracle or the HIP library.
 
-Usage:  python tools/gen_golden_with_mujoco.py [--out DIR]          exits 0 with a message when `mujoco` is not importable
+Contact-count convention: next to every snapshot's contact records the script stores, per geom pair in contact, the pair's two geom types and the
+NUMBER of contacts MuJoCo generated for it (`snapK_pair_counts`, rows geom1 geom2 type1 type2 count).  This project's narrow phase returns one contact
+per convex (MPR) pair and up to eight per box-box pair; MuJoCo's libccd path returns one per convex pair unless `multiccd` is enabled, its box-box
+routine up to eight -- the first thing tests/test_mujoco_pin.py diffs once a fixture exists.
+
+Usage:  python tools/gen_golden_with_mujoco.py [--out DIR] [--cases Lift:0,Stack:0] [--steps N]
+        exits 0 with a message when `mujoco` is not importable.  The recorder is exercised end to end today by tests/test_mujoco_pin.py, which runs it
+        against robosuite_amd.shim posing as `mujoco` (fp64 oracle backend): file layout, keys and the comparisons of that test stay alive.
 """
 import os
 import sys
@@ -26,6 +33,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "golden")
 if "--out" in sys.argv:
     OUT = sys.argv[sys.argv.index("--out") + 1]
+ONLY = sys.argv[sys.argv.index("--cases") + 1].split(",") if "--cases" in sys.argv else None      # "Env:seed" items
+MAX_STEPS = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else None
 
 CASES = (  # (env, robots, controller type or None = robot default, seed, control steps, action scale): the tapes of tools/gen_golden.py
     ("Lift", "Panda", None, 0, 40, 0.1),
@@ -48,11 +57,16 @@ def snapshot(sim):
     for i in range(d.ncon):
         c = d.contact[i]
         con[i, 0] = c.dist; con[i, 1:4] = c.pos; con[i, 4:13] = np.asarray(c.frame); con[i, 13] = c.geom1; con[i, 14] = c.geom2; con[i, 15] = c.dim
+    pairs = {}
+    for r in con:
+        pairs[(int(r[13]), int(r[14]))] = pairs.get((int(r[13]), int(r[14])), 0) + 1
+    gt = np.asarray(m.geom_type)
+    pair_counts = np.array([[g1, g2, int(gt[g1]), int(gt[g2]), n] for (g1, g2), n in sorted(pairs.items())], dtype=np.int64).reshape(-1, 5)
     return dict(ws=ws, qpos=np.array(d.qpos), qvel=np.array(d.qvel), ctrl=np.array(d.ctrl), qM=qM, qfrc_bias=np.array(d.qfrc_bias),
                 qfrc_passive=np.array(d.qfrc_passive), qfrc_actuator=np.array(d.qfrc_actuator), qacc=np.array(d.qacc),
                 qfrc_constraint=np.array(d.qfrc_constraint), ncon=int(d.ncon), contact=con, nefc=int(d.nefc),
                 efc_force=np.array(d.efc_force[:d.nefc]), efc_aref=np.array(d.efc_aref[:d.nefc]), efc_R=np.array(d.efc_R[:d.nefc]),
-                efc_type=np.array(d.efc_type[:d.nefc]))
+                efc_type=np.array(d.efc_type[:d.nefc]), pair_counts=pair_counts)
 
 
 def record(env_name, robot, ctype, seed, n_steps, scale):
@@ -89,11 +103,15 @@ def record(env_name, robot, ctype, seed, n_steps, scale):
 
 if __name__ == "__main__":
     try:
-        import mujoco  # noqa: F401
+        import mujoco  # noqa: F401  (a real wheel, or -- in the self-test -- robosuite_amd.shim registered as `mujoco` by the caller)
     except ImportError:
         print("gen_golden_with_mujoco: the `mujoco` wheel is not importable here -- nothing recorded (physics half of the oracle stays unpinned)")
         sys.exit(0)
     sys.path.insert(0, os.environ.get("ROBOSUITE_ROOT", "/root/reference"))
     os.makedirs(OUT, exist_ok=True)
     for case in CASES:
+        if ONLY is not None and f"{case[0]}:{case[3]}" not in ONLY:
+            continue
+        if MAX_STEPS is not None:
+            case = case[:4] + (min(case[4], MAX_STEPS),) + case[5:]
         record(*case)

@@ -8,9 +8,13 @@ robosuite issues through utils/binding_utils.py:1059-1192 (mj_forward / mj_step1
 tests/test_hip_shim_trace.py replays the trace on the GPU box (no reference checkout there) through HipShimBackend, call by call from the
 recorded inputs, and compares every returned array.
 
-Writes tests/golden/shim_trace_lift.npz.   Usage: python tools/gen_shim_trace.py [n_steps] [--playback]
+Writes tests/golden/shim_trace_lift.npz.   Usage: python tools/gen_shim_trace.py [n_steps] [--playback] [--gripper panda|robotiq140|rethink]
 --playback: the trace of the reference's action-playback determinism test instead (get_xml -> reset_from_xml_string -> set_state_from_flattened ->
 replay; tests/golden/shim_trace_lift_playback.npz).
+--gripper NAME: the trace of the reference's gripper behaviour test (tests/test_grippers/test_panda_gripper.py:8-24, test_robotiq_140.py, test_rethink_gripper.py ->
+models/grippers/gripper_tester.py:204-226): a gripper on a vertical slide above a cube on a table, lower / grip / raise, 4 x 400 calls of sim.step() with
+ctrl and the gravity-compensating qfrc_applied written before each; the test's own verdict (cube lifted above y_baseline) is recorded with it
+(tests/golden/shim_trace_gripper_<name>.npz; every 8th step keeps its full record, all keep ctrl / qfrc_applied / cube height).
 """
 import os
 import sys
@@ -75,7 +79,47 @@ class TracingBackend:
         return M
 
 
+def gripper_trace(name):
+    """GripperTester of the reference over the shim (oracle arithmetic), traced call by call."""
+    global PRE
+    PRE = PRE + ("qfrc_applied",)
+    shim.install(TracingBackend)
+    from robosuite.models.grippers import GripperTester, PandaGripper, RethinkGripper, Robotiq140Gripper
+
+    cases = {"panda": (PandaGripper, dict(gripper_low_pos=-0.10, gripper_high_pos=0.01)),                                   # test_panda_gripper.py:13-20
+             "robotiq140": (Robotiq140Gripper, dict(gripper_low_pos=0.02, gripper_high_pos=0.1, box_size=[0.025] * 3)),     # test_robotiq_140.py:10-18
+             "rethink": (RethinkGripper, dict(gripper_low_pos=-0.07, gripper_high_pos=0.02))}                               # test_rethink_gripper.py:14-21
+    cls, kw = cases[name]
+    tester = GripperTester(gripper=cls(), pos="0 0 0.3", quat="0 0 1 0", render=False, **kw)
+    tester.start_simulation()
+    del EVENTS[:]; ROWS.clear()
+    heights, ctrls, applied = [], [], []
+    inner_step = tester.sim.step
+
+    def step_and_note():
+        ctrls.append(np.array(tester.sim.data.ctrl)); applied.append(np.array(tester.sim.data.qfrc_applied))
+        inner_step()
+        heights.append(tester.object_height)
+
+    tester.sim.step = step_and_note
+    tester.loop(total_iters=1, test_y=True)          # raises ValueError if the cube is not lifted: the reference test's verdict
+    mi = len(MODELS) - 1
+    rows = ROWS[("step", mi)]
+    keep = [k for k in range(len(rows)) if k % 8 == 0 or k == len(rows) - 1]
+    f = tester.sim.model._model._flat
+    out = dict(ops=np.array(OPS), pre=np.array(PRE), post=np.array(POST), model=MODELS[mi], kept=np.array(keep, dtype=np.int32), rows_step=np.stack([rows[k] for k in keep]),
+               ctrl=np.array(ctrls), qfrc_applied=np.array(applied), height=np.array(heights), y_baseline=np.array(0.01),
+               object_body=np.array(tester.object_id), z_dof=np.array(tester._gravity_corrected_qvels[0]), object_default_z=np.array(tester.object_default_pos[2]),
+               state0=np.array(tester.sim_state.flatten()), nq=np.array(int(f.nq)))
+    path = os.path.join(ROOT, "tests", "golden", f"shim_trace_gripper_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, "steps", len(rows), "kept", len(keep), "final cube height", heights[-1], "bytes", os.path.getsize(path))
+
+
 if __name__ == "__main__":
+    if "--gripper" in sys.argv:
+        gripper_trace(sys.argv[sys.argv.index("--gripper") + 1])
+        sys.exit(0)
     n_steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10
     shim.install(TracingBackend)
     import robosuite as suite

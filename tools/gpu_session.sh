@@ -45,10 +45,10 @@ for step in "$@"; do
     bench)
       timeout 900 python bench.py --config $a1 ${a2:-$(bench_extra $a1)} > $O/${tag}_bench_$a1.json 2> $O/${tag}_bench_$a1.err; line $O/${tag}_bench_$a1.json; tail -3 $O/${tag}_bench_$a1.err | cut -c1-300;;
     quick)
-      timeout 400 python bench.py --config $a1 ${a2:-$(quick_extra $a1)} --no-open-loop --no-cpu-baseline --no-double-buffer > $O/${tag}_quick_$a1.json 2> $O/${tag}_quick_$a1.err; line $O/${tag}_quick_$a1.json; tail -3 $O/${tag}_quick_$a1.err | cut -c1-300;;
+      timeout 400 python bench.py --config $a1 ${a2:-$(quick_extra $a1)} --no-open-loop --no-cpu-baseline --no-double-buffer --no-other-configs > $O/${tag}_quick_$a1.json 2> $O/${tag}_quick_$a1.err; line $O/${tag}_quick_$a1.json; tail -3 $O/${tag}_quick_$a1.err | cut -c1-300;;
     stats)
       rm -rf $O/prof_${tag}_$a1
-      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${tag}_$a1 -o r -- python bench.py --config $a1 ${a2:-$(quick_extra $a1)} --no-open-loop --no-cpu-baseline --no-double-buffer > $O/${tag}_prof_$a1.log 2>&1
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${tag}_$a1 -o r -- python bench.py --config $a1 ${a2:-$(quick_extra $a1)} --no-open-loop --no-cpu-baseline --no-double-buffer --no-other-configs > $O/${tag}_prof_$a1.log 2>&1
       cp $(find $O/prof_${tag}_$a1 -name "*kernel_stats.csv" | head -1) $O/${tag}_kernel_stats_$a1.csv; head -5 $O/${tag}_kernel_stats_$a1.csv | cut -c1-200; rm -rf $O/prof_${tag}_$a1;;
     pmc)
       export RSIM_CONFIG=$a1 PMC_TIMEOUT=${PMC_TIMEOUT:-150}
@@ -66,7 +66,7 @@ for step in "$@"; do
     ab)
       cfg=${a3:-lift}
       for rep in 1 2; do for lib in $a1 $a2; do
-        RSIM_LIB=$GRAFT_REPO_ROOT/robosuite_amd/$lib timeout 400 python bench.py --config $cfg ${a4:-$(quick_extra $cfg)} --no-open-loop --no-cpu-baseline --no-double-buffer > $O/${tag}_ab_${cfg}_${lib%.so}_$rep.json 2> $O/${tag}_ab.err
+        RSIM_LIB=$GRAFT_REPO_ROOT/robosuite_amd/$lib timeout 400 python bench.py --config $cfg ${a4:-$(quick_extra $cfg)} --no-open-loop --no-cpu-baseline --no-double-buffer --no-other-configs > $O/${tag}_ab_${cfg}_${lib%.so}_$rep.json 2> $O/${tag}_ab.err
         line $O/${tag}_ab_${cfg}_${lib%.so}_$rep.json
       done; done;;
     py)

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 run() { # name, counters
   rm -rf gpurun_out/$tag.$1
-  timeout ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/$tag.$1 -o r -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --groups 1 --config ${RSIM_CONFIG:-lift} ${RSIM_BENCH_EXTRA} > gpurun_out/$tag.$1.log 2>&1
+  timeout ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/$tag.$1 -o r -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --groups 1 --config ${RSIM_CONFIG:-lift} ${RSIM_BENCH_EXTRA} > gpurun_out/$tag.$1.log 2>&1
   python tools/pmc_sum.py gpurun_out/$tag.$1 'k_step<' | tee gpurun_out/$tag.$1.txt; [ -n "$KEEP" ] || rm -rf gpurun_out/$tag.$1
 }
 for s in $sets; do
