@@ -47,6 +47,7 @@ def lib():
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [vp]
         L.rso_contact_get.argtypes = [vp, C.c_int, dp]
+        L.rso_set_round_rows.argtypes = [vp, C.c_int]
         L.rso_cost.restype = C.c_double
         L.rso_cost.argtypes = [vp, dp, dp]
         L.rso_forward_with_contact_geometry.restype = C.c_int
@@ -144,6 +145,10 @@ class OracleData:
         g = np.zeros(self.nv)
         c = self._L.rso_cost(self.ptr, _dp(a), _dp(g) if with_gradient else None)
         return (c, g) if with_gradient else c
+
+    def set_round_rows(self, on: bool):
+        """Conditioning probe: the constraint solve of every later forward / step sees its inputs rounded to float32 (rsim_oracle.c round_inputs_f32)."""
+        self._L.rso_set_round_rows(self.ptr, int(bool(on)))
 
     def forward_with_contact_geometry(self, contacts) -> bool:
         """forward() with dist / pos / frame of every contact taken from `contacts` (dicts as returned by contacts(), e.g. the HIP batch's list of the

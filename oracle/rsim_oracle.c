@@ -190,6 +190,7 @@ typedef struct {
   double *efc_AR; /* MAXEFC x MAXEFC */
   double *efc_MinvJT; /* nv x MAXEFC */
   int solver_iter;
+  int round_rows;  /* test infrastructure (rso_set_round_rows): the constraint solve sees its INPUTS rounded to float32 -- what a kernel that stores them in fp32 is handed at best */
   int con_overflow;
 } rso_data;
 
@@ -1661,10 +1662,27 @@ static void solve_newton(rso_data *d) {
   free(Ma); free(grad); free(search); free(H); free(Lh); free(Mv); free(hcone);
 }
 
+/* Conditioning probe (tests/test_full_size_parity.py): with d->round_rows set, every input of the constraint solve -- Jacobian rows, reference accelerations,
+ * regularisers, friction coefficients, the mass matrix and the smooth forces / accelerations -- is rounded to the nearest float32 before the fp64 solver runs
+ * on it.  The difference to the plain solve is what storing those quantities in single precision costs ON THIS STATE even with exact arithmetic downstream:
+ * the floor under any fp32 kernel's deviation from this oracle, and the yardstick the PickPlace full-size test measures the kernel against per env. */
+static void round_inputs_f32(rso_data *d) {
+  int nv = d->m->nv, n = d->nefc;
+#define RF(x) ((x) = (double)(float)(x))
+  for (size_t i = 0; i < (size_t)n * nv; i++) RF(d->efc_J[i]);
+  for (int i = 0; i < n; i++) { RF(d->efc_aref[i]); RF(d->efc_R[i]); d->efc_D[i] = 1.0 / d->efc_R[i]; }
+  for (int c = 0; c < d->ncon; c++) { RF(d->contact[c].mu); for (int k = 0; k < 5; k++) RF(d->contact[c].friction[k]); }
+  for (int i = 0; i < nv * nv; i++) RF(d->qM[i]);
+  for (int i = 0; i < nv; i++) { RF(d->qfrc_smooth[i]); RF(d->qacc_smooth[i]); RF(d->qacc_warmstart[i]); }
+#undef RF
+}
+void rso_set_round_rows(rso_data *d, int on) { d->round_rows = on; }
+
 static void fwd_constraint(rso_data *d) {
   int nv = d->m->nv;
   memset(d->qfrc_constraint, 0, sizeof(double) * nv);
   d->solver_iter = 0;
+  if (d->round_rows && d->nefc > 0) round_inputs_f32(d);
   if (d->nefc == 0) { memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv); return; }
   if (d->m->solver == 0) solve_pgs(d); else solve_newton(d);
 }

@@ -199,10 +199,11 @@ def lib():
         vp = C.c_void_p
         L.rsim_last_error.restype = C.c_char_p
         L.rsim_model_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
-        L.rsim_model_compile.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(vp)]
-        L.rsim_mjcf_to_blob.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
-        L.rsim_blob_free.argtypes = [vp]
-        L.rsim_blob_free.restype = None
+        if hasattr(L, "rsim_model_compile"):       # (RSIM_LIB may name a build of an earlier round for an A/B: it has no compiler inside)
+            L.rsim_model_compile.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(vp)]
+            L.rsim_mjcf_to_blob.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
+            L.rsim_blob_free.argtypes = [vp]
+            L.rsim_blob_free.restype = None
         L.rsim_model_free.argtypes = [vp]
         L.rsim_model_int.argtypes = [vp, C.c_char_p]
         L.rsim_model_set_controller.argtypes = [vp, C.POINTER(CtrlDesc)]

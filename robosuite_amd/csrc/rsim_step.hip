@@ -2218,6 +2218,8 @@ struct Sim {
   // the 256-register build more in spills than the list saves.
   int task_obj = 0;                     // PickPlace single-object mode 1: this env's object (DBatch.task_object)
   int act_n = -1;                       // pairs on the list (-1: none)
+  double __attribute__((address_space(1)))* h64 = nullptr;   // this env's fp64 scratch in global memory (DBatch.h64): Hessian / Cholesky factor [NV][NV], then the weighted rows (float [NEFC][NV]) -- the polish's rare path
+  __device__ __forceinline__ void hsync() const { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
   float applied = 0.f;   // this lane's dof: mjData.qfrc_applied (RSIM_QFRC_APPLIED), read by the debug form of the kernel only (step_body)
   int __attribute__((address_space(1)))* bpl = nullptr;   // [0..2][lane g]: centre of geom g's bounding sphere when the list was built; [3][lane i]: packed
                                                           // constants (geom1 | geom2 << 8 | enabled << 16) of the i-th listed pair; [4][lane i]: its index
@@ -3645,6 +3647,7 @@ struct Sim {
     float a = cost_ws < cost_sm ? a_ws : a_sm;
     int iter = 0;
     bool have_eval = false;   // the rows are already evaluated at `a` (cost_pre)
+    bool used64 = false;      // the polish factorised H in fp64 (wide configurations, rare)
     float cost_pre = 0.f;
     for (;;) {
       float cost = have_eval ? cost_pre : wave_sum(evaluate(a));
@@ -3809,7 +3812,11 @@ struct Sim {
       //   * a step is kept only if it lowers the fp64 objective; one that does not (it crossed a state boundary) is halved, at most three times;
       //   * passes end on MuJoCo's own criteria, evaluated in fp64: scaled gradient or scaled improvement below `tolerance`, or after `newton_refine` passes.
       const int R = m.newton_refine;
-      if (R > 0 && factored && n > 0) {
+      if (R > 0 && n > 0) {
+        // (not only behind a factorisation of the iteration above: its fp32 exits -- a gradient within the rounding noise of its own terms, which for a light body
+        // beside a 2 kN squeeze is hundreds of rad/s^2 -- can end it before any Hessian was formed; exactly those solves need the fp64 look most.  Round 5: the
+        // per-env tail of the PickPlace full-size test was made of such envs, whatever the number of passes.)
+        bool need_factor = !factored;
         float a_lo = 0.f, a_keep = a, alo_keep = 0.f, force_keep[NSLOT], dk = 0.f;
         int state_keep[NSLOT];
         double err_keep = 1.0e300;
@@ -3823,6 +3830,67 @@ struct Sim {
           hi = __fadd_rn(sm_, l2);
           lo = __fsub_rn(l2, __fsub_rn(hi, sm_));
         };
+        // ---- the factor itself in fp64 (rare path).  When fp32 cannot factorise H -- a light body squeezed by stiff contacts: after diagonal scaling the
+        // translation / rotation block is singular to 1 - I / (D r^2), 1e-7 and below -- its directions are noise, no step lowers the objective and the passes
+        // above stall (what the tail of the round-4 full-size test was made of).  Then H = M + J^T W is ACCUMULATED and FACTORISED in double precision from the
+        // same float data (weights from the LDS table hess_wide() reads, J and M as stored): in this env's scratch in global memory (DBatch.h64: no LDS, no
+        // registers held across the kernel), lane i = row i, right-looking Cholesky with a workgroup-scope fence per column.  ~0.1 ms; taken by the envs that need it.
+        bool use64 = false, have64 = false;
+        const int ld = nv;
+        auto build64 = [&]() -> bool {
+          typedef float __attribute__((address_space(1)))* gf;
+          gf A = (gf)(h64 + (size_t)SM::NV_ * SM::NV_);       // weighted rows A[r][i] = sum_k coef_r[k] J[head_r + min(k, dim - 1)][i]  (or D_r J[r][i])
+          for (int r = 0; r < n; r++) {
+            const float* o = sm.u.W + 5 * r;
+            const int bd = ((const int*)o)[4];
+            float ai = 0.f;
+            if (lane < nv) {
+              if ((bd >> 16) & 1) {
+                const int head = bd & 255, dm1 = ((bd >> 8) & 7) - 1;
+#pragma unroll
+                for (int k2 = 0; k2 < 4; k2++) ai = fmaf(o[k2], Jrd((head + (k2 < dm1 ? k2 : dm1)) * JS + lane), ai);
+              } else ai = o[0] * Jrd(r * JS + lane);
+              A[r * nv + lane] = ai;
+            }
+          }
+          hsync();
+          for (int j = 0; j < nv; j++) {
+            if (lane >= j && lane < nv) {
+              double acc = (double)Mrd(lane * NVP + j);
+              for (int r = 0; r < n; r++) acc = fma((double)A[r * nv + lane], (double)Jrd(r * JS + j), acc);
+              h64[lane * ld + j] = acc;
+            }
+          }
+          hsync();
+          bool ok = true;
+          for (int k = 0; k < nv; k++) {
+            const double dkk = h64[k * ld + k];
+            if (!(dkk > 0.0)) { ok = false; break; }
+            const double lkk = sqrt(dkk);
+            double lik = 0.0;
+            if (lane > k && lane < nv) { lik = h64[lane * ld + k] / lkk; h64[lane * ld + k] = lik; }
+            if (lane == k) h64[k * ld + k] = lkk;
+            hsync();
+            if (lane > k && lane < nv) for (int j = k + 1; j <= lane; j++) h64[lane * ld + j] = fma(-lik, h64[j * ld + k], h64[lane * ld + j]);
+            hsync();
+          }
+          return ok;
+        };
+        auto solve64 = [&](double rhs) -> double {    // x = H^-1 rhs with the factor above; component i in lane i
+          double acc = lane < nv ? rhs : 0.0;
+          for (int k = 0; k < nv; k++) {
+            const double yk = __shfl(acc / h64[k * ld + k], k);
+            if (lane == k) acc = yk;
+            else if (lane > k && lane < nv) acc = fma(-h64[lane * ld + k], yk, acc);
+          }
+          for (int k = nv - 1; k >= 0; k--) {
+            const double xk = __shfl(acc / h64[k * ld + k], k);
+            if (lane == k) acc = xk;
+            else if (lane < k) acc = fma(-h64[k * ld + lane], xk, acc);
+          }
+          return lane < nv ? acc : 0.0;
+        };
+        double gn_prev = 1.0e300;
         for (int it = 0;;) {
           double jr[NSLOT], u64[NSLOT], c64 = 0.0;   // c64: this lane's share of the objective at a + a_lo, in fp64 (same pieces as row_update)
 #pragma unroll
@@ -3903,6 +3971,12 @@ struct Sim {
               continue;
             }
             a = a_keep; a_lo = alo_keep;
+            if (it > 0 && !use64 && h64 && err - err_keep > 1e-13 * fabs(err_keep)) {
+              // no part of the fp32 direction lowered the objective: the factor is noise.  Back at the kept point, with the fp64 factor from here on.
+              use64 = true; have64 = false; err_keep = 1.0e300; nback = 0;
+              SYNC();
+              continue;
+            }
 #pragma unroll
             for (int s = 0; s < NSLOT; s++) { force[s] = force_keep[s]; state[s] = state_keep[s]; }
             break;
@@ -3912,18 +3986,33 @@ struct Sim {
 #pragma unroll
           for (int s = 0; s < NSLOT; s++) { force_keep[s] = force[s]; state_keep[s] = state[s]; }
           const double gn = wave_sum_f64(lane < nv ? gk * gk : 0.0);
-          if (it >= R || (double)scale * sqrt(gn) < (double)tolerance || (it > 0 && (double)scale * gain < (double)tolerance)) break;
+          const double sg = (double)scale * sqrt(gn), tol64 = (double)tolerance * (double)m.newton_polish_tol;
+          if (it >= R || sg < tol64 || (it > 0 && (double)scale * gain < tol64)) break;
+          // a pass with a sound factor shrinks the gradient by orders of magnitude; one that leaves more than half of it did not resolve the direction that matters:
+          // with a gradient still far from the tolerance the factor is taken in fp64 from here on, near the tolerance the passes simply end
+          if (it > 0 && gn > 0.25 * gn_prev) {
+            if (use64 || !h64 || sg < 100.0 * tol64) break;
+            use64 = true; have64 = false;
+          }
+          gn_prev = gn;
           it++;
           bool other = false;
 #pragma unroll
           for (int s = 0; s < NSLOT; s++) if SLOT_ON(s) other |= rw[s].valid && state[s] != fst[s];
           SYNC();
-          if (__ballot(other)) {   // the factor in LDS belongs to another active set: H from these states
+          if (__ballot(other) || need_factor || (use64 && !have64)) {   // no factor yet, one of another active set, or one to be had in fp64: H from these states
+            need_factor = false;
             weights();
             SYNC();
-            factorize();
+            if (use64) {
+              if (!build64()) break;     // not positive definite even in fp64: keep what we have
+              have64 = true; used64 = true;
+#pragma unroll
+              for (int s = 0; s < NSLOT; s++) fst[s] = state[s];
+            } else factorize();
           }
-          dk = bchol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -(float)gk : 0.f, nv, lane);
+          if (use64) dk = (float)solve64(-gk);
+          else dk = bchol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -(float)gk : 0.f, nv, lane);
           if (lane >= nv) dk = 0.f;
           dfadd(a, a_lo, dk);
           SYNC();
@@ -3935,7 +4024,7 @@ struct Sim {
     SYNC();
     const float fc = jt_times_force(nch);
     if (lane < nv) { sm.qfrc_constraint[lane] = fc; sm.qacc[lane] = a; }
-    if (lane == 0) sm.niter = iter;
+    if (lane == 0) sm.niter = iter + (used64 ? 1000 : 0);   // + 1000: the polish had to factorise in fp64 (RSIM_NITER of the debug entries)
     pf.count(RP_N_NEWTON, iter);
     SYNC();
 #undef SLOT_ON
@@ -4157,6 +4246,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   if (b.mprc) { sim.mprc = (gwf)(b.mprc + (size_t)env * Sim<SM>::MPRC * m.npair); sim.mpr_portal = b.mprc_portal != 0; }
   if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * b.jg_stride);   // one stride for every configuration that steps envs of this batch (the native and the wide pass run side by side)
   if constexpr (Sim<SM>::MG) sim.Mg = sim.Jg + SM::NEFC_ * SM::JS_;
+  if (b.h64) sim.h64 = (double __attribute__((address_space(1)))*)(b.h64 + (size_t)env * b.h64_stride);
   if (lane < csl) sm.cstate[lane] = sim.cst[lane];
   if constexpr (DBG) if (b.qfrc_applied && lane < m.nv) sim.applied = b.qfrc_applied[(size_t)env * m.nv + lane];   // user forces of the B = 1 shim entries (GripperTester's gravity compensation)
   if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; }

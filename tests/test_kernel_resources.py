@@ -18,7 +18,7 @@ STEP_BUDGET = {"ILi32ELi16ELi16ELi24ELi16ELi16ELi64ELi192E": (8, 256, 64),    # 
                "ILi64ELi16ELi16ELi32ELi32ELi32ELi64ELi320E": (5, 512, 0), "ILi64ELi32ELi48ELi64ELi32ELi32ELi128ELi640E": (4, 512, 0),   # J and M in global memory (RSIM_JGLOBAL round 4: 74.8 -> 49.7 KB = 3; RSIM_MGLOBAL round 5: 40.3 KB = 4, one wavefront per SIMD)
                "ILi64ELi32ELi64ELi64ELi32ELi32ELi128ELi640E": (1, 512, 0),
                # the capacity tiers (round 4): above 64 x 48, above the Lift configuration, above the Stack configuration
-               "ILi64ELi32ELi48ELi64ELi32ELi64ELi256ELi640E": (1, 512, 0), "ILi32ELi16ELi16ELi24ELi16ELi32ELi128ELi192E": (5, 512, 0), "ILi32ELi16ELi32ELi24ELi16ELi32ELi128ELi192E": (3, 512, 0)}
+               "ILi64ELi32ELi48ELi64ELi32ELi64ELi256ELi640E": (2, 512, 0), "ILi32ELi16ELi16ELi24ELi16ELi32ELi128ELi192E": (5, 512, 0), "ILi32ELi16ELi32ELi24ELi16ELi32ELi128ELi192E": (3, 512, 0)}
 
 
 def test_fused_kernel_configurations_keep_their_lds_and_register_budgets():
