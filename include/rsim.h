@@ -206,6 +206,10 @@ enum rsim_field {
                         *               rsim_step (the B = 1 compatibility entries: models/grippers/gripper_tester.py:197-202 writes its gravity compensation
                         *               there); zeroed by rsim_reset.  The fused rsim_control_step does not read it -- nothing on robosuite's env.step path
                         *               writes qfrc_applied */
+  RSIM_POLISH,         /* [B] int32    wide configurations, debug entries: how the fp64 polish behind the Newton iteration of the last substep ended (no MuJoCo counterpart;
+                        *               solve_newton in csrc/rsim_step.hip): 10000 x passes + 100000 x floor(-log10 of the scaled fp64 gradient at the accepted point)
+                        *               + 10^7 x exit (1 gradient below tolerance, 2 improvement below tolerance, 3 pass budget,
+                        *               5 direction was no descent direction, 6 a step raised the objective; 0 not run) */
   RSIM_FIELD_COUNT
 };
 #define RSIM_PATCH_TASK_OBJECT (-1)   /* rsim_set_reset_bank patch index: this column of a reset row is the episode's RSIM_TASK_OBJECT, not a float-table entry */

@@ -1854,6 +1854,16 @@ double rso_cost(rso_data *d, const double *a, double *grad) {
   return cost;
 }
 
+/* Constraint forces and row states (0 satisfied, 1 quadratic, 2 linear-, 3 linear+, 4 cone) the rows of the last forward() give at acceleration `a` (test tooling:
+ * where does a kernel's solution differ -- in the rows' data or in the minimiser?) */
+void rso_forces_at(rso_data *d, const double *a, double *f, int *state) {
+  int nv = d->m->nv, n = d->nefc;
+  double *jar = dalloc(n);
+  for (int i = 0; i < n; i++) { double sj = 0; for (int k = 0; k < nv; k++) sj += d->efc_J[(size_t)i * nv + k] * a[k]; jar[i] = sj - d->efc_aref[i]; }
+  constraint_update(d, jar, f, state, NULL);
+  free(jar);
+}
+
 /* forward() with the contact GEOMETRY given by the caller: the collision pass runs as usual (pairs, dimensions, mixed friction / solref / solimp),
  * then contact i takes dist = geo[13 i], pos = geo[13 i + 1 .. 3], frame = geo[13 i + 4 .. 12] before the constraint rows are built.  Test
  * infrastructure for the solver / dynamics half of a parity check: fed the kernel's own contact list, everything downstream of the narrow phase is
@@ -1894,7 +1904,7 @@ double *rso_data_field(rso_data *d, const char *name, int *count) {
   F(sensordata, d->nsensordata) F(cfrc_int, 6 * m->nbody) F(cfrc_ext, 6 * m->nbody) F(cacc, 6 * m->nbody)
 #undef F
 #define FA(n, c) if (!strcmp(name, #n)) { *count = (c); return d->n; }
-  FA(efc_pos, d->nefc) FA(efc_R, d->nefc) FA(efc_D, d->nefc) FA(efc_aref, d->nefc) FA(efc_force, d->nefc) FA(efc_vel, d->nefc) FA(efc_b, d->nefc)
+  FA(efc_frictionloss, d->nefc) FA(efc_pos, d->nefc) FA(efc_R, d->nefc) FA(efc_D, d->nefc) FA(efc_aref, d->nefc) FA(efc_force, d->nefc) FA(efc_vel, d->nefc) FA(efc_b, d->nefc)
 #undef FA
   if (!strcmp(name, "time")) { *count = 1; return &d->time; }
   *count = 0;
@@ -1914,6 +1924,7 @@ void rso_contact_get(rso_data *d, int i, double *out) {
   memcpy(out + 18, c->friction, 5 * sizeof(double));
 }
 int rso_efc_type(rso_data *d, int i) { return d->efc_type[i]; }
+int rso_efc_id(rso_data *d, int i) { return d->efc_id[i]; }
 
 /* ------------------------------------------------------------------------------------------- */
 /* controllers: OSC_POSE arm + GRIP gripper (restates the reference Python, see file header)   */

@@ -19,9 +19,9 @@ _LIB = None
 # enum rsim_field (include/rsim.h)
 FIELDS = ["qpos", "qvel", "qacc_warmstart", "ctrl", "time", "cstate", "xpos", "xquat", "qM", "qfrc_bias", "qfrc_passive", "qfrc_actuator",
           "qfrc_constraint", "qacc", "cdof", "rootcom", "contact", "efc_force", "ncon", "nefc", "niter", "obs", "reward", "success", "done", "ep_step",
-          "ep_index", "diverged", "overflow", "bank_stale", "terminal_obs", "sensordata", "task_object", "cap_need", "qfrc_applied"]
+          "ep_index", "diverged", "overflow", "bank_stale", "terminal_obs", "sensordata", "task_object", "cap_need", "qfrc_applied", "polish"]
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
-INT_FIELDS = {"ncon", "nefc", "niter", "success", "done", "ep_step", "ep_index", "diverged", "overflow", "bank_stale", "task_object", "cap_need"}
+INT_FIELDS = {"polish", "ncon", "nefc", "niter", "success", "done", "ep_step", "ep_index", "diverged", "overflow", "bank_stale", "task_object", "cap_need"}
 CON_REC = 24
 CSTATE = 32
 OBS_MAX = 128
@@ -430,7 +430,7 @@ class HipBatch:
                        "qfrc_actuator": (B, nv), "qfrc_constraint": (B, nv), "qacc": (B, nv), "cdof": (B, nv, 6), "rootcom": (B, nb, 3),
                        "contact": (B, self.maxcon, CON_REC), "efc_force": (B, self.maxefc), "ncon": (B,), "nefc": (B,), "niter": (B,),
                        "obs": (B, model.nobs), "reward": (B,), "success": (B,), "done": (B,), "ep_step": (B,), "ep_index": (B,), "diverged": (B,), "overflow": (B,), "bank_stale": (B,), "terminal_obs": (B, model.nobs),
-                       "sensordata": (B, int(m.arrays["sensor_dim"].sum()) if getattr(m, "nsensor", 0) else 0), "task_object": (B,), "cap_need": (B, 2), "qfrc_applied": (B, m.nv)}
+                       "sensordata": (B, int(m.arrays["sensor_dim"].sum()) if getattr(m, "nsensor", 0) else 0), "task_object": (B,), "cap_need": (B, 2), "qfrc_applied": (B, m.nv), "polish": (B,)}
 
     # ---- state access (host copies) --------------------------------------------------------
     def get(self, name):

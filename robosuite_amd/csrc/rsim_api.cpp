@@ -863,8 +863,9 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.newton_ls = getenv("RSIM_NEWTON_LS") ? (float)atof(getenv("RSIM_NEWTON_LS")) : RSIM_NEWTON_LS;
   // refinement passes with an fp64 gradient: on for the models of the 64 x 48 class and beyond (PickPlace: mesh objects and Robotiq links of 1e-5 .. 4e-3 kg m^2
   // under condim-4 contacts at the refsafe limit); Stack-class models reach 2e-5 of the oracle without it and would pay 13 % for it
-  dm.newton_refine = getenv("RSIM_NEWTON_REFINE") ? atoi(getenv("RSIM_NEWTON_REFINE")) : (b->cfg >= 3 ? 6 : 0);
+  dm.newton_refine = getenv("RSIM_NEWTON_REFINE") ? atoi(getenv("RSIM_NEWTON_REFINE")) : (b->cfg >= 3 ? 16 : 0);
   dm.newton_polish_tol = getenv("RSIM_POLISH_TOL") ? (float)atof(getenv("RSIM_POLISH_TOL")) : 1.0f;
+  dm.newton_polish_gate = getenv("RSIM_POLISH_GATE") ? (float)atof(getenv("RSIM_POLISH_GATE")) : 0.0f;
   dm.newton_exact = getenv("RSIM_NEWTON_EXACT") ? atoi(getenv("RSIM_NEWTON_EXACT")) : 1;
   dm.newton_ng = getenv("RSIM_NEWTON_NG") ? (float)atof(getenv("RSIM_NEWTON_NG")) : RSIM_NEWTON_NG;
   if (m->multijoint) { int r = fail("rsim_batch_create: bodies with more than one joint are not supported by the fused kernel"); delete b; return r; }
@@ -896,13 +897,6 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
     if (b->cfg_w >= 0 && (b->lim_w[9] & 4)) jgf = std::max(jgf, (size_t)b->lim_w[6] * (size_t)(b->lim_w[2] + 1) + ((b->lim_w[9] & 8) ? (size_t)b->lim_w[2] * (size_t)(b->lim_w[2] + 1) : 0));
     b->db.jg_stride = (long long)jgf;
     if (jgf && dalloc(&b->db.jg, (size_t)B * jgf)) return 1;
-    // fp64 scratch of the polish's rare path (solve_newton build64): [NV][NV] doubles + [NEFC][NV] floats per env, sized for the larger of the native and the wide configuration
-    b->db.h64 = nullptr; b->db.h64_stride = 0;
-    if (dm.newton_refine > 0 && !getenv("RSIM_NO_H64")) {
-      const size_t nvc = std::max(b->lim[2], b->cfg_w >= 0 ? b->lim_w[2] : 0), nec = std::max(b->lim[6], b->cfg_w >= 0 ? b->lim_w[6] : 0);
-      b->db.h64_stride = (long long)(nvc * nvc + (nec * nvc + 1) / 2);
-      if (dalloc(&b->db.h64, (size_t)B * (size_t)b->db.h64_stride)) return 1;
-    }
   }
   b->d_cm_w = nullptr; b->d_tier[0] = b->d_tier[1] = nullptr; b->d_wlist[0] = b->d_wlist[1] = nullptr; b->d_wcount = nullptr; b->wstream = nullptr; b->tier_flip = 0;
   if (b->cfg_w >= 0) {
@@ -953,7 +947,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
       {RSIM_EP_INDEX, (void**)&db.ep_index, (size_t)B, 1}, {RSIM_DIVERGED, (void**)&db.diverged, (size_t)B, 1}, {RSIM_OVERFLOW, (void**)&db.overflow, (size_t)B, 1},
       {RSIM_BANK_STALE, (void**)&db.bank_stale, (size_t)B, 1}, {RSIM_TERMINAL_OBS, (void**)&db.term_obs, (size_t)B * (m->has_task ? m->task.nobs : 0), 0},
       {RSIM_SENSORDATA, (void**)&db.sensordata, (size_t)B * m->nsensordata, 0}, {RSIM_TASK_OBJECT, (void**)&db.task_object, (size_t)B, 1},
-      {RSIM_CAP_NEED, (void**)&db.cap_need, (size_t)B * 2, 1}, {RSIM_QFRC_APPLIED, (void**)&db.qfrc_applied, (size_t)B * nv, 0}};
+      {RSIM_CAP_NEED, (void**)&db.cap_need, (size_t)B * 2, 1}, {RSIM_QFRC_APPLIED, (void**)&db.qfrc_applied, (size_t)B * nv, 0},
+      {RSIM_POLISH, (void**)&db.polish, (size_t)B, 1}};
   for (auto& fd : fields) {
     if (dalloc((float**)fd.p, fd.n)) return 1;
     b->fptr[fd.id] = *fd.p; b->fcount[fd.id] = fd.n; b->fis_int[fd.id] = fd.is_int;
@@ -978,7 +973,6 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   }
   if (b->db.mprc) hipFree(b->db.mprc);
   if (b->db.jg) hipFree(b->db.jg);
-  if (b->db.h64) hipFree(b->db.h64);
   if (b->db.bpl) hipFree(b->db.bpl);
   hipFree(b->d_it); hipFree(b->d_lt); hipFree(b->d_ft); hipFree(b->d_ft0); if (b->d_obsprog) hipFree(b->d_obsprog);
   if (b->d_bank) hipFree(b->d_bank); if (b->d_bank_tag) hipFree(b->d_bank_tag); if (b->d_patch) hipFree(b->d_patch); hipFree(b->db.needs_reset); if (b->d_ft_base) hipFree(b->d_ft_base); hipFree(b->d_mesh); hipFree(b->d_mask);

@@ -137,6 +137,7 @@ struct DModel {
   float newton_ns, newton_na, newton_ng, newton_ls;
   int newton_refine;   // wide configurations: at most this many polish passes behind the fp32 Newton iteration (fp64 residuals / states / objective / gradient, solve_newton), 0 = none
   float newton_polish_tol;   // the passes end when the scaled fp64 gradient or improvement falls below tolerance x this (1: MuJoCo's own criteria)
+  float newton_polish_gate;  // < 0: the polish searches the line from its first pass on (A/B); default 0: plain Newton step first
   int newton_exact;    // 1: a Newton step that leaves every row's state where it was (and no row on the cone) ends the solve -- the objective is quadratic on that piece, the step is its minimiser
   int newton_wide;     // wide (nv > 16) configurations: 0 = neither fp32 rule, 1 = step rule and line-search exit as in the one-tile ones, 2 = line-search exit only   // fp32 stopping rules of the Newton solver (solve_newton): relative / absolute step floor, gradient noise factor
   const int* it;
@@ -196,8 +197,7 @@ struct DBatch {
   int* task_object;      // [B] PickPlace single-object mode 1: the object of the env's current episode (RSIM_TASK_OBJECT)
   float* sensordata;     // [B][nsensordata] (debug build of the kernel: rsim_step.hip sensor_acc)
   int* bpl;              // [B][5][64] or null: broadphase pair list (rsim_step.hip collision(): sphere centres at build time, packed pair constants, pair indices)
-  double* h64;           // [B][h64_stride] fp64 scratch of the polish's rare path (Hessian / factor [NV][NV] doubles, then the weighted rows [NEFC][NV] floats); null: no fp64 factor
-  long long h64_stride;  // doubles per env, one stride for the native and the wide configuration
+  int* polish;           // [B] RSIM_POLISH: how the fp64 polish of the last substep's solve ended (debug entries only)
   float* qfrc_applied;   // [B][nv] mjData.qfrc_applied: added to the smooth forces by the debug form of the kernel (rsim_forward / step1 / step2 / step); the fused control step ignores it
   float* jg;             // RSIM_JGLOBAL builds: per-env scratch in global memory, [B][jg_stride] floats: the constraint Jacobian, NEFC * (NV + 1), then (RSIM_MGLOBAL) the mass matrix, NV * (NV + 1); null otherwise
   long long jg_stride;   // floats per env = the largest need of the configurations that step this batch (native and wide tier): ONE stride for all of them --

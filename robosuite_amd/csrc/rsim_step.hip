@@ -110,6 +110,9 @@ typedef unsigned long long u64;
 #else
 #define RSIM_MG_ENABLED 0
 #endif
+#ifndef RSIM_LS_MAXSLOT
+#define RSIM_LS_MAXSLOT 4   // rows per lane up to which the polish carries the fp64 line search (4: every configuration)
+#endif
 #define SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define FMIN 1e-20f
 #define PI_F 3.14159265358979f
@@ -363,7 +366,7 @@ struct Smem {
   float cstate[RSIM_CS_LDS];     // first RSIM_CS_LDS floats of the controller state (all of it for the OSC and plain joint-space types); the tail stays in global memory
   float red[NV];
   float hull[3 * HULLPOOL_ + 1];    // LDS-resident hull vertex pool (SoA x | y | z); filled once per launch
-  int ncon, nefc, niter;
+  int ncon, nefc, niter, polish;
 };
 
 // Model constants of one environment in the layout the kernel's lane roles read them: built by prepare_constants() (k_prepare, or the env's own
@@ -2218,8 +2221,6 @@ struct Sim {
   // the 256-register build more in spills than the list saves.
   int task_obj = 0;                     // PickPlace single-object mode 1: this env's object (DBatch.task_object)
   int act_n = -1;                       // pairs on the list (-1: none)
-  double __attribute__((address_space(1)))* h64 = nullptr;   // this env's fp64 scratch in global memory (DBatch.h64): Hessian / Cholesky factor [NV][NV], then the weighted rows (float [NEFC][NV]) -- the polish's rare path
-  __device__ __forceinline__ void hsync() const { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
   float applied = 0.f;   // this lane's dof: mjData.qfrc_applied (RSIM_QFRC_APPLIED), read by the debug form of the kernel only (step_body)
   int __attribute__((address_space(1)))* bpl = nullptr;   // [0..2][lane g]: centre of geom g's bounding sphere when the list was built; [3][lane i]: packed
                                                           // constants (geom1 | geom2 << 8 | enabled << 16) of the i-th listed pair; [4][lane i]: its index
@@ -3647,7 +3648,7 @@ struct Sim {
     float a = cost_ws < cost_sm ? a_ws : a_sm;
     int iter = 0;
     bool have_eval = false;   // the rows are already evaluated at `a` (cost_pre)
-    bool used64 = false;      // the polish factorised H in fp64 (wide configurations, rare)
+    int pol_exit = 0, pol_pass = 0, pol_sgb = 0;   // how the polish ended (RSIM_POLISH of the debug entries carries it: see the end of this function)
     float cost_pre = 0.f;
     for (;;) {
       float cost = have_eval ? cost_pre : wave_sum(evaluate(a));
@@ -3800,17 +3801,21 @@ struct Sim {
       }
     }
     if constexpr (!FAST) {
-      // ---- polish of the solution with everything that DECIDES evaluated in fp64 (wide configurations).  What fp32 cannot resolve on these models: a direction
-      // of 1e-5 .. 4e-3 kg m^2 (an object's or a Robotiq link's own rotation) beside contact rows of D ~ 1e6.  The cost is flat there to fp32 (half H_soft da^2 of
-      // 1e-3 in a cost of 1e3), so the iteration above stops a hundred rad/s^2 short, or on the wrong side of a row's state change.  The GRADIENT tells the
-      // directions apart if its parts are kept apart: residuals J a - aref, the row states and forces they give, the objective and J^T f summed in fp64 from the
-      // float data (every product exact), the acceleration carried as a pair of floats.  Each pass is then a Newton step of the TRUE objective:
-      //   * rows are re-classified from the fp64 residuals (rounds 3-4 froze them where the fp32 iteration had left them and threw the pass away when a row turned
-      //     out to sit in another state: exactly the envs of the tail, whose per-env deviation from the fp64 oracle stayed at 1e-1 of the largest acceleration);
-      //   * the direction is -H^-1 g with the fp32 factor in LDS (it resolves the soft directions to a few per cent: a pass gains a factor of ~20); when the
-      //     rows' states are no longer the ones the factor was built on, H is formed and factorised again (fp32, matrix cores) from the fp64-decided states;
-      //   * a step is kept only if it lowers the fp64 objective; one that does not (it crossed a state boundary) is halved, at most three times;
-      //   * passes end on MuJoCo's own criteria, evaluated in fp64: scaled gradient or scaled improvement below `tolerance`, or after `newton_refine` passes.
+      // ---- polish of the solution with everything that DECIDES evaluated in fp64 (wide configurations).  What fp32 cannot see on these models: cost differences below
+      // 1e-7 of a cost of 1e3.  The iteration above therefore ends where a step gains nothing it can measure -- characteristically ON a kink of the piecewise objective:
+      // a cone block (the condim-4 contacts of the PickPlace objects) or a row about to change its state.  Round 5 traced the per-env tail of the full-size test to
+      // exactly that (tests/test_full_size_parity.py, profiles/r05_g_*): in every one of the worst envs one contact sits in the cone (or satisfied) state at the kernel's
+      // answer and in the quadratic state at the minimiser, the fp64 gradient left is 1e-2 .. 1 (scaled), forces are ordinary (20 - 1500 N) -- not conditioning (rounding
+      // the solver's inputs to fp32 moves the fp64 solution by 1e-7), not the fp32 factor (a plain Newton step does not descend there even with an exact one), but the
+      // missing line search ACROSS the kink: Newton with an exact fp64 line search walks through in 3 - 10 passes (1e-5, 1e-5, 1e-5, 3e-6, 2e-7, 7e-10), with an fp32
+      // factor just as well (tools/emulate_polish.py).  So:
+      //   * residuals J a - aref, row states, forces, objective and J^T f in fp64 from the float data (every product exact), the acceleration a pair of floats;
+      //   * direction -H^-1 g with H = M + J^T W of the fp64-decided states, formed and factorised in fp32 on the matrix cores (re-done when the states changed);
+      //   * exact line search along it in fp64 (MuJoCo's: safeguarded 1-D Newton on the derivative of the piecewise-quadratic + cone objective);
+      //   * a point is kept unless it is higher than the rounding of the objective; passes end on MuJoCo's criteria (scaled gradient / improvement below `tolerance`,
+      //     the latter not while rows are still flipping), or after `newton_refine` passes;
+      //   * the first pass is a plain Newton step (most solves end there); the line search comes on when that step raises the objective or leaves more than a
+      //     quarter of the gradient.
       const int R = m.newton_refine;
       if (R > 0 && n > 0) {
         // (not only behind a factorisation of the iteration above: its fp32 exits -- a gradient within the rounding noise of its own terms, which for a light body
@@ -3820,7 +3825,6 @@ struct Sim {
         float a_lo = 0.f, a_keep = a, alo_keep = 0.f, force_keep[NSLOT], dk = 0.f;
         int state_keep[NSLOT];
         double err_keep = 1.0e300;
-        int nback = 0;
 #pragma unroll
         for (int s = 0; s < NSLOT; s++) { force_keep[s] = force[s]; state_keep[s] = state[s]; }
         // (hi, lo) += d, exactly up to the pair's precision
@@ -3830,66 +3834,8 @@ struct Sim {
           hi = __fadd_rn(sm_, l2);
           lo = __fsub_rn(l2, __fsub_rn(hi, sm_));
         };
-        // ---- the factor itself in fp64 (rare path).  When fp32 cannot factorise H -- a light body squeezed by stiff contacts: after diagonal scaling the
-        // translation / rotation block is singular to 1 - I / (D r^2), 1e-7 and below -- its directions are noise, no step lowers the objective and the passes
-        // above stall (what the tail of the round-4 full-size test was made of).  Then H = M + J^T W is ACCUMULATED and FACTORISED in double precision from the
-        // same float data (weights from the LDS table hess_wide() reads, J and M as stored): in this env's scratch in global memory (DBatch.h64: no LDS, no
-        // registers held across the kernel), lane i = row i, right-looking Cholesky with a workgroup-scope fence per column.  ~0.1 ms; taken by the envs that need it.
-        bool use64 = false, have64 = false;
-        const int ld = nv;
-        auto build64 = [&]() -> bool {
-          typedef float __attribute__((address_space(1)))* gf;
-          gf A = (gf)(h64 + (size_t)SM::NV_ * SM::NV_);       // weighted rows A[r][i] = sum_k coef_r[k] J[head_r + min(k, dim - 1)][i]  (or D_r J[r][i])
-          for (int r = 0; r < n; r++) {
-            const float* o = sm.u.W + 5 * r;
-            const int bd = ((const int*)o)[4];
-            float ai = 0.f;
-            if (lane < nv) {
-              if ((bd >> 16) & 1) {
-                const int head = bd & 255, dm1 = ((bd >> 8) & 7) - 1;
-#pragma unroll
-                for (int k2 = 0; k2 < 4; k2++) ai = fmaf(o[k2], Jrd((head + (k2 < dm1 ? k2 : dm1)) * JS + lane), ai);
-              } else ai = o[0] * Jrd(r * JS + lane);
-              A[r * nv + lane] = ai;
-            }
-          }
-          hsync();
-          for (int j = 0; j < nv; j++) {
-            if (lane >= j && lane < nv) {
-              double acc = (double)Mrd(lane * NVP + j);
-              for (int r = 0; r < n; r++) acc = fma((double)A[r * nv + lane], (double)Jrd(r * JS + j), acc);
-              h64[lane * ld + j] = acc;
-            }
-          }
-          hsync();
-          bool ok = true;
-          for (int k = 0; k < nv; k++) {
-            const double dkk = h64[k * ld + k];
-            if (!(dkk > 0.0)) { ok = false; break; }
-            const double lkk = sqrt(dkk);
-            double lik = 0.0;
-            if (lane > k && lane < nv) { lik = h64[lane * ld + k] / lkk; h64[lane * ld + k] = lik; }
-            if (lane == k) h64[k * ld + k] = lkk;
-            hsync();
-            if (lane > k && lane < nv) for (int j = k + 1; j <= lane; j++) h64[lane * ld + j] = fma(-lik, h64[j * ld + k], h64[lane * ld + j]);
-            hsync();
-          }
-          return ok;
-        };
-        auto solve64 = [&](double rhs) -> double {    // x = H^-1 rhs with the factor above; component i in lane i
-          double acc = lane < nv ? rhs : 0.0;
-          for (int k = 0; k < nv; k++) {
-            const double yk = __shfl(acc / h64[k * ld + k], k);
-            if (lane == k) acc = yk;
-            else if (lane > k && lane < nv) acc = fma(-h64[lane * ld + k], yk, acc);
-          }
-          for (int k = nv - 1; k >= 0; k--) {
-            const double xk = __shfl(acc / h64[k * ld + k], k);
-            if (lane == k) acc = xk;
-            else if (lane < k) acc = fma(-h64[k * ld + lane], xk, acc);
-          }
-          return lane < nv ? acc : 0.0;
-        };
+        int flat = 0;
+        bool use_ls = m.newton_polish_gate < 0.f;   // (RSIM_POLISH_GATE < 0: line search from the first pass on, for A/B)
         double gn_prev = 1.0e300;
         for (int it = 0;;) {
           double jr[NSLOT], u64[NSLOT], c64 = 0.0;   // c64: this lane's share of the objective at a + a_lo, in fp64 (same pieces as row_update)
@@ -3950,71 +3896,145 @@ struct Sim {
             }
           }
           SYNC();
-          double gk = 0.0;
+          double gk = 0.0, ma64 = 0.0;
           if (lane < nv) {
             double ma = 0.0, jf = 0.0;
             for (int j = 0; j < nv; j++) ma = fma((double)Mrd(lane * NVP + j), (double)bcast(a, j) + (double)bcast(a_lo, j), ma);
             for (int r = 0; r < n; r++) jf = fma((double)Jrd(r * JS + lane), (double)sm.u.W[r] + (double)sm.u.W[NEFCAP + r], jf);
-            gk = ma - (double)f_sm - jf;
+            gk = ma - (double)f_sm - jf; ma64 = ma;
             // the objective's Gauss term half (M a - f_smooth) . (a - a_smooth)
             c64 += 0.5 * (ma - (double)f_sm) * ((double)a + (double)a_lo - (double)a_sm);
           }
           const double err = wave_sum_f64(c64);
-          if (!(err < err_keep)) {
-            // not lower (or not a number): half the step from the kept point, unless the difference is rounding of the objective itself
-            if (it > 0 && nback < 3 && err - err_keep > 1e-13 * fabs(err_keep)) {
-              nback++;
-              dk *= 0.5f;
-              a = a_keep; a_lo = alo_keep;
-              dfadd(a, a_lo, dk);
-              SYNC();
-              continue;
-            }
+          // The line search returns the minimiser along a descent direction of this convex objective, so the new point is not higher -- but where the kept point sits
+          // ON a kink (a row or a cone block about to change its state: where the fp32 iteration above characteristically ends) the first steps gain next to nothing
+          // and only flip the block; the gain comes in the passes after it (tools/emulate_polish.py on the dumped tail envs: 1e-5, 1e-5, 1e-5, 3e-6, 2e-7, 7e-10).
+          // A point is therefore kept unless it is HIGHER by more than the objective's own rounding.
+          if (!(err <= err_keep + 1e-12 * fabs(err_keep))) {
             a = a_keep; a_lo = alo_keep;
-            if (it > 0 && !use64 && h64 && err - err_keep > 1e-13 * fabs(err_keep)) {
-              // no part of the fp32 direction lowered the objective: the factor is noise.  Back at the kept point, with the fp64 factor from here on.
-              use64 = true; have64 = false; err_keep = 1.0e300; nback = 0;
+            if (!use_ls && NSLOT <= RSIM_LS_MAXSLOT) {   // the plain Newton step raised the objective: from the kept point again, with the line search from here on
+              use_ls = true; err_keep = 1.0e300;
               SYNC();
               continue;
             }
 #pragma unroll
             for (int s = 0; s < NSLOT; s++) { force[s] = force_keep[s]; state[s] = state_keep[s]; }
+            pol_exit = 6; pol_pass = it;
             break;
           }
           const double gain = err_keep - err;
-          a_keep = a; alo_keep = a_lo; err_keep = err; nback = 0;
+          bool flipped = false;       // some row sits in another state than at the kept point
+#pragma unroll
+          for (int s = 0; s < NSLOT; s++) if SLOT_ON(s) flipped |= rw[s].valid && state[s] != state_keep[s];
+          flipped = __ballot(flipped) != 0;
+          a_keep = a; alo_keep = a_lo; err_keep = err;
 #pragma unroll
           for (int s = 0; s < NSLOT; s++) { force_keep[s] = force[s]; state_keep[s] = state[s]; }
           const double gn = wave_sum_f64(lane < nv ? gk * gk : 0.0);
           const double sg = (double)scale * sqrt(gn), tol64 = (double)tolerance * (double)m.newton_polish_tol;
-          if (it >= R || sg < tol64 || (it > 0 && (double)scale * gain < tol64)) break;
-          // a pass with a sound factor shrinks the gradient by orders of magnitude; one that leaves more than half of it did not resolve the direction that matters:
-          // with a gradient still far from the tolerance the factor is taken in fp64 from here on, near the tolerance the passes simply end
-          if (it > 0 && gn > 0.25 * gn_prev) {
-            if (use64 || !h64 || sg < 100.0 * tol64) break;
-            use64 = true; have64 = false;
-          }
+          { const int bk = sg > 0.0 ? (int)(-log10(sg)) : 15; pol_sgb = bk < 0 ? 0 : (bk > 15 ? 15 : bk); pol_pass = it; }
+          if (sg < tol64) { pol_exit = 1; break; }
+          // MuJoCo's improvement criterion -- but not while the passes are still flipping rows at a kink (no gain yet, by construction)
+          // (three passes in a row: at a kink two passes without gain and without a flip do occur before the block lets go -- 1e-5, 1e-5, 1e-5, 3e-6, ... in the emulation)
+          if (it > 0 && !flipped && (double)scale * gain < tol64) { if (++flat >= 3) { pol_exit = 2; break; } } else flat = 0;
+          if (it >= R) { pol_exit = 3; break; }
+          // The first step is the plain Newton step: inside a piece of the objective it lands on the minimiser, and most solves are done after it (5000 of 8192 in
+          // the PickPlace workload).  One that does not shrink the gradient to a quarter -- the point sits on a kink -- switches the line search on for the rest.
+          if (it > 0 && gn > 0.0625 * gn_prev) use_ls = true;
           gn_prev = gn;
           it++;
           bool other = false;
 #pragma unroll
-          for (int s = 0; s < NSLOT; s++) if SLOT_ON(s) other |= rw[s].valid && state[s] != fst[s];
+          for (int s = 0; s < NSLOT; s++) if SLOT_ON(s) other |= rw[s].valid && (state[s] != fst[s] || (it >= 2 && state[s] == ST_CONE));
           SYNC();
-          if (__ballot(other) || need_factor || (use64 && !have64)) {   // no factor yet, one of another active set, or one to be had in fp64: H from these states
+          // no factor yet, one of another active set, or -- from the second pass on -- a row on the cone, whose Hessian moves with the point (a stale factor makes
+          // the passes a quasi-Newton iteration: the envs that used up a 16-pass budget in profiles/r05_k_*): H from these states, fp32 on the matrix cores
+          if (__ballot(other) || need_factor) {
             need_factor = false;
             weights();
             SYNC();
-            if (use64) {
-              if (!build64()) break;     // not positive definite even in fp64: keep what we have
-              have64 = true; used64 = true;
-#pragma unroll
-              for (int s = 0; s < NSLOT; s++) fst[s] = state[s];
-            } else factorize();
+            factorize();
           }
-          if (use64) dk = (float)solve64(-gk);
-          else dk = bchol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -(float)gk : 0.f, nv, lane);
+          dk = bchol_solve<NVP>(sm.H, sm.invdiag, lane < nv ? -(float)gk : 0.f, nv, lane);
           if (lane >= nv) dk = 0.f;
-          dfadd(a, a_lo, dk);
+          // ---- exact line search along dk, in fp64 (MuJoCo's primal line search: the objective along a line is piecewise quadratic plus the cone terms; a
+          // safeguarded 1-D Newton iteration on its derivative).  The rows' residuals move as jr + alpha jv.
+          double alpha = 1.0;
+          if (use_ls && NSLOT <= RSIM_LS_MAXSLOT) {
+            // (the gathered vectors of every cone block are kept: forming T^2 along the line from expanded sums cancels where the line passes the cone's axis -- the very
+            // kinks this search has to cross; measured: the per-env tail came back with the expanded form, profiles/r05_i_*)
+            double jv[NSLOT], v64[NSLOT], g0[NSLOT][CD], gv[NSLOT][CD];
+#pragma unroll
+            for (int s = 0; s < NSLOT; s++) { jv[s] = SLOT_ON(s) ? row_res64(rw[s], dk, 0.f) + (double)rw[s].aref : 0.0; v64[s] = jv[s] * (double)rw[s].fr_own; }   // J_r . dk with exact products
+#pragma unroll
+            for (int s = 0; s < NSLOT; s++)
+#pragma unroll
+              for (int j = 0; j < CD; j++) {
+                const int Rr = rw[s].head + j;
+                double tu = __shfl(u64[0], Rr & 63), tv = __shfl(v64[0], Rr & 63);
+#pragma unroll
+                for (int s2 = 1; s2 < NSLOT; s2++) { const double t1 = __shfl(u64[s2], Rr & 63), t2 = __shfl(v64[s2], Rr & 63); if ((Rr >> 6) == s2) { tu = t1; tv = t2; } }
+                const bool on = rw[s].ell && j < rw[s].dim;
+                g0[s][j] = on ? tu : 0.0; gv[s][j] = on ? tv : 0.0;
+              }
+            const double mvv = (double)mass_dot(Mr, dk);
+            const double q1 = wave_sum_f64(lane < nv ? (double)dk * (ma64 - (double)f_sm) : 0.0), q2 = wave_sum_f64(lane < nv ? 0.5 * (double)dk * mvv : 0.0);
+            auto line64 = [&](double al, double& d1, double& d2) {     // first and second derivative of the rows' part along the line, this lane's share
+              d1 = d2 = 0.0;
+#pragma unroll
+              for (int s = 0; s < NSLOT; s++) {
+                const Row& w_ = rw[s];
+                if (!(w_.valid && SLOT_ON(s))) continue;
+                const double x = fma(al, jv[s], jr[s]), v = jv[s], D = (double)w_.D;
+                if (w_.type == C_FRICTION_DOF) {
+                  const double fl = (double)w_.fl, lim = (double)w_.R * fl;
+                  if (x <= -lim) d1 -= fl * v; else if (x >= lim) d1 += fl * v; else { d1 += D * x * v; d2 += D * v * v; }
+                } else if (TENDONS && w_.type == C_EQUALITY) { d1 += D * x * v; d2 += D * v * v; }
+                else if (!w_.ell) { if (x < 0) { d1 += D * x * v; d2 += D * v * v; } }
+                else {
+                  const double mu = (double)w_.mu, N = fma(al, gv[s][0], g0[s][0]);
+                  double T2 = 0.0, UV = 0.0, VV = 0.0;
+#pragma unroll
+                  for (int j = 1; j < CD; j++) { const double U = fma(al, gv[s][j], g0[s][j]); T2 = fma(U, U, T2); UV = fma(U, gv[s][j], UV); VV = fma(gv[s][j], gv[s][j], VV); }
+                  const double Tn = sqrt(T2);
+                  if (N >= mu * Tn || (Tn <= 0 && N >= 0)) {
+                  } else if (mu * N + Tn <= 0 || (Tn <= 0 && N < 0)) { d1 += D * x * v; d2 += D * v * v; }
+                  else if (w_.kk == 0) {
+                    const double g_ = N - mu * Tn, iT = 1.0 / Tn, g1 = gv[s][0] - mu * UV * iT, g2 = -mu * (VV * iT - UV * UV * iT * iT * iT);
+                    d1 += (double)w_.Dm * g_ * g1; d2 += (double)w_.Dm * (g1 * g1 + g_ * g2);
+                  }
+                }
+              }
+            };
+            double c1, c2;
+            line64(0.0, c1, c2);
+            const double d0 = q1 + wave_sum_f64(c1), h0 = 2.0 * q2 + wave_sum_f64(c2);
+            if (!(d0 < 0.0) || !(h0 > 0.0)) {
+              // not a descent direction of the true objective (an fp32 factor that is noise): the passes end here
+              pol_exit = 5; break;
+            }
+            alpha = -d0 / h0;
+            double lo = 0.0, hi = -1.0;
+            bool conv = false;
+            for (int ls = 0; ls < 24; ls++) {
+              line64(alpha, c1, c2);
+              const double dp = q1 + 2.0 * alpha * q2 + wave_sum_f64(c1), hp = 2.0 * q2 + wave_sum_f64(c2);
+              if (fabs(dp) < 1e-9 * fabs(d0)) { conv = true; break; }
+              if (dp < 0) lo = alpha; else hi = alpha;
+              double next = hp > 0 ? alpha - dp / hp : -1.0;
+              if (hi < 0) { if (next <= lo) next = 2.0 * alpha + 1e-12; }
+              else if (next <= lo || next >= hi) next = 0.5 * (lo + hi);
+              if (fabs(next - alpha) <= 1e-12 * fabs(alpha)) { conv = true; break; }
+              alpha = next;
+            }
+            // out of evaluations on a fresh alpha: the largest step known to lie on the descending side (the objective is convex along the line: it is lower there)
+            if (!conv && lo > 0.0) alpha = lo;
+            // where the bracket has closed on a kink (the derivative jumps from negative to positive there) the step goes to its FAR side: the rows that change state
+            // there then sit in their new state at the next evaluation and the next Hessian belongs to the piece the minimiser lies in; on the near side the same
+            // direction would come back (the objective at the two ends differs by the bracket's width times the derivative: nothing)
+            if (conv && hi > 0.0 && hi - lo <= 1e-6 * hi) alpha = hi;
+          }
+          dfadd(a, a_lo, (float)(alpha * (double)dk));
           SYNC();
         }
       }
@@ -4024,7 +4044,10 @@ struct Sim {
     SYNC();
     const float fc = jt_times_force(nch);
     if (lane < nv) { sm.qfrc_constraint[lane] = fc; sm.qacc[lane] = a; }
-    if (lane == 0) sm.niter = iter + (used64 ? 1000 : 0);   // + 1000: the polish had to factorise in fp64 (RSIM_NITER of the debug entries)
+    // RSIM_POLISH of the debug entries: 1000 (the polish factorised in fp64) + 10000 x polish passes + 100000 x floor(-log10(scaled fp64 gradient at the kept
+    // point)) + 10^7 x how the polish ended (1 gradient below tolerance, 2 improvement below tolerance, 3 pass budget, 4 stagnation near the tolerance, 5 stagnation
+    // with the fp64 factor, 6 no step lowered the objective, 7 H not positive definite in fp64; 0 not run)
+    if (lane == 0) { sm.niter = iter; sm.polish = 10000 * pol_pass + 100000 * pol_sgb + 10000000 * pol_exit; }
     pf.count(RP_N_NEWTON, iter);
     SYNC();
 #undef SLOT_ON
@@ -4246,10 +4269,9 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   if (b.mprc) { sim.mprc = (gwf)(b.mprc + (size_t)env * Sim<SM>::MPRC * m.npair); sim.mpr_portal = b.mprc_portal != 0; }
   if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * b.jg_stride);   // one stride for every configuration that steps envs of this batch (the native and the wide pass run side by side)
   if constexpr (Sim<SM>::MG) sim.Mg = sim.Jg + SM::NEFC_ * SM::JS_;
-  if (b.h64) sim.h64 = (double __attribute__((address_space(1)))*)(b.h64 + (size_t)env * b.h64_stride);
   if (lane < csl) sm.cstate[lane] = sim.cst[lane];
   if constexpr (DBG) if (b.qfrc_applied && lane < m.nv) sim.applied = b.qfrc_applied[(size_t)env * m.nv + lane];   // user forces of the B = 1 shim entries (GripperTester's gravity compensation)
-  if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; }
+  if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; sm.polish = 0; }
   sim.load_opt();
   sim.init_lds();
   const float* act = actions ? actions + (size_t)env * m.ctrl.action_dim : nullptr;
@@ -4431,7 +4453,7 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
     }
     if (flags & RF_ACTSOLVE)
       for (int i = lane; i < sm.nefc; i += 64) b.efc_force[(size_t)env * NEFC + i] = sm.e_force[i];
-    if (lane == 0) { b.ncon[env] = ncon; b.nefc[env] = sm.nefc; b.niter[env] = sm.niter; }
+    if (lane == 0) { b.ncon[env] = ncon; b.nefc[env] = sm.nefc; b.niter[env] = sm.niter; if (b.polish) b.polish[env] = sm.polish; }
   }
 }
 

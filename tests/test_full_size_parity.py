@@ -36,13 +36,20 @@ pytestmark = pytest.mark.gpu
 # 9e-4, forces p50 2e-5 -> 7e-6, p90 7e-4 -> 2e-4.  The tail (p99 ~ 1e-1, one env per few hundred with the maximum near 1) is where the fp32 iteration itself stops on the
 # wrong side of a state change or the factor resolves nothing of the soft direction; it is unchanged.  So the 90th percentile is now asserted, an order below what
 # the medians were held to in round 3, and the medians two orders below.
-PP_COST_GAP = 1e-3
-PP_COST_GAP_P90 = 1e-6
-PP_ARM_TOL = 5e-3
+# Round 5: the tail is gone.  It was traced (RSIM_POLISH diagnostics, per-state fp32-input floors, dumps of the worst envs analysed on the CPU: tools/analyze_parity_dump.py,
+# tools/emulate_polish.py, profiles/r05_g_*) to ONE mechanism: the fp32 iteration ends on a kink of the piecewise objective -- in every one of the worst envs a condim-4
+# contact of an object sat in the cone (or satisfied) state at the kernel's answer and in the quadratic state at the minimiser -- where a plain Newton step gains nothing
+# even with an exact Hessian, and only an exact line search ACROSS the kink gets on (the fp64 oracle, started at the kernel's answer, needed 3 - 10 more iterations).
+# Not conditioning: rounding the fp64 solve's inputs to float32 moves it by 1e-7 of the group's largest on those very states (`g_floor`).  The polish behind the wide
+# Newton solver is now that iteration (fp64 evaluation + exact fp64 line search, fp32 factor; csrc/rsim_step.hip solve_newton), and the assertions below are per-env
+# MAXIMA over the sample (197 envs measured: objects 1e-3, gripper 1e-3, forces 4e-3, objective gap 4e-8; before: 3e-1, 9e-2, 1e+0, 9e-4).
+PP_COST_GAP = 2e-6
+PP_COST_GAP_P90 = 1e-8
+PP_ARM_TOL = 1e-3
 PP_FORCE_MEDIAN = 2e-4
-PP_FORCE_P90 = 4e-3
+PP_FORCE_MAX = 1e-2
 PP_GROUP_MEDIAN = {"gripper": 5e-4, "objects": 2e-4}
-PP_GROUP_P90 = {"gripper": 5e-3, "objects": 2e-2}
+PP_GROUP_MAX = {"gripper": 5e-3, "objects": 5e-3}
 torch = pytest.importorskip("torch")
 
 # float model arrays an env may carry its own values for (rsim_model_param_set / domain randomisation / per-episode patches)
@@ -63,7 +70,9 @@ def oracle_for_env(flat, hb, e):
     opt = hb.param_get("opt", e, 1)[0]
     f.arrays["timestep"] = np.array([opt[0]]); f.arrays["gravity"] = opt[1:4].copy(); f.arrays["density"] = np.array([opt[4]])
     f.arrays["viscosity"] = np.array([opt[5]]); f.arrays["impratio"] = np.array([opt[6]]); f.arrays["wind"] = opt[7:10].copy()
-    om = OracleModel(mjcf.to_blob(f))
+    blob = mjcf.to_blob(f)
+    om = OracleModel(blob)
+    om.blob_bytes = blob          # kept for RSIM_PARITY_DUMP (offline analysis of single envs on the CPU)
     return om, OracleData(om)
 
 
@@ -74,6 +83,7 @@ def compare_reached_states(flat, hb, pick, mpr_geoms=(), with_contacts=0, ignore
     q, v, ws, ctrl = hb.get("qpos"), hb.get("qvel"), hb.get("qacc_warmstart"), hb.get("ctrl")
     hb.forward()
     ncon, nefc, qacc, efc, con = hb.get("ncon"), hb.get("nefc"), hb.get("qacc"), hb.get("efc_force"), hb.get("contact")
+    niter_all = hb.get("polish") if "polish" in hb.shapes else hb.get("niter")
     if with_contacts:
         have = np.nonzero(ncon > 0)[0]
         if len(have):
@@ -112,10 +122,23 @@ def compare_reached_states(flat, hb, pick, mpr_geoms=(), with_contacts=0, ignore
                 # ... and in the solver's own metric: the objective the Newton solver minimises, evaluated in fp64 at the kernel's acceleration and at
                 # the oracle's (the unique minimiser).  Where the Hessian is nearly flat -- a 1e-5 kg m^2 object or finger link under contacts of
                 # D ~ 1e6 -- accelerations far apart have costs equal to single precision; this number says how far from optimal the kernel stopped
-                c_opt, c_hip = od.cost(np.array(od.qacc)), od.cost(qacc[e].astype(np.float64))
+                (c_opt, g_opt), c_hip = od.cost(np.array(od.qacc), True), od.cost(qacc[e].astype(np.float64))
                 r["g_cost_gap"] = float((c_hip - c_opt) / max(1.0, abs(c_opt)))
+                # the yardstick itself: the oracle's Newton iteration stops on MuJoCo's criteria too, and in single envs it stops short (gradient of 0.4 - 0.6 left on an
+                # object dof while the kernel's answer has the LOWER objective: profiles/r05_m_*).  Such an env says nothing about the kernel
+                r["oracle_grad"] = float(np.abs(g_opt).max())
                 if dof_groups:
                     r["g_groups"] = {k: (float(np.abs(qacc[e][ix] - od.qacc[ix]).max()), float(np.abs(od.qacc[ix]).max())) for k, ix in dof_groups.items()}
+                    # conditioning of THIS state: how far the fp64 solve itself moves when its inputs are rounded to float32 (oracle/rsim_oracle.c round_inputs_f32)
+                    a_exact = np.array(od.qacc)
+                    od.set_round_rows(True); od.qacc_warmstart[:] = ws[e]
+                    if od.forward_with_contact_geometry(hc):
+                        r["g_floor"] = {k: float(np.abs(np.asarray(od.qacc)[ix] - a_exact[ix]).max()) for k, ix in dof_groups.items()}
+                    od.set_round_rows(False)
+                r["niter"] = int(niter_all[e])
+                if os.environ.get("RSIM_PARITY_DUMP"):
+                    r["dump"] = dict(blob=np.frombuffer(om.blob_bytes, dtype=np.uint8).copy(), qpos=q[e].copy(), qvel=v[e].copy(), ws=ws[e].copy(), ctrl=ctrl[e].copy(), qacc=qacc[e].copy(),
+                                     efc=efc[e][:od.nefc].copy(), geo=np.array([[c["dist"], *c["pos"], *np.asarray(c["frame"]).ravel(), c["geom1"], c["geom2"], c["dim"]] for c in hc]))
         out.append(r)
     return out
 
@@ -143,6 +166,13 @@ def summarize(name, res):
             print(f"      {k}: max |dqacc| {max(r['g_groups'][k][0] for r in gg):.2e}  relative to the group's largest {max(r['g_groups'][k][0] / max(1.0, r['g_groups'][k][1]) for r in gg):.1e}")
             print(f"      {k} per env, relative, sorted:", " ".join(f"{x:.0e}" for x in sorted(r['g_groups'][k][0] / max(1.0, r['g_groups'][k][1]) for r in gg)))
         print("      objective gap per env, sorted:", " ".join(f"{x:.0e}" for x in sorted(r['g_cost_gap'] for r in gg)))
+        if gg[0].get("g_groups") and "objects" in gg[0]["g_groups"]:
+            worst = sorted(gg, key=lambda r: -max(r["g_groups"][k][0] / max(1.0, r["g_groups"][k][1]) for k in r["g_groups"]))[:16]
+            print("      worst envs (env; per group: error / fp32-input floor of the fp64 solve, relative to the group's largest; objective gap; fscale; RSIM_POLISH = exit|-log10 grad|passes|fp64|000):")
+            for r in worst:
+                fl = r.get("g_floor", {})
+                print("        ", r["env"], " ".join(f"{k} {r['g_groups'][k][0] / max(1.0, r['g_groups'][k][1]):.0e}/{fl.get(k, float('nan')) / max(1.0, r['g_groups'][k][1]):.0e}" for k in r["g_groups"]),
+                      f"gap {r['g_cost_gap']:.0e} fmax {r['g_fscale']:.0f} niter {r.get('niter', -1):08d} ncon {r['ncon'][0]} nefc {r['nefc'][0]}")
         print("      rel dforce per env, sorted:", " ".join(f"{x:.0e}" for x in sorted(r['g_force'] / max(1.0, r['g_fscale']) for r in gg)))
     for r in res:
         if not r["same"]:
@@ -323,8 +353,15 @@ def test_pickplace_8192_with_dynamics_randomisation_reached_states():
     assert len(ov) <= 3 and all(need[e, 0] > 64 or need[e, 1] > 256 for e in ov), (ov, need[ov])
     res = compare_reached_states(flat, b, spread(B, int(os.environ.get("RSIM_PARITY_SAMPLE", "32"))), ignore_pair=lambda g1, g2: g1 in grip and g2 in grip, dof_groups=groups)
     ok = summarize("PickPlace step 50", res)
-    nit = b.get("niter")        # of the forward evaluation above; + 1000 marks a solve whose polish factorised H in fp64 (rsim_step.hip solve_newton)
-    print(f"   envs whose solve took the fp64 factor: {int((nit >= 1000).sum())} of {B}; Newton iterations median {int(np.median(nit % 1000))} max {int((nit % 1000).max())}")
+    if os.environ.get("RSIM_PARITY_DUMP"):
+        worst = sorted([r for r in res if "dump" in r], key=lambda r: -max(r["g_groups"][k][0] / max(1.0, r["g_groups"][k][1]) for k in r["g_groups"]))[:12]
+        np.savez_compressed(os.environ["RSIM_PARITY_DUMP"], **{f"e{r['env']}_{k}": a for r in worst for k, a in r["dump"].items()}, envs=np.array([r["env"] for r in worst]),
+                            polish=np.array([r["niter"] for r in worst]))
+    nit, iters = b.get("polish"), b.get("niter")        # of the forward evaluation above: RSIM_POLISH = the polish's diagnostics (include/rsim.h)
+    ex = nit // 10000000
+    print(f"   Newton iterations median {int(np.median(iters))} max {int(iters.max())}; "
+          f"polish exits (0 not run, 1 gradient below tolerance, 2 improvement below tolerance, 3 pass budget, 5 no descent direction, 6 a step raised the objective): {np.bincount(ex, minlength=8).tolist()}; "
+          f"passes histogram {np.bincount((nit // 10000) % 10, minlength=8).tolist()}")
     assert np.isfinite(b.get("qpos")).all() and np.isfinite(b.get("obs")).all()
     assert len(res) >= 32 and len(ok) >= len(res) - 4
     good = [r for r in ok if r["geom_ok"]]
@@ -336,16 +373,25 @@ def test_pickplace_8192_with_dynamics_randomisation_reached_states():
     # four free objects are compared on identical rows.  Bounds are relative to the env's largest force / each group's largest acceleration.
     fed = [r for r in ok if "g_qacc" in r]
     assert len(fed) == len(ok)
+    # The kernel says which solves its polish did not finish (RSIM_POLISH exit 3 / 5 / 6: the pass budget ran out, the direction was no descent direction, or a searched step raised the objective --
+    # MuJoCo's own solver reports non-convergence through mjData warnings): they must be few, and every OTHER sampled env is held to the per-env bounds
+    unfinished = np.isin(nit // 10000000, (3, 5, 6))     # (3: the pass budget ran out)
+    print(f"   solves the polish reports unfinished: {int(unfinished.sum())} of {B} ({100.0 * unfinished.mean():.2f} %); in the sample: {[r['env'] for r in fed if unfinished[r['env']]]}")
+    assert unfinished.mean() < 0.01
+    fed = [r for r in fed if not unfinished[r["env"]]]
+    short = [r["env"] for r in fed if r["oracle_grad"] > 1e-3 and r["g_cost_gap"] < 1e-7]
+    print(f"   sampled envs in which the ORACLE stopped short (its own gradient > 1e-3 at its answer, the kernel's objective not higher): {short}")
+    assert len(short) <= 0.03 * len(fed) + 1
+    fed = [r for r in fed if r["env"] not in short]
     gaps = np.array([r["g_cost_gap"] for r in fed])
     assert gaps.max() < PP_COST_GAP and float(np.percentile(gaps, 90)) < PP_COST_GAP_P90 and float(np.median(gaps)) < 1e-7, np.percentile(gaps, [50, 90, 100])
     med = lambda xs: float(np.median(list(xs)))   # noqa: E731
     assert med(r["g_force"] / max(1.0, r["g_fscale"]) for r in fed) < PP_FORCE_MEDIAN
     assert max(r["g_groups"]["arm"][0] / max(1.0, r["g_groups"]["arm"][1]) for r in fed) < PP_ARM_TOL
-    p90 = lambda xs: float(np.percentile(list(xs), 90))   # noqa: E731
-    assert p90(r["g_force"] / max(1.0, r["g_fscale"]) for r in fed) < PP_FORCE_P90
+    assert max(r["g_force"] / max(1.0, r["g_fscale"]) for r in fed) < PP_FORCE_MAX
     for k, tol in PP_GROUP_MEDIAN.items():
         assert med(r["g_groups"][k][0] / max(1.0, r["g_groups"][k][1]) for r in fed) < tol, k
-        assert p90(r["g_groups"][k][0] / max(1.0, r["g_groups"][k][1]) for r in fed) < PP_GROUP_P90[k], k
+        assert max(r["g_groups"][k][0] / max(1.0, r["g_groups"][k][1]) for r in fed) < PP_GROUP_MAX[k], k          # every sampled env, not a percentile
     # the same rollout without the solimp draw (the one dynamics parameter whose per-step re-draw makes the restated model itself run away, fp64 oracle
     # included: DESIGN.md section 8): no env may hit the bad-state guard
     env2 = pick_place.PickPlaceBatch(flat, cfg, ids[:2048], seed0=0, horizon=500, bank_episodes=2, per_env_params=True)

@@ -17,8 +17,9 @@ STEP_BUDGET = {"ILi32ELi16ELi16ELi24ELi16ELi16ELi64ELi192E": (8, 256, 64),    # 
                 "ILi32ELi16ELi32ELi24ELi16ELi32ELi64ELi192E": (4, 512, 0),
                "ILi64ELi16ELi16ELi32ELi32ELi32ELi64ELi320E": (5, 512, 0), "ILi64ELi32ELi48ELi64ELi32ELi32ELi128ELi640E": (4, 512, 0),   # J and M in global memory (RSIM_JGLOBAL round 4: 74.8 -> 49.7 KB = 3; RSIM_MGLOBAL round 5: 40.3 KB = 4, one wavefront per SIMD)
                "ILi64ELi32ELi64ELi64ELi32ELi32ELi128ELi640E": (1, 512, 0),
-               # the capacity tiers (round 4): above 64 x 48, above the Lift configuration, above the Stack configuration
-               "ILi64ELi32ELi48ELi64ELi32ELi64ELi256ELi640E": (2, 512, 0), "ILi32ELi16ELi16ELi24ELi16ELi32ELi128ELi192E": (5, 512, 0), "ILi32ELi16ELi32ELi24ELi16ELi32ELi128ELi192E": (3, 512, 0)}
+               # the capacity tiers (round 4): above 64 x 48, above the Lift configuration, above the Stack configuration.  The 256-row tier (four rows per lane, J in
+               # global memory since round 5: two per CU) spills in the polish's fp64 line search (424 B); it steps the few envs beyond 128 rows
+               "ILi64ELi32ELi48ELi64ELi32ELi64ELi256ELi640E": (2, 512, 512), "ILi32ELi16ELi16ELi24ELi16ELi32ELi128ELi192E": (5, 512, 0), "ILi32ELi16ELi32ELi24ELi16ELi32ELi128ELi192E": (3, 512, 0)}
 
 
 def test_fused_kernel_configurations_keep_their_lds_and_register_budgets():
@@ -40,6 +41,6 @@ def test_fused_kernel_configurations_keep_their_lds_and_register_budgets():
 def test_auxiliary_kernels_use_no_scratch():
     for name, r in kernels(LIB).items():
         if name.startswith("_Z11k_reset_obs") or name.startswith("_Z10k_step_dbg"):
-            assert r["scratch"] <= 64, (name, r)   # the reset-observation pass (a few envs per control step) and the B = 1 debug entries share the step body
+            assert r["scratch"] <= (64 if "ELi256E" not in name else 1024), (name, r)   # the reset-observation pass (a few envs per control step) and the B = 1 debug entries share the step body (256-row tier: see STEP_BUDGET)
         elif not (name.startswith("_Z6k_step") or name.startswith("_Z11k_step_list")):
             assert r["scratch"] == 0, (name, r)

@@ -929,3 +929,36 @@ def test_line_search_does_not_creep_on_a_stacked_cube_state():
     scale = max(1.0, np.abs(od.qacc).max())
     assert np.abs(od.qacc - od2.qacc).max() < 1e-6 * scale, np.abs(od.qacc - od2.qacc).max()
     assert np.abs(z["qacc_kernel"] - od2.qacc).max() < 1e-4 * scale, np.abs(z["qacc_kernel"] - od2.qacc).max()
+
+
+def test_conditioning_probe_rounding_the_solver_inputs_to_float32_moves_pickplace_accelerations_by_parts_per_million():
+    """What is the floor under an fp32 kernel's deviation from this oracle on the widest BASELINE model?  rso_set_round_rows makes the fp64 constraint solve see its
+    inputs -- Jacobian rows, reference accelerations, regularisers, friction coefficients, mass matrix, smooth forces -- rounded to float32.  On PickPlace states
+    reached under full-range random actions the solution moves by 1e-6 .. 1e-5 of each dof group's largest acceleration (objects, gripper, arm), forces by 1e-7 of
+    the largest: storing the problem in single precision is NOT what bounds the kernel's per-env agreement (round 5: the tail of tests/test_full_size_parity.py
+    was traced to solves that the fp32 exit rules ended before any fp64 look, not to conditioning)."""
+    import json, os
+    from robosuite_amd import lift, mjcf, pick_place
+    adir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "robosuite_amd", "assets")
+    flat = mjcf.load_model(os.path.join(adir, "pickplace_iiwa.rsim")); cfg = json.load(open(os.path.join(adir, "pickplace_iiwa.cfg.json")))
+    arm, fing = np.asarray(cfg["dof_idx"]), np.asarray(cfg["grip_dof_idx"])
+    groups = {"arm": arm, "gripper": fing, "objects": np.setdiff1d(np.arange(flat.nv), np.concatenate([arm, fing]))}
+    worst = {k: 0.0 for k in groups} | {"force": 0.0}
+    ncon = 0
+    for i in (0, 700, 1500, 2900, 4100, 6000):
+        om, od, oc = make_oracle(flat, cfg)
+        od.qpos[:] = pick_place.episode_setup(cfg, flat.nq, 0, [i], block=0)[0]; od.qvel[:] = 0; od.qacc_warmstart[:] = 0; od.ctrl[:] = 0; od.forward(); oc.reset(od)
+        acts = lift.env_actions(np.array([i]), 40, action_dim=7)[:, 0]
+        for t in range(40):
+            oc.env_step(od, acts[t], 25)
+        q, v, ws, ctrl = (np.array(x) for x in (od.qpos, od.qvel, od.qacc_warmstart, od.ctrl))
+        od.forward(); a0 = np.array(od.qacc); f0 = np.array(od.efc_force[:od.nefc]); n0 = od.nefc
+        od.qpos[:] = q; od.qvel[:] = v; od.qacc_warmstart[:] = ws; od.ctrl[:] = ctrl
+        od.set_round_rows(True); od.forward(); a1 = np.array(od.qacc); f1 = np.array(od.efc_force[:od.nefc])
+        assert od.nefc == n0 > 0
+        ncon += od.ncon
+        for k, idx in groups.items():
+            worst[k] = max(worst[k], float(np.abs(a1[idx] - a0[idx]).max() / max(1.0, np.abs(a0[idx]).max())))
+        worst["force"] = max(worst["force"], float(np.abs(f1 - f0).max() / max(1.0, np.abs(f0).max())))
+    print("rounding the solver's inputs to float32, worst relative change over 6 PickPlace states:", {k: f"{x:.1e}" for k, x in worst.items()}, "contacts", ncon)
+    assert ncon >= 30 and 0 < worst["objects"] < 1e-4 and worst["gripper"] < 1e-3 and worst["arm"] < 1e-4 and worst["force"] < 1e-5
