@@ -213,7 +213,15 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="lift only: skip the short secondary regions of BASELINE configs[2..4] (config.other_configs)")
     ap.add_argument("--other-steps", type=int, default=10, help="timed lockstep control steps of each secondary configuration")
     ap.add_argument("--other-preroll", type=int, default=50, help="untimed launches before each secondary region (episode steps staggered as in the headline region)")
+    ap.add_argument("--secondary-only", choices=sorted(CONFIGS), default=None, help="internal: run one secondary region and print its record (the default run starts one child per configuration)")
     args = ap.parse_args()
+
+    if args.secondary_only:
+        if not torch.cuda.is_available():
+            raise SystemExit(3)
+        torch.cuda.set_device(0)
+        print(json.dumps(secondary_region(args.secondary_only, 0, 0, 1, torch.device("cuda", 0), args.other_steps, args.other_preroll)), flush=True)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- one process per GPU under torch.distributed.run (RCCL rendezvous on 127.0.0.1),
@@ -364,10 +372,23 @@ def main():
         env.bank_quiesce()
         other = {}
         for oc in ("stack", "peg", "pickplace"):
-            try:
-                other[oc] = secondary_region(oc, rank, local_rank, world, dev, args.other_steps, args.other_preroll)
-            except Exception as e:   # a failing secondary region is reported, it does not take the headline line with it
-                other[oc] = {"error": f"{type(e).__name__}: {e}"}
+            if world == 1:
+                # one child process per configuration: a fault of the GPU queue there (which aborts the process that owns it) is reported in the record
+                # instead of taking the headline line with it
+                import subprocess
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--secondary-only", oc, "--other-steps", str(args.other_steps), "--other-preroll", str(args.other_preroll)],
+                                       capture_output=True, text=True, timeout=900)
+                    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    other[oc] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": f"exit code {r.returncode}: {r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else ''}"}
+                except Exception as e:
+                    other[oc] = {"error": f"{type(e).__name__}: {e}"}
+            else:
+                # under torch.distributed.run every rank takes part (weak scaling like the headline), in process
+                try:
+                    other[oc] = secondary_region(oc, rank, local_rank, world, dev, args.other_steps, args.other_preroll)
+                except Exception as e:   # a failing secondary region is reported, it does not take the headline line with it
+                    other[oc] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         abytes = algorithmic_bytes_per_env_step(env, flat, dr) * B   # one control step = one launch of all B envs

@@ -1026,6 +1026,7 @@ struct Sim {
   static constexpr int JS = SM::JS_, CS6 = SM::CS6_, FS = SM::FS_;
   static constexpr int SM_NB = SM::NB_;
   static constexpr bool FAST = SM::NV_ == 16;   // one-tile dense algebra: 16 x 16 MFMA products + register Cholesky
+  static constexpr bool POLISH = SM::NV_ >= 48;  // the fp64 polish behind the wide solver is compiled for the configurations that run it (64 x 48 / 64 x 64 and their tiers: rsim_api.cpp sets DModel.newton_refine for those only)
   static constexpr bool TREE = SM::TREE_TILE_;  // tree products (CRBA composite inertias, RNE sums) as incidence-matrix MFMAs
   static constexpr int NPT = SM::NPT_;          // rows of 64 candidate pairs
   static constexpr int NROOT = SM::NROOT_;
@@ -3800,7 +3801,7 @@ struct Sim {
         if (!__ballot(moved)) break;
       }
     }
-    if constexpr (!FAST) {
+    if constexpr (!FAST && POLISH) {
       // ---- polish of the solution with everything that DECIDES evaluated in fp64 (wide configurations).  What fp32 cannot see on these models: cost differences below
       // 1e-7 of a cost of 1e3.  The iteration above therefore ends where a step gains nothing it can measure -- characteristically ON a kink of the piecewise objective:
       // a cone block (the condim-4 contacts of the PickPlace objects) or a row about to change its state.  Round 5 traced the per-env tail of the full-size test to
