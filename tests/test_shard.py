@@ -78,6 +78,16 @@ def test_bench_launches_its_own_ranks(config):
     assert "bench.py rank 0/2: no GPU visible" in out.stderr and "bench.py rank 1/2: no GPU visible" in out.stderr, out.stderr[-3000:]
 
 
+def test_bench_secondary_region_child_fails_loudly_without_a_gpu():
+    """The default `python bench.py` times BASELINE configs[2..4] in one child process each (`--secondary-only <config>`); a child that dies -- a fault of the GPU queue
+    aborts the process that owns it -- must leave a non-zero exit code and no JSON record, which the parent reports as `{"error": ...}` in config.other_configs."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the child runs the region on a GPU box")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--secondary-only", "stack", "--other-steps", "1", "--other-preroll", "0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 3 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_c_abi_comm_rejects_bad_arguments_before_touching_rccl():
     """rsim_comm_create / rsim_allreduce_stats (include/rsim.h) fail loudly on bad arguments -- checked before RCCL or a device is touched, so this runs without a GPU."""
     import ctypes as C
