@@ -110,6 +110,9 @@ typedef unsigned long long u64;
 #else
 #define RSIM_MG_ENABLED 0
 #endif
+#ifndef RSIM_NOHULLPOOL
+#define RSIM_NOHULLPOOL 0   /* 1: no LDS-resident hull vertices in the middle configurations either (all hulls scanned from global memory, as the 32 x 16 build does) */
+#endif
 #ifndef RSIM_LS_MAXSLOT
 #define RSIM_LS_MAXSLOT 4   // rows per lane up to which the polish carries the fp64 line search (4: every configuration)
 #endif
@@ -321,7 +324,7 @@ struct Smem {
   // configurations trade pool for a third environment per CU: 64 x 16 keeps 192 vertices (53.7 KB; 57.6 KB = two per CU with the full pool),
   // 32 x 32 keeps 64 and factors M + hD again at the Euler step instead of keeping it (53.6 KB instead of 63.2 KB).  The host assigns pool
   // slots for the largest pool and load_constants() drops what does not fit.
-  static constexpr int HULLPOOL_ = (NV > 32 || (NB == 32 && NV == 16)) ? 0 : (NV == 32 ? 64 : 192);   // 32 x 16: 20 KB = eight environments per CU, hulls are scanned from global memory (L1-resident: every env of the CU scans the same vertices)
+  static constexpr int HULLPOOL_ = (NV > 32 || (NB == 32 && NV == 16) || RSIM_NOHULLPOOL) ? 0 : (NV == 32 ? 64 : 192);   // 32 x 16: 20 KB = eight environments per CU, hulls are scanned from global memory (L1-resident: every env of the CU scans the same vertices)
   static constexpr int NB_ = NB;
   float qpos[NV + 8], qvel[NV], qacc[NV], qacc_ws[NV], ctrl[NV];
   float xpos[NB * 3], xquat[NB * 4];
@@ -344,7 +347,7 @@ struct Smem {
   } u;
   // RSIM_MGLOBAL (on top of RSIM_JGLOBAL): the mass matrix behind J in the same per-env global buffer: 49.7 -> 40.3 KB = FOUR environments per CU, one wavefront
   // per SIMD.  PickPlace @8192 + DR: 112.4 -> 89.5 ms per control step (+25.6 %, five round-robin reps, profiles/r05_a_ab_variants_pickplace.txt)
-  static constexpr bool MG_ = RSIM_MG_ENABLED && RSIM_JG_ENABLED && NV == 48 && NEFC == 128;
+  static constexpr bool MG_ = RSIM_MG_ENABLED && RSIM_JG_ENABLED && ((NV == 48 && NEFC == 128) || (NV == 32 && NEFC == 64));
   float M[MG_ ? 4 : NV * NVP];
   union { float L[NV * NVP]; float H[NV * NVP]; };  // L (factor of M) is dead once qacc_smooth exists; H is the solver / Euler work matrix
   float invdiag[NV];
@@ -359,7 +362,7 @@ struct Smem {
   // RSIM_JGLOBAL (64 x 48 build with 128 rows only): the constraint Jacobian lives in a per-env buffer in GLOBAL memory (DBatch.jg; 25 KB per env, L2-resident
   // for the resident envs of an XCD) instead of LDS: 74.8 -> 49.7 KB = three environments per CU instead of two
   // (RSIM_JG256: the 256-row tier of the same shape as well -- 116 -> 66 KB, two jumbo envs per CU instead of one)
-  static constexpr bool JG_ = RSIM_JG_ENABLED && NV == 48 && (NEFC == 128 || (RSIM_JG256_ENABLED && NEFC == 256));
+  static constexpr bool JG_ = RSIM_JG_ENABLED && ((NV == 48 && (NEFC == 128 || (RSIM_JG256_ENABLED && NEFC == 256))) || (NV == 32 && NEFC == 64));
   float J[JG_ ? 4 : NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
   float e_R[NEFC], e_aref[NEFC], e_force[NEFC];   // e_force doubles as the row's velocity gain B between make_constraint's two halves
   int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
