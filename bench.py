@@ -141,14 +141,25 @@ def cpu_baseline(config, flat, cfg, budget_s=12.0):
                       f"{'' if config != 'pickplace' else ', without the per-step dynamics randomisation'}) in {dt:.1f} s"}
 
 
-def pmc_evidence(name, key, lib_sha):
-    """A PMC-derived figure from profiles/<name>, valid only for the library build it was measured on (the file carries that build's sha).  Evidence of
-    another build is reported as the string "stale:<its sha>", a missing file as "absent" -- never as a silent null (round-4 review)."""
+def pmc_evidence(name, key, lib_sha, config=None):
+    """A PMC-derived figure from profiles/<name>, valid only for the kernel it was measured on: the file carries the sha of the library build and (since round 5,
+    session 13) of the configuration's own code object.  The library holds one code object per kernel configuration; a later build that changed another
+    configuration runs the bit-identical kernel for this one, and its evidence stands.  Evidence of another kernel is reported as the string "stale:<its library
+    sha>", a missing file as "absent" -- never as a silent null (round-4 review)."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return "absent"
-    return d.get(key) if d.get("lib_sha16") == lib_sha else f"stale:{d.get('lib_sha16')}"
+    if d.get("lib_sha16") == lib_sha:
+        return d.get(key)
+    if config is not None and d.get("code_sha16"):
+        try:
+            from tools.kernel_resources import config_code_sha16
+            if config_code_sha16(backend.LIB_PATH, config) == d["code_sha16"]:
+                return d.get(key)
+        except Exception:
+            pass
+    return f"stale:{d.get('lib_sha16')}"
 
 
 def secondary_region(config, rank, local_rank, world, dev, K, P):
@@ -185,7 +196,7 @@ def secondary_region(config, rank, local_rank, world, dev, K, P):
     ovf = shard.max_over_ranks(float((env.batch.tensor("overflow") > 0).sum().item()), dev)
     cn = env.batch.tensor("cap_need").view(B, 2)
     lib_sha = hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16]
-    valu = pmc_evidence(f"valu_count_{config}.json", "valu_per_env_substep", lib_sha)
+    valu = pmc_evidence(f"valu_count_{config}.json", "valu_per_env_substep", lib_sha, config)
     issue = valu if isinstance(valu, str) or valu is None else valu * B * world * N_SUB * K / dt / (world * VALU_ISSUE_PEAK)
     env.bank_quiesce(); env._bank_stop()
     out = {"workload": f"{label} (BASELINE {which})", "envs_per_gpu": B, "steps": K, "preroll": P, "value": B * world * K / dt, "unit": "env-steps/s",
@@ -397,8 +408,8 @@ def main():
         lib_sha = hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16]
         sfx = "" if args.config == "lift" else "_" + args.config
 
-        traffic = pmc_evidence(f"hbm_traffic{sfx}.json", "bytes_per_launch", lib_sha)      # tools/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE passes), one launch of all B envs
-        valu = pmc_evidence(f"valu_count{sfx}.json", "valu_per_env_substep", lib_sha)      # tools/pmc_valu.py (SQ_INSTS_VALU pass on this workload)
+        traffic = pmc_evidence(f"hbm_traffic{sfx}.json", "bytes_per_launch", lib_sha, args.config)      # tools/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE passes), one launch of all B envs
+        valu = pmc_evidence(f"valu_count{sfx}.json", "valu_per_env_substep", lib_sha, args.config)      # tools/pmc_valu.py (SQ_INSTS_VALU pass on this workload)
         issue = valu if isinstance(valu, str) else None       # "stale:<sha>" / "absent": said out loud, never a silent null
         if valu and not isinstance(valu, str):
             rate = valu * B * N_SUB * K / dt   # wave-instructions per second of this GPU over the timed region

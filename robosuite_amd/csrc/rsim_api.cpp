@@ -892,9 +892,13 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   {
     // builds that keep the constraint Jacobian in global memory (RSIM_JGLOBAL: limits bit 2) get their per-env buffer, [B][NEFC * (NV + 1)] floats
     // limits bit 3 (RSIM_MGLOBAL): the mass matrix behind J in the same buffer, NV * (NV + 1) floats more.  One stride for the native and the wide configuration.
-    size_t jgf = 0;
-    if (b->lim[9] & 4) jgf = (size_t)b->lim[6] * (size_t)(b->lim[2] + 1) + ((b->lim[9] & 8) ? (size_t)b->lim[2] * (size_t)(b->lim[2] + 1) : 0);
-    if (b->cfg_w >= 0 && (b->lim_w[9] & 4)) jgf = std::max(jgf, (size_t)b->lim_w[6] * (size_t)(b->lim_w[2] + 1) + ((b->lim_w[9] & 8) ? (size_t)b->lim_w[2] * (size_t)(b->lim_w[2] + 1) : 0));
+    // limits bit 4 (RSIM_CGLOBAL): the contact block (frames and material parameters, 22 floats per contact) behind M.
+    auto jg_need = [](const int* lim) -> size_t {
+      if (!(lim[9] & 4)) return 0;
+      return (size_t)lim[6] * (size_t)(lim[2] + 1) + ((lim[9] & 8) ? (size_t)lim[2] * (size_t)(lim[2] + 1) : 0) + ((lim[9] & 16) ? (size_t)lim[5] * 22 : 0);
+    };
+    size_t jgf = jg_need(b->lim);
+    if (b->cfg_w >= 0) jgf = std::max(jgf, jg_need(b->lim_w));
     b->db.jg_stride = (long long)jgf;
     if (jgf && dalloc(&b->db.jg, (size_t)B * jgf)) return 1;
   }

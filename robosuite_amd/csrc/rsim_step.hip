@@ -110,6 +110,11 @@ typedef unsigned long long u64;
 #else
 #define RSIM_MG_ENABLED 0
 #endif
+#ifdef RSIM_CGLOBAL
+#define RSIM_CG_ENABLED 1
+#else
+#define RSIM_CG_ENABLED 0
+#endif
 #ifndef RSIM_NOHULLPOOL
 #define RSIM_NOHULLPOOL 0   /* 1: no LDS-resident hull vertices in the middle configurations either (all hulls scanned from global memory, as the 32 x 16 build does) */
 #endif
@@ -347,7 +352,7 @@ struct Smem {
   } u;
   // RSIM_MGLOBAL (on top of RSIM_JGLOBAL): the mass matrix behind J in the same per-env global buffer: 49.7 -> 40.3 KB = FOUR environments per CU, one wavefront
   // per SIMD.  PickPlace @8192 + DR: 112.4 -> 89.5 ms per control step (+25.6 %, five round-robin reps, profiles/r05_a_ab_variants_pickplace.txt)
-  static constexpr bool MG_ = RSIM_MG_ENABLED && RSIM_JG_ENABLED && ((NV == 48 && NEFC == 128) || (NV == 32 && NEFC == 64));
+  static constexpr bool MG_ = RSIM_MG_ENABLED && RSIM_JG_ENABLED && ((NV == 48 && NEFC == 128) || (NV == 32 && (NEFC == 64 || NEFC == 128)));
   float M[MG_ ? 4 : NV * NVP];
   union { float L[NV * NVP]; float H[NV * NVP]; };  // L (factor of M) is dead once qacc_smooth exists; H is the solver / Euler work matrix
   float invdiag[NV];
@@ -356,13 +361,17 @@ struct Smem {
   float gpos[NG * 3], gmat[NG * 9], gcen[NG * 3];
   float spos[NS * 3], smat[NS * 9];
   // contacts
-  float cpos[NCON * 3], cframe[NCON * 9], cdist[NCON], cfri[NCON * 5], csolref[NCON * 2], csolimp[NCON * 5], cmu[NCON], cmargin[NCON];
+  // RSIM_CGLOBAL (32 x 32 build, on top of RSIM_JGLOBAL / RSIM_MGLOBAL): contact frames and contact material parameters -- written once per contact by the narrow phase, read
+  // by the row builders -- in the same per-env global buffer behind J and M: 22.6 -> 19.8 KB = EIGHT environments per CU, two wavefronts on every SIMD (layout: CG_* below)
+  static constexpr bool CG_ = RSIM_CG_ENABLED && RSIM_JG_ENABLED && RSIM_MG_ENABLED && NV == 32 && NEFC == 64;
+  static constexpr int CG_FRAME_ = 0, CG_FRI_ = NCON * 9, CG_SOLIMP_ = NCON * 14, CG_SOLREF_ = NCON * 19, CG_MARGIN_ = NCON * 21, CG_WORDS_ = NCON * 22;
+  float cpos[NCON * 3], cframe[CG_ ? 1 : NCON * 9], cdist[NCON], cfri[CG_ ? 1 : NCON * 5], csolref[CG_ ? 1 : NCON * 2], csolimp[CG_ ? 1 : NCON * 5], cmu[NCON], cmargin[CG_ ? 1 : NCON];
   int cg1[NCON], cg2[NCON], cdim[NCON], cefc[NCON];
   // constraint rows
   // RSIM_JGLOBAL (64 x 48 build with 128 rows only): the constraint Jacobian lives in a per-env buffer in GLOBAL memory (DBatch.jg; 25 KB per env, L2-resident
   // for the resident envs of an XCD) instead of LDS: 74.8 -> 49.7 KB = three environments per CU instead of two
   // (RSIM_JG256: the 256-row tier of the same shape as well -- 116 -> 66 KB, two jumbo envs per CU instead of one)
-  static constexpr bool JG_ = RSIM_JG_ENABLED && ((NV == 48 && (NEFC == 128 || (RSIM_JG256_ENABLED && NEFC == 256))) || (NV == 32 && NEFC == 64));
+  static constexpr bool JG_ = RSIM_JG_ENABLED && ((NV == 48 && (NEFC == 128 || (RSIM_JG256_ENABLED && NEFC == 256))) || (NV == 32 && (NEFC == 64 || NEFC == 128)));
   float J[JG_ ? 4 : NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
   float e_R[NEFC], e_aref[NEFC], e_force[NEFC];   // e_force doubles as the row's velocity gain B between make_constraint's two halves
   int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
@@ -1007,6 +1016,20 @@ struct Sim {
   gwf Mg = nullptr;                                         // MG builds: this env's mass matrix [NV][NVP] in global memory (behind J in DBatch.jg)
   __device__ __forceinline__ float Mrd(int i) const { if constexpr (MG) return Mg[i]; else return sm.M[i]; }
   __device__ __forceinline__ void Mwr(int i, float v) const { if constexpr (MG) Mg[i] = v; else sm.M[i] = v; }
+  static constexpr bool CG = SM::CG_;
+  // CG builds: this env's contact frames / material parameters in global memory, behind M in DBatch.jg (no member of its own: the layout of Sim, and with it the
+  // register allocation of the builds that do not use it, stays what it was)
+  __device__ __forceinline__ gwf Cgp() const { return Mg + SM::NV_ * SM::NVP; }
+  __device__ __forceinline__ float cframe_rd(int i) const { if constexpr (CG) return Cgp()[SM::CG_FRAME_ + i]; else return sm.cframe[i]; }
+  __device__ __forceinline__ float cfri_rd(int i) const { if constexpr (CG) return Cgp()[SM::CG_FRI_ + i]; else return sm.cfri[i]; }
+  __device__ __forceinline__ float csolimp_rd(int i) const { if constexpr (CG) return Cgp()[SM::CG_SOLIMP_ + i]; else return sm.csolimp[i]; }
+  __device__ __forceinline__ float csolref_rd(int i) const { if constexpr (CG) return Cgp()[SM::CG_SOLREF_ + i]; else return sm.csolref[i]; }
+  __device__ __forceinline__ float cmargin_rd(int i) const { if constexpr (CG) return Cgp()[SM::CG_MARGIN_ + i]; else return sm.cmargin[i]; }
+  __device__ __forceinline__ V3 cframe_ax(int i) const { return v3(cframe_rd(i), cframe_rd(i + 1), cframe_rd(i + 2)); }
+  // the narrow phase's stores of the contact block have left the wavefront before another lane reads them (LDS build: the SYNC() sites between the phases do)
+  __device__ __forceinline__ void csync() const {
+    if constexpr (CG) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+  }
   __device__ __forceinline__ float Jrd(int i) const { if constexpr (JG) return Jg[i]; else return sm.J[i]; }
   __device__ __forceinline__ void Jwr(int i, float v) const { if constexpr (JG) Jg[i] = v; else sm.J[i] = v; }
   // J written by some lanes, read by others of the same wavefront: LDS needs the wavefront fence of SYNC(); global memory needs the stores to have left the
@@ -1747,7 +1770,7 @@ struct Sim {
         if (b1 != b && b2 != b) continue;
         V3 fw = v3(0, 0, 0), tw = v3(0, 0, 0);
         for (int k = 0; k < dim; k++) {
-          const V3 ax = ld3(sm.cframe + 9 * c + 3 * (k < 3 ? k : k - 3));
+          const V3 ax = CG ? cframe_ax(9 * c + 3 * (k < 3 ? k : k - 3)) : ld3(sm.cframe + 9 * c + 3 * (k < 3 ? k : k - 3));
           if (k < 3) fw = fw + ax * sm.e_force[ea + k]; else tw = tw + ax * sm.e_force[ea + k];
         }
         const float sgn = (b2 == b ? 1.f : 0.f) - (b1 == b ? 1.f : 0.f);
@@ -1846,13 +1869,25 @@ struct Sim {
       const int c = base + rank;
       sm.cdist[c] = dist;
       st3(sm.cpos + 3 * c, pos);
-      make_frame(nrm, sm.cframe + 9 * c);
+      if constexpr (CG) { float fr_[9]; make_frame(nrm, fr_);
+#pragma unroll
+        for (int k = 0; k < 9; k++) Cgp()[SM::CG_FRAME_ + 9 * c + k] = fr_[k]; }
+      else make_frame(nrm, sm.cframe + 9 * c);
       sm.cg1[c] = g1 | (cp.b1 << 8); sm.cg2[c] = g2 | (cp.b2 << 8); sm.cdim[c] = cp.dim;
-      sm.cmargin[c] = cp.margin_gap;
-      sm.csolref[2 * c] = cp.solref[0]; sm.csolref[2 * c + 1] = cp.solref[1];
-      for (int k = 0; k < 5; k++) sm.csolimp[5 * c + k] = cp.solimp[k];
-      float* f = sm.cfri + 5 * c;
-      f[0] = f[1] = cp.fr[0]; f[2] = cp.fr[1]; f[3] = f[4] = cp.fr[2];
+      if constexpr (CG) {
+        Cgp()[SM::CG_MARGIN_ + c] = cp.margin_gap;
+        Cgp()[SM::CG_SOLREF_ + 2 * c] = cp.solref[0]; Cgp()[SM::CG_SOLREF_ + 2 * c + 1] = cp.solref[1];
+#pragma unroll
+        for (int k = 0; k < 5; k++) Cgp()[SM::CG_SOLIMP_ + 5 * c + k] = cp.solimp[k];
+        gwf f = Cgp() + SM::CG_FRI_ + 5 * c;
+        f[0] = cp.fr[0]; f[1] = cp.fr[0]; f[2] = cp.fr[1]; f[3] = cp.fr[2]; f[4] = cp.fr[2];
+      } else {
+        sm.cmargin[c] = cp.margin_gap;
+        sm.csolref[2 * c] = cp.solref[0]; sm.csolref[2 * c + 1] = cp.solref[1];
+        for (int k = 0; k < 5; k++) sm.csolimp[5 * c + k] = cp.solimp[k];
+        float* f = sm.cfri + 5 * c;
+        f[0] = f[1] = cp.fr[0]; f[2] = cp.fr[1]; f[3] = f[4] = cp.fr[2];
+      }
     }
     SYNC();
     if (lane == 0) sm.ncon = base + total;
@@ -2536,12 +2571,13 @@ struct Sim {
     SUBMARK_U(RP_X0);
     // (3) contacts: lane c owns contact c; exclusive scan of the active dimensions gives the first row of each block
     {
+      csync();   // (CG builds) first reader of the contact block after the narrow phase
       const int ncon = uni(sm.ncon);
       const bool has = lane < ncon;
       const int dim = has ? sm.cdim[lane] : 0;
       // fp32: hulls that share a face plane (UR5e base / shoulder) come out of MPR at -5e-9 m, which is rounding, not penetration; a contact
       // becomes active 0.1 um inside the margin (MuJoCo: dist < margin), so that such pairs do not add constraint rows the fp64 path lacks
-      const bool active = has && sm.cdist[lane] < sm.cmargin[lane] - 1.0e-7f;
+      const bool active = has && sm.cdist[lane] < (CG ? cmargin_rd(lane) : sm.cmargin[lane]) - 1.0e-7f;
       int need = active ? dim : 0, incl = need;
 #pragma unroll
       for (int o = 1; o < SM::NCON_; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
@@ -2556,9 +2592,16 @@ struct Sim {
         const int b1 = sm.cg1[lane] >> 8, b2 = sm.cg2[lane] >> 8;
         const float tran = cmf(MK_biw)->biw[2 * b1] + cmf(MK_biw)->biw[2 * b2], rot = cmf(MK_biw)->biw[2 * b1 + 1] + cmf(MK_biw)->biw[2 * b2 + 1];
         float R0, Bd, Kt;
-        row_scalars(sm.cdist[lane], sm.cmargin[lane], sm.csolref + 2 * lane, sm.csolimp + 5 * lane, tran, R0, Bd, Kt);
+        float sr_[CG ? 2 : 1], si_[CG ? 5 : 1], fg_[CG ? 5 : 1];   // CG builds: the contact's parameters fetched from the global block
+        if constexpr (CG) {
+#pragma unroll
+          for (int k = 0; k < 2; k++) sr_[k] = csolref_rd(2 * lane + k);
+#pragma unroll
+          for (int k = 0; k < 5; k++) { si_[k] = csolimp_rd(5 * lane + k); fg_[k] = cfri_rd(5 * lane + k); }
+          row_scalars(sm.cdist[lane], cmargin_rd(lane), sr_, si_, tran, R0, Bd, Kt);
+        } else row_scalars(sm.cdist[lane], sm.cmargin[lane], sm.csolref + 2 * lane, sm.csolimp + 5 * lane, tran, R0, Bd, Kt);
         const int type = dim == 1 ? C_CONTACT_FRICTIONLESS : C_CONTACT_ELLIPTIC;
-        const float* f = sm.cfri + 5 * lane;
+        const float* f = CG ? fg_ : sm.cfri + 5 * lane;
         const float R1 = R0 / fmaxf(1e-15f, opt_impratio);
         (void)rot;  // friction rows: same gains, zero position term; their regularisers follow the cone scaling of R0
 #pragma unroll
@@ -2618,7 +2661,7 @@ struct Sim {
         const int b1 = sm.cg1[c] >> 8, b2 = sm.cg2[c] >> 8;
         const dmask_t d1 = cm->bdofs[b1], d2 = cm->bdofs[b2];
         const V3 pos = ld3(sm.cpos + 3 * c);
-        const V3 ax = ld3(sm.cframe + 9 * c + 3 * (kk < 3 ? kk : kk - 3));
+        const V3 ax = CG ? cframe_ax(9 * c + 3 * (kk < 3 ? kk : kk - 3)) : ld3(sm.cframe + 9 * c + 3 * (kk < 3 ? kk : kk - 3));
         const V3 o1 = pos - ld3(sm.rootcom + 3 * cm->broot[b1]), o2 = pos - ld3(sm.rootcom + 3 * cm->broot[b2]);
         const V3 t1 = cross(o1, ax), t2 = cross(o2, ax);  // ax . (ca x o) = ca . (o x ax)
         const bool lin = kk < 3;
@@ -2660,7 +2703,7 @@ struct Sim {
         const int b1 = sm.cg1[c] >> 8, b2 = sm.cg2[c] >> 8;
         m1 = (u64)cm->bdofs[b1]; m2 = (u64)cm->bdofs[b2];
         const V3 pos = ld3(sm.cpos + 3 * c);
-        const V3 ax = ld3(sm.cframe + 9 * c + 3 * (kk < 3 ? kk : kk - 3));
+        const V3 ax = CG ? cframe_ax(9 * c + 3 * (kk < 3 ? kk : kk - 3)) : ld3(sm.cframe + 9 * c + 3 * (kk < 3 ? kk : kk - 3));
         if (kk < 3) {
           const V3 t1 = cross(pos - ld3(sm.rootcom + 3 * cm->broot[b1]), ax), t2 = cross(pos - ld3(sm.rootcom + 3 * cm->broot[b2]), ax);   // ax . (ca x o) = ca . (o x ax)
           w1[0] = -t1.x; w1[1] = -t1.y; w1[2] = -t1.z; w1[3] = -ax.x; w1[4] = -ax.y; w1[5] = -ax.z;
@@ -3532,8 +3575,8 @@ struct Sim {
       w_.kk = w_.ell ? (desc >> 12) & 15 : 0; w_.head = row - w_.kk; w_.dim = w_.ell ? sm.cdim[c] : 1;
       w_.mu = sm.cmu[c];
 #pragma unroll
-      for (int j = 0; j < CD - 1; j++) w_.fj[j] = sm.cfri[5 * c + j];
-      w_.fr_own = w_.kk == 0 ? w_.mu : sm.cfri[5 * c + w_.kk - 1];
+      for (int j = 0; j < CD - 1; j++) w_.fj[j] = cfri_rd(5 * c + j);
+      w_.fr_own = w_.kk == 0 ? w_.mu : cfri_rd(5 * c + w_.kk - 1);
       w_.Dm = (1.0f / sm.e_R[w_.ell ? w_.head : r]) / fmaxf(w_.mu * w_.mu * (1 + w_.mu * w_.mu), 1e-15f);
     }
     // M: row i in lane i (matrix-vector products) and in the MFMA accumulator layout (Hessian seed)
@@ -4446,14 +4489,15 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
       if (flags & RF_ACTSOLVE) { b.qfrc_actuator[o] = sm.qfrc_actuator[i]; b.qfrc_constraint[o] = sm.qfrc_constraint[i]; b.qacc[o] = sm.qacc[i]; }
     }
     int ncon = sm.ncon;
+    sim.csync();
     for (int c = lane; c < ncon; c += 64) {
       float* r = b.contact + ((size_t)env * NCON + c) * RSIM_CON_REC;
       r[0] = sm.cdist[c];
       for (int k = 0; k < 3; k++) r[1 + k] = sm.cpos[3 * c + k];
-      for (int k = 0; k < 9; k++) r[4 + k] = sm.cframe[9 * c + k];
+      for (int k = 0; k < 9; k++) r[4 + k] = sim.cframe_rd(9 * c + k);
       r[13] = (float)IT(IO_cg_geomid, sm.cg1[c] & 255); r[14] = (float)IT(IO_cg_geomid, sm.cg2[c] & 255); r[15] = (float)sm.cdim[c]; r[16] = (float)sm.cefc[c];
       r[17] = ((flags & RF_ACTSOLVE) && sm.cefc[c] >= 0) ? sm.e_force[sm.cefc[c]] : 0.f;
-      for (int k = 0; k < 5; k++) r[18 + k] = sm.cfri[5 * c + k];
+      for (int k = 0; k < 5; k++) r[18 + k] = sim.cfri_rd(5 * c + k);
     }
     if (flags & RF_ACTSOLVE)
       for (int i = lane; i < sm.nefc; i += 64) b.efc_force[(size_t)env * NEFC + i] = sm.e_force[i];
@@ -4693,6 +4737,6 @@ extern "C" int RSIM_SYM(rsim_cmem_bytes)(void) { return (int)((sizeof(Cmem0) + 2
 extern "C" int RSIM_SYM(rsim_limits)(int* lim) {
   const int dims[8] = {RSIM_DIMS};
   for (int i = 0; i < 8; i++) lim[i] = dims[i];
-  lim[8] = Smem0::NROOT_; lim[9] = (Smem0::TENDONS_ ? 1 : 0) | (Smem0::NB_ > 32 ? 2 : 0) | (Smem0::JG_ ? 4 : 0) | (Smem0::MG_ ? 8 : 0);   // bit 2: the constraint Jacobian lives in DBatch.jg (NEFC * (NV + 1) floats per env)   // bit 1: two OSC arm parts
+  lim[8] = Smem0::NROOT_; lim[9] = (Smem0::TENDONS_ ? 1 : 0) | (Smem0::NB_ > 32 ? 2 : 0) | (Smem0::JG_ ? 4 : 0) | (Smem0::MG_ ? 8 : 0) | (Smem0::CG_ ? 16 : 0);   // bit 2: the constraint Jacobian lives in DBatch.jg (NEFC * (NV + 1) floats per env)   // bit 1: two OSC arm parts
   return 0;
 }

@@ -29,6 +29,21 @@ def code_objects(lib):
     return out
 
 
+# mangled template arguments of k_step<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> of the configuration that serves each bench.py --config
+CONFIG_TAG = {"lift": "ILi32ELi16ELi16ELi24ELi16ELi16ELi64ELi192E", "stack": "ILi32ELi16ELi32ELi24ELi16ELi32ELi64ELi192E",
+              "peg": "ILi64ELi16ELi16ELi32ELi32ELi32ELi64ELi320E", "pickplace": "ILi64ELi32ELi48ELi64ELi32ELi32ELi128ELi640E"}
+
+
+def config_code_sha16(lib, config):
+    """sha256[:16] of the gfx950 code object (one translation unit = one kernel configuration) that holds the fused kernel of a bench configuration.  PMC evidence
+    under profiles/ carries it next to the library's sha: a build whose code object for the configuration is bit-identical runs the very kernel that was measured,
+    whatever changed in the other configurations of the library (bench.py pmc_evidence)."""
+    import hashlib
+    tag = ("_Z6k_step" + CONFIG_TAG[config]).encode()
+    hits = [co for co in code_objects(lib) if tag in co]
+    return hashlib.sha256(hits[0]).hexdigest()[:16] if len(hits) == 1 else None
+
+
 def kernels(lib=None):
     """{kernel name: {lds, scratch, vgpr, agpr, sgpr}} over all code objects of the library."""
     lib = lib or os.path.join(ROOT, "robosuite_amd", "librsim_hip.so")
