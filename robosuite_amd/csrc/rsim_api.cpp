@@ -1179,8 +1179,11 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   // contact-rich envs, ends after it.  An env that overflows unflagged costs more (its step is redone after the native pass), but on the 32 x 16 build (Lift)
   // flagged-and-never-overflowing env-steps outnumber overflows by orders of magnitude (largest demand 16 contacts / 63-66 rows of 16 / 64), so that build
   // flags nothing in advance: 3.42 -> 3.31 ms per control step; Stack is flat between 0 / 0 and 2 / 6 (profiles/r04_x_tier_overhead.txt)
-  b->db.tier_up_con = getenv("RSIM_TIER_UP_CON") ? atoi(getenv("RSIM_TIER_UP_CON")) : (b->cfg == 0 ? 0 : 2);
-  b->db.tier_up_efc = getenv("RSIM_TIER_UP_EFC") ? atoi(getenv("RSIM_TIER_UP_EFC")) : (b->cfg == 0 ? 0 : 6);
+  // (configurations 0 and 1 flag nothing in advance: an env that does overflow is redone by the wide build in the same control step.  Lift: round 4; Stack: round 5,
+  // session 14 -- with seven / eight envs per CU the wide workgroups of flagged envs wait longer for room than the rare redo costs: 6.65 -> 6.31 ms per control step)
+  const bool no_advance = b->cfg == 0 || b->cfg == 1;
+  b->db.tier_up_con = getenv("RSIM_TIER_UP_CON") ? atoi(getenv("RSIM_TIER_UP_CON")) : (no_advance ? 0 : 2);
+  b->db.tier_up_efc = getenv("RSIM_TIER_UP_EFC") ? atoi(getenv("RSIM_TIER_UP_EFC")) : (no_advance ? 0 : 6);
   b->db.tier_pass = tiered ? 0 : -1; b->db.wlist = nullptr; b->db.wcount = nullptr; b->db.wlist2 = nullptr; b->db.wcount2 = nullptr;
   const bool grouped = (flags & RF_EPISODE) && (flags & RF_CTRL) && b->ngroups > 1;
   if (!grouped || b->cm_dirty || memcmp(&b->cm_ctrl, &b->dm.ctrl, sizeof(DCtrl))) { if (join_groups(b)) return 1; }   // main-stream work ahead

@@ -35,13 +35,25 @@ CONFIG_TAG = {"lift": "ILi32ELi16ELi16ELi24ELi16ELi16ELi64ELi192E", "stack": "IL
 
 
 def config_code_sha16(lib, config):
-    """sha256[:16] of the gfx950 code object (one translation unit = one kernel configuration) that holds the fused kernel of a bench configuration.  PMC evidence
-    under profiles/ carries it next to the library's sha: a build whose code object for the configuration is bit-identical runs the very kernel that was measured,
-    whatever changed in the other configurations of the library (bench.py pmc_evidence)."""
+    """sha256[:16] of the machine code (.text: every kernel of the translation unit; .rodata: their kernel descriptors) of the gfx950 code object that holds the fused
+    kernel of a bench configuration.  PMC evidence under profiles/ carries it next to the library's sha: a build whose machine code for the configuration is
+    bit-identical runs the very kernel that was measured, whatever changed in the other configurations of the library (bench.py pmc_evidence).  Not the whole code
+    object: it also carries a compilation-unit id hashed from the compiler's command line (output path included), which differs between `make` and a variant build of
+    the same source and flags (tools/sessions/r05_s13_prep.sh)."""
     import hashlib
     tag = ("_Z6k_step" + CONFIG_TAG[config]).encode()
     hits = [co for co in code_objects(lib) if tag in co]
-    return hashlib.sha256(hits[0]).hexdigest()[:16] if len(hits) == 1 else None
+    if len(hits) != 1:
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "a.co")
+        open(f, "wb").write(hits[0])
+        code = b""
+        for sec in (".text", ".rodata"):
+            o = os.path.join(td, "sec.bin")
+            subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", f"--only-section={sec}", f, o])
+            code += open(o, "rb").read()
+    return hashlib.sha256(code).hexdigest()[:16]
 
 
 def kernels(lib=None):
