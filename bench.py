@@ -162,6 +162,17 @@ def pmc_evidence(name, key, lib_sha, config=None):
     return f"stale:{d.get('lib_sha16')}"
 
 
+# (timed steps, untimed pre-roll launches) of the secondary regions of the default command: the quick-bench protocol of tools/ab_many.sh where a control step takes a few
+# milliseconds (2 - 3 s per region), a shorter one for PickPlace (91 ms per step).  Round 5, session 15: ten steps after fifty said 603 K for Stack where the longer
+# protocols say 647 K (quick) / 620 - 650 K (full): the first control steps after a cold start carry the redo passes in which envs find their capacity tier.
+OTHER_REGION = {"stack": (50, 300), "peg": (50, 300), "pickplace": (10, 50)}
+
+
+def other_region(args, config):
+    k, p = OTHER_REGION.get(config, (10, 50))
+    return (args.other_steps if args.other_steps >= 0 else k), (args.other_preroll if args.other_preroll >= 0 else p)
+
+
 def secondary_region(config, rank, local_rank, world, dev, K, P):
     """K lockstep control steps of another BASELINE configuration at its stated batch size, after P untimed launches from staggered episode steps (same
     protocol as the headline region, shorter): ms per step, env-steps/s, dropped / diverged envs and the VALU issue fraction when PMC evidence of this
@@ -222,8 +233,8 @@ def main():
     ap.add_argument("--no-open-loop", action="store_true", help="skip the second and third timed regions (the same K steps with stream groups; two half-batches alternating)")
     ap.add_argument("--no-double-buffer", action="store_true", help="skip the third timed region (two half-batches stepped alternately, closed-loop compatible)")
     ap.add_argument("--no-other-configs", action="store_true", help="lift only: skip the short secondary regions of BASELINE configs[2..4] (config.other_configs)")
-    ap.add_argument("--other-steps", type=int, default=10, help="timed lockstep control steps of each secondary configuration")
-    ap.add_argument("--other-preroll", type=int, default=50, help="untimed launches before each secondary region (episode steps staggered as in the headline region)")
+    ap.add_argument("--other-steps", type=int, default=-1, help="timed lockstep control steps of each secondary configuration (default: OTHER_REGION, 50 where a step takes a few ms, 10 for PickPlace)")
+    ap.add_argument("--other-preroll", type=int, default=-1, help="untimed launches before each secondary region (episode steps staggered as in the headline region; default: OTHER_REGION, 300 / 50)")
     ap.add_argument("--secondary-only", choices=sorted(CONFIGS), default=None, help="internal: run one secondary region and print its record (the default run starts one child per configuration)")
     args = ap.parse_args()
 
@@ -231,7 +242,7 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit(3)
         torch.cuda.set_device(0)
-        print(json.dumps(secondary_region(args.secondary_only, 0, 0, 1, torch.device("cuda", 0), args.other_steps, args.other_preroll)), flush=True)
+        print(json.dumps(secondary_region(args.secondary_only, 0, 0, 1, torch.device("cuda", 0), *other_region(args, args.secondary_only))), flush=True)
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -388,7 +399,7 @@ def main():
                 # instead of taking the headline line with it
                 import subprocess
                 try:
-                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--secondary-only", oc, "--other-steps", str(args.other_steps), "--other-preroll", str(args.other_preroll)],
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--secondary-only", oc, "--other-steps", str(other_region(args, oc)[0]), "--other-preroll", str(other_region(args, oc)[1])],
                                        capture_output=True, text=True, timeout=900)
                     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                     other[oc] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": f"exit code {r.returncode}: {r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else ''}"}
@@ -397,7 +408,7 @@ def main():
             else:
                 # under torch.distributed.run every rank takes part (weak scaling like the headline), in process
                 try:
-                    other[oc] = secondary_region(oc, rank, local_rank, world, dev, args.other_steps, args.other_preroll)
+                    other[oc] = secondary_region(oc, rank, local_rank, world, dev, *other_region(args, oc))
                 except Exception as e:   # a failing secondary region is reported, it does not take the headline line with it
                     other[oc] = {"error": f"{type(e).__name__}: {e}"}
 

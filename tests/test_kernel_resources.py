@@ -44,3 +44,35 @@ def test_auxiliary_kernels_use_no_scratch():
             assert r["scratch"] <= (64 if "ELi256E" not in name else 1024), (name, r)   # the reset-observation pass (a few envs per control step) and the B = 1 debug entries share the step body (256-row tier: see STEP_BUDGET)
         elif not (name.startswith("_Z6k_step") or name.startswith("_Z11k_step_list")):
             assert r["scratch"] == 0, (name, r)
+
+
+def test_pmc_evidence_is_keyed_to_the_machine_code_of_its_configuration(tmp_path, monkeypatch):
+    """profiles/valu_count*.json / hbm_traffic*.json carry the sha of the library they were measured on AND of the machine code (.text + kernel descriptors) of
+    their configuration's code object.  bench.py accepts a figure when either matches the library it runs -- a build that changed another configuration runs the
+    bit-identical kernel for this one -- and says "stale:<sha>" otherwise (never a silent null).  The committed evidence must be valid for the in-tree build."""
+    import hashlib
+    import json
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from tools.kernel_resources import CONFIG_TAG, config_code_sha16
+
+    lib_sha = hashlib.sha256(open(LIB, "rb").read()).hexdigest()[:16]
+    shas = {c: config_code_sha16(LIB, c) for c in CONFIG_TAG}
+    assert all(shas.values()) and len(set(shas.values())) == len(shas)          # one code object per configuration, all different
+    for cfg, sfx in (("lift", ""), ("stack", "_stack"), ("peg", "_peg"), ("pickplace", "_pickplace")):
+        for stem, key in (("valu_count", "valu_per_env_substep"), ("hbm_traffic", "bytes_per_launch")):
+            d = json.load(open(os.path.join(root, "profiles", f"{stem}{sfx}.json")))
+            assert d["code_sha16"] == shas[cfg], (stem, cfg, "evidence of another kernel: re-run tools/gpu_session.sh <tag> pmc:" + cfg)
+            v = bench.pmc_evidence(f"{stem}{sfx}.json", key, lib_sha, cfg)
+            assert isinstance(v, float) and v > 0, (stem, cfg, v)
+    # evidence of another kernel is said out loud
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    json.dump({"valu_per_env_substep": 1.0, "lib_sha16": "0123456789abcdef", "code_sha16": "fedcba9876543210"}, open(tmp_path / "profiles" / "valu_count.json", "w"))
+    assert bench.pmc_evidence("valu_count.json", "valu_per_env_substep", lib_sha, "lift") == "stale:0123456789abcdef"
+    assert bench.pmc_evidence("hbm_traffic.json", "bytes_per_launch", lib_sha, "lift") == "absent"
+    json.dump({"valu_per_env_substep": 2.0, "lib_sha16": "0123456789abcdef", "code_sha16": shas["lift"]}, open(tmp_path / "profiles" / "valu_count.json", "w"))
+    assert bench.pmc_evidence("valu_count.json", "valu_per_env_substep", lib_sha, "lift") == 2.0
