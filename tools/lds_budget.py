@@ -1,12 +1,16 @@
 """Per-field byte budget of the per-environment LDS object (struct Smem) of one kernel configuration, from clang's record-layout dump of the
 device compilation.  Occupancy is LDS-bound: this is the table to look at before adding a field.
-Usage: python tools/lds_budget.py [cfg 0..3]"""
+Usage: python tools/lds_budget.py [cfg 0..7]"""
 import os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 src = os.path.join(ROOT, "robosuite_amd", "csrc", "rsim_step.hip")
-out = subprocess.run(["/opt/rocm/bin/hipcc", "-O0", "-std=c++17", "--offload-arch=gfx950", f"-DRSIM_CFG={cfg}", "--cuda-device-only", "-fsyntax-only",
+# the -D flags the Makefile builds this configuration with (J / M / contact block in global memory, hull pool) decide the layout
+var = {0: "CFG0FLAGS", 1: "CFG1FLAGS", 2: "CFG2FLAGS", 3: "CFG3FLAGS", 5: "CFG3FLAGS", 7: "CFG7FLAGS"}.get(cfg)
+flags = subprocess.run(["make", "-s", f"print-{var}"], capture_output=True, text=True, cwd=os.path.dirname(src)).stdout.split() if var else []
+defs = [f for f in flags if f.startswith("-D")]
+out = subprocess.run(["/opt/rocm/bin/hipcc", "-O0", "-std=c++17", "--offload-arch=gfx950", f"-DRSIM_CFG={cfg}", *defs, "--cuda-device-only", "-fsyntax-only",
                       "-Xclang", "-fdump-record-layouts", src], capture_output=True, text=True, cwd=os.path.dirname(src)).stdout
 for block in out.split("*** Dumping AST Record Layout"):
     lines = block.strip().splitlines()
