@@ -16,6 +16,8 @@ _LIB = None
 
 
 def build(force=False):
+    if os.environ.get("RSIM_ORACLE_LIB"):       # another build of the same source (tests/test_oracle_sanitizers.py: -fsanitize=address,undefined)
+        return os.environ["RSIM_ORACLE_LIB"]
     so = os.path.join(_HERE, "librsim_oracle.so")
     src = os.path.join(_HERE, "rsim_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
