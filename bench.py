@@ -316,6 +316,34 @@ def main():
     ring1 = env.bank_stats()
     if os.environ.get("RSIM_BENCH_TRACE"):
         print("per-step ms:", " ".join(f"{r[0]:.2f}" for r in evms), file=sys.stderr)
+    # ---- secondary regions: BASELINE configs[2..4] at their stated batch sizes, a short lockstep region each, so that the clock of whoever runs the
+    # default command also covers them.  After the headline region (which they cannot disturb) and BEFORE the open-loop / double-buffered regions of the headline
+    # configuration: behind those (sixteen stream groups, two more batches) the children of session 16 read 6 - 9 % lower than the same regions stand-alone or
+    # behind a parent that had run the headline region only (session 17: identical); 12 s of sustained load alone costs 1 % (session 18, tools/sustained_load.py).
+    # Every rank takes part (weak scaling like the headline).
+    other = None
+    if args.config == "lift" and not args.no_other_configs:
+        env.bank_quiesce()
+        other = {}
+        for oc in ("stack", "peg", "pickplace"):
+            if world == 1:
+                # one child process per configuration: a fault of the GPU queue there (which aborts the process that owns it) is reported in the record
+                # instead of taking the headline line with it
+                import subprocess
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--secondary-only", oc, "--other-steps", str(other_region(args, oc)[0]), "--other-preroll", str(other_region(args, oc)[1])],
+                                       capture_output=True, text=True, timeout=900)
+                    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    other[oc] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": f"exit code {r.returncode}: {r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else ''}"}
+                except Exception as e:
+                    other[oc] = {"error": f"{type(e).__name__}: {e}"}
+            else:
+                # under torch.distributed.run every rank takes part (weak scaling like the headline), in process
+                try:
+                    other[oc] = secondary_region(oc, rank, local_rank, world, dev, *other_region(args, oc))
+                except Exception as e:   # a failing secondary region is reported, it does not take the headline line with it
+                    other[oc] = {"error": f"{type(e).__name__}: {e}"}
+
     open_loop = None
     if K2:
         env.batch.set_stream_groups(G)
@@ -386,31 +414,6 @@ def main():
     need_con, need_efc = shard.max_over_ranks(float(cn[:, 0].max().item()), dev), shard.max_over_ranks(float(cn[:, 1].max().item()), dev)
     need_hist = {f"contacts>{t}": int((cn[:, 0] > t).sum().item()) for t in (16, 24, 32, 48)} | {f"rows>{t}": int((cn[:, 1] > t).sum().item()) for t in (64, 80, 96, 128, 160)}   # rank-local
     tot = st.allreduce()
-
-    # ---- secondary regions: BASELINE configs[2..4] at their stated batch sizes, a short lockstep region each, so that the clock of whoever runs the
-    # default command also covers them.  After the headline region (which they cannot disturb); every rank takes part (weak scaling like the headline).
-    other = None
-    if args.config == "lift" and not args.no_other_configs:
-        env.bank_quiesce()
-        other = {}
-        for oc in ("stack", "peg", "pickplace"):
-            if world == 1:
-                # one child process per configuration: a fault of the GPU queue there (which aborts the process that owns it) is reported in the record
-                # instead of taking the headline line with it
-                import subprocess
-                try:
-                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--secondary-only", oc, "--other-steps", str(other_region(args, oc)[0]), "--other-preroll", str(other_region(args, oc)[1])],
-                                       capture_output=True, text=True, timeout=900)
-                    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                    other[oc] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": f"exit code {r.returncode}: {r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else ''}"}
-                except Exception as e:
-                    other[oc] = {"error": f"{type(e).__name__}: {e}"}
-            else:
-                # under torch.distributed.run every rank takes part (weak scaling like the headline), in process
-                try:
-                    other[oc] = secondary_region(oc, rank, local_rank, world, dev, *other_region(args, oc))
-                except Exception as e:   # a failing secondary region is reported, it does not take the headline line with it
-                    other[oc] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         abytes = algorithmic_bytes_per_env_step(env, flat, dr) * B   # one control step = one launch of all B envs
