@@ -236,7 +236,9 @@ void rsim_model_free(rsim_model* m);
 int rsim_model_int(const rsim_model* m, const char* name);
 /* Which compiled kernel configuration serves this model: 0 = 32 bodies x 16 dofs (Lift/Panda), 1 = 32 x 32 (Stack/Panda), 2 = 64 x 16 (Baxter);
  * 3 = 64 x 64 with tendon rows (PickPlace/IIWA+Robotiq140); -1 = none (rsim_batch_create would refuse it).  limits, if not NULL, receives 10 ints: {nbody, njnt, nv, ncgeom, nsite, ncon, nefc, npair, articulated trees} maxima
- * and whether the configuration carries tendon / equality rows (the 32 x 16 one does not: such models go to the next larger one). */
+ * and a flag word: bit 0 = the configuration carries tendon / equality rows (the 32 x 16 one does not: such models go to the next larger one), bit 1 = two-arm
+ * controller masks, bits 2 / 3 / 4 = the build keeps its constraint Jacobian / mass matrix / contact block in a per-env buffer in global memory instead of LDS
+ * (an occupancy choice of the build, sized by rsim_batch_create; nothing a caller has to act on). */
 int rsim_model_config(const rsim_model* m, int* limits);
 /* mj_name2id / mj_id2name as robosuite's MjModel wrapper uses them (binding_utils.py:296-360: body_name2id, joint_name2id, geom_name2id, site_name2id,
  * actuator_name2id, camera_name2id, sensor_name2id, ... and the id2name inverses).  kind = "body" | "joint" | "geom" | "site" | "actuator" | "camera" | "light" |
