@@ -67,6 +67,9 @@ def test_kernel_configuration_is_chosen_by_model_size():
         cid, lim = backend.HipModel(flat).kernel_config()
         assert cid == want, (model, cid)
         assert flat.nbody <= lim["nbody"] and flat.nv <= lim["nv"] and len(flat.arrays["pair_geom1"]) <= lim["npair"]
+        # what each build keeps in the per-env global buffer instead of LDS (flag word bits 2 / 3 / 4: constraint Jacobian, mass matrix, contact block): the occupancy
+        # choices the measured figures rest on (csrc/Makefile CFG1FLAGS / CFG3FLAGS) -- the one-tile builds keep everything in LDS
+        assert (lim["tendons"] >> 2) & 7 == {0: 0, 1: 7, 2: 0, 3: 3}[want], (model, lim["tendons"])
     # two-arm joint-space parts: 14 joints in one descriptor; the OSC types stay at one arm of <= 8 joints
     _, cfg, flat = load_golden("ctl_joint_velocity", "peg_baxter")
     m = backend.HipModel(flat)
