@@ -343,6 +343,10 @@ int rsim_profile(rsim_batch* b, int enable, unsigned long long* out, int n_out);
 int rsim_wavelog(rsim_batch* b, unsigned long long* out);
 /* restrict the phase accumulators to one env (-1 = all envs) */
 int rsim_profile_env(rsim_batch* b, int env);
+/* Capacity tier of every env for the NEXT control step, HOST int32 [B]: 0 = stepped by the batch's native kernel configuration, 1 = by the wider one (MuJoCo
+ * never truncates contacts -- nconmax = 5000, models/assets/base.xml:5 -- so an env that outgrows the native contact / row capacity is stepped with more).
+ * Synchronises the batch's stream.  No reference counterpart (diagnostics: which envs a lockstep launch waits for). */
+int rsim_tier_snapshot(rsim_batch* b, int* host_tier);
 /* per candidate pair p (model pair order): out[p] = narrow-phase visits, out[640 + p] = support-function calls (out: 1280 entries), summed over envs and launches since arming */
 int rsim_pairlog(rsim_batch* b, unsigned long long* out);
 

@@ -246,6 +246,7 @@ def lib():
         L.rsim_set_stream_groups.argtypes = [vp, C.c_int]
         L.rsim_group_stream.restype = vp; L.rsim_group_stream.argtypes = [vp, C.c_int]
         L.rsim_profile_env.argtypes = [vp, C.c_int]
+        L.rsim_tier_snapshot.argtypes = [vp, vp]
         L.rsim_name2id.argtypes = [vp, C.c_char_p, C.c_char_p]
         L.rsim_id2name.argtypes = [vp, C.c_char_p, C.c_int]; L.rsim_id2name.restype = C.c_char_p
         L.rsim_full_M.argtypes = [vp, C.c_int, vp]
@@ -609,6 +610,12 @@ class HipBatch:
 
     def profile_env(self, env=-1):
         _chk(self._L.rsim_profile_env(self.ptr, int(env)))
+
+    def tier_snapshot(self):
+        """Capacity tier of every env for the next control step (int32 [B]: 0 native configuration, 1 the wider one); synchronises the batch's stream."""
+        out = np.zeros(self.B, dtype=np.int32)
+        _chk(self._L.rsim_tier_snapshot(self.ptr, out.ctypes.data))
+        return out
 
     def wavelog(self):
         """Per-env {hw_id, xcc_id, t_start, t_end} of the last launch (profiling must be armed)."""

@@ -43,6 +43,7 @@ extern "C" int rsim_limits_cfg4(int* lim);
 RSIM_TIER_DECL(5) RSIM_TIER_DECL(6) RSIM_TIER_DECL(7)
 extern "C" int rsim_launch_step_list_cfg3(const DModel* m, const DBatch* b, const float* actions, int n_sub, int flags, int grid, hipStream_t stream);
 extern "C" int rsim_launch_tier_list(const int* tier, int* list, int* count, int* zero_next, int env0, int n, hipStream_t stream);
+extern "C" int rsim_limits_w_cfg0(int* lim);   // limits of the wide body compiled into configuration 0's control-step kernel (fused tier); 0: this build has none
 typedef int (*step_list_fn)(const DModel*, const DBatch*, const float*, int, int, int, hipStream_t);
 typedef int (*step_fn)(const DModel*, const DBatch*, const float*, int, int, hipStream_t);
 typedef int (*creset_fn)(const DModel*, const DBatch*, const unsigned char*, hipStream_t);
@@ -173,6 +174,8 @@ struct rsim_batch {
   // between steps (tier_next), an env that runs out of capacity in mid-step commits nothing and is redone by the wide configuration inside the same
   // rsim_control_step (redo list).  -1: no tier above this batch's configuration.
   int cfg_w;
+  int fused;          // the tier above the batch's configuration is compiled into its control-step kernel (limits bit 5): an env that needs it is stepped -- or carried on
+                      // from the substep in which it outgrew the native capacity -- by the wide body inside its own workgroup; no list, no wide launch, no redo
   int lim_w[10];
   void* d_cm_w;       // constant blocks of the wide configuration: one shared, one per env (built on demand for the envs a wide pass steps)
   size_t cm_bytes_w;
@@ -889,6 +892,11 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.ctrl.cs_size = b->cs;
   // capacity tiers: only for controllers whose state lives in LDS for the whole launch (a step that is handed over must not have written anything)
   b->cfg_w = b->cs <= RSIM_CS_LDS ? pick_wide(m, b->cfg, b->lim, b->lim_w) : -1;
+  b->fused = 0;
+  if (b->cfg_w >= 0 && b->cfg == 0 && (b->lim[9] & 32) && !getenv("RSIM_NO_TIERS")) {
+    int lw[10];
+    if (rsim_limits_w_cfg0(lw) && config_holds(m, lw)) { memcpy(b->lim_w, lw, sizeof(lw)); b->fused = 1; }
+  }
   {
     // builds that keep the constraint Jacobian in global memory (RSIM_JGLOBAL: limits bit 2) get their per-env buffer, [B][NEFC * (NV + 1)] floats
     // limits bit 3 (RSIM_MGLOBAL): the mass matrix behind J in the same buffer, NV * (NV + 1) floats more.  One stride for the native and the wide configuration.
@@ -1115,7 +1123,7 @@ static int ensure_constants(rsim_batch* b) {
     int e = k_prepare_launch[b->cfg](&b->dm, &b->db, b->B, 0, b->stream);
     if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   }
-  if (b->cfg_w >= 0) {   // the shared block of the wide configuration (its per-env blocks are built on demand, right before a wide pass)
+  if (b->cfg_w >= 0 && !b->fused) {   // the shared block of the wide configuration (its per-env blocks are built on demand, right before a wide pass; a fused wide body reads the native blocks)
     DModel dm0 = b->dm; DBatch db0 = b->db;
     dm0.fenv = 0; db0.cm_env = b->d_cm_w; db0.cm_stride = 0;
     int e = prepare_launch_any(b->cfg_w)(&dm0, &db0, 1, 0, b->stream);
@@ -1185,6 +1193,12 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   b->db.tier_up_con = getenv("RSIM_TIER_UP_CON") ? atoi(getenv("RSIM_TIER_UP_CON")) : (no_advance ? 0 : 2);
   b->db.tier_up_efc = getenv("RSIM_TIER_UP_EFC") ? atoi(getenv("RSIM_TIER_UP_EFC")) : (no_advance ? 0 : 6);
   b->db.tier_pass = tiered ? 0 : -1; b->db.wlist = nullptr; b->db.wcount = nullptr; b->db.wlist2 = nullptr; b->db.wcount2 = nullptr;
+  // fused tier: k_step picks the body per env and hands over in place; the thresholds at which the wide body lets an env go back are the native capacity's
+  const bool fused = tiered && b->fused;
+  if (fused) {
+    b->db.tier_con = b->lim[5]; b->db.tier_efc = b->lim[6];
+    if (const char* e = getenv("RSIM_FORCE_HANDOVER")) b->db.tier_pass = 100 + atoi(e);   // test hook: every native-tier env hands over to the wide body at this substep (tests/test_hip_edge_cases.py)
+  }
   const bool grouped = (flags & RF_EPISODE) && (flags & RF_CTRL) && b->ngroups > 1;
   if (!grouped || b->cm_dirty || memcmp(&b->cm_ctrl, &b->dm.ctrl, sizeof(DCtrl))) { if (join_groups(b)) return 1; }   // main-stream work ahead
   if (ensure_constants(b)) return 1;
@@ -1206,7 +1220,7 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
         }
         db.cost = b->d_cost;
       }
-      if (tiered) {   // this env block's lists; every pass of the block runs on the block's own stream, one after the other
+      if (tiered && !fused) {   // this env block's lists; every pass of the block runs on the block's own stream, one after the other
         int* cnt = b->d_wcount + b->tier_flip * WCN + 2 + 2 * g;
         int el = rsim_launch_tier_list(b->db.tier_cur, b->d_wlist[0] + e0, cnt, b->d_wcount + (b->tier_flip ^ 1) * WCN + 2 + 2 * g, e0, e1 - e0, b->gstream[g]);
         if (el) return fail("tier-list kernel launch failed: %s", hipGetErrorString((hipError_t)el));
@@ -1214,7 +1228,7 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
       }
       int e = k_step_launch[b->cfg](&b->dm, &db, actions, n_sub, flags, b->gstream[g]);
       if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-      if (tiered) {
+      if (tiered && !fused) {
         int* cnt = b->d_wcount + b->tier_flip * WCN + 2 + 2 * g;
         if (wide_pass(b, actions, n_sub, flags, 1, b->d_wlist[0] + e0, cnt, b->gstream[g])) return 1;
         if (wide_pass(b, actions, n_sub, flags, 2, b->d_wlist[1] + e0, cnt + 1, b->gstream[g])) return 1;
@@ -1262,7 +1276,7 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
     b->db.cost = b->d_cost2[cur];
   }
   if (traced) tr_mark(b, 1);
-  if (tiered) {
+  if (tiered && !fused) {
     // beside the native pass, on a stream of its own: the envs whose tier is 1 (they were close to the native capacity, or beyond it, last step)
     int* cnt = b->d_wcount + b->tier_flip * WCN;
     if (b->tier_mode == 1) {   // everything on the batch's stream: list, wide pass, then the native pass
@@ -1283,13 +1297,16 @@ static int launch(rsim_batch* b, const float* actions, int n_sub, int flags) {
   int e = k_step_launch[b->cfg](&b->dm, &b->db, actions, n_sub, flags, b->stream);
   if (e) return fail("kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   if (traced) tr_mark(b, 3);
-  if (tiered) {
+  if (tiered && !fused) {
     // after both: the envs the native pass had to hand over in mid-step (rare: most move up between steps), redone from their unchanged state
     if (b->tier_mode != 1) HIPCHK(hipStreamWaitEvent(b->stream, b->wjoin, 0));
     if (traced) tr_mark(b, 4);
     if (wide_pass(b, actions, n_sub, flags, 2, b->d_wlist[1], b->d_wcount + b->tier_flip * WCN + 1, b->stream)) return 1;
     b->tier_flip ^= 1;
-  } else if (traced) tr_mark(b, 4);
+  } else {
+    if (fused) b->tier_flip ^= 1;
+    if (traced) tr_mark(b, 4);
+  }
   if (traced) tr_mark(b, 5);
   if (sched1) {
     if (!b->order_fresh) HIPCHK(hipEventRecord(b->step_done[cur], b->stream));
@@ -1607,6 +1624,18 @@ extern "C" int rsim_pairlog(rsim_batch* b, unsigned long long* out) { if (join_g
   return 0;
 }
 extern "C" int rsim_profile_env(rsim_batch* b, int env) { b->db.prof_env = env; return 0; }
+// Capacity tier of every env for the NEXT control step (0: the native configuration steps it, 1: the wider one), host int32 [B]; all zeros for a batch without a
+// tier above its configuration.  Diagnostics (tools/window_trace.py, bench.py's per-step record): an env whose entry went 0 -> 1 over a control step was handed
+// over in mid-step (redone), an env at 1 is on next step's wide list.
+extern "C" int rsim_tier_snapshot(rsim_batch* b, int* host_tier) {
+  if (!host_tier) return fail("rsim_tier_snapshot: null destination");
+  HIPCHK(hipSetDevice(b->device));
+  if (b->cfg_w < 0 || !b->d_tier[0]) { memset(host_tier, 0, (size_t)b->B * sizeof(int)); return 0; }
+  if (join_groups(b)) return 1;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(host_tier, b->d_tier[b->tier_flip], (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
 
 extern "C" int rsim_wavelog(rsim_batch* b, unsigned long long* out) { if (join_groups(b)) return 1;
   if (!b->db.prof) return fail("rsim_wavelog: profiling is not enabled");

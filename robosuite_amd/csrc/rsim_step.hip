@@ -27,6 +27,13 @@
 #if RSIM_CFG == 0
 #define RSIM_DIMS 32, 16, 16, 24, 16, 16, 64, 192
 #define RSIM_SYM(x) x##_cfg0
+#ifdef RSIM_FUSED_TIER
+// The capacity tier above this configuration (32 contacts x 128 rows: the dimensions of configuration 6) compiled INTO this configuration's control-step kernel:
+// an env that outgrows 16 contacts / 64 rows in mid-step carries on with the wide body from the substep it is in, inside the same workgroup (k_step below), instead
+// of being redone by another kernel after the launch.  The wide body keeps its Jacobian and contact block in the per-env global buffer so that both bodies
+// fit the same 20 KB of LDS (eight envs per CU).
+#define RSIM_DIMS_W 32, 16, 16, 24, 16, 32, 128, 192
+#endif
 #elif RSIM_CFG == 1
 #define RSIM_DIMS 32, 16, 32, 24, 16, 32, 64, 192
 #define RSIM_SYM(x) x##_cfg1
@@ -114,6 +121,11 @@ typedef unsigned long long u64;
 #define RSIM_CG_ENABLED 1
 #else
 #define RSIM_CG_ENABLED 0
+#endif
+#ifdef RSIM_FUSED_TIER
+#define RSIM_FUSED_ENABLED 1
+#else
+#define RSIM_FUSED_ENABLED 0
 #endif
 #ifndef RSIM_NOHULLPOOL
 #define RSIM_NOHULLPOOL 0   /* 1: no LDS-resident hull vertices in the middle configurations either (all hulls scanned from global memory, as the 32 x 16 build does) */
@@ -363,7 +375,8 @@ struct Smem {
   // contacts
   // RSIM_CGLOBAL (32 x 32 build, on top of RSIM_JGLOBAL / RSIM_MGLOBAL): contact frames and contact material parameters -- written once per contact by the narrow phase, read
   // by the row builders -- in the same per-env global buffer behind J and M: 22.6 -> 19.8 KB = EIGHT environments per CU, two wavefronts on every SIMD (layout: CG_* below)
-  static constexpr bool CG_ = RSIM_CG_ENABLED && RSIM_JG_ENABLED && RSIM_MG_ENABLED && NV == 32 && NEFC == 64;
+  static constexpr bool FUSEDW_ = RSIM_FUSED_ENABLED && NV == 16 && NEFC == 128;   // the wide body of a fused-tier build (RSIM_DIMS_W): J and the contact block in DBatch.jg
+  static constexpr bool CG_ = (RSIM_CG_ENABLED && RSIM_JG_ENABLED && RSIM_MG_ENABLED && NV == 32 && NEFC == 64) || FUSEDW_;
   static constexpr int CG_FRAME_ = 0, CG_FRI_ = NCON * 9, CG_SOLIMP_ = NCON * 14, CG_SOLREF_ = NCON * 19, CG_MARGIN_ = NCON * 21, CG_WORDS_ = NCON * 22;
   float cpos[NCON * 3], cframe[CG_ ? 1 : NCON * 9], cdist[NCON], cfri[CG_ ? 1 : NCON * 5], csolref[CG_ ? 1 : NCON * 2], csolimp[CG_ ? 1 : NCON * 5], cmu[NCON], cmargin[CG_ ? 1 : NCON];
   int cg1[NCON], cg2[NCON], cdim[NCON], cefc[NCON];
@@ -371,7 +384,7 @@ struct Smem {
   // RSIM_JGLOBAL (64 x 48 build with 128 rows only): the constraint Jacobian lives in a per-env buffer in GLOBAL memory (DBatch.jg; 25 KB per env, L2-resident
   // for the resident envs of an XCD) instead of LDS: 74.8 -> 49.7 KB = three environments per CU instead of two
   // (RSIM_JG256: the 256-row tier of the same shape as well -- 116 -> 66 KB, two jumbo envs per CU instead of one)
-  static constexpr bool JG_ = RSIM_JG_ENABLED && ((NV == 48 && (NEFC == 128 || (RSIM_JG256_ENABLED && NEFC == 256))) || (NV == 32 && (NEFC == 64 || NEFC == 128)));
+  static constexpr bool JG_ = (RSIM_JG_ENABLED && ((NV == 48 && (NEFC == 128 || (RSIM_JG256_ENABLED && NEFC == 256))) || (NV == 32 && (NEFC == 64 || NEFC == 128)))) || (RSIM_FUSED_ENABLED && NV == 16 && NEFC == 128);
   float J[JG_ ? 4 : NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
   float e_R[NEFC], e_aref[NEFC], e_force[NEFC];   // e_force doubles as the row's velocity gain B between make_constraint's two halves
   int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
@@ -416,7 +429,22 @@ struct Cmem {
 // The one per-workgroup LDS object, declared at file scope so that every access is a direct LDS (ds_*) instruction with an
 // immediate offset: routing it through a reference member made the compiler fall back to flat_* loads/stores.
 typedef Smem<RSIM_DIMS> Smem0;
-static __shared__ Smem0 sm;
+#ifdef RSIM_DIMS_W
+// fused-tier build: the native and the wide body of one kernel share the workgroup's LDS (a workgroup runs one of them at a time; the hand-over in mid-step
+// relies on the state arrays qpos .. ctrl at the head of both layouts having the same offsets)
+typedef Smem<RSIM_DIMS_W> SmemW;
+union SmemU { Smem0 n; SmemW w; };
+static __shared__ SmemU smu;
+template <class S> struct LdsOf;
+template <> struct LdsOf<Smem0> { static __device__ __forceinline__ Smem0& get() { return smu.n; } };
+template <> struct LdsOf<SmemW> { static __device__ __forceinline__ SmemW& get() { return smu.w; } };
+static_assert(offsetof(Smem0, xpos) == offsetof(SmemW, xpos), "state arrays at the head of both LDS layouts");
+#else
+static __shared__ Smem0 sm0_;
+template <class S> struct LdsOf { static __device__ __forceinline__ Smem0& get() { return sm0_; } };
+#endif
+// `sm` = the LDS object in the layout of the configuration the enclosing template is instantiated for (SM must name it at every use)
+#define sm (LdsOf<SM>::get())
 typedef Cmem<RSIM_DIMS> Cmem0;
 typedef const Cmem0 __attribute__((address_space(1)))* cmr_t;   // read view of an env's constant block (global_load, never flat_load)
 typedef Cmem0 __attribute__((address_space(1)))* cmw_t;         // write view (prepare_constants)
@@ -802,6 +830,7 @@ __device__ __forceinline__ void spd_solve_small(const float* A, const float* b, 
 // `org`: origin the result is expressed in.  MPR passes the first geom's position, so that its portal algebra runs on centimetre-sized coordinates
 // (rounding ~4e-9 m) instead of metre-sized world coordinates (~1e-7 m): which facet of the Minkowski difference the origin ray leaves through is
 // then decided by the geometry, not by fp32 noise (fine meshes in deep penetration ended on neighbouring facets, degrees apart, in half of the cases).
+template <class SM>
 __device__ __forceinline__ V3 geom_support(cmr_t cm, cmr_t cmg, int g, V3 dir, gcf mesh_vert, int lane, V3 org) {
   const int t = cm->gtype[g];
   const M3 R = ldm(sm.gmat + 9 * g);
@@ -826,8 +855,8 @@ __device__ __forceinline__ V3 geom_support(cmr_t cm, cmr_t cmg, int g, V3 dir, g
     const int adr = cm->gmesh[g] & 0xffff, num = cm->gmesh[g] >> 16;
     float bv = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f;
     int bi = 0x7fffffff;
-    const int pool = Smem0::HULLPOOL_ > 0 ? cm->ghull[g] : -1;
-    if (Smem0::HULLPOOL_ > 0 && pool >= 0) {
+    const int pool = SM::HULLPOOL_ > 0 ? cm->ghull[g] : -1;
+    if (SM::HULLPOOL_ > 0 && pool >= 0) {
       // hull resident in LDS: lane l scans vertices l, l+64, ... (at most 256 per hull in the pool)
       const float* hv = sm.hull + pool;
 #pragma unroll
@@ -835,7 +864,7 @@ __device__ __forceinline__ V3 geom_support(cmr_t cm, cmr_t cmg, int g, V3 dir, g
         const int i = 64 * u + lane;
         if (64 * u < num) {
           const int ii = i < num ? i : 0;
-          const float x = hv[ii], y = hv[Smem0::HULLPOOL_ + ii], z = hv[2 * Smem0::HULLPOOL_ + ii];
+          const float x = hv[ii], y = hv[SM::HULLPOOL_ + ii], z = hv[2 * SM::HULLPOOL_ + ii];
           const float val = x * ld.x + y * ld.y + z * ld.z;
           if (i < num && val > bv) { bv = val; bi = i; bx = x; by = y; bz = z; }
         }
@@ -881,6 +910,7 @@ struct SupGeom {
   float vx[4], vy[4], vz[4];
   bool regs;
 };
+template <class SM>
 __device__ __forceinline__ SupGeom sup_load(cmr_t cm, cmr_t cmg, int g, gcf mesh_vert, int lane, V3 org) {
   SupGeom s;
   s.t = uni(cm->gtype[g]);          // scalar: the type dispatch of every support call becomes s_cbranch on an SGPR instead of exec-masked regions
@@ -1019,7 +1049,7 @@ struct Sim {
   static constexpr bool CG = SM::CG_;
   // CG builds: this env's contact frames / material parameters in global memory, behind M in DBatch.jg (no member of its own: the layout of Sim, and with it the
   // register allocation of the builds that do not use it, stays what it was)
-  __device__ __forceinline__ gwf Cgp() const { return Mg + SM::NV_ * SM::NVP; }
+  __device__ __forceinline__ gwf Cgp() const { if constexpr (MG) return Mg + SM::NV_ * SM::NVP; else return Jg + SM::NEFC_ * SM::JS_; }   // behind M where the build keeps M there, behind J otherwise (fused wide body)
   __device__ __forceinline__ float cframe_rd(int i) const { if constexpr (CG) return Cgp()[SM::CG_FRAME_ + i]; else return sm.cframe[i]; }
   __device__ __forceinline__ float cfri_rd(int i) const { if constexpr (CG) return Cgp()[SM::CG_FRI_ + i]; else return sm.cfri[i]; }
   __device__ __forceinline__ float csolimp_rd(int i) const { if constexpr (CG) return Cgp()[SM::CG_SOLIMP_ + i]; else return sm.csolimp[i]; }
@@ -1822,7 +1852,7 @@ struct Sim {
   }
 
   __device__ __forceinline__ V3 sup(const SupGeom& sg, V3 dir) { pf.count(RP_N_SUPPORT, 1); return sup_eval(sg, dir, (gcf)m.mesh_vert, lane); }
-  __device__ __forceinline__ V3 support(int g, V3 dir, V3 org = {0.f, 0.f, 0.f}) { pf.count(RP_N_SUPPORT, 1); return geom_support(cm, cmf(MK_gst), g, dir, (gcf)m.mesh_vert, lane, org); }
+  __device__ __forceinline__ V3 support(int g, V3 dir, V3 org = {0.f, 0.f, 0.f}) { pf.count(RP_N_SUPPORT, 1); return geom_support<SM>(cm, cmf(MK_gst), g, dir, (gcf)m.mesh_vert, lane, org); }
 
   // contact parameters of a geom pair (MuJoCo's mixing rules: priority, solmix-weighted solref/solimp, max friction);
   // evaluated once per candidate pair, uniformly by every lane, from the per-geom table staged in LDS
@@ -2074,7 +2104,7 @@ struct Sim {
     const float tol = 1e-6f;
     const int mprstat_s0 = pf.c_support; (void)mprstat_s0;
     const V3 org = ld3(sm.gpos + 3 * g1);   // all support points relative to the first geom's position (see geom_support)
-    const SupGeom sg1 = sup_load(cm, cmf(MK_gst), g1, (gcf)m.mesh_vert, lane, org), sg2 = sup_load(cm, cmf(MK_gst), g2, (gcf)m.mesh_vert, lane, org);
+    const SupGeom sg1 = sup_load<SM>(cm, cmf(MK_gst), g1, (gcf)m.mesh_vert, lane, org), sg2 = sup_load<SM>(cm, cmf(MK_gst), g2, (gcf)m.mesh_vert, lane, org);
     if (wh == 1) {
       const V3 a1 = sup(sg1, wd), a2 = sup(sg2, -wd);
       if (dot(a1 - a2, wd) <= 0) { MPRSTAT(8, 1); return; }
@@ -2676,10 +2706,11 @@ struct Sim {
       }
       float jv = 0.f;
 #pragma unroll
-      for (int k = 0; k < NV16; k++) { sm.J[row * JS + k] = Jr[k]; jv = fmaf(Jr[k], sm.qvel[k], jv); }
+      for (int k = 0; k < NV16; k++) { Jwr(row * JS + k, Jr[k]); jv = fmaf(Jr[k], sm.qvel[k], jv); }
       if (valid) sm.e_aref[row] = -sm.e_force[row] * jv - sm.e_aref[row];
     }
     SYNC();
+    if constexpr (JG) jsync();   // the rows have left the wavefront before the solver's lanes read other lanes' rows back from global memory
   }
 
   // Wide configurations: the Jacobian rows on the matrix cores.  A contact row is J[r][k] = s2(r, k) (w2_r . cdof_k) - s1(r, k) (w1_r . cdof_k) with
@@ -3524,7 +3555,7 @@ struct Sim {
         for (int c0 = 0; c0 < nch; c0 += 4) {
           float ja[4], fb[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { const int r = 4 * (c0 + u) + (lane >> 4); ja[u] = sm.J[r * JS + (lane & 15)]; fb[u] = sm.e_force[r]; }
+          for (int u = 0; u < 4; u++) { const int r = 4 * (c0 + u) + (lane >> 4); ja[u] = Jrd(r * JS + (lane & 15)); fb[u] = sm.e_force[r]; }
 #pragma unroll
           for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ja[u], fb[u], acc, 0, 0, 0);
         }
@@ -3563,7 +3594,7 @@ struct Sim {
       const int r = w_.valid ? row : 0;
       if constexpr (FAST) {
 #pragma unroll
-        for (int k = 0; k < NV16; k++) w_.J[k] = sm.J[row * JS + k];  // rows >= n were written as zeros
+        for (int k = 0; k < NV16; k++) w_.J[k] = Jrd(row * JS + k);  // rows >= n were written as zeros
       }
       const int desc = w_.valid ? sm.e_desc[r] : 0;
       w_.type = w_.valid ? (desc & 15) : -1;
@@ -3641,9 +3672,9 @@ struct Sim {
 #pragma unroll
             for (int k2 = 0; k2 < CD; k2++) {
               if (k2 < w_.dim) {
-                const float* Js = sm.J + (w_.head + k2) * JS;
+                const int js = (w_.head + k2) * JS;
 #pragma unroll
-                for (int k = 0; k < NV16; k++) w[k] = fmaf(hk[k2], Js[k], w[k]);
+                for (int k = 0; k < NV16; k++) w[k] = fmaf(hk[k2], Jrd(js + k), w[k]);
               }
             }
           }
@@ -3734,7 +3765,7 @@ struct Sim {
         for (int c0 = 0; c0 < nch; c0 += 4) {
           float wa[4], jb[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { const int o = (4 * (c0 + u) + (lane >> 4)) * JS + (lane & 15); wa[u] = sm.u.W[o]; jb[u] = sm.J[o]; }
+          for (int u = 0; u < 4; u++) { const int o = (4 * (c0 + u) + (lane >> 4)) * JS + (lane & 15); wa[u] = sm.u.W[o]; jb[u] = Jrd(o); }
 #pragma unroll
           for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u], jb[u], acc, 0, 0, 0);
         }
@@ -4277,46 +4308,57 @@ struct Sim {
 // ------------------------------------------------------------------------------------------------------------
 // the step kernel
 // ------------------------------------------------------------------------------------------------------------
-template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR, bool DBG>
-__device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, const float* __restrict__ actions, int n_sub, int flags, int slot) {
+// What an env carries from the native body of a fused-tier kernel (RSIM_DIMS_W) into the wide body when a substep asks for more contacts / rows than the native
+// capacity: the substep to carry on with and the per-env values that live in registers.  The state arrays (qpos, qvel, qacc, qacc_warmstart, ctrl) stay where
+// they are -- both LDS layouts keep them at the same offsets -- and nothing else of a substep is persistent before its solver / integrator ran.
+struct Handover { int sub0; float time; bool fresh_ctrl; int ndiverged, need_con, need_efc; float cstate; unsigned t_launch; };
+
+// FUSED: 0 = the kernel holds this body only; 1 = native body of a fused-tier kernel (returns true, with `ho` filled, when the env has to carry on in the wide
+// body); 2 = the wide body of such a kernel (ho->sub0 > 0: carries on from the native body's LDS state at that substep; 0: an env that was on the tier already)
+template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR, bool DBG, int FUSED = 0>
+__device__ __forceinline__ bool step_body(const DModel& m, const DBatch& b, const float* __restrict__ actions, int n_sub, int flags, int slot, Handover* ho = nullptr) {
   typedef Smem<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR> SM;
   const int lane = threadIdx.x;
   // Capacity tiers (DBatch.tier_pass >= 0, rsim_api.cpp launch()): pass 0 = this configuration steps the envs whose tier is 0 and hands an env that
   // runs out of contact / row capacity to the redo list WITHOUT committing anything of the step; passes 1 / 2 = a wider configuration steps the
   // envs of a list (1: the envs that were close to the native capacity last step, 2: the redo list), `slot` = index into that list.
-  const int tpass = (!DBG && b.tier_cur) ? b.tier_pass : -1;
-  if (tpass <= 0 && slot >= (b.nenv ? b.nenv : b.B)) return;
+  // Fused-tier kernels: the native body is pass 0 without a redo list (it hands over in place), the wide body behaves as pass 2 on the env of its own slot.
+  const int tpass = (!DBG && b.tier_cur) ? (FUSED == 2 ? 2 : FUSED == 1 ? 0 : b.tier_pass) : -1;
+  const bool resume = FUSED == 2 && ho->sub0 > 0;
+  if ((tpass <= 0 || FUSED) && slot >= (b.nenv ? b.nenv : b.B)) return false;
   // workgroups are dispatched in index order: handing the envs that were slowest in the previous launch to the first workgroups
   // (contact-rich envs stay contact-rich for many control steps) keeps the last wave of envs short
-  const int env = uni(tpass > 0 ? b.wlist[slot] : (b.order ? b.order[slot] : slot) + b.env0);   // scalar: every per-env base address below then lives in SGPRs
+  const int env = uni((tpass > 0 && !FUSED) ? b.wlist[slot] : (b.order ? b.order[slot] : slot) + b.env0);   // scalar: every per-env base address below then lives in SGPRs
   // RF_RESET_ONLY: the pass that follows a control step and produces the observation MujocoEnv.reset() returns (forward + epilogue, no reward)
   // for the envs that step re-initialised from the reset bank; every other workgroup leaves at once
-  if ((flags & RF_RESET_ONLY) && !b.needs_reset[env]) return;
-  if (tpass == 0 && b.tier_cur[env] != 0) return;    // stepped by the wide configuration in this control step
-  const unsigned t_launch = b.cost ? (unsigned)uni((int)(clock64() >> 6)) : 0u;   // 64-tick units, scalar
+  if ((flags & RF_RESET_ONLY) && !b.needs_reset[env]) return false;
+  if (!FUSED && tpass == 0 && b.tier_cur[env] != 0) return false;    // stepped by the wide configuration in this control step (fused kernels: k_step picks the body)
+  const unsigned t_launch = resume ? ho->t_launch : (b.cost ? (unsigned)uni((int)(clock64() >> 6)) : 0u);   // 64-tick units, scalar
   const float* fp = m.ft + (size_t)env * m.fstride;
   Sim<SM> sim(m, fp, lane, b.prof, b.cm, b.cm_stride ? (const char*)b.cm_env + (size_t)env * b.cm_stride : (const char*)b.cm);
   sim.pf.acc = b.prof_env == -1 || b.prof_env == env;   // -1: every env, -2: none (undistorted wave log)
   if (b.prof) sim.pf.pairs = b.prof + RP_COUNT + 8 * (size_t)b.B;
   sim.pf.start();
-  if (b.prof && lane == 0) {
+  if (b.prof && lane == 0 && !resume) {
     unsigned long long* wl = b.prof + RP_COUNT + 8 * (size_t)env;
     wl[0] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
     wl[1] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
     wl[2] = wall_clock64();
   }
-  // ---- load state
-  for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = b.qpos[(size_t)env * m.nq + i];
-  for (int i = lane; i < m.nv; i += 64) { sm.qvel[i] = b.qvel[(size_t)env * m.nv + i]; sm.qacc_ws[i] = b.qacc_ws[(size_t)env * m.nv + i]; }
-  if (lane >= m.nv && lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.qacc[lane] = 0.f; }
-  for (int i = lane; i < m.nu; i += 64) sm.ctrl[i] = b.ctrl[(size_t)env * m.nu + i];
+  // ---- load state (an env handed over in mid-step finds qpos .. ctrl in LDS, as of the start of the substep it carries on with)
+  if (!resume) {
+    for (int i = lane; i < m.nq; i += 64) sm.qpos[i] = b.qpos[(size_t)env * m.nq + i];
+    for (int i = lane; i < m.nv; i += 64) { sm.qvel[i] = b.qvel[(size_t)env * m.nv + i]; sm.qacc_ws[i] = b.qacc_ws[(size_t)env * m.nv + i]; }
+    if (lane >= m.nv && lane < NV) { sm.qvel[lane] = 0.f; sm.qacc_ws[lane] = 0.f; sm.qacc[lane] = 0.f; }
+    for (int i = lane; i < m.nu; i += 64) sm.ctrl[i] = b.ctrl[(size_t)env * m.nu + i];
+  }
   const int cs = m.ctrl.cs_size, csl = cs < RSIM_CS_LDS ? cs : RSIM_CS_LDS;
   sim.cst = (gwf)(b.cstate + (size_t)env * cs);
   if (b.bpl) sim.bpl = (int __attribute__((address_space(1)))*)(b.bpl + (size_t)env * 320);
   if (b.mprc) { sim.mprc = (gwf)(b.mprc + (size_t)env * Sim<SM>::MPRC * m.npair); sim.mpr_portal = b.mprc_portal != 0; }
   if constexpr (Sim<SM>::JG) sim.Jg = (gwf)(b.jg + (size_t)env * b.jg_stride);   // one stride for every configuration that steps envs of this batch (the native and the wide pass run side by side)
   if constexpr (Sim<SM>::MG) sim.Mg = sim.Jg + SM::NEFC_ * SM::JS_;
-  if (lane < csl) sm.cstate[lane] = sim.cst[lane];
+  if (lane < csl) sm.cstate[lane] = resume ? ho->cstate : sim.cst[lane];
   if constexpr (DBG) if (b.qfrc_applied && lane < m.nv) sim.applied = b.qfrc_applied[(size_t)env * m.nv + lane];   // user forces of the B = 1 shim entries (GripperTester's gravity compensation)
   if (lane == 0) { sm.ncon = 0; sm.nefc = 0; sm.niter = 0; sm.polish = 0; }
   sim.load_opt();
@@ -4325,7 +4367,8 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
   float time = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, b.time[env])));   // wave-uniform, carried over all substeps: a scalar register
   bool fresh_ctrl = false;
   int ndiverged = 0;
-  if ((flags & RF_CTRL) && b.needs_reset[env]) {
+  if (resume) { time = ho->time; fresh_ctrl = ho->fresh_ctrl; ndiverged = ho->ndiverged; sim.need_con = ho->need_con; sim.need_efc = ho->need_efc; }
+  if (!resume && (flags & RF_CTRL) && b.needs_reset[env]) {
     // this env was re-initialised on the device when its previous episode ended: fresh controller objects (robots/robot.py:271)
     V3 xp0; Q4 xq0;
     if (lane < csl) sm.cstate[lane] = 0.f;
@@ -4338,7 +4381,10 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
     fresh_ctrl = true;   // the flag is cleared when the step is committed (a step handed to the wide configuration must find it still set)
   }
   sim.pf.mark(RP_LOAD);
-  for (int sub = 0; sub < n_sub; sub++) {
+  int sub = resume ? ho->sub0 : 0;
+  bool over = false;   // fused native body: this env carries on in the wide body from substep `sub`
+  const int force_sub = (FUSED == 1 && b.tier_pass >= 100) ? b.tier_pass - 100 : -1;   // test hook (RSIM_FORCE_HANDOVER): hand over at this substep whatever the demand
+  for (; sub < n_sub; sub++) {
     V3 xp; Q4 xq;
     sim.phase();
     sim.kinematics(xp, xq);
@@ -4354,9 +4400,11 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
     sim.phase();
     sim.collision(n_sub - sub);
     sim.pf.mark(RP_NARROW);
+    if (FUSED == 1 && tpass == 0 && (uni(sim.ovf) || sub == force_sub)) { over = true; break; }   // more contacts than this body holds: the wide body carries on with this substep (nothing of it is persistent yet)
     sim.phase();
     sim.make_constraint();
     sim.pf.mark(RP_MAKEC);
+    if (FUSED == 1 && tpass == 0 && uni(sim.ovf)) { over = true; break; }   // ... or more constraint rows
     sim.phase();
     sim.velocity(xp, xq);
     sim.pf.mark(RP_VEL);
@@ -4409,13 +4457,20 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
     }
     sim.pf.count(RP_N_SUB, 1);
   }
-  if (tpass == 0 && sim.ovf) {
+  if (FUSED == 1 && over) {
+    // hand-over in place: the env carries on in the wide body of this kernel from substep `sub`, on the LDS-resident state as the substeps before left it
+    ho->sub0 = sub; ho->time = time; ho->fresh_ctrl = fresh_ctrl; ho->ndiverged = ndiverged; ho->need_con = sim.need_con; ho->need_efc = sim.need_efc;
+    ho->cstate = lane < csl ? sm.cstate[lane] : 0.f; ho->t_launch = t_launch;
+    SYNC();   // (a hand-over in the first substep, sub0 == 0, is simply a wide step from the stored state)
+    return true;
+  }
+  if (!FUSED && tpass == 0 && sim.ovf) {
     // a substep asked for more contacts / rows than this configuration holds: nothing of this control step is committed (state, controller
     // state, episode counters, observation record are as they were); the env goes on the redo list and the wide configuration steps it from the
     // same state later in this same rsim_control_step.  The caches this pass touched (warm-start records, broadphase list) validate themselves.
     if (lane == 0) { b.wlist2[atomicAdd(b.wcount2, 1)] = env; b.tier_next[env] = 1; }
     if (b.cost && lane == 0) b.cost[env] = (unsigned)(clock64() >> 6) - t_launch;
-    return;
+    return false;
   }
   if (fresh_ctrl && lane == 0) b.needs_reset[env] = 0;
   if (ndiverged && lane == 0) b.diverged[env] += ndiverged;
@@ -4503,11 +4558,52 @@ __device__ __forceinline__ void step_body(const DModel& m, const DBatch& b, cons
       for (int i = lane; i < sm.nefc; i += 64) b.efc_force[(size_t)env * NEFC + i] = sm.e_force[i];
     if (lane == 0) { b.ncon[env] = ncon; b.nefc[env] = sm.nefc; b.niter[env] = sm.niter; if (b.polish) b.polish[env] = sm.polish; }
   }
+  return false;
 }
 
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
 __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
+#ifdef RSIM_DIMS_W
+  // fused-tier kernel: the workgroup steps its env with the native body; an env that is on the wide tier already (DBatch.tier_cur) or outgrows the native
+  // capacity in mid-step (step_body returns true) is stepped / carried on by the wide body in this same workgroup.  No list, no second launch: the envs that
+  // need the tier are the slowest of a control step, and a kernel of their own could not start before the native launch had drained.
+  // Both bodies read the kernel arguments straight from the kernarg segment.  Left to itself the compiler copies the by-value DModel / DBatch into the private
+  // segment once TWO bodies use them (2.4 KB of scratch per lane, every per-lane table lookup a scratch load: the copy is only elided while the uses of the
+  // argument stay below an analysis limit, which one body does and two do not).
+  typedef const char __attribute__((address_space(4)))* ka_t;
+  ka_t ka = (ka_t)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr size_t b_off = (sizeof(DModel) + alignof(DBatch) - 1) & ~(alignof(DBatch) - 1);
+  const DModel& mk = *(const DModel*)(const DModel __attribute__((address_space(4)))*)ka;
+  const DBatch& bk = *(const DBatch*)(const DBatch __attribute__((address_space(4)))*)(ka + b_off);
+#define m mk
+#define b bk
+  const int slot = (int)blockIdx.x;
+  Handover ho;
+  ho.sub0 = 0; ho.time = 0.f; ho.fresh_ctrl = false; ho.ndiverged = 0; ho.need_con = 0; ho.need_efc = 0; ho.cstate = 0.f; ho.t_launch = 0u;
+  bool wide = false;
+#ifdef RSIM_FUSED_TEST_WIDE_ONLY
+  step_body<RSIM_DIMS_W, false, 2>(m, b, actions, n_sub, flags, slot, &ho); return;
+#endif
+  if (b.tier_cur) {
+    if (slot >= (b.nenv ? b.nenv : b.B)) return;
+    wide = b.tier_cur[uni((b.order ? b.order[slot] : slot) + b.env0)] != 0;
+  }
+  if (!wide) {
+    const int over = uni(step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR, false, 1>(m, b, actions, n_sub, flags, slot, &ho) ? 1 : 0);
+    if (!over) return;
+#ifdef RSIM_FUSED_TEST_NATIVE_ONLY
+    return;
+#endif
+    // wave-uniform by construction; said so explicitly (the compiler sees them leave a branch on a vector condition)
+    ho.sub0 = uni(ho.sub0); ho.time = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, ho.time))); ho.fresh_ctrl = uni(ho.fresh_ctrl ? 1 : 0) != 0;
+    ho.ndiverged = uni(ho.ndiverged); ho.need_con = uni(ho.need_con); ho.need_efc = uni(ho.need_efc); ho.t_launch = (unsigned)uni((int)ho.t_launch);
+  }
+  step_body<RSIM_DIMS_W, false, 2>(m, b, actions, n_sub, flags, slot, &ho);
+#undef m
+#undef b
+#else
   step_body<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR, false>(m, b, actions, n_sub, flags, (int)blockIdx.x);
+#endif
 }
 // The same control step as the upper capacity tier of a batch whose model belongs to a narrower configuration: a fixed, small grid walks the list
 // of envs this pass steps (DBatch.wlist / wcount, filled on the device), so a control step in which no env needs the tier costs one empty launch.
@@ -4701,6 +4797,20 @@ extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStr
 }
 #endif  // RSIM_CFG == 0
 
+#if RSIM_CFG == 0
+// limits of the wide body of a fused-tier build (layout of rsim_limits); returns 0 when this build has none
+extern "C" int rsim_limits_w_cfg0(int* lim) {
+#ifdef RSIM_DIMS_W
+  const int dims[8] = {RSIM_DIMS_W};
+  for (int i = 0; i < 8; i++) lim[i] = dims[i];
+  lim[8] = SmemW::NROOT_; lim[9] = (SmemW::TENDONS_ ? 1 : 0) | (SmemW::NB_ > 32 ? 2 : 0) | (SmemW::JG_ ? 4 : 0) | (SmemW::MG_ ? 8 : 0) | (SmemW::CG_ ? 16 : 0) | 32;
+  static_assert(sizeof(Cmem<RSIM_DIMS_W>) == sizeof(Cmem0), "the wide body reads the native configuration's constant blocks");
+  return 1;
+#else
+  (void)lim; return 0;
+#endif
+}
+#endif
 // explicit instantiations + launchers (one set per configuration build) ----------------------------------------------------------
 template __global__ void k_step<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
 template __global__ void k_step_dbg<RSIM_DIMS>(DModel, DBatch, const float*, int, int);
@@ -4737,6 +4847,6 @@ extern "C" int RSIM_SYM(rsim_cmem_bytes)(void) { return (int)((sizeof(Cmem0) + 2
 extern "C" int RSIM_SYM(rsim_limits)(int* lim) {
   const int dims[8] = {RSIM_DIMS};
   for (int i = 0; i < 8; i++) lim[i] = dims[i];
-  lim[8] = Smem0::NROOT_; lim[9] = (Smem0::TENDONS_ ? 1 : 0) | (Smem0::NB_ > 32 ? 2 : 0) | (Smem0::JG_ ? 4 : 0) | (Smem0::MG_ ? 8 : 0) | (Smem0::CG_ ? 16 : 0);   // bit 2: the constraint Jacobian lives in DBatch.jg (NEFC * (NV + 1) floats per env)   // bit 1: two OSC arm parts
+  lim[8] = Smem0::NROOT_; lim[9] = (Smem0::TENDONS_ ? 1 : 0) | (Smem0::NB_ > 32 ? 2 : 0) | (Smem0::JG_ ? 4 : 0) | (Smem0::MG_ ? 8 : 0) | (Smem0::CG_ ? 16 : 0) | (RSIM_FUSED_ENABLED ? 32 : 0);   // bit 5: the capacity tier above this configuration is compiled into its control-step kernel (rsim_limits_w)   // bit 2: the constraint Jacobian lives in DBatch.jg (NEFC * (NV + 1) floats per env)   // bit 1: two OSC arm parts
   return 0;
 }

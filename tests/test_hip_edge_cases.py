@@ -481,6 +481,53 @@ def test_capacity_tiers_step_an_env_beyond_the_native_capacity_without_dropping_
     assert errs[0][2] > 50 * errs[0][0], errs          # dropping 10 of 26 contacts is a different problem: 1e-2 after one control step
 
 
+def test_fused_tier_hand_over_in_mid_step_carries_the_step_on(monkeypatch):
+    """Round 6: the tier above the Lift configuration is a second body inside its control-step kernel; an env that outgrows the native capacity at substep k
+    carries on in the wide body from that substep, on the LDS-resident state (qpos, qvel, warm start, actuator ctrl, controller state, time, episode flags).
+    RSIM_FORCE_HANDOVER=k makes every env hand over at substep k whatever its demand: the control step must then end where the native body alone takes it
+    (the two bodies differ in row slots and the memory J lives in, not in the algorithm), at every k, including with a fresh controller (needs_reset) and
+    across an episode end; the demand counters, observation record and reward come out the same."""
+    from robosuite_amd import lift
+    flat, cfg = _lift_assets()
+    ids = np.arange(24)
+    T0 = 60   # contact-rich by then (hand at the table, cube pushed around)
+    tape = torch.tensor(lift.env_actions(ids, T0 + 4), device="cuda")
+
+    def run(force):
+        monkeypatch.delenv("RSIM_FORCE_HANDOVER", raising=False)
+        env = lift.LiftBatch(flat, cfg, ids, seed0=0, horizon=T0 + 2, bank_episodes=3)   # the episode ends inside the compared steps: on-device reset + fresh controllers
+        b = env.batch
+        for t in range(T0):
+            env.step(tape[t])
+        b.sync()
+        out = []
+        for t in range(T0, T0 + 4):
+            if force is not None:
+                monkeypatch.setenv("RSIM_FORCE_HANDOVER", str(force[t - T0]))
+            env.step(tape[t])
+            b.sync()
+            out.append({k: b.get(k).copy() for k in ("qpos", "qvel", "qacc_warmstart", "ctrl", "time", "cstate", "obs", "reward", "ep_step", "ep_index", "done", "cap_need", "overflow", "diverged")})
+        monkeypatch.delenv("RSIM_FORCE_HANDOVER", raising=False)
+        env.bank_quiesce(); env._bank_stop()
+        return out
+
+    ref = run(None)
+    assert ref[1]["done"].all() and not ref[0]["done"].any()          # step T0 + 1 ends every episode
+    for force in ([7, 7, 7, 7], [1, 24, 12, 3], [0, 0, 0, 0]):
+        got = run(force)
+        for t in range(4):
+            for k in ("ep_step", "ep_index", "done", "overflow", "diverged"):
+                assert np.array_equal(got[t][k], ref[t][k]), (force, t, k)
+            assert np.array_equal(got[t]["time"], ref[t]["time"]), (force, t)
+            dq, dv = np.abs(got[t]["qpos"] - ref[t]["qpos"]).max(), np.abs(got[t]["qvel"] - ref[t]["qvel"]).max()
+            dc, do = np.abs(got[t]["cstate"] - ref[t]["cstate"]).max(), np.abs(got[t]["obs"] - ref[t]["obs"]).max()
+            print(f"forced hand-over at substep {force[t]}, control step {t}: |dq| {dq:.1e} |dv| {dv:.1e} |dcstate| {dc:.1e} |dobs| {do:.1e}")
+            # the two bodies solve the same problem with rows in other lanes: fp32 noise, growing a little over chaotic contact steps
+            assert dq < 2e-4 * (t + 1) and dv < 5e-3 * (t + 1) and dc < 1e-3 * (t + 1), (force, t, dq, dv, dc)
+            assert np.abs(got[t]["reward"] - ref[t]["reward"]).max() < 1e-3
+        assert np.array_equal(got[0]["cap_need"], ref[0]["cap_need"])       # same contacts found in the first compared step (identical state going in)
+
+
 def test_capacity_tiers_with_per_env_model_parameters_and_stream_groups():
     """The wide configuration reads an env's OWN constant block (per-episode cube sizes: built on demand right before the wide pass steps the env);
     with stream groups every env block runs its own native pass, wide pass and redo pass on its own stream.  Same envs, same results."""

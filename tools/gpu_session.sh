@@ -28,7 +28,7 @@ try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     c = d["config"]; r = d["roofline"]
     print(f"{sys.argv[1]}: value {d['value']:.0f} ms/step {d['ms_per_step']:.3f} kernel_ms {r['kernel_ms']:.3f} overflow_envs {c.get('overflow_envs')} capacity {c.get('capacity')} diverged {c.get('diverged_envs')} "
-          f"dbuf {(c.get('double_buffered') or {}).get('value')} open {(c.get('open_loop') or {}).get('value')} issue {(r.get('issue') or {}).get('frac')} traffic {r.get('traffic')}")
+          f"dbuf {(c.get('double_buffered') or {}).get('value')} open {(c.get('open_loop') or {}).get('value')} issue {(r.get('issue') or {}).get('frac') if isinstance(r.get('issue'), dict) else r.get('issue')} traffic {r.get('traffic')}")
 except Exception as e:
     print(sys.argv[1], "unreadable:", e)
 EOF
