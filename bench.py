@@ -165,7 +165,10 @@ def pmc_evidence(name, key, lib_sha, config=None):
 # (timed steps, untimed pre-roll launches) of the secondary regions of the default command: the quick-bench protocol of tools/ab_many.sh where a control step takes a few
 # milliseconds (2 - 3 s per region), a shorter one for PickPlace (91 ms per step).  Round 5, session 15: ten steps after fifty said 603 K for Stack where the longer
 # protocols say 647 K (quick) / 620 - 650 K (full): the first control steps after a cold start carry the redo passes in which envs find their capacity tier.
-OTHER_REGION = {"stack": (50, 300), "peg": (50, 300), "pickplace": (10, 50)}
+# Round 6: the pre-roll of every secondary region is the horizon, as for the headline -- every env has then passed an on-device reset and sits at its staggered
+# episode step, the tiers are found and the record says "steady_state": true (a shorter --other-preroll says false).  The round-5 PickPlace child (10 steps after 50)
+# read 6 % above the full protocol.
+OTHER_REGION = {"stack": (50, HORIZON), "peg": (50, HORIZON), "pickplace": (20, HORIZON)}
 
 
 def other_region(args, config):
@@ -173,10 +176,57 @@ def other_region(args, config):
     return (args.other_steps if args.other_steps >= 0 else k), (args.other_preroll if args.other_preroll >= 0 else p)
 
 
-def secondary_region(config, rank, local_rank, world, dev, K, P):
+def step_stats(ms):
+    """Distribution of the per-step durations of a timed region (HIP events around every control step on the stream it runs on): a slow window explains itself."""
+    a = np.asarray(ms, dtype=np.float64)
+    return {"min": float(a.min()), "p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "max": float(a.max())}
+
+
+def double_buffered_region(config, flat, cfg, ids, local_rank, dev, world, dr, P, K, adim):
+    """Closed-loop compatible: the batch as two halves (two rsim batches on their own streams) stepped alternately; the host waits for a half's step t (the point
+    where a policy would read that half's observations) before it issues that half's step t + 1, the other half steps meanwhile.  Returns (seconds, bank_stale)."""
+    halves = [ids[:len(ids) // 2], ids[len(ids) // 2:]]
+    envs2 = [build_env(config, flat, cfg, h, local_rank, 3 + (P + K) // HORIZON) for h in halves]
+    tapes2 = [torch.tensor(lift.env_actions(h, P + K, action_dim=adim), device=dev) for h in halves]
+    if P:
+        for e2, h in zip(envs2, halves):
+            e2.batch.set("ep_step", ((197 * h) % HORIZON).astype(np.int32))
+    drs = [0, 0]
+
+    def step2(k, t):
+        if dr:
+            envs2[k].batch.randomize_dynamics(seed=11, step=drs[k]); drs[k] += 1
+        envs2[k].step(tapes2[k][t])
+
+    for t in range(P):
+        for k in (0, 1):
+            step2(k, t)
+    for e2 in envs2:
+        e2.batch.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for t in range(K):
+        for k in (0, 1):
+            envs2[k].batch.sync()          # half k's observations of step t - 1 are complete: its policy can act
+            step2(k, P + t)
+    for e2 in envs2:
+        e2.batch.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt3 = shard.max_over_ranks(time.perf_counter() - t0, dev)
+    stale3 = sum(float(e2.batch.tensor("bank_stale").sum().item()) for e2 in envs2)
+    for e2 in envs2:
+        e2.bank_quiesce(); e2._bank_stop()
+    return dt3, int(stale3), [len(h) for h in halves]
+
+
+def secondary_region(config, rank, local_rank, world, dev, K, P, double_buffer=True):
     """K lockstep control steps of another BASELINE configuration at its stated batch size, after P untimed launches from staggered episode steps (same
-    protocol as the headline region, shorter): ms per step, env-steps/s, dropped / diverged envs and the VALU issue fraction when PMC evidence of this
-    build exists."""
+    protocol as the headline region): ms per step and its distribution, env-steps/s, dropped / diverged envs, tier statistics, the VALU issue fraction and
+    HBM traffic per launch when PMC evidence of this build exists, and the two-half (double-buffered) figure."""
     label, stem, B, dr, which = CONFIGS[config]
     flat, cfg = factory.load_shipped(stem)
     ids = shard.env_block(B * world, rank, world)
@@ -195,13 +245,19 @@ def secondary_region(config, rank, local_rank, world, dev, K, P):
     env.batch.sync(); torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
+    tier0 = env.batch.tier_stats()
+    s_ = torch.cuda.ExternalStream(env.batch.stream(), device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     t0 = time.perf_counter()
     for t in range(K):
+        ev[t][0].record(s_)
         step(P + t)
+        ev[t][1].record(s_)
     env.batch.sync(); torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     dt = shard.max_over_ranks(time.perf_counter() - t0, dev)
+    tier1 = env.batch.tier_stats()
     q = env.batch.tensor("qpos")
     div = shard.max_over_ranks(float(int((~torch.isfinite(q).all(dim=1)).sum().item()) + int((env.batch.tensor("diverged") > 0).sum().item())), dev)
     ovf = shard.max_over_ranks(float((env.batch.tensor("overflow") > 0).sum().item()), dev)
@@ -209,13 +265,21 @@ def secondary_region(config, rank, local_rank, world, dev, K, P):
     lib_sha = hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16]
     valu = pmc_evidence(f"valu_count_{config}.json", "valu_per_env_substep", lib_sha, config)
     issue = valu if isinstance(valu, str) or valu is None else valu * B * world * N_SUB * K / dt / (world * VALU_ISSUE_PEAK)
+    traffic = pmc_evidence(f"hbm_traffic_{config}.json", "bytes_per_launch", lib_sha, config)
     env.bank_quiesce(); env._bank_stop()
-    out = {"workload": f"{label} (BASELINE {which})", "envs_per_gpu": B, "steps": K, "preroll": P, "value": B * world * K / dt, "unit": "env-steps/s",
-           "ms_per_step": 1e3 * dt / K, "overflow_envs": int(ovf), "diverged_envs": int(div),
+    out = {"workload": f"{label} (BASELINE {which})", "envs_per_gpu": B, "steps": K, "preroll": P, "steady_state": bool(P >= HORIZON), "value": B * world * K / dt, "unit": "env-steps/s",
+           "ms_per_step": 1e3 * dt / K, "step_ms": step_stats([a.elapsed_time(b_) for a, b_ in ev]), "overflow_envs": int(ovf), "diverged_envs": int(div),
+           "tier_env_steps": tier1[0] - tier0[0], "tier_changes_in_mid_step": tier1[1] - tier0[1],
            "max_contacts_needed": int(cn[:, 0].max().item()), "max_rows_needed": int(cn[:, 1].max().item()), "capacity": [env.batch.maxcon, env.batch.maxefc],
-           "issue_frac": issue, "dynamics_randomisation": "re-drawn before every control step" if dr else None}
+           "issue_frac": issue, "traffic": traffic, "algorithmic_bytes_per_launch": algorithmic_bytes_per_env_step(env, flat, dr) * B,
+           "dynamics_randomisation": "re-drawn before every control step" if dr else None}
+    adim = env.model.action_dim
     del env, tape
     torch.cuda.empty_cache()
+    if double_buffer:
+        dt3, stale3, hl = double_buffered_region(config, flat, cfg, ids, local_rank, dev, world, dr, P, K, adim)
+        out["double_buffered"] = {"value": B * world * K / dt3, "ms_per_step": 1e3 * dt3 / K, "steps": K, "halves": hl, "bank_stale": stale3}
+        torch.cuda.empty_cache()
     return out
 
 
@@ -235,6 +299,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="lift only: skip the short secondary regions of BASELINE configs[2..4] (config.other_configs)")
     ap.add_argument("--other-steps", type=int, default=-1, help="timed lockstep control steps of each secondary configuration (default: OTHER_REGION, 50 where a step takes a few ms, 10 for PickPlace)")
     ap.add_argument("--other-preroll", type=int, default=-1, help="untimed launches before each secondary region (episode steps staggered as in the headline region; default: OTHER_REGION, 300 / 50)")
+    ap.add_argument("--allow-collective-fallback", action="store_true", help="N > 1: if the C-ABI RCCL communicator cannot be formed, reduce the rollout statistics through torch.distributed (reported as \"collective\": \"fallback: ...\") instead of failing")
     ap.add_argument("--secondary-only", choices=sorted(CONFIGS), default=None, help="internal: run one secondary region and print its record (the default run starts one child per configuration)")
     args = ap.parse_args()
 
@@ -296,6 +361,7 @@ def main():
         step(t)
     env.batch.sync(); torch.cuda.synchronize(); barrier()
     ring0 = env.bank_stats()
+    tier0 = env.batch.tier_stats()
 
     def timed(first, n, strs):
         ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in strs] for _ in range(n)]
@@ -314,6 +380,7 @@ def main():
     dt, evms = timed(W, K, [torch.cuda.ExternalStream(env.batch.stream(), device=dev)])
     kern_ms = float(np.mean(evms))   # one control step of all B envs: dispatch order + k_step + reset passes
     ring1 = env.bank_stats()
+    tier1 = env.batch.tier_stats()
     if os.environ.get("RSIM_BENCH_TRACE"):
         print("per-step ms:", " ".join(f"{r[0]:.2f}" for r in evms), file=sys.stderr)
     # ---- secondary regions: BASELINE configs[2..4] at their stated batch sizes, a short lockstep region each, so that the clock of whoever runs the
@@ -357,52 +424,26 @@ def main():
     # step t complete (stream synchronisation = the point where a policy would read that half's observations) -- while the other half is stepping
     double_buffered = None
     if K2 and not args.no_double_buffer:
-        halves = [ids[:len(ids) // 2], ids[len(ids) // 2:]]
-        envs2 = [build_env(args.config, flat, cfg, h, local_rank, 3 + (P + W + K) // HORIZON) for h in halves]
-        tapes2 = [torch.tensor(lift.env_actions(h, P + W + K, action_dim=adim), device=dev) for h in halves]
-        if P:
-            for e2, h in zip(envs2, halves):
-                e2.batch.set("ep_step", ((197 * h) % HORIZON).astype(np.int32))
-        drs = [0, 0]
-
-        def step2(k, t):
-            if dr:
-                envs2[k].batch.randomize_dynamics(seed=11, step=drs[k]); drs[k] += 1
-            envs2[k].step(tapes2[k][t])
-
-        for t in range(P + W):
-            for k in (0, 1):
-                step2(k, t)
-        for e2 in envs2:
-            e2.batch.sync()
-        torch.cuda.synchronize(); barrier()
-        t0 = time.perf_counter()
-        for t in range(K):
-            for k in (0, 1):
-                envs2[k].batch.sync()          # half k's observations of step t - 1 are complete: its policy can act
-                step2(k, P + W + t)
-        for e2 in envs2:
-            e2.batch.sync()
-        torch.cuda.synchronize(); barrier()
-        dt3 = shard.max_over_ranks(time.perf_counter() - t0, dev)
-        stale3 = sum(float(e2.batch.tensor("bank_stale").sum().item()) for e2 in envs2)
-        double_buffered = {"value": B * world * K / dt3, "ms_per_step": 1e3 * dt3 / K, "steps": K, "halves": [len(h) for h in halves], "bank_stale": int(stale3),
+        dt3, stale3, hl = double_buffered_region(args.config, flat, cfg, ids, local_rank, dev, world, dr, P + W, K, adim)
+        double_buffered = {"value": B * world * K / dt3, "ms_per_step": 1e3 * dt3 / K, "steps": K, "halves": hl, "bank_stale": stale3,
                            "note": "closed-loop compatible: two half-batches (two rsim batches on their own streams) stepped alternately; the host waits for a half's "
                                    "step t (its observations) before it issues that half's step t + 1, the other half steps meanwhile -- what a policy evaluated per "
                                    "half can reach; `value` above is the stricter one-policy-call-per-step protocol"}
-        del envs2, tapes2
 
-    # the end-of-rollout statistics go through the C-ABI's own collective (rsim_comm_* / rsim_allreduce_stats over RCCL) when there is more than one rank; if
-    # that communicator cannot be formed the job's torch process group carries them and the line says so (config.stats_allreduce)
+    # the end-of-rollout statistics go through the C-ABI's own collective (rsim_comm_* / rsim_allreduce_stats over RCCL) when there is more than one rank.  If
+    # that communicator cannot be formed the run FAILS (exit code 4) unless --allow-collective-fallback was given, in which case the job's torch process group
+    # carries the numbers and the line says so at top level ("collective": "fallback: ..."): a multi-GPU line that never touched the C-ABI collective must not
+    # look like one that did (round-5 review).  shard.hip_comm raises on every rank or on none.
     comm, comm_note = None, None
     if world > 1:
         try:
             comm = shard.hip_comm(rank, world, local_rank)
-        except Exception as e:   # noqa: BLE001
-            comm_note = f"rsim_comm_create failed ({type(e).__name__}: {e})"
-        ok = shard.max_over_ranks(0.0 if comm is not None else 1.0, dev) == 0.0   # all ranks or none
-        if not ok:
-            comm = None
+        except shard.CommUnavailable as e:
+            comm_note = str(e)
+            if not args.allow_collective_fallback:
+                print(f"bench.py rank {rank}: the C-ABI collective is unavailable ({e}); pass --allow-collective-fallback to reduce through torch.distributed instead", file=sys.stderr, flush=True)
+                torch.distributed.destroy_process_group()
+                raise SystemExit(4)
     st = shard.RolloutStats(dev, comm=comm)
     q = env.batch.tensor("qpos")
     # envs that hit the bad-state guard (RSIM_DIVERGED, MuJoCo's mj_checkPos semantics) or hold a non-finite coordinate
@@ -435,12 +476,17 @@ def main():
         dsteps = max(1, ring1["steps"] - ring0["steps"])
         out = {
             "metric": f"env-steps/sec (whole node), {label.split(' +')[0]} @{B} envs/GPU", "value": tot["env_steps"] / dt, "unit": "env-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K,
+            # per-step durations of the timed region on rank 0 (HIP events on the batch's stream) and what the capacity tier did in it: a slow window explains itself
+            "step_ms": step_stats([r[0] for r in evms]), "tier_env_steps": tier1[0] - tier0[0], "tier_changes_in_mid_step": tier1[1] - tier0[1],
+            "collective": ("none (one rank)" if world == 1 else ("rsim_allreduce_stats (C-ABI, RCCL)" if comm is not None else f"fallback: torch.distributed; {comm_note}")),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}, 25 substeps x dt 0.002 + controllers per substep, fused in one launch per env (BASELINE {which})",
                        "envs_per_gpu": B, "global_envs": B * world, "n_sub": N_SUB, "per_env_seeded_reset": True, "horizon": HORIZON, "on_device_auto_reset": True,
                        "protocol": "lockstep: one control step of all envs per call, the next starts when all have finished (closed-loop compatible)",
                        "open_loop": open_loop, "double_buffered": double_buffered, "dynamics_randomisation": "re-drawn before every control step" if dr else None,
+                       "steady_state": bool(P >= HORIZON), "episode_window": [P + W, P + W + K],
                        "episode_phase": (f"uniform over the horizon: step counters offset by (197 i) mod 500, then {P} untimed pre-roll launches" if P else "fresh: all envs at step W of their first episode"),
                        "reset_ring": {"bank_stale": int(bank_stale), "polls_in_region": ring1["polls"] - ring0["polls"], "rows_refilled_in_region": ring1["rows"] - ring0["rows"],
                                       "stepping_thread_ms_per_1000_steps": 1e6 * (ring1["tick_s"] - ring0["tick_s"]) / dsteps,

@@ -247,6 +247,7 @@ def lib():
         L.rsim_group_stream.restype = vp; L.rsim_group_stream.argtypes = [vp, C.c_int]
         L.rsim_profile_env.argtypes = [vp, C.c_int]
         L.rsim_tier_snapshot.argtypes = [vp, vp]
+        L.rsim_tier_stats.argtypes = [vp, vp]
         L.rsim_name2id.argtypes = [vp, C.c_char_p, C.c_char_p]
         L.rsim_id2name.argtypes = [vp, C.c_char_p, C.c_int]; L.rsim_id2name.restype = C.c_char_p
         L.rsim_full_M.argtypes = [vp, C.c_int, vp]
@@ -616,6 +617,12 @@ class HipBatch:
         out = np.zeros(self.B, dtype=np.int32)
         _chk(self._L.rsim_tier_snapshot(self.ptr, out.ctypes.data))
         return out
+
+    def tier_stats(self):
+        """(env-steps the wider capacity tier stepped, of these handed over / redone in mid-step) since the batch was created; synchronises the stream."""
+        out = np.zeros(2, dtype=np.uint64)
+        _chk(self._L.rsim_tier_stats(self.ptr, out.ctypes.data))
+        return int(out[0]), int(out[1])
 
     def wavelog(self):
         """Per-env {hw_id, xcc_id, t_start, t_end} of the last launch (profiling must be armed)."""

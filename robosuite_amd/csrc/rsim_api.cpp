@@ -916,6 +916,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
     if (dalloc((char**)&b->d_cm_w, b->cm_bytes_w * (1 + (b->per_env ? (size_t)B : 0)))) return 1;
     for (int k = 0; k < 2; k++) if (dalloc(&b->d_tier[k], (size_t)B) || dalloc(&b->d_wlist[k], (size_t)B)) return 1;
     if (dalloc(&b->d_wcount, (size_t)2 * (2 + 2 * RSIM_MAX_GROUPS))) return 1;
+    if (dalloc(&b->db.tstat, (size_t)2)) return 1;
+    HIPCHK(hipMemset(b->db.tstat, 0, 2 * sizeof(unsigned long long)));
     {
       // the wide pass runs beside the native one on a stream of the highest priority (its few workgroups are the slowest envs of the step)
       int lo = 0, hi = 0;
@@ -980,7 +982,7 @@ extern "C" void rsim_batch_free(rsim_batch* b) {
   hipFree(b->d_cm);
   if (b->cfg_w >= 0) {
     hipStreamSynchronize(b->wstream); hipStreamDestroy(b->wstream); hipEventDestroy(b->wfork); hipEventDestroy(b->wjoin);
-    hipFree(b->d_cm_w); hipFree(b->d_wcount);
+    hipFree(b->d_cm_w); hipFree(b->d_wcount); hipFree(b->db.tstat);
     for (int k = 0; k < 2; k++) { hipFree(b->d_tier[k]); hipFree(b->d_wlist[k]); }
   }
   if (b->db.mprc) hipFree(b->db.mprc);
@@ -1627,6 +1629,17 @@ extern "C" int rsim_profile_env(rsim_batch* b, int env) { b->db.prof_env = env; 
 // Capacity tier of every env for the NEXT control step (0: the native configuration steps it, 1: the wider one), host int32 [B]; all zeros for a batch without a
 // tier above its configuration.  Diagnostics (tools/window_trace.py, bench.py's per-step record): an env whose entry went 0 -> 1 over a control step was handed
 // over in mid-step (redone), an env at 1 is on next step's wide list.
+// {env-steps the wider capacity tier stepped, env-steps of these that were handed over (fused tier) / redone (tier kernels) in mid-step} since the batch was created
+extern "C" int rsim_tier_stats(rsim_batch* b, unsigned long long* out2) {
+  if (!out2) return fail("rsim_tier_stats: null destination");
+  out2[0] = out2[1] = 0;
+  if (b->cfg_w < 0 || !b->db.tstat) return 0;
+  HIPCHK(hipSetDevice(b->device));
+  if (join_groups(b)) return 1;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(out2, b->db.tstat, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return 0;
+}
 extern "C" int rsim_tier_snapshot(rsim_batch* b, int* host_tier) {
   if (!host_tier) return fail("rsim_tier_snapshot: null destination");
   HIPCHK(hipSetDevice(b->device));

@@ -191,6 +191,7 @@ struct DBatch {
   int* wlist2; int* wcount2;
   int tier_pass;         // -1 (or tier_cur == null): no tiers; 0: native pass; 1 / 2: wide pass over wlist
   int tier_con, tier_efc;
+  unsigned long long* tstat;   // [2] or null: env-steps the wider capacity tier stepped (in whole or from mid-step on) | of these, env-steps handed over / redone in mid-step (rsim_tier_stats)
   int tier_up_con, tier_up_efc;   // an env moves up once a substep came within this many contacts / rows of the native capacity (and back down 2 / 8 below that)
   int* cap_need;         // [B][2] largest number of contacts / constraint rows any substep of the env asked for (RSIM_CAP_NEED), null = not tracked
   int mprc_portal;       // 0: keep only the (exact) separating-direction warm start

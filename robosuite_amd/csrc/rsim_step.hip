@@ -4311,7 +4311,7 @@ struct Sim {
 // What an env carries from the native body of a fused-tier kernel (RSIM_DIMS_W) into the wide body when a substep asks for more contacts / rows than the native
 // capacity: the substep to carry on with and the per-env values that live in registers.  The state arrays (qpos, qvel, qacc, qacc_warmstart, ctrl) stay where
 // they are -- both LDS layouts keep them at the same offsets -- and nothing else of a substep is persistent before its solver / integrator ran.
-struct Handover { int sub0; float time; bool fresh_ctrl; int ndiverged, need_con, need_efc; float cstate; unsigned t_launch; };
+struct Handover { int sub0; float time; bool fresh_ctrl, handed; int ndiverged, need_con, need_efc; float cstate; unsigned t_launch; };
 
 // FUSED: 0 = the kernel holds this body only; 1 = native body of a fused-tier kernel (returns true, with `ho` filled, when the env has to carry on in the wide
 // body); 2 = the wide body of such a kernel (ho->sub0 > 0: carries on from the native body's LDS state at that substep; 0: an env that was on the tier already)
@@ -4459,7 +4459,7 @@ __device__ __forceinline__ bool step_body(const DModel& m, const DBatch& b, cons
   }
   if (FUSED == 1 && over) {
     // hand-over in place: the env carries on in the wide body of this kernel from substep `sub`, on the LDS-resident state as the substeps before left it
-    ho->sub0 = sub; ho->time = time; ho->fresh_ctrl = fresh_ctrl; ho->ndiverged = ndiverged; ho->need_con = sim.need_con; ho->need_efc = sim.need_efc;
+    ho->handed = true; ho->sub0 = sub; ho->time = time; ho->fresh_ctrl = fresh_ctrl; ho->ndiverged = ndiverged; ho->need_con = sim.need_con; ho->need_efc = sim.need_efc;
     ho->cstate = lane < csl ? sm.cstate[lane] : 0.f; ho->t_launch = t_launch;
     SYNC();   // (a hand-over in the first substep, sub0 == 0, is simply a wide step from the stored state)
     return true;
@@ -4474,6 +4474,7 @@ __device__ __forceinline__ bool step_body(const DModel& m, const DBatch& b, cons
   }
   if (fresh_ctrl && lane == 0) b.needs_reset[env] = 0;
   if (ndiverged && lane == 0) b.diverged[env] += ndiverged;
+  if (tpass > 0 && b.tstat && lane == 0) { atomicAdd(b.tstat, 1ull); if (FUSED == 2 ? ho->handed : tpass == 2) atomicAdd(b.tstat + 1, 1ull); }   // a step the wider tier committed (rsim_tier_stats)
   if (tpass >= 0 && lane == 0) {
     // next step's tier: up when a substep came within a few contacts / rows of the native capacity (so that most hand-overs happen between steps,
     // without a redo), down again once the demand has dropped well below it
@@ -4561,8 +4562,13 @@ __device__ __forceinline__ bool step_body(const DModel& m, const DBatch& b, cons
   return false;
 }
 
+#ifdef RSIM_WAVES_PER_EU   /* experiment builds: state the occupancy target to the register allocator directly (launch_bounds' second argument tops out at two for 64-thread blocks) */
+#define RSIM_KSTEP_ATTR __attribute__((amdgpu_waves_per_eu(RSIM_WAVES_PER_EU, RSIM_WAVES_PER_EU)))
+#else
+#define RSIM_KSTEP_ATTR
+#endif
 template <int NB, int NJ, int NV, int NG, int NS, int NCON, int NEFC, int NPAIR>
-__global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
+__global__ RSIM_KSTEP_ATTR __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, const float* __restrict__ actions, int n_sub, int flags) {
 #ifdef RSIM_DIMS_W
   // fused-tier kernel: the workgroup steps its env with the native body; an env that is on the wide tier already (DBatch.tier_cur) or outgrows the native
   // capacity in mid-step (step_body returns true) is stepped / carried on by the wide body in this same workgroup.  No list, no second launch: the envs that
@@ -4579,7 +4585,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
 #define b bk
   const int slot = (int)blockIdx.x;
   Handover ho;
-  ho.sub0 = 0; ho.time = 0.f; ho.fresh_ctrl = false; ho.ndiverged = 0; ho.need_con = 0; ho.need_efc = 0; ho.cstate = 0.f; ho.t_launch = 0u;
+  ho.sub0 = 0; ho.time = 0.f; ho.fresh_ctrl = false; ho.handed = false; ho.ndiverged = 0; ho.need_con = 0; ho.need_efc = 0; ho.cstate = 0.f; ho.t_launch = 0u;
   bool wide = false;
 #ifdef RSIM_FUSED_TEST_WIDE_ONLY
   step_body<RSIM_DIMS_W, false, 2>(m, b, actions, n_sub, flags, slot, &ho); return;
@@ -4595,7 +4601,7 @@ __global__ __launch_bounds__(64, RSIM_MINWAVES) void k_step(DModel m, DBatch b, 
     return;
 #endif
     // wave-uniform by construction; said so explicitly (the compiler sees them leave a branch on a vector condition)
-    ho.sub0 = uni(ho.sub0); ho.time = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, ho.time))); ho.fresh_ctrl = uni(ho.fresh_ctrl ? 1 : 0) != 0;
+    ho.sub0 = uni(ho.sub0); ho.time = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, ho.time))); ho.fresh_ctrl = uni(ho.fresh_ctrl ? 1 : 0) != 0; ho.handed = true;
     ho.ndiverged = uni(ho.ndiverged); ho.need_con = uni(ho.need_con); ho.need_efc = uni(ho.need_efc); ho.t_launch = (unsigned)uni((int)ho.t_launch);
   }
   step_body<RSIM_DIMS_W, false, 2>(m, b, actions, n_sub, flags, slot, &ho);

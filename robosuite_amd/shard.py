@@ -48,9 +48,19 @@ def init_process_group(backend: str | None = None):
     return rank, local_rank, world
 
 
-def hip_comm(rank: int, world: int, device: int):
+class CommUnavailable(RuntimeError):
+    """The C-ABI communicator could not be formed on some rank; raised on EVERY rank (the ranks agree before anyone joins)."""
+
+
+def hip_comm(rank: int, world: int, device: int, unique_id=None, create=None):
     """The C-ABI's own RCCL communicator (include/rsim.h rsim_comm_*, backend.HipComm) for a job that was launched under torch.distributed: rank 0 draws the
-    unique id, the job's process group carries its 128 bytes to the other ranks, every rank joins.  Returns None for world size 1."""
+    unique id, the job's process group carries its 128 bytes to the other ranks, every rank joins.  Returns None for world size 1.
+
+    Collective-safe: every rank runs the SAME sequence of collectives whatever fails where (round-5 advisor finding: a rank that raised before the broadcast
+    left the others blocked in it).  Rank 0 always broadcasts [status byte | 128-byte id]; a failed draw travels as status 1 and every rank raises
+    CommUnavailable without calling rsim_comm_create.  After the creation the ranks agree (MAX over ranks of a failure flag) and all of them either keep
+    their communicator or free it and raise.  A rank that dies INSIDE ncclCommInitRank can still stall the others in it -- that is RCCL's own rendezvous.
+    `unique_id` / `create` replace HipComm.unique_id / HipComm (the gloo tests inject failures through them)."""
     import torch
     import torch.distributed as dist
 
@@ -58,12 +68,34 @@ def hip_comm(rank: int, world: int, device: int):
 
     if world == 1:
         return None
+    unique_id = unique_id or HipComm.unique_id
+    create = create or HipComm
     dev = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
-    buf = torch.zeros(HipComm.ID_BYTES, dtype=torch.uint8, device=dev)
+    buf = torch.zeros(1 + HipComm.ID_BYTES, dtype=torch.uint8, device=dev)
+    note = ""
     if rank == 0:
-        buf.copy_(torch.frombuffer(bytearray(HipComm.unique_id()), dtype=torch.uint8))
+        try:
+            uid = bytes(unique_id())
+            if len(uid) != HipComm.ID_BYTES:
+                raise ValueError(f"unique id of {len(uid)} bytes")
+            buf[1:].copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
+        except Exception as e:   # noqa: BLE001 -- reported to every rank through the status byte
+            buf[0] = 1
+            note = f"{type(e).__name__}: {e}"
     dist.broadcast(buf, src=0)
-    return HipComm(bytes(buf.cpu().numpy().tobytes()), rank, world, device)
+    host = buf.cpu().numpy()
+    if int(host[0]) != 0:
+        raise CommUnavailable("rank 0 could not draw the RCCL unique id" + (f" ({note})" if note else ""))
+    comm, err = None, ""
+    try:
+        comm = create(host[1:].tobytes(), rank, world, device)
+    except Exception as e:   # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if max_over_ranks(0.0 if comm is not None else 1.0, dev) != 0.0:
+        if comm is not None and hasattr(comm, "close"):
+            comm.close()
+        raise CommUnavailable("rsim_comm_create failed on " + (f"this rank ({err})" if err else "another rank"))
+    return comm
 
 
 class RolloutStats:

@@ -52,6 +52,9 @@ class _Batch:
     def randomize_dynamics(self, seed, step):
         self.log.append(("dr", step))
 
+    def tier_stats(self):
+        return (3 * self.log.count(("step", self.n)), self.log.count(("step", self.n)))
+
     def tensor(self, name):
         if name == "qpos":
             return torch.zeros(self.n, 9)
@@ -140,7 +143,10 @@ def test_default_command_flow_and_contract(monkeypatch, capsys):
     oc = d["config"]["other_configs"]
     assert set(oc) == {"stack", "peg", "pickplace"} and all(v["value"] == 1.0 for v in oc.values())
     kids = [e for e in log if e[0] == "child"]
-    assert kids == [("child", "stack", "50", "300"), ("child", "peg", "50", "300"), ("child", "pickplace", "10", "50")]
+    assert kids == [("child", "stack", "50", "500"), ("child", "peg", "50", "500"), ("child", "pickplace", "20", "500")]       # pre-roll = the horizon: steady state
+    # the slow-window diagnostics of the round-5 review: per-step distribution and what the capacity tier did in the timed region, at top level
+    assert d["step_ms"] == {"min": 1.5, "p50": 1.5, "p90": 1.5, "max": 1.5} and d["tier_env_steps"] == 3 * 4 and d["tier_changes_in_mid_step"] == 4
+    assert d["collective"] == "none (one rank)" and d["config"]["steady_state"] is False and d["config"]["episode_window"] == [5, 9]
     # ... directly behind the headline region: 3 pre-roll + 2 warm-up + 4 timed steps of the full batch, the children, THEN stream groups and the two half batches
     first_child, groups_on = log.index(kids[0]), log.index(("groups", 2))
     assert [e for e in log[:first_child] if e[0] == "step"] == [("step", 8)] * 9 and log[first_child - 1] == ("quiesce", 8)

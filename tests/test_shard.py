@@ -65,6 +65,57 @@ def test_world_size_2_gloo(tmp_path):
     assert r["tot2"]["env_steps"] == 33 and r["tot2"]["successes"] == 3
 
 
+HANDSHAKE_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["RSIM_ROOT"])
+import numpy as np, torch
+from robosuite_amd import shard
+rank, local_rank, world = shard.init_process_group("gloo")
+class Comm:
+    def __init__(self, uid, rank, world, device): self.uid, self.closed = uid, False
+    def close(self): self.closed = True
+def draw_ok(): return bytes(range(128))
+def draw_fails(): raise OSError("librccl: undefined symbol ncclGetUniqueId")
+made = []
+def create_ok(uid, r, w, d): made.append(Comm(uid, r, w, d)); return made[-1]
+def create_fails_on_1(uid, r, w, d):
+    if r == 1: raise RuntimeError("ncclCommInitRank: unhandled system error")
+    return create_ok(uid, r, w, d)
+res = {}
+for name, draw, create in (("ok", draw_ok, create_ok), ("draw_fails", draw_fails, create_ok), ("create_fails_on_1", draw_ok, create_fails_on_1)):
+    made.clear()
+    try:
+        c = shard.hip_comm(rank, world, 0, unique_id=draw, create=create)
+        res[name] = ["comm", c.uid == bytes(range(128))]
+    except shard.CommUnavailable as e:
+        res[name] = ["unavailable", str(e), len(made), all(m.closed for m in made)]
+    # whatever happened, the ranks are still in step: a collective right behind it pairs up
+    res[name].append(shard.max_over_ranks(float(rank)))
+print("RANK%d %s" % (rank, json.dumps(res)))
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_c_abi_communicator_handshake_is_collective_safe(tmp_path):
+    """Round-5 advisor finding: a rank that failed before the broadcast of the unique id left the others blocked in it, and a creation that failed on a subset of
+    ranks left the job with a half-formed communicator.  With injected failures (rank 0 cannot draw the id; rank 1 cannot create) every rank must raise
+    CommUnavailable -- none hangs, none keeps a communicator -- and the next collective of the job still pairs up."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(HANDSHAKE_WORKER)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(script)], env=dict(os.environ, RSIM_ROOT=ROOT), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = {int(l[4]): json.loads(l[6:]) for l in out.stdout.splitlines() if l.startswith("RANK")}
+    assert sorted(rows) == [0, 1]
+    for r in (0, 1):
+        assert rows[r]["ok"] == ["comm", True, 1.0]
+        assert rows[r]["draw_fails"][0] == "unavailable" and rows[r]["draw_fails"][2] == 0 and rows[r]["draw_fails"][-1] == 1.0      # nobody called create
+        assert rows[r]["create_fails_on_1"][0] == "unavailable" and rows[r]["create_fails_on_1"][3] is True and rows[r]["create_fails_on_1"][-1] == 1.0   # rank 0 closed the one it made
+    assert "undefined symbol" in rows[0]["draw_fails"][1] and "this rank" in rows[1]["create_fails_on_1"][1] and "another rank" in rows[0]["create_fails_on_1"][1]
+
+
 @pytest.mark.parametrize("config", ("lift", "stack"))     # stack = BASELINE configs[2], the one BASELINE.json assigns to eight GPUs
 def test_bench_launches_its_own_ranks(config):
     """`python bench.py --gpus 2` (no torchrun around it) must spawn one rank per GPU itself; without a GPU every rank stops at the

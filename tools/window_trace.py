@@ -62,9 +62,10 @@ def window(config, P, W, K, snapshot=True, wavelog=False):
             w = env.batch.wavelog()
             t0_, t1_ = w[:, 2].astype(np.int64), w[:, 3].astype(np.int64)
             dur = (t1_ - t0_) / 100.0
+            t1_ = np.where(dur > 200, t1_, 0)   # (the reset-observation pass that follows the step rewrites the records of the few envs it touches: ~45 us entries)
             e = int(np.argmax(t1_))   # the env that finished last
             slow.append({"last_env": e, "last_env_start_us": float((t0_[e] - t0_.min()) / 100.0), "last_env_dur_us": float(dur[e]), "span_us": float((t1_.max() - t0_.min()) / 100.0),
-                         "dur_p50_us": float(np.percentile(dur, 50)), "dur_p99_us": float(np.percentile(dur, 99)), "dur_max_us": float(dur.max()), "longest_env": int(np.argmax(dur)),
+                         "dur_p50_us": float(np.percentile(dur, 50)), "dur_p99_us": float(np.percentile(dur, 99)), "dur_max_us": float(dur.max()), "longest_env": int(np.argmax(dur)), "longest_env_counts": w[int(np.argmax(dur)), 4:8].astype(np.int64).tolist(),
                          "last_env_counts_mpr_support_newton_cand": w[e, 4:8].astype(np.int64).tolist()})
     env.batch.sync(); torch.cuda.synchronize()
     ms = [r[0].elapsed_time(r[1]) for r in rows]
@@ -74,6 +75,20 @@ def window(config, P, W, K, snapshot=True, wavelog=False):
            "max_contacts_needed": int(cn[:, 0].max().item()), "max_rows_needed": int(cn[:, 1].max().item()), "capacity": [env.batch.maxcon, env.batch.maxefc]}
     if wavelog:
         out["per_step_envs"] = slow
+        # three more steps, each with the phase accumulators restricted to the env that ran longest in the step before: where its time goes
+        prof = []
+        for t in range(3):
+            e = slow[-1]["longest_env"] if t == 0 else prof[-1]["next"]
+            env.batch.profile(True); env.batch.profile_env(e)
+            step(P + W + K - 3 + t)   # (tape rows reused: the content of the actions does not matter here)
+            env.batch.sync()
+            w = env.batch.wavelog(); p = env.batch.profile(True)
+            dur = (w[:, 3].astype(np.int64) - w[:, 2].astype(np.int64)) / 100.0
+            ns = max(1, p["n_sub"])
+            cyc = {k: int(v / ns) for k, v in p.items() if not k.startswith("n_") and not k.startswith("x") and k not in ("boxbox", "mpr", "plane") and v}
+            prof.append({"env": int(e), "dur_us": float(dur[e]), "ticks_per_substep": cyc, "narrow_split": {k: int(p[k] / ns) for k in ("boxbox", "mpr", "plane")},
+                         "per_substep": {k[2:]: round(p[k] / ns, 2) for k in p if k.startswith("n_") and k != "n_sub"}, "next": int(np.argmax(np.where(dur > 200, dur, 0)))})
+        out["slowest_env_profile"] = prof
         env.batch.profile(False)
     env.bank_quiesce(); env._bank_stop()
     del env, tape
@@ -101,7 +116,9 @@ def main():
             print("   on tier  " + " ".join(f"{x:5d}" for x in r["wide_list"]))
             print("   redone   " + " ".join(f"{x:5d}" for x in r["redone"]), flush=True)
         for t, e in enumerate(r.get("per_step_envs", [])):
-            print(f"   step {t:2d}: span {e['span_us']:6.0f} us  last env {e['last_env']:5d} started {e['last_env_start_us']:6.0f} ran {e['last_env_dur_us']:6.0f}  (p50 {e['dur_p50_us']:.0f} p99 {e['dur_p99_us']:.0f} max {e['dur_max_us']:.0f} env {e['longest_env']})  mpr/support/newton/cand {e['last_env_counts_mpr_support_newton_cand']}")
+            print(f"   step {t:2d}: span {e['span_us']:6.0f} us  last env {e['last_env']:5d} started {e['last_env_start_us']:6.0f} ran {e['last_env_dur_us']:6.0f}  (p50 {e['dur_p50_us']:.0f} p99 {e['dur_p99_us']:.0f} max {e['dur_max_us']:.0f} env {e['longest_env']} mpr/support/newton/cand {e['longest_env_counts']})")
+        for q in r.get("slowest_env_profile", []):
+            print(f"   env {q['env']} ({q['dur_us']:.0f} us) ticks/substep {q['ticks_per_substep']}  narrow {q['narrow_split']}  per substep {q['per_substep']}")
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
 
