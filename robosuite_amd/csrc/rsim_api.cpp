@@ -861,12 +861,15 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.meaninertia = m->meaninertia;
   dm.newton_ns = getenv("RSIM_NEWTON_NS") ? (float)atof(getenv("RSIM_NEWTON_NS")) : RSIM_NEWTON_NS;
   dm.newton_na = getenv("RSIM_NEWTON_NA") ? (float)atof(getenv("RSIM_NEWTON_NA")) : RSIM_NEWTON_NA;
+  dm.mpr_cone = getenv("RSIM_MPR_CONE") ? (float)atof(getenv("RSIM_MPR_CONE")) : RSIM_MPR_CONE;
   dm.bp_reach = getenv("RSIM_BP_REACH") ? (float)atof(getenv("RSIM_BP_REACH")) : RSIM_BP_REACH;
   dm.newton_wide = getenv("RSIM_NEWTON_WIDE") ? atoi(getenv("RSIM_NEWTON_WIDE")) : 1;
   dm.newton_ls = getenv("RSIM_NEWTON_LS") ? (float)atof(getenv("RSIM_NEWTON_LS")) : RSIM_NEWTON_LS;
   // refinement passes with an fp64 gradient: on for the models of the 64 x 48 class and beyond (PickPlace: mesh objects and Robotiq links of 1e-5 .. 4e-3 kg m^2
   // under condim-4 contacts at the refsafe limit); Stack-class models reach 2e-5 of the oracle without it and would pay 13 % for it
   dm.newton_refine = getenv("RSIM_NEWTON_REFINE") ? atoi(getenv("RSIM_NEWTON_REFINE")) : (b->cfg >= 3 ? 16 : 0);
+  if (dm.newton_refine > 0 && b->cfg < 3 && getenv("RSIM_NEWTON_REFINE"))
+    fprintf(stderr, "[rsim] RSIM_NEWTON_REFINE=%d ignored: the fp64 polish is compiled into the 64 x 48 / 64 x 64 configurations and their tiers only (this batch runs configuration %d)\n", dm.newton_refine, b->cfg);
   dm.newton_polish_tol = getenv("RSIM_POLISH_TOL") ? (float)atof(getenv("RSIM_POLISH_TOL")) : 1.0f;
   dm.newton_polish_gate = getenv("RSIM_POLISH_GATE") ? (float)atof(getenv("RSIM_POLISH_GATE")) : 0.0f;
   dm.newton_exact = getenv("RSIM_NEWTON_EXACT") ? atoi(getenv("RSIM_NEWTON_EXACT")) : 1;

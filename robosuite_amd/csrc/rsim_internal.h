@@ -133,6 +133,8 @@ struct DModel {
   int nv_damped;       // dofs 0 .. nv_damped - 1 cover every kinematic tree that has a damped joint (implicit-damping Euler factors only those)
   int iterations, ls_iterations, cone, solver;
   float tolerance, meaninertia;
+  float mpr_cone;      // half-angle (rad) of the cone of three directions around the previous contact normal from which a pair with a smooth shape restarts its portal
+                       // (rsim_step.hip convex_convex, warm-start flag 3); 0: such pairs start cold every substep
   float bp_reach;      // broadphase active pair list: bounding-sphere gap (m) up to which a pair is listed; 0: every pair every substep
   float newton_ns, newton_na, newton_ng, newton_ls;
   int newton_refine;   // wide configurations: at most this many polish passes behind the fp32 Newton iteration (fp64 residuals / states / objective / gradient, solve_newton), 0 = none
@@ -223,6 +225,9 @@ struct DBatch {
 #define RSIM_NEWTON_LS 1.0f    // line search: a correction of alpha below this multiple of the step rule's threshold ends it (0: relative 1e-6 only)
 #endif
 #ifndef RSIM_NEWTON_NS
+#ifndef RSIM_MPR_CONE
+#define RSIM_MPR_CONE 0.0f   // rad: restart cone of smooth-shape contacts (rsim_step.hip convex_convex, flag 3); 0 = off (the default: see the note there -- +5 % on Lift, but another path to the contact than the cold run the oracle takes)
+#endif
 #ifndef RSIM_BP_REACH
 #define RSIM_BP_REACH 0.04f   // broadphase active pair list (rsim_step.hip collision()): listed up to this bounding-sphere gap; valid while no geom centre moved reach / 2
 #endif

@@ -2124,6 +2124,38 @@ struct Sim {
       warm = dot(v1, d1) > 0.f && dot(v2, d2) > 0.f && dot(v3_, d3) > 0.f && dot(cross(v1, v3_), v0) >= 0.f && dot(cross(v3_, v2), v0) >= 0.f && dot(cross(v2, v1), v0) >= 0.f;
       MPRSTAT(9, warm ? 1 : 0);
     }
+    if (wh == 3) {
+      // A contact in which one shape is SMOOTH (cylinder, capsule, sphere, ellipsoid) persists like any other -- a finger or a link resting against the mount's
+      // cylinder -- and is the expensive kind: the refinement gains one bit of the tolerance per step on a curved surface (the portal has to shrink to
+      // sqrt(2 R tol), ~0.6 mm on the mount), 13 - 20 support pairs per run, every substep; such runs are 60 % of the slowest env of a Lift launch
+      // (profiles/r06_d_window_trace.txt), and that env IS the launch.  The converged portal itself cannot be reused (its three directions are nearly
+      // parallel and their supports coincide: see the note at the end of this function), but its NORMAL can: the supports along three directions on a cone
+      // of half-angle DModel.mpr_cone around it span a well-shaped triangle of the Minkowski difference (~cone x R across: millimetres, not micrometres)
+      // right where the origin ray left through last time.  If it satisfies the invariant the discovery loop ends on -- every support beyond the origin
+      // along its direction, the origin ray inside the three side planes -- it IS a portal and the refinement starts from it, two or three steps from its
+      // tolerance; if not (the contact moved by more than the cone), the run starts cold.  A valid portal is a valid state of the algorithm however it was
+      // found, and next to a smooth shape the boundary has no near-coplanar facets for the path to choose between: same DEPTH to the tolerance.
+      // OFF by default (DModel.mpr_cone = 0, RSIM_MPR_CONE): measured +5 % on the Lift headline (profiles/r06_g_ab_mpr_cone.txt), but MPR's normal on a curved
+      // surface is the plane normal of the LAST portal -- good to (portal size / R), 0.3 degrees on a 6 cm cylinder -- and a run that arrives from another side
+      // ends on another portal: Baxter's elbow-cylinder contacts then agree with the cold-started fp64 oracle in 83 % of the sampled envs instead of 94 %
+      // (tests/test_full_size_parity.py bound: 85 %).  Both are MPR answers; only the cold one is the path the oracle (and any cold-starting reference) takes.
+      const V3 nn = wd, ax = fabsf(nn.x) < 0.6f ? v3(1.f, 0.f, 0.f) : v3(0.f, 1.f, 0.f);
+      const V3 t1 = normalized(cross(nn, ax)), t2 = cross(nn, t1);
+      const float ce = m.mpr_cone;
+      const V3 d1 = normalized(nn + t1 * ce), d2 = normalized(nn + (t1 * -0.5f + t2 * 0.8660254f) * ce), d3 = normalized(nn + (t1 * -0.5f - t2 * 0.8660254f) * ce);
+      p11 = sup(sg1, d1); p12 = sup(sg2, -d1); v1 = p11 - p12;
+      p21 = sup(sg1, d2); p22 = sup(sg2, -d2); v2 = p21 - p22;
+      p31 = sup(sg1, d3); p32 = sup(sg2, -d3); v3_ = p31 - p32;
+      const float s13 = dot(cross(v1, v3_), v0), s32 = dot(cross(v3_, v2), v0), s21 = dot(cross(v2, v1), v0);
+      const bool beyond = dot(v1, d1) > 0.f && dot(v2, d2) > 0.f && dot(v3_, d3) > 0.f;
+      if (beyond && s13 >= 0.f && s32 >= 0.f && s21 >= 0.f) { warm = true; mpr_setd(0, d1); mpr_setd(1, d2); mpr_setd(2, d3); }
+      else if (beyond && s13 <= 0.f && s32 <= 0.f && s21 <= 0.f && (s13 < 0.f || s32 < 0.f || s21 < 0.f)) {   // the other winding: second and third vertex swapped
+        V3 t;
+        t = v2; v2 = v3_; v3_ = t; t = p21; p21 = p31; p31 = t; t = p22; p22 = p32; p32 = t;
+        warm = true; mpr_setd(0, d1); mpr_setd(1, d3); mpr_setd(2, d2);
+      }
+      MPRSTAT(9, warm ? 1 : 0);
+    }
     if (!warm) {
     // A box or cylinder against anything: MPR's own exit test (a direction D, oriented from geom 1 to geom 2, in which the first shape's
     // farthest point does not reach the second's nearest) tried first on the primitive's most promising face / radial axis.  The table top or
@@ -2247,7 +2279,9 @@ struct Sim {
     // slowest envs of a Lift launch) and the well-posed one: one large flat facet.
     {
       const int ta = uni(sg1.t), tb = uni(sg2.t);
+      const bool smooth_a = ta == G_CYLINDER || ta == G_CAPSULE || ta == G_SPHERE || ta == G_ELLIPSOID, smooth_b = tb == G_CYLINDER || tb == G_CAPSULE || tb == G_SPHERE || tb == G_ELLIPSOID;
       if (((ta == G_BOX && tb == G_MESH) || (ta == G_MESH && tb == G_BOX)) && depth < 5e-3f) mpr_store_portal(wout);
+      else if ((smooth_a || smooth_b) && m.mpr_cone > 0.f && norm(dir) > 0.5f) mpr_store(wout, dot(dir, v1) >= 0.f ? dir : -dir, 3.f);   // the final portal's outward normal (flag 3 above)
       else mpr_store(wout, v3(0.f, 0.f, 0.f), 0.f);
     }
     V3 w1 = p11 * bw.x + p21 * bw.y + p31 * bw.z, w2 = p12 * bw.x + p22 * bw.y + p32 * bw.z;
@@ -2442,7 +2476,7 @@ struct Sim {
         pf.mark(RP_PLANE);
         V3 wd = v3(0.f, 0.f, 0.f);
         int wh = 0;
-        if (mprc && ci < 64) { wd = v3(bcast(wc[0], ci), bcast(wc[1], ci), bcast(wc[2], ci)); wh = uni((int)bcast(wc[3], ci)); if (wh == 2 && !mpr_portal) wh = 0; }
+        if (mprc && ci < 64) { wd = v3(bcast(wc[0], ci), bcast(wc[1], ci), bcast(wc[2], ci)); wh = uni((int)bcast(wc[3], ci)); if ((wh == 2 || wh == 3) && !mpr_portal) wh = 0; }
         convex_convex(g1, g2, margin, cp, wd, wh, mprc ? mprc + MPRC * p : nullptr);
         pf.mark(RP_MPR); pf.count(RP_N_MPR, 1);
       }
@@ -4122,9 +4156,9 @@ struct Sim {
     SYNC();
     const float fc = jt_times_force(nch);
     if (lane < nv) { sm.qfrc_constraint[lane] = fc; sm.qacc[lane] = a; }
-    // RSIM_POLISH of the debug entries: 1000 (the polish factorised in fp64) + 10000 x polish passes + 100000 x floor(-log10(scaled fp64 gradient at the kept
-    // point)) + 10^7 x how the polish ended (1 gradient below tolerance, 2 improvement below tolerance, 3 pass budget, 4 stagnation near the tolerance, 5 stagnation
-    // with the fp64 factor, 6 no step lowered the objective, 7 H not positive definite in fp64; 0 not run)
+    // RSIM_POLISH of the debug entries (same encoding as include/rsim.h): 10000 x polish passes + 100000 x floor(-log10(scaled fp64 gradient at the kept point))
+    // + 10^7 x how the polish ended (1 gradient below tolerance, 2 improvement below tolerance, 3 pass budget, 5 the direction was no descent direction, 6 a step
+    // raised the objective; 0 not run)
     if (lane == 0) { sm.niter = iter; sm.polish = 10000 * pol_pass + 100000 * pol_sgb + 10000000 * pol_exit; }
     pf.count(RP_N_NEWTON, iter);
     SYNC();
