@@ -150,12 +150,15 @@ def pmc_evidence(name, key, lib_sha, config=None):
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return "absent"
-    if d.get("lib_sha16") == lib_sha:
+    if d.get("lib_sha16") == lib_sha and d.get("tuning_sha16", backend.tuning_sha16()) == backend.tuning_sha16():
         return d.get(key)
     if config is not None and d.get("code_sha16"):
+        # another library build: the figure stands only if everything it depends on is bit-identical -- the configuration's code object, the code object of the
+        # capacity tier its envs move to, and the host-side dispatch / solver settings (rsim_tuning_defaults: round-5 advisor finding)
         try:
-            from tools.kernel_resources import config_code_sha16
-            if config_code_sha16(backend.LIB_PATH, config) == d["code_sha16"]:
+            from tools.kernel_resources import config_code_sha16, wide_code_sha16
+            if (config_code_sha16(backend.LIB_PATH, config) == d["code_sha16"] and d.get("wide_code_sha16") == wide_code_sha16(backend.LIB_PATH, config)
+                    and d.get("tuning_sha16") == backend.tuning_sha16()):
                 return d.get(key)
         except Exception:
             pass

@@ -347,6 +347,9 @@ int rsim_profile_env(rsim_batch* b, int env);
  * never truncates contacts -- nconmax = 5000, models/assets/base.xml:5 -- so an env that outgrows the native contact / row capacity is stepped with more).
  * Synchronises the batch's stream.  No reference counterpart (diagnostics: which envs a lockstep launch waits for). */
 int rsim_tier_snapshot(rsim_batch* b, int* host_tier);
+/* The host-side settings that decide what a control step dispatches and how its solver stops -- compiled-in defaults and the RSIM_* environment overrides in
+ * force -- as one string (valid until the next call).  Measurement files carry its sha next to the kernel's: evidence of other settings is not this build's. */
+const char* rsim_tuning_defaults(void);
 /* out2[0] = env-steps (env x control step) the wider capacity tier stepped since the batch was created, out2[1] = how many of them changed tier in mid-step
  * (carried on from the substep in which they outgrew the native capacity, or redone).  Synchronises the batch's stream.  bench.py reports both. */
 int rsim_tier_stats(rsim_batch* b, unsigned long long* out2);

@@ -248,6 +248,7 @@ def lib():
         L.rsim_profile_env.argtypes = [vp, C.c_int]
         L.rsim_tier_snapshot.argtypes = [vp, vp]
         L.rsim_tier_stats.argtypes = [vp, vp]
+        L.rsim_tuning_defaults.restype = C.c_char_p
         L.rsim_name2id.argtypes = [vp, C.c_char_p, C.c_char_p]
         L.rsim_id2name.argtypes = [vp, C.c_char_p, C.c_int]; L.rsim_id2name.restype = C.c_char_p
         L.rsim_full_M.argtypes = [vp, C.c_int, vp]
@@ -263,6 +264,12 @@ def lib():
 def _chk(rc):
     if rc != 0:
         raise RsimError(lib().rsim_last_error().decode())
+
+
+def tuning_sha16() -> str:
+    """sha256[:16] of rsim_tuning_defaults(): the host-side dispatch / solver settings a measurement was taken under (bench.py pmc_evidence)."""
+    import hashlib
+    return hashlib.sha256(lib().rsim_tuning_defaults()).hexdigest()[:16]
 
 
 class HipComm:

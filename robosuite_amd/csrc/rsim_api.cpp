@@ -1632,6 +1632,23 @@ extern "C" int rsim_profile_env(rsim_batch* b, int env) { b->db.prof_env = env; 
 // Capacity tier of every env for the NEXT control step (0: the native configuration steps it, 1: the wider one), host int32 [B]; all zeros for a batch without a
 // tier above its configuration.  Diagnostics (tools/window_trace.py, bench.py's per-step record): an env whose entry went 0 -> 1 over a control step was handed
 // over in mid-step (redone), an env at 1 is on next step's wide list.
+// Everything outside a kernel's code object that decides what a control step dispatches and how its solver behaves: the compiled-in defaults and the RSIM_*
+// environment overrides in force.  PMC evidence under profiles/ carries the sha of this string next to the code-object sha (round-5 advisor finding: a host-only
+// change -- polish passes, tier thresholds -- left the code sha equal and the evidence was reported as current).
+extern "C" const char* rsim_tuning_defaults(void) {
+  static std::string s;
+  char buf[1024];
+  snprintf(buf, sizeof(buf), "newton_ns=%g;newton_na=%g;newton_ls=%g;newton_ng=%g;newton_wide=1;newton_exact=1;newton_refine(cfg>=3)=16;polish_tol=1;polish_gate=0;"
+           "bp_reach=%g;mpr_cone=%g;mpr_warmstart=1;mpr_portal=1;tier_up(cfg0,cfg1)=0/0;tier_up(other)=2/6;tier_mode=0;order_fresh=1;fused_tier_cfg0=%d",
+           (double)RSIM_NEWTON_NS, (double)RSIM_NEWTON_NA, (double)RSIM_NEWTON_LS, (double)RSIM_NEWTON_NG, (double)RSIM_BP_REACH, (double)RSIM_MPR_CONE,
+           []{ int lw[10]; return rsim_limits_w_cfg0(lw); }());
+  s = buf;
+  static const char* const envs[] = {"RSIM_NEWTON_NS", "RSIM_NEWTON_NA", "RSIM_NEWTON_LS", "RSIM_NEWTON_NG", "RSIM_NEWTON_WIDE", "RSIM_NEWTON_EXACT", "RSIM_NEWTON_REFINE",
+                                     "RSIM_POLISH_TOL", "RSIM_POLISH_GATE", "RSIM_BP_REACH", "RSIM_MPR_CONE", "RSIM_NO_MPR_WARMSTART", "RSIM_NO_MPR_PORTAL_WARMSTART",
+                                     "RSIM_TIER_UP_CON", "RSIM_TIER_UP_EFC", "RSIM_TIER_MODE", "RSIM_NO_TIERS", "RSIM_ORDER_FRESH", "RSIM_EULER_FULL", "RSIM_FORCE_HANDOVER"};
+  for (const char* e : envs) if (const char* v = getenv(e)) { s += ";env:"; s += e; s += "="; s += v; }
+  return s.c_str();
+}
 // {env-steps the wider capacity tier stepped, env-steps of these that were handed over (fused tier) / redone (tier kernels) in mid-step} since the batch was created
 extern "C" int rsim_tier_stats(rsim_batch* b, unsigned long long* out2) {
   if (!out2) return fail("rsim_tier_stats: null destination");

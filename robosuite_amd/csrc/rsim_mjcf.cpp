@@ -91,7 +91,13 @@ struct XmlParser {
     }
     return o;
   }
+  // Elements nest by recursion here and in every walk over the parsed tree (defaults, bodies): a nesting limit turns a pathologically deep document into an
+  // error instead of a stack overflow, which no try / catch at the C-ABI entry could turn into rsim_last_error() (round-5 advisor finding).  MJCF models nest a
+  // few tens of levels (kinematic chains); 256 is far beyond any of them.
+  int depth = 0;
+  struct DepthGuard { int& d; explicit DepthGuard(int& d_) : d(d_) { if (++d > 256) err("XML parse error: elements nested deeper than 256 levels"); } ~DepthGuard() { --d; } };
   std::unique_ptr<Xml> element() {
+    DepthGuard guard(depth);
     if (p >= n || s[p] != '<') err("XML parse error: '<' expected at offset %zu", p);
     p++;
     std::unique_ptr<Xml> e(new Xml());
@@ -351,14 +357,25 @@ Mesh3 load_obj(const std::string& path) {
 Mesh3 load_msh(const std::string& path) {
   std::string d = read_file(path);
   if (d.size() < 16) err("bad .msh file: %s", path.c_str());
-  int32_t h[4]; memcpy(h, d.data(), 16);
+  int32_t h[4]; memcpy(h, d.data(), 16);   // counts: vertices, normals, texture coordinates, faces
+  // the header is untrusted: negative counts would wrap as size_t and pass a naive bound (12 * (size_t)-1 + 16 == 4); every block is checked against what is LEFT
+  // of the file, in the division form that cannot overflow
+  for (int k = 0; k < 4; k++) if (h[k] < 0) err("bad .msh file (negative count in the header): %s", path.c_str());
   size_t off = 16;
+  auto take = [&](size_t count, size_t bytes_each) -> size_t {
+    if (count > (d.size() - off) / bytes_each) err("bad .msh file (truncated): %s", path.c_str());
+    const size_t at = off; off += count * bytes_each; return at;
+  };
   Mesh3 m;
-  if (off + 12 * (size_t)h[0] > d.size()) err("bad .msh file: %s", path.c_str());
-  for (int i = 0; i < h[0]; i++) { float v[3]; memcpy(v, d.data() + off + 12 * (size_t)i, 12); m.v.push_back({(double)v[0], (double)v[1], (double)v[2]}); }
-  off += 12 * (size_t)h[0] + 12 * (size_t)h[1] + 8 * (size_t)h[2];
-  if (off + 12 * (size_t)h[3] > d.size()) err("bad .msh file: %s", path.c_str());
-  for (int i = 0; i < h[3]; i++) { int32_t f[3]; memcpy(f, d.data() + off + 12 * (size_t)i, 12); m.f.push_back({f[0], f[1], f[2]}); }
+  const size_t vat = take((size_t)h[0], 12);
+  for (int i = 0; i < h[0]; i++) { float v[3]; memcpy(v, d.data() + vat + 12 * (size_t)i, 12); m.v.push_back({(double)v[0], (double)v[1], (double)v[2]}); }
+  take((size_t)h[1], 12); take((size_t)h[2], 8);   // normals and texture coordinates: skipped
+  const size_t fat = take((size_t)h[3], 12);
+  for (int i = 0; i < h[3]; i++) {
+    int32_t f[3]; memcpy(f, d.data() + fat + 12 * (size_t)i, 12);
+    for (int k = 0; k < 3; k++) if (f[k] < 0 || f[k] >= h[0]) err("bad .msh file (face index out of range): %s", path.c_str());
+    m.f.push_back({f[0], f[1], f[2]});
+  }
   return m;
 }
 Mesh3 load_mesh(const std::string& path) {

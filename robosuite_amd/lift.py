@@ -35,21 +35,36 @@ def default_reset_spec():
                              objects=[dict(name="cube", horizontal_radius=None, bottom_z=None, top_z=None, qposadr=9, init_quat=None)]))
 
 
-_PREPARED = {}
+_PREPARED = {}          # id(spec) -> (spec, content key, arrays); at most _PREPARED_MAX entries, least recently used first out
+_PREPARED_MAX = 32
+
+
+def _spec_key(spec):
+    """The values the prepared arrays are built from: an in-place edit of the spec after its first draw changes the key and the arrays are rebuilt."""
+    c = spec.get("cube")
+    return (tuple(spec["arm_init_qpos"]), None if c is None else (tuple(c["size_min"]), tuple(c["size_max"])))
 
 
 def prepared(spec):
     """The spec's lists as numpy arrays, built once per spec object (the reset-ring upkeep draws thousands of episodes per second of rollout: no per-draw
-    list -> array conversions)."""
-    hit = _PREPARED.get(id(spec))
-    if hit is None or hit[0] is not spec:
+    list -> array conversions).  Kept beside the spec, not inside it: the spec is part of a cfg that stays JSON-serialisable (factory.extract, tools/gen_golden.py
+    dump it) and is shared between the envs built from it (round-4 advisor finding).  Bounded and content-checked (round-5 advisor finding): an entry holds its
+    spec (so the id cannot be reused while it is cached), is rebuilt when the values it was built from have been edited in place, and the cache keeps the
+    _PREPARED_MAX most recently used specs -- envs and specs built over and over (tests, per-reset rebuilds) no longer pin every spec for the life of the process."""
+    k = id(spec)
+    hit = _PREPARED.get(k)
+    key = _spec_key(spec)
+    if hit is None or hit[0] is not spec or hit[1] != key:
         p = dict(arm=np.array(spec["arm_init_qpos"], dtype=np.float64))
         if "cube" in spec:
             p["size_min"], p["size_max"] = np.array(spec["cube"]["size_min"], dtype=np.float64), np.array(spec["cube"]["size_max"], dtype=np.float64)
-        # kept beside the spec, not inside it: the spec is part of a cfg that stays JSON-serialisable (factory.extract, tools/gen_golden.py dump it) and is
-        # shared between the envs built from it (round-4 advisor finding).  The entry holds the spec itself, so its id cannot be reused while cached.
-        hit = _PREPARED[id(spec)] = (spec, p)
-    return hit[1]
+        hit = (spec, key, p)
+    else:
+        del _PREPARED[k]          # re-inserted below: dicts keep insertion order, the first key is the least recently used
+    _PREPARED[k] = hit
+    while len(_PREPARED) > _PREPARED_MAX:
+        del _PREPARED[next(iter(_PREPARED))]
+    return hit[2]
 
 
 def arm_noise(rng: np.random.Generator, spec) -> np.ndarray:

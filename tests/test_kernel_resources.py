@@ -13,7 +13,7 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(os.p
 
 LDS_PER_CU = 160 * 1024
 # k_step<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR>: (environments per CU by LDS, register budget VGPR + AGPR, private-segment bytes tolerated)
-STEP_BUDGET = {"ILi32ELi16ELi16ELi24ELi16ELi16ELi64ELi192E": (8, 256, 64),    # 52 B (round 3: 156, round 4 before the MachineLICM flags: 124): profiles/r04_y_ab_spills.txt
+STEP_BUDGET = {"ILi32ELi16ELi16ELi24ELi16ELi16ELi64ELi192E": (8, 256, 32),    # round 6: 0 B at 234 registers with BOTH bodies (native + fused wide tier, 20 408 B of LDS) reading their arguments from the kernarg segment; 52 B in round 5 (round 3: 156, round 4 before the MachineLICM flags: 124): profiles/r04_y_ab_spills.txt
                 "ILi32ELi16ELi32ELi24ELi16ELi32ELi64ELi192E": (8, 256, 96),   # Stack: J, M and the contact block in global memory, no LDS hull pool, two wavefronts per SIMD (round 5, sessions 12 / 13: 36.1 -> 19.8 KB, four -> eight envs per CU)
                "ILi64ELi16ELi16ELi32ELi32ELi32ELi64ELi320E": (5, 512, 0), "ILi64ELi32ELi48ELi64ELi32ELi32ELi128ELi640E": (4, 512, 0),   # J and M in global memory (RSIM_JGLOBAL round 4: 74.8 -> 49.7 KB = 3; RSIM_MGLOBAL round 5: 40.3 KB = 4, one wavefront per SIMD)
                "ILi64ELi32ELi64ELi64ELi32ELi32ELi128ELi640E": (1, 512, 0),
@@ -41,7 +41,9 @@ def test_fused_kernel_configurations_keep_their_lds_and_register_budgets():
 def test_auxiliary_kernels_use_no_scratch():
     for name, r in kernels(LIB).items():
         if name.startswith("_Z11k_reset_obs") or name.startswith("_Z10k_step_dbg"):
-            assert r["scratch"] <= (64 if "ELi256E" not in name else 1024), (name, r)   # the reset-observation pass (a few envs per control step) and the B = 1 debug entries share the step body (256-row tier: see STEP_BUDGET)
+            # (the Lift-class tier's own translation unit, 32 x 16 with 128 rows, is not on the Lift path any more -- round 6: that tier is a body of the native
+            # kernel -- and its reset / debug kernels are never launched: the reset observation of every env comes from the native build)
+            assert r["scratch"] <= (64 if "ELi256E" not in name else 1024) or "ILi32ELi16ELi16ELi24ELi16ELi32ELi128ELi192E" in name, (name, r)   # the reset-observation pass (a few envs per control step) and the B = 1 debug entries share the step body (256-row tier: see STEP_BUDGET)
         elif not (name.startswith("_Z6k_step") or name.startswith("_Z11k_step_list")):
             assert r["scratch"] == 0, (name, r)
 
@@ -74,5 +76,17 @@ def test_pmc_evidence_is_keyed_to_the_machine_code_of_its_configuration(tmp_path
     json.dump({"valu_per_env_substep": 1.0, "lib_sha16": "0123456789abcdef", "code_sha16": "fedcba9876543210"}, open(tmp_path / "profiles" / "valu_count.json", "w"))
     assert bench.pmc_evidence("valu_count.json", "valu_per_env_substep", lib_sha, "lift") == "stale:0123456789abcdef"
     assert bench.pmc_evidence("hbm_traffic.json", "bytes_per_launch", lib_sha, "lift") == "absent"
-    json.dump({"valu_per_env_substep": 2.0, "lib_sha16": "0123456789abcdef", "code_sha16": shas["lift"]}, open(tmp_path / "profiles" / "valu_count.json", "w"))
+    # another library build: the figure stands only with the configuration's code object, its capacity tier's and the host-side dispatch / solver settings all equal
+    # (round-5 advisor finding: a host-only change of polish passes or tier thresholds left code_sha16 equal)
+    from robosuite_amd import backend
+    from tools.kernel_resources import wide_code_sha16
+    rec = {"valu_per_env_substep": 2.0, "lib_sha16": "0123456789abcdef", "code_sha16": shas["lift"], "wide_code_sha16": wide_code_sha16(LIB, "lift"), "tuning_sha16": backend.tuning_sha16()}
+    json.dump(rec, open(tmp_path / "profiles" / "valu_count.json", "w"))
     assert bench.pmc_evidence("valu_count.json", "valu_per_env_substep", lib_sha, "lift") == 2.0
+    json.dump(dict(rec, tuning_sha16="0000000000000000"), open(tmp_path / "profiles" / "valu_count.json", "w"))
+    assert bench.pmc_evidence("valu_count.json", "valu_per_env_substep", lib_sha, "lift") == "stale:0123456789abcdef"
+    monkeypatch.setenv("RSIM_NEWTON_REFINE", "3")            # an override in force is another setting than the one the evidence was taken under
+    json.dump(rec, open(tmp_path / "profiles" / "valu_count.json", "w"))
+    assert bench.pmc_evidence("valu_count.json", "valu_per_env_substep", lib_sha, "lift") == "stale:0123456789abcdef"
+    monkeypatch.delenv("RSIM_NEWTON_REFINE")
+    assert wide_code_sha16(LIB, "stack") not in (None, "same-object", shas["stack"]) and wide_code_sha16(LIB, "pickplace") not in (None, shas["pickplace"])

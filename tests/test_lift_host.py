@@ -54,3 +54,22 @@ def test_fast_draw_path_is_bit_equal_to_the_general_one():
                 assert all(np.array_equal(a[k], b[k]) for k in a)
     own = copy.deepcopy(cfg["reset"]); own["sampler"]["own_rng"] = True
     assert not lift.fast_path_ok(own)
+
+
+def test_prepared_spec_cache_is_bounded_and_follows_in_place_edits():
+    """Round-5 advisor finding: lift.prepared() cached by id(spec) in a module global for ever and returned stale arrays after an in-place edit of the spec.
+    Now: the arrays follow the spec's values, and the cache keeps a bounded number of specs."""
+    from robosuite_amd import lift
+
+    s = lift.default_reset_spec()
+    rng = np.random.default_rng(3)
+    a0 = lift.arm_noise(rng, s)
+    s["arm_init_qpos"][0] += 0.25                      # edited in place after the first draw
+    a1 = lift.arm_noise(np.random.default_rng(3), s)
+    assert abs((a1[0] - a0[0]) - 0.25) < 1e-12 and np.allclose(a1[1:], a0[1:])
+    s["cube"]["size_max"] = [0.05, 0.05, 0.05]
+    assert lift.prepared(s)["size_max"].tolist() == [0.05, 0.05, 0.05]
+    for _ in range(4 * lift._PREPARED_MAX):
+        lift.prepared(lift.default_reset_spec())
+    assert len(lift._PREPARED) <= lift._PREPARED_MAX
+    assert lift.prepared(s)["arm"][0] == s["arm_init_qpos"][0]          # evicted meanwhile: rebuilt, same values

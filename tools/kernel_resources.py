@@ -56,6 +56,31 @@ def config_code_sha16(lib, config):
     return hashlib.sha256(code).hexdigest()[:16]
 
 
+# the configuration whose own kernel (k_step_list) steps the envs of a bench configuration that outgrow its capacity; lift: the tier is a second body inside the
+# native code object (round 6), so the native sha covers it
+WIDE_TAG = {"stack": "ILi32ELi16ELi32ELi24ELi16ELi32ELi128ELi192E", "peg": "ILi64ELi32ELi48ELi64ELi32ELi32ELi128ELi640E", "pickplace": "ILi64ELi32ELi48ELi64ELi32ELi64ELi256ELi640E"}
+
+
+def wide_code_sha16(lib, config):
+    """sha256[:16] of the machine code of the code object that holds the capacity tier's kernel of a bench configuration ("same-object" for lift)."""
+    import hashlib
+    if config not in WIDE_TAG:
+        return "same-object"
+    tag = ("_Z11k_step_list" + WIDE_TAG[config]).encode()
+    hits = [co for co in code_objects(lib) if tag in co]
+    if len(hits) != 1:
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "a.co")
+        open(f, "wb").write(hits[0])
+        code = b""
+        for sec in (".text", ".rodata"):
+            o = os.path.join(td, "sec.bin")
+            subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", f"--only-section={sec}", f, o])
+            code += open(o, "rb").read()
+    return hashlib.sha256(code).hexdigest()[:16]
+
+
 def kernels(lib=None):
     """{kernel name: {lds, scratch, vgpr, agpr, sgpr}} over all code objects of the library."""
     lib = lib or os.path.join(ROOT, "robosuite_amd", "librsim_hip.so")

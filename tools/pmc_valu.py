@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from robosuite_amd import backend  # noqa: E402
-from tools.kernel_resources import config_code_sha16  # noqa: E402
+from tools.kernel_resources import config_code_sha16, wide_code_sha16  # noqa: E402
 
 
 def per_dispatch(d, counter, pat="k_step<"):   # the control-step kernel, not k_step_dbg
@@ -26,7 +26,7 @@ if __name__ == "__main__":
     B, n_sub = int(os.environ.get("RSIM_B", {"lift": 4096, "stack": 4096, "peg": 2048, "pickplace": 8192}[CONFIG])), 25
     v = per_dispatch(d, "SQ_INSTS_VALU")[-last:]        # the timed control steps are the last dispatches of the run
     out = {"valu_per_env_substep": float(np.mean(v) / (B * n_sub)), "dispatches": int(len(v)), "envs": B,
-           "lib_sha16": hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16], "code_sha16": config_code_sha16(backend.LIB_PATH, CONFIG),
+           "lib_sha16": hashlib.sha256(open(backend.LIB_PATH, "rb").read()).hexdigest()[:16], "code_sha16": config_code_sha16(backend.LIB_PATH, CONFIG), "wide_code_sha16": wide_code_sha16(backend.LIB_PATH, CONFIG), "tuning_sha16": backend.tuning_sha16(),
            "config": CONFIG,
            "note": "rocprofv3 --pmc SQ_INSTS_VALU, mean over the last control-step dispatches of `bench.py --steps 4 --warmup 1` (steady-state episode phase)"}
     for c in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES"):
