@@ -376,7 +376,8 @@ struct Smem {
   // RSIM_CGLOBAL (32 x 32 build, on top of RSIM_JGLOBAL / RSIM_MGLOBAL): contact frames and contact material parameters -- written once per contact by the narrow phase, read
   // by the row builders -- in the same per-env global buffer behind J and M: 22.6 -> 19.8 KB = EIGHT environments per CU, two wavefronts on every SIMD (layout: CG_* below)
   static constexpr bool FUSEDW_ = RSIM_FUSED_ENABLED && NV == 16 && NEFC == 128;   // the wide body of a fused-tier build (RSIM_DIMS_W): J and the contact block in DBatch.jg
-  static constexpr bool CG_ = (RSIM_CG_ENABLED && RSIM_JG_ENABLED && RSIM_MG_ENABLED && NV == 32 && NEFC == 64) || FUSEDW_;
+  // (64 x 16 build, round 6: J and the contact block out, M stays -- 23.1 KB = seven envs per CU at two wavefronts per SIMD, see the Makefile)
+  static constexpr bool CG_ = (RSIM_CG_ENABLED && RSIM_JG_ENABLED && ((RSIM_MG_ENABLED && NV == 32 && NEFC == 64) || (NB == 64 && NV == 16 && NEFC == 64))) || FUSEDW_;
   static constexpr int CG_FRAME_ = 0, CG_FRI_ = NCON * 9, CG_SOLIMP_ = NCON * 14, CG_SOLREF_ = NCON * 19, CG_MARGIN_ = NCON * 21, CG_WORDS_ = NCON * 22;
   float cpos[NCON * 3], cframe[CG_ ? 1 : NCON * 9], cdist[NCON], cfri[CG_ ? 1 : NCON * 5], csolref[CG_ ? 1 : NCON * 2], csolimp[CG_ ? 1 : NCON * 5], cmu[NCON], cmargin[CG_ ? 1 : NCON];
   int cg1[NCON], cg2[NCON], cdim[NCON], cefc[NCON];
@@ -384,7 +385,7 @@ struct Smem {
   // RSIM_JGLOBAL (64 x 48 build with 128 rows only): the constraint Jacobian lives in a per-env buffer in GLOBAL memory (DBatch.jg; 25 KB per env, L2-resident
   // for the resident envs of an XCD) instead of LDS: 74.8 -> 49.7 KB = three environments per CU instead of two
   // (RSIM_JG256: the 256-row tier of the same shape as well -- 116 -> 66 KB, two jumbo envs per CU instead of one)
-  static constexpr bool JG_ = (RSIM_JG_ENABLED && ((NV == 48 && (NEFC == 128 || (RSIM_JG256_ENABLED && NEFC == 256))) || (NV == 32 && (NEFC == 64 || NEFC == 128)))) || (RSIM_FUSED_ENABLED && NV == 16 && NEFC == 128);
+  static constexpr bool JG_ = (RSIM_JG_ENABLED && ((NV == 48 && (NEFC == 128 || (RSIM_JG256_ENABLED && NEFC == 256))) || (NV == 32 && (NEFC == 64 || NEFC == 128)) || (NB == 64 && NV == 16 && NEFC == 64))) || (RSIM_FUSED_ENABLED && NV == 16 && NEFC == 128);
   float J[JG_ ? 4 : NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
   float e_R[NEFC], e_aref[NEFC], e_force[NEFC];   // e_force doubles as the row's velocity gain B between make_constraint's two halves
   int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
