@@ -199,6 +199,19 @@ def test_narrow_phase_against_elementary_geometry():
         check_narrow_phase(hb.contacts(0), expected, 3e-6, 1e-3 if mpr else 5e-6, 2e-2 if mpr else 1e-5, name)
 
 
+def test_contact_conventions_on_the_kernel():
+    """Contact COUNT and PLACEMENT per pair type on the canonical poses of tests/test_contact_conventions.py (what MuJoCo documents per pair and where this project's
+    narrow phase deviates is written there): plane-box corners, one contact for plane-convex, the clipped-face manifold of box-box up to its eight vertices, one
+    contact inside the patch for the MPR pairs -- the kernel's answers in fp32."""
+    from tests.test_contact_conventions import check_conventions, convention_cases
+    from tests.test_oracle import narrow_phase_scene
+    for name, bodies, expected in convention_cases():
+        flat, hb = _batch(narrow_phase_scene(bodies))
+        hb.forward()
+        mpr = "MPR" in name
+        check_conventions(hb.contacts(0), expected, 3e-6, 5e-6, 2e-3 if mpr else 1e-5, name)
+
+
 def test_mesh_narrow_phase_against_elementary_geometry(tmp_path):
     """The kernel's plane-hull and MPR-on-hull paths (hull vertices in registers, support scans as wave arg-max, coordinates relative to the first geom) on the
     mesh cases of tests/test_oracle.py: a hull vertex in the plane and in a box face, a hull flat on a box, two hulls edge on edge, a 64-gon prism, a geodesic
