@@ -174,17 +174,42 @@ __device__ __forceinline__ double wave_sum_f64(double x) {   // butterfly over t
 // DPP steps that leave lanes without a source unchanged (reductions whose identity is not 0)
 template <int CTRL>
 __device__ __forceinline__ int dpp_keep_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false); }
+// Wave-wide max / min with ONE dpp instruction per step (round 6).  Written as C (update_dpp + fmaxf) each of the six steps compiled to five instructions -- a
+// register copy, the two wait states a DPP read of a fresh VALU result needs, v_mov_b32_dpp, a canonicalising v_max x, x (fmaxf must quiet signalling NaNs) and the
+// v_max itself -- a ~170-cycle dependent chain in front of every mesh support evaluation of the narrow phase, whose runs are what the slowest env of a launch is made
+// of.  v_max_f32_dpp with the shifted lane as first source does a step in one instruction (lanes without a source keep their value: no bound_ctrl); same result bit
+// for bit (max and min are exact; the operands here are never NaN).
 __device__ __forceinline__ float wave_max(float x) {
+#ifdef RSIM_NO_DPP_ASM
 #define RSIM_MX(C) x = fmaxf(x, __builtin_bit_cast(float, dpp_keep_i<C>(__builtin_bit_cast(int, x))))
   RSIM_MX(0x111); RSIM_MX(0x112); RSIM_MX(0x114); RSIM_MX(0x118); RSIM_MX(0x142); RSIM_MX(0x143);
 #undef RSIM_MX
+#else
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0" : "+v"(x));
+#endif
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 __device__ __forceinline__ float wave_min_f(float x) { return -wave_max(-x); }
 __device__ __forceinline__ int wave_min_i(int x) {
+#ifdef RSIM_NO_DPP_ASM
 #define RSIM_MN(C) { int t_ = dpp_keep_i<C>(x); x = t_ < x ? t_ : x; }
   RSIM_MN(0x111) RSIM_MN(0x112) RSIM_MN(0x114) RSIM_MN(0x118) RSIM_MN(0x142) RSIM_MN(0x143)
 #undef RSIM_MN
+#else
+  asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0" : "+v"(x));
+#endif
   return __builtin_amdgcn_readlane(x, 63);
 }
 __device__ __forceinline__ float bcast(float x, int srclane) {
@@ -867,7 +892,7 @@ __device__ __forceinline__ V3 geom_support(cmr_t cm, cmr_t cmg, int g, V3 dir, g
           const int ii = i < num ? i : 0;
           const float x = hv[ii], y = hv[SM::HULLPOOL_ + ii], z = hv[2 * SM::HULLPOOL_ + ii];
           const float val = x * ld.x + y * ld.y + z * ld.z;
-          if (i < num && val > bv) { bv = val; bi = i; bx = x; by = y; bz = z; }
+          const bool take = i < num && val > bv; bv = take ? val : bv; bi = take ? i : bi; bx = take ? x : bx; by = take ? y : by; bz = take ? z : bz;
         }
       }
     } else {
@@ -883,7 +908,7 @@ __device__ __forceinline__ V3 geom_support(cmr_t cm, cmr_t cmg, int g, V3 dir, g
         for (int u = 0; u < 4; u++) {
           const int i = base + 64 * u + lane;
           const float val = vx[u] * ld.x + vy[u] * ld.y + vz[u] * ld.z;
-          if (i < num && val > bv) { bv = val; bi = i; bx = vx[u]; by = vy[u]; bz = vz[u]; }
+          const bool take = i < num && val > bv; bv = take ? val : bv; bi = take ? i : bi; bx = take ? vx[u] : bx; by = take ? vy[u] : by; bz = take ? vz[u] : bz;
         }
       }
     }
@@ -951,11 +976,15 @@ __device__ __forceinline__ V3 sup_eval(const SupGeom& s, V3 dir, gcf mesh_vert, 
     float bv = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f;
     int bi = 0x7fffffff;
     if (s.regs) {
+      // the lane's four vertices: all four projections first, then the first-maximum rule as selects (`if` blocks compiled to four exec-masked regions in a
+      // row, each a VALU -> SALU -> VALU round trip on the critical path of the run)
+      float val[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) val[u] = (64 * u + lane < num) ? s.vx[u] * ld.x + s.vy[u] * ld.y + s.vz[u] * ld.z : -3.0e38f;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int i = 64 * u + lane;
-        const float val = s.vx[u] * ld.x + s.vy[u] * ld.y + s.vz[u] * ld.z;
-        if (i < num && val > bv) { bv = val; bi = i; bx = s.vx[u]; by = s.vy[u]; bz = s.vz[u]; }
+        const bool take = val[u] > bv;   // strictly greater: the lowest index keeps a tie, as the serial scan does
+        bv = take ? val[u] : bv; bi = take ? 64 * u + lane : bi; bx = take ? s.vx[u] : bx; by = take ? s.vy[u] : by; bz = take ? s.vz[u] : bz;
       }
     } else {
       for (int base = 0; base < num; base += 256) {
@@ -970,7 +999,7 @@ __device__ __forceinline__ V3 sup_eval(const SupGeom& s, V3 dir, gcf mesh_vert, 
         for (int u = 0; u < 4; u++) {
           const int i = base + 64 * u + lane;
           const float val = vx[u] * ld.x + vy[u] * ld.y + vz[u] * ld.z;
-          if (i < num && val > bv) { bv = val; bi = i; bx = vx[u]; by = vy[u]; bz = vz[u]; }
+          const bool take = i < num && val > bv; bv = take ? val : bv; bi = take ? i : bi; bx = take ? vx[u] : bx; by = take ? vy[u] : by; bz = take ? vz[u] : bz;
         }
       }
     }
