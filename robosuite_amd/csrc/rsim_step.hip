@@ -37,6 +37,9 @@
 #elif RSIM_CFG == 1
 #define RSIM_DIMS 32, 16, 32, 24, 16, 32, 64, 192
 #define RSIM_SYM(x) x##_cfg1
+#ifdef RSIM_FUSED_TIER   /* the Stack-class tier (32 contacts x 128 rows: the dimensions of configuration 7) as a second body of this configuration's kernel, as for configuration 0 */
+#define RSIM_DIMS_W 32, 16, 32, 24, 16, 32, 128, 192
+#endif
 #elif RSIM_CFG == 2  // 64 bodies x 16 dofs (Baxter: 36 bodies, 29 colliding geoms, 17 sites, 299 candidate pairs): tree products as mask loops, dense ones on one tile
 #define RSIM_DIMS 64, 16, 16, 32, 32, 32, 64, 320
 #define RSIM_SYM(x) x##_cfg2
@@ -384,7 +387,7 @@ struct Smem {
     struct { float cvel[NB * 9]; union { struct { float cvb[NV * 9], cdd[NV * 9]; }; float cacc[NB * 9]; };
              union { float cf[NB * 17]; float F[NV * 17]; }; } v;                          // velocity(): later stages overwrite dead earlier ones
     struct { float cvel[NB * 9]; float Jm[48], Li[36], vv[8], Lt[64], Ys[128]; } k;                  // ctrl_run(): cvel stays live from velocity()
-    float rowst[NV == 16 ? 1 : NEFC * 20];                                                 // make_constraint() (wide): per contact row the two 6-vectors (padded to 8) that multiply cdof, and the two bodies' dof masks
+    float rowst[NV == 16 ? 1 : 64 * 20];                                                 // make_constraint() (wide): per contact row the two 6-vectors (padded to 8) that multiply cdof, and the two bodies' dof masks
     float W[NV == 16 ? NEFC * (NV + 1) : NEFC * 5];                                        // solve_newton(): Hessian-weighted rows (one-tile configurations); wide: five words per row (four block coefficients, block head | dim | cone flag) from which the products form the weighted row on the fly
   } u;
   // RSIM_MGLOBAL (on top of RSIM_JGLOBAL): the mass matrix behind J in the same per-env global buffer: 49.7 -> 40.3 KB = FOUR environments per CU, one wavefront
@@ -400,12 +403,14 @@ struct Smem {
   // contacts
   // RSIM_CGLOBAL (32 x 32 build, on top of RSIM_JGLOBAL / RSIM_MGLOBAL): contact frames and contact material parameters -- written once per contact by the narrow phase, read
   // by the row builders -- in the same per-env global buffer behind J and M: 22.6 -> 19.8 KB = EIGHT environments per CU, two wavefronts on every SIMD (layout: CG_* below)
-  static constexpr bool FUSEDW_ = RSIM_FUSED_ENABLED && NV == 16 && NEFC == 128;   // the wide body of a fused-tier build (RSIM_DIMS_W): J and the contact block in DBatch.jg
+  static constexpr bool FUSEDW_ = RSIM_FUSED_ENABLED && NEFC == 128 && (NV == 16 || NV == 32);   // the wide body of a fused-tier build (RSIM_DIMS_W): J and the contact block in DBatch.jg (32 x 32: M as well, with the build's RSIM_MGLOBAL)
   // (64 x 16 build, round 6: J and the contact block out, M stays -- 23.1 KB = seven envs per CU at two wavefronts per SIMD, see the Makefile)
   static constexpr bool CG_ = (RSIM_CG_ENABLED && RSIM_JG_ENABLED && ((RSIM_MG_ENABLED && NV == 32 && NEFC == 64) || (NB == 64 && NV == 16 && NEFC == 64))) || FUSEDW_;
   static constexpr int CG_FRAME_ = 0, CG_FRI_ = NCON * 9, CG_SOLIMP_ = NCON * 14, CG_SOLREF_ = NCON * 19, CG_MARGIN_ = NCON * 21, CG_WORDS_ = NCON * 22;
   float cpos[NCON * 3], cframe[CG_ ? 1 : NCON * 9], cdist[NCON], cfri[CG_ ? 1 : NCON * 5], csolref[CG_ ? 1 : NCON * 2], csolimp[CG_ ? 1 : NCON * 5], cmu[NCON], cmargin[CG_ ? 1 : NCON];
-  int cg1[NCON], cg2[NCON], cdim[NCON], cefc[NCON];
+  // geom | body << 8 of the two sides, contact dimension, first constraint row (-1: none): 16 / 8-bit fields (round 6: with the row descriptors below 0.5 KB of the wide
+  // bodies' LDS, which is what lets the Stack-class tier share the native body's 20 KB)
+  unsigned short cg1[NCON], cg2[NCON]; short cefc[NCON]; unsigned char cdim[NCON];
   // constraint rows
   // RSIM_JGLOBAL (64 x 48 build with 128 rows only): the constraint Jacobian lives in a per-env buffer in GLOBAL memory (DBatch.jg; 25 KB per env, L2-resident
   // for the resident envs of an XCD) instead of LDS: 74.8 -> 49.7 KB = three environments per CU instead of two
@@ -413,7 +418,7 @@ struct Smem {
   static constexpr bool JG_ = (RSIM_JG_ENABLED && ((NV == 48 && (NEFC == 128 || (RSIM_JG256_ENABLED && NEFC == 256))) || (NV == 32 && (NEFC == 64 || NEFC == 128)) || (NB == 64 && NV == 16 && NEFC == 64))) || (RSIM_FUSED_ENABLED && NV == 16 && NEFC == 128);
   float J[JG_ ? 4 : NEFC * (NV + 1)];  // row-major, stride JS = NV + 1 (odd: the row-owner lanes hit distinct banks); four rows = one MFMA B operand
   float e_R[NEFC], e_aref[NEFC], e_force[NEFC];   // e_force doubles as the row's velocity gain B between make_constraint's two halves
-  int e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block)
+  unsigned short e_desc[NEFC];    // type | id<<4 | k<<12 (row k of its block): 16 bits
   float cstate[RSIM_CS_LDS];     // first RSIM_CS_LDS floats of the controller state (all of it for the OSC and plain joint-space types); the tail stays in global memory
   float red[NV];
   float hull[3 * HULLPOOL_ + 1];    // LDS-resident hull vertex pool (SoA x | y | z); filled once per launch
@@ -2783,10 +2788,19 @@ struct Sim {
   // rows (friction loss, limits, tendons) stage zeros and write their one to four entries afterwards.
   __device__ __forceinline__ void make_rows_wide(int nefc) {
     const int nv = m.nv, q = lane >> 4, r = lane & 15;
-    float* st = sm.u.rowst;   // [row][20]: w2[8] | -w1[8] | mask2 lo hi | mask1 lo hi
+    float* st = sm.u.rowst;   // [64][20], one slot (64 rows) of the lanes at a time: w2[8] | -w1[8] | mask2 lo hi | mask1 lo hi
+    float cb[NT][2];   // B operands: cdof rows of every dof tile, components 4 kc + q (6 and 7 are the zero padding of the stride-9 rows)
+#pragma unroll
+    for (int ct = 0; ct < NT; ct++)
+#pragma unroll
+      for (int kc = 0; kc < 2; kc++) cb[ct][kc] = sm.cdof[(16 * ct + r) * CS6 + 4 * kc + q];
+    const int nrt = (nefc + 15) >> 4;
+    // slot by slot (round 6): the staging holds 64 rows whatever the row capacity -- 5 KB instead of 10 / 20 KB in the 128 / 256-row builds, where it was the
+    // largest member of the phase union
 #pragma unroll
     for (int slot = 0; slot < NSLOT; slot++) {
       if (64 * slot >= nefc) continue;   // this slot of the lanes holds no row (the 128 / 256-row configurations at the usual row counts)
+      if (slot > 0) SYNC();              // the products of the slot before have read the staging
       const int row = lane + 64 * slot;
       const bool valid = row < nefc;
       const int desc = valid ? sm.e_desc[row] : 0;
@@ -2808,27 +2822,21 @@ struct Sim {
           w2[0] = ax.x; w2[1] = ax.y; w2[2] = ax.z;
         }
       }
-      float* o = st + 20 * row;
+      float* o = st + 20 * lane;
 #pragma unroll
       for (int k = 0; k < 6; k++) { o[k] = w2[k]; o[8 + k] = w1[k]; }
       o[6] = 0.f; o[7] = 0.f; o[14] = 0.f; o[15] = 0.f;
       ((unsigned*)o)[16] = (unsigned)m2; ((unsigned*)o)[17] = (unsigned)(m2 >> 32); ((unsigned*)o)[18] = (unsigned)m1; ((unsigned*)o)[19] = (unsigned)(m1 >> 32);
-    }
-    SYNC();
-    {
-      float cb[NT][2];   // B operands: cdof rows of every dof tile, components 4 kc + q (6 and 7 are the zero padding of the stride-9 rows)
-#pragma unroll
-      for (int ct = 0; ct < NT; ct++)
-#pragma unroll
-        for (int kc = 0; kc < 2; kc++) cb[ct][kc] = sm.cdof[(16 * ct + r) * CS6 + 4 * kc + q];
-      const int nrt = (nefc + 15) >> 4;
-      for (int rt = 0; rt < nrt; rt++) {
-        const float* o = st + 20 * (16 * rt + r);
+      SYNC();
+      const int rt1 = nrt < 4 * slot + 4 ? nrt : 4 * slot + 4;
+      for (int rt = 4 * slot; rt < rt1; rt++) {
+        const int lt = rt - 4 * slot;   // row tile inside the staging
+        const float* o = st + 20 * (16 * lt + r);
         const float a2[2] = {o[q], o[4 + q]}, a1[2] = {o[8 + q], o[12 + q]};
         u64 k2[4], k1[4];
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-          const unsigned* w = (const unsigned*)(st + 20 * (16 * rt + 4 * q + v)) + 16;
+          const unsigned* w = (const unsigned*)(st + 20 * (16 * lt + 4 * q + v)) + 16;
           k2[v] = (u64)w[0] | ((u64)w[1] << 32); k1[v] = (u64)w[2] | ((u64)w[3] << 32);
         }
 #pragma unroll
@@ -4867,9 +4875,9 @@ extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStr
 }
 #endif  // RSIM_CFG == 0
 
-#if RSIM_CFG == 0
+#if RSIM_CFG == 0 || RSIM_CFG == 1
 // limits of the wide body of a fused-tier build (layout of rsim_limits); returns 0 when this build has none
-extern "C" int rsim_limits_w_cfg0(int* lim) {
+extern "C" int RSIM_SYM(rsim_limits_w)(int* lim) {
 #ifdef RSIM_DIMS_W
   const int dims[8] = {RSIM_DIMS_W};
   for (int i = 0; i < 8; i++) lim[i] = dims[i];
