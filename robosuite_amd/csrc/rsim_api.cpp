@@ -45,6 +45,9 @@ extern "C" int rsim_launch_step_list_cfg3(const DModel* m, const DBatch* b, cons
 extern "C" int rsim_launch_tier_list(const int* tier, int* list, int* count, int* zero_next, int env0, int n, hipStream_t stream);
 extern "C" int rsim_limits_w_cfg0(int* lim);   // limits of the wide body compiled into configuration 0's / 1's control-step kernel (fused tier); 0: this build has none
 extern "C" int rsim_limits_w_cfg1(int* lim);
+extern "C" int rsim_limits_w_cfg2(int* lim);
+typedef int (*limits_w_fn)(int*);
+static const limits_w_fn k_limits_w[3] = {rsim_limits_w_cfg0, rsim_limits_w_cfg1, rsim_limits_w_cfg2};
 typedef int (*step_list_fn)(const DModel*, const DBatch*, const float*, int, int, int, hipStream_t);
 typedef int (*step_fn)(const DModel*, const DBatch*, const float*, int, int, hipStream_t);
 typedef int (*creset_fn)(const DModel*, const DBatch*, const unsigned char*, hipStream_t);
@@ -897,9 +900,9 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   // capacity tiers: only for controllers whose state lives in LDS for the whole launch (a step that is handed over must not have written anything)
   b->cfg_w = b->cs <= RSIM_CS_LDS ? pick_wide(m, b->cfg, b->lim, b->lim_w) : -1;
   b->fused = 0;
-  if (b->cfg_w >= 0 && (b->cfg == 0 || b->cfg == 1) && (b->lim[9] & 32) && !getenv("RSIM_NO_TIERS")) {
+  if (b->cfg >= 0 && b->cfg <= 2 && (b->lim[9] & 32) && b->cs <= RSIM_CS_LDS && !getenv("RSIM_NO_TIERS")) {
     int lw[10];
-    if ((b->cfg == 0 ? rsim_limits_w_cfg0(lw) : rsim_limits_w_cfg1(lw)) && config_holds(m, lw)) { memcpy(b->lim_w, lw, sizeof(lw)); b->fused = 1; }
+    if (k_limits_w[b->cfg](lw) && config_holds(m, lw)) { memcpy(b->lim_w, lw, sizeof(lw)); b->fused = 1; if (b->cfg_w < 0) b->cfg_w = b->cfg; }   // (cfg_w only marks "tiered" from here on: a fused batch launches no tier kernel)
   }
   {
     // builds that keep the constraint Jacobian in global memory (RSIM_JGLOBAL: limits bit 2) get their per-env buffer, [B][NEFC * (NV + 1)] floats
@@ -1640,9 +1643,9 @@ extern "C" const char* rsim_tuning_defaults(void) {
   static std::string s;
   char buf[1024];
   snprintf(buf, sizeof(buf), "newton_ns=%g;newton_na=%g;newton_ls=%g;newton_ng=%g;newton_wide=1;newton_exact=1;newton_refine(cfg>=3)=16;polish_tol=1;polish_gate=0;"
-           "bp_reach=%g;mpr_cone=%g;mpr_warmstart=1;mpr_portal=1;tier_up(cfg0,cfg1)=0/0;tier_up(other)=2/6;tier_mode=0;order_fresh=1;fused_tier_cfg0=%d;fused_tier_cfg1=%d",
+           "bp_reach=%g;mpr_cone=%g;mpr_warmstart=1;mpr_portal=1;tier_up(cfg0,cfg1)=0/0;tier_up(other)=2/6;tier_mode=0;order_fresh=1;fused_tier_cfg0=%d;fused_tier_cfg1=%d;fused_tier_cfg2=%d",
            (double)RSIM_NEWTON_NS, (double)RSIM_NEWTON_NA, (double)RSIM_NEWTON_LS, (double)RSIM_NEWTON_NG, (double)RSIM_BP_REACH, (double)RSIM_MPR_CONE,
-           []{ int lw[10]; return rsim_limits_w_cfg0(lw); }(), []{ int lw[10]; return rsim_limits_w_cfg1(lw); }());
+           []{ int lw[10]; return rsim_limits_w_cfg0(lw); }(), []{ int lw[10]; return rsim_limits_w_cfg1(lw); }(), []{ int lw[10]; return rsim_limits_w_cfg2(lw); }());
   s = buf;
   static const char* const envs[] = {"RSIM_NEWTON_NS", "RSIM_NEWTON_NA", "RSIM_NEWTON_LS", "RSIM_NEWTON_NG", "RSIM_NEWTON_WIDE", "RSIM_NEWTON_EXACT", "RSIM_NEWTON_REFINE",
                                      "RSIM_POLISH_TOL", "RSIM_POLISH_GATE", "RSIM_BP_REACH", "RSIM_MPR_CONE", "RSIM_NO_MPR_WARMSTART", "RSIM_NO_MPR_PORTAL_WARMSTART",

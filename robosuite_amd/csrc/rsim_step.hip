@@ -43,6 +43,9 @@
 #elif RSIM_CFG == 2  // 64 bodies x 16 dofs (Baxter: 36 bodies, 29 colliding geoms, 17 sites, 299 candidate pairs): tree products as mask loops, dense ones on one tile
 #define RSIM_DIMS 64, 16, 16, 32, 32, 32, 64, 320
 #define RSIM_SYM(x) x##_cfg2
+#ifdef RSIM_FUSED_TIER   /* the tier above this configuration as a second body of its kernel: the same lane roles with 128 rows (before: the 64 x 48 build's kernel served as its tier) */
+#define RSIM_DIMS_W 64, 16, 16, 32, 32, 32, 128, 320
+#endif
 #elif RSIM_CFG == 3  // 64 bodies x 48 dofs x 128 constraint rows (PickPlace / IIWA + Robotiq140: 36 bodies, 37 dofs, 41 colliding geoms, 622 candidate
        // pairs, tendon rows; a closed Robotiq gripper alone holds ~30 rows of self-contact).  Three 16-dof tiles instead of four: the dense matrices
        // (M, H, J) shrink to 75 KB of LDS per environment = TWO environments per CU
@@ -4875,7 +4878,7 @@ extern "C" int rsim_launch_order(const unsigned* cost, int* order, int B, hipStr
 }
 #endif  // RSIM_CFG == 0
 
-#if RSIM_CFG == 0 || RSIM_CFG == 1
+#if RSIM_CFG == 0 || RSIM_CFG == 1 || RSIM_CFG == 2
 // limits of the wide body of a fused-tier build (layout of rsim_limits); returns 0 when this build has none
 extern "C" int RSIM_SYM(rsim_limits_w)(int* lim) {
 #ifdef RSIM_DIMS_W

@@ -528,6 +528,37 @@ def test_fused_tier_hand_over_in_mid_step_carries_the_step_on(monkeypatch):
         assert np.array_equal(got[0]["cap_need"], ref[0]["cap_need"])       # same contacts found in the first compared step (identical state going in)
 
 
+def test_fused_tier_hand_over_with_two_osc_arm_parts(monkeypatch):
+    """The 64 x 16 build (Baxter class) carries its tier as a second body too.  Its hand-over has more to carry: 64 floats of controller state (two OSC arm parts).
+    The reference-recorded Baxter / OSC_POSE fixture, every control step handed over at substep 9, tracks the oracle loop and the fixture at the tolerances of the
+    plain run (tests/test_hip_parity.py::test_baxter_two_osc_arm_parts_track_the_reference_loop)."""
+    from oracle.oracle import env_step_parts
+    from tests.util import load_golden, make_hip, make_oracle_parts
+    g, cfg, flat = load_golden("ctl_osc_pose", "peg_baxter")
+    nq = flat.nq
+    om, od, parts = make_oracle_parts(flat, cfg)
+    hm, hb = make_hip(flat, cfg, B=3)
+    s0 = g["states"][0]
+    od.qpos[:] = s0[1:1 + nq]; od.qvel[:] = s0[1 + nq:]; od.qacc_warmstart[:] = 0; od.forward()
+    for c, _ in parts:
+        c.reset(od)
+    hb.set("qpos", s0[1:1 + nq][None].repeat(3, 0)); hb.set("qvel", s0[1 + nq:][None].repeat(3, 0)); hb.set("qacc_warmstart", 0); hb.set("ctrl", 0)
+    hb.forward(); hb.ctrl_reset()
+    monkeypatch.setenv("RSIM_FORCE_HANDOVER", "9")
+    t0 = hb.tier_stats()
+    for t in range(len(g["actions"])):
+        hb.control_step(torch.tensor(np.repeat(g["actions"][t][None], 3, 0), dtype=torch.float32, device="cuda"), 25)
+        env_step_parts(od, parts, g["actions"][t], 25)
+        hq, hv = hb.get("qpos")[0], hb.get("qvel")[0]
+        assert np.abs(hq - od.qpos).max() < 5e-4 and np.abs(hv - od.qvel).max() < 5e-3, t
+        assert np.abs(hq - g["states"][t + 1][1:1 + nq]).max() < 5e-4 and np.abs(hv - g["states"][t + 1][1 + nq:]).max() < 5e-3, t
+        assert np.abs(hb.get("ctrl")[0] - g["ctrl"][t]).max() < 2e-3 * max(1.0, np.abs(g["ctrl"][t]).max()), t
+    t1 = hb.tier_stats()
+    monkeypatch.delenv("RSIM_FORCE_HANDOVER")
+    assert t1[1] - t0[1] == 3 * len(g["actions"])          # every env of every step really went through the hand-over
+    assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[2]) and int(hb.get("overflow").sum()) == 0
+
+
 def test_capacity_tiers_with_per_env_model_parameters_and_stream_groups():
     """The wide configuration reads an env's OWN constant block (per-episode cube sizes: built on demand right before the wide pass steps the env);
     with stream groups every env block runs its own native pass, wide pass and redo pass on its own stream.  Same envs, same results."""
