@@ -178,6 +178,9 @@ struct rsim_batch {
   // between steps (tier_next), an env that runs out of capacity in mid-step commits nothing and is redone by the wide configuration inside the same
   // rsim_control_step (redo list).  -1: no tier above this batch's configuration.
   int cfg_w;
+  int share_cm;       // the tier's kernel reads the NATIVE constant blocks: its configuration differs from the batch's in contact / row capacity only, and the block layout
+                      // (Cmem) depends on neither -- no wide blocks to build before a wide pass (round 6: PickPlace's 256-row tier rebuilt its listed envs' blocks
+                      // three times per control step under per-step DR, 3 ms a launch, one of them on the critical path behind the native pass)
   int fused;          // the tier above the batch's configuration is compiled into its control-step kernel (limits bit 5): an env that needs it is stepped -- or carried on
                       // from the substep in which it outgrew the native capacity -- by the wide body inside its own workgroup; no list, no wide launch, no redo
   int lim_w[10];
@@ -899,7 +902,7 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.ctrl.cs_size = b->cs;
   // capacity tiers: only for controllers whose state lives in LDS for the whole launch (a step that is handed over must not have written anything)
   b->cfg_w = b->cs <= RSIM_CS_LDS ? pick_wide(m, b->cfg, b->lim, b->lim_w) : -1;
-  b->fused = 0;
+  b->fused = 0; b->share_cm = 0;
   if (b->cfg >= 0 && b->cfg <= 2 && (b->lim[9] & 32) && b->cs <= RSIM_CS_LDS && !getenv("RSIM_NO_TIERS")) {
     int lw[10];
     if (k_limits_w[b->cfg](lw) && config_holds(m, lw)) { memcpy(b->lim_w, lw, sizeof(lw)); b->fused = 1; if (b->cfg_w < 0) b->cfg_w = b->cfg; }   // (cfg_w only marks "tiered" from here on: a fused batch launches no tier kernel)
@@ -920,6 +923,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   b->d_cm_w = nullptr; b->d_tier[0] = b->d_tier[1] = nullptr; b->d_wlist[0] = b->d_wlist[1] = nullptr; b->d_wcount = nullptr; b->wstream = nullptr; b->tier_flip = 0;
   if (b->cfg_w >= 0) {
     b->cm_bytes_w = (size_t)cmem_bytes_any(b->cfg_w);
+    b->share_cm = b->cm_bytes_w == b->cm_bytes && b->lim_w[0] == b->lim[0] && b->lim_w[1] == b->lim[1] && b->lim_w[2] == b->lim[2] && b->lim_w[3] == b->lim[3] &&
+                  b->lim_w[4] == b->lim[4] && b->lim_w[7] == b->lim[7] && !getenv("RSIM_NO_SHARE_CM");
     if (dalloc((char**)&b->d_cm_w, b->cm_bytes_w * (1 + (b->per_env ? (size_t)B : 0)))) return 1;
     for (int k = 0; k < 2; k++) if (dalloc(&b->d_tier[k], (size_t)B) || dalloc(&b->d_wlist[k], (size_t)B)) return 1;
     if (dalloc(&b->d_wcount, (size_t)2 * (2 + 2 * RSIM_MAX_GROUPS))) return 1;
@@ -1132,7 +1137,7 @@ static int ensure_constants(rsim_batch* b) {
     int e = k_prepare_launch[b->cfg](&b->dm, &b->db, b->B, 0, b->stream);
     if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   }
-  if (b->cfg_w >= 0 && !b->fused) {   // the shared block of the wide configuration (its per-env blocks are built on demand, right before a wide pass; a fused wide body reads the native blocks)
+  if (b->cfg_w >= 0 && !b->fused && !b->share_cm) {   // the shared block of the wide configuration (its per-env blocks are built on demand, right before a wide pass; a fused wide body reads the native blocks)
     DModel dm0 = b->dm; DBatch db0 = b->db;
     dm0.fenv = 0; db0.cm_env = b->d_cm_w; db0.cm_stride = 0;
     int e = prepare_launch_any(b->cfg_w)(&dm0, &db0, 1, 0, b->stream);
@@ -1171,11 +1176,11 @@ static void tr_mark(rsim_batch* b, int point) {
 static inline bool sched1_trace(int flags) { return (flags & RF_EPISODE) && (flags & RF_CTRL); }
 static int wide_pass(rsim_batch* b, const float* actions, int n_sub, int flags, int pass, const int* list, const int* count, hipStream_t stream) {
   DBatch dw = b->db;
-  dw.cm = b->d_cm_w; dw.cm_env = (char*)b->d_cm_w + b->cm_bytes_w; dw.cm_stride = b->db.cm_stride ? (long long)b->cm_bytes_w : 0;
+  if (!b->share_cm) { dw.cm = b->d_cm_w; dw.cm_env = (char*)b->d_cm_w + b->cm_bytes_w; dw.cm_stride = b->db.cm_stride ? (long long)b->cm_bytes_w : 0; }   // else: the native blocks, as b->db has them
   dw.order = nullptr; dw.cost = nullptr; dw.env0 = 0; dw.nenv = 0;
   dw.tier_pass = pass; dw.wlist = list; dw.wcount = count; dw.tier_con = b->lim[5]; dw.tier_efc = b->lim[6];
   const int grid = b->B < 512 ? b->B : 512;
-  if (dw.cm_stride) {
+  if (dw.cm_stride && !b->share_cm) {
     int e = prepare_launch_any(b->cfg_w)(&b->dm, &dw, grid, 2, stream);
     if (e) return fail("constant-block kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   }
