@@ -165,3 +165,22 @@ def test_other_config_line_and_a_failing_child(monkeypatch, capsys):
     d, log = _run_main(monkeypatch, capsys, ["--steps", "2", "--warmup", "1", "--preroll", "0", "--envs-per-gpu", "4", "--no-open-loop", "--no-cpu-baseline"], child=dying)
     oc = d["config"]["other_configs"]
     assert set(oc) == {"stack", "peg", "pickplace"} and all("Memory access fault" in v["error"] for v in oc.values()) and d["value"] > 0
+
+
+def test_reference_baseline_harness_is_blocked_loudly_without_mujoco_and_runs_on_the_shim():
+    """tools/bench_reference.py (BASELINE.md section 2, B-ref): without the `mujoco` wheel it must say so and exit 3 -- never substitute anything silently; with
+    `--backend shim` the same harness (N processes, barrier, suite.make with the B-ref kwargs, env.step loop) runs end to end on the fp64 oracle and labels its number
+    "port" / B-cpu, so that the day a wheel exists only the backend changes."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "bench_reference.py")
+    if importlib.util.find_spec("mujoco") is None:
+        r = subprocess.run([sys.executable, tool, "--procs", "1", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=120)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert r.returncode == 3 and d["baseline"] == "B-ref" and "not importable" in d["error"]
+    if not os.path.isdir("/root/reference/robosuite"):
+        pytest.skip("no reference checkout: the shim run needs robosuite's own Python")
+    r = subprocess.run([sys.executable, tool, "--procs", "2", "--steps", "3", "--warmup", "1", "--backend", "shim"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["baseline"] == "B-cpu" and d["kind"] == "port" and d["cores"] == 2 and d["value"] > 0 and "NOT MuJoCo" in d["sample"] and len(d["per_worker_steps_per_s"]) == 2

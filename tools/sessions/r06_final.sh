@@ -12,7 +12,7 @@ echo "=== driver-like bench"
 ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_driver_like.json 2> $O/${TAG}_bench_driver_like.err ) 2>&1 | tail -3
 python - <<'PY'
 import json, os
-d = json.loads(open("gpurun_out/${TAG}_bench_driver_like.json").read().strip().splitlines()[-1])
+d = json.loads(open(os.environ["TAG_FILE"]).read().strip().splitlines()[-1])
 print("value", d["value"], "ms", d["ms_per_step"], d["step_ms"], "tier", d["tier_env_steps"], d["tier_changes_in_mid_step"], "issue", (d["roofline"].get("issue") or {}).get("frac") if isinstance(d["roofline"].get("issue"), dict) else d["roofline"].get("issue"), "traffic", d["roofline"]["traffic"])
 for k, v in (d["config"].get("other_configs") or {}).items(): print(k, {a: v.get(a) for a in ("value", "ms_per_step", "step_ms", "overflow_envs", "diverged_envs", "issue_frac", "traffic", "error")}, (v.get("double_buffered") or {}).get("value"))
 print("cpu", d.get("cpu_baseline", {}).get("value"), d.get("cpu_baseline", {}).get("cores"))
