@@ -302,7 +302,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="lift only: skip the short secondary regions of BASELINE configs[2..4] (config.other_configs)")
     ap.add_argument("--other-steps", type=int, default=-1, help="timed lockstep control steps of each secondary configuration (default: OTHER_REGION, 50 where a step takes a few ms, 10 for PickPlace)")
     ap.add_argument("--other-preroll", type=int, default=-1, help="untimed launches before each secondary region (episode steps staggered as in the headline region; default: OTHER_REGION, 300 / 50)")
-    ap.add_argument("--allow-collective-fallback", action="store_true", help="N > 1: if the C-ABI RCCL communicator cannot be formed, reduce the rollout statistics through torch.distributed (reported as \"collective\": \"fallback: ...\") instead of failing")
+    ap.add_argument("--strict-collective", action="store_true", help="N > 1: exit with code 4 if the C-ABI RCCL communicator cannot be formed (default: reduce the rollout statistics through torch.distributed and say so at top level, \"collective\": \"fallback: ...\", and on stderr)")
     ap.add_argument("--secondary-only", choices=sorted(CONFIGS), default=None, help="internal: run one secondary region and print its record (the default run starts one child per configuration)")
     args = ap.parse_args()
 
@@ -434,17 +434,17 @@ def main():
                                    "half can reach; `value` above is the stricter one-policy-call-per-step protocol"}
 
     # the end-of-rollout statistics go through the C-ABI's own collective (rsim_comm_* / rsim_allreduce_stats over RCCL) when there is more than one rank.  If
-    # that communicator cannot be formed the run FAILS (exit code 4) unless --allow-collective-fallback was given, in which case the job's torch process group
-    # carries the numbers and the line says so at top level ("collective": "fallback: ..."): a multi-GPU line that never touched the C-ABI collective must not
-    # look like one that did (round-5 review).  shard.hip_comm raises on every rank or on none.
+    # that communicator cannot be formed the job's torch process group carries the five numbers and the line says so LOUDLY -- top-level "collective":
+    # "fallback: <why>" and a warning on stderr from every rank -- so that a multi-GPU line that never touched the C-ABI collective cannot look like one that did
+    # (round-5 review); --strict-collective turns it into exit code 4.  shard.hip_comm raises on every rank or on none.
     comm, comm_note = None, None
     if world > 1:
         try:
             comm = shard.hip_comm(rank, world, local_rank)
         except shard.CommUnavailable as e:
             comm_note = str(e)
-            if not args.allow_collective_fallback:
-                print(f"bench.py rank {rank}: the C-ABI collective is unavailable ({e}); pass --allow-collective-fallback to reduce through torch.distributed instead", file=sys.stderr, flush=True)
+            print(f"bench.py rank {rank}: WARNING: the C-ABI collective is unavailable ({e}); the rollout statistics go through torch.distributed (reported as \"collective\": \"fallback\")", file=sys.stderr, flush=True)
+            if args.strict_collective:
                 torch.distributed.destroy_process_group()
                 raise SystemExit(4)
     st = shard.RolloutStats(dev, comm=comm)
