@@ -372,7 +372,7 @@ struct Smem {
   // configurations trade pool for a third environment per CU: 64 x 16 keeps 192 vertices (53.7 KB; 57.6 KB = two per CU with the full pool),
   // 32 x 32 keeps 64 and factors M + hD again at the Euler step instead of keeping it (53.6 KB instead of 63.2 KB).  The host assigns pool
   // slots for the largest pool and load_constants() drops what does not fit.
-  static constexpr int HULLPOOL_ = (NV > 32 || (NB == 32 && NV == 16) || RSIM_NOHULLPOOL) ? 0 : (NV == 32 ? 64 : 192);   // 32 x 16: 20 KB = eight environments per CU, hulls are scanned from global memory (L1-resident: every env of the CU scans the same vertices)
+  static constexpr int HULLPOOL_ = (NV > 32 || (NB == 32 && NV == 16) || RSIM_NOHULLPOOL) ? 0 : (NV == 32 ? 64 : 176);   // (64 x 16: 176 pool vertices, not 192: 31 892 B = 25 LDS allocation granules of 1280 B = FIVE envs per CU, round 6)  32 x 16: 20 KB = eight environments per CU, hulls are scanned from global memory (L1-resident: every env of the CU scans the same vertices)
   static constexpr int NB_ = NB;
   float qpos[NV + 8], qvel[NV], qacc[NV], qacc_ws[NV], ctrl[NV];
   float xpos[NB * 3], xquat[NB * 4];

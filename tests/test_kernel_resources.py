@@ -15,7 +15,8 @@ LDS_PER_CU = 160 * 1024
 # k_step<NB, NJ, NV, NG, NS, NCON, NEFC, NPAIR>: (environments per CU by LDS, register budget VGPR + AGPR, private-segment bytes tolerated)
 STEP_BUDGET = {"ILi32ELi16ELi16ELi24ELi16ELi16ELi64ELi192E": (8, 256, 32),    # round 6: 0 B at 234 registers with BOTH bodies (native + fused wide tier, 20 408 B of LDS) reading their arguments from the kernarg segment; 52 B in round 5 (round 3: 156, round 4 before the MachineLICM flags: 124): profiles/r04_y_ab_spills.txt
                 "ILi32ELi16ELi32ELi24ELi16ELi32ELi64ELi192E": (8, 256, 32),   # Stack: J, M and the contact block in global memory, no LDS hull pool, two wavefronts per SIMD (round 5, sessions 12 / 13: 36.1 -> 19.8 KB, four -> eight envs per CU); round 6: native + fused wide body in 20 328 B, 249 registers, no scratch
-               "ILi64ELi16ELi16ELi32ELi32ELi32ELi64ELi320E": (5, 512, 0), "ILi64ELi32ELi48ELi64ELi32ELi32ELi128ELi640E": (4, 512, 0),   # J and M in global memory (RSIM_JGLOBAL round 4: 74.8 -> 49.7 KB = 3; RSIM_MGLOBAL round 5: 40.3 KB = 4, one wavefront per SIMD)
+               "ILi64ELi16ELi16ELi32ELi32ELi32ELi64ELi320E": (5, 256, 32),   # round 6: 31 892 B = 25 granules, 247 registers: five envs per CU (before: 32 084 B = 26 granules = four, whatever the registers)
+                "ILi64ELi32ELi48ELi64ELi32ELi32ELi128ELi640E": (4, 512, 0),   # J and M in global memory (RSIM_JGLOBAL round 4: 74.8 -> 49.7 KB = 3; RSIM_MGLOBAL round 5: 40.3 KB = 4, one wavefront per SIMD)
                "ILi64ELi32ELi64ELi64ELi32ELi32ELi128ELi640E": (1, 512, 0),
                # the capacity tiers (round 4): above 64 x 48, above the Lift configuration, above the Stack configuration.  The 256-row tier (four rows per lane, J in
                # global memory since round 5: two per CU) spills in the polish's fp64 line search (424 B); it steps the few envs beyond 128 rows
@@ -31,9 +32,9 @@ def test_fused_kernel_configurations_keep_their_lds_and_register_budgets():
     for tag, (envs, regs, scratch) in STEP_BUDGET.items():
         (name,) = [n for n in steps if tag in n]
         r = steps[name]
-        # LDS is allocated in granules (512 B assumed): the budget is checked on the rounded size
-        assert envs * (-(-r["lds"] // 512) * 512) <= LDS_PER_CU, (name, r)
-        assert (envs + 1) * (-(-r["lds"] // 512) * 512) > LDS_PER_CU   # the table above states the real LDS occupancy (at the allocation granule), not a lower bound
+        # LDS is allocated in granules of 1280 B (measured in round 6: tools/kernel_resources.py LDS_GRANULE): the budget is checked on the rounded size
+        assert envs * (-(-r["lds"] // 1280) * 1280) <= LDS_PER_CU, (name, r)
+        assert (envs + 1) * (-(-r["lds"] // 1280) * 1280) > LDS_PER_CU   # the table above states the real LDS occupancy (at the allocation granule), not a lower bound
         assert r["vgpr"] <= regs, (name, r)                            # vgpr_count of the code object = VGPR + AGPR; <= 256: two wavefronts per SIMD
         # (almost) no private segment: besides spills, a run-time index into the by-value DModel kernel argument -- or a select between two
         # pointers derived from it -- makes the compiler keep a 1.9 KB copy of DModel there and read every model scalar from that copy
