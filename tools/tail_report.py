@@ -1,7 +1,7 @@
 """What sets the length of a lockstep launch: per-env wavefront durations of ONE control step of the bench workload (4096 Lift envs, all at
 episode step `nskip`), their percentiles, the event counts of the slowest envs, and the per-phase profile of the slowest / p99 / median env.
 With a -DRSIM_MPRSTAT build (tools/subprof.sh mpr) slots x0..x7 say how the MPR runs end.
-Usage (GPU box): [RSIM_LIB=...] python tools/tail_report.py [nskip=200] [B=4096] [task=lift|stack|peg]   (slots per launch: 8 / 4 / 4 resident envs per CU x 256 CUs)"""
+Usage (GPU box): [RSIM_LIB=...] python tools/tail_report.py [nskip=200] [B=4096] [task=lift|stack|peg]   (slots per launch: 8 / 8 / 5 resident envs per CU x 256 CUs)"""
 import json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ from robosuite_amd import lift, mjcf, peg_in_hole, stack
 nskip = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 TASK = sys.argv[3] if len(sys.argv) > 3 else "lift"
-STEM, CLS, SLOTS = {"lift": ("lift_panda", lift.LiftBatch, 2048), "stack": ("stack_panda", stack.StackBatch, 1024), "peg": ("peg_baxter_joint_velocity", peg_in_hole.PegBatch, 1024)}[TASK]
+STEM, CLS, SLOTS = {"lift": ("lift_panda", lift.LiftBatch, 2048), "stack": ("stack_panda", stack.StackBatch, 2048), "peg": ("peg_baxter_joint_velocity", peg_in_hole.PegBatch, 1280)}[TASK]
 adir = os.path.join(ROOT, "robosuite_amd", "assets")
 flat = mjcf.load_model(os.path.join(adir, STEM + ".rsim")); cfg = json.load(open(os.path.join(adir, STEM + ".cfg.json")))
 MPR_SLOTS = ("x0 exit pre-test", "x1 exit 1st support", "x2 exit 2nd support", "x3 exit portal discovery", "x4 exit refinement", "x5 contact", "x6 supports of contacts", "x7 supports of late exits", "x8 exit warm start", "x9 portal warm start valid")
