@@ -869,6 +869,8 @@ extern "C" int rsim_batch_create(rsim_model* m, int B, int device, int per_env, 
   dm.newton_ns = getenv("RSIM_NEWTON_NS") ? (float)atof(getenv("RSIM_NEWTON_NS")) : RSIM_NEWTON_NS;
   dm.newton_na = getenv("RSIM_NEWTON_NA") ? (float)atof(getenv("RSIM_NEWTON_NA")) : RSIM_NEWTON_NA;
   dm.mpr_cone = getenv("RSIM_MPR_CONE") ? (float)atof(getenv("RSIM_MPR_CONE")) : RSIM_MPR_CONE;
+  dm.near_gain = getenv("RSIM_NEAR_GAIN") ? (float)atof(getenv("RSIM_NEAR_GAIN")) : RSIM_NEAR_GAIN;
+  dm.near_thresh = getenv("RSIM_NEAR_THRESH") ? (float)atof(getenv("RSIM_NEAR_THRESH")) : RSIM_NEAR_THRESH;
   dm.bp_reach = getenv("RSIM_BP_REACH") ? (float)atof(getenv("RSIM_BP_REACH")) : RSIM_BP_REACH;
   dm.newton_wide = getenv("RSIM_NEWTON_WIDE") ? atoi(getenv("RSIM_NEWTON_WIDE")) : 1;
   dm.newton_ls = getenv("RSIM_NEWTON_LS") ? (float)atof(getenv("RSIM_NEWTON_LS")) : RSIM_NEWTON_LS;
@@ -1648,12 +1650,12 @@ extern "C" const char* rsim_tuning_defaults(void) {
   static std::string s;
   char buf[1024];
   snprintf(buf, sizeof(buf), "newton_ns=%g;newton_na=%g;newton_ls=%g;newton_ng=%g;newton_wide=1;newton_exact=1;newton_refine(cfg>=3)=16;polish_tol=1;polish_gate=0;"
-           "bp_reach=%g;mpr_cone=%g;mpr_warmstart=1;mpr_portal=1;tier_up(cfg0,cfg1)=0/0;tier_up(other)=2/6;tier_mode=0;order_fresh=1;fused_tier_cfg0=%d;fused_tier_cfg1=%d;fused_tier_cfg2=%d",
-           (double)RSIM_NEWTON_NS, (double)RSIM_NEWTON_NA, (double)RSIM_NEWTON_LS, (double)RSIM_NEWTON_NG, (double)RSIM_BP_REACH, (double)RSIM_MPR_CONE,
+           "bp_reach=%g;near_thresh=%g;near_gain=%g;mpr_cone=%g;mpr_warmstart=1;mpr_portal=1;tier_up(cfg0,cfg1)=0/0;tier_up(other)=2/6;tier_mode=0;order_fresh=1;fused_tier_cfg0=%d;fused_tier_cfg1=%d;fused_tier_cfg2=%d",
+           (double)RSIM_NEWTON_NS, (double)RSIM_NEWTON_NA, (double)RSIM_NEWTON_LS, (double)RSIM_NEWTON_NG, (double)RSIM_BP_REACH, (double)RSIM_NEAR_THRESH, (double)RSIM_NEAR_GAIN, (double)RSIM_MPR_CONE,
            []{ int lw[10]; return rsim_limits_w_cfg0(lw); }(), []{ int lw[10]; return rsim_limits_w_cfg1(lw); }(), []{ int lw[10]; return rsim_limits_w_cfg2(lw); }());
   s = buf;
   static const char* const envs[] = {"RSIM_NEWTON_NS", "RSIM_NEWTON_NA", "RSIM_NEWTON_LS", "RSIM_NEWTON_NG", "RSIM_NEWTON_WIDE", "RSIM_NEWTON_EXACT", "RSIM_NEWTON_REFINE",
-                                     "RSIM_POLISH_TOL", "RSIM_POLISH_GATE", "RSIM_BP_REACH", "RSIM_MPR_CONE", "RSIM_NO_MPR_WARMSTART", "RSIM_NO_MPR_PORTAL_WARMSTART",
+                                     "RSIM_POLISH_TOL", "RSIM_POLISH_GATE", "RSIM_BP_REACH", "RSIM_NEAR_THRESH", "RSIM_NEAR_GAIN", "RSIM_MPR_CONE", "RSIM_NO_MPR_WARMSTART", "RSIM_NO_MPR_PORTAL_WARMSTART",
                                      "RSIM_TIER_UP_CON", "RSIM_TIER_UP_EFC", "RSIM_TIER_MODE", "RSIM_NO_TIERS", "RSIM_ORDER_FRESH", "RSIM_EULER_FULL", "RSIM_FORCE_HANDOVER"};
   for (const char* e : envs) if (const char* v = getenv(e)) { s += ";env:"; s += e; s += "="; s += v; }
   return s.c_str();

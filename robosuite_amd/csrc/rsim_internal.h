@@ -135,6 +135,8 @@ struct DModel {
   float tolerance, meaninertia;
   float mpr_cone;      // half-angle (rad) of the cone of three directions around the previous contact normal from which a pair with a smooth shape restarts its portal
                        // (rsim_step.hip convex_convex, warm-start flag 3); 0: such pairs start cold every substep
+  float near_gain;     // ... by this fraction of its duration (0.5: as if it took 1.5 x)
+  float near_thresh;   // (m) an env whose closest separated convex pair is nearer than this is dispatched as if it took 1.5 x its duration (rsim_step.hip step_body); 0: off
   float bp_reach;      // broadphase active pair list: bounding-sphere gap (m) up to which a pair is listed; 0: every pair every substep
   float newton_ns, newton_na, newton_ng, newton_ls;
   int newton_refine;   // wide configurations: at most this many polish passes behind the fp32 Newton iteration (fp64 residuals / states / objective / gradient, solve_newton), 0 = none
@@ -227,6 +229,12 @@ struct DBatch {
 #ifndef RSIM_NEWTON_NS
 #ifndef RSIM_MPR_CONE
 #define RSIM_MPR_CONE 0.0f   // rad: restart cone of smooth-shape contacts (rsim_step.hip convex_convex, flag 3); 0 = off (the default: see the note there -- +5 % on Lift, but another path to the contact than the cold run the oracle takes)
+#endif
+#ifndef RSIM_NEAR_THRESH
+#define RSIM_NEAR_THRESH 0.002f   // dispatch-order hint for contacts about to start (rsim_step.hip step_body); swept 0.0005 .. 0.05 on three configurations: profiles/r06_v_near_contact_hint.txt
+#endif
+#ifndef RSIM_NEAR_GAIN
+#define RSIM_NEAR_GAIN 0.5f
 #endif
 #ifndef RSIM_BP_REACH
 #define RSIM_BP_REACH 0.04f   // broadphase active pair list (rsim_step.hip collision()): listed up to this bounding-sphere gap; valid while no geom centre moved reach / 2

@@ -1111,6 +1111,8 @@ struct Sim {
   float __attribute__((address_space(1)))* cst = nullptr;   // this env's controller-state record in global memory (slots >= RSIM_CS_LDS are used in place)
   Prof pf;
   int ovf = 0;   // contacts / constraint rows this launch had to drop for lack of capacity (RSIM_OVERFLOW); MuJoCo's nconmax = 5000 never truncates
+  float near_sep = 3.0e38f;   // smallest separation (m) along a separating direction any convex pair of the LAST substep's narrow phase ended on: how close the env is to a
+                              // contact that does not exist yet (step_body: dispatch-order hint, DModel.near_thresh)
   int con_raw = 0, need_con = 0, need_efc = 0;   // contacts this substep's narrow phase found (before the capacity clamp); largest contact / row demand of any substep of this launch (RSIM_CAP_NEED)
   float opt_h, opt_density, opt_viscosity, opt_impratio;
   V3 opt_grav, opt_wind;
@@ -2145,7 +2147,8 @@ struct Sim {
     const SupGeom sg1 = sup_load<SM>(cm, cmf(MK_gst), g1, (gcf)m.mesh_vert, lane, org), sg2 = sup_load<SM>(cm, cmf(MK_gst), g2, (gcf)m.mesh_vert, lane, org);
     if (wh == 1) {
       const V3 a1 = sup(sg1, wd), a2 = sup(sg2, -wd);
-      if (dot(a1 - a2, wd) <= 0) { MPRSTAT(8, 1); return; }
+      const float s_w = dot(a1 - a2, wd);
+      if (s_w <= 0) { MPRSTAT(8, 1); near_sep = fminf(near_sep, -s_w); return; }
     }
     V3 v0 = (ld3(sm.gcen + 3 * g1) - org) - (ld3(sm.gcen + 3 * g2) - org);
     if (norm(v0) < 1e-9f) v0.x = 1e-5f;
@@ -2236,7 +2239,8 @@ struct Sim {
         V3 D = mv(sp.R, dl);
         if (!first) D = -D;
         const V3 a1 = sup(sg1, D), a2 = sup(sg2, -D);
-        if (dot(a1 - a2, D) <= 0) { MPRSTAT(0, 1); mpr_store(wout, D, 1.f); return; }
+        const float s_p = dot(a1 - a2, D);
+        if (s_p <= 0) { MPRSTAT(0, 1); mpr_store(wout, D, 1.f); near_sep = fminf(near_sep, -s_p); return; }
       }
     }
     dir = normalized(-v0);
@@ -2421,6 +2425,7 @@ struct Sim {
     const LaneConst K = fetchK();
     if (lane == 0) sm.ncon = 0;
     con_raw = 0;
+    near_sep = 3.0e38f;
     // broadphase: lane p tests candidate pair p (bounding spheres, then the 6 face axes of the two oriented boxes);
     // order-preserving compaction of the survivors
     int ncand = 0;
@@ -4603,7 +4608,14 @@ __device__ __forceinline__ bool step_body(const DModel& m, const DBatch& b, cons
   }
   if (b.overflow && lane == 0 && sim.ovf) b.overflow[env] += sim.ovf;   // with capacity tiers: drops of the WIDE configuration only (pass 0 left above)
   if (b.cap_need && lane == 0) { int* cn = b.cap_need + 2 * (size_t)env; if (sim.need_con > cn[0]) cn[0] = sim.need_con; if (sim.need_efc > cn[1]) cn[1] = sim.need_efc; }
-  if (b.cost && lane == 0) b.cost[env] = (unsigned)(clock64() >> 6) - t_launch;
+  if (b.cost && lane == 0) {
+    // dispatch-order key of the next step: this step's duration -- and half as much again for an env one of whose convex pairs ended within DModel.near_thresh of
+    // touching: a contact that STARTS next step (full MPR runs, several times the Newton iterations) is what a duration cannot see coming, and such an env in the
+    // last round of a launch is what ends it (profiles/r06_t_ab_peg_five_per_cu.txt).  Ordering only: no result depends on it.
+    unsigned cst = (unsigned)(clock64() >> 6) - t_launch;
+    if (sim.near_sep < m.near_thresh) cst += (unsigned)((float)cst * m.near_gain);
+    b.cost[env] = cst;
+  }
   if (b.prof && lane == 0) {
     unsigned long long* wl = b.prof + RP_COUNT + 8 * (size_t)env;
     wl[3] = wall_clock64(); wl[4] = sim.pf.c_mpr; wl[5] = sim.pf.c_support; wl[6] = sim.pf.c_newton; wl[7] = sim.pf.c_cand;
