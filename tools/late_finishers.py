@@ -10,7 +10,7 @@ cfgname = sys.argv[1] if len(sys.argv) > 1 else "stack"
 label, stem, B, dr, which = bench.CONFIGS[cfgname]
 flat, cfg = factory.load_shipped(stem)
 ids = shard.env_block(B, 0, 1)
-P = 520
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 520
 env = bench.build_env(cfgname, flat, cfg, ids, 0, 6)
 tape = torch.tensor(lift.env_actions(ids, P + 8, action_dim=env.model.action_dim), device="cuda")
 env.batch.set("ep_step", ((197 * ids) % 500).astype(np.int32))
@@ -23,12 +23,12 @@ for t in range(P, P + 6):
     w = env.batch.wavelog()
     t0, t1 = w[:, 2].astype(np.int64), w[:, 3].astype(np.int64)
     dur = (t1 - t0) / 100.0; st = (t0 - t0.min()) / 100.0; en = (t1 - t0.min()) / 100.0
-    ok = dur > 200
+    ok = dur > 600   # (the reset-observation pass that follows the step rewrites the records of the envs it touches: 45 - 400 us entries)
     if prev is not None:
-        both = ok & (prev > 200)
+        both = ok & (prev > 600)
         c = np.corrcoef(prev[both], dur[both])[0, 1]
         last = np.argsort(-np.where(ok, en, 0))[:12]
         rk = np.argsort(np.argsort(st, kind="stable"), kind="stable")
-        print(f"step {t}: span {en[ok].max():.0f} us  corr(prev dur, dur) {c:.3f}  slowest {dur[ok].max():.0f}  sum/slots {dur[ok].sum() / (2048 if cfgname != 'peg' else 1280):.0f}")
+        print(f"step {t}: span {en[ok].max():.0f} us  corr(prev dur, dur) {c:.3f}  slowest {dur[ok].max():.0f}  sum/slots {dur[ok].sum() / {'lift': 2048, 'stack': 2048, 'peg': 1280, 'pickplace': 1024}[cfgname]:.0f}")
         print("   last finishers [env, start, dur, prev dur, start rank, tier before]:", [[int(e), int(st[e]), int(dur[e]), int(prev[e]), int(rk[e]), int(tier0[e])] for e in last])
     prev = np.where(ok, dur, 0)
