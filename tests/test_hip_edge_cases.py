@@ -559,6 +559,34 @@ def test_fused_tier_hand_over_with_two_osc_arm_parts(monkeypatch):
     assert np.array_equal(hb.get("qpos")[0], hb.get("qpos")[2]) and int(hb.get("overflow").sum()) == 0
 
 
+def test_contact_onset_hint_changes_the_dispatch_order_and_nothing_else(monkeypatch):
+    """Round 6: the dispatch-order key of an env is its duration, raised by half when one of its convex pairs ended the last substep within RSIM_NEAR_THRESH of touching
+    (a contact about to start is what a duration cannot predict).  It must be ORDERING ONLY: the same rollout with the hint off, at its default and with a net so wide
+    that every env is flagged ends in bitwise the same states, rewards and demand counters."""
+    from robosuite_amd import lift
+    flat, cfg = _lift_assets()
+    ids = np.arange(96)
+    T = 45
+    tape = torch.tensor(lift.env_actions(ids, T), device="cuda")
+    out = []
+    for thr in ("0", None, "10"):
+        if thr is None:
+            monkeypatch.delenv("RSIM_NEAR_THRESH", raising=False)
+        else:
+            monkeypatch.setenv("RSIM_NEAR_THRESH", thr)
+        env = lift.LiftBatch(flat, cfg, ids, seed0=0, horizon=0)       # the threshold is read when the batch is created
+        for t in range(T):
+            env.step(tape[t])
+        b = env.batch
+        b.sync()
+        out.append({k: b.get(k).copy() for k in ("qpos", "qvel", "qacc_warmstart", "ctrl", "cstate", "obs", "reward", "cap_need")})
+    monkeypatch.delenv("RSIM_NEAR_THRESH", raising=False)
+    assert np.abs(out[0]["qvel"]).max() > 0.05 and int((out[0]["cap_need"][:, 0] > 4).sum()) > 10      # a rollout with contacts, not a trivial one
+    for o in out[1:]:
+        for k in out[0]:
+            assert np.array_equal(o[k], out[0][k]), k
+
+
 def test_capacity_tiers_with_per_env_model_parameters_and_stream_groups():
     """The wide configuration reads an env's OWN constant block (per-episode cube sizes: built on demand right before the wide pass steps the env);
     with stream groups every env block runs its own native pass, wide pass and redo pass on its own stream.  Same envs, same results."""
