@@ -91,7 +91,8 @@ for name, draw, create in (("ok", draw_ok, create_ok), ("draw_fails", draw_fails
         res[name] = ["unavailable", str(e), len(made), all(m.closed for m in made)]
     # whatever happened, the ranks are still in step: a collective right behind it pairs up
     res[name].append(shard.max_over_ranks(float(rank)))
-print("RANK%d %s" % (rank, json.dumps(res)))
+# one file per rank: two ranks writing to the launcher's one stdout pipe can land on the same line
+with open(os.path.join(os.environ["RSIM_OUT"], "rank%d.json" % rank), "w") as f: json.dump(res, f)
 torch.distributed.destroy_process_group()
 """
 
@@ -105,9 +106,9 @@ def test_c_abi_communicator_handshake_is_collective_safe(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(HANDSHAKE_WORKER)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), str(script)], env=dict(os.environ, RSIM_ROOT=ROOT), capture_output=True, text=True, timeout=120)
+                          "--master-port", str(port), str(script)], env=dict(os.environ, RSIM_ROOT=ROOT, RSIM_OUT=str(tmp_path)), capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
-    rows = {int(l[4]): json.loads(l[6:]) for l in out.stdout.splitlines() if l.startswith("RANK")}
+    rows = {r: json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in (0, 1) if (tmp_path / ("rank%d.json" % r)).exists()}
     assert sorted(rows) == [0, 1]
     for r in (0, 1):
         assert rows[r]["ok"] == ["comm", True, 1.0]
