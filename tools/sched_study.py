@@ -12,7 +12,7 @@ TASK = sys.argv[1] if len(sys.argv) > 1 else "stack"
 nskip = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
-STEM, CLS, SLOTS = {"lift": ("lift_panda", lift.LiftBatch, 2048), "stack": ("stack_panda", stack.StackBatch, 1024), "peg": ("peg_baxter_joint_velocity", peg_in_hole.PegBatch, 1024)}[TASK]
+STEM, CLS, SLOTS = {"lift": ("lift_panda", lift.LiftBatch, 2048), "stack": ("stack_panda", stack.StackBatch, 2048), "peg": ("peg_baxter_joint_velocity", peg_in_hole.PegBatch, 1280)}[TASK]   # resident envs: 8 / 8 / 5 per CU (round 6)
 adir = os.path.join(ROOT, "robosuite_amd", "assets")
 flat = mjcf.load_model(os.path.join(adir, STEM + ".rsim")); cfg = json.load(open(os.path.join(adir, STEM + ".cfg.json")))
 env = CLS(flat, cfg, np.arange(B), seed0=0)
@@ -57,3 +57,21 @@ for t in range(4, N):
 print("list-scheduling makespan us (mean over steps) by dispatch-order predictor; lower bound sum/slots = %.0f, longest env %.0f" % (D[4:].sum(1).mean() / SLOTS, D[4:].max(1).mean()))
 for k, v in preds.items():
     print(f"  {k:34s} {np.mean(v):8.0f}")
+
+# round 6: how much of a step's duration is predictable from what the previous step knew?  Least squares of dur[t] on (1, dur[t-1], dur[t-2], the four event counts of t-1),
+# fitted on the first half of the recorded steps, replayed on the second half
+h = max(5, N // 2)
+X = lambda t: np.column_stack([np.ones(B), D[t - 1], D[t - 2], C[t - 1]])
+A = np.concatenate([X(t) for t in range(2, h)]); y = np.concatenate([D[t] for t in range(2, h)])
+w = np.linalg.lstsq(A, y, rcond=None)[0]
+res = {"oracle (own duration)": [], "dur[t-1]": [], "least squares on t-1": [], "dur[t-1] + 0.5 (dur[t-1] - dur[t-2])+": []}
+for t in range(h, N):
+    res["oracle (own duration)"].append(makespan(D[t], np.argsort(-D[t], kind="stable")))
+    res["dur[t-1]"].append(makespan(D[t], np.argsort(-D[t - 1], kind="stable")))
+    res["least squares on t-1"].append(makespan(D[t], np.argsort(-(X(t) @ w), kind="stable")))
+    res["dur[t-1] + 0.5 (dur[t-1] - dur[t-2])+"].append(makespan(D[t], np.argsort(-(D[t - 1] + 0.5 * np.maximum(D[t - 1] - D[t - 2], 0)), kind="stable")))
+print("second half of the steps (least squares fitted on the first): weights", np.round(w, 3), " corr(pred, dur) %.3f vs corr(dur[t-1], dur) %.3f" % (
+    np.mean([np.corrcoef(X(t) @ w, D[t])[0, 1] for t in range(h, N)]), np.mean([np.corrcoef(D[t - 1], D[t])[0, 1] for t in range(h, N)])))
+for k, v in res.items():
+    print(f"  {k:42s} {np.mean(v):8.0f}")
+print("measured span of those steps %.0f; sum / slots %.0f; longest env %.0f" % (np.mean(SP[h:]), D[h:].sum(1).mean() / SLOTS, D[h:].max(1).mean()))
