@@ -180,7 +180,7 @@ def summarize(name, res):
     return ok
 
 
-def continue_on_the_oracle(name, flat, cfg, env, pick, actions, dq, dv, min_over=1, assert_all=False):
+def continue_on_the_oracle(name, flat, cfg, env, pick, actions, dq, dv, min_over=1, assert_all=False, collect=None):
     """ONE more control step of the whole batch through the fused path (capacity tiers included), and for the picked envs the same control step on the fp64
     oracle from the kernel's own state: positions, velocities, warm start, actuator commands and the controller record (goal, initial joints, gripper
     action) are copied over, so the comparison covers what the debug entry rsim_forward cannot -- a step in which the env needs MORE contacts / rows
@@ -208,13 +208,19 @@ def continue_on_the_oracle(name, flat, cfg, env, pick, actions, dq, dv, min_over
         print(f"   [{name}] env {e}: demand {need[e, 0]} contacts / {need[e, 1]} rows (native {b.maxcon} / {b.maxefc}){' -> stepped by the wide configuration' if beyond else ''}: one control step vs the oracle |dq| {eq:.1e} |dv| {ev:.1e}")
         if beyond:
             over += 1
-        if beyond or assert_all:
+        if collect is not None:
+            collect.append(dict(env=e, dq=np.abs(q1[e] - od.qpos), dv=np.abs(v1[e] - od.qvel), beyond=beyond, finite=bool(np.isfinite(od.qpos).all())))     # the caller's verdict
+        elif beyond or assert_all:
             assert eq < dq and ev < dv, (e, eq, ev)
     assert over >= min_over, f"{name}: none of the picked envs exceeded the native capacity in this step"
     assert int(b.get("overflow").sum()) == 0
     return over
 
 
+# one whole control step of a PickPlace env through the fused path against the oracle.  Measured (round 6, 22 envs of control step 31, a dynamics draw before the step): arm joints
+# |dq| p50 4.7e-7 max 5.4e-4; gripper joints (the Robotiq's interpenetrating four-bar links: MPR facet choices, see the 8192-env test) p50 4.2e-4 max 1.1e-2; object
+# coordinates p50 4.4e-4 max 3.4e-3 -- 25 substeps of bodies of 1e-5 .. 4e-3 kg m^2 whose single-solve accelerations agree to the 5e-3 of that test
+PP_STEP_DQ_MEDIAN, PP_STEP_DQ_ARM, PP_STEP_DQ_MAX, PP_STEP_DQ_ARM_MEDIAN = 3e-3, 3e-3, 5e-2, 1e-5
 # one whole control step of a Lift env (25 substeps), fused kernel against the fp64 oracle from the same state and the env's live model.  Measured (round 6, 24 envs of
 # control step 251): |dq| 3e-7 typical, 2.2e-5 on the most contact-rich env (12 contacts / 50 rows); |dv| 5e-6 typical, 2.1e-4 worst
 LIFT_STEP_DQ, LIFT_STEP_DV = 2e-4, 5e-3
@@ -469,6 +475,41 @@ def test_stack_one_whole_control_step_of_the_slowest_envs_against_the_oracle():
     print(f"   [Stack, slowest envs] |dq| after one control step: p50 {np.median(dq):.1e} p90 {np.percentile(dq, 90):.1e} max {dq.max():.1e}; oracle Newton iterations per substep "
           f"mean {it.mean():.2f} max {it.max():.2f} (kernel, recorded: {z['newton'].mean() / n_sub:.2f} / {z['newton'].max() / n_sub:.2f})")
     assert np.median(dq) < 5e-6 and np.percentile(dq, 90) < 2e-4 and dq.max() < 5e-2, (np.median(dq), np.percentile(dq, 90), dq.max())
+
+
+def test_pickplace_one_whole_control_step_of_the_fused_path_against_the_oracle():
+    """BASELINE configs[4], the fused control step itself (native pass, tier pass, redo pass) rather than the debug entry: after 30 control steps of the bench's workload
+    with a dynamics draw before every step, ONE more control step (a fresh draw first) of the whole batch, and for the envs that asked for the most contacts plus envs
+    spread over the batch the same 25 substeps on the fp64 oracle from the kernel's own state with the env's LIVE model (this step's draw).  Nothing is fed from one side
+    to the other in between, so a light object under a kilonewton squeeze amplifies what one MPR facet choice differs by: the typical env is held to rounding, the arm
+    in every env, the objects' tail to what a contact-rich step of a 1e-5 kg m^2 body does with a 1e-5 difference in a normal (round 3 - 5 analyses)."""
+    from robosuite_amd import pick_place
+    g, cfg, flat = load_golden("seed0_full", "pickplace_iiwa")
+    B = 2048
+    ids = np.arange(B)
+    env = pick_place.PickPlaceBatch(flat, cfg, ids, seed0=0, horizon=500, bank_episodes=2, per_env_params=True)
+    b = env.batch
+    b.dr_save_defaults()
+    tape = torch.tensor(lift.env_actions(ids, 31), device="cuda")
+    for t in range(30):
+        if t == 29:
+            b.set("cap_need", 0)
+        b.randomize_dynamics(seed=11, step=t)
+        env.step(tape[t])
+    need = b.get("cap_need")
+    pick = np.unique(np.concatenate([np.argsort(-need[:, 0], kind="stable")[:8], spread(B, 8)]))
+    b.randomize_dynamics(seed=11, step=30)
+    rows = []
+    continue_on_the_oracle("PickPlace", flat, cfg, env, pick, tape[30], dq=0.0, dv=0.0, min_over=0, collect=rows)
+    arm, armq, gripq = np.asarray(cfg["dof_idx"]), np.asarray(cfg["qpos_idx"]), np.asarray(cfg["grip_qpos_idx"])
+    objq = np.setdiff1d(np.arange(flat.nq), np.concatenate([armq, gripq]))
+    dq_all = np.array([r["dq"].max() for r in rows]); dq_arm = np.array([r["dq"][armq].max() for r in rows]); dv_arm = np.array([r["dv"][arm].max() for r in rows])
+    dq_grip = np.array([r["dq"][gripq].max() for r in rows]); dq_obj = np.array([r["dq"][objq].max() for r in rows])
+    print(f"   [PickPlace, fused step] {len(rows)} envs: |dq| all coordinates p50 {np.median(dq_all):.1e} p90 {np.percentile(dq_all, 90):.1e} max {dq_all.max():.1e}; arm joints |dq| max {dq_arm.max():.1e} |dv| max {dv_arm.max():.1e}")
+    print(f"      gripper joints |dq| p50 {np.median(dq_grip):.1e} max {dq_grip.max():.1e}; object coordinates |dq| p50 {np.median(dq_obj):.1e} max {dq_obj.max():.1e}; arm p50 {np.median(dq_arm):.1e}")
+    assert all(r["finite"] for r in rows) and int((b.get("diverged")[pick] > 0).sum()) == 0
+    assert np.median(dq_all) < PP_STEP_DQ_MEDIAN and dq_arm.max() < PP_STEP_DQ_ARM and dq_all.max() < PP_STEP_DQ_MAX, (np.median(dq_all), dq_arm.max(), dq_all.max())
+    assert np.median(dq_arm) < PP_STEP_DQ_ARM_MEDIAN, np.median(dq_arm)
 
 
 def _oracle_dr_episode(job):
