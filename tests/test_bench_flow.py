@@ -175,7 +175,7 @@ def test_reference_baseline_harness_is_blocked_loudly_without_mujoco_and_runs_on
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tool = os.path.join(root, "tools", "bench_reference.py")
     if importlib.util.find_spec("mujoco") is None:
-        r = subprocess.run([sys.executable, tool, "--procs", "1", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=120)
+        r = subprocess.run([sys.executable, tool, "--procs", "1", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600)
         d = json.loads(r.stdout.strip().splitlines()[-1])
         assert r.returncode == 3 and d["baseline"] == "B-ref" and "not importable" in d["error"]
     if not os.path.isdir("/root/reference/robosuite"):

@@ -25,7 +25,7 @@ def test_recorder_is_a_clean_no_op_without_the_wheel(tmp_path):
     # a real wheel (an installed distribution), not this project's mujoco-shaped shim that other tests register in sys.modules
     if "mujoco" not in sys.modules and importlib.util.find_spec("mujoco") is not None:
         pytest.skip("mujoco is importable here: run tools/gen_golden_with_mujoco.py and commit its fixtures instead")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden_with_mujoco.py"), "--out", str(tmp_path)], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden_with_mujoco.py"), "--out", str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "not importable" in r.stdout and not os.listdir(tmp_path)
 
 

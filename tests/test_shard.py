@@ -106,7 +106,7 @@ def test_c_abi_communicator_handshake_is_collective_safe(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(HANDSHAKE_WORKER)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), str(script)], env=dict(os.environ, RSIM_ROOT=ROOT, RSIM_OUT=str(tmp_path)), capture_output=True, text=True, timeout=120)
+                          "--master-port", str(port), str(script)], env=dict(os.environ, RSIM_ROOT=ROOT, RSIM_OUT=str(tmp_path)), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = {r: json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in (0, 1) if (tmp_path / ("rank%d.json" % r)).exists()}
     assert sorted(rows) == [0, 1]
